@@ -1,0 +1,428 @@
+"""CPU oracle (TEST INFRASTRUCTURE ONLY -- never imported by the product path).
+
+A restatement, in plain Python, of the reference's ``encode`` / ``encode_batch`` /
+``encode_with_special`` path.  Only ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may import this package.
+
+What is restated and what it follows (all paths into ``/root/reference``):
+
+* ``split_pcre2``   -- the regex pre-tokeniser.  The arithmetic lives in a third-party
+  dependency that is NOT under ``/root/reference``: ``regexr 0.1.0-beta.5`` (default) or
+  the ``pcre2 0.2`` crate -> system ``libpcre2-8`` with ``utf(true)``/``ucp(true)``
+  (``src/core/tokenizer.rs:474-481``).  The reference tests assert that both backends yield
+  identical tokens (``python/tests/test_cl100k.py:436-454``), so this oracle drives the very
+  same ``libpcre2-8`` (10.39, Unicode 14.0.0 in this image) through ctypes with the verbatim
+  pattern strings (``src/core/tokenizer.rs:39``, ``:42``) and the flags ``UTF|UCP``.
+* ``split_regex``   -- an independent second engine (Python ``regex``), same pattern strings.
+* ``byte_pair_encode`` -- ``src/core/bpe.rs:67-197`` (span list instead of the index-linked
+  list; same leftmost-strict-minimum rule, same fallbacks).
+* ``byte_level_encode`` -- ``src/core/byte_level.rs:46-74, 105-107``.
+* ``Oracle.encode`` / ``encode_with_special`` / ``encode_batch`` --
+  ``src/core/tokenizer.rs:693-724, 729-808, 842-874, 932-942``.  The LRU cache
+  (``:708-721``) is result-transparent and is not restated.
+* vocab parsing -- ``src/core/vocab.rs:57-89`` semantics (last duplicate wins); read from this
+  repo's own ``.splv`` container (made by ``tools/pack_vocab.py``), never from the reference.
+
+Parity pinning: checked against all 18 exact-id vectors the reference's tests/docs hold
+(``tests/golden/reference_vectors.json``; see ``tests/test_oracle.py``).  Beyond those the
+regex boundary is pinned to PCRE2 10.39 / Unicode 14 semantics only ("parity unpinned" for
+code points whose category changed after Unicode 14 -- regexr's table version is unknowable
+here).
+"""
+from __future__ import annotations
+
+import ctypes
+import json
+import os
+import struct
+from typing import Dict, List, Optional, Sequence, Tuple
+
+# Verbatim pattern strings (src/core/tokenizer.rs:39, :42, :45).
+CL100K_BASE_PATTERN = (
+    r"(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+"
+)
+O200K_BASE_PATTERN = (
+    r"[^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]*[\p{Ll}\p{Lm}\p{Lo}\p{M}]+(?i:'s|'t|'re|'ve|'m|'ll|'d)?"
+    r"|[^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]+[\p{Ll}\p{Lm}\p{Lo}\p{M}]*(?i:'s|'t|'re|'ve|'m|'ll|'d)?"
+    r"|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+"
+)
+LLAMA3_PATTERN = O200K_BASE_PATTERN
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_DATA = os.path.join(os.path.dirname(_HERE), "splintr_amd", "data")
+
+# name -> (vocab container, pattern, byte_level)   (src/python/bindings.rs:101-129)
+PRETRAINED = {
+    "cl100k_base": ("cl100k_base.splv", CL100K_BASE_PATTERN, False),
+    "o200k_base": ("o200k_base.splv", O200K_BASE_PATTERN, False),
+    "llama3": ("llama3.splv", LLAMA3_PATTERN, False),
+    "llama3.1": ("llama3.splv", LLAMA3_PATTERN, False),
+    "llama3.2": ("llama3.splv", LLAMA3_PATTERN, False),
+    "llama3.3": ("llama3.splv", LLAMA3_PATTERN, False),
+    "deepseek_v3": ("deepseek_v3.splv", LLAMA3_PATTERN, True),
+    "deepseek-v3": ("deepseek_v3.splv", LLAMA3_PATTERN, True),
+}
+_SPECIAL_KEY = {
+    "cl100k_base": "cl100k_base", "o200k_base": "o200k_base", "llama3": "llama3",
+    "llama3.1": "llama3", "llama3.2": "llama3", "llama3.3": "llama3",
+    "deepseek_v3": "deepseek_v3", "deepseek-v3": "deepseek_v3",
+}
+
+
+# --------------------------------------------------------------------------------------
+# PCRE2 through ctypes (the reference's own optional backend, src/core/tokenizer.rs:474-481)
+# --------------------------------------------------------------------------------------
+PCRE2_UTF = 0x00080000
+PCRE2_UCP = 0x00020000
+PCRE2_NO_UTF_CHECK = 0x40000000
+_pcre2_lib = None
+
+
+def pcre2_available() -> bool:
+    try:
+        _pcre2()
+        return True
+    except OSError:
+        return False
+
+
+def _pcre2():
+    global _pcre2_lib
+    if _pcre2_lib is None:
+        lib = ctypes.CDLL("libpcre2-8.so.0")
+        lib.pcre2_compile_8.restype = ctypes.c_void_p
+        lib.pcre2_compile_8.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32,
+                                        ctypes.POINTER(ctypes.c_int),
+                                        ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p]
+        lib.pcre2_match_data_create_from_pattern_8.restype = ctypes.c_void_p
+        lib.pcre2_match_data_create_from_pattern_8.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lib.pcre2_match_8.restype = ctypes.c_int
+        lib.pcre2_match_8.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t,
+                                      ctypes.c_size_t, ctypes.c_uint32, ctypes.c_void_p,
+                                      ctypes.c_void_p]
+        lib.pcre2_get_ovector_pointer_8.restype = ctypes.POINTER(ctypes.c_size_t)
+        lib.pcre2_get_ovector_pointer_8.argtypes = [ctypes.c_void_p]
+        lib.pcre2_jit_compile_8.restype = ctypes.c_int
+        lib.pcre2_jit_compile_8.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
+        lib.pcre2_config_8.restype = ctypes.c_int
+        lib.pcre2_config_8.argtypes = [ctypes.c_uint32, ctypes.c_void_p]
+        _pcre2_lib = lib
+    return _pcre2_lib
+
+
+def pcre2_versions() -> Tuple[str, str]:
+    lib = _pcre2()
+    out = []
+    for what in (11, 10):  # PCRE2_CONFIG_VERSION, PCRE2_CONFIG_UNICODE_VERSION
+        buf = ctypes.create_string_buffer(64)
+        lib.pcre2_config_8(what, buf)
+        out.append(buf.value.decode())
+    return out[0], out[1]
+
+
+class Pcre2Pattern:
+    """One compiled pattern with the reference's flags (UTF|UCP, JIT if available)."""
+
+    def __init__(self, pattern: str):
+        lib = _pcre2()
+        pat = pattern.encode("utf-8")
+        err = ctypes.c_int(0)
+        off = ctypes.c_size_t(0)
+        self.code = lib.pcre2_compile_8(pat, len(pat), PCRE2_UTF | PCRE2_UCP, ctypes.byref(err),
+                                        ctypes.byref(off), None)
+        if not self.code:
+            raise ValueError(f"pcre2_compile failed: err={err.value} at {off.value}")
+        lib.pcre2_jit_compile_8(self.code, 1)  # PCRE2_JIT_COMPLETE; failure is fine
+        self.md = lib.pcre2_match_data_create_from_pattern_8(self.code, None)
+        self.ov = lib.pcre2_get_ovector_pointer_8(self.md)
+        self.lib = lib
+
+    def find_iter(self, data: bytes) -> List[Tuple[int, int]]:
+        """Successive leftmost non-overlapping matches, as (start, end) byte offsets
+        (what ``RegexBackend::find_iter`` returns, src/core/tokenizer.rs:244-257)."""
+        lib, code, md, ov = self.lib, self.code, self.md, self.ov
+        n = len(data)
+        pos = 0
+        out = []
+        while pos <= n:
+            rc = lib.pcre2_match_8(code, data, n, pos, PCRE2_NO_UTF_CHECK, md, None)
+            if rc < 0:
+                break
+            s, e = ov[0], ov[1]
+            out.append((s, e))
+            if e == s:  # empty match: step one UTF-8 char (never happens for these patterns)
+                e += 1
+                while e < n and (data[e] & 0xC0) == 0x80:
+                    e += 1
+            pos = e
+        return out
+
+
+_pcre2_cache: Dict[str, Pcre2Pattern] = {}
+
+
+def split_pcre2(pattern: str, data: bytes) -> List[Tuple[int, int]]:
+    p = _pcre2_cache.get(pattern)
+    if p is None:
+        p = _pcre2_cache[pattern] = Pcre2Pattern(pattern)
+    return p.find_iter(data)
+
+
+_regex_cache: Dict[str, object] = {}
+
+
+def split_regex(pattern: str, text: str) -> List[Tuple[int, int]]:
+    """Second, independent engine (Python ``regex``); returns BYTE offsets like split_pcre2."""
+    import regex  # noqa: WPS433  (kept local: optional dependency)
+    r = _regex_cache.get(pattern)
+    if r is None:
+        r = _regex_cache[pattern] = regex.compile(pattern)
+    out = []
+    # char offset -> byte offset
+    boff = [0]
+    for ch in text:
+        boff.append(boff[-1] + len(ch.encode("utf-8")))
+    for m in r.finditer(text):
+        out.append((boff[m.start()], boff[m.end()]))
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# ByteLevel map (src/core/byte_level.rs:46-74, 105-107)
+# --------------------------------------------------------------------------------------
+def _byte_to_char() -> List[str]:
+    direct = list(range(33, 127)) + list(range(161, 173)) + list(range(174, 256))
+    mapping = [""] * 256
+    for b in direct:
+        mapping[b] = chr(b)
+    nxt = 256
+    for b in range(256):
+        if mapping[b] == "":
+            mapping[b] = chr(nxt)
+            nxt += 1
+    return mapping
+
+
+BYTE_TO_CHAR = _byte_to_char()
+CHAR_TO_BYTE = {c: b for b, c in enumerate(BYTE_TO_CHAR)}
+_BL_BYTES = [c.encode("utf-8") for c in BYTE_TO_CHAR]
+
+
+def byte_level_encode(data: bytes) -> bytes:
+    """byte_level_encode(...).into_bytes()  (src/core/tokenizer.rs:695-700)."""
+    return b"".join(_BL_BYTES[b] for b in data)
+
+
+def byte_level_decode_bytes(enc: bytes) -> Optional[bytes]:
+    """src/core/byte_level.rs:125-146."""
+    try:
+        s = enc.decode("utf-8")
+    except UnicodeDecodeError:
+        return None
+    out = bytearray()
+    for ch in s:
+        b = CHAR_TO_BYTE.get(ch)
+        if b is None:
+            return None
+        out.append(b)
+    return bytes(out)
+
+
+# --------------------------------------------------------------------------------------
+# BPE merge (src/core/bpe.rs:67-197)
+# --------------------------------------------------------------------------------------
+U32_MAX = 0xFFFFFFFF
+
+
+def byte_pair_encode(piece: bytes, encoder: Dict[bytes, int]) -> List[int]:
+    n = len(piece)
+    if n == 0:                                      # bpe.rs:68-70
+        return []
+    if n == 1:                                      # bpe.rs:73-75
+        r = encoder.get(piece)
+        return [] if r is None else [r]
+    r = encoder.get(piece)                          # bpe.rs:78-80
+    if r is not None:
+        return [r]
+    # spans: starts[i] .. starts[i+1]; one per byte initially (bpe.rs:83-96)
+    starts = list(range(n + 1))
+
+    def rank_at(i: int) -> int:                     # get_rank closure, bpe.rs:99-111
+        if i + 2 > len(starts) - 1:                 # span i has no right neighbour
+            return U32_MAX
+        return encoder.get(piece[starts[i]:starts[i + 2]], U32_MAX)
+
+    ranks = [rank_at(i) for i in range(n - 1)] + [U32_MAX]   # bpe.rs:114-116
+    while True:
+        # strictly-smaller scan => leftmost minimum (bpe.rs:121-138)
+        m = U32_MAX
+        mi = -1
+        for i, rk in enumerate(ranks):
+            if rk < m:
+                m = rk
+                mi = i
+        if m == U32_MAX:                            # bpe.rs:141-143
+            break
+        # merge span mi with mi+1 (bpe.rs:146-156)
+        del starts[mi + 1]
+        del ranks[mi + 1]
+        # re-rank (prev, mi) and (mi, next) (bpe.rs:160-166)
+        if mi > 0:
+            ranks[mi - 1] = rank_at(mi - 1)
+        ranks[mi] = rank_at(mi)
+    out: List[int] = []
+    for i in range(len(starts) - 1):                # bpe.rs:170-194
+        sl = piece[starts[i]:starts[i + 1]]
+        rk = encoder.get(sl)
+        if rk is not None:
+            out.append(rk)
+        else:
+            for b in sl:
+                rb = encoder.get(bytes([b]))
+                if rb is not None:
+                    out.append(rb)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# Vocab container (.splv, this repo's own format; tools/pack_vocab.py)
+# --------------------------------------------------------------------------------------
+def load_splv(path: str) -> Tuple[Dict[bytes, int], int]:
+    """Returns (encoder, flags).  Insert order = file order, so a later duplicate key
+    overwrites an earlier one exactly as ``encoder.insert`` does (src/core/vocab.rs:85)."""
+    with open(path, "rb") as f:
+        blob = f.read()
+    magic, version, n, flags, _maxlen = struct.unpack_from("<4sIIII", blob, 0)
+    if magic != b"SPLV" or version != 1:
+        raise ValueError(f"{path}: not a SPLV v1 container")
+    off = 20
+    enc: Dict[bytes, int] = {}
+    for _ in range(n):
+        rank, ln = struct.unpack_from("<IH", blob, off)
+        off += 6
+        enc[blob[off:off + ln]] = rank
+        off += ln
+    return enc, flags
+
+
+def load_special_tokens(name: str) -> Dict[str, int]:
+    with open(os.path.join(_DATA, "special_tokens.json"), "r", encoding="utf-8") as f:
+        return json.load(f)[_SPECIAL_KEY[name]]
+
+
+# --------------------------------------------------------------------------------------
+# Tokenizer facade (src/core/tokenizer.rs)
+# --------------------------------------------------------------------------------------
+class Oracle:
+    def __init__(self, encoder: Dict[bytes, int], pattern: str, byte_level: bool,
+                 special_tokens: Optional[Dict[str, int]] = None, engine: str = "pcre2"):
+        self.encoder = encoder
+        self.pattern = pattern
+        self.byte_level = byte_level
+        self.special_tokens = dict(special_tokens or {})
+        self.engine = engine
+        self._chunk_memo: Dict[bytes, List[int]] = {}   # plain memo; result-transparent
+
+    @classmethod
+    def from_pretrained(cls, name: str, engine: str = "pcre2") -> "Oracle":
+        if name not in PRETRAINED:
+            raise ValueError(
+                f"Unknown pretrained model: {name}. See from_pretrained docstring for supported models.")
+        fn, pattern, bl = PRETRAINED[name]
+        enc, _flags = load_splv(os.path.join(_DATA, fn))
+        return cls(enc, pattern, bl, load_special_tokens(name), engine)
+
+    # src/core/tokenizer.rs:964-972
+    @property
+    def vocab_size(self) -> int:
+        m = max(self.encoder.values()) if self.encoder else 0
+        if self.special_tokens:
+            m = max(m, max(self.special_tokens.values()))
+        return m + 1
+
+    def split(self, data: bytes) -> List[Tuple[int, int]]:
+        if self.engine == "pcre2":
+            return split_pcre2(self.pattern, data)
+        return split_regex(self.pattern, data.decode("utf-8"))
+
+    # src/core/tokenizer.rs:693-724 (minus the LRU)
+    def encode_chunk(self, sl: bytes) -> List[int]:
+        hit = self._chunk_memo.get(sl)
+        if hit is not None:
+            return hit
+        b = byte_level_encode(sl) if self.byte_level else sl
+        r = self.encoder.get(b)
+        out = [r] if r is not None else byte_pair_encode(b, self.encoder)
+        if len(self._chunk_memo) < 1 << 20:
+            self._chunk_memo[sl] = out
+        return out
+
+    # src/core/tokenizer.rs:729-808 (non-SentencePiece branch)
+    def encode_bytes(self, data: bytes) -> List[int]:
+        out: List[int] = []
+        for s, e in self.split(data):
+            out.extend(self.encode_chunk(data[s:e]))
+        return out
+
+    def encode(self, text: str) -> List[int]:
+        return self.encode_bytes(text.encode("utf-8"))
+
+    encode_rayon = encode   # src/core/tokenizer.rs:815-837: identical output by construction
+
+    # src/core/tokenizer.rs:842-874.  Aho-Corasick MatchKind::Standard, non-overlapping
+    # find_iter: report the match that ENDS first; on equal ends nothing can tie here because
+    # no in-scope literal is a suffix of another (asserted in tests/test_oracle.py).
+    def encode_with_special(self, text: str) -> List[int]:
+        data = text.encode("utf-8")
+        if not self.special_tokens:
+            return self.encode_bytes(data)
+        lits = [(k.encode("utf-8"), v) for k, v in self.special_tokens.items()]
+        out: List[int] = []
+        last = 0
+        pos = 0
+        n = len(data)
+        while pos < n:
+            best = None  # (end, start, id)
+            # earliest-ending occurrence at or after pos
+            for lit, tid in lits:
+                i = data.find(lit, pos)
+                if i >= 0:
+                    cand = (i + len(lit), i, tid)
+                    if best is None or cand < best:
+                        best = cand
+            if best is None:
+                break
+            end, start, tid = best
+            if start > last:
+                out.extend(self.encode_bytes(data[last:start]))
+            out.append(tid)
+            last = end
+            pos = end
+        if last < n:
+            out.extend(self.encode_bytes(data[last:]))
+        return out
+
+    # src/core/tokenizer.rs:932-942
+    def encode_batch(self, texts: Sequence[str]) -> List[List[int]]:
+        return [self.encode(t) for t in texts]
+
+    def encode_batch_with_special(self, texts: Sequence[str]) -> List[List[int]]:
+        return [self.encode_with_special(t) for t in texts]
+
+    # src/core/tokenizer.rs:877-897
+    def decode_bytes(self, tokens: Sequence[int]) -> bytes:
+        if not hasattr(self, "_decoder"):
+            self._decoder = {v: k for k, v in self.encoder.items()}
+            self._sdecoder = {v: k for k, v in self.special_tokens.items()}
+        out = bytearray()
+        for t in tokens:
+            b = self._decoder.get(t)
+            if b is not None:
+                if self.byte_level:
+                    d = byte_level_decode_bytes(b)
+                    out += d if d is not None else b
+                else:
+                    out += b
+            elif t in self._sdecoder:
+                out += self._sdecoder[t].encode("utf-8")
+        return bytes(out)

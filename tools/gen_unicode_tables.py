@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Build-time generator of the code-point class table used by the pre-tokeniser kernels.
+
+The classes are PROBED from the system libpcre2-8 (the reference's own optional regex backend,
+``src/core/tokenizer.rs:474-481``, flags UTF|UCP) so the table is, by construction, the exact
+character-class semantics of ``\\p{Lu} \\p{Ll} \\p{Lt} \\p{Lm} \\p{Lo} \\p{M} \\p{N} \\s`` that the
+oracle's split engine applies (PCRE2 10.39 => Unicode 14.0.0).  Also probes which code points the
+caseless contraction letters ``(?i:s|t|r|e|v|m|l|d)`` match under UTF|UCP.
+
+Output: ``splintr_amd/data/unicode_classes.bin``
+    char[4] "SPLU" | u32 version=1 | u32 block_shift | u32 n_blocks | char[16] unicode_version
+    u16 stage1[0x110000 >> block_shift]      block index per code-point block
+    u8  stage2[n_blocks << block_shift]      class code per code point
+    u32 n_fold | n_fold x { u32 code_point | u32 ascii_lower }   caseless partners of s,t,r,e,v,m,l,d
+Class codes: see CLASS_NAMES (shared with splintr_amd/csrc/spl_scan.h).
+"""
+import os
+import struct
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle.pyoracle import Pcre2Pattern, pcre2_versions  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "splintr_amd", "data")
+
+CLASS_NAMES = ["P", "AP", "SP", "WS", "NL", "N", "Lu", "Ll", "Lt", "Lm", "Lo", "M"]
+C = {n: i for i, n in enumerate(CLASS_NAMES)}
+BLOCK_SHIFT = 7
+
+
+def all_codepoints_utf8():
+    cps = [cp for cp in range(0x110000) if not (0xD800 <= cp <= 0xDFFF)]
+    data = "".join(map(chr, cps)).encode("utf-8")
+    # byte offset -> cp
+    offs = {}
+    o = 0
+    for cp in cps:
+        offs[o] = cp
+        o += 1 if cp < 0x80 else 2 if cp < 0x800 else 3 if cp < 0x10000 else 4
+    offs[o] = 0x110000
+    return data, offs
+
+
+def members(pattern, data, offs):
+    s = set()
+    for a, b in Pcre2Pattern(pattern).find_iter(data):
+        o = a
+        while o < b:
+            cp = offs[o]
+            s.add(cp)
+            o += 1 if cp < 0x80 else 2 if cp < 0x800 else 3 if cp < 0x10000 else 4
+    return s
+
+
+def main():
+    ver, uver = pcre2_versions()
+    print("PCRE2", ver, "Unicode", uver)
+    data, offs = all_codepoints_utf8()
+    sets = {k: members(p, data, offs) for k, p in {
+        "Lu": r"\p{Lu}", "Ll": r"\p{Ll}", "Lt": r"\p{Lt}", "Lm": r"\p{Lm}", "Lo": r"\p{Lo}",
+        "L": r"\p{L}", "M": r"\p{M}", "N": r"\p{N}", "S": r"\s",
+        "notS": r"\S", "X": r"[^\r\n\p{L}\p{N}]", "Pset": r"[^\s\p{L}\p{N}]",
+    }.items()}
+    L = sets["Lu"] | sets["Ll"] | sets["Lt"] | sets["Lm"] | sets["Lo"]
+    assert L == sets["L"], "L != Lu|Ll|Lt|Lm|Lo"
+    for a in ("Lu", "Ll", "Lt", "Lm", "Lo", "M", "N", "S"):
+        for b in ("Lu", "Ll", "Lt", "Lm", "Lo", "M", "N", "S"):
+            if a < b:
+                assert not (sets[a] & sets[b]), (a, b)
+    allcp = set(offs.values()) - {0x110000}
+    assert sets["notS"] == allcp - sets["S"]
+    assert sets["X"] == allcp - L - sets["N"] - {0x0A, 0x0D}
+    assert sets["Pset"] == allcp - L - sets["N"] - sets["S"]
+    assert 0x0A in sets["S"] and 0x0D in sets["S"] and 0x20 in sets["S"]
+    print({k: len(v) for k, v in sets.items()})
+    print("whitespace:", " ".join(f"U+{c:04X}" for c in sorted(sets["S"])))
+
+    cls = bytearray(0x110000)  # default P (also for surrogates: never seen in valid UTF-8)
+    for name in ("Lu", "Ll", "Lt", "Lm", "Lo", "M", "N"):
+        code = C[name]
+        for cp in sets[name]:
+            cls[cp] = code
+    for cp in sets["S"]:
+        cls[cp] = C["WS"]
+    cls[0x20] = C["SP"]
+    cls[0x0A] = C["NL"]
+    cls[0x0D] = C["NL"]
+    cls[0x27] = C["AP"]
+
+    bs = 1 << BLOCK_SHIFT
+    blocks = {}
+    stage1 = []
+    stage2 = bytearray()
+    for b in range(0x110000 >> BLOCK_SHIFT):
+        blk = bytes(cls[b * bs:(b + 1) * bs])
+        idx = blocks.get(blk)
+        if idx is None:
+            idx = blocks[blk] = len(blocks)
+            stage2 += blk
+        stage1.append(idx)
+    print(f"blocks: {len(blocks)} x {bs} B = {len(stage2)} B; stage1 {len(stage1) * 2} B")
+
+    folds = []
+    for ch in "stremvld":
+        m = members(f"(?i:{ch})", data, offs)
+        for cp in sorted(m):
+            folds.append((cp, ord(ch)))
+        print(f"(?i:{ch}) ->", [f"U+{c:04X}" for c in sorted(m)])
+
+    out = bytearray(struct.pack("<4sIII16s", b"SPLU", 1, BLOCK_SHIFT, len(blocks), uver.encode()))
+    out += struct.pack(f"<{len(stage1)}H", *stage1)
+    out += stage2
+    out += struct.pack("<I", len(folds))
+    for cp, lo in folds:
+        out += struct.pack("<II", cp, lo)
+    path = os.path.join(OUT, "unicode_classes.bin")
+    with open(path, "wb") as f:
+        f.write(out)
+    print("wrote", path, len(out), "B")
+
+
+if __name__ == "__main__":
+    main()
