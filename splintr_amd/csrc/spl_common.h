@@ -1,0 +1,111 @@
+// spl_common.h -- definitions shared by the host table builder and the gfx950 kernels.
+//
+// Everything here is integer/byte work: class codes of the split patterns
+// (reference src/core/tokenizer.rs:39, :42), the packed lookup-table entry formats that
+// replace the reference's FxHashMap<Vec<u8>,u32> (src/core/tokenizer.rs:302), and the
+// hash functions the host builder and the device probes must agree on.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SPL_HD __host__ __device__ __forceinline__
+#else
+#define SPL_HD inline
+#endif
+
+namespace spl {
+
+// ----------------------------------------------------------------------------------------
+// Code-point classes (same numbering as tools/gen_unicode_tables.py CLASS_NAMES).
+// ----------------------------------------------------------------------------------------
+enum : uint32_t {
+    C_P = 0,    // anything else: punctuation, symbols, controls, format, unassigned, emoji
+    C_AP = 1,   // U+0027 apostrophe (member of the "other" set, singled out for contractions)
+    C_SP = 2,   // U+0020
+    C_WS = 3,   // \s minus U+0020, CR, LF
+    C_NL = 4,   // CR, LF
+    C_N = 5,    // \p{N}
+    C_LU = 6, C_LL = 7, C_LT = 8, C_LM = 9, C_LO = 10,   // \p{Lu} \p{Ll} \p{Lt} \p{Lm} \p{Lo}
+    C_M = 11,   // \p{M}
+    C_EOT = 12, // end of the current text (document end / special-token span)
+    C_WEND = 13,// end of the staged window: the scanner must defer
+    C_CONT = 15 // UTF-8 continuation byte (not a character start)
+};
+#define SPL_BIT(c) (1u << (c))
+constexpr uint32_t M_L = SPL_BIT(C_LU) | SPL_BIT(C_LL) | SPL_BIT(C_LT) | SPL_BIT(C_LM) | SPL_BIT(C_LO);
+constexpr uint32_t M_S = SPL_BIT(C_SP) | SPL_BIT(C_WS) | SPL_BIT(C_NL);
+constexpr uint32_t M_OTHER = SPL_BIT(C_P) | SPL_BIT(C_AP) | SPL_BIT(C_M);           // [^\s\p{L}\p{N}]
+constexpr uint32_t M_X = SPL_BIT(C_P) | SPL_BIT(C_AP) | SPL_BIT(C_SP) | SPL_BIT(C_WS) | SPL_BIT(C_M); // [^\r\n\p{L}\p{N}]
+constexpr uint32_t M_U = SPL_BIT(C_LU) | SPL_BIT(C_LT) | SPL_BIT(C_LM) | SPL_BIT(C_LO) | SPL_BIT(C_M);
+constexpr uint32_t M_W = SPL_BIT(C_LL) | SPL_BIT(C_LM) | SPL_BIT(C_LO) | SPL_BIT(C_M);
+constexpr uint32_t M_UW = SPL_BIT(C_LM) | SPL_BIT(C_LO) | SPL_BIT(C_M);             // in both U and W
+
+// Per-byte class record kept in LDS by the pre-tokeniser:
+//   bits 0-3 class code, bit 4 SYNC (context-free match start), bit 5 TSTART (a text starts
+//   here: look-ahead from the left must see end-of-text), bits 6-7 UTF-8 length - 1.
+constexpr uint32_t CB_CLASS = 0x0F, CB_SYNC = 0x10, CB_TSTART = 0x20, CB_LEN_SHIFT = 6;
+
+enum : int { PAT_CL100K = 0, PAT_O200K = 1 };
+
+// ----------------------------------------------------------------------------------------
+// Lookup tables in HBM (built on the host by spl_tables.cpp, probed by the kernels).
+// ----------------------------------------------------------------------------------------
+// Short-key table: vocabulary entries whose key is <= 12 bytes, key stored inline.
+struct ShortEnt {            // 16 B, one dwordx4 load
+    uint32_t k0, k1, k2;     // key bytes, little endian, zero padded
+    uint32_t id_len;         // id | len << 24 ; 0xFFFFFFFF = empty slot
+};
+// Long-key table: 13..max_key_len bytes; key bytes live in a 4-byte-aligned blob.
+struct LongEnt {             // 16 B
+    uint32_t tag;            // second hash, filters almost every false candidate
+    uint32_t id;             // 0xFFFFFFFF = empty slot
+    uint32_t off;            // byte offset into key blob (multiple of 4)
+    uint32_t len;
+};
+constexpr uint32_t SPL_EMPTY = 0xFFFFFFFFu;
+constexpr int SPL_SHORT_MAX = 12;
+// Pair table: (left id, right id) -> id of the concatenation, one u64 per entry:
+//   bits 0-20 left, 21-41 right, 42-62 merged id; all-ones = empty.  Ids < 2^21.
+constexpr uint64_t SPL_PAIR_EMPTY = ~0ull;
+constexpr uint32_t SPL_ID_BITS = 21;
+constexpr uint32_t SPL_ID_MASK = (1u << SPL_ID_BITS) - 1;
+constexpr uint32_t SPL_NO_RANK = 0xFFFFFFFFu;
+
+struct DeviceTables {
+    // code-point classes
+    const uint16_t* ucls_stage1;
+    const uint8_t* ucls_stage2;
+    uint32_t ucls_shift;
+    uint32_t cjk_fast;        // 1 if U+4E00..U+9FFF and U+AC00..U+D7A3 are uniformly C_LO
+    // vocabulary
+    const ShortEnt* short_tab; uint32_t short_mask;
+    const LongEnt* long_tab;   uint32_t long_mask;
+    const uint8_t* key_blob;
+    const uint64_t* pair_tab;  uint32_t pair_mask;
+    const uint32_t* byte_id;   // [256] id of each single-byte token or SPL_NO_RANK
+    uint32_t max_key_len;
+    uint32_t pattern;         // PAT_*
+    uint32_t all_bytes;       // 1 if all 256 single bytes are tokens
+};
+
+// ----------------------------------------------------------------------------------------
+// Hashes (host builder and device probes use these very functions).
+// ----------------------------------------------------------------------------------------
+SPL_HD uint32_t mix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    return h;
+}
+SPL_HD uint32_t hash_short(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len) {
+    uint32_t h = k0 * 0x9E3779B1u ^ (k1 * 0x85EBCA77u + 0x165667B1u) ^ (k2 * 0xC2B2AE3Du) ^ (len * 0x27D4EB2Fu);
+    return mix32(h);
+}
+// long keys: word-at-a-time over the zero-padded little-endian words of the key
+SPL_HD uint32_t hash_long_step(uint32_t h, uint32_t w) { h = (h ^ w) * 0x9E3779B1u; return (h << 13) | (h >> 19); }
+SPL_HD uint32_t hash_long_fin(uint32_t h, uint32_t len) { return mix32(h ^ len); }
+SPL_HD uint32_t hash_long_tag(uint32_t h) { return mix32(h * 0x85EBCA77u + 0x3C6EF372u); }
+SPL_HD uint32_t hash_pair(uint32_t l, uint32_t r) { return mix32(l * 0x9E3779B1u + r * 0x85EBCA77u + 0x27D4EB2Fu); }
+SPL_HD uint64_t pair_key(uint32_t l, uint32_t r) { return (uint64_t)l | ((uint64_t)r << SPL_ID_BITS); }
+constexpr uint64_t SPL_PAIR_KEY_MASK = (1ull << (2 * SPL_ID_BITS)) - 1;
+
+}  // namespace spl

@@ -1,0 +1,222 @@
+// spl_tables.cpp -- see spl_tables.h.
+#include "spl_tables.h"
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+
+namespace spl {
+
+namespace {
+
+uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+uint16_t rd16(const uint8_t* p) { uint16_t v; memcpy(&v, p, 2); return v; }
+
+uint32_t pow2_at_least(size_t n) {
+    uint32_t c = 16;
+    while (c < n) c <<= 1;
+    return c;
+}
+
+// ByteLevel alphabet (reference src/core/byte_level.rs:46-74): byte -> code point.
+void byte_level_alphabet(uint32_t cp_of_byte[256]) {
+    bool direct[256] = {false};
+    for (int b = 33; b <= 126; b++) direct[b] = true;
+    for (int b = 161; b <= 172; b++) direct[b] = true;
+    for (int b = 174; b <= 255; b++) direct[b] = true;
+    uint32_t next = 256;
+    for (int b = 0; b < 256; b++) cp_of_byte[b] = direct[b] ? (uint32_t)b : next++;
+}
+
+// Decode a ByteLevel key (UTF-8 of alphabet chars) into raw bytes; false if any char is foreign.
+bool byte_level_to_raw(const std::string& key, const std::unordered_map<uint32_t, uint8_t>& byte_of_cp,
+                       std::string& raw) {
+    raw.clear();
+    size_t i = 0;
+    while (i < key.size()) {
+        const uint8_t b = (uint8_t)key[i];
+        uint32_t cp;
+        size_t l;
+        if (b < 0x80) { cp = b; l = 1; }
+        else if (b >= 0xC0 && b < 0xE0 && i + 1 < key.size()) { cp = ((b & 0x1Fu) << 6) | ((uint8_t)key[i + 1] & 0x3Fu); l = 2; }
+        else return false;                              // alphabet is U+0021..U+0143: at most 2 bytes
+        auto it = byte_of_cp.find(cp);
+        if (it == byte_of_cp.end()) return false;
+        raw.push_back((char)it->second);
+        i += l;
+    }
+    return true;
+}
+
+uint32_t load_le(const std::string& s, size_t off) {      // up to 4 bytes, zero padded
+    uint32_t w = 0;
+    for (size_t i = 0; i < 4 && off + i < s.size(); i++) w |= (uint32_t)(uint8_t)s[off + i] << (8 * i);
+    return w;
+}
+
+}  // namespace
+
+uint32_t host_cp_class(const HostTables& t, uint32_t cp) {
+    if (cp >= 0x110000u) return C_P;
+    const uint32_t blk = t.ucls_stage1[cp >> t.ucls_shift];
+    return t.ucls_stage2[(blk << t.ucls_shift) | (cp & ((1u << t.ucls_shift) - 1u))];
+}
+
+int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size_t ucls_len, int pattern,
+                 HostTables& out, std::string& err) {
+    // ---- class table -------------------------------------------------------------------
+    if (ucls_len < 32 || memcmp(ucls, "SPLU", 4) != 0 || rd32(ucls + 4) != 1) { err = "bad unicode class table"; return 1; }
+    out.ucls_shift = rd32(ucls + 8);
+    const uint32_t nblocks = rd32(ucls + 12);
+    const size_t n1 = 0x110000u >> out.ucls_shift, n2 = (size_t)nblocks << out.ucls_shift;
+    if (ucls_len < 32 + n1 * 2 + n2) { err = "truncated unicode class table"; return 1; }
+    out.ucls_stage1.resize(n1);
+    memcpy(out.ucls_stage1.data(), ucls + 32, n1 * 2);
+    out.ucls_stage2.assign(ucls + 32 + n1 * 2, ucls + 32 + n1 * 2 + n2);
+    for (uint16_t b : out.ucls_stage1)
+        if (b >= nblocks) { err = "unicode class table: block index out of range"; return 1; }
+    out.cjk_fast = true;
+    for (uint32_t cp = 0x4E00; cp < 0xA000 && out.cjk_fast; cp++) out.cjk_fast = host_cp_class(out, cp) == C_LO;
+    for (uint32_t cp = 0xAC00; cp < 0xD7A4 && out.cjk_fast; cp++) out.cjk_fast = host_cp_class(out, cp) == C_LO;
+    if (pattern != PAT_CL100K && pattern != PAT_O200K) { err = "unknown pattern id"; return 1; }
+    out.pattern = pattern;
+
+    // ---- vocabulary (reference src/core/vocab.rs:57-89: later duplicate wins) ---------------
+    if (splv_len < 20 || memcmp(splv, "SPLV", 4) != 0 || rd32(splv + 4) != 1) { err = "bad vocabulary container"; return 1; }
+    const uint32_t nrec = rd32(splv + 8);
+    out.byte_level = (rd32(splv + 12) & 1u) != 0;
+    std::unordered_map<std::string, uint32_t> enc;
+    enc.reserve(nrec * 2);
+    {
+        size_t off = 20;
+        for (uint32_t i = 0; i < nrec; i++) {
+            if (off + 6 > splv_len) { err = "truncated vocabulary container"; return 1; }
+            const uint32_t rank = rd32(splv + off);
+            const uint16_t len = rd16(splv + off + 4);
+            off += 6;
+            if (off + len > splv_len) { err = "truncated vocabulary container"; return 1; }
+            enc[std::string((const char*)splv + off, len)] = rank;
+            off += len;
+        }
+    }
+    if (out.byte_level) {
+        // Re-key into raw-byte space.  Exact iff every alphabet char is a token and all of them
+        // rank below every multi-char token (then the reference's merge loop completes all
+        // intra-char merges first; DESIGN.md "ByteLevel equivalence").
+        uint32_t cp_of_byte[256];
+        byte_level_alphabet(cp_of_byte);
+        std::unordered_map<uint32_t, uint8_t> byte_of_cp;
+        for (int b = 0; b < 256; b++) byte_of_cp[cp_of_byte[b]] = (uint8_t)b;
+        std::unordered_map<std::string, uint32_t> raw_enc;
+        raw_enc.reserve(enc.size() * 2);
+        uint32_t max_char_rank = 0, min_multi_rank = 0xFFFFFFFFu;
+        std::string raw;
+        for (const auto& kv : enc) {
+            if (!byte_level_to_raw(kv.first, byte_of_cp, raw)) continue;   // unreachable from encoded text
+            if (raw.empty()) continue;
+            raw_enc[raw] = kv.second;
+            if (raw.size() == 1) max_char_rank = std::max(max_char_rank, kv.second);
+            else min_multi_rank = std::min(min_multi_rank, kv.second);
+        }
+        for (int b = 0; b < 256; b++)
+            if (!raw_enc.count(std::string(1, (char)b))) { err = "ByteLevel vocabulary lacks an alphabet character"; return 1; }
+        if (max_char_rank >= min_multi_rank) { err = "ByteLevel vocabulary: a merge outranks an alphabet character"; return 1; }
+        enc.swap(raw_enc);
+    }
+    if (enc.empty()) { err = "empty vocabulary"; return 1; }
+    out.max_id = 0;
+    out.max_key_len = 0;
+    for (const auto& kv : enc) {
+        if (kv.second > SPL_ID_MASK) { err = "token id does not fit 21 bits"; return 1; }
+        out.max_id = std::max(out.max_id, kv.second);
+        out.max_key_len = std::max<uint32_t>(out.max_key_len, (uint32_t)kv.first.size());
+    }
+    out.n_keys = (uint32_t)enc.size();
+    out.byte_id.assign(256, SPL_NO_RANK);
+    out.all_bytes = true;
+    for (int b = 0; b < 256; b++) {
+        auto it = enc.find(std::string(1, (char)b));
+        if (it != enc.end()) out.byte_id[b] = it->second; else out.all_bytes = false;
+    }
+    if (!out.all_bytes) {
+        // The pair-table merge loop is exact only when every node's bytes are a token
+        // (DESIGN.md "Pair table equivalence"); all four in-scope vocabularies qualify.
+        err = "vocabulary must contain all 256 single-byte tokens";
+        return 1;
+    }
+
+    // ---- short / long key tables ----------------------------------------------------------
+    size_t n_short = 0, n_long = 0;
+    for (const auto& kv : enc) (kv.first.size() <= (size_t)SPL_SHORT_MAX ? n_short : n_long)++;
+    const uint32_t scap = pow2_at_least(n_short * 2 + 2), lcap = pow2_at_least(n_long * 2 + 2);
+    out.short_tab.assign(scap, ShortEnt{0, 0, 0, SPL_EMPTY});
+    out.long_tab.assign(lcap, LongEnt{0, SPL_EMPTY, 0, 0});
+    out.key_blob.clear();
+    for (const auto& kv : enc) {
+        const std::string& k = kv.first;
+        const uint32_t n = (uint32_t)k.size();
+        if (n <= (uint32_t)SPL_SHORT_MAX) {
+            const uint32_t k0 = load_le(k, 0), k1 = load_le(k, 4), k2 = load_le(k, 8);
+            uint32_t slot = hash_short(k0, k1, k2, n) & (scap - 1);
+            while (out.short_tab[slot].id_len != SPL_EMPTY) slot = (slot + 1) & (scap - 1);
+            out.short_tab[slot] = ShortEnt{k0, k1, k2, kv.second | (n << 24)};
+        } else {
+            uint32_t h = 0;
+            for (uint32_t i = 0; i < n; i += 4) h = hash_long_step(h, load_le(k, i));
+            h = hash_long_fin(h, n);
+            uint32_t slot = h & (lcap - 1);
+            while (out.long_tab[slot].id != SPL_EMPTY) slot = (slot + 1) & (lcap - 1);
+            const uint32_t off = (uint32_t)out.key_blob.size();
+            out.key_blob.insert(out.key_blob.end(), k.begin(), k.end());
+            while (out.key_blob.size() & 3) out.key_blob.push_back(0);
+            out.long_tab[slot] = LongEnt{hash_long_tag(h), kv.second, off, n};
+        }
+    }
+    out.key_blob.resize(out.key_blob.size() + 16, 0);
+
+    // ---- pair table: every 2-split of every token whose halves are tokens --------------------
+    std::vector<std::pair<uint64_t, uint32_t>> pairs;
+    pairs.reserve(enc.size() * 3);
+    for (const auto& kv : enc) {
+        const std::string& k = kv.first;
+        for (size_t cut = 1; cut < k.size(); cut++) {
+            auto l = enc.find(k.substr(0, cut));
+            if (l == enc.end()) continue;
+            auto r = enc.find(k.substr(cut));
+            if (r == enc.end()) continue;
+            pairs.emplace_back(pair_key(l->second, r->second), kv.second);
+        }
+    }
+    out.n_pairs = (uint32_t)pairs.size();
+    const uint32_t pcap = pow2_at_least(pairs.size() * 2 + 2);
+    out.pair_tab.assign(pcap, SPL_PAIR_EMPTY);
+    for (const auto& pr : pairs) {
+        const uint32_t l = (uint32_t)(pr.first & SPL_ID_MASK), r = (uint32_t)(pr.first >> SPL_ID_BITS);
+        uint32_t slot = hash_pair(l, r) & (pcap - 1);
+        bool dup = false;
+        while (out.pair_tab[slot] != SPL_PAIR_EMPTY) {
+            if ((out.pair_tab[slot] & SPL_PAIR_KEY_MASK) == pr.first) { dup = true; break; }
+            slot = (slot + 1) & (pcap - 1);
+        }
+        if (dup) {   // two different tokens with the same (left,right) split would be the same bytes
+            if ((uint32_t)(out.pair_tab[slot] >> (2 * SPL_ID_BITS)) != pr.second) { err = "pair table conflict"; return 1; }
+            continue;
+        }
+        out.pair_tab[slot] = pr.first | ((uint64_t)pr.second << (2 * SPL_ID_BITS));
+    }
+
+    // ---- decoder CSR (id -> raw bytes) ---------------------------------------------------------
+    std::vector<const std::string*> by_id(out.max_id + 1, nullptr);
+    for (const auto& kv : enc) by_id[kv.second] = &kv.first;   // duplicate ids: arbitrary, as build_decoder
+    out.tok_off.assign(out.max_id + 2, 0);
+    out.tok_bytes.clear();
+    for (uint32_t id = 0; id <= out.max_id; id++) {
+        out.tok_off[id] = (uint32_t)out.tok_bytes.size();
+        if (by_id[id]) out.tok_bytes.insert(out.tok_bytes.end(), by_id[id]->begin(), by_id[id]->end());
+    }
+    out.tok_off[out.max_id + 1] = (uint32_t)out.tok_bytes.size();
+    return 0;
+}
+
+}  // namespace spl

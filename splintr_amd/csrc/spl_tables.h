@@ -1,0 +1,46 @@
+// spl_tables.h -- host-side construction of the packed lookup tables (pure C++17, no HIP).
+//
+// Takes the place of load_tiktoken_bpe + the FxHashMap encoder (reference
+// src/core/vocab.rs:57-89, src/core/tokenizer.rs:302, 410-456): parses this repo's SPLV
+// vocabulary container, re-keys ByteLevel vocabularies into raw-byte space
+// (src/core/byte_level.rs:46-74; DESIGN.md "ByteLevel equivalence"), and builds the
+// short-key / long-key / pair tables the kernels probe (spl_common.h).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "spl_common.h"
+
+namespace spl {
+
+struct HostTables {
+    // code-point classes
+    std::vector<uint16_t> ucls_stage1;
+    std::vector<uint8_t> ucls_stage2;
+    uint32_t ucls_shift = 7;
+    bool cjk_fast = false;
+    // vocabulary
+    std::vector<ShortEnt> short_tab;
+    std::vector<LongEnt> long_tab;
+    std::vector<uint8_t> key_blob;
+    std::vector<uint64_t> pair_tab;
+    std::vector<uint32_t> byte_id;      // 256
+    uint32_t max_key_len = 0;           // in the key space the kernels see (raw bytes)
+    uint32_t n_keys = 0, n_pairs = 0;
+    uint32_t max_id = 0;
+    bool all_bytes = false;
+    bool byte_level = false;
+    int pattern = PAT_CL100K;
+    // decoder side: id -> raw bytes (CSR); ids with no entry have empty spans
+    std::vector<uint32_t> tok_off;      // max_id + 2
+    std::vector<uint8_t> tok_bytes;
+};
+
+// Returns 0 on success; on failure fills err.
+int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size_t ucls_len, int pattern,
+                 HostTables& out, std::string& err);
+
+// Host mirror of the device two-stage lookup (used by build checks and tests/hostsim).
+uint32_t host_cp_class(const HostTables& t, uint32_t cp);
+
+}  // namespace spl

@@ -1,0 +1,66 @@
+"""Deterministic adversarial string generator shared by the parity tests.
+
+The alphabet concentrates on everything the split patterns (src/core/tokenizer.rs:39, :42 in
+the reference) distinguish: letter case classes (Lu/Ll/Lt/Lm/Lo), marks, three kinds of
+numbers, every flavour of whitespace, CR/LF, apostrophes with (caseless) contraction letters,
+punctuation, emoji/ZWJ, and multi-byte forms of each.  Nothing here was assigned after
+Unicode 13, so PCRE2 (Unicode 14), Python `regex` and unicodedata agree on every class.
+"""
+import random
+from typing import List
+
+ATOMS = [
+    # ASCII letters, incl. all contraction letters in both cases
+    "a", "b", "s", "t", "r", "e", "v", "m", "l", "d", "x", "S", "T", "R", "E", "V", "M", "L", "D", "A", "Z",
+    "the", "Hello", "HTTP", "camelCase", "don", "re", "ll", "ve", "LL", "Re",
+    # digits and other numbers (Nd / No / Nl), incl. non-ASCII
+    "0", "1", "7", "12", "123", "1234", "²", "½", "Ⅷ", "٣", "５",
+    # whitespace of every kind (\s under UCP)
+    " ", " ", " ", "  ", "\t", "\n", "\r", "\r\n", "\n\n", "\x0b", "\x0c", "\x85", " ", " ",
+    "᠎", " ", " ", " ", " ", "　",
+    # apostrophes and look-alikes
+    "'", "'", "'s", "'t", "'re", "'ve", "'m", "'ll", "'d", "'S", "'RE", "'ſ", "’", "`",
+    # punctuation / symbols / controls / format chars (all class "other")
+    ".", ",", "!", "?", "-", "_", "(", ")", "{", "}", "[", "]", "\"", "/", "\\", "=", "==", "+", "#", "$", "%",
+    ":", ";", "<", ">", "|", "<|", "|>", "\x00", "\x1f", "\x7f", "‍", "​", "﻿", "。",
+    "，", "§", "€", "—",
+    # letters: Lu/Ll non-ASCII, Lt, Lm, Lo (several scripts), caseless oddities
+    "É", "é", "ß", "ſ", "K", "İ", "ı", "ǅ", "ǈ", "ʰ", "ˠ",
+    "々", "你", "好", "世", "界", "あ", "ア", "한", "א", "ا", "ก",
+    "Α", "α", "Ж", "ж", "\U00020000", "\U0001d400",
+    # marks (Mn/Mc/Me)
+    "́", "̈", "ः", "⃝", "゙",
+    # emoji and friends
+    "\U0001f30d", "\U0001f600", "❤️", "\U0001f468‍\U0001f469",
+]
+
+WORDS = ["the", "of", "and", "to", "in", "is", "that", "for", "it", "as", "was", "with", "be", "by", "on",
+         "not", "he", "this", "are", "or", "his", "from", "at", "which", "but", "have", "an", "had", "they",
+         "you", "were", "their", "one", "all", "we", "can", "her", "has", "there", "been", "if", "more",
+         "when", "will", "would", "who", "so", "no", "tokenizer", "wavefront", "bandwidth", "parallel",
+         "International", "HTTPServer", "getElementById", "snake_case_name", "don't", "I'm", "they'll",
+         "we've", "it's", "you'd", "they're", "DON'T", "x86_64", "utf8", "3.14159", "1,000,000", "2024-01-02"]
+
+
+def fuzz_string(rng: random.Random, max_atoms: int = 40) -> str:
+    n = rng.randint(0, max_atoms)
+    mode = rng.random()
+    out: List[str] = []
+    for _ in range(n):
+        r = rng.random()
+        if mode < 0.3:  # word-ish text with occasional oddities
+            if r < 0.6:
+                out.append(rng.choice(WORDS))
+                out.append(rng.choice([" ", " ", " ", "  ", "\n", ", ", ". ", "\t", ""]))
+            else:
+                out.append(rng.choice(ATOMS))
+        elif mode < 0.5:  # runs: repeat the same atom several times
+            out.append(rng.choice(ATOMS) * rng.randint(1, 6))
+        else:
+            out.append(rng.choice(ATOMS))
+    return "".join(out)
+
+
+def fuzz_corpus(seed: int, count: int, max_atoms: int = 40) -> List[str]:
+    rng = random.Random(seed)
+    return [fuzz_string(rng, max_atoms) for _ in range(count)]

@@ -1,0 +1,82 @@
+"""ctypes wrapper of tests/hostsim/hostsim.cpp (TEST TOOL; builds with g++, no GPU needed)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(os.path.dirname(_HERE))
+_DATA = os.path.join(_ROOT, "splintr_amd", "data")
+_CSRC = os.path.join(_ROOT, "splintr_amd", "csrc")
+_LIB = os.path.join(_HERE, "libhostsim.so")
+_REG = {"cl100k_base": ("cl100k_base.splv", 0), "o200k_base": ("o200k_base.splv", 1),
+        "llama3": ("llama3.splv", 1), "deepseek_v3": ("deepseek_v3.splv", 1)}
+
+
+def build():
+    srcs = [os.path.join(_HERE, "hostsim.cpp"), os.path.join(_CSRC, "spl_tables.cpp")]
+    deps = srcs + [os.path.join(_CSRC, h) for h in ("spl_common.h", "spl_scan.h", "spl_lookup.h", "spl_tables.h")]
+    if not os.path.exists(_LIB) or any(os.path.getmtime(d) > os.path.getmtime(_LIB) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", _LIB] + srcs)
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = ctypes.CDLL(build())
+        L.hs_create.restype = ctypes.c_void_p
+        L.hs_create.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
+        L.hs_destroy.argtypes = [ctypes.c_void_p]
+        L.hs_info.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.hs_split.restype = ctypes.c_int
+        L.hs_split.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        L.hs_split_sync.restype = ctypes.c_int
+        L.hs_split_sync.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.hs_encode.restype = ctypes.c_int
+        L.hs_encode.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        _lib = L
+    return _lib
+
+
+class HostSim:
+    def __init__(self, name):
+        fn, pid = _REG[name]
+        err = ctypes.create_string_buffer(256)
+        self._h = lib().hs_create(os.path.join(_DATA, fn).encode(), os.path.join(_DATA, "unicode_classes.bin").encode(),
+                                  pid, err, 256)
+        if not self._h:
+            raise ValueError(err.value.decode())
+
+    def info(self):
+        a = np.zeros(8, dtype=np.uint32)
+        lib().hs_info(self._h, a.ctypes.data)
+        return dict(zip(["n_keys", "n_pairs", "max_key_len", "max_id", "short_cap", "long_cap", "pair_cap", "cjk_fast"],
+                        a.tolist()))
+
+    def split(self, data: bytes, window: int = 0):
+        out = np.zeros(len(data) + 1, dtype=np.uint32)
+        k = lib().hs_split(self._h, data, len(data), out.ctypes.data, window)
+        if k < 0:
+            raise RuntimeError(f"hs_split failed: {k}")
+        return out[:k].tolist()
+
+    def split_sync(self, data: bytes):
+        out = np.zeros(len(data) + 1, dtype=np.uint32)
+        st = np.zeros(2, dtype=np.uint32)
+        k = lib().hs_split_sync(self._h, data, len(data), out.ctypes.data, st.ctypes.data)
+        if k < 0:
+            raise RuntimeError(f"hs_split_sync failed: {k}")
+        return out[:k].tolist(), int(st[0]), int(st[1])
+
+    def encode(self, data: bytes):
+        out = np.zeros(len(data) + 1, dtype=np.uint32)
+        hits = ctypes.c_uint32(0)
+        k = lib().hs_encode(self._h, data, len(data), out.ctypes.data, ctypes.byref(hits))
+        if k < 0:
+            raise RuntimeError(f"hs_encode failed: {k}")
+        return out[:k].tolist()
