@@ -1,0 +1,120 @@
+/* splintr_hip.h -- C ABI of the MI355X (gfx950) batch BPE encoder.
+ *
+ * The reference (ml-rust/splintr v0.8.0) has no C ABI: its only boundary is the PyO3 class
+ * `Tokenizer` (src/python/bindings.rs:57-446) over `core::Tokenizer` (src/core/tokenizer.rs).
+ * Each entry point below names the reference interface it stands in for; INTEGRATION.md shows the
+ * binding a maintainer would add on the reference side (a `mod hip` FFI block in Rust, or the
+ * ctypes class this repo ships as splintr_amd.Tokenizer).
+ *
+ * Conventions: plain pointers and sizes, no exceptions, no aborts.  Functions returning int
+ * return SPL_OK (0) or a negative SPL_E* code; spl_last_error() gives the thread-local message.
+ * Text is UTF-8, documents are packed back to back: doc d = utf8[doc_off[d] .. doc_off[d+1]).
+ * Results are CSR: ids[T] (u32) + out_off[n_docs+1] (u64), in document order -- the flattened
+ * form of the reference's Vec<Vec<u32>>.  A handle is bound to one GPU; one batch in flight per
+ * handle; different handles may be used from different threads.
+ */
+#ifndef SPLINTR_HIP_H
+#define SPLINTR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPL_OK 0
+#define SPL_EINVAL (-1)   /* bad argument / malformed table blob */
+#define SPL_EDEVICE (-2)  /* HIP runtime error (no GPU, out of memory, launch failure) */
+#define SPL_ECAPACITY (-3)/* caller-provided output buffer too small */
+
+/* Split pattern ids: CL100K_BASE_PATTERN (src/core/tokenizer.rs:39), O200K_BASE_PATTERN (:42;
+ * also LLAMA3_PATTERN :45 and deepseek_v3, src/python/bindings.rs:116-129). */
+#define SPL_PATTERN_CL100K 0
+#define SPL_PATTERN_O200K 1
+
+/* encode flags */
+#define SPL_WITH_SPECIAL 1u /* encode_with_special semantics (src/core/tokenizer.rs:842-874) */
+#define SPL_INTRA_DOC 2u    /* encode_rayon (tokenizer.rs:815-837): accepted, no effect -- the GPU
+                               path is always chunk-parallel inside a document, output identical */
+
+typedef struct spl_tokenizer spl_tokenizer;
+typedef struct spl_result spl_result;
+
+typedef struct spl_opts {
+    int32_t pattern;   /* SPL_PATTERN_* */
+    int32_t device;    /* HIP device ordinal */
+} spl_opts;
+
+/* Thread-local text of the last failure in this thread. */
+const char* spl_last_error(void);
+
+/* Number of visible HIP devices (0 if none / no driver). */
+int spl_device_count(void);
+
+/* Tokenizer::from_bytes / from_bytes_byte_level (src/core/tokenizer.rs:552-569) + with_full_options
+ * (:410-456): parse the vocabulary (SPLV container, tools/pack_vocab.py; ByteLevel flag inside) and
+ * the code-point class table (tools/gen_unicode_tables.py), build the lookup tables and upload them
+ * to the device.  Returns NULL on failure. */
+spl_tokenizer* spl_create(const void* vocab_splv, size_t vocab_len, const void* uclass_tab, size_t uclass_len,
+                          const spl_opts* opts);
+
+/* One entry of the special_tokens map (src/core/tokenizer.rs:304, 429-434).  Call before the first
+ * encode.  Literals must be non-empty. */
+int spl_add_special(spl_tokenizer* t, const uint8_t* literal, size_t len, uint32_t id);
+
+/* Tokenizer::vocab_size (src/core/tokenizer.rs:964-972): max id over vocab and specials, plus 1. */
+uint32_t spl_vocab_size(const spl_tokenizer* t);
+
+void spl_destroy(spl_tokenizer* t);
+
+/* Pre-size the device workspace for batches of up to max_bytes / max_docs, so that later encode
+ * calls neither allocate nor synchronise. */
+int spl_reserve(spl_tokenizer* t, uint64_t max_bytes, uint64_t max_docs);
+
+/* Tokenizer::encode_batch / encode_batch_with_special (src/core/tokenizer.rs:932-942) on HOST
+ * buffers: copies the corpus to the GPU, encodes, copies the CSR result back.  *out is owned by
+ * the library; release with spl_result_free. */
+int spl_encode_batch(spl_tokenizer* t, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs,
+                     uint32_t flags, spl_result** out);
+const uint32_t* spl_result_tokens(const spl_result* r);   /* ids[T] */
+const uint64_t* spl_result_offsets(const spl_result* r);  /* out_off[n_docs+1] */
+uint64_t spl_result_n_tokens(const spl_result* r);
+uint64_t spl_result_n_docs(const spl_result* r);
+void spl_result_free(spl_result* r);
+
+/* Same path with everything resident in HBM (device pointers).  Fully asynchronous on `hip_stream`
+ * (a hipStream_t; NULL = the default stream) once spl_reserve has sized the workspace.
+ *   d_utf8[n_bytes]       corpus; doc offsets d_doc_off[n_docs+1] with d_doc_off[0]==0,
+ *                         d_doc_off[n_docs]==n_bytes
+ *   d_ids[ids_capacity]   output ids; n_bytes entries always suffice
+ *   d_out_off[n_docs+1]   output offsets; d_out_off[n_docs] is the total token count
+ * Tokens beyond ids_capacity are dropped (compare d_out_off[n_docs] with the capacity). */
+int spl_encode_batch_device(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
+                            uint64_t n_docs, uint32_t flags, uint32_t* d_ids, uint64_t ids_capacity,
+                            uint64_t* d_out_off, void* hip_stream);
+
+/* Tokenizer::decode_bytes for a batch (src/core/tokenizer.rs:877-897, 944-958), HOST buffers:
+ * ids CSR in, bytes CSR out.  *out_bytes / *out_off are malloc'd; release with spl_free. */
+int spl_decode_batch(spl_tokenizer* t, const uint32_t* ids, const uint64_t* ids_off, uint64_t n_docs,
+                     uint8_t** out_bytes, uint64_t** out_off);
+void spl_free(void* p);
+
+/* Per-kernel timing (HIP events on the launch stream).  While enabled every encode call records
+ * events around each kernel; spl_profile_read returns the accumulated milliseconds and launch
+ * counts per kernel since the last spl_profile_reset and synchronises the stream. */
+#define SPL_MAX_KERNELS 16
+int spl_profile_enable(spl_tokenizer* t, int on);
+int spl_profile_reset(spl_tokenizer* t);
+int spl_profile_read(spl_tokenizer* t, double ms_out[SPL_MAX_KERNELS], uint64_t launches_out[SPL_MAX_KERNELS]);
+const char* spl_kernel_name(int index);   /* NULL past the last kernel */
+
+/* Counters of the last encode call on this handle (device -> host copy, synchronises):
+ * [0] chunks resolved by the whole-chunk probe is not tracked; entries are
+ * [0] short-merge queue items (<=16 B), [1] medium (17..64 B), [2] long (>64 B), [3] deferred segments. */
+int spl_last_queue_counts(spl_tokenizer* t, uint32_t counts_out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPLINTR_HIP_H */

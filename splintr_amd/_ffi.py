@@ -1,0 +1,83 @@
+"""ctypes binding of libsplintr_hip.so (include/splintr_hip.h).
+
+The library is the product: if it is missing or cannot be loaded this module raises -- there is
+no CPU fallback anywhere in the package.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsplintr_hip.so")
+
+SPL_OK = 0
+SPL_WITH_SPECIAL = 1
+SPL_INTRA_DOC = 2
+SPL_MAX_KERNELS = 16
+
+# every symbol include/splintr_hip.h declares (tests/test_abi.py checks the header against this)
+SYMBOLS = [
+    "spl_last_error", "spl_device_count", "spl_create", "spl_add_special", "spl_vocab_size", "spl_destroy",
+    "spl_reserve", "spl_encode_batch", "spl_result_tokens", "spl_result_offsets", "spl_result_n_tokens",
+    "spl_result_n_docs", "spl_result_free", "spl_encode_batch_device", "spl_decode_batch", "spl_free",
+    "spl_profile_enable", "spl_profile_reset", "spl_profile_read", "spl_kernel_name", "spl_last_queue_counts",
+]
+
+
+class SplOpts(ctypes.Structure):
+    _fields_ = [("pattern", ctypes.c_int32), ("device", ctypes.c_int32)]
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). splintr_amd has no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, u8p, u32p, u64p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint32), \
+        ctypes.POINTER(ctypes.c_uint64)
+    L.spl_last_error.restype = ctypes.c_char_p
+    L.spl_device_count.restype = ctypes.c_int
+    L.spl_create.restype = vp
+    L.spl_create.argtypes = [vp, ctypes.c_size_t, vp, ctypes.c_size_t, ctypes.POINTER(SplOpts)]
+    L.spl_add_special.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32]
+    L.spl_vocab_size.restype = ctypes.c_uint32
+    L.spl_vocab_size.argtypes = [vp]
+    L.spl_destroy.argtypes = [vp]
+    L.spl_destroy.restype = None
+    L.spl_reserve.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint64]
+    L.spl_encode_batch.argtypes = [vp, vp, vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(vp)]
+    L.spl_result_tokens.restype = u32p
+    L.spl_result_tokens.argtypes = [vp]
+    L.spl_result_offsets.restype = u64p
+    L.spl_result_offsets.argtypes = [vp]
+    L.spl_result_n_tokens.restype = ctypes.c_uint64
+    L.spl_result_n_tokens.argtypes = [vp]
+    L.spl_result_n_docs.restype = ctypes.c_uint64
+    L.spl_result_n_docs.argtypes = [vp]
+    L.spl_result_free.argtypes = [vp]
+    L.spl_result_free.restype = None
+    L.spl_encode_batch_device.argtypes = [vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, ctypes.c_uint32, vp,
+                                          ctypes.c_uint64, vp, vp]
+    L.spl_decode_batch.argtypes = [vp, vp, vp, ctypes.c_uint64, ctypes.POINTER(u8p), ctypes.POINTER(u64p)]
+    L.spl_free.argtypes = [vp]
+    L.spl_free.restype = None
+    L.spl_profile_enable.argtypes = [vp, ctypes.c_int]
+    L.spl_profile_reset.argtypes = [vp]
+    L.spl_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
+    L.spl_kernel_name.restype = ctypes.c_char_p
+    L.spl_kernel_name.argtypes = [ctypes.c_int]
+    L.spl_last_queue_counts.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32)]
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return (lib().spl_last_error() or b"").decode("utf-8", "replace")

@@ -1,0 +1,446 @@
+// spl_api.hip -- the C ABI (include/splintr_hip.h): handle, device tables, workspace, launch order.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/splintr_hip.h"
+#include "spl_kernels.hip"
+#include "spl_tables.h"
+
+using namespace spl;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(SPL_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+enum { KI_MARK = 0, KI_SPECIAL, KI_PRETOK, KI_DEFER, KI_BPE16, KI_BPE64, KI_BPELONG, KI_COUNT, KI_SCAN, KI_COMPACT, KI_DOCOFF, KI_N };
+const char* const k_names[KI_N] = {"k_mark_docs", "k_special_scan+ends", "k_pretok", "k_deferred", "k_bpe_lanes<16>", "k_bpe_lanes<64>",
+                                   "k_bpe_block", "k_count", "k_scan", "k_compact", "k_doc_offsets"};
+
+template <class T> int dev_upload(const std::vector<T>& v, const T** out) {
+    void* p = nullptr;
+    const size_t bytes = v.size() * sizeof(T);
+    HIP_TRY(hipMalloc(&p, bytes ? bytes : 16));
+    if (bytes) HIP_TRY(hipMemcpy(p, v.data(), bytes, hipMemcpyHostToDevice));
+    *out = (const T*)p;
+    return SPL_OK;
+}
+
+struct Special { std::string lit; uint32_t id; };
+
+}  // namespace
+
+struct spl_tokenizer {
+    int device = 0;
+    HostTables ht;
+    DeviceTables dt{};
+    const uint32_t* d_tok_off = nullptr;
+    const uint8_t* d_tok_bytes = nullptr;
+    std::vector<Special> specials;
+    uint32_t max_special_id = 0;
+    uint8_t* d_sp_lits = nullptr;      // uploaded lazily; invalidated by spl_add_special
+    bool sp_uploaded = false;
+    // workspace
+    uint64_t cap_bytes = 0, cap_docs = 0;
+    uint32_t* d_zero = nullptr;    // [tbits | tstart | skip | qcount]
+    size_t zero_words = 0, bitmap_words = 0;
+    uint32_t* d_stage = nullptr;
+    uint32_t* d_rank = nullptr;
+    uint2* d_q16 = nullptr; uint2* d_q64 = nullptr; uint2* d_qlong = nullptr; uint32_t* d_qdefer = nullptr;
+    uint32_t qcap16 = 0, qcap64 = 0, qcaplong = 0, qcapdefer = 0;
+    uint32_t* d_blk = nullptr;
+    // host-path staging
+    uint8_t* d_in_text = nullptr; uint64_t* d_in_off = nullptr; uint32_t* d_out_ids = nullptr; uint64_t* d_out_off = nullptr;
+    uint64_t in_cap_bytes = 0, in_cap_docs = 0;
+    // profiling
+    bool prof = false;
+    hipEvent_t ev[KI_N + 1]{};
+    bool ev_ready = false;
+    double prof_ms[SPL_MAX_KERNELS]{};
+    uint64_t prof_n[SPL_MAX_KERNELS]{};
+};
+
+struct spl_result {
+    std::vector<uint32_t> ids;
+    std::vector<uint64_t> off;
+};
+
+namespace {
+
+void free_workspace(spl_tokenizer* t) {
+    hipFree(t->d_zero); hipFree(t->d_stage); hipFree(t->d_rank); hipFree(t->d_q16); hipFree(t->d_q64);
+    hipFree(t->d_qlong); hipFree(t->d_qdefer); hipFree(t->d_blk);
+    t->d_zero = nullptr; t->d_stage = nullptr; t->d_rank = nullptr; t->d_q16 = nullptr; t->d_q64 = nullptr;
+    t->d_qlong = nullptr; t->d_qdefer = nullptr; t->d_blk = nullptr;
+    t->cap_bytes = t->cap_docs = 0;
+}
+
+int reserve(spl_tokenizer* t, uint64_t max_bytes, uint64_t max_docs) {
+    if (max_bytes <= t->cap_bytes && max_docs <= t->cap_docs) return SPL_OK;
+    HIP_TRY(hipSetDevice(t->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const uint64_t nb = std::max<uint64_t>(max_bytes, t->cap_bytes), nd = std::max<uint64_t>(max_docs, t->cap_docs);
+    free_workspace(t);
+    const size_t nblk = (size_t)(nb / RANK_BLK) + 2;
+    t->bitmap_words = nblk * 32 + 64;
+    t->zero_words = 3 * t->bitmap_words + 8;
+    HIP_TRY(hipMalloc((void**)&t->d_zero, t->zero_words * 4));
+    HIP_TRY(hipMalloc((void**)&t->d_stage, (nb + 8192) * 4));
+    HIP_TRY(hipMalloc((void**)&t->d_rank, (nb + 8192) * 4));
+    t->qcap16 = (uint32_t)(nb / 2 + 64);
+    t->qcap64 = (uint32_t)(nb / 17 + 64);
+    t->qcaplong = (uint32_t)(nb / 65 + 64);
+    t->qcapdefer = (uint32_t)(2 * (nb / TB + 2) + 64);
+    HIP_TRY(hipMalloc((void**)&t->d_q16, (size_t)t->qcap16 * 8));
+    HIP_TRY(hipMalloc((void**)&t->d_q64, (size_t)t->qcap64 * 8));
+    HIP_TRY(hipMalloc((void**)&t->d_qlong, (size_t)t->qcaplong * 8));
+    HIP_TRY(hipMalloc((void**)&t->d_qdefer, (size_t)t->qcapdefer * 4));
+    HIP_TRY(hipMalloc((void**)&t->d_blk, (nblk + 2) * 4));
+    t->cap_bytes = nb;
+    t->cap_docs = nd;
+    return SPL_OK;
+}
+
+int upload_specials(spl_tokenizer* t) {
+    if (t->sp_uploaded) return SPL_OK;
+    std::vector<uint8_t> recs(t->specials.size() * SP_REC + 16, 0);
+    for (size_t k = 0; k < t->specials.size(); k++) {
+        uint8_t* r = recs.data() + k * SP_REC;
+        r[0] = (uint8_t)t->specials[k].lit.size();
+        memcpy(r + 4, &t->specials[k].id, 4);
+        memcpy(r + 8, t->specials[k].lit.data(), t->specials[k].lit.size());
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    hipFree(t->d_sp_lits);
+    t->d_sp_lits = nullptr;
+    HIP_TRY(hipMalloc((void**)&t->d_sp_lits, recs.size()));
+    HIP_TRY(hipMemcpy(t->d_sp_lits, recs.data(), recs.size(), hipMemcpyHostToDevice));
+    t->sp_uploaded = true;
+    return SPL_OK;
+}
+
+int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off, uint64_t n_docs,
+               uint32_t flags, uint32_t* d_ids, uint64_t ids_cap, uint64_t* d_out_off, hipStream_t s) {
+    if (((uintptr_t)d_utf8 & 15) != 0) return fail(SPL_EINVAL, "text buffer must be 16-byte aligned");
+    const bool special = (flags & SPL_WITH_SPECIAL) && !t->specials.empty();
+    if (special) { int rc0 = upload_specials(t); if (rc0) return rc0; }
+    if (n_bytes > 0x7FFF0000ull) return fail(SPL_EINVAL, "n_bytes per device call must be < 2^31 - 65536");
+    if (n_docs > 0xFFFFFFF0ull) return fail(SPL_EINVAL, "n_docs per device call must be < 2^32 - 16");
+    int rc = reserve(t, n_bytes, n_docs);
+    if (rc) return rc;
+    if (t->prof && !t->ev_ready) {
+        for (auto& e : t->ev) HIP_TRY(hipEventCreate(&e));
+        t->ev_ready = true;
+    }
+    Batch b{};
+    b.text = d_utf8; b.n_bytes = (uint32_t)n_bytes; b.doc_off = d_doc_off; b.n_docs = (uint32_t)n_docs;
+    b.tbits = t->d_zero; b.tstart = t->d_zero + t->bitmap_words; b.qcount = t->d_zero + 3 * t->bitmap_words;
+    b.skip = special ? t->d_zero + 2 * t->bitmap_words : nullptr;
+    b.sp_lits = t->d_sp_lits; b.n_special = special ? (uint32_t)t->specials.size() : 0u;
+    b.stage = t->d_stage; b.rank_scr = t->d_rank;
+    b.q16 = t->d_q16; b.q64 = t->d_q64; b.qlong = t->d_qlong; b.qdefer = t->d_qdefer;
+    b.qcap16 = t->qcap16; b.qcap64 = t->qcap64; b.qcaplong = t->qcaplong; b.qcapdefer = t->qcapdefer;
+    b.blk_base = t->d_blk; b.n_blk = (uint32_t)(n_bytes / RANK_BLK + 1);
+    b.ids_out = d_ids; b.ids_cap = ids_cap; b.off_out = d_out_off;
+
+    // only the words this batch touches need clearing
+    const size_t used_words = (size_t)b.n_blk * 32 + 32;
+    HIP_TRY(hipMemsetAsync(b.tbits, 0, used_words * 4, s));
+    HIP_TRY(hipMemsetAsync(b.tstart, 0, used_words * 4, s));
+    if (special) HIP_TRY(hipMemsetAsync(b.skip, 0, used_words * 4, s));
+    HIP_TRY(hipMemsetAsync(b.qcount, 0, 32, s));
+
+    const bool pf = t->prof;
+#define MARK(i) do { if (pf) HIP_TRY(hipEventRecord(t->ev[i], s)); } while (0)
+    const uint32_t ntiles = (uint32_t)((n_bytes + TB - 1) / TB);
+    MARK(KI_MARK);
+    if (n_docs) hipLaunchKernelGGL(k_mark_docs, dim3((uint32_t)((n_docs + 255) / 256)), dim3(256), 0, s, b);
+    MARK(KI_SPECIAL);
+    if (special && n_bytes) {
+        hipLaunchKernelGGL(k_special_scan, dim3((uint32_t)((n_bytes + 255) / 256)), dim3(256), 0, s, b);
+        hipLaunchKernelGGL(k_special_ends, dim3((uint32_t)((n_bytes + 255) / 256)), dim3(256), 0, s, b);
+    }
+    MARK(KI_PRETOK);
+    if (ntiles) hipLaunchKernelGGL(k_pretok, dim3(ntiles), dim3(NT), 0, s, t->dt, b);
+    MARK(KI_DEFER);
+    if (ntiles) hipLaunchKernelGGL(k_deferred, dim3(64), dim3(64), 0, s, t->dt, b);
+    MARK(KI_BPE16);
+    if (ntiles) hipLaunchKernelGGL((k_bpe_lanes<16, 256>), dim3(std::min<uint32_t>(1024, ntiles * 2 + 8)), dim3(256), 0, s, t->dt, b, 0);
+    MARK(KI_BPE64);
+    if (ntiles) hipLaunchKernelGGL((k_bpe_lanes<64, 64>), dim3(std::min<uint32_t>(2048, ntiles * 4 + 8)), dim3(64), 0, s, t->dt, b, 1);
+    MARK(KI_BPELONG);
+    if (ntiles) hipLaunchKernelGGL(k_bpe_block, dim3(std::min<uint32_t>(512, ntiles + 8)), dim3(NT), 0, s, t->dt, b);
+    MARK(KI_COUNT);
+    hipLaunchKernelGGL(k_count, dim3((b.n_blk + 255) / 256), dim3(256), 0, s, b);
+    MARK(KI_SCAN);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, b);
+    MARK(KI_COMPACT);
+    hipLaunchKernelGGL(k_compact, dim3((b.n_blk * 32 + NT - 1) / NT), dim3(NT), 0, s, b);
+    MARK(KI_DOCOFF);
+    hipLaunchKernelGGL(k_doc_offsets, dim3((uint32_t)((n_docs + 1 + 255) / 256)), dim3(256), 0, s, b);
+    MARK(KI_N);
+#undef MARK
+    HIP_TRY(hipGetLastError());
+    if (pf) {
+        HIP_TRY(hipEventSynchronize(t->ev[KI_N]));
+        for (int i = 0; i < KI_N; i++) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, t->ev[i], t->ev[i + 1]));
+            t->prof_ms[i] += ms;
+            t->prof_n[i] += 1;
+        }
+    }
+    return SPL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* spl_last_error(void) { return g_err.c_str(); }
+
+int spl_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+spl_tokenizer* spl_create(const void* vocab_splv, size_t vocab_len, const void* uclass_tab, size_t uclass_len,
+                          const spl_opts* opts) {
+    if (!vocab_splv || !uclass_tab || !opts) { fail(SPL_EINVAL, "spl_create: null argument"); return nullptr; }
+    spl_tokenizer* t = new spl_tokenizer();
+    std::string err;
+    if (build_tables((const uint8_t*)vocab_splv, vocab_len, (const uint8_t*)uclass_tab, uclass_len, opts->pattern, t->ht, err)) {
+        fail(SPL_EINVAL, "spl_create: " + err);
+        delete t;
+        return nullptr;
+    }
+    t->device = opts->device;
+    auto up = [&]() -> int {
+        HIP_TRY(hipSetDevice(t->device));
+        int rc;
+        if ((rc = dev_upload(t->ht.ucls_stage1, &t->dt.ucls_stage1))) return rc;
+        if ((rc = dev_upload(t->ht.ucls_stage2, &t->dt.ucls_stage2))) return rc;
+        if ((rc = dev_upload(t->ht.short_tab, &t->dt.short_tab))) return rc;
+        if ((rc = dev_upload(t->ht.long_tab, &t->dt.long_tab))) return rc;
+        if ((rc = dev_upload(t->ht.key_blob, &t->dt.key_blob))) return rc;
+        if ((rc = dev_upload(t->ht.pair_tab, &t->dt.pair_tab))) return rc;
+        if ((rc = dev_upload(t->ht.byte_id, &t->dt.byte_id))) return rc;
+        if ((rc = dev_upload(t->ht.tok_off, &t->d_tok_off))) return rc;
+        if ((rc = dev_upload(t->ht.tok_bytes, &t->d_tok_bytes))) return rc;
+        return SPL_OK;
+    };
+    if (up() != SPL_OK) { delete t; return nullptr; }
+    t->dt.ucls_shift = t->ht.ucls_shift;
+    t->dt.cjk_fast = t->ht.cjk_fast ? 1u : 0u;
+    t->dt.short_mask = (uint32_t)t->ht.short_tab.size() - 1;
+    t->dt.long_mask = (uint32_t)t->ht.long_tab.size() - 1;
+    t->dt.pair_mask = (uint32_t)t->ht.pair_tab.size() - 1;
+    t->dt.max_key_len = t->ht.max_key_len;
+    t->dt.pattern = (uint32_t)t->ht.pattern;
+    t->dt.all_bytes = t->ht.all_bytes ? 1u : 0u;
+    return t;
+}
+
+int spl_add_special(spl_tokenizer* t, const uint8_t* literal, size_t len, uint32_t id) {
+    if (!t || !literal || len == 0) return fail(SPL_EINVAL, "spl_add_special: bad argument");
+    if (len > (size_t)SP_MAXLEN) return fail(SPL_EINVAL, "spl_add_special: literal longer than 32 bytes");
+    const std::string lit((const char*)literal, len);
+    // The device scan treats every occurrence as a match, which equals Aho-Corasick's
+    // non-overlapping Standard semantics only if no two occurrences can ever overlap.
+    auto overlaps = [](const std::string& a, const std::string& b) {
+        if (a.find(b) != std::string::npos || b.find(a) != std::string::npos) return true;
+        for (size_t k = 1; k < a.size() && k < b.size(); k++) {
+            if (a.compare(a.size() - k, k, b, 0, k) == 0) return true;   // suffix of a == prefix of b
+            if (b.compare(b.size() - k, k, a, 0, k) == 0) return true;
+        }
+        return false;
+    };
+    for (size_t k = 1; k < lit.size(); k++)
+        if (lit.compare(lit.size() - k, k, lit, 0, k) == 0)
+            return fail(SPL_EINVAL, "spl_add_special: literal can overlap itself");
+    for (const auto& sp : t->specials)
+        if (overlaps(sp.lit, lit)) return fail(SPL_EINVAL, "spl_add_special: literal can overlap '" + sp.lit + "'");
+    t->specials.push_back(Special{lit, id});
+    t->sp_uploaded = false;
+    t->max_special_id = std::max(t->max_special_id, id);
+    return SPL_OK;
+}
+
+uint32_t spl_vocab_size(const spl_tokenizer* t) {
+    if (!t) return 0;
+    return std::max(t->ht.max_id, t->max_special_id) + 1;
+}
+
+void spl_destroy(spl_tokenizer* t) {
+    if (!t) return;
+    hipSetDevice(t->device);
+    hipDeviceSynchronize();
+    free_workspace(t);
+    hipFree((void*)t->dt.ucls_stage1); hipFree((void*)t->dt.ucls_stage2); hipFree((void*)t->dt.short_tab);
+    hipFree((void*)t->dt.long_tab); hipFree((void*)t->dt.key_blob); hipFree((void*)t->dt.pair_tab);
+    hipFree((void*)t->dt.byte_id); hipFree((void*)t->d_tok_off); hipFree((void*)t->d_tok_bytes);
+    hipFree(t->d_in_text); hipFree(t->d_in_off); hipFree(t->d_out_ids); hipFree(t->d_out_off); hipFree(t->d_sp_lits);
+    if (t->ev_ready) for (auto& e : t->ev) hipEventDestroy(e);
+    delete t;
+}
+
+int spl_reserve(spl_tokenizer* t, uint64_t max_bytes, uint64_t max_docs) {
+    if (!t) return fail(SPL_EINVAL, "spl_reserve: null handle");
+    return reserve(t, max_bytes, max_docs);
+}
+
+int spl_encode_batch_device(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
+                            uint64_t n_docs, uint32_t flags, uint32_t* d_ids, uint64_t ids_capacity,
+                            uint64_t* d_out_off, void* hip_stream) {
+    if (!t || !d_doc_off || !d_out_off || (n_bytes && (!d_utf8 || !d_ids)))
+        return fail(SPL_EINVAL, "spl_encode_batch_device: null argument");
+    HIP_TRY(hipSetDevice(t->device));
+    return launch_all(t, d_utf8, n_bytes, d_doc_off, n_docs, flags, d_ids, ids_capacity, d_out_off, (hipStream_t)hip_stream);
+}
+
+int spl_encode_batch(spl_tokenizer* t, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,
+                     spl_result** out) {
+    if (!t || !doc_off || !out) return fail(SPL_EINVAL, "spl_encode_batch: null argument");
+    if (doc_off[0] != 0) return fail(SPL_EINVAL, "spl_encode_batch: doc_off[0] must be 0");
+    for (uint64_t d = 0; d < n_docs; d++)
+        if (doc_off[d + 1] < doc_off[d]) return fail(SPL_EINVAL, "spl_encode_batch: doc_off must be non-decreasing");
+    const uint64_t n_bytes = doc_off[n_docs];
+    if (n_bytes && !utf8) return fail(SPL_EINVAL, "spl_encode_batch: null text");
+    HIP_TRY(hipSetDevice(t->device));
+
+    spl_result* r = new spl_result();
+    r->off.assign(n_docs + 1, 0);
+    // a device call takes < 2^31 bytes: walk the documents in slabs of about 1 GiB
+    const uint64_t SLAB = 1ull << 30;
+    uint64_t d0 = 0;
+    while (d0 < n_docs) {
+        uint64_t d1 = d0;
+        while (d1 < n_docs && (d1 == d0 || doc_off[d1 + 1] - doc_off[d0] <= SLAB)) d1++;
+        const uint64_t nb = doc_off[d1] - doc_off[d0], nd = d1 - d0;
+        if (nb > 0x7FFF0000ull) { delete r; return fail(SPL_EINVAL, "spl_encode_batch: a single document exceeds 2^31 bytes"); }
+        if (nb > t->in_cap_bytes || nd > t->in_cap_docs || !t->d_in_off) {
+            HIP_TRY(hipDeviceSynchronize());
+            hipFree(t->d_in_text); hipFree(t->d_in_off); hipFree(t->d_out_ids); hipFree(t->d_out_off);
+            t->in_cap_bytes = std::max<uint64_t>(nb, t->in_cap_bytes);
+            t->in_cap_docs = std::max<uint64_t>(nd, t->in_cap_docs);
+            HIP_TRY(hipMalloc((void**)&t->d_in_text, t->in_cap_bytes + 64));
+            HIP_TRY(hipMalloc((void**)&t->d_in_off, (t->in_cap_docs + 1) * 8));
+            HIP_TRY(hipMalloc((void**)&t->d_out_ids, (t->in_cap_bytes + 16) * 4));
+            HIP_TRY(hipMalloc((void**)&t->d_out_off, (t->in_cap_docs + 1) * 8));
+        }
+        std::vector<uint64_t> rel(nd + 1);
+        for (uint64_t k = 0; k <= nd; k++) rel[k] = doc_off[d0 + k] - doc_off[d0];
+        if (nb) HIP_TRY(hipMemcpyAsync(t->d_in_text, utf8 + doc_off[d0], nb, hipMemcpyHostToDevice, 0));
+        HIP_TRY(hipMemcpyAsync(t->d_in_off, rel.data(), (nd + 1) * 8, hipMemcpyHostToDevice, 0));
+        int rc = launch_all(t, t->d_in_text, nb, t->d_in_off, nd, flags, t->d_out_ids, nb, t->d_out_off, 0);
+        if (rc) { delete r; return rc; }
+        std::vector<uint64_t> oo(nd + 1);
+        HIP_TRY(hipMemcpy(oo.data(), t->d_out_off, (nd + 1) * 8, hipMemcpyDeviceToHost));
+        const uint64_t total = oo[nd], base = r->ids.size();
+        r->ids.resize(base + total);
+        if (total) HIP_TRY(hipMemcpy(r->ids.data() + base, t->d_out_ids, total * 4, hipMemcpyDeviceToHost));
+        for (uint64_t k = 0; k <= nd; k++) r->off[d0 + k] = base + oo[k];
+        d0 = d1;
+    }
+    *out = r;
+    return SPL_OK;
+}
+
+const uint32_t* spl_result_tokens(const spl_result* r) { return r ? r->ids.data() : nullptr; }
+const uint64_t* spl_result_offsets(const spl_result* r) { return r ? r->off.data() : nullptr; }
+uint64_t spl_result_n_tokens(const spl_result* r) { return r ? r->ids.size() : 0; }
+uint64_t spl_result_n_docs(const spl_result* r) { return r ? r->off.size() - 1 : 0; }
+void spl_result_free(spl_result* r) { delete r; }
+
+int spl_decode_batch(spl_tokenizer* t, const uint32_t* ids, const uint64_t* ids_off, uint64_t n_docs, uint8_t** out_bytes,
+                     uint64_t** out_off) {
+    if (!t || !ids_off || !out_bytes || !out_off) return fail(SPL_EINVAL, "spl_decode_batch: null argument");
+    HIP_TRY(hipSetDevice(t->device));
+    const uint64_t n = ids_off[n_docs] - ids_off[0];
+    const uint32_t* src = ids + ids_off[0];
+    // special ids decode to their literal on the host side (few); vocabulary ids gather on the GPU
+    uint32_t* d_ids = nullptr; uint64_t* d_len = nullptr; uint8_t* d_out = nullptr;
+    std::vector<uint64_t> len(n + 1, 0);
+    if (n) {
+        HIP_TRY(hipMalloc((void**)&d_ids, n * 4));
+        HIP_TRY(hipMalloc((void**)&d_len, n * 8));
+        HIP_TRY(hipMemcpy(d_ids, src, n * 4, hipMemcpyHostToDevice));
+        DecodeArgs a{d_ids, n, t->d_tok_off, t->d_tok_bytes, t->ht.max_id, d_len, nullptr};
+        hipLaunchKernelGGL(k_decode_len, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, a);
+        HIP_TRY(hipMemcpy(len.data(), d_len, n * 8, hipMemcpyDeviceToHost));
+    }
+    // splice special literals: they are not in the device table (id > max_id or unmapped)
+    std::vector<const std::string*> sp_of(n, nullptr);
+    for (uint64_t i = 0; i < n; i++) {
+        const bool in_vocab = src[i] <= t->ht.max_id && t->ht.tok_off[src[i] + 1] > t->ht.tok_off[src[i]];
+        if (!in_vocab)
+            for (const auto& s : t->specials)
+                if (s.id == src[i]) { sp_of[i] = &s.lit; len[i] = s.lit.size(); break; }
+    }
+    uint64_t acc = 0;
+    for (uint64_t i = 0; i < n; i++) { const uint64_t l = len[i]; len[i] = acc; acc += l; }
+    len[n] = acc;
+    uint8_t* ob = (uint8_t*)malloc(acc ? acc : 1);
+    uint64_t* oo = (uint64_t*)malloc((n_docs + 1) * 8);
+    if (n) {
+        HIP_TRY(hipMalloc((void**)&d_out, acc ? acc : 16));
+        HIP_TRY(hipMemcpy(d_len, len.data(), n * 8, hipMemcpyHostToDevice));
+        DecodeArgs a{d_ids, n, t->d_tok_off, t->d_tok_bytes, t->ht.max_id, d_len, d_out};
+        hipLaunchKernelGGL(k_decode_copy, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, a);
+        if (acc) HIP_TRY(hipMemcpy(ob, d_out, acc, hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < n; i++)
+            if (sp_of[i]) memcpy(ob + len[i], sp_of[i]->data(), sp_of[i]->size());
+        hipFree(d_ids); hipFree(d_len); hipFree(d_out);
+    }
+    for (uint64_t d = 0; d <= n_docs; d++) oo[d] = len[ids_off[d] - ids_off[0]];
+    *out_bytes = ob;
+    *out_off = oo;
+    return SPL_OK;
+}
+
+void spl_free(void* p) { free(p); }
+
+int spl_profile_enable(spl_tokenizer* t, int on) {
+    if (!t) return fail(SPL_EINVAL, "null handle");
+    t->prof = on != 0;
+    return SPL_OK;
+}
+int spl_profile_reset(spl_tokenizer* t) {
+    if (!t) return fail(SPL_EINVAL, "null handle");
+    memset(t->prof_ms, 0, sizeof t->prof_ms);
+    memset(t->prof_n, 0, sizeof t->prof_n);
+    return SPL_OK;
+}
+int spl_profile_read(spl_tokenizer* t, double ms_out[SPL_MAX_KERNELS], uint64_t launches_out[SPL_MAX_KERNELS]) {
+    if (!t) return fail(SPL_EINVAL, "null handle");
+    memcpy(ms_out, t->prof_ms, sizeof t->prof_ms);
+    memcpy(launches_out, t->prof_n, sizeof t->prof_n);
+    return SPL_OK;
+}
+const char* spl_kernel_name(int index) { return (index >= 0 && index < KI_N) ? k_names[index] : nullptr; }
+
+int spl_last_queue_counts(spl_tokenizer* t, uint32_t counts_out[4]) {
+    if (!t || !t->d_zero) return fail(SPL_EINVAL, "no batch has run");
+    HIP_TRY(hipSetDevice(t->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(counts_out, t->d_zero + 3 * t->bitmap_words, 16, hipMemcpyDeviceToHost));
+    return SPL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,591 @@
+// spl_kernels.hip -- gfx950 kernels of the batch encode path.
+//
+//   k_mark_docs     text-start bitmap from the document offsets
+//   k_pretok        per 4 KiB tile: stage text in LDS, classify code points, find context-free
+//                   sync points, run the split scanner from each of them (spl_scan.h), enumerate
+//                   the chunks, whole-chunk vocabulary probe (spl_lookup.h); misses go to queues
+//                   (reference: Tokenizer::encode, src/core/tokenizer.rs:729-808 + :703-705)
+//   k_deferred      segments that outgrew a tile window: same scanner over global memory
+//   k_bpe_lanes<N>  byte_pair_encode (src/core/bpe.rs:67-197), one lane per chunk, nodes in LDS
+//   k_bpe_block     the same for long chunks, one workgroup per chunk, nodes in HBM scratch
+//   k_count / k_scan / k_compact / k_doc_offsets
+//                   token-start bitmap -> ranks -> dense ids[] and per-document offsets (CSR)
+//
+// Token bookkeeping: a token is identified by the byte position where it starts.  Producers set a
+// bit in `tbits` and store the id at `stage[pos]`; the final order is the bitmap order, so
+// ranks are popcount prefix sums and no kernel needs to know how many tokens another produced.
+#include <hip/hip_runtime.h>
+
+#include "spl_common.h"
+#include "spl_lookup.h"
+#include "spl_scan.h"
+
+namespace spl {
+
+constexpr int TB = 4096;                 // tile bytes owned by one workgroup
+constexpr int LH = 32;                   // left halo (previous character's class)
+constexpr int RH = 480;                  // right halo (chains may run past the tile)
+constexpr int W = LH + TB + RH;          // 4608 staged bytes
+constexpr int WPAD = 16;                 // real bytes staged past W (straddling chars, load32)
+constexpr int NT = 256;
+constexpr int NWORDS = W / 32 + 1;       // bitmap words incl. the bit for position W
+constexpr int RANK_BLK = 1024;           // positions per rank block (32 bitmap words)
+
+struct Batch {
+    const uint8_t* text;
+    uint32_t n_bytes;
+    const uint64_t* doc_off;
+    uint32_t n_docs;
+    uint32_t* tstart;      // bitmap: a text starts at this byte
+    uint32_t* skip;        // bitmap: byte belongs to a special-token literal (nullptr: none)
+    const uint8_t* sp_lits; // special literals: n_special records of SP_REC bytes
+    uint32_t n_special;
+    uint32_t* tbits;       // bitmap: a token starts at this byte
+    uint32_t* stage;       // id of the token starting at this byte
+    uint32_t* rank_scr;    // per-byte scratch for k_bpe_block
+    uint32_t* qcount;      // [0] q16 [1] q64 [2] qlong [3] qdefer
+    uint2* q16; uint2* q64; uint2* qlong; uint32_t* qdefer;
+    uint32_t qcap16, qcap64, qcaplong, qcapdefer;
+    uint32_t* blk_base;    // exclusive token count per RANK_BLK block (+1 entry: total)
+    uint32_t n_blk;
+    uint32_t* ids_out; uint64_t ids_cap; uint64_t* off_out;
+};
+
+// ------------------------------------------------------------------------------------------
+__global__ void k_mark_docs(Batch b) {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= b.n_docs) return;
+    const uint64_t p = b.doc_off[d];
+    if (p < b.n_bytes) atomicOr(&b.tstart[p >> 5], 1u << (p & 31));
+}
+
+// Special-token literals (reference src/core/tokenizer.rs:842-874: Aho-Corasick, Standard match
+// kind, non-overlapping find_iter).  spl_add_special only admits literal sets in which no
+// occurrence can overlap another (no literal contains another, no proper suffix of one is a
+// prefix of another), so every occurrence is a match and positions are independent: one lane per
+// byte compares the literals that start with that byte.  A match inside one text
+//   * becomes a token at its first byte (id = the literal's id),
+//   * is masked out of the text (skip bits; its first byte reads as end-of-text from the left),
+//   * makes the byte after it a text start.
+// Record layout (SP_REC = 40 bytes): u8 len | u8[3] pad | u32 id | u8 bytes[32].
+constexpr int SP_REC = 40;
+constexpr int SP_MAXLEN = 32;
+__global__ void k_special_scan(Batch b) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= b.n_bytes) return;
+    const uint32_t c0 = b.text[p];
+    for (uint32_t k = 0; k < b.n_special; k++) {
+        const uint8_t* rec = b.sp_lits + (size_t)k * SP_REC;
+        if (rec[8] != c0) continue;
+        const uint32_t len = rec[0];
+        if (p + len > b.n_bytes) continue;
+        bool ok = true;
+        for (uint32_t i = 1; i < len && ok; i++) ok = b.text[p + i] == rec[8 + i];
+        // the occurrence must lie inside one document
+        for (uint32_t i = 1; i < len && ok; i++) ok = !((b.tstart[(p + i) >> 5] >> ((p + i) & 31)) & 1u);
+        if (!ok) continue;
+        uint32_t id;
+        memcpy(&id, rec + 4, 4);
+        b.stage[p] = id;
+        atomicOr(&b.tbits[p >> 5], 1u << (p & 31));
+        for (uint32_t i = 0; i < len; i++) atomicOr(&b.skip[(p + i) >> 5], 1u << ((p + i) & 31));
+        return;
+    }
+}
+// second pass (after every skip bit is in place): the byte after a literal starts a text
+__global__ void k_special_ends(Batch b) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p == 0 || p >= b.n_bytes) return;
+    const bool prev_skip = (b.skip[(p - 1) >> 5] >> ((p - 1) & 31)) & 1u;
+    const bool this_skip = (b.skip[p >> 5] >> (p & 31)) & 1u;
+    if (prev_skip && !this_skip) atomicOr(&b.tstart[p >> 5], 1u << (p & 31));
+}
+
+// ------------------------------------------------------------------------------------------
+struct LdsAcc {
+    const uint8_t* rec_;
+    const uint8_t* txt_;
+    __device__ __forceinline__ uint32_t rec(int q) const { return rec_[q]; }
+    __device__ __forceinline__ uint32_t txt(int q) const { return txt_[q]; }
+    __device__ __forceinline__ uint32_t load32(int p) const {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(txt_) + (p >> 2);
+        return __builtin_amdgcn_alignbyte(w[1], w[0], p & 3);
+    }
+};
+
+__device__ __forceinline__ void push2(uint32_t* cnt, uint2* q, uint32_t cap, uint32_t pos, uint32_t len) {
+    const uint32_t i = atomicAdd(cnt, 1u);
+    if (i < cap) q[i] = make_uint2(pos, len);
+}
+
+__device__ __forceinline__ void route_miss(const Batch& b, uint32_t pos, uint32_t n) {
+    if (n <= 16) push2(&b.qcount[0], b.q16, b.qcap16, pos, n);
+    else if (n <= 64) push2(&b.qcount[1], b.q64, b.qcap64, pos, n);
+    else push2(&b.qcount[2], b.qlong, b.qcaplong, pos, n);
+}
+
+__global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_txt[W + WPAD];
+    __shared__ __attribute__((aligned(16))) uint8_t s_rec[W + WPAD];
+    __shared__ uint32_t s_cbits[NWORDS + 1];
+    __shared__ uint32_t s_tbits[NWORDS + 1];
+    __shared__ uint16_t s_cpos[W + 2];
+    __shared__ uint8_t s_ascii[128];
+    __shared__ uint32_t s_wsum[NT / 64];
+    __shared__ uint32_t s_total;
+
+    const int tid = threadIdx.x;
+    const int64_t t0 = (int64_t)blockIdx.x * TB;
+    const int64_t w0 = t0 - LH;                       // global position of window index 0
+    const int64_t B = b.n_bytes;
+
+    // ---- stage text (coalesced 16 B per lane) -------------------------------------------
+    for (int v = tid; v < (W + WPAD) / 16; v += NT) {
+        const int64_t g = w0 + (int64_t)v * 16;
+        uint4 x = make_uint4(0, 0, 0, 0);
+        if (g >= 0 && g + 16 <= B) x = *reinterpret_cast<const uint4*>(b.text + g);
+        else if (g >= 0 && g < B) {
+            uint8_t tmp[16];
+            for (int k = 0; k < 16; k++) tmp[k] = (g + k < B) ? b.text[g + k] : 0;
+            x = *reinterpret_cast<uint4*>(tmp);
+        }
+        *reinterpret_cast<uint4*>(s_txt + v * 16) = x;
+    }
+    if (tid < 128) s_ascii[tid] = T.ucls_stage2[((uint32_t)T.ucls_stage1[0] << T.ucls_shift) + tid];
+    for (int v = tid; v < NWORDS + 1; v += NT) { s_cbits[v] = 0; s_tbits[v] = 0; }
+    __syncthreads();
+
+    // ---- classify: one record per byte -------------------------------------------------------
+    const int iB = (B - w0 < (int64_t)W) ? (int)(B - w0) : W;    // first index past the text
+    const int iT = (B - w0 < (int64_t)(W + WPAD)) ? (int)(B - w0) : W + WPAD;   // staged text end
+    for (int v = tid; v < (W + WPAD) / 16; v += NT) {
+        const int i0 = v * 16;
+        const int64_t g0 = w0 + i0;
+        uint32_t ts_bits = 0, sk_bits = 0;
+        if (g0 >= 0 && g0 < B) {
+            ts_bits = (b.tstart[g0 >> 5] >> (g0 & 31)) & 0xFFFFu;
+            if (b.skip) sk_bits = (b.skip[g0 >> 5] >> (g0 & 31)) & 0xFFFFu;
+        }
+        uint8_t rec[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int i = i0 + k;
+            uint32_t r;
+            if (i >= iB) {
+                r = (i == iB && iB < W) ? (uint32_t)(C_EOT | CB_TSTART | CB_SYNC) : (uint32_t)C_WEND;
+            } else if (w0 + i < 0) {
+                r = C_CONT;
+            } else if ((sk_bits >> k) & 1u) {
+                r = C_EOT | CB_TSTART;                 // inside a special literal: no text here
+            } else {
+                const uint32_t c0 = s_txt[i];
+                if (c0 < 0x80u) r = s_ascii[c0];
+                else if (c0 < 0xC0u) r = C_CONT;
+                else {
+                    // clamp the length to the continuation bytes actually present
+                    uint32_t want = utf8_len(c0), len = 1;
+                    while (len < want && i + (int)len < iT && (s_txt[i + len] & 0xC0u) == 0x80u) len++;
+                    LdsAcc tx{s_rec, s_txt};
+                    const uint32_t cls = (len == want) ? cp_class(T, decode_at(tx, i, c0)) : (uint32_t)C_P;
+                    r = cls | ((len - 1) << CB_LEN_SHIFT);
+                }
+                if ((ts_bits >> k) & 1u) r |= CB_TSTART | CB_SYNC;
+            }
+            rec[k] = (uint8_t)r;
+        }
+        *reinterpret_cast<uint4*>(s_rec + i0) = *reinterpret_cast<uint4*>(rec);
+    }
+    __syncthreads();
+
+    // ---- sync flags: (class of previous char, class here) --------------------------------------
+    // Only positions a chain can start from or stop at need the flag: the tile and its right halo.
+    for (int v = tid; v < (W - LH) / 16; v += NT) {
+        const int i0 = LH + v * 16;
+        uint4 rv = *reinterpret_cast<uint4*>(s_rec + i0);
+        uint8_t* r = reinterpret_cast<uint8_t*>(&rv);
+        bool changed = false;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint32_t rr = r[k];
+            const uint32_t cur = rr & CB_CLASS;
+            if (cur >= C_EOT || (rr & CB_SYNC)) continue;       // CONT / sentinels / already set
+            int j = i0 + k - 1;
+            while ((s_rec[j] & CB_CLASS) == C_CONT && j > i0 + k - 4) j--;
+            const uint32_t prev = s_rec[j] & CB_CLASS;
+            if (prev < C_EOT && is_sync((int)T.pattern, prev, cur)) { r[k] = (uint8_t)(rr | CB_SYNC); changed = true; }
+        }
+        if (changed) *reinterpret_cast<uint4*>(s_rec + i0) = rv;
+    }
+    __syncthreads();
+
+    // ---- chains: each sync point inside the tile scans to the next sync point -------------------
+    {
+        LdsAcc acc{s_rec, s_txt};
+        for (int v = tid; v < TB / 16; v += NT) {
+            const int i0 = LH + v * 16;
+            const uint4 rv = *reinterpret_cast<const uint4*>(s_rec + i0);
+            const uint8_t* r = reinterpret_cast<const uint8_t*>(&rv);
+            uint32_t m = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) m |= ((r[k] & CB_SYNC) && (r[k] & CB_CLASS) < C_EOT) ? (1u << k) : 0u;
+            while (m) {
+                const int k = __ffs(m) - 1;
+                m &= m - 1;
+                int p = i0 + k;
+                for (;;) {
+                    atomicOr(&s_cbits[p >> 5], 1u << (p & 31));
+                    const int e = match_end(acc, p, (int)T.pattern);
+                    if (e == SPL_DEFER) {                 // the match outgrows the window
+                        const uint32_t qi = atomicAdd(&b.qcount[3], 1u);
+                        if (qi < b.qcapdefer) b.qdefer[qi] = (uint32_t)(w0 + p);
+                        break;
+                    }
+                    p = e;
+                    if (p >= W) {                          // ended exactly on the window edge
+                        atomicOr(&s_cbits[W >> 5], 1u << (W & 31));
+                        if (w0 + W < B) {
+                            const uint32_t qi = atomicAdd(&b.qcount[3], 1u);
+                            if (qi < b.qcapdefer) b.qdefer[qi] = (uint32_t)(w0 + W);
+                        }
+                        break;
+                    }
+                    if (s_rec[p] & (CB_SYNC | CB_TSTART)) {  // next owner's start: terminator mark
+                        atomicOr(&s_cbits[p >> 5], 1u << (p & 31));
+                        break;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- enumerate marked positions ------------------------------------------------------------
+    {
+        uint32_t word = tid < NWORDS ? s_cbits[tid] : 0u;
+        uint32_t cnt = __popc(word);
+        // inclusive scan over 256 threads: wave scan + cross-wave sums
+        uint32_t x = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d);
+            if ((tid & 63) >= d) x += y;
+        }
+        if ((tid & 63) == 63) s_wsum[tid >> 6] = x;
+        __syncthreads();
+        uint32_t base = x - cnt;
+        for (int wv = 0; wv < (tid >> 6); wv++) base += s_wsum[wv];
+        if (tid == NT - 1) s_total = base + cnt;
+        while (word) {
+            const int bit = __ffs(word) - 1;
+            word &= word - 1;
+            s_cpos[base++] = (uint16_t)(tid * 32 + bit);
+        }
+    }
+    __syncthreads();
+
+    // ---- whole-chunk probe; the last marked position is only a terminator ------------------------
+    {
+        LdsAcc tx{s_rec, s_txt};
+        const int K = (int)s_total;
+        for (int k = tid; k + 1 < K; k += NT) {
+            const int p = s_cpos[k];
+            const int n = (int)s_cpos[k + 1] - p;
+            const uint32_t id = probe_chunk(T, tx, p, n);
+            if (id != SPL_NO_RANK) {
+                b.stage[w0 + p] = id;
+                atomicOr(&s_tbits[p >> 5], 1u << (p & 31));
+            } else if (n > 1) {
+                route_miss(b, (uint32_t)(w0 + p), (uint32_t)n);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < NWORDS) {
+        const uint32_t wv = s_tbits[tid];
+        if (wv) atomicOr(&b.tbits[(w0 >> 5) + tid], wv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Global-memory accessor: class records computed on the fly (slow path, rare).
+struct GlobalAcc {
+    const DeviceTables* T;
+    const Batch* b;
+    __device__ uint32_t txt(int64_t q) const { return q < (int64_t)b->n_bytes ? b->text[q] : 0u; }
+    __device__ uint32_t txt(int q) const { return txt((int64_t)(uint32_t)q); }
+    __device__ uint32_t load32(int p) const {
+        const int64_t q = (uint32_t)p;
+        return txt(q) | (txt(q + 1) << 8) | (txt(q + 2) << 16) | (txt(q + 3) << 24);
+    }
+    __device__ uint32_t rec(int qi) const {
+        const int64_t q = (uint32_t)qi;
+        const int64_t B = b->n_bytes;
+        if (q >= B) return C_EOT | CB_TSTART | CB_SYNC;
+        if (b->skip && ((b->skip[q >> 5] >> (q & 31)) & 1u)) return C_EOT | CB_TSTART;
+        const uint32_t c0 = b->text[q];
+        uint32_t r;
+        if (c0 < 0x80u) r = cp_class(*T, c0);
+        else if (c0 < 0xC0u) r = C_CONT;
+        else {
+            uint32_t want = utf8_len(c0), len = 1;
+            while (len < want && q + len < B && (b->text[q + len] & 0xC0u) == 0x80u) len++;
+            const uint32_t cls = (len == want) ? cp_class(*T, decode_at(*this, (int)q, c0)) : (uint32_t)C_P;
+            r = cls | ((len - 1) << CB_LEN_SHIFT);
+        }
+        if ((b->tstart[q >> 5] >> (q & 31)) & 1u) r |= CB_TSTART | CB_SYNC;
+        return r;
+    }
+};
+
+__device__ __forceinline__ void emit_token(const Batch& b, uint32_t pos, uint32_t id) {
+    b.stage[pos] = id;
+    atomicOr(&b.tbits[pos >> 5], 1u << (pos & 31));
+}
+
+// One lane per deferred segment: continue the chain from its start to the next sync point.
+__global__ void k_deferred(DeviceTables T, Batch b) {
+    const uint32_t nq = min(b.qcount[3], b.qcapdefer);
+    GlobalAcc acc{&T, &b};
+    for (uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; it < nq; it += gridDim.x * blockDim.x) {
+        uint32_t p = b.qdefer[it];
+        for (;;) {
+            if (p >= b.n_bytes) break;
+            const int e = match_end(acc, (int)p, (int)T.pattern);     // never defers: no window end
+            const uint32_t n = (uint32_t)e - p;
+            const uint32_t id = probe_chunk(T, acc, (int)p, (int)n);
+            if (id != SPL_NO_RANK) emit_token(b, p, id);
+            else if (n > 1) route_miss(b, p, n);
+            p = (uint32_t)e;
+            if (p >= b.n_bytes) break;
+            const uint32_t r = acc.rec((int)p);
+            if (r & (CB_SYNC | CB_TSTART)) break;
+            // sync test against the previous character's class
+            int64_t j = (int64_t)p - 1;
+            while (j > 0 && (b.text[j] & 0xC0u) == 0x80u && j > (int64_t)p - 4) j--;
+            const uint32_t prev = acc.rec((int)j) & CB_CLASS;
+            if (prev < C_EOT && is_sync((int)T.pattern, prev, r & CB_CLASS)) break;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// byte_pair_encode, one lane per chunk; node arrays interleaved in LDS (node-major, lane-minor).
+template <int NMAX, int THREADS> struct LaneStore {
+    uint32_t* ids;
+    uint32_t* rks;
+    int lane;
+    __device__ __forceinline__ uint32_t& id(int i) { return ids[i * THREADS + lane]; }
+    __device__ __forceinline__ uint32_t& rk(int i) { return rks[i * THREADS + lane]; }
+};
+struct GlobalText {
+    const uint8_t* text;
+    __device__ __forceinline__ uint32_t txt(int q) const { return text[(uint32_t)q]; }
+};
+
+template <int NMAX, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_bpe_lanes(DeviceTables T, Batch b, int which) {
+    __shared__ uint32_t s_ids[NMAX * THREADS];
+    __shared__ uint32_t s_rks[NMAX * THREADS];
+    const uint32_t nq = which == 0 ? min(b.qcount[0], b.qcap16) : min(b.qcount[1], b.qcap64);
+    const uint2* q = which == 0 ? b.q16 : b.q64;
+    LaneStore<NMAX, THREADS> st{s_ids, s_rks, (int)threadIdx.x};
+    GlobalText tx{b.text};
+    for (uint32_t it = blockIdx.x * THREADS + threadIdx.x; it < nq; it += gridDim.x * THREADS) {
+        const uint2 item = q[it];
+        const int n = (int)item.y;
+        bpe_serial(T, st, tx, (int)item.x, n);
+        for (int i = 0; i < n; i++) {
+            const uint32_t id = st.id(i);
+            if (id != SPL_DEAD && id != SPL_NO_RANK) emit_token(b, item.x + i, id);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Long chunks: one workgroup per chunk.  Node i of the chunk at [pos, pos+n) keeps its id in
+// stage[pos+i] (where the surviving ids have to end up anyway) and the rank of the pair
+// (i, next alive) in rank_scr[pos+i].  Each thread owns the nodes i == tid (mod NT) and caches
+// the minimum over them; per merge only the owners of the (at most three) touched nodes rescan.
+__global__ __launch_bounds__(NT) void k_bpe_block(DeviceTables T, Batch b) {
+    __shared__ unsigned long long s_red[NT / 64];
+    __shared__ unsigned long long s_best;
+    const uint32_t nq = min(b.qcount[2], b.qcaplong);
+    const int tid = threadIdx.x;
+    for (uint32_t it = blockIdx.x; it < nq; it += gridDim.x) {
+        const uint2 item = b.qlong[it];
+        const uint32_t pos = item.x;
+        const int n = (int)item.y;
+        uint32_t* ids = b.stage + pos;
+        uint32_t* rks = b.rank_scr + pos;
+        for (int i = tid; i < n; i += NT) ids[i] = T.byte_id[b.text[pos + i]];
+        __syncthreads();
+        for (int i = tid; i < n; i += NT) rks[i] = (i + 1 < n) ? pair_rank(T, ids[i], ids[i + 1]) : SPL_NO_RANK;
+        __syncthreads();
+        bool dirty = true;
+        unsigned long long mine = ~0ull;          // (rank << 32 | index): min == leftmost minimum
+        for (;;) {
+            if (dirty) {
+                mine = ~0ull;
+                for (int i = tid; i < n; i += NT) {
+                    const unsigned long long c = ((unsigned long long)rks[i] << 32) | (uint32_t)i;
+                    mine = c < mine ? c : mine;
+                }
+                dirty = false;
+            }
+            unsigned long long x = mine;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const unsigned long long y = __shfl_xor(x, d);
+                x = y < x ? y : x;
+            }
+            if ((tid & 63) == 0) s_red[tid >> 6] = x;
+            __syncthreads();
+            if (tid == 0) {
+                unsigned long long m = s_red[0];
+                for (int wv = 1; wv < NT / 64; wv++) m = s_red[wv] < m ? s_red[wv] : m;
+                s_best = m;
+            }
+            __syncthreads();
+            const unsigned long long best = s_best;
+            const uint32_t mn = (uint32_t)(best >> 32);
+            if (mn == SPL_NO_RANK) break;
+            const int mi = (int)(uint32_t)best;
+            // thread 0 performs the merge (the neighbour searches walk tomb-stones; at most a
+            // token's length of them)
+            __shared__ int s_touch[3];
+            if (tid == 0) {
+                int j = mi + 1;
+                while (ids[j] == SPL_DEAD) j++;
+                ids[mi] = mn;
+                ids[j] = SPL_DEAD;
+                rks[j] = SPL_NO_RANK;
+                int j2 = j + 1;
+                while (j2 < n && ids[j2] == SPL_DEAD) j2++;
+                rks[mi] = j2 < n ? pair_rank(T, mn, ids[j2]) : SPL_NO_RANK;
+                int h = mi - 1;
+                while (h >= 0 && ids[h] == SPL_DEAD) h--;
+                if (h >= 0) rks[h] = pair_rank(T, ids[h], mn);
+                s_touch[0] = mi; s_touch[1] = j; s_touch[2] = h;
+                __threadfence_block();
+            }
+            __syncthreads();
+            const int a0 = s_touch[0] % NT, a1 = s_touch[1] % NT, a2 = s_touch[2] < 0 ? -1 : s_touch[2] % NT;
+            if (tid == a0 || tid == a1 || tid == a2) dirty = true;
+            __syncthreads();
+        }
+        // survivors become tokens (ids already sit in stage[]); only the bitmap is left to set
+        for (int i = tid; i < n; i += NT) {
+            const uint32_t id = ids[i];
+            if (id != SPL_DEAD && id != SPL_NO_RANK) atomicOr(&b.tbits[(pos + i) >> 5], 1u << ((pos + i) & 31));
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Rank structure over the token-start bitmap.
+__global__ void k_count(Batch b) {
+    const uint32_t blk = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blk >= b.n_blk) return;
+    const uint4* w = reinterpret_cast<const uint4*>(b.tbits + (size_t)blk * 32);
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint4 v = w[k];
+        c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    }
+    b.blk_base[blk] = c;
+}
+
+// single workgroup, in-place exclusive scan of blk_base[0..n_blk) ; blk_base[n_blk] = total
+__global__ __launch_bounds__(1024) void k_scan(Batch b) {
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < b.n_blk; base += 1024) {
+        const uint32_t i = base + tid;
+        const uint32_t v = i < b.n_blk ? b.blk_base[i] : 0u;
+        uint32_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d);
+            if ((tid & 63) >= d) x += y;
+        }
+        if ((tid & 63) == 63) s_w[tid >> 6] = x;
+        __syncthreads();
+        uint32_t pre = s_carry;
+        for (int wv = 0; wv < (tid >> 6); wv++) pre += s_w[wv];
+        if (i < b.n_blk) b.blk_base[i] = pre + x - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = pre + x;
+        __syncthreads();
+    }
+    if (tid == 0) b.blk_base[b.n_blk] = s_carry;
+}
+
+// one lane per bitmap word; the 32 words of a rank block sit in one half-wave
+__global__ __launch_bounds__(NT) void k_compact(Batch b) {
+    const uint32_t w = blockIdx.x * NT + threadIdx.x;          // word index
+    const uint32_t nwords = b.n_blk * 32;
+    uint32_t word = w < nwords ? b.tbits[w] : 0u;
+    const uint32_t cnt = __popc(word);
+    uint32_t x = cnt;
+    const int l32 = threadIdx.x & 31;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 32);
+        if (l32 >= d) x += y;
+    }
+    if (w >= nwords || !word) return;
+    uint64_t r = (uint64_t)b.blk_base[w >> 5] + (x - cnt);
+    const uint32_t p0 = w * 32;
+    while (word) {
+        const int bit = __ffs(word) - 1;
+        word &= word - 1;
+        if (r < b.ids_cap) b.ids_out[r] = b.stage[p0 + bit];
+        r++;
+    }
+}
+
+__global__ void k_doc_offsets(Batch b) {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d > b.n_docs) return;
+    if (d == b.n_docs) { b.off_out[d] = b.blk_base[b.n_blk]; return; }
+    const uint64_t p64 = b.doc_off[d];
+    if (p64 >= b.n_bytes) { b.off_out[d] = b.blk_base[b.n_blk]; return; }
+    const uint32_t p = (uint32_t)p64;
+    const uint32_t blk = p / RANK_BLK;
+    uint32_t r = b.blk_base[blk];
+    const uint32_t wfirst = blk * 32, wlast = p >> 5;
+    for (uint32_t w = wfirst; w < wlast; w++) r += __popc(b.tbits[w]);
+    r += __popc(b.tbits[wlast] & ((1u << (p & 31)) - 1u));
+    b.off_out[d] = r;
+}
+
+// ------------------------------------------------------------------------------------------
+// decode_bytes (reference src/core/tokenizer.rs:877-897): gather token byte strings.
+struct DecodeArgs {
+    const uint32_t* ids; uint64_t n_ids;
+    const uint32_t* tok_off; const uint8_t* tok_bytes; uint32_t max_id;
+    uint64_t* len_or_off;   // per id: length, then exclusive offsets
+    uint8_t* out;
+};
+__global__ void k_decode_len(DecodeArgs a) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_ids) return;
+    const uint32_t id = a.ids[i];
+    a.len_or_off[i] = id <= a.max_id ? (uint64_t)(a.tok_off[id + 1] - a.tok_off[id]) : 0ull;
+}
+__global__ void k_decode_copy(DecodeArgs a) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_ids) return;
+    const uint32_t id = a.ids[i];
+    if (id > a.max_id) return;
+    const uint32_t s = a.tok_off[id], e = a.tok_off[id + 1];
+    uint8_t* o = a.out + a.len_or_off[i];
+    for (uint32_t k = s; k < e; k++) o[k - s] = a.tok_bytes[k];
+}
+
+}  // namespace spl

@@ -1,0 +1,269 @@
+"""`Tokenizer`: the reference's Python surface over the HIP backend.
+
+Mirrors the PyO3 class `Tokenizer` of the reference (src/python/bindings.rs:57-446) method for
+method for the encode path: same names, argument meaning, return shapes and error behaviour.
+Every encode call goes through the C ABI (include/splintr_hip.h) into the gfx950 kernels; there
+is no CPU implementation in this package.
+"""
+from __future__ import annotations
+
+import ctypes
+import json
+import os
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _ffi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_DATA = os.path.join(_HERE, "data")
+
+# Verbatim pattern strings exported by the reference module (src/lib.rs:42-44,
+# src/core/tokenizer.rs:39, :42, :45).  The HIP backend implements exactly these two.
+CL100K_BASE_PATTERN = (
+    r"(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+"
+)
+O200K_BASE_PATTERN = (
+    r"[^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]*[\p{Ll}\p{Lm}\p{Lo}\p{M}]+(?i:'s|'t|'re|'ve|'m|'ll|'d)?"
+    r"|[^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]+[\p{Ll}\p{Lm}\p{Lo}\p{M}]*(?i:'s|'t|'re|'ve|'m|'ll|'d)?"
+    r"|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+"
+)
+LLAMA3_PATTERN = O200K_BASE_PATTERN
+_PATTERN_ID = {CL100K_BASE_PATTERN: 0, O200K_BASE_PATTERN: 1}
+
+# name -> (vocab container, pattern, special-token table key)      src/python/bindings.rs:101-129
+_PRETRAINED = {
+    "cl100k_base": ("cl100k_base.splv", CL100K_BASE_PATTERN, "cl100k_base"),
+    "o200k_base": ("o200k_base.splv", O200K_BASE_PATTERN, "o200k_base"),
+    "llama3": ("llama3.splv", LLAMA3_PATTERN, "llama3"),
+    "llama3.1": ("llama3.splv", LLAMA3_PATTERN, "llama3"),
+    "llama3.2": ("llama3.splv", LLAMA3_PATTERN, "llama3"),
+    "llama3.3": ("llama3.splv", LLAMA3_PATTERN, "llama3"),
+    "deepseek_v3": ("deepseek_v3.splv", LLAMA3_PATTERN, "deepseek_v3"),
+    "deepseek-v3": ("deepseek_v3.splv", LLAMA3_PATTERN, "deepseek_v3"),
+}
+
+
+def _read(path: str) -> bytes:
+    with open(path, "rb") as f:
+        return f.read()
+
+
+def _pack(texts: Sequence[str]):
+    """list[str] -> (uint8 buffer, uint64 offsets).  TypeError for anything that is not a
+    sequence of str (PyO3 refuses a bare str for Vec<String>; src/python/bindings.rs:337)."""
+    if isinstance(texts, (str, bytes)):
+        raise TypeError("Can't extract `str` to `Vec`")
+    parts = []
+    for t in texts:
+        if not isinstance(t, str):
+            raise TypeError(f"argument 'texts': '{type(t).__name__}' object cannot be converted to 'PyString'")
+        parts.append(t.encode("utf-8"))          # lone surrogates -> UnicodeEncodeError, as in PyO3
+    off = np.zeros(len(parts) + 1, dtype=np.uint64)
+    if parts:
+        np.cumsum([len(p) for p in parts], out=off[1:])
+    buf = b"".join(parts)
+    return buf, off
+
+
+class Tokenizer:
+    """Drop-in for `splintr.Tokenizer` on the encode path (MI355X backend)."""
+
+    def __init__(self, vocab_path: str, pattern: str, special_tokens: Optional[Dict[str, int]] = None, *,
+                 device: int = 0):
+        try:
+            blob = _read(vocab_path)
+        except OSError as e:                      # PyIOError in the reference (bindings.rs:80)
+            raise IOError(str(e)) from None
+        self._init_from_blob(blob, pattern, special_tokens or {}, device)
+
+    # ------------------------------------------------------------------ construction
+    def _init_from_blob(self, blob: bytes, pattern: str, special_tokens: Dict[str, int], device: int):
+        if pattern not in _PATTERN_ID:
+            raise ValueError("Regex compilation error: the HIP backend implements CL100K_BASE_PATTERN and "
+                             "O200K_BASE_PATTERN/LLAMA3_PATTERN only")
+        L = _ffi.lib()
+        ucls = _read(os.path.join(_DATA, "unicode_classes.bin"))
+        opts = _ffi.SplOpts(_PATTERN_ID[pattern], device)
+        self._h = L.spl_create(blob, len(blob), ucls, len(ucls), ctypes.byref(opts))
+        if not self._h:
+            raise ValueError(_ffi.last_error())
+        self._device = device
+        self._pattern = pattern
+        self._special = dict(special_tokens)
+        for lit, tid in self._special.items():
+            b = lit.encode("utf-8")
+            if L.spl_add_special(self._h, b, len(b), int(tid)) != 0:
+                raise ValueError(_ffi.last_error())
+
+    @classmethod
+    def _from_blob(cls, blob: bytes, pattern: str, special_tokens: Dict[str, int], device: int = 0) -> "Tokenizer":
+        self = cls.__new__(cls)
+        self._init_from_blob(blob, pattern, special_tokens, device)
+        return self
+
+    @staticmethod
+    def from_pretrained(name: str, device: int = 0) -> "Tokenizer":
+        """src/python/bindings.rs:101-166 (in-scope names: cl100k_base, o200k_base, llama3*,
+        deepseek_v3 / deepseek-v3)."""
+        if not isinstance(name, str):
+            raise TypeError("argument 'name': object cannot be converted to 'PyString'")
+        ent = _PRETRAINED.get(name)
+        if ent is None:
+            raise ValueError(
+                f"Unknown pretrained model: {name}. See from_pretrained docstring for supported models.")
+        fn, pattern, skey = ent
+        with open(os.path.join(_DATA, "special_tokens.json"), encoding="utf-8") as f:
+            special = json.load(f)[skey]
+        return Tokenizer._from_blob(_read(os.path.join(_DATA, fn)), pattern, special, device)
+
+    @staticmethod
+    def from_bytes(vocab_data: bytes, pattern: str, special_tokens: Optional[Dict[str, int]] = None,
+                   device: int = 0) -> "Tokenizer":
+        """src/python/bindings.rs:174-187.  `vocab_data` is this repo's SPLV container
+        (tools/pack_vocab.py); the tiktoken text format is a "next" row."""
+        return Tokenizer._from_blob(bytes(vocab_data), pattern, special_tokens or {}, device)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _ffi.lib().spl_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    # ------------------------------------------------------------------ encode path
+    def _encode_packed(self, buf: bytes, off: np.ndarray, flags: int):
+        """C-ABI call: packed UTF-8 + offsets in, CSR (ids uint32, offsets uint64) out."""
+        L = _ffi.lib()
+        res = ctypes.c_void_p()
+        nd = len(off) - 1
+        rc = L.spl_encode_batch(self._h, buf, off.ctypes.data, nd, flags, ctypes.byref(res))
+        if rc != 0:
+            raise RuntimeError(f"spl_encode_batch failed ({rc}): {_ffi.last_error()}")
+        try:
+            nt = L.spl_result_n_tokens(res)
+            ids = np.ctypeslib.as_array(L.spl_result_tokens(res), shape=(max(nt, 1),))[:nt].copy()
+            oo = np.ctypeslib.as_array(L.spl_result_offsets(res), shape=(nd + 1,)).copy()
+        finally:
+            L.spl_result_free(res)
+        return ids, oo
+
+    def encode_batch_csr(self, texts: Sequence[str], with_special: bool = False):
+        """Extension: the batch result as CSR numpy arrays (ids uint32[T], offsets uint64[N+1])
+        without materialising Python lists."""
+        buf, off = _pack(texts)
+        return self._encode_packed(buf, off, _ffi.SPL_WITH_SPECIAL if with_special else 0)
+
+    def _encode_one(self, text: str, flags: int) -> List[int]:
+        if not isinstance(text, str):
+            raise TypeError(f"argument 'text': '{type(text).__name__}' object cannot be converted to 'PyString'")
+        buf = text.encode("utf-8")
+        off = np.array([0, len(buf)], dtype=np.uint64)
+        ids, _ = self._encode_packed(buf, off, flags)
+        return ids.tolist()
+
+    def encode(self, text: str) -> List[int]:
+        """src/python/bindings.rs:254-256."""
+        return self._encode_one(text, 0)
+
+    def encode_rayon(self, text: str) -> List[int]:
+        """src/python/bindings.rs:273-275: same ids as encode (the GPU path is always
+        chunk-parallel inside a text)."""
+        return self._encode_one(text, _ffi.SPL_INTRA_DOC)
+
+    def encode_with_special(self, text: str) -> List[int]:
+        """src/python/bindings.rs:286-288."""
+        return self._encode_one(text, _ffi.SPL_WITH_SPECIAL)
+
+    def _batch(self, texts: Sequence[str], flags: int) -> List[List[int]]:
+        buf, off = _pack(texts)
+        ids, oo = self._encode_packed(buf, off, flags)
+        flat = ids.tolist()
+        o = oo.tolist()
+        return [flat[o[i]:o[i + 1]] for i in range(len(o) - 1)]
+
+    def encode_batch(self, texts: Sequence[str]) -> List[List[int]]:
+        """src/python/bindings.rs:337-339."""
+        return self._batch(texts, 0)
+
+    def encode_batch_with_special(self, texts: Sequence[str]) -> List[List[int]]:
+        """src/python/bindings.rs:348-350."""
+        return self._batch(texts, _ffi.SPL_WITH_SPECIAL)
+
+    # ------------------------------------------------------------------ decode (test helper / "next" row)
+    def decode_bytes(self, tokens: Sequence[int]) -> bytes:
+        """src/python/bindings.rs:313-315."""
+        return self._decode_batch_bytes([tokens])[0]
+
+    def _decode_batch_bytes(self, token_lists: Sequence[Sequence[int]]) -> List[bytes]:
+        L = _ffi.lib()
+        off = np.zeros(len(token_lists) + 1, dtype=np.uint64)
+        if len(token_lists):
+            np.cumsum([len(t) for t in token_lists], out=off[1:])
+        ids = np.fromiter((x for t in token_lists for x in t), dtype=np.uint32, count=int(off[-1]))
+        ob = ctypes.POINTER(ctypes.c_uint8)()
+        oo = ctypes.POINTER(ctypes.c_uint64)()
+        rc = L.spl_decode_batch(self._h, ids.ctypes.data, off.ctypes.data, len(token_lists), ctypes.byref(ob),
+                                ctypes.byref(oo))
+        if rc != 0:
+            raise RuntimeError(f"spl_decode_batch failed ({rc}): {_ffi.last_error()}")
+        try:
+            o = [oo[i] for i in range(len(token_lists) + 1)]
+            raw = ctypes.string_at(ob, o[-1]) if o[-1] else b""
+        finally:
+            L.spl_free(ob)
+            L.spl_free(oo)
+        return [raw[o[i]:o[i + 1]] for i in range(len(token_lists))]
+
+    def decode(self, tokens: Sequence[int]) -> str:
+        """src/python/bindings.rs:300-304 (ValueError on invalid UTF-8)."""
+        try:
+            return self.decode_bytes(tokens).decode("utf-8")
+        except UnicodeDecodeError:
+            raise ValueError("Decoding error: invalid UTF-8") from None
+
+    def decode_lossy(self, tokens: Sequence[int]) -> str:
+        return self.decode_bytes(tokens).decode("utf-8", "replace")
+
+    def decode_batch(self, token_lists: Sequence[Sequence[int]]) -> List[str]:
+        try:
+            return [b.decode("utf-8") for b in self._decode_batch_bytes(token_lists)]
+        except UnicodeDecodeError:
+            raise ValueError("Decoding error: invalid UTF-8") from None
+
+    def decode_batch_lossy(self, token_lists: Sequence[Sequence[int]]) -> List[str]:
+        return [b.decode("utf-8", "replace") for b in self._decode_batch_bytes(token_lists)]
+
+    # ------------------------------------------------------------------ cheap surface
+    @property
+    def vocab_size(self) -> int:
+        """src/python/bindings.rs:382-385 -> src/core/tokenizer.rs:964-972."""
+        return int(_ffi.lib().spl_vocab_size(self._h))
+
+    @property
+    def cache_len(self) -> int:
+        """The reference's LRU (src/core/tokenizer.rs:310) is a CPU optimisation that does not
+        change results; the GPU path keeps no cache."""
+        return 0
+
+    def clear_cache(self) -> None:
+        return None
+
+    def pcre2(self, use_pcre2: bool = True) -> "Tokenizer":
+        """Backend switches (src/python/bindings.rs:207-242) select between regex engines that
+        the reference's tests require to agree; here both map to the one scanner."""
+        return self
+
+    def jit(self, use_jit: bool = True) -> "Tokenizer":
+        return self
+
+    def __repr__(self) -> str:
+        return f"Tokenizer(vocab_size={self.vocab_size})"
+
+    # ------------------------------------------------------------------ backend hooks (bench / tests)
+    @property
+    def handle(self) -> int:
+        return self._h
