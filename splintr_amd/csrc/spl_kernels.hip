@@ -289,6 +289,7 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
         const int K = (int)s_total;
         for (int k = tid; k + 1 < K; k += NT) {
             const int p = s_cpos[k];
+            if ((s_rec[p] & CB_CLASS) >= C_EOT) continue;   // terminator on a special-literal span
             const int n = (int)s_cpos[k + 1] - p;
             const uint32_t id = probe_chunk(T, tx, p, n);
             if (id != SPL_NO_RANK) {
