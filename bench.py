@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""encode_batch throughput on MI355X (BASELINE.json metric: MB/s of input bytes, MB = 1e6 B).
+
+A "step" is ONE pass of the hot path (Tokenizer.encode_batch semantics through the C ABI,
+spl_encode_batch_device) over ONE batch of synthetic text already resident in HBM:
+config[1] of BASELINE.json = cl100k_base, 1000 x ~1 KB mixed English/code (splintr_amd.corpus.c2).
+With --gpus N > 1 every rank holds its own 1000-document shard (weak scaling) and the step also
+all-gathers the ragged ids over RCCL so that every rank ends up with the whole CSR result.
+
+    python bench.py --gpus 1 --steps 500 --warmup 50
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints one JSON line on rank 0.  The oracle (oracle/) is used only as the checker of the
+untimed verification pass and as the timed CPU baseline ("port"); it is never on the measured path.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--docs", type=int, default=1000, help="documents per GPU (BASELINE config: 1000)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build()
+    if world > 1:
+        dist.barrier()
+    from splintr_amd import Tokenizer, corpus, _ffi
+    from splintr_amd.device import DeviceBatch, encode_device, reserve, result_csr
+    from splintr_amd.distributed import all_gather_csr
+
+    tok = Tokenizer.from_pretrained("cl100k_base", device=local_rank)
+    texts = corpus.c2(args.docs, seed=1002 + rank)          # rank-distinct shard, same distribution
+    batch = DeviceBatch(texts, dev)
+    reserve(tok, batch.n_bytes, batch.n_docs)
+    L = _ffi.lib()
+
+    def step():
+        encode_device(tok, batch)
+        if world > 1:
+            dc = batch.out_off[1:] - batch.out_off[:-1]
+            return all_gather_csr(batch.ids, batch.out_off[-1], dc)
+        return None
+
+    # ---- untimed verification pass: bit-exact vs the oracle on this very batch -----------------
+    step()
+    torch.cuda.synchronize()
+    ids, off = result_csr(batch)
+    n_tokens = int(off[-1])
+    from oracle.coracle import COracle
+    orc = COracle("cl100k_base")
+    text_np = np.frombuffer(b"".join(t.encode("utf-8") for t in texts), dtype=np.uint8)
+    ncpu = os.cpu_count() or 1
+    o_ids, o_off = orc.encode_packed(text_np, batch.host_offsets, threads=ncpu)
+    if not (np.array_equal(ids, o_ids) and np.array_equal(off, o_off)):
+        raise SystemExit(f"rank {rank}: HIP result differs from the oracle -- refusing to report a throughput")
+
+    # ---- timed region ----------------------------------------------------------------------------
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        et = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(et, op=dist.ReduceOp.MAX)
+        elapsed = float(et.item())
+        nb = torch.tensor([batch.n_bytes], dtype=torch.int64, device=dev)
+        dist.all_reduce(nb)
+        total_bytes = int(nb.item())
+    else:
+        total_bytes = batch.n_bytes
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_bytes * args.steps / elapsed / 1e6
+
+    # ---- per-kernel durations: HIP events on the launch stream (separate pass) ---------------------
+    roofline = None
+    kernels = {}
+    if rank == 0:
+        L.spl_profile_enable(tok.handle, 1)
+        L.spl_profile_reset(tok.handle)
+        nprof = 100
+        for _ in range(nprof):
+            encode_device(tok, batch)
+        torch.cuda.synchronize()
+        ms = (ctypes.c_double * _ffi.SPL_MAX_KERNELS)()
+        cnt = (ctypes.c_uint64 * _ffi.SPL_MAX_KERNELS)()
+        L.spl_profile_read(tok.handle, ms, cnt)
+        L.spl_profile_enable(tok.handle, 0)
+        for i in range(_ffi.SPL_MAX_KERNELS):
+            nm = L.spl_kernel_name(i)
+            if nm and cnt[i]:
+                kernels[nm.decode()] = round(ms[i] / cnt[i] * 1e3, 3)      # us per launch
+        dom = max(kernels, key=kernels.get)
+        # algorithmic bytes of one batch: text read once, u32 ids written once,
+        # input and output offset arrays (u64 each)
+        b_alg = batch.n_bytes + 4 * n_tokens + 16 * (batch.n_docs + 1)
+        achieved = b_alg / (kernels[dom] * 1e-6) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom, {}).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": b_alg, "kernel_us": kernels[dom],
+                    "all_kernels_us": kernels}
+
+    # ---- CPU baseline: the oracle (a port of the reference's Rayon path) on the host cores ---------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        reps, t_cpu = 0, 0.0
+        orc_t = COracle("cl100k_base", memo=True)      # with the reference's LRU-style memo + mutex
+        orc_t.encode_packed(text_np, batch.host_offsets, threads=ncpu)
+        c0 = time.perf_counter()
+        while t_cpu < 10.0 or reps < 3:
+            orc_t.encode_packed(text_np, batch.host_offsets, threads=ncpu)
+            reps += 1
+            t_cpu = time.perf_counter() - c0
+        cpu = {"value": round(batch.n_bytes * reps / t_cpu / 1e6, 2), "unit": "MB/s", "cores": ncpu, "kind": "port",
+               "sample": f"the full bench batch ({batch.n_docs} docs, {batch.n_bytes} B) x {reps} repetitions, "
+                         f"{ncpu} threads pulling documents off a shared counter (CSR in/out, no Python lists)"}
+
+    if rank == 0:
+        out = {
+            "metric": "encode_batch MB/s (bytes in)", "value": round(value, 2), "unit": "MB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": f"cl100k_base, {args.docs} x ~1 KB mixed English/code per GPU "
+                                   f"(splintr_amd.corpus.c2, seed 1002+rank), HBM-resident, CSR out"
+                                   + ("; + RCCL all-gatherv of the ragged ids" if world > 1 else ""),
+                       "vocab": "cl100k_base", "docs_per_gpu": args.docs, "bytes_per_gpu": batch.n_bytes,
+                       "tokens_per_gpu": n_tokens, "parallelism": f"doc-shard x{world}"},
+            "parity": "bit-exact vs oracle (untimed verification pass on the bench batch)",
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,85 @@
+"""Document sharding across the GPUs of one node and the ragged all-gather of the result.
+
+The reference has nothing distributed (Rayon on one host, src/core/tokenizer.rs:932-934);
+documents are independent, so the only exchange is reassembly: one process per GPU encodes a
+contiguous, byte-balanced range of documents, then an all-gatherv over RCCL/xGMI gives every
+rank the whole CSR result.  RCCL has no all-gatherv: it is composed from an all-gather of the
+counts and an all-gather of slices padded to the largest count.  The functions work on whatever
+backend the default process group uses (nccl = RCCL on GPU tensors, gloo on CPU tensors), which
+is how the CPU tests cover this logic.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(doc_bytes: Sequence[int], world: int) -> List[int]:
+    """Cut N documents into `world` contiguous ranges of about equal bytes.
+    Returns world+1 document indices; rank r owns [b[r], b[r+1])."""
+    n = len(doc_bytes)
+    csum = np.concatenate([[0], np.cumsum(np.asarray(doc_bytes, dtype=np.int64))])
+    total = int(csum[-1])
+    bounds = [0]
+    for r in range(1, world):
+        target = total * r / world
+        i = int(np.searchsorted(csum, target, side="left"))
+        # nearest document boundary, monotone
+        if i > 0 and abs(csum[i - 1] - target) <= abs(csum[min(i, n)] - target):
+            i -= 1
+        bounds.append(min(max(i, bounds[-1]), n))
+    bounds.append(n)
+    return bounds
+
+
+def all_gather_csr(ids: torch.Tensor, n_tokens, doc_counts: torch.Tensor,
+                   group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Ragged all-gather.  ids[:n_tokens] = this rank's token ids (int32), doc_counts = tokens per
+    local document (int64); n_tokens may be an int or a 0-dim device tensor (no host sync needed
+    before the exchange).  Every rank returns (all_ids int32[T_total], all_off int64[N_total+1])
+    in rank order, i.e. in global document order."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = ids.device
+    # 1. counts
+    if torch.is_tensor(n_tokens):
+        mine = torch.stack([n_tokens.to(torch.int64).reshape(()),
+                            torch.tensor(doc_counts.numel(), dtype=torch.int64, device=dev)])
+    else:
+        mine = torch.tensor([int(n_tokens), doc_counts.numel()], dtype=torch.int64, device=dev)
+    allc = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(allc, mine, group=group)
+    counts = torch.stack(allc).cpu().numpy()          # the one host sync of the exchange
+    n_tokens = int(counts[rank, 0])
+    tmax, dmax = int(counts[:, 0].max()), int(counts[:, 1].max())
+    # 2. padded slices (equal sizes: one collective each, every link busy at once over xGMI)
+    pad_ids = torch.zeros(max(tmax, 1), dtype=torch.int32, device=dev)
+    pad_ids[:n_tokens] = ids[:n_tokens]
+    g_ids = [torch.empty_like(pad_ids) for _ in range(world)]
+    dist.all_gather(g_ids, pad_ids, group=group)
+    pad_dc = torch.zeros(max(dmax, 1), dtype=torch.int64, device=dev)
+    pad_dc[: doc_counts.numel()] = doc_counts
+    g_dc = [torch.empty_like(pad_dc) for _ in range(world)]
+    dist.all_gather(g_dc, pad_dc, group=group)
+    # 3. strip the padding, rebase offsets
+    all_ids = torch.cat([g_ids[r][: int(counts[r, 0])] for r in range(world)])
+    all_dc = torch.cat([g_dc[r][: int(counts[r, 1])] for r in range(world)])
+    all_off = torch.zeros(all_dc.numel() + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(all_dc, 0, out=all_off[1:])
+    return all_ids, all_off
+
+
+def encode_batch_sharded(encode_csr, texts: Sequence[str], device: torch.device, group=None):
+    """encode_batch over the process group: rank r encodes its byte-balanced document range with
+    `encode_csr(list[str]) -> (ids uint32 ndarray, off uint64 ndarray)` and the ragged result is
+    all-gathered.  Returns (ids, off) numpy arrays for ALL documents on every rank."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    bounds = shard_bounds([len(t.encode("utf-8")) for t in texts], world)
+    local = texts[bounds[rank]:bounds[rank + 1]]
+    ids, off = encode_csr(local)
+    t_ids = torch.from_numpy(ids.astype(np.int32, copy=False).copy()).to(device)
+    dc = torch.from_numpy(np.diff(off.astype(np.int64))).to(device)
+    all_ids, all_off = all_gather_csr(t_ids, int(off[-1]), dc, group)
+    return all_ids.cpu().numpy().view(np.uint32), all_off.cpu().numpy().astype(np.uint64)

@@ -1,0 +1,73 @@
+"""C-ABI surface: the library loads without a GPU, exports every symbol the header declares, and
+reports errors through return codes (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as entry
+    entry.build()
+    from splintr_amd import _ffi
+    return _ffi
+
+
+def test_header_symbols_are_exported(built):
+    hdr = open(os.path.join(ROOT, "include", "splintr_hip.h")).read()
+    declared = set(re.findall(r"\b(spl_[a-z_0-9]+)\s*\(", hdr)) - {"spl_opts"}
+    assert declared == set(built.SYMBOLS), declared ^ set(built.SYMBOLS)
+    L = built.lib()
+    for s in declared:
+        assert hasattr(L, s), s
+
+
+def test_header_cites_reference_interfaces():
+    hdr = open(os.path.join(ROOT, "include", "splintr_hip.h")).read()
+    for cite in ("src/core/tokenizer.rs:932-942", "src/core/tokenizer.rs:842-874", "src/python/bindings.rs:57-446",
+                 "src/core/tokenizer.rs:964-972"):
+        assert cite in hdr
+
+
+def test_errors_without_gpu_or_bad_input(built):
+    L = built.lib()
+    assert L.spl_device_count() >= 0
+    opts = built.SplOpts(0, 0)
+    assert not L.spl_create(b"junk", 4, b"junk", 4, ctypes.byref(opts))
+    assert b"spl_create" in L.spl_last_error()
+    assert L.spl_kernel_name(0) and L.spl_kernel_name(99) is None
+    assert L.spl_vocab_size(None) == 0
+
+
+def test_product_has_no_cpu_fallback_and_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "splintr_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".h", ".hip", ".cpp")):
+                src = open(os.path.join(dirpath, fn), encoding="utf-8").read()
+                assert "oracle" not in src.replace("the oracle's split engine", ""), (fn, "product code mentions the oracle")
+                assert "/root/reference" not in src, fn
+    import splintr_amd
+    from splintr_amd import _ffi
+    if _ffi.lib().spl_device_count() == 0:
+        with pytest.raises(Exception):
+            splintr_amd.Tokenizer.from_pretrained("cl100k_base")      # fails loudly without a GPU
+
+
+def test_python_surface_argument_errors(built):
+    from splintr_amd import Tokenizer
+    from splintr_amd.tokenizer import _pack
+    with pytest.raises(ValueError, match="Unknown pretrained model: gpt9. See from_pretrained docstring"):
+        Tokenizer.from_pretrained("gpt9")
+    with pytest.raises(TypeError):
+        _pack("a bare string")
+    with pytest.raises(TypeError):
+        _pack([b"bytes"])
+    with pytest.raises(UnicodeEncodeError):
+        _pack(["\ud800"])
+    buf, off = _pack(["ab", "", "é"])
+    assert buf == b"ab\xc3\xa9" and off.tolist() == [0, 2, 2, 4]

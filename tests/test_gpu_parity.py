@@ -1,0 +1,234 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the oracle on the
+same inputs -- bit-exact token ids.  Sizes are chosen so the oracle finishes in seconds; the
+full BASELINE.json sizes are covered through size-independent properties at the end."""
+import hashlib
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, VOCABS
+from fuzzgen import fuzz_corpus
+
+pytestmark = pytest.mark.gpu
+
+_toks = {}
+
+
+def tok(name):
+    from splintr_amd import Tokenizer
+    if name not in _toks:
+        _toks[name] = Tokenizer.from_pretrained(name)
+    return _toks[name]
+
+
+def oracle_csr(orc, texts, special=False):
+    bs = [t.encode("utf-8") for t in texts]
+    off = np.zeros(len(bs) + 1, dtype=np.uint64)
+    if bs:
+        np.cumsum([len(b) for b in bs], out=off[1:])
+    return orc.encode_packed(np.frombuffer(b"".join(bs), dtype=np.uint8), off, special, threads=os.cpu_count() or 8)
+
+
+def assert_batch_equal(name, texts, coracle, special=False):
+    ids, off = tok(name).encode_batch_csr(texts, with_special=special)
+    o_ids, o_off = oracle_csr(coracle(name), texts, special)
+    if not np.array_equal(off, o_off) or not np.array_equal(ids, o_ids):
+        bad = [i for i in range(len(texts))
+               if ids[int(off[i]):int(off[i + 1])].tolist() != o_ids[int(o_off[i]):int(o_off[i + 1])].tolist()]
+        i = bad[0]
+        raise AssertionError(f"{name}: {len(bad)} of {len(texts)} docs differ; first #{i} {texts[i][:120]!r}: "
+                             f"{ids[int(off[i]):int(off[i + 1])][:24].tolist()} vs "
+                             f"{o_ids[int(o_off[i]):int(o_off[i + 1])][:24].tolist()}")
+
+
+def test_extension_is_native_and_loaded():
+    from splintr_amd import _ffi
+    assert os.path.exists(_ffi.LIB_PATH)
+    assert _ffi.lib().spl_device_count() >= 1
+    with open("/proc/self/maps") as f:
+        assert "libsplintr_hip.so" in f.read()
+
+
+@pytest.mark.parametrize("name", VOCABS)
+def test_reference_vectors(golden, name):
+    t = tok(name)
+    for text, ids in golden[name]:
+        assert t.encode(text) == ids, (name, text)
+        assert t.encode_rayon(text) == ids
+    assert t.encode_batch([x for x, _ in golden[name]]) == [y for _, y in golden[name]]
+
+
+@pytest.mark.parametrize("name", VOCABS)
+def test_surface(name):
+    t = tok(name)
+    sizes = {"cl100k_base": 100331, "o200k_base": 200073, "llama3": 128354, "deepseek_v3": 128954}
+    assert t.vocab_size == sizes[name]
+    assert repr(t) == f"Tokenizer(vocab_size={sizes[name]})"
+    assert t.encode("") == [] and t.encode_batch([]) == [] and t.encode_batch(["", ""]) == [[], []]
+    with pytest.raises(TypeError):
+        t.encode_batch("not a list")
+    with pytest.raises(TypeError):
+        t.encode(b"bytes")
+    assert t.pcre2(True).encode("Hello") == t.jit(False).encode("Hello") == t.encode("Hello")
+
+
+@pytest.mark.parametrize("name", VOCABS)
+def test_fuzz_batch(coracle, name):
+    assert_batch_equal(name, fuzz_corpus(101, 20000, 60), coracle)
+
+
+@pytest.mark.parametrize("name", VOCABS)
+def test_corpora_and_worst_case(coracle, name):
+    from splintr_amd import corpus
+    texts = corpus.c1(100) + corpus.c2(300) + corpus.c3(60) + corpus.c4(2000) + corpus.c5(1, doc_bytes=1 << 19)
+    assert_batch_equal(name, texts, coracle)
+    assert_batch_equal(name, corpus.worst_case(20000), coracle)
+
+
+def test_corpus_fixtures_sha256():
+    from splintr_amd import corpus
+    with open(os.path.join(ROOT, "tests", "golden", "corpus_fixtures.json")) as f:
+        fx = json.load(f)
+    for key, ent in fx.items():
+        texts = getattr(corpus, ent["generator"])(ent["n"], **ent.get("kwargs", {}))
+        ids, off = tok(ent["vocab"]).encode_batch_csr(texts)
+        h = hashlib.sha256()
+        for i in range(len(texts)):
+            h.update(ids[int(off[i]):int(off[i + 1])].tobytes())
+            h.update(b"|")
+        assert h.hexdigest() == ent["sha256"], key
+
+
+@pytest.mark.parametrize("name", ["cl100k_base", "o200k_base"])
+def test_tile_and_window_edges(coracle, name):
+    """Documents and runs placed around the 4096-byte tile edge and the 480-byte right halo."""
+    rng = random.Random(5)
+    texts = []
+    for size in (1, 2, 31, 32, 33, 4095, 4096, 4097, 4575, 4576, 4577, 4607, 4608, 4609, 8191, 8192, 8193):
+        texts.append(("ab cd, " * (size // 7 + 1))[:size])
+    for lead in (4000, 4090, 4096, 4100, 4500, 4570):
+        for run in (" " * 600, "a" * 700, "1" * 500, "=" * 490, "\n" * 481, "你" * 200, " \n" * 300, "x'" * 300,
+                    "A" * 500 + "b", "é́" * 200):
+            filler = ("lorem ipsum 12 " * 400)[:lead]
+            texts.append(filler + run + " tail" + str(rng.randint(0, 9)))
+    assert_batch_equal(name, texts, coracle)
+    assert_batch_equal(name, ["".join(texts)], coracle)       # same content as ONE long document
+
+
+@pytest.mark.parametrize("name", VOCABS)
+def test_many_tiny_and_empty_documents(coracle, name):
+    rng = random.Random(9)
+    texts = []
+    for _ in range(30000):
+        r = rng.random()
+        texts.append("" if r < 0.2 else rng.choice(["a", " ", "\n", "1", "é", "你", "'s", "ab", "a b", "12", "  "])
+                     if r < 0.7 else "word " * rng.randint(1, 4))
+    assert_batch_equal(name, texts, coracle)
+
+
+def test_huge_single_chunk(coracle):
+    for t in ("a" * 65536, " " * 65536 + "x", "ab" * 20000):
+        assert_batch_equal("cl100k_base", [t, "after"], coracle)
+
+
+@pytest.mark.parametrize("name", VOCABS)
+def test_special_tokens(coracle, name):
+    with open(os.path.join(ROOT, "splintr_amd", "data", "special_tokens.json"), encoding="utf-8") as f:
+        lits = list(json.load(f)[name])
+    rng = random.Random(3)
+    base = fuzz_corpus(55, 3000, 20)
+    texts = []
+    for s in base:
+        parts = [s]
+        for _ in range(rng.randint(0, 3)):
+            parts.insert(rng.randint(0, len(parts)), rng.choice(lits))
+        texts.append("".join(parts))
+    texts += ["".join(lits), lits[0] * 50, "<|", "<|endoftext", "x<" + lits[0][1:-1], lits[0][:-1] + " " + lits[0][-1]]
+    assert_batch_equal(name, texts, coracle, special=True)
+    assert_batch_equal(name, texts, coracle, special=False)    # plain encode_batch never scans
+    t = tok(name)
+    assert t.encode_with_special(texts[0]) == coracle(name).encode_with_special(texts[0])
+    assert t.encode_batch_with_special(texts[:50]) == [coracle(name).encode_with_special(x) for x in texts[:50]]
+
+
+@pytest.mark.parametrize("name", VOCABS)
+def test_decode_round_trip(name):
+    from splintr_amd import corpus
+    t = tok(name)
+    texts = ["Hello, world!", "   \n\t  ", "Unicode: こんにちは 世界 🦀", "don't — “quoted” it’s", ""] + corpus.c3(20)
+    enc = t.encode_batch(texts)
+    assert t.decode_batch(enc) == texts
+    assert t.decode(enc[2]) == texts[2] and t.decode_bytes(enc[0]) == texts[0].encode()
+
+
+def test_device_api_and_profile(coracle):
+    import ctypes
+    import torch
+    from splintr_amd import _ffi, corpus
+    from splintr_amd.device import DeviceBatch, encode_device, reserve, result_csr
+    t = tok("cl100k_base")
+    texts = corpus.c2(200)
+    batch = DeviceBatch(texts, torch.device("cuda", 0))
+    reserve(t, batch.n_bytes, batch.n_docs)
+    _ffi.lib().spl_profile_enable(t.handle, 1)
+    _ffi.lib().spl_profile_reset(t.handle)
+    for _ in range(3):
+        encode_device(t, batch)
+    torch.cuda.synchronize()
+    ms = (ctypes.c_double * 16)()
+    n = (ctypes.c_uint64 * 16)()
+    _ffi.lib().spl_profile_read(t.handle, ms, n)
+    _ffi.lib().spl_profile_enable(t.handle, 0)
+    assert max(n) == 3 and sum(ms) > 0
+    ids, off = result_csr(batch)
+    o_ids, o_off = oracle_csr(coracle("cl100k_base"), texts)
+    assert np.array_equal(ids, o_ids) and np.array_equal(off, o_off)
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json full sizes, through size-independent properties
+# ------------------------------------------------------------------------------------------------
+def _check_replicated(name, base_texts, copies, coracle):
+    """N copies of a base set in shuffled order: every copy of a document must get the ids the
+    oracle gives the base document (positions, tile alignment and neighbours all differ)."""
+    rng = random.Random(17)
+    order = list(range(len(base_texts))) * copies
+    rng.shuffle(order)
+    texts = [base_texts[i] for i in order]
+    ids, off = tok(name).encode_batch_csr(texts)
+    o_ids, o_off = oracle_csr(coracle(name), base_texts)
+    starts = off[:-1].astype(np.int64)
+    lens = np.diff(off.astype(np.int64))
+    o_lens = np.diff(o_off.astype(np.int64))
+    assert np.array_equal(lens, o_lens[order])
+    # checksum of checksums: per-document sums must match the oracle's, then spot-check ids exactly
+    csum = np.concatenate([[0], np.cumsum(ids.astype(np.uint64))])
+    o_csum = np.concatenate([[0], np.cumsum(o_ids.astype(np.uint64))])
+    got = csum[off[1:].astype(np.int64)] - csum[starts]
+    want = (o_csum[o_off[1:].astype(np.int64)] - o_csum[o_off[:-1].astype(np.int64)])[order]
+    assert np.array_equal(got, want)
+    for k in rng.sample(range(len(texts)), 200):
+        i = order[k]
+        assert np.array_equal(ids[int(off[k]):int(off[k + 1])], o_ids[int(o_off[i]):int(o_off[i + 1])])
+    return sum(len(t.encode("utf-8")) for t in texts)
+
+
+def test_full_size_c3_o200k(coracle):
+    from splintr_amd import corpus
+    n = _check_replicated("o200k_base", corpus.c3(500), 20, coracle)           # 10 000 x ~4 KB
+    assert n > 35e6
+
+
+def test_full_size_c4_llama3(coracle):
+    from splintr_amd import corpus
+    n = _check_replicated("llama3", corpus.c4(10000), 100, coracle)            # 1 000 000 prompts
+    assert n > 150e6
+
+
+def test_full_size_c5_deepseek(coracle):
+    from splintr_amd import corpus
+    n = _check_replicated("deepseek_v3", corpus.c5(2), 50, coracle)            # 100 x 2 MiB
+    assert n >= 100 * (2 << 20) - 400

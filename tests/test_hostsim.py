@@ -1,0 +1,61 @@
+"""The product's host/device-shared code (spl_scan.h, spl_lookup.h, spl_tables.cpp) driven
+serially on the CPU by tests/hostsim (a TEST TOOL, g++-built) against the oracle: scanner closed
+forms, deferral contract at tiny windows, sync-point rules, table formats, the lane-serial merge."""
+import pytest
+
+from conftest import VOCABS
+from fuzzgen import fuzz_corpus
+from hostsim import HostSim
+
+_sims = {}
+
+
+def sim(name):
+    if name not in _sims:
+        _sims[name] = HostSim(name)
+    return _sims[name]
+
+
+@pytest.mark.parametrize("name", VOCABS)
+def test_table_build_info(name):
+    info = sim(name).info()
+    expect = {"cl100k_base": (100256, 233378), "o200k_base": (199998, 446189), "llama3": (128000, 280147),
+              "deepseek_v3": (127997, 238951)}[name]          # SURVEY appendix A probe values
+    assert (info["n_keys"], info["n_pairs"]) == expect
+    assert info["max_key_len"] == 128 and info["cjk_fast"] == 1
+
+
+@pytest.mark.parametrize("name", ["cl100k_base", "o200k_base"])
+def test_scanner_and_sync_points_match_oracle(coracle, name):
+    h, c = sim(name), coracle(name)
+    n_sync = n_chunks = 0
+    for s in fuzz_corpus(31337, 8000):
+        b = s.encode("utf-8")
+        ref = c.split_bytes(b)
+        assert h.split(b) == ref, s
+        for w in (1, 3, 8, 21):                    # the window-end deferral contract
+            assert h.split(b, w) == ref, (w, s)
+        marks, ns, _ = h.split_sync(b)             # every sync point is a true match start, and the
+        assert marks == ref, s                     # chains between them find all the others
+        n_sync += ns
+        n_chunks += len(ref)
+    assert n_sync > 0.5 * n_chunks                 # sync points are dense enough to parallelise on
+
+
+@pytest.mark.parametrize("name", VOCABS)
+def test_encode_matches_oracle(golden, coracle, name):
+    h, c = sim(name), coracle(name)
+    for text, ids in golden[name]:
+        assert h.encode(text.encode("utf-8")) == ids
+    for s in fuzz_corpus(4711, 4000):
+        b = s.encode("utf-8")
+        assert h.encode(b) == c.encode_bytes(b), (name, s)
+
+
+def test_long_runs(coracle):
+    from splintr_amd import corpus
+    for name in ("cl100k_base", "deepseek_v3"):
+        h, c = sim(name), coracle(name)
+        for t in corpus.worst_case(1500):
+            b = t.encode("utf-8")
+            assert h.encode(b) == c.encode_bytes(b)
