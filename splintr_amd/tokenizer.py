@@ -145,7 +145,8 @@ class Tokenizer:
             raise RuntimeError(f"spl_encode_batch failed ({rc}): {_ffi.last_error()}")
         try:
             nt = L.spl_result_n_tokens(res)
-            ids = np.ctypeslib.as_array(L.spl_result_tokens(res), shape=(max(nt, 1),))[:nt].copy()
+            ids = (np.ctypeslib.as_array(L.spl_result_tokens(res), shape=(nt,)).copy() if nt
+                   else np.zeros(0, dtype=np.uint32))
             oo = np.ctypeslib.as_array(L.spl_result_offsets(res), shape=(nd + 1,)).copy()
         finally:
             L.spl_result_free(res)

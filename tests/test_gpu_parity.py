@@ -210,7 +210,7 @@ def _check_replicated(name, base_texts, copies, coracle):
     got = csum[off[1:].astype(np.int64)] - csum[starts]
     want = (o_csum[o_off[1:].astype(np.int64)] - o_csum[o_off[:-1].astype(np.int64)])[order]
     assert np.array_equal(got, want)
-    for k in rng.sample(range(len(texts)), 200):
+    for k in rng.sample(range(len(texts)), min(200, len(texts))):
         i = order[k]
         assert np.array_equal(ids[int(off[k]):int(off[k + 1])], o_ids[int(o_off[i]):int(o_off[i + 1])])
     return sum(len(t.encode("utf-8")) for t in texts)
