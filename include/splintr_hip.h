@@ -110,9 +110,13 @@ int spl_profile_read(spl_tokenizer* t, double ms_out[SPL_MAX_KERNELS], uint64_t 
 const char* spl_kernel_name(int index);   /* NULL past the last kernel */
 
 /* Counters of the last encode call on this handle (device -> host copy, synchronises):
- * [0] chunks resolved by the whole-chunk probe is not tracked; entries are
- * [0] short-merge queue items (<=16 B), [1] medium (17..64 B), [2] long (>64 B), [3] deferred segments. */
+ * [2] items of the global long-chunk queue (> 64 B, plus every miss of a deferred segment),
+ * [3] deferred segments (scanner chains that outgrew a tile window); [0], [1] unused. */
 int spl_last_queue_counts(spl_tokenizer* t, uint32_t counts_out[4]);
+
+/* Development aid: when enabled, one k_pretok workgroup stamps the shader clock at its phase
+ * boundaries; the call returns the stamps of the previous batch (synchronises). */
+int spl_debug_phases(spl_tokenizer* t, int enable, unsigned long long stamps_out[16]);
 
 #ifdef __cplusplus
 }

@@ -22,6 +22,7 @@ SYMBOLS = [
     "spl_reserve", "spl_encode_batch", "spl_result_tokens", "spl_result_offsets", "spl_result_n_tokens",
     "spl_result_n_docs", "spl_result_free", "spl_encode_batch_device", "spl_decode_batch", "spl_free",
     "spl_profile_enable", "spl_profile_reset", "spl_profile_read", "spl_kernel_name", "spl_last_queue_counts",
+    "spl_debug_phases",
 ]
 
 
@@ -75,6 +76,7 @@ def lib() -> ctypes.CDLL:
     L.spl_kernel_name.restype = ctypes.c_char_p
     L.spl_kernel_name.argtypes = [ctypes.c_int]
     L.spl_last_queue_counts.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32)]
+    L.spl_debug_phases.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
     _lib = L
     return L
 

@@ -28,9 +28,9 @@ int fail(int code, const std::string& msg) {
             return fail(SPL_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));   \
     } while (0)
 
-enum { KI_MARK = 0, KI_SPECIAL, KI_PRETOK, KI_DEFER, KI_BPE16, KI_BPE64, KI_BPELONG, KI_COUNT, KI_SCAN, KI_COMPACT, KI_DOCOFF, KI_N };
-const char* const k_names[KI_N] = {"k_mark_docs", "k_special_scan+ends", "k_pretok", "k_deferred", "k_bpe_lanes<16>", "k_bpe_lanes<64>",
-                                   "k_bpe_block", "k_count", "k_scan", "k_compact", "k_doc_offsets"};
+enum { KI_MARK = 0, KI_SPECIAL, KI_PRETOK, KI_DEFER, KI_BPEGROUPS, KI_BPELONG, KI_COUNT, KI_SCAN, KI_COMPACT, KI_N };
+const char* const k_names[KI_N] = {"memset+k_mark_docs", "k_special_scan+ends", "k_pretok", "k_deferred", "k_bpe_groups",
+                                   "k_bpe_block", "k_count", "k_scan", "k_compact_docs"};
 
 template <class T> int dev_upload(const std::vector<T>& v, const T** out) {
     void* p = nullptr;
@@ -61,8 +61,9 @@ struct spl_tokenizer {
     size_t zero_words = 0, bitmap_words = 0;
     uint32_t* d_stage = nullptr;
     uint32_t* d_rank = nullptr;
-    uint2* d_q16 = nullptr; uint2* d_q64 = nullptr; uint2* d_qlong = nullptr; uint32_t* d_qdefer = nullptr;
-    uint32_t qcap16 = 0, qcap64 = 0, qcaplong = 0, qcapdefer = 0;
+    uint2* d_tileq = nullptr; uint2* d_tile_cnt = nullptr; uint2* d_qlong = nullptr; uint32_t* d_qdefer = nullptr;
+    uint32_t qcaplong = 0, qcapdefer = 0;
+    unsigned long long* d_dbg = nullptr;
     uint32_t* d_blk = nullptr;
     // host-path staging
     uint8_t* d_in_text = nullptr; uint64_t* d_in_off = nullptr; uint32_t* d_out_ids = nullptr; uint64_t* d_out_off = nullptr;
@@ -73,6 +74,9 @@ struct spl_tokenizer {
     bool ev_ready = false;
     double prof_ms[SPL_MAX_KERNELS]{};
     uint64_t prof_n[SPL_MAX_KERNELS]{};
+    uint32_t* last_qcount = nullptr;
+    bool dbg_on = false;
+    int force_tile = 0;     // 0 auto, 1 small tiles, 2 large tiles (spl_debug_phases bit 1/2)
 };
 
 struct spl_result {
@@ -83,10 +87,10 @@ struct spl_result {
 namespace {
 
 void free_workspace(spl_tokenizer* t) {
-    hipFree(t->d_zero); hipFree(t->d_stage); hipFree(t->d_rank); hipFree(t->d_q16); hipFree(t->d_q64);
-    hipFree(t->d_qlong); hipFree(t->d_qdefer); hipFree(t->d_blk);
-    t->d_zero = nullptr; t->d_stage = nullptr; t->d_rank = nullptr; t->d_q16 = nullptr; t->d_q64 = nullptr;
-    t->d_qlong = nullptr; t->d_qdefer = nullptr; t->d_blk = nullptr;
+    hipFree(t->d_zero); hipFree(t->d_stage); hipFree(t->d_rank); hipFree(t->d_tileq); hipFree(t->d_tile_cnt);
+    hipFree(t->d_qlong); hipFree(t->d_qdefer); hipFree(t->d_blk); hipFree(t->d_dbg);
+    t->d_zero = nullptr; t->d_stage = nullptr; t->d_rank = nullptr; t->d_tileq = nullptr; t->d_tile_cnt = nullptr;
+    t->d_qlong = nullptr; t->d_qdefer = nullptr; t->d_blk = nullptr; t->d_dbg = nullptr;
     t->cap_bytes = t->cap_docs = 0;
 }
 
@@ -102,12 +106,16 @@ int reserve(spl_tokenizer* t, uint64_t max_bytes, uint64_t max_docs) {
     HIP_TRY(hipMalloc((void**)&t->d_zero, t->zero_words * 4));
     HIP_TRY(hipMalloc((void**)&t->d_stage, (nb + 8192) * 4));
     HIP_TRY(hipMalloc((void**)&t->d_rank, (nb + 8192) * 4));
-    t->qcap16 = (uint32_t)(nb / 2 + 64);
-    t->qcap64 = (uint32_t)(nb / 17 + 64);
-    t->qcaplong = (uint32_t)(nb / 65 + 64);
-    t->qcapdefer = (uint32_t)(2 * (nb / TB + 2) + 64);
-    HIP_TRY(hipMalloc((void**)&t->d_q16, (size_t)t->qcap16 * 8));
-    HIP_TRY(hipMalloc((void**)&t->d_q64, (size_t)t->qcap64 * 8));
+    // per-tile miss lists: sized for whichever geometry needs more per input byte
+    using GS = TileGeom<SPL_TILE_SMALL>;
+    using GL = TileGeom<SPL_TILE_LARGE>;
+    const size_t tiles_s = (size_t)(nb / GS::TBv) + 2, tiles_l = (size_t)(nb / GL::TBv) + 2;
+    const size_t tileq_items = std::max(tiles_s * GS::QCAP, tiles_l * GL::QCAP);
+    t->qcaplong = (uint32_t)(nb / 2 + 64);          // long chunks AND every miss of a deferred segment
+    t->qcapdefer = (uint32_t)(2 * tiles_s + 64);
+    HIP_TRY(hipMalloc((void**)&t->d_tileq, tileq_items * 8));
+    HIP_TRY(hipMalloc((void**)&t->d_tile_cnt, tiles_s * 8));
+    HIP_TRY(hipMalloc((void**)&t->d_dbg, 16 * 8));
     HIP_TRY(hipMalloc((void**)&t->d_qlong, (size_t)t->qcaplong * 8));
     HIP_TRY(hipMalloc((void**)&t->d_qdefer, (size_t)t->qcapdefer * 4));
     HIP_TRY(hipMalloc((void**)&t->d_blk, (nblk + 2) * 4));
@@ -149,26 +157,30 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
     }
     Batch b{};
     b.text = d_utf8; b.n_bytes = (uint32_t)n_bytes; b.doc_off = d_doc_off; b.n_docs = (uint32_t)n_docs;
-    b.tbits = t->d_zero; b.tstart = t->d_zero + t->bitmap_words; b.qcount = t->d_zero + 3 * t->bitmap_words;
-    b.skip = special ? t->d_zero + 2 * t->bitmap_words : nullptr;
+    b.n_blk = (uint32_t)(n_bytes / RANK_BLK + 1);
+    // bitmaps and queue counters packed back to back for THIS batch size: one memset clears them
+    const size_t uw = (size_t)b.n_blk * 32 + 32;
+    b.tbits = t->d_zero; b.tstart = t->d_zero + uw;
+    b.skip = special ? t->d_zero + 2 * uw : nullptr;
+    b.qcount = t->d_zero + (special ? 3 : 2) * uw;
+    t->last_qcount = b.qcount;
     b.sp_lits = t->d_sp_lits; b.n_special = special ? (uint32_t)t->specials.size() : 0u;
     b.stage = t->d_stage; b.rank_scr = t->d_rank;
-    b.q16 = t->d_q16; b.q64 = t->d_q64; b.qlong = t->d_qlong; b.qdefer = t->d_qdefer;
-    b.qcap16 = t->qcap16; b.qcap64 = t->qcap64; b.qcaplong = t->qcaplong; b.qcapdefer = t->qcapdefer;
-    b.blk_base = t->d_blk; b.n_blk = (uint32_t)(n_bytes / RANK_BLK + 1);
+    b.tileq = t->d_tileq; b.tile_cnt = t->d_tile_cnt; b.qlong = t->d_qlong; b.qdefer = t->d_qdefer;
+    b.qcaplong = t->qcaplong; b.qcapdefer = t->qcapdefer;
+    b.dbg = t->dbg_on ? t->d_dbg : nullptr;
+    b.blk_base = t->d_blk;
     b.ids_out = d_ids; b.ids_cap = ids_cap; b.off_out = d_out_off;
-
-    // only the words this batch touches need clearing
-    const size_t used_words = (size_t)b.n_blk * 32 + 32;
-    HIP_TRY(hipMemsetAsync(b.tbits, 0, used_words * 4, s));
-    HIP_TRY(hipMemsetAsync(b.tstart, 0, used_words * 4, s));
-    if (special) HIP_TRY(hipMemsetAsync(b.skip, 0, used_words * 4, s));
-    HIP_TRY(hipMemsetAsync(b.qcount, 0, 32, s));
 
     const bool pf = t->prof;
 #define MARK(i) do { if (pf) HIP_TRY(hipEventRecord(t->ev[i], s)); } while (0)
-    const uint32_t ntiles = (uint32_t)((n_bytes + TB - 1) / TB);
+    // small batches: small tiles (occupancy hides latency); large batches: 4 KiB tiles
+    const bool small_tiles = t->force_tile == 1 || (t->force_tile == 0 && n_bytes <= (8u << 20));
+    const uint32_t tile_bytes = small_tiles ? TileGeom<SPL_TILE_SMALL>::TBv : TileGeom<SPL_TILE_LARGE>::TBv;
+    const uint32_t qcap = small_tiles ? TileGeom<SPL_TILE_SMALL>::QCAP : TileGeom<SPL_TILE_LARGE>::QCAP;
+    const uint32_t ntiles = (uint32_t)((n_bytes + tile_bytes - 1) / tile_bytes);
     MARK(KI_MARK);
+    HIP_TRY(hipMemsetAsync(t->d_zero, 0, ((special ? 3 : 2) * uw + 8) * 4, s));
     if (n_docs) hipLaunchKernelGGL(k_mark_docs, dim3((uint32_t)((n_docs + 255) / 256)), dim3(256), 0, s, b);
     MARK(KI_SPECIAL);
     if (special && n_bytes) {
@@ -176,23 +188,32 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
         hipLaunchKernelGGL(k_special_ends, dim3((uint32_t)((n_bytes + 255) / 256)), dim3(256), 0, s, b);
     }
     MARK(KI_PRETOK);
-    if (ntiles) hipLaunchKernelGGL(k_pretok, dim3(ntiles), dim3(NT), 0, s, t->dt, b);
+    if (ntiles) {
+        if (small_tiles) hipLaunchKernelGGL((k_pretok<SPL_TILE_SMALL>), dim3(ntiles), dim3(NT), 0, s, t->dt, b);
+        else hipLaunchKernelGGL((k_pretok<SPL_TILE_LARGE>), dim3(ntiles), dim3(NT), 0, s, t->dt, b);
+    }
     MARK(KI_DEFER);
     if (ntiles) hipLaunchKernelGGL(k_deferred, dim3(64), dim3(64), 0, s, t->dt, b);
-    MARK(KI_BPE16);
-    if (ntiles) hipLaunchKernelGGL((k_bpe_lanes<16, 256>), dim3(std::min<uint32_t>(1024, ntiles * 2 + 8)), dim3(256), 0, s, t->dt, b, 0);
-    MARK(KI_BPE64);
-    if (ntiles) hipLaunchKernelGGL((k_bpe_lanes<64, 64>), dim3(std::min<uint32_t>(2048, ntiles * 4 + 8)), dim3(64), 0, s, t->dt, b, 1);
+    MARK(KI_BPEGROUPS);
+    if (ntiles) {
+        // several workgroups share one tile's miss list while the batch is too small to fill the chip
+        const uint32_t bpt = ntiles >= 2048 ? 1u : ntiles >= 1024 ? 2u : 4u;
+        hipLaunchKernelGGL(k_bpe_groups, dim3(2 * ntiles * bpt), dim3(NT), 0, s, t->dt, b, ntiles, bpt, qcap);
+    }
     MARK(KI_BPELONG);
     if (ntiles) hipLaunchKernelGGL(k_bpe_block, dim3(std::min<uint32_t>(512, ntiles + 8)), dim3(NT), 0, s, t->dt, b);
     MARK(KI_COUNT);
-    hipLaunchKernelGGL(k_count, dim3((b.n_blk + 255) / 256), dim3(256), 0, s, b);
+    const bool fused_scan = b.n_blk <= 8192;
+    if (!fused_scan) hipLaunchKernelGGL(k_count, dim3((b.n_blk + 255) / 256), dim3(256), 0, s, b);
     MARK(KI_SCAN);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, b);
+    if (fused_scan) hipLaunchKernelGGL(k_scan<true>, dim3(1), dim3(1024), 0, s, b);
+    else hipLaunchKernelGGL(k_scan<false>, dim3(1), dim3(1024), 0, s, b);
     MARK(KI_COMPACT);
-    hipLaunchKernelGGL(k_compact, dim3((b.n_blk * 32 + NT - 1) / NT), dim3(NT), 0, s, b);
-    MARK(KI_DOCOFF);
-    hipLaunchKernelGGL(k_doc_offsets, dim3((uint32_t)((n_docs + 1 + 255) / 256)), dim3(256), 0, s, b);
+    {
+        const uint32_t n_compact = (b.n_blk * 32 + NT - 1) / NT;
+        const uint32_t n_docblk = (uint32_t)((n_docs + 1 + NT - 1) / NT);
+        hipLaunchKernelGGL(k_compact_docs, dim3(n_compact + n_docblk), dim3(NT), 0, s, b, n_compact);
+    }
     MARK(KI_N);
 #undef MARK
     HIP_TRY(hipGetLastError());
@@ -435,11 +456,22 @@ int spl_profile_read(spl_tokenizer* t, double ms_out[SPL_MAX_KERNELS], uint64_t 
 }
 const char* spl_kernel_name(int index) { return (index >= 0 && index < KI_N) ? k_names[index] : nullptr; }
 
+int spl_debug_phases(spl_tokenizer* t, int enable, unsigned long long stamps_out[16]) {
+    if (!t) return fail(SPL_EINVAL, "null handle");
+    HIP_TRY(hipSetDevice(t->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (stamps_out && t->d_dbg) HIP_TRY(hipMemcpy(stamps_out, t->d_dbg, 16 * 8, hipMemcpyDeviceToHost));
+    t->dbg_on = (enable & 1) != 0;
+    t->force_tile = (enable >> 1) & 3;      // development: bit 1 = force small tiles, bit 2 = force large
+    return SPL_OK;
+}
+
 int spl_last_queue_counts(spl_tokenizer* t, uint32_t counts_out[4]) {
     if (!t || !t->d_zero) return fail(SPL_EINVAL, "no batch has run");
     HIP_TRY(hipSetDevice(t->device));
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(counts_out, t->d_zero + 3 * t->bitmap_words, 16, hipMemcpyDeviceToHost));
+    if (!t->last_qcount) return fail(SPL_EINVAL, "no batch has run");
+    HIP_TRY(hipMemcpy(counts_out, t->last_qcount, 16, hipMemcpyDeviceToHost));
     return SPL_OK;
 }
 

@@ -6,9 +6,11 @@
 //                   the chunks, whole-chunk vocabulary probe (spl_lookup.h); misses go to queues
 //                   (reference: Tokenizer::encode, src/core/tokenizer.rs:729-808 + :703-705)
 //   k_deferred      segments that outgrew a tile window: same scanner over global memory
-//   k_bpe_lanes<N>  byte_pair_encode (src/core/bpe.rs:67-197), one lane per chunk, nodes in LDS
+//   k_bpe_groups    byte_pair_encode (src/core/bpe.rs:67-197), one node per lane: 16-lane groups
+//                   for chunks <= 16 B, whole waves for 17..64 B; everything in registers, the
+//                   leftmost-minimum search is a shuffle reduction, neighbours come from a ballot
 //   k_bpe_block     the same for long chunks, one workgroup per chunk, nodes in HBM scratch
-//   k_count / k_scan / k_compact / k_doc_offsets
+//   k_scan_count (or k_count + k_scan) / k_compact_docs
 //                   token-start bitmap -> ranks -> dense ids[] and per-document offsets (CSR)
 //
 // Token bookkeeping: a token is identified by the byte position where it starts.  Producers set a
@@ -22,14 +24,13 @@
 
 namespace spl {
 
-constexpr int TB = 4096;                 // tile bytes owned by one workgroup
 constexpr int LH = 32;                   // left halo (previous character's class)
-constexpr int RH = 480;                  // right halo (chains may run past the tile)
-constexpr int W = LH + TB + RH;          // 4608 staged bytes
-constexpr int WPAD = 16;                 // real bytes staged past W (straddling chars, load32)
+constexpr int WPAD = 16;                 // real bytes staged past the window (straddling chars, load32)
 constexpr int NT = 256;
-constexpr int NWORDS = W / 32 + 1;       // bitmap words incl. the bit for position W
 constexpr int RANK_BLK = 1024;           // positions per rank block (32 bitmap words)
+// tile geometries (tile bytes, right halo): chains may run past the tile into the halo
+#define SPL_TILE_SMALL 768, 224          /* window 1024 B: one 4-byte word per lane */
+#define SPL_TILE_LARGE 4096, 480         /* window 4608 B */
 
 struct Batch {
     const uint8_t* text;
@@ -43,9 +44,12 @@ struct Batch {
     uint32_t* tbits;       // bitmap: a token starts at this byte
     uint32_t* stage;       // id of the token starting at this byte
     uint32_t* rank_scr;    // per-byte scratch for k_bpe_block
-    uint32_t* qcount;      // [0] q16 [1] q64 [2] qlong [3] qdefer
-    uint2* q16; uint2* q64; uint2* qlong; uint32_t* qdefer;
-    uint32_t qcap16, qcap64, qcaplong, qcapdefer;
+    uint32_t* qcount;      // [2] qlong [3] qdefer   (global, atomically appended: rare paths)
+    uint2* tileq;          // per-tile miss lists (TileGeom::QCAP items per tile): chunks <= 16 B from the
+    uint2* tile_cnt;       //   front, 17..64 B from the back; tile_cnt[t] = (n_short, n_medium)
+    uint2* qlong; uint32_t* qdefer;
+    uint32_t qcaplong, qcapdefer;
+    unsigned long long* dbg;   // optional phase cycle stamps of one k_pretok workgroup
     uint32_t* blk_base;    // exclusive token count per RANK_BLK block (+1 entry: total)
     uint32_t n_blk;
     uint32_t* ids_out; uint64_t ids_cap; uint64_t* off_out;
@@ -113,72 +117,95 @@ struct LdsAcc {
     }
 };
 
-__device__ __forceinline__ void push2(uint32_t* cnt, uint2* q, uint32_t cap, uint32_t pos, uint32_t len) {
-    const uint32_t i = atomicAdd(cnt, 1u);
-    if (i < cap) q[i] = make_uint2(pos, len);
+__device__ __forceinline__ void push_long(const Batch& b, uint32_t pos, uint32_t len) {
+    const uint32_t i = atomicAdd(&b.qcount[2], 1u);
+    if (i < b.qcaplong) b.qlong[i] = make_uint2(pos, len);
 }
 
-__device__ __forceinline__ void route_miss(const Batch& b, uint32_t pos, uint32_t n) {
-    if (n <= 16) push2(&b.qcount[0], b.q16, b.qcap16, pos, n);
-    else if (n <= 64) push2(&b.qcount[1], b.q64, b.qcap64, pos, n);
-    else push2(&b.qcount[2], b.qlong, b.qcaplong, pos, n);
-}
+// Tile geometry is a template parameter: small batches use small tiles (many wavefronts, 4 bytes
+// per lane, latency hidden by occupancy), large batches use 4 KiB tiles (less halo overhead).
+// Every phase maps ONE 4-byte word of the window to one lane, so LDS traffic is bank-conflict free.
+template <int TB_, int RH_> struct TileGeom {
+    static constexpr int TBv = TB_;
+    static constexpr int Wv = LH + TB_ + RH_;            // staged bytes
+    static constexpr int NW32 = (Wv + WPAD) / 4;         // dwords of text / records
+    static constexpr int NBW = Wv / 32 + 1;              // bitmap words incl. the bit for position W
+    static constexpr int QCAP = ((Wv + 1) / 2 + 63) / 64 * 64;   // per-tile miss list capacity
+    static_assert(Wv % 32 == 0 && NBW <= NT, "window must be a multiple of 32 bytes and fit one scan");
+};
 
+template <int TB_, int RH_>
 __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_txt[W + WPAD];
-    __shared__ __attribute__((aligned(16))) uint8_t s_rec[W + WPAD];
-    __shared__ uint32_t s_cbits[NWORDS + 1];
-    __shared__ uint32_t s_tbits[NWORDS + 1];
-    __shared__ uint16_t s_cpos[W + 2];
+    using G = TileGeom<TB_, RH_>;
+    constexpr int Wv = G::Wv;
+    __shared__ __attribute__((aligned(16))) uint32_t s_txt32[G::NW32];
+    __shared__ __attribute__((aligned(16))) uint32_t s_rec32[G::NW32];
+    __shared__ uint32_t s_ts[G::NBW + 1];                // text-start bits of the window
+    __shared__ uint32_t s_sk[G::NBW + 1];                // special-literal bits of the window
+    __shared__ uint32_t s_cbits[G::NBW + 1];
+    __shared__ uint32_t s_tbits[G::NBW + 1];
+    __shared__ uint16_t s_cpos[Wv + 2];
     __shared__ uint8_t s_ascii[128];
     __shared__ uint32_t s_wsum[NT / 64];
     __shared__ uint32_t s_total;
+    __shared__ uint32_t s_nq[2];
+    uint8_t* const s_txt = reinterpret_cast<uint8_t*>(s_txt32);
+    uint8_t* const s_rec = reinterpret_cast<uint8_t*>(s_rec32);
+#define SPL_STAMP(i) do { if (b.dbg && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) b.dbg[i] = clock64(); } while (0)
 
     const int tid = threadIdx.x;
-    const int64_t t0 = (int64_t)blockIdx.x * TB;
+    const int64_t t0 = (int64_t)blockIdx.x * TB_;
     const int64_t w0 = t0 - LH;                       // global position of window index 0
     const int64_t B = b.n_bytes;
 
-    // ---- stage text (coalesced 16 B per lane) -------------------------------------------
-    for (int v = tid; v < (W + WPAD) / 16; v += NT) {
+    // ---- stage text (coalesced 16 B per lane) and the window's flag bits ------------------------
+    for (int v = tid; v < (Wv + WPAD) / 16; v += NT) {
         const int64_t g = w0 + (int64_t)v * 16;
         uint4 x = make_uint4(0, 0, 0, 0);
         if (g >= 0 && g + 16 <= B) x = *reinterpret_cast<const uint4*>(b.text + g);
         else if (g >= 0 && g < B) {
-            uint8_t tmp[16];
-            for (int k = 0; k < 16; k++) tmp[k] = (g + k < B) ? b.text[g + k] : 0;
-            x = *reinterpret_cast<uint4*>(tmp);
+            uint32_t tmp[4] = {0, 0, 0, 0};
+            for (int k = 0; k < 16; k++)
+                if (g + k < B) tmp[k >> 2] |= (uint32_t)b.text[g + k] << (8 * (k & 3));
+            x = make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]);
         }
-        *reinterpret_cast<uint4*>(s_txt + v * 16) = x;
+        *reinterpret_cast<uint4*>(s_txt32 + v * 4) = x;
+    }
+    if (tid < G::NBW + 1) {
+        const int64_t wi = (w0 >> 5) + tid;           // w0 is a multiple of 32
+        const bool in = wi >= 0 && wi * 32 < B;
+        s_ts[tid] = in ? b.tstart[wi] : 0u;
+        s_sk[tid] = (in && b.skip) ? b.skip[wi] : 0u;
+        s_cbits[tid] = 0;
+        s_tbits[tid] = 0;
     }
     if (tid < 128) s_ascii[tid] = T.ucls_stage2[((uint32_t)T.ucls_stage1[0] << T.ucls_shift) + tid];
-    for (int v = tid; v < NWORDS + 1; v += NT) { s_cbits[v] = 0; s_tbits[v] = 0; }
+    if (tid < 2) s_nq[tid] = 0;
+    SPL_STAMP(0);
     __syncthreads();
+    SPL_STAMP(1);
 
-    // ---- classify: one record per byte -------------------------------------------------------
-    const int iB = (B - w0 < (int64_t)W) ? (int)(B - w0) : W;    // first index past the text
-    const int iT = (B - w0 < (int64_t)(W + WPAD)) ? (int)(B - w0) : W + WPAD;   // staged text end
-    for (int v = tid; v < (W + WPAD) / 16; v += NT) {
-        const int i0 = v * 16;
-        const int64_t g0 = w0 + i0;
-        uint32_t ts_bits = 0, sk_bits = 0;
-        if (g0 >= 0 && g0 < B) {
-            ts_bits = (b.tstart[g0 >> 5] >> (g0 & 31)) & 0xFFFFu;
-            if (b.skip) sk_bits = (b.skip[g0 >> 5] >> (g0 & 31)) & 0xFFFFu;
-        }
-        uint8_t rec[16];
+    // ---- classify: one record per byte, one word per lane -----------------------------------------
+    const int iB = (B - w0 < (int64_t)Wv) ? (int)(B - w0) : Wv;   // first index past the text
+    const int iT = (B - w0 < (int64_t)(Wv + WPAD)) ? (int)(B - w0) : Wv + WPAD;   // staged text end
+    for (int wi = tid; wi < G::NW32; wi += NT) {
+        const int i0 = wi * 4;
+        const uint32_t tw = s_txt32[wi];
+        const uint32_t ts4 = i0 < Wv ? (s_ts[i0 >> 5] >> (i0 & 31)) & 0xFu : 0u;
+        const uint32_t sk4 = i0 < Wv ? (s_sk[i0 >> 5] >> (i0 & 31)) & 0xFu : 0u;
+        uint32_t out = 0;
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
+        for (int k = 0; k < 4; k++) {
             const int i = i0 + k;
             uint32_t r;
             if (i >= iB) {
-                r = (i == iB && iB < W) ? (uint32_t)(C_EOT | CB_TSTART | CB_SYNC) : (uint32_t)C_WEND;
+                r = (i == iB && iB < Wv) ? (uint32_t)(C_EOT | CB_TSTART | CB_SYNC) : (uint32_t)C_WEND;
             } else if (w0 + i < 0) {
                 r = C_CONT;
-            } else if ((sk_bits >> k) & 1u) {
+            } else if ((sk4 >> k) & 1u) {
                 r = C_EOT | CB_TSTART;                 // inside a special literal: no text here
             } else {
-                const uint32_t c0 = s_txt[i];
+                const uint32_t c0 = (tw >> (8 * k)) & 0xFFu;
                 if (c0 < 0x80u) r = s_ascii[c0];
                 else if (c0 < 0xC0u) r = C_CONT;
                 else {
@@ -189,45 +216,48 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
                     const uint32_t cls = (len == want) ? cp_class(T, decode_at(tx, i, c0)) : (uint32_t)C_P;
                     r = cls | ((len - 1) << CB_LEN_SHIFT);
                 }
-                if ((ts_bits >> k) & 1u) r |= CB_TSTART | CB_SYNC;
+                if ((ts4 >> k) & 1u) r |= CB_TSTART | CB_SYNC;
             }
-            rec[k] = (uint8_t)r;
+            out |= r << (8 * k);
         }
-        *reinterpret_cast<uint4*>(s_rec + i0) = *reinterpret_cast<uint4*>(rec);
+        s_rec32[wi] = out;
     }
     __syncthreads();
+    SPL_STAMP(2);
 
     // ---- sync flags: (class of previous char, class here) --------------------------------------
     // Only positions a chain can start from or stop at need the flag: the tile and its right halo.
-    for (int v = tid; v < (W - LH) / 16; v += NT) {
-        const int i0 = LH + v * 16;
-        uint4 rv = *reinterpret_cast<uint4*>(s_rec + i0);
-        uint8_t* r = reinterpret_cast<uint8_t*>(&rv);
-        bool changed = false;
+    for (int wi = LH / 4 + tid; wi < Wv / 4; wi += NT) {
+        const int i0 = wi * 4;
+        uint32_t rv = s_rec32[wi];
+        uint32_t add = 0;
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const uint32_t rr = r[k];
+        for (int k = 0; k < 4; k++) {
+            const uint32_t rr = (rv >> (8 * k)) & 0xFFu;
             const uint32_t cur = rr & CB_CLASS;
             if (cur >= C_EOT || (rr & CB_SYNC)) continue;       // CONT / sentinels / already set
             int j = i0 + k - 1;
             while ((s_rec[j] & CB_CLASS) == C_CONT && j > i0 + k - 4) j--;
             const uint32_t prev = s_rec[j] & CB_CLASS;
-            if (prev < C_EOT && is_sync((int)T.pattern, prev, cur)) { r[k] = (uint8_t)(rr | CB_SYNC); changed = true; }
+            if (prev < C_EOT && is_sync((int)T.pattern, prev, cur)) add |= (uint32_t)CB_SYNC << (8 * k);
         }
-        if (changed) *reinterpret_cast<uint4*>(s_rec + i0) = rv;
+        if (add) s_rec32[wi] = rv | add;
     }
     __syncthreads();
+    SPL_STAMP(3);
 
     // ---- chains: each sync point inside the tile scans to the next sync point -------------------
     {
         LdsAcc acc{s_rec, s_txt};
-        for (int v = tid; v < TB / 16; v += NT) {
-            const int i0 = LH + v * 16;
-            const uint4 rv = *reinterpret_cast<const uint4*>(s_rec + i0);
-            const uint8_t* r = reinterpret_cast<const uint8_t*>(&rv);
+        for (int wi = LH / 4 + tid; wi < (LH + TB_) / 4; wi += NT) {
+            const int i0 = wi * 4;
+            const uint32_t rv = s_rec32[wi];
             uint32_t m = 0;
 #pragma unroll
-            for (int k = 0; k < 16; k++) m |= ((r[k] & CB_SYNC) && (r[k] & CB_CLASS) < C_EOT) ? (1u << k) : 0u;
+            for (int k = 0; k < 4; k++) {
+                const uint32_t rr = (rv >> (8 * k)) & 0xFFu;
+                m |= ((rr & CB_SYNC) && (rr & CB_CLASS) < C_EOT) ? (1u << k) : 0u;
+            }
             while (m) {
                 const int k = __ffs(m) - 1;
                 m &= m - 1;
@@ -241,11 +271,11 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
                         break;
                     }
                     p = e;
-                    if (p >= W) {                          // ended exactly on the window edge
-                        atomicOr(&s_cbits[W >> 5], 1u << (W & 31));
-                        if (w0 + W < B) {
+                    if (p >= Wv) {                         // ended exactly on the window edge
+                        atomicOr(&s_cbits[Wv >> 5], 1u << (Wv & 31));
+                        if (w0 + Wv < B) {
                             const uint32_t qi = atomicAdd(&b.qcount[3], 1u);
-                            if (qi < b.qcapdefer) b.qdefer[qi] = (uint32_t)(w0 + W);
+                            if (qi < b.qcapdefer) b.qdefer[qi] = (uint32_t)(w0 + Wv);
                         }
                         break;
                     }
@@ -258,10 +288,11 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
         }
     }
     __syncthreads();
+    SPL_STAMP(4);
 
     // ---- enumerate marked positions ------------------------------------------------------------
     {
-        uint32_t word = tid < NWORDS ? s_cbits[tid] : 0u;
+        uint32_t word = tid < G::NBW ? s_cbits[tid] : 0u;
         uint32_t cnt = __popc(word);
         // inclusive scan over 256 threads: wave scan + cross-wave sums
         uint32_t x = cnt;
@@ -282,11 +313,13 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
         }
     }
     __syncthreads();
+    SPL_STAMP(5);
 
     // ---- whole-chunk probe; the last marked position is only a terminator ------------------------
     {
         LdsAcc tx{s_rec, s_txt};
         const int K = (int)s_total;
+        uint2* tq = b.tileq + (size_t)blockIdx.x * G::QCAP;
         for (int k = tid; k + 1 < K; k += NT) {
             const int p = s_cpos[k];
             if ((s_rec[p] & CB_CLASS) >= C_EOT) continue;   // terminator on a special-literal span
@@ -296,15 +329,23 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
                 b.stage[w0 + p] = id;
                 atomicOr(&s_tbits[p >> 5], 1u << (p & 31));
             } else if (n > 1) {
-                route_miss(b, (uint32_t)(w0 + p), (uint32_t)n);
+                // misses: short and medium chunks go to this tile's own list (LDS counters, no
+                // contended global atomics); long ones to the global queue
+                if (n <= 16) tq[atomicAdd(&s_nq[0], 1u)] = make_uint2((uint32_t)(w0 + p), (uint32_t)n);
+                else if (n <= 64) tq[G::QCAP - 1 - atomicAdd(&s_nq[1], 1u)] = make_uint2((uint32_t)(w0 + p), (uint32_t)n);
+                else push_long(b, (uint32_t)(w0 + p), (uint32_t)n);
             }
         }
     }
     __syncthreads();
-    if (tid < NWORDS) {
+    SPL_STAMP(6);
+    if (tid < G::NBW) {
         const uint32_t wv = s_tbits[tid];
         if (wv) atomicOr(&b.tbits[(w0 >> 5) + tid], wv);
     }
+    if (tid == 0) b.tile_cnt[blockIdx.x] = make_uint2(s_nq[0], s_nq[1]);
+    SPL_STAMP(7);
+#undef SPL_STAMP
 }
 
 // ------------------------------------------------------------------------------------------
@@ -355,7 +396,7 @@ __global__ void k_deferred(DeviceTables T, Batch b) {
             const uint32_t n = (uint32_t)e - p;
             const uint32_t id = probe_chunk(T, acc, (int)p, (int)n);
             if (id != SPL_NO_RANK) emit_token(b, p, id);
-            else if (n > 1) route_miss(b, p, n);
+            else if (n > 1) push_long(b, p, n);     // any length: k_bpe_block takes n >= 2
             p = (uint32_t)e;
             if (p >= b.n_bytes) break;
             const uint32_t r = acc.rec((int)p);
@@ -370,34 +411,87 @@ __global__ void k_deferred(DeviceTables T, Batch b) {
 }
 
 // ------------------------------------------------------------------------------------------
-// byte_pair_encode, one lane per chunk; node arrays interleaved in LDS (node-major, lane-minor).
-template <int NMAX, int THREADS> struct LaneStore {
-    uint32_t* ids;
-    uint32_t* rks;
-    int lane;
-    __device__ __forceinline__ uint32_t& id(int i) { return ids[i * THREADS + lane]; }
-    __device__ __forceinline__ uint32_t& rk(int i) { return rks[i * THREADS + lane]; }
-};
-struct GlobalText {
-    const uint8_t* text;
-    __device__ __forceinline__ uint32_t txt(int q) const { return text[(uint32_t)q]; }
-};
+// byte_pair_encode (reference src/core/bpe.rs:67-197) with ONE NODE PER LANE: a group of G lanes
+// (G = 16: four chunks per wavefront; G = 64: one) holds a chunk of n <= G bytes, lane i = the node
+// that starts at byte i.  Per merge: key = (rank << 6 | lane) reduced with xor-shuffles inside the
+// group -> the leftmost minimum (bpe.rs:121-138); the right neighbour / the one after / the left
+// neighbour come from the group's slice of one ballot of the alive lanes; the winner takes the
+// merged id (= the pair's rank), its right neighbour dies, and the two affected pairs are
+// re-ranked by the two lanes that own them in ONE predicated pair-table probe (bpe.rs:160-166).
+// No LDS, no scratch; survivors write their id to stage[pos + lane].
+template <int G>
+__device__ __forceinline__ void bpe_group(const DeviceTables& T, const Batch& b, uint2 item, bool has) {
+    const int lane = threadIdx.x & 63;
+    const int gl = lane & (G - 1);
+    const int gbase = lane - gl;
+    const int n = has ? (int)item.y : 0;
+    const uint32_t pos = item.x;
+    uint32_t id = gl < n ? T.byte_id[b.text[pos + gl]] : SPL_DEAD;
+    bool alive = gl < n;
+    const uint32_t idn = __shfl(id, lane + 1);
+    uint32_t rk = (gl + 1 < n) ? pair_rank(T, id, idn) : SPL_NO_RANK;
+    constexpr unsigned long long GMASK = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+    for (;;) {
+        const uint32_t key = rk == SPL_NO_RANK ? 0xFFFFFFFFu : ((rk << 6) | (uint32_t)gl);
+        uint32_t m = key;
+#pragma unroll
+        for (int d = 1; d < G; d <<= 1) {
+            const uint32_t o = __shfl_xor(m, d);
+            m = o < m ? o : m;
+        }
+        const bool gactive = m != 0xFFFFFFFFu;
+        if (!__any(gactive)) break;
+        const unsigned long long ga = (__ballot(alive) >> gbase) & GMASK;
+        const int mi = (int)(m & 63u);
+        const uint32_t mn = m >> 6;
+        const unsigned long long above = ga & ~((2ull << mi) - 1ull);          // alive nodes right of mi
+        const int j = above ? __ffsll((long long)above) - 1 : 0;
+        const unsigned long long above2 = above & (above - 1ull);              // ... right of j
+        const int j2 = above2 ? __ffsll((long long)above2) - 1 : -1;
+        const unsigned long long below = ga & ((1ull << mi) - 1ull);
+        const int h = below ? 63 - __clzll((long long)below) : -1;
+        const uint32_t id_j2 = __shfl(id, gbase + (j2 >= 0 ? j2 : 0));
+        if (gactive) {
+            uint32_t L = 0, R = 0;
+            bool need = false;
+            if (gl == mi) {
+                id = mn;
+                if (j2 >= 0) { L = mn; R = id_j2; need = true; } else rk = SPL_NO_RANK;
+            } else if (gl == h) {
+                L = id; R = mn; need = true;
+            } else if (gl == j) {
+                alive = false; id = SPL_DEAD; rk = SPL_NO_RANK;
+            }
+            if (need) rk = pair_rank(T, L, R);
+        }
+    }
+    if (alive && id != SPL_NO_RANK) emit_token(b, pos + (uint32_t)gl, id);
+}
 
-template <int NMAX, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_bpe_lanes(DeviceTables T, Batch b, int which) {
-    __shared__ uint32_t s_ids[NMAX * THREADS];
-    __shared__ uint32_t s_rks[NMAX * THREADS];
-    const uint32_t nq = which == 0 ? min(b.qcount[0], b.qcap16) : min(b.qcount[1], b.qcap64);
-    const uint2* q = which == 0 ? b.q16 : b.q64;
-    LaneStore<NMAX, THREADS> st{s_ids, s_rks, (int)threadIdx.x};
-    GlobalText tx{b.text};
-    for (uint32_t it = blockIdx.x * THREADS + threadIdx.x; it < nq; it += gridDim.x * THREADS) {
-        const uint2 item = q[it];
-        const int n = (int)item.y;
-        bpe_serial(T, st, tx, (int)item.x, n);
-        for (int i = 0; i < n; i++) {
-            const uint32_t id = st.id(i);
-            if (id != SPL_DEAD && id != SPL_NO_RANK) emit_token(b, item.x + i, id);
+// One launch for both group sizes: blocks [0, ntiles*bpt) work the short lists (G = 16), blocks
+// [ntiles*bpt, 2*ntiles*bpt) the medium lists (G = 64); `bpt` blocks share one tile's list.
+__global__ __launch_bounds__(NT) void k_bpe_groups(DeviceTables T, Batch b, uint32_t ntiles, uint32_t bpt, uint32_t qcap) {
+    const uint32_t nshort_blocks = ntiles * bpt;
+    const bool medium = blockIdx.x >= nshort_blocks;
+    const uint32_t bi = medium ? blockIdx.x - nshort_blocks : blockIdx.x;
+    const uint32_t tile = bi / bpt, part = bi % bpt;
+    const uint2 cnt = b.tile_cnt[tile];
+    const uint2* tq = b.tileq + (size_t)tile * qcap;
+    if (!medium) {
+        const uint32_t c = min(cnt.x, qcap);
+        const uint32_t g = part * (NT / 16) + (threadIdx.x >> 4);
+        for (uint32_t base = 0; base < c; base += bpt * (NT / 16)) {
+            const uint32_t it = base + g;
+            const bool has = it < c;
+            bpe_group<16>(T, b, has ? tq[it] : make_uint2(0, 0), has);
+        }
+    } else {
+        const uint32_t c = min(cnt.y, qcap);
+        const uint32_t g = part * (NT / 64) + (threadIdx.x >> 6);
+        for (uint32_t base = 0; base < c; base += bpt * (NT / 64)) {
+            const uint32_t it = base + g;
+            const bool has = it < c;
+            bpe_group<64>(T, b, has ? tq[qcap - 1 - it] : make_uint2(0, 0), has);
         }
     }
 }
@@ -498,7 +592,9 @@ __global__ void k_count(Batch b) {
     b.blk_base[blk] = c;
 }
 
-// single workgroup, in-place exclusive scan of blk_base[0..n_blk) ; blk_base[n_blk] = total
+// single workgroup: exclusive scan of the per-block token counts; blk_base[n_blk] = total.
+// FUSED = true counts the bitmap words itself (small batches: saves the k_count launch).
+template <bool FUSED>
 __global__ __launch_bounds__(1024) void k_scan(Batch b) {
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_carry;
@@ -507,7 +603,19 @@ __global__ __launch_bounds__(1024) void k_scan(Batch b) {
     __syncthreads();
     for (uint32_t base = 0; base < b.n_blk; base += 1024) {
         const uint32_t i = base + tid;
-        const uint32_t v = i < b.n_blk ? b.blk_base[i] : 0u;
+        uint32_t v = 0;
+        if (i < b.n_blk) {
+            if (FUSED) {
+                const uint4* w = reinterpret_cast<const uint4*>(b.tbits + (size_t)i * 32);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const uint4 q = w[k];
+                    v += __popc(q.x) + __popc(q.y) + __popc(q.z) + __popc(q.w);
+                }
+            } else {
+                v = b.blk_base[i];
+            }
+        }
         uint32_t x = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -526,32 +634,34 @@ __global__ __launch_bounds__(1024) void k_scan(Batch b) {
     if (tid == 0) b.blk_base[b.n_blk] = s_carry;
 }
 
-// one lane per bitmap word; the 32 words of a rank block sit in one half-wave
-__global__ __launch_bounds__(NT) void k_compact(Batch b) {
-    const uint32_t w = blockIdx.x * NT + threadIdx.x;          // word index
-    const uint32_t nwords = b.n_blk * 32;
-    uint32_t word = w < nwords ? b.tbits[w] : 0u;
-    const uint32_t cnt = __popc(word);
-    uint32_t x = cnt;
-    const int l32 = threadIdx.x & 31;
+// Final pass, two roles in one launch.  Blocks [0, n_compact): one lane per bitmap word (the 32
+// words of a rank block sit in one half-wave): ranks -> dense ids[].  Blocks [n_compact, ...): one
+// lane per document: out_off[d] = rank of the document's first byte.
+__global__ __launch_bounds__(NT) void k_compact_docs(Batch b, uint32_t n_compact) {
+    if (blockIdx.x < n_compact) {
+        const uint32_t w = blockIdx.x * NT + threadIdx.x;          // word index
+        const uint32_t nwords = b.n_blk * 32;
+        uint32_t word = w < nwords ? b.tbits[w] : 0u;
+        const uint32_t cnt = __popc(word);
+        uint32_t x = cnt;
+        const int l32 = threadIdx.x & 31;
 #pragma unroll
-    for (int d = 1; d < 32; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d, 32);
-        if (l32 >= d) x += y;
+        for (int d = 1; d < 32; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d, 32);
+            if (l32 >= d) x += y;
+        }
+        if (w >= nwords || !word) return;
+        uint64_t r = (uint64_t)b.blk_base[w >> 5] + (x - cnt);
+        const uint32_t p0 = w * 32;
+        while (word) {
+            const int bit = __ffs(word) - 1;
+            word &= word - 1;
+            if (r < b.ids_cap) b.ids_out[r] = b.stage[p0 + bit];
+            r++;
+        }
+        return;
     }
-    if (w >= nwords || !word) return;
-    uint64_t r = (uint64_t)b.blk_base[w >> 5] + (x - cnt);
-    const uint32_t p0 = w * 32;
-    while (word) {
-        const int bit = __ffs(word) - 1;
-        word &= word - 1;
-        if (r < b.ids_cap) b.ids_out[r] = b.stage[p0 + bit];
-        r++;
-    }
-}
-
-__global__ void k_doc_offsets(Batch b) {
-    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t d = (blockIdx.x - n_compact) * NT + threadIdx.x;
     if (d > b.n_docs) return;
     if (d == b.n_docs) { b.off_out[d] = b.blk_base[b.n_blk]; return; }
     const uint64_t p64 = b.doc_off[d];

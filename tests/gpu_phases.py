@@ -1,0 +1,44 @@
+"""Dev aid: phase cycle stamps of one k_pretok workgroup + per-kernel event times on the bench batch."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from splintr_amd import Tokenizer, corpus, _ffi
+from splintr_amd.device import DeviceBatch, encode_device, reserve
+L = _ffi.lib()
+name = sys.argv[1] if len(sys.argv) > 1 else "cl100k_base"
+gen = sys.argv[2] if len(sys.argv) > 2 else "c2"
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
+tok = Tokenizer.from_pretrained(name)
+texts = getattr(corpus, gen)(n)
+batch = DeviceBatch(texts, torch.device("cuda", 0))
+reserve(tok, batch.n_bytes, batch.n_docs)
+st = (ctypes.c_uint64 * 16)()
+force = int(sys.argv[4]) if len(sys.argv) > 4 else 0      # 0 auto, 1 small tiles, 2 large tiles
+L.spl_debug_phases(tok.handle, 1 | (force << 1), st)
+for _ in range(5):
+    encode_device(tok, batch)
+torch.cuda.synchronize()
+L.spl_debug_phases(tok.handle, force << 1, st)
+names = ["stage text", "barrier", "classify", "sync flags", "chains", "enumerate", "probe", "flush"]
+print("k_pretok phases (shader cycles) of the middle workgroup:")
+for i in range(7):
+    print(f"  {names[i + 1]:12s} {st[i + 1] - st[i]:8d}")
+print("  total        %8d" % (st[7] - st[0]))
+qc = (ctypes.c_uint32 * 4)()
+L.spl_last_queue_counts(tok.handle, qc)
+print("queues: long", qc[2], "deferred", qc[3], "bytes", batch.n_bytes)
+L.spl_profile_enable(tok.handle, 1); L.spl_profile_reset(tok.handle)
+for _ in range(50):
+    encode_device(tok, batch)
+torch.cuda.synchronize()
+ms = (ctypes.c_double * 16)(); cnt = (ctypes.c_uint64 * 16)()
+L.spl_profile_read(tok.handle, ms, cnt); L.spl_profile_enable(tok.handle, 0)
+for i in range(16):
+    nm = L.spl_kernel_name(i)
+    if nm and cnt[i]: print(f"  {nm.decode():24s} {ms[i] / cnt[i] * 1e3:9.2f} us")
+import time
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(200): encode_device(tok, batch)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 200
+print(f"step {dt * 1e6:.1f} us  -> {batch.n_bytes / dt / 1e6:.1f} MB/s")

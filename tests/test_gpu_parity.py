@@ -102,20 +102,35 @@ def test_corpus_fixtures_sha256():
         assert h.hexdigest() == ent["sha256"], key
 
 
+def _force_tiles(name, mode):
+    """Development hook of the C ABI: 0 auto, 1 small tiles (768+224), 2 large tiles (4096+480)."""
+    import ctypes
+    from splintr_amd import _ffi
+    st = (ctypes.c_uint64 * 16)()
+    assert _ffi.lib().spl_debug_phases(tok(name).handle, mode << 1, st) == 0
+
+
+@pytest.mark.parametrize("geom", [1, 2])
 @pytest.mark.parametrize("name", ["cl100k_base", "o200k_base"])
-def test_tile_and_window_edges(coracle, name):
-    """Documents and runs placed around the 4096-byte tile edge and the 480-byte right halo."""
+def test_tile_and_window_edges(coracle, name, geom):
+    """Documents and runs placed around the tile edge and the right halo of BOTH tile geometries."""
     rng = random.Random(5)
     texts = []
-    for size in (1, 2, 31, 32, 33, 4095, 4096, 4097, 4575, 4576, 4577, 4607, 4608, 4609, 8191, 8192, 8193):
+    for size in (1, 2, 31, 32, 33, 767, 768, 769, 991, 992, 993, 1023, 1024, 1025, 1535, 1536, 1537,
+                 4095, 4096, 4097, 4575, 4576, 4577, 4607, 4608, 4609, 8191, 8192, 8193):
         texts.append(("ab cd, " * (size // 7 + 1))[:size])
-    for lead in (4000, 4090, 4096, 4100, 4500, 4570):
+    for lead in (700, 760, 768, 770, 900, 990, 4000, 4090, 4096, 4100, 4500, 4570):
         for run in (" " * 600, "a" * 700, "1" * 500, "=" * 490, "\n" * 481, "你" * 200, " \n" * 300, "x'" * 300,
                     "A" * 500 + "b", "é́" * 200):
             filler = ("lorem ipsum 12 " * 400)[:lead]
             texts.append(filler + run + " tail" + str(rng.randint(0, 9)))
-    assert_batch_equal(name, texts, coracle)
-    assert_batch_equal(name, ["".join(texts)], coracle)       # same content as ONE long document
+    _force_tiles(name, geom)
+    try:
+        assert_batch_equal(name, texts, coracle)
+        assert_batch_equal(name, ["".join(texts)], coracle)       # same content as ONE long document
+        assert_batch_equal(name, fuzz_corpus(202, 4000, 60), coracle)
+    finally:
+        _force_tiles(name, 0)
 
 
 @pytest.mark.parametrize("name", VOCABS)
