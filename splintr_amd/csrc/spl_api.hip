@@ -28,8 +28,8 @@ int fail(int code, const std::string& msg) {
             return fail(SPL_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));   \
     } while (0)
 
-enum { KI_MARK = 0, KI_SPECIAL, KI_PRETOK, KI_DEFER, KI_BPEGROUPS, KI_BPELONG, KI_COUNT, KI_SCAN, KI_COMPACT, KI_N };
-const char* const k_names[KI_N] = {"memset+k_mark_docs", "k_special_scan+ends", "k_pretok", "k_deferred", "k_bpe_groups",
+enum { KI_MARK = 0, KI_SPECIAL, KI_PRETOK, KI_DEFER, KI_BPELONG, KI_COUNT, KI_SCAN, KI_COMPACT, KI_N };
+const char* const k_names[KI_N] = {"memset+k_mark_docs", "k_special_scan+ends", "k_pretok", "k_deferred",
                                    "k_bpe_block", "k_count", "k_scan", "k_compact_docs"};
 
 template <class T> int dev_upload(const std::vector<T>& v, const T** out) {
@@ -61,7 +61,7 @@ struct spl_tokenizer {
     size_t zero_words = 0, bitmap_words = 0;
     uint32_t* d_stage = nullptr;
     uint32_t* d_rank = nullptr;
-    uint2* d_tileq = nullptr; uint2* d_tile_cnt = nullptr; uint2* d_qlong = nullptr; uint32_t* d_qdefer = nullptr;
+    uint2* d_qlong = nullptr; uint32_t* d_qdefer = nullptr;
     uint32_t qcaplong = 0, qcapdefer = 0;
     unsigned long long* d_dbg = nullptr;
     uint32_t* d_blk = nullptr;
@@ -87,9 +87,9 @@ struct spl_result {
 namespace {
 
 void free_workspace(spl_tokenizer* t) {
-    hipFree(t->d_zero); hipFree(t->d_stage); hipFree(t->d_rank); hipFree(t->d_tileq); hipFree(t->d_tile_cnt);
+    hipFree(t->d_zero); hipFree(t->d_stage); hipFree(t->d_rank);
     hipFree(t->d_qlong); hipFree(t->d_qdefer); hipFree(t->d_blk); hipFree(t->d_dbg);
-    t->d_zero = nullptr; t->d_stage = nullptr; t->d_rank = nullptr; t->d_tileq = nullptr; t->d_tile_cnt = nullptr;
+    t->d_zero = nullptr; t->d_stage = nullptr; t->d_rank = nullptr;
     t->d_qlong = nullptr; t->d_qdefer = nullptr; t->d_blk = nullptr; t->d_dbg = nullptr;
     t->cap_bytes = t->cap_docs = 0;
 }
@@ -106,15 +106,9 @@ int reserve(spl_tokenizer* t, uint64_t max_bytes, uint64_t max_docs) {
     HIP_TRY(hipMalloc((void**)&t->d_zero, t->zero_words * 4));
     HIP_TRY(hipMalloc((void**)&t->d_stage, (nb + 8192) * 4));
     HIP_TRY(hipMalloc((void**)&t->d_rank, (nb + 8192) * 4));
-    // per-tile miss lists: sized for whichever geometry needs more per input byte
-    using GS = TileGeom<SPL_TILE_SMALL>;
-    using GL = TileGeom<SPL_TILE_LARGE>;
-    const size_t tiles_s = (size_t)(nb / GS::TBv) + 2, tiles_l = (size_t)(nb / GL::TBv) + 2;
-    const size_t tileq_items = std::max(tiles_s * GS::QCAP, tiles_l * GL::QCAP);
+    const size_t tiles_s = (size_t)(nb / TileGeom<SPL_TILE_SMALL>::TBv) + 2;
     t->qcaplong = (uint32_t)(nb / 2 + 64);          // long chunks AND every miss of a deferred segment
     t->qcapdefer = (uint32_t)(2 * tiles_s + 64);
-    HIP_TRY(hipMalloc((void**)&t->d_tileq, tileq_items * 8));
-    HIP_TRY(hipMalloc((void**)&t->d_tile_cnt, tiles_s * 8));
     HIP_TRY(hipMalloc((void**)&t->d_dbg, 16 * 8));
     HIP_TRY(hipMalloc((void**)&t->d_qlong, (size_t)t->qcaplong * 8));
     HIP_TRY(hipMalloc((void**)&t->d_qdefer, (size_t)t->qcapdefer * 4));
@@ -166,7 +160,7 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
     t->last_qcount = b.qcount;
     b.sp_lits = t->d_sp_lits; b.n_special = special ? (uint32_t)t->specials.size() : 0u;
     b.stage = t->d_stage; b.rank_scr = t->d_rank;
-    b.tileq = t->d_tileq; b.tile_cnt = t->d_tile_cnt; b.qlong = t->d_qlong; b.qdefer = t->d_qdefer;
+    b.qlong = t->d_qlong; b.qdefer = t->d_qdefer;
     b.qcaplong = t->qcaplong; b.qcapdefer = t->qcapdefer;
     b.dbg = t->dbg_on ? t->d_dbg : nullptr;
     b.blk_base = t->d_blk;
@@ -177,7 +171,6 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
     // small batches: small tiles (occupancy hides latency); large batches: 4 KiB tiles
     const bool small_tiles = t->force_tile == 1 || (t->force_tile == 0 && n_bytes <= (8u << 20));
     const uint32_t tile_bytes = small_tiles ? TileGeom<SPL_TILE_SMALL>::TBv : TileGeom<SPL_TILE_LARGE>::TBv;
-    const uint32_t qcap = small_tiles ? TileGeom<SPL_TILE_SMALL>::QCAP : TileGeom<SPL_TILE_LARGE>::QCAP;
     const uint32_t ntiles = (uint32_t)((n_bytes + tile_bytes - 1) / tile_bytes);
     MARK(KI_MARK);
     HIP_TRY(hipMemsetAsync(t->d_zero, 0, ((special ? 3 : 2) * uw + 8) * 4, s));
@@ -194,12 +187,6 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
     }
     MARK(KI_DEFER);
     if (ntiles) hipLaunchKernelGGL(k_deferred, dim3(64), dim3(64), 0, s, t->dt, b);
-    MARK(KI_BPEGROUPS);
-    if (ntiles) {
-        // several workgroups share one tile's miss list while the batch is too small to fill the chip
-        const uint32_t bpt = ntiles >= 2048 ? 1u : ntiles >= 1024 ? 2u : 4u;
-        hipLaunchKernelGGL(k_bpe_groups, dim3(2 * ntiles * bpt), dim3(NT), 0, s, t->dt, b, ntiles, bpt, qcap);
-    }
     MARK(KI_BPELONG);
     if (ntiles) hipLaunchKernelGGL(k_bpe_block, dim3(std::min<uint32_t>(512, ntiles + 8)), dim3(NT), 0, s, t->dt, b);
     MARK(KI_COUNT);

@@ -6,9 +6,9 @@
 //                   the chunks, whole-chunk vocabulary probe (spl_lookup.h); misses go to queues
 //                   (reference: Tokenizer::encode, src/core/tokenizer.rs:729-808 + :703-705)
 //   k_deferred      segments that outgrew a tile window: same scanner over global memory
-//   k_bpe_groups    byte_pair_encode (src/core/bpe.rs:67-197), one node per lane: 16-lane groups
-//                   for chunks <= 16 B, whole waves for 17..64 B; everything in registers, the
-//                   leftmost-minimum search is a shuffle reduction, neighbours come from a ballot
+//                   ... and byte_pair_encode (src/core/bpe.rs:67-197) for the tile's own misses, one
+//                   node per lane: 16-lane groups for chunks <= 16 B, whole waves for 17..64 B;
+//                   nodes in registers, leftmost-minimum by DPP reduction, neighbours by ballot
 //   k_bpe_block     the same for long chunks, one workgroup per chunk, nodes in HBM scratch
 //   k_scan_count (or k_count + k_scan) / k_compact_docs
 //                   token-start bitmap -> ranks -> dense ids[] and per-document offsets (CSR)
@@ -45,8 +45,6 @@ struct Batch {
     uint32_t* stage;       // id of the token starting at this byte
     uint32_t* rank_scr;    // per-byte scratch for k_bpe_block
     uint32_t* qcount;      // [2] qlong [3] qdefer   (global, atomically appended: rare paths)
-    uint2* tileq;          // per-tile miss lists (TileGeom::QCAP items per tile): chunks <= 16 B from the
-    uint2* tile_cnt;       //   front, 17..64 B from the back; tile_cnt[t] = (n_short, n_medium)
     uint2* qlong; uint32_t* qdefer;
     uint32_t qcaplong, qcapdefer;
     unsigned long long* dbg;   // optional phase cycle stamps of one k_pretok workgroup
@@ -122,6 +120,80 @@ __device__ __forceinline__ void push_long(const Batch& b, uint32_t pos, uint32_t
     if (i < b.qcaplong) b.qlong[i] = make_uint2(pos, len);
 }
 
+// byte_pair_encode (reference src/core/bpe.rs:67-197) with ONE NODE PER LANE: a group of G lanes
+// (G = 16: four chunks per wavefront; G = 64: one) holds a chunk of n <= G bytes, lane i = the node
+// that starts at byte i.  Per merge: key = (rank << 6 | lane) min-reduced inside the group with
+// DPP row operations -> the leftmost minimum (bpe.rs:121-138); the right neighbour / the one after
+// / the left neighbour come from the group's slice of one ballot of the alive lanes; the winner
+// takes the merged id (= the pair's rank), its right neighbour dies, and the two affected pairs
+// are re-ranked by the two lanes that own them in ONE predicated pair-table probe
+// (bpe.rs:160-166).  No LDS arrays, no scratch.  Runs inside k_pretok on the tile's own misses:
+// bytes come from the staged window, survivors write stage[] and the tile's token bitmap.
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_min_u32(uint32_t x) {
+    const uint32_t y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xF, 0xF, false);
+    return y < x ? y : x;
+}
+// all-reduce(min) inside each 16-lane row: quad xor 1, quad xor 2, half-row mirror, row mirror
+__device__ __forceinline__ uint32_t row16_min(uint32_t x) {
+    x = dpp_min_u32<0xB1>(x);     // quad_perm [1,0,3,2]
+    x = dpp_min_u32<0x4E>(x);     // quad_perm [2,3,0,1]
+    x = dpp_min_u32<0x141>(x);    // row_half_mirror
+    x = dpp_min_u32<0x140>(x);    // row_mirror
+    return x;
+}
+
+template <int G>
+__device__ __forceinline__ void bpe_group(const DeviceTables& T, const uint8_t* s_txt, uint32_t* s_tbits,
+                                          uint32_t* stage_w0, int p, int n) {
+    const int lane = threadIdx.x & 63;
+    const int gl = lane & (G - 1);
+    const int gbase = lane - gl;
+    uint32_t id = gl < n ? T.byte_id[s_txt[p + gl]] : SPL_DEAD;
+    bool alive = gl < n;
+    const uint32_t idn = __shfl(id, lane + 1);
+    uint32_t rk = (gl + 1 < n) ? pair_rank(T, id, idn) : SPL_NO_RANK;
+    constexpr unsigned long long GMASK = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+    for (;;) {
+        const uint32_t key = rk == SPL_NO_RANK ? 0xFFFFFFFFu : ((rk << 6) | (uint32_t)gl);
+        uint32_t m = row16_min(key);
+        if (G == 64) {                                   // combine the four rows through SGPRs
+            const uint32_t r0 = __builtin_amdgcn_readlane(m, 0), r1 = __builtin_amdgcn_readlane(m, 16);
+            const uint32_t r2 = __builtin_amdgcn_readlane(m, 32), r3 = __builtin_amdgcn_readlane(m, 48);
+            const uint32_t a = r0 < r1 ? r0 : r1, c = r2 < r3 ? r2 : r3;
+            m = a < c ? a : c;
+        }
+        const bool gactive = m != 0xFFFFFFFFu;
+        if (!__any(gactive)) break;
+        const unsigned long long ga = (__ballot(alive) >> gbase) & GMASK;
+        const int mi = (int)(m & 63u);
+        const uint32_t mn = m >> 6;
+        const unsigned long long above = ga & ~((2ull << mi) - 1ull);          // alive nodes right of mi
+        const int j = above ? __ffsll((long long)above) - 1 : 0;
+        const unsigned long long above2 = above & (above - 1ull);              // ... right of j
+        const int j2 = above2 ? __ffsll((long long)above2) - 1 : -1;
+        const unsigned long long below = ga & ((1ull << mi) - 1ull);
+        const int h = below ? 63 - __clzll((long long)below) : -1;
+        const uint32_t id_j2 = __shfl(id, gbase + (j2 >= 0 ? j2 : 0));
+        if (gactive) {
+            uint32_t L = 0, R = 0;
+            bool need = false;
+            if (gl == mi) {
+                id = mn;
+                if (j2 >= 0) { L = mn; R = id_j2; need = true; } else rk = SPL_NO_RANK;
+            } else if (gl == h) {
+                L = id; R = mn; need = true;
+            } else if (gl == j) {
+                alive = false; id = SPL_DEAD; rk = SPL_NO_RANK;
+            }
+            if (need) rk = pair_rank(T, L, R);
+        }
+    }
+    if (alive && id != SPL_NO_RANK) {
+        stage_w0[p + gl] = id;
+        atomicOr(&s_tbits[(p + gl) >> 5], 1u << ((p + gl) & 31));
+    }
+}
+
 // Tile geometry is a template parameter: small batches use small tiles (many wavefronts, 4 bytes
 // per lane, latency hidden by occupancy), large batches use 4 KiB tiles (less halo overhead).
 // Every phase maps ONE 4-byte word of the window to one lane, so LDS traffic is bank-conflict free.
@@ -148,7 +220,8 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
     __shared__ uint8_t s_ascii[128];
     __shared__ uint32_t s_wsum[NT / 64];
     __shared__ uint32_t s_total;
-    __shared__ uint32_t s_nq[2];
+    __shared__ uint32_t s_nq[4];                         // misses: [0] short [1] medium; work cursors [2] [3]
+    __shared__ uint32_t s_miss[G::QCAP];                 // p | n << 16 : short from the front, medium from the back
     uint8_t* const s_txt = reinterpret_cast<uint8_t*>(s_txt32);
     uint8_t* const s_rec = reinterpret_cast<uint8_t*>(s_rec32);
 #define SPL_STAMP(i) do { if (b.dbg && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) b.dbg[i] = clock64(); } while (0)
@@ -180,7 +253,7 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
         s_tbits[tid] = 0;
     }
     if (tid < 128) s_ascii[tid] = T.ucls_stage2[((uint32_t)T.ucls_stage1[0] << T.ucls_shift) + tid];
-    if (tid < 2) s_nq[tid] = 0;
+    if (tid < 4) s_nq[tid] = 0;
     SPL_STAMP(0);
     __syncthreads();
     SPL_STAMP(1);
@@ -319,7 +392,6 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
     {
         LdsAcc tx{s_rec, s_txt};
         const int K = (int)s_total;
-        uint2* tq = b.tileq + (size_t)blockIdx.x * G::QCAP;
         for (int k = tid; k + 1 < K; k += NT) {
             const int p = s_cpos[k];
             if ((s_rec[p] & CB_CLASS) >= C_EOT) continue;   // terminator on a special-literal span
@@ -329,22 +401,47 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
                 b.stage[w0 + p] = id;
                 atomicOr(&s_tbits[p >> 5], 1u << (p & 31));
             } else if (n > 1) {
-                // misses: short and medium chunks go to this tile's own list (LDS counters, no
-                // contended global atomics); long ones to the global queue
-                if (n <= 16) tq[atomicAdd(&s_nq[0], 1u)] = make_uint2((uint32_t)(w0 + p), (uint32_t)n);
-                else if (n <= 64) tq[G::QCAP - 1 - atomicAdd(&s_nq[1], 1u)] = make_uint2((uint32_t)(w0 + p), (uint32_t)n);
+                // misses: short and medium chunks are merged right here by this workgroup (list in
+                // LDS); long ones go to the global queue for k_bpe_block
+                if (n <= 16) s_miss[atomicAdd(&s_nq[0], 1u)] = (uint32_t)p | ((uint32_t)n << 16);
+                else if (n <= 64) s_miss[G::QCAP - 1 - atomicAdd(&s_nq[1], 1u)] = (uint32_t)p | ((uint32_t)n << 16);
                 else push_long(b, (uint32_t)(w0 + p), (uint32_t)n);
             }
         }
     }
     __syncthreads();
     SPL_STAMP(6);
+
+    // ---- merge loop for this tile's misses: wavefronts pull work until both lists are empty ------
+    {
+        const uint32_t m16 = s_nq[0], m64 = s_nq[1];
+        uint32_t* const stage_w0 = b.stage + w0;          // window index -> global position
+        const int lane = tid & 63;
+        for (;;) {                                         // medium chunks: one per wavefront
+            uint32_t it = 0;
+            if (lane == 0) it = atomicAdd(&s_nq[3], 1u);
+            it = __builtin_amdgcn_readfirstlane(it);
+            if (it >= m64) break;
+            const uint32_t item = s_miss[G::QCAP - 1 - it];
+            bpe_group<64>(T, s_txt, s_tbits, stage_w0, (int)(item & 0xFFFFu), (int)(item >> 16));
+        }
+        for (;;) {                                         // short chunks: four per wavefront
+            uint32_t it = 0;
+            if ((lane & 15) == 0) it = atomicAdd(&s_nq[2], 1u);
+            it = __shfl(it, lane & ~15);
+            const bool has = it < m16;
+            if (!__any(has)) break;
+            const uint32_t item = has ? s_miss[it] : 0u;
+            bpe_group<16>(T, s_txt, s_tbits, stage_w0, (int)(item & 0xFFFFu), has ? (int)(item >> 16) : 0);
+        }
+    }
+    __syncthreads();
+    SPL_STAMP(7);
     if (tid < G::NBW) {
         const uint32_t wv = s_tbits[tid];
         if (wv) atomicOr(&b.tbits[(w0 >> 5) + tid], wv);
     }
-    if (tid == 0) b.tile_cnt[blockIdx.x] = make_uint2(s_nq[0], s_nq[1]);
-    SPL_STAMP(7);
+    SPL_STAMP(8);
 #undef SPL_STAMP
 }
 
@@ -411,91 +508,6 @@ __global__ void k_deferred(DeviceTables T, Batch b) {
 }
 
 // ------------------------------------------------------------------------------------------
-// byte_pair_encode (reference src/core/bpe.rs:67-197) with ONE NODE PER LANE: a group of G lanes
-// (G = 16: four chunks per wavefront; G = 64: one) holds a chunk of n <= G bytes, lane i = the node
-// that starts at byte i.  Per merge: key = (rank << 6 | lane) reduced with xor-shuffles inside the
-// group -> the leftmost minimum (bpe.rs:121-138); the right neighbour / the one after / the left
-// neighbour come from the group's slice of one ballot of the alive lanes; the winner takes the
-// merged id (= the pair's rank), its right neighbour dies, and the two affected pairs are
-// re-ranked by the two lanes that own them in ONE predicated pair-table probe (bpe.rs:160-166).
-// No LDS, no scratch; survivors write their id to stage[pos + lane].
-template <int G>
-__device__ __forceinline__ void bpe_group(const DeviceTables& T, const Batch& b, uint2 item, bool has) {
-    const int lane = threadIdx.x & 63;
-    const int gl = lane & (G - 1);
-    const int gbase = lane - gl;
-    const int n = has ? (int)item.y : 0;
-    const uint32_t pos = item.x;
-    uint32_t id = gl < n ? T.byte_id[b.text[pos + gl]] : SPL_DEAD;
-    bool alive = gl < n;
-    const uint32_t idn = __shfl(id, lane + 1);
-    uint32_t rk = (gl + 1 < n) ? pair_rank(T, id, idn) : SPL_NO_RANK;
-    constexpr unsigned long long GMASK = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
-    for (;;) {
-        const uint32_t key = rk == SPL_NO_RANK ? 0xFFFFFFFFu : ((rk << 6) | (uint32_t)gl);
-        uint32_t m = key;
-#pragma unroll
-        for (int d = 1; d < G; d <<= 1) {
-            const uint32_t o = __shfl_xor(m, d);
-            m = o < m ? o : m;
-        }
-        const bool gactive = m != 0xFFFFFFFFu;
-        if (!__any(gactive)) break;
-        const unsigned long long ga = (__ballot(alive) >> gbase) & GMASK;
-        const int mi = (int)(m & 63u);
-        const uint32_t mn = m >> 6;
-        const unsigned long long above = ga & ~((2ull << mi) - 1ull);          // alive nodes right of mi
-        const int j = above ? __ffsll((long long)above) - 1 : 0;
-        const unsigned long long above2 = above & (above - 1ull);              // ... right of j
-        const int j2 = above2 ? __ffsll((long long)above2) - 1 : -1;
-        const unsigned long long below = ga & ((1ull << mi) - 1ull);
-        const int h = below ? 63 - __clzll((long long)below) : -1;
-        const uint32_t id_j2 = __shfl(id, gbase + (j2 >= 0 ? j2 : 0));
-        if (gactive) {
-            uint32_t L = 0, R = 0;
-            bool need = false;
-            if (gl == mi) {
-                id = mn;
-                if (j2 >= 0) { L = mn; R = id_j2; need = true; } else rk = SPL_NO_RANK;
-            } else if (gl == h) {
-                L = id; R = mn; need = true;
-            } else if (gl == j) {
-                alive = false; id = SPL_DEAD; rk = SPL_NO_RANK;
-            }
-            if (need) rk = pair_rank(T, L, R);
-        }
-    }
-    if (alive && id != SPL_NO_RANK) emit_token(b, pos + (uint32_t)gl, id);
-}
-
-// One launch for both group sizes: blocks [0, ntiles*bpt) work the short lists (G = 16), blocks
-// [ntiles*bpt, 2*ntiles*bpt) the medium lists (G = 64); `bpt` blocks share one tile's list.
-__global__ __launch_bounds__(NT) void k_bpe_groups(DeviceTables T, Batch b, uint32_t ntiles, uint32_t bpt, uint32_t qcap) {
-    const uint32_t nshort_blocks = ntiles * bpt;
-    const bool medium = blockIdx.x >= nshort_blocks;
-    const uint32_t bi = medium ? blockIdx.x - nshort_blocks : blockIdx.x;
-    const uint32_t tile = bi / bpt, part = bi % bpt;
-    const uint2 cnt = b.tile_cnt[tile];
-    const uint2* tq = b.tileq + (size_t)tile * qcap;
-    if (!medium) {
-        const uint32_t c = min(cnt.x, qcap);
-        const uint32_t g = part * (NT / 16) + (threadIdx.x >> 4);
-        for (uint32_t base = 0; base < c; base += bpt * (NT / 16)) {
-            const uint32_t it = base + g;
-            const bool has = it < c;
-            bpe_group<16>(T, b, has ? tq[it] : make_uint2(0, 0), has);
-        }
-    } else {
-        const uint32_t c = min(cnt.y, qcap);
-        const uint32_t g = part * (NT / 64) + (threadIdx.x >> 6);
-        for (uint32_t base = 0; base < c; base += bpt * (NT / 64)) {
-            const uint32_t it = base + g;
-            const bool has = it < c;
-            bpe_group<64>(T, b, has ? tq[qcap - 1 - it] : make_uint2(0, 0), has);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // Long chunks: one workgroup per chunk.  Node i of the chunk at [pos, pos+n) keeps its id in
 // stage[pos+i] (where the surviving ids have to end up anyway) and the rank of the pair

@@ -20,11 +20,11 @@ for _ in range(5):
     encode_device(tok, batch)
 torch.cuda.synchronize()
 L.spl_debug_phases(tok.handle, force << 1, st)
-names = ["stage text", "barrier", "classify", "sync flags", "chains", "enumerate", "probe", "flush"]
+names = ["stage text", "barrier", "classify", "sync flags", "chains", "enumerate", "probe", "merge", "flush"]
 print("k_pretok phases (shader cycles) of the middle workgroup:")
-for i in range(7):
+for i in range(8):
     print(f"  {names[i + 1]:12s} {st[i + 1] - st[i]:8d}")
-print("  total        %8d" % (st[7] - st[0]))
+print("  total        %8d" % (st[8] - st[0]))
 qc = (ctypes.c_uint32 * 4)()
 L.spl_last_queue_counts(tok.handle, qc)
 print("queues: long", qc[2], "deferred", qc[3], "bytes", batch.n_bytes)
