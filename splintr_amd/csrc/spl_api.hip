@@ -30,7 +30,7 @@ int fail(int code, const std::string& msg) {
 
 enum { KI_MARK = 0, KI_SPECIAL, KI_PRETOK, KI_DEFER, KI_BPELONG, KI_COUNT, KI_SCAN, KI_COMPACT, KI_N };
 const char* const k_names[KI_N] = {"memset+k_mark_docs", "k_special_scan+ends", "k_pretok", "k_deferred",
-                                   "k_bpe_block", "k_count", "k_scan", "k_compact_docs"};
+                                   "k_bpe_long", "k_count", "k_scan", "k_compact_docs"};
 
 template <class T> int dev_upload(const std::vector<T>& v, const T** out) {
     void* p = nullptr;
@@ -188,7 +188,7 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
     MARK(KI_DEFER);
     if (ntiles) hipLaunchKernelGGL(k_deferred, dim3(64), dim3(64), 0, s, t->dt, b);
     MARK(KI_BPELONG);
-    if (ntiles) hipLaunchKernelGGL(k_bpe_block, dim3(std::min<uint32_t>(512, ntiles + 8)), dim3(NT), 0, s, t->dt, b);
+    if (ntiles) hipLaunchKernelGGL(k_bpe_long, dim3(std::min<uint32_t>(2048, ntiles / 4 + 8)), dim3(NT), 0, s, t->dt, b);
     MARK(KI_COUNT);
     const bool fused_scan = b.n_blk <= 8192;
     if (!fused_scan) hipLaunchKernelGGL(k_count, dim3((b.n_blk + 255) / 256), dim3(256), 0, s, b);
@@ -256,9 +256,9 @@ spl_tokenizer* spl_create(const void* vocab_splv, size_t vocab_len, const void* 
     if (up() != SPL_OK) { delete t; return nullptr; }
     t->dt.ucls_shift = t->ht.ucls_shift;
     t->dt.cjk_fast = t->ht.cjk_fast ? 1u : 0u;
-    t->dt.short_mask = (uint32_t)t->ht.short_tab.size() - 1;
+    t->dt.short_mask = (uint32_t)(t->ht.short_tab.size() / SPL_SHORT_BUCKET) - 1;
     t->dt.long_mask = (uint32_t)t->ht.long_tab.size() - 1;
-    t->dt.pair_mask = (uint32_t)t->ht.pair_tab.size() - 1;
+    t->dt.pair_mask = (uint32_t)(t->ht.pair_tab.size() / SPL_PAIR_BUCKET) - 1;
     t->dt.max_key_len = t->ht.max_key_len;
     t->dt.pattern = (uint32_t)t->ht.pattern;
     t->dt.all_bytes = t->ht.all_bytes ? 1u : 0u;
@@ -452,6 +452,15 @@ int spl_debug_phases(spl_tokenizer* t, int enable, unsigned long long stamps_out
     t->force_tile = (enable >> 1) & 3;      // development: bit 1 = force small tiles, bit 2 = force large
     return SPL_OK;
 }
+
+#ifdef SPL_MERGE_TIMING
+int spl_debug_merge_timing(unsigned long long out[8], int reset) {
+    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(spl::g_mt), z, sizeof z); return 0; }
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(spl::g_mt), 64);
+    return 0;
+}
+#endif
 
 int spl_last_queue_counts(spl_tokenizer* t, uint32_t counts_out[4]) {
     if (!t || !t->d_zero) return fail(SPL_EINVAL, "no batch has run");

@@ -51,11 +51,18 @@ enum : int { PAT_CL100K = 0, PAT_O200K = 1 };
 // ----------------------------------------------------------------------------------------
 // Lookup tables in HBM (built on the host by spl_tables.cpp, probed by the kernels).
 // ----------------------------------------------------------------------------------------
+// Both big tables are BUCKETED: a probe fetches one whole bucket with back-to-back 16-byte loads
+// (one memory round trip) and almost never needs a second bucket, because a wavefront waits for
+// its slowest lane and linear probing by single entries made that lane take 3-5 dependent trips.
+// Buckets fill left to right and nothing is ever deleted, so "last slot empty" == "bucket not
+// full" == "the key cannot have overflowed into the next bucket".
+struct alignas(16) Quad { uint32_t x, y, z, w; };       // one dwordx4 load
 // Short-key table: vocabulary entries whose key is <= 12 bytes, key stored inline.
-struct ShortEnt {            // 16 B, one dwordx4 load
+struct ShortEnt {            // 16 B
     uint32_t k0, k1, k2;     // key bytes, little endian, zero padded
     uint32_t id_len;         // id | len << 24 ; 0xFFFFFFFF = empty slot
 };
+constexpr int SPL_SHORT_BUCKET = 4;                     // entries per 64-byte bucket (one cache line)
 // Long-key table: 13..max_key_len bytes; key bytes live in a 4-byte-aligned blob.
 struct LongEnt {             // 16 B
     uint32_t tag;            // second hash, filters almost every false candidate
@@ -67,7 +74,9 @@ constexpr uint32_t SPL_EMPTY = 0xFFFFFFFFu;
 constexpr int SPL_SHORT_MAX = 12;
 // Pair table: (left id, right id) -> id of the concatenation, one u64 per entry:
 //   bits 0-20 left, 21-41 right, 42-62 merged id; all-ones = empty.  Ids < 2^21.
+// Buckets of SPL_PAIR_BUCKET entries (32 bytes).
 constexpr uint64_t SPL_PAIR_EMPTY = ~0ull;
+constexpr int SPL_PAIR_BUCKET = 4;
 constexpr uint32_t SPL_ID_BITS = 21;
 constexpr uint32_t SPL_ID_MASK = (1u << SPL_ID_BITS) - 1;
 constexpr uint32_t SPL_NO_RANK = 0xFFFFFFFFu;
@@ -79,7 +88,7 @@ struct DeviceTables {
     uint32_t ucls_shift;
     uint32_t cjk_fast;        // 1 if U+4E00..U+9FFF and U+AC00..U+D7A3 are uniformly C_LO
     // vocabulary
-    const ShortEnt* short_tab; uint32_t short_mask;
+    const ShortEnt* short_tab; uint32_t short_mask;   // masks index BUCKETS
     const LongEnt* long_tab;   uint32_t long_mask;
     const uint8_t* key_blob;
     const uint64_t* pair_tab;  uint32_t pair_mask;

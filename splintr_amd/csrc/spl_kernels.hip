@@ -9,7 +9,8 @@
 //                   ... and byte_pair_encode (src/core/bpe.rs:67-197) for the tile's own misses, one
 //                   node per lane: 16-lane groups for chunks <= 16 B, whole waves for 17..64 B;
 //                   nodes in registers, leftmost-minimum by DPP reduction, neighbours by ballot
-//   k_bpe_block     the same for long chunks, one workgroup per chunk, nodes in HBM scratch
+//   k_bpe_long      the same for long chunks: one wavefront per chunk (<= 512 B, nodes as an
+//                   index-linked list in LDS) or one workgroup per chunk (larger, nodes in HBM)
 //   k_scan_count (or k_count + k_scan) / k_compact_docs
 //                   token-start bitmap -> ranks -> dense ids[] and per-document offsets (CSR)
 //
@@ -43,7 +44,7 @@ struct Batch {
     uint32_t n_special;
     uint32_t* tbits;       // bitmap: a token starts at this byte
     uint32_t* stage;       // id of the token starting at this byte
-    uint32_t* rank_scr;    // per-byte scratch for k_bpe_block
+    uint32_t* rank_scr;    // per-byte scratch for oversize chunks (bpe_block_global)
     uint32_t* qcount;      // [2] qlong [3] qdefer   (global, atomically appended: rare paths)
     uint2* qlong; uint32_t* qdefer;
     uint32_t qcaplong, qcapdefer;
@@ -120,15 +121,17 @@ __device__ __forceinline__ void push_long(const Batch& b, uint32_t pos, uint32_t
     if (i < b.qcaplong) b.qlong[i] = make_uint2(pos, len);
 }
 
-// byte_pair_encode (reference src/core/bpe.rs:67-197) with ONE NODE PER LANE: a group of G lanes
-// (G = 16: four chunks per wavefront; G = 64: one) holds a chunk of n <= G bytes, lane i = the node
-// that starts at byte i.  Per merge: key = (rank << 6 | lane) min-reduced inside the group with
-// DPP row operations -> the leftmost minimum (bpe.rs:121-138); the right neighbour / the one after
-// / the left neighbour come from the group's slice of one ballot of the alive lanes; the winner
-// takes the merged id (= the pair's rank), its right neighbour dies, and the two affected pairs
-// are re-ranked by the two lanes that own them in ONE predicated pair-table probe
-// (bpe.rs:160-166).  No LDS arrays, no scratch.  Runs inside k_pretok on the tile's own misses:
-// bytes come from the staged window, survivors write stage[] and the tile's token bitmap.
+// byte_pair_encode (reference src/core/bpe.rs:67-197) by a GROUP OF 16 LANES holding up to
+// 16*NPL nodes in registers: node i (the token that starts at byte i of the chunk) lives in lane
+// i % 16, slot i / 16.  Four chunks per wavefront advance in lock step.  Per merge:
+//   * key = (rank << 8 | node index), minimum over the lane's slots, then a DPP min-reduction
+//     inside the 16-lane row -> the leftmost minimum (bpe.rs:121-138);
+//   * right neighbour / the one after / left neighbour from the group's alive bitmap, which every
+//     lane of the group keeps and updates identically (no ballots);
+//   * the winner takes the merged id (= the pair's rank), its right neighbour dies, and the two
+//     affected pairs are re-ranked by the two lanes that own them in one predicated pair-table
+//     probe, so both loads are in flight together (bpe.rs:160-166).
+// No LDS arrays, no scratch.  `byte_at(i)` supplies chunk bytes, `emit(i, id)` takes survivors.
 template <int CTRL> __device__ __forceinline__ uint32_t dpp_min_u32(uint32_t x) {
     const uint32_t y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xF, 0xF, false);
     return y < x ? y : x;
@@ -142,55 +145,128 @@ __device__ __forceinline__ uint32_t row16_min(uint32_t x) {
     return x;
 }
 
-template <int G>
-__device__ __forceinline__ void bpe_group(const DeviceTables& T, const uint8_t* s_txt, uint32_t* s_tbits,
-                                          uint32_t* stage_w0, int p, int n) {
+// Alive bitmaps are arrays of 32-bit words (64-bit shifts and bit scans are multi-instruction
+// and slow on the vector ALU; v_ffbl_b32 / v_ffbh_u32 / 32-bit shifts are single full-rate ops).
+template <int NW> __device__ __forceinline__ int next_set_bit(const uint32_t (&a)[NW], int from) {
+    int res = -1;                                     // lowest set bit with index >= from
+#pragma unroll
+    for (int w = NW - 1; w >= 0; w--) {
+        uint32_t x = a[w];
+        const int lo = from - 32 * w;
+        if (lo >= 32) x = 0;
+        else if (lo > 0) x &= ~((1u << lo) - 1u);
+        if (x) res = 32 * w + __ffs((int)x) - 1;
+    }
+    return res;
+}
+template <int NW> __device__ __forceinline__ int prev_set_bit(const uint32_t (&a)[NW], int before) {
+    int res = -1;                                     // highest set bit with index < before
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        uint32_t x = a[w];
+        const int hi = before - 32 * w;
+        if (hi <= 0) x = 0;
+        else if (hi < 32) x &= (1u << hi) - 1u;
+        if (x) res = 32 * w + 31 - __clz((int)x);
+    }
+    return res;
+}
+
+#ifdef SPL_MERGE_TIMING
+__device__ unsigned long long g_mt[8];
+#define MT_T(v) const long long v = clock64()
+#define MT_ACC(i, a, b_) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) g_mt[i] += (unsigned long long)((b_) - (a)); } while (0)
+#else
+#define MT_T(v)
+#define MT_ACC(i, a, b_)
+#endif
+template <int NPL, class ByteAt, class Emit>
+__device__ __forceinline__ void bpe_group16(const DeviceTables& T, int n, ByteAt byte_at, Emit emit) {
+    constexpr int NW = (16 * NPL + 31) / 32;
+    MT_T(t_init0);
     const int lane = threadIdx.x & 63;
-    const int gl = lane & (G - 1);
+    const int gl = lane & 15;
     const int gbase = lane - gl;
-    uint32_t id = gl < n ? T.byte_id[s_txt[p + gl]] : SPL_DEAD;
-    bool alive = gl < n;
-    const uint32_t idn = __shfl(id, lane + 1);
-    uint32_t rk = (gl + 1 < n) ? pair_rank(T, id, idn) : SPL_NO_RANK;
-    constexpr unsigned long long GMASK = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+    uint32_t id[NPL], rk[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; k++) {
+        const int i = gl + 16 * k;
+        id[k] = i < n ? T.byte_id[byte_at(i)] : SPL_DEAD;
+    }
+#pragma unroll
+    for (int k = 0; k < NPL; k++) {                    // initial ranks (bpe.rs:114-116)
+        const uint32_t same_slot = __shfl(id[k], gbase + ((gl + 1) & 15));
+        const uint32_t next_slot = __shfl(k + 1 < NPL ? id[k + 1 < NPL ? k + 1 : k] : (uint32_t)SPL_DEAD, gbase);
+        const uint32_t idn = gl < 15 ? same_slot : next_slot;
+        rk[k] = (gl + 16 * k + 1 < n) ? pair_rank(T, id[k], idn) : SPL_NO_RANK;
+    }
+    uint32_t alive[NW];
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        const int c = n - 32 * w;
+        alive[w] = c >= 32 ? ~0u : c > 0 ? (1u << c) - 1u : 0u;
+    }
+    MT_T(t_init1);
+    MT_ACC(0, t_init0, t_init1);
     for (;;) {
-        const uint32_t key = rk == SPL_NO_RANK ? 0xFFFFFFFFu : ((rk << 6) | (uint32_t)gl);
-        uint32_t m = row16_min(key);
-        if (G == 64) {                                   // combine the four rows through SGPRs
-            const uint32_t r0 = __builtin_amdgcn_readlane(m, 0), r1 = __builtin_amdgcn_readlane(m, 16);
-            const uint32_t r2 = __builtin_amdgcn_readlane(m, 32), r3 = __builtin_amdgcn_readlane(m, 48);
-            const uint32_t a = r0 < r1 ? r0 : r1, c = r2 < r3 ? r2 : r3;
-            m = a < c ? a : c;
+        MT_T(t0);
+        uint32_t key = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < NPL; k++) {
+            const uint32_t c = rk[k] == SPL_NO_RANK ? 0xFFFFFFFFu : ((rk[k] << 8) | (uint32_t)(gl + 16 * k));
+            key = c < key ? c : key;
         }
-        const bool gactive = m != 0xFFFFFFFFu;
-        if (!__any(gactive)) break;
-        const unsigned long long ga = (__ballot(alive) >> gbase) & GMASK;
-        const int mi = (int)(m & 63u);
-        const uint32_t mn = m >> 6;
-        const unsigned long long above = ga & ~((2ull << mi) - 1ull);          // alive nodes right of mi
-        const int j = above ? __ffsll((long long)above) - 1 : 0;
-        const unsigned long long above2 = above & (above - 1ull);              // ... right of j
-        const int j2 = above2 ? __ffsll((long long)above2) - 1 : -1;
-        const unsigned long long below = ga & ((1ull << mi) - 1ull);
-        const int h = below ? 63 - __clzll((long long)below) : -1;
-        const uint32_t id_j2 = __shfl(id, gbase + (j2 >= 0 ? j2 : 0));
-        if (gactive) {
-            uint32_t L = 0, R = 0;
-            bool need = false;
-            if (gl == mi) {
-                id = mn;
-                if (j2 >= 0) { L = mn; R = id_j2; need = true; } else rk = SPL_NO_RANK;
-            } else if (gl == h) {
-                L = id; R = mn; need = true;
-            } else if (gl == j) {
-                alive = false; id = SPL_DEAD; rk = SPL_NO_RANK;
+        const uint32_t m = row16_min(key);
+        const bool active = m != 0xFFFFFFFFu;
+        if (!__any(active)) break;
+        MT_T(t1);
+        MT_ACC(1, t0, t1);
+        const int mi = (int)(m & 255u);
+        const uint32_t mn = m >> 8;
+        // neighbours (group-uniform; meaningless but harmless when the group is idle)
+        const int j = active ? next_set_bit<NW>(alive, mi + 1) : 0;
+        const int j2 = active ? next_set_bit<NW>(alive, j + 1) : -1;
+        const int h = active ? prev_set_bit<NW>(alive, mi) : -1;
+        uint32_t sel_j2 = id[0], sel_h = id[0];
+#pragma unroll
+        for (int k = 1; k < NPL; k++) {
+            sel_j2 = (j2 >> 4) == k ? id[k] : sel_j2;
+            sel_h = (h >> 4) == k ? id[k] : sel_h;       // own slot: only meaningful in the lane that owns h
+        }
+        MT_T(t2);
+        MT_ACC(2, t1, t2);
+        const uint32_t id_j2 = __shfl(sel_j2, gbase + (j2 & 15));
+        MT_T(t3);
+        MT_ACC(3, t2, t3);
+        // the owner of mi re-ranks (mi, j2), the owner of h re-ranks (h, mi): one predicated probe,
+        // two loads in flight.  Only when both nodes sit in the same lane (NPL > 1) does that lane
+        // probe a second time.
+        const int la = mi & 15, lh = h & 15;
+        uint32_t res = SPL_NO_RANK, res2 = SPL_NO_RANK;
+        if (active) {
+            if (gl == la) { if (j2 >= 0) res = pair_rank(T, mn, id_j2); }
+            else if (h >= 0 && gl == lh) res = pair_rank(T, sel_h, mn);
+            if (NPL > 1 && h >= 0 && la == lh && gl == la) res2 = pair_rank(T, sel_h, mn);
+#ifdef SPL_MERGE_TIMING
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            { MT_T(t4); MT_ACC(4, t3, t4); if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) g_mt[6] += 1; }
+#endif
+#pragma unroll
+            for (int w = 0; w < NW; w++)
+                if ((j >> 5) == w) alive[w] &= ~(1u << (j & 31));
+#pragma unroll
+            for (int k = 0; k < NPL; k++) {
+                const int i = gl + 16 * k;
+                if (i == mi) { id[k] = mn; rk[k] = res; }          // res = NO_RANK when there is no right neighbour
+                else if (i == j) rk[k] = SPL_NO_RANK;
+                else if (i == h) rk[k] = (NPL > 1 && la == lh) ? res2 : res;
             }
-            if (need) rk = pair_rank(T, L, R);
         }
     }
-    if (alive && id != SPL_NO_RANK) {
-        stage_w0[p + gl] = id;
-        atomicOr(&s_tbits[(p + gl) >> 5], 1u << ((p + gl) & 31));
+#pragma unroll
+    for (int k = 0; k < NPL; k++) {
+        const int i = gl + 16 * k;
+        if (i < n && ((alive[(gl + 16 * k) >> 5] >> (i & 31)) & 1u) && id[k] != SPL_NO_RANK) emit(i, id[k]);
     }
 }
 
@@ -202,7 +278,9 @@ template <int TB_, int RH_> struct TileGeom {
     static constexpr int Wv = LH + TB_ + RH_;            // staged bytes
     static constexpr int NW32 = (Wv + WPAD) / 4;         // dwords of text / records
     static constexpr int NBW = Wv / 32 + 1;              // bitmap words incl. the bit for position W
-    static constexpr int QCAP = ((Wv + 1) / 2 + 63) / 64 * 64;   // per-tile miss list capacity
+    static constexpr int C16 = Wv / 2 + 1;               // miss list capacities: chunks of 2..16 bytes,
+    static constexpr int C64 = Wv / 17 + 2;              //   17..64 bytes
+    static constexpr int QCAP = C16 + C64;
     static_assert(Wv % 32 == 0 && NBW <= NT, "window must be a multiple of 32 bytes and fit one scan");
 };
 
@@ -220,8 +298,8 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
     __shared__ uint8_t s_ascii[128];
     __shared__ uint32_t s_wsum[NT / 64];
     __shared__ uint32_t s_total;
-    __shared__ uint32_t s_nq[4];                         // misses: [0] short [1] medium; work cursors [2] [3]
-    __shared__ uint32_t s_miss[G::QCAP];                 // p | n << 16 : short from the front, medium from the back
+    __shared__ uint32_t s_nq[4];                         // miss counts [0] (<= 16 B) [1] (17..64 B), work cursors [2] [3]
+    __shared__ uint32_t s_miss[G::QCAP];                 // p | n << 16, one region per size class
     uint8_t* const s_txt = reinterpret_cast<uint8_t*>(s_txt32);
     uint8_t* const s_rec = reinterpret_cast<uint8_t*>(s_rec32);
 #define SPL_STAMP(i) do { if (b.dbg && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) b.dbg[i] = clock64(); } while (0)
@@ -402,9 +480,10 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
                 atomicOr(&s_tbits[p >> 5], 1u << (p & 31));
             } else if (n > 1) {
                 // misses: short and medium chunks are merged right here by this workgroup (list in
-                // LDS); long ones go to the global queue for k_bpe_block
-                if (n <= 16) s_miss[atomicAdd(&s_nq[0], 1u)] = (uint32_t)p | ((uint32_t)n << 16);
-                else if (n <= 64) s_miss[G::QCAP - 1 - atomicAdd(&s_nq[1], 1u)] = (uint32_t)p | ((uint32_t)n << 16);
+                // LDS); long ones go to the global queue for k_bpe_long
+                const uint32_t item = (uint32_t)p | ((uint32_t)n << 16);
+                if (n <= 16) s_miss[atomicAdd(&s_nq[0], 1u)] = item;
+                else if (n <= 64) s_miss[G::C16 + atomicAdd(&s_nq[1], 1u)] = item;
                 else push_long(b, (uint32_t)(w0 + p), (uint32_t)n);
             }
         }
@@ -417,22 +496,35 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
         const uint32_t m16 = s_nq[0], m64 = s_nq[1];
         uint32_t* const stage_w0 = b.stage + w0;          // window index -> global position
         const int lane = tid & 63;
-        for (;;) {                                         // medium chunks: one per wavefront
+        // every 16-lane group pulls its own work: first the 17..64-byte chunks (four nodes per
+        // lane), then the short ones (one node per lane)
+        for (;;) {
             uint32_t it = 0;
-            if (lane == 0) it = atomicAdd(&s_nq[3], 1u);
-            it = __builtin_amdgcn_readfirstlane(it);
-            if (it >= m64) break;
-            const uint32_t item = s_miss[G::QCAP - 1 - it];
-            bpe_group<64>(T, s_txt, s_tbits, stage_w0, (int)(item & 0xFFFFu), (int)(item >> 16));
+            if ((lane & 15) == 0) it = atomicAdd(&s_nq[3], 1u);
+            it = __shfl(it, lane & ~15);
+            const bool has = it < m64;
+            if (!__any(has)) break;
+            const uint32_t item = has ? s_miss[G::C16 + it] : 0u;
+            const int p = (int)(item & 0xFFFFu);
+            bpe_group16<4>(T, has ? (int)(item >> 16) : 0, [&](int i) { return (uint32_t)s_txt[p + i]; },
+                           [&](int i, uint32_t id) {
+                               stage_w0[p + i] = id;
+                               atomicOr(&s_tbits[(p + i) >> 5], 1u << ((p + i) & 31));
+                           });
         }
-        for (;;) {                                         // short chunks: four per wavefront
+        for (;;) {
             uint32_t it = 0;
             if ((lane & 15) == 0) it = atomicAdd(&s_nq[2], 1u);
             it = __shfl(it, lane & ~15);
             const bool has = it < m16;
             if (!__any(has)) break;
             const uint32_t item = has ? s_miss[it] : 0u;
-            bpe_group<16>(T, s_txt, s_tbits, stage_w0, (int)(item & 0xFFFFu), has ? (int)(item >> 16) : 0);
+            const int p = (int)(item & 0xFFFFu);
+            bpe_group16<1>(T, has ? (int)(item >> 16) : 0, [&](int i) { return (uint32_t)s_txt[p + i]; },
+                           [&](int i, uint32_t id) {
+                               stage_w0[p + i] = id;
+                               atomicOr(&s_tbits[(p + i) >> 5], 1u << ((p + i) & 31));
+                           });
         }
     }
     __syncthreads();
@@ -493,7 +585,7 @@ __global__ void k_deferred(DeviceTables T, Batch b) {
             const uint32_t n = (uint32_t)e - p;
             const uint32_t id = probe_chunk(T, acc, (int)p, (int)n);
             if (id != SPL_NO_RANK) emit_token(b, p, id);
-            else if (n > 1) push_long(b, p, n);     // any length: k_bpe_block takes n >= 2
+            else if (n > 1) push_long(b, p, n);     // any length: k_bpe_long takes n >= 2
             p = (uint32_t)e;
             if (p >= b.n_bytes) break;
             const uint32_t r = acc.rec((int)p);
@@ -508,85 +600,183 @@ __global__ void k_deferred(DeviceTables T, Batch b) {
 }
 
 // ------------------------------------------------------------------------------------------
-// ------------------------------------------------------------------------------------------
-// Long chunks: one workgroup per chunk.  Node i of the chunk at [pos, pos+n) keeps its id in
-// stage[pos+i] (where the surviving ids have to end up anyway) and the rank of the pair
-// (i, next alive) in rank_scr[pos+i].  Each thread owns the nodes i == tid (mod NT) and caches
-// the minimum over them; per merge only the owners of the (at most three) touched nodes rescan.
-__global__ __launch_bounds__(NT) void k_bpe_block(DeviceTables T, Batch b) {
-    __shared__ unsigned long long s_red[NT / 64];
-    __shared__ unsigned long long s_best;
-    const uint32_t nq = min(b.qcount[2], b.qcaplong);
+// Long chunks (> 64 bytes; plus every miss of a deferred segment).
+//
+// bpe_wave: ONE WAVEFRONT per chunk of up to WAVE_NMAX bytes.  Nodes live in the wavefront's own
+// LDS slab as an index-linked list (id, rank of the pair with the next node, next, prev -- the
+// reference's Node, src/core/bpe.rs:43-54, minus start/len which are implied by the index); lane l
+// owns nodes l, l+64, ...  Per merge: each lane scans its <= 8 nodes, DPP min-reduction of
+// (rank << 9 | index) gives the leftmost minimum, lane 0 relinks, lanes 1 and 2 re-rank the two
+// affected pairs concurrently.  No workgroup barrier: the four wavefronts of a workgroup work
+// on four different chunks.
+// bpe_block_global: chunks beyond WAVE_NMAX (pathological single-class runs): one workgroup per
+// chunk, nodes in HBM scratch (ids in stage[], ranks in rank_scr[]), cached per-thread minima.
+constexpr int GROUP_NMAX = 256;       // 16 lanes x 16 register slots
+constexpr int WAVE_NMAX = 512;
+constexpr uint32_t NIL16 = 0xFFFFu;
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void bpe_wave(const DeviceTables& T, const Batch& b, uint32_t pos, int n, uint32_t* s_id,
+                                         uint32_t* s_rk, uint16_t* s_nx, uint16_t* s_pv) {
+    const int lane = threadIdx.x & 63;
+    for (int i = lane; i < n; i += 64) {
+        s_id[i] = T.byte_id[b.text[pos + i]];
+        s_nx[i] = (uint16_t)(i + 1 < n ? i + 1 : (int)NIL16);
+        s_pv[i] = (uint16_t)(i > 0 ? i - 1 : (int)NIL16);
+    }
+    wave_lds_sync();
+    for (int i = lane; i < n; i += 64) s_rk[i] = (i + 1 < n) ? pair_rank(T, s_id[i], s_id[i + 1]) : SPL_NO_RANK;
+    wave_lds_sync();
+    for (;;) {
+        uint32_t key = 0xFFFFFFFFu;
+        for (int i = lane; i < n; i += 64) {
+            const uint32_t r = s_rk[i];
+            const uint32_t k = r == SPL_NO_RANK ? 0xFFFFFFFFu : ((r << 9) | (uint32_t)i);
+            key = k < key ? k : key;
+        }
+        uint32_t m = row16_min(key);
+        const uint32_t r0 = __builtin_amdgcn_readlane(m, 0), r1 = __builtin_amdgcn_readlane(m, 16);
+        const uint32_t r2 = __builtin_amdgcn_readlane(m, 32), r3 = __builtin_amdgcn_readlane(m, 48);
+        const uint32_t a = r0 < r1 ? r0 : r1, c = r2 < r3 ? r2 : r3;
+        m = a < c ? a : c;
+        if (m == 0xFFFFFFFFu) break;
+        const uint32_t mi = m & 511u, mn = m >> 9;
+        const uint32_t j = s_nx[mi];                       // uniform addresses: LDS broadcasts
+        const uint32_t j2 = s_nx[j];
+        const uint32_t h = s_pv[mi];
+        const uint32_t id_j2 = j2 != NIL16 ? s_id[j2] : 0u;
+        const uint32_t id_h = h != NIL16 ? s_id[h] : 0u;
+        wave_lds_sync();
+        if (lane == 0) {
+            s_id[mi] = mn;
+            s_id[j] = SPL_DEAD;
+            s_rk[j] = SPL_NO_RANK;
+            s_nx[mi] = (uint16_t)j2;
+            if (j2 != NIL16) s_pv[j2] = (uint16_t)mi;
+        } else if (lane == 1) {
+            s_rk[mi] = j2 != NIL16 ? pair_rank(T, mn, id_j2) : SPL_NO_RANK;
+        } else if (lane == 2) {
+            if (h != NIL16) s_rk[h] = pair_rank(T, id_h, mn);
+        }
+        wave_lds_sync();
+    }
+    for (int i = lane; i < n; i += 64) {
+        const uint32_t id = s_id[i];
+        if (id != SPL_DEAD && id != SPL_NO_RANK) emit_token(b, pos + (uint32_t)i, id);
+    }
+    wave_lds_sync();
+}
+
+__device__ void bpe_block_global(const DeviceTables& T, const Batch& b, uint32_t pos, int n, unsigned long long* s_red,
+                                 unsigned long long* s_best, int* s_touch) {
     const int tid = threadIdx.x;
-    for (uint32_t it = blockIdx.x; it < nq; it += gridDim.x) {
-        const uint2 item = b.qlong[it];
-        const uint32_t pos = item.x;
-        const int n = (int)item.y;
-        uint32_t* ids = b.stage + pos;
-        uint32_t* rks = b.rank_scr + pos;
-        for (int i = tid; i < n; i += NT) ids[i] = T.byte_id[b.text[pos + i]];
-        __syncthreads();
-        for (int i = tid; i < n; i += NT) rks[i] = (i + 1 < n) ? pair_rank(T, ids[i], ids[i + 1]) : SPL_NO_RANK;
-        __syncthreads();
-        bool dirty = true;
-        unsigned long long mine = ~0ull;          // (rank << 32 | index): min == leftmost minimum
-        for (;;) {
-            if (dirty) {
-                mine = ~0ull;
-                for (int i = tid; i < n; i += NT) {
-                    const unsigned long long c = ((unsigned long long)rks[i] << 32) | (uint32_t)i;
-                    mine = c < mine ? c : mine;
-                }
-                dirty = false;
+    uint32_t* ids = b.stage + pos;
+    uint32_t* rks = b.rank_scr + pos;
+    for (int i = tid; i < n; i += NT) ids[i] = T.byte_id[b.text[pos + i]];
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) rks[i] = (i + 1 < n) ? pair_rank(T, ids[i], ids[i + 1]) : SPL_NO_RANK;
+    __syncthreads();
+    bool dirty = true;
+    unsigned long long mine = ~0ull;          // (rank << 32 | index): min == leftmost minimum
+    for (;;) {
+        if (dirty) {
+            mine = ~0ull;
+            for (int i = tid; i < n; i += NT) {
+                const unsigned long long c = ((unsigned long long)rks[i] << 32) | (uint32_t)i;
+                mine = c < mine ? c : mine;
             }
-            unsigned long long x = mine;
+            dirty = false;
+        }
+        unsigned long long x = mine;
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                const unsigned long long y = __shfl_xor(x, d);
-                x = y < x ? y : x;
-            }
-            if ((tid & 63) == 0) s_red[tid >> 6] = x;
-            __syncthreads();
-            if (tid == 0) {
-                unsigned long long m = s_red[0];
-                for (int wv = 1; wv < NT / 64; wv++) m = s_red[wv] < m ? s_red[wv] : m;
-                s_best = m;
-            }
-            __syncthreads();
-            const unsigned long long best = s_best;
-            const uint32_t mn = (uint32_t)(best >> 32);
-            if (mn == SPL_NO_RANK) break;
-            const int mi = (int)(uint32_t)best;
-            // thread 0 performs the merge (the neighbour searches walk tomb-stones; at most a
-            // token's length of them)
-            __shared__ int s_touch[3];
-            if (tid == 0) {
-                int j = mi + 1;
-                while (ids[j] == SPL_DEAD) j++;
-                ids[mi] = mn;
-                ids[j] = SPL_DEAD;
-                rks[j] = SPL_NO_RANK;
-                int j2 = j + 1;
-                while (j2 < n && ids[j2] == SPL_DEAD) j2++;
-                rks[mi] = j2 < n ? pair_rank(T, mn, ids[j2]) : SPL_NO_RANK;
-                int h = mi - 1;
-                while (h >= 0 && ids[h] == SPL_DEAD) h--;
-                if (h >= 0) rks[h] = pair_rank(T, ids[h], mn);
-                s_touch[0] = mi; s_touch[1] = j; s_touch[2] = h;
-                __threadfence_block();
-            }
-            __syncthreads();
-            const int a0 = s_touch[0] % NT, a1 = s_touch[1] % NT, a2 = s_touch[2] < 0 ? -1 : s_touch[2] % NT;
-            if (tid == a0 || tid == a1 || tid == a2) dirty = true;
-            __syncthreads();
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned long long y = __shfl_xor(x, d);
+            x = y < x ? y : x;
         }
-        // survivors become tokens (ids already sit in stage[]); only the bitmap is left to set
-        for (int i = tid; i < n; i += NT) {
-            const uint32_t id = ids[i];
-            if (id != SPL_DEAD && id != SPL_NO_RANK) atomicOr(&b.tbits[(pos + i) >> 5], 1u << ((pos + i) & 31));
+        if ((tid & 63) == 0) s_red[tid >> 6] = x;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long m = s_red[0];
+            for (int wv = 1; wv < NT / 64; wv++) m = s_red[wv] < m ? s_red[wv] : m;
+            *s_best = m;
         }
+        __syncthreads();
+        const unsigned long long best = *s_best;
+        const uint32_t mn = (uint32_t)(best >> 32);
+        if (mn == SPL_NO_RANK) break;
+        const int mi = (int)(uint32_t)best;
+        if (tid == 0) {     // the neighbour searches walk tomb-stones; at most a token's length of them
+            int j = mi + 1;
+            while (ids[j] == SPL_DEAD) j++;
+            ids[mi] = mn;
+            ids[j] = SPL_DEAD;
+            rks[j] = SPL_NO_RANK;
+            int j2 = j + 1;
+            while (j2 < n && ids[j2] == SPL_DEAD) j2++;
+            rks[mi] = j2 < n ? pair_rank(T, mn, ids[j2]) : SPL_NO_RANK;
+            int h = mi - 1;
+            while (h >= 0 && ids[h] == SPL_DEAD) h--;
+            if (h >= 0) rks[h] = pair_rank(T, ids[h], mn);
+            s_touch[0] = mi; s_touch[1] = j; s_touch[2] = h;
+            __threadfence_block();
+        }
+        __syncthreads();
+        const int a0 = s_touch[0] % NT, a1 = s_touch[1] % NT, a2 = s_touch[2] < 0 ? -1 : s_touch[2] % NT;
+        if (tid == a0 || tid == a1 || tid == a2) dirty = true;
         __syncthreads();
     }
+    // survivors become tokens (ids already sit in stage[]); only the bitmap is left to set
+    for (int i = tid; i < n; i += NT) {
+        const uint32_t id = ids[i];
+        if (id != SPL_DEAD && id != SPL_NO_RANK) atomicOr(&b.tbits[(pos + i) >> 5], 1u << ((pos + i) & 31));
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(NT) void k_bpe_long(DeviceTables T, Batch b) {
+    __shared__ uint32_t s_id[NT / 64][WAVE_NMAX];
+    __shared__ uint32_t s_rk[NT / 64][WAVE_NMAX];
+    __shared__ uint16_t s_nx[NT / 64][WAVE_NMAX];
+    __shared__ uint16_t s_pv[NT / 64][WAVE_NMAX];
+    __shared__ unsigned long long s_red[NT / 64];
+    __shared__ unsigned long long s_best;
+    __shared__ int s_touch[3];
+    const uint32_t nq = min(b.qcount[2], b.qcaplong);
+    const int wv = threadIdx.x >> 6;
+    const uint32_t nwaves = gridDim.x * (NT / 64);
+    // group phase: chunks of up to GROUP_NMAX bytes, four per wavefront, nodes in registers
+    {
+        const int lane = threadIdx.x & 63;
+        const uint32_t ngroups = nwaves * 4;
+        const uint32_t g0 = (blockIdx.x * (NT / 64) + wv) * 4 + (lane >> 4);
+        for (uint32_t base = 0; base < nq; base += ngroups) {          // uniform trip count
+            const uint32_t it = base + g0;
+            uint2 item = make_uint2(0, 0);
+            if (it < nq) item = b.qlong[it];
+            const bool has = it < nq && (int)item.y <= GROUP_NMAX;
+            if (!__any(has)) continue;
+            const uint32_t pos = item.x;
+            bpe_group16<GROUP_NMAX / 16>(T, has ? (int)item.y : 0, [&](int i) { return (uint32_t)b.text[pos + i]; },
+                                         [&](int i, uint32_t id) { emit_token(b, pos + (uint32_t)i, id); });
+        }
+    }
+    // wavefront phase: GROUP_NMAX < n <= WAVE_NMAX; item `it` belongs to wavefront it % nwaves
+    for (uint32_t it = blockIdx.x * (NT / 64) + wv; it < nq; it += nwaves) {
+        const uint2 item = b.qlong[it];
+        if ((int)item.y > GROUP_NMAX && (int)item.y <= WAVE_NMAX)
+            bpe_wave(T, b, item.x, (int)item.y, s_id[wv], s_rk[wv], s_nx[wv], s_pv[wv]);
+    }
+    __syncthreads();
+    // workgroup phase: the oversize items among this workgroup's share (uniform loop for all threads)
+    for (int w = 0; w < NT / 64; w++)
+        for (uint32_t it = blockIdx.x * (NT / 64) + w; it < nq; it += nwaves) {
+            const uint2 item = b.qlong[it];
+            if ((int)item.y > WAVE_NMAX) bpe_block_global(T, b, item.x, (int)item.y, s_red, &s_best, s_touch);
+        }
 }
 
 // ------------------------------------------------------------------------------------------

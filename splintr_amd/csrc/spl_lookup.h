@@ -22,13 +22,25 @@ SPL_HD uint32_t mask_tail(uint32_t w, int nbytes) {     // keep the low nbytes (
     return nbytes >= 4 ? w : nbytes <= 0 ? 0u : (w & ((1u << (8 * nbytes)) - 1u));
 }
 
+// NOTE: the bucket compares are written branch-free on purpose.  With early returns the compiler
+// sinks the later loads into the "not found yet" branches and a miss costs several DEPENDENT
+// memory round trips; with selects every load of the bucket is issued before the first wait.
 SPL_HD uint32_t probe_short(const DeviceTables& T, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t n) {
-    uint32_t slot = hash_short(k0, k1, k2, n) & T.short_mask;
+    uint32_t bkt = hash_short(k0, k1, k2, n) & T.short_mask;
     for (;;) {
-        const ShortEnt e = T.short_tab[slot];
-        if (e.id_len == SPL_EMPTY) return SPL_NO_RANK;
-        if (e.k0 == k0 && e.k1 == k1 && e.k2 == k2 && (e.id_len >> 24) == n) return e.id_len & 0xFFFFFFu;
-        slot = (slot + 1) & T.short_mask;
+        const Quad* q = reinterpret_cast<const Quad*>(T.short_tab + (size_t)bkt * SPL_SHORT_BUCKET);
+        const Quad e0 = q[0], e1 = q[1], e2 = q[2], e3 = q[3];     // four independent 16-byte loads
+        const bool f0 = (e0.x == k0) & (e0.y == k1) & (e0.z == k2) & ((e0.w >> 24) == n);
+        const bool f1 = (e1.x == k0) & (e1.y == k1) & (e1.z == k2) & ((e1.w >> 24) == n);
+        const bool f2 = (e2.x == k0) & (e2.y == k1) & (e2.z == k2) & ((e2.w >> 24) == n);
+        const bool f3 = (e3.x == k0) & (e3.y == k1) & (e3.z == k2) & ((e3.w >> 24) == n);
+        uint32_t r = SPL_NO_RANK;
+        r = f3 ? (e3.w & 0xFFFFFFu) : r;
+        r = f2 ? (e2.w & 0xFFFFFFu) : r;
+        r = f1 ? (e1.w & 0xFFFFFFu) : r;
+        r = f0 ? (e0.w & 0xFFFFFFu) : r;
+        if ((f0 | f1 | f2 | f3) | (e3.w == SPL_EMPTY)) return r;   // found, or bucket not full: no overflow
+        bkt = (bkt + 1) & T.short_mask;
     }
 }
 
@@ -66,12 +78,22 @@ template <class TX> SPL_HD uint32_t probe_chunk(const DeviceTables& T, const TX&
 SPL_HD uint32_t pair_rank(const DeviceTables& T, uint32_t l, uint32_t r) {
     if ((l | r) > SPL_ID_MASK) return SPL_NO_RANK;      // an unknown single byte never merges
     const uint64_t key = pair_key(l, r);
-    uint32_t slot = hash_pair(l, r) & T.pair_mask;
+    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);       // key occupies bits 0..41
+    uint32_t bkt = hash_pair(l, r) & T.pair_mask;
     for (;;) {
-        const uint64_t e = T.pair_tab[slot];
-        if (e == SPL_PAIR_EMPTY) return SPL_NO_RANK;
-        if ((e & SPL_PAIR_KEY_MASK) == key) return (uint32_t)(e >> (2 * SPL_ID_BITS));
-        slot = (slot + 1) & T.pair_mask;
+        const Quad* q = reinterpret_cast<const Quad*>(T.pair_tab + (size_t)bkt * SPL_PAIR_BUCKET);
+        const Quad a = q[0], c = q[1];                              // 4 entries, two 16-byte loads
+        const bool f0 = (a.x == klo) & ((a.y & 0x3FFu) == khi);
+        const bool f1 = (a.z == klo) & ((a.w & 0x3FFu) == khi);
+        const bool f2 = (c.x == klo) & ((c.y & 0x3FFu) == khi);
+        const bool f3 = (c.z == klo) & ((c.w & 0x3FFu) == khi);
+        uint32_t res = SPL_NO_RANK;
+        res = f3 ? (c.w >> 10) : res;
+        res = f2 ? (c.y >> 10) : res;
+        res = f1 ? (a.w >> 10) : res;
+        res = f0 ? (a.y >> 10) : res;
+        if ((f0 | f1 | f2 | f3) | ((c.z & c.w) == 0xFFFFFFFFu)) return res;   // found / bucket not full
+        bkt = (bkt + 1) & T.pair_mask;
     }
 }
 

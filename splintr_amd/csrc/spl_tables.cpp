@@ -149,8 +149,9 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
     // ---- short / long key tables ----------------------------------------------------------
     size_t n_short = 0, n_long = 0;
     for (const auto& kv : enc) (kv.first.size() <= (size_t)SPL_SHORT_MAX ? n_short : n_long)++;
-    const uint32_t scap = pow2_at_least(n_short * 2 + 2), lcap = pow2_at_least(n_long * 2 + 2);
-    out.short_tab.assign(scap, ShortEnt{0, 0, 0, SPL_EMPTY});
+    // short table: buckets of 4, about 1.5 entries per bucket on average
+    const uint32_t sbuckets = pow2_at_least(n_short * 2 / 3 + 2), lcap = pow2_at_least(n_long * 2 + 2);
+    out.short_tab.assign((size_t)sbuckets * SPL_SHORT_BUCKET, ShortEnt{0, 0, 0, SPL_EMPTY});
     out.long_tab.assign(lcap, LongEnt{0, SPL_EMPTY, 0, 0});
     out.key_blob.clear();
     for (const auto& kv : enc) {
@@ -158,9 +159,14 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
         const uint32_t n = (uint32_t)k.size();
         if (n <= (uint32_t)SPL_SHORT_MAX) {
             const uint32_t k0 = load_le(k, 0), k1 = load_le(k, 4), k2 = load_le(k, 8);
-            uint32_t slot = hash_short(k0, k1, k2, n) & (scap - 1);
-            while (out.short_tab[slot].id_len != SPL_EMPTY) slot = (slot + 1) & (scap - 1);
-            out.short_tab[slot] = ShortEnt{k0, k1, k2, kv.second | (n << 24)};
+            uint32_t bkt = hash_short(k0, k1, k2, n) & (sbuckets - 1);
+            for (;;) {                                   // first bucket with a free slot, slots left to right
+                ShortEnt* e = &out.short_tab[(size_t)bkt * SPL_SHORT_BUCKET];
+                int f = 0;
+                while (f < SPL_SHORT_BUCKET && e[f].id_len != SPL_EMPTY) f++;
+                if (f < SPL_SHORT_BUCKET) { e[f] = ShortEnt{k0, k1, k2, kv.second | (n << 24)}; break; }
+                bkt = (bkt + 1) & (sbuckets - 1);
+            }
         } else {
             uint32_t h = 0;
             for (uint32_t i = 0; i < n; i += 4) h = hash_long_step(h, load_le(k, i));
@@ -189,21 +195,27 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
         }
     }
     out.n_pairs = (uint32_t)pairs.size();
-    const uint32_t pcap = pow2_at_least(pairs.size() * 2 + 2);
-    out.pair_tab.assign(pcap, SPL_PAIR_EMPTY);
+    // buckets of 4, about 1.8 entries per bucket on average
+    const uint32_t pbuckets = pow2_at_least(pairs.size() * 5 / 9 + 2);
+    out.pair_tab.assign((size_t)pbuckets * SPL_PAIR_BUCKET, SPL_PAIR_EMPTY);
     for (const auto& pr : pairs) {
         const uint32_t l = (uint32_t)(pr.first & SPL_ID_MASK), r = (uint32_t)(pr.first >> SPL_ID_BITS);
-        uint32_t slot = hash_pair(l, r) & (pcap - 1);
-        bool dup = false;
-        while (out.pair_tab[slot] != SPL_PAIR_EMPTY) {
-            if ((out.pair_tab[slot] & SPL_PAIR_KEY_MASK) == pr.first) { dup = true; break; }
-            slot = (slot + 1) & (pcap - 1);
+        uint32_t bkt = hash_pair(l, r) & (pbuckets - 1);
+        for (;;) {
+            uint64_t* e = &out.pair_tab[(size_t)bkt * SPL_PAIR_BUCKET];
+            int f = 0;
+            bool dup = false;
+            while (f < SPL_PAIR_BUCKET && e[f] != SPL_PAIR_EMPTY) {
+                if ((e[f] & SPL_PAIR_KEY_MASK) == pr.first) { dup = true; break; }
+                f++;
+            }
+            if (dup) {   // two different tokens with the same (left,right) split would be the same bytes
+                if ((uint32_t)(e[f] >> (2 * SPL_ID_BITS)) != pr.second) { err = "pair table conflict"; return 1; }
+                break;
+            }
+            if (f < SPL_PAIR_BUCKET) { e[f] = pr.first | ((uint64_t)pr.second << (2 * SPL_ID_BITS)); break; }
+            bkt = (bkt + 1) & (pbuckets - 1);
         }
-        if (dup) {   // two different tokens with the same (left,right) split would be the same bytes
-            if ((uint32_t)(out.pair_tab[slot] >> (2 * SPL_ID_BITS)) != pr.second) { err = "pair table conflict"; return 1; }
-            continue;
-        }
-        out.pair_tab[slot] = pr.first | ((uint64_t)pr.second << (2 * SPL_ID_BITS));
     }
 
     // ---- decoder CSR (id -> raw bytes) ---------------------------------------------------------
