@@ -152,8 +152,8 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
     Batch b{};
     b.text = d_utf8; b.n_bytes = (uint32_t)n_bytes; b.doc_off = d_doc_off; b.n_docs = (uint32_t)n_docs;
     b.n_blk = (uint32_t)(n_bytes / RANK_BLK + 1);
-    // bitmaps and queue counters packed back to back for THIS batch size: one memset clears them
     const size_t uw = (size_t)b.n_blk * 32 + 32;
+    // bitmaps and queue counters packed back to back for THIS batch size: one memset clears them
     b.tbits = t->d_zero; b.tstart = t->d_zero + uw;
     b.skip = special ? t->d_zero + 2 * uw : nullptr;
     b.qcount = t->d_zero + (special ? 3 : 2) * uw;
@@ -172,6 +172,10 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
     const bool small_tiles = t->force_tile == 1 || (t->force_tile == 0 && n_bytes <= (8u << 20));
     const uint32_t tile_bytes = small_tiles ? TileGeom<SPL_TILE_SMALL>::TBv : TileGeom<SPL_TILE_LARGE>::TBv;
     const uint32_t ntiles = (uint32_t)((n_bytes + tile_bytes - 1) / tile_bytes);
+    // (A/B on the 1 MB bench batch: folding these launches together -- clean-after-use bitmaps, one
+    //  tail kernel with a grid barrier and a last-workgroup scan -- was SLOWER than this plain
+    //  sequence: back-to-back launches overlap their dispatch with the previous kernel, while
+    //  single-workgroup tails and agent-scope fences sit on the critical path.)
     MARK(KI_MARK);
     HIP_TRY(hipMemsetAsync(t->d_zero, 0, ((special ? 3 : 2) * uw + 8) * 4, s));
     if (n_docs) hipLaunchKernelGGL(k_mark_docs, dim3((uint32_t)((n_docs + 255) / 256)), dim3(256), 0, s, b);
@@ -203,7 +207,12 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
     }
     MARK(KI_N);
 #undef MARK
-    HIP_TRY(hipGetLastError());
+    {
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) {
+            return fail(SPL_EDEVICE, std::string("kernel launch: ") + hipGetErrorString(le));
+        }
+    }
     if (pf) {
         HIP_TRY(hipEventSynchronize(t->ev[KI_N]));
         for (int i = 0; i < KI_N; i++) {

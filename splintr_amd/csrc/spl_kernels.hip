@@ -574,10 +574,10 @@ __device__ __forceinline__ void emit_token(const Batch& b, uint32_t pos, uint32_
 }
 
 // One lane per deferred segment: continue the chain from its start to the next sync point.
-__global__ void k_deferred(DeviceTables T, Batch b) {
+__device__ void deferred_items(const DeviceTables& T, const Batch& b, uint32_t first, uint32_t stride) {
     const uint32_t nq = min(b.qcount[3], b.qcapdefer);
     GlobalAcc acc{&T, &b};
-    for (uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; it < nq; it += gridDim.x * blockDim.x) {
+    for (uint32_t it = first; it < nq; it += stride) {
         uint32_t p = b.qdefer[it];
         for (;;) {
             if (p >= b.n_bytes) break;
@@ -597,6 +597,9 @@ __global__ void k_deferred(DeviceTables T, Batch b) {
             if (prev < C_EOT && is_sync((int)T.pattern, prev, r & CB_CLASS)) break;
         }
     }
+}
+__global__ void k_deferred(DeviceTables T, Batch b) {
+    deferred_items(T, b, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 // ------------------------------------------------------------------------------------------
