@@ -153,17 +153,27 @@ def main():
     # ---- CPU baseline: the oracle (a port of the reference's Rayon path) on the host cores ---------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        reps, t_cpu = 0, 0.0
-        orc_t = COracle("cl100k_base", memo=True)      # with the reference's LRU-style memo + mutex
-        orc_t.encode_packed(text_np, batch.host_offsets, threads=ncpu)
-        c0 = time.perf_counter()
-        while t_cpu < 10.0 or reps < 3:
-            orc_t.encode_packed(text_np, batch.host_offsets, threads=ncpu)
-            reps += 1
-            t_cpu = time.perf_counter() - c0
-        cpu = {"value": round(batch.n_bytes * reps / t_cpu / 1e6, 2), "unit": "MB/s", "cores": ncpu, "kind": "port",
-               "sample": f"the full bench batch ({batch.n_docs} docs, {batch.n_bytes} B) x {reps} repetitions, "
-                         f"{ncpu} threads pulling documents off a shared counter (CSR in/out, no Python lists)"}
+        # sweep the thread count and the LRU-style memo, keep the best: the GPU is compared with the
+        # strongest configuration of the port on this host, not with an arbitrary one
+        best = None
+        cands = sorted({t for t in (8, 16, 32, 64, 128, ncpu) if t <= ncpu} | {min(8, ncpu)})
+        for memo in (False, True):
+            orc_t = COracle("cl100k_base", memo=memo)
+            for th in cands:
+                orc_t.encode_packed(text_np, batch.host_offsets, threads=th)
+                reps, c0 = 0, time.perf_counter()
+                while time.perf_counter() - c0 < 1.2 or reps < 3:
+                    orc_t.encode_packed(text_np, batch.host_offsets, threads=th)
+                    reps += 1
+                rate = batch.n_bytes * reps / (time.perf_counter() - c0) / 1e6
+                if best is None or rate > best[0]:
+                    best = (rate, th, memo, reps)
+        cpu = {"value": round(best[0], 2), "unit": "MB/s", "cores": best[1], "kind": "port",
+               "host_cpus": ncpu,
+               "sample": f"the full bench batch ({batch.n_docs} docs, {batch.n_bytes} B) x {best[3]} repetitions; "
+                         f"best of threads in {cands} x memo on/off (best: {best[1]} threads, "
+                         f"{'with' if best[2] else 'without'} the mutex-guarded 4096-entry memo that stands in for the "
+                         f"reference's LRU); persistent pool pulling documents off a shared counter, CSR in/out"}
 
     if rank == 0:
         out = {

@@ -13,8 +13,8 @@
  *                                                     its cost model for the baseline timing)
  *   orc_encode()         src/core/tokenizer.rs:729-808 (non-SentencePiece branch)
  *   orc_encode_special() src/core/tokenizer.rs:842-874 (Aho-Corasick Standard, non-overlapping)
- *   orc_encode_batch()   src/core/tokenizer.rs:932-942 (Rayon par_iter -> pthread pool that
- *                                                     pulls documents off a shared counter)
+ *   orc_encode_batch()   src/core/tokenizer.rs:932-942 (Rayon par_iter -> persistent pthread pool
+ *                                                     that pulls documents off a shared counter)
  *   byte-keyed hash map  FxHashMap<Vec<u8>,u32> (src/core/tokenizer.rs:302) -> open addressing
  *   vocab parse          src/core/vocab.rs:57-89 semantics (later duplicate wins), from .splv
  *
@@ -531,6 +531,50 @@ static void *batch_worker(void *arg) {
     return NULL;
 }
 
+/* Persistent worker pool (Rayon keeps one too: the reference pays no thread creation per call). */
+typedef struct {
+    pthread_t *th;
+    int n;
+    pthread_mutex_t mu;
+    pthread_cond_t cv_work, cv_done;
+    uint64_t gen;
+    int pending;
+    batch_t *job;
+    int stop;
+} pool_t;
+static pool_t g_pool = {NULL, 0, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, 0, 0, NULL, 0};
+
+static void *pool_main(void *arg) {
+    uint64_t seen = (uint64_t)(uintptr_t)arg;      /* generation at creation: only later jobs count */
+    for (;;) {
+        pthread_mutex_lock(&g_pool.mu);
+        while (g_pool.gen == seen && !g_pool.stop) pthread_cond_wait(&g_pool.cv_work, &g_pool.mu);
+        if (g_pool.stop) { pthread_mutex_unlock(&g_pool.mu); return NULL; }
+        seen = g_pool.gen;
+        batch_t *job = g_pool.job;
+        pthread_mutex_unlock(&g_pool.mu);
+        batch_worker(job);
+        pthread_mutex_lock(&g_pool.mu);
+        if (--g_pool.pending == 0) pthread_cond_signal(&g_pool.cv_done);
+        pthread_mutex_unlock(&g_pool.mu);
+    }
+}
+static void pool_resize(int n) {
+    if (g_pool.n == n) return;
+    if (g_pool.n) {
+        pthread_mutex_lock(&g_pool.mu);
+        g_pool.stop = 1;
+        pthread_cond_broadcast(&g_pool.cv_work);
+        pthread_mutex_unlock(&g_pool.mu);
+        for (int i = 0; i < g_pool.n; i++) pthread_join(g_pool.th[i], NULL);
+        free(g_pool.th);
+        g_pool.stop = 0;
+    }
+    g_pool.n = n;
+    g_pool.th = malloc(sizeof(pthread_t) * (n ? n : 1));
+    for (int i = 0; i < n; i++) pthread_create(&g_pool.th[i], NULL, pool_main, (void *)(uintptr_t)g_pool.gen);
+}
+
 /* Batch encode (tokenizer.rs:932-942).  text = concatenated UTF-8, off[ndocs+1].
  * Outputs CSR: *ids (malloc'd), out_off[ndocs+1] (caller-provided). Returns total tokens. */
 uint64_t orc_encode_batch(orc_t *t, const uint8_t *text, const uint64_t *off, uint64_t ndocs,
@@ -539,10 +583,17 @@ uint64_t orc_encode_batch(orc_t *t, const uint8_t *text, const uint64_t *off, ui
     if (nthreads < 1) nthreads = 1;
     if (nthreads == 1) batch_worker(&b);
     else {
-        pthread_t *th = malloc(sizeof(pthread_t) * nthreads);
-        for (int i = 0; i < nthreads; i++) pthread_create(&th[i], NULL, batch_worker, &b);
-        for (int i = 0; i < nthreads; i++) pthread_join(th[i], NULL);
-        free(th);
+        pool_resize(nthreads - 1);               /* the calling thread works too */
+        pthread_mutex_lock(&g_pool.mu);
+        g_pool.job = &b;
+        g_pool.pending = g_pool.n;
+        g_pool.gen++;
+        pthread_cond_broadcast(&g_pool.cv_work);
+        pthread_mutex_unlock(&g_pool.mu);
+        batch_worker(&b);
+        pthread_mutex_lock(&g_pool.mu);
+        while (g_pool.pending) pthread_cond_wait(&g_pool.cv_done, &g_pool.mu);
+        pthread_mutex_unlock(&g_pool.mu);
     }
     uint64_t total = 0;
     for (uint64_t d = 0; d < ndocs; d++) { out_off[d] = total; total += b.res[d].n; }
