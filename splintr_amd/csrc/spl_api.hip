@@ -162,7 +162,11 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
     b.stage = t->d_stage; b.rank_scr = t->d_rank;
     b.qlong = t->d_qlong; b.qdefer = t->d_qdefer;
     b.qcaplong = t->qcaplong; b.qcapdefer = t->qcapdefer;
-    b.dbg = t->dbg_on ? t->d_dbg : nullptr;
+    b.dbg = (t->dbg_on || t->prof) ? t->d_dbg : nullptr;
+    if (t->prof) {
+        const unsigned long long init[2] = {~0ull, 0ull};
+        HIP_TRY(hipMemcpyAsync(t->d_dbg + 14, init, 16, hipMemcpyHostToDevice, s));
+    }
     b.blk_base = t->d_blk;
     b.ids_out = d_ids; b.ids_cap = ids_cap; b.off_out = d_out_off;
 
@@ -218,6 +222,14 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
         for (int i = 0; i < KI_N; i++) {
             float ms = 0;
             HIP_TRY(hipEventElapsedTime(&ms, t->ev[i], t->ev[i + 1]));
+            if (i == KI_PRETOK && ntiles) {
+                // the dominant kernel is timed on the device's wall clock instead (see k_pretok)
+                unsigned long long span[2];
+                HIP_TRY(hipMemcpy(span, t->d_dbg + 14, 16, hipMemcpyDeviceToHost));
+                int khz = 0;
+                HIP_TRY(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, t->device));
+                if (khz > 0 && span[1] > span[0]) ms = (float)((double)(span[1] - span[0]) / (double)khz);
+            }
             t->prof_ms[i] += ms;
             t->prof_n[i] += 1;
         }

@@ -308,6 +308,9 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
     const int64_t t0 = (int64_t)blockIdx.x * TB_;
     const int64_t w0 = t0 - LH;                       // global position of window index 0
     const int64_t B = b.n_bytes;
+    // profiling: span of this kernel on the constant-rate wall clock (start of workgroup 0, max end
+    // over all workgroups) -- what a kernel trace reports, without host-side event overhead
+    if (b.dbg && tid == 0 && blockIdx.x == 0) b.dbg[14] = (unsigned long long)wall_clock64();   // dispatched first
 
     // ---- stage text (coalesced 16 B per lane) and the window's flag bits ------------------------
     for (int v = tid; v < (Wv + WPAD) / 16; v += NT) {
@@ -534,6 +537,7 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
         if (wv) atomicOr(&b.tbits[(w0 >> 5) + tid], wv);
     }
     SPL_STAMP(8);
+    if (b.dbg && tid == 0) atomicMax(&b.dbg[15], (unsigned long long)wall_clock64());
 #undef SPL_STAMP
 }
 
