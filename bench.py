@@ -51,18 +51,19 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("SPL_BENCH_FORCE_DIST") == "1"   # the latter: 1-rank smoke of the RCCL path
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import __graft_entry__ as entry
     if rank == 0:
         entry.build()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     from splintr_amd import Tokenizer, corpus, _ffi
-    from splintr_amd.device import DeviceBatch, encode_device, reserve, result_csr
-    from splintr_amd.distributed import all_gather_csr
+    from splintr_amd.device import DeviceBatch, GatherV, encode_device, reserve, result_csr
 
     tok = Tokenizer.from_pretrained("cl100k_base", device=local_rank)
     texts = corpus.c2(args.docs, seed=1002 + rank)          # rank-distinct shard, same distribution
@@ -70,12 +71,12 @@ def main():
     reserve(tok, batch.n_bytes, batch.n_docs)
     L = _ffi.lib()
 
+    gv = None
+
     def step():
         encode_device(tok, batch)
-        if world > 1:
-            dc = batch.out_off[1:] - batch.out_off[:-1]
-            return all_gather_csr(batch.ids, batch.out_off[-1], dc)
-        return None
+        if gv is not None:
+            gv.submit(batch)          # pack -> async RCCL all-gather -> (unpack of the previous batch)
 
     # ---- untimed verification pass: bit-exact vs the oracle on this very batch -----------------
     step()
@@ -90,20 +91,43 @@ def main():
     if not (np.array_equal(ids, o_ids) and np.array_equal(off, o_off)):
         raise SystemExit(f"rank {rank}: HIP result differs from the oracle -- refusing to report a throughput")
 
+    if use_dist:
+        # size the slabs from the largest shard (one-time, untimed), then check that the exchange
+        # reproduces this rank's ids and offsets at its place in the global CSR
+        mx = torch.tensor([n_tokens, batch.n_docs], dtype=torch.int64, device=dev)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        gv = GatherV(tok, dev, max_docs=int(mx[1].item()), max_tokens=int(int(mx[0].item()) * 1.02) + 64)
+        step()
+        g_ids, g_off = gv.finish()
+        torch.cuda.synchronize()
+        assert not gv.overflowed()
+        cnt = torch.tensor([n_tokens, batch.n_docs], dtype=torch.int64, device=dev)
+        allc = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(allc, cnt)
+        allc = torch.stack(allc).cpu().numpy()
+        t_before, d_before = int(allc[:rank, 0].sum()), int(allc[:rank, 1].sum())
+        assert int(g_off[int(allc[:, 1].sum())].item()) == int(allc[:, 0].sum())
+        assert np.array_equal(g_ids[t_before:t_before + n_tokens].cpu().numpy().view(np.uint32), ids)
+        assert np.array_equal((g_off[d_before:d_before + batch.n_docs + 1] - t_before).cpu().numpy().astype(np.uint64), off)
+
     # ---- timed region ----------------------------------------------------------------------------
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if gv is not None:
+        gv.finish()
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if gv is not None:
+        gv.finish()                   # the last batch's exchange completes inside the timed region
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         et = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
         elapsed = float(et.item())
@@ -183,14 +207,14 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"cl100k_base, {args.docs} x ~1 KB mixed English/code per GPU "
                                    f"(splintr_amd.corpus.c2, seed 1002+rank), HBM-resident, CSR out"
-                                   + ("; + RCCL all-gatherv of the ragged ids" if world > 1 else ""),
+                                   + ("; + RCCL all-gatherv of the ragged ids (one all-gather of packed slabs per batch, overlapped with the next batch's encode)" if use_dist else ""),
                        "vocab": "cl100k_base", "docs_per_gpu": args.docs, "bytes_per_gpu": batch.n_bytes,
                        "tokens_per_gpu": n_tokens, "parallelism": f"doc-shard x{world}"},
             "parity": "bit-exact vs oracle (untimed verification pass on the bench batch)",
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -94,6 +94,21 @@ int spl_encode_batch_device(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_
                             uint64_t n_docs, uint32_t flags, uint32_t* d_ids, uint64_t ids_capacity,
                             uint64_t* d_out_off, void* hip_stream);
 
+/* Ragged all-gather of the CSR result across the GPUs of a node (north_star: "RCCL all-gatherv
+ * over xGMI"; the reference has nothing distributed).  RCCL has no all-gatherv, so every rank
+ * packs {T, N, local offsets, ids} into a fixed-capacity slab of u32 words, ONE all-gather of
+ * equal-sized slabs moves them (the caller's collective, e.g. torch.distributed
+ * all_gather_into_tensor on RCCL), and every rank unpacks the `world` slabs into the global CSR in
+ * rank order.  Both kernels are asynchronous on `hip_stream`; no host synchronisation is needed
+ * because the counts travel inside the slabs.
+ *   slab: [0] T, [1] N, [2 .. 2+max_docs] local out_off, then ids; cap_words >= max_docs + 4.
+ *   d_status[0] is set to 1 by the unpacker if any rank's ids exceeded its slab (re-run larger). */
+int spl_gatherv_pack(spl_tokenizer* t, const uint32_t* d_ids, const uint64_t* d_out_off, uint64_t n_docs,
+                     uint32_t* d_slab, uint64_t cap_words, uint64_t max_docs, void* hip_stream);
+int spl_gatherv_unpack(spl_tokenizer* t, const uint32_t* d_slabs, uint32_t world, uint64_t cap_words,
+                       uint64_t max_docs, uint32_t* d_all_ids, uint64_t all_ids_cap, uint64_t* d_all_off,
+                       uint32_t* d_status, void* hip_stream);
+
 /* Tokenizer::decode_bytes for a batch (src/core/tokenizer.rs:877-897, 944-958), HOST buffers:
  * ids CSR in, bytes CSR out.  *out_bytes / *out_off are malloc'd; release with spl_free. */
 int spl_decode_batch(spl_tokenizer* t, const uint32_t* ids, const uint64_t* ids_off, uint64_t n_docs,

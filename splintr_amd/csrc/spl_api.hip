@@ -464,6 +464,29 @@ int spl_profile_read(spl_tokenizer* t, double ms_out[SPL_MAX_KERNELS], uint64_t 
 }
 const char* spl_kernel_name(int index) { return (index >= 0 && index < KI_N) ? k_names[index] : nullptr; }
 
+int spl_gatherv_pack(spl_tokenizer* t, const uint32_t* d_ids, const uint64_t* d_out_off, uint64_t n_docs, uint32_t* d_slab,
+                     uint64_t cap_words, uint64_t max_docs, void* hip_stream) {
+    if (!t || !d_ids || !d_out_off || !d_slab) return fail(SPL_EINVAL, "spl_gatherv_pack: null argument");
+    if (n_docs > max_docs || cap_words < max_docs + 4 || cap_words > 0xFFFFFFFFull)
+        return fail(SPL_EINVAL, "spl_gatherv_pack: slab too small for the document table");
+    HIP_TRY(hipSetDevice(t->device));
+    hipLaunchKernelGGL(k_gatherv_pack, dim3(256), dim3(256), 0, (hipStream_t)hip_stream, d_ids, d_out_off, (uint32_t)n_docs,
+                       d_slab, (uint32_t)cap_words, (uint32_t)max_docs);
+    HIP_TRY(hipGetLastError());
+    return SPL_OK;
+}
+
+int spl_gatherv_unpack(spl_tokenizer* t, const uint32_t* d_slabs, uint32_t world, uint64_t cap_words, uint64_t max_docs,
+                       uint32_t* d_all_ids, uint64_t all_ids_cap, uint64_t* d_all_off, uint32_t* d_status, void* hip_stream) {
+    if (!t || !d_slabs || !d_all_ids || !d_all_off || !d_status || world == 0)
+        return fail(SPL_EINVAL, "spl_gatherv_unpack: bad argument");
+    HIP_TRY(hipSetDevice(t->device));
+    hipLaunchKernelGGL(k_gatherv_unpack, dim3(128, world), dim3(256), 0, (hipStream_t)hip_stream, d_slabs, world,
+                       (uint32_t)cap_words, (uint32_t)max_docs, d_all_ids, all_ids_cap, d_all_off, d_status);
+    HIP_TRY(hipGetLastError());
+    return SPL_OK;
+}
+
 int spl_debug_phases(spl_tokenizer* t, int enable, unsigned long long stamps_out[16]) {
     if (!t) return fail(SPL_EINVAL, "null handle");
     HIP_TRY(hipSetDevice(t->device));

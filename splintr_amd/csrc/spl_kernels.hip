@@ -908,4 +908,38 @@ __global__ void k_decode_copy(DecodeArgs a) {
     for (uint32_t k = s; k < e; k++) o[k - s] = a.tok_bytes[k];
 }
 
+// ------------------------------------------------------------------------------------------
+// Ragged all-gather support (multi-GPU reassembly of the CSR result).  RCCL has no all-gatherv:
+// every rank packs {T, N, local offsets[N+1], ids[T]} into a fixed-capacity slab, ONE
+// all_gather_into_tensor moves the slabs over xGMI, and every rank unpacks them into the global
+// CSR.  No host synchronisation: the token counts travel inside the slabs.
+//   slab (u32 words): [0] T  [1] N  [2 .. 2+max_docs] local out_off (N+1 used)  [2+max_docs+1 ..] ids
+__global__ void k_gatherv_pack(const uint32_t* ids, const uint64_t* out_off, uint32_t n_docs, uint32_t* slab,
+                               uint32_t cap_words, uint32_t max_docs) {
+    const uint32_t T = (uint32_t)out_off[n_docs];
+    const uint32_t ids_at = 3 + max_docs, ids_cap = cap_words - ids_at;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    if (i == 0) { slab[0] = T; slab[1] = n_docs; }
+    for (uint32_t d = i; d <= n_docs; d += stride) slab[2 + d] = (uint32_t)out_off[d];
+    const uint32_t ncopy = T < ids_cap ? T : ids_cap;        // T > ids_cap is reported by the unpacker
+    for (uint32_t k = i; k < ncopy; k += stride) slab[ids_at + k] = ids[k];
+}
+// grid.y = source rank.  status[0] is set to 1 if any slab overflowed its id capacity.
+__global__ void k_gatherv_unpack(const uint32_t* slabs, uint32_t world, uint32_t cap_words, uint32_t max_docs,
+                                 uint32_t* all_ids, uint64_t all_ids_cap, uint64_t* all_off, uint32_t* status) {
+    const uint32_t r = blockIdx.y;
+    const uint32_t ids_at = 3 + max_docs, ids_cap = cap_words - ids_at;
+    uint64_t tbase = 0, dbase = 0;
+    for (uint32_t q = 0; q < r; q++) { tbase += slabs[(size_t)q * cap_words]; dbase += slabs[(size_t)q * cap_words + 1]; }
+    const uint32_t* slab = slabs + (size_t)r * cap_words;
+    const uint32_t T = slab[0], N = slab[1];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    if (i == 0 && T > ids_cap) status[0] = 1;
+    for (uint32_t d = i; d < N; d += stride) all_off[dbase + d] = tbase + slab[2 + d];
+    if (r == world - 1 && i == 0) all_off[dbase + N] = tbase + T;
+    const uint32_t ncopy = T < ids_cap ? T : ids_cap;
+    for (uint32_t k = i; k < ncopy; k += stride)
+        if (tbase + k < all_ids_cap) all_ids[tbase + k] = slab[ids_at + k];
+}
+
 }  // namespace spl

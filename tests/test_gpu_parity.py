@@ -247,3 +247,51 @@ def test_full_size_c5_deepseek(coracle):
     from splintr_amd import corpus
     n = _check_replicated("deepseek_v3", corpus.c5(2), 50, coracle)            # 100 x 2 MiB
     assert n >= 100 * (2 << 20) - 400
+
+
+def test_gatherv_pack_unpack_two_simulated_ranks(coracle):
+    """The slab pack / unpack kernels of the ragged all-gather, without a process group: two
+    different shards are packed as if by two ranks, their slabs are laid side by side exactly as
+    all_gather_into_tensor would, and the unpacked global CSR must equal the oracle's."""
+    import torch
+    from splintr_amd import _ffi, corpus
+    from splintr_amd.device import DeviceBatch, encode_device, reserve
+    t = tok("cl100k_base")
+    dev = torch.device("cuda", 0)
+    shards = [corpus.c2(70, seed=5) + ["", "x"], corpus.c4(300, seed=6)]
+    L = _ffi.lib()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    max_docs = max(len(s) for s in shards)
+    batches = [DeviceBatch(s, dev) for s in shards]
+    for bt in batches:
+        reserve(t, bt.n_bytes, bt.n_docs)
+        encode_device(t, bt)
+    torch.cuda.synchronize()
+    max_tokens = max(int(bt.out_off[-1].item()) for bt in batches) + 7
+    cap = max_tokens + max_docs + 4
+    recv = torch.zeros(2 * cap, dtype=torch.int32, device=dev)
+    for r, bt in enumerate(batches):
+        assert L.spl_gatherv_pack(t.handle, bt.ids.data_ptr(), bt.out_off.data_ptr(), bt.n_docs,
+                                  recv[r * cap:].data_ptr(), cap, max_docs, stream) == 0
+    all_ids = torch.zeros(2 * max_tokens, dtype=torch.int32, device=dev)
+    all_off = torch.zeros(2 * max_docs + 1, dtype=torch.int64, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    assert L.spl_gatherv_unpack(t.handle, recv.data_ptr(), 2, cap, max_docs, all_ids.data_ptr(), all_ids.numel(),
+                                all_off.data_ptr(), status.data_ptr(), stream) == 0
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    texts = shards[0] + shards[1]
+    o_ids, o_off = oracle_csr(coracle("cl100k_base"), texts)
+    n = len(texts)
+    assert np.array_equal(all_off[: n + 1].cpu().numpy().astype(np.uint64), o_off)
+    assert np.array_equal(all_ids[: int(o_off[-1])].cpu().numpy().view(np.uint32), o_ids)
+    # a slab that is too small is reported, not silently truncated
+    small = max_docs + 4 + 10
+    recv2 = torch.zeros(2 * small, dtype=torch.int32, device=dev)
+    for r, bt in enumerate(batches):
+        L.spl_gatherv_pack(t.handle, bt.ids.data_ptr(), bt.out_off.data_ptr(), bt.n_docs, recv2[r * small:].data_ptr(),
+                           small, max_docs, stream)
+    L.spl_gatherv_unpack(t.handle, recv2.data_ptr(), 2, small, max_docs, all_ids.data_ptr(), all_ids.numel(),
+                         all_off.data_ptr(), status.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 1
