@@ -22,6 +22,7 @@
 #include "spl_common.h"
 #include "spl_lookup.h"
 #include "spl_scan.h"
+#include "spl_scan_masks.h"
 
 namespace spl {
 
@@ -114,6 +115,20 @@ struct LdsAcc {
         const uint32_t* w = reinterpret_cast<const uint32_t*>(txt_) + (p >> 2);
         return __builtin_amdgcn_alignbyte(w[1], w[0], p & 3);
     }
+};
+
+// LdsAcc plus the window's class bitmasks (spl_scan_masks.h)
+struct MaskLdsAcc {
+    const uint8_t* rec_;
+    const uint8_t* txt_;
+    const uint32_t* mk_;      // [MK_COUNT][nbw]
+    int nbw_, w_;
+    bool eot_;
+    __device__ __forceinline__ uint32_t rec(int q) const { return rec_[q]; }
+    __device__ __forceinline__ uint32_t txt(int q) const { return txt_[q]; }
+    __device__ __forceinline__ uint32_t mw(int which, int w) const { return mk_[which * nbw_ + w]; }
+    __device__ __forceinline__ int wbits() const { return w_; }
+    __device__ __forceinline__ bool end_is_eot() const { return eot_; }
 };
 
 __device__ __forceinline__ void push_long(const Batch& b, uint32_t pos, uint32_t len) {
@@ -292,6 +307,7 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
     __shared__ __attribute__((aligned(16))) uint32_t s_rec32[G::NW32];
     __shared__ uint32_t s_ts[G::NBW + 1];                // text-start bits of the window
     __shared__ uint32_t s_sk[G::NBW + 1];                // special-literal bits of the window
+    __shared__ uint32_t s_mk[MK_COUNT * (G::NBW + 1)];   // class bitmasks of the window (spl_scan_masks.h)
     __shared__ uint32_t s_cbits[G::NBW + 1];
     __shared__ uint32_t s_tbits[G::NBW + 1];
     __shared__ uint16_t s_cpos[Wv + 2];
@@ -379,46 +395,62 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
     __syncthreads();
     SPL_STAMP(2);
 
-    // ---- sync flags: (class of previous char, class here) --------------------------------------
-    // Only positions a chain can start from or stop at need the flag: the tile and its right halo.
-    for (int wi = LH / 4 + tid; wi < Wv / 4; wi += NT) {
-        const int i0 = wi * 4;
-        uint32_t rv = s_rec32[wi];
-        uint32_t add = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t rr = (rv >> (8 * k)) & 0xFFu;
-            const uint32_t cur = rr & CB_CLASS;
-            if (cur >= C_EOT || (rr & CB_SYNC)) continue;       // CONT / sentinels / already set
-            int j = i0 + k - 1;
-            while ((s_rec[j] & CB_CLASS) == C_CONT && j > i0 + k - 4) j--;
-            const uint32_t prev = s_rec[j] & CB_CLASS;
-            if (prev < C_EOT && is_sync((int)T.pattern, prev, cur)) add |= (uint32_t)CB_SYNC << (8 * k);
+    // ---- class bitmasks: one ballot per kind and 64-byte row; continuation bytes inherit their lead --
+    constexpr int NBW1 = G::NBW + 1;
+    for (int row = tid >> 6; row < Wv / 64; row += NT / 64) {
+        const int lane = tid & 63;
+        const int i = row * 64 + lane;
+        const uint32_t r = s_rec[i];
+        const uint32_t cls = r & CB_CLASS;
+        uint32_t kc = cls;
+        if (cls == C_CONT) {
+            int j = i - 1;
+            while (j >= 0 && (s_rec[j] & CB_CLASS) == C_CONT && j > i - 3) j--;
+            kc = j >= 0 ? (s_rec[j] & CB_CLASS) : (uint32_t)C_CONT;
         }
-        if (add) s_rec32[wi] = rv | add;
+        const uint32_t kb = kc < C_EOT ? kind_bits(kc) : 0u;
+        unsigned long long bal[MK_SY];
+#pragma unroll
+        for (int k = 0; k < MK_CS; k++) bal[k] = __ballot((kb >> k) & 1u);
+        bal[MK_CS] = __ballot(cls < C_EOT);
+        bal[MK_TS] = __ballot((r & CB_TSTART) != 0);
+        if (lane < 2 * MK_SY) {
+            const int which = lane >> 1;
+            unsigned long long v = bal[0];
+#pragma unroll
+            for (int k = 1; k < MK_SY; k++) v = which == k ? bal[k] : v;
+            s_mk[which * NBW1 + row * 2 + (lane & 1)] = (lane & 1) ? (uint32_t)(v >> 32) : (uint32_t)v;
+        }
+    }
+    if (tid < MK_COUNT) s_mk[tid * NBW1 + G::NBW - 1] = 0;   // the word of position W (never a real byte)
+    if (tid < MK_COUNT) s_mk[tid * NBW1 + G::NBW] = 0;
+    __syncthreads();
+    // ---- sync-point mask: word operations on the kind masks (same rules as is_sync) -------------
+    if (tid < G::NBW) {
+        uint32_t kw[MK_COUNT], kp[MK_COUNT];
+#pragma unroll
+        for (int k = 0; k < MK_COUNT; k++) {
+            kw[k] = k < MK_SY ? s_mk[k * NBW1 + tid] : 0u;
+            kp[k] = (k < MK_SY && tid > 0) ? s_mk[k * NBW1 + tid - 1] : 0u;
+        }
+        s_mk[MK_SY * NBW1 + tid] = sync_word((int)T.pattern, kw, kp);
     }
     __syncthreads();
     SPL_STAMP(3);
 
     // ---- chains: each sync point inside the tile scans to the next sync point -------------------
     {
-        LdsAcc acc{s_rec, s_txt};
+        const MaskLdsAcc acc{s_rec, s_txt, s_mk, NBW1, Wv, (B - w0) <= (int64_t)Wv};
         for (int wi = LH / 4 + tid; wi < (LH + TB_) / 4; wi += NT) {
             const int i0 = wi * 4;
-            const uint32_t rv = s_rec32[wi];
-            uint32_t m = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t rr = (rv >> (8 * k)) & 0xFFu;
-                m |= ((rr & CB_SYNC) && (rr & CB_CLASS) < C_EOT) ? (1u << k) : 0u;
-            }
+            uint32_t m = (s_mk[MK_SY * NBW1 + (i0 >> 5)] >> (i0 & 31)) & 0xFu;
             while (m) {
                 const int k = __ffs(m) - 1;
                 m &= m - 1;
                 int p = i0 + k;
                 for (;;) {
                     atomicOr(&s_cbits[p >> 5], 1u << (p & 31));
-                    const int e = match_end(acc, p, (int)T.pattern);
+                    const int e = match_end_m(acc, p, (int)T.pattern);
                     if (e == SPL_DEFER) {                 // the match outgrows the window
                         const uint32_t qi = atomicAdd(&b.qcount[3], 1u);
                         if (qi < b.qcapdefer) b.qdefer[qi] = (uint32_t)(w0 + p);
@@ -433,8 +465,8 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
                         }
                         break;
                     }
-                    if (s_rec[p] & (CB_SYNC | CB_TSTART)) {  // next owner's start: terminator mark
-                        atomicOr(&s_cbits[p >> 5], 1u << (p & 31));
+                    if (((s_mk[MK_SY * NBW1 + (p >> 5)] | s_mk[MK_TS * NBW1 + (p >> 5)]) >> (p & 31)) & 1u) {
+                        atomicOr(&s_cbits[p >> 5], 1u << (p & 31));   // next owner's start: terminator mark
                         break;
                     }
                 }

@@ -12,6 +12,7 @@
 
 #include "../../splintr_amd/csrc/spl_lookup.h"
 #include "../../splintr_amd/csrc/spl_scan.h"
+#include "../../splintr_amd/csrc/spl_scan_masks.h"
 #include "../../splintr_amd/csrc/spl_tables.h"
 
 using namespace spl;
@@ -181,3 +182,104 @@ int hs_encode(void* p, const uint8_t* text, int n, uint32_t* ids, uint32_t* n_pr
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Mask-based scanner (spl_scan_masks.h) driven the way k_pretok drives it: tiles of `tb` bytes
+// with a 32-byte left halo and `rh` bytes of right halo; masks are built per window from the class
+// records; every sync point inside the tile runs its chain; chains that return SPL_DEFER or run
+// off the window are finished with the byte-wise scanner over the whole text (what k_deferred
+// does).  Returns the union of marked starts.
+struct MaskWin {
+    const uint8_t* recs;      // records of the window, index 0 = window start
+    const uint8_t* text;
+    std::vector<uint32_t> mk[MK_COUNT];
+    int W;
+    bool eot;
+    int text_n_rel;           // readable text bytes relative to the window start
+    uint32_t mw(int which, int w) const { return (w >= 0 && w < (int)mk[which].size()) ? mk[which][w] : 0u; }
+    uint32_t rec(int q) const { return recs[q]; }
+    uint32_t txt(int q) const { return q < text_n_rel ? text[q] : 0u; }
+    int wbits() const { return W; }
+    bool end_is_eot() const { return eot; }
+};
+
+extern "C" int hs_split_masks(void* p, const uint8_t* text, int n, uint32_t* starts, int tb, int rh) {
+    Sim* s = (Sim*)p;
+    std::vector<uint8_t> recs;
+    classify(*s, text, n, recs);
+    recs.resize(n + 64, 0);
+    std::vector<uint8_t> mark(n + 1, 0);
+    const int LHv = 32;
+    for (int t0 = 0; t0 < n; t0 += tb) {
+        const int w0 = t0 - LHv;
+        const int W = LHv + tb + rh;
+        const int iB = (n - w0 < W) ? n - w0 : W;
+        // window-local records (positions before the text read as CONT, sentinel at iB)
+        std::vector<uint8_t> wrec(W + 64, (uint8_t)C_WEND);
+        std::vector<uint8_t> wtxt(W + 64, 0);
+        for (int i = 0; i < W + 32; i++) {
+            const int g = w0 + i;
+            if (g >= 0 && g < n) wtxt[i] = text[g];
+            if (i >= iB) continue;
+            wrec[i] = g < 0 ? (uint8_t)C_CONT : (uint8_t)(recs[g] & ~CB_SYNC);
+        }
+        if (iB < W) wrec[iB] = (uint8_t)(C_EOT | CB_TSTART);
+        MaskWin m;
+        m.recs = wrec.data(); m.text = wtxt.data(); m.W = W; m.eot = (n - w0 <= W); m.text_n_rel = W + 32;
+        const int nw = W / 32 + 1;
+        for (int k = 0; k < MK_COUNT; k++) m.mk[k].assign(nw, 0);
+        for (int i = 0; i <= W && i < (int)wrec.size(); i++) {
+            if (i > iB || (i == W && iB == W)) break;
+            const uint32_t r = wrec[i];
+            uint32_t cls = r & CB_CLASS;
+            if (r & CB_TSTART) m.mk[MK_TS][i >> 5] |= 1u << (i & 31);
+            if (i == iB) break;
+            uint32_t kc = cls;
+            if (cls == C_CONT) {                       // inherit the kind of the lead byte
+                int j = i - 1;
+                while (j >= 0 && (wrec[j] & CB_CLASS) == C_CONT && j > i - 3) j--;
+                kc = j >= 0 ? (wrec[j] & CB_CLASS) : (uint32_t)C_CONT;
+            } else if (cls < C_EOT) {
+                m.mk[MK_CS][i >> 5] |= 1u << (i & 31);
+            }
+            if (kc < C_EOT) {
+                const uint32_t kb = kind_bits(kc);
+                for (int k = 0; k < MK_CS; k++) if ((kb >> k) & 1u) m.mk[k][i >> 5] |= 1u << (i & 31);
+            }
+        }
+        for (int w = 0; w < nw; w++) {
+            uint32_t kw[MK_COUNT], kp[MK_COUNT];
+            for (int k = 0; k < MK_COUNT; k++) { kw[k] = m.mk[k][w]; kp[k] = w ? m.mk[k][w - 1] : 0u; }
+            m.mk[MK_SY][w] = sync_word(s->ht.pattern, kw, kp);
+        }
+        // chains from the sync points inside the tile
+        for (int i = LHv; i < LHv + tb && i < iB; i++) {
+            if (!bit_m(m, MK_SY, i)) continue;
+            int pos = i;
+            for (;;) {
+                mark[w0 + pos] = 1;
+                int e = match_end_m(m, pos, s->ht.pattern);
+                bool deferred = (e == SPL_DEFER);
+                if (!deferred && e >= W && w0 + e < n) { pos = e; deferred = true; mark[w0 + pos] = 1; }
+                if (deferred) {                          // finish the segment over the whole text (k_deferred)
+                    WinAcc g{recs.data(), text, n, (uint32_t)(C_EOT | CB_TSTART | CB_SYNC), n};
+                    int gp = w0 + pos;
+                    for (;;) {
+                        mark[gp] = 1;
+                        int ge = match_end(g, gp, s->ht.pattern);
+                        if (ge <= gp) return -1;
+                        gp = ge;
+                        if (gp >= n || (recs[gp] & (CB_SYNC | CB_TSTART))) break;
+                    }
+                    break;
+                }
+                if (e <= pos) return -2;
+                pos = e;
+                if (pos >= iB || bit_m(m, MK_SY, pos) || bit_m(m, MK_TS, pos)) break;
+            }
+        }
+    }
+    int k = 0;
+    for (int q = 0; q < n; q++) if (mark[q]) starts[k++] = q;
+    return k;
+}

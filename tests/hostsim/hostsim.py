@@ -16,7 +16,7 @@ _REG = {"cl100k_base": ("cl100k_base.splv", 0), "o200k_base": ("o200k_base.splv"
 
 def build():
     srcs = [os.path.join(_HERE, "hostsim.cpp"), os.path.join(_CSRC, "spl_tables.cpp")]
-    deps = srcs + [os.path.join(_CSRC, h) for h in ("spl_common.h", "spl_scan.h", "spl_lookup.h", "spl_tables.h")]
+    deps = srcs + [os.path.join(_CSRC, h) for h in ("spl_common.h", "spl_scan.h", "spl_scan_masks.h", "spl_lookup.h", "spl_tables.h")]
     if not os.path.exists(_LIB) or any(os.path.getmtime(d) > os.path.getmtime(_LIB) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", _LIB] + srcs)
     return _LIB
@@ -37,6 +37,8 @@ def lib():
         L.hs_split.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
         L.hs_split_sync.restype = ctypes.c_int
         L.hs_split_sync.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.hs_split_masks.restype = ctypes.c_int
+        L.hs_split_masks.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         L.hs_encode.restype = ctypes.c_int
         L.hs_encode.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         _lib = L
@@ -72,6 +74,13 @@ class HostSim:
         if k < 0:
             raise RuntimeError(f"hs_split_sync failed: {k}")
         return out[:k].tolist(), int(st[0]), int(st[1])
+
+    def split_masks(self, data: bytes, tb: int = 64, rh: int = 32):
+        out = np.zeros(len(data) + 1, dtype=np.uint32)
+        k = lib().hs_split_masks(self._h, data, len(data), out.ctypes.data, tb, rh)
+        if k < 0:
+            raise RuntimeError(f"hs_split_masks failed: {k}")
+        return out[:k].tolist()
 
     def encode(self, data: bytes):
         out = np.zeros(len(data) + 1, dtype=np.uint32)
