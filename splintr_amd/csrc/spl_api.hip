@@ -28,8 +28,8 @@ int fail(int code, const std::string& msg) {
             return fail(SPL_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));   \
     } while (0)
 
-enum { KI_MARK = 0, KI_SPECIAL, KI_PRETOK, KI_DEFER, KI_BPELONG, KI_COUNT, KI_SCAN, KI_COMPACT, KI_N };
-const char* const k_names[KI_N] = {"memset+k_mark_docs", "k_special_scan+ends", "k_pretok", "k_deferred",
+enum { KI_MARK = 0, KI_SPECIAL, KI_PRETOK, KI_DEFER, KI_BPELANES, KI_BPELONG, KI_COUNT, KI_SCAN, KI_COMPACT, KI_N };
+const char* const k_names[KI_N] = {"memset+k_mark_docs", "k_special_scan+ends", "k_pretok", "k_deferred", "k_bpe_lanes64",
                                    "k_bpe_long", "k_count", "k_scan", "k_compact_docs"};
 
 template <class T> int dev_upload(const std::vector<T>& v, const T** out) {
@@ -61,8 +61,8 @@ struct spl_tokenizer {
     size_t zero_words = 0, bitmap_words = 0;
     uint32_t* d_stage = nullptr;
     uint32_t* d_rank = nullptr;
-    uint2* d_qlong = nullptr; uint32_t* d_qdefer = nullptr;
-    uint32_t qcaplong = 0, qcapdefer = 0;
+    uint2* d_q64 = nullptr; uint2* d_qlong = nullptr; uint32_t* d_qdefer = nullptr;
+    uint32_t qcap64 = 0, qcaplong = 0, qcapdefer = 0;
     unsigned long long* d_dbg = nullptr;
     uint32_t* d_blk = nullptr;
     // host-path staging
@@ -88,9 +88,9 @@ namespace {
 
 void free_workspace(spl_tokenizer* t) {
     hipFree(t->d_zero); hipFree(t->d_stage); hipFree(t->d_rank);
-    hipFree(t->d_qlong); hipFree(t->d_qdefer); hipFree(t->d_blk); hipFree(t->d_dbg);
+    hipFree(t->d_q64); hipFree(t->d_qlong); hipFree(t->d_qdefer); hipFree(t->d_blk); hipFree(t->d_dbg);
     t->d_zero = nullptr; t->d_stage = nullptr; t->d_rank = nullptr;
-    t->d_qlong = nullptr; t->d_qdefer = nullptr; t->d_blk = nullptr; t->d_dbg = nullptr;
+    t->d_q64 = nullptr; t->d_qlong = nullptr; t->d_qdefer = nullptr; t->d_blk = nullptr; t->d_dbg = nullptr;
     t->cap_bytes = t->cap_docs = 0;
 }
 
@@ -109,6 +109,8 @@ int reserve(spl_tokenizer* t, uint64_t max_bytes, uint64_t max_docs) {
     const size_t tiles_s = (size_t)(nb / TileGeom<SPL_TILE_SMALL>::TBv) + 2;
     t->qcaplong = (uint32_t)(nb / 2 + 64);          // long chunks AND every miss of a deferred segment
     t->qcapdefer = (uint32_t)(2 * tiles_s + 64);
+    t->qcap64 = (uint32_t)(nb / 17 + 64);
+    HIP_TRY(hipMalloc((void**)&t->d_q64, (size_t)t->qcap64 * 8));
     HIP_TRY(hipMalloc((void**)&t->d_dbg, 16 * 8));
     HIP_TRY(hipMalloc((void**)&t->d_qlong, (size_t)t->qcaplong * 8));
     HIP_TRY(hipMalloc((void**)&t->d_qdefer, (size_t)t->qcapdefer * 4));
@@ -160,8 +162,8 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
     t->last_qcount = b.qcount;
     b.sp_lits = t->d_sp_lits; b.n_special = special ? (uint32_t)t->specials.size() : 0u;
     b.stage = t->d_stage; b.rank_scr = t->d_rank;
-    b.qlong = t->d_qlong; b.qdefer = t->d_qdefer;
-    b.qcaplong = t->qcaplong; b.qcapdefer = t->qcapdefer;
+    b.q64 = t->d_q64; b.qlong = t->d_qlong; b.qdefer = t->d_qdefer;
+    b.qcap64 = t->qcap64; b.qcaplong = t->qcaplong; b.qcapdefer = t->qcapdefer;
     b.dbg = (t->dbg_on || t->prof) ? t->d_dbg : nullptr;
     if (t->prof) {
         const unsigned long long init[2] = {~0ull, 0ull};
@@ -190,11 +192,13 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
     }
     MARK(KI_PRETOK);
     if (ntiles) {
-        if (small_tiles) hipLaunchKernelGGL((k_pretok<SPL_TILE_SMALL>), dim3(ntiles), dim3(NT), 0, s, t->dt, b);
-        else hipLaunchKernelGGL((k_pretok<SPL_TILE_LARGE>), dim3(ntiles), dim3(NT), 0, s, t->dt, b);
+        if (small_tiles) hipLaunchKernelGGL((k_pretok<SPL_TILE_SMALL, false>), dim3(ntiles), dim3(NT), 0, s, t->dt, b);
+        else hipLaunchKernelGGL((k_pretok<SPL_TILE_LARGE, true>), dim3(ntiles), dim3(NT), 0, s, t->dt, b);
     }
     MARK(KI_DEFER);
     if (ntiles) hipLaunchKernelGGL(k_deferred, dim3(64), dim3(64), 0, s, t->dt, b);
+    MARK(KI_BPELANES);
+    if (ntiles && !small_tiles) hipLaunchKernelGGL(k_bpe_lanes64, dim3(256 * 5), dim3(64), 0, s, t->dt, b);
     MARK(KI_BPELONG);
     if (ntiles) hipLaunchKernelGGL(k_bpe_long, dim3(std::min<uint32_t>(2048, ntiles / 4 + 8)), dim3(NT), 0, s, t->dt, b);
     MARK(KI_COUNT);

@@ -46,9 +46,10 @@ struct Batch {
     uint32_t* tbits;       // bitmap: a token starts at this byte
     uint32_t* stage;       // id of the token starting at this byte
     uint32_t* rank_scr;    // per-byte scratch for oversize chunks (bpe_block_global)
-    uint32_t* qcount;      // [2] qlong [3] qdefer   (global, atomically appended: rare paths)
+    uint32_t* qcount;      // [0] q64 [2] qlong [3] qdefer (global queues), [6] [7] work cursors of k_bpe_long
+    uint2* q64;            // large batches: 17..64-byte misses, appended one workgroup at a time
     uint2* qlong; uint32_t* qdefer;
-    uint32_t qcaplong, qcapdefer;
+    uint32_t qcap64, qcaplong, qcapdefer;
     unsigned long long* dbg;   // optional phase cycle stamps of one k_pretok workgroup
     uint32_t* blk_base;    // exclusive token count per RANK_BLK block (+1 entry: total)
     uint32_t n_blk;
@@ -299,7 +300,11 @@ template <int TB_, int RH_> struct TileGeom {
     static_assert(Wv % 32 == 0 && NBW <= NT, "window must be a multiple of 32 bytes and fit one scan");
 };
 
-template <int TB_, int RH_>
+// EXPORT_MEDIUM (large batches): the 17..64-byte misses are not merged here but appended to the
+// global q64 (one atomic per workgroup) for k_bpe_lanes64, which works them one lane per chunk --
+// with hundreds of thousands of such chunks in flight (CJK text) that is the throughput-optimal
+// shape; for small batches the latency-optimal in-kernel groups are used instead.
+template <int TB_, int RH_, bool EXPORT_MEDIUM>
 __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
     using G = TileGeom<TB_, RH_>;
     constexpr int Wv = G::Wv;
@@ -531,9 +536,18 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
         const uint32_t m16 = s_nq[0], m64 = s_nq[1];
         uint32_t* const stage_w0 = b.stage + w0;          // window index -> global position
         const int lane = tid & 63;
+        if (EXPORT_MEDIUM) {
+            if (tid == 0) s_total = m64 ? atomicAdd(&b.qcount[0], m64) : 0u;
+            __syncthreads();
+            const uint32_t base = s_total;
+            for (uint32_t k = tid; k < m64; k += NT) {
+                const uint32_t item = s_miss[G::C16 + k];
+                if (base + k < b.qcap64) b.q64[base + k] = make_uint2((uint32_t)(w0 + (item & 0xFFFFu)), item >> 16);
+            }
+        }
         // every 16-lane group pulls its own work: first the 17..64-byte chunks (four nodes per
         // lane), then the short ones (one node per lane)
-        for (;;) {
+        for (; !EXPORT_MEDIUM;) {
             uint32_t it = 0;
             if ((lane & 15) == 0) it = atomicAdd(&s_nq[3], 1u);
             it = __shfl(it, lane & ~15);
@@ -639,6 +653,39 @@ __global__ void k_deferred(DeviceTables T, Batch b) {
 }
 
 // ------------------------------------------------------------------------------------------
+// byte_pair_encode, ONE LANE PER CHUNK (17..64 bytes), for large batches: node arrays interleaved
+// in LDS (node-major, lane-minor: conflict-free when lanes touch the same node index), merge loop
+// = bpe_serial (spl_lookup.h).  Slow per chunk, but every lane carries its own chain of dependent
+// pair-table probes, so a CU keeps hundreds of them in flight.
+template <int NMAX, int THREADS> struct LaneStore {
+    uint32_t* ids;
+    uint32_t* rks;
+    int lane;
+    __device__ __forceinline__ uint32_t& id(int i) { return ids[i * THREADS + lane]; }
+    __device__ __forceinline__ uint32_t& rk(int i) { return rks[i * THREADS + lane]; }
+};
+struct GlobalText {
+    const uint8_t* text;
+    __device__ __forceinline__ uint32_t txt(int q) const { return text[(uint32_t)q]; }
+};
+__global__ __launch_bounds__(64) void k_bpe_lanes64(DeviceTables T, Batch b) {
+    __shared__ uint32_t s_ids[64 * 64];
+    __shared__ uint32_t s_rks[64 * 64];
+    const uint32_t nq = min(b.qcount[0], b.qcap64);
+    LaneStore<64, 64> st{s_ids, s_rks, (int)threadIdx.x};
+    GlobalText tx{b.text};
+    for (uint32_t it = blockIdx.x * 64 + threadIdx.x; it < nq; it += gridDim.x * 64) {
+        const uint2 item = b.q64[it];
+        const int n = (int)item.y;
+        bpe_serial(T, st, tx, (int)item.x, n);
+        for (int i = 0; i < n; i++) {
+            const uint32_t id = st.id(i);
+            if (id != SPL_DEAD && id != SPL_NO_RANK) emit_token(b, item.x + i, id);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Long chunks (> 64 bytes; plus every miss of a deferred segment).
 //
 // bpe_wave: ONE WAVEFRONT per chunk of up to WAVE_NMAX bytes.  Nodes live in the wavefront's own
@@ -650,7 +697,7 @@ __global__ void k_deferred(DeviceTables T, Batch b) {
 // on four different chunks.
 // bpe_block_global: chunks beyond WAVE_NMAX (pathological single-class runs): one workgroup per
 // chunk, nodes in HBM scratch (ids in stage[], ranks in rank_scr[]), cached per-thread minima.
-constexpr int GROUP_NMAX = 256;       // 16 lanes x 16 register slots
+constexpr int GROUP_NMAX = 128;       // 16 lanes x 8 register slots
 constexpr int WAVE_NMAX = 512;
 constexpr uint32_t NIL16 = 0xFFFFu;
 
@@ -787,13 +834,27 @@ __global__ __launch_bounds__(NT) void k_bpe_long(DeviceTables T, Batch b) {
     const uint32_t nq = min(b.qcount[2], b.qcaplong);
     const int wv = threadIdx.x >> 6;
     const uint32_t nwaves = gridDim.x * (NT / 64);
-    // group phase: chunks of up to GROUP_NMAX bytes, four per wavefront, nodes in registers
+    // Work is pulled dynamically (one atomic per wavefront and pull): chunk lengths range from 65
+    // to several hundred bytes, and a static split leaves most wavefronts idle behind the longest.
+    // wavefront phase FIRST (the longest chains start earliest): GROUP_NMAX < n <= WAVE_NMAX
     {
         const int lane = threadIdx.x & 63;
-        const uint32_t ngroups = nwaves * 4;
-        const uint32_t g0 = (blockIdx.x * (NT / 64) + wv) * 4 + (lane >> 4);
-        for (uint32_t base = 0; base < nq; base += ngroups) {          // uniform trip count
-            const uint32_t it = base + g0;
+        for (;;) {
+            uint32_t it = 0;
+            if (lane == 0) it = atomicAdd(&b.qcount[6], 1u);
+            it = __builtin_amdgcn_readfirstlane(it);
+            if (it >= nq) break;
+            const uint2 item = b.qlong[it];
+            if ((int)item.y > GROUP_NMAX && (int)item.y <= WAVE_NMAX)
+                bpe_wave(T, b, item.x, (int)item.y, s_id[wv], s_rk[wv], s_nx[wv], s_pv[wv]);
+        }
+        // group phase: chunks of up to GROUP_NMAX bytes, four per wavefront, nodes in registers
+        for (;;) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&b.qcount[7], 4u);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= nq) break;
+            const uint32_t it = base + (lane >> 4);
             uint2 item = make_uint2(0, 0);
             if (it < nq) item = b.qlong[it];
             const bool has = it < nq && (int)item.y <= GROUP_NMAX;
@@ -802,12 +863,6 @@ __global__ __launch_bounds__(NT) void k_bpe_long(DeviceTables T, Batch b) {
             bpe_group16<GROUP_NMAX / 16>(T, has ? (int)item.y : 0, [&](int i) { return (uint32_t)b.text[pos + i]; },
                                          [&](int i, uint32_t id) { emit_token(b, pos + (uint32_t)i, id); });
         }
-    }
-    // wavefront phase: GROUP_NMAX < n <= WAVE_NMAX; item `it` belongs to wavefront it % nwaves
-    for (uint32_t it = blockIdx.x * (NT / 64) + wv; it < nq; it += nwaves) {
-        const uint2 item = b.qlong[it];
-        if ((int)item.y > GROUP_NMAX && (int)item.y <= WAVE_NMAX)
-            bpe_wave(T, b, item.x, (int)item.y, s_id[wv], s_rk[wv], s_nx[wv], s_pv[wv]);
     }
     __syncthreads();
     // workgroup phase: the oversize items among this workgroup's share (uniform loop for all threads)

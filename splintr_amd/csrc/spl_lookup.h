@@ -97,19 +97,83 @@ SPL_HD uint32_t pair_rank(const DeviceTables& T, uint32_t l, uint32_t r) {
     }
 }
 
+// Split form of pair_rank for callers that want several probes in flight: issue the bucket loads
+// of all of them, then resolve each (falling back to the generic loop on a bucket overflow).
+struct PairProbe { Quad a, c; uint32_t bkt, klo, khi; bool valid; };
+SPL_HD void pair_issue(const DeviceTables& T, uint32_t l, uint32_t r, PairProbe& pp) {
+    pp.valid = (l | r) <= SPL_ID_MASK;
+    const uint64_t key = pair_key(l & SPL_ID_MASK, r & SPL_ID_MASK);
+    pp.klo = (uint32_t)key; pp.khi = (uint32_t)(key >> 32);
+    pp.bkt = hash_pair(l & SPL_ID_MASK, r & SPL_ID_MASK) & T.pair_mask;
+    const Quad* q = reinterpret_cast<const Quad*>(T.pair_tab + (size_t)pp.bkt * SPL_PAIR_BUCKET);
+    pp.a = q[0]; pp.c = q[1];
+}
+SPL_HD uint32_t pair_finish(const DeviceTables& T, const PairProbe& pp) {
+    if (!pp.valid) return SPL_NO_RANK;
+    const bool f0 = (pp.a.x == pp.klo) & ((pp.a.y & 0x3FFu) == pp.khi);
+    const bool f1 = (pp.a.z == pp.klo) & ((pp.a.w & 0x3FFu) == pp.khi);
+    const bool f2 = (pp.c.x == pp.klo) & ((pp.c.y & 0x3FFu) == pp.khi);
+    const bool f3 = (pp.c.z == pp.klo) & ((pp.c.w & 0x3FFu) == pp.khi);
+    uint32_t res = SPL_NO_RANK;
+    res = f3 ? (pp.c.w >> 10) : res;
+    res = f2 ? (pp.c.y >> 10) : res;
+    res = f1 ? (pp.a.w >> 10) : res;
+    res = f0 ? (pp.a.y >> 10) : res;
+    if ((f0 | f1 | f2 | f3) | ((pp.c.z & pp.c.w) == 0xFFFFFFFFu)) return res;
+    // home bucket full without a match (rare): continue with the generic probe from the next bucket
+    uint32_t bkt = (pp.bkt + 1) & T.pair_mask;
+    for (;;) {
+        const Quad* q = reinterpret_cast<const Quad*>(T.pair_tab + (size_t)bkt * SPL_PAIR_BUCKET);
+        const Quad a = q[0], c = q[1];
+        const bool g0 = (a.x == pp.klo) & ((a.y & 0x3FFu) == pp.khi);
+        const bool g1 = (a.z == pp.klo) & ((a.w & 0x3FFu) == pp.khi);
+        const bool g2 = (c.x == pp.klo) & ((c.y & 0x3FFu) == pp.khi);
+        const bool g3 = (c.z == pp.klo) & ((c.w & 0x3FFu) == pp.khi);
+        uint32_t r2 = SPL_NO_RANK;
+        r2 = g3 ? (c.w >> 10) : r2;
+        r2 = g2 ? (c.y >> 10) : r2;
+        r2 = g1 ? (a.w >> 10) : r2;
+        r2 = g0 ? (a.y >> 10) : r2;
+        if ((g0 | g1 | g2 | g3) | ((c.z & c.w) == 0xFFFFFFFFu)) return r2;
+        bkt = (bkt + 1) & T.pair_mask;
+    }
+}
+
 // One lane, one chunk.  S provides per-node storage:  uint32_t& id(int i), uint32_t& rk(int i).
 // On return node i is alive iff id(i) != SPL_DEAD; alive nodes in index order are the tokens
 // (id SPL_NO_RANK = an unknown single byte: emits nothing, bpe.rs:187-191).
 template <class S, class TX> SPL_HD void bpe_serial(const DeviceTables& T, S& s, const TX& tx, int p, int n) {
-    for (int i = 0; i < n; i++) s.id(i) = T.byte_id[tx.txt(p + i)];
-    for (int i = 0; i + 1 < n; i++) s.rk(i) = pair_rank(T, s.id(i), s.id(i + 1));
+    // bytes -> ids and the initial pair ranks in batches, so that the independent loads of a batch
+    // are all in flight before the first one is consumed
+    for (int i0 = 0; i0 < n; i0 += 8) {
+        uint32_t bb[8], iv[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) bb[k] = i0 + k < n ? tx.txt(p + i0 + k) : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; k++) iv[k] = T.byte_id[bb[k]];
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (i0 + k < n) s.id(i0 + k) = iv[k];
+    }
+    for (int i0 = 0; i0 + 1 < n; i0 += 4) {
+        PairProbe pp[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool on = i0 + k + 1 < n;
+            pair_issue(T, on ? s.id(i0 + k) : 0u, on ? s.id(i0 + k + 1) : 0u, pp[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (i0 + k + 1 < n) s.rk(i0 + k) = pair_finish(T, pp[k]);
+    }
     s.rk(n - 1) = SPL_NO_RANK;
     for (;;) {
         uint32_t mn = SPL_NO_RANK;
         int mi = -1;
-        for (int i = 0; i < n; i++) {                   // strict '<' => leftmost minimum (bpe.rs:133)
-            const uint32_t r = s.rk(i);
-            if (r < mn) { mn = r; mi = i; }
+        for (int i0 = 0; i0 < n; i0 += 8) {             // strict '<' => leftmost minimum (bpe.rs:133);
+            uint32_t r[8];                              // eight independent reads per round
+#pragma unroll
+            for (int k = 0; k < 8; k++) r[k] = i0 + k < n ? s.rk(i0 + k) : SPL_NO_RANK;
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (r[k] < mn) { mn = r[k]; mi = i0 + k; }
         }
         if (mi < 0) break;
         int j = mi + 1;
@@ -119,10 +183,14 @@ template <class S, class TX> SPL_HD void bpe_serial(const DeviceTables& T, S& s,
         s.rk(j) = SPL_NO_RANK;
         int j2 = j + 1;
         while (j2 < n && s.id(j2) == SPL_DEAD) j2++;
-        s.rk(mi) = j2 < n ? pair_rank(T, mn, s.id(j2)) : SPL_NO_RANK;
         int h = mi - 1;
         while (h >= 0 && s.id(h) == SPL_DEAD) h--;
-        if (h >= 0) s.rk(h) = pair_rank(T, s.id(h), mn);
+        // both re-rank probes in flight together (bpe.rs:160-166)
+        PairProbe pr, ph;
+        pair_issue(T, mn, j2 < n ? s.id(j2) : 0u, pr);
+        pair_issue(T, h >= 0 ? s.id(h) : 0u, mn, ph);
+        s.rk(mi) = j2 < n ? pair_finish(T, pr) : SPL_NO_RANK;
+        if (h >= 0) s.rk(h) = pair_finish(T, ph);
     }
 }
 

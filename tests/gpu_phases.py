@@ -27,7 +27,7 @@ for i in range(8):
 print("  total        %8d" % (st[8] - st[0]))
 qc = (ctypes.c_uint32 * 4)()
 L.spl_last_queue_counts(tok.handle, qc)
-print("queues: long", qc[2], "deferred", qc[3], "bytes", batch.n_bytes)
+print("queues: q64", qc[0], "long", qc[2], "deferred", qc[3], "bytes", batch.n_bytes)
 L.spl_profile_enable(tok.handle, 1); L.spl_profile_reset(tok.handle)
 for _ in range(50):
     encode_device(tok, batch)
