@@ -839,29 +839,31 @@ __global__ __launch_bounds__(NT) void k_bpe_long(DeviceTables T, Batch b) {
     // wavefront phase FIRST (the longest chains start earliest): GROUP_NMAX < n <= WAVE_NMAX
     {
         const int lane = threadIdx.x & 63;
-        for (;;) {
-            uint32_t it = 0;
-            if (lane == 0) it = atomicAdd(&b.qcount[6], 1u);
-            it = __builtin_amdgcn_readfirstlane(it);
-            if (it >= nq) break;
+        // (the first item of every wavefront is its own index, later ones come from the cursor: an
+        //  empty or short queue costs no atomics at all)
+        const uint32_t wgid = blockIdx.x * (NT / 64) + wv;
+        for (uint32_t it = wgid; it < nq;) {
             const uint2 item = b.qlong[it];
             if ((int)item.y > GROUP_NMAX && (int)item.y <= WAVE_NMAX)
                 bpe_wave(T, b, item.x, (int)item.y, s_id[wv], s_rk[wv], s_nx[wv], s_pv[wv]);
+            uint32_t nxt = 0;
+            if (lane == 0) nxt = atomicAdd(&b.qcount[6], 1u);
+            it = nwaves + __builtin_amdgcn_readfirstlane(nxt);
         }
         // group phase: chunks of up to GROUP_NMAX bytes, four per wavefront, nodes in registers
-        for (;;) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&b.qcount[7], 4u);
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (base >= nq) break;
+        for (uint32_t base = wgid * 4; base < nq;) {
             const uint32_t it = base + (lane >> 4);
             uint2 item = make_uint2(0, 0);
             if (it < nq) item = b.qlong[it];
             const bool has = it < nq && (int)item.y <= GROUP_NMAX;
-            if (!__any(has)) continue;
-            const uint32_t pos = item.x;
-            bpe_group16<GROUP_NMAX / 16>(T, has ? (int)item.y : 0, [&](int i) { return (uint32_t)b.text[pos + i]; },
-                                         [&](int i, uint32_t id) { emit_token(b, pos + (uint32_t)i, id); });
+            if (__any(has)) {
+                const uint32_t pos = item.x;
+                bpe_group16<GROUP_NMAX / 16>(T, has ? (int)item.y : 0, [&](int i) { return (uint32_t)b.text[pos + i]; },
+                                             [&](int i, uint32_t id) { emit_token(b, pos + (uint32_t)i, id); });
+            }
+            uint32_t nxt = 0;
+            if (lane == 0) nxt = atomicAdd(&b.qcount[7], 4u);
+            base = nwaves * 4 + __builtin_amdgcn_readfirstlane(nxt);
         }
     }
     __syncthreads();
