@@ -6,7 +6,7 @@
 // space), and "where does this run end", "where is its last newline", "where does its last
 // character start" become a handful of word operations (v_ffbl / v_ffbh).  The match semantics
 // are exactly those of spl_scan.h (same alternatives, same closed forms); tests/hostsim checks
-// the two against each other and against the oracle.
+// the two against each other and against the CPU reference restatement kept under tests.
 //
 // Accessor MA:
 //     uint32_t mw(int which, int w)   word w of mask `which` (MK_*), zero past the window
