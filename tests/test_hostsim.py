@@ -59,3 +59,15 @@ def test_long_runs(coracle):
         for t in corpus.worst_case(1500):
             b = t.encode("utf-8")
             assert h.encode(b) == c.encode_bytes(b)
+
+
+@pytest.mark.parametrize("name", ["cl100k_base", "o200k_base"])
+def test_mask_scanner_tiled_like_the_kernel(coracle, name):
+    """spl_scan_masks.h (class bitmasks, word-op run searches, mask sync points) driven tile by
+    tile exactly as k_pretok drives it, incl. deferral past tiny windows."""
+    h, c = sim(name), coracle(name)
+    for s in fuzz_corpus(90210, 6000, 60):
+        b = s.encode("utf-8")
+        ref = c.split_bytes(b)
+        for tb, rh in ((32, 32), (64, 32), (96, 64), (768, 224)):
+            assert h.split_masks(b, tb, rh) == ref, (tb, rh, s)
