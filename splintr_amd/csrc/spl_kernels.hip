@@ -444,36 +444,64 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
     SPL_STAMP(3);
 
     // ---- chains: each sync point inside the tile scans to the next sync point -------------------
+    // The sync points are first enumerated (popcount scan of the sync mask restricted to the tile)
+    // so that every lane runs ONE chain: lanes that own a word with several sync points would
+    // otherwise serialise them while their neighbours idle.
+    {
+        uint32_t word = 0;
+        if (tid < G::NBW) {
+            word = s_mk[MK_SY * NBW1 + tid];
+            const int lo = LH - tid * 32, hi = LH + TB_ - tid * 32;       // tile range inside this word
+            if (hi <= 0 || lo >= 32) word = 0;
+            else {
+                if (lo > 0) word &= ~0u << lo;
+                if (hi < 32) word &= (1u << hi) - 1u;
+            }
+        }
+        const uint32_t cnt = __popc(word);
+        uint32_t x = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d);
+            if ((tid & 63) >= d) x += y;
+        }
+        if ((tid & 63) == 63) s_wsum[tid >> 6] = x;
+        __syncthreads();
+        uint32_t base = x - cnt;
+        for (int wv = 0; wv < (tid >> 6); wv++) base += s_wsum[wv];
+        if (tid == NT - 1) s_total = base + cnt;
+        while (word) {
+            const int bit = __ffs(word) - 1;
+            word &= word - 1;
+            s_cpos[base++] = (uint16_t)(tid * 32 + bit);
+        }
+        __syncthreads();
+    }
     {
         const MaskLdsAcc acc{s_rec, s_txt, s_mk, NBW1, Wv, (B - w0) <= (int64_t)Wv};
-        for (int wi = LH / 4 + tid; wi < (LH + TB_) / 4; wi += NT) {
-            const int i0 = wi * 4;
-            uint32_t m = (s_mk[MK_SY * NBW1 + (i0 >> 5)] >> (i0 & 31)) & 0xFu;
-            while (m) {
-                const int k = __ffs(m) - 1;
-                m &= m - 1;
-                int p = i0 + k;
-                for (;;) {
-                    atomicOr(&s_cbits[p >> 5], 1u << (p & 31));
-                    const int e = match_end_m(acc, p, (int)T.pattern);
-                    if (e == SPL_DEFER) {                 // the match outgrows the window
+        const int nsync = (int)s_total;
+        for (int k = tid; k < nsync; k += NT) {
+            int p = s_cpos[k];
+            for (;;) {
+                atomicOr(&s_cbits[p >> 5], 1u << (p & 31));
+                const int e = match_end_m(acc, p, (int)T.pattern);
+                if (e == SPL_DEFER) {                 // the match outgrows the window
+                    const uint32_t qi = atomicAdd(&b.qcount[3], 1u);
+                    if (qi < b.qcapdefer) b.qdefer[qi] = (uint32_t)(w0 + p);
+                    break;
+                }
+                p = e;
+                if (p >= Wv) {                         // ended exactly on the window edge
+                    atomicOr(&s_cbits[Wv >> 5], 1u << (Wv & 31));
+                    if (w0 + Wv < B) {
                         const uint32_t qi = atomicAdd(&b.qcount[3], 1u);
-                        if (qi < b.qcapdefer) b.qdefer[qi] = (uint32_t)(w0 + p);
-                        break;
+                        if (qi < b.qcapdefer) b.qdefer[qi] = (uint32_t)(w0 + Wv);
                     }
-                    p = e;
-                    if (p >= Wv) {                         // ended exactly on the window edge
-                        atomicOr(&s_cbits[Wv >> 5], 1u << (Wv & 31));
-                        if (w0 + Wv < B) {
-                            const uint32_t qi = atomicAdd(&b.qcount[3], 1u);
-                            if (qi < b.qcapdefer) b.qdefer[qi] = (uint32_t)(w0 + Wv);
-                        }
-                        break;
-                    }
-                    if (((s_mk[MK_SY * NBW1 + (p >> 5)] | s_mk[MK_TS * NBW1 + (p >> 5)]) >> (p & 31)) & 1u) {
-                        atomicOr(&s_cbits[p >> 5], 1u << (p & 31));   // next owner's start: terminator mark
-                        break;
-                    }
+                    break;
+                }
+                if (((s_mk[MK_SY * NBW1 + (p >> 5)] | s_mk[MK_TS * NBW1 + (p >> 5)]) >> (p & 31)) & 1u) {
+                    atomicOr(&s_cbits[p >> 5], 1u << (p & 31));   // next owner's start: terminator mark
+                    break;
                 }
             }
         }
