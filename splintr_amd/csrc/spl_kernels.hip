@@ -286,6 +286,47 @@ __device__ __forceinline__ void bpe_group16(const DeviceTables& T, int n, ByteAt
     }
 }
 
+// The same merge loop for ONE chunk of up to 64 bytes per WAVEFRONT, one node per lane.  Everything
+// that is per-chunk is wave-uniform here (the minimum, the alive bitmap, the neighbour indices), so
+// it lives in scalar registers: bit scans are single SALU ops and neighbour ids come from
+// v_readlane instead of an LDS permute.  Lowest latency per merge; used for a tile's few
+// 17..64-byte chunks, whose chains are the critical path of a small batch.
+template <class ByteAt, class Emit>
+__device__ __forceinline__ void bpe_wave64_regs(const DeviceTables& T, int n, ByteAt byte_at, Emit emit) {
+    const int lane = threadIdx.x & 63;
+    uint32_t id = lane < n ? T.byte_id[byte_at(lane)] : SPL_DEAD;
+    const uint32_t idn = __shfl(id, lane + 1);
+    uint32_t rk = (lane + 1 < n) ? pair_rank(T, id, idn) : SPL_NO_RANK;
+    unsigned long long alive = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+    for (;;) {
+        const uint32_t key = rk == SPL_NO_RANK ? 0xFFFFFFFFu : ((rk << 6) | (uint32_t)lane);
+        uint32_t m = row16_min(key);
+        const uint32_t r0 = __builtin_amdgcn_readlane(m, 0), r1 = __builtin_amdgcn_readlane(m, 16);
+        const uint32_t r2 = __builtin_amdgcn_readlane(m, 32), r3 = __builtin_amdgcn_readlane(m, 48);
+        const uint32_t a = r0 < r1 ? r0 : r1, c = r2 < r3 ? r2 : r3;
+        m = a < c ? a : c;                                  // wave-uniform
+        if (m == 0xFFFFFFFFu) break;
+        const int mi = (int)(m & 63u);
+        const uint32_t mn = m >> 6;
+        const unsigned long long above = alive & ~((2ull << mi) - 1ull);
+        const int j = __builtin_ctzll(above);                       // exists: rk(mi) is a rank
+        const unsigned long long above2 = above & (above - 1ull);
+        const int j2 = above2 ? __builtin_ctzll(above2) : -1;
+        const unsigned long long below = alive & ((1ull << mi) - 1ull);
+        const int h = below ? 63 - __builtin_clzll(below) : -1;
+        const uint32_t id_j2 = j2 >= 0 ? __builtin_amdgcn_readlane(id, j2) : 0u;
+        const uint32_t id_h = h >= 0 ? __builtin_amdgcn_readlane(id, h) : 0u;
+        uint32_t res = SPL_NO_RANK;
+        if (lane == mi) { if (j2 >= 0) res = pair_rank(T, mn, id_j2); }
+        else if (lane == h) res = pair_rank(T, id_h, mn);
+        if (lane == mi) { id = mn; rk = res; }
+        else if (lane == h) rk = res;
+        else if (lane == j) rk = SPL_NO_RANK;
+        alive &= ~(1ull << j);
+    }
+    if (lane < n && ((alive >> lane) & 1ull) && id != SPL_NO_RANK) emit(lane, id);
+}
+
 // Tile geometry is a template parameter: small batches use small tiles (many wavefronts, 4 bytes
 // per lane, latency hidden by occupancy), large batches use 4 KiB tiles (less halo overhead).
 // Every phase maps ONE 4-byte word of the window to one lane, so LDS traffic is bank-conflict free.
@@ -573,9 +614,26 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
                 if (base + k < b.qcap64) b.q64[base + k] = make_uint2((uint32_t)(w0 + (item & 0xFFFFu)), item >> 16);
             }
         }
+        // A tile with only a few 17..64-byte chunks gives each of them a whole wavefront (lowest
+        // latency per merge: their chains are the critical path); a tile dense with them (CJK)
+        // uses the 16-lane groups below, four chunks per wavefront.
+        const bool few_medium = m64 <= 2 * (NT / 64);
+        for (; !EXPORT_MEDIUM && few_medium;) {
+            uint32_t it = 0;
+            if (lane == 0) it = atomicAdd(&s_nq[3], 1u);
+            it = __builtin_amdgcn_readfirstlane(it);
+            if (it >= m64) break;
+            const uint32_t item = s_miss[G::C16 + it];
+            const int p = (int)(item & 0xFFFFu);
+            bpe_wave64_regs(T, (int)(item >> 16), [&](int i) { return (uint32_t)s_txt[p + i]; },
+                            [&](int i, uint32_t id) {
+                                stage_w0[p + i] = id;
+                                atomicOr(&s_tbits[(p + i) >> 5], 1u << ((p + i) & 31));
+                            });
+        }
         // every 16-lane group pulls its own work: first the 17..64-byte chunks (four nodes per
         // lane), then the short ones (one node per lane)
-        for (; !EXPORT_MEDIUM;) {
+        for (; !EXPORT_MEDIUM && !few_medium;) {
             uint32_t it = 0;
             if ((lane & 15) == 0) it = atomicAdd(&s_nq[3], 1u);
             it = __shfl(it, lane & ~15);
