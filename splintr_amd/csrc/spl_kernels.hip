@@ -286,6 +286,109 @@ __device__ __forceinline__ void bpe_group16(const DeviceTables& T, int n, ByteAt
     }
 }
 
+// Short chunks (<= 16 bytes), one node per lane, with the pair ranks TABULATED up front.  The
+// reference ranks a pair by looking up the concatenated bytes (bpe.rs:99-111): the rank of (node
+// starting at i, its right neighbour ending at e) is the id of the token text[i, e).  The lane that
+// owns start i probes the short-key table for text[i, i+len), len = 2..8, in three batches whose
+// bucket loads are all in flight together, and keeps the ids in its own LDS row.  The merge loop
+// then needs no memory round trip per merge (one LDS read of the lane's own row); only spans
+// longer than 8 bytes fall back to the pair table.
+constexpr int SUB_LMAX = 8;
+constexpr int SUB_W = SUB_LMAX - 1;          // table width: lengths 2..8
+
+__device__ __forceinline__ void probe_issue(const DeviceTables& T, uint32_t k0, uint32_t k1, uint32_t n, Quad (&q)[4],
+                                            uint32_t& bkt) {
+    bkt = hash_short(k0, k1, 0u, n) & T.short_mask;
+    const Quad* src = reinterpret_cast<const Quad*>(T.short_tab + (size_t)bkt * SPL_SHORT_BUCKET);
+    q[0] = src[0]; q[1] = src[1]; q[2] = src[2]; q[3] = src[3];
+}
+__device__ __forceinline__ uint32_t probe_finish(const DeviceTables& T, uint32_t k0, uint32_t k1, uint32_t n,
+                                                 const Quad (&q)[4], uint32_t bkt) {
+    uint32_t r = SPL_NO_RANK;
+    bool found = false;
+#pragma unroll
+    for (int e = 3; e >= 0; e--) {
+        const bool f = (q[e].x == k0) & (q[e].y == k1) & (q[e].z == 0u) & ((q[e].w >> 24) == n);
+        r = f ? (q[e].w & 0xFFFFFFu) : r;
+        found |= f;
+    }
+    if (found | (q[3].w == SPL_EMPTY)) return r;
+    (void)bkt;
+    return probe_short(T, k0, k1, 0u, n);      // home bucket full without a match (rare): generic probe
+}
+
+template <class Emit>
+__device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const LdsAcc& tx, int p, int n, uint32_t* sub,
+                                                Emit emit) {
+    const int lane = threadIdx.x & 63;
+    const int gl = lane & 15;
+    const int gbase = lane - gl;
+    const bool own = gl < n;
+    const int maxlen = own ? (n - gl < SUB_LMAX ? n - gl : SUB_LMAX) : 0;
+    const uint32_t w0 = own ? tx.load32(p + gl) : 0u;
+    const uint32_t w1 = own ? tx.load32(p + gl + 4) : 0u;
+    uint32_t id = own ? T.byte_id[w0 & 0xFFu] : SPL_DEAD;
+    uint32_t* row = sub + gl * SUB_W;
+    {
+        Quad qa[4], qb[4], qc[4];
+        uint32_t ba = 0, bb = 0, bc = 0;
+        const uint32_t ka = w0 & 0xFFFFu, kb = w0 & 0xFFFFFFu;
+        if (maxlen >= 2) probe_issue(T, ka, 0u, 2u, qa, ba);
+        if (maxlen >= 3) probe_issue(T, kb, 0u, 3u, qb, bb);
+        if (maxlen >= 4) probe_issue(T, w0, 0u, 4u, qc, bc);
+        if (maxlen >= 2) row[0] = probe_finish(T, ka, 0u, 2u, qa, ba);
+        if (maxlen >= 3) row[1] = probe_finish(T, kb, 0u, 3u, qb, bb);
+        if (maxlen >= 4) row[2] = probe_finish(T, w0, 0u, 4u, qc, bc);
+    }
+    if (__any(maxlen >= 5)) {
+        Quad qa[4], qb[4], qc[4];
+        uint32_t ba = 0, bb = 0, bc = 0;
+        const uint32_t ha = w1 & 0xFFu, hb = w1 & 0xFFFFu, hc = w1 & 0xFFFFFFu;
+        if (maxlen >= 5) probe_issue(T, w0, ha, 5u, qa, ba);
+        if (maxlen >= 6) probe_issue(T, w0, hb, 6u, qb, bb);
+        if (maxlen >= 7) probe_issue(T, w0, hc, 7u, qc, bc);
+        if (maxlen >= 5) row[3] = probe_finish(T, w0, ha, 5u, qa, ba);
+        if (maxlen >= 6) row[4] = probe_finish(T, w0, hb, 6u, qb, bb);
+        if (maxlen >= 7) row[5] = probe_finish(T, w0, hc, 7u, qc, bc);
+    }
+    if (maxlen >= 8) row[6] = probe_short(T, w0, w1, 0u, 8u);
+    uint32_t rk = (gl + 1 < n) ? row[0] : SPL_NO_RANK;          // initial ranks (bpe.rs:114-116)
+    uint32_t alive = n >= 16 ? 0xFFFFu : ((1u << n) - 1u);       // group-uniform, kept by every lane
+    for (;;) {
+        const uint32_t key = rk == SPL_NO_RANK ? 0xFFFFFFFFu : ((rk << 8) | (uint32_t)gl);
+        const uint32_t m = row16_min(key);
+        const bool active = m != 0xFFFFFFFFu;
+        if (!__any(active)) break;
+        const int mi = (int)(m & 255u);
+        const uint32_t mn = m >> 8;
+        const uint32_t above = active ? alive & ~((2u << mi) - 1u) : 1u;
+        const int j = __ffs((int)above) - 1;
+        const uint32_t above2 = above & (above - 1u);
+        const int j2 = above2 ? __ffs((int)above2) - 1 : -1;
+        const uint32_t above3 = above2 & (above2 - 1u);
+        const int e_r = above3 ? __ffs((int)above3) - 1 : n;    // end of the pair (mi, j2)
+        const int e_mi = j2 >= 0 ? j2 : n;                       // end of the merged node
+        const uint32_t below = active ? alive & ((1u << mi) - 1u) : 0u;
+        const int h = below ? 31 - __clz((int)below) : -1;
+        const int len_r = e_r - mi, len_h = e_mi - h;
+        const bool need_far = active && ((j2 >= 0 && len_r > SUB_LMAX) || (h >= 0 && len_h > SUB_LMAX));
+        uint32_t id_j2 = 0;
+        if (__any(need_far)) id_j2 = __shfl(id, gbase + (j2 & 15));   // only long spans need neighbour ids
+        if (active) {
+            if (gl == mi) {
+                id = mn;
+                rk = j2 < 0 ? SPL_NO_RANK : len_r <= SUB_LMAX ? row[len_r - 2] : pair_rank(T, mn, id_j2);
+            } else if (gl == h) {
+                rk = len_h <= SUB_LMAX ? row[len_h - 2] : pair_rank(T, id, mn);
+            } else if (gl == j) {
+                rk = SPL_NO_RANK;
+            }
+            alive &= ~(1u << j);
+        }
+    }
+    if (own && ((alive >> gl) & 1u) && id != SPL_NO_RANK) emit(gl, id);
+}
+
 // The same merge loop for ONE chunk of up to 64 bytes per WAVEFRONT, one node per lane.  Everything
 // that is per-chunk is wave-uniform here (the minimum, the alive bitmap, the neighbour indices), so
 // it lives in scalar registers: bit scans are single SALU ops and neighbour ids come from
@@ -327,6 +430,77 @@ __device__ __forceinline__ void bpe_wave64_regs(const DeviceTables& T, int n, By
     if (lane < n && ((alive >> lane) & 1ull) && id != SPL_NO_RANK) emit(lane, id);
 }
 
+// bpe_wave64_regs with tabulated pair ranks (see bpe_group16_tab): one chunk of 17..64 bytes per
+// wavefront, lane i owns node i and the ids of text[i, i+len), len = 2..8, in its LDS row.
+template <class Emit>
+__device__ __forceinline__ void bpe_wave64_tab(const DeviceTables& T, const LdsAcc& tx, int p, int n, uint32_t* sub,
+                                               Emit emit) {
+    const int lane = threadIdx.x & 63;
+    const bool own = lane < n;
+    const int maxlen = own ? (n - lane < SUB_LMAX ? n - lane : SUB_LMAX) : 0;
+    const uint32_t w0 = own ? tx.load32(p + lane) : 0u;
+    const uint32_t w1 = own ? tx.load32(p + lane + 4) : 0u;
+    uint32_t id = own ? T.byte_id[w0 & 0xFFu] : SPL_DEAD;
+    uint32_t* row = sub + lane * SUB_W;
+    {
+        Quad qa[4], qb[4], qc[4];
+        uint32_t ba = 0, bb = 0, bc = 0;
+        const uint32_t ka = w0 & 0xFFFFu, kb = w0 & 0xFFFFFFu;
+        if (maxlen >= 2) probe_issue(T, ka, 0u, 2u, qa, ba);
+        if (maxlen >= 3) probe_issue(T, kb, 0u, 3u, qb, bb);
+        if (maxlen >= 4) probe_issue(T, w0, 0u, 4u, qc, bc);
+        if (maxlen >= 2) row[0] = probe_finish(T, ka, 0u, 2u, qa, ba);
+        if (maxlen >= 3) row[1] = probe_finish(T, kb, 0u, 3u, qb, bb);
+        if (maxlen >= 4) row[2] = probe_finish(T, w0, 0u, 4u, qc, bc);
+    }
+    {
+        Quad qa[4], qb[4], qc[4];
+        uint32_t ba = 0, bb = 0, bc = 0;
+        const uint32_t ha = w1 & 0xFFu, hb = w1 & 0xFFFFu, hc = w1 & 0xFFFFFFu;
+        if (maxlen >= 5) probe_issue(T, w0, ha, 5u, qa, ba);
+        if (maxlen >= 6) probe_issue(T, w0, hb, 6u, qb, bb);
+        if (maxlen >= 7) probe_issue(T, w0, hc, 7u, qc, bc);
+        if (maxlen >= 5) row[3] = probe_finish(T, w0, ha, 5u, qa, ba);
+        if (maxlen >= 6) row[4] = probe_finish(T, w0, hb, 6u, qb, bb);
+        if (maxlen >= 7) row[5] = probe_finish(T, w0, hc, 7u, qc, bc);
+    }
+    if (maxlen >= 8) row[6] = probe_short(T, w0, w1, 0u, 8u);
+    uint32_t rk = (lane + 1 < n) ? row[0] : SPL_NO_RANK;
+    unsigned long long alive = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+    for (;;) {
+        const uint32_t key = rk == SPL_NO_RANK ? 0xFFFFFFFFu : ((rk << 6) | (uint32_t)lane);
+        uint32_t m = row16_min(key);
+        const uint32_t r0 = __builtin_amdgcn_readlane(m, 0), r1 = __builtin_amdgcn_readlane(m, 16);
+        const uint32_t r2 = __builtin_amdgcn_readlane(m, 32), r3 = __builtin_amdgcn_readlane(m, 48);
+        const uint32_t a = r0 < r1 ? r0 : r1, c = r2 < r3 ? r2 : r3;
+        m = a < c ? a : c;                                  // wave-uniform
+        if (m == 0xFFFFFFFFu) break;
+        const int mi = (int)(m & 63u);
+        const uint32_t mn = m >> 6;
+        const unsigned long long above = alive & ~((2ull << mi) - 1ull);
+        const int j = __builtin_ctzll(above);
+        const unsigned long long above2 = above & (above - 1ull);
+        const int j2 = above2 ? __builtin_ctzll(above2) : -1;
+        const unsigned long long above3 = above2 & (above2 - 1ull);
+        const int e_r = above3 ? __builtin_ctzll(above3) : n;
+        const int e_mi = j2 >= 0 ? j2 : n;
+        const unsigned long long below = alive & ((1ull << mi) - 1ull);
+        const int h = below ? 63 - __builtin_clzll(below) : -1;
+        const int len_r = e_r - mi, len_h = e_mi - h;
+        const uint32_t id_j2 = (j2 >= 0 && len_r > SUB_LMAX) ? __builtin_amdgcn_readlane(id, j2) : 0u;
+        if (lane == mi) {
+            id = mn;
+            rk = j2 < 0 ? SPL_NO_RANK : len_r <= SUB_LMAX ? row[len_r - 2] : pair_rank(T, mn, id_j2);
+        } else if (lane == h) {
+            rk = len_h <= SUB_LMAX ? row[len_h - 2] : pair_rank(T, id, mn);
+        } else if (lane == j) {
+            rk = SPL_NO_RANK;
+        }
+        alive &= ~(1ull << j);
+    }
+    if (own && ((alive >> lane) & 1ull) && id != SPL_NO_RANK) emit(lane, id);
+}
+
 // Tile geometry is a template parameter: small batches use small tiles (many wavefronts, 4 bytes
 // per lane, latency hidden by occupancy), large batches use 4 KiB tiles (less halo overhead).
 // Every phase maps ONE 4-byte word of the window to one lane, so LDS traffic is bank-conflict free.
@@ -361,6 +535,7 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
     __shared__ uint32_t s_wsum[NT / 64];
     __shared__ uint32_t s_total;
     __shared__ uint32_t s_nq[4];                         // miss counts [0] (<= 16 B) [1] (17..64 B), work cursors [2] [3]
+    __shared__ uint32_t s_sub[NT / 16][16 * SUB_W];      // per 16-lane group: tabulated substring ids
     __shared__ uint32_t s_miss[G::QCAP];                 // p | n << 16, one region per size class
     uint8_t* const s_txt = reinterpret_cast<uint8_t*>(s_txt32);
     uint8_t* const s_rec = reinterpret_cast<uint8_t*>(s_rec32);
@@ -625,12 +800,13 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
             if (it >= m64) break;
             const uint32_t item = s_miss[G::C16 + it];
             const int p = (int)(item & 0xFFFFu);
-            bpe_wave64_regs(T, (int)(item >> 16), [&](int i) { return (uint32_t)s_txt[p + i]; },
-                            [&](int i, uint32_t id) {
-                                stage_w0[p + i] = id;
-                                atomicOr(&s_tbits[(p + i) >> 5], 1u << ((p + i) & 31));
-                            });
+            bpe_wave64_tab(T, LdsAcc{s_rec, s_txt}, p, (int)(item >> 16), s_sub[(tid >> 6) * 4],
+                           [&](int i, uint32_t id) {
+                               stage_w0[p + i] = id;
+                               atomicOr(&s_tbits[(p + i) >> 5], 1u << ((p + i) & 31));
+                           });
         }
+        SPL_STAMP(9);
         // every 16-lane group pulls its own work: first the 17..64-byte chunks (four nodes per
         // lane), then the short ones (one node per lane)
         for (; !EXPORT_MEDIUM && !few_medium;) {
@@ -655,13 +831,14 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
             if (!__any(has)) break;
             const uint32_t item = has ? s_miss[it] : 0u;
             const int p = (int)(item & 0xFFFFu);
-            bpe_group16<1>(T, has ? (int)(item >> 16) : 0, [&](int i) { return (uint32_t)s_txt[p + i]; },
-                           [&](int i, uint32_t id) {
-                               stage_w0[p + i] = id;
-                               atomicOr(&s_tbits[(p + i) >> 5], 1u << ((p + i) & 31));
-                           });
+            bpe_group16_tab(T, LdsAcc{s_rec, s_txt}, p, has ? (int)(item >> 16) : 0, s_sub[tid >> 4],
+                            [&](int i, uint32_t id) {
+                                stage_w0[p + i] = id;
+                                atomicOr(&s_tbits[(p + i) >> 5], 1u << ((p + i) & 31));
+                            });
         }
     }
+    SPL_STAMP(10);
     __syncthreads();
     SPL_STAMP(7);
     if (tid < G::NBW) {

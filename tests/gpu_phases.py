@@ -25,6 +25,7 @@ print("k_pretok phases (shader cycles) of the middle workgroup:")
 for i in range(8):
     print(f"  {names[i + 1]:12s} {st[i + 1] - st[i]:8d}")
 print("  total        %8d" % (st[8] - st[0]))
+print("  merge: medium (wave 0) %d, short (wave 0) %d, wait for other waves %d" % (st[9] - st[6], st[10] - st[9], st[7] - st[10]))
 qc = (ctypes.c_uint32 * 4)()
 L.spl_last_queue_counts(tok.handle, qc)
 print("queues: q64", qc[0], "long", qc[2], "deferred", qc[3], "bytes", batch.n_bytes)
