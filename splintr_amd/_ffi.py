@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsplintr_hip.so")
+# SPL_LIB_PATH: development override used to A/B kernel variants built with different -D flags
+LIB_PATH = os.environ.get("SPL_LIB_PATH") or os.path.join(_HERE, "libsplintr_hip.so")
 
 SPL_OK = 0
 SPL_WITH_SPECIAL = 1
@@ -22,7 +23,7 @@ SYMBOLS = [
     "spl_reserve", "spl_encode_batch", "spl_result_tokens", "spl_result_offsets", "spl_result_n_tokens",
     "spl_result_n_docs", "spl_result_free", "spl_encode_batch_device", "spl_decode_batch", "spl_free",
     "spl_profile_enable", "spl_profile_reset", "spl_profile_read", "spl_kernel_name", "spl_last_queue_counts",
-    "spl_debug_phases", "spl_gatherv_pack", "spl_gatherv_unpack",
+    "spl_debug_phases", "spl_debug_blocks", "spl_gatherv_pack", "spl_gatherv_unpack",
 ]
 
 
@@ -77,6 +78,7 @@ def lib() -> ctypes.CDLL:
     L.spl_kernel_name.argtypes = [ctypes.c_int]
     L.spl_last_queue_counts.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32)]
     L.spl_debug_phases.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
+    L.spl_debug_blocks.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
     L.spl_gatherv_pack.argtypes = [vp, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, ctypes.c_uint64, vp]
     L.spl_gatherv_unpack.argtypes = [vp, vp, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64, vp, ctypes.c_uint64, vp,
                                      vp, vp]

@@ -76,6 +76,7 @@ struct spl_tokenizer {
     uint64_t prof_n[SPL_MAX_KERNELS]{};
     uint32_t* last_qcount = nullptr;
     bool dbg_on = false;
+    int stop_phase = 0;     // spl_debug_phases bits 3..5 (profiling builds of the instruction mix per phase)
     int force_tile = 0;     // 0 auto, 1 small tiles, 2 large tiles (spl_debug_phases bit 1/2)
 };
 
@@ -111,7 +112,7 @@ int reserve(spl_tokenizer* t, uint64_t max_bytes, uint64_t max_docs) {
     t->qcapdefer = (uint32_t)(2 * tiles_s + 64);
     t->qcap64 = (uint32_t)(nb / 17 + 64);
     HIP_TRY(hipMalloc((void**)&t->d_q64, (size_t)t->qcap64 * 8));
-    HIP_TRY(hipMalloc((void**)&t->d_dbg, 16 * 8));
+    HIP_TRY(hipMalloc((void**)&t->d_dbg, (16 + 4 * SPL_DEBUG_BLOCKS) * 8));
     HIP_TRY(hipMalloc((void**)&t->d_qlong, (size_t)t->qcaplong * 8));
     HIP_TRY(hipMalloc((void**)&t->d_qdefer, (size_t)t->qcapdefer * 4));
     HIP_TRY(hipMalloc((void**)&t->d_blk, (nblk + 2) * 4));
@@ -165,6 +166,7 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
     b.q64 = t->d_q64; b.qlong = t->d_qlong; b.qdefer = t->d_qdefer;
     b.qcap64 = t->qcap64; b.qcaplong = t->qcaplong; b.qcapdefer = t->qcapdefer;
     b.dbg = (t->dbg_on || t->prof) ? t->d_dbg : nullptr;
+    b.stop_phase = (uint32_t)t->stop_phase;
     if (t->prof) {
         const unsigned long long init[2] = {~0ull, 0ull};
         HIP_TRY(hipMemcpyAsync(t->d_dbg + 14, init, 16, hipMemcpyHostToDevice, s));
@@ -491,12 +493,23 @@ int spl_gatherv_unpack(spl_tokenizer* t, const uint32_t* d_slabs, uint32_t world
     return SPL_OK;
 }
 
+int spl_debug_blocks(spl_tokenizer* t, unsigned long long* out, int max_blocks) {
+    if (!t || !out) return fail(SPL_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(t->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (!t->d_dbg) return 0;
+    const int n = max_blocks < SPL_DEBUG_BLOCKS ? max_blocks : SPL_DEBUG_BLOCKS;
+    HIP_TRY(hipMemcpy(out, t->d_dbg + 16, (size_t)n * 32, hipMemcpyDeviceToHost));
+    return n;
+}
+
 int spl_debug_phases(spl_tokenizer* t, int enable, unsigned long long stamps_out[16]) {
     if (!t) return fail(SPL_EINVAL, "null handle");
     HIP_TRY(hipSetDevice(t->device));
     HIP_TRY(hipDeviceSynchronize());
     if (stamps_out && t->d_dbg) HIP_TRY(hipMemcpy(stamps_out, t->d_dbg, 16 * 8, hipMemcpyDeviceToHost));
     t->dbg_on = (enable & 1) != 0;
+    t->stop_phase = (enable >> 3) & 7;
     t->force_tile = (enable >> 1) & 3;      // development: bit 1 = force small tiles, bit 2 = force large
     return SPL_OK;
 }

@@ -51,6 +51,7 @@ struct Batch {
     uint2* qlong; uint32_t* qdefer;
     uint32_t qcap64, qcaplong, qcapdefer;
     unsigned long long* dbg;   // optional phase cycle stamps of one k_pretok workgroup
+    uint32_t stop_phase;       // profiling only: k_pretok returns at this phase boundary (0 = never)
     uint32_t* blk_base;    // exclusive token count per RANK_BLK block (+1 entry: total)
     uint32_t n_blk;
     uint32_t* ids_out; uint64_t ids_cap; uint64_t* off_out;
@@ -293,7 +294,10 @@ __device__ __forceinline__ void bpe_group16(const DeviceTables& T, int n, ByteAt
 // bucket loads are all in flight together, and keeps the ids in its own LDS row.  The merge loop
 // then needs no memory round trip per merge (one LDS read of the lane's own row); only spans
 // longer than 8 bytes fall back to the pair table.
-constexpr int SUB_LMAX = 8;
+#ifndef SPL_SUB_LMAX
+#define SPL_SUB_LMAX 8
+#endif
+constexpr int SUB_LMAX = SPL_SUB_LMAX;
 constexpr int SUB_W = SUB_LMAX - 1;          // table width: lengths 2..8
 
 __device__ __forceinline__ void probe_issue(const DeviceTables& T, uint32_t k0, uint32_t k1, uint32_t n, Quad (&q)[4],
@@ -319,7 +323,8 @@ __device__ __forceinline__ uint32_t probe_finish(const DeviceTables& T, uint32_t
 
 template <class Emit>
 __device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const LdsAcc& tx, int p, int n, uint32_t* sub,
-                                                Emit emit) {
+                                                Emit emit, long long* dbgc = nullptr) {
+    const long long c_in = dbgc ? clock64() : 0;
     const int lane = threadIdx.x & 63;
     const int gl = lane & 15;
     const int gbase = lane - gl;
@@ -340,7 +345,7 @@ __device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const Lds
         if (maxlen >= 3) row[1] = probe_finish(T, kb, 0u, 3u, qb, bb);
         if (maxlen >= 4) row[2] = probe_finish(T, w0, 0u, 4u, qc, bc);
     }
-    if (__any(maxlen >= 5)) {
+    if (SUB_LMAX >= 5 && __any(maxlen >= 5)) {
         Quad qa[4], qb[4], qc[4];
         uint32_t ba = 0, bb = 0, bc = 0;
         const uint32_t ha = w1 & 0xFFu, hb = w1 & 0xFFFFu, hc = w1 & 0xFFFFFFu;
@@ -351,10 +356,12 @@ __device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const Lds
         if (maxlen >= 6) row[4] = probe_finish(T, w0, hb, 6u, qb, bb);
         if (maxlen >= 7) row[5] = probe_finish(T, w0, hc, 7u, qc, bc);
     }
-    if (maxlen >= 8) row[6] = probe_short(T, w0, w1, 0u, 8u);
+    if (SUB_LMAX >= 8 && maxlen >= 8) row[6] = probe_short(T, w0, w1, 0u, 8u);
     uint32_t rk = (gl + 1 < n) ? row[0] : SPL_NO_RANK;          // initial ranks (bpe.rs:114-116)
     uint32_t alive = n >= 16 ? 0xFFFFu : ((1u << n) - 1u);       // group-uniform, kept by every lane
+    if (dbgc) { dbgc[0] += clock64() - c_in; dbgc[1] += 1; }
     for (;;) {
+        if (dbgc) dbgc[2] += 1;
         const uint32_t key = rk == SPL_NO_RANK ? 0xFFFFFFFFu : ((rk << 8) | (uint32_t)gl);
         const uint32_t m = row16_min(key);
         const bool active = m != 0xFFFFFFFFu;
@@ -453,7 +460,7 @@ __device__ __forceinline__ void bpe_wave64_tab(const DeviceTables& T, const LdsA
         if (maxlen >= 3) row[1] = probe_finish(T, kb, 0u, 3u, qb, bb);
         if (maxlen >= 4) row[2] = probe_finish(T, w0, 0u, 4u, qc, bc);
     }
-    {
+    if (SUB_LMAX >= 5) {
         Quad qa[4], qb[4], qc[4];
         uint32_t ba = 0, bb = 0, bc = 0;
         const uint32_t ha = w1 & 0xFFu, hb = w1 & 0xFFFFu, hc = w1 & 0xFFFFFFu;
@@ -464,7 +471,7 @@ __device__ __forceinline__ void bpe_wave64_tab(const DeviceTables& T, const LdsA
         if (maxlen >= 6) row[4] = probe_finish(T, w0, hb, 6u, qb, bb);
         if (maxlen >= 7) row[5] = probe_finish(T, w0, hc, 7u, qc, bc);
     }
-    if (maxlen >= 8) row[6] = probe_short(T, w0, w1, 0u, 8u);
+    if (SUB_LMAX >= 8 && maxlen >= 8) row[6] = probe_short(T, w0, w1, 0u, 8u);
     uint32_t rk = (lane + 1 < n) ? row[0] : SPL_NO_RANK;
     unsigned long long alive = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
     for (;;) {
@@ -539,7 +546,8 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
     __shared__ uint32_t s_miss[G::QCAP];                 // p | n << 16, one region per size class
     uint8_t* const s_txt = reinterpret_cast<uint8_t*>(s_txt32);
     uint8_t* const s_rec = reinterpret_cast<uint8_t*>(s_rec32);
-#define SPL_STAMP(i) do { if (b.dbg && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) b.dbg[i] = clock64(); } while (0)
+#define SPL_STAMP(i) do { if (b.dbg && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) b.dbg[i] = clock64(); \
+                          if ((i) >= 1 && (i) <= 7 && b.stop_phase == (uint32_t)(i)) return; } while (0)
 
     const int tid = threadIdx.x;
     const int64_t t0 = (int64_t)blockIdx.x * TB_;
@@ -548,6 +556,11 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
     // profiling: span of this kernel on the constant-rate wall clock (start of workgroup 0, max end
     // over all workgroups) -- what a kernel trace reports, without host-side event overhead
     if (b.dbg && tid == 0 && blockIdx.x == 0) b.dbg[14] = (unsigned long long)wall_clock64();   // dispatched first
+    if (b.dbg && tid == 0 && blockIdx.x == gridDim.x / 2) b.dbg[11] = (unsigned long long)wall_clock64();
+    const unsigned long long blk_t0 = b.dbg ? (unsigned long long)wall_clock64() : 0ull;
+    long long blk_c0 = 0, blk_c1 = 0, blk_c2 = 0;
+    long long blk_dc[3] = {0, 0, 0};
+    if (b.dbg && tid == 0 && blockIdx.x == gridDim.x - 1) b.dbg[13] = (unsigned long long)wall_clock64();
 
     // ---- stage text (coalesced 16 B per lane) and the window's flag bits ------------------------
     for (int v = tid; v < (Wv + WPAD) / 16; v += NT) {
@@ -573,6 +586,7 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
     if (tid < 128) s_ascii[tid] = T.ucls_stage2[((uint32_t)T.ucls_stage1[0] << T.ucls_shift) + tid];
     if (tid < 4) s_nq[tid] = 0;
     SPL_STAMP(0);
+    if (b.dbg) blk_c0 = clock64();
     __syncthreads();
     SPL_STAMP(1);
 
@@ -776,6 +790,7 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
     SPL_STAMP(6);
 
     // ---- merge loop for this tile's misses: wavefronts pull work until both lists are empty ------
+    if (b.dbg) blk_c1 = clock64();
     {
         const uint32_t m16 = s_nq[0], m64 = s_nq[1];
         uint32_t* const stage_w0 = b.stage + w0;          // window index -> global position
@@ -835,17 +850,27 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
                             [&](int i, uint32_t id) {
                                 stage_w0[p + i] = id;
                                 atomicOr(&s_tbits[(p + i) >> 5], 1u << ((p + i) & 31));
-                            });
+                            }, b.dbg && tid == 0 ? blk_dc : nullptr);
         }
     }
     SPL_STAMP(10);
     __syncthreads();
     SPL_STAMP(7);
+    if (b.dbg) blk_c2 = clock64();
     if (tid < G::NBW) {
         const uint32_t wv = s_tbits[tid];
         if (wv) atomicOr(&b.tbits[(w0 >> 5) + tid], wv);
     }
     SPL_STAMP(8);
+    if (b.dbg && tid == 0 && blockIdx.x == gridDim.x / 2) b.dbg[12] = (unsigned long long)wall_clock64();
+    if (b.dbg && tid == 0 && blockIdx.x < SPL_DEBUG_BLOCKS) {
+        unsigned long long* r = b.dbg + 16 + 4 * blockIdx.x;
+        r[0] = (unsigned long long)wall_clock64() - blk_t0;
+        r[1] = (unsigned long long)(blk_c2 - blk_c1);
+        r[2] = s_nq[0] | (s_nq[1] << 16) | ((unsigned long long)blk_dc[1] << 32) | ((unsigned long long)blk_dc[2] << 40)
+               | ((unsigned long long)blk_dc[0] << 48 >> 0);
+        r[3] = (unsigned long long)(blk_c1 - blk_c0);
+    }
     if (b.dbg && tid == 0) atomicMax(&b.dbg[15], (unsigned long long)wall_clock64());
 #undef SPL_STAMP
 }
