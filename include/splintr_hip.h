@@ -133,9 +133,9 @@ int spl_last_queue_counts(spl_tokenizer* t, uint32_t counts_out[4]);
  * boundaries; the call returns the stamps of the previous batch (synchronises). */
 int spl_debug_phases(spl_tokenizer* t, int enable, unsigned long long stamps_out[16]);
 
-/* Development aid: per-workgroup records of the last stamped k_pretok launch, 4 words each
- * (wall-clock ticks resident, merge-phase shader cycles, short | medium << 16 miss counts,
- * scanner shader cycles) for the first SPL_DEBUG_BLOCKS workgroups.  Returns the count copied. */
+/* Development aid: per-workgroup records of the last stamped k_pretok launch, 4 wall-clock ticks
+ * each (start, end of the merge phase, look-back done, end) for the first SPL_DEBUG_BLOCKS
+ * workgroups.  Returns the count copied. */
 #define SPL_DEBUG_BLOCKS 4096
 int spl_debug_blocks(spl_tokenizer* t, unsigned long long* out, int max_blocks);
 

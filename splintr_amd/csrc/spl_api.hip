@@ -65,6 +65,12 @@ struct spl_tokenizer {
     uint32_t qcap64 = 0, qcaplong = 0, qcapdefer = 0;
     unsigned long long* d_dbg = nullptr;
     uint32_t* d_blk = nullptr;
+    // single-pass path: look-back status words (epoch-tagged), and whether the token bitmap may hold
+    // stale bits (after hipMalloc or a multi-pass call) -- the single-pass kernel needs it all-zero
+    unsigned long long* d_lb = nullptr;
+    size_t lb_words = 0;
+    uint32_t epoch = 0;
+    bool bitmap_dirty = true;
     // host-path staging
     uint8_t* d_in_text = nullptr; uint64_t* d_in_off = nullptr; uint32_t* d_out_ids = nullptr; uint64_t* d_out_off = nullptr;
     uint64_t in_cap_bytes = 0, in_cap_docs = 0;
@@ -90,6 +96,7 @@ namespace {
 void free_workspace(spl_tokenizer* t) {
     hipFree(t->d_zero); hipFree(t->d_stage); hipFree(t->d_rank);
     hipFree(t->d_q64); hipFree(t->d_qlong); hipFree(t->d_qdefer); hipFree(t->d_blk); hipFree(t->d_dbg);
+    hipFree(t->d_lb); t->d_lb = nullptr;
     t->d_zero = nullptr; t->d_stage = nullptr; t->d_rank = nullptr;
     t->d_q64 = nullptr; t->d_qlong = nullptr; t->d_qdefer = nullptr; t->d_blk = nullptr; t->d_dbg = nullptr;
     t->cap_bytes = t->cap_docs = 0;
@@ -116,6 +123,11 @@ int reserve(spl_tokenizer* t, uint64_t max_bytes, uint64_t max_docs) {
     HIP_TRY(hipMalloc((void**)&t->d_qlong, (size_t)t->qcaplong * 8));
     HIP_TRY(hipMalloc((void**)&t->d_qdefer, (size_t)t->qcapdefer * 4));
     HIP_TRY(hipMalloc((void**)&t->d_blk, (nblk + 2) * 4));
+    t->lb_words = (size_t)(std::min<uint64_t>(nb, SPL_DIRECT_MAX_BYTES) / TileGeom<SPL_TILE_SMALL>::TBv) + 2;
+    HIP_TRY(hipMalloc((void**)&t->d_lb, t->lb_words * 8));
+    HIP_TRY(hipMemset(t->d_lb, 0, t->lb_words * 8));
+    t->epoch = 0;
+    t->bitmap_dirty = true;
     t->cap_bytes = nb;
     t->cap_docs = nd;
     return SPL_OK;
@@ -177,13 +189,33 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
     const bool pf = t->prof;
 #define MARK(i) do { if (pf) HIP_TRY(hipEventRecord(t->ev[i], s)); } while (0)
     // small batches: small tiles (occupancy hides latency); large batches: 4 KiB tiles
-    const bool small_tiles = t->force_tile == 1 || (t->force_tile == 0 && n_bytes <= (8u << 20));
+    const bool small_tiles = t->force_tile == 1 || t->force_tile == 3 || (t->force_tile == 0 && n_bytes <= SPL_DIRECT_MAX_BYTES);
     const uint32_t tile_bytes = small_tiles ? TileGeom<SPL_TILE_SMALL>::TBv : TileGeom<SPL_TILE_LARGE>::TBv;
     const uint32_t ntiles = (uint32_t)((n_bytes + tile_bytes - 1) / tile_bytes);
     // (A/B on the 1 MB bench batch: folding these launches together -- clean-after-use bitmaps, one
     //  tail kernel with a grid barrier and a last-workgroup scan -- was SLOWER than this plain
     //  sequence: back-to-back launches overlap their dispatch with the previous kernel, while
     //  single-workgroup tails and agent-scope fences sit on the critical path.)
+    // Single pass: small batches without special tokens are finished by ONE kernel.
+    const bool direct = small_tiles && !special && t->force_tile != 3 && n_bytes <= SPL_DIRECT_MAX_BYTES;
+    if (direct) {
+        if (t->bitmap_dirty) {
+            HIP_TRY(hipMemsetAsync(t->d_zero, 0, t->zero_words * 4, s));
+            t->bitmap_dirty = false;
+        }
+        if (++t->epoch >= 0xFFFFFFu) {          // tag wrap: forget every old status word
+            HIP_TRY(hipMemsetAsync(t->d_lb, 0, t->lb_words * 8, s));
+            t->epoch = 1;
+        }
+        b.lb = t->d_lb; b.epoch = t->epoch;
+        b.tstart = nullptr; b.qcount = nullptr;
+        t->last_qcount = nullptr;
+        MARK(KI_MARK); MARK(KI_SPECIAL); MARK(KI_PRETOK);
+        if (ntiles) hipLaunchKernelGGL((k_pretok<SPL_TILE_SMALL, false, true>), dim3(ntiles), dim3(NT), 0, s, t->dt, b);
+        else HIP_TRY(hipMemsetAsync(d_out_off, 0, (n_docs + 1) * 8, s));
+        MARK(KI_DEFER); MARK(KI_BPELANES); MARK(KI_BPELONG); MARK(KI_COUNT); MARK(KI_SCAN); MARK(KI_COMPACT); MARK(KI_N);
+    } else {
+    t->bitmap_dirty = true;
     MARK(KI_MARK);
     HIP_TRY(hipMemsetAsync(t->d_zero, 0, ((special ? 3 : 2) * uw + 8) * 4, s));
     if (n_docs) hipLaunchKernelGGL(k_mark_docs, dim3((uint32_t)((n_docs + 255) / 256)), dim3(256), 0, s, b);
@@ -216,6 +248,7 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
         hipLaunchKernelGGL(k_compact_docs, dim3(n_compact + n_docblk), dim3(NT), 0, s, b, n_compact);
     }
     MARK(KI_N);
+    }
 #undef MARK
     {
         const hipError_t le = hipGetLastError();
@@ -510,7 +543,7 @@ int spl_debug_phases(spl_tokenizer* t, int enable, unsigned long long stamps_out
     if (stamps_out && t->d_dbg) HIP_TRY(hipMemcpy(stamps_out, t->d_dbg, 16 * 8, hipMemcpyDeviceToHost));
     t->dbg_on = (enable & 1) != 0;
     t->stop_phase = (enable >> 3) & 7;
-    t->force_tile = (enable >> 1) & 3;      // development: bit 1 = force small tiles, bit 2 = force large
+    t->force_tile = (enable >> 1) & 3;      // development: 1 = small tiles, 2 = large tiles, 3 = small tiles + multi-pass
     return SPL_OK;
 }
 
@@ -527,7 +560,10 @@ int spl_last_queue_counts(spl_tokenizer* t, uint32_t counts_out[4]) {
     if (!t || !t->d_zero) return fail(SPL_EINVAL, "no batch has run");
     HIP_TRY(hipSetDevice(t->device));
     HIP_TRY(hipDeviceSynchronize());
-    if (!t->last_qcount) return fail(SPL_EINVAL, "no batch has run");
+    if (!t->last_qcount) {       // single-pass call: no global queues exist
+        for (int i = 0; i < 4; i++) counts_out[i] = 0;
+        return SPL_OK;
+    }
     HIP_TRY(hipMemcpy(counts_out, t->last_qcount, 16, hipMemcpyDeviceToHost));
     return SPL_OK;
 }

@@ -31,8 +31,11 @@ constexpr int WPAD = 16;                 // real bytes staged past the window (s
 constexpr int NT = 256;
 constexpr int RANK_BLK = 1024;           // positions per rank block (32 bitmap words)
 // tile geometries (tile bytes, right halo): chains may run past the tile into the halo
+#ifndef SPL_TILE_SMALL
 #define SPL_TILE_SMALL 768, 224          /* window 1024 B: one 4-byte word per lane */
+#endif
 #define SPL_TILE_LARGE 4096, 480         /* window 4608 B */
+constexpr uint64_t SPL_DIRECT_MAX_BYTES = 8ull << 20;   // batches up to this size: small tiles, single pass
 
 struct Batch {
     const uint8_t* text;
@@ -55,6 +58,8 @@ struct Batch {
     uint32_t* blk_base;    // exclusive token count per RANK_BLK block (+1 entry: total)
     uint32_t n_blk;
     uint32_t* ids_out; uint64_t ids_cap; uint64_t* off_out;
+    unsigned long long* lb;    // single-pass mode: per-tile look-back status words
+    uint32_t epoch;            // single-pass mode: tag of this call inside the status words (never 0)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -323,8 +328,7 @@ __device__ __forceinline__ uint32_t probe_finish(const DeviceTables& T, uint32_t
 
 template <class Emit>
 __device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const LdsAcc& tx, int p, int n, uint32_t* sub,
-                                                Emit emit, long long* dbgc = nullptr) {
-    const long long c_in = dbgc ? clock64() : 0;
+                                                Emit emit) {
     const int lane = threadIdx.x & 63;
     const int gl = lane & 15;
     const int gbase = lane - gl;
@@ -359,9 +363,7 @@ __device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const Lds
     if (SUB_LMAX >= 8 && maxlen >= 8) row[6] = probe_short(T, w0, w1, 0u, 8u);
     uint32_t rk = (gl + 1 < n) ? row[0] : SPL_NO_RANK;          // initial ranks (bpe.rs:114-116)
     uint32_t alive = n >= 16 ? 0xFFFFu : ((1u << n) - 1u);       // group-uniform, kept by every lane
-    if (dbgc) { dbgc[0] += clock64() - c_in; dbgc[1] += 1; }
     for (;;) {
-        if (dbgc) dbgc[2] += 1;
         const uint32_t key = rk == SPL_NO_RANK ? 0xFFFFFFFFu : ((rk << 8) | (uint32_t)gl);
         const uint32_t m = row16_min(key);
         const bool active = m != 0xFFFFFFFFu;
@@ -508,6 +510,277 @@ __device__ __forceinline__ void bpe_wave64_tab(const DeviceTables& T, const LdsA
     if (own && ((alive >> lane) & 1ull) && id != SPL_NO_RANK) emit(lane, id);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Global-memory accessor: class records computed on the fly (slow path, rare).
+struct GlobalAcc {
+    const DeviceTables* T;
+    const Batch* b;
+    __device__ uint32_t txt(int64_t q) const { return q < (int64_t)b->n_bytes ? b->text[q] : 0u; }
+    __device__ uint32_t txt(int q) const { return txt((int64_t)(uint32_t)q); }
+    __device__ uint32_t load32(int p) const {
+        const int64_t q = (uint32_t)p;
+        return txt(q) | (txt(q + 1) << 8) | (txt(q + 2) << 16) | (txt(q + 3) << 24);
+    }
+    __device__ uint32_t rec(int qi) const {
+        const int64_t q = (uint32_t)qi;
+        const int64_t B = b->n_bytes;
+        if (q >= B) return C_EOT | CB_TSTART | CB_SYNC;
+        if (b->skip && ((b->skip[q >> 5] >> (q & 31)) & 1u)) return C_EOT | CB_TSTART;
+        const uint32_t c0 = b->text[q];
+        uint32_t r;
+        if (c0 < 0x80u) r = cp_class(*T, c0);
+        else if (c0 < 0xC0u) r = C_CONT;
+        else {
+            uint32_t want = utf8_len(c0), len = 1;
+            while (len < want && q + len < B && (b->text[q + len] & 0xC0u) == 0x80u) len++;
+            const uint32_t cls = (len == want) ? cp_class(*T, decode_at(*this, (int)q, c0)) : (uint32_t)C_P;
+            r = cls | ((len - 1) << CB_LEN_SHIFT);
+        }
+        if ((b->tstart[q >> 5] >> (q & 31)) & 1u) r |= CB_TSTART | CB_SYNC;
+        return r;
+    }
+};
+
+// GlobalAcc for the single-pass kernel, which has no text-start bitmap in HBM: a chain that is
+// continued beyond the window stops at the first text start after its own start, so that ONE
+// position (found once by a search of doc_off) stands in for the bitmap.
+struct DirectAcc {
+    const DeviceTables* T;
+    const Batch* b;
+    uint32_t next_ts;          // first text start after the chain's start (n_bytes if none)
+    __device__ __forceinline__ uint32_t txt(int64_t q) const { return q < (int64_t)b->n_bytes ? b->text[q] : 0u; }
+    __device__ __forceinline__ uint32_t txt(int q) const { return txt((int64_t)(uint32_t)q); }
+    __device__ __forceinline__ uint32_t load32(int p) const {
+        const int64_t q = (uint32_t)p;
+        return txt(q) | (txt(q + 1) << 8) | (txt(q + 2) << 16) | (txt(q + 3) << 24);
+    }
+    __device__ __forceinline__ uint32_t rec(int qi) const {
+        const int64_t q = (uint32_t)qi;
+        const int64_t B = b->n_bytes;
+        if (q >= B) return C_EOT | CB_TSTART | CB_SYNC;
+        const uint32_t c0 = b->text[q];
+        uint32_t r;
+        if (c0 < 0x80u) r = cp_class(*T, c0);
+        else if (c0 < 0xC0u) r = C_CONT;
+        else {
+            uint32_t want = utf8_len(c0), len = 1;
+            while (len < want && q + len < B && (b->text[q + len] & 0xC0u) == 0x80u) len++;
+            const uint32_t cls = (len == want) ? cp_class(*T, decode_at(*this, (int)q, c0)) : (uint32_t)C_P;
+            r = cls | ((len - 1) << CB_LEN_SHIFT);
+        }
+        if ((uint32_t)q == next_ts) r |= CB_TSTART | CB_SYNC;
+        return r;
+    }
+};
+
+__device__ __forceinline__ void emit_token(const Batch& b, uint32_t pos, uint32_t id) {
+    b.stage[pos] = id;
+    atomicOr(&b.tbits[pos >> 5], 1u << (pos & 31));
+}
+
+// One lane per deferred segment: continue the chain from its start to the next sync point.
+__device__ void deferred_items(const DeviceTables& T, const Batch& b, uint32_t first, uint32_t stride) {
+    const uint32_t nq = min(b.qcount[3], b.qcapdefer);
+    GlobalAcc acc{&T, &b};
+    for (uint32_t it = first; it < nq; it += stride) {
+        uint32_t p = b.qdefer[it];
+        for (;;) {
+            if (p >= b.n_bytes) break;
+            const int e = match_end(acc, (int)p, (int)T.pattern);     // never defers: no window end
+            const uint32_t n = (uint32_t)e - p;
+            const uint32_t id = probe_chunk(T, acc, (int)p, (int)n);
+            if (id != SPL_NO_RANK) emit_token(b, p, id);
+            else if (n > 1) push_long(b, p, n);     // any length: k_bpe_long takes n >= 2
+            p = (uint32_t)e;
+            if (p >= b.n_bytes) break;
+            const uint32_t r = acc.rec((int)p);
+            if (r & (CB_SYNC | CB_TSTART)) break;
+            // sync test against the previous character's class
+            int64_t j = (int64_t)p - 1;
+            while (j > 0 && (b.text[j] & 0xC0u) == 0x80u && j > (int64_t)p - 4) j--;
+            const uint32_t prev = acc.rec((int)j) & CB_CLASS;
+            if (prev < C_EOT && is_sync((int)T.pattern, prev, r & CB_CLASS)) break;
+        }
+    }
+}
+__global__ void k_deferred(DeviceTables T, Batch b) {
+    deferred_items(T, b, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// ------------------------------------------------------------------------------------------
+// byte_pair_encode, ONE LANE PER CHUNK (17..64 bytes), for large batches: node arrays interleaved
+// in LDS (node-major, lane-minor: conflict-free when lanes touch the same node index), merge loop
+// = bpe_serial (spl_lookup.h).  Slow per chunk, but every lane carries its own chain of dependent
+// pair-table probes, so a CU keeps hundreds of them in flight.
+template <int NMAX, int THREADS> struct LaneStore {
+    uint32_t* ids;
+    uint32_t* rks;
+    int lane;
+    __device__ __forceinline__ uint32_t& id(int i) { return ids[i * THREADS + lane]; }
+    __device__ __forceinline__ uint32_t& rk(int i) { return rks[i * THREADS + lane]; }
+};
+struct GlobalText {
+    const uint8_t* text;
+    __device__ __forceinline__ uint32_t txt(int q) const { return text[(uint32_t)q]; }
+};
+__global__ __launch_bounds__(64) void k_bpe_lanes64(DeviceTables T, Batch b) {
+    __shared__ uint32_t s_ids[64 * 64];
+    __shared__ uint32_t s_rks[64 * 64];
+    const uint32_t nq = min(b.qcount[0], b.qcap64);
+    LaneStore<64, 64> st{s_ids, s_rks, (int)threadIdx.x};
+    GlobalText tx{b.text};
+    for (uint32_t it = blockIdx.x * 64 + threadIdx.x; it < nq; it += gridDim.x * 64) {
+        const uint2 item = b.q64[it];
+        const int n = (int)item.y;
+        bpe_serial(T, st, tx, (int)item.x, n);
+        for (int i = 0; i < n; i++) {
+            const uint32_t id = st.id(i);
+            if (id != SPL_DEAD && id != SPL_NO_RANK) emit_token(b, item.x + i, id);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Long chunks (> 64 bytes; plus every miss of a deferred segment).
+//
+// bpe_wave: ONE WAVEFRONT per chunk of up to WAVE_NMAX bytes.  Nodes live in the wavefront's own
+// LDS slab as an index-linked list (id, rank of the pair with the next node, next, prev -- the
+// reference's Node, src/core/bpe.rs:43-54, minus start/len which are implied by the index); lane l
+// owns nodes l, l+64, ...  Per merge: each lane scans its <= 8 nodes, DPP min-reduction of
+// (rank << 9 | index) gives the leftmost minimum, lane 0 relinks, lanes 1 and 2 re-rank the two
+// affected pairs concurrently.  No workgroup barrier: the four wavefronts of a workgroup work
+// on four different chunks.
+// bpe_block_global: chunks beyond WAVE_NMAX (pathological single-class runs): one workgroup per
+// chunk, nodes in HBM scratch (ids in stage[], ranks in rank_scr[]), cached per-thread minima.
+constexpr int GROUP_NMAX = 128;       // 16 lanes x 8 register slots
+constexpr int WAVE_NMAX = 512;
+constexpr uint32_t NIL16 = 0xFFFFu;
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <class Emit>
+__device__ __forceinline__ void bpe_wave(const DeviceTables& T, const Batch& b, uint32_t pos, int n, uint32_t* s_id,
+                                         uint32_t* s_rk, uint16_t* s_nx, uint16_t* s_pv, Emit emit) {
+    const int lane = threadIdx.x & 63;
+    for (int i = lane; i < n; i += 64) {
+        s_id[i] = T.byte_id[b.text[pos + i]];
+        s_nx[i] = (uint16_t)(i + 1 < n ? i + 1 : (int)NIL16);
+        s_pv[i] = (uint16_t)(i > 0 ? i - 1 : (int)NIL16);
+    }
+    wave_lds_sync();
+    for (int i = lane; i < n; i += 64) s_rk[i] = (i + 1 < n) ? pair_rank(T, s_id[i], s_id[i + 1]) : SPL_NO_RANK;
+    wave_lds_sync();
+    for (;;) {
+        uint32_t key = 0xFFFFFFFFu;
+        for (int i = lane; i < n; i += 64) {
+            const uint32_t r = s_rk[i];
+            const uint32_t k = r == SPL_NO_RANK ? 0xFFFFFFFFu : ((r << 9) | (uint32_t)i);
+            key = k < key ? k : key;
+        }
+        uint32_t m = row16_min(key);
+        const uint32_t r0 = __builtin_amdgcn_readlane(m, 0), r1 = __builtin_amdgcn_readlane(m, 16);
+        const uint32_t r2 = __builtin_amdgcn_readlane(m, 32), r3 = __builtin_amdgcn_readlane(m, 48);
+        const uint32_t a = r0 < r1 ? r0 : r1, c = r2 < r3 ? r2 : r3;
+        m = a < c ? a : c;
+        if (m == 0xFFFFFFFFu) break;
+        const uint32_t mi = m & 511u, mn = m >> 9;
+        const uint32_t j = s_nx[mi];                       // uniform addresses: LDS broadcasts
+        const uint32_t j2 = s_nx[j];
+        const uint32_t h = s_pv[mi];
+        const uint32_t id_j2 = j2 != NIL16 ? s_id[j2] : 0u;
+        const uint32_t id_h = h != NIL16 ? s_id[h] : 0u;
+        wave_lds_sync();
+        if (lane == 0) {
+            s_id[mi] = mn;
+            s_id[j] = SPL_DEAD;
+            s_rk[j] = SPL_NO_RANK;
+            s_nx[mi] = (uint16_t)j2;
+            if (j2 != NIL16) s_pv[j2] = (uint16_t)mi;
+        } else if (lane == 1) {
+            s_rk[mi] = j2 != NIL16 ? pair_rank(T, mn, id_j2) : SPL_NO_RANK;
+        } else if (lane == 2) {
+            if (h != NIL16) s_rk[h] = pair_rank(T, id_h, mn);
+        }
+        wave_lds_sync();
+    }
+    for (int i = lane; i < n; i += 64) {
+        const uint32_t id = s_id[i];
+        if (id != SPL_DEAD && id != SPL_NO_RANK) emit(pos + (uint32_t)i, id);
+    }
+    wave_lds_sync();
+}
+
+template <class Emit>
+__device__ __forceinline__ void bpe_block_global(const DeviceTables& T, const Batch& b, uint32_t pos, int n, unsigned long long* s_red,
+                                 unsigned long long* s_best, int* s_touch, Emit emit) {
+    const int tid = threadIdx.x;
+    uint32_t* ids = b.stage + pos;
+    uint32_t* rks = b.rank_scr + pos;
+    for (int i = tid; i < n; i += NT) ids[i] = T.byte_id[b.text[pos + i]];
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) rks[i] = (i + 1 < n) ? pair_rank(T, ids[i], ids[i + 1]) : SPL_NO_RANK;
+    __syncthreads();
+    bool dirty = true;
+    unsigned long long mine = ~0ull;          // (rank << 32 | index): min == leftmost minimum
+    for (;;) {
+        if (dirty) {
+            mine = ~0ull;
+            for (int i = tid; i < n; i += NT) {
+                const unsigned long long c = ((unsigned long long)rks[i] << 32) | (uint32_t)i;
+                mine = c < mine ? c : mine;
+            }
+            dirty = false;
+        }
+        unsigned long long x = mine;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned long long y = __shfl_xor(x, d);
+            x = y < x ? y : x;
+        }
+        if ((tid & 63) == 0) s_red[tid >> 6] = x;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long m = s_red[0];
+            for (int wv = 1; wv < NT / 64; wv++) m = s_red[wv] < m ? s_red[wv] : m;
+            *s_best = m;
+        }
+        __syncthreads();
+        const unsigned long long best = *s_best;
+        const uint32_t mn = (uint32_t)(best >> 32);
+        if (mn == SPL_NO_RANK) break;
+        const int mi = (int)(uint32_t)best;
+        if (tid == 0) {     // the neighbour searches walk tomb-stones; at most a token's length of them
+            int j = mi + 1;
+            while (ids[j] == SPL_DEAD) j++;
+            ids[mi] = mn;
+            ids[j] = SPL_DEAD;
+            rks[j] = SPL_NO_RANK;
+            int j2 = j + 1;
+            while (j2 < n && ids[j2] == SPL_DEAD) j2++;
+            rks[mi] = j2 < n ? pair_rank(T, mn, ids[j2]) : SPL_NO_RANK;
+            int h = mi - 1;
+            while (h >= 0 && ids[h] == SPL_DEAD) h--;
+            if (h >= 0) rks[h] = pair_rank(T, ids[h], mn);
+            s_touch[0] = mi; s_touch[1] = j; s_touch[2] = h;
+            __threadfence_block();
+        }
+        __syncthreads();
+        const int a0 = s_touch[0] % NT, a1 = s_touch[1] % NT, a2 = s_touch[2] < 0 ? -1 : s_touch[2] % NT;
+        if (tid == a0 || tid == a1 || tid == a2) dirty = true;
+        __syncthreads();
+    }
+    // survivors become tokens
+    for (int i = tid; i < n; i += NT) {
+        const uint32_t id = ids[i];
+        if (id != SPL_DEAD && id != SPL_NO_RANK) emit(pos + (uint32_t)i, id);
+    }
+    __syncthreads();
+}
+
 // Tile geometry is a template parameter: small batches use small tiles (many wavefronts, 4 bytes
 // per lane, latency hidden by occupancy), large batches use 4 KiB tiles (less halo overhead).
 // Every phase maps ONE 4-byte word of the window to one lane, so LDS traffic is bank-conflict free.
@@ -526,15 +799,58 @@ template <int TB_, int RH_> struct TileGeom {
 // global q64 (one atomic per workgroup) for k_bpe_lanes64, which works them one lane per chunk --
 // with hundreds of thousands of such chunks in flight (CJK text) that is the throughput-optimal
 // shape; for small batches the latency-optimal in-kernel groups are used instead.
-template <int TB_, int RH_, bool EXPORT_MEDIUM>
-__global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
+//
+// DIRECT (single pass, small batches without special tokens): the workgroup also produces the
+// FINAL output of its tile.  Text-start bits come from a search of doc_off (no k_mark_docs),
+// token ids are kept in LDS, chunks longer than 64 bytes and the (at most one) chain that
+// outgrows the window are finished right here, the tile's token count is published in a
+// look-back status word (epoch-tagged: nothing to clear between calls), and once the counts of
+// all earlier tiles are known the ids go straight to ids_out[] and the document offsets to
+// off_out[].  One launch instead of seven; stage[] / tbits[] in HBM are touched only by tokens
+// that start beyond the window (and cleaned up by the workgroup that set them).
+#ifndef SPL_LB_SLEEP
+#define SPL_LB_SLEEP 16
+#endif
+#ifndef SPL_WORK_PRIO
+#define SPL_WORK_PRIO 2
+#endif
+#ifndef SPL_PRETOK_WAVES
+#define SPL_PRETOK_WAVES 6
+#endif
+constexpr int DIRECT_LQCAP = 32;          // long-chunk list of one workgroup (refilled while a chain is continued)
+constexpr int DIRECT_WAVE_NMAX = 256;     // nodes of one wavefront's LDS slab in the single-pass tail
+constexpr unsigned long long LB_AGG = 1ull << 38, LB_PFX = 2ull << 38, LB_VAL = (1ull << 38) - 1ull;
+
+template <int TB_, int RH_> struct PretokScanLds {           // dead once the merge loop is done
+    using G = TileGeom<TB_, RH_>;
+    uint32_t rec32[G::NW32];
+    uint32_t mk[MK_COUNT * (G::NBW + 1)];                // class bitmasks of the window (spl_scan_masks.h)
+    uint32_t sub[NT / 16][16 * SUB_W];                   // per 16-lane group: tabulated substring ids
+    uint32_t miss[G::QCAP];                              // p | n << 16, one region per size class
+};
+struct PretokTailLds {                                   // single-pass tail: one node slab per wavefront
+    uint32_t id[NT / 64][DIRECT_WAVE_NMAX];
+    uint32_t rk[NT / 64][DIRECT_WAVE_NMAX];
+    uint16_t nx[NT / 64][DIRECT_WAVE_NMAX];
+    uint16_t pv[NT / 64][DIRECT_WAVE_NMAX];
+};
+
+template <int TB_, int RH_, bool EXPORT_MEDIUM, bool DIRECT = false>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPL_PRETOK_WAVES)))
+void k_pretok(DeviceTables T, Batch b) {
     using G = TileGeom<TB_, RH_>;
     constexpr int Wv = G::Wv;
     __shared__ __attribute__((aligned(16))) uint32_t s_txt32[G::NW32];
-    __shared__ __attribute__((aligned(16))) uint32_t s_rec32[G::NW32];
+    __shared__ __attribute__((aligned(16))) union {
+        PretokScanLds<TB_, RH_> a;
+        PretokTailLds t;
+    } s_u;
+    uint32_t* const s_rec32 = s_u.a.rec32;
+    uint32_t* const s_mk = s_u.a.mk;
+    auto& s_sub = s_u.a.sub;
+    uint32_t* const s_miss = s_u.a.miss;
     __shared__ uint32_t s_ts[G::NBW + 1];                // text-start bits of the window
     __shared__ uint32_t s_sk[G::NBW + 1];                // special-literal bits of the window
-    __shared__ uint32_t s_mk[MK_COUNT * (G::NBW + 1)];   // class bitmasks of the window (spl_scan_masks.h)
     __shared__ uint32_t s_cbits[G::NBW + 1];
     __shared__ uint32_t s_tbits[G::NBW + 1];
     __shared__ uint16_t s_cpos[Wv + 2];
@@ -542,14 +858,23 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
     __shared__ uint32_t s_wsum[NT / 64];
     __shared__ uint32_t s_total;
     __shared__ uint32_t s_nq[4];                         // miss counts [0] (<= 16 B) [1] (17..64 B), work cursors [2] [3]
-    __shared__ uint32_t s_sub[NT / 16][16 * SUB_W];      // per 16-lane group: tabulated substring ids
-    __shared__ uint32_t s_miss[G::QCAP];                 // p | n << 16, one region per size class
+    // single-pass state
+    __shared__ uint32_t s_ids[DIRECT ? Wv : 1];          // id of the token that starts at this window index
+    __shared__ uint32_t s_wpre[DIRECT ? G::NBW + 2 : 1]; // exclusive token counts of the window's bitmap words
+    __shared__ uint32_t s_lq[DIRECT ? 2 * DIRECT_LQCAP : 1];   // (global position, length) of chunks > 64 bytes
+    __shared__ uint32_t s_dq[12];                        // [0] long-list fill [1] deferred count [2],[3] deferred starts
+                                                         // [4] end of the overflow range [5] chain cursor [6] chain done
+    __shared__ unsigned long long s_red[NT / 64];
+    __shared__ unsigned long long s_best;
+    __shared__ int s_touch[3];
+    __shared__ unsigned long long s_base;                // tokens of all earlier tiles
     uint8_t* const s_txt = reinterpret_cast<uint8_t*>(s_txt32);
     uint8_t* const s_rec = reinterpret_cast<uint8_t*>(s_rec32);
 #define SPL_STAMP(i) do { if (b.dbg && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) b.dbg[i] = clock64(); \
                           if ((i) >= 1 && (i) <= 7 && b.stop_phase == (uint32_t)(i)) return; } while (0)
 
     const int tid = threadIdx.x;
+    if (DIRECT) __builtin_amdgcn_s_setprio(SPL_WORK_PRIO);
     const int64_t t0 = (int64_t)blockIdx.x * TB_;
     const int64_t w0 = t0 - LH;                       // global position of window index 0
     const int64_t B = b.n_bytes;
@@ -558,8 +883,7 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
     if (b.dbg && tid == 0 && blockIdx.x == 0) b.dbg[14] = (unsigned long long)wall_clock64();   // dispatched first
     if (b.dbg && tid == 0 && blockIdx.x == gridDim.x / 2) b.dbg[11] = (unsigned long long)wall_clock64();
     const unsigned long long blk_t0 = b.dbg ? (unsigned long long)wall_clock64() : 0ull;
-    long long blk_c0 = 0, blk_c1 = 0, blk_c2 = 0;
-    long long blk_dc[3] = {0, 0, 0};
+    unsigned long long blk_w1 = 0, blk_w2 = 0;
     if (b.dbg && tid == 0 && blockIdx.x == gridDim.x - 1) b.dbg[13] = (unsigned long long)wall_clock64();
 
     // ---- stage text (coalesced 16 B per lane) and the window's flag bits ------------------------
@@ -578,15 +902,44 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
     if (tid < G::NBW + 1) {
         const int64_t wi = (w0 >> 5) + tid;           // w0 is a multiple of 32
         const bool in = wi >= 0 && wi * 32 < B;
-        s_ts[tid] = in ? b.tstart[wi] : 0u;
-        s_sk[tid] = (in && b.skip) ? b.skip[wi] : 0u;
+        s_ts[tid] = (in && !DIRECT) ? b.tstart[wi] : 0u;
+        s_sk[tid] = (in && b.skip && !DIRECT) ? b.skip[wi] : 0u;
         s_cbits[tid] = 0;
         s_tbits[tid] = 0;
     }
     if (tid < 128) s_ascii[tid] = T.ucls_stage2[((uint32_t)T.ucls_stage1[0] << T.ucls_shift) + tid];
     if (tid < 4) s_nq[tid] = 0;
+    if (tid < 12) s_dq[tid] = 0;
+    // single pass: the window's text starts straight from doc_off.  NT-ary search for the first
+    // document that starts at or after the window (two rounds up to 65 536 documents), then the
+    // documents of the window set their bits.
+    uint32_t dw = 0;                                   // first document with doc_off >= max(w0, 0)
+    if (DIRECT) {
+        uint32_t lo = 0, hi = b.n_docs;
+        const uint64_t target = w0 > 0 ? (uint64_t)w0 : 0ull;
+        while (target != 0 && lo < hi) {
+            const uint32_t span = hi - lo, st = (span + NT - 1) / NT;
+            const uint64_t idx = (uint64_t)lo + (uint64_t)tid * st;
+            const bool below = idx < hi && b.doc_off[idx] < target;
+            const uint32_t c = (uint32_t)__syncthreads_count(below);
+            if (c == 0) { hi = lo; break; }
+            const uint64_t nhi = (uint64_t)lo + (uint64_t)c * st;
+            lo = lo + (c - 1) * st + 1;                // element lo + (c-1)*st is below the target
+            hi = nhi < hi ? (uint32_t)nhi : hi;        // element lo + c*st (if any) is not
+        }
+        dw = lo;
+        __syncthreads();                               // s_ts zeroed by all before any bit is set
+        const uint64_t lim = (uint64_t)(w0 + (int64_t)(G::NBW + 1) * 32);
+        for (uint32_t base = dw;; base += NT) {
+            const uint64_t d = (uint64_t)base + tid;
+            uint64_t p = ~0ull;
+            if (d < b.n_docs) p = b.doc_off[d];
+            const bool in = p < lim && p < (uint64_t)B;
+            if (in) { const uint32_t i = (uint32_t)(p - (uint64_t)w0); atomicOr(&s_ts[i >> 5], 1u << (i & 31)); }
+            if (!__syncthreads_or(tid == NT - 1 && in)) break;
+        }
+    }
     SPL_STAMP(0);
-    if (b.dbg) blk_c0 = clock64();
     __syncthreads();
     SPL_STAMP(1);
 
@@ -710,23 +1063,29 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
     {
         const MaskLdsAcc acc{s_rec, s_txt, s_mk, NBW1, Wv, (B - w0) <= (int64_t)Wv};
         const int nsync = (int)s_total;
+        // only the LAST chain of a tile can reach the window end, so at most one start is recorded
+        auto push_defer = [&](uint32_t gpos) {
+            if (DIRECT) {
+                const uint32_t qi = atomicAdd(&s_dq[1], 1u);
+                if (qi < 2) s_dq[2 + qi] = gpos;
+            } else {
+                const uint32_t qi = atomicAdd(&b.qcount[3], 1u);
+                if (qi < b.qcapdefer) b.qdefer[qi] = gpos;
+            }
+        };
         for (int k = tid; k < nsync; k += NT) {
             int p = s_cpos[k];
             for (;;) {
                 atomicOr(&s_cbits[p >> 5], 1u << (p & 31));
                 const int e = match_end_m(acc, p, (int)T.pattern);
                 if (e == SPL_DEFER) {                 // the match outgrows the window
-                    const uint32_t qi = atomicAdd(&b.qcount[3], 1u);
-                    if (qi < b.qcapdefer) b.qdefer[qi] = (uint32_t)(w0 + p);
+                    push_defer((uint32_t)(w0 + p));
                     break;
                 }
                 p = e;
                 if (p >= Wv) {                         // ended exactly on the window edge
                     atomicOr(&s_cbits[Wv >> 5], 1u << (Wv & 31));
-                    if (w0 + Wv < B) {
-                        const uint32_t qi = atomicAdd(&b.qcount[3], 1u);
-                        if (qi < b.qcapdefer) b.qdefer[qi] = (uint32_t)(w0 + Wv);
-                    }
+                    if (w0 + Wv < B) push_defer((uint32_t)(w0 + Wv));
                     break;
                 }
                 if (((s_mk[MK_SY * NBW1 + (p >> 5)] | s_mk[MK_TS * NBW1 + (p >> 5)]) >> (p & 31)) & 1u) {
@@ -774,7 +1133,8 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
             const int n = (int)s_cpos[k + 1] - p;
             const uint32_t id = probe_chunk(T, tx, p, n);
             if (id != SPL_NO_RANK) {
-                b.stage[w0 + p] = id;
+                if (DIRECT) s_ids[p] = id;
+                else b.stage[w0 + p] = id;
                 atomicOr(&s_tbits[p >> 5], 1u << (p & 31));
             } else if (n > 1) {
                 // misses: short and medium chunks are merged right here by this workgroup (list in
@@ -782,7 +1142,11 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
                 const uint32_t item = (uint32_t)p | ((uint32_t)n << 16);
                 if (n <= 16) s_miss[atomicAdd(&s_nq[0], 1u)] = item;
                 else if (n <= 64) s_miss[G::C16 + atomicAdd(&s_nq[1], 1u)] = item;
-                else push_long(b, (uint32_t)(w0 + p), (uint32_t)n);
+                else if (DIRECT) {                       // at most Wv / 65 of them
+                    const uint32_t qi = atomicAdd(&s_dq[0], 1u);
+                    s_lq[2 * qi] = (uint32_t)(w0 + p);
+                    s_lq[2 * qi + 1] = (uint32_t)n;
+                } else push_long(b, (uint32_t)(w0 + p), (uint32_t)n);
             }
         }
     }
@@ -790,10 +1154,14 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
     SPL_STAMP(6);
 
     // ---- merge loop for this tile's misses: wavefronts pull work until both lists are empty ------
-    if (b.dbg) blk_c1 = clock64();
     {
         const uint32_t m16 = s_nq[0], m64 = s_nq[1];
         uint32_t* const stage_w0 = b.stage + w0;          // window index -> global position
+        auto put = [&](int q, uint32_t id) {
+            if (DIRECT) s_ids[q] = id;
+            else stage_w0[q] = id;
+            atomicOr(&s_tbits[q >> 5], 1u << (q & 31));
+        };
         const int lane = tid & 63;
         if (EXPORT_MEDIUM) {
             if (tid == 0) s_total = m64 ? atomicAdd(&b.qcount[0], m64) : 0u;
@@ -817,8 +1185,7 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
             const int p = (int)(item & 0xFFFFu);
             bpe_wave64_tab(T, LdsAcc{s_rec, s_txt}, p, (int)(item >> 16), s_sub[(tid >> 6) * 4],
                            [&](int i, uint32_t id) {
-                               stage_w0[p + i] = id;
-                               atomicOr(&s_tbits[(p + i) >> 5], 1u << ((p + i) & 31));
+                               put(p + i, id);
                            });
         }
         SPL_STAMP(9);
@@ -834,8 +1201,7 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
             const int p = (int)(item & 0xFFFFu);
             bpe_group16<4>(T, has ? (int)(item >> 16) : 0, [&](int i) { return (uint32_t)s_txt[p + i]; },
                            [&](int i, uint32_t id) {
-                               stage_w0[p + i] = id;
-                               atomicOr(&s_tbits[(p + i) >> 5], 1u << ((p + i) & 31));
+                               put(p + i, id);
                            });
         }
         for (;;) {
@@ -848,267 +1214,240 @@ __global__ __launch_bounds__(NT) void k_pretok(DeviceTables T, Batch b) {
             const int p = (int)(item & 0xFFFFu);
             bpe_group16_tab(T, LdsAcc{s_rec, s_txt}, p, has ? (int)(item >> 16) : 0, s_sub[tid >> 4],
                             [&](int i, uint32_t id) {
-                                stage_w0[p + i] = id;
-                                atomicOr(&s_tbits[(p + i) >> 5], 1u << ((p + i) & 31));
-                            }, b.dbg && tid == 0 ? blk_dc : nullptr);
+                                put(p + i, id);
+                            });
         }
     }
     SPL_STAMP(10);
     __syncthreads();
     SPL_STAMP(7);
-    if (b.dbg) blk_c2 = clock64();
-    if (tid < G::NBW) {
-        const uint32_t wv = s_tbits[tid];
-        if (wv) atomicOr(&b.tbits[(w0 >> 5) + tid], wv);
+    if (b.dbg) blk_w1 = blk_w2 = (unsigned long long)wall_clock64();
+    if (!DIRECT) {
+        if (tid < G::NBW) {
+            const uint32_t wv = s_tbits[tid];
+            if (wv) atomicOr(&b.tbits[(w0 >> 5) + tid], wv);
+        }
+    } else {
+        static_assert(!(DIRECT && EXPORT_MEDIUM), "the single-pass kernel merges everything itself");
+        const int lane = tid & 63, wv = tid >> 6;
+        const uint32_t ovf_lo = (uint32_t)(w0 + Wv);       // tokens from here on live in HBM (stage[] / tbits[])
+        auto emit_g = [&](uint32_t q, uint32_t id) {
+            const int64_t i = (int64_t)q - w0;
+            if (i < (int64_t)Wv) {
+                s_ids[i] = id;
+                atomicOr(&s_tbits[i >> 5], 1u << (i & 31));
+            } else {
+                __hip_atomic_store(&b.stage[q], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicOr(&b.tbits[q >> 5], 1u << (q & 31));
+                atomicMax(&s_dq[4], q + 1u);
+            }
+        };
+        // ---- rare: chunks of more than 64 bytes, and the chain that outgrew the window -----------
+        if (s_dq[0] | s_dq[1]) {                           // workgroup-uniform
+            for (;;) {
+                const uint32_t nl = s_dq[0] < (uint32_t)DIRECT_LQCAP ? s_dq[0] : (uint32_t)DIRECT_LQCAP;
+                for (uint32_t it = wv; it < nl; it += NT / 64) {         // one wavefront per chunk
+                    const int n = (int)s_lq[2 * it + 1];
+                    if (n <= DIRECT_WAVE_NMAX)
+                        bpe_wave(T, b, s_lq[2 * it], n, s_u.t.id[wv], s_u.t.rk[wv], s_u.t.nx[wv], s_u.t.pv[wv], emit_g);
+                }
+                __syncthreads();
+                for (uint32_t it = 0; it < nl; it++) {                   // oversize: the whole workgroup
+                    const int n = (int)s_lq[2 * it + 1];
+                    if (n > DIRECT_WAVE_NMAX) bpe_block_global(T, b, s_lq[2 * it], n, s_red, &s_best, s_touch, emit_g);
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    // continue the chain(s) lane-serially (deferred_items): whole-chunk hits become
+                    // tokens at once, misses of ANY length refill the list for the loop above
+                    uint32_t fill = 0;
+                    const uint32_t nd = s_dq[1] < 2u ? s_dq[1] : 2u;
+                    uint32_t done = s_dq[6], pcur = s_dq[5];
+                    bool running = s_dq[7] != 0;
+                    DirectAcc acc{&T, &b, s_dq[8]};
+                    while (done < nd && fill < (uint32_t)DIRECT_LQCAP) {
+                        if (!running) {
+                            pcur = s_dq[2 + done];
+                            // first text start after the chain's start
+                            uint32_t lo = 0, hi = b.n_docs;
+                            while (lo < hi) {
+                                const uint32_t mid = lo + (hi - lo) / 2;
+                                if (b.doc_off[mid] <= (uint64_t)pcur) lo = mid + 1; else hi = mid;
+                            }
+                            acc.next_ts = lo < b.n_docs ? (uint32_t)b.doc_off[lo] : b.n_bytes;
+                            running = true;
+                        }
+                        bool finished = false;
+                        for (;;) {
+                            if (pcur >= b.n_bytes) { finished = true; break; }
+                            const int e = match_end(acc, (int)pcur, (int)T.pattern);   // never defers: no window end
+                            const uint32_t n = (uint32_t)e - pcur;
+                            const uint32_t id = probe_chunk(T, acc, (int)pcur, (int)n);
+                            if (id != SPL_NO_RANK) emit_g(pcur, id);
+                            else if (n > 1) { s_lq[2 * fill] = pcur; s_lq[2 * fill + 1] = n; fill++; }
+                            pcur = (uint32_t)e;
+                            if (pcur >= b.n_bytes) { finished = true; break; }
+                            const uint32_t r = acc.rec((int)pcur);
+                            if (r & (CB_SYNC | CB_TSTART)) { finished = true; break; }
+                            int64_t j = (int64_t)pcur - 1;
+                            while (j > 0 && (b.text[j] & 0xC0u) == 0x80u && j > (int64_t)pcur - 4) j--;
+                            const uint32_t prev = acc.rec((int)j) & CB_CLASS;
+                            if (prev < C_EOT && is_sync((int)T.pattern, prev, r & CB_CLASS)) { finished = true; break; }
+                            if (fill >= (uint32_t)DIRECT_LQCAP) break;
+                        }
+                        if (finished) { done++; running = false; }
+                    }
+                    s_dq[0] = fill; s_dq[5] = pcur; s_dq[6] = done; s_dq[7] = running ? 1u : 0u; s_dq[8] = acc.next_ts;
+                }
+                __syncthreads();
+                const uint32_t nd = s_dq[1] < 2u ? s_dq[1] : 2u;
+                if (s_dq[0] == 0 && s_dq[6] >= nd) break;
+            }
+        }
+        // ---- token count of the tile: window bitmap + overflow range --------------------------------
+        uint32_t c_win;
+        {
+            uint32_t word = tid < G::NBW + 1 ? s_tbits[tid] : 0u;
+            const uint32_t cnt = __popc(word);
+            uint32_t x = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(x, d);
+                if (lane >= d) x += y;
+            }
+            if (lane == 63) s_wsum[wv] = x;
+            __syncthreads();
+            uint32_t basew = x - cnt;
+            for (int k = 0; k < wv; k++) basew += s_wsum[k];
+            if (tid == NT - 1) s_total = basew + cnt;
+            if (tid < G::NBW + 2) s_wpre[tid] = basew;
+            while (word) {                                  // token positions in order
+                const int bit = __ffs(word) - 1;
+                word &= word - 1;
+                s_cpos[basew++] = (uint16_t)(tid * 32 + bit);
+            }
+            __syncthreads();
+            c_win = s_total;
+        }
+        const uint32_t ovf_hi = s_dq[4];                     // exclusive; 0 if nothing went beyond the window
+        const uint32_t wlo = ovf_lo >> 5, whi = ovf_hi > ovf_lo ? (ovf_hi + 31) >> 5 : wlo;
+        uint32_t c_ovf = 0;
+        if (whi > wlo) {
+            uint32_t mine = 0;
+            for (uint32_t w = wlo + tid; w < whi; w += NT)
+                mine += __popc(__hip_atomic_load(&b.tbits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (tid == 0) s_dq[9] = 0;
+            __syncthreads();
+            if (mine) atomicAdd(&s_dq[9], mine);
+            __syncthreads();
+            c_ovf = s_dq[9];
+        }
+        const unsigned long long total = (unsigned long long)c_win + c_ovf;
+        // ---- publish the count, look back over the earlier tiles ------------------------------------
+        const unsigned long long tag = (unsigned long long)b.epoch << 40;
+        if (tid == 0) {
+            __hip_atomic_store(&b.lb[blockIdx.x], tag | (blockIdx.x == 0 ? LB_PFX : LB_AGG) | total, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            if (blockIdx.x == 0) s_base = 0;
+        }
+        // waiting wavefronts must not compete with the ones still merging (issue arbitration favours
+        // the OLDEST wavefront, and the waiting ones are the old ones): lowest priority, long naps
+        __builtin_amdgcn_s_setprio(0);
+        if (wv == 0 && blockIdx.x > 0) {
+            unsigned long long excl = 0;
+            int64_t top = (int64_t)blockIdx.x - 1;
+            for (;;) {
+                const int64_t i = top - lane;
+                unsigned long long st = 0;
+                bool ready = true;
+                if (i >= 0) {
+                    st = __hip_atomic_load(&b.lb[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ready = (st >> 40) == (unsigned long long)b.epoch;
+                }
+                const bool is_pfx = i < 0 || (ready && (st & LB_PFX) != 0);
+                const unsigned long long m_pfx = __ballot(is_pfx), m_nr = __ballot(!ready);
+                const int fp = m_pfx ? __ffsll((long long)m_pfx) - 1 : 64;     // first lane holding a prefix
+                const unsigned long long need = fp >= 63 ? ~0ull : ((2ull << fp) - 1ull);
+                if (m_nr & need) { __builtin_amdgcn_s_sleep(SPL_LB_SLEEP); continue; }
+                unsigned long long v = (lane <= fp && i >= 0) ? (st & LB_VAL) : 0ull;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+                excl += v;
+                if (fp < 64) break;
+                top -= 64;
+            }
+            if (lane == 0) {
+                __hip_atomic_store(&b.lb[blockIdx.x], tag | LB_PFX | (excl + total), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                s_base = excl;
+            }
+        }
+        __syncthreads();
+        if (b.dbg) blk_w2 = (unsigned long long)wall_clock64();
+        const unsigned long long base = s_base;
+        // ---- final output: ids in position order, document offsets ----------------------------------
+        for (uint32_t k = tid; k < c_win; k += NT) {
+            const unsigned long long r = base + k;
+            if (r < b.ids_cap) b.ids_out[r] = s_ids[s_cpos[k]];
+        }
+        if (whi > wlo) {
+            unsigned long long running = base + c_win;
+            for (uint32_t wb = wlo; wb < whi; wb += NT) {
+                const uint32_t w = wb + tid;
+                uint32_t word = w < whi ? __hip_atomic_load(&b.tbits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                const uint32_t cnt = __popc(word);
+                uint32_t x = cnt;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t y = __shfl_up(x, d);
+                    if (lane >= d) x += y;
+                }
+                __syncthreads();
+                if (lane == 63) s_wsum[wv] = x;
+                __syncthreads();
+                unsigned long long r = running + (x - cnt);
+                uint32_t all = 0;
+                for (int k = 0; k < NT / 64; k++) { if (k < wv) r += s_wsum[k]; all += s_wsum[k]; }
+                if (word) b.tbits[w] = 0u;                  // clean after use: the bitmap is all-zero between calls
+                while (word) {
+                    const int bit = __ffs(word) - 1;
+                    word &= word - 1;
+                    if (r < b.ids_cap)
+                        b.ids_out[r] = __hip_atomic_load(&b.stage[w * 32 + bit], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    r++;
+                }
+                running += all;
+            }
+        }
+        {
+            const bool last_tile = blockIdx.x == gridDim.x - 1;
+            const uint64_t own_lo = (uint64_t)t0, own_hi = (uint64_t)(t0 + TB_);
+            for (uint32_t db = dw;; db += NT) {
+                const uint64_t d = (uint64_t)db + tid;
+                uint64_t p = ~0ull;
+                if (d <= b.n_docs) p = b.doc_off[d];         // entry n_docs is the end of the corpus
+                const bool in = d <= b.n_docs && (p < own_hi || last_tile);
+                if (in && p >= own_lo) {
+                    const uint32_t i = (uint32_t)(p - (uint64_t)w0);
+                    b.off_out[d] = base + s_wpre[i >> 5] + __popc(s_tbits[i >> 5] & ((1u << (i & 31)) - 1u))
+                                   + ((last_tile && p >= (uint64_t)B) ? c_ovf : 0u);
+                }
+                if (!__syncthreads_or(tid == NT - 1 && in)) break;
+            }
+        }
     }
     SPL_STAMP(8);
     if (b.dbg && tid == 0 && blockIdx.x == gridDim.x / 2) b.dbg[12] = (unsigned long long)wall_clock64();
     if (b.dbg && tid == 0 && blockIdx.x < SPL_DEBUG_BLOCKS) {
+        // wall-clock ticks: start, end of the merge phase, look-back done (single pass), end
         unsigned long long* r = b.dbg + 16 + 4 * blockIdx.x;
-        r[0] = (unsigned long long)wall_clock64() - blk_t0;
-        r[1] = (unsigned long long)(blk_c2 - blk_c1);
-        r[2] = s_nq[0] | (s_nq[1] << 16) | ((unsigned long long)blk_dc[1] << 32) | ((unsigned long long)blk_dc[2] << 40)
-               | ((unsigned long long)blk_dc[0] << 48 >> 0);
-        r[3] = (unsigned long long)(blk_c1 - blk_c0);
+        r[0] = blk_t0;
+        r[1] = blk_w1;
+        r[2] = blk_w2;
+        r[3] = (unsigned long long)wall_clock64();
     }
     if (b.dbg && tid == 0) atomicMax(&b.dbg[15], (unsigned long long)wall_clock64());
 #undef SPL_STAMP
-}
-
-// ------------------------------------------------------------------------------------------
-// Global-memory accessor: class records computed on the fly (slow path, rare).
-struct GlobalAcc {
-    const DeviceTables* T;
-    const Batch* b;
-    __device__ uint32_t txt(int64_t q) const { return q < (int64_t)b->n_bytes ? b->text[q] : 0u; }
-    __device__ uint32_t txt(int q) const { return txt((int64_t)(uint32_t)q); }
-    __device__ uint32_t load32(int p) const {
-        const int64_t q = (uint32_t)p;
-        return txt(q) | (txt(q + 1) << 8) | (txt(q + 2) << 16) | (txt(q + 3) << 24);
-    }
-    __device__ uint32_t rec(int qi) const {
-        const int64_t q = (uint32_t)qi;
-        const int64_t B = b->n_bytes;
-        if (q >= B) return C_EOT | CB_TSTART | CB_SYNC;
-        if (b->skip && ((b->skip[q >> 5] >> (q & 31)) & 1u)) return C_EOT | CB_TSTART;
-        const uint32_t c0 = b->text[q];
-        uint32_t r;
-        if (c0 < 0x80u) r = cp_class(*T, c0);
-        else if (c0 < 0xC0u) r = C_CONT;
-        else {
-            uint32_t want = utf8_len(c0), len = 1;
-            while (len < want && q + len < B && (b->text[q + len] & 0xC0u) == 0x80u) len++;
-            const uint32_t cls = (len == want) ? cp_class(*T, decode_at(*this, (int)q, c0)) : (uint32_t)C_P;
-            r = cls | ((len - 1) << CB_LEN_SHIFT);
-        }
-        if ((b->tstart[q >> 5] >> (q & 31)) & 1u) r |= CB_TSTART | CB_SYNC;
-        return r;
-    }
-};
-
-__device__ __forceinline__ void emit_token(const Batch& b, uint32_t pos, uint32_t id) {
-    b.stage[pos] = id;
-    atomicOr(&b.tbits[pos >> 5], 1u << (pos & 31));
-}
-
-// One lane per deferred segment: continue the chain from its start to the next sync point.
-__device__ void deferred_items(const DeviceTables& T, const Batch& b, uint32_t first, uint32_t stride) {
-    const uint32_t nq = min(b.qcount[3], b.qcapdefer);
-    GlobalAcc acc{&T, &b};
-    for (uint32_t it = first; it < nq; it += stride) {
-        uint32_t p = b.qdefer[it];
-        for (;;) {
-            if (p >= b.n_bytes) break;
-            const int e = match_end(acc, (int)p, (int)T.pattern);     // never defers: no window end
-            const uint32_t n = (uint32_t)e - p;
-            const uint32_t id = probe_chunk(T, acc, (int)p, (int)n);
-            if (id != SPL_NO_RANK) emit_token(b, p, id);
-            else if (n > 1) push_long(b, p, n);     // any length: k_bpe_long takes n >= 2
-            p = (uint32_t)e;
-            if (p >= b.n_bytes) break;
-            const uint32_t r = acc.rec((int)p);
-            if (r & (CB_SYNC | CB_TSTART)) break;
-            // sync test against the previous character's class
-            int64_t j = (int64_t)p - 1;
-            while (j > 0 && (b.text[j] & 0xC0u) == 0x80u && j > (int64_t)p - 4) j--;
-            const uint32_t prev = acc.rec((int)j) & CB_CLASS;
-            if (prev < C_EOT && is_sync((int)T.pattern, prev, r & CB_CLASS)) break;
-        }
-    }
-}
-__global__ void k_deferred(DeviceTables T, Batch b) {
-    deferred_items(T, b, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
-}
-
-// ------------------------------------------------------------------------------------------
-// byte_pair_encode, ONE LANE PER CHUNK (17..64 bytes), for large batches: node arrays interleaved
-// in LDS (node-major, lane-minor: conflict-free when lanes touch the same node index), merge loop
-// = bpe_serial (spl_lookup.h).  Slow per chunk, but every lane carries its own chain of dependent
-// pair-table probes, so a CU keeps hundreds of them in flight.
-template <int NMAX, int THREADS> struct LaneStore {
-    uint32_t* ids;
-    uint32_t* rks;
-    int lane;
-    __device__ __forceinline__ uint32_t& id(int i) { return ids[i * THREADS + lane]; }
-    __device__ __forceinline__ uint32_t& rk(int i) { return rks[i * THREADS + lane]; }
-};
-struct GlobalText {
-    const uint8_t* text;
-    __device__ __forceinline__ uint32_t txt(int q) const { return text[(uint32_t)q]; }
-};
-__global__ __launch_bounds__(64) void k_bpe_lanes64(DeviceTables T, Batch b) {
-    __shared__ uint32_t s_ids[64 * 64];
-    __shared__ uint32_t s_rks[64 * 64];
-    const uint32_t nq = min(b.qcount[0], b.qcap64);
-    LaneStore<64, 64> st{s_ids, s_rks, (int)threadIdx.x};
-    GlobalText tx{b.text};
-    for (uint32_t it = blockIdx.x * 64 + threadIdx.x; it < nq; it += gridDim.x * 64) {
-        const uint2 item = b.q64[it];
-        const int n = (int)item.y;
-        bpe_serial(T, st, tx, (int)item.x, n);
-        for (int i = 0; i < n; i++) {
-            const uint32_t id = st.id(i);
-            if (id != SPL_DEAD && id != SPL_NO_RANK) emit_token(b, item.x + i, id);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Long chunks (> 64 bytes; plus every miss of a deferred segment).
-//
-// bpe_wave: ONE WAVEFRONT per chunk of up to WAVE_NMAX bytes.  Nodes live in the wavefront's own
-// LDS slab as an index-linked list (id, rank of the pair with the next node, next, prev -- the
-// reference's Node, src/core/bpe.rs:43-54, minus start/len which are implied by the index); lane l
-// owns nodes l, l+64, ...  Per merge: each lane scans its <= 8 nodes, DPP min-reduction of
-// (rank << 9 | index) gives the leftmost minimum, lane 0 relinks, lanes 1 and 2 re-rank the two
-// affected pairs concurrently.  No workgroup barrier: the four wavefronts of a workgroup work
-// on four different chunks.
-// bpe_block_global: chunks beyond WAVE_NMAX (pathological single-class runs): one workgroup per
-// chunk, nodes in HBM scratch (ids in stage[], ranks in rank_scr[]), cached per-thread minima.
-constexpr int GROUP_NMAX = 128;       // 16 lanes x 8 register slots
-constexpr int WAVE_NMAX = 512;
-constexpr uint32_t NIL16 = 0xFFFFu;
-
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ void bpe_wave(const DeviceTables& T, const Batch& b, uint32_t pos, int n, uint32_t* s_id,
-                                         uint32_t* s_rk, uint16_t* s_nx, uint16_t* s_pv) {
-    const int lane = threadIdx.x & 63;
-    for (int i = lane; i < n; i += 64) {
-        s_id[i] = T.byte_id[b.text[pos + i]];
-        s_nx[i] = (uint16_t)(i + 1 < n ? i + 1 : (int)NIL16);
-        s_pv[i] = (uint16_t)(i > 0 ? i - 1 : (int)NIL16);
-    }
-    wave_lds_sync();
-    for (int i = lane; i < n; i += 64) s_rk[i] = (i + 1 < n) ? pair_rank(T, s_id[i], s_id[i + 1]) : SPL_NO_RANK;
-    wave_lds_sync();
-    for (;;) {
-        uint32_t key = 0xFFFFFFFFu;
-        for (int i = lane; i < n; i += 64) {
-            const uint32_t r = s_rk[i];
-            const uint32_t k = r == SPL_NO_RANK ? 0xFFFFFFFFu : ((r << 9) | (uint32_t)i);
-            key = k < key ? k : key;
-        }
-        uint32_t m = row16_min(key);
-        const uint32_t r0 = __builtin_amdgcn_readlane(m, 0), r1 = __builtin_amdgcn_readlane(m, 16);
-        const uint32_t r2 = __builtin_amdgcn_readlane(m, 32), r3 = __builtin_amdgcn_readlane(m, 48);
-        const uint32_t a = r0 < r1 ? r0 : r1, c = r2 < r3 ? r2 : r3;
-        m = a < c ? a : c;
-        if (m == 0xFFFFFFFFu) break;
-        const uint32_t mi = m & 511u, mn = m >> 9;
-        const uint32_t j = s_nx[mi];                       // uniform addresses: LDS broadcasts
-        const uint32_t j2 = s_nx[j];
-        const uint32_t h = s_pv[mi];
-        const uint32_t id_j2 = j2 != NIL16 ? s_id[j2] : 0u;
-        const uint32_t id_h = h != NIL16 ? s_id[h] : 0u;
-        wave_lds_sync();
-        if (lane == 0) {
-            s_id[mi] = mn;
-            s_id[j] = SPL_DEAD;
-            s_rk[j] = SPL_NO_RANK;
-            s_nx[mi] = (uint16_t)j2;
-            if (j2 != NIL16) s_pv[j2] = (uint16_t)mi;
-        } else if (lane == 1) {
-            s_rk[mi] = j2 != NIL16 ? pair_rank(T, mn, id_j2) : SPL_NO_RANK;
-        } else if (lane == 2) {
-            if (h != NIL16) s_rk[h] = pair_rank(T, id_h, mn);
-        }
-        wave_lds_sync();
-    }
-    for (int i = lane; i < n; i += 64) {
-        const uint32_t id = s_id[i];
-        if (id != SPL_DEAD && id != SPL_NO_RANK) emit_token(b, pos + (uint32_t)i, id);
-    }
-    wave_lds_sync();
-}
-
-__device__ void bpe_block_global(const DeviceTables& T, const Batch& b, uint32_t pos, int n, unsigned long long* s_red,
-                                 unsigned long long* s_best, int* s_touch) {
-    const int tid = threadIdx.x;
-    uint32_t* ids = b.stage + pos;
-    uint32_t* rks = b.rank_scr + pos;
-    for (int i = tid; i < n; i += NT) ids[i] = T.byte_id[b.text[pos + i]];
-    __syncthreads();
-    for (int i = tid; i < n; i += NT) rks[i] = (i + 1 < n) ? pair_rank(T, ids[i], ids[i + 1]) : SPL_NO_RANK;
-    __syncthreads();
-    bool dirty = true;
-    unsigned long long mine = ~0ull;          // (rank << 32 | index): min == leftmost minimum
-    for (;;) {
-        if (dirty) {
-            mine = ~0ull;
-            for (int i = tid; i < n; i += NT) {
-                const unsigned long long c = ((unsigned long long)rks[i] << 32) | (uint32_t)i;
-                mine = c < mine ? c : mine;
-            }
-            dirty = false;
-        }
-        unsigned long long x = mine;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const unsigned long long y = __shfl_xor(x, d);
-            x = y < x ? y : x;
-        }
-        if ((tid & 63) == 0) s_red[tid >> 6] = x;
-        __syncthreads();
-        if (tid == 0) {
-            unsigned long long m = s_red[0];
-            for (int wv = 1; wv < NT / 64; wv++) m = s_red[wv] < m ? s_red[wv] : m;
-            *s_best = m;
-        }
-        __syncthreads();
-        const unsigned long long best = *s_best;
-        const uint32_t mn = (uint32_t)(best >> 32);
-        if (mn == SPL_NO_RANK) break;
-        const int mi = (int)(uint32_t)best;
-        if (tid == 0) {     // the neighbour searches walk tomb-stones; at most a token's length of them
-            int j = mi + 1;
-            while (ids[j] == SPL_DEAD) j++;
-            ids[mi] = mn;
-            ids[j] = SPL_DEAD;
-            rks[j] = SPL_NO_RANK;
-            int j2 = j + 1;
-            while (j2 < n && ids[j2] == SPL_DEAD) j2++;
-            rks[mi] = j2 < n ? pair_rank(T, mn, ids[j2]) : SPL_NO_RANK;
-            int h = mi - 1;
-            while (h >= 0 && ids[h] == SPL_DEAD) h--;
-            if (h >= 0) rks[h] = pair_rank(T, ids[h], mn);
-            s_touch[0] = mi; s_touch[1] = j; s_touch[2] = h;
-            __threadfence_block();
-        }
-        __syncthreads();
-        const int a0 = s_touch[0] % NT, a1 = s_touch[1] % NT, a2 = s_touch[2] < 0 ? -1 : s_touch[2] % NT;
-        if (tid == a0 || tid == a1 || tid == a2) dirty = true;
-        __syncthreads();
-    }
-    // survivors become tokens (ids already sit in stage[]); only the bitmap is left to set
-    for (int i = tid; i < n; i += NT) {
-        const uint32_t id = ids[i];
-        if (id != SPL_DEAD && id != SPL_NO_RANK) atomicOr(&b.tbits[(pos + i) >> 5], 1u << ((pos + i) & 31));
-    }
-    __syncthreads();
 }
 
 __global__ __launch_bounds__(NT) void k_bpe_long(DeviceTables T, Batch b) {
@@ -1133,7 +1472,8 @@ __global__ __launch_bounds__(NT) void k_bpe_long(DeviceTables T, Batch b) {
         for (uint32_t it = wgid; it < nq;) {
             const uint2 item = b.qlong[it];
             if ((int)item.y > GROUP_NMAX && (int)item.y <= WAVE_NMAX)
-                bpe_wave(T, b, item.x, (int)item.y, s_id[wv], s_rk[wv], s_nx[wv], s_pv[wv]);
+                bpe_wave(T, b, item.x, (int)item.y, s_id[wv], s_rk[wv], s_nx[wv], s_pv[wv],
+                         [&](uint32_t q, uint32_t id) { emit_token(b, q, id); });
             uint32_t nxt = 0;
             if (lane == 0) nxt = atomicAdd(&b.qcount[6], 1u);
             it = nwaves + __builtin_amdgcn_readfirstlane(nxt);
@@ -1159,7 +1499,9 @@ __global__ __launch_bounds__(NT) void k_bpe_long(DeviceTables T, Batch b) {
     for (int w = 0; w < NT / 64; w++)
         for (uint32_t it = blockIdx.x * (NT / 64) + w; it < nq; it += nwaves) {
             const uint2 item = b.qlong[it];
-            if ((int)item.y > WAVE_NMAX) bpe_block_global(T, b, item.x, (int)item.y, s_red, &s_best, s_touch);
+            if ((int)item.y > WAVE_NMAX)
+                bpe_block_global(T, b, item.x, (int)item.y, s_red, &s_best, s_touch,
+                                 [&](uint32_t q, uint32_t id) { emit_token(b, q, id); });
         }
 }
 

@@ -35,13 +35,17 @@ L.spl_debug_blocks(tok.handle, rec, nb_)
 R = np.ctypeslib.as_array(rec).reshape(nb_, 4).astype(np.int64)
 nblk = (batch.n_bytes + 767) // 768 if (force == 1 or (force == 0 and batch.n_bytes <= 8 << 20)) else (batch.n_bytes + 4095) // 4096
 R = R[:min(nblk, nb_)]
-print("  per-workgroup residency (10 ns ticks): p50 %d p90 %d p99 %d max %d" % tuple(np.percentile(R[:, 0], [50, 90, 99, 100])))
-print("  merge phase cycles: p50 %d p90 %d p99 %d max %d ; scanner part: p50 %d p99 %d max %d" % (tuple(np.percentile(R[:, 1], [50, 90, 99, 100])) + tuple(np.percentile(R[:, 3], [50, 99, 100]))))
-for i in np.argsort(-R[:, 0])[:12]:
-    print("    wg %5d ticks %5d merge %6d scan %6d short %3d medium %3d ; wave0 rounds %d iterations %d tab cycles %d" % (i, R[i, 0], R[i, 1], R[i, 3], R[i, 2] & 0xFFFF, (R[i, 2] >> 16) & 0xFFFF, (R[i, 2] >> 32) & 0xFF, (R[i, 2] >> 40) & 0xFF, (R[i, 2] >> 48) & 0xFFFF))
-print("  mean short %.1f medium %.2f ; wave 0: rounds %.2f iterations %.1f tab cycles %.0f" % ((R[:, 2] & 0xFFFF).mean(), ((R[:, 2] >> 16) & 0xFFFF).mean(), ((R[:, 2] >> 32) & 0xFF).mean(), ((R[:, 2] >> 40) & 0xFF).mean(), ((R[:, 2] >> 48) & 0xFFFF).mean()))
-mid = nblk // 2
-print("  middle wg: short %d medium %d wave0 rounds %d iterations %d tab cycles %d" % (R[mid, 2] & 0xFFFF, (R[mid, 2] >> 16) & 0xFFFF, (R[mid, 2] >> 32) & 0xFF, (R[mid, 2] >> 40) & 0xFF, (R[mid, 2] >> 48) & 0xFFFF))
+k0 = int(st[14])
+rel = R - k0
+pc = lambda col: tuple(np.percentile(rel[:, col], [50, 90, 99, 100]))
+print("  per-workgroup wall clock, 10 ns ticks since the kernel's first workgroup started (p50 p90 p99 max):")
+print("    start          %6d %6d %6d %6d" % pc(0))
+print("    merge done     %6d %6d %6d %6d" % pc(1))
+print("    look-back done %6d %6d %6d %6d" % pc(2))
+print("    end            %6d %6d %6d %6d" % pc(3))
+slow = int(np.argmax(rel[:, 1]))
+print("    slowest merge: wg %d at %d; its look-back done %d, end %d" % (slow, rel[slow, 1], rel[slow, 2], rel[slow, 3]))
+print("    tail after look-back (end - look-back done): p50 %d max %d" % tuple(np.percentile(rel[:, 3] - rel[:, 2], [50, 100])))
 qc = (ctypes.c_uint32 * 4)()
 L.spl_last_queue_counts(tok.handle, qc)
 print("queues: q64", qc[0], "long", qc[2], "deferred", qc[3], "bytes", batch.n_bytes)

@@ -103,14 +103,15 @@ def test_corpus_fixtures_sha256():
 
 
 def _force_tiles(name, mode):
-    """Development hook of the C ABI: 0 auto, 1 small tiles (768+224), 2 large tiles (4096+480)."""
+    """Development hook of the C ABI: 0 auto, 1 small tiles (768+224; single pass when the batch
+    qualifies), 2 large tiles (4096+480), 3 small tiles with the multi-pass pipeline."""
     import ctypes
     from splintr_amd import _ffi
     st = (ctypes.c_uint64 * 16)()
     assert _ffi.lib().spl_debug_phases(tok(name).handle, mode << 1, st) == 0
 
 
-@pytest.mark.parametrize("geom", [1, 2])
+@pytest.mark.parametrize("geom", [1, 2, 3])
 @pytest.mark.parametrize("name", ["cl100k_base", "o200k_base"])
 def test_tile_and_window_edges(coracle, name, geom):
     """Documents and runs placed around the tile edge and the right halo of BOTH tile geometries."""
