@@ -809,10 +809,16 @@ template <int TB_, int RH_> struct TileGeom {
 // off_out[].  One launch instead of seven; stage[] / tbits[] in HBM are touched only by tokens
 // that start beyond the window (and cleaned up by the workgroup that set them).
 #ifndef SPL_LB_SLEEP
-#define SPL_LB_SLEEP 16
+#define SPL_LB_SLEEP 4
 #endif
 #ifndef SPL_WORK_PRIO
-#define SPL_WORK_PRIO 2
+#define SPL_WORK_PRIO 3
+#endif
+#ifndef SPL_MERGE_PRIO
+#define SPL_MERGE_PRIO 1
+#endif
+#ifndef SPL_MEDIUM_PRIO
+#define SPL_MEDIUM_PRIO 2
 #endif
 #ifndef SPL_PRETOK_WAVES
 #define SPL_PRETOK_WAVES 6
@@ -1154,6 +1160,9 @@ void k_pretok(DeviceTables T, Batch b) {
     SPL_STAMP(6);
 
     // ---- merge loop for this tile's misses: wavefronts pull work until both lists are empty ------
+    // (scanner phases run at high priority, the merge loops below them: a workgroup that is still
+    // scanning is never starved by older workgroups that already merge; +3 % on the bench batch)
+    if (DIRECT) __builtin_amdgcn_s_setprio(SPL_MERGE_PRIO);
     {
         const uint32_t m16 = s_nq[0], m64 = s_nq[1];
         uint32_t* const stage_w0 = b.stage + w0;          // window index -> global position
@@ -1181,6 +1190,7 @@ void k_pretok(DeviceTables T, Batch b) {
             if (lane == 0) it = atomicAdd(&s_nq[3], 1u);
             it = __builtin_amdgcn_readfirstlane(it);
             if (it >= m64) break;
+            if (DIRECT && SPL_MEDIUM_PRIO != SPL_MERGE_PRIO) __builtin_amdgcn_s_setprio(SPL_MEDIUM_PRIO);
             const uint32_t item = s_miss[G::C16 + it];
             const int p = (int)(item & 0xFFFFu);
             bpe_wave64_tab(T, LdsAcc{s_rec, s_txt}, p, (int)(item >> 16), s_sub[(tid >> 6) * 4],
@@ -1188,6 +1198,7 @@ void k_pretok(DeviceTables T, Batch b) {
                                put(p + i, id);
                            });
         }
+        if (DIRECT && SPL_MEDIUM_PRIO != SPL_MERGE_PRIO) __builtin_amdgcn_s_setprio(SPL_MERGE_PRIO);
         SPL_STAMP(9);
         // every 16-lane group pulls its own work: first the 17..64-byte chunks (four nodes per
         // lane), then the short ones (one node per lane)
@@ -1304,6 +1315,13 @@ void k_pretok(DeviceTables T, Batch b) {
                 if (s_dq[0] == 0 && s_dq[6] >= nd) break;
             }
         }
+        // the first NT documents of the window are fetched now, so that after the look-back only
+        // stores are left on the critical path of the last tiles
+        const bool last_tile = blockIdx.x == gridDim.x - 1;
+        const uint64_t own_lo = (uint64_t)t0, own_hi = (uint64_t)(t0 + TB_);
+        const uint64_t d_first = (uint64_t)dw + tid;
+        uint64_t p_first = ~0ull;
+        if (d_first <= b.n_docs) p_first = b.doc_off[d_first];      // entry n_docs is the end of the corpus
         // ---- token count of the tile: window bitmap + overflow range --------------------------------
         uint32_t c_win;
         {
@@ -1420,12 +1438,10 @@ void k_pretok(DeviceTables T, Batch b) {
             }
         }
         {
-            const bool last_tile = blockIdx.x == gridDim.x - 1;
-            const uint64_t own_lo = (uint64_t)t0, own_hi = (uint64_t)(t0 + TB_);
             for (uint32_t db = dw;; db += NT) {
                 const uint64_t d = (uint64_t)db + tid;
-                uint64_t p = ~0ull;
-                if (d <= b.n_docs) p = b.doc_off[d];         // entry n_docs is the end of the corpus
+                uint64_t p = p_first;
+                if (db != dw) { p = ~0ull; if (d <= b.n_docs) p = b.doc_off[d]; }
                 const bool in = d <= b.n_docs && (p < own_hi || last_tile);
                 if (in && p >= own_lo) {
                     const uint32_t i = (uint32_t)(p - (uint64_t)w0);
