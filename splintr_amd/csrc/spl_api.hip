@@ -67,9 +67,10 @@ struct spl_tokenizer {
     uint32_t* d_blk = nullptr;
     // single-pass path: look-back status words (epoch-tagged), and whether the token bitmap may hold
     // stale bits (after hipMalloc or a multi-pass call) -- the single-pass kernel needs it all-zero
-    unsigned long long* d_lb = nullptr;
-    size_t lb_words = 0;
-    uint32_t epoch = 0;
+    TileDesc* d_tdesc = nullptr;
+    uint32_t* d_tile_ids = nullptr;
+    uint32_t* d_tctl = nullptr;
+    uint32_t tgroups = 0, tpar = 0;
     bool bitmap_dirty = true;
     // host-path staging
     uint8_t* d_in_text = nullptr; uint64_t* d_in_off = nullptr; uint32_t* d_out_ids = nullptr; uint64_t* d_out_off = nullptr;
@@ -96,7 +97,8 @@ namespace {
 void free_workspace(spl_tokenizer* t) {
     hipFree(t->d_zero); hipFree(t->d_stage); hipFree(t->d_rank);
     hipFree(t->d_q64); hipFree(t->d_qlong); hipFree(t->d_qdefer); hipFree(t->d_blk); hipFree(t->d_dbg);
-    hipFree(t->d_lb); t->d_lb = nullptr;
+    hipFree(t->d_tdesc); hipFree(t->d_tile_ids); hipFree(t->d_tctl);
+    t->d_tdesc = nullptr; t->d_tile_ids = nullptr; t->d_tctl = nullptr;
     t->d_zero = nullptr; t->d_stage = nullptr; t->d_rank = nullptr;
     t->d_q64 = nullptr; t->d_qlong = nullptr; t->d_qdefer = nullptr; t->d_blk = nullptr; t->d_dbg = nullptr;
     t->cap_bytes = t->cap_docs = 0;
@@ -123,10 +125,16 @@ int reserve(spl_tokenizer* t, uint64_t max_bytes, uint64_t max_docs) {
     HIP_TRY(hipMalloc((void**)&t->d_qlong, (size_t)t->qcaplong * 8));
     HIP_TRY(hipMalloc((void**)&t->d_qdefer, (size_t)t->qcapdefer * 4));
     HIP_TRY(hipMalloc((void**)&t->d_blk, (nblk + 2) * 4));
-    t->lb_words = (size_t)(std::min<uint64_t>(nb, SPL_DIRECT_MAX_BYTES) / TileGeom<SPL_TILE_SMALL>::TBv) + 2;
-    HIP_TRY(hipMalloc((void**)&t->d_lb, t->lb_words * 8));
-    HIP_TRY(hipMemset(t->d_lb, 0, t->lb_words * 8));
-    t->epoch = 0;
+    {
+        const size_t dbytes = (size_t)std::min<uint64_t>(nb, SPL_DIRECT_MAX_BYTES);
+        const size_t tiles = dbytes / TileGeom<SPL_TILE_SMALL>::TBv + 2;
+        t->tgroups = (uint32_t)(tiles / 64 + 2);
+        HIP_TRY(hipMalloc((void**)&t->d_tdesc, tiles * sizeof(TileDesc)));
+        HIP_TRY(hipMalloc((void**)&t->d_tile_ids, (dbytes + 8192) * 4));
+        HIP_TRY(hipMalloc((void**)&t->d_tctl, (16 + 2 * (size_t)t->tgroups) * 4));
+        HIP_TRY(hipMemset(t->d_tctl, 0, (16 + 2 * (size_t)t->tgroups) * 4));
+        t->tpar = 0;
+    }
     t->bitmap_dirty = true;
     t->cap_bytes = nb;
     t->cap_docs = nd;
@@ -203,17 +211,17 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
             HIP_TRY(hipMemsetAsync(t->d_zero, 0, t->zero_words * 4, s));
             t->bitmap_dirty = false;
         }
-        if (++t->epoch >= 0xFFFFFFu) {          // tag wrap: forget every old status word
-            HIP_TRY(hipMemsetAsync(t->d_lb, 0, t->lb_words * 8, s));
-            t->epoch = 1;
-        }
-        b.lb = t->d_lb; b.epoch = t->epoch;
+        b.tdesc = t->d_tdesc; b.tile_ids = t->d_tile_ids; b.tctl = t->d_tctl;
+        b.tgroups = t->tgroups; b.tpar = t->tpar;
+        if (ntiles) t->tpar ^= 1u;              // k_tile_out zeroes the other parity's sums for the next call
         b.tstart = nullptr; b.qcount = nullptr;
         t->last_qcount = nullptr;
         MARK(KI_MARK); MARK(KI_SPECIAL); MARK(KI_PRETOK);
         if (ntiles) hipLaunchKernelGGL((k_pretok<SPL_TILE_SMALL, false, true>), dim3(ntiles), dim3(NT), 0, s, t->dt, b);
         else HIP_TRY(hipMemsetAsync(d_out_off, 0, (n_docs + 1) * 8, s));
-        MARK(KI_DEFER); MARK(KI_BPELANES); MARK(KI_BPELONG); MARK(KI_COUNT); MARK(KI_SCAN); MARK(KI_COMPACT); MARK(KI_N);
+        MARK(KI_DEFER); MARK(KI_BPELANES); MARK(KI_BPELONG); MARK(KI_COUNT); MARK(KI_SCAN); MARK(KI_COMPACT);
+        if (ntiles) hipLaunchKernelGGL(k_tile_out, dim3(ntiles), dim3(NT), 0, s, b);
+        MARK(KI_N);
     } else {
     t->bitmap_dirty = true;
     MARK(KI_MARK);

@@ -37,6 +37,17 @@ constexpr int RANK_BLK = 1024;           // positions per rank block (32 bitmap 
 #define SPL_TILE_LARGE 4096, 480         /* window 4608 B */
 constexpr uint64_t SPL_DIRECT_MAX_BYTES = 8ull << 20;   // batches up to this size: small tiles, single pass
 
+// What a tile of the tile-owned mode leaves behind for k_tile_out.
+struct TileDesc {
+    uint32_t slot;             // first entry of the tile's window tokens in tile_ids[]
+    uint32_t c_win;            // tokens that start inside the window (ids in tile_ids[])
+    uint32_t c_ovf;            // tokens that start beyond it (ids in stage[], bits in tbits[])
+    uint32_t ovf_hi;           // end (exclusive) of the byte range those occupy; 0 if none
+    uint32_t d_first, d_cnt;   // documents that start in the tile: off_out[d] holds the LOCAL rank
+    uint32_t ovf_lo;           // first byte beyond the window
+    uint32_t pad;
+};
+
 struct Batch {
     const uint8_t* text;
     uint32_t n_bytes;
@@ -58,8 +69,12 @@ struct Batch {
     uint32_t* blk_base;    // exclusive token count per RANK_BLK block (+1 entry: total)
     uint32_t n_blk;
     uint32_t* ids_out; uint64_t ids_cap; uint64_t* off_out;
-    unsigned long long* lb;    // single-pass mode: per-tile look-back status words
-    uint32_t epoch;            // single-pass mode: tag of this call inside the status words (never 0)
+    // tile-owned mode (k_pretok<.., DIRECT> + k_tile_out)
+    TileDesc* tdesc;           // one record per tile
+    uint32_t* tile_ids;        // the tiles' window tokens, packed in order of completion (cursor = tctl[0])
+    uint32_t* tctl;            // [0] packing cursor; [16 + par * tgroups ...] token sums per 64 tiles, two parities
+    uint32_t tgroups;          // capacity of one parity's group-sum array
+    uint32_t tpar;             // parity of this call
 };
 
 // ------------------------------------------------------------------------------------------
@@ -800,17 +815,18 @@ template <int TB_, int RH_> struct TileGeom {
 // with hundreds of thousands of such chunks in flight (CJK text) that is the throughput-optimal
 // shape; for small batches the latency-optimal in-kernel groups are used instead.
 //
-// DIRECT (single pass, small batches without special tokens): the workgroup also produces the
-// FINAL output of its tile.  Text-start bits come from a search of doc_off (no k_mark_docs),
-// token ids are kept in LDS, chunks longer than 64 bytes and the (at most one) chain that
-// outgrows the window are finished right here, the tile's token count is published in a
-// look-back status word (epoch-tagged: nothing to clear between calls), and once the counts of
-// all earlier tiles are known the ids go straight to ids_out[] and the document offsets to
-// off_out[].  One launch instead of seven; stage[] / tbits[] in HBM are touched only by tokens
-// that start beyond the window (and cleaned up by the workgroup that set them).
-#ifndef SPL_LB_SLEEP
-#define SPL_LB_SLEEP 4
-#endif
+// DIRECT (tile-owned mode, batches without special tokens): the workgroup finishes EVERYTHING that
+// starts in its tile and leaves a self-contained record.  Text-start bits come from a search of
+// doc_off (no k_mark_docs, no bitmap to clear), token ids are kept in LDS, chunks longer than 64
+// bytes and the (at most one) chain that outgrows the window are finished right here; the tile's
+// window tokens are packed into tile_ids[] at a slot taken from one atomic cursor, its token
+// count is added to the sum of its 64-tile group, and the documents that start in the tile get
+// their LOCAL rank.  k_tile_out then only has to add each tile's base.  Two launches instead of
+// seven, no workgroup ever waits for another one, and stage[] / tbits[] in HBM are touched only
+// by tokens that start beyond the window (k_tile_out cleans those bits up again).
+// (A decoupled look-back inside this kernel -- ONE launch -- measured 1.4 us faster on the 1 MB
+//  bench batch but collapses when tile times vary: tiles wait, resident, for the slowest
+//  predecessor.  8 MB of CJK-heavy text took 4.4 ms that way and 1.3 ms this way.)
 #ifndef SPL_WORK_PRIO
 #define SPL_WORK_PRIO 3
 #endif
@@ -825,7 +841,6 @@ template <int TB_, int RH_> struct TileGeom {
 #endif
 constexpr int DIRECT_LQCAP = 32;          // long-chunk list of one workgroup (refilled while a chain is continued)
 constexpr int DIRECT_WAVE_NMAX = 256;     // nodes of one wavefront's LDS slab in the single-pass tail
-constexpr unsigned long long LB_AGG = 1ull << 38, LB_PFX = 2ull << 38, LB_VAL = (1ull << 38) - 1ull;
 
 template <int TB_, int RH_> struct PretokScanLds {           // dead once the merge loop is done
     using G = TileGeom<TB_, RH_>;
@@ -1361,95 +1376,48 @@ void k_pretok(DeviceTables T, Batch b) {
             c_ovf = s_dq[9];
         }
         const unsigned long long total = (unsigned long long)c_win + c_ovf;
-        // ---- publish the count, look back over the earlier tiles ------------------------------------
-        const unsigned long long tag = (unsigned long long)b.epoch << 40;
+        // ---- the tile's record: packed window tokens, local document ranks, counts ------------------
+        // (k_tile_out turns these into the final CSR once every tile's count is known; nothing here
+        //  waits for another workgroup, so a tile that is slow -- long chunks, a chain that runs far
+        //  beyond the window -- only delays itself)
         if (tid == 0) {
-            __hip_atomic_store(&b.lb[blockIdx.x], tag | (blockIdx.x == 0 ? LB_PFX : LB_AGG) | total, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            if (blockIdx.x == 0) s_base = 0;
-        }
-        // waiting wavefronts must not compete with the ones still merging (issue arbitration favours
-        // the OLDEST wavefront, and the waiting ones are the old ones): lowest priority, long naps
-        __builtin_amdgcn_s_setprio(0);
-        if (wv == 0 && blockIdx.x > 0) {
-            unsigned long long excl = 0;
-            int64_t top = (int64_t)blockIdx.x - 1;
-            for (;;) {
-                const int64_t i = top - lane;
-                unsigned long long st = 0;
-                bool ready = true;
-                if (i >= 0) {
-                    st = __hip_atomic_load(&b.lb[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ready = (st >> 40) == (unsigned long long)b.epoch;
-                }
-                const bool is_pfx = i < 0 || (ready && (st & LB_PFX) != 0);
-                const unsigned long long m_pfx = __ballot(is_pfx), m_nr = __ballot(!ready);
-                const int fp = m_pfx ? __ffsll((long long)m_pfx) - 1 : 64;     // first lane holding a prefix
-                const unsigned long long need = fp >= 63 ? ~0ull : ((2ull << fp) - 1ull);
-                if (m_nr & need) { __builtin_amdgcn_s_sleep(SPL_LB_SLEEP); continue; }
-                unsigned long long v = (lane <= fp && i >= 0) ? (st & LB_VAL) : 0ull;
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-                excl += v;
-                if (fp < 64) break;
-                top -= 64;
-            }
-            if (lane == 0) {
-                __hip_atomic_store(&b.lb[blockIdx.x], tag | LB_PFX | (excl + total), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-                s_base = excl;
-            }
+            s_base = atomicAdd(&b.tctl[0], c_win);
+            atomicAdd(&b.tctl[16 + b.tpar * b.tgroups + (blockIdx.x >> 6)], (uint32_t)total);
         }
         __syncthreads();
         if (b.dbg) blk_w2 = (unsigned long long)wall_clock64();
-        const unsigned long long base = s_base;
-        // ---- final output: ids in position order, document offsets ----------------------------------
-        for (uint32_t k = tid; k < c_win; k += NT) {
-            const unsigned long long r = base + k;
-            if (r < b.ids_cap) b.ids_out[r] = s_ids[s_cpos[k]];
-        }
-        if (whi > wlo) {
-            unsigned long long running = base + c_win;
-            for (uint32_t wb = wlo; wb < whi; wb += NT) {
-                const uint32_t w = wb + tid;
-                uint32_t word = w < whi ? __hip_atomic_load(&b.tbits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                const uint32_t cnt = __popc(word);
-                uint32_t x = cnt;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t y = __shfl_up(x, d);
-                    if (lane >= d) x += y;
-                }
-                __syncthreads();
-                if (lane == 63) s_wsum[wv] = x;
-                __syncthreads();
-                unsigned long long r = running + (x - cnt);
-                uint32_t all = 0;
-                for (int k = 0; k < NT / 64; k++) { if (k < wv) r += s_wsum[k]; all += s_wsum[k]; }
-                if (word) b.tbits[w] = 0u;                  // clean after use: the bitmap is all-zero between calls
-                while (word) {
-                    const int bit = __ffs(word) - 1;
-                    word &= word - 1;
-                    if (r < b.ids_cap)
-                        b.ids_out[r] = __hip_atomic_load(&b.stage[w * 32 + bit], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    r++;
-                }
-                running += all;
+        const uint32_t slot = (uint32_t)s_base;
+        for (uint32_t k = tid; k < c_win; k += NT) b.tile_ids[slot + k] = s_ids[s_cpos[k]];
+        uint32_t d_lo = 0xFFFFFFFFu, d_n = 0;
+        for (uint32_t db = dw;; db += NT) {
+            const uint64_t d = (uint64_t)db + tid;
+            uint64_t p = p_first;
+            if (db != dw) { p = ~0ull; if (d <= b.n_docs) p = b.doc_off[d]; }
+            const bool in = d <= b.n_docs && (p < own_hi || last_tile);
+            const bool own = in && p >= own_lo;
+            if (own) {
+                const uint32_t i = (uint32_t)(p - (uint64_t)w0);
+                b.off_out[d] = (uint64_t)(s_wpre[i >> 5] + __popc(s_tbits[i >> 5] & ((1u << (i & 31)) - 1u)))
+                               + ((last_tile && p >= (uint64_t)B) ? c_ovf : 0u);
             }
-        }
-        {
-            for (uint32_t db = dw;; db += NT) {
-                const uint64_t d = (uint64_t)db + tid;
-                uint64_t p = p_first;
-                if (db != dw) { p = ~0ull; if (d <= b.n_docs) p = b.doc_off[d]; }
-                const bool in = d <= b.n_docs && (p < own_hi || last_tile);
-                if (in && p >= own_lo) {
-                    const uint32_t i = (uint32_t)(p - (uint64_t)w0);
-                    b.off_out[d] = base + s_wpre[i >> 5] + __popc(s_tbits[i >> 5] & ((1u << (i & 31)) - 1u))
-                                   + ((last_tile && p >= (uint64_t)B) ? c_ovf : 0u);
+            // owned documents are consecutive: first index and count by ballots (s_wsum as mailboxes)
+            const unsigned long long mo = __ballot(own);
+            if (lane == 0) { s_red[wv] = mo; }
+            __syncthreads();
+            for (int k = 0; k < NT / 64; k++) {
+                const unsigned long long mk = s_red[k];
+                if (mk) {
+                    if (d_lo == 0xFFFFFFFFu) d_lo = db + 64u * k + (uint32_t)(__ffsll((long long)mk) - 1);
+                    d_n += (uint32_t)__popcll(mk);
                 }
-                if (!__syncthreads_or(tid == NT - 1 && in)) break;
             }
+            if (!__syncthreads_or(tid == NT - 1 && in)) break;
+        }
+        if (tid == 0) {
+            TileDesc td;
+            td.slot = slot; td.c_win = c_win; td.c_ovf = c_ovf; td.ovf_hi = whi > wlo ? ovf_hi : 0u;
+            td.d_first = d_lo == 0xFFFFFFFFu ? 0u : d_lo; td.d_cnt = d_n; td.ovf_lo = ovf_lo; td.pad = 0;
+            b.tdesc[blockIdx.x] = td;
         }
     }
     SPL_STAMP(8);
@@ -1464,6 +1432,73 @@ void k_pretok(DeviceTables T, Batch b) {
     }
     if (b.dbg && tid == 0) atomicMax(&b.dbg[15], (unsigned long long)wall_clock64());
 #undef SPL_STAMP
+}
+
+// ------------------------------------------------------------------------------------------
+// Tile-owned mode, second and last kernel: one workgroup per tile turns the tile records into the
+// final CSR.  The number of tokens before a tile is the sum of the 64-tile group sums before its
+// group (accumulated by k_pretok with one atomic per tile) plus the counts of the earlier tiles of
+// its own group -- every workgroup computes its own base, there is no scan pass and nothing waits.
+// Workgroup 0 also re-arms the next call: packing cursor and the OTHER parity's group sums to zero.
+__global__ __launch_bounds__(NT) void k_tile_out(Batch b) {
+    __shared__ unsigned long long s_part[NT / 64];
+    __shared__ uint32_t s_wsum[NT / 64];
+    const uint32_t t = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t* gs = b.tctl + 16 + b.tpar * b.tgroups;
+    const uint32_t g = t >> 6;
+    unsigned long long mine = 0;
+    for (uint32_t k = tid; k < g; k += NT) mine += gs[k];
+    {
+        const uint32_t u = (g << 6) + (uint32_t)tid;
+        if (tid < 64 && u < t) { const TileDesc q = b.tdesc[u]; mine += (unsigned long long)q.c_win + q.c_ovf; }
+    }
+    const TileDesc td = b.tdesc[t];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+    if (lane == 0) s_part[wv] = mine;
+    __syncthreads();
+    unsigned long long base = 0;
+    for (int k = 0; k < NT / 64; k++) base += s_part[k];
+    for (uint32_t k = tid; k < td.c_win; k += NT) {
+        const unsigned long long r = base + k;
+        if (r < b.ids_cap) b.ids_out[r] = b.tile_ids[td.slot + k];
+    }
+    for (uint32_t k = tid; k < td.d_cnt; k += NT) b.off_out[td.d_first + k] += base;
+    if (td.ovf_hi > td.ovf_lo) {                             // rare: tokens that start beyond the window
+        const uint32_t wlo = td.ovf_lo >> 5, whi = (td.ovf_hi + 31) >> 5;
+        unsigned long long running = base + td.c_win;
+        for (uint32_t wb = wlo; wb < whi; wb += NT) {
+            const uint32_t w = wb + tid;
+            uint32_t word = w < whi ? b.tbits[w] : 0u;
+            const uint32_t cnt = __popc(word);
+            uint32_t x = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(x, d);
+                if (lane >= d) x += y;
+            }
+            __syncthreads();
+            if (lane == 63) s_wsum[wv] = x;
+            __syncthreads();
+            unsigned long long r = running + (x - cnt);
+            uint32_t all = 0;
+            for (int k = 0; k < NT / 64; k++) { if (k < wv) r += s_wsum[k]; all += s_wsum[k]; }
+            if (word) b.tbits[w] = 0u;                      // clean after use: the bitmap is all-zero between calls
+            while (word) {
+                const int bit = __ffs(word) - 1;
+                word &= word - 1;
+                if (r < b.ids_cap) b.ids_out[r] = b.stage[w * 32 + bit];
+                r++;
+            }
+            running += all;
+        }
+    }
+    if (t == 0) {
+        uint32_t* other = b.tctl + 16 + (b.tpar ^ 1u) * b.tgroups;
+        for (uint32_t k = tid; k < b.tgroups; k += NT) other[k] = 0u;
+        if (tid == 0) b.tctl[0] = 0u;
+    }
 }
 
 __global__ __launch_bounds__(NT) void k_bpe_long(DeviceTables T, Batch b) {

@@ -11,8 +11,11 @@ name = sys.argv[1] if len(sys.argv) > 1 else "cl100k_base"
 gen = sys.argv[2] if len(sys.argv) > 2 else "c2"
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
 tok = Tokenizer.from_pretrained(name)
+force = int(sys.argv[4]) if len(sys.argv) > 4 else 0   # 0 auto, 1 small tiles, 2 large tiles, 3 small tiles + multi-pass
 batch = DeviceBatch(getattr(corpus, gen)(n), torch.device("cuda", 0))
 reserve(tok, batch.n_bytes, batch.n_docs)
+if force:
+    L.spl_debug_phases(tok.handle, force << 1, (ctypes.c_uint64 * 16)())
 for _ in range(20):
     encode_device(tok, batch)
 torch.cuda.synchronize()
