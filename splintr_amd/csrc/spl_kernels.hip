@@ -357,23 +357,30 @@ __device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const Lds
         Quad qa[4], qb[4], qc[4];
         uint32_t ba = 0, bb = 0, bc = 0;
         const uint32_t ka = w0 & 0xFFFFu, kb = w0 & 0xFFFFFFu;
-        if (maxlen >= 2) probe_issue(T, ka, 0u, 2u, qa, ba);
-        if (maxlen >= 3) probe_issue(T, kb, 0u, 3u, qb, bb);
-        if (maxlen >= 4) probe_issue(T, w0, 0u, 4u, qc, bc);
-        if (maxlen >= 2) row[0] = probe_finish(T, ka, 0u, 2u, qa, ba);
-        if (maxlen >= 3) row[1] = probe_finish(T, kb, 0u, 3u, qb, bb);
-        if (maxlen >= 4) row[2] = probe_finish(T, w0, 0u, 4u, qc, bc);
+        // (ONE predicate for the three probes: cells for lengths beyond maxlen are never read, so
+        //  the lanes need no per-length predicate -- with one, the compiler waits after every
+        //  single probe instead of keeping the twelve bucket loads in flight together)
+        if (maxlen >= 2) {
+            probe_issue(T, ka, 0u, 2u, qa, ba);
+            probe_issue(T, kb, 0u, 3u, qb, bb);
+            probe_issue(T, w0, 0u, 4u, qc, bc);
+            row[0] = probe_finish(T, ka, 0u, 2u, qa, ba);
+            row[1] = probe_finish(T, kb, 0u, 3u, qb, bb);
+            row[2] = probe_finish(T, w0, 0u, 4u, qc, bc);
+        }
     }
     if (SUB_LMAX >= 5 && __any(maxlen >= 5)) {
         Quad qa[4], qb[4], qc[4];
         uint32_t ba = 0, bb = 0, bc = 0;
         const uint32_t ha = w1 & 0xFFu, hb = w1 & 0xFFFFu, hc = w1 & 0xFFFFFFu;
-        if (maxlen >= 5) probe_issue(T, w0, ha, 5u, qa, ba);
-        if (maxlen >= 6) probe_issue(T, w0, hb, 6u, qb, bb);
-        if (maxlen >= 7) probe_issue(T, w0, hc, 7u, qc, bc);
-        if (maxlen >= 5) row[3] = probe_finish(T, w0, ha, 5u, qa, ba);
-        if (maxlen >= 6) row[4] = probe_finish(T, w0, hb, 6u, qb, bb);
-        if (maxlen >= 7) row[5] = probe_finish(T, w0, hc, 7u, qc, bc);
+        if (maxlen >= 5) {
+            probe_issue(T, w0, ha, 5u, qa, ba);
+            probe_issue(T, w0, hb, 6u, qb, bb);
+            probe_issue(T, w0, hc, 7u, qc, bc);
+            row[3] = probe_finish(T, w0, ha, 5u, qa, ba);
+            row[4] = probe_finish(T, w0, hb, 6u, qb, bb);
+            row[5] = probe_finish(T, w0, hc, 7u, qc, bc);
+        }
     }
     if (SUB_LMAX >= 8 && maxlen >= 8) row[6] = probe_short(T, w0, w1, 0u, 8u);
     uint32_t rk = (gl + 1 < n) ? row[0] : SPL_NO_RANK;          // initial ranks (bpe.rs:114-116)
@@ -470,23 +477,30 @@ __device__ __forceinline__ void bpe_wave64_tab(const DeviceTables& T, const LdsA
         Quad qa[4], qb[4], qc[4];
         uint32_t ba = 0, bb = 0, bc = 0;
         const uint32_t ka = w0 & 0xFFFFu, kb = w0 & 0xFFFFFFu;
-        if (maxlen >= 2) probe_issue(T, ka, 0u, 2u, qa, ba);
-        if (maxlen >= 3) probe_issue(T, kb, 0u, 3u, qb, bb);
-        if (maxlen >= 4) probe_issue(T, w0, 0u, 4u, qc, bc);
-        if (maxlen >= 2) row[0] = probe_finish(T, ka, 0u, 2u, qa, ba);
-        if (maxlen >= 3) row[1] = probe_finish(T, kb, 0u, 3u, qb, bb);
-        if (maxlen >= 4) row[2] = probe_finish(T, w0, 0u, 4u, qc, bc);
+        // (ONE predicate for the three probes: cells for lengths beyond maxlen are never read, so
+        //  the lanes need no per-length predicate -- with one, the compiler waits after every
+        //  single probe instead of keeping the twelve bucket loads in flight together)
+        if (maxlen >= 2) {
+            probe_issue(T, ka, 0u, 2u, qa, ba);
+            probe_issue(T, kb, 0u, 3u, qb, bb);
+            probe_issue(T, w0, 0u, 4u, qc, bc);
+            row[0] = probe_finish(T, ka, 0u, 2u, qa, ba);
+            row[1] = probe_finish(T, kb, 0u, 3u, qb, bb);
+            row[2] = probe_finish(T, w0, 0u, 4u, qc, bc);
+        }
     }
     if (SUB_LMAX >= 5) {
         Quad qa[4], qb[4], qc[4];
         uint32_t ba = 0, bb = 0, bc = 0;
         const uint32_t ha = w1 & 0xFFu, hb = w1 & 0xFFFFu, hc = w1 & 0xFFFFFFu;
-        if (maxlen >= 5) probe_issue(T, w0, ha, 5u, qa, ba);
-        if (maxlen >= 6) probe_issue(T, w0, hb, 6u, qb, bb);
-        if (maxlen >= 7) probe_issue(T, w0, hc, 7u, qc, bc);
-        if (maxlen >= 5) row[3] = probe_finish(T, w0, ha, 5u, qa, ba);
-        if (maxlen >= 6) row[4] = probe_finish(T, w0, hb, 6u, qb, bb);
-        if (maxlen >= 7) row[5] = probe_finish(T, w0, hc, 7u, qc, bc);
+        if (maxlen >= 5) {
+            probe_issue(T, w0, ha, 5u, qa, ba);
+            probe_issue(T, w0, hb, 6u, qb, bb);
+            probe_issue(T, w0, hc, 7u, qc, bc);
+            row[3] = probe_finish(T, w0, ha, 5u, qa, ba);
+            row[4] = probe_finish(T, w0, hb, 6u, qb, bb);
+            row[5] = probe_finish(T, w0, hc, 7u, qc, bc);
+        }
     }
     if (SUB_LMAX >= 8 && maxlen >= 8) row[6] = probe_short(T, w0, w1, 0u, 8u);
     uint32_t rk = (lane + 1 < n) ? row[0] : SPL_NO_RANK;
