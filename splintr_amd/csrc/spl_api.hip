@@ -30,7 +30,7 @@ int fail(int code, const std::string& msg) {
 
 enum { KI_MARK = 0, KI_SPECIAL, KI_PRETOK, KI_DEFER, KI_BPELANES, KI_BPELONG, KI_COUNT, KI_SCAN, KI_COMPACT, KI_N };
 const char* const k_names[KI_N] = {"memset+k_mark_docs", "k_special_scan+ends", "k_pretok", "k_deferred", "k_bpe_lanes64",
-                                   "k_bpe_long", "k_count", "k_scan", "k_compact_docs"};
+                                   "k_bpe_long", "k_count", "k_scan", "k_compact_docs|k_tile_out"};
 
 template <class T> int dev_upload(const std::vector<T>& v, const T** out) {
     void* p = nullptr;
@@ -313,6 +313,8 @@ spl_tokenizer* spl_create(const void* vocab_splv, size_t vocab_len, const void* 
         if ((rc = dev_upload(t->ht.ucls_stage1, &t->dt.ucls_stage1))) return rc;
         if ((rc = dev_upload(t->ht.ucls_stage2, &t->dt.ucls_stage2))) return rc;
         if ((rc = dev_upload(t->ht.short_tab, &t->dt.short_tab))) return rc;
+        if ((rc = dev_upload(t->ht.tiny_tab, &t->dt.tiny_tab))) return rc;
+        if ((rc = dev_upload(t->ht.t8_tab, &t->dt.t8_tab))) return rc;
         if ((rc = dev_upload(t->ht.long_tab, &t->dt.long_tab))) return rc;
         if ((rc = dev_upload(t->ht.key_blob, &t->dt.key_blob))) return rc;
         if ((rc = dev_upload(t->ht.pair_tab, &t->dt.pair_tab))) return rc;
@@ -325,6 +327,8 @@ spl_tokenizer* spl_create(const void* vocab_splv, size_t vocab_len, const void* 
     t->dt.ucls_shift = t->ht.ucls_shift;
     t->dt.cjk_fast = t->ht.cjk_fast ? 1u : 0u;
     t->dt.short_mask = (uint32_t)(t->ht.short_tab.size() / SPL_SHORT_BUCKET) - 1;
+    t->dt.tiny_mask = (uint32_t)(t->ht.tiny_tab.size() / (SPL_TINY_BUCKET * 2)) - 1;
+    t->dt.t8_mask = (uint32_t)(t->ht.t8_tab.size() / SPL_T8_WORDS) - 1;
     t->dt.long_mask = (uint32_t)t->ht.long_tab.size() - 1;
     t->dt.pair_mask = (uint32_t)(t->ht.pair_tab.size() / SPL_PAIR_BUCKET) - 1;
     t->dt.max_key_len = t->ht.max_key_len;
@@ -369,6 +373,7 @@ void spl_destroy(spl_tokenizer* t) {
     hipDeviceSynchronize();
     free_workspace(t);
     hipFree((void*)t->dt.ucls_stage1); hipFree((void*)t->dt.ucls_stage2); hipFree((void*)t->dt.short_tab);
+    hipFree((void*)t->dt.tiny_tab); hipFree((void*)t->dt.t8_tab);
     hipFree((void*)t->dt.long_tab); hipFree((void*)t->dt.key_blob); hipFree((void*)t->dt.pair_tab);
     hipFree((void*)t->dt.byte_id); hipFree((void*)t->d_tok_off); hipFree((void*)t->d_tok_bytes);
     hipFree(t->d_in_text); hipFree(t->d_in_off); hipFree(t->d_out_ids); hipFree(t->d_out_off); hipFree(t->d_sp_lits);

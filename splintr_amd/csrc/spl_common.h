@@ -63,6 +63,19 @@ struct ShortEnt {            // 16 B
     uint32_t id_len;         // id | len << 24 ; 0xFFFFFFFF = empty slot
 };
 constexpr int SPL_SHORT_BUCKET = 4;                     // entries per 64-byte bucket (one cache line)
+// Keys of up to 8 bytes -- nearly every probe of the hot path (whole chunks of a few bytes, the
+// substring tabulation of the merge loops) -- have two smaller tables of their own, so that those
+// probes move fewer bytes, need fewer registers and stay resident in L2:
+//   tiny table: keys of 1..4 bytes, 8-byte entries {key, id | len << 24}, buckets of 4 = 32 bytes
+//   t8 table  : keys of 5..8 bytes, 12-byte entries {k0, k1, id | len << 24}, 4 per 64-byte bucket
+//               (48 bytes used: three dwordx4 loads)
+// Same bucket discipline as the short table (fill left to right, never delete, last slot empty ==
+// bucket not full).  The short table keeps the keys of 9..12 bytes.
+constexpr int SPL_TINY_BUCKET = 4;                      // entries per 32-byte bucket
+constexpr int SPL_TINY_MAX = 4;
+constexpr int SPL_T8_BUCKET = 4;                        // entries per 64-byte bucket
+constexpr int SPL_T8_WORDS = 16;                        // u32 words per bucket (12 used)
+constexpr int SPL_T8_MAX = 8;
 // Long-key table: 13..max_key_len bytes; key bytes live in a 4-byte-aligned blob.
 struct LongEnt {             // 16 B
     uint32_t tag;            // second hash, filters almost every false candidate
@@ -89,6 +102,8 @@ struct DeviceTables {
     uint32_t cjk_fast;        // 1 if U+4E00..U+9FFF and U+AC00..U+D7A3 are uniformly C_LO
     // vocabulary
     const ShortEnt* short_tab; uint32_t short_mask;   // masks index BUCKETS
+    const uint32_t* tiny_tab;  uint32_t tiny_mask;
+    const uint32_t* t8_tab;    uint32_t t8_mask;
     const LongEnt* long_tab;   uint32_t long_mask;
     const uint8_t* key_blob;
     const uint64_t* pair_tab;  uint32_t pair_mask;
@@ -104,6 +119,10 @@ struct DeviceTables {
 SPL_HD uint32_t mix32(uint32_t h) {
     h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
     return h;
+}
+SPL_HD uint32_t hash_tiny(uint32_t k0, uint32_t len) { return mix32(k0 * 0x9E3779B1u ^ (len * 0x27D4EB2Fu)); }
+SPL_HD uint32_t hash_t8(uint32_t k0, uint32_t k1, uint32_t len) {
+    return mix32(k0 * 0x9E3779B1u ^ (k1 * 0x85EBCA77u + 0x165667B1u) ^ (len * 0x27D4EB2Fu));
 }
 SPL_HD uint32_t hash_short(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len) {
     uint32_t h = k0 * 0x9E3779B1u ^ (k1 * 0x85EBCA77u + 0x165667B1u) ^ (k2 * 0xC2B2AE3Du) ^ (len * 0x27D4EB2Fu);

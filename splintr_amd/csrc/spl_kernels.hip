@@ -320,25 +320,42 @@ __device__ __forceinline__ void bpe_group16(const DeviceTables& T, int n, ByteAt
 constexpr int SUB_LMAX = SPL_SUB_LMAX;
 constexpr int SUB_W = SUB_LMAX - 1;          // table width: lengths 2..8
 
-__device__ __forceinline__ void probe_issue(const DeviceTables& T, uint32_t k0, uint32_t k1, uint32_t n, Quad (&q)[4],
-                                            uint32_t& bkt) {
-    bkt = hash_short(k0, k1, 0u, n) & T.short_mask;
-    const Quad* src = reinterpret_cast<const Quad*>(T.short_tab + (size_t)bkt * SPL_SHORT_BUCKET);
-    q[0] = src[0]; q[1] = src[1]; q[2] = src[2]; q[3] = src[3];
+// split probes of the tiny table (keys of 2..4 bytes) and of the t8 table (5..8 bytes)
+__device__ __forceinline__ void tiny_issue(const DeviceTables& T, uint32_t k0, uint32_t n, Quad (&q)[2]) {
+    const uint32_t bkt = hash_tiny(k0, n) & T.tiny_mask;
+    const Quad* src = reinterpret_cast<const Quad*>(T.tiny_tab + (size_t)bkt * (SPL_TINY_BUCKET * 2));
+    q[0] = src[0]; q[1] = src[1];
 }
-__device__ __forceinline__ uint32_t probe_finish(const DeviceTables& T, uint32_t k0, uint32_t k1, uint32_t n,
-                                                 const Quad (&q)[4], uint32_t bkt) {
+__device__ __forceinline__ uint32_t tiny_finish(const DeviceTables& T, uint32_t k0, uint32_t n, const Quad (&q)[2]) {
+    const bool f0 = (q[0].x == k0) & ((q[0].y >> 24) == n);
+    const bool f1 = (q[0].z == k0) & ((q[0].w >> 24) == n);
+    const bool f2 = (q[1].x == k0) & ((q[1].y >> 24) == n);
+    const bool f3 = (q[1].z == k0) & ((q[1].w >> 24) == n);
     uint32_t r = SPL_NO_RANK;
-    bool found = false;
-#pragma unroll
-    for (int e = 3; e >= 0; e--) {
-        const bool f = (q[e].x == k0) & (q[e].y == k1) & (q[e].z == 0u) & ((q[e].w >> 24) == n);
-        r = f ? (q[e].w & 0xFFFFFFu) : r;
-        found |= f;
-    }
-    if (found | (q[3].w == SPL_EMPTY)) return r;
-    (void)bkt;
-    return probe_short(T, k0, k1, 0u, n);      // home bucket full without a match (rare): generic probe
+    r = f3 ? (q[1].w & 0xFFFFFFu) : r;
+    r = f2 ? (q[1].y & 0xFFFFFFu) : r;
+    r = f1 ? (q[0].w & 0xFFFFFFu) : r;
+    r = f0 ? (q[0].y & 0xFFFFFFu) : r;
+    if ((f0 | f1 | f2 | f3) | (q[1].w == SPL_EMPTY)) return r;
+    return probe_tiny(T, k0, n);               // home bucket full without a match (rare): generic probe
+}
+__device__ __forceinline__ void t8_issue(const DeviceTables& T, uint32_t k0, uint32_t k1, uint32_t n, Quad (&q)[3]) {
+    const uint32_t bkt = hash_t8(k0, k1, n) & T.t8_mask;
+    const Quad* src = reinterpret_cast<const Quad*>(T.t8_tab + (size_t)bkt * SPL_T8_WORDS);
+    q[0] = src[0]; q[1] = src[1]; q[2] = src[2];
+}
+__device__ __forceinline__ uint32_t t8_finish(const DeviceTables& T, uint32_t k0, uint32_t k1, uint32_t n, const Quad (&q)[3]) {
+    const bool f0 = (q[0].x == k0) & (q[0].y == k1) & ((q[0].z >> 24) == n);
+    const bool f1 = (q[0].w == k0) & (q[1].x == k1) & ((q[1].y >> 24) == n);
+    const bool f2 = (q[1].z == k0) & (q[1].w == k1) & ((q[2].x >> 24) == n);
+    const bool f3 = (q[2].y == k0) & (q[2].z == k1) & ((q[2].w >> 24) == n);
+    uint32_t r = SPL_NO_RANK;
+    r = f3 ? (q[2].w & 0xFFFFFFu) : r;
+    r = f2 ? (q[2].x & 0xFFFFFFu) : r;
+    r = f1 ? (q[1].y & 0xFFFFFFu) : r;
+    r = f0 ? (q[0].z & 0xFFFFFFu) : r;
+    if ((f0 | f1 | f2 | f3) | (q[2].w == SPL_EMPTY)) return r;
+    return probe_t8(T, k0, k1, n);
 }
 
 template <class Emit>
@@ -354,32 +371,30 @@ __device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const Lds
     uint32_t id = own ? T.byte_id[w0 & 0xFFu] : SPL_DEAD;
     uint32_t* row = sub + gl * SUB_W;
     {
-        Quad qa[4], qb[4], qc[4];
-        uint32_t ba = 0, bb = 0, bc = 0;
+        Quad qa[2], qb[2], qc[2];
         const uint32_t ka = w0 & 0xFFFFu, kb = w0 & 0xFFFFFFu;
         // (ONE predicate for the three probes: cells for lengths beyond maxlen are never read, so
         //  the lanes need no per-length predicate -- with one, the compiler waits after every
-        //  single probe instead of keeping the twelve bucket loads in flight together)
+        //  single probe instead of keeping all the bucket loads in flight together)
         if (maxlen >= 2) {
-            probe_issue(T, ka, 0u, 2u, qa, ba);
-            probe_issue(T, kb, 0u, 3u, qb, bb);
-            probe_issue(T, w0, 0u, 4u, qc, bc);
-            row[0] = probe_finish(T, ka, 0u, 2u, qa, ba);
-            row[1] = probe_finish(T, kb, 0u, 3u, qb, bb);
-            row[2] = probe_finish(T, w0, 0u, 4u, qc, bc);
+            tiny_issue(T, ka, 2u, qa);
+            tiny_issue(T, kb, 3u, qb);
+            tiny_issue(T, w0, 4u, qc);
+            row[0] = tiny_finish(T, ka, 2u, qa);
+            row[1] = tiny_finish(T, kb, 3u, qb);
+            row[2] = tiny_finish(T, w0, 4u, qc);
         }
     }
     if (SUB_LMAX >= 5 && __any(maxlen >= 5)) {
-        Quad qa[4], qb[4], qc[4];
-        uint32_t ba = 0, bb = 0, bc = 0;
+        Quad qa[3], qb[3], qc[3];
         const uint32_t ha = w1 & 0xFFu, hb = w1 & 0xFFFFu, hc = w1 & 0xFFFFFFu;
         if (maxlen >= 5) {
-            probe_issue(T, w0, ha, 5u, qa, ba);
-            probe_issue(T, w0, hb, 6u, qb, bb);
-            probe_issue(T, w0, hc, 7u, qc, bc);
-            row[3] = probe_finish(T, w0, ha, 5u, qa, ba);
-            row[4] = probe_finish(T, w0, hb, 6u, qb, bb);
-            row[5] = probe_finish(T, w0, hc, 7u, qc, bc);
+            t8_issue(T, w0, ha, 5u, qa);
+            t8_issue(T, w0, hb, 6u, qb);
+            t8_issue(T, w0, hc, 7u, qc);
+            row[3] = t8_finish(T, w0, ha, 5u, qa);
+            row[4] = t8_finish(T, w0, hb, 6u, qb);
+            row[5] = t8_finish(T, w0, hc, 7u, qc);
         }
     }
     if (SUB_LMAX >= 8 && maxlen >= 8) row[6] = probe_short(T, w0, w1, 0u, 8u);
@@ -474,32 +489,30 @@ __device__ __forceinline__ void bpe_wave64_tab(const DeviceTables& T, const LdsA
     uint32_t id = own ? T.byte_id[w0 & 0xFFu] : SPL_DEAD;
     uint32_t* row = sub + lane * SUB_W;
     {
-        Quad qa[4], qb[4], qc[4];
-        uint32_t ba = 0, bb = 0, bc = 0;
+        Quad qa[2], qb[2], qc[2];
         const uint32_t ka = w0 & 0xFFFFu, kb = w0 & 0xFFFFFFu;
         // (ONE predicate for the three probes: cells for lengths beyond maxlen are never read, so
         //  the lanes need no per-length predicate -- with one, the compiler waits after every
-        //  single probe instead of keeping the twelve bucket loads in flight together)
+        //  single probe instead of keeping all the bucket loads in flight together)
         if (maxlen >= 2) {
-            probe_issue(T, ka, 0u, 2u, qa, ba);
-            probe_issue(T, kb, 0u, 3u, qb, bb);
-            probe_issue(T, w0, 0u, 4u, qc, bc);
-            row[0] = probe_finish(T, ka, 0u, 2u, qa, ba);
-            row[1] = probe_finish(T, kb, 0u, 3u, qb, bb);
-            row[2] = probe_finish(T, w0, 0u, 4u, qc, bc);
+            tiny_issue(T, ka, 2u, qa);
+            tiny_issue(T, kb, 3u, qb);
+            tiny_issue(T, w0, 4u, qc);
+            row[0] = tiny_finish(T, ka, 2u, qa);
+            row[1] = tiny_finish(T, kb, 3u, qb);
+            row[2] = tiny_finish(T, w0, 4u, qc);
         }
     }
     if (SUB_LMAX >= 5) {
-        Quad qa[4], qb[4], qc[4];
-        uint32_t ba = 0, bb = 0, bc = 0;
+        Quad qa[3], qb[3], qc[3];
         const uint32_t ha = w1 & 0xFFu, hb = w1 & 0xFFFFu, hc = w1 & 0xFFFFFFu;
         if (maxlen >= 5) {
-            probe_issue(T, w0, ha, 5u, qa, ba);
-            probe_issue(T, w0, hb, 6u, qb, bb);
-            probe_issue(T, w0, hc, 7u, qc, bc);
-            row[3] = probe_finish(T, w0, ha, 5u, qa, ba);
-            row[4] = probe_finish(T, w0, hb, 6u, qb, bb);
-            row[5] = probe_finish(T, w0, hc, 7u, qc, bc);
+            t8_issue(T, w0, ha, 5u, qa);
+            t8_issue(T, w0, hb, 6u, qb);
+            t8_issue(T, w0, hc, 7u, qc);
+            row[3] = t8_finish(T, w0, ha, 5u, qa);
+            row[4] = t8_finish(T, w0, hb, 6u, qb);
+            row[5] = t8_finish(T, w0, hc, 7u, qc);
         }
     }
     if (SUB_LMAX >= 8 && maxlen >= 8) row[6] = probe_short(T, w0, w1, 0u, 8u);
@@ -905,8 +918,14 @@ void k_pretok(DeviceTables T, Batch b) {
     __shared__ unsigned long long s_base;                // tokens of all earlier tiles
     uint8_t* const s_txt = reinterpret_cast<uint8_t*>(s_txt32);
     uint8_t* const s_rec = reinterpret_cast<uint8_t*>(s_rec32);
+    // Phase stamps, per-workgroup records and the phase cut-off are compiled in only with
+    // -DSPL_DEBUG_STAMPS (tools/ab_build.sh): their live values cost the product kernel registers.
+#ifdef SPL_DEBUG_STAMPS
 #define SPL_STAMP(i) do { if (b.dbg && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) b.dbg[i] = clock64(); \
                           if ((i) >= 1 && (i) <= 7 && b.stop_phase == (uint32_t)(i)) return; } while (0)
+#else
+#define SPL_STAMP(i) do { } while (0)
+#endif
 
     const int tid = threadIdx.x;
     if (DIRECT) __builtin_amdgcn_s_setprio(SPL_WORK_PRIO);
@@ -916,10 +935,12 @@ void k_pretok(DeviceTables T, Batch b) {
     // profiling: span of this kernel on the constant-rate wall clock (start of workgroup 0, max end
     // over all workgroups) -- what a kernel trace reports, without host-side event overhead
     if (b.dbg && tid == 0 && blockIdx.x == 0) b.dbg[14] = (unsigned long long)wall_clock64();   // dispatched first
+#ifdef SPL_DEBUG_STAMPS
     if (b.dbg && tid == 0 && blockIdx.x == gridDim.x / 2) b.dbg[11] = (unsigned long long)wall_clock64();
     const unsigned long long blk_t0 = b.dbg ? (unsigned long long)wall_clock64() : 0ull;
     unsigned long long blk_w1 = 0, blk_w2 = 0;
     if (b.dbg && tid == 0 && blockIdx.x == gridDim.x - 1) b.dbg[13] = (unsigned long long)wall_clock64();
+#endif
 
     // ---- stage text (coalesced 16 B per lane) and the window's flag bits ------------------------
     for (int v = tid; v < (Wv + WPAD) / 16; v += NT) {
@@ -1261,7 +1282,9 @@ void k_pretok(DeviceTables T, Batch b) {
     SPL_STAMP(10);
     __syncthreads();
     SPL_STAMP(7);
+#ifdef SPL_DEBUG_STAMPS
     if (b.dbg) blk_w1 = blk_w2 = (unsigned long long)wall_clock64();
+#endif
     if (!DIRECT) {
         if (tid < G::NBW) {
             const uint32_t wv = s_tbits[tid];
@@ -1399,7 +1422,9 @@ void k_pretok(DeviceTables T, Batch b) {
             atomicAdd(&b.tctl[16 + b.tpar * b.tgroups + (blockIdx.x >> 6)], (uint32_t)total);
         }
         __syncthreads();
+#ifdef SPL_DEBUG_STAMPS
         if (b.dbg) blk_w2 = (unsigned long long)wall_clock64();
+#endif
         const uint32_t slot = (uint32_t)s_base;
         for (uint32_t k = tid; k < c_win; k += NT) b.tile_ids[slot + k] = s_ids[s_cpos[k]];
         uint32_t d_lo = 0xFFFFFFFFu, d_n = 0;
@@ -1435,6 +1460,7 @@ void k_pretok(DeviceTables T, Batch b) {
         }
     }
     SPL_STAMP(8);
+#ifdef SPL_DEBUG_STAMPS
     if (b.dbg && tid == 0 && blockIdx.x == gridDim.x / 2) b.dbg[12] = (unsigned long long)wall_clock64();
     if (b.dbg && tid == 0 && blockIdx.x < SPL_DEBUG_BLOCKS) {
         // wall-clock ticks: start, end of the merge phase, look-back done (single pass), end
@@ -1444,6 +1470,7 @@ void k_pretok(DeviceTables T, Batch b) {
         r[2] = blk_w2;
         r[3] = (unsigned long long)wall_clock64();
     }
+#endif
     if (b.dbg && tid == 0) atomicMax(&b.dbg[15], (unsigned long long)wall_clock64());
 #undef SPL_STAMP
 }

@@ -25,7 +25,48 @@ SPL_HD uint32_t mask_tail(uint32_t w, int nbytes) {     // keep the low nbytes (
 // NOTE: the bucket compares are written branch-free on purpose.  With early returns the compiler
 // sinks the later loads into the "not found yet" branches and a miss costs several DEPENDENT
 // memory round trips; with selects every load of the bucket is issued before the first wait.
+// keys of 1..4 bytes: two dwordx4 loads per bucket
+SPL_HD uint32_t probe_tiny(const DeviceTables& T, uint32_t k0, uint32_t n) {
+    uint32_t bkt = hash_tiny(k0, n) & T.tiny_mask;
+    for (;;) {
+        const Quad* q = reinterpret_cast<const Quad*>(T.tiny_tab + (size_t)bkt * (SPL_TINY_BUCKET * 2));
+        const Quad a = q[0], c = q[1];
+        const bool f0 = (a.x == k0) & ((a.y >> 24) == n);
+        const bool f1 = (a.z == k0) & ((a.w >> 24) == n);
+        const bool f2 = (c.x == k0) & ((c.y >> 24) == n);
+        const bool f3 = (c.z == k0) & ((c.w >> 24) == n);
+        uint32_t r = SPL_NO_RANK;
+        r = f3 ? (c.w & 0xFFFFFFu) : r;
+        r = f2 ? (c.y & 0xFFFFFFu) : r;
+        r = f1 ? (a.w & 0xFFFFFFu) : r;
+        r = f0 ? (a.y & 0xFFFFFFu) : r;
+        if ((f0 | f1 | f2 | f3) | (c.w == SPL_EMPTY)) return r;
+        bkt = (bkt + 1) & T.tiny_mask;
+    }
+}
+// keys of 5..8 bytes: three dwordx4 loads per bucket (entries of three words straddle them)
+SPL_HD uint32_t probe_t8(const DeviceTables& T, uint32_t k0, uint32_t k1, uint32_t n) {
+    uint32_t bkt = hash_t8(k0, k1, n) & T.t8_mask;
+    for (;;) {
+        const Quad* q = reinterpret_cast<const Quad*>(T.t8_tab + (size_t)bkt * SPL_T8_WORDS);
+        const Quad a = q[0], c = q[1], d = q[2];
+        const bool f0 = (a.x == k0) & (a.y == k1) & ((a.z >> 24) == n);
+        const bool f1 = (a.w == k0) & (c.x == k1) & ((c.y >> 24) == n);
+        const bool f2 = (c.z == k0) & (c.w == k1) & ((d.x >> 24) == n);
+        const bool f3 = (d.y == k0) & (d.z == k1) & ((d.w >> 24) == n);
+        uint32_t r = SPL_NO_RANK;
+        r = f3 ? (d.w & 0xFFFFFFu) : r;
+        r = f2 ? (d.x & 0xFFFFFFu) : r;
+        r = f1 ? (c.y & 0xFFFFFFu) : r;
+        r = f0 ? (a.z & 0xFFFFFFu) : r;
+        if ((f0 | f1 | f2 | f3) | (d.w == SPL_EMPTY)) return r;
+        bkt = (bkt + 1) & T.t8_mask;
+    }
+}
+// keys of up to 12 bytes, by length class
 SPL_HD uint32_t probe_short(const DeviceTables& T, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t n) {
+    if (n <= (uint32_t)SPL_TINY_MAX) return probe_tiny(T, k0, n);
+    if (n <= (uint32_t)SPL_T8_MAX) return probe_t8(T, k0, k1, n);
     uint32_t bkt = hash_short(k0, k1, k2, n) & T.short_mask;
     for (;;) {
         const Quad* q = reinterpret_cast<const Quad*>(T.short_tab + (size_t)bkt * SPL_SHORT_BUCKET);

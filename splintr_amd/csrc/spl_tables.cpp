@@ -147,8 +147,15 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
     }
 
     // ---- short / long key tables ----------------------------------------------------------
-    size_t n_short = 0, n_long = 0;
-    for (const auto& kv : enc) (kv.first.size() <= (size_t)SPL_SHORT_MAX ? n_short : n_long)++;
+    size_t n_short = 0, n_long = 0, n_tiny = 0, n_t8 = 0;
+    for (const auto& kv : enc) {
+        const size_t n = kv.first.size();
+        (n <= (size_t)SPL_TINY_MAX ? n_tiny : n <= (size_t)SPL_T8_MAX ? n_t8 : n <= (size_t)SPL_SHORT_MAX ? n_short : n_long)++;
+    }
+    // tiny / t8 tables: buckets of 4, at most about 1.5 entries per bucket on average
+    const uint32_t tbuckets = pow2_at_least(n_tiny * 2 / 3 + 2), ebuckets = pow2_at_least(n_t8 * 2 / 3 + 2);
+    out.tiny_tab.assign((size_t)tbuckets * SPL_TINY_BUCKET * 2, SPL_EMPTY);
+    out.t8_tab.assign((size_t)ebuckets * SPL_T8_WORDS, SPL_EMPTY);
     // short table: buckets of 4, about 1.5 entries per bucket on average
     const uint32_t sbuckets = pow2_at_least(n_short * 2 / 3 + 2), lcap = pow2_at_least(n_long * 2 + 2);
     out.short_tab.assign((size_t)sbuckets * SPL_SHORT_BUCKET, ShortEnt{0, 0, 0, SPL_EMPTY});
@@ -157,7 +164,27 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
     for (const auto& kv : enc) {
         const std::string& k = kv.first;
         const uint32_t n = (uint32_t)k.size();
-        if (n <= (uint32_t)SPL_SHORT_MAX) {
+        if (n <= (uint32_t)SPL_TINY_MAX) {
+            const uint32_t k0 = load_le(k, 0);
+            uint32_t bkt = hash_tiny(k0, n) & (tbuckets - 1);
+            for (;;) {
+                uint32_t* e = &out.tiny_tab[(size_t)bkt * SPL_TINY_BUCKET * 2];
+                int f = 0;
+                while (f < SPL_TINY_BUCKET && e[2 * f + 1] != SPL_EMPTY) f++;
+                if (f < SPL_TINY_BUCKET) { e[2 * f] = k0; e[2 * f + 1] = kv.second | (n << 24); break; }
+                bkt = (bkt + 1) & (tbuckets - 1);
+            }
+        } else if (n <= (uint32_t)SPL_T8_MAX) {
+            const uint32_t k0 = load_le(k, 0), k1 = load_le(k, 4);
+            uint32_t bkt = hash_t8(k0, k1, n) & (ebuckets - 1);
+            for (;;) {
+                uint32_t* e = &out.t8_tab[(size_t)bkt * SPL_T8_WORDS];
+                int f = 0;
+                while (f < SPL_T8_BUCKET && e[3 * f + 2] != SPL_EMPTY) f++;
+                if (f < SPL_T8_BUCKET) { e[3 * f] = k0; e[3 * f + 1] = k1; e[3 * f + 2] = kv.second | (n << 24); break; }
+                bkt = (bkt + 1) & (ebuckets - 1);
+            }
+        } else if (n <= (uint32_t)SPL_SHORT_MAX) {
             const uint32_t k0 = load_le(k, 0), k1 = load_le(k, 4), k2 = load_le(k, 8);
             uint32_t bkt = hash_short(k0, k1, k2, n) & (sbuckets - 1);
             for (;;) {                                   // first bucket with a free slot, slots left to right

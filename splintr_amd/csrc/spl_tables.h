@@ -20,7 +20,9 @@ struct HostTables {
     uint32_t ucls_shift = 7;
     bool cjk_fast = false;
     // vocabulary
-    std::vector<ShortEnt> short_tab;
+    std::vector<ShortEnt> short_tab;     // keys of 9..12 bytes
+    std::vector<uint32_t> tiny_tab;      // keys of 1..4 bytes: 2 words per entry, 4 entries per bucket
+    std::vector<uint32_t> t8_tab;        // keys of 5..8 bytes: 3 words per entry, SPL_T8_WORDS per bucket
     std::vector<LongEnt> long_tab;
     std::vector<uint8_t> key_blob;
     std::vector<uint64_t> pair_tab;

@@ -79,7 +79,9 @@ void* hs_create(const char* splv, const char* ucls, int pattern, char* errbuf, i
     }
     HostTables& h = s->ht;
     s->dt = DeviceTables{h.ucls_stage1.data(), h.ucls_stage2.data(), h.ucls_shift, h.cjk_fast ? 1u : 0u,
-                         h.short_tab.data(), (uint32_t)(h.short_tab.size() / SPL_SHORT_BUCKET) - 1, h.long_tab.data(),
+                         h.short_tab.data(), (uint32_t)(h.short_tab.size() / SPL_SHORT_BUCKET) - 1,
+                         h.tiny_tab.data(), (uint32_t)(h.tiny_tab.size() / (SPL_TINY_BUCKET * 2)) - 1,
+                         h.t8_tab.data(), (uint32_t)(h.t8_tab.size() / SPL_T8_WORDS) - 1, h.long_tab.data(),
                          (uint32_t)h.long_tab.size() - 1, h.key_blob.data(), h.pair_tab.data(),
                          (uint32_t)(h.pair_tab.size() / SPL_PAIR_BUCKET) - 1, h.byte_id.data(), h.max_key_len, (uint32_t)h.pattern,
                          h.all_bytes ? 1u : 0u};
