@@ -371,33 +371,34 @@ __device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const Lds
     uint32_t id = own ? T.byte_id[w0 & 0xFFu] : SPL_DEAD;
     uint32_t* row = sub + gl * SUB_W;
     {
-        Quad qa[2], qb[2], qc[2];
-        const uint32_t ka = w0 & 0xFFFFu, kb = w0 & 0xFFFFFFu;
-        // (ONE predicate for the three probes: cells for lengths beyond maxlen are never read, so
+        Quad qa[2], qb[2], qc[2], qd[3];
+        const uint32_t ka = w0 & 0xFFFFu, kb = w0 & 0xFFFFFFu, ha = w1 & 0xFFu;
+        // (ONE predicate for the four probes: cells for lengths beyond maxlen are never read, so
         //  the lanes need no per-length predicate -- with one, the compiler waits after every
         //  single probe instead of keeping all the bucket loads in flight together)
         if (maxlen >= 2) {
             tiny_issue(T, ka, 2u, qa);
             tiny_issue(T, kb, 3u, qb);
             tiny_issue(T, w0, 4u, qc);
+            t8_issue(T, w0, ha, 5u, qd);
             row[0] = tiny_finish(T, ka, 2u, qa);
             row[1] = tiny_finish(T, kb, 3u, qb);
             row[2] = tiny_finish(T, w0, 4u, qc);
+            row[3] = t8_finish(T, w0, ha, 5u, qd);
         }
     }
-    if (SUB_LMAX >= 5 && __any(maxlen >= 5)) {
+    if (SUB_LMAX >= 6 && __any(maxlen >= 6)) {
         Quad qa[3], qb[3], qc[3];
-        const uint32_t ha = w1 & 0xFFu, hb = w1 & 0xFFFFu, hc = w1 & 0xFFFFFFu;
-        if (maxlen >= 5) {
-            t8_issue(T, w0, ha, 5u, qa);
-            t8_issue(T, w0, hb, 6u, qb);
-            t8_issue(T, w0, hc, 7u, qc);
-            row[3] = t8_finish(T, w0, ha, 5u, qa);
-            row[4] = t8_finish(T, w0, hb, 6u, qb);
-            row[5] = t8_finish(T, w0, hc, 7u, qc);
+        const uint32_t hb = w1 & 0xFFFFu, hc = w1 & 0xFFFFFFu;
+        if (maxlen >= 6) {
+            t8_issue(T, w0, hb, 6u, qa);
+            t8_issue(T, w0, hc, 7u, qb);
+            t8_issue(T, w0, w1, 8u, qc);
+            row[4] = t8_finish(T, w0, hb, 6u, qa);
+            row[5] = t8_finish(T, w0, hc, 7u, qb);
+            if (SUB_LMAX >= 8) row[6] = t8_finish(T, w0, w1, 8u, qc);
         }
     }
-    if (SUB_LMAX >= 8 && maxlen >= 8) row[6] = probe_short(T, w0, w1, 0u, 8u);
     uint32_t rk = (gl + 1 < n) ? row[0] : SPL_NO_RANK;          // initial ranks (bpe.rs:114-116)
     uint32_t alive = n >= 16 ? 0xFFFFu : ((1u << n) - 1u);       // group-uniform, kept by every lane
     for (;;) {
@@ -489,33 +490,34 @@ __device__ __forceinline__ void bpe_wave64_tab(const DeviceTables& T, const LdsA
     uint32_t id = own ? T.byte_id[w0 & 0xFFu] : SPL_DEAD;
     uint32_t* row = sub + lane * SUB_W;
     {
-        Quad qa[2], qb[2], qc[2];
-        const uint32_t ka = w0 & 0xFFFFu, kb = w0 & 0xFFFFFFu;
-        // (ONE predicate for the three probes: cells for lengths beyond maxlen are never read, so
+        Quad qa[2], qb[2], qc[2], qd[3];
+        const uint32_t ka = w0 & 0xFFFFu, kb = w0 & 0xFFFFFFu, ha = w1 & 0xFFu;
+        // (ONE predicate for the four probes: cells for lengths beyond maxlen are never read, so
         //  the lanes need no per-length predicate -- with one, the compiler waits after every
         //  single probe instead of keeping all the bucket loads in flight together)
         if (maxlen >= 2) {
             tiny_issue(T, ka, 2u, qa);
             tiny_issue(T, kb, 3u, qb);
             tiny_issue(T, w0, 4u, qc);
+            t8_issue(T, w0, ha, 5u, qd);
             row[0] = tiny_finish(T, ka, 2u, qa);
             row[1] = tiny_finish(T, kb, 3u, qb);
             row[2] = tiny_finish(T, w0, 4u, qc);
+            row[3] = t8_finish(T, w0, ha, 5u, qd);
         }
     }
-    if (SUB_LMAX >= 5) {
+    if (SUB_LMAX >= 6) {
         Quad qa[3], qb[3], qc[3];
-        const uint32_t ha = w1 & 0xFFu, hb = w1 & 0xFFFFu, hc = w1 & 0xFFFFFFu;
-        if (maxlen >= 5) {
-            t8_issue(T, w0, ha, 5u, qa);
-            t8_issue(T, w0, hb, 6u, qb);
-            t8_issue(T, w0, hc, 7u, qc);
-            row[3] = t8_finish(T, w0, ha, 5u, qa);
-            row[4] = t8_finish(T, w0, hb, 6u, qb);
-            row[5] = t8_finish(T, w0, hc, 7u, qc);
+        const uint32_t hb = w1 & 0xFFFFu, hc = w1 & 0xFFFFFFu;
+        if (maxlen >= 6) {
+            t8_issue(T, w0, hb, 6u, qa);
+            t8_issue(T, w0, hc, 7u, qb);
+            t8_issue(T, w0, w1, 8u, qc);
+            row[4] = t8_finish(T, w0, hb, 6u, qa);
+            row[5] = t8_finish(T, w0, hc, 7u, qb);
+            if (SUB_LMAX >= 8) row[6] = t8_finish(T, w0, w1, 8u, qc);
         }
     }
-    if (SUB_LMAX >= 8 && maxlen >= 8) row[6] = probe_short(T, w0, w1, 0u, 8u);
     uint32_t rk = (lane + 1 < n) ? row[0] : SPL_NO_RANK;
     unsigned long long alive = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
     for (;;) {
