@@ -130,7 +130,7 @@ int reserve(spl_tokenizer* t, uint64_t max_bytes, uint64_t max_docs) {
         const size_t tiles = dbytes / TileGeom<SPL_TILE_SMALL>::TBv + 2;
         t->tgroups = (uint32_t)(tiles / 64 + 2);
         HIP_TRY(hipMalloc((void**)&t->d_tdesc, tiles * sizeof(TileDesc)));
-        HIP_TRY(hipMalloc((void**)&t->d_tile_ids, (dbytes + 8192) * 4));
+        HIP_TRY(hipMalloc((void**)&t->d_tile_ids, tiles * (size_t)(TileGeom<SPL_TILE_SMALL>::Wv + 1) * 4));
         HIP_TRY(hipMalloc((void**)&t->d_tctl, (16 + 2 * (size_t)t->tgroups) * 4));
         HIP_TRY(hipMemset(t->d_tctl, 0, (16 + 2 * (size_t)t->tgroups) * 4));
         t->tpar = 0;

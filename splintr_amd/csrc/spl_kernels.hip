@@ -307,6 +307,60 @@ __device__ __forceinline__ void bpe_group16(const DeviceTables& T, int n, ByteAt
     }
 }
 
+// Whole-chunk probe of the tile kernel for keys of up to 12 bytes: the three length classes live in
+// three tables, and a wavefront's lanes hold a mix of them.  All lanes first issue their bucket
+// loads (two quads always, a third / fourth by class -- predicated loads, no wait in between),
+// then compare by class; the wavefront pays ONE memory round trip instead of one per class.
+__device__ __forceinline__ uint32_t probe_short_mixed(const DeviceTables& T, uint32_t k0, uint32_t k1, uint32_t k2,
+                                                      uint32_t n) {
+    const bool tiny = n <= (uint32_t)SPL_TINY_MAX, t8 = !tiny && n <= (uint32_t)SPL_T8_MAX;
+    const uint32_t h = tiny ? hash_tiny(k0, n) : t8 ? hash_t8(k0, k1, n) : hash_short(k0, k1, k2, n);
+    const Quad* src = tiny ? reinterpret_cast<const Quad*>(T.tiny_tab + (size_t)(h & T.tiny_mask) * (SPL_TINY_BUCKET * 2))
+                    : t8   ? reinterpret_cast<const Quad*>(T.t8_tab + (size_t)(h & T.t8_mask) * SPL_T8_WORDS)
+                           : reinterpret_cast<const Quad*>(T.short_tab + (size_t)(h & T.short_mask) * SPL_SHORT_BUCKET);
+    Quad q0 = src[0], q1 = src[1], q2 = Quad{0, 0, 0, 0}, q3 = Quad{0, 0, 0, 0};
+    if (!tiny) q2 = src[2];
+    if (!tiny && !t8) q3 = src[3];
+    uint32_t r = SPL_NO_RANK;
+    bool settled;
+    if (tiny) {
+        const bool f0 = (q0.x == k0) & ((q0.y >> 24) == n), f1 = (q0.z == k0) & ((q0.w >> 24) == n);
+        const bool f2 = (q1.x == k0) & ((q1.y >> 24) == n), f3 = (q1.z == k0) & ((q1.w >> 24) == n);
+        r = f3 ? (q1.w & 0xFFFFFFu) : r; r = f2 ? (q1.y & 0xFFFFFFu) : r;
+        r = f1 ? (q0.w & 0xFFFFFFu) : r; r = f0 ? (q0.y & 0xFFFFFFu) : r;
+        settled = (f0 | f1 | f2 | f3) | (q1.w == SPL_EMPTY);
+    } else if (t8) {
+        const bool f0 = (q0.x == k0) & (q0.y == k1) & ((q0.z >> 24) == n);
+        const bool f1 = (q0.w == k0) & (q1.x == k1) & ((q1.y >> 24) == n);
+        const bool f2 = (q1.z == k0) & (q1.w == k1) & ((q2.x >> 24) == n);
+        const bool f3 = (q2.y == k0) & (q2.z == k1) & ((q2.w >> 24) == n);
+        r = f3 ? (q2.w & 0xFFFFFFu) : r; r = f2 ? (q2.x & 0xFFFFFFu) : r;
+        r = f1 ? (q1.y & 0xFFFFFFu) : r; r = f0 ? (q0.z & 0xFFFFFFu) : r;
+        settled = (f0 | f1 | f2 | f3) | (q2.w == SPL_EMPTY);
+    } else {
+        const bool f0 = (q0.x == k0) & (q0.y == k1) & (q0.z == k2) & ((q0.w >> 24) == n);
+        const bool f1 = (q1.x == k0) & (q1.y == k1) & (q1.z == k2) & ((q1.w >> 24) == n);
+        const bool f2 = (q2.x == k0) & (q2.y == k1) & (q2.z == k2) & ((q2.w >> 24) == n);
+        const bool f3 = (q3.x == k0) & (q3.y == k1) & (q3.z == k2) & ((q3.w >> 24) == n);
+        r = f3 ? (q3.w & 0xFFFFFFu) : r; r = f2 ? (q2.w & 0xFFFFFFu) : r;
+        r = f1 ? (q1.w & 0xFFFFFFu) : r; r = f0 ? (q0.w & 0xFFFFFFu) : r;
+        settled = (f0 | f1 | f2 | f3) | (q3.w == SPL_EMPTY);
+    }
+    if (settled) return r;
+    return probe_short(T, k0, k1, k2, n);       // home bucket full without a match (rare): generic probe
+}
+template <class TX>
+__device__ __forceinline__ uint32_t probe_chunk_tile(const DeviceTables& T, const TX& tx, int p, int n) {
+    if (n <= SPL_SHORT_MAX) {
+        const uint32_t k0 = mask_tail(tx.load32(p), n);
+        const uint32_t k1 = n > 4 ? mask_tail(tx.load32(p + 4), n - 4) : 0u;
+        const uint32_t k2 = n > 8 ? mask_tail(tx.load32(p + 8), n - 8) : 0u;
+        return probe_short_mixed(T, k0, k1, k2, (uint32_t)n);
+    }
+    if ((uint32_t)n > T.max_key_len) return SPL_NO_RANK;
+    return probe_long(T, tx, p, n);
+}
+
 // Short chunks (<= 16 bytes), one node per lane, with the pair ranks TABULATED up front.  The
 // reference ranks a pair by looking up the concatenated bytes (bpe.rs:99-111): the rank of (node
 // starting at i, its right neighbour ending at e) is the id of the token text[i, e).  The lane that
@@ -1189,7 +1243,7 @@ void k_pretok(DeviceTables T, Batch b) {
             const int p = s_cpos[k];
             if ((s_rec[p] & CB_CLASS) >= C_EOT) continue;   // terminator on a special-literal span
             const int n = (int)s_cpos[k + 1] - p;
-            const uint32_t id = probe_chunk(T, tx, p, n);
+            const uint32_t id = probe_chunk_tile(T, tx, p, n);
             if (id != SPL_NO_RANK) {
                 if (DIRECT) s_ids[p] = id;
                 else b.stage[w0 + p] = id;
@@ -1419,15 +1473,11 @@ void k_pretok(DeviceTables T, Batch b) {
         // (k_tile_out turns these into the final CSR once every tile's count is known; nothing here
         //  waits for another workgroup, so a tile that is slow -- long chunks, a chain that runs far
         //  beyond the window -- only delays itself)
-        if (tid == 0) {
-            s_base = atomicAdd(&b.tctl[0], c_win);
-            atomicAdd(&b.tctl[16 + b.tpar * b.tgroups + (blockIdx.x >> 6)], (uint32_t)total);
-        }
-        __syncthreads();
+        if (tid == 0) atomicAdd(&b.tctl[16 + b.tpar * b.tgroups + (blockIdx.x >> 6)], (uint32_t)total);
 #ifdef SPL_DEBUG_STAMPS
         if (b.dbg) blk_w2 = (unsigned long long)wall_clock64();
 #endif
-        const uint32_t slot = (uint32_t)s_base;
+        const uint32_t slot = blockIdx.x * (uint32_t)(Wv + 1);     // fixed slots: nothing to wait for
         for (uint32_t k = tid; k < c_win; k += NT) b.tile_ids[slot + k] = s_ids[s_cpos[k]];
         uint32_t d_lo = 0xFFFFFFFFu, d_n = 0;
         for (uint32_t db = dw;; db += NT) {
