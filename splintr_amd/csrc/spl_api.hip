@@ -212,7 +212,7 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
             t->bitmap_dirty = false;
         }
         b.tdesc = t->d_tdesc; b.tile_ids = t->d_tile_ids; b.tctl = t->d_tctl;
-        b.tgroups = t->tgroups; b.tpar = t->tpar;
+        b.tgroups = t->tgroups; b.tpar = t->tpar; b.tslot = (uint32_t)TileGeom<SPL_TILE_SMALL>::Wv + 1u;
         if (ntiles) t->tpar ^= 1u;              // k_tile_out zeroes the other parity's sums for the next call
         b.tstart = nullptr; b.qcount = nullptr;
         t->last_qcount = nullptr;

@@ -74,6 +74,7 @@ struct Batch {
     uint32_t* tile_ids;        // the tiles' window tokens, packed in order of completion (cursor = tctl[0])
     uint32_t* tctl;            // [0] packing cursor; [16 + par * tgroups ...] token sums per 64 tiles, two parities
     uint32_t tgroups;          // capacity of one parity's group-sum array
+    uint32_t tslot;            // words per tile in tile_ids[] (window size + 1)
     uint32_t tpar;             // parity of this call
 };
 
@@ -971,7 +972,6 @@ void k_pretok(DeviceTables T, Batch b) {
     __shared__ unsigned long long s_red[NT / 64];
     __shared__ unsigned long long s_best;
     __shared__ int s_touch[3];
-    __shared__ unsigned long long s_base;                // tokens of all earlier tiles
     uint8_t* const s_txt = reinterpret_cast<uint8_t*>(s_txt32);
     uint8_t* const s_rec = reinterpret_cast<uint8_t*>(s_rec32);
     // Phase stamps, per-workgroup records and the phase cut-off are compiled in only with
@@ -1477,7 +1477,7 @@ void k_pretok(DeviceTables T, Batch b) {
 #ifdef SPL_DEBUG_STAMPS
         if (b.dbg) blk_w2 = (unsigned long long)wall_clock64();
 #endif
-        const uint32_t slot = blockIdx.x * (uint32_t)(Wv + 1);     // fixed slots: nothing to wait for
+        const uint32_t slot = blockIdx.x * b.tslot;                // fixed slots: nothing to wait for
         for (uint32_t k = tid; k < c_win; k += NT) b.tile_ids[slot + k] = s_ids[s_cpos[k]];
         uint32_t d_lo = 0xFFFFFFFFu, d_n = 0;
         for (uint32_t db = dw;; db += NT) {
@@ -1540,6 +1540,10 @@ __global__ __launch_bounds__(NT) void k_tile_out(Batch b) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t* gs = b.tctl + 16 + b.tpar * b.tgroups;
     const uint32_t g = t >> 6;
+    // the tile's slot is fixed, so its first NT tokens are fetched before the counts are known
+    // (most tiles hold fewer): the copy below then depends on ONE round of loads, not two
+    const uint32_t slot0 = t * b.tslot;
+    const uint32_t first_id = b.tile_ids[slot0 + tid];
     unsigned long long mine = 0;
     for (uint32_t k = tid; k < g; k += NT) mine += gs[k];
     {
@@ -1555,7 +1559,7 @@ __global__ __launch_bounds__(NT) void k_tile_out(Batch b) {
     for (int k = 0; k < NT / 64; k++) base += s_part[k];
     for (uint32_t k = tid; k < td.c_win; k += NT) {
         const unsigned long long r = base + k;
-        if (r < b.ids_cap) b.ids_out[r] = b.tile_ids[td.slot + k];
+        if (r < b.ids_cap) b.ids_out[r] = k < (uint32_t)NT ? first_id : b.tile_ids[td.slot + k];
     }
     for (uint32_t k = tid; k < td.d_cnt; k += NT) b.off_out[td.d_first + k] += base;
     if (td.ovf_hi > td.ovf_lo) {                             // rare: tokens that start beyond the window
