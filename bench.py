@@ -76,7 +76,7 @@ def main():
     def step():
         encode_device(tok, batch)
         if gv is not None:
-            gv.submit(batch)          # pack -> async RCCL all-gather -> (unpack of the previous batch)
+            gv.submit(batch)          # pack; every 8th batch: one RCCL all-gather of the bucket + unpack, on its own stream
 
     # ---- untimed verification pass: bit-exact vs the oracle on this very batch -----------------
     step()
@@ -207,7 +207,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"cl100k_base, {args.docs} x ~1 KB mixed English/code per GPU "
                                    f"(splintr_amd.corpus.c2, seed 1002+rank), HBM-resident, CSR out"
-                                   + ("; + RCCL all-gatherv of the ragged ids (one all-gather of packed slabs per batch, overlapped with the next batch's encode)" if use_dist else ""),
+                                   + ("; + RCCL all-gatherv of the ragged ids (slabs packed per batch, ONE all-gather per bucket of 8 batches on its own stream, overlapped with the following encodes; every rank ends with every batch's global CSR)" if use_dist else ""),
                        "vocab": "cl100k_base", "docs_per_gpu": args.docs, "bytes_per_gpu": batch.n_bytes,
                        "tokens_per_gpu": n_tokens, "parallelism": f"doc-shard x{world}"},
             "parity": "bit-exact vs oracle (untimed verification pass on the bench batch)",

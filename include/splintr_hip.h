@@ -108,6 +108,14 @@ int spl_gatherv_pack(spl_tokenizer* t, const uint32_t* d_ids, const uint64_t* d_
 int spl_gatherv_unpack(spl_tokenizer* t, const uint32_t* d_slabs, uint32_t world, uint64_t cap_words,
                        uint64_t max_docs, uint32_t* d_all_ids, uint64_t all_ids_cap, uint64_t* d_all_off,
                        uint32_t* d_status, void* hip_stream);
+/* Bucketed form (fewer, larger collectives: xGMI rings are per-link bound and a collective has a
+ * fixed launch cost): every rank packs up to `depth` consecutive batches into `depth` slabs laid
+ * back to back, ONE all-gather moves world x depth slabs, and one launch unpacks the first
+ * n_batches of them: batch j's global CSR goes to d_all_ids + j * all_ids_cap and
+ * d_all_off + j * off_stride. */
+int spl_gatherv_unpack_group(spl_tokenizer* t, const uint32_t* d_slabs, uint32_t world, uint32_t depth, uint32_t n_batches,
+                             uint64_t cap_words, uint64_t max_docs, uint32_t* d_all_ids, uint64_t all_ids_cap,
+                             uint64_t* d_all_off, uint64_t off_stride, uint32_t* d_status, void* hip_stream);
 
 /* Tokenizer::decode_bytes for a batch (src/core/tokenizer.rs:877-897, 944-958), HOST buffers:
  * ids CSR in, bytes CSR out.  *out_bytes / *out_off are malloc'd; release with spl_free. */

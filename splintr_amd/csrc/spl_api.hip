@@ -534,7 +534,22 @@ int spl_gatherv_unpack(spl_tokenizer* t, const uint32_t* d_slabs, uint32_t world
         return fail(SPL_EINVAL, "spl_gatherv_unpack: bad argument");
     HIP_TRY(hipSetDevice(t->device));
     hipLaunchKernelGGL(k_gatherv_unpack, dim3(128, world), dim3(256), 0, (hipStream_t)hip_stream, d_slabs, world,
-                       (uint32_t)cap_words, (uint32_t)max_docs, d_all_ids, all_ids_cap, d_all_off, d_status);
+                       (uint32_t)cap_words, (uint32_t)max_docs, d_all_ids, all_ids_cap, d_all_off, d_status,
+                       (uint64_t)cap_words, (uint64_t)0);
+    HIP_TRY(hipGetLastError());
+    return SPL_OK;
+}
+
+int spl_gatherv_unpack_group(spl_tokenizer* t, const uint32_t* d_slabs, uint32_t world, uint32_t depth, uint32_t n_batches,
+                             uint64_t cap_words, uint64_t max_docs, uint32_t* d_all_ids, uint64_t all_ids_cap,
+                             uint64_t* d_all_off, uint64_t off_stride, uint32_t* d_status, void* hip_stream) {
+    if (!t || !d_slabs || !d_all_ids || !d_all_off || !d_status || world == 0 || depth == 0 || n_batches > depth)
+        return fail(SPL_EINVAL, "spl_gatherv_unpack_group: bad argument");
+    if (n_batches == 0) return SPL_OK;
+    HIP_TRY(hipSetDevice(t->device));
+    hipLaunchKernelGGL(k_gatherv_unpack, dim3(128, world, n_batches), dim3(256), 0, (hipStream_t)hip_stream, d_slabs, world,
+                       (uint32_t)cap_words, (uint32_t)max_docs, d_all_ids, all_ids_cap, d_all_off, d_status,
+                       (uint64_t)depth * cap_words, off_stride);
     HIP_TRY(hipGetLastError());
     return SPL_OK;
 }

@@ -1791,14 +1791,20 @@ __global__ void k_gatherv_pack(const uint32_t* ids, const uint64_t* out_off, uin
     const uint32_t ncopy = T < ids_cap ? T : ids_cap;        // T > ids_cap is reported by the unpacker
     for (uint32_t k = i; k < ncopy; k += stride) slab[ids_at + k] = ids[k];
 }
-// grid.y = source rank.  status[0] is set to 1 if any slab overflowed its id capacity.
-__global__ void k_gatherv_unpack(const uint32_t* slabs, uint32_t world, uint32_t cap_words, uint32_t max_docs,
-                                 uint32_t* all_ids, uint64_t all_ids_cap, uint64_t* all_off, uint32_t* status) {
-    const uint32_t r = blockIdx.y;
+// grid.y = source rank, grid.z = batch of the group (a rank sends `depth` slabs back to back per
+// collective: rank_stride = depth * cap_words; batch j's slabs start at j * cap_words and its outputs
+// at j * all_ids_cap / j * off_stride).  status[0] is set to 1 if any slab overflowed its id capacity.
+__global__ void k_gatherv_unpack(const uint32_t* slabs_all, uint32_t world, uint32_t cap_words, uint32_t max_docs,
+                                 uint32_t* all_ids_all, uint64_t all_ids_cap, uint64_t* all_off_all, uint32_t* status,
+                                 uint64_t rank_stride, uint64_t off_stride) {
+    const uint32_t r = blockIdx.y, j = blockIdx.z;
+    const uint32_t* slabs = slabs_all + (size_t)j * cap_words;
+    uint32_t* all_ids = all_ids_all + (size_t)j * all_ids_cap;
+    uint64_t* all_off = all_off_all + (size_t)j * off_stride;
     const uint32_t ids_at = 3 + max_docs, ids_cap = cap_words - ids_at;
     uint64_t tbase = 0, dbase = 0;
-    for (uint32_t q = 0; q < r; q++) { tbase += slabs[(size_t)q * cap_words]; dbase += slabs[(size_t)q * cap_words + 1]; }
-    const uint32_t* slab = slabs + (size_t)r * cap_words;
+    for (uint32_t q = 0; q < r; q++) { tbase += slabs[(size_t)q * rank_stride]; dbase += slabs[(size_t)q * rank_stride + 1]; }
+    const uint32_t* slab = slabs + (size_t)r * rank_stride;
     const uint32_t T = slab[0], N = slab[1];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
     if (i == 0 && T > ids_cap) status[0] = 1;

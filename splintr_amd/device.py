@@ -54,60 +54,94 @@ def result_csr(batch: DeviceBatch) -> Tuple[np.ndarray, np.ndarray]:
 
 
 class GatherV:
-    """Pipelined ragged all-gather of per-rank CSR results (one RCCL collective per batch).
+    """Pipelined, bucketed ragged all-gather of per-rank CSR results.
 
-    pack (HIP kernel) -> all_gather_into_tensor of equal slabs (async, RCCL over xGMI) -> unpack
-    (HIP kernel).  Two slab sets alternate, so the collective of batch i overlaps the encode of
-    batch i+1; `finish()` drains the pipeline.  No host synchronisation per batch."""
+    Every batch is packed into a slab right after its encode (HIP kernel, same stream).  `depth`
+    consecutive slabs form one bucket; a full bucket is handed to an exchange stream of its own:
+    ONE all_gather_into_tensor of world x depth equal slabs (RCCL over xGMI) and ONE unpack launch
+    that rebuilds the global CSR of each of the bucket's batches on every rank.  Two bucket sets
+    alternate, so the exchange of one bucket overlaps the encodes of the next and no cross-stream
+    wait sits between two encodes.  Fewer, larger collectives on purpose: xGMI rings are per-link
+    bound and a collective costs tens of microseconds of launch work, as much as encoding a whole
+    1 MB batch.  `finish()` flushes a partial bucket and drains.  No host synchronisation per batch.
+    """
 
-    def __init__(self, tok: Tokenizer, device: torch.device, max_docs: int, max_tokens: int, group=None):
+    def __init__(self, tok: Tokenizer, device: torch.device, max_docs: int, max_tokens: int, group=None, depth: int = 8):
         import torch.distributed as dist
         self.tok, self.dev, self.group, self.dist = tok, device, group, dist
         self.world = dist.get_world_size(group)
+        self.depth = int(depth)
         self.max_docs = int(max_docs)
-        self.cap_words = int(max_tokens) + self.max_docs + 4
-        self.send = [torch.zeros(self.cap_words, dtype=torch.int32, device=device) for _ in range(2)]
-        self.recv = [torch.zeros(self.world * self.cap_words, dtype=torch.int32, device=device) for _ in range(2)]
-        self.all_ids = torch.zeros(self.world * int(max_tokens), dtype=torch.int32, device=device)
-        self.all_off = torch.zeros(self.world * self.max_docs + 1, dtype=torch.int64, device=device)
+        self.max_tokens = int(max_tokens)
+        self.cap_words = self.max_tokens + self.max_docs + 4
+        self.off_stride = self.world * self.max_docs + 1
+        self.send = [torch.zeros(self.depth * self.cap_words, dtype=torch.int32, device=device) for _ in range(2)]
+        self.recv = [torch.zeros(self.world * self.depth * self.cap_words, dtype=torch.int32, device=device)
+                     for _ in range(2)]
+        # global CSR of each batch of the last exchanged bucket
+        self.all_ids = torch.zeros(self.depth * self.world * self.max_tokens, dtype=torch.int32, device=device)
+        self.all_off = torch.zeros(self.depth * self.off_stride, dtype=torch.int64, device=device)
         self.status = torch.zeros(1, dtype=torch.int32, device=device)
-        self.pending = None       # (work, slot)
-        self.slot = 0
-
-    def _unpack(self, slot: int) -> None:
-        L = _ffi.lib()
-        stream = torch.cuda.current_stream(self.dev).cuda_stream
-        rc = L.spl_gatherv_unpack(self.tok.handle, self.recv[slot].data_ptr(), self.world, self.cap_words, self.max_docs,
-                                  self.all_ids.data_ptr(), self.all_ids.numel(), self.all_off.data_ptr(),
-                                  self.status.data_ptr(), stream)
-        if rc != 0:
-            raise RuntimeError(_ffi.last_error())
+        self.exch = torch.cuda.Stream(device=device)
+        self.packed = [torch.cuda.Event() for _ in range(2)]      # the bucket in set s is fully packed
+        self.drained = [torch.cuda.Event() for _ in range(2)]     # the exchange of the bucket in set s is through
+        self.in_flight = [False, False]
+        self.cur, self.fill = 0, 0
+        self.last_n = 0
 
     def submit(self, batch: "DeviceBatch") -> None:
-        """Queue the exchange of `batch`'s current result; completes the previous one first."""
+        """Pack `batch`'s current result into the open bucket (call right after encode_device on the
+        same stream); a full bucket goes out."""
         L = _ffi.lib()
-        stream = torch.cuda.current_stream(self.dev).cuda_stream
-        slot = self.slot
+        main = torch.cuda.current_stream(self.dev)
+        s = self.cur
+        if self.fill == 0 and self.in_flight[s]:
+            main.wait_event(self.drained[s])      # the set's previous exchange: normally long through
+            self.in_flight[s] = False
+        slab = self.send[s][self.fill * self.cap_words:]
         rc = L.spl_gatherv_pack(self.tok.handle, batch.ids.data_ptr(), batch.out_off.data_ptr(), batch.n_docs,
-                                self.send[slot].data_ptr(), self.cap_words, self.max_docs, stream)
+                                slab.data_ptr(), self.cap_words, self.max_docs, main.cuda_stream)
         if rc != 0:
             raise RuntimeError(_ffi.last_error())
-        if self.pending is not None:
-            work, pslot = self.pending
-            work.wait()                       # current stream waits for the collective of the previous batch
-            self._unpack(pslot)
-        work = self.dist.all_gather_into_tensor(self.recv[slot], self.send[slot], group=self.group, async_op=True)
-        self.pending = (work, slot)
-        self.slot ^= 1
+        self.fill += 1
+        if self.fill == self.depth:
+            self._exchange()
+
+    def _exchange(self) -> None:
+        L = _ffi.lib()
+        main = torch.cuda.current_stream(self.dev)
+        s, n = self.cur, self.fill
+        self.packed[s].record(main)
+        with torch.cuda.stream(self.exch):
+            self.exch.wait_event(self.packed[s])
+            work = self.dist.all_gather_into_tensor(self.recv[s], self.send[s], group=self.group, async_op=True)
+            work.wait()                       # the exchange stream (not the encode stream) waits for RCCL
+            rc = L.spl_gatherv_unpack_group(self.tok.handle, self.recv[s].data_ptr(), self.world, self.depth, n,
+                                            self.cap_words, self.max_docs, self.all_ids.data_ptr(),
+                                            self.world * self.max_tokens, self.all_off.data_ptr(), self.off_stride,
+                                            self.status.data_ptr(), self.exch.cuda_stream)
+            if rc != 0:
+                raise RuntimeError(_ffi.last_error())
+            self.drained[s].record(self.exch)
+        self.in_flight[s] = True
+        self.last_n = n
+        self.cur ^= 1
+        self.fill = 0
 
     def finish(self):
-        """Drain: returns (all_ids int32 view, all_off int64) of the LAST submitted batch."""
-        if self.pending is not None:
-            work, pslot = self.pending
-            work.wait()
-            self._unpack(pslot)
-            self.pending = None
-        return self.all_ids, self.all_off
+        """Flush and drain.  Returns (all_ids, all_off) of the LAST submitted batch: int32 ids (the
+        first all_off[-1] entries are valid) and int64 offsets [world * max_docs + 1]."""
+        if self.fill:
+            self._exchange()
+        main = torch.cuda.current_stream(self.dev)
+        for s in (0, 1):
+            if self.in_flight[s]:
+                main.wait_event(self.drained[s])
+                self.in_flight[s] = False
+        j = max(self.last_n - 1, 0)
+        ids = self.all_ids[j * self.world * self.max_tokens:(j + 1) * self.world * self.max_tokens]
+        off = self.all_off[j * self.off_stride:(j + 1) * self.off_stride]
+        return ids, off
 
     def overflowed(self) -> bool:
         return bool(self.status.item())

@@ -296,3 +296,51 @@ def test_gatherv_pack_unpack_two_simulated_ranks(coracle):
                          all_off.data_ptr(), status.data_ptr(), stream)
     torch.cuda.synchronize()
     assert int(status.item()) == 1
+
+
+@pytest.mark.gpu
+def test_gatherv_bucketed_unpack_two_simulated_ranks(coracle):
+    """Bucketed form: two ranks x a bucket of depth 3 holding two batches each, laid out
+    [rank][slot][slab] as one all_gather_into_tensor of whole buckets would; ONE unpack launch must
+    rebuild both batches' global CSRs."""
+    import torch
+    from splintr_amd import _ffi, corpus
+    from splintr_amd.device import DeviceBatch, encode_device, reserve
+    t = tok("cl100k_base")
+    dev = torch.device("cuda", 0)
+    L = _ffi.lib()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    # shards[rank][batch]
+    shards = [[corpus.c2(40, seed=11) + [""], corpus.c1(25, seed=12)],
+              [corpus.c4(200, seed=13), ["solo document", "", "tail"]]]
+    depth, world, nb = 3, 2, 2
+    enc = [[DeviceBatch(s, dev) for s in row] for row in shards]
+    for row in enc:
+        for bt in row:
+            reserve(t, bt.n_bytes, bt.n_docs)
+            encode_device(t, bt)
+    torch.cuda.synchronize()
+    max_docs = max(bt.n_docs for row in enc for bt in row)
+    max_tokens = max(int(bt.out_off[-1].item()) for row in enc for bt in row) + 5
+    cap = max_tokens + max_docs + 4
+    recv = torch.zeros(world * depth * cap, dtype=torch.int32, device=dev)
+    for r in range(world):
+        for j in range(nb):
+            bt = enc[r][j]
+            assert L.spl_gatherv_pack(t.handle, bt.ids.data_ptr(), bt.out_off.data_ptr(), bt.n_docs,
+                                      recv[(r * depth + j) * cap:].data_ptr(), cap, max_docs, stream) == 0
+    off_stride = world * max_docs + 1
+    all_ids = torch.zeros(depth * world * max_tokens, dtype=torch.int32, device=dev)
+    all_off = torch.zeros(depth * off_stride, dtype=torch.int64, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    assert L.spl_gatherv_unpack_group(t.handle, recv.data_ptr(), world, depth, nb, cap, max_docs, all_ids.data_ptr(),
+                                      world * max_tokens, all_off.data_ptr(), off_stride, status.data_ptr(), stream) == 0
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    for j in range(nb):
+        texts = shards[0][j] + shards[1][j]
+        o_ids, o_off = oracle_csr(coracle("cl100k_base"), texts)
+        g_off = all_off[j * off_stride:(j + 1) * off_stride]
+        g_ids = all_ids[j * world * max_tokens:(j + 1) * world * max_tokens]
+        assert np.array_equal(g_off[: len(texts) + 1].cpu().numpy().astype(np.uint64), o_off)
+        assert np.array_equal(g_ids[: int(o_off[-1])].cpu().numpy().view(np.uint32), o_ids)
