@@ -170,17 +170,26 @@ __device__ __forceinline__ void push_long(const Batch& b, uint32_t pos, uint32_t
 //     affected pairs are re-ranked by the two lanes that own them in one predicated pair-table
 //     probe, so both loads are in flight together (bpe.rs:160-166).
 // No LDS arrays, no scratch.  `byte_at(i)` supplies chunk bytes, `emit(i, id)` takes survivors.
-template <int CTRL> __device__ __forceinline__ uint32_t dpp_min_u32(uint32_t x) {
-    const uint32_t y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xF, 0xF, false);
-    return y < x ? y : x;
-}
-// all-reduce(min) inside each 16-lane row: quad xor 1, quad xor 2, half-row mirror, row mirror
+// all-reduce(min) inside each 16-lane row: quad xor 1, quad xor 2, half-row mirror, row mirror.
+// The compiler turns update_dpp + min into v_mov_b32_dpp + v_min_u32 (two instructions and a wait
+// state per step); v_min_u32_dpp does a step in one.  (s_nop 1: a VALU result needs two wait
+// states before a DPP read; hazards inside inline asm are not the compiler's business.)
 __device__ __forceinline__ uint32_t row16_min(uint32_t x) {
-    x = dpp_min_u32<0xB1>(x);     // quad_perm [1,0,3,2]
-    x = dpp_min_u32<0x4E>(x);     // quad_perm [2,3,0,1]
-    x = dpp_min_u32<0x141>(x);    // row_half_mirror
-    x = dpp_min_u32<0x140>(x);    // row_mirror
+#ifndef SPL_NO_DPP_ASM
+    asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
+                 : "+v"(x));
     return x;
+#else
+    auto step = [](uint32_t v, uint32_t y) { return y < v ? y : v; };
+    x = step(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+    x = step(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+    x = step(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xF, 0xF, false));   // row_half_mirror
+    x = step(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xF, 0xF, false));   // row_mirror
+    return x;
+#endif
 }
 
 // Alive bitmaps are arrays of 32-bit words (64-bit shifts and bit scans are multi-instruction
