@@ -482,20 +482,23 @@ __device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const Lds
         const uint32_t below = active ? alive & ((1u << mi) - 1u) : 0u;
         const int h = below ? 31 - __clz((int)below) : -1;
         const int len_r = e_r - mi, len_h = e_mi - h;
-        const bool need_far = active && ((j2 >= 0 && len_r > SUB_LMAX) || (h >= 0 && len_h > SUB_LMAX));
-        uint32_t id_j2 = 0;
-        if (__any(need_far)) id_j2 = __shfl(id, gbase + (j2 & 15));   // only long spans need neighbour ids
-        if (active) {
-            if (gl == mi) {
-                id = mn;
-                rk = j2 < 0 ? SPL_NO_RANK : len_r <= SUB_LMAX ? row[len_r - 2] : pair_rank(T, mn, id_j2);
-            } else if (gl == h) {
-                rk = len_h <= SUB_LMAX ? row[len_h - 2] : pair_rank(T, id, mn);
-            } else if (gl == j) {
-                rk = SPL_NO_RANK;
-            }
-            alive &= ~(1u << j);
+        // Branch-free update: every lane reads the one cell of its own row it could need (the owner
+        // of mi the cell of the pair (mi, j2), everybody else -- of whom only the owner of h matters
+        // -- the cell of (h, mi)); selects pick the three lanes that change.  Only spans longer than
+        // the table (rare) take the branch to the pair table.
+        const bool is_mi = gl == mi, is_h = gl == h;
+        const int len = is_mi ? len_r : len_h;
+        const bool far = active && len > SUB_LMAX && ((is_mi && j2 >= 0) || is_h);
+        const int cell = len - 2 < 0 ? 0 : len - 2 > SUB_W - 1 ? SUB_W - 1 : len - 2;
+        uint32_t nr = row[cell];
+        if (__any(far)) {
+            const uint32_t id_j2 = __shfl(id, gbase + (j2 & 15));     // only long spans need neighbour ids
+            if (far) nr = is_mi ? pair_rank(T, mn, id_j2) : pair_rank(T, id, mn);
         }
+        nr = (is_mi && j2 < 0) ? SPL_NO_RANK : nr;
+        rk = (active && (is_mi || is_h)) ? nr : (active && gl == j) ? SPL_NO_RANK : rk;
+        id = (active && is_mi) ? mn : id;
+        alive = active ? alive & ~(1u << j) : alive;
     }
     if (own && ((alive >> gl) & 1u) && id != SPL_NO_RANK) emit(gl, id);
 }
