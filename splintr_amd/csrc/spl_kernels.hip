@@ -1070,7 +1070,10 @@ void k_pretok(DeviceTables T, Batch b) {
     // ---- classify: one record per byte, one word per lane -----------------------------------------
     const int iB = (B - w0 < (int64_t)Wv) ? (int)(B - w0) : Wv;   // first index past the text
     const int iT = (B - w0 < (int64_t)(Wv + WPAD)) ? (int)(B - w0) : Wv + WPAD;   // staged text end
-    for (int wi = tid; wi < G::NW32; wi += NT) {
+    // (records past the window are all "window end": written directly, so that no wavefront runs a
+    //  second pass of the loop body for the WPAD / 4 extra words)
+    for (int wi = Wv / 4 + tid; wi < G::NW32; wi += NT) s_rec32[wi] = (uint32_t)C_WEND * 0x01010101u;
+    for (int wi = tid; wi < Wv / 4; wi += NT) {
         const int i0 = wi * 4;
         const uint32_t tw = s_txt32[wi];
         const uint32_t ts4 = i0 < Wv ? (s_ts[i0 >> 5] >> (i0 & 31)) & 0xFu : 0u;
