@@ -974,6 +974,7 @@ void k_pretok(DeviceTables T, Batch b) {
     __shared__ uint8_t s_ascii[128];
     __shared__ uint32_t s_wsum[NT / 64];
     __shared__ uint32_t s_total;
+    __shared__ uint32_t s_scnt[17];                      // counting sort of the short misses by length
     __shared__ uint32_t s_nq[4];                         // miss counts [0] (<= 16 B) [1] (17..64 B), work cursors [2] [3]
     // single-pass state
     __shared__ uint32_t s_ids[DIRECT ? Wv : 1];          // id of the token that starts at this window index
@@ -1286,6 +1287,35 @@ void k_pretok(DeviceTables T, Batch b) {
     if (DIRECT) __builtin_amdgcn_s_setprio(SPL_MERGE_PRIO);
     {
         const uint32_t m16 = s_nq[0], m64 = s_nq[1];
+        // Short misses sorted by length, longest first (counting sort into s_cpos, which is free
+        // until the tile record): the four chunks a wavefront merges in lock step then have similar
+        // lengths -- a round lasts as long as its longest chunk -- and the longest chains start first.
+        constexpr bool SORT_SHORT = Wv <= 1024;            // window index (10 bits) | n - 1 (4 bits) in 16 bits
+        if (SORT_SHORT) {
+            if (tid < 17) s_scnt[tid] = 0;
+            __syncthreads();
+            uint32_t my_item[(G::C16 + NT - 1) / NT], my_r[(G::C16 + NT - 1) / NT];
+#pragma unroll
+            for (int q = 0; q < (G::C16 + NT - 1) / NT; q++) {
+                const uint32_t k = tid + q * NT;
+                if (k < m16) { my_item[q] = s_miss[k]; my_r[q] = atomicAdd(&s_scnt[16 - (my_item[q] >> 16)], 1u); }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t acc = 0;
+                for (int k = 0; k < 17; k++) { const uint32_t c = s_scnt[k]; s_scnt[k] = acc; acc += c; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < (G::C16 + NT - 1) / NT; q++) {
+                const uint32_t k = tid + q * NT;
+                if (k < m16) {
+                    const uint32_t n = my_item[q] >> 16;
+                    s_cpos[s_scnt[16 - n] + my_r[q]] = (uint16_t)((my_item[q] & 0x3FFu) | ((n - 1) << 10));
+                }
+            }
+            __syncthreads();
+        }
         uint32_t* const stage_w0 = b.stage + w0;          // window index -> global position
         auto put = [&](int q, uint32_t id) {
             if (DIRECT) s_ids[q] = id;
@@ -1342,7 +1372,11 @@ void k_pretok(DeviceTables T, Batch b) {
             it = __shfl(it, lane & ~15);
             const bool has = it < m16;
             if (!__any(has)) break;
-            const uint32_t item = has ? s_miss[it] : 0u;
+            uint32_t item = 0;
+            if (has) {
+                if (SORT_SHORT) { const uint32_t c = s_cpos[it]; item = (c & 0x3FFu) | (((c >> 10) + 1u) << 16); }
+                else item = s_miss[it];
+            }
             const int p = (int)(item & 0xFFFFu);
             bpe_group16_tab(T, LdsAcc{s_rec, s_txt}, p, has ? (int)(item >> 16) : 0, s_sub[tid >> 4],
                             [&](int i, uint32_t id) {
