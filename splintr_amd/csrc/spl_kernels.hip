@@ -35,7 +35,10 @@ constexpr int RANK_BLK = 1024;           // positions per rank block (32 bitmap 
 #define SPL_TILE_SMALL 768, 224          /* window 1024 B: one 4-byte word per lane */
 #endif
 #define SPL_TILE_LARGE 4096, 480         /* window 4608 B */
-constexpr uint64_t SPL_DIRECT_MAX_BYTES = 8ull << 20;   // batches up to this size: small tiles, single pass
+#ifndef SPL_DIRECT_MAX_MB
+#define SPL_DIRECT_MAX_MB 8
+#endif
+constexpr uint64_t SPL_DIRECT_MAX_BYTES = (uint64_t)SPL_DIRECT_MAX_MB << 20;   // batches up to this size: small tiles, tile-owned mode
 
 // What a tile of the tile-owned mode leaves behind for k_tile_out.
 struct TileDesc {
