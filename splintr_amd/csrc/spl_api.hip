@@ -205,6 +205,7 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
     //  sequence: back-to-back launches overlap their dispatch with the previous kernel, while
     //  single-workgroup tails and agent-scope fences sit on the critical path.)
     // Single pass: small batches without special tokens are finished by ONE kernel.
+    bool fused_scan_used = false;
     const bool direct = small_tiles && !special && t->force_tile != 3 && n_bytes <= SPL_DIRECT_MAX_BYTES;
     if (direct) {
         if (t->bitmap_dirty) {
@@ -245,6 +246,7 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
     if (ntiles) hipLaunchKernelGGL(k_bpe_long, dim3(std::min<uint32_t>(2048, ntiles / 4 + 8)), dim3(NT), 0, s, t->dt, b);
     MARK(KI_COUNT);
     const bool fused_scan = b.n_blk <= 8192;
+    fused_scan_used = fused_scan;
     if (!fused_scan) hipLaunchKernelGGL(k_count, dim3((b.n_blk + 255) / 256), dim3(256), 0, s, b);
     MARK(KI_SCAN);
     if (fused_scan) hipLaunchKernelGGL(k_scan<true>, dim3(1), dim3(1024), 0, s, b);
@@ -267,6 +269,11 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
     if (pf) {
         HIP_TRY(hipEventSynchronize(t->ev[KI_N]));
         for (int i = 0; i < KI_N; i++) {
+            // slots whose kernels were not launched in this mode would only show the event overhead
+            const bool launched = direct ? (i == KI_PRETOK || i == KI_COMPACT)
+                                         : !((i == KI_SPECIAL && !special) || (i == KI_BPELANES && small_tiles) ||
+                                             (i == KI_COUNT && fused_scan_used));
+            if (!launched) continue;
             float ms = 0;
             HIP_TRY(hipEventElapsedTime(&ms, t->ev[i], t->ev[i + 1]));
             if (i == KI_PRETOK && ntiles) {
