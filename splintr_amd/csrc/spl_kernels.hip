@@ -895,6 +895,118 @@ __device__ __forceinline__ void bpe_block_global(const DeviceTables& T, const Ba
     __syncthreads();
 }
 
+// Longer chunks (up to 64 * NPL bytes) by ONE wavefront with tabulated pair ranks: node i lives in
+// lane i % 64, slot i / 64, and row i of the wavefront's LDS table holds the ids of
+// text[i, i+len), len = 2..8 (see bpe_group16_tab).  The alive bitmap is wave-uniform (scalar
+// registers); a merge costs one min-reduction and LDS reads of the two affected rows -- no memory
+// round trip unless a merged token is longer than 8 bytes.  `word_at(q)` returns the 4 text bytes
+// at chunk offset q (little endian; bytes past the chunk may be anything).  `sub` holds 64 * NPL
+// rows of SUB_W words followed by 64 * NPL words for the initial ids.
+// The table is filled ONE probe per pass of a plain loop over (slot, length): any batching of the
+// probe code inside a loop makes the register allocator need 150-220 VGPRs.
+template <int NW> __device__ __forceinline__ int next_set64(const unsigned long long (&a)[NW], int from) {
+    int res = -1;                                     // lowest set bit with index >= from
+#pragma unroll
+    for (int w = NW - 1; w >= 0; w--) {
+        unsigned long long x = a[w];
+        const int lo = from - 64 * w;
+        if (lo >= 64) x = 0;
+        else if (lo > 0) x &= ~((1ull << lo) - 1ull);
+        if (x) res = 64 * w + __builtin_ctzll(x);
+    }
+    return res;
+}
+template <int NW> __device__ __forceinline__ int prev_set64(const unsigned long long (&a)[NW], int before) {
+    int res = -1;                                     // highest set bit with index < before
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        unsigned long long x = a[w];
+        const int hi = before - 64 * w;
+        if (hi <= 0) x = 0;
+        else if (hi < 64) x &= (1ull << hi) - 1ull;
+        if (x) res = 64 * w + 63 - __builtin_clzll(x);
+    }
+    return res;
+}
+template <int NPL, class WordAt, class Emit>
+__device__ __forceinline__ void bpe_wave_tab(const DeviceTables& T, int n, uint32_t* sub, WordAt word_at, Emit emit) {
+    const int lane = threadIdx.x & 63;
+    const int slots = (n + 63) >> 6;
+#pragma nounroll
+    for (int job = 0; job < slots * SUB_W; job++) {
+        const int k = job / SUB_W, len = 2 + job % SUB_W;
+        const int i = lane + 64 * k;
+        if (i + len <= n) {
+            const uint32_t k0 = mask_tail(word_at(i), len);
+            const uint32_t k1 = len > 4 ? mask_tail(word_at(i + 4), len - 4) : 0u;
+            sub[i * SUB_W + len - 2] = probe_short(T, k0, k1, 0u, (uint32_t)len);
+        }
+    }
+    uint32_t id[NPL], rk[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; k++) {
+        const int i = lane + 64 * k;
+        id[k] = i < n ? T.byte_id[word_at(i) & 0xFFu] : SPL_DEAD;
+        rk[k] = (i + 1 < n) ? sub[i * SUB_W] : SPL_NO_RANK;
+    }
+    unsigned long long alive[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; k++) {
+        const int c = n - 64 * k;
+        alive[k] = c >= 64 ? ~0ull : c > 0 ? (1ull << c) - 1ull : 0ull;
+    }
+    for (;;) {
+        uint32_t key = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < NPL; k++) {
+            const uint32_t c = rk[k] == SPL_NO_RANK ? 0xFFFFFFFFu : ((rk[k] << 8) | (uint32_t)(lane + 64 * k));
+            key = c < key ? c : key;
+        }
+        uint32_t m = row16_min(key);
+        const uint32_t r0 = __builtin_amdgcn_readlane(m, 0), r1 = __builtin_amdgcn_readlane(m, 16);
+        const uint32_t r2 = __builtin_amdgcn_readlane(m, 32), r3 = __builtin_amdgcn_readlane(m, 48);
+        const uint32_t a = r0 < r1 ? r0 : r1, c = r2 < r3 ? r2 : r3;
+        m = a < c ? a : c;                                  // wave-uniform
+        if (m == 0xFFFFFFFFu) break;
+        const int mi = (int)(m & 255u);
+        const uint32_t mn = m >> 8;
+        const int j = next_set64<NPL>(alive, mi + 1);
+        const int j2 = next_set64<NPL>(alive, j + 1);
+        const int j3 = j2 >= 0 ? next_set64<NPL>(alive, j2 + 1) : -1;
+        const int h = prev_set64<NPL>(alive, mi);
+        const int e_r = j3 >= 0 ? j3 : n;                   // end of the pair (mi, j2)
+        const int e_mi = j2 >= 0 ? j2 : n;                  // end of the merged node
+        const int len_r = e_r - mi, len_h = e_mi - h;
+        uint32_t id_j2 = 0;
+        if (j2 >= 0 && len_r > SUB_LMAX) {
+            uint32_t sel = id[0];
+#pragma unroll
+            for (int k = 1; k < NPL; k++) sel = (j2 >> 6) == k ? id[k] : sel;
+            id_j2 = __builtin_amdgcn_readlane(sel, j2 & 63);
+        }
+#pragma unroll
+        for (int k = 0; k < NPL; k++) {
+            const int i = lane + 64 * k;
+            if (i == mi) {
+                id[k] = mn;
+                rk[k] = j2 < 0 ? SPL_NO_RANK : len_r <= SUB_LMAX ? sub[i * SUB_W + len_r - 2] : pair_rank(T, mn, id_j2);
+            } else if (i == h) {
+                rk[k] = len_h <= SUB_LMAX ? sub[i * SUB_W + len_h - 2] : pair_rank(T, id[k], mn);
+            } else if (i == j) {
+                rk[k] = SPL_NO_RANK;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NPL; k++)
+            if ((j >> 6) == k) alive[k] &= ~(1ull << (j & 63));
+    }
+#pragma unroll
+    for (int k = 0; k < NPL; k++) {
+        const int i = lane + 64 * k;
+        if (i < n && ((alive[k] >> lane) & 1ull) && id[k] != SPL_NO_RANK) emit(i, id[k]);
+    }
+}
+
 // Tile geometry is a template parameter: small batches use small tiles (many wavefronts, 4 bytes
 // per lane, latency hidden by occupancy), large batches use 4 KiB tiles (less halo overhead).
 // Every phase maps ONE 4-byte word of the window to one lane, so LDS traffic is bank-conflict free.
@@ -948,12 +1060,11 @@ template <int TB_, int RH_> struct PretokScanLds {           // dead once the me
     uint32_t sub[NT / 16][16 * SUB_W];                   // per 16-lane group: tabulated substring ids
     uint32_t miss[G::QCAP];                              // p | n << 16, one region per size class
 };
-struct PretokTailLds {                                   // single-pass tail: one node slab per wavefront
-    uint32_t id[NT / 64][DIRECT_WAVE_NMAX];
-    uint32_t rk[NT / 64][DIRECT_WAVE_NMAX];
-    uint16_t nx[NT / 64][DIRECT_WAVE_NMAX];
-    uint16_t pv[NT / 64][DIRECT_WAVE_NMAX];
+constexpr int DIRECT_TAB_NMAX = 128;      // chunks up to this size: tabulated wavefront merge (bpe_wave_tab<2>)
+struct PretokTailLds {                                   // tile-owned tail: one slab per wavefront, used either as
+    uint32_t slab[NT / 64][DIRECT_TAB_NMAX * SUB_W];     // bpe_wave_tab's table or as bpe_wave's node arrays
 };
+static_assert(DIRECT_TAB_NMAX * SUB_W >= 3 * DIRECT_WAVE_NMAX, "a slab must hold bpe_wave's id, rank and link arrays");
 
 template <int TB_, int RH_, bool EXPORT_MEDIUM, bool DIRECT = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPL_PRETOK_WAVES)))
@@ -1419,8 +1530,24 @@ void k_pretok(DeviceTables T, Batch b) {
                 const uint32_t nl = s_dq[0] < (uint32_t)DIRECT_LQCAP ? s_dq[0] : (uint32_t)DIRECT_LQCAP;
                 for (uint32_t it = wv; it < nl; it += NT / 64) {         // one wavefront per chunk
                     const int n = (int)s_lq[2 * it + 1];
-                    if (n <= DIRECT_WAVE_NMAX)
-                        bpe_wave(T, b, s_lq[2 * it], n, s_u.t.id[wv], s_u.t.rk[wv], s_u.t.nx[wv], s_u.t.pv[wv], emit_g);
+                    const uint32_t pos = s_lq[2 * it];
+                    uint32_t* const slab = s_u.t.slab[wv];
+                    if (n <= DIRECT_TAB_NMAX) {                          // tabulated: no round trip per merge
+                        bpe_wave_tab<DIRECT_TAB_NMAX / 64>(T, n, slab,
+                            [&](int q) {
+                                const uint64_t g = (uint64_t)pos + (uint32_t)q;
+                                uint32_t w = 0;
+                                if (g + 4 <= (uint64_t)B) __builtin_memcpy(&w, b.text + g, 4);
+                                else for (int k = 0; k < 4; k++) if (g + k < (uint64_t)B) w |= (uint32_t)b.text[g + k] << (8 * k);
+                                return w;
+                            },
+                            [&](int i, uint32_t id) { emit_g(pos + (uint32_t)i, id); });
+                        wave_lds_sync();
+                    } else if (n <= DIRECT_WAVE_NMAX) {
+                        bpe_wave(T, b, pos, n, slab, slab + DIRECT_WAVE_NMAX,
+                                 reinterpret_cast<uint16_t*>(slab + 2 * DIRECT_WAVE_NMAX),
+                                 reinterpret_cast<uint16_t*>(slab + 2 * DIRECT_WAVE_NMAX) + DIRECT_WAVE_NMAX, emit_g);
+                    }
                 }
                 __syncthreads();
                 for (uint32_t it = 0; it < nl; it++) {                   // oversize: the whole workgroup
