@@ -29,7 +29,7 @@ int fail(int code, const std::string& msg) {
     } while (0)
 
 enum { KI_MARK = 0, KI_SPECIAL, KI_PRETOK, KI_DEFER, KI_BPELANES, KI_BPELONG, KI_COUNT, KI_SCAN, KI_COMPACT, KI_N };
-const char* const k_names[KI_N] = {"memset+k_mark_docs", "k_special_scan+ends", "k_pretok", "k_deferred", "k_bpe_lanes64",
+const char* const k_names[KI_N] = {"memset+k_mark_docs", "k_special_scan", "k_pretok", "k_deferred", "k_bpe_lanes64",
                                    "k_bpe_long", "k_count", "k_scan", "k_compact_docs|k_tile_out"};
 
 template <class T> int dev_upload(const std::vector<T>& v, const T** out) {
@@ -143,9 +143,12 @@ int reserve(spl_tokenizer* t, uint64_t max_bytes, uint64_t max_docs) {
 
 int upload_specials(spl_tokenizer* t) {
     if (t->sp_uploaded) return SPL_OK;
-    std::vector<uint8_t> recs(t->specials.size() * SP_REC + 16, 0);
+    // 32-byte header: the set of first bytes (256 bits); then one record per literal
+    std::vector<uint8_t> recs(SP_HDR + t->specials.size() * SP_REC + 16, 0);
     for (size_t k = 0; k < t->specials.size(); k++) {
-        uint8_t* r = recs.data() + k * SP_REC;
+        const uint8_t c0 = (uint8_t)t->specials[k].lit[0];
+        recs[c0 >> 3] |= (uint8_t)(1u << (c0 & 7));
+        uint8_t* r = recs.data() + SP_HDR + k * SP_REC;
         r[0] = (uint8_t)t->specials[k].lit.size();
         memcpy(r + 4, &t->specials[k].id, 4);
         memcpy(r + 8, t->specials[k].lit.data(), t->specials[k].lit.size());
@@ -206,18 +209,30 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
     //  single-workgroup tails and agent-scope fences sit on the critical path.)
     // Single pass: small batches without special tokens are finished by ONE kernel.
     bool fused_scan_used = false;
-    const bool direct = small_tiles && !special && t->force_tile != 3 && n_bytes <= SPL_DIRECT_MAX_BYTES;
+    const bool direct = small_tiles && t->force_tile != 3 && n_bytes <= SPL_DIRECT_MAX_BYTES;
     if (direct) {
-        if (t->bitmap_dirty) {
+        if (special) {
+            // the three bitmaps are cleared per call; documents and literals are marked by the
+            // multi-pass kernels, the tile kernel reads the bitmaps on top of its document search
+            HIP_TRY(hipMemsetAsync(t->d_zero, 0, (3 * uw + 8) * 4, s));
+            t->bitmap_dirty = true;
+        } else if (t->bitmap_dirty) {
             HIP_TRY(hipMemsetAsync(t->d_zero, 0, t->zero_words * 4, s));
             t->bitmap_dirty = false;
         }
         b.tdesc = t->d_tdesc; b.tile_ids = t->d_tile_ids; b.tctl = t->d_tctl;
         b.tgroups = t->tgroups; b.tpar = t->tpar; b.tslot = (uint32_t)TileGeom<SPL_TILE_SMALL>::Wv + 1u;
         if (ntiles) t->tpar ^= 1u;              // k_tile_out zeroes the other parity's sums for the next call
-        b.tstart = nullptr; b.qcount = nullptr;
+        if (!special) b.tstart = nullptr;
+        b.qcount = nullptr;
         t->last_qcount = nullptr;
-        MARK(KI_MARK); MARK(KI_SPECIAL); MARK(KI_PRETOK);
+        MARK(KI_MARK);
+        if (special && n_docs) hipLaunchKernelGGL(k_mark_docs, dim3((uint32_t)((n_docs + 255) / 256)), dim3(256), 0, s, b);
+        MARK(KI_SPECIAL);
+        if (special && n_bytes) {
+            hipLaunchKernelGGL(k_special_scan, dim3((uint32_t)((n_bytes + 255) / 256)), dim3(256), 0, s, b);
+        }
+        MARK(KI_PRETOK);
         if (ntiles) hipLaunchKernelGGL((k_pretok<SPL_TILE_SMALL, false, true>), dim3(ntiles), dim3(NT), 0, s, t->dt, b);
         else HIP_TRY(hipMemsetAsync(d_out_off, 0, (n_docs + 1) * 8, s));
         MARK(KI_DEFER); MARK(KI_BPELANES); MARK(KI_BPELONG); MARK(KI_COUNT); MARK(KI_SCAN); MARK(KI_COMPACT);
@@ -231,7 +246,6 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
     MARK(KI_SPECIAL);
     if (special && n_bytes) {
         hipLaunchKernelGGL(k_special_scan, dim3((uint32_t)((n_bytes + 255) / 256)), dim3(256), 0, s, b);
-        hipLaunchKernelGGL(k_special_ends, dim3((uint32_t)((n_bytes + 255) / 256)), dim3(256), 0, s, b);
     }
     MARK(KI_PRETOK);
     if (ntiles) {
@@ -270,7 +284,7 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
         HIP_TRY(hipEventSynchronize(t->ev[KI_N]));
         for (int i = 0; i < KI_N; i++) {
             // slots whose kernels were not launched in this mode would only show the event overhead
-            const bool launched = direct ? (i == KI_PRETOK || i == KI_COMPACT)
+            const bool launched = direct ? (i == KI_PRETOK || i == KI_COMPACT || (special && (i == KI_MARK || i == KI_SPECIAL)))
                                          : !((i == KI_SPECIAL && !special) || (i == KI_BPELANES && small_tiles) ||
                                              (i == KI_COUNT && fused_scan_used));
             if (!launched) continue;

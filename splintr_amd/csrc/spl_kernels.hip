@@ -98,14 +98,20 @@ __global__ void k_mark_docs(Batch b) {
 //   * is masked out of the text (skip bits; its first byte reads as end-of-text from the left),
 //   * makes the byte after it a text start.
 // Record layout (SP_REC = 40 bytes): u8 len | u8[3] pad | u32 id | u8 bytes[32].
+// The buffer starts with a 32-byte header: the set of the literals' first bytes, so that all but the
+// candidate positions leave after one bit test.  The byte after a match starts a text: its bit is
+// set right here (if another literal starts there its skip bit wins in every reader, and occurrences
+// never overlap, so that bit can never fall strictly inside a literal someone else is checking).
 constexpr int SP_REC = 40;
+constexpr int SP_HDR = 32;
 constexpr int SP_MAXLEN = 32;
 __global__ void k_special_scan(Batch b) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= b.n_bytes) return;
     const uint32_t c0 = b.text[p];
+    if (!((reinterpret_cast<const uint32_t*>(b.sp_lits)[c0 >> 5] >> (c0 & 31)) & 1u)) return;
     for (uint32_t k = 0; k < b.n_special; k++) {
-        const uint8_t* rec = b.sp_lits + (size_t)k * SP_REC;
+        const uint8_t* rec = b.sp_lits + SP_HDR + (size_t)k * SP_REC;
         if (rec[8] != c0) continue;
         const uint32_t len = rec[0];
         if (p + len > b.n_bytes) continue;
@@ -119,16 +125,9 @@ __global__ void k_special_scan(Batch b) {
         b.stage[p] = id;
         atomicOr(&b.tbits[p >> 5], 1u << (p & 31));
         for (uint32_t i = 0; i < len; i++) atomicOr(&b.skip[(p + i) >> 5], 1u << ((p + i) & 31));
+        if (p + len < b.n_bytes) atomicOr(&b.tstart[(p + len) >> 5], 1u << ((p + len) & 31));
         return;
     }
-}
-// second pass (after every skip bit is in place): the byte after a literal starts a text
-__global__ void k_special_ends(Batch b) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p == 0 || p >= b.n_bytes) return;
-    const bool prev_skip = (b.skip[(p - 1) >> 5] >> ((p - 1) & 31)) & 1u;
-    const bool this_skip = (b.skip[p >> 5] >> (p & 31)) & 1u;
-    if (prev_skip && !this_skip) atomicOr(&b.tstart[p >> 5], 1u << (p & 31));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -673,6 +672,7 @@ struct DirectAcc {
         const int64_t q = (uint32_t)qi;
         const int64_t B = b->n_bytes;
         if (q >= B) return C_EOT | CB_TSTART | CB_SYNC;
+        if (b->skip && ((b->skip[q >> 5] >> (q & 31)) & 1u)) return C_EOT | CB_TSTART;          // inside a special literal
         const uint32_t c0 = b->text[q];
         uint32_t r;
         if (c0 < 0x80u) r = cp_class(*T, c0);
@@ -684,6 +684,7 @@ struct DirectAcc {
             r = cls | ((len - 1) << CB_LEN_SHIFT);
         }
         if ((uint32_t)q == next_ts) r |= CB_TSTART | CB_SYNC;
+        if (b->tstart && ((b->tstart[q >> 5] >> (q & 31)) & 1u)) r |= CB_TSTART | CB_SYNC;    // behind a special literal
         return r;
     }
 };
@@ -1141,8 +1142,10 @@ void k_pretok(DeviceTables T, Batch b) {
     if (tid < G::NBW + 1) {
         const int64_t wi = (w0 >> 5) + tid;           // w0 is a multiple of 32
         const bool in = wi >= 0 && wi * 32 < B;
-        s_ts[tid] = (in && !DIRECT) ? b.tstart[wi] : 0u;
-        s_sk[tid] = (in && b.skip && !DIRECT) ? b.skip[wi] : 0u;
+        // (tile-owned mode has these bitmaps only for SPL_WITH_SPECIAL: document starts come from
+        //  the search below, the bitmap adds the text starts behind special literals)
+        s_ts[tid] = (in && (!DIRECT || b.tstart)) ? b.tstart[wi] : 0u;
+        s_sk[tid] = (in && b.skip) ? b.skip[wi] : 0u;
         s_cbits[tid] = 0;
         s_tbits[tid] = 0;
     }
@@ -1601,6 +1604,27 @@ void k_pretok(DeviceTables T, Batch b) {
                 const uint32_t nd = s_dq[1] < 2u ? s_dq[1] : 2u;
                 if (s_dq[0] == 0 && s_dq[6] >= nd) break;
             }
+        }
+        // SPL_WITH_SPECIAL: the literals that start in this tile are tokens of this tile (k_special_scan
+        // left their ids in stage[] and marked their first bytes in tbits[], inside the skip spans)
+        if (b.skip) {
+            if (tid < G::NBW + 1) {
+                const int64_t wi = (w0 >> 5) + tid;
+                uint32_t sp = (wi >= 0 && wi * 32 < B) ? (b.tbits[wi] & s_sk[tid]) : 0u;
+                const int lo = LH - tid * 32, hi = LH + TB_ - tid * 32;     // the tile's own range inside this word
+                if (hi <= 0 || lo >= 32) sp = 0;
+                else {
+                    if (lo > 0) sp &= ~0u << lo;
+                    if (hi < 32) sp &= (1u << hi) - 1u;
+                }
+                if (sp) atomicOr(&s_tbits[tid], sp);
+                while (sp) {
+                    const int bit = __ffs(sp) - 1;
+                    sp &= sp - 1;
+                    s_ids[tid * 32 + bit] = b.stage[w0 + tid * 32 + bit];
+                }
+            }
+            __syncthreads();
         }
         // the first NT documents of the window are fetched now, so that after the look-back only
         // stores are left on the critical path of the last tiles
