@@ -74,9 +74,12 @@ def main():
     gv = None
 
     def step():
-        encode_device(tok, batch)
-        if gv is not None:
-            gv.submit(batch)          # pack; every 8th batch: one RCCL all-gather of the bucket + unpack, on its own stream
+        if gv is None:
+            encode_device(tok, batch)
+        else:
+            # encode with the slab written by the encoder's last kernel; every 8th batch: one RCCL
+            # all-gather of the bucket + one unpack launch, on a stream of their own
+            gv.encode_and_submit(batch)
 
     # ---- untimed verification pass: bit-exact vs the oracle on this very batch -----------------
     step()

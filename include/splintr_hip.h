@@ -108,6 +108,14 @@ int spl_gatherv_pack(spl_tokenizer* t, const uint32_t* d_ids, const uint64_t* d_
 int spl_gatherv_unpack(spl_tokenizer* t, const uint32_t* d_slabs, uint32_t world, uint64_t cap_words,
                        uint64_t max_docs, uint32_t* d_all_ids, uint64_t all_ids_cap, uint64_t* d_all_off,
                        uint32_t* d_status, void* hip_stream);
+/* spl_encode_batch_device that ALSO leaves the result in slab form (the layout spl_gatherv_pack
+ * makes) in d_slab[cap_words]: in tile-owned mode the last kernel writes both copies in one pass,
+ * so the per-batch pack launch of a multi-GPU pipeline goes away; otherwise the pack kernel is
+ * queued behind the encode. */
+int spl_encode_batch_device_packed(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
+                                   uint64_t n_docs, uint32_t flags, uint32_t* d_ids, uint64_t ids_capacity,
+                                   uint64_t* d_out_off, uint32_t* d_slab, uint64_t cap_words, uint64_t max_docs,
+                                   void* hip_stream);
 /* Bucketed form (fewer, larger collectives: xGMI rings are per-link bound and a collective has a
  * fixed launch cost): every rank packs up to `depth` consecutive batches into `depth` slabs laid
  * back to back, ONE all-gather moves world x depth slabs, and one launch unpacks the first

@@ -23,7 +23,7 @@ SYMBOLS = [
     "spl_reserve", "spl_encode_batch", "spl_result_tokens", "spl_result_offsets", "spl_result_n_tokens",
     "spl_result_n_docs", "spl_result_free", "spl_encode_batch_device", "spl_decode_batch", "spl_free",
     "spl_profile_enable", "spl_profile_reset", "spl_profile_read", "spl_kernel_name", "spl_last_queue_counts",
-    "spl_debug_phases", "spl_debug_blocks", "spl_gatherv_pack", "spl_gatherv_unpack", "spl_gatherv_unpack_group",
+    "spl_debug_phases", "spl_debug_blocks", "spl_gatherv_pack", "spl_gatherv_unpack", "spl_gatherv_unpack_group", "spl_encode_batch_device_packed",
 ]
 
 
@@ -82,6 +82,8 @@ def lib() -> ctypes.CDLL:
     L.spl_gatherv_pack.argtypes = [vp, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, ctypes.c_uint64, vp]
     L.spl_gatherv_unpack.argtypes = [vp, vp, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64, vp, ctypes.c_uint64, vp,
                                      vp, vp]
+    L.spl_encode_batch_device_packed.argtypes = [vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, ctypes.c_uint32, vp,
+                                                 ctypes.c_uint64, vp, vp, ctypes.c_uint64, ctypes.c_uint64, vp]
     L.spl_gatherv_unpack_group.argtypes = [vp, vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64,
                                            ctypes.c_uint64, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp]
     _lib = L

@@ -162,8 +162,11 @@ int upload_specials(spl_tokenizer* t) {
     return SPL_OK;
 }
 
+struct SlabOut { uint32_t* d_slab = nullptr; uint64_t cap_words = 0, max_docs = 0; };
+
 int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off, uint64_t n_docs,
-               uint32_t flags, uint32_t* d_ids, uint64_t ids_cap, uint64_t* d_out_off, hipStream_t s) {
+               uint32_t flags, uint32_t* d_ids, uint64_t ids_cap, uint64_t* d_out_off, hipStream_t s,
+               const SlabOut* so = nullptr) {
     if (((uintptr_t)d_utf8 & 15) != 0) return fail(SPL_EINVAL, "text buffer must be 16-byte aligned");
     const bool special = (flags & SPL_WITH_SPECIAL) && !t->specials.empty();
     if (special) { int rc0 = upload_specials(t); if (rc0) return rc0; }
@@ -222,6 +225,7 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
         }
         b.tdesc = t->d_tdesc; b.tile_ids = t->d_tile_ids; b.tctl = t->d_tctl;
         b.tgroups = t->tgroups; b.tpar = t->tpar; b.tslot = (uint32_t)TileGeom<SPL_TILE_SMALL>::Wv + 1u;
+        if (so && ntiles) { b.slab = so->d_slab; b.slab_cap = (uint32_t)so->cap_words; b.slab_max_docs = (uint32_t)so->max_docs; }
         if (ntiles) t->tpar ^= 1u;              // k_tile_out zeroes the other parity's sums for the next call
         if (!special) b.tstart = nullptr;
         b.qcount = nullptr;
@@ -280,6 +284,9 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
             return fail(SPL_EDEVICE, std::string("kernel launch: ") + hipGetErrorString(le));
         }
     }
+    if (so && !(direct && ntiles))          // the slab copy of the result, where k_tile_out did not write it
+        hipLaunchKernelGGL(k_gatherv_pack, dim3(256), dim3(256), 0, s, d_ids, d_out_off, (uint32_t)n_docs, so->d_slab,
+                           (uint32_t)so->cap_words, (uint32_t)so->max_docs);
     if (pf) {
         HIP_TRY(hipEventSynchronize(t->ev[KI_N]));
         for (int i = 0; i < KI_N; i++) {
@@ -414,6 +421,19 @@ int spl_encode_batch_device(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_
         return fail(SPL_EINVAL, "spl_encode_batch_device: null argument");
     HIP_TRY(hipSetDevice(t->device));
     return launch_all(t, d_utf8, n_bytes, d_doc_off, n_docs, flags, d_ids, ids_capacity, d_out_off, (hipStream_t)hip_stream);
+}
+
+int spl_encode_batch_device_packed(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
+                                   uint64_t n_docs, uint32_t flags, uint32_t* d_ids, uint64_t ids_capacity,
+                                   uint64_t* d_out_off, uint32_t* d_slab, uint64_t cap_words, uint64_t max_docs,
+                                   void* hip_stream) {
+    if (!t || !d_doc_off || !d_out_off || !d_slab || (n_bytes && (!d_utf8 || !d_ids)))
+        return fail(SPL_EINVAL, "spl_encode_batch_device_packed: null argument");
+    if (cap_words < max_docs + 4 || n_docs > max_docs) return fail(SPL_EINVAL, "spl_encode_batch_device_packed: slab too small");
+    HIP_TRY(hipSetDevice(t->device));
+    SlabOut so;
+    so.d_slab = d_slab; so.cap_words = cap_words; so.max_docs = max_docs;
+    return launch_all(t, d_utf8, n_bytes, d_doc_off, n_docs, flags, d_ids, ids_capacity, d_out_off, (hipStream_t)hip_stream, &so);
 }
 
 int spl_encode_batch(spl_tokenizer* t, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,

@@ -78,6 +78,9 @@ struct Batch {
     uint32_t* tctl;            // [0] packing cursor; [16 + par * tgroups ...] token sums per 64 tiles, two parities
     uint32_t tgroups;          // capacity of one parity's group-sum array
     uint32_t tslot;            // words per tile in tile_ids[] (window size + 1)
+    // optional second copy of the result, laid out as a ragged all-gather slab (k_gatherv_pack's
+    // format): k_tile_out writes it in the same pass, the separate pack launch goes away
+    uint32_t* slab; uint32_t slab_cap, slab_max_docs;
     uint32_t tpar;             // parity of this call
 };
 
@@ -1760,11 +1763,22 @@ __global__ __launch_bounds__(NT) void k_tile_out(Batch b) {
     __syncthreads();
     unsigned long long base = 0;
     for (int k = 0; k < NT / 64; k++) base += s_part[k];
+    const uint32_t s_ids_at = 3 + b.slab_max_docs, s_ids_cap = b.slab ? b.slab_cap - s_ids_at : 0u;
     for (uint32_t k = tid; k < td.c_win; k += NT) {
         const unsigned long long r = base + k;
-        if (r < b.ids_cap) b.ids_out[r] = k < (uint32_t)NT ? first_id : b.tile_ids[td.slot + k];
+        const uint32_t id = k < (uint32_t)NT ? first_id : b.tile_ids[td.slot + k];
+        if (r < b.ids_cap) b.ids_out[r] = id;
+        if (r < s_ids_cap) b.slab[s_ids_at + r] = id;
     }
-    for (uint32_t k = tid; k < td.d_cnt; k += NT) b.off_out[td.d_first + k] += base;
+    for (uint32_t k = tid; k < td.d_cnt; k += NT) {
+        const unsigned long long v = b.off_out[td.d_first + k] + base;
+        b.off_out[td.d_first + k] = v;
+        if (b.slab && td.d_first + k <= b.slab_max_docs) b.slab[2 + td.d_first + k] = (uint32_t)v;
+    }
+    if (b.slab && t == gridDim.x - 1 && tid == 0) {        // header: T (the last tile ends the corpus), N
+        b.slab[0] = (uint32_t)(base + td.c_win + td.c_ovf);
+        b.slab[1] = b.n_docs;
+    }
     if (td.ovf_hi > td.ovf_lo) {                             // rare: tokens that start beyond the window
         const uint32_t wlo = td.ovf_lo >> 5, whi = (td.ovf_hi + 31) >> 5;
         unsigned long long running = base + td.c_win;
@@ -1789,6 +1803,7 @@ __global__ __launch_bounds__(NT) void k_tile_out(Batch b) {
                 const int bit = __ffs(word) - 1;
                 word &= word - 1;
                 if (r < b.ids_cap) b.ids_out[r] = b.stage[w * 32 + bit];
+                if (r < s_ids_cap) b.slab[s_ids_at + r] = b.stage[w * 32 + bit];
                 r++;
             }
             running += all;

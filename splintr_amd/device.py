@@ -89,23 +89,42 @@ class GatherV:
         self.cur, self.fill = 0, 0
         self.last_n = 0
 
-    def submit(self, batch: "DeviceBatch") -> None:
-        """Pack `batch`'s current result into the open bucket (call right after encode_device on the
-        same stream); a full bucket goes out."""
-        L = _ffi.lib()
+    def _open_slab(self) -> torch.Tensor:
         main = torch.cuda.current_stream(self.dev)
         s = self.cur
         if self.fill == 0 and self.in_flight[s]:
             main.wait_event(self.drained[s])      # the set's previous exchange: normally long through
             self.in_flight[s] = False
-        slab = self.send[s][self.fill * self.cap_words:]
-        rc = L.spl_gatherv_pack(self.tok.handle, batch.ids.data_ptr(), batch.out_off.data_ptr(), batch.n_docs,
-                                slab.data_ptr(), self.cap_words, self.max_docs, main.cuda_stream)
-        if rc != 0:
-            raise RuntimeError(_ffi.last_error())
+        return self.send[s][self.fill * self.cap_words:]
+
+    def _close_slab(self) -> None:
         self.fill += 1
         if self.fill == self.depth:
             self._exchange()
+
+    def submit(self, batch: "DeviceBatch") -> None:
+        """Pack `batch`'s current result into the open bucket (call right after encode_device on the
+        same stream); a full bucket goes out."""
+        slab = self._open_slab()
+        main = torch.cuda.current_stream(self.dev)
+        rc = _ffi.lib().spl_gatherv_pack(self.tok.handle, batch.ids.data_ptr(), batch.out_off.data_ptr(), batch.n_docs,
+                                         slab.data_ptr(), self.cap_words, self.max_docs, main.cuda_stream)
+        if rc != 0:
+            raise RuntimeError(_ffi.last_error())
+        self._close_slab()
+
+    def encode_and_submit(self, batch: "DeviceBatch", with_special: bool = False) -> None:
+        """encode_device + submit in ONE call: the encoder's last kernel writes the slab itself
+        (spl_encode_batch_device_packed), no separate pack launch."""
+        slab = self._open_slab()
+        main = torch.cuda.current_stream(self.dev)
+        rc = _ffi.lib().spl_encode_batch_device_packed(
+            self.tok.handle, batch.text.data_ptr(), batch.n_bytes, batch.doc_off.data_ptr(), batch.n_docs,
+            _ffi.SPL_WITH_SPECIAL if with_special else 0, batch.ids.data_ptr(), batch.ids.numel(),
+            batch.out_off.data_ptr(), slab.data_ptr(), self.cap_words, self.max_docs, main.cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"spl_encode_batch_device_packed failed ({rc}): {_ffi.last_error()}")
+        self._close_slab()
 
     def _exchange(self) -> None:
         L = _ffi.lib()

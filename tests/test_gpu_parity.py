@@ -344,3 +344,44 @@ def test_gatherv_bucketed_unpack_two_simulated_ranks(coracle):
         g_ids = all_ids[j * world * max_tokens:(j + 1) * world * max_tokens]
         assert np.array_equal(g_off[: len(texts) + 1].cpu().numpy().astype(np.uint64), o_off)
         assert np.array_equal(g_ids[: int(o_off[-1])].cpu().numpy().view(np.uint32), o_ids)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom", [0, 2])
+def test_encode_packed_slab_equals_pack_kernel(geom):
+    """spl_encode_batch_device_packed must leave the same slab as encode + spl_gatherv_pack, in
+    tile-owned mode (the last kernel writes it) and in multi-pass mode (pack kernel queued)."""
+    import torch
+    from splintr_amd import _ffi, corpus
+    from splintr_amd.device import DeviceBatch, encode_device, reserve
+    t = tok("cl100k_base")
+    dev = torch.device("cuda", 0)
+    L = _ffi.lib()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    texts = corpus.c2(120, seed=21) + ["", "a" * 3000, " " * 1500 + "x", ""] + corpus.c4(200, seed=22)
+    bt = DeviceBatch(texts, dev)
+    reserve(t, bt.n_bytes, bt.n_docs)
+    _force_tiles("cl100k_base", geom)
+    try:
+        encode_device(t, bt)
+        torch.cuda.synchronize()
+        T = int(bt.out_off[-1].item())
+        max_docs, cap = bt.n_docs + 3, T + bt.n_docs + 3 + 4 + 11
+        ref = torch.zeros(cap, dtype=torch.int32, device=dev)
+        assert L.spl_gatherv_pack(t.handle, bt.ids.data_ptr(), bt.out_off.data_ptr(), bt.n_docs, ref.data_ptr(), cap,
+                                  max_docs, stream) == 0
+        got = torch.zeros(cap, dtype=torch.int32, device=dev)
+        ids2 = torch.zeros_like(bt.ids)
+        off2 = torch.zeros_like(bt.out_off)
+        assert L.spl_encode_batch_device_packed(t.handle, bt.text.data_ptr(), bt.n_bytes, bt.doc_off.data_ptr(), bt.n_docs,
+                                                0, ids2.data_ptr(), ids2.numel(), off2.data_ptr(), got.data_ptr(), cap,
+                                                max_docs, stream) == 0
+        torch.cuda.synchronize()
+    finally:
+        _force_tiles("cl100k_base", 0)
+    assert torch.equal(off2, bt.out_off) and torch.equal(ids2[:T], bt.ids[:T])
+    used = 3 + max_docs + T
+    r, g = ref[:used].cpu().numpy(), got[:used].cpu().numpy()
+    # offsets beyond n_docs + 1 are unspecified padding in both
+    assert np.array_equal(r[: 2 + bt.n_docs + 1], g[: 2 + bt.n_docs + 1])
+    assert np.array_equal(r[3 + max_docs:], g[3 + max_docs:])
