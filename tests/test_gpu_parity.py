@@ -385,3 +385,14 @@ def test_encode_packed_slab_equals_pack_kernel(geom):
     # offsets beyond n_docs + 1 are unspecified padding in both
     assert np.array_equal(r[: 2 + bt.n_docs + 1], g[: 2 + bt.n_docs + 1])
     assert np.array_equal(r[3 + max_docs:], g[3 + max_docs:])
+
+
+@pytest.mark.gpu
+def test_more_than_65536_documents_in_tile_owned_mode(coracle):
+    """The tile kernel finds its first document by a 256-ary search of doc_off: more than 65 536
+    documents need a third round; runs of empty documents share an offset."""
+    rng = random.Random(17)
+    words = ["alpha", " beta", "gamma,", " 12345", "δέλτα", " don't", "x", "", "", "\n\n", "  indent", "世界"]
+    texts = [rng.choice(words) + (rng.choice(words) if rng.random() < 0.5 else "") for _ in range(140000)]
+    assert_batch_equal("cl100k_base", texts, coracle)
+    assert_batch_equal("o200k_base", texts[:70000], coracle)
