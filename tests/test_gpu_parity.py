@@ -396,3 +396,14 @@ def test_more_than_65536_documents_in_tile_owned_mode(coracle):
     texts = [rng.choice(words) + (rng.choice(words) if rng.random() < 0.5 else "") for _ in range(140000)]
     assert_batch_equal("cl100k_base", texts, coracle)
     assert_batch_equal("o200k_base", texts[:70000], coracle)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["o200k_base", "deepseek_v3"])
+def test_seven_megabytes_mixed_in_tile_owned_mode(coracle, name):
+    """Just under the tile-owned limit (8 MB): several rounds of tiles, CJK-dense tiles with many long
+    chunks next to prose and JSON."""
+    from splintr_amd import corpus
+    texts = corpus.c3(1800, seed=77)
+    assert sum(len(t.encode()) for t in texts) < (8 << 20)
+    assert_batch_equal(name, texts, coracle)
