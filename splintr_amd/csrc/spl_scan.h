@@ -203,6 +203,12 @@ template <class A> SPL_HD int match_end(const A& a, int p, int pattern) {
 // checked against PCRE2 in tests/test_hostsim.py.)
 SPL_HD bool is_sync(int pattern, uint32_t prev, uint32_t cur) {
     const uint32_t pb = SPL_BIT(prev), cb = SPL_BIT(cur);
+    // (f) a number after anything but a number: no alternative has a digit behind a non-digit
+    //     inside one match (only \p{N}{1,3} consumes digits, and it starts with one)
+    if (cur == C_N && prev < C_EOT) return prev != C_N;
+    // (g) cl100k: "other" after a newline -- every match that consumes a newline ends with its
+    //     newline run (o200k's [\r\n/]* may go on with '/', so not there)
+    if (pattern == PAT_CL100K && prev == C_NL && (cb & M_OTHER)) return true;
     if (pb & M_L)
         return pattern == PAT_CL100K ? !(cb & M_L) : !(cb & (M_L | SPL_BIT(C_M) | SPL_BIT(C_AP)));
     if (prev == C_N) return cur != C_N;

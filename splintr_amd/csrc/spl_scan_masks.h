@@ -190,9 +190,9 @@ SPL_HD uint32_t sync_word(int pattern, const uint32_t (&kw)[MK_COUNT], const uin
     const uint32_t pL = prev(MK_L), pN = prev(MK_N), pNL = prev(MK_NL), pO = prev(MK_O), pM = prev(MK_M);
     uint32_t sy;
     if (pattern == PAT_CL100K) {
-        sy = (pL & ~L) | (pN & ~N) | (pNL & (L | N)) | (pO & (S & ~NL));
+        sy = (pL & ~L) | (pN & ~N) | (pNL & (L | N)) | (pO & (S & ~NL)) | (N & ~pN) | (pNL & kw[MK_O]);
     } else {
-        sy = (pL & ~(L | kw[MK_M] | kw[MK_AP])) | (pN & ~N) | (pNL & (L | N)) | ((pO & ~pM) & (S & ~NL));
+        sy = (pL & ~(L | kw[MK_M] | kw[MK_AP])) | (pN & ~N) | (pNL & (L | N)) | ((pO & ~pM) & (S & ~NL)) | (N & ~pN);
     }
     // only real character starts can be sync points; a text start always is one
     const uint32_t real = kw[MK_CS];
