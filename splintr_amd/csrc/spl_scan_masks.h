@@ -130,17 +130,42 @@ template <class MA> SPL_HD int match_end_cl100k_m(const MA& m, int p) {
         const int e = contraction(m, p);
         if (e != 0) return e;
     }
-    if (SPL_BIT(c) & M_L) {
-        const int e = run_end_m(m, MK_L, q1);
+    // The lanes of a wavefront take different alternatives.  Letters, "other" runs and whitespace
+    // all begin with ONE run search that differs only in the mask and the start, so that search is
+    // shared (one inlined loop for every lane) and only the short tails stay divergent.
+    const uint32_t cb = SPL_BIT(c), c1b = SPL_BIT(c1);
+    const bool letters = (cb & M_L) || ((cb & M_X) && (c1b & M_L));
+    const bool other = !letters && ((cb & M_OTHER) || (c == C_SP && (c1b & M_OTHER)));
+    const bool space = !letters && !other && c != C_N;            // whitespace: maximal \s run from q1
+    if (c == C_N && !letters) {
+        if (c1 != C_N) return q1;
+        const int q2 = q1 + l1;
+        int l2;
+        const uint32_t c2 = peek_m(m, q2, l2);
+        if (c2 == C_WEND) return SPL_DEFER;
+        return c2 == C_N ? q2 + l2 : q2;
+    }
+    const int which = letters ? MK_L : other ? MK_O : MK_S;
+    const int start = letters ? ((cb & M_L) ? q1 : q1 + l1) : other ? ((cb & M_OTHER) ? q1 : q1 + l1) : q1;
+    int e = run_end_m(m, which, start);
+    if (letters) {
         SPL_RUN_OR_DEFER(e);
         return e;
     }
-    if ((SPL_BIT(c) & M_X) && (SPL_BIT(c1) & M_L)) {
-        const int e = run_end_m(m, MK_L, q1 + l1);
+    if (other) {
+        e = run_end_m(m, MK_NL, e);                      // [\r\n]* (no-op when the next char is no newline)
         SPL_RUN_OR_DEFER(e);
         return e;
     }
-    return match_tail_m(m, p, c, q1, c1, l1);
+    (void)space;
+    const int r = e;                                     // maximal \s run [p, r)
+    SPL_RUN_OR_DEFER(r);
+    const int nl = last_bit_in_m(m, MK_NL, p, r);
+    if (nl >= 0) return nl + 1;                          // \s*[\r\n]+ : through the LAST newline
+    const bool eot = r >= m.wbits() || bit_m(m, MK_TS, r);
+    if (eot) return r;                                   // \s+(?!\S) at end of text
+    const int lc = last_bit_in_m(m, MK_CS, p, r);        // start of the run's last character
+    return lc > p ? lc : r;
 }
 
 // o200k: letter bodies keep the character-wise closed form of spl_scan.h (case structure inside
