@@ -197,6 +197,18 @@ __device__ __forceinline__ uint32_t row16_min(uint32_t x) {
 #endif
 }
 
+// Inclusive prefix sum over the 64 lanes of a wavefront with DPP row shifts and row broadcasts
+// (six full-rate instructions, no LDS permutes and no per-lane address registers to keep alive).
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);    // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);    // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);    // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);    // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
 // Alive bitmaps are arrays of 32-bit words (64-bit shifts and bit scans are multi-instruction
 // and slow on the vector ALU; v_ffbl_b32 / v_ffbh_u32 / 32-bit shifts are single full-rate ops).
 template <int NW> __device__ __forceinline__ int next_set_bit(const uint32_t (&a)[NW], int from) {
@@ -1290,12 +1302,7 @@ void k_pretok(DeviceTables T, Batch b) {
             }
         }
         const uint32_t cnt = __popc(word);
-        uint32_t x = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t y = __shfl_up(x, d);
-            if ((tid & 63) >= d) x += y;
-        }
+        uint32_t x = wave_scan_incl(cnt);
         if ((tid & 63) == 63) s_wsum[tid >> 6] = x;
         __syncthreads();
         uint32_t base = x - cnt;
@@ -1351,12 +1358,7 @@ void k_pretok(DeviceTables T, Batch b) {
         uint32_t word = tid < G::NBW ? s_cbits[tid] : 0u;
         uint32_t cnt = __popc(word);
         // inclusive scan over 256 threads: wave scan + cross-wave sums
-        uint32_t x = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t y = __shfl_up(x, d);
-            if ((tid & 63) >= d) x += y;
-        }
+        uint32_t x = wave_scan_incl(cnt);
         if ((tid & 63) == 63) s_wsum[tid >> 6] = x;
         __syncthreads();
         uint32_t base = x - cnt;
@@ -1641,12 +1643,7 @@ void k_pretok(DeviceTables T, Batch b) {
         {
             uint32_t word = tid < G::NBW + 1 ? s_tbits[tid] : 0u;
             const uint32_t cnt = __popc(word);
-            uint32_t x = cnt;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t y = __shfl_up(x, d);
-                if (lane >= d) x += y;
-            }
+            uint32_t x = wave_scan_incl(cnt);
             if (lane == 63) s_wsum[wv] = x;
             __syncthreads();
             uint32_t basew = x - cnt;
@@ -1786,12 +1783,7 @@ __global__ __launch_bounds__(NT) void k_tile_out(Batch b) {
             const uint32_t w = wb + tid;
             uint32_t word = w < whi ? b.tbits[w] : 0u;
             const uint32_t cnt = __popc(word);
-            uint32_t x = cnt;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t y = __shfl_up(x, d);
-                if (lane >= d) x += y;
-            }
+            uint32_t x = wave_scan_incl(cnt);
             __syncthreads();
             if (lane == 63) s_wsum[wv] = x;
             __syncthreads();
@@ -1910,12 +1902,7 @@ __global__ __launch_bounds__(1024) void k_scan(Batch b) {
                 v = b.blk_base[i];
             }
         }
-        uint32_t x = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t y = __shfl_up(x, d);
-            if ((tid & 63) >= d) x += y;
-        }
+        uint32_t x = wave_scan_incl(v);
         if ((tid & 63) == 63) s_w[tid >> 6] = x;
         __syncthreads();
         uint32_t pre = s_carry;
