@@ -150,7 +150,7 @@ int spl_last_queue_counts(spl_tokenizer* t, uint32_t counts_out[4]);
 int spl_debug_phases(spl_tokenizer* t, int enable, unsigned long long stamps_out[16]);
 
 /* Development aid: per-workgroup records of the last stamped k_pretok launch, 4 wall-clock ticks
- * each (start, end of the merge phase, look-back done, end) for the first SPL_DEBUG_BLOCKS
+ * each (start, end of the merge phase, counts done, end) for the first SPL_DEBUG_BLOCKS
  * workgroups.  Returns the count copied. */
 #define SPL_DEBUG_BLOCKS 4096
 int spl_debug_blocks(spl_tokenizer* t, unsigned long long* out, int max_blocks);

@@ -65,7 +65,7 @@ struct spl_tokenizer {
     uint32_t qcap64 = 0, qcaplong = 0, qcapdefer = 0;
     unsigned long long* d_dbg = nullptr;
     uint32_t* d_blk = nullptr;
-    // single-pass path: look-back status words (epoch-tagged), and whether the token bitmap may hold
+    // tile-owned mode: tile records, the tiles' token slots, group sums; and whether the token bitmap may hold
     // stale bits (after hipMalloc or a multi-pass call) -- the single-pass kernel needs it all-zero
     TileDesc* d_tdesc = nullptr;
     uint32_t* d_tile_ids = nullptr;

@@ -74,8 +74,8 @@ struct Batch {
     uint32_t* ids_out; uint64_t ids_cap; uint64_t* off_out;
     // tile-owned mode (k_pretok<.., DIRECT> + k_tile_out)
     TileDesc* tdesc;           // one record per tile
-    uint32_t* tile_ids;        // the tiles' window tokens, packed in order of completion (cursor = tctl[0])
-    uint32_t* tctl;            // [0] packing cursor; [16 + par * tgroups ...] token sums per 64 tiles, two parities
+    uint32_t* tile_ids;        // the tiles' window tokens, one fixed slot of tslot words per tile
+    uint32_t* tctl;            // [16 + par * tgroups ...] token sums per 64 tiles, two parities ([0..15] spare)
     uint32_t tgroups;          // capacity of one parity's group-sum array
     uint32_t tslot;            // words per tile in tile_ids[] (window size + 1)
     // optional second copy of the result, laid out as a ragged all-gather slab (k_gatherv_pack's
@@ -1631,8 +1631,7 @@ void k_pretok(DeviceTables T, Batch b) {
             }
             __syncthreads();
         }
-        // the first NT documents of the window are fetched now, so that after the look-back only
-        // stores are left on the critical path of the last tiles
+        // the first NT documents of the window are fetched now: their load overlaps the count below
         const bool last_tile = blockIdx.x == gridDim.x - 1;
         const uint64_t own_lo = (uint64_t)t0, own_hi = (uint64_t)(t0 + TB_);
         const uint64_t d_first = (uint64_t)dw + tid;
@@ -1718,7 +1717,7 @@ void k_pretok(DeviceTables T, Batch b) {
 #ifdef SPL_DEBUG_STAMPS
     if (b.dbg && tid == 0 && blockIdx.x == gridDim.x / 2) b.dbg[12] = (unsigned long long)wall_clock64();
     if (b.dbg && tid == 0 && blockIdx.x < SPL_DEBUG_BLOCKS) {
-        // wall-clock ticks: start, end of the merge phase, look-back done (single pass), end
+        // wall-clock ticks: start, end of the merge phase, counts done, end
         unsigned long long* r = b.dbg + 16 + 4 * blockIdx.x;
         r[0] = blk_t0;
         r[1] = blk_w1;
@@ -1804,7 +1803,6 @@ __global__ __launch_bounds__(NT) void k_tile_out(Batch b) {
     if (t == 0) {
         uint32_t* other = b.tctl + 16 + (b.tpar ^ 1u) * b.tgroups;
         for (uint32_t k = tid; k < b.tgroups; k += NT) other[k] = 0u;
-        if (tid == 0) b.tctl[0] = 0u;
     }
 }
 

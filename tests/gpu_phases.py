@@ -41,11 +41,11 @@ pc = lambda col: tuple(np.percentile(rel[:, col], [50, 90, 99, 100]))
 print("  per-workgroup wall clock, 10 ns ticks since the kernel's first workgroup started (p50 p90 p99 max):")
 print("    start          %6d %6d %6d %6d" % pc(0))
 print("    merge done     %6d %6d %6d %6d" % pc(1))
-print("    look-back done %6d %6d %6d %6d" % pc(2))
+print("    counts done    %6d %6d %6d %6d" % pc(2))
 print("    end            %6d %6d %6d %6d" % pc(3))
 slow = int(np.argmax(rel[:, 1]))
-print("    slowest merge: wg %d at %d; its look-back done %d, end %d" % (slow, rel[slow, 1], rel[slow, 2], rel[slow, 3]))
-print("    tail after look-back (end - look-back done): p50 %d max %d" % tuple(np.percentile(rel[:, 3] - rel[:, 2], [50, 100])))
+print("    slowest merge: wg %d at %d; its counts done %d, end %d" % (slow, rel[slow, 1], rel[slow, 2], rel[slow, 3]))
+print("    tile record (end - counts done): p50 %d max %d" % tuple(np.percentile(rel[:, 3] - rel[:, 2], [50, 100])))
 qc = (ctypes.c_uint32 * 4)()
 L.spl_last_queue_counts(tok.handle, qc)
 print("queues: q64", qc[0], "long", qc[2], "deferred", qc[3], "bytes", batch.n_bytes)
