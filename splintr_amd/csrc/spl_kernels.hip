@@ -1174,6 +1174,20 @@ void k_pretok(DeviceTables T, Batch b) {
     if (DIRECT) {
         uint32_t lo = 0, hi = b.n_docs;
         const uint64_t target = w0 > 0 ? (uint64_t)w0 : 0ull;
+        if (target != 0 && hi > (uint32_t)NT) {
+            // first round by interpolation: with documents of similar size the answer lies within NT
+            // entries of target * n_docs / n_bytes, and ONE round of loads finds it; otherwise this
+            // round only narrows [lo, hi] for the search below
+            const uint64_t g = target * (uint64_t)hi / (uint64_t)B;
+            const uint32_t glo = g > (uint64_t)(NT / 2) ? (uint32_t)g - NT / 2 : 0u;
+            const uint32_t ghi = glo + NT < hi ? glo + NT : hi;
+            const uint32_t idx = glo + (uint32_t)tid;
+            const bool below = idx < ghi && b.doc_off[idx] < target;
+            const uint32_t c = (uint32_t)__syncthreads_count(below);
+            if (c == 0) hi = glo;                           // entry glo (if any) is not below the target
+            else if (c == ghi - glo) lo = ghi;              // every probed entry is
+            else lo = hi = glo + c;
+        }
         while (target != 0 && lo < hi) {
             const uint32_t span = hi - lo, st = (span + NT - 1) / NT;
             const uint64_t idx = (uint64_t)lo + (uint64_t)tid * st;
