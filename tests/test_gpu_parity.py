@@ -407,3 +407,13 @@ def test_seven_megabytes_mixed_in_tile_owned_mode(coracle, name):
     texts = corpus.c3(1800, seed=77)
     assert sum(len(t.encode()) for t in texts) < (8 << 20)
     assert_batch_equal(name, texts, coracle)
+
+
+@pytest.mark.gpu
+def test_document_search_with_skewed_document_sizes(coracle):
+    """The tile kernel's first search round interpolates on document index; batches whose document
+    sizes are far from uniform must fall through to the plain search."""
+    big = [("lorem ipsum dolor 42, " * 120)[:2048 + 7 * i % 300] for i in range(320)]
+    tiny = [("ab" if i % 3 else "") + str(i % 10) for i in range(4000)]
+    for texts in (big + tiny, tiny + big, tiny[:500] + big + tiny[500:] + big[:40]):
+        assert_batch_equal("cl100k_base", texts, coracle)
