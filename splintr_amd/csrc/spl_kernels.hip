@@ -1104,6 +1104,7 @@ void k_pretok(DeviceTables T, Batch b) {
     __shared__ uint8_t s_ascii[128];
     __shared__ uint32_t s_wsum[NT / 64];
     __shared__ uint32_t s_total;
+    __shared__ uint32_t s_nch;                           // chunks on the probe list (small windows)
     __shared__ uint32_t s_scnt[17];                      // counting sort of the short misses by length
     __shared__ uint32_t s_nq[4];                         // miss counts [0] (<= 16 B) [1] (17..64 B), work cursors [2] [3]
     // single-pass state
@@ -1117,6 +1118,9 @@ void k_pretok(DeviceTables T, Batch b) {
     __shared__ int s_touch[3];
     uint8_t* const s_txt = reinterpret_cast<uint8_t*>(s_txt32);
     uint8_t* const s_rec = reinterpret_cast<uint8_t*>(s_rec32);
+    // probe list of a small window: p | n << 16 per chunk, in the (then still unused) substring table
+    constexpr bool LIST_CHUNKS = Wv <= (NT / 16) * 16 * SUB_W;
+    uint32_t* const s_chunk = &s_sub[0][0];
     // Phase stamps, per-workgroup records and the phase cut-off are compiled in only with
     // -DSPL_DEBUG_STAMPS (tools/ab_build.sh): their live values cost the product kernel registers.
 #ifdef SPL_DEBUG_STAMPS
@@ -1167,6 +1171,7 @@ void k_pretok(DeviceTables T, Batch b) {
     if (tid < 128) s_ascii[tid] = T.ucls_stage2[((uint32_t)T.ucls_stage1[0] << T.ucls_shift) + tid];
     if (tid < 4) s_nq[tid] = 0;
     if (tid < 12) s_dq[tid] = 0;
+    if (tid == 0) s_nch = 0;
     // single pass: the window's text starts straight from doc_off.  NT-ary search for the first
     // document that starts at or after the window (two rounds up to 65 536 documents), then the
     // documents of the window set their bits.
@@ -1345,20 +1350,23 @@ void k_pretok(DeviceTables T, Batch b) {
         for (int k = tid; k < nsync; k += NT) {
             int p = s_cpos[k];
             for (;;) {
-                atomicOr(&s_cbits[p >> 5], 1u << (p & 31));
+                if (!LIST_CHUNKS) atomicOr(&s_cbits[p >> 5], 1u << (p & 31));
                 const int e = match_end_m(acc, p, (int)T.pattern);
                 if (e == SPL_DEFER) {                 // the match outgrows the window
                     push_defer((uint32_t)(w0 + p));
                     break;
                 }
+                // small windows: the chunk goes straight onto the probe list (order is irrelevant:
+                // tokens are identified by their position) -- no marks, no second enumeration
+                if (LIST_CHUNKS) s_chunk[atomicAdd(&s_nch, 1u)] = (uint32_t)p | ((uint32_t)(e - p) << 16);
                 p = e;
                 if (p >= Wv) {                         // ended exactly on the window edge
-                    atomicOr(&s_cbits[Wv >> 5], 1u << (Wv & 31));
+                    if (!LIST_CHUNKS) atomicOr(&s_cbits[Wv >> 5], 1u << (Wv & 31));
                     if (w0 + Wv < B) push_defer((uint32_t)(w0 + Wv));
                     break;
                 }
                 if (((s_mk[MK_SY * NBW1 + (p >> 5)] | s_mk[MK_TS * NBW1 + (p >> 5)]) >> (p & 31)) & 1u) {
-                    atomicOr(&s_cbits[p >> 5], 1u << (p & 31));   // next owner's start: terminator mark
+                    if (!LIST_CHUNKS) atomicOr(&s_cbits[p >> 5], 1u << (p & 31));   // next owner's start: terminator mark
                     break;
                 }
             }
@@ -1367,8 +1375,8 @@ void k_pretok(DeviceTables T, Batch b) {
     __syncthreads();
     SPL_STAMP(4);
 
-    // ---- enumerate marked positions ------------------------------------------------------------
-    {
+    // ---- enumerate marked positions (large windows only) ---------------------------------------------
+    if (!LIST_CHUNKS) {
         uint32_t word = tid < G::NBW ? s_cbits[tid] : 0u;
         uint32_t cnt = __popc(word);
         // inclusive scan over 256 threads: wave scan + cross-wave sums
@@ -1384,17 +1392,23 @@ void k_pretok(DeviceTables T, Batch b) {
             s_cpos[base++] = (uint16_t)(tid * 32 + bit);
         }
     }
-    __syncthreads();
+    if (!LIST_CHUNKS) __syncthreads();
     SPL_STAMP(5);
 
-    // ---- whole-chunk probe; the last marked position is only a terminator ------------------------
+    // ---- whole-chunk probe (large windows: the last marked position is only a terminator) -------------
     {
         LdsAcc tx{s_rec, s_txt};
-        const int K = (int)s_total;
+        const int K = LIST_CHUNKS ? (int)s_nch + 1 : (int)s_total;
         for (int k = tid; k + 1 < K; k += NT) {
-            const int p = s_cpos[k];
-            if ((s_rec[p] & CB_CLASS) >= C_EOT) continue;   // terminator on a special-literal span
-            const int n = (int)s_cpos[k + 1] - p;
+            int p, n;
+            if (LIST_CHUNKS) {
+                const uint32_t c = s_chunk[k];
+                p = (int)(c & 0xFFFFu); n = (int)(c >> 16);
+            } else {
+                p = s_cpos[k];
+                if ((s_rec[p] & CB_CLASS) >= C_EOT) continue;   // terminator on a special-literal span
+                n = (int)s_cpos[k + 1] - p;
+            }
             const uint32_t id = probe_chunk_tile(T, tx, p, n);
             if (id != SPL_NO_RANK) {
                 if (DIRECT) s_ids[p] = id;
