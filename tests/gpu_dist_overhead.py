@@ -1,4 +1,4 @@
-"""Dev aid: where the per-step time of the N>1 bench path goes (1-rank RCCL group on one GPU)."""
+"""Dev aid: per-step time of the N>1 bench path (1-rank RCCL group on one GPU) for several bucket depths."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,38 +13,17 @@ batch = DeviceBatch(corpus.c2(1000), dev)
 reserve(tok, batch.n_bytes, batch.n_docs)
 encode_device(tok, batch); torch.cuda.synchronize()
 ids, off = result_csr(batch)
-gv = GatherV(tok, dev, max_docs=batch.n_docs, max_tokens=int(off[-1] * 1.02) + 64)
-def run(name, fn, n=300):
-    for _ in range(30): fn()
-    gv.finish(); torch.cuda.synchronize()
+def run(name, fn, fin, n=320):
+    for _ in range(40): fn()
+    fin(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n): fn()
     t_host = (time.perf_counter() - t0) / n
-    gv.finish(); torch.cuda.synchronize()
+    fin(); torch.cuda.synchronize()
     t_all = (time.perf_counter() - t0) / n
-    print(f"{name:44s} host issue {t_host * 1e6:7.1f} us/step   total {t_all * 1e6:7.1f} us/step")
-run("encode only", lambda: encode_device(tok, batch))
-run("encode + submit (pack, all_gather, unpack)", lambda: (encode_device(tok, batch), gv.submit(batch)))
-import ctypes
-from splintr_amd import _ffi
-L = _ffi.lib()
-def enc_pack():
-    encode_device(tok, batch)
-    L.spl_gatherv_pack(tok.handle, batch.ids.data_ptr(), batch.out_off.data_ptr(), batch.n_docs, gv.send[0].data_ptr(),
-                       gv.cap_words, gv.max_docs, torch.cuda.current_stream(dev).cuda_stream)
-run("encode + pack only", enc_pack)
-for d in (8, 16):
-    g2 = GatherV(tok, dev, max_docs=batch.n_docs, max_tokens=int(off[-1] * 1.02) + 64, depth=d)
-    def f():
-        encode_device(tok, batch); g2.submit(batch)
-    for _ in range(40): f()
-    g2.finish(); torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(320): f()
-    g2.finish(); torch.cuda.synchronize()
-    print(f"depth {d}: total {(time.perf_counter() - t0) / 320 * 1e6:.1f} us/step")
-send, recv = gv.send[0], gv.recv[0]
-run("all_gather_into_tensor only (async)", lambda: dist.all_gather_into_tensor(recv, send, async_op=True))
-def ag_wait():
-    w = dist.all_gather_into_tensor(recv, send, async_op=True); w.wait()
-run("all_gather_into_tensor + wait()", ag_wait)
+    print(f"{name:34s} host issue {t_host * 1e6:7.1f} us/step   total {t_all * 1e6:7.1f} us/step")
+run("encode only", lambda: encode_device(tok, batch), lambda: None)
+for d in (4, 8, 16, 32):
+    gv = GatherV(tok, dev, max_docs=batch.n_docs, max_tokens=int(off[-1] * 1.02) + 64, depth=d)
+    run(f"encode_and_submit, depth {d}", lambda: gv.encode_and_submit(batch), gv.finish)
 dist.destroy_process_group()
