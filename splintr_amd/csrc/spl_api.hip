@@ -68,6 +68,7 @@ struct spl_tokenizer {
     // tile-owned mode: tile records, the tiles' token slots, group sums; and whether the token bitmap may hold
     // stale bits (after hipMalloc or a multi-pass call) -- the single-pass kernel needs it all-zero
     TileDesc* d_tdesc = nullptr;
+    uint32_t* d_tile_bits = nullptr; uint32_t* d_tcnt = nullptr;     // queue mode
     uint32_t* d_tile_ids = nullptr;
     uint32_t* d_tctl = nullptr;
     uint32_t tgroups = 0, tpar = 0;
@@ -97,8 +98,8 @@ namespace {
 void free_workspace(spl_tokenizer* t) {
     hipFree(t->d_zero); hipFree(t->d_stage); hipFree(t->d_rank);
     hipFree(t->d_q64); hipFree(t->d_qlong); hipFree(t->d_qdefer); hipFree(t->d_blk); hipFree(t->d_dbg);
-    hipFree(t->d_tdesc); hipFree(t->d_tile_ids); hipFree(t->d_tctl);
-    t->d_tdesc = nullptr; t->d_tile_ids = nullptr; t->d_tctl = nullptr;
+    hipFree(t->d_tdesc); hipFree(t->d_tile_ids); hipFree(t->d_tctl); hipFree(t->d_tile_bits); hipFree(t->d_tcnt);
+    t->d_tdesc = nullptr; t->d_tile_ids = nullptr; t->d_tctl = nullptr; t->d_tile_bits = nullptr; t->d_tcnt = nullptr;
     t->d_zero = nullptr; t->d_stage = nullptr; t->d_rank = nullptr;
     t->d_q64 = nullptr; t->d_qlong = nullptr; t->d_qdefer = nullptr; t->d_blk = nullptr; t->d_dbg = nullptr;
     t->cap_bytes = t->cap_docs = 0;
@@ -126,11 +127,13 @@ int reserve(spl_tokenizer* t, uint64_t max_bytes, uint64_t max_docs) {
     HIP_TRY(hipMalloc((void**)&t->d_qdefer, (size_t)t->qcapdefer * 4));
     HIP_TRY(hipMalloc((void**)&t->d_blk, (nblk + 2) * 4));
     {
-        const size_t dbytes = (size_t)std::min<uint64_t>(nb, SPL_DIRECT_MAX_BYTES);
+        const size_t dbytes = (size_t)std::min<uint64_t>(nb, std::max<uint64_t>(SPL_DIRECT_MAX_BYTES, SPL_QUEUE_MAX_BYTES));
         const size_t tiles = dbytes / TileGeom<SPL_TILE_SMALL>::TBv + 2;
         t->tgroups = (uint32_t)(tiles / 64 + 2);
         HIP_TRY(hipMalloc((void**)&t->d_tdesc, tiles * sizeof(TileDesc)));
         HIP_TRY(hipMalloc((void**)&t->d_tile_ids, tiles * (size_t)(TileGeom<SPL_TILE_SMALL>::Wv + 1) * 4));
+        HIP_TRY(hipMalloc((void**)&t->d_tile_bits, tiles * (size_t)TILE_BITS_W * 4));
+        HIP_TRY(hipMalloc((void**)&t->d_tcnt, tiles * 4));
         HIP_TRY(hipMalloc((void**)&t->d_tctl, (16 + 2 * (size_t)t->tgroups) * 4));
         HIP_TRY(hipMemset(t->d_tctl, 0, (16 + 2 * (size_t)t->tgroups) * 4));
         t->tpar = 0;
@@ -203,7 +206,10 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
     const bool pf = t->prof;
 #define MARK(i) do { if (pf) HIP_TRY(hipEventRecord(t->ev[i], s)); } while (0)
     // small batches: small tiles (occupancy hides latency); large batches: 4 KiB tiles
-    const bool small_tiles = t->force_tile == 1 || t->force_tile == 3 || (t->force_tile == 0 && n_bytes <= SPL_DIRECT_MAX_BYTES);
+    // queue mode: tile-owned tiles + global queues for what is long, for batches beyond the two-launch limit
+    const bool queue_mode = !special && t->force_tile == 0 && n_bytes > SPL_DIRECT_MAX_BYTES && n_bytes <= SPL_QUEUE_MAX_BYTES;
+    const bool small_tiles = queue_mode || t->force_tile == 1 || t->force_tile == 3 ||
+                             (t->force_tile == 0 && n_bytes <= SPL_DIRECT_MAX_BYTES);
     const uint32_t tile_bytes = small_tiles ? TileGeom<SPL_TILE_SMALL>::TBv : TileGeom<SPL_TILE_LARGE>::TBv;
     const uint32_t ntiles = (uint32_t)((n_bytes + tile_bytes - 1) / tile_bytes);
     // (A/B on the 1 MB bench batch: folding these launches together -- clean-after-use bitmaps, one
@@ -212,8 +218,28 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
     //  single-workgroup tails and agent-scope fences sit on the critical path.)
     // Single pass: small batches without special tokens are finished by ONE kernel.
     bool fused_scan_used = false;
-    const bool direct = small_tiles && t->force_tile != 3 && n_bytes <= SPL_DIRECT_MAX_BYTES;
-    if (direct) {
+    const bool direct = !queue_mode && small_tiles && t->force_tile != 3 && n_bytes <= SPL_DIRECT_MAX_BYTES;
+    if (queue_mode) {
+        t->bitmap_dirty = true;
+        HIP_TRY(hipMemsetAsync(t->d_zero, 0, (2 * uw + 8) * 4, s));
+        b.tdesc = t->d_tdesc; b.tile_ids = t->d_tile_ids; b.tctl = t->d_tctl; b.tile_bits = t->d_tile_bits; b.tcnt = t->d_tcnt;
+        b.tgroups = t->tgroups; b.tpar = t->tpar; b.tslot = (uint32_t)TileGeom<SPL_TILE_SMALL>::Wv + 1u;
+        t->tpar ^= 1u;
+        MARK(KI_MARK);
+        if (n_docs) hipLaunchKernelGGL(k_mark_docs, dim3((uint32_t)((n_docs + 255) / 256)), dim3(256), 0, s, b);
+        MARK(KI_SPECIAL); MARK(KI_PRETOK);
+        hipLaunchKernelGGL((k_pretok<SPL_TILE_SMALL, false, true>), dim3(ntiles), dim3(NT), 0, s, t->dt, b);
+        MARK(KI_DEFER);
+        // (small windows defer far more chains than the 4 KiB ones: one lane per chain, so many lanes)
+        hipLaunchKernelGGL(k_deferred, dim3(std::min<uint32_t>(4096, ntiles / 16 + 64)), dim3(64), 0, s, t->dt, b);
+        MARK(KI_BPELANES); MARK(KI_BPELONG);
+        hipLaunchKernelGGL(k_bpe_long, dim3(std::min<uint32_t>(2048, ntiles / 4 + 8)), dim3(NT), 0, s, t->dt, b);
+        MARK(KI_COUNT);
+        hipLaunchKernelGGL((k_range_count<SPL_TILE_SMALL>), dim3(ntiles), dim3(64), 0, s, b);
+        MARK(KI_SCAN); MARK(KI_COMPACT);
+        hipLaunchKernelGGL((k_range_out<SPL_TILE_SMALL>), dim3(ntiles), dim3(64), 0, s, b);
+        MARK(KI_N);
+    } else if (direct) {
         if (special) {
             // the three bitmaps are cleared per call; documents and literals are marked by the
             // multi-pass kernels, the tile kernel reads the bitmaps on top of its document search
@@ -291,7 +317,7 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
         HIP_TRY(hipEventSynchronize(t->ev[KI_N]));
         for (int i = 0; i < KI_N; i++) {
             // slots whose kernels were not launched in this mode would only show the event overhead
-            const bool launched = direct ? (i == KI_PRETOK || i == KI_COMPACT || (special && (i == KI_MARK || i == KI_SPECIAL)))
+            const bool launched = queue_mode ? (i != KI_SPECIAL && i != KI_BPELANES && i != KI_SCAN) : direct ? (i == KI_PRETOK || i == KI_COMPACT || (special && (i == KI_MARK || i == KI_SPECIAL)))
                                          : !((i == KI_SPECIAL && !special) || (i == KI_BPELANES && small_tiles) ||
                                              (i == KI_COUNT && fused_scan_used));
             if (!launched) continue;

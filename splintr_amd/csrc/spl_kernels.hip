@@ -38,6 +38,10 @@ constexpr int RANK_BLK = 1024;           // positions per rank block (32 bitmap 
 #ifndef SPL_DIRECT_MAX_MB
 #define SPL_DIRECT_MAX_MB 8
 #endif
+#ifndef SPL_QUEUE_MAX_MB
+#define SPL_QUEUE_MAX_MB 2047         /* 0: queue mode off (larger batches then run the multi-pass pipeline) */
+#endif
+constexpr uint64_t SPL_QUEUE_MAX_BYTES = (uint64_t)SPL_QUEUE_MAX_MB << 20;
 constexpr uint64_t SPL_DIRECT_MAX_BYTES = (uint64_t)SPL_DIRECT_MAX_MB << 20;   // batches up to this size: small tiles, tile-owned mode
 
 // What a tile of the tile-owned mode leaves behind for k_tile_out.
@@ -48,8 +52,10 @@ struct TileDesc {
     uint32_t ovf_hi;           // end (exclusive) of the byte range those occupy; 0 if none
     uint32_t d_first, d_cnt;   // documents that start in the tile: off_out[d] holds the LOCAL rank
     uint32_t ovf_lo;           // first byte beyond the window
-    uint32_t pad;
+    uint32_t c_own;            // queue mode: window tokens that start inside the tile's own byte range
 };
+
+constexpr int TILE_BITS_W = 36;   // >= window words + 1 of the small tile (34)
 
 struct Batch {
     const uint8_t* text;
@@ -78,6 +84,10 @@ struct Batch {
     uint32_t* tctl;            // [16 + par * tgroups ...] token sums per 64 tiles, two parities ([0..15] spare)
     uint32_t tgroups;          // capacity of one parity's group-sum array
     uint32_t tslot;            // words per tile in tile_ids[] (window size + 1)
+    // queue mode (tile-owned tiles + global queues for what is long, batches beyond the two-launch
+    // limit): the tile's window token bitmap goes to tile_bits[] (TILE_BITS_W words per tile)
+    uint32_t* tile_bits;
+    uint32_t* tcnt;            // tokens per tile RANGE (k_range_count)
     // optional second copy of the result, laid out as a ragged all-gather slab (k_gatherv_pack's
     // format): k_tile_out writes it in the same pass, the separate pack launch goes away
     uint32_t* slab; uint32_t slab_cap, slab_max_docs;
@@ -1339,7 +1349,7 @@ void k_pretok(DeviceTables T, Batch b) {
         const int nsync = (int)s_total;
         // only the LAST chain of a tile can reach the window end, so at most one start is recorded
         auto push_defer = [&](uint32_t gpos) {
-            if (DIRECT) {
+            if (DIRECT && !b.qcount) {
                 const uint32_t qi = atomicAdd(&s_dq[1], 1u);
                 if (qi < 2) s_dq[2 + qi] = gpos;
             } else {
@@ -1420,7 +1430,7 @@ void k_pretok(DeviceTables T, Batch b) {
                 const uint32_t item = (uint32_t)p | ((uint32_t)n << 16);
                 if (n <= 16) s_miss[atomicAdd(&s_nq[0], 1u)] = item;
                 else if (n <= 64) s_miss[G::C16 + atomicAdd(&s_nq[1], 1u)] = item;
-                else if (DIRECT) {                       // at most Wv / 65 of them
+                else if (DIRECT && !b.qcount) {          // at most Wv / 65 of them
                     const uint32_t qi = atomicAdd(&s_dq[0], 1u);
                     s_lq[2 * qi] = (uint32_t)(w0 + p);
                     s_lq[2 * qi + 1] = (uint32_t)n;
@@ -1705,7 +1715,10 @@ void k_pretok(DeviceTables T, Batch b) {
         // (k_tile_out turns these into the final CSR once every tile's count is known; nothing here
         //  waits for another workgroup, so a tile that is slow -- long chunks, a chain that runs far
         //  beyond the window -- only delays itself)
-        if (tid == 0) atomicAdd(&b.tctl[16 + b.tpar * b.tgroups + (blockIdx.x >> 6)], (uint32_t)total);
+        const bool queue_mode = b.qcount != nullptr;          // long chunks / chains went to the global queues
+        if (tid == 0 && !queue_mode) atomicAdd(&b.tctl[16 + b.tpar * b.tgroups + (blockIdx.x >> 6)], (uint32_t)total);
+        if (queue_mode && tid < TILE_BITS_W)
+            b.tile_bits[(size_t)blockIdx.x * TILE_BITS_W + tid] = tid < G::NBW + 1 ? s_tbits[tid] : 0u;
 #ifdef SPL_DEBUG_STAMPS
         if (b.dbg) blk_w2 = (unsigned long long)wall_clock64();
 #endif
@@ -1718,7 +1731,7 @@ void k_pretok(DeviceTables T, Batch b) {
             if (db != dw) { p = ~0ull; if (d <= b.n_docs) p = b.doc_off[d]; }
             const bool in = d <= b.n_docs && (p < own_hi || last_tile);
             const bool own = in && p >= own_lo;
-            if (own) {
+            if (own && !queue_mode) {
                 const uint32_t i = (uint32_t)(p - (uint64_t)w0);
                 b.off_out[d] = (uint64_t)(s_wpre[i >> 5] + __popc(s_tbits[i >> 5] & ((1u << (i & 31)) - 1u)))
                                + ((last_tile && p >= (uint64_t)B) ? c_ovf : 0u);
@@ -1739,7 +1752,8 @@ void k_pretok(DeviceTables T, Batch b) {
         if (tid == 0) {
             TileDesc td;
             td.slot = slot; td.c_win = c_win; td.c_ovf = c_ovf; td.ovf_hi = whi > wlo ? ovf_hi : 0u;
-            td.d_first = d_lo == 0xFFFFFFFFu ? 0u : d_lo; td.d_cnt = d_n; td.ovf_lo = ovf_lo; td.pad = 0;
+            td.d_first = d_lo == 0xFFFFFFFFu ? 0u : d_lo; td.d_cnt = d_n; td.ovf_lo = ovf_lo;
+            td.c_own = s_wpre[(LH + TB_) >> 5];             // tile range ends on a word boundary
             b.tdesc[blockIdx.x] = td;
         }
     }
@@ -1833,6 +1847,98 @@ __global__ __launch_bounds__(NT) void k_tile_out(Batch b) {
     if (t == 0) {
         uint32_t* other = b.tctl + 16 + (b.tpar ^ 1u) * b.tgroups;
         for (uint32_t k = tid; k < b.tgroups; k += NT) other[k] = 0u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Queue mode (batches beyond the two-launch limit): k_pretok<.., DIRECT> works its tiles as in
+// tile-owned mode but sends chunks of more than 64 bytes and chains that outgrow a window to the
+// GLOBAL queues, where k_deferred / k_bpe_long balance them over the whole GPU and leave their tokens
+// in stage[] / tbits[].  The CSR is then assembled per tile RANGE [t * TB, (t + 1) * TB): its
+// tokens are the window tokens of tile t inside the range (A own), those of tile t - 1 that start
+// beyond ITS range (A spill, at most the right halo) and the queue tokens of the range (B).
+//   k_range_count: tokens per range -> tcnt[t], group sums
+//   k_range_out  : base of the range (as k_tile_out), tokens in position order from the three
+//                  sources, document offsets as ranks in the merged bitmap
+template <int TB_, int RH_>
+__device__ __forceinline__ void range_words(const Batch& b, uint32_t t, int j, uint32_t& a_own, uint32_t& a_spill,
+                                            uint32_t& bq) {
+    constexpr int W0 = LH / 32;                          // window word of the tile's first own byte
+    constexpr int NOWN = TB_ / 32;                       // words of a range
+    constexpr int NSP = RH_ / 32;                        // words the previous tile can spill into
+    a_own = j < NOWN ? b.tile_bits[(size_t)t * TILE_BITS_W + W0 + j] : 0u;
+    a_spill = (t > 0 && j < NSP) ? b.tile_bits[(size_t)(t - 1) * TILE_BITS_W + W0 + NOWN + j] : 0u;
+    const uint64_t wg = (uint64_t)t * NOWN + (uint32_t)j;
+    bq = (j < NOWN && wg * 32 < b.n_bytes) ? b.tbits[wg] : 0u;
+}
+template <int TB_, int RH_>
+__global__ __launch_bounds__(64) void k_range_count(Batch b) {
+    const uint32_t t = blockIdx.x;
+    const int j = threadIdx.x;
+    uint32_t ao, as, bq;
+    range_words<TB_, RH_>(b, t, j, ao, as, bq);
+    uint32_t c = __popc(ao | as | bq);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+    if (j == 0) {
+        b.tcnt[t] = c;
+        atomicAdd(&b.tctl[16 + b.tpar * b.tgroups + (t >> 6)], c);
+    }
+}
+template <int TB_, int RH_>
+__global__ __launch_bounds__(64) void k_range_out(Batch b) {
+    __shared__ uint32_t s_m[TB_ / 32 + 1], s_pre[TB_ / 32 + 1];
+    const uint32_t t = blockIdx.x;
+    const int j = threadIdx.x;
+    constexpr int NOWN = TB_ / 32;
+    // base of the range
+    const uint32_t* gs = b.tctl + 16 + b.tpar * b.tgroups;
+    const uint32_t g = t >> 6;
+    unsigned long long mine = 0;
+    for (uint32_t k = (uint32_t)j; k < g; k += 64) mine += gs[k];
+    { const uint32_t u = (g << 6) + (uint32_t)j; if (u < t) mine += b.tcnt[u]; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+    const unsigned long long base = mine;
+    // merged bitmap of the range and per-source prefix counts
+    uint32_t ao, as, bq;
+    range_words<TB_, RH_>(b, t, j, ao, as, bq);
+    const uint32_t m = ao | as | bq;
+    const uint32_t pm = wave_scan_incl(__popc(m)) - __popc(m);       // tokens of the range before this word
+    const uint32_t pao = wave_scan_incl(__popc(ao)) - __popc(ao);   // own window tokens before this word
+    const uint32_t pas = wave_scan_incl(__popc(as)) - __popc(as);
+    if (j <= NOWN) { s_m[j] = j < NOWN ? m : 0u; s_pre[j] = pm; }
+    const TileDesc td = b.tdesc[t];
+    const uint32_t c_own_prev = t > 0 ? b.tdesc[t - 1].c_own : 0u;
+    const uint32_t slot_own = t * b.tslot, slot_prev = (t > 0 ? t - 1 : 0u) * b.tslot;
+    const uint64_t p0 = ((uint64_t)t * NOWN + (uint32_t)j) * 32;
+    uint32_t word = m, r = pm;
+    while (word) {
+        const int bit = __ffs(word) - 1;
+        const uint32_t below = (1u << bit) - 1u;
+        word &= word - 1;
+        uint32_t id;
+        if ((ao >> bit) & 1u) id = b.tile_ids[slot_own + pao + __popc(ao & below)];
+        else if ((as >> bit) & 1u) id = b.tile_ids[slot_prev + c_own_prev + pas + __popc(as & below)];
+        else id = b.stage[p0 + bit];
+        if (base + r < b.ids_cap) b.ids_out[base + r] = id;
+        r++;
+    }
+    __syncthreads();
+    // documents that start in the range: rank of their first byte in the merged bitmap
+    const bool last_tile = t == gridDim.x - 1;
+    for (uint32_t k = (uint32_t)j; k < td.d_cnt; k += 64) {
+        const uint32_t d = td.d_first + k;
+        const uint64_t p = b.doc_off[d];
+        const uint64_t i = p - (uint64_t)t * TB_;                    // offset inside the range (== TB_ at most)
+        const uint32_t w = (uint32_t)(i >> 5) < (uint32_t)NOWN ? (uint32_t)(i >> 5) : (uint32_t)NOWN;
+        const uint32_t inword = w < (uint32_t)NOWN ? __popc(s_m[w] & ((1u << (i & 31)) - 1u)) : 0u;
+        (void)last_tile;
+        b.off_out[d] = base + s_pre[w] + inword;
+    }
+    if (t == 0) {                                        // re-arm the other parity's group sums (as k_tile_out)
+        uint32_t* other = b.tctl + 16 + (b.tpar ^ 1u) * b.tgroups;
+        for (uint32_t k = (uint32_t)j; k < b.tgroups; k += 64) other[k] = 0u;
     }
 }
 
