@@ -659,7 +659,10 @@ int spl_last_queue_counts(spl_tokenizer* t, uint32_t counts_out[4]) {
         for (int i = 0; i < 4; i++) counts_out[i] = 0;
         return SPL_OK;
     }
-    HIP_TRY(hipMemcpy(counts_out, t->last_qcount, 16, hipMemcpyDeviceToHost));
+    uint32_t q[8];
+    HIP_TRY(hipMemcpy(q, t->last_qcount, 32, hipMemcpyDeviceToHost));
+    counts_out[0] = q[0]; counts_out[1] = q[1]; counts_out[3] = q[3];
+    counts_out[2] = q[2] + q[4];             // the long-chunk queue is filled from both ends
     return SPL_OK;
 }
 

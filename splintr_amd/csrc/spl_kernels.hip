@@ -169,9 +169,19 @@ struct MaskLdsAcc {
     __device__ __forceinline__ bool end_is_eot() const { return eot_; }
 };
 
+// The long-chunk queue is filled from both ends: chunks the 16-lane groups of k_bpe_long take (up to
+// 128 bytes) from the front, larger ones from the back -- each phase of k_bpe_long then walks only
+// its own items (walking all of them cost one same-address atomic per item and wavefront phase).
+// Chunks do not overlap and have at least two bytes, so the two ends never meet (capacity n_bytes/2).
+constexpr int LONG_SMALL_NMAX = 128;
 __device__ __forceinline__ void push_long(const Batch& b, uint32_t pos, uint32_t len) {
-    const uint32_t i = atomicAdd(&b.qcount[2], 1u);
-    if (i < b.qcaplong) b.qlong[i] = make_uint2(pos, len);
+    if (len <= (uint32_t)LONG_SMALL_NMAX) {
+        const uint32_t i = atomicAdd(&b.qcount[2], 1u);
+        if (i < b.qcaplong) b.qlong[i] = make_uint2(pos, len);
+    } else {
+        const uint32_t i = atomicAdd(&b.qcount[4], 1u);
+        if (i < b.qcaplong) b.qlong[b.qcaplong - 1u - i] = make_uint2(pos, len);
+    }
 }
 
 // byte_pair_encode (reference src/core/bpe.rs:67-197) by a GROUP OF 16 LANES holding up to
@@ -1950,7 +1960,10 @@ __global__ __launch_bounds__(NT) void k_bpe_long(DeviceTables T, Batch b) {
     __shared__ unsigned long long s_red[NT / 64];
     __shared__ unsigned long long s_best;
     __shared__ int s_touch[3];
-    const uint32_t nq = min(b.qcount[2], b.qcaplong);
+    static_assert(LONG_SMALL_NMAX == GROUP_NMAX, "the front of the queue is what the group phase takes");
+    const uint32_t nq = min(b.qcount[2], b.qcaplong);          // front: chunks of up to GROUP_NMAX bytes
+    const uint32_t nbig = min(b.qcount[4], b.qcaplong);        // back: larger ones
+    const uint2* const qbig = b.qlong + (b.qcaplong - 1u);     // item k of the back is qbig[-k]
     const int wv = threadIdx.x >> 6;
     const uint32_t nwaves = gridDim.x * (NT / 64);
     // Work is pulled dynamically (one atomic per wavefront and pull): chunk lengths range from 65
@@ -1961,9 +1974,9 @@ __global__ __launch_bounds__(NT) void k_bpe_long(DeviceTables T, Batch b) {
         // (the first item of every wavefront is its own index, later ones come from the cursor: an
         //  empty or short queue costs no atomics at all)
         const uint32_t wgid = blockIdx.x * (NT / 64) + wv;
-        for (uint32_t it = wgid; it < nq;) {
-            const uint2 item = b.qlong[it];
-            if ((int)item.y > GROUP_NMAX && (int)item.y <= WAVE_NMAX)
+        for (uint32_t it = wgid; it < nbig;) {
+            const uint2 item = *(qbig - it);
+            if ((int)item.y <= WAVE_NMAX)
                 bpe_wave(T, b, item.x, (int)item.y, s_id[wv], s_rk[wv], s_nx[wv], s_pv[wv],
                          [&](uint32_t q, uint32_t id) { emit_token(b, q, id); });
             uint32_t nxt = 0;
@@ -1975,7 +1988,7 @@ __global__ __launch_bounds__(NT) void k_bpe_long(DeviceTables T, Batch b) {
             const uint32_t it = base + (lane >> 4);
             uint2 item = make_uint2(0, 0);
             if (it < nq) item = b.qlong[it];
-            const bool has = it < nq && (int)item.y <= GROUP_NMAX;
+            const bool has = it < nq;
             if (__any(has)) {
                 const uint32_t pos = item.x;
                 bpe_group16<GROUP_NMAX / 16>(T, has ? (int)item.y : 0, [&](int i) { return (uint32_t)b.text[pos + i]; },
@@ -1989,8 +2002,8 @@ __global__ __launch_bounds__(NT) void k_bpe_long(DeviceTables T, Batch b) {
     __syncthreads();
     // workgroup phase: the oversize items among this workgroup's share (uniform loop for all threads)
     for (int w = 0; w < NT / 64; w++)
-        for (uint32_t it = blockIdx.x * (NT / 64) + w; it < nq; it += nwaves) {
-            const uint2 item = b.qlong[it];
+        for (uint32_t it = blockIdx.x * (NT / 64) + w; it < nbig; it += nwaves) {
+            const uint2 item = *(qbig - it);
             if ((int)item.y > WAVE_NMAX)
                 bpe_block_global(T, b, item.x, (int)item.y, s_red, &s_best, s_touch,
                                  [&](uint32_t q, uint32_t id) { emit_token(b, q, id); });
