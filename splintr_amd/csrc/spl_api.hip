@@ -230,8 +230,7 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
         MARK(KI_SPECIAL); MARK(KI_PRETOK);
         hipLaunchKernelGGL((k_pretok<SPL_TILE_SMALL, false, true>), dim3(ntiles), dim3(NT), 0, s, t->dt, b);
         MARK(KI_DEFER);
-        // (small windows defer far more chains than the 4 KiB ones: one lane per chain, so many lanes)
-        hipLaunchKernelGGL(k_deferred, dim3(std::min<uint32_t>(4096, ntiles / 16 + 64)), dim3(64), 0, s, t->dt, b);
+        hipLaunchKernelGGL(k_deferred_wave, dim3(256), dim3(64), 0, s, t->dt, b);
         MARK(KI_BPELANES); MARK(KI_BPELONG);
         hipLaunchKernelGGL(k_bpe_long, dim3(std::min<uint32_t>(2048, ntiles / 4 + 8)), dim3(NT), 0, s, t->dt, b);
         MARK(KI_COUNT);
@@ -283,7 +282,7 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
         else hipLaunchKernelGGL((k_pretok<SPL_TILE_LARGE, true>), dim3(ntiles), dim3(NT), 0, s, t->dt, b);
     }
     MARK(KI_DEFER);
-    if (ntiles) hipLaunchKernelGGL(k_deferred, dim3(64), dim3(64), 0, s, t->dt, b);
+    if (ntiles) hipLaunchKernelGGL(k_deferred_wave, dim3(256), dim3(64), 0, s, t->dt, b);
     MARK(KI_BPELANES);
     if (ntiles && !small_tiles) hipLaunchKernelGGL(k_bpe_lanes64, dim3(256 * 5), dim3(64), 0, s, t->dt, b);
     MARK(KI_BPELONG);

@@ -94,6 +94,12 @@ struct Batch {
     uint32_t tpar;             // parity of this call
 };
 
+// LDS hand-over between the lanes of ONE wavefront (no workgroup barrier)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // ------------------------------------------------------------------------------------------
 __global__ void k_mark_docs(Batch b) {
     const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
@@ -758,6 +764,120 @@ __global__ void k_deferred(DeviceTables T, Batch b) {
     deferred_items(T, b, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
+// The same by ONE WAVEFRONT per chain: there are few such chains (tens per 40 MB) but each is long,
+// and a lane that walks it byte by byte from HBM pays a memory round trip per character.  Here the
+// 64 lanes stage a window of DEFER_WIN bytes and its class records in LDS (classified in parallel,
+// as k_pretok does), lane 0 runs the scanner over LDS, and the window is moved along the chain.
+// A single chunk longer than the window falls back to the byte-wise walk.
+constexpr int DEFER_WIN = 2048;
+constexpr int DEFER_BACK = 4;                 // bytes staged before the start (previous character's class)
+struct WinAcc {
+    const uint8_t* rec_;
+    const uint8_t* txt_;
+    int n_;                                   // staged records; beyond: window end
+    __device__ __forceinline__ uint32_t rec(int q) const { return q < n_ ? (uint32_t)rec_[q] : (uint32_t)C_WEND; }
+    __device__ __forceinline__ uint32_t txt(int q) const { return txt_[q]; }
+    __device__ __forceinline__ uint32_t load32(int p) const {
+        return (uint32_t)txt_[p] | ((uint32_t)txt_[p + 1] << 8) | ((uint32_t)txt_[p + 2] << 16) | ((uint32_t)txt_[p + 3] << 24);
+    }
+};
+__global__ __launch_bounds__(64) void k_deferred_wave(DeviceTables T, Batch b) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_txt[DEFER_WIN + 32];
+    __shared__ uint8_t s_rec[DEFER_WIN + 32];
+    __shared__ uint8_t s_ascii[128];
+    const int lane = threadIdx.x;
+    const uint32_t nq = min(b.qcount[3], b.qcapdefer);
+    const int64_t B = b.n_bytes;
+    for (int k = lane; k < 128; k += 64) s_ascii[k] = T.ucls_stage2[((uint32_t)T.ucls_stage1[0] << T.ucls_shift) + k];
+    for (uint32_t it = blockIdx.x; it < nq; it += gridDim.x) {
+        int64_t p = b.qdefer[it];                               // wave-uniform: start of the next chunk
+        bool first_chunk = true;
+        for (;;) {                                              // one window per pass
+            if (p >= B) break;
+            const int64_t base = p >= DEFER_BACK ? p - DEFER_BACK : 0;
+            const int q0 = (int)(p - base);
+            const int nst = (int)((B - base) < (int64_t)(DEFER_WIN + 16) ? (B - base) : (int64_t)(DEFER_WIN + 16));   // staged text bytes
+            const int nrec = nst < DEFER_WIN ? nst + 1 : DEFER_WIN;     // records (one past the text = end of text)
+            wave_lds_sync();
+            for (int i = lane; i < DEFER_WIN + 32; i += 64) s_txt[i] = i < nst ? b.text[base + i] : (uint8_t)0;
+            wave_lds_sync();
+            for (int i = lane; i < nrec; i += 64) {
+                const int64_t g = base + i;
+                uint32_t r;
+                if (g >= B) r = C_EOT | CB_TSTART | CB_SYNC;
+                else if (b.skip && ((b.skip[g >> 5] >> (g & 31)) & 1u)) r = C_EOT | CB_TSTART;
+                else {
+                    const uint32_t c0 = s_txt[i];
+                    if (c0 < 0x80u) r = s_ascii[c0];
+                    else if (c0 < 0xC0u) r = C_CONT;
+                    else {
+                        uint32_t want = utf8_len(c0), len = 1;
+                        while (len < want && i + (int)len < nst && (s_txt[i + len] & 0xC0u) == 0x80u) len++;
+                        const WinAcc tx{s_rec, s_txt, 0};
+                        const uint32_t cls = (len == want) ? cp_class(T, decode_at(tx, i, c0)) : (uint32_t)C_P;
+                        r = cls | ((len - 1) << CB_LEN_SHIFT);
+                    }
+                    if ((b.tstart[g >> 5] >> (g & 31)) & 1u) r |= CB_TSTART | CB_SYNC;
+                }
+                s_rec[i] = (uint8_t)r;
+            }
+            wave_lds_sync();
+            // lane 0 walks the chain inside the window; state back to the wavefront through LDS-free
+            // broadcasts: next position, and whether the chain is finished
+            int64_t np = p;
+            int done = 0, fallback = 0;
+            if (lane == 0) {
+                const WinAcc acc{s_rec, s_txt, nrec};
+                int q = q0;
+                bool fc = first_chunk;
+                for (;;) {
+                    if (!fc) {                                          // does a chunk start here at all?
+                        const uint32_t r = acc.rec(q);
+                        if (r == (uint32_t)C_WEND) { np = base + q; break; }       // need the next window to tell
+                        if (r & (CB_SYNC | CB_TSTART)) { done = 1; break; }
+                        int j = q - 1;
+                        while (j > 0 && (s_txt[j] & 0xC0u) == 0x80u && j > q - 4) j--;
+                        const uint32_t prev = acc.rec(j) & CB_CLASS;
+                        if (prev < C_EOT && is_sync((int)T.pattern, prev, r & CB_CLASS)) { done = 1; break; }
+                    }
+                    const int e = match_end(acc, q, (int)T.pattern);
+                    if (e == SPL_DEFER) {
+                        if (q == q0) fallback = 1;                      // longer than a whole window
+                        np = base + q;
+                        break;
+                    }
+                    fc = false;
+                    const uint32_t gp = (uint32_t)(base + q), n = (uint32_t)(e - q);
+                    const uint32_t id = probe_chunk(T, acc, q, (int)n);
+                    if (id != SPL_NO_RANK) emit_token(b, gp, id);
+                    else if (n > 1) push_long(b, gp, n);
+                    q = e;
+                    np = base + q;
+                    if (np >= B) { done = 1; break; }
+                }
+                if (fallback) {                                         // one chunk, byte-wise from HBM
+                    const GlobalAcc ga{&T, &b};
+                    const uint32_t gp = (uint32_t)np;
+                    const int e = match_end(ga, (int)gp, (int)T.pattern);
+                    const uint32_t n = (uint32_t)e - gp;
+                    const uint32_t id = probe_chunk(T, ga, (int)gp, (int)n);
+                    if (id != SPL_NO_RANK) emit_token(b, gp, id);
+                    else if (n > 1) push_long(b, gp, n);
+                    np = (int64_t)(uint32_t)e;
+                    if (np >= B) done = 1;
+                }
+            }
+            const uint32_t np_lo = __builtin_amdgcn_readfirstlane((uint32_t)np);
+            done = __builtin_amdgcn_readfirstlane(done);
+            // (a window that made no progress can only be the "need the next window" case right at its
+            //  start, which cannot happen: DEFER_BACK + 1 records are always staged before the end)
+            first_chunk = (int64_t)np_lo == p ? first_chunk : false;
+            p = (int64_t)np_lo;
+            if (done) break;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // byte_pair_encode, ONE LANE PER CHUNK (17..64 bytes), for large batches: node arrays interleaved
 // in LDS (node-major, lane-minor: conflict-free when lanes touch the same node index), merge loop
@@ -807,10 +927,6 @@ constexpr int GROUP_NMAX = 128;       // 16 lanes x 8 register slots
 constexpr int WAVE_NMAX = 512;
 constexpr uint32_t NIL16 = 0xFFFFu;
 
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
 
 template <class Emit>
 __device__ __forceinline__ void bpe_wave(const DeviceTables& T, const Batch& b, uint32_t pos, int n, uint32_t* s_id,
@@ -1763,7 +1879,7 @@ void k_pretok(DeviceTables T, Batch b) {
             TileDesc td;
             td.slot = slot; td.c_win = c_win; td.c_ovf = c_ovf; td.ovf_hi = whi > wlo ? ovf_hi : 0u;
             td.d_first = d_lo == 0xFFFFFFFFu ? 0u : d_lo; td.d_cnt = d_n; td.ovf_lo = ovf_lo;
-            td.c_own = s_wpre[(LH + TB_) >> 5];             // tile range ends on a word boundary
+            td.c_own = s_wpre[DIRECT ? (LH + TB_) >> 5 : 0];             // tile range ends on a word boundary
             b.tdesc[blockIdx.x] = td;
         }
     }
