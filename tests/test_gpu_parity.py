@@ -417,3 +417,24 @@ def test_document_search_with_skewed_document_sizes(coracle):
     tiny = [("ab" if i % 3 else "") + str(i % 10) for i in range(4000)]
     for texts in (big + tiny, tiny + big, tiny[:500] + big + tiny[500:] + big[:40]):
         assert_batch_equal("cl100k_base", texts, coracle)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cl100k_base", "o200k_base"])
+def test_queue_mode_with_window_edges_and_long_runs(coracle, name):
+    """A batch over 8 MB (queue mode: tile-owned tiles, global queues for long chunks and outgrown
+    chains, CSR assembled per tile range) that contains the window-edge documents, runs of every
+    class far longer than a window, and many tiny / empty documents."""
+    from splintr_amd import corpus
+    rng = random.Random(23)
+    texts = list(corpus.c2(8600, seed=31))
+    for lead in (700, 760, 768, 770, 900, 990, 1000, 1023, 1024, 1500):
+        for run in (" " * 600, "a" * 3000, "1" * 500, "=" * 4900, "\n" * 481, "你" * 1200, " \n" * 300, "x'" * 300,
+                    "A" * 500 + "b", "é́" * 200):
+            filler = ("lorem ipsum 12 " * 400)[:lead]
+            texts.insert(rng.randrange(len(texts)), filler + run + " tail" + str(rng.randint(0, 9)))
+    for _ in range(3000):
+        texts.insert(rng.randrange(len(texts)), rng.choice(["", "a", " ", "\n", "é", "你好", "12", "  "]))
+    texts += list(corpus.worst_case(20000))
+    assert sum(len(t.encode("utf-8")) for t in texts) > (8 << 20)
+    assert_batch_equal(name, texts, coracle)
