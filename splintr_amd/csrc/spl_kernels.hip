@@ -1217,6 +1217,7 @@ struct PretokTailLds {                                   // tile-owned tail: one
     uint32_t slab[NT / 64][DIRECT_TAB_NMAX * SUB_W];     // bpe_wave_tab's table or as bpe_wave's node arrays
 };
 static_assert(DIRECT_TAB_NMAX * SUB_W >= 3 * DIRECT_WAVE_NMAX, "a slab must hold bpe_wave's id, rank and link arrays");
+static_assert(2 * DIRECT_TAB_NMAX * SUB_W >= 3 * 512, "two slabs must hold bpe_wave's arrays for 512 nodes");
 
 template <int TB_, int RH_, bool EXPORT_MEDIUM, bool DIRECT = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPL_PRETOK_WAVES)))
@@ -1717,16 +1718,33 @@ void k_pretok(DeviceTables T, Batch b) {
                             },
                             [&](int i, uint32_t id) { emit_g(pos + (uint32_t)i, id); });
                         wave_lds_sync();
-                    } else if (n <= DIRECT_WAVE_NMAX) {
-                        bpe_wave(T, b, pos, n, slab, slab + DIRECT_WAVE_NMAX,
-                                 reinterpret_cast<uint16_t*>(slab + 2 * DIRECT_WAVE_NMAX),
-                                 reinterpret_cast<uint16_t*>(slab + 2 * DIRECT_WAVE_NMAX) + DIRECT_WAVE_NMAX, emit_g);
                     }
                 }
                 __syncthreads();
+                // 129..256 bytes: the LDS node list, a quarter of the slab per wavefront; 257..512
+                // bytes: the same with half of the slab, two wavefronts (ONE call site: a second
+                // instance of the merge loop costs the kernel registers it does not have).  The
+                // workgroup-wide fallback for what is longer costs tens of microseconds per merge.
+#pragma nounroll
+                for (int pass = 0; pass < 2; pass++) {
+                    const int cap = pass ? WAVE_NMAX : DIRECT_WAVE_NMAX, lo = pass ? DIRECT_WAVE_NMAX : DIRECT_TAB_NMAX;
+                    const uint32_t nwav = pass ? 2u : 4u;
+                    if ((uint32_t)wv < nwav) {
+                        uint32_t* const slab = s_u.t.slab[pass ? 2 * wv : wv];
+                        uint32_t seen = 0;
+                        for (uint32_t it = 0; it < nl; it++) {
+                            const int n = (int)s_lq[2 * it + 1];
+                            if (n <= lo || n > cap) continue;
+                            if ((seen++ % nwav) != (uint32_t)wv) continue;
+                            bpe_wave(T, b, s_lq[2 * it], n, slab, slab + cap, reinterpret_cast<uint16_t*>(slab + 2 * cap),
+                                     reinterpret_cast<uint16_t*>(slab + 2 * cap) + cap, emit_g);
+                        }
+                    }
+                    __syncthreads();
+                }
                 for (uint32_t it = 0; it < nl; it++) {                   // oversize: the whole workgroup
                     const int n = (int)s_lq[2 * it + 1];
-                    if (n > DIRECT_WAVE_NMAX) bpe_block_global(T, b, s_lq[2 * it], n, s_red, &s_best, s_touch, emit_g);
+                    if (n > WAVE_NMAX) bpe_block_global(T, b, s_lq[2 * it], n, s_red, &s_best, s_touch, emit_g);
                 }
                 __syncthreads();
                 if (tid == 0) {
