@@ -61,6 +61,7 @@ struct spl_tokenizer {
     size_t zero_words = 0, bitmap_words = 0;
     uint32_t* d_stage = nullptr;
     uint32_t* d_rank = nullptr;
+    uint32_t* d_aux = nullptr;    // inside d_rank's allocation
     uint2* d_q64 = nullptr; uint2* d_qlong = nullptr; uint32_t* d_qdefer = nullptr;
     uint32_t qcap64 = 0, qcaplong = 0, qcapdefer = 0;
     unsigned long long* d_dbg = nullptr;
@@ -116,7 +117,8 @@ int reserve(spl_tokenizer* t, uint64_t max_bytes, uint64_t max_docs) {
     t->zero_words = 3 * t->bitmap_words + 8;
     HIP_TRY(hipMalloc((void**)&t->d_zero, t->zero_words * 4));
     HIP_TRY(hipMalloc((void**)&t->d_stage, (nb + 8192) * 4));
-    HIP_TRY(hipMalloc((void**)&t->d_rank, (nb + 8192) * 4));
+    HIP_TRY(hipMalloc((void**)&t->d_rank, (nb + 8192) * 12));   // ranks + two words of aux per byte
+    t->d_aux = t->d_rank + (nb + 8192);
     const size_t tiles_s = (size_t)(nb / TileGeom<SPL_TILE_SMALL>::TBv) + 2;
     t->qcaplong = (uint32_t)(nb / 2 + 64);          // long chunks AND every miss of a deferred segment
     t->qcapdefer = (uint32_t)(2 * tiles_s + 64);
@@ -191,7 +193,7 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
     b.qcount = t->d_zero + (special ? 3 : 2) * uw;
     t->last_qcount = b.qcount;
     b.sp_lits = t->d_sp_lits; b.n_special = special ? (uint32_t)t->specials.size() : 0u;
-    b.stage = t->d_stage; b.rank_scr = t->d_rank;
+    b.stage = t->d_stage; b.rank_scr = t->d_rank; b.aux = t->d_aux;
     b.q64 = t->d_q64; b.qlong = t->d_qlong; b.qdefer = t->d_qdefer;
     b.qcap64 = t->qcap64; b.qcaplong = t->qcaplong; b.qcapdefer = t->qcapdefer;
     b.dbg = (t->dbg_on || t->prof) ? t->d_dbg : nullptr;

@@ -68,7 +68,8 @@ struct Batch {
     uint32_t n_special;
     uint32_t* tbits;       // bitmap: a token starts at this byte
     uint32_t* stage;       // id of the token starting at this byte
-    uint32_t* rank_scr;    // per-byte scratch for oversize chunks (bpe_block_global)
+    uint32_t* rank_scr;    // per-byte scratch for oversize chunks (bpe_block_rounds)
+    uint32_t* aux;         // two more words per byte for the same
     uint32_t* qcount;      // [0] q64 [2] qlong [3] qdefer (global queues), [6] [7] work cursors of k_bpe_long
     uint2* q64;            // large batches: 17..64-byte misses, appended one workgroup at a time
     uint2* qlong; uint32_t* qdefer;
@@ -921,8 +922,7 @@ __global__ __launch_bounds__(64) void k_bpe_lanes64(DeviceTables T, Batch b) {
 // (rank << 9 | index) gives the leftmost minimum, lane 0 relinks, lanes 1 and 2 re-rank the two
 // affected pairs concurrently.  No workgroup barrier: the four wavefronts of a workgroup work
 // on four different chunks.
-// bpe_block_global: chunks beyond WAVE_NMAX (pathological single-class runs): one workgroup per
-// chunk, nodes in HBM scratch (ids in stage[], ranks in rank_scr[]), cached per-thread minima.
+// Beyond WAVE_NMAX (pathological single-class runs): bpe_block_lds, then bpe_block_rounds.
 constexpr int GROUP_NMAX = 128;       // 16 lanes x 8 register slots
 constexpr int WAVE_NMAX = 512;
 constexpr uint32_t NIL16 = 0xFFFFu;
@@ -980,67 +980,230 @@ __device__ __forceinline__ void bpe_wave(const DeviceTables& T, const Batch& b, 
     wave_lds_sync();
 }
 
+// bpe_block_lds: chunks of up to BLOCK_LDS_NMAX bytes by the WHOLE workgroup with the node list
+// in LDS (the layout of bpe_wave, capacity `cap` nodes): every thread scans its nodes for the
+// minimum, a workgroup min-reduction picks the leftmost one, one thread relinks while two others
+// (in other wavefronts) re-rank the two affected pairs.  Three barriers and one memory round trip
+// per merge.
+constexpr int BLOCK_LDS_NMAX = 2048;      // index bits in the reduction key
 template <class Emit>
-__device__ __forceinline__ void bpe_block_global(const DeviceTables& T, const Batch& b, uint32_t pos, int n, unsigned long long* s_red,
-                                 unsigned long long* s_best, int* s_touch, Emit emit) {
+__device__ __forceinline__ void bpe_block_lds(const DeviceTables& T, const Batch& b, uint32_t pos, int n, uint32_t* s_id,
+                                              uint32_t* s_rk, uint16_t* s_nx, uint16_t* s_pv, uint32_t* s_red4, Emit emit) {
     const int tid = threadIdx.x;
-    uint32_t* ids = b.stage + pos;
-    uint32_t* rks = b.rank_scr + pos;
-    for (int i = tid; i < n; i += NT) ids[i] = T.byte_id[b.text[pos + i]];
+    for (int i = tid; i < n; i += NT) {
+        s_id[i] = T.byte_id[b.text[pos + i]];
+        s_nx[i] = (uint16_t)(i + 1 < n ? i + 1 : (int)NIL16);
+        s_pv[i] = (uint16_t)(i > 0 ? i - 1 : (int)NIL16);
+    }
     __syncthreads();
-    for (int i = tid; i < n; i += NT) rks[i] = (i + 1 < n) ? pair_rank(T, ids[i], ids[i + 1]) : SPL_NO_RANK;
+    for (int i = tid; i < n; i += NT) s_rk[i] = (i + 1 < n) ? pair_rank(T, s_id[i], s_id[i + 1]) : SPL_NO_RANK;
     __syncthreads();
-    bool dirty = true;
-    unsigned long long mine = ~0ull;          // (rank << 32 | index): min == leftmost minimum
     for (;;) {
-        if (dirty) {
-            mine = ~0ull;
-            for (int i = tid; i < n; i += NT) {
-                const unsigned long long c = ((unsigned long long)rks[i] << 32) | (uint32_t)i;
-                mine = c < mine ? c : mine;
-            }
-            dirty = false;
+        uint32_t key = 0xFFFFFFFFu;
+        for (int i = tid; i < n; i += NT) {
+            const uint32_t r = s_rk[i];
+            const uint32_t k = r == SPL_NO_RANK ? 0xFFFFFFFFu : ((r << 11) | (uint32_t)i);
+            key = k < key ? k : key;
         }
-        unsigned long long x = mine;
+        uint32_t m = row16_min(key);
+        const uint32_t r0 = __builtin_amdgcn_readlane(m, 0), r1 = __builtin_amdgcn_readlane(m, 16);
+        const uint32_t r2 = __builtin_amdgcn_readlane(m, 32), r3 = __builtin_amdgcn_readlane(m, 48);
+        const uint32_t a = r0 < r1 ? r0 : r1, c = r2 < r3 ? r2 : r3;
+        m = a < c ? a : c;
+        if ((tid & 63) == 0) s_red4[tid >> 6] = m;
+        __syncthreads();
+        m = s_red4[0];
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const unsigned long long y = __shfl_xor(x, d);
-            x = y < x ? y : x;
-        }
-        if ((tid & 63) == 0) s_red[tid >> 6] = x;
+        for (int w = 1; w < NT / 64; w++) m = s_red4[w] < m ? s_red4[w] : m;
+        if (m == 0xFFFFFFFFu) break;
+        const uint32_t mi = m & 2047u, mn = m >> 11;
+        const uint32_t j = s_nx[mi];
+        const uint32_t j2 = s_nx[j];
+        const uint32_t h = s_pv[mi];
+        const uint32_t id_j2 = j2 != NIL16 ? s_id[j2] : 0u;
+        const uint32_t id_h = h != NIL16 ? s_id[h] : 0u;
         __syncthreads();
         if (tid == 0) {
-            unsigned long long m = s_red[0];
-            for (int wv = 1; wv < NT / 64; wv++) m = s_red[wv] < m ? s_red[wv] : m;
-            *s_best = m;
+            s_id[mi] = mn;
+            s_id[j] = SPL_DEAD;
+            s_rk[j] = SPL_NO_RANK;
+            s_nx[mi] = (uint16_t)j2;
+            if (j2 != NIL16) s_pv[j2] = (uint16_t)mi;
+        } else if (tid == 64) {
+            s_rk[mi] = j2 != NIL16 ? pair_rank(T, mn, id_j2) : SPL_NO_RANK;
+        } else if (tid == 128) {
+            if (h != NIL16) s_rk[h] = pair_rank(T, id_h, mn);
         }
-        __syncthreads();
-        const unsigned long long best = *s_best;
-        const uint32_t mn = (uint32_t)(best >> 32);
-        if (mn == SPL_NO_RANK) break;
-        const int mi = (int)(uint32_t)best;
-        if (tid == 0) {     // the neighbour searches walk tomb-stones; at most a token's length of them
-            int j = mi + 1;
-            while (ids[j] == SPL_DEAD) j++;
-            ids[mi] = mn;
-            ids[j] = SPL_DEAD;
-            rks[j] = SPL_NO_RANK;
-            int j2 = j + 1;
-            while (j2 < n && ids[j2] == SPL_DEAD) j2++;
-            rks[mi] = j2 < n ? pair_rank(T, mn, ids[j2]) : SPL_NO_RANK;
-            int h = mi - 1;
-            while (h >= 0 && ids[h] == SPL_DEAD) h--;
-            if (h >= 0) rks[h] = pair_rank(T, ids[h], mn);
-            s_touch[0] = mi; s_touch[1] = j; s_touch[2] = h;
-            __threadfence_block();
-        }
-        __syncthreads();
-        const int a0 = s_touch[0] % NT, a1 = s_touch[1] % NT, a2 = s_touch[2] < 0 ? -1 : s_touch[2] % NT;
-        if (tid == a0 || tid == a1 || tid == a2) dirty = true;
         __syncthreads();
     }
-    // survivors become tokens
     for (int i = tid; i < n; i += NT) {
+        const uint32_t id = s_id[i];
+        if (id != SPL_DEAD && id != SPL_NO_RANK) emit(pos + (uint32_t)i, id);
+    }
+    __syncthreads();
+}
+
+// bpe_block_rounds: chunks beyond the LDS capacities (pathological single-class runs of any
+// length): one workgroup per chunk, nodes in HBM scratch in their original slots (ids in stage[],
+// pair ranks in rank_scr[], merged-away slots are tomb-stones).  The reference's loop
+// (src/core/bpe.rs:118-190) takes the leftmost pair of minimal rank, one merge at a time; here one
+// ROUND takes EVERY pair of the minimal rank m at once -- in a run of consecutive pairs of rank m
+// the 1st, 3rd, ... (what leftmost-first leaves of such a run) -- which is the same sequence of
+// merges as long as no merge creates a pair of rank <= m.  That is checked, not assumed: each
+// selected merge looks up the two pairs it creates (left: with the final left neighbour; right:
+// with the still unmerged right neighbour, the state the sequential order passes through), the
+// leftmost merge whose new pair ranks <= m ends the round, and only the merges up to it are
+// committed.  64 KB of one character takes ~15 rounds instead of ~60 000 merges.
+// Four coalesced passes over the slots per round, each wavefront on a contiguous quarter:
+//   A  minimum rank m                        C  neighbours + new ranks of the selected -> aux[]
+//   B  selection by parity inside runs       D  commit (writes only what aux[] says)
+// Selection marks live in rank_scr (RK_SEL bit); a selected pair (a, b) owns aux[2a], aux[2a+1],
+// aux[2b], aux[2b+1], so pass D needs no neighbour search while ids and ranks change under it.
+constexpr uint32_t RK_DEAD = 0xFFFFFFFEu;     // rank slot of a merged-away node
+constexpr uint32_t RK_SEL = 0x40000000u;      // rank slot: selected for this round
+__device__ __forceinline__ uint32_t mbcnt64(unsigned long long mask) {      // set bits of `mask` below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+__device__ __forceinline__ void bpe_rounds_core(const uint8_t* text, const uint32_t* byte_id, const uint64_t* pair_tab,
+                                                          uint32_t pair_mask, uint32_t* ids, uint32_t* rks, uint32_t* aux, int n,
+                                                          uint32_t* s_red4) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    DeviceTables T{};
+    T.pair_tab = pair_tab;
+    T.pair_mask = pair_mask;
+#pragma nounroll
+    for (int i = tid; i < n; i += NT) ids[i] = byte_id[text[i]];
+    __syncthreads();
+#pragma nounroll
+    for (int i = tid; i < n; i += NT) rks[i] = (i + 1 < n) ? pair_rank(T, ids[i], ids[i + 1]) : SPL_NO_RANK;
+    __syncthreads();
+    const int groups = (n + 63) >> 6, gw = (groups + NT / 64 - 1) / (NT / 64);
+    const int g0 = wv * gw, g1 = g0 + gw < groups ? g0 + gw : groups;
+    for (;;) {
+        // A: the minimal rank
+        uint32_t key = SPL_NO_RANK;
+#pragma unroll 4
+        for (int g = g0; g < g1; g++) {
+            const int i = g * 64 + lane;
+            const uint32_t r = i < n ? rks[i] : RK_DEAD;
+            key = r < key ? r : key;
+        }
+        uint32_t m = row16_min(key);
+        {
+            const uint32_t r0 = __builtin_amdgcn_readlane(m, 0), r1 = __builtin_amdgcn_readlane(m, 16);
+            const uint32_t r2 = __builtin_amdgcn_readlane(m, 32), r3 = __builtin_amdgcn_readlane(m, 48);
+            const uint32_t x = r0 < r1 ? r0 : r1, y = r2 < r3 ? r2 : r3;
+            m = x < y ? x : y;
+        }
+        if (lane == 0) s_red4[wv] = m;
+        __syncthreads();
+        m = s_red4[0];
+#pragma unroll
+        for (int w = 1; w < NT / 64; w++) m = s_red4[w] < m ? s_red4[w] : m;
+        if (m >= RK_DEAD) break;
+        const uint32_t msel = m | RK_SEL;
+        // B: selection.  carry = alive nodes of rank m immediately before the group (its parity counts)
+        uint32_t carry = 0;
+        for (int g = g0 - 1; g >= 0 && g0 < g1; g--) {            // the run entering this quarter
+            const uint32_t r = rks[g * 64 + lane];                // (other wavefronts may be marking: m or msel)
+            const unsigned long long alive = __ballot(r != RK_DEAD), eqm = __ballot((r & ~RK_SEL) == m);
+            const unsigned long long noneq = alive & ~eqm;
+            if (noneq == 0) { carry += (uint32_t)__popcll(alive); continue; }
+            const int hb = 63 - __builtin_clzll(noneq);
+            carry += (uint32_t)__popcll((alive >> hb) >> 1);
+            break;
+        }
+        for (int g = g0; g < g1; g++) {
+            const int i = g * 64 + lane;
+            const uint32_t r = i < n ? rks[i] : RK_DEAD;
+            const unsigned long long alive = __ballot(r != RK_DEAD), eqm = __ballot(r == m);
+            const unsigned long long noneq = alive & ~eqm;
+            uint32_t off = mbcnt64(alive);                       // alive nodes below this lane in the group
+            if (mbcnt64(noneq) == 0) off += carry;               // the run comes in from the previous group
+            else {
+                int l2 = lane;
+                asm volatile("" : "+v"(l2));                     // (keeps the lane mask out of long-lived registers)
+                const unsigned long long below = (1ull << l2) - 1ull;
+                off -= (uint32_t)__popcll(alive & ((2ull << (63 - __builtin_clzll(noneq & below))) - 1ull));
+            }
+            if (r == m && !(off & 1u)) rks[i] = msel;
+            if (noneq == 0) carry += (uint32_t)__popcll(alive);
+            else carry = (uint32_t)__popcll((alive >> (63 - __builtin_clzll(noneq))) >> 1);
+        }
+        __syncthreads();
+        // C: neighbours and new ranks of every selected merge; F = leftmost one that ends the round
+        uint32_t fail = 0xFFFFFFFFu;
+        for (int g = g0; g < g1; g++) {
+            const int i = g * 64 + lane;
+            const uint32_t r = i < n ? rks[i] : RK_DEAD;
+            if (r == msel) {
+                uint32_t bb = (uint32_t)i + 1;
+                while (rks[bb] == RK_DEAD) bb++;                 // exists: slot i has a rank
+                uint32_t idl = SPL_NO_RANK, idc = SPL_NO_RANK;   // ids left and right of the new token (none: no pair)
+                {
+                    int h = i - 1;
+                    while (h >= 0 && rks[h] == RK_DEAD) h--;
+                    uint32_t leftw = 0xFFFFFFFFu;                // whose slot holds the left pair's rank
+                    if (h >= 0) {
+                        int hh = h - 1;
+                        while (hh >= 0 && rks[hh] == RK_DEAD) hh--;
+                        if (hh >= 0 && rks[hh] == msel) idl = m;                 // h merges into hh first
+                        else { leftw = (uint32_t)h; idl = ids[h]; }
+                    }
+                    aux[2 * bb] = leftw;
+                    uint32_t c = bb + 1;
+                    while (c < (uint32_t)n && rks[c] == RK_DEAD) c++;
+                    uint32_t csel = 0xFFFFFFFFu;
+                    if (c < (uint32_t)n) { idc = ids[c]; csel = rks[c] == msel ? c : csel; }
+                    aux[2 * bb + 1] = csel;
+                }
+#pragma nounroll
+                for (int side = 0; side < 2; side++) {           // (one lookup site: registers)
+                    const uint32_t q = pair_rank(T, side ? m : idl, side ? idc : m);
+                    aux[2 * i + side] = q;
+                    if (q <= m) fail = (uint32_t)i < fail ? (uint32_t)i : fail;
+                }
+            }
+        }
+        fail = row16_min(fail);
+        {
+            const uint32_t r0 = __builtin_amdgcn_readlane(fail, 0), r1 = __builtin_amdgcn_readlane(fail, 16);
+            const uint32_t r2 = __builtin_amdgcn_readlane(fail, 32), r3 = __builtin_amdgcn_readlane(fail, 48);
+            const uint32_t x = r0 < r1 ? r0 : r1, y = r2 < r3 ? r2 : r3;
+            fail = x < y ? x : y;
+        }
+        if (lane == 0) s_red4[wv] = fail;
+        __syncthreads();
+        fail = s_red4[0];
+#pragma unroll
+        for (int w = 1; w < NT / 64; w++) fail = s_red4[w] < fail ? s_red4[w] : fail;
+        // D: commit the merges up to `fail`; the others lose their mark
+        for (int g = g0; g < g1; g++) {
+            const int i = g * 64 + lane;
+            const uint32_t r = i < n ? rks[i] : RK_DEAD;
+            if (r == msel) {
+                if ((uint32_t)i > fail) { rks[i] = m; continue; }
+                uint32_t bb = (uint32_t)i + 1;
+                while (rks[bb] == RK_DEAD) bb++;                 // only this lane ever writes slot bb
+                const uint32_t ql = aux[2 * i], qr = aux[2 * i + 1], leftw = aux[2 * bb], csel = aux[2 * bb + 1];
+                uint32_t nr = qr;
+                if (csel != 0xFFFFFFFFu && csel <= fail) nr = aux[2 * (size_t)csel];   // the right neighbour merges too
+                ids[i] = m;
+                ids[bb] = SPL_DEAD;
+                rks[bb] = RK_DEAD;
+                rks[i] = nr;
+                if (leftw != 0xFFFFFFFFu) rks[leftw] = ql;
+            }
+        }
+        __syncthreads();
+    }
+}
+template <class Emit>
+__device__ __forceinline__ void bpe_block_rounds(const DeviceTables& T, const Batch& b, uint32_t pos, int n, uint32_t* s_red4,
+                                                 Emit emit) {
+    uint32_t* ids = b.stage + pos;
+    bpe_rounds_core(b.text + pos, T.byte_id, T.pair_tab, T.pair_mask, ids, b.rank_scr + pos, b.aux + 2 * (size_t)pos, n, s_red4);
+    for (int i = threadIdx.x; i < n; i += NT) {           // survivors become tokens
         const uint32_t id = ids[i];
         if (id != SPL_DEAD && id != SPL_NO_RANK) emit(pos + (uint32_t)i, id);
     }
@@ -1218,6 +1381,8 @@ struct PretokTailLds {                                   // tile-owned tail: one
 };
 static_assert(DIRECT_TAB_NMAX * SUB_W >= 3 * DIRECT_WAVE_NMAX, "a slab must hold bpe_wave's id, rank and link arrays");
 static_assert(2 * DIRECT_TAB_NMAX * SUB_W >= 3 * 512, "two slabs must hold bpe_wave's arrays for 512 nodes");
+constexpr int DIRECT_BLOCK_NMAX = 1024;   // workgroup-wide LDS node list in the whole slab
+static_assert((NT / 64) * DIRECT_TAB_NMAX * SUB_W >= 3 * DIRECT_BLOCK_NMAX, "the slab must hold the workgroup-wide list");
 
 template <int TB_, int RH_, bool EXPORT_MEDIUM, bool DIRECT = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPL_PRETOK_WAVES)))
@@ -1251,8 +1416,6 @@ void k_pretok(DeviceTables T, Batch b) {
     __shared__ uint32_t s_dq[12];                        // [0] long-list fill [1] deferred count [2],[3] deferred starts
                                                          // [4] end of the overflow range [5] chain cursor [6] chain done
     __shared__ unsigned long long s_red[NT / 64];
-    __shared__ unsigned long long s_best;
-    __shared__ int s_touch[3];
     uint8_t* const s_txt = reinterpret_cast<uint8_t*>(s_txt32);
     uint8_t* const s_rec = reinterpret_cast<uint8_t*>(s_rec32);
     // probe list of a small window: p | n << 16 per chunk, in the (then still unused) substring table
@@ -1744,7 +1907,7 @@ void k_pretok(DeviceTables T, Batch b) {
                 }
                 for (uint32_t it = 0; it < nl; it++) {                   // oversize: the whole workgroup
                     const int n = (int)s_lq[2 * it + 1];
-                    if (n > WAVE_NMAX) bpe_block_global(T, b, s_lq[2 * it], n, s_red, &s_best, s_touch, emit_g);
+                    if (n > WAVE_NMAX) bpe_block_rounds(T, b, s_lq[2 * it], n, s_wsum, emit_g);
                 }
                 __syncthreads();
                 if (tid == 0) {
@@ -1796,21 +1959,23 @@ void k_pretok(DeviceTables T, Batch b) {
         }
         // SPL_WITH_SPECIAL: the literals that start in this tile are tokens of this tile (k_special_scan
         // left their ids in stage[] and marked their first bytes in tbits[], inside the skip spans)
+        int tid_late = tid;                                  // (64-bit values derived from tid are rebuilt after
+        asm volatile("" : "+v"(tid_late));                   //  the tail instead of living in registers across it)
         if (b.skip) {
-            if (tid < G::NBW + 1) {
-                const int64_t wi = (w0 >> 5) + tid;
-                uint32_t sp = (wi >= 0 && wi * 32 < B) ? (b.tbits[wi] & s_sk[tid]) : 0u;
-                const int lo = LH - tid * 32, hi = LH + TB_ - tid * 32;     // the tile's own range inside this word
+            if (tid_late < G::NBW + 1) {
+                const int64_t wi = (w0 >> 5) + tid_late;
+                uint32_t sp = (wi >= 0 && wi * 32 < B) ? (b.tbits[wi] & s_sk[tid_late]) : 0u;
+                const int lo = LH - tid_late * 32, hi = LH + TB_ - tid_late * 32;     // the tile's own range inside this word
                 if (hi <= 0 || lo >= 32) sp = 0;
                 else {
                     if (lo > 0) sp &= ~0u << lo;
                     if (hi < 32) sp &= (1u << hi) - 1u;
                 }
-                if (sp) atomicOr(&s_tbits[tid], sp);
+                if (sp) atomicOr(&s_tbits[tid_late], sp);
                 while (sp) {
                     const int bit = __ffs(sp) - 1;
                     sp &= sp - 1;
-                    s_ids[tid * 32 + bit] = b.stage[w0 + tid * 32 + bit];
+                    s_ids[tid_late * 32 + bit] = b.stage[w0 + tid_late * 32 + bit];
                 }
             }
             __syncthreads();
@@ -1818,25 +1983,25 @@ void k_pretok(DeviceTables T, Batch b) {
         // the first NT documents of the window are fetched now: their load overlaps the count below
         const bool last_tile = blockIdx.x == gridDim.x - 1;
         const uint64_t own_lo = (uint64_t)t0, own_hi = (uint64_t)(t0 + TB_);
-        const uint64_t d_first = (uint64_t)dw + tid;
+        const uint64_t d_first = (uint64_t)dw + (uint32_t)tid_late;
         uint64_t p_first = ~0ull;
         if (d_first <= b.n_docs) p_first = b.doc_off[d_first];      // entry n_docs is the end of the corpus
         // ---- token count of the tile: window bitmap + overflow range --------------------------------
         uint32_t c_win;
         {
-            uint32_t word = tid < G::NBW + 1 ? s_tbits[tid] : 0u;
+            uint32_t word = tid_late < G::NBW + 1 ? s_tbits[tid_late] : 0u;
             const uint32_t cnt = __popc(word);
             uint32_t x = wave_scan_incl(cnt);
             if (lane == 63) s_wsum[wv] = x;
             __syncthreads();
             uint32_t basew = x - cnt;
             for (int k = 0; k < wv; k++) basew += s_wsum[k];
-            if (tid == NT - 1) s_total = basew + cnt;
-            if (tid < G::NBW + 2) s_wpre[tid] = basew;
+            if (tid_late == NT - 1) s_total = basew + cnt;
+            if (tid_late < G::NBW + 2) s_wpre[tid_late] = basew;
             while (word) {                                  // token positions in order
                 const int bit = __ffs(word) - 1;
                 word &= word - 1;
-                s_cpos[basew++] = (uint16_t)(tid * 32 + bit);
+                s_cpos[basew++] = (uint16_t)(tid_late * 32 + bit);
             }
             __syncthreads();
             c_win = s_total;
@@ -1846,9 +2011,9 @@ void k_pretok(DeviceTables T, Batch b) {
         uint32_t c_ovf = 0;
         if (whi > wlo) {
             uint32_t mine = 0;
-            for (uint32_t w = wlo + tid; w < whi; w += NT)
+            for (uint32_t w = wlo + tid_late; w < whi; w += NT)
                 mine += __popc(__hip_atomic_load(&b.tbits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            if (tid == 0) s_dq[9] = 0;
+            if (tid_late == 0) s_dq[9] = 0;
             __syncthreads();
             if (mine) atomicAdd(&s_dq[9], mine);
             __syncthreads();
@@ -1860,17 +2025,17 @@ void k_pretok(DeviceTables T, Batch b) {
         //  waits for another workgroup, so a tile that is slow -- long chunks, a chain that runs far
         //  beyond the window -- only delays itself)
         const bool queue_mode = b.qcount != nullptr;          // long chunks / chains went to the global queues
-        if (tid == 0 && !queue_mode) atomicAdd(&b.tctl[16 + b.tpar * b.tgroups + (blockIdx.x >> 6)], (uint32_t)total);
-        if (queue_mode && tid < TILE_BITS_W)
-            b.tile_bits[(size_t)blockIdx.x * TILE_BITS_W + tid] = tid < G::NBW + 1 ? s_tbits[tid] : 0u;
+        if (tid_late == 0 && !queue_mode) atomicAdd(&b.tctl[16 + b.tpar * b.tgroups + (blockIdx.x >> 6)], (uint32_t)total);
+        if (queue_mode && tid_late < TILE_BITS_W)
+            b.tile_bits[(size_t)blockIdx.x * TILE_BITS_W + tid_late] = tid_late < G::NBW + 1 ? s_tbits[tid_late] : 0u;
 #ifdef SPL_DEBUG_STAMPS
         if (b.dbg) blk_w2 = (unsigned long long)wall_clock64();
 #endif
         const uint32_t slot = blockIdx.x * b.tslot;                // fixed slots: nothing to wait for
-        for (uint32_t k = tid; k < c_win; k += NT) b.tile_ids[slot + k] = s_ids[s_cpos[k]];
+        for (uint32_t k = tid_late; k < c_win; k += NT) b.tile_ids[slot + k] = s_ids[s_cpos[k]];
         uint32_t d_lo = 0xFFFFFFFFu, d_n = 0;
         for (uint32_t db = dw;; db += NT) {
-            const uint64_t d = (uint64_t)db + tid;
+            const uint64_t d = (uint64_t)db + tid_late;
             uint64_t p = p_first;
             if (db != dw) { p = ~0ull; if (d <= b.n_docs) p = b.doc_off[d]; }
             const bool in = d <= b.n_docs && (p < own_hi || last_tile);
@@ -1891,9 +2056,11 @@ void k_pretok(DeviceTables T, Batch b) {
                     d_n += (uint32_t)__popcll(mk);
                 }
             }
-            if (!__syncthreads_or(tid == NT - 1 && in)) break;
+            if (tid_late == NT - 1) s_dq[10] = in ? 1u : 0u;     // more documents beyond this batch of NT?
+            __syncthreads();
+            if (!s_dq[10]) break;
         }
-        if (tid == 0) {
+        if (tid_late == 0) {
             TileDesc td;
             td.slot = slot; td.c_win = c_win; td.c_ovf = c_ovf; td.ovf_hi = whi > wlo ? ovf_hi : 0u;
             td.d_first = d_lo == 0xFFFFFFFFu ? 0u : d_lo; td.d_cnt = d_n; td.ovf_lo = ovf_lo;
@@ -1903,8 +2070,8 @@ void k_pretok(DeviceTables T, Batch b) {
     }
     SPL_STAMP(8);
 #ifdef SPL_DEBUG_STAMPS
-    if (b.dbg && tid == 0 && blockIdx.x == gridDim.x / 2) b.dbg[12] = (unsigned long long)wall_clock64();
-    if (b.dbg && tid == 0 && blockIdx.x < SPL_DEBUG_BLOCKS) {
+    if (b.dbg && tid_late == 0 && blockIdx.x == gridDim.x / 2) b.dbg[12] = (unsigned long long)wall_clock64();
+    if (b.dbg && tid_late == 0 && blockIdx.x < SPL_DEBUG_BLOCKS) {
         // wall-clock ticks: start, end of the merge phase, counts done, end
         unsigned long long* r = b.dbg + 16 + 4 * blockIdx.x;
         r[0] = blk_t0;
@@ -1913,7 +2080,11 @@ void k_pretok(DeviceTables T, Batch b) {
         r[3] = (unsigned long long)wall_clock64();
     }
 #endif
-    if (b.dbg && tid == 0) atomicMax(&b.dbg[15], (unsigned long long)wall_clock64());
+    {
+        int tid_end = tid;                                   // (as tid_late: nothing tid-derived kept for this)
+        asm volatile("" : "+v"(tid_end));
+        if (b.dbg && tid_end == 0) atomicMax(&b.dbg[15], (unsigned long long)wall_clock64());
+    }
 #undef SPL_STAMP
 }
 
@@ -2091,9 +2262,8 @@ __global__ __launch_bounds__(NT) void k_bpe_long(DeviceTables T, Batch b) {
     __shared__ uint32_t s_rk[NT / 64][WAVE_NMAX];
     __shared__ uint16_t s_nx[NT / 64][WAVE_NMAX];
     __shared__ uint16_t s_pv[NT / 64][WAVE_NMAX];
-    __shared__ unsigned long long s_red[NT / 64];
-    __shared__ unsigned long long s_best;
-    __shared__ int s_touch[3];
+    __shared__ uint32_t s_red4[NT / 64];
+    static_assert((NT / 64) * WAVE_NMAX == BLOCK_LDS_NMAX, "the four slabs together hold the workgroup-wide list");
     static_assert(LONG_SMALL_NMAX == GROUP_NMAX, "the front of the queue is what the group phase takes");
     const uint32_t nq = min(b.qcount[2], b.qcaplong);          // front: chunks of up to GROUP_NMAX bytes
     const uint32_t nbig = min(b.qcount[4], b.qcaplong);        // back: larger ones
@@ -2138,8 +2308,11 @@ __global__ __launch_bounds__(NT) void k_bpe_long(DeviceTables T, Batch b) {
     for (int w = 0; w < NT / 64; w++)
         for (uint32_t it = blockIdx.x * (NT / 64) + w; it < nbig; it += nwaves) {
             const uint2 item = *(qbig - it);
-            if ((int)item.y > WAVE_NMAX)
-                bpe_block_global(T, b, item.x, (int)item.y, s_red, &s_best, s_touch,
+            if ((int)item.y > WAVE_NMAX && (int)item.y <= BLOCK_LDS_NMAX)     // the four wavefront slabs as ONE list
+                bpe_block_lds(T, b, item.x, (int)item.y, &s_id[0][0], &s_rk[0][0], &s_nx[0][0], &s_pv[0][0], s_red4,
+                              [&](uint32_t q, uint32_t id) { emit_token(b, q, id); });
+            else if ((int)item.y > BLOCK_LDS_NMAX)
+                bpe_block_rounds(T, b, item.x, (int)item.y, s_red4,
                                  [&](uint32_t q, uint32_t id) { emit_token(b, q, id); });
         }
 }

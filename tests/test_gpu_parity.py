@@ -150,6 +150,29 @@ def test_huge_single_chunk(coracle):
         assert_batch_equal("cl100k_base", [t, "after"], coracle)
 
 
+@pytest.mark.parametrize("geom", [1, 3])
+@pytest.mark.parametrize("name", VOCABS)
+def test_oversize_chunks_merge_by_rounds(coracle, name, geom):
+    """Chunks beyond the LDS node lists are merged a whole rank at a time (bpe_block_rounds): low-entropy
+    runs make long stretches of equal pair ranks (the parity selection inside runs) and merges whose
+    new pairs rank below the round's rank (the round must stop there), at lengths either side of
+    every capacity, in the tile kernel's tail (1) and in k_bpe_long (3)."""
+    rng = random.Random(77)
+    texts = []
+    for alphabet in ("a", "ab", "abc", "aab", "etaoin", "ABab", "\u4f60\u597d", "\u4f60\u4f60\u597d\u5417", "\u00e9e", " ", "\n",
+                     " \n", "=-", "-"):
+        for size in (513, 1023, 1025, 2047, 2049, 2500, 5000):
+            texts.append("start " + "".join(rng.choice(alphabet) for _ in range(size)) + " end")
+    for alphabet, size in (("ab", 70000), ("a", 33333), (" ", 40000), ("abcdefgh", 30000), ("\u4f60\u597d\u5417", 20000)):
+        texts.append("".join(rng.choice(alphabet) for _ in range(size)))
+    texts.append(("ab" * 3000 + "a" * 3001 + "ba" * 2999) * 3)
+    _force_tiles(name, geom)
+    try:
+        assert_batch_equal(name, texts, coracle)
+    finally:
+        _force_tiles(name, 0)
+
+
 @pytest.mark.parametrize("name", VOCABS)
 def test_special_tokens(coracle, name):
     with open(os.path.join(ROOT, "splintr_amd", "data", "special_tokens.json"), encoding="utf-8") as f:
