@@ -111,6 +111,10 @@ struct DeviceTables {
     uint32_t max_key_len;
     uint32_t pattern;         // PAT_*
     uint32_t all_bytes;       // 1 if all 256 single bytes are tokens
+    // p8: an upper bound of the length of tokens longer than 8 bytes by their first 8 bytes.  Slot =
+    // hash of the 8 bytes; entry = tag << 8 | longest such token (255 = "unbounded"), 0 = none; tag
+    // 255 matches every key (two prefixes met in the slot).  A miss is exact, a hit may be too long.
+    const uint16_t* p8_tab;    uint32_t p8_mask;
 };
 
 // ----------------------------------------------------------------------------------------
@@ -123,6 +127,12 @@ SPL_HD uint32_t mix32(uint32_t h) {
 SPL_HD uint32_t hash_tiny(uint32_t k0, uint32_t len) { return mix32(k0 * 0x9E3779B1u ^ (len * 0x27D4EB2Fu)); }
 SPL_HD uint32_t hash_t8(uint32_t k0, uint32_t k1, uint32_t len) {
     return mix32(k0 * 0x9E3779B1u ^ (k1 * 0x85EBCA77u + 0x165667B1u) ^ (len * 0x27D4EB2Fu));
+}
+SPL_HD uint32_t hash_p8(uint32_t k0, uint32_t k1) { return hash_t8(k0, k1, 9u); }
+SPL_HD uint32_t p8_tag(uint32_t h) { return (h >> 24) % 254u + 1u; }                 // 1..254
+SPL_HD uint32_t p8_len(const uint16_t* tab, uint32_t mask, uint32_t k0, uint32_t k1) {   // 0: no longer token starts so
+    const uint32_t h = hash_p8(k0, k1), e = tab[h & mask], t = e >> 8;
+    return (t == 255u || t == p8_tag(h)) ? (e & 0xFFu) : 0u;
 }
 SPL_HD uint32_t hash_short(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len) {
     uint32_t h = k0 * 0x9E3779B1u ^ (k1 * 0x85EBCA77u + 0x165667B1u) ^ (k2 * 0xC2B2AE3Du) ^ (len * 0x27D4EB2Fu);

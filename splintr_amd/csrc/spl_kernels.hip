@@ -236,6 +236,18 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
     return x;
 }
 
+// The same for the running maximum (values are non-negative: shifted-in zeros are neutral).
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t x) {
+    auto mx = [](uint32_t a, int b) { return a > (uint32_t)b ? a : (uint32_t)b; };
+    x = mx(x, __builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true));
+    x = mx(x, __builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true));
+    x = mx(x, __builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true));
+    x = mx(x, __builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true));
+    x = mx(x, __builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false));
+    x = mx(x, __builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false));
+    return x;
+}
+
 // Alive bitmaps are arrays of 32-bit words (64-bit shifts and bit scans are multi-instruction
 // and slow on the vector ALU; v_ffbl_b32 / v_ffbh_u32 / 32-bit shifts are single full-rate ops).
 template <int NW> __device__ __forceinline__ int next_set_bit(const uint32_t (&a)[NW], int from) {
@@ -466,6 +478,54 @@ __device__ __forceinline__ uint32_t t8_finish(const DeviceTables& T, uint32_t k0
     return probe_t8(T, k0, k1, n);
 }
 
+// The merge loop of one 16-lane group over `n` <= 16 nodes whose substring ids are tabulated: lane
+// gl owns node gl, `row` is ITS table row, `id` its byte's id.  Survivors go to emit(gl, id).
+template <class Emit>
+__device__ __forceinline__ void group16_merge(const DeviceTables& T, const uint32_t* row, uint32_t id, int n, Emit emit) {
+    const int lane = threadIdx.x & 63;
+    const int gl = lane & 15;
+    const int gbase = lane - gl;
+    const bool own = gl < n;
+    uint32_t rk = (gl + 1 < n) ? row[0] : SPL_NO_RANK;          // initial ranks (bpe.rs:114-116)
+    uint32_t alive = n >= 16 ? 0xFFFFu : ((1u << n) - 1u);       // group-uniform, kept by every lane
+    for (;;) {
+        const uint32_t key = rk == SPL_NO_RANK ? 0xFFFFFFFFu : ((rk << 8) | (uint32_t)gl);
+        const uint32_t m = row16_min(key);
+        const bool active = m != 0xFFFFFFFFu;
+        if (!__any(active)) break;
+        const int mi = (int)(m & 255u);
+        const uint32_t mn = m >> 8;
+        const uint32_t above = active ? alive & ~((2u << mi) - 1u) : 1u;
+        const int j = __ffs((int)above) - 1;
+        const uint32_t above2 = above & (above - 1u);
+        const int j2 = above2 ? __ffs((int)above2) - 1 : -1;
+        const uint32_t above3 = above2 & (above2 - 1u);
+        const int e_r = above3 ? __ffs((int)above3) - 1 : n;    // end of the pair (mi, j2)
+        const int e_mi = j2 >= 0 ? j2 : n;                       // end of the merged node
+        const uint32_t below = active ? alive & ((1u << mi) - 1u) : 0u;
+        const int h = below ? 31 - __clz((int)below) : -1;
+        const int len_r = e_r - mi, len_h = e_mi - h;
+        // Branch-free update: every lane reads the one cell of its own row it could need (the owner
+        // of mi the cell of the pair (mi, j2), everybody else -- of whom only the owner of h matters
+        // -- the cell of (h, mi)); selects pick the three lanes that change.  Only spans longer than
+        // the table (rare) take the branch to the pair table.
+        const bool is_mi = gl == mi, is_h = gl == h;
+        const int len = is_mi ? len_r : len_h;
+        const bool far = active && len > SUB_LMAX && ((is_mi && j2 >= 0) || is_h);
+        const int cell = len - 2 < 0 ? 0 : len - 2 > SUB_W - 1 ? SUB_W - 1 : len - 2;
+        uint32_t nr = row[cell];
+        if (__any(far)) {
+            const uint32_t id_j2 = __shfl(id, gbase + (j2 & 15));     // only long spans need neighbour ids
+            if (far) nr = is_mi ? pair_rank(T, mn, id_j2) : pair_rank(T, id, mn);
+        }
+        nr = (is_mi && j2 < 0) ? SPL_NO_RANK : nr;
+        rk = (active && (is_mi || is_h)) ? nr : (active && gl == j) ? SPL_NO_RANK : rk;
+        id = (active && is_mi) ? mn : id;
+        alive = active ? alive & ~(1u << j) : alive;
+    }
+    if (own && ((alive >> gl) & 1u) && id != SPL_NO_RANK) emit(gl, id);
+}
+
 template <class Emit>
 __device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const LdsAcc& tx, int p, int n, uint32_t* sub,
                                                 Emit emit) {
@@ -507,44 +567,7 @@ __device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const Lds
             if (SUB_LMAX >= 8) row[6] = t8_finish(T, w0, w1, 8u, qc);
         }
     }
-    uint32_t rk = (gl + 1 < n) ? row[0] : SPL_NO_RANK;          // initial ranks (bpe.rs:114-116)
-    uint32_t alive = n >= 16 ? 0xFFFFu : ((1u << n) - 1u);       // group-uniform, kept by every lane
-    for (;;) {
-        const uint32_t key = rk == SPL_NO_RANK ? 0xFFFFFFFFu : ((rk << 8) | (uint32_t)gl);
-        const uint32_t m = row16_min(key);
-        const bool active = m != 0xFFFFFFFFu;
-        if (!__any(active)) break;
-        const int mi = (int)(m & 255u);
-        const uint32_t mn = m >> 8;
-        const uint32_t above = active ? alive & ~((2u << mi) - 1u) : 1u;
-        const int j = __ffs((int)above) - 1;
-        const uint32_t above2 = above & (above - 1u);
-        const int j2 = above2 ? __ffs((int)above2) - 1 : -1;
-        const uint32_t above3 = above2 & (above2 - 1u);
-        const int e_r = above3 ? __ffs((int)above3) - 1 : n;    // end of the pair (mi, j2)
-        const int e_mi = j2 >= 0 ? j2 : n;                       // end of the merged node
-        const uint32_t below = active ? alive & ((1u << mi) - 1u) : 0u;
-        const int h = below ? 31 - __clz((int)below) : -1;
-        const int len_r = e_r - mi, len_h = e_mi - h;
-        // Branch-free update: every lane reads the one cell of its own row it could need (the owner
-        // of mi the cell of the pair (mi, j2), everybody else -- of whom only the owner of h matters
-        // -- the cell of (h, mi)); selects pick the three lanes that change.  Only spans longer than
-        // the table (rare) take the branch to the pair table.
-        const bool is_mi = gl == mi, is_h = gl == h;
-        const int len = is_mi ? len_r : len_h;
-        const bool far = active && len > SUB_LMAX && ((is_mi && j2 >= 0) || is_h);
-        const int cell = len - 2 < 0 ? 0 : len - 2 > SUB_W - 1 ? SUB_W - 1 : len - 2;
-        uint32_t nr = row[cell];
-        if (__any(far)) {
-            const uint32_t id_j2 = __shfl(id, gbase + (j2 & 15));     // only long spans need neighbour ids
-            if (far) nr = is_mi ? pair_rank(T, mn, id_j2) : pair_rank(T, id, mn);
-        }
-        nr = (is_mi && j2 < 0) ? SPL_NO_RANK : nr;
-        rk = (active && (is_mi || is_h)) ? nr : (active && gl == j) ? SPL_NO_RANK : rk;
-        id = (active && is_mi) ? mn : id;
-        alive = active ? alive & ~(1u << j) : alive;
-    }
-    if (own && ((alive >> gl) & 1u) && id != SPL_NO_RANK) emit(gl, id);
+    group16_merge(T, row, id, n, emit);
 }
 
 // The same merge loop for ONE chunk of up to 64 bytes per WAVEFRONT, one node per lane.  Everything
@@ -588,6 +611,46 @@ __device__ __forceinline__ void bpe_wave64_regs(const DeviceTables& T, int n, By
     if (lane < n && ((alive >> lane) & 1ull) && id != SPL_NO_RANK) emit(lane, id);
 }
 
+// The merge loop of one WAVEFRONT over the nodes in `alive` (lanes of a range that ends at `end`),
+// with tabulated substring ids: `row` is the lane's own table row, `rk` its pair's rank, `idv` its id.
+template <class Emit>
+__device__ __forceinline__ void wave64_merge(const DeviceTables& T, const uint32_t* row, unsigned long long alive, int end,
+                                             uint32_t rk, uint32_t idv, Emit emit) {
+    const int lane = threadIdx.x & 63;
+    for (;;) {
+        const uint32_t key = rk == SPL_NO_RANK ? 0xFFFFFFFFu : ((rk << 6) | (uint32_t)lane);
+        uint32_t m = row16_min(key);
+        const uint32_t r0 = __builtin_amdgcn_readlane(m, 0), r1 = __builtin_amdgcn_readlane(m, 16);
+        const uint32_t r2 = __builtin_amdgcn_readlane(m, 32), r3 = __builtin_amdgcn_readlane(m, 48);
+        const uint32_t a = r0 < r1 ? r0 : r1, c = r2 < r3 ? r2 : r3;
+        m = a < c ? a : c;                                  // wave-uniform
+        if (m == 0xFFFFFFFFu) break;
+        const int mi = (int)(m & 63u);
+        const uint32_t mn = m >> 6;
+        const unsigned long long above = alive & ~((2ull << mi) - 1ull);
+        const int j = __builtin_ctzll(above);
+        const unsigned long long above2 = above & (above - 1ull);
+        const int j2 = above2 ? __builtin_ctzll(above2) : -1;
+        const unsigned long long above3 = above2 & (above2 - 1ull);
+        const int e_r = above3 ? __builtin_ctzll(above3) : end;
+        const int e_mi = j2 >= 0 ? j2 : end;
+        const unsigned long long below = alive & ((1ull << mi) - 1ull);
+        const int h = below ? 63 - __builtin_clzll(below) : -1;
+        const int len_r = e_r - mi, len_h = e_mi - h;
+        const uint32_t id_j2 = (j2 >= 0 && len_r > SUB_LMAX) ? __builtin_amdgcn_readlane(idv, j2) : 0u;
+        if (lane == mi) {
+            idv = mn;
+            rk = j2 < 0 ? SPL_NO_RANK : len_r <= SUB_LMAX ? row[len_r - 2] : pair_rank(T, mn, id_j2);
+        } else if (lane == h) {
+            rk = len_h <= SUB_LMAX ? row[len_h - 2] : pair_rank(T, idv, mn);
+        } else if (lane == j) {
+            rk = SPL_NO_RANK;
+        }
+        alive &= ~(1ull << j);
+    }
+    if (((alive >> lane) & 1ull) && idv != SPL_NO_RANK) emit(lane, idv);
+}
+
 // bpe_wave64_regs with tabulated pair ranks (see bpe_group16_tab): one chunk of 17..64 bytes per
 // wavefront, lane i owns node i and the ids of text[i, i+len), len = 2..8, in its LDS row.
 template <class Emit>
@@ -629,40 +692,54 @@ __device__ __forceinline__ void bpe_wave64_tab(const DeviceTables& T, const LdsA
             if (SUB_LMAX >= 8) row[6] = t8_finish(T, w0, w1, 8u, qc);
         }
     }
-    uint32_t rk = (lane + 1 < n) ? row[0] : SPL_NO_RANK;
-    unsigned long long alive = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
-    for (;;) {
-        const uint32_t key = rk == SPL_NO_RANK ? 0xFFFFFFFFu : ((rk << 6) | (uint32_t)lane);
-        uint32_t m = row16_min(key);
-        const uint32_t r0 = __builtin_amdgcn_readlane(m, 0), r1 = __builtin_amdgcn_readlane(m, 16);
-        const uint32_t r2 = __builtin_amdgcn_readlane(m, 32), r3 = __builtin_amdgcn_readlane(m, 48);
-        const uint32_t a = r0 < r1 ? r0 : r1, c = r2 < r3 ? r2 : r3;
-        m = a < c ? a : c;                                  // wave-uniform
-        if (m == 0xFFFFFFFFu) break;
-        const int mi = (int)(m & 63u);
-        const uint32_t mn = m >> 6;
-        const unsigned long long above = alive & ~((2ull << mi) - 1ull);
-        const int j = __builtin_ctzll(above);
-        const unsigned long long above2 = above & (above - 1ull);
-        const int j2 = above2 ? __builtin_ctzll(above2) : -1;
-        const unsigned long long above3 = above2 & (above2 - 1ull);
-        const int e_r = above3 ? __builtin_ctzll(above3) : n;
-        const int e_mi = j2 >= 0 ? j2 : n;
-        const unsigned long long below = alive & ((1ull << mi) - 1ull);
-        const int h = below ? 63 - __builtin_clzll(below) : -1;
-        const int len_r = e_r - mi, len_h = e_mi - h;
-        const uint32_t id_j2 = (j2 >= 0 && len_r > SUB_LMAX) ? __builtin_amdgcn_readlane(id, j2) : 0u;
-        if (lane == mi) {
-            id = mn;
-            rk = j2 < 0 ? SPL_NO_RANK : len_r <= SUB_LMAX ? row[len_r - 2] : pair_rank(T, mn, id_j2);
-        } else if (lane == h) {
-            rk = len_h <= SUB_LMAX ? row[len_h - 2] : pair_rank(T, id, mn);
-        } else if (lane == j) {
-            rk = SPL_NO_RANK;
+    const unsigned long long all = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+    // Independent segments.  A merge never crosses a byte boundary that no token spans, so the
+    // stretches between such boundaries merge independently of each other -- and a chunk of CJK
+    // text is mostly such boundaries (few tokens span two characters).  Lane i knows the longest
+    // token starting at byte i (its table row; beyond 8 bytes the bound of the p8 table); the
+    // running maximum of "last byte covered" says which boundaries nothing spans.  Segments of up
+    // to 16 bytes then go through the 16-lane loop four at a time, on the rows already filled:
+    // a few short loops side by side instead of one loop over every merge of the chunk.
+    unsigned long long starts = 1ull;
+    if (__any(own && (w0 & 0x80u))) {
+        int ml = 1;
+#pragma unroll
+        for (int k = 0; k < SUB_W; k++) ml = (k + 2 <= maxlen && row[k] != SPL_NO_RANK) ? k + 2 : ml;
+        if (own && n - lane > SUB_LMAX) {
+            const int l8 = (int)p8_len(T.p8_tab, T.p8_mask, w0, w1), cap = n - lane;
+            ml = l8 == 0 ? ml : (l8 == 255 || l8 > cap) ? cap : l8;
         }
-        alive &= ~(1ull << j);
+        const uint32_t cover = wave_scan_max(own ? (uint32_t)(lane + ml - 1) : 0u);
+        starts = ((__ballot(own && cover == (uint32_t)lane) << 1) | 1ull) & all;
     }
-    if (own && ((alive >> lane) & 1ull) && id != SPL_NO_RANK) emit(lane, id);
+    wave_lds_sync();                                           // rows are read across lanes from here on
+    const int gl = lane & 15, g = lane >> 4;
+    unsigned long long rem = starts, longsegs = 0;             // longsegs: starts of segments beyond 16 bytes
+    if (starts == 1ull) { rem = 0; longsegs = 1ull; }          // (the usual case: one segment, the whole chunk)
+    while (rem) {
+        int gs = 0, glen = 0;                                  // this 16-lane group's segment
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (rem) {
+                const int sk = __builtin_ctzll(rem);
+                rem &= rem - 1ull;
+                const int ek = rem ? __builtin_ctzll(rem) : n;
+                if (ek - sk > 16) longsegs |= 1ull << sk;
+                else if (g == k) { gs = sk; glen = ek - sk; }
+            }
+        }
+        const uint32_t gid = __shfl(id, gs + gl);
+        group16_merge(T, sub + (gl < glen ? gs + gl : 0) * SUB_W, gl < glen ? gid : SPL_DEAD, glen,
+                      [&](int i, uint32_t tid_) { emit(gs + i, tid_); });
+    }
+    while (longsegs) {
+        const int sk = __builtin_ctzll(longsegs);
+        longsegs &= longsegs - 1ull;
+        const unsigned long long later = starts & ~((2ull << sk) - 1ull);
+        const int ek = later ? __builtin_ctzll(later) : n;
+        const unsigned long long seg = (ek >= 64 ? ~0ull : ((1ull << ek) - 1ull)) & ~((1ull << sk) - 1ull);
+        wave64_merge(T, row, seg, ek, (lane >= sk && lane + 1 < ek) ? row[0] : SPL_NO_RANK, id, emit);
+    }
 }
 
 
@@ -1366,6 +1443,7 @@ template <int TB_, int RH_> struct TileGeom {
 #define SPL_PRETOK_WAVES 6
 #endif
 constexpr int DIRECT_LQCAP = 32;          // long-chunk list of one workgroup (refilled while a chain is continued)
+constexpr int DIRECT_WIN = 2048;           // bytes staged per turn for a chain that continues beyond the window
 constexpr int DIRECT_WAVE_NMAX = 256;     // nodes of one wavefront's LDS slab in the single-pass tail
 
 template <int TB_, int RH_> struct PretokScanLds {           // dead once the merge loop is done
@@ -1380,9 +1458,258 @@ struct PretokTailLds {                                   // tile-owned tail: one
     uint32_t slab[NT / 64][DIRECT_TAB_NMAX * SUB_W];     // bpe_wave_tab's table or as bpe_wave's node arrays
 };
 static_assert(DIRECT_TAB_NMAX * SUB_W >= 3 * DIRECT_WAVE_NMAX, "a slab must hold bpe_wave's id, rank and link arrays");
+static_assert((NT / 64) * DIRECT_TAB_NMAX * SUB_W * 4 >= 2 * (DIRECT_WIN + 32), "the slab must hold a chain window's text and records");
 static_assert(2 * DIRECT_TAB_NMAX * SUB_W >= 3 * 512, "two slabs must hold bpe_wave's arrays for 512 nodes");
 constexpr int DIRECT_BLOCK_NMAX = 1024;   // workgroup-wide LDS node list in the whole slab
 static_assert((NT / 64) * DIRECT_TAB_NMAX * SUB_W >= 3 * DIRECT_BLOCK_NMAX, "the slab must hold the workgroup-wide list");
+
+// Tile-owned tail: the long chunks of a tile, several at a time, through the table of substring
+// ids and the segments between boundaries that no token spans (see bpe_wave64_tab).  The chunks
+// are laid end to end over up to SEG_ROWS table rows, one row per thread -- a chunk's end is such a
+// boundary by construction -- and filled with two batches of probes for ALL of them together;
+// then the 16 groups of 16 lanes take the segments of up to 16 bytes (each group those that start
+// in its 16 rows), wavefronts take those of 17..64 bytes, and a chunk with a longer segment is
+// left on the list for the merge loops below.  Chinese text is chunks of 60..200 bytes made of
+// 3-byte segments: two memory round trips and a few two-step loops per tile, where the node-list
+// loops pay a round trip per merge.
+constexpr int SEG_ROWS = NT;
+constexpr int SG_OFF = 0;        // [33] row of each packed chunk's first byte (+ total)
+constexpr int SG_ITEM = 33;      // [32] its index on the long list
+constexpr int SG_HARD = 65;      // [8 + 2 zero words] bit r: nothing spans the boundary after row r
+constexpr int SG_LONG = 75;      // [16] segments of 17..64 bytes: first row | length << 16
+constexpr int SG_CTL = 91;       // [8] packed chunks, long segments, chunks to leave (bit = packing slot), chunks tried
+                                 //     (bit = list index), cut, chunks appended, mid segments
+constexpr int SG_ID = 100;       // [SEG_ROWS] id of each row's byte
+constexpr int SG_MID = SG_ID + SEG_ROWS;     // [32] segments of 9..16 bytes
+constexpr int SG_WORDS = SG_MID + 32;
+template <class EmitG>
+__device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, const Batch& b, uint32_t* s_lq, uint32_t nl,
+                                                      uint32_t* slab, uint32_t* scr, uint32_t* s_wsum4, EmitG emit_g) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t* const off = scr + SG_OFF;
+    uint32_t* const item = scr + SG_ITEM;
+    uint32_t* const hard = scr + SG_HARD;
+    uint32_t* const lseg = scr + SG_LONG;
+    uint32_t* const mseg = scr + SG_MID;
+    uint32_t* const ctl = scr + SG_CTL;
+    uint32_t* const sid = scr + SG_ID;
+    auto hbits = [&](int pos) {                              // 32 boundary bits from row `pos` on
+        const int w = pos >> 5, sh = pos & 31;
+        return (hard[w] >> sh) | (sh ? hard[w + 1] << (32 - sh) : 0u);
+    };
+    auto first_byte_of = [&](int row) {                      // global position of a row's byte
+        uint32_t k = 0;
+        while (off[k + 1] <= (uint32_t)row) k++;
+        return s_lq[2 * item[k]] + ((uint32_t)row - off[k]);
+    };
+    if (tid == 0) { ctl[3] = 0; ctl[5] = 0; hard[8] = 0; hard[9] = 0; }
+    for (;;) {
+        __syncthreads();
+        if (wv == 0) {
+            // pack: the untried chunks in list order while they fit (lane = list index); a chunk beyond
+            // SEG_ROWS goes alone -- its first SEG_ROWS bytes -- once it is the first one left
+            const uint32_t tried = ctl[3];
+            const uint32_t n = (lane < 32 && (uint32_t)lane < nl) ? s_lq[2 * lane + 1] : 0u;
+            const bool elig = n >= 2u && !((tried >> (lane & 31)) & 1u);
+            const unsigned long long em = __ballot(elig);
+            bool take = false;
+            uint32_t offv = 0, cut = 0;
+            if (em) {
+                const int first = __builtin_ctzll(em);
+                if ((uint32_t)__builtin_amdgcn_readlane((int)n, first) > (uint32_t)SEG_ROWS) { cut = 1; take = lane == first; }
+                else {
+                    const uint32_t v = (elig && n <= (uint32_t)SEG_ROWS) ? n : 0u;
+                    const uint32_t x = wave_scan_incl(v);
+                    take = v != 0 && x <= (uint32_t)SEG_ROWS;
+                    offv = x - v;
+                }
+            }
+            const unsigned long long tm = __ballot(take);
+            const uint32_t k = mbcnt64(tm), nk = (uint32_t)__popcll(tm);
+            if (take) { off[k] = offv; item[k] = (uint32_t)lane; }
+            const uint32_t endv = offv + (n < (uint32_t)SEG_ROWS ? n : (uint32_t)SEG_ROWS);
+            const uint32_t total = tm ? (uint32_t)__builtin_amdgcn_readlane((int)endv, 63 - __builtin_clzll(tm)) : 0u;
+            if (lane == 0) {
+                off[nk] = total;
+                ctl[0] = nk; ctl[1] = 0; ctl[2] = 0; ctl[3] = tried | (uint32_t)tm; ctl[4] = cut; ctl[6] = 0;
+            }
+        }
+        __syncthreads();
+        const uint32_t nk = ctl[0];
+        if (nk == 0) break;
+        const uint32_t total = off[nk];
+        // ---- table rows, longest token per row, boundaries ------------------------------------------
+        const bool own = (uint32_t)tid < total;
+        const bool cut = ctl[4] != 0;                        // the (one) chunk continues beyond the rows
+        int maxlen = 0, cap = 0;                             // cap: bytes left in the row's chunk
+        uint32_t w0 = 0, w1 = 0, bid = SPL_DEAD;
+        if (own) {
+            uint32_t k = 0;
+            while (off[k + 1] <= (uint32_t)tid) k++;
+            const uint32_t ci = (uint32_t)tid - off[k], cn = s_lq[2 * item[k] + 1];
+            const uint64_t g = (uint64_t)s_lq[2 * item[k]] + ci, B = b.n_bytes;
+            cap = (int)(cn - ci);
+            maxlen = cn - ci < (uint32_t)SUB_LMAX ? (int)(cn - ci) : SUB_LMAX;
+            if (g + 8 <= B) { __builtin_memcpy(&w0, b.text + g, 4); __builtin_memcpy(&w1, b.text + g + 4, 4); }
+            else for (int q = 0; q < 8; q++) if (g + q < B) (q < 4 ? w0 : w1) |= (uint32_t)b.text[g + q] << (8 * (q & 3));
+            bid = T.byte_id[w0 & 0xFFu];
+        }
+        uint32_t* const row = slab + tid * SUB_W;
+        int ml = 1;
+        {
+            Quad qa[2], qb[2], qc[2], qd[3];
+            const uint32_t ka = w0 & 0xFFFFu, kb = w0 & 0xFFFFFFu, ha = w1 & 0xFFu;
+            if (maxlen >= 2) {                               // (one predicate per batch: see bpe_group16_tab)
+                tiny_issue(T, ka, 2u, qa);
+                tiny_issue(T, kb, 3u, qb);
+                tiny_issue(T, w0, 4u, qc);
+                t8_issue(T, w0, ha, 5u, qd);
+                const uint32_t r2 = tiny_finish(T, ka, 2u, qa), r3 = tiny_finish(T, kb, 3u, qb);
+                const uint32_t r4 = tiny_finish(T, w0, 4u, qc), r5 = t8_finish(T, w0, ha, 5u, qd);
+                row[0] = r2; row[1] = r3; row[2] = r4; row[3] = r5;
+                ml = r2 != SPL_NO_RANK ? 2 : ml;
+                ml = (r3 != SPL_NO_RANK && maxlen >= 3) ? 3 : ml;
+                ml = (r4 != SPL_NO_RANK && maxlen >= 4) ? 4 : ml;
+                ml = (r5 != SPL_NO_RANK && maxlen >= 5) ? 5 : ml;
+            }
+        }
+        sid[tid] = bid;
+        {
+            uint32_t e8 = 0, h8 = 0;                          // the p8 entry travels with the second batch
+            if (cap > SUB_LMAX) { h8 = hash_p8(w0, w1); e8 = T.p8_tab[h8 & T.p8_mask]; }
+            if (__any(maxlen >= 6)) {
+                Quad qa[3], qb[3], qc[3];
+                const uint32_t hb = w1 & 0xFFFFu, hc = w1 & 0xFFFFFFu;
+                if (maxlen >= 6) {
+                    t8_issue(T, w0, hb, 6u, qa);
+                    t8_issue(T, w0, hc, 7u, qb);
+                    t8_issue(T, w0, w1, 8u, qc);
+                    const uint32_t r6 = t8_finish(T, w0, hb, 6u, qa), r7 = t8_finish(T, w0, hc, 7u, qb);
+                    const uint32_t r8 = t8_finish(T, w0, w1, 8u, qc);
+                    row[4] = r6; row[5] = r7; row[6] = r8;
+                    ml = r6 != SPL_NO_RANK ? 6 : ml;
+                    ml = (r7 != SPL_NO_RANK && maxlen >= 7) ? 7 : ml;
+                    ml = (r8 != SPL_NO_RANK && maxlen >= 8) ? 8 : ml;
+                }
+            }
+            const uint32_t t8 = e8 >> 8;
+            if (e8 != 0 && (t8 == 255u || t8 == p8_tag(h8))) {
+                const int l8 = (int)(e8 & 0xFFu);
+                ml = (l8 == 255 || l8 > cap) ? cap : l8;
+            }
+        }
+        {
+            uint32_t cover = wave_scan_max(own ? (uint32_t)(tid + ml - 1) : 0u);
+            if (lane == 63) s_wsum4[wv] = cover;
+            __syncthreads();
+            for (int k = 0; k < wv; k++) cover = s_wsum4[k] > cover ? s_wsum4[k] : cover;
+            const unsigned long long hb = __ballot(own && cover == (uint32_t)tid);
+            if (lane == 0) { hard[2 * wv] = (uint32_t)hb; hard[2 * wv + 1] = (uint32_t)(hb >> 32); }
+        }
+        __syncthreads();
+        // a cut chunk: only what lies before the last boundary among the rows is complete; the rest
+        // goes back on the list as a chunk of its own (nothing spans that boundary)
+        uint32_t rows = total;
+        if (cut) {
+            int last = -1;
+            for (int w = SEG_ROWS / 32 - 1; w >= 0 && last < 0; w--) if (hard[w]) last = 32 * w + 31 - __clz((int)hard[w]);
+            rows = (uint32_t)(last + 1);
+            if (last < 0 && tid == 0) ctl[2] = 1u;           // no boundary at all: left to the node-list loops
+        }
+        // ---- every row that starts a segment: up to 8 bytes are merged by the row's own lane (all spans
+        //      are in the table), longer ones go to a group of 16 lanes, a wavefront, or back on the list
+        if ((uint32_t)tid < rows && (tid == 0 || ((hard[(tid - 1) >> 5] >> ((tid - 1) & 31)) & 1u))) {
+            const uint32_t h0 = hbits(tid);                  // the first boundary at or after the start ends the segment
+            if (h0 & 0xFFu) {
+                const int len = __ffs((int)h0);
+                const uint32_t gpos = first_byte_of(tid);
+                const uint32_t* const cells = slab + tid * SUB_W;      // node x of the segment: cells + x * SUB_W
+                uint32_t alive = (1u << len) - 1u;
+                for (;;) {                                   // bpe.rs:118-190 on at most 8 nodes in a bit mask
+                    uint32_t best = SPL_NO_RANK, kill = 0, m = alive;
+                    int x = __ffs((int)m) - 1;
+                    m &= m - 1u;
+                    while (m) {
+                        const int y = __ffs((int)m) - 1;
+                        const uint32_t m2 = m & (m - 1u);
+                        const int e2 = m2 ? __ffs((int)m2) - 1 : len;
+                        const uint32_t r = cells[x * SUB_W + (e2 - x - 2)];
+                        if (r < best) { best = r; kill = 1u << y; }
+                        x = y;
+                        m = m2;
+                    }
+                    if (!kill) break;
+                    alive &= ~kill;
+                }
+                for (uint32_t m = alive; m;) {
+                    const int x = __ffs((int)m) - 1;
+                    m &= m - 1u;
+                    const int e2 = m ? __ffs((int)m) - 1 : len;
+                    emit_g(gpos + (uint32_t)x, e2 - x == 1 ? sid[tid + x] : cells[x * SUB_W + (e2 - x - 2)]);
+                }
+            } else if (h0 & 0xFFFFu) {
+                mseg[atomicAdd(&ctl[6], 1u)] = (uint32_t)tid | (uint32_t)__ffs((int)h0) << 16;
+            } else {
+                const uint32_t h1 = hbits(tid + 32);
+                const uint32_t l2 = h0 ? (uint32_t)__ffs((int)h0) : h1 ? 32u + (uint32_t)__ffs((int)h1) : 65u;
+                if (l2 <= 64u) lseg[atomicAdd(&ctl[1], 1u)] = (uint32_t)tid | l2 << 16;
+                else {                                       // longer than a wavefront: a chunk of its own for the loops below
+                    int q = tid + 64;
+                    uint32_t hq;
+                    while ((hq = hbits(q)) == 0) q += 32;    // (the last row of a chunk is a boundary)
+                    const uint32_t qi = nl + atomicAdd(&ctl[5], 1u);
+                    if (qi < (uint32_t)DIRECT_LQCAP) {
+                        s_lq[2 * qi] = first_byte_of(tid);
+                        s_lq[2 * qi + 1] = (uint32_t)(q - tid) + (uint32_t)__ffs((int)hq);
+                        atomicOr(&ctl[3], 1u << qi);         // (not to be packed again)
+                    } else {                                 // no room: the whole chunk stays on the list
+                        uint32_t k = 0;
+                        while (off[k + 1] <= (uint32_t)tid) k++;
+                        atomicOr(&ctl[2], 1u << k);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- segments of 9..16 bytes: a group of 16 lanes each ------------------------------------------
+        {
+            const int gi = tid >> 4, gl = tid & 15;
+            const uint32_t nmid = ctl[6];
+            for (uint32_t q0 = 0; q0 < nmid; q0 += NT / 16) {
+                const uint32_t q = q0 + (uint32_t)gi;
+                const int s0 = q < nmid ? (int)(mseg[q] & 0xFFFFu) : 0, len = q < nmid ? (int)(mseg[q] >> 16) : 0;
+                const uint32_t gpos = len ? first_byte_of(s0) : 0u;
+                const bool gown = gl < len;
+                group16_merge(T, slab + (gown ? s0 + gl : 0) * SUB_W, gown ? sid[s0 + gl] : SPL_DEAD, len,
+                              [&](int i, uint32_t id) { emit_g(gpos + (uint32_t)i, id); });
+            }
+        }
+        // ---- segments of 17..64 bytes: one wavefront each ------------------------------------------
+        for (uint32_t q = (uint32_t)wv; q < ctl[1]; q += NT / 64) {
+            const int s0 = (int)(lseg[q] & 0xFFFFu), len = (int)(lseg[q] >> 16);
+            const uint32_t gpos = first_byte_of(s0);
+            const bool lown = lane < len;
+            const uint32_t* const lrow = slab + (lown ? s0 + lane : 0) * SUB_W;
+            wave64_merge(T, lrow, len >= 64 ? ~0ull : ((1ull << len) - 1ull), len, lane + 1 < len ? lrow[0] : SPL_NO_RANK,
+                         lown ? sid[s0 + lane] : SPL_DEAD,
+                         [&](int i, uint32_t id) { emit_g(gpos + (uint32_t)i, id); });
+        }
+        __syncthreads();
+        if ((uint32_t)tid < nk && !((ctl[2] >> tid) & 1u)) {
+            if (!cut) s_lq[2 * item[tid] + 1] = 0;          // done: off the list
+            else {                                           // the rest of a cut chunk: to be packed again
+                const uint32_t rest = s_lq[2 * item[tid] + 1] - rows, at = s_lq[2 * item[tid]] + rows;
+                if (rest == 1u) emit_g(at, T.byte_id[b.text[at]]);       // a lone last byte is its own token
+                s_lq[2 * item[tid]] = at;
+                s_lq[2 * item[tid] + 1] = rest == 1u ? 0u : rest;
+                ctl[3] &= ~(1u << item[tid]);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t nl2 = nl + ctl[5];                       // the list grew by the segments set aside
+    return nl2 < (uint32_t)DIRECT_LQCAP ? nl2 : (uint32_t)DIRECT_LQCAP;
+}
 
 template <int TB_, int RH_, bool EXPORT_MEDIUM, bool DIRECT = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPL_PRETOK_WAVES)))
@@ -1402,7 +1729,8 @@ void k_pretok(DeviceTables T, Batch b) {
     __shared__ uint32_t s_sk[G::NBW + 1];                // special-literal bits of the window
     __shared__ uint32_t s_cbits[G::NBW + 1];
     __shared__ uint32_t s_tbits[G::NBW + 1];
-    __shared__ uint16_t s_cpos[Wv + 2];
+    static_assert(!DIRECT || (Wv + 2) / 2 >= SG_WORDS, "bpe_tail_segments' scratch must fit s_cpos");
+    __shared__ __attribute__((aligned(16))) uint16_t s_cpos[Wv + 2];   // (the single-pass tail borrows it: bpe_tail_segments)
     __shared__ uint8_t s_ascii[128];
     __shared__ uint32_t s_wsum[NT / 64];
     __shared__ uint32_t s_total;
@@ -1865,12 +2193,13 @@ void k_pretok(DeviceTables T, Batch b) {
         // ---- rare: chunks of more than 64 bytes, and the chain that outgrew the window -----------
         if (s_dq[0] | s_dq[1]) {                           // workgroup-uniform
             for (;;) {
-                const uint32_t nl = s_dq[0] < (uint32_t)DIRECT_LQCAP ? s_dq[0] : (uint32_t)DIRECT_LQCAP;
+                const uint32_t nl0 = s_dq[0] < (uint32_t)DIRECT_LQCAP ? s_dq[0] : (uint32_t)DIRECT_LQCAP;
+                const uint32_t nl = bpe_tail_segments(T, b, s_lq, nl0, s_u.t.slab[0], reinterpret_cast<uint32_t*>(s_cpos), s_wsum, emit_g);
                 for (uint32_t it = wv; it < nl; it += NT / 64) {         // one wavefront per chunk
                     const int n = (int)s_lq[2 * it + 1];
                     const uint32_t pos = s_lq[2 * it];
                     uint32_t* const slab = s_u.t.slab[wv];
-                    if (n <= DIRECT_TAB_NMAX) {                          // tabulated: no round trip per merge
+                    if (n >= 2 && n <= DIRECT_TAB_NMAX) {                // tabulated: no round trip per merge
                         bpe_wave_tab<DIRECT_TAB_NMAX / 64>(T, n, slab,
                             [&](int q) {
                                 const uint64_t g = (uint64_t)pos + (uint32_t)q;
@@ -1910,47 +2239,103 @@ void k_pretok(DeviceTables T, Batch b) {
                     if (n > WAVE_NMAX) bpe_block_rounds(T, b, s_lq[2 * it], n, s_wsum, emit_g);
                 }
                 __syncthreads();
-                if (tid == 0) {
-                    // continue the chain(s) lane-serially (deferred_items): whole-chunk hits become
-                    // tokens at once, misses of ANY length refill the list for the loop above
-                    uint32_t fill = 0;
-                    const uint32_t nd = s_dq[1] < 2u ? s_dq[1] : 2u;
-                    uint32_t done = s_dq[6], pcur = s_dq[5];
-                    bool running = s_dq[7] != 0;
-                    DirectAcc acc{&T, &b, s_dq[8]};
-                    while (done < nd && fill < (uint32_t)DIRECT_LQCAP) {
-                        if (!running) {
-                            pcur = s_dq[2 + done];
-                            // first text start after the chain's start
-                            uint32_t lo = 0, hi = b.n_docs;
-                            while (lo < hi) {
-                                const uint32_t mid = lo + (hi - lo) / 2;
-                                if (b.doc_off[mid] <= (uint64_t)pcur) lo = mid + 1; else hi = mid;
-                            }
-                            acc.next_ts = lo < b.n_docs ? (uint32_t)b.doc_off[lo] : b.n_bytes;
-                            running = true;
+                // continue the chain(s) that ran beyond the window: the workgroup stages the next DIRECT_WIN
+                // bytes and their class records in LDS (in parallel), thread 0 walks the chain there --
+                // whole-chunk hits become tokens at once, misses of ANY length refill the list for the
+                // loops above.  (s_dq[7]: 0 no chain open, 1 the next chunk is the chain's first, 2 a
+                // chunk only starts here if this is no sync point.)
+                if (tid == 0) s_dq[0] = 0;
+                for (;;) {
+                    __syncthreads();
+                    const uint32_t ndc = s_dq[1] < 2u ? s_dq[1] : 2u;
+                    if (s_dq[6] >= ndc || s_dq[0] >= (uint32_t)DIRECT_LQCAP) break;
+                    if (tid == 0 && s_dq[7] == 0) {
+                        const uint32_t pc = s_dq[2 + s_dq[6]];
+                        uint32_t lo = 0, hi = b.n_docs;         // first text start after the chain's start
+                        while (lo < hi) {
+                            const uint32_t mid = lo + (hi - lo) / 2;
+                            if (b.doc_off[mid] <= (uint64_t)pc) lo = mid + 1; else hi = mid;
                         }
-                        bool finished = false;
-                        for (;;) {
-                            if (pcur >= b.n_bytes) { finished = true; break; }
-                            const int e = match_end(acc, (int)pcur, (int)T.pattern);   // never defers: no window end
-                            const uint32_t n = (uint32_t)e - pcur;
-                            const uint32_t id = probe_chunk(T, acc, (int)pcur, (int)n);
-                            if (id != SPL_NO_RANK) emit_g(pcur, id);
-                            else if (n > 1) { s_lq[2 * fill] = pcur; s_lq[2 * fill + 1] = n; fill++; }
-                            pcur = (uint32_t)e;
-                            if (pcur >= b.n_bytes) { finished = true; break; }
-                            const uint32_t r = acc.rec((int)pcur);
-                            if (r & (CB_SYNC | CB_TSTART)) { finished = true; break; }
-                            int64_t j = (int64_t)pcur - 1;
-                            while (j > 0 && (b.text[j] & 0xC0u) == 0x80u && j > (int64_t)pcur - 4) j--;
-                            const uint32_t prev = acc.rec((int)j) & CB_CLASS;
-                            if (prev < C_EOT && is_sync((int)T.pattern, prev, r & CB_CLASS)) { finished = true; break; }
-                            if (fill >= (uint32_t)DIRECT_LQCAP) break;
-                        }
-                        if (finished) { done++; running = false; }
+                        s_dq[5] = pc;
+                        s_dq[8] = lo < b.n_docs ? (uint32_t)b.doc_off[lo] : b.n_bytes;
+                        s_dq[7] = 1;
                     }
-                    s_dq[0] = fill; s_dq[5] = pcur; s_dq[6] = done; s_dq[7] = running ? 1u : 0u; s_dq[8] = acc.next_ts;
+                    __syncthreads();
+                    const int64_t pc = s_dq[5];
+                    const uint32_t next_ts = s_dq[8];
+                    uint8_t* const wtxt = reinterpret_cast<uint8_t*>(s_u.t.slab[0]);
+                    uint8_t* const wrec = wtxt + DIRECT_WIN + 32;
+                    const int64_t base = pc >= DEFER_BACK ? pc - DEFER_BACK : 0;
+                    const int q0 = (int)(pc - base);
+                    const int nst = (int)((B - base) < (int64_t)(DIRECT_WIN + 16) ? (B - base) : (int64_t)(DIRECT_WIN + 16));
+                    const int nrec = nst < DIRECT_WIN ? nst + 1 : DIRECT_WIN;
+                    for (int i = tid; i < DIRECT_WIN + 32; i += NT) wtxt[i] = i < nst ? b.text[base + i] : (uint8_t)0;
+                    __syncthreads();
+                    for (int i = tid; i < nrec; i += NT) {
+                        const int64_t g = base + i;
+                        uint32_t r;
+                        if (g >= B) r = C_EOT | CB_TSTART | CB_SYNC;
+                        else if (b.skip && ((b.skip[g >> 5] >> (g & 31)) & 1u)) r = C_EOT | CB_TSTART;
+                        else {
+                            const uint32_t c0 = wtxt[i];
+                            if (c0 < 0x80u) r = s_ascii[c0];
+                            else if (c0 < 0xC0u) r = C_CONT;
+                            else {
+                                uint32_t want = utf8_len(c0), len = 1;
+                                while (len < want && i + (int)len < nst && (wtxt[i + len] & 0xC0u) == 0x80u) len++;
+                                const WinAcc tx{wrec, wtxt, 0};
+                                const uint32_t cls = (len == want) ? cp_class(T, decode_at(tx, i, c0)) : (uint32_t)C_P;
+                                r = cls | ((len - 1) << CB_LEN_SHIFT);
+                            }
+                            if ((uint32_t)g == next_ts) r |= CB_TSTART | CB_SYNC;
+                            if (b.tstart && ((b.tstart[g >> 5] >> (g & 31)) & 1u)) r |= CB_TSTART | CB_SYNC;
+                        }
+                        wrec[i] = (uint8_t)r;
+                    }
+                    __syncthreads();
+                    if (tid == 0) {
+                        const WinAcc acc{wrec, wtxt, nrec};
+                        uint32_t fill = s_dq[0];
+                        int q = q0;
+                        bool fc = s_dq[7] == 1, finished = false, whole = false;
+                        for (;;) {
+                            if (!fc) {                               // does a chunk start here at all?
+                                const uint32_t r = acc.rec(q);
+                                if (r == (uint32_t)C_WEND) break;                  // the next window will tell
+                                if (r & (CB_SYNC | CB_TSTART)) { finished = true; break; }
+                                int j = q - 1;
+                                while (j > 0 && (wtxt[j] & 0xC0u) == 0x80u && j > q - 4) j--;
+                                const uint32_t prev = acc.rec(j) & CB_CLASS;
+                                if (prev < C_EOT && is_sync((int)T.pattern, prev, r & CB_CLASS)) { finished = true; break; }
+                            }
+                            if (fill >= (uint32_t)DIRECT_LQCAP) break;
+                            const int e = match_end(acc, q, (int)T.pattern);
+                            if (e == SPL_DEFER) { whole = q == q0; break; }       // (longer than a whole window: below)
+                            fc = false;
+                            const uint32_t gp = (uint32_t)(base + q), n = (uint32_t)(e - q);
+                            const uint32_t id = probe_chunk(T, acc, q, (int)n);
+                            if (id != SPL_NO_RANK) emit_g(gp, id);
+                            else if (n > 1) { s_lq[2 * fill] = gp; s_lq[2 * fill + 1] = n; fill++; }
+                            q = e;
+                            if (base + q >= B) { finished = true; break; }
+                        }
+                        uint32_t np = (uint32_t)(base + q);
+                        if (whole) {                                 // one chunk, byte-wise from HBM
+                            const DirectAcc ga{&T, &b, next_ts};
+                            const int e = match_end(ga, (int)np, (int)T.pattern);
+                            const uint32_t n = (uint32_t)e - np;
+                            const uint32_t id = probe_chunk(T, ga, (int)np, (int)n);
+                            if (id != SPL_NO_RANK) emit_g(np, id);
+                            else if (n > 1) { s_lq[2 * fill] = np; s_lq[2 * fill + 1] = n; fill++; }
+                            np = (uint32_t)e;
+                            fc = false;
+                            if (np >= b.n_bytes) finished = true;
+                        }
+                        s_dq[0] = fill;
+                        s_dq[5] = np;
+                        if (finished) { s_dq[6] += 1; s_dq[7] = 0; }
+                        else s_dq[7] = fc ? 1u : 2u;
+                    }
                 }
                 __syncthreads();
                 const uint32_t nd = s_dq[1] < 2u ? s_dq[1] : 2u;
@@ -2070,8 +2455,8 @@ void k_pretok(DeviceTables T, Batch b) {
     }
     SPL_STAMP(8);
 #ifdef SPL_DEBUG_STAMPS
-    if (b.dbg && tid_late == 0 && blockIdx.x == gridDim.x / 2) b.dbg[12] = (unsigned long long)wall_clock64();
-    if (b.dbg && tid_late == 0 && blockIdx.x < SPL_DEBUG_BLOCKS) {
+    if (b.dbg && tid == 0 && blockIdx.x == gridDim.x / 2) b.dbg[12] = (unsigned long long)wall_clock64();
+    if (b.dbg && tid == 0 && blockIdx.x < SPL_DEBUG_BLOCKS) {
         // wall-clock ticks: start, end of the merge phase, counts done, end
         unsigned long long* r = b.dbg + 16 + 4 * blockIdx.x;
         r[0] = blk_t0;

@@ -161,6 +161,24 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
     out.short_tab.assign((size_t)sbuckets * SPL_SHORT_BUCKET, ShortEnt{0, 0, 0, SPL_EMPTY});
     out.long_tab.assign(lcap, LongEnt{0, SPL_EMPTY, 0, 0});
     out.key_blob.clear();
+    {   // p8: for every 8-byte prefix of a longer token, the longest such token
+        size_t n9 = 0;
+        for (const auto& kv : enc) n9 += kv.first.size() > (size_t)SPL_T8_MAX;
+        const uint32_t slots = std::max<uint32_t>(1u << 16, pow2_at_least(n9 * 16 + 2));   // sparse: a false hit costs parallelism
+        out.p8_tab.assign(slots, 0);
+        for (const auto& kv : enc) {
+            const std::string& k = kv.first;
+            if (k.size() <= (size_t)SPL_T8_MAX) continue;
+            const uint32_t h = hash_p8(load_le(k, 0), load_le(k, 4));
+            uint16_t& cell = out.p8_tab[h & (slots - 1)];
+            const uint32_t len = (uint32_t)std::min<size_t>(k.size(), 255), tag = p8_tag(h);
+            if (cell == 0) cell = (uint16_t)(tag << 8 | len);
+            else {
+                const uint32_t t = cell >> 8, l = std::max<uint32_t>(cell & 0xFFu, len);
+                cell = (uint16_t)((t == tag ? tag : 255u) << 8 | l);
+            }
+        }
+    }
     for (const auto& kv : enc) {
         const std::string& k = kv.first;
         const uint32_t n = (uint32_t)k.size();
