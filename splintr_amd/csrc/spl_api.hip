@@ -374,7 +374,7 @@ spl_tokenizer* spl_create(const void* vocab_splv, size_t vocab_len, const void* 
         if ((rc = dev_upload(t->ht.key_blob, &t->dt.key_blob))) return rc;
         if ((rc = dev_upload(t->ht.pair_tab, &t->dt.pair_tab))) return rc;
         if ((rc = dev_upload(t->ht.byte_id, &t->dt.byte_id))) return rc;
-        if ((rc = dev_upload(t->ht.p8_tab, &t->dt.p8_tab))) return rc;
+        if ((rc = dev_upload(t->ht.p8_tab, reinterpret_cast<const uint32_t**>(&t->dt.p8_tab)))) return rc;
         if ((rc = dev_upload(t->ht.tok_off, &t->d_tok_off))) return rc;
         if ((rc = dev_upload(t->ht.tok_bytes, &t->d_tok_bytes))) return rc;
         return SPL_OK;
@@ -387,7 +387,7 @@ spl_tokenizer* spl_create(const void* vocab_splv, size_t vocab_len, const void* 
     t->dt.t8_mask = (uint32_t)(t->ht.t8_tab.size() / SPL_T8_WORDS) - 1;
     t->dt.long_mask = (uint32_t)t->ht.long_tab.size() - 1;
     t->dt.pair_mask = (uint32_t)(t->ht.pair_tab.size() / SPL_PAIR_BUCKET) - 1;
-    t->dt.p8_mask = (uint32_t)t->ht.p8_tab.size() - 1;
+    t->dt.p8_mask = (uint32_t)(t->ht.p8_tab.size() / 2) - 1;
     t->dt.max_key_len = t->ht.max_key_len;
     t->dt.pattern = (uint32_t)t->ht.pattern;
     t->dt.all_bytes = t->ht.all_bytes ? 1u : 0u;

@@ -94,6 +94,8 @@ constexpr uint32_t SPL_ID_BITS = 21;
 constexpr uint32_t SPL_ID_MASK = (1u << SPL_ID_BITS) - 1;
 constexpr uint32_t SPL_NO_RANK = 0xFFFFFFFFu;
 
+struct P8Bucket { uint32_t a, b; };
+
 struct DeviceTables {
     // code-point classes
     const uint16_t* ucls_stage1;
@@ -111,10 +113,11 @@ struct DeviceTables {
     uint32_t max_key_len;
     uint32_t pattern;         // PAT_*
     uint32_t all_bytes;       // 1 if all 256 single bytes are tokens
-    // p8: an upper bound of the length of tokens longer than 8 bytes by their first 8 bytes.  Slot =
-    // hash of the 8 bytes; entry = tag << 8 | longest such token (255 = "unbounded"), 0 = none; tag
-    // 255 matches every key (two prefixes met in the slot).  A miss is exact, a hit may be too long.
-    const uint16_t* p8_tab;    uint32_t p8_mask;
+    // p8: an upper bound of the length of tokens longer than 8 bytes by their first 8 bytes.  Bucket =
+    // hash of the 8 bytes, two entries of tag << 8 | longest such token (255 = "unbounded"), 0 = free;
+    // tag 0xFFFFFF matches every key (a third prefix met in the bucket).  A miss is exact, a hit may
+    // be too long (another prefix with the same 24-bit tag).
+    const P8Bucket* p8_tab;    uint32_t p8_mask;
 };
 
 // ----------------------------------------------------------------------------------------
@@ -129,10 +132,15 @@ SPL_HD uint32_t hash_t8(uint32_t k0, uint32_t k1, uint32_t len) {
     return mix32(k0 * 0x9E3779B1u ^ (k1 * 0x85EBCA77u + 0x165667B1u) ^ (len * 0x27D4EB2Fu));
 }
 SPL_HD uint32_t hash_p8(uint32_t k0, uint32_t k1) { return hash_t8(k0, k1, 9u); }
-SPL_HD uint32_t p8_tag(uint32_t h) { return (h >> 24) % 254u + 1u; }                 // 1..254
-SPL_HD uint32_t p8_len(const uint16_t* tab, uint32_t mask, uint32_t k0, uint32_t k1) {   // 0: no longer token starts so
-    const uint32_t h = hash_p8(k0, k1), e = tab[h & mask], t = e >> 8;
-    return (t == 255u || t == p8_tag(h)) ? (e & 0xFFu) : 0u;
+SPL_HD uint32_t p8_tag(uint32_t k0, uint32_t k1) {                                   // 1 .. 0xFFFFFE
+    return mix32(k0 * 0x85EBCA77u ^ (k1 * 0xC2B2AE3Du + 0x27D4EB2Fu)) % 0xFFFFFEu + 1u;
+}
+SPL_HD uint32_t p8_match(uint32_t e0, uint32_t e1, uint32_t tag) {                   // 0: no longer token starts so
+    const uint32_t t0 = e0 >> 8, t1 = e1 >> 8;
+    uint32_t l = 0;
+    if (e0 != 0 && (t0 == tag || t0 == 0xFFFFFFu)) l = e0 & 0xFFu;
+    if (e1 != 0 && (t1 == tag || t1 == 0xFFFFFFu) && (e1 & 0xFFu) > l) l = e1 & 0xFFu;
+    return l;
 }
 SPL_HD uint32_t hash_short(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len) {
     uint32_t h = k0 * 0x9E3779B1u ^ (k1 * 0x85EBCA77u + 0x165667B1u) ^ (k2 * 0xC2B2AE3Du) ^ (len * 0x27D4EB2Fu);

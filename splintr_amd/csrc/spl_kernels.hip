@@ -706,7 +706,8 @@ __device__ __forceinline__ void bpe_wave64_tab(const DeviceTables& T, const LdsA
 #pragma unroll
         for (int k = 0; k < SUB_W; k++) ml = (k + 2 <= maxlen && row[k] != SPL_NO_RANK) ? k + 2 : ml;
         if (own && n - lane > SUB_LMAX) {
-            const int l8 = (int)p8_len(T.p8_tab, T.p8_mask, w0, w1), cap = n - lane;
+            const P8Bucket e8 = T.p8_tab[hash_p8(w0, w1) & T.p8_mask];
+            const int l8 = (int)p8_match(e8.a, e8.b, p8_tag(w0, w1)), cap = n - lane;
             ml = l8 == 0 ? ml : (l8 == 255 || l8 > cap) ? cap : l8;
         }
         const uint32_t cover = wave_scan_max(own ? (uint32_t)(lane + ml - 1) : 0u);
@@ -1442,6 +1443,7 @@ template <int TB_, int RH_> struct TileGeom {
 #ifndef SPL_PRETOK_WAVES
 #define SPL_PRETOK_WAVES 6
 #endif
+constexpr int DIRECT_LQ_MEDIUM = 16;      // of which, from the back: medium chunks of multi-byte text
 constexpr int DIRECT_LQCAP = 32;          // long-chunk list of one workgroup (refilled while a chain is continued)
 constexpr int DIRECT_WIN = 2048;           // bytes staged per turn for a chain that continues beyond the window
 constexpr int DIRECT_WAVE_NMAX = 256;     // nodes of one wavefront's LDS slab in the single-pass tail
@@ -1575,8 +1577,8 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
         }
         sid[tid] = bid;
         {
-            uint32_t e8 = 0, h8 = 0;                          // the p8 entry travels with the second batch
-            if (cap > SUB_LMAX) { h8 = hash_p8(w0, w1); e8 = T.p8_tab[h8 & T.p8_mask]; }
+            P8Bucket e8{0u, 0u};                               // the p8 bucket travels with the second batch
+            if (cap > SUB_LMAX) e8 = T.p8_tab[hash_p8(w0, w1) & T.p8_mask];
             if (__any(maxlen >= 6)) {
                 Quad qa[3], qb[3], qc[3];
                 const uint32_t hb = w1 & 0xFFFFu, hc = w1 & 0xFFFFFFu;
@@ -1592,11 +1594,8 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
                     ml = (r8 != SPL_NO_RANK && maxlen >= 8) ? 8 : ml;
                 }
             }
-            const uint32_t t8 = e8 >> 8;
-            if (e8 != 0 && (t8 == 255u || t8 == p8_tag(h8))) {
-                const int l8 = (int)(e8 & 0xFFu);
-                ml = (l8 == 255 || l8 > cap) ? cap : l8;
-            }
+            const int l8 = (int)p8_match(e8.a, e8.b, p8_tag(w0, w1));
+            if (l8) ml = (l8 == 255 || l8 > cap) ? cap : l8;
         }
         {
             uint32_t cover = wave_scan_max(own ? (uint32_t)(tid + ml - 1) : 0u);
@@ -1799,6 +1798,7 @@ void k_pretok(DeviceTables T, Batch b) {
     if (tid < 128) s_ascii[tid] = T.ucls_stage2[((uint32_t)T.ucls_stage1[0] << T.ucls_shift) + tid];
     if (tid < 4) s_nq[tid] = 0;
     if (tid < 12) s_dq[tid] = 0;
+    if (DIRECT && tid < DIRECT_LQCAP) s_lq[2 * tid + 1] = 0;     // (length 0: no entry)
     if (tid == 0) s_nch = 0;
     // single pass: the window's text starts straight from doc_off.  NT-ary search for the first
     // document that starts at or after the window (two rounds up to 65 536 documents), then the
@@ -2047,8 +2047,20 @@ void k_pretok(DeviceTables T, Batch b) {
                 // LDS); long ones go to the global queue for k_bpe_long
                 const uint32_t item = (uint32_t)p | ((uint32_t)n << 16);
                 if (n <= 16) s_miss[atomicAdd(&s_nq[0], 1u)] = item;
-                else if (n <= 64) s_miss[G::C16 + atomicAdd(&s_nq[1], 1u)] = item;
-                else if (DIRECT && !b.qcount) {          // at most Wv / 65 of them
+                else if (n <= 64) {
+                    // multi-byte text of the single-pass tile: to the back of the long list, whose
+                    // chunks are merged together, segment by segment (bpe_tail_segments)
+                    bool sent = false;
+                    if (DIRECT && !b.qcount && ((s_txt[p] | s_txt[p + 1]) & 0x80u)) {
+                        const uint32_t m = atomicAdd(&s_dq[11], 1u);
+                        if (m < (uint32_t)DIRECT_LQ_MEDIUM) {
+                            s_lq[2 * (DIRECT_LQCAP - 1 - m)] = (uint32_t)(w0 + p);
+                            s_lq[2 * (DIRECT_LQCAP - 1 - m) + 1] = (uint32_t)n;
+                            sent = true;
+                        }
+                    }
+                    if (!sent) s_miss[G::C16 + atomicAdd(&s_nq[1], 1u)] = item;
+                } else if (DIRECT && !b.qcount) {        // at most Wv / 65 of them
                     const uint32_t qi = atomicAdd(&s_dq[0], 1u);
                     s_lq[2 * qi] = (uint32_t)(w0 + p);
                     s_lq[2 * qi + 1] = (uint32_t)n;
@@ -2191,9 +2203,10 @@ void k_pretok(DeviceTables T, Batch b) {
             }
         };
         // ---- rare: chunks of more than 64 bytes, and the chain that outgrew the window -----------
-        if (s_dq[0] | s_dq[1]) {                           // workgroup-uniform
+        if (s_dq[0] | s_dq[1] | s_dq[11]) {                // workgroup-uniform
             for (;;) {
-                const uint32_t nl0 = s_dq[0] < (uint32_t)DIRECT_LQCAP ? s_dq[0] : (uint32_t)DIRECT_LQCAP;
+                // (medium chunks sit at the back of the list, unused entries have length 0)
+                const uint32_t nl0 = (s_dq[11] || s_dq[0] > (uint32_t)DIRECT_LQCAP) ? (uint32_t)DIRECT_LQCAP : s_dq[0];
                 const uint32_t nl = bpe_tail_segments(T, b, s_lq, nl0, s_u.t.slab[0], reinterpret_cast<uint32_t*>(s_cpos), s_wsum, emit_g);
                 for (uint32_t it = wv; it < nl; it += NT / 64) {         // one wavefront per chunk
                     const int n = (int)s_lq[2 * it + 1];
@@ -2244,7 +2257,7 @@ void k_pretok(DeviceTables T, Batch b) {
                 // whole-chunk hits become tokens at once, misses of ANY length refill the list for the
                 // loops above.  (s_dq[7]: 0 no chain open, 1 the next chunk is the chain's first, 2 a
                 // chunk only starts here if this is no sync point.)
-                if (tid == 0) s_dq[0] = 0;
+                if (tid == 0) { s_dq[0] = 0; s_dq[11] = 0; }
                 for (;;) {
                     __syncthreads();
                     const uint32_t ndc = s_dq[1] < 2u ? s_dq[1] : 2u;

@@ -164,18 +164,23 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
     {   // p8: for every 8-byte prefix of a longer token, the longest such token
         size_t n9 = 0;
         for (const auto& kv : enc) n9 += kv.first.size() > (size_t)SPL_T8_MAX;
-        const uint32_t slots = std::max<uint32_t>(1u << 16, pow2_at_least(n9 * 16 + 2));   // sparse: a false hit costs parallelism
-        out.p8_tab.assign(slots, 0);
+        const uint32_t buckets = std::max<uint32_t>(1u << 14, pow2_at_least(n9 * 4 + 2));   // sparse: a false hit costs parallelism
+        out.p8_tab.assign((size_t)buckets * 2, 0);
         for (const auto& kv : enc) {
             const std::string& k = kv.first;
             if (k.size() <= (size_t)SPL_T8_MAX) continue;
-            const uint32_t h = hash_p8(load_le(k, 0), load_le(k, 4));
-            uint16_t& cell = out.p8_tab[h & (slots - 1)];
-            const uint32_t len = (uint32_t)std::min<size_t>(k.size(), 255), tag = p8_tag(h);
-            if (cell == 0) cell = (uint16_t)(tag << 8 | len);
-            else {
-                const uint32_t t = cell >> 8, l = std::max<uint32_t>(cell & 0xFFu, len);
-                cell = (uint16_t)((t == tag ? tag : 255u) << 8 | l);
+            const uint32_t k0 = load_le(k, 0), k1 = load_le(k, 4);
+            uint32_t* e = &out.p8_tab[(size_t)(hash_p8(k0, k1) & (buckets - 1)) * 2];
+            const uint32_t len = (uint32_t)std::min<size_t>(k.size(), 255), tag = p8_tag(k0, k1);
+            int slot = -1;
+            for (int i = 0; i < 2 && slot < 0; i++) if (e[i] != 0 && (e[i] >> 8) == tag) slot = i;
+            for (int i = 0; i < 2 && slot < 0; i++) if (e[i] == 0) slot = i;
+            if (slot < 0) {                              // a third prefix: entry 1 turns into "every key"
+                e[1] = 0xFFFFFFu << 8 | std::max<uint32_t>(e[1] & 0xFFu, len);
+            } else if ((e[slot] >> 8) == 0xFFFFFFu) {    // (cannot happen: the wildcard tag is not a key's tag)
+                e[slot] = 0xFFFFFFu << 8 | std::max<uint32_t>(e[slot] & 0xFFu, len);
+            } else {
+                e[slot] = tag << 8 | std::max<uint32_t>(e[slot] & 0xFFu, len);
             }
         }
     }

@@ -27,7 +27,7 @@ struct HostTables {
     std::vector<uint8_t> key_blob;
     std::vector<uint64_t> pair_tab;
     std::vector<uint32_t> byte_id;      // 256
-    std::vector<uint16_t> p8_tab;       // DeviceTables::p8_tab
+    std::vector<uint32_t> p8_tab;       // DeviceTables::p8_tab (two words per bucket)
     uint32_t max_key_len = 0;           // in the key space the kernels see (raw bytes)
     uint32_t n_keys = 0, n_pairs = 0;
     uint32_t max_id = 0;
