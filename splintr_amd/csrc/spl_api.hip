@@ -28,8 +28,9 @@ int fail(int code, const std::string& msg) {
             return fail(SPL_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));   \
     } while (0)
 
+constexpr size_t QCOUNT_WORDS = 16;      // Batch::qcount
 enum { KI_MARK = 0, KI_SPECIAL, KI_PRETOK, KI_DEFER, KI_BPELANES, KI_BPELONG, KI_COUNT, KI_SCAN, KI_COMPACT, KI_N };
-const char* const k_names[KI_N] = {"memset+k_mark_docs", "k_special_scan", "k_pretok", "k_deferred", "k_bpe_lanes64",
+const char* const k_names[KI_N] = {"memset+k_mark_docs", "k_special_scan", "k_pretok", "k_deferred", "k_bpe_lanes64|k_bpe_segments",
                                    "k_bpe_long", "k_count", "k_scan", "k_compact_docs|k_tile_out"};
 
 template <class T> int dev_upload(const std::vector<T>& v, const T** out) {
@@ -114,7 +115,7 @@ int reserve(spl_tokenizer* t, uint64_t max_bytes, uint64_t max_docs) {
     free_workspace(t);
     const size_t nblk = (size_t)(nb / RANK_BLK) + 2;
     t->bitmap_words = nblk * 32 + 64;
-    t->zero_words = 3 * t->bitmap_words + 8;
+    t->zero_words = 3 * t->bitmap_words + QCOUNT_WORDS;
     HIP_TRY(hipMalloc((void**)&t->d_zero, t->zero_words * 4));
     HIP_TRY(hipMalloc((void**)&t->d_stage, (nb + 8192) * 4));
     HIP_TRY(hipMalloc((void**)&t->d_rank, (nb + 8192) * 12));   // ranks + two words of aux per byte
@@ -223,7 +224,7 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
     const bool direct = !queue_mode && small_tiles && t->force_tile != 3 && n_bytes <= SPL_DIRECT_MAX_BYTES;
     if (queue_mode) {
         t->bitmap_dirty = true;
-        HIP_TRY(hipMemsetAsync(t->d_zero, 0, (2 * uw + 8) * 4, s));
+        HIP_TRY(hipMemsetAsync(t->d_zero, 0, (2 * uw + QCOUNT_WORDS) * 4, s));
         b.tdesc = t->d_tdesc; b.tile_ids = t->d_tile_ids; b.tctl = t->d_tctl; b.tile_bits = t->d_tile_bits; b.tcnt = t->d_tcnt;
         b.tgroups = t->tgroups; b.tpar = t->tpar; b.tslot = (uint32_t)TileGeom<SPL_TILE_SMALL>::Wv + 1u;
         t->tpar ^= 1u;
@@ -233,7 +234,9 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
         hipLaunchKernelGGL((k_pretok<SPL_TILE_SMALL, false, true>), dim3(ntiles), dim3(NT), 0, s, t->dt, b);
         MARK(KI_DEFER);
         hipLaunchKernelGGL(k_deferred_wave, dim3(256), dim3(64), 0, s, t->dt, b);
-        MARK(KI_BPELANES); MARK(KI_BPELONG);
+        MARK(KI_BPELANES);
+        hipLaunchKernelGGL(k_bpe_segments, dim3(std::min<uint32_t>(2048, ntiles / 4 + 8)), dim3(NT), 0, s, t->dt, b);
+        MARK(KI_BPELONG);
         hipLaunchKernelGGL(k_bpe_long, dim3(std::min<uint32_t>(2048, ntiles / 4 + 8)), dim3(NT), 0, s, t->dt, b);
         MARK(KI_COUNT);
         hipLaunchKernelGGL((k_range_count<SPL_TILE_SMALL>), dim3(ntiles), dim3(64), 0, s, b);
@@ -244,7 +247,7 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
         if (special) {
             // the three bitmaps are cleared per call; documents and literals are marked by the
             // multi-pass kernels, the tile kernel reads the bitmaps on top of its document search
-            HIP_TRY(hipMemsetAsync(t->d_zero, 0, (3 * uw + 8) * 4, s));
+            HIP_TRY(hipMemsetAsync(t->d_zero, 0, (3 * uw + QCOUNT_WORDS) * 4, s));
             t->bitmap_dirty = true;
         } else if (t->bitmap_dirty) {
             HIP_TRY(hipMemsetAsync(t->d_zero, 0, t->zero_words * 4, s));
@@ -272,7 +275,7 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
     } else {
     t->bitmap_dirty = true;
     MARK(KI_MARK);
-    HIP_TRY(hipMemsetAsync(t->d_zero, 0, ((special ? 3 : 2) * uw + 8) * 4, s));
+    HIP_TRY(hipMemsetAsync(t->d_zero, 0, ((special ? 3 : 2) * uw + QCOUNT_WORDS) * 4, s));
     if (n_docs) hipLaunchKernelGGL(k_mark_docs, dim3((uint32_t)((n_docs + 255) / 256)), dim3(256), 0, s, b);
     MARK(KI_SPECIAL);
     if (special && n_bytes) {
@@ -287,6 +290,7 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
     if (ntiles) hipLaunchKernelGGL(k_deferred_wave, dim3(256), dim3(64), 0, s, t->dt, b);
     MARK(KI_BPELANES);
     if (ntiles && !small_tiles) hipLaunchKernelGGL(k_bpe_lanes64, dim3(256 * 5), dim3(64), 0, s, t->dt, b);
+    if (ntiles && small_tiles) hipLaunchKernelGGL(k_bpe_segments, dim3(std::min<uint32_t>(2048, ntiles / 4 + 8)), dim3(NT), 0, s, t->dt, b);
     MARK(KI_BPELONG);
     if (ntiles) hipLaunchKernelGGL(k_bpe_long, dim3(std::min<uint32_t>(2048, ntiles / 4 + 8)), dim3(NT), 0, s, t->dt, b);
     MARK(KI_COUNT);
@@ -318,8 +322,8 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
         HIP_TRY(hipEventSynchronize(t->ev[KI_N]));
         for (int i = 0; i < KI_N; i++) {
             // slots whose kernels were not launched in this mode would only show the event overhead
-            const bool launched = queue_mode ? (i != KI_SPECIAL && i != KI_BPELANES && i != KI_SCAN) : direct ? (i == KI_PRETOK || i == KI_COMPACT || (special && (i == KI_MARK || i == KI_SPECIAL)))
-                                         : !((i == KI_SPECIAL && !special) || (i == KI_BPELANES && small_tiles) ||
+            const bool launched = queue_mode ? (i != KI_SPECIAL && i != KI_SCAN) : direct ? (i == KI_PRETOK || i == KI_COMPACT || (special && (i == KI_MARK || i == KI_SPECIAL)))
+                                         : !((i == KI_SPECIAL && !special) ||
                                              (i == KI_COUNT && fused_scan_used));
             if (!launched) continue;
             float ms = 0;

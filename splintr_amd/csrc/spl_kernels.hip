@@ -1486,7 +1486,8 @@ constexpr int SG_MID = SG_ID + SEG_ROWS;     // [32] segments of 9..16 bytes
 constexpr int SG_WORDS = SG_MID + 32;
 template <class EmitG>
 __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, const Batch& b, uint32_t* s_lq, uint32_t nl,
-                                                      uint32_t* slab, uint32_t* scr, uint32_t* s_wsum4, EmitG emit_g) {
+                                                      uint32_t* slab, uint32_t* scr, uint32_t* s_wsum4, const uint8_t* win_txt,
+                                                      int64_t win_lo, int64_t win_hi, EmitG emit_g) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     uint32_t* const off = scr + SG_OFF;
     uint32_t* const item = scr + SG_ITEM;
@@ -1552,7 +1553,10 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
             const uint64_t g = (uint64_t)s_lq[2 * item[k]] + ci, B = b.n_bytes;
             cap = (int)(cn - ci);
             maxlen = cn - ci < (uint32_t)SUB_LMAX ? (int)(cn - ci) : SUB_LMAX;
-            if (g + 8 <= B) { __builtin_memcpy(&w0, b.text + g, 4); __builtin_memcpy(&w1, b.text + g + 4, 4); }
+            if ((int64_t)g >= win_lo && (int64_t)g + 8 <= win_hi) {        // staged with the tile's window: no trip to HBM
+                const uint8_t* const t8 = win_txt + ((int64_t)g - win_lo);
+                for (int q = 0; q < 4; q++) { w0 |= (uint32_t)t8[q] << (8 * q); w1 |= (uint32_t)t8[4 + q] << (8 * q); }
+            } else if (g + 8 <= B) { __builtin_memcpy(&w0, b.text + g, 4); __builtin_memcpy(&w1, b.text + g + 4, 4); }
             else for (int q = 0; q < 8; q++) if (g + q < B) (q < 4 ? w0 : w1) |= (uint32_t)b.text[g + q] << (8 * (q & 3));
             bid = T.byte_id[w0 & 0xFFu];
         }
@@ -2207,7 +2211,8 @@ void k_pretok(DeviceTables T, Batch b) {
             for (;;) {
                 // (medium chunks sit at the back of the list, unused entries have length 0)
                 const uint32_t nl0 = (s_dq[11] || s_dq[0] > (uint32_t)DIRECT_LQCAP) ? (uint32_t)DIRECT_LQCAP : s_dq[0];
-                const uint32_t nl = bpe_tail_segments(T, b, s_lq, nl0, s_u.t.slab[0], reinterpret_cast<uint32_t*>(s_cpos), s_wsum, emit_g);
+                const uint32_t nl = bpe_tail_segments(T, b, s_lq, nl0, s_u.t.slab[0], reinterpret_cast<uint32_t*>(s_cpos), s_wsum,
+                                                      s_txt, w0, w0 + iT, emit_g);
                 for (uint32_t it = wv; it < nl; it += NT / 64) {         // one wavefront per chunk
                     const int n = (int)s_lq[2 * it + 1];
                     const uint32_t pos = s_lq[2 * it];
@@ -2655,6 +2660,41 @@ __global__ __launch_bounds__(64) void k_range_out(Batch b) {
     }
 }
 
+// Long chunks from the global queue, first pass: the segment merge of the tile tail
+// (bpe_tail_segments) over batches of queue items.  What it finishes is struck off the queue
+// (length 0); a chunk it leaves -- a segment beyond a wavefront's 64 bytes -- stays, or comes back
+// as a shorter item, for the node-list loops of k_bpe_long.
+constexpr uint32_t SEG_BATCH = 12;
+__global__ __launch_bounds__(NT) void k_bpe_segments(DeviceTables T, Batch b) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_slab[SEG_ROWS * SUB_W];
+    __shared__ uint32_t s_lq[2 * DIRECT_LQCAP];
+    __shared__ uint32_t s_scr[SG_WORDS];
+    __shared__ uint32_t s_wsum[NT / 64];
+    __shared__ uint32_t s_first;
+    const int tid = threadIdx.x;
+    const uint32_t nq = min(b.qcount[2], b.qcaplong), nbig = min(b.qcount[4], b.qcaplong), total = nq + nbig;
+    uint2* const qbig = b.qlong + (b.qcaplong - 1u);
+    auto slot = [&](uint32_t i) -> uint2* { return i < nq ? b.qlong + i : qbig - (i - nq); };
+    for (uint32_t first = blockIdx.x * SEG_BATCH;;) {              // (the first batch is the workgroup's own index)
+        if (first >= total) break;
+        const uint32_t cnt = total - first < SEG_BATCH ? total - first : SEG_BATCH;
+        if ((uint32_t)tid < cnt) {
+            const uint2 item = *slot(first + tid);
+            s_lq[2 * tid] = item.x;
+            s_lq[2 * tid + 1] = item.y;
+        }
+        __syncthreads();
+        const uint32_t nl2 = bpe_tail_segments(T, b, s_lq, cnt, s_slab, s_scr, s_wsum, nullptr, 0, 0,
+                                               [&](uint32_t q, uint32_t id) { emit_token(b, q, id); });
+        if ((uint32_t)tid < cnt) *slot(first + tid) = make_uint2(s_lq[2 * tid], s_lq[2 * tid + 1]);
+        else if ((uint32_t)tid < nl2 && s_lq[2 * tid + 1] >= 2u) push_long(b, s_lq[2 * tid], s_lq[2 * tid + 1]);   // segments set aside
+        if (tid == 0) s_first = gridDim.x * SEG_BATCH + atomicAdd(&b.qcount[8], SEG_BATCH);
+        __syncthreads();
+        first = s_first;
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(NT) void k_bpe_long(DeviceTables T, Batch b) {
     __shared__ uint32_t s_id[NT / 64][WAVE_NMAX];
     __shared__ uint32_t s_rk[NT / 64][WAVE_NMAX];
@@ -2678,7 +2718,7 @@ __global__ __launch_bounds__(NT) void k_bpe_long(DeviceTables T, Batch b) {
         const uint32_t wgid = blockIdx.x * (NT / 64) + wv;
         for (uint32_t it = wgid; it < nbig;) {
             const uint2 item = *(qbig - it);
-            if ((int)item.y <= WAVE_NMAX)
+            if ((int)item.y <= WAVE_NMAX && item.y >= 2u)               // (length 0: done by k_bpe_segments)
                 bpe_wave(T, b, item.x, (int)item.y, s_id[wv], s_rk[wv], s_nx[wv], s_pv[wv],
                          [&](uint32_t q, uint32_t id) { emit_token(b, q, id); });
             uint32_t nxt = 0;
@@ -2690,7 +2730,7 @@ __global__ __launch_bounds__(NT) void k_bpe_long(DeviceTables T, Batch b) {
             const uint32_t it = base + (lane >> 4);
             uint2 item = make_uint2(0, 0);
             if (it < nq) item = b.qlong[it];
-            const bool has = it < nq;
+            const bool has = it < nq && item.y >= 2u;
             if (__any(has)) {
                 const uint32_t pos = item.x;
                 bpe_group16<GROUP_NMAX / 16>(T, has ? (int)item.y : 0, [&](int i) { return (uint32_t)b.text[pos + i]; },
