@@ -2716,29 +2716,49 @@ __global__ __launch_bounds__(NT) void k_bpe_long(DeviceTables T, Batch b) {
         // (the first item of every wavefront is its own index, later ones come from the cursor: an
         //  empty or short queue costs no atomics at all)
         const uint32_t wgid = blockIdx.x * (NT / 64) + wv;
-        for (uint32_t it = wgid; it < nbig;) {
-            const uint2 item = *(qbig - it);
-            if ((int)item.y <= WAVE_NMAX && item.y >= 2u)               // (length 0: done by k_bpe_segments)
-                bpe_wave(T, b, item.x, (int)item.y, s_id[wv], s_rk[wv], s_nx[wv], s_pv[wv],
-                         [&](uint32_t q, uint32_t id) { emit_token(b, q, id); });
+        // (items are pulled 16 and 64 at a time and the ones k_bpe_segments struck off -- most of
+        //  them in multi-byte text -- cost a ballot, not a trip to the shared cursor each)
+        for (uint32_t base = wgid * 16u; base < nbig;) {
+            const uint32_t it = base + (uint32_t)(lane & 15);
+            uint2 item = make_uint2(0, 0);
+            if (lane < 16 && it < nbig) item = *(qbig - it);
+            unsigned long long live = __ballot(item.y >= 2u && (int)item.y <= WAVE_NMAX);
+            while (live) {
+                const int k = __builtin_ctzll(live);
+                live &= live - 1ull;
+                bpe_wave(T, b, (uint32_t)__builtin_amdgcn_readlane((int)item.x, k), __builtin_amdgcn_readlane((int)item.y, k),
+                         s_id[wv], s_rk[wv], s_nx[wv], s_pv[wv], [&](uint32_t q, uint32_t id) { emit_token(b, q, id); });
+            }
             uint32_t nxt = 0;
-            if (lane == 0) nxt = atomicAdd(&b.qcount[6], 1u);
-            it = nwaves + __builtin_amdgcn_readfirstlane(nxt);
+            if (lane == 0) nxt = atomicAdd(&b.qcount[6], 16u);
+            base = nwaves * 16u + __builtin_amdgcn_readfirstlane(nxt);
         }
         // group phase: chunks of up to GROUP_NMAX bytes, four per wavefront, nodes in registers
-        for (uint32_t base = wgid * 4; base < nq;) {
-            const uint32_t it = base + (lane >> 4);
+        for (uint32_t base = wgid * 64u; base < nq;) {
+            const uint32_t it = base + (uint32_t)lane;
             uint2 item = make_uint2(0, 0);
             if (it < nq) item = b.qlong[it];
-            const bool has = it < nq && item.y >= 2u;
-            if (__any(has)) {
-                const uint32_t pos = item.x;
-                bpe_group16<GROUP_NMAX / 16>(T, has ? (int)item.y : 0, [&](int i) { return (uint32_t)b.text[pos + i]; },
+            unsigned long long live = __ballot(item.y >= 2u);
+            while (live) {
+                int mine = -1;                               // the item of this lane's group of 16
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    if (live) {
+                        const int k = __builtin_ctzll(live);
+                        live &= live - 1ull;
+                        mine = (lane >> 4) == g ? k : mine;
+                    }
+                }
+                const int src = mine < 0 ? 0 : mine;         // (every lane takes part in the exchange)
+                const uint32_t pos = (uint32_t)__shfl((int)item.x, src);
+                const int n_src = __shfl((int)item.y, src);
+                const int n = mine < 0 ? 0 : n_src;
+                bpe_group16<GROUP_NMAX / 16>(T, n, [&](int i) { return (uint32_t)b.text[pos + i]; },
                                              [&](int i, uint32_t id) { emit_token(b, pos + (uint32_t)i, id); });
             }
             uint32_t nxt = 0;
-            if (lane == 0) nxt = atomicAdd(&b.qcount[7], 4u);
-            base = nwaves * 4 + __builtin_amdgcn_readfirstlane(nxt);
+            if (lane == 0) nxt = atomicAdd(&b.qcount[7], 64u);
+            base = nwaves * 64u + __builtin_amdgcn_readfirstlane(nxt);
         }
     }
     __syncthreads();
