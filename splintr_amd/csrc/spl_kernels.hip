@@ -1321,6 +1321,8 @@ template <int NW> __device__ __forceinline__ int prev_set64(const unsigned long 
     }
     return res;
 }
+template <int NPL, class IdAt, class Emit>
+__device__ __forceinline__ void wave_tab_merge(const DeviceTables& T, int n, const uint32_t* sub, IdAt id_at, Emit emit);
 template <int NPL, class WordAt, class Emit>
 __device__ __forceinline__ void bpe_wave_tab(const DeviceTables& T, int n, uint32_t* sub, WordAt word_at, Emit emit) {
     const int lane = threadIdx.x & 63;
@@ -1335,11 +1337,17 @@ __device__ __forceinline__ void bpe_wave_tab(const DeviceTables& T, int n, uint3
             sub[i * SUB_W + len - 2] = probe_short(T, k0, k1, 0u, (uint32_t)len);
         }
     }
+    wave_tab_merge<NPL>(T, n, sub, [&](int i) { return T.byte_id[word_at(i) & 0xFFu]; }, emit);
+}
+// The merge loop of bpe_wave_tab over a filled table: `sub` is row 0, id_at(i) the id of byte i.
+template <int NPL, class IdAt, class Emit>
+__device__ __forceinline__ void wave_tab_merge(const DeviceTables& T, int n, const uint32_t* sub, IdAt id_at, Emit emit) {
+    const int lane = threadIdx.x & 63;
     uint32_t id[NPL], rk[NPL];
 #pragma unroll
     for (int k = 0; k < NPL; k++) {
         const int i = lane + 64 * k;
-        id[k] = i < n ? T.byte_id[word_at(i) & 0xFFu] : SPL_DEAD;
+        id[k] = i < n ? id_at(i) : SPL_DEAD;
         rk[k] = (i + 1 < n) ? sub[i * SUB_W] : SPL_NO_RANK;
     }
     unsigned long long alive[NPL];
@@ -1483,8 +1491,9 @@ constexpr int SG_CTL = 91;       // [8] packed chunks, long segments, chunks to 
                                  //     (bit = list index), cut, chunks appended, mid segments
 constexpr int SG_ID = 100;       // [SEG_ROWS] id of each row's byte
 constexpr int SG_MID = SG_ID + SEG_ROWS;     // [32] segments of 9..16 bytes
-constexpr int SG_WORDS = SG_MID + 32;
-template <class EmitG>
+constexpr int SG_XSEG = SG_MID + 32;          // [4] segments of 65 .. 64 XNPL bytes
+constexpr int SG_WORDS = SG_XSEG + 4;
+template <int XNPL, class EmitG>
 __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, const Batch& b, uint32_t* s_lq, uint32_t nl,
                                                       uint32_t* slab, uint32_t* scr, uint32_t* s_wsum4, const uint8_t* win_txt,
                                                       int64_t win_lo, int64_t win_hi, EmitG emit_g) {
@@ -1494,6 +1503,7 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
     uint32_t* const hard = scr + SG_HARD;
     uint32_t* const lseg = scr + SG_LONG;
     uint32_t* const mseg = scr + SG_MID;
+    uint32_t* const xseg = scr + SG_XSEG;
     uint32_t* const ctl = scr + SG_CTL;
     uint32_t* const sid = scr + SG_ID;
     auto hbits = [&](int pos) {                              // 32 boundary bits from row `pos` on
@@ -1534,7 +1544,7 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
             const uint32_t total = tm ? (uint32_t)__builtin_amdgcn_readlane((int)endv, 63 - __builtin_clzll(tm)) : 0u;
             if (lane == 0) {
                 off[nk] = total;
-                ctl[0] = nk; ctl[1] = 0; ctl[2] = 0; ctl[3] = tried | (uint32_t)tm; ctl[4] = cut; ctl[6] = 0;
+                ctl[0] = nk; ctl[1] = 0; ctl[2] = 0; ctl[3] = tried | (uint32_t)tm; ctl[4] = cut; ctl[6] = 0; ctl[7] = 0;
             }
         }
         __syncthreads();
@@ -1656,14 +1666,16 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
                 const uint32_t h1 = hbits(tid + 32);
                 const uint32_t l2 = h0 ? (uint32_t)__ffs((int)h0) : h1 ? 32u + (uint32_t)__ffs((int)h1) : 65u;
                 if (l2 <= 64u) lseg[atomicAdd(&ctl[1], 1u)] = (uint32_t)tid | l2 << 16;
-                else {                                       // longer than a wavefront: a chunk of its own for the loops below
+                else {
                     int q = tid + 64;
                     uint32_t hq;
                     while ((hq = hbits(q)) == 0) q += 32;    // (the last row of a chunk is a boundary)
-                    const uint32_t qi = nl + atomicAdd(&ctl[5], 1u);
-                    if (qi < (uint32_t)DIRECT_LQCAP) {
+                    const uint32_t l3 = (uint32_t)(q - tid) + (uint32_t)__ffs((int)hq);
+                    const uint32_t qi = nl + (l3 <= 64u * XNPL ? 0u : atomicAdd(&ctl[5], 1u));
+                    if (l3 <= 64u * XNPL) xseg[atomicAdd(&ctl[7], 1u)] = (uint32_t)tid | l3 << 16;   // a wavefront, several nodes per lane
+                    else if (qi < (uint32_t)DIRECT_LQCAP) {  // longer still: a chunk of its own for the loops below
                         s_lq[2 * qi] = first_byte_of(tid);
-                        s_lq[2 * qi + 1] = (uint32_t)(q - tid) + (uint32_t)__ffs((int)hq);
+                        s_lq[2 * qi + 1] = l3;
                         atomicOr(&ctl[3], 1u << qi);         // (not to be packed again)
                     } else {                                 // no room: the whole chunk stays on the list
                         uint32_t k = 0;
@@ -1696,6 +1708,12 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
             wave64_merge(T, lrow, len >= 64 ? ~0ull : ((1ull << len) - 1ull), len, lane + 1 < len ? lrow[0] : SPL_NO_RANK,
                          lown ? sid[s0 + lane] : SPL_DEAD,
                          [&](int i, uint32_t id) { emit_g(gpos + (uint32_t)i, id); });
+        }
+        for (uint32_t q = (uint32_t)wv; q < ctl[7]; q += NT / 64) {          // 65 .. 64 XNPL bytes
+            const int s0 = (int)(xseg[q] & 0xFFFFu), len = (int)(xseg[q] >> 16);
+            const uint32_t gpos = first_byte_of(s0);
+            wave_tab_merge<XNPL>(T, len, slab + s0 * SUB_W, [&](int i) { return sid[s0 + i]; },
+                                 [&](int i, uint32_t id) { emit_g(gpos + (uint32_t)i, id); });
         }
         __syncthreads();
         if ((uint32_t)tid < nk && !((ctl[2] >> tid) & 1u)) {
@@ -2211,7 +2229,7 @@ void k_pretok(DeviceTables T, Batch b) {
             for (;;) {
                 // (medium chunks sit at the back of the list, unused entries have length 0)
                 const uint32_t nl0 = (s_dq[11] || s_dq[0] > (uint32_t)DIRECT_LQCAP) ? (uint32_t)DIRECT_LQCAP : s_dq[0];
-                const uint32_t nl = bpe_tail_segments(T, b, s_lq, nl0, s_u.t.slab[0], reinterpret_cast<uint32_t*>(s_cpos), s_wsum,
+                const uint32_t nl = bpe_tail_segments<2>(T, b, s_lq, nl0, s_u.t.slab[0], reinterpret_cast<uint32_t*>(s_cpos), s_wsum,
                                                       s_txt, w0, w0 + iT, emit_g);
                 for (uint32_t it = wv; it < nl; it += NT / 64) {         // one wavefront per chunk
                     const int n = (int)s_lq[2 * it + 1];
@@ -2684,7 +2702,7 @@ __global__ __launch_bounds__(NT) void k_bpe_segments(DeviceTables T, Batch b) {
             s_lq[2 * tid + 1] = item.y;
         }
         __syncthreads();
-        const uint32_t nl2 = bpe_tail_segments(T, b, s_lq, cnt, s_slab, s_scr, s_wsum, nullptr, 0, 0,
+        const uint32_t nl2 = bpe_tail_segments<2>(T, b, s_lq, cnt, s_slab, s_scr, s_wsum, nullptr, 0, 0,
                                                [&](uint32_t q, uint32_t id) { emit_token(b, q, id); });
         if ((uint32_t)tid < cnt) *slot(first + tid) = make_uint2(s_lq[2 * tid], s_lq[2 * tid + 1]);
         else if ((uint32_t)tid < nl2 && s_lq[2 * tid + 1] >= 2u) push_long(b, s_lq[2 * tid], s_lq[2 * tid + 1]);   // segments set aside
