@@ -461,3 +461,66 @@ def test_queue_mode_with_window_edges_and_long_runs(coracle, name):
     texts += list(corpus.worst_case(20000))
     assert sum(len(t.encode("utf-8")) for t in texts) > (8 << 20)
     assert_batch_equal(name, texts, coracle)
+
+
+def _multibyte_texts(seed, n_docs, doc_bytes):
+    """CJK / kana / hangul / emoji text (splintr_amd.corpus.cjk) with everything the segment merge has
+    to get right mixed in: runs without punctuation far beyond a table pass (256 rows) and beyond a
+    chain window (2048 bytes), Latin words glued to CJK characters (one \\p{L}+ chunk), multi-character
+    tokens, repeated characters, lone continuation bytes' neighbours (4-byte emoji), combining marks."""
+    from splintr_amd import corpus
+    rng = random.Random(seed)
+    han = "的一是不了人我在有他这为之大来以个中上们到说国和地也子时道出而要于就下得可你年生自会那后能对着事其里所去行过家十用发天如然作方成者多日都三小军二无同么经法当起与好看学进种将还分此心前面又定见只主没公从"
+    kana = "あいうえおかきくけこさしすせそたちつてとなにぬねのはひふへほまみむめもやゆよらりるれろわをんアイウエオカキクケコ"
+    hangul = "가나다라마바사아자차카타파하각간갈감강개거건걸검것게결경계고공과관교구국군그극근금기길김나남내너녀년노"
+    out = []
+    for _ in range(n_docs):
+        parts = []
+        size = 0
+        while size < doc_bytes:
+            r = rng.random()
+            if r < 0.55:
+                s = corpus.cjk(rng, rng.randint(30, 400))
+            elif r < 0.65:
+                s = "".join(rng.choice(han) for _ in range(rng.choice((40, 90, 200, 700, 1500))))       # no punctuation at all
+            elif r < 0.72:
+                s = "".join(rng.choice(kana) for _ in range(rng.choice((30, 60, 120, 300))))
+            elif r < 0.78:
+                s = "".join(rng.choice(hangul) for _ in range(rng.choice((25, 50, 100))))
+            elif r < 0.86:
+                s = "".join(rng.choice(["data", "Token", "x", "über", "naïve", "Ελλάδα", "мир"]) + rng.choice(han) * rng.randint(1, 3)
+                            for _ in range(rng.randint(3, 30)))
+            elif r < 0.92:
+                s = rng.choice(han) * rng.choice((3, 17, 64, 65, 129, 300)) + rng.choice(["。", "", " "])
+            elif r < 0.96:
+                s = "".join(rng.choice(["👨‍👩‍👧", "🙂", "🇯🇵", "é", "की", "ไทย"]) for _ in range(rng.randint(1, 40)))
+            else:
+                s = rng.choice([" ", "\n", "，", "、", "「", "」 ", "123", " the "]) * rng.randint(1, 5)
+            parts.append(s)
+            size += len(s.encode("utf-8"))
+        out.append("".join(parts))
+    return out
+
+
+@pytest.mark.parametrize("geom", [0, 1, 3])
+@pytest.mark.parametrize("name", VOCABS)
+def test_multibyte_text_merges_by_segments(coracle, name, geom):
+    """Multi-byte text goes through the segment merge (bpe_wave64_tab's groups, bpe_tail_segments in the
+    tile tail, k_bpe_segments over the global queue in the multi-pass pipeline): ~1.5 MB of it, every
+    vocabulary, documents of 200 B to 20 KB so that tile and window edges fall everywhere."""
+    texts = _multibyte_texts(41, 60, 20000) + _multibyte_texts(42, 400, 600) + _multibyte_texts(43, 300, 200)
+    _force_tiles(name, geom)
+    try:
+        assert_batch_equal(name, texts, coracle)
+        assert_batch_equal(name, ["".join(texts[:40])], coracle)       # one document of ~0.8 MB
+    finally:
+        _force_tiles(name, 0)
+
+
+@pytest.mark.parametrize("name", ["o200k_base", "deepseek_v3"])
+def test_multibyte_text_in_queue_mode(coracle, name):
+    """The same through queue mode (a batch over 8 MB: long chunks travel the global queue to
+    k_bpe_segments and k_bpe_long)."""
+    texts = _multibyte_texts(51, 450, 20000)
+    assert sum(len(t.encode("utf-8")) for t in texts) > (8 << 20)
+    assert_batch_equal(name, texts, coracle)
