@@ -1820,7 +1820,11 @@ void k_pretok(DeviceTables T, Batch b) {
     if (tid < 128) s_ascii[tid] = T.ucls_stage2[((uint32_t)T.ucls_stage1[0] << T.ucls_shift) + tid];
     if (tid < 4) s_nq[tid] = 0;
     if (tid < 12) s_dq[tid] = 0;
-    if (DIRECT && tid < DIRECT_LQCAP) s_lq[2 * tid + 1] = 0;     // (length 0: no entry)
+    if (DIRECT) {                                            // (length 0: no entry)
+        int t_early = tid;                                   // an index of its own: shared with the tail's uses of
+        asm volatile("" : "+v"(t_early));                    // s_lq[2 * tid], it would be kept -- spilled -- until then
+        if (t_early < DIRECT_LQCAP) s_lq[2 * t_early + 1] = 0;
+    }
     if (tid == 0) s_nch = 0;
     // single pass: the window's text starts straight from doc_off.  NT-ary search for the first
     // document that starts at or after the window (two rounds up to 65 536 documents), then the

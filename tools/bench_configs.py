@@ -16,6 +16,13 @@ from splintr_amd import Tokenizer, corpus  # noqa: E402
 from splintr_amd.device import DeviceBatch, encode_device, reserve, result_csr  # noqa: E402
 
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.25
+
+
+def _cjk_docs(n):
+    import random
+    rng = random.Random(7)
+    return [corpus.cjk(rng, 4200)[:4096] for _ in range(n)]
+
 dev = torch.device("cuda", 0)
 CFG = [
     ("C1 cl100k 1000 x ~1 KB English", "cl100k_base", lambda: corpus.c1(1000)),
@@ -23,6 +30,9 @@ CFG = [
     ("C3 o200k %d x 4 KB prose+JSON+CJK" % int(10000 * scale), "o200k_base", lambda: corpus.c3(int(10000 * scale))),
     ("C4 llama3 %d short prompts" % int(1000000 * scale * 0.25), "llama3", lambda: corpus.c4(int(1000000 * scale * 0.25))),
     ("C5 deepseek_v3 %d x 2 MiB" % max(1, int(100 * scale * 0.25)), "deepseek_v3", lambda: corpus.c5(max(1, int(100 * scale * 0.25)))),
+    # not a BASELINE config: the worst case of the segment merge's target, text that is multi-byte throughout
+    ("X1 cl100k 250 x 4 KB CJK / kana / hangul only", "cl100k_base", lambda: _cjk_docs(250)),
+    ("X2 o200k 2500 x 4 KB CJK / kana / hangul only", "o200k_base", lambda: _cjk_docs(2500)),
 ]
 print(f"{'config':52s} {'MB':>8s} {'tokens':>10s} {'us/step':>10s} {'GB/s':>8s}  parity")
 for label, vocab, gen in CFG:
