@@ -237,7 +237,7 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
         MARK(KI_BPELANES);
         hipLaunchKernelGGL(k_bpe_segments, dim3(std::min<uint32_t>(2048, ntiles / 4 + 8)), dim3(NT), 0, s, t->dt, b);
         MARK(KI_BPELONG);
-        hipLaunchKernelGGL(k_bpe_long, dim3(std::min<uint32_t>(2048, ntiles / 4 + 8)), dim3(NT), 0, s, t->dt, b);
+        hipLaunchKernelGGL(k_bpe_long, dim3(std::min<uint32_t>(2048, ntiles / 4 + 8)), dim3(NT), 0, s, t->dt, b, 1);
         MARK(KI_COUNT);
         hipLaunchKernelGGL((k_range_count<SPL_TILE_SMALL>), dim3(ntiles), dim3(64), 0, s, b);
         MARK(KI_SCAN); MARK(KI_COMPACT);
@@ -292,7 +292,7 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
     if (ntiles && !small_tiles) hipLaunchKernelGGL(k_bpe_lanes64, dim3(256 * 5), dim3(64), 0, s, t->dt, b);
     if (ntiles && small_tiles) hipLaunchKernelGGL(k_bpe_segments, dim3(std::min<uint32_t>(2048, ntiles / 4 + 8)), dim3(NT), 0, s, t->dt, b);
     MARK(KI_BPELONG);
-    if (ntiles) hipLaunchKernelGGL(k_bpe_long, dim3(std::min<uint32_t>(2048, ntiles / 4 + 8)), dim3(NT), 0, s, t->dt, b);
+    if (ntiles) hipLaunchKernelGGL(k_bpe_long, dim3(std::min<uint32_t>(2048, ntiles / 4 + 8)), dim3(NT), 0, s, t->dt, b, small_tiles ? 1 : 0);
     MARK(KI_COUNT);
     const bool fused_scan = b.n_blk <= 8192;
     fused_scan_used = fused_scan;

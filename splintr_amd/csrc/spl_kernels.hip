@@ -1143,8 +1143,8 @@ __device__ __forceinline__ uint32_t mbcnt64(unsigned long long mask) {      // s
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 __device__ __forceinline__ void bpe_rounds_core(const uint8_t* text, const uint32_t* byte_id, const uint64_t* pair_tab,
-                                                          uint32_t pair_mask, uint32_t* ids, uint32_t* rks, uint32_t* aux, int n,
-                                                          uint32_t* s_red4) {
+                                                uint32_t pair_mask, uint32_t* ids, uint32_t* rks, uint32_t* aux, const int n,
+                                                uint32_t* s_red4, int& n_out, const uint32_t*& pos_out) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     DeviceTables T{};
     T.pair_tab = pair_tab;
@@ -1155,16 +1155,22 @@ __device__ __forceinline__ void bpe_rounds_core(const uint8_t* text, const uint3
 #pragma nounroll
     for (int i = tid; i < n; i += NT) rks[i] = (i + 1 < n) ? pair_rank(T, ids[i], ids[i + 1]) : SPL_NO_RANK;
     __syncthreads();
-    const int groups = (n + 63) >> 6, gw = (groups + NT / 64 - 1) / (NT / 64);
-    const int g0 = wv * gw, g1 = g0 + gw < groups ? g0 + gw : groups;
+    // The slots are compacted whenever half of them are tomb-stones (every pass of a round walks all
+    // slots): ncur slots in use, posbuf[i] = original offset of slot i's node once that differs from i.
+    // aux: [0, n) scratch of passes C / D and of the compaction, [n, 2n) two position arrays in turn.
+    int ncur = n, flip = 0;
+    const uint32_t* posbuf = nullptr;
     for (;;) {
-        // A: the minimal rank
-        uint32_t key = SPL_NO_RANK;
+        const int groups = (ncur + 63) >> 6, gw = (groups + NT / 64 - 1) / (NT / 64);
+        const int g0 = wv * gw, g1 = g0 + gw < groups ? g0 + gw : groups;
+        // A: the minimal rank (and how many slots are alive)
+        uint32_t key = SPL_NO_RANK, wcnt = 0;
 #pragma unroll 4
         for (int g = g0; g < g1; g++) {
             const int i = g * 64 + lane;
-            const uint32_t r = i < n ? rks[i] : RK_DEAD;
+            const uint32_t r = i < ncur ? rks[i] : RK_DEAD;
             key = r < key ? r : key;
+            wcnt += (uint32_t)__popcll(__ballot(r != RK_DEAD));
         }
         uint32_t m = row16_min(key);
         {
@@ -1179,6 +1185,39 @@ __device__ __forceinline__ void bpe_rounds_core(const uint8_t* text, const uint3
 #pragma unroll
         for (int w = 1; w < NT / 64; w++) m = s_red4[w] < m ? s_red4[w] : m;
         if (m >= RK_DEAD) break;
+        if (ncur > 4096) {
+            __syncthreads();
+            if (lane == 0) s_red4[wv] = wcnt;
+            __syncthreads();
+            uint32_t total = 0, base = 0;
+#pragma unroll
+            for (int w = 0; w < NT / 64; w++) { total += s_red4[w]; base += w < wv ? s_red4[w] : 0u; }
+            __syncthreads();
+            if (2 * total <= (uint32_t)ncur) {
+                uint32_t* const t_id = aux;
+                uint32_t* const t_rk = aux + total;
+                uint32_t* const npos = aux + n + (flip ? (n + 1) / 2 : 0);
+                for (int g = g0; g < g1; g++) {
+                    const int i = g * 64 + lane;
+                    const uint32_t r = i < ncur ? rks[i] : RK_DEAD;
+                    const unsigned long long al = __ballot(r != RK_DEAD);
+                    if (r != RK_DEAD) {
+                        const uint32_t d = base + mbcnt64(al);
+                        t_id[d] = ids[i];
+                        t_rk[d] = r;
+                        npos[d] = posbuf ? posbuf[i] : (uint32_t)i;
+                    }
+                    base += (uint32_t)__popcll(al);
+                }
+                __syncthreads();
+                for (uint32_t k = (uint32_t)tid; k < total; k += NT) { ids[k] = t_id[k]; rks[k] = t_rk[k]; }
+                __syncthreads();
+                posbuf = npos;
+                flip ^= 1;
+                ncur = (int)total;
+                continue;                                    // (the next turn finds the same minimum among fewer slots)
+            }
+        }
         const uint32_t msel = m | RK_SEL;
         // B: selection.  carry = alive nodes of rank m immediately before the group (its parity counts)
         uint32_t carry = 0;
@@ -1193,7 +1232,7 @@ __device__ __forceinline__ void bpe_rounds_core(const uint8_t* text, const uint3
         }
         for (int g = g0; g < g1; g++) {
             const int i = g * 64 + lane;
-            const uint32_t r = i < n ? rks[i] : RK_DEAD;
+            const uint32_t r = i < ncur ? rks[i] : RK_DEAD;
             const unsigned long long alive = __ballot(r != RK_DEAD), eqm = __ballot(r == m);
             const unsigned long long noneq = alive & ~eqm;
             uint32_t off = mbcnt64(alive);                       // alive nodes below this lane in the group
@@ -1213,7 +1252,7 @@ __device__ __forceinline__ void bpe_rounds_core(const uint8_t* text, const uint3
         uint32_t fail = 0xFFFFFFFFu;
         for (int g = g0; g < g1; g++) {
             const int i = g * 64 + lane;
-            const uint32_t r = i < n ? rks[i] : RK_DEAD;
+            const uint32_t r = i < ncur ? rks[i] : RK_DEAD;
             if (r == msel) {
                 uint32_t bb = (uint32_t)i + 1;
                 while (rks[bb] == RK_DEAD) bb++;                 // exists: slot i has a rank
@@ -1230,9 +1269,9 @@ __device__ __forceinline__ void bpe_rounds_core(const uint8_t* text, const uint3
                     }
                     aux[2 * bb] = leftw;
                     uint32_t c = bb + 1;
-                    while (c < (uint32_t)n && rks[c] == RK_DEAD) c++;
+                    while (c < (uint32_t)ncur && rks[c] == RK_DEAD) c++;
                     uint32_t csel = 0xFFFFFFFFu;
-                    if (c < (uint32_t)n) { idc = ids[c]; csel = rks[c] == msel ? c : csel; }
+                    if (c < (uint32_t)ncur) { idc = ids[c]; csel = rks[c] == msel ? c : csel; }
                     aux[2 * bb + 1] = csel;
                 }
 #pragma nounroll
@@ -1258,7 +1297,7 @@ __device__ __forceinline__ void bpe_rounds_core(const uint8_t* text, const uint3
         // D: commit the merges up to `fail`; the others lose their mark
         for (int g = g0; g < g1; g++) {
             const int i = g * 64 + lane;
-            const uint32_t r = i < n ? rks[i] : RK_DEAD;
+            const uint32_t r = i < ncur ? rks[i] : RK_DEAD;
             if (r == msel) {
                 if ((uint32_t)i > fail) { rks[i] = m; continue; }
                 uint32_t bb = (uint32_t)i + 1;
@@ -1275,15 +1314,26 @@ __device__ __forceinline__ void bpe_rounds_core(const uint8_t* text, const uint3
         }
         __syncthreads();
     }
+    n_out = ncur;
+    pos_out = posbuf;
 }
 template <class Emit>
 __device__ __forceinline__ void bpe_block_rounds(const DeviceTables& T, const Batch& b, uint32_t pos, int n, uint32_t* s_red4,
                                                  Emit emit) {
     uint32_t* ids = b.stage + pos;
-    bpe_rounds_core(b.text + pos, T.byte_id, T.pair_tab, T.pair_mask, ids, b.rank_scr + pos, b.aux + 2 * (size_t)pos, n, s_red4);
-    for (int i = threadIdx.x; i < n; i += NT) {           // survivors become tokens
-        const uint32_t id = ids[i];
-        if (id != SPL_DEAD && id != SPL_NO_RANK) emit(pos + (uint32_t)i, id);
+    uint32_t* aux = b.aux + 2 * (size_t)pos;
+    int nc = n;
+    const uint32_t* posbuf = nullptr;
+    bpe_rounds_core(b.text + pos, T.byte_id, T.pair_tab, T.pair_mask, ids, b.rank_scr + pos, aux, n, s_red4, nc, posbuf);
+    const uint32_t* from = ids;
+    if (posbuf) {                                         // compacted: the ids leave stage[] before tokens are written there
+        for (int i = threadIdx.x; i < nc; i += NT) aux[i] = ids[i];
+        __syncthreads();
+        from = aux;
+    }
+    for (int i = threadIdx.x; i < nc; i += NT) {          // survivors become tokens
+        const uint32_t id = from[i];
+        if (id != SPL_DEAD && id != SPL_NO_RANK) emit(pos + (posbuf ? posbuf[i] : (uint32_t)i), id);
     }
     __syncthreads();
 }
@@ -2683,9 +2733,9 @@ __global__ __launch_bounds__(64) void k_range_out(Batch b) {
 }
 
 // Long chunks from the global queue, first pass: the segment merge of the tile tail
-// (bpe_tail_segments) over batches of queue items.  What it finishes is struck off the queue
-// (length 0); a chunk it leaves -- a segment beyond a wavefront's 64 bytes -- stays, or comes back
-// as a shorter item, for the node-list loops of k_bpe_long.
+// (bpe_tail_segments) over batches of queue items.  A chunk it leaves -- one with a segment beyond
+// 128 bytes -- goes, whole or what remains of it, on the survivor list for the node-list loops of
+// k_bpe_long.
 constexpr uint32_t SEG_BATCH = 12;
 __global__ __launch_bounds__(NT) void k_bpe_segments(DeviceTables T, Batch b) {
     __shared__ __attribute__((aligned(16))) uint32_t s_slab[SEG_ROWS * SUB_W];
@@ -2708,8 +2758,12 @@ __global__ __launch_bounds__(NT) void k_bpe_segments(DeviceTables T, Batch b) {
         __syncthreads();
         const uint32_t nl2 = bpe_tail_segments<2>(T, b, s_lq, cnt, s_slab, s_scr, s_wsum, nullptr, 0, 0,
                                                [&](uint32_t q, uint32_t id) { emit_token(b, q, id); });
-        if ((uint32_t)tid < cnt) *slot(first + tid) = make_uint2(s_lq[2 * tid], s_lq[2 * tid + 1]);
-        else if ((uint32_t)tid < nl2 && s_lq[2 * tid + 1] >= 2u) push_long(b, s_lq[2 * tid], s_lq[2 * tid + 1]);   // segments set aside
+        // what is left -- chunks not finished, segments set aside -- goes on the survivor list (q64: a
+        // dense list that k_bpe_long walks one item per wavefront; the long queue itself is done with)
+        if ((uint32_t)tid < nl2 && s_lq[2 * tid + 1] >= 2u) {
+            const uint32_t qi = atomicAdd(&b.qcount[0], 1u);
+            if (qi < b.qcap64) b.q64[qi] = make_uint2(s_lq[2 * tid], s_lq[2 * tid + 1]);
+        }
         if (tid == 0) s_first = gridDim.x * SEG_BATCH + atomicAdd(&b.qcount[8], SEG_BATCH);
         __syncthreads();
         first = s_first;
@@ -2717,7 +2771,7 @@ __global__ __launch_bounds__(NT) void k_bpe_segments(DeviceTables T, Batch b) {
     }
 }
 
-__global__ __launch_bounds__(NT) void k_bpe_long(DeviceTables T, Batch b) {
+__global__ __launch_bounds__(NT) void k_bpe_long(DeviceTables T, Batch b, int survivors) {
     __shared__ uint32_t s_id[NT / 64][WAVE_NMAX];
     __shared__ uint32_t s_rk[NT / 64][WAVE_NMAX];
     __shared__ uint16_t s_nx[NT / 64][WAVE_NMAX];
@@ -2738,56 +2792,51 @@ __global__ __launch_bounds__(NT) void k_bpe_long(DeviceTables T, Batch b) {
         // (the first item of every wavefront is its own index, later ones come from the cursor: an
         //  empty or short queue costs no atomics at all)
         const uint32_t wgid = blockIdx.x * (NT / 64) + wv;
-        // (items are pulled 16 and 64 at a time and the ones k_bpe_segments struck off -- most of
-        //  them in multi-byte text -- cost a ballot, not a trip to the shared cursor each)
-        for (uint32_t base = wgid * 16u; base < nbig;) {
-            const uint32_t it = base + (uint32_t)(lane & 15);
-            uint2 item = make_uint2(0, 0);
-            if (lane < 16 && it < nbig) item = *(qbig - it);
-            unsigned long long live = __ballot(item.y >= 2u && (int)item.y <= WAVE_NMAX);
-            while (live) {
-                const int k = __builtin_ctzll(live);
-                live &= live - 1ull;
-                bpe_wave(T, b, (uint32_t)__builtin_amdgcn_readlane((int)item.x, k), __builtin_amdgcn_readlane((int)item.y, k),
-                         s_id[wv], s_rk[wv], s_nx[wv], s_pv[wv], [&](uint32_t q, uint32_t id) { emit_token(b, q, id); });
+        if (survivors) {
+            // after k_bpe_segments: the survivor list, any length, one item per wavefront and pull
+            const uint32_t ns = min(b.qcount[0], b.qcap64);
+            for (uint32_t it = wgid; it < ns;) {
+                const uint2 item = b.q64[it];
+                if ((int)item.y <= WAVE_NMAX)
+                    bpe_wave(T, b, item.x, (int)item.y, s_id[wv], s_rk[wv], s_nx[wv], s_pv[wv],
+                             [&](uint32_t q, uint32_t id) { emit_token(b, q, id); });
+                uint32_t nxt = 0;
+                if (lane == 0) nxt = atomicAdd(&b.qcount[6], 1u);
+                it = nwaves + __builtin_amdgcn_readfirstlane(nxt);
             }
+        } else {
+        for (uint32_t it = wgid; it < nbig;) {
+            const uint2 item = *(qbig - it);
+            if ((int)item.y <= WAVE_NMAX)
+                bpe_wave(T, b, item.x, (int)item.y, s_id[wv], s_rk[wv], s_nx[wv], s_pv[wv],
+                         [&](uint32_t q, uint32_t id) { emit_token(b, q, id); });
             uint32_t nxt = 0;
-            if (lane == 0) nxt = atomicAdd(&b.qcount[6], 16u);
-            base = nwaves * 16u + __builtin_amdgcn_readfirstlane(nxt);
+            if (lane == 0) nxt = atomicAdd(&b.qcount[6], 1u);
+            it = nwaves + __builtin_amdgcn_readfirstlane(nxt);
         }
         // group phase: chunks of up to GROUP_NMAX bytes, four per wavefront, nodes in registers
-        for (uint32_t base = wgid * 64u; base < nq;) {
-            const uint32_t it = base + (uint32_t)lane;
+        for (uint32_t base = wgid * 4; base < nq;) {
+            const uint32_t it = base + (lane >> 4);
             uint2 item = make_uint2(0, 0);
             if (it < nq) item = b.qlong[it];
-            unsigned long long live = __ballot(item.y >= 2u);
-            while (live) {
-                int mine = -1;                               // the item of this lane's group of 16
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    if (live) {
-                        const int k = __builtin_ctzll(live);
-                        live &= live - 1ull;
-                        mine = (lane >> 4) == g ? k : mine;
-                    }
-                }
-                const int src = mine < 0 ? 0 : mine;         // (every lane takes part in the exchange)
-                const uint32_t pos = (uint32_t)__shfl((int)item.x, src);
-                const int n_src = __shfl((int)item.y, src);
-                const int n = mine < 0 ? 0 : n_src;
-                bpe_group16<GROUP_NMAX / 16>(T, n, [&](int i) { return (uint32_t)b.text[pos + i]; },
+            const bool has = it < nq;
+            if (__any(has)) {
+                const uint32_t pos = item.x;
+                bpe_group16<GROUP_NMAX / 16>(T, has ? (int)item.y : 0, [&](int i) { return (uint32_t)b.text[pos + i]; },
                                              [&](int i, uint32_t id) { emit_token(b, pos + (uint32_t)i, id); });
             }
             uint32_t nxt = 0;
-            if (lane == 0) nxt = atomicAdd(&b.qcount[7], 64u);
-            base = nwaves * 64u + __builtin_amdgcn_readfirstlane(nxt);
+            if (lane == 0) nxt = atomicAdd(&b.qcount[7], 4u);
+            base = nwaves * 4 + __builtin_amdgcn_readfirstlane(nxt);
+        }
         }
     }
     __syncthreads();
     // workgroup phase: the oversize items among this workgroup's share (uniform loop for all threads)
+    const uint32_t nover = survivors ? min(b.qcount[0], b.qcap64) : nbig;
     for (int w = 0; w < NT / 64; w++)
-        for (uint32_t it = blockIdx.x * (NT / 64) + w; it < nbig; it += nwaves) {
-            const uint2 item = *(qbig - it);
+        for (uint32_t it = blockIdx.x * (NT / 64) + w; it < nover; it += nwaves) {
+            const uint2 item = survivors ? b.q64[it] : *(qbig - it);
             if ((int)item.y > WAVE_NMAX && (int)item.y <= BLOCK_LDS_NMAX)     // the four wavefront slabs as ONE list
                 bpe_block_lds(T, b, item.x, (int)item.y, &s_id[0][0], &s_rk[0][0], &s_nx[0][0], &s_pv[0][0], s_red4,
                               [&](uint32_t q, uint32_t id) { emit_token(b, q, id); });

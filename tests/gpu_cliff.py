@@ -11,7 +11,8 @@ from splintr_amd import _ffi
 force = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 _ffi.lib().spl_debug_phases(tok.handle, force << 1, (ctypes.c_uint64 * 16)())
 for label, extra in (("plain", []), ("+ 64 KB of spaces", [" " * 65536 + "x"]), ("+ 64 KB of 'a'", ["a" * 65536]),
-                     ("+ 64 KB of CJK", ["你" * 21845]), ("+ 300 B runs x 50", [("b" * 300 + " ") * 50])):
+                     ("+ 64 KB of CJK", ["你" * 21845]), ("+ 300 B runs x 50", [("b" * 300 + " ") * 50]),
+                     ("+ 300 B words x 50", [" ".join("".join(__import__("random").Random(k).choice("etaoinshrdlucmfw") for _ in range(300)) for k in range(50))])):
     batch = DeviceBatch(corpus.c2(1000) + extra, torch.device("cuda", 0))
     reserve(tok, batch.n_bytes, batch.n_docs)
     for _ in range(2): encode_device(tok, batch)
