@@ -210,7 +210,8 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
 #define MARK(i) do { if (pf) HIP_TRY(hipEventRecord(t->ev[i], s)); } while (0)
     // small batches: small tiles (occupancy hides latency); large batches: 4 KiB tiles
     // queue mode: tile-owned tiles + global queues for what is long, for batches beyond the two-launch limit
-    const bool queue_mode = !special && t->force_tile == 0 && n_bytes > SPL_DIRECT_MAX_BYTES && n_bytes <= SPL_QUEUE_MAX_BYTES;
+    const bool queue_mode = !special && (t->force_tile == 4 || (t->force_tile == 0 && n_bytes > SPL_DIRECT_MAX_BYTES)) &&
+                            n_bytes <= SPL_QUEUE_MAX_BYTES;
     const bool small_tiles = queue_mode || t->force_tile == 1 || t->force_tile == 3 ||
                              (t->force_tile == 0 && n_bytes <= SPL_DIRECT_MAX_BYTES);
     const uint32_t tile_bytes = small_tiles ? TileGeom<SPL_TILE_SMALL>::TBv : TileGeom<SPL_TILE_LARGE>::TBv;
@@ -644,8 +645,8 @@ int spl_debug_phases(spl_tokenizer* t, int enable, unsigned long long stamps_out
     HIP_TRY(hipDeviceSynchronize());
     if (stamps_out && t->d_dbg) HIP_TRY(hipMemcpy(stamps_out, t->d_dbg, 16 * 8, hipMemcpyDeviceToHost));
     t->dbg_on = (enable & 1) != 0;
-    t->stop_phase = (enable >> 3) & 7;
-    t->force_tile = (enable >> 1) & 3;      // development: 1 = small tiles, 2 = large tiles, 3 = small tiles + multi-pass
+    t->stop_phase = (enable >> 4) & 7;
+    t->force_tile = (enable >> 1) & 7;      // development: 1 = small tiles, 2 = large tiles, 3 = small tiles + multi-pass, 4 = queue mode
     return SPL_OK;
 }
 

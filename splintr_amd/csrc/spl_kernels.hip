@@ -36,7 +36,7 @@ constexpr int RANK_BLK = 1024;           // positions per rank block (32 bitmap 
 #endif
 #define SPL_TILE_LARGE 4096, 480         /* window 4608 B */
 #ifndef SPL_DIRECT_MAX_MB
-#define SPL_DIRECT_MAX_MB 8
+#define SPL_DIRECT_MAX_MB 256
 #endif
 #ifndef SPL_QUEUE_MAX_MB
 #define SPL_QUEUE_MAX_MB 2047         /* 0: queue mode off (larger batches then run the multi-pass pipeline) */

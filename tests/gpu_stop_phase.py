@@ -12,7 +12,7 @@ tok = Tokenizer.from_pretrained("cl100k_base")
 batch = DeviceBatch(corpus.c2(1000), torch.device("cuda", 0))
 reserve(tok, batch.n_bytes, batch.n_docs)
 st = (ctypes.c_uint64 * 16)()
-L.spl_debug_phases(tok.handle, stop << 3, st)
+L.spl_debug_phases(tok.handle, stop << 4, st)
 for _ in range(20):
     try:
         encode_device(tok, batch)

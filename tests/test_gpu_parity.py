@@ -104,7 +104,7 @@ def test_corpus_fixtures_sha256():
 
 def _force_tiles(name, mode):
     """Development hook of the C ABI: 0 auto, 1 small tiles (768+224; single pass when the batch
-    qualifies), 2 large tiles (4096+480), 3 small tiles with the multi-pass pipeline."""
+    qualifies), 2 large tiles (4096+480), 3 small tiles with the multi-pass pipeline, 4 queue mode."""
     import ctypes
     from splintr_amd import _ffi
     st = (ctypes.c_uint64 * 16)()
@@ -255,22 +255,37 @@ def _check_replicated(name, base_texts, copies, coracle):
     return sum(len(t.encode("utf-8")) for t in texts)
 
 
-def test_full_size_c3_o200k(coracle):
+@pytest.mark.parametrize("mode", [0, 4])          # the mode the size selects (tile-owned), and queue mode
+def test_full_size_c3_o200k(coracle, mode):
     from splintr_amd import corpus
-    n = _check_replicated("o200k_base", corpus.c3(500), 20, coracle)           # 10 000 x ~4 KB
-    assert n > 35e6
+    _force_tiles("o200k_base", mode)
+    try:
+        n = _check_replicated("o200k_base", corpus.c3(500), 20, coracle)           # 10 000 x ~4 KB
+        assert n > 35e6
+    finally:
+        _force_tiles("o200k_base", 0)
 
 
-def test_full_size_c4_llama3(coracle):
+@pytest.mark.parametrize("mode", [0, 4])          # the mode the size selects (tile-owned), and queue mode
+def test_full_size_c4_llama3(coracle, mode):
     from splintr_amd import corpus
-    n = _check_replicated("llama3", corpus.c4(10000), 100, coracle)            # 1 000 000 prompts
-    assert n > 150e6
+    _force_tiles("llama3", mode)
+    try:
+        n = _check_replicated("llama3", corpus.c4(10000), 100, coracle)            # 1 000 000 prompts
+        assert n > 150e6
+    finally:
+        _force_tiles("llama3", 0)
 
 
-def test_full_size_c5_deepseek(coracle):
+@pytest.mark.parametrize("mode", [0, 4])          # the mode the size selects (tile-owned), and queue mode
+def test_full_size_c5_deepseek(coracle, mode):
     from splintr_amd import corpus
-    n = _check_replicated("deepseek_v3", corpus.c5(2), 50, coracle)            # 100 x 2 MiB
-    assert n >= 100 * (2 << 20) - 400
+    _force_tiles("deepseek_v3", mode)
+    try:
+        n = _check_replicated("deepseek_v3", corpus.c5(2), 50, coracle)            # 100 x 2 MiB
+        assert n >= 100 * (2 << 20) - 400
+    finally:
+        _force_tiles("deepseek_v3", 0)
 
 
 def test_gatherv_pack_unpack_two_simulated_ranks(coracle):
@@ -445,8 +460,8 @@ def test_document_search_with_skewed_document_sizes(coracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["cl100k_base", "o200k_base"])
 def test_queue_mode_with_window_edges_and_long_runs(coracle, name):
-    """A batch over 8 MB (queue mode: tile-owned tiles, global queues for long chunks and outgrown
-    chains, CSR assembled per tile range) that contains the window-edge documents, runs of every
+    """Queue mode (tile-owned tiles, global queues for long chunks and outgrown chains, CSR assembled
+    per tile range; forced here, it is what batches beyond 256 MB run in) on a batch that contains the window-edge documents, runs of every
     class far longer than a window, and many tiny / empty documents."""
     from splintr_amd import corpus
     rng = random.Random(23)
@@ -460,7 +475,12 @@ def test_queue_mode_with_window_edges_and_long_runs(coracle, name):
         texts.insert(rng.randrange(len(texts)), rng.choice(["", "a", " ", "\n", "é", "你好", "12", "  "]))
     texts += list(corpus.worst_case(20000))
     assert sum(len(t.encode("utf-8")) for t in texts) > (8 << 20)
-    assert_batch_equal(name, texts, coracle)
+    _force_tiles(name, 4)
+    try:
+        assert_batch_equal(name, texts, coracle)
+    finally:
+        _force_tiles(name, 0)
+    assert_batch_equal(name, texts, coracle)                      # and in the mode the size selects (tile-owned)
 
 
 def _multibyte_texts(seed, n_docs, doc_bytes):
@@ -519,8 +539,12 @@ def test_multibyte_text_merges_by_segments(coracle, name, geom):
 
 @pytest.mark.parametrize("name", ["o200k_base", "deepseek_v3"])
 def test_multibyte_text_in_queue_mode(coracle, name):
-    """The same through queue mode (a batch over 8 MB: long chunks travel the global queue to
-    k_bpe_segments and k_bpe_long)."""
+    """The same through queue mode (forced; it is what batches beyond 256 MB run in): long chunks travel
+    the global queue to k_bpe_segments and k_bpe_long."""
     texts = _multibyte_texts(51, 450, 20000)
     assert sum(len(t.encode("utf-8")) for t in texts) > (8 << 20)
-    assert_batch_equal(name, texts, coracle)
+    _force_tiles(name, 4)
+    try:
+        assert_batch_equal(name, texts, coracle)
+    finally:
+        _force_tiles(name, 0)
