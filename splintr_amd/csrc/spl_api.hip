@@ -380,6 +380,7 @@ spl_tokenizer* spl_create(const void* vocab_splv, size_t vocab_len, const void* 
         if ((rc = dev_upload(t->ht.pair_tab, &t->dt.pair_tab))) return rc;
         if ((rc = dev_upload(t->ht.byte_id, &t->dt.byte_id))) return rc;
         if ((rc = dev_upload(t->ht.p8_tab, reinterpret_cast<const uint32_t**>(&t->dt.p8_tab)))) return rc;
+        if ((rc = dev_upload(t->ht.len_mask, &t->dt.len_mask))) return rc;
         if ((rc = dev_upload(t->ht.tok_off, &t->d_tok_off))) return rc;
         if ((rc = dev_upload(t->ht.tok_bytes, &t->d_tok_bytes))) return rc;
         return SPL_OK;
@@ -393,6 +394,7 @@ spl_tokenizer* spl_create(const void* vocab_splv, size_t vocab_len, const void* 
     t->dt.long_mask = (uint32_t)t->ht.long_tab.size() - 1;
     t->dt.pair_mask = (uint32_t)(t->ht.pair_tab.size() / SPL_PAIR_BUCKET) - 1;
     t->dt.p8_mask = (uint32_t)(t->ht.p8_tab.size() / 2) - 1;
+    t->dt.tiny_free = t->ht.tiny_free; t->dt.t8_free = t->ht.t8_free;
     t->dt.max_key_len = t->ht.max_key_len;
     t->dt.pattern = (uint32_t)t->ht.pattern;
     t->dt.all_bytes = t->ht.all_bytes ? 1u : 0u;
@@ -437,7 +439,7 @@ void spl_destroy(spl_tokenizer* t) {
     hipFree((void*)t->dt.ucls_stage1); hipFree((void*)t->dt.ucls_stage2); hipFree((void*)t->dt.short_tab);
     hipFree((void*)t->dt.tiny_tab); hipFree((void*)t->dt.t8_tab);
     hipFree((void*)t->dt.long_tab); hipFree((void*)t->dt.key_blob); hipFree((void*)t->dt.pair_tab);
-    hipFree((void*)t->dt.byte_id); hipFree((void*)t->dt.p8_tab); hipFree((void*)t->d_tok_off); hipFree((void*)t->d_tok_bytes);
+    hipFree((void*)t->dt.byte_id); hipFree((void*)t->dt.p8_tab); hipFree((void*)t->dt.len_mask); hipFree((void*)t->d_tok_off); hipFree((void*)t->d_tok_bytes);
     hipFree(t->d_in_text); hipFree(t->d_in_off); hipFree(t->d_out_ids); hipFree(t->d_out_off); hipFree(t->d_sp_lits);
     if (t->ev_ready) for (auto& e : t->ev) hipEventDestroy(e);
     delete t;

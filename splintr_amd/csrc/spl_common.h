@@ -118,6 +118,10 @@ struct DeviceTables {
     // tag 0xFFFFFF matches every key (a third prefix met in the bucket).  A miss is exact, a hit may
     // be too long (another prefix with the same 24-bit tag).
     const P8Bucket* p8_tab;    uint32_t p8_mask;
+    // len_mask[b0 | b1 << 8]: bit L-2 set iff some token of exactly L bytes (L = 2..8) starts with
+    // these two bytes, bit 7 iff a longer one does.  tiny_free / t8_free: a bucket of each table
+    // with a free slot -- where probes known to miss are sent (one cache line for all of them).
+    const uint8_t* len_mask;   uint32_t tiny_free, t8_free;
 };
 
 // ----------------------------------------------------------------------------------------

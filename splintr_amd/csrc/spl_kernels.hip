@@ -441,6 +441,18 @@ constexpr int SUB_LMAX = SPL_SUB_LMAX;
 constexpr int SUB_W = SUB_LMAX - 1;          // table width: lengths 2..8
 
 // split probes of the tiny table (keys of 2..4 bytes) and of the t8 table (5..8 bytes)
+// (`on` false: the key is known to miss -- the lane loads the table's spare bucket instead, one
+//  cache line for all such lanes, and the finish step finds nothing there)
+__device__ __forceinline__ void tiny_issue_if(const DeviceTables& T, bool on, uint32_t k0, uint32_t n, Quad (&q)[2]) {
+    const uint32_t bkt = on ? hash_tiny(k0, n) & T.tiny_mask : T.tiny_free;
+    const Quad* src = reinterpret_cast<const Quad*>(T.tiny_tab + (size_t)bkt * (SPL_TINY_BUCKET * 2));
+    q[0] = src[0]; q[1] = src[1];
+}
+__device__ __forceinline__ void t8_issue_if(const DeviceTables& T, bool on, uint32_t k0, uint32_t k1, uint32_t n, Quad (&q)[3]) {
+    const uint32_t bkt = on ? hash_t8(k0, k1, n) & T.t8_mask : T.t8_free;
+    const Quad* src = reinterpret_cast<const Quad*>(T.t8_tab + (size_t)bkt * SPL_T8_WORDS);
+    q[0] = src[0]; q[1] = src[1]; q[2] = src[2];
+}
 __device__ __forceinline__ void tiny_issue(const DeviceTables& T, uint32_t k0, uint32_t n, Quad (&q)[2]) {
     const uint32_t bkt = hash_tiny(k0, n) & T.tiny_mask;
     const Quad* src = reinterpret_cast<const Quad*>(T.tiny_tab + (size_t)bkt * (SPL_TINY_BUCKET * 2));
@@ -1605,7 +1617,7 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
         const bool own = (uint32_t)tid < total;
         const bool cut = ctl[4] != 0;                        // the (one) chunk continues beyond the rows
         int maxlen = 0, cap = 0;                             // cap: bytes left in the row's chunk
-        uint32_t w0 = 0, w1 = 0, bid = SPL_DEAD;
+        uint32_t w0 = 0, w1 = 0, bid = SPL_DEAD, lm = 0;
         if (own) {
             uint32_t k = 0;
             while (off[k + 1] <= (uint32_t)tid) k++;
@@ -1619,6 +1631,7 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
             } else if (g + 8 <= B) { __builtin_memcpy(&w0, b.text + g, 4); __builtin_memcpy(&w1, b.text + g + 4, 4); }
             else for (int q = 0; q < 8; q++) if (g + q < B) (q < 4 ? w0 : w1) |= (uint32_t)b.text[g + q] << (8 * (q & 3));
             bid = T.byte_id[w0 & 0xFFu];
+            lm = T.len_mask[w0 & 0xFFFFu];                   // which token lengths exist at all behind these two bytes
         }
         uint32_t* const row = slab + tid * SUB_W;
         int ml = 1;
@@ -1626,10 +1639,10 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
             Quad qa[2], qb[2], qc[2], qd[3];
             const uint32_t ka = w0 & 0xFFFFu, kb = w0 & 0xFFFFFFu, ha = w1 & 0xFFu;
             if (maxlen >= 2) {                               // (one predicate per batch: see bpe_group16_tab)
-                tiny_issue(T, ka, 2u, qa);
-                tiny_issue(T, kb, 3u, qb);
-                tiny_issue(T, w0, 4u, qc);
-                t8_issue(T, w0, ha, 5u, qd);
+                tiny_issue_if(T, (lm & 1u) != 0, ka, 2u, qa);
+                tiny_issue_if(T, (lm & 2u) != 0, kb, 3u, qb);
+                tiny_issue_if(T, (lm & 4u) != 0, w0, 4u, qc);
+                t8_issue_if(T, (lm & 8u) != 0, w0, ha, 5u, qd);
                 const uint32_t r2 = tiny_finish(T, ka, 2u, qa), r3 = tiny_finish(T, kb, 3u, qb);
                 const uint32_t r4 = tiny_finish(T, w0, 4u, qc), r5 = t8_finish(T, w0, ha, 5u, qd);
                 row[0] = r2; row[1] = r3; row[2] = r4; row[3] = r5;
@@ -1642,14 +1655,14 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
         sid[tid] = bid;
         {
             P8Bucket e8{0u, 0u};                               // the p8 bucket travels with the second batch
-            if (cap > SUB_LMAX) e8 = T.p8_tab[hash_p8(w0, w1) & T.p8_mask];
-            if (__any(maxlen >= 6)) {
+            if (cap > SUB_LMAX && (lm & 0x80u)) e8 = T.p8_tab[hash_p8(w0, w1) & T.p8_mask];
+            if (__any(maxlen >= 6 && (lm & 0x70u))) {
                 Quad qa[3], qb[3], qc[3];
                 const uint32_t hb = w1 & 0xFFFFu, hc = w1 & 0xFFFFFFu;
                 if (maxlen >= 6) {
-                    t8_issue(T, w0, hb, 6u, qa);
-                    t8_issue(T, w0, hc, 7u, qb);
-                    t8_issue(T, w0, w1, 8u, qc);
+                    t8_issue_if(T, (lm & 0x10u) != 0, w0, hb, 6u, qa);
+                    t8_issue_if(T, (lm & 0x20u) != 0, w0, hc, 7u, qb);
+                    t8_issue_if(T, (lm & 0x40u) != 0, w0, w1, 8u, qc);
                     const uint32_t r6 = t8_finish(T, w0, hb, 6u, qa), r7 = t8_finish(T, w0, hc, 7u, qb);
                     const uint32_t r8 = t8_finish(T, w0, w1, 8u, qc);
                     row[4] = r6; row[5] = r7; row[6] = r8;
@@ -1657,6 +1670,8 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
                     ml = (r7 != SPL_NO_RANK && maxlen >= 7) ? 7 : ml;
                     ml = (r8 != SPL_NO_RANK && maxlen >= 8) ? 8 : ml;
                 }
+            } else if (maxlen >= 6) {                        // nothing of 6..8 bytes starts in this wavefront's rows
+                row[4] = SPL_NO_RANK; row[5] = SPL_NO_RANK; row[6] = SPL_NO_RANK;
             }
             const int l8 = (int)p8_match(e8.a, e8.b, p8_tag(w0, w1));
             if (l8) ml = (l8 == 255 || l8 > cap) ? cap : l8;

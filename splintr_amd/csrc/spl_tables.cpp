@@ -161,6 +161,12 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
     out.short_tab.assign((size_t)sbuckets * SPL_SHORT_BUCKET, ShortEnt{0, 0, 0, SPL_EMPTY});
     out.long_tab.assign(lcap, LongEnt{0, SPL_EMPTY, 0, 0});
     out.key_blob.clear();
+    out.len_mask.assign(65536, 0);
+    for (const auto& kv : enc) {
+        const std::string& k = kv.first;
+        if (k.size() < 2) continue;
+        out.len_mask[(uint8_t)k[0] | (uint32_t)(uint8_t)k[1] << 8] |= (uint8_t)(1u << (k.size() > (size_t)SPL_T8_MAX ? 7 : k.size() - 2));
+    }
     {   // p8: for every 8-byte prefix of a longer token, the longest such token
         size_t n9 = 0;
         for (const auto& kv : enc) n9 += kv.first.size() > (size_t)SPL_T8_MAX;
@@ -278,6 +284,16 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
         if (by_id[id]) out.tok_bytes.insert(out.tok_bytes.end(), by_id[id]->begin(), by_id[id]->end());
     }
     out.tok_off[out.max_id + 1] = (uint32_t)out.tok_bytes.size();
+    // a bucket with a free last slot in each of the two small-key tables (load factors are below 0.4)
+    {
+        const size_t tb = out.tiny_tab.size() / (SPL_TINY_BUCKET * 2), eb = out.t8_tab.size() / SPL_T8_WORDS;
+        bool ft = false, fe = false;
+        for (size_t i = 0; i < tb && !ft; i++)
+            if (out.tiny_tab[i * SPL_TINY_BUCKET * 2 + 2 * (SPL_TINY_BUCKET - 1) + 1] == SPL_EMPTY) { out.tiny_free = (uint32_t)i; ft = true; }
+        for (size_t i = 0; i < eb && !fe; i++)
+            if (out.t8_tab[i * SPL_T8_WORDS + 3 * (SPL_T8_BUCKET - 1) + 2] == SPL_EMPTY) { out.t8_free = (uint32_t)i; fe = true; }
+        if (!ft || !fe) { err = "small-key tables have no bucket with a free slot"; return 1; }
+    }
     return 0;
 }
 

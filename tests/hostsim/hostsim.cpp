@@ -84,7 +84,8 @@ void* hs_create(const char* splv, const char* ucls, int pattern, char* errbuf, i
                          h.t8_tab.data(), (uint32_t)(h.t8_tab.size() / SPL_T8_WORDS) - 1, h.long_tab.data(),
                          (uint32_t)h.long_tab.size() - 1, h.key_blob.data(), h.pair_tab.data(),
                          (uint32_t)(h.pair_tab.size() / SPL_PAIR_BUCKET) - 1, h.byte_id.data(), h.max_key_len, (uint32_t)h.pattern,
-                         h.all_bytes ? 1u : 0u, reinterpret_cast<const P8Bucket*>(h.p8_tab.data()), (uint32_t)(h.p8_tab.size() / 2) - 1};
+                         h.all_bytes ? 1u : 0u, reinterpret_cast<const P8Bucket*>(h.p8_tab.data()), (uint32_t)(h.p8_tab.size() / 2) - 1,
+                         h.len_mask.data(), h.tiny_free, h.t8_free};
     return s;
 }
 void hs_destroy(void* p) { delete (Sim*)p; }
