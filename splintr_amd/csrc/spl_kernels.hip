@@ -550,6 +550,9 @@ __device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const Lds
     const uint32_t w1 = own ? tx.load32(p + gl + 4) : 0u;
     uint32_t id = own ? T.byte_id[w0 & 0xFFu] : SPL_DEAD;
     uint32_t* row = sub + gl * SUB_W;
+    // which token lengths exist at all behind the lane's first two bytes: the other probes go to the
+    // spare bucket (28 % fewer table lines for English text, 85 % for CJK)
+    const uint32_t lm = own ? T.len_mask[w0 & 0xFFFFu] : 0u;
     {
         Quad qa[2], qb[2], qc[2], qd[3];
         const uint32_t ka = w0 & 0xFFFFu, kb = w0 & 0xFFFFFFu, ha = w1 & 0xFFu;
@@ -557,10 +560,10 @@ __device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const Lds
         //  the lanes need no per-length predicate -- with one, the compiler waits after every
         //  single probe instead of keeping all the bucket loads in flight together)
         if (maxlen >= 2) {
-            tiny_issue(T, ka, 2u, qa);
-            tiny_issue(T, kb, 3u, qb);
-            tiny_issue(T, w0, 4u, qc);
-            t8_issue(T, w0, ha, 5u, qd);
+            tiny_issue_if(T, (lm & 1u) != 0, ka, 2u, qa);
+            tiny_issue_if(T, (lm & 2u) != 0, kb, 3u, qb);
+            tiny_issue_if(T, (lm & 4u) != 0, w0, 4u, qc);
+            t8_issue_if(T, (lm & 8u) != 0, w0, ha, 5u, qd);
             row[0] = tiny_finish(T, ka, 2u, qa);
             row[1] = tiny_finish(T, kb, 3u, qb);
             row[2] = tiny_finish(T, w0, 4u, qc);
@@ -571,9 +574,9 @@ __device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const Lds
         Quad qa[3], qb[3], qc[3];
         const uint32_t hb = w1 & 0xFFFFu, hc = w1 & 0xFFFFFFu;
         if (maxlen >= 6) {
-            t8_issue(T, w0, hb, 6u, qa);
-            t8_issue(T, w0, hc, 7u, qb);
-            t8_issue(T, w0, w1, 8u, qc);
+            t8_issue_if(T, (lm & 0x10u) != 0, w0, hb, 6u, qa);
+            t8_issue_if(T, (lm & 0x20u) != 0, w0, hc, 7u, qb);
+            t8_issue_if(T, (lm & 0x40u) != 0, w0, w1, 8u, qc);
             row[4] = t8_finish(T, w0, hb, 6u, qa);
             row[5] = t8_finish(T, w0, hc, 7u, qb);
             if (SUB_LMAX >= 8) row[6] = t8_finish(T, w0, w1, 8u, qc);
@@ -675,6 +678,9 @@ __device__ __forceinline__ void bpe_wave64_tab(const DeviceTables& T, const LdsA
     const uint32_t w1 = own ? tx.load32(p + lane + 4) : 0u;
     uint32_t id = own ? T.byte_id[w0 & 0xFFu] : SPL_DEAD;
     uint32_t* row = sub + lane * SUB_W;
+    // which token lengths exist at all behind the lane's first two bytes: the other probes go to the
+    // spare bucket (28 % fewer table lines for English text, 85 % for CJK)
+    const uint32_t lm = own ? T.len_mask[w0 & 0xFFFFu] : 0u;
     {
         Quad qa[2], qb[2], qc[2], qd[3];
         const uint32_t ka = w0 & 0xFFFFu, kb = w0 & 0xFFFFFFu, ha = w1 & 0xFFu;
@@ -682,10 +688,10 @@ __device__ __forceinline__ void bpe_wave64_tab(const DeviceTables& T, const LdsA
         //  the lanes need no per-length predicate -- with one, the compiler waits after every
         //  single probe instead of keeping all the bucket loads in flight together)
         if (maxlen >= 2) {
-            tiny_issue(T, ka, 2u, qa);
-            tiny_issue(T, kb, 3u, qb);
-            tiny_issue(T, w0, 4u, qc);
-            t8_issue(T, w0, ha, 5u, qd);
+            tiny_issue_if(T, (lm & 1u) != 0, ka, 2u, qa);
+            tiny_issue_if(T, (lm & 2u) != 0, kb, 3u, qb);
+            tiny_issue_if(T, (lm & 4u) != 0, w0, 4u, qc);
+            t8_issue_if(T, (lm & 8u) != 0, w0, ha, 5u, qd);
             row[0] = tiny_finish(T, ka, 2u, qa);
             row[1] = tiny_finish(T, kb, 3u, qb);
             row[2] = tiny_finish(T, w0, 4u, qc);
@@ -696,9 +702,9 @@ __device__ __forceinline__ void bpe_wave64_tab(const DeviceTables& T, const LdsA
         Quad qa[3], qb[3], qc[3];
         const uint32_t hb = w1 & 0xFFFFu, hc = w1 & 0xFFFFFFu;
         if (maxlen >= 6) {
-            t8_issue(T, w0, hb, 6u, qa);
-            t8_issue(T, w0, hc, 7u, qb);
-            t8_issue(T, w0, w1, 8u, qc);
+            t8_issue_if(T, (lm & 0x10u) != 0, w0, hb, 6u, qa);
+            t8_issue_if(T, (lm & 0x20u) != 0, w0, hc, 7u, qb);
+            t8_issue_if(T, (lm & 0x40u) != 0, w0, w1, 8u, qc);
             row[4] = t8_finish(T, w0, hb, 6u, qa);
             row[5] = t8_finish(T, w0, hc, 7u, qb);
             if (SUB_LMAX >= 8) row[6] = t8_finish(T, w0, w1, 8u, qc);
