@@ -570,7 +570,7 @@ __device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const Lds
             row[3] = t8_finish(T, w0, ha, 5u, qd);
         }
     }
-    if (SUB_LMAX >= 6 && __any(maxlen >= 6)) {
+    if (SUB_LMAX >= 6 && __any(maxlen >= 6 && (lm & 0x70u))) {
         Quad qa[3], qb[3], qc[3];
         const uint32_t hb = w1 & 0xFFFFu, hc = w1 & 0xFFFFFFu;
         if (maxlen >= 6) {
@@ -581,6 +581,8 @@ __device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const Lds
             row[5] = t8_finish(T, w0, hc, 7u, qb);
             if (SUB_LMAX >= 8) row[6] = t8_finish(T, w0, w1, 8u, qc);
         }
+    } else if (maxlen >= 6) {                                // nothing of 6..8 bytes starts in this wavefront's chunks
+        row[4] = SPL_NO_RANK; row[5] = SPL_NO_RANK; row[6] = SPL_NO_RANK;
     }
     group16_merge(T, row, id, n, emit);
 }
@@ -698,7 +700,7 @@ __device__ __forceinline__ void bpe_wave64_tab(const DeviceTables& T, const LdsA
             row[3] = t8_finish(T, w0, ha, 5u, qd);
         }
     }
-    if (SUB_LMAX >= 6) {
+    if (SUB_LMAX >= 6 && __any(maxlen >= 6 && (lm & 0x70u))) {
         Quad qa[3], qb[3], qc[3];
         const uint32_t hb = w1 & 0xFFFFu, hc = w1 & 0xFFFFFFu;
         if (maxlen >= 6) {
@@ -709,6 +711,8 @@ __device__ __forceinline__ void bpe_wave64_tab(const DeviceTables& T, const LdsA
             row[5] = t8_finish(T, w0, hc, 7u, qb);
             if (SUB_LMAX >= 8) row[6] = t8_finish(T, w0, w1, 8u, qc);
         }
+    } else if (maxlen >= 6) {
+        row[4] = SPL_NO_RANK; row[5] = SPL_NO_RANK; row[6] = SPL_NO_RANK;
     }
     const unsigned long long all = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
     // Independent segments.  A merge never crosses a byte boundary that no token spans, so the
