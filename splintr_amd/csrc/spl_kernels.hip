@@ -2511,8 +2511,13 @@ void k_pretok(DeviceTables T, Batch b) {
         uint32_t c_ovf = 0;
         if (whi > wlo) {
             uint32_t mine = 0;
-            for (uint32_t w = wlo + tid_late; w < whi; w += NT)
-                mine += __popc(__hip_atomic_load(&b.tbits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            // (the range ends inside its last word: a special token's bit just behind it -- k_special_scan
+            //  marks those in the same bitmap -- belongs to the tile that owns that byte)
+            for (uint32_t w = wlo + tid_late; w < whi; w += NT) {
+                uint32_t word = __hip_atomic_load(&b.tbits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (w == whi - 1u && (ovf_hi & 31u)) word &= (1u << (ovf_hi & 31u)) - 1u;
+                mine += __popc(word);
+            }
             if (tid_late == 0) s_dq[9] = 0;
             __syncthreads();
             if (mine) atomicAdd(&s_dq[9], mine);
@@ -2640,6 +2645,7 @@ __global__ __launch_bounds__(NT) void k_tile_out(Batch b) {
         for (uint32_t wb = wlo; wb < whi; wb += NT) {
             const uint32_t w = wb + tid;
             uint32_t word = w < whi ? b.tbits[w] : 0u;
+            if (w == whi - 1u && (td.ovf_hi & 31u)) word &= (1u << (td.ovf_hi & 31u)) - 1u;     // (as in k_pretok's count)
             const uint32_t cnt = __popc(word);
             uint32_t x = wave_scan_incl(cnt);
             __syncthreads();
@@ -2648,7 +2654,8 @@ __global__ __launch_bounds__(NT) void k_tile_out(Batch b) {
             unsigned long long r = running + (x - cnt);
             uint32_t all = 0;
             for (int k = 0; k < NT / 64; k++) { if (k < wv) r += s_wsum[k]; all += s_wsum[k]; }
-            if (word) b.tbits[w] = 0u;                      // clean after use: the bitmap is all-zero between calls
+            if (word && !b.skip) b.tbits[w] = 0u;           // clean after use: the bitmap is all-zero between calls
+                                                            // (with special tokens it is cleared per call instead)
             while (word) {
                 const int bit = __ffs(word) - 1;
                 word &= word - 1;

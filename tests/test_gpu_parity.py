@@ -548,3 +548,26 @@ def test_multibyte_text_in_queue_mode(coracle, name):
         assert_batch_equal(name, texts, coracle)
     finally:
         _force_tiles(name, 0)
+
+
+@pytest.mark.parametrize("geom", [0, 3])
+@pytest.mark.parametrize("name", ["cl100k_base", "deepseek_v3"])
+def test_multibyte_text_with_special_tokens(coracle, name, geom):
+    """Special-token literals inside multi-byte text: their spans cut the chunks that the segment merge
+    then works on (tile-owned mode with the skip bitmaps, and the multi-pass pipeline)."""
+    with open(os.path.join(ROOT, "splintr_amd", "data", "special_tokens.json"), encoding="utf-8") as f:
+        lits = list(json.load(f)[name])
+    rng = random.Random(61)
+    texts = []
+    for s in _multibyte_texts(62, 300, 1500):
+        cut = sorted(rng.randrange(len(s) + 1) for _ in range(rng.randint(0, 4)))
+        parts, prev = [], 0
+        for c in cut:
+            parts += [s[prev:c], rng.choice(lits)]
+            prev = c
+        texts.append("".join(parts) + s[prev:])
+    _force_tiles(name, geom)
+    try:
+        assert_batch_equal(name, texts, coracle, special=True)
+    finally:
+        _force_tiles(name, 0)
