@@ -571,3 +571,49 @@ def test_multibyte_text_with_special_tokens(coracle, name, geom):
         assert_batch_equal(name, texts, coracle, special=True)
     finally:
         _force_tiles(name, 0)
+
+
+@pytest.mark.parametrize("geom", [0, 3, 4])
+@pytest.mark.parametrize("name", VOCABS)
+def test_segment_pass_corner_cases(coracle, name, geom):
+    """Crafted inputs for the corners of the segment pass: more multi-byte medium chunks in a tile than
+    its list takes (16), a chunk cut at the 256-row limit with 0 / 1 / 2 bytes left over, a 65..128-byte
+    segment (two nodes per lane), a segment beyond 128 bytes next to a full list (no room to set it
+    aside), chunks that end exactly at row 256, and single bytes between hard boundaries."""
+    han = "的一是不了人我在有他这为之大来以个中上们到说国和地也子时道出而要于就下得可你年生自会那后能对着事其里所去行过家十用发天如然作方成者多日都三小军二无同么经法当起与好看学进种将还分此心前面又定见只主没公从"
+    rng = random.Random(97)
+    texts = ["你好世界你好，" * 3000,                                   # ~38 medium chunks per tile
+             "".join(rng.choice(han) for _ in range(6)).join(["，"] * 4000)]
+    for tail in ("", "q", "qx", "zq", "ab", "the", "é", "éa", "́"):  # a cut chunk and what is left of it
+        for k in (84, 85, 86, 170, 171):
+            texts.append("x " + "".join(rng.choice(han) for _ in range(k)) + tail + " y")
+    for w in (60, 64, 65, 100, 128, 129, 200, 300):                        # one long soft segment inside CJK text
+        word = "".join(rng.choice("etaoinshrdlu") for _ in range(w))
+        texts.append("你好" * 10 + word + "世界" * 10 + "，" + "你好世界，" * 40 + word)
+        texts.append(("你好世界，" * 30 + "a" * w + "。") * 4)
+    for pad in range(0, 40, 3):                                            # chunks ending at row 256 and around it
+        texts.append("，".join("".join(rng.choice(han) for _ in range(n)) for n in (20 + pad, 30, 35, 25, 40, 33)))
+    texts.append("".join(rng.choice(han) + rng.choice("aeiou") for _ in range(2000)))   # 1-byte segments between characters
+    _force_tiles(name, geom)
+    try:
+        assert_batch_equal(name, texts, coracle)
+        assert_batch_equal(name, ["".join(texts)], coracle)
+    finally:
+        _force_tiles(name, 0)
+
+
+def test_special_tokens_in_a_large_tile_owned_batch(coracle):
+    """SPL_WITH_SPECIAL beyond 8 MB runs tile-owned too (up to 256 MB): ~9 MB of English/code and
+    multi-byte text with literals inserted."""
+    from splintr_amd import corpus
+    name = "cl100k_base"
+    with open(os.path.join(ROOT, "splintr_amd", "data", "special_tokens.json"), encoding="utf-8") as f:
+        lits = list(json.load(f)[name])
+    rng = random.Random(71)
+    texts = list(corpus.c2(6000, seed=72)) + _multibyte_texts(73, 300, 10000)
+    for i in range(0, len(texts), 3):
+        t = texts[i]
+        c = rng.randrange(len(t) + 1)
+        texts[i] = t[:c] + rng.choice(lits) + t[c:]
+    assert sum(len(t.encode("utf-8")) for t in texts) > (8 << 20)
+    assert_batch_equal(name, texts, coracle, special=True)
