@@ -30,7 +30,7 @@ int fail(int code, const std::string& msg) {
 
 constexpr size_t QCOUNT_WORDS = 16;      // Batch::qcount
 enum { KI_MARK = 0, KI_SPECIAL, KI_PRETOK, KI_DEFER, KI_BPELANES, KI_BPELONG, KI_COUNT, KI_SCAN, KI_COMPACT, KI_N };
-const char* const k_names[KI_N] = {"memset+k_mark_docs", "k_special_scan", "k_pretok", "k_deferred", "k_bpe_lanes64|k_bpe_segments",
+const char* const k_names[KI_N] = {"memset+k_mark_docs", "k_special_scan", "k_pretok", "k_deferred_wave", "k_bpe_lanes64|k_bpe_segments",
                                    "k_bpe_long", "k_count", "k_scan", "k_compact_docs|k_tile_out"};
 
 template <class T> int dev_upload(const std::vector<T>& v, const T** out) {

@@ -1,22 +1,28 @@
-// spl_kernels.hip -- gfx950 kernels of the batch encode path.
+// spl_kernels.hip -- gfx950 kernels of the batch encode path (DESIGN.md 4 has the full table).
 //
-//   k_mark_docs     text-start bitmap from the document offsets
-//   k_pretok        per 4 KiB tile: stage text in LDS, classify code points, find context-free
-//                   sync points, run the split scanner from each of them (spl_scan.h), enumerate
-//                   the chunks, whole-chunk vocabulary probe (spl_lookup.h); misses go to queues
-//                   (reference: Tokenizer::encode, src/core/tokenizer.rs:729-808 + :703-705)
-//   k_deferred      segments that outgrew a tile window: same scanner over global memory
-//                   ... and byte_pair_encode (src/core/bpe.rs:67-197) for the tile's own misses, one
-//                   node per lane: 16-lane groups for chunks <= 16 B, whole waves for 17..64 B;
-//                   nodes in registers, leftmost-minimum by DPP reduction, neighbours by ballot
-//   k_bpe_long      the same for long chunks: one wavefront per chunk (<= 512 B, nodes as an
-//                   index-linked list in LDS) or one workgroup per chunk (larger, nodes in HBM)
-//   k_scan_count (or k_count + k_scan) / k_compact_docs
-//                   token-start bitmap -> ranks -> dense ids[] and per-document offsets (CSR)
+//   k_pretok<tile, halo, EXPORT_MEDIUM, DIRECT>
+//                   one workgroup per tile: stage the window in LDS, classify code points, class
+//                   bit masks and context-free sync points (spl_scan_masks.h), one scanner chain
+//                   per lane (spl_scan.h), whole-chunk vocabulary probe (spl_lookup.h), and
+//                   byte_pair_encode (src/core/bpe.rs:67-197) for the tile's misses with tabulated
+//                   pair ranks -- reference: Tokenizer::encode, src/core/tokenizer.rs:729-808.
+//                   DIRECT (tile-owned and queue mode): the tile also finishes its long chunks
+//                   (bpe_tail_segments, node-list loops) and the chain that outgrew its window, and
+//                   leaves a self-contained record
+//   k_tile_out      tile-owned mode: tile records -> dense ids[] and per-document offsets (CSR)
+//   k_mark_docs / k_special_scan
+//                   text-start bitmap from the document offsets; special-token literals
+//   k_deferred_wave, k_bpe_segments, k_bpe_long, k_bpe_lanes64
+//                   queue mode / multi-pass: chains and chunks that went to the global queues
+//   k_range_count / k_range_out (queue mode), k_count / k_scan / k_compact_docs (multi-pass)
+//                   token bitmaps -> ranks -> CSR
+//   k_gatherv_pack / k_gatherv_unpack, k_decode
+//                   slabs around the RCCL all-gather; id -> bytes gather
 //
-// Token bookkeeping: a token is identified by the byte position where it starts.  Producers set a
-// bit in `tbits` and store the id at `stage[pos]`; the final order is the bitmap order, so
-// ranks are popcount prefix sums and no kernel needs to know how many tokens another produced.
+// Token bookkeeping: a token is identified by the byte position where it starts.  In the multi-pass
+// pipeline producers set a bit in `tbits` and store the id at `stage[pos]`; the final order is the
+// bitmap order, so ranks are popcount prefix sums and no kernel needs to know how many tokens
+// another produced.  Tile-owned mode keeps the same bookkeeping per tile in LDS.
 #include <hip/hip_runtime.h>
 
 #include "spl_common.h"
@@ -836,37 +842,9 @@ __device__ __forceinline__ void emit_token(const Batch& b, uint32_t pos, uint32_
     atomicOr(&b.tbits[pos >> 5], 1u << (pos & 31));
 }
 
-// One lane per deferred segment: continue the chain from its start to the next sync point.
-__device__ void deferred_items(const DeviceTables& T, const Batch& b, uint32_t first, uint32_t stride) {
-    const uint32_t nq = min(b.qcount[3], b.qcapdefer);
-    GlobalAcc acc{&T, &b};
-    for (uint32_t it = first; it < nq; it += stride) {
-        uint32_t p = b.qdefer[it];
-        for (;;) {
-            if (p >= b.n_bytes) break;
-            const int e = match_end(acc, (int)p, (int)T.pattern);     // never defers: no window end
-            const uint32_t n = (uint32_t)e - p;
-            const uint32_t id = probe_chunk(T, acc, (int)p, (int)n);
-            if (id != SPL_NO_RANK) emit_token(b, p, id);
-            else if (n > 1) push_long(b, p, n);     // any length: k_bpe_long takes n >= 2
-            p = (uint32_t)e;
-            if (p >= b.n_bytes) break;
-            const uint32_t r = acc.rec((int)p);
-            if (r & (CB_SYNC | CB_TSTART)) break;
-            // sync test against the previous character's class
-            int64_t j = (int64_t)p - 1;
-            while (j > 0 && (b.text[j] & 0xC0u) == 0x80u && j > (int64_t)p - 4) j--;
-            const uint32_t prev = acc.rec((int)j) & CB_CLASS;
-            if (prev < C_EOT && is_sync((int)T.pattern, prev, r & CB_CLASS)) break;
-        }
-    }
-}
-__global__ void k_deferred(DeviceTables T, Batch b) {
-    deferred_items(T, b, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
-}
-
-// The same by ONE WAVEFRONT per chain: there are few such chains (tens per 40 MB) but each is long,
-// and a lane that walks it byte by byte from HBM pays a memory round trip per character.  Here the
+// Chains that outgrew a tile window, ONE WAVEFRONT per chain: there are few such chains (tens per
+// 40 MB) but each is long, and a lane that walks it byte by byte from HBM pays a memory round trip
+// per character.  Here the
 // 64 lanes stage a window of DEFER_WIN bytes and its class records in LDS (classified in parallel,
 // as k_pretok does), lane 0 runs the scanner over LDS, and the window is moved along the chain.
 // A single chunk longer than the window falls back to the byte-wise walk.
@@ -2675,7 +2653,7 @@ __global__ __launch_bounds__(NT) void k_tile_out(Batch b) {
 // ------------------------------------------------------------------------------------------
 // Queue mode (batches beyond the two-launch limit): k_pretok<.., DIRECT> works its tiles as in
 // tile-owned mode but sends chunks of more than 64 bytes and chains that outgrow a window to the
-// GLOBAL queues, where k_deferred / k_bpe_long balance them over the whole GPU and leave their tokens
+// GLOBAL queues, where k_deferred_wave / k_bpe_segments / k_bpe_long balance them over the whole GPU and leave their tokens
 // in stage[] / tbits[].  The CSR is then assembled per tile RANGE [t * TB, (t + 1) * TB): its
 // tokens are the window tokens of tile t inside the range (A own), those of tile t - 1 that start
 // beyond ITS range (A spill, at most the right halo) and the queue tokens of the range (B).
