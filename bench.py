@@ -34,7 +34,9 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--inflight", type=int, default=3, help="supplementary figure: batches in flight (1 = skip)")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="N > 1: also report the steps with N batches in flight on their own handles and streams "
+                         "(\"pipelined\"; off by default so that a profile of the default command sees one batch at a time)")
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--docs", type=int, default=1000, help="documents per GPU (BASELINE config: 1000)")
