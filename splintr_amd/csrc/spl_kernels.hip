@@ -2336,7 +2336,7 @@ void k_pretok(DeviceTables T, Batch b) {
                 // bytes and their class records in LDS (in parallel), thread 0 walks the chain there --
                 // whole-chunk hits become tokens at once, misses of ANY length refill the list for the
                 // loops above.  (s_dq[7]: 0 no chain open, 1 the next chunk is the chain's first, 2 a
-                // chunk only starts here if this is no sync point.)
+                // chunk only starts here if this is no sync point; + 4 / + 8 see below.)
                 if (tid == 0) { s_dq[0] = 0; s_dq[11] = 0; }
                 for (;;) {
                     __syncthreads();
@@ -2356,16 +2356,81 @@ void k_pretok(DeviceTables T, Batch b) {
                     __syncthreads();
                     const int64_t pc = s_dq[5];
                     const uint32_t next_ts = s_dq[8];
+                    const uint32_t st = s_dq[7];                // 1 / 2 as above; + 4: splice a periodic run; + 8: walk it from HBM
                     uint8_t* const wtxt = reinterpret_cast<uint8_t*>(s_u.t.slab[0]);
                     uint8_t* const wrec = wtxt + DIRECT_WIN + 32;
                     const int64_t base = pc >= DEFER_BACK ? pc - DEFER_BACK : 0;
                     const int q0 = (int)(pc - base);
-                    const int nst = (int)((B - base) < (int64_t)(DIRECT_WIN + 16) ? (B - base) : (int64_t)(DIRECT_WIN + 16));
+                    if (st & 8u) {                           // one chunk, byte-wise from HBM (no window could hold it)
+                        if (tid == 0) {
+                            uint32_t fill = s_dq[0];
+                            const uint32_t np = (uint32_t)pc;
+                            const DirectAcc ga{&T, &b, next_ts};
+                            const int e = match_end(ga, (int)np, (int)T.pattern);
+                            const uint32_t n = (uint32_t)e - np;
+                            const uint32_t id = probe_chunk(T, ga, (int)np, (int)n);
+                            if (id != SPL_NO_RANK) emit_g(np, id);
+                            else if (n > 1) { s_lq[2 * fill] = np; s_lq[2 * fill + 1] = n; fill++; }
+                            s_dq[0] = fill;
+                            s_dq[5] = (uint32_t)e;
+                            if ((uint32_t)e >= b.n_bytes) { s_dq[6] += 1; s_dq[7] = 0; }
+                            else s_dq[7] = 2u;
+                        }
+                        continue;
+                    }
+                    // A chunk that no window holds is, in practice, one character repeated (64 KB of spaces):
+                    // the text is periodic with the character's length P.  The window is then staged with the
+                    // middle of that stretch cut out -- 16 characters of it stay on either side, what is cut
+                    // is a whole number of characters from the inside of a run of identical ones, which no
+                    // rule of the patterns can tell from a shorter run (no counted repeat is that long) -- and
+                    // match_end's result is shifted by what was cut.  Found in parallel: 64 KB in 16 steps.
+                    int split = 0x7FFFFFFF;                   // window index where the cut is
+                    uint32_t removed = 0;
+                    if (st & 4u) {
+                        const int64_t lim = (int64_t)next_ts < B ? (int64_t)next_ts : B;
+                        int tid_s = tid;                      // (as tid_late below: no 64-bit value derived from tid
+                        asm volatile("" : "+v"(tid_s));      //  is kept from the kernel's start for this rare path)
+                        int64_t g0 = pc + DIRECT_WIN / 2;
+                        while (g0 > pc && (b.text[g0] & 0xC0u) == 0x80u) g0--;
+                        const int P = (int)utf8_len(b.text[g0]);
+                        if (tid == 0) { s_dq[9] = 0xFFFFFFFFu; s_dq[10] = 0; }
+                        __syncthreads();
+                        for (int64_t blk = g0;; blk += NT * 16) {       // first byte that differs from the one P further on
+                            uint32_t bad = 0xFFFFFFFFu;
+                            for (int k = 0; k < 16 && bad == 0xFFFFFFFFu; k++) {
+                                const int64_t i = blk + tid_s * 16 + k;
+                                if (i + P >= lim || b.text[i] != b.text[i + P]) bad = (uint32_t)i;
+                            }
+                            if (bad != 0xFFFFFFFFu) atomicMin(&s_dq[9], bad);
+                            __syncthreads();
+                            const bool found = s_dq[9] != 0xFFFFFFFFu;
+                            __syncthreads();
+                            if (found) break;
+                        }
+                        for (int64_t i = g0 - 1 - tid_s; i >= pc; i -= NT)  // and the last such byte before g0
+                            if (i + P >= lim || b.text[i] != b.text[i + P]) { atomicMax(&s_dq[10], (uint32_t)(i - pc) + 1u); break; }
+                        __syncthreads();
+                        const int64_t e_per = (int64_t)s_dq[9] + P;      // the periodic text is [a_per, e_per)
+                        const int64_t a_per = pc + (int64_t)s_dq[10];
+                        const int64_t a_al = g0 - (g0 - a_per) / P * P;  // whole characters in phase with g0
+                        const int64_t e_al = g0 + (e_per - g0) / P * P;
+                        const int64_t head_end = a_al + 16 * P, tail_start = e_al - 16 * P;
+                        if (tail_start <= head_end || head_end - base > DIRECT_WIN / 2 + 64 * 4) {
+                            __syncthreads();
+                            if (tid == 0) s_dq[7] = (st & 3u) | 8u;     // not periodic (enough): from HBM
+                            continue;
+                        }
+                        removed = (uint32_t)(tail_start - head_end);
+                        split = (int)(head_end - base);
+                    }
+                    const int64_t Bv = B - (int64_t)removed;           // length of the text as the window sees it
+                    const int nst = (int)((Bv - base) < (int64_t)(DIRECT_WIN + 16) ? (Bv - base) : (int64_t)(DIRECT_WIN + 16));
                     const int nrec = nst < DIRECT_WIN ? nst + 1 : DIRECT_WIN;
-                    for (int i = tid; i < DIRECT_WIN + 32; i += NT) wtxt[i] = i < nst ? b.text[base + i] : (uint8_t)0;
+                    for (int i = tid; i < DIRECT_WIN + 32; i += NT)
+                        wtxt[i] = i < nst ? b.text[base + i + (i >= split ? (int64_t)removed : 0)] : (uint8_t)0;
                     __syncthreads();
                     for (int i = tid; i < nrec; i += NT) {
-                        const int64_t g = base + i;
+                        const int64_t g = base + i + (i >= split ? (int64_t)removed : 0);
                         uint32_t r;
                         if (g >= B) r = C_EOT | CB_TSTART | CB_SYNC;
                         else if (b.skip && ((b.skip[g >> 5] >> (g & 31)) & 1u)) r = C_EOT | CB_TSTART;
@@ -2388,9 +2453,10 @@ void k_pretok(DeviceTables T, Batch b) {
                     __syncthreads();
                     if (tid == 0) {
                         const WinAcc acc{wrec, wtxt, nrec};
+                        auto gpos = [&](int q) { return (uint32_t)(base + q + (q >= split ? (int64_t)removed : 0)); };
                         uint32_t fill = s_dq[0];
                         int q = q0;
-                        bool fc = s_dq[7] == 1, finished = false, whole = false;
+                        bool fc = (st & 3u) == 1u, finished = false, whole = false, at_cut = false;
                         for (;;) {
                             if (!fc) {                               // does a chunk start here at all?
                                 const uint32_t r = acc.rec(q);
@@ -2405,29 +2471,22 @@ void k_pretok(DeviceTables T, Batch b) {
                             const int e = match_end(acc, q, (int)T.pattern);
                             if (e == SPL_DEFER) { whole = q == q0; break; }       // (longer than a whole window: below)
                             fc = false;
-                            const uint32_t gp = (uint32_t)(base + q), n = (uint32_t)(e - q);
-                            const uint32_t id = probe_chunk(T, acc, q, (int)n);
+                            const bool spans = q < split && e > split;             // the chunk the cut was made for
+                            const uint32_t gp = gpos(q), n = (uint32_t)(e - q) + (spans ? removed : 0u);
+                            const uint32_t id = spans ? SPL_NO_RANK : probe_chunk(T, acc, q, (int)n);   // (far beyond any token's length)
                             if (id != SPL_NO_RANK) emit_g(gp, id);
                             else if (n > 1) { s_lq[2 * fill] = gp; s_lq[2 * fill + 1] = n; fill++; }
                             q = e;
-                            if (base + q >= B) { finished = true; break; }
-                        }
-                        uint32_t np = (uint32_t)(base + q);
-                        if (whole) {                                 // one chunk, byte-wise from HBM
-                            const DirectAcc ga{&T, &b, next_ts};
-                            const int e = match_end(ga, (int)np, (int)T.pattern);
-                            const uint32_t n = (uint32_t)e - np;
-                            const uint32_t id = probe_chunk(T, ga, (int)np, (int)n);
-                            if (id != SPL_NO_RANK) emit_g(np, id);
-                            else if (n > 1) { s_lq[2 * fill] = np; s_lq[2 * fill + 1] = n; fill++; }
-                            np = (uint32_t)e;
-                            fc = false;
-                            if (np >= b.n_bytes) finished = true;
+                            if ((int64_t)gpos(q) >= B) { finished = true; break; }
+                            if (q == split) { at_cut = true; break; }              // (a chunk ended at the cut: plain windows from here)
                         }
                         s_dq[0] = fill;
-                        s_dq[5] = np;
-                        if (finished) { s_dq[6] += 1; s_dq[7] = 0; }
-                        else s_dq[7] = fc ? 1u : 2u;
+                        if (whole) s_dq[7] = (fc ? 1u : 2u) | ((st & 4u) ? 8u : 4u);   // first the splice, then the walk from HBM
+                        else {
+                            s_dq[5] = at_cut ? (uint32_t)(base + q) : gpos(q);
+                            if (finished) { s_dq[6] += 1; s_dq[7] = 0; }
+                            else s_dq[7] = fc ? 1u : 2u;
+                        }
                     }
                 }
                 __syncthreads();

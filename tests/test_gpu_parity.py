@@ -617,3 +617,30 @@ def test_special_tokens_in_a_large_tile_owned_batch(coracle):
         texts[i] = t[:c] + rng.choice(lits) + t[c:]
     assert sum(len(t.encode("utf-8")) for t in texts) > (8 << 20)
     assert_batch_equal(name, texts, coracle, special=True)
+
+
+@pytest.mark.parametrize("geom", [0, 3])
+@pytest.mark.parametrize("name", ["cl100k_base", "o200k_base"])
+def test_chunks_longer_than_a_chain_window(coracle, name, geom):
+    """A chunk that no staged window holds (2 KiB) is a run of one repeated character: tile-owned mode finds
+    its end in parallel and lets the scanner see it with the middle cut out.  Runs of 1- to 4-byte
+    characters, what follows them (the rules at a run's end differ by class), a run that ends with the
+    document or the text, two documents of the same character back to back, runs that are NOT periodic
+    (walked from HBM), a periodic run right after a non-periodic one in the same chunk."""
+    rng = random.Random(113)
+    texts = []
+    for ch in ("a", " ", "\n", "=", "\u00e9", "\u4f60", "\ud55c", "\U0001F642", "\u093c"):
+        for n, afters in ((2100, ("", " x", "x", "\n", "1", "'s", "\u3002", ch + "b", " " + ch)), (4500, (" x", "x"))):
+            for after in afters:
+                texts.append("lead " + ch * n + after)
+    texts += ["a" * 3000, "a" * 3000, " " * 4000, "", " " * 4000 + "z", "\u4f60" * 1500, "\u4f60" * 1500]
+    texts.append("".join(rng.choice("abcdefgh") for _ in range(3000)) + " tail")           # not periodic
+    texts.append("".join(rng.choice("abcdefgh") for _ in range(1200)) + "q" * 3000 + "rst uvw")
+    texts.append("ab" * 1500 + " " + "xyz" * 1000 + " " + "\u4f60\u597d" * 700)              # period of two / three characters
+    texts.append("x" * 2040 + " " + "y" * 2050 + "\n" + "z" * 2300)
+    _force_tiles(name, geom)
+    try:
+        assert_batch_equal(name, texts, coracle)
+        assert_batch_equal(name, ["".join(texts)], coracle)
+    finally:
+        _force_tiles(name, 0)
