@@ -145,8 +145,11 @@ const char* spl_kernel_name(int index);   /* NULL past the last kernel */
  * [3] deferred segments (scanner chains that outgrew a tile window); [0], [1] unused. */
 int spl_last_queue_counts(spl_tokenizer* t, uint32_t counts_out[4]);
 
-/* Development aid: when enabled, one k_pretok workgroup stamps the shader clock at its phase
- * boundaries; the call returns the stamps of the previous batch (synchronises). */
+/* Development aid: when enabled (bit 0 of `enable`; -DSPL_DEBUG_STAMPS builds), one k_pretok workgroup
+ * stamps the shader clock at its phase boundaries; the call returns the stamps of the previous batch
+ * (synchronises).  Bits 1-3 force an execution mode for the tests (0 the size decides, 1 small tiles,
+ * 2 large tiles, 3 small tiles + multi-pass pipeline, 4 queue mode); bits 4-6 cut the kernel off after a
+ * phase (profiling builds only). */
 int spl_debug_phases(spl_tokenizer* t, int enable, unsigned long long stamps_out[16]);
 
 /* Development aid: per-workgroup records of the last stamped k_pretok launch, 4 wall-clock ticks
