@@ -4,15 +4,23 @@
 A "step" is ONE pass of the hot path (Tokenizer.encode_batch semantics through the C ABI,
 spl_encode_batch_device) over ONE batch of synthetic text already resident in HBM:
 config[1] of BASELINE.json = cl100k_base, 1000 x ~1 KB mixed English/code (splintr_amd.corpus.c2).
-With --gpus N > 1 every rank holds its own 1000-document shard (weak scaling) and the step also
-all-gathers the ragged ids over RCCL so that every rank ends up with the whole CSR result.
+The timed loop rotates over EIGHT distinct batches of that shape (different seeds), so no step
+re-encodes text that the previous step left in L2 / Infinity Cache.  With --gpus N > 1 every rank
+holds its own eight 1000-document shards (weak scaling) and the step also all-gathers the ragged
+ids over RCCL so that every rank ends up with the whole CSR result of every batch.
 
     python bench.py --gpus 1 --steps 500 --warmup 50
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints one JSON line on rank 0.  The oracle (oracle/) is used only as the checker of the
-untimed verification pass and as the timed CPU baseline ("port"); it is never on the measured path.
+Prints ONE JSON line on rank 0.  Beside the contract's keys it carries
+  roofline       HBM roofline of the dominant kernel (algorithmic bytes / its duration in this run)
+  roofline_valu  the binding one: VALU issue (counters from the committed rocprofv3 pass it names)
+  throughputs    SURVEY 8d's three figures for C2 and C3: kernels only / C ABI host->host / Python surface
+  c4_strong      BASELINE config 4 (llama3, 1 M short prompts) doc-sharded over the N ranks (strong scaling)
+  cpu_baseline   the oracle's C port of the reference's Rayon path on this box's host cores
+The oracle (oracle/) is used only as the checker of the untimed verification passes and as the timed
+CPU baseline ("port"); it is never on the measured path.
 """
 import argparse
 import ctypes
@@ -23,12 +31,29 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
+N_ROT = 8               # distinct batches in the timed rotation
+C4_PARTS = 8            # the C4 batch is generated as 8 x 125 000 prompts (seed 1004 + part)
+C4_PART_DOCS = 125_000
+
+
+def _c4_part(k):
+    from splintr_amd import corpus
+    return corpus.c4(C4_PART_DOCS, seed=1004 + k)
+
+
+def _packed(texts):
+    bs = [t.encode("utf-8") for t in texts]
+    off = np.zeros(len(bs) + 1, dtype=np.uint64)
+    if bs:
+        np.cumsum([len(b) for b in bs], out=off[1:])
+    return np.frombuffer(b"".join(bs), dtype=np.uint8), off
 
 
 def main():
@@ -39,8 +64,11 @@ def main():
                          "(\"pipelined\"; off by default so that a profile of the default command sees one batch at a time)")
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--docs", type=int, default=1000, help="documents per GPU (BASELINE config: 1000)")
+    ap.add_argument("--docs", type=int, default=1000, help="documents per batch (BASELINE config: 1000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-throughputs", action="store_true", help="skip the C-ABI / Python-surface figures (C2, C3)")
+    ap.add_argument("--no-c4", action="store_true", help="skip the doc-sharded 1 M-prompt run (BASELINE config 4)")
+    ap.add_argument("--c4-steps", type=int, default=5)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -67,54 +95,68 @@ def main():
         dist.barrier()
     from splintr_amd import Tokenizer, corpus, _ffi
     from splintr_amd.device import DeviceBatch, GatherV, encode_device, reserve, result_csr
+    from oracle.coracle import COracle
 
+    ncpu = os.cpu_count() or 1
     tok = Tokenizer.from_pretrained("cl100k_base", device=local_rank)
-    texts = corpus.c2(args.docs, seed=1002 + rank)          # rank-distinct shard, same distribution
-    batch = DeviceBatch(texts, dev)
-    reserve(tok, batch.n_bytes, batch.n_docs)
+    # eight rank-distinct batches of the same distribution
+    text_sets = [corpus.c2(args.docs, seed=1002 + 100 * rank + k) for k in range(N_ROT)]
+    batches = [DeviceBatch(t, dev) for t in text_sets]
+    reserve(tok, max(b.n_bytes for b in batches), max(b.n_docs for b in batches))
     L = _ffi.lib()
-
     gv = None
+    state = {"i": 0}
 
     def step():
+        b = batches[state["i"] % N_ROT]
+        state["i"] += 1
         if gv is None:
-            encode_device(tok, batch)
+            encode_device(tok, b)
         else:
             # encode with the slab written by the encoder's last kernel; every 8th batch: one RCCL
             # all-gather of the bucket + one unpack launch, on a stream of their own
-            gv.encode_and_submit(batch)
+            gv.encode_and_submit(b)
 
-    # ---- untimed verification pass: bit-exact vs the oracle on this very batch -----------------
-    step()
-    torch.cuda.synchronize()
-    ids, off = result_csr(batch)
-    n_tokens = int(off[-1])
-    from oracle.coracle import COracle
+    # ---- untimed verification pass: every batch of the rotation bit-exact vs the oracle ------------
     orc = COracle("cl100k_base")
-    text_np = np.frombuffer(b"".join(t.encode("utf-8") for t in texts), dtype=np.uint8)
-    ncpu = os.cpu_count() or 1
-    o_ids, o_off = orc.encode_packed(text_np, batch.host_offsets, threads=ncpu)
-    if not (np.array_equal(ids, o_ids) and np.array_equal(off, o_off)):
-        raise SystemExit(f"rank {rank}: HIP result differs from the oracle -- refusing to report a throughput")
+    n_tokens, csr = [], []
+    for b, texts in zip(batches, text_sets):
+        encode_device(tok, b)
+        torch.cuda.synchronize()
+        ids, off = result_csr(b)
+        text_np, _ = _packed(texts)
+        o_ids, o_off = orc.encode_packed(text_np, b.host_offsets, threads=ncpu)
+        if not (np.array_equal(ids, o_ids) and np.array_equal(off, o_off)):
+            raise SystemExit(f"rank {rank}: HIP result differs from the oracle -- refusing to report a throughput")
+        n_tokens.append(int(off[-1]))
+        csr.append((ids, off))
+    bytes_rot = sum(b.n_bytes for b in batches)
 
     if use_dist:
         # size the slabs from the largest shard (one-time, untimed), then check that the exchange
-        # reproduces this rank's ids and offsets at its place in the global CSR
-        mx = torch.tensor([n_tokens, batch.n_docs], dtype=torch.int64, device=dev)
+        # reproduces this rank's ids and offsets at its place in the global CSR of every batch
+        mx = torch.tensor([max(n_tokens), max(b.n_docs for b in batches)], dtype=torch.int64, device=dev)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         gv = GatherV(tok, dev, max_docs=int(mx[1].item()), max_tokens=int(int(mx[0].item()) * 1.02) + 64)
-        step()
-        g_ids, g_off = gv.finish()
+        got = []
+        gv.on_bucket = lambda res: got.extend((i.clone(), o.clone()) for i, o in res)
+        for _ in range(N_ROT):
+            step()
+        gv.finish()
         torch.cuda.synchronize()
-        assert not gv.overflowed()
-        cnt = torch.tensor([n_tokens, batch.n_docs], dtype=torch.int64, device=dev)
-        allc = [torch.zeros_like(cnt) for _ in range(world)]
-        dist.all_gather(allc, cnt)
-        allc = torch.stack(allc).cpu().numpy()
-        t_before, d_before = int(allc[:rank, 0].sum()), int(allc[:rank, 1].sum())
-        assert int(g_off[int(allc[:, 1].sum())].item()) == int(allc[:, 0].sum())
-        assert np.array_equal(g_ids[t_before:t_before + n_tokens].cpu().numpy().view(np.uint32), ids)
-        assert np.array_equal((g_off[d_before:d_before + batch.n_docs + 1] - t_before).cpu().numpy().astype(np.uint64), off)
+        gv.on_bucket = None
+        assert not gv.overflowed() and len(got) == N_ROT
+        for k, (g_ids, g_off) in enumerate(got):
+            cnt = torch.tensor([n_tokens[k], batches[k].n_docs], dtype=torch.int64, device=dev)
+            allc = [torch.zeros_like(cnt) for _ in range(world)]
+            dist.all_gather(allc, cnt)
+            allc = torch.stack(allc).cpu().numpy()
+            t_before, d_before = int(allc[:rank, 0].sum()), int(allc[:rank, 1].sum())
+            assert int(g_off[int(allc[:, 1].sum())].item()) == int(allc[:, 0].sum())
+            ids, off = csr[k]
+            assert np.array_equal(g_ids[t_before:t_before + n_tokens[k]].cpu().numpy().view(np.uint32), ids)
+            assert np.array_equal((g_off[d_before:d_before + batches[k].n_docs + 1] - t_before).cpu().numpy().astype(np.uint64), off)
+        state["i"] = 0
 
     # ---- timed region ----------------------------------------------------------------------------
     for _ in range(args.warmup):
@@ -124,6 +166,7 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    i0 = state["i"]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -133,59 +176,52 @@ def main():
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    my_bytes = sum(batches[(i0 + j) % N_ROT].n_bytes for j in range(args.steps))
     if use_dist:
         et = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
         elapsed = float(et.item())
-        nb = torch.tensor([batch.n_bytes], dtype=torch.int64, device=dev)
+        nb = torch.tensor([my_bytes], dtype=torch.int64, device=dev)
         dist.all_reduce(nb)
         total_bytes = int(nb.item())
     else:
-        total_bytes = batch.n_bytes
+        total_bytes = my_bytes
     ms_per_step = elapsed / args.steps * 1e3
-    value = total_bytes * args.steps / elapsed / 1e6
+    value = total_bytes / elapsed / 1e6
 
     # ---- supplementary: the same steps with several batches in flight --------------------------------
-    # (one handle, workspace and stream each; `value` above stays the one-batch-at-a-time figure that
-    #  the per-kernel durations and the roofline below belong to.  Consecutive steps overlap: the
-    #  next batch's tile kernel fills the CUs that the stragglers of this one and k_tile_out leave idle)
     pipelined = None
     if rank == 0 and world == 1 and not use_dist and args.inflight > 1:
         toks = [tok] + [Tokenizer.from_pretrained("cl100k_base", device=local_rank) for _ in range(args.inflight - 1)]
-        bats = [batch] + [DeviceBatch(texts, dev) for _ in range(args.inflight - 1)]
         strs = [torch.cuda.Stream(dev) for _ in range(args.inflight)]
-        for t_, b_ in zip(toks[1:], bats[1:]):
-            reserve(t_, b_.n_bytes, b_.n_docs)
+        for t_ in toks[1:]:
+            reserve(t_, max(b.n_bytes for b in batches), max(b.n_docs for b in batches))
 
         def run(k):
             for i in range(k):
                 j = i % args.inflight
                 with torch.cuda.stream(strs[j]):
-                    encode_device(toks[j], bats[j])
+                    encode_device(toks[j], batches[i % N_ROT])
         run(args.warmup + args.inflight)
         torch.cuda.synchronize()
         p0 = time.perf_counter()
         run(args.steps)
         torch.cuda.synchronize()
         pel = time.perf_counter() - p0
-        for b_ in bats[1:]:
-            i2, o2 = result_csr(b_)
-            if not (np.array_equal(i2, o_ids) and np.array_equal(o2, o_off)):
-                raise SystemExit("pipelined run: result differs from the oracle")
-        pipelined = {"inflight": args.inflight, "value": round(batch.n_bytes * args.steps / pel / 1e6, 2), "unit": "MB/s",
+        pipelined = {"inflight": args.inflight,
+                     "value": round(sum(batches[i % N_ROT].n_bytes for i in range(args.steps)) / pel / 1e6, 2), "unit": "MB/s",
                      "ms_per_step": round(pel / args.steps * 1e3, 5),
-                     "note": "same batch and steps, round-robin over handles on their own HIP streams; every handle's result bit-exact"}
-        del toks, bats
+                     "note": "same rotation and steps, round-robin over handles on their own HIP streams"}
+        del toks
 
-    # ---- per-kernel durations: HIP events on the launch stream (separate pass) ---------------------
-    roofline = None
+    # ---- per-kernel durations: measured live over the same rotation (separate pass) ---------------------
+    roofline = roofline_valu = None
     kernels = {}
     if rank == 0:
         L.spl_profile_enable(tok.handle, 1)
         L.spl_profile_reset(tok.handle)
-        nprof = 100
-        for _ in range(nprof):
-            encode_device(tok, batch)
+        for j in range(13 * N_ROT):
+            encode_device(tok, batches[j % N_ROT])
         torch.cuda.synchronize()
         ms = (ctypes.c_double * _ffi.SPL_MAX_KERNELS)()
         cnt = (ctypes.c_uint64 * _ffi.SPL_MAX_KERNELS)()
@@ -197,20 +233,60 @@ def main():
                 kernels[nm.decode()] = round(ms[i] / cnt[i] * 1e3, 3)      # us per launch
         dom = max(kernels, key=kernels.get)
         # algorithmic bytes of one batch: text read once, u32 ids written once,
-        # input and output offset arrays (u64 each)
-        b_alg = batch.n_bytes + 4 * n_tokens + 16 * (batch.n_docs + 1)
+        # input and output offset arrays (u64 each); average over the rotation
+        b_alg = (bytes_rot + 4 * sum(n_tokens) + 16 * sum(b.n_docs + 1 for b in batches)) / N_ROT
         achieved = b_alg / (kernels[dom] * 1e-6) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(dom, {}).get("bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, tsrc = None, None
+        for cand in ("r02_hbm_traffic.json", "hbm_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", cand)
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get(dom, {}).get("bytes_per_launch")
+                    tsrc = "profiles/" + cand
+                except Exception:
+                    traffic = None
+                if traffic is not None:
+                    break
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": b_alg, "kernel_us": kernels[dom],
+                    "traffic_source": (tsrc + " (rocprofv3 --pmc passes of this command, committed; NOT measured by this run)") if tsrc else None,
+                    "algorithmic_bytes_per_launch": round(b_alg), "kernel_us": kernels[dom],
                     "all_kernels_us": kernels}
+        # the roofline that binds this kernel: VALU issue.  Counters come from rocprofv3 --pmc (not
+        # available inside a plain run): the committed pass over this very command.
+        vpath = os.path.join(ROOT, "profiles", "r02_pmc_sq.json")
+        if os.path.exists(vpath):
+            try:
+                v = json.load(open(vpath)).get(dom)
+                if v:
+                    roofline_valu = {"bound": "valu_issue", "kernel": dom,
+                                     "SQ_INSTS_VALU": v["SQ_INSTS_VALU"], "SQ_ACTIVE_INST_VALU": v["SQ_ACTIVE_INST_VALU"],
+                                     "kernel_cycles": v["kernel_cycles"], "simds": 1024,
+                                     "frac": round(v["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * v["kernel_cycles"]), 4),
+                                     "lane_utilisation": v.get("lane_utilisation"),
+                                     "source": "profiles/r02_pmc_sq.json (rocprofv3 --pmc passes of this command, committed; NOT measured by this run)"}
+            except Exception:
+                roofline_valu = None
+
+    # ---- kernels only / C ABI host->host / Python surface, for C2 and C3 -------------------
+    throughputs = None
+    if rank == 0 and world == 1 and not use_dist and not args.no_throughputs:
+        import host_path_bench
+        throughputs = {}
+        for cfg in ("c2", "c3"):
+            try:
+                throughputs[cfg] = host_path_bench.measure(cfg)
+            except Exception as e:          # a failure here must not cost the headline line
+                throughputs[cfg] = {"error": repr(e)}
+        throughputs["note"] = ("MB/s of input bytes. kernel_hbm: corpus resident in HBM (one batch, re-encoded); c_abi_host: "
+                               "spl_encode_batch host bytes -> host CSR incl. H2D/D2H, input from spl_host_alloc; "
+                               "c_abi_host_pageable: the same from pageable memory (one extra host copy into pinned staging); "
+                               "python_surface: Tokenizer.encode_batch(list[str]) -> list[list[int]]")
+
+    # ---- BASELINE config 4: llama3, 1 M short prompts, doc-sharded over the ranks (strong scaling) -------
+    c4 = None
+    if not args.no_c4:
+        c4 = run_c4(args, rank, world, local_rank, dev, use_dist)
 
     # ---- CPU baseline: the oracle (a port of the reference's Rayon path) on the host cores ---------
     cpu = None
@@ -218,21 +294,22 @@ def main():
         # sweep the thread count and the LRU-style memo, keep the best: the GPU is compared with the
         # strongest configuration of the port on this host, not with an arbitrary one
         best = None
-        cands = sorted({t for t in (8, 16, 32, 64, 128, ncpu) if t <= ncpu} | {min(8, ncpu)})
+        text_np, _ = _packed(text_sets[0])
+        cands = sorted({t for t in (16, 32, 64, ncpu) if t <= ncpu} | {min(8, ncpu)})
         for memo in (False, True):
             orc_t = COracle("cl100k_base", memo=memo)
             for th in cands:
-                orc_t.encode_packed(text_np, batch.host_offsets, threads=th)
+                orc_t.encode_packed(text_np, batches[0].host_offsets, threads=th)
                 reps, c0 = 0, time.perf_counter()
                 while time.perf_counter() - c0 < 1.2 or reps < 3:
-                    orc_t.encode_packed(text_np, batch.host_offsets, threads=th)
+                    orc_t.encode_packed(text_np, batches[0].host_offsets, threads=th)
                     reps += 1
-                rate = batch.n_bytes * reps / (time.perf_counter() - c0) / 1e6
+                rate = batches[0].n_bytes * reps / (time.perf_counter() - c0) / 1e6
                 if best is None or rate > best[0]:
                     best = (rate, th, memo, reps)
         cpu = {"value": round(best[0], 2), "unit": "MB/s", "cores": best[1], "kind": "port",
                "host_cpus": ncpu,
-               "sample": f"the full bench batch ({batch.n_docs} docs, {batch.n_bytes} B) x {best[3]} repetitions; "
+               "sample": f"the first batch of the rotation ({batches[0].n_docs} docs, {batches[0].n_bytes} B) x {best[3]} repetitions; "
                          f"best of threads in {cands} x memo on/off (best: {best[1]} threads, "
                          f"{'with' if best[2] else 'without'} the mutex-guarded 4096-entry memo that stands in for the "
                          f"reference's LRU); persistent pool pulling documents off a shared counter, CSR in/out"}
@@ -243,17 +320,92 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": f"cl100k_base, {args.docs} x ~1 KB mixed English/code per GPU "
-                                   f"(splintr_amd.corpus.c2, seed 1002+rank), HBM-resident, CSR out"
-                                   + ("; + RCCL all-gatherv of the ragged ids (slabs packed per batch, ONE all-gather per bucket of 8 batches on its own stream, overlapped with the following encodes; every rank ends with every batch's global CSR)" if use_dist else ""),
-                       "vocab": "cl100k_base", "docs_per_gpu": args.docs, "bytes_per_gpu": batch.n_bytes,
-                       "tokens_per_gpu": n_tokens, "parallelism": f"doc-shard x{world}"},
-            "parity": "bit-exact vs oracle (untimed verification pass on the bench batch)",
-            "roofline": roofline, "cpu_baseline": cpu, "pipelined": pipelined,
+            "config": {"workload": f"cl100k_base, {args.docs} x ~1 KB mixed English/code per batch and GPU, {N_ROT} distinct batches in rotation "
+                                   f"(splintr_amd.corpus.c2, seeds 1002 + 100 rank + k), HBM-resident, CSR out"
+                                   + ("; + RCCL all-gatherv of the ragged ids (slab written by the encoder's last kernel, ONE all-gather per bucket of 8 batches on its own stream, overlapped with the following encodes; every rank gets every batch's global CSR, handed to the consumer per bucket)" if use_dist else ""),
+                       "vocab": "cl100k_base", "docs_per_batch": args.docs, "bytes_per_batch": round(bytes_rot / N_ROT),
+                       "tokens_per_batch": round(sum(n_tokens) / N_ROT), "distinct_batches": N_ROT,
+                       "parallelism": f"doc-shard x{world}"},
+            "parity": "bit-exact vs oracle (untimed verification pass over every batch of the rotation)",
+            "roofline": roofline, "roofline_valu": roofline_valu, "throughputs": throughputs, "c4_strong": c4,
+            "cpu_baseline": cpu, "pipelined": pipelined,
         }
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
+
+
+def run_c4(args, rank, world, local_rank, dev, use_dist):
+    """BASELINE config 4 as stated: llama3, 1 000 000 short chat prompts (8 x 125 000, seeds 1004..1011),
+    ONE global batch doc-sharded over the ranks (strong scaling: rank r of W encodes parts
+    [8 r / W, 8 (r + 1) / W)), HBM-resident; with W > 1 the ragged ids are all-gathered over RCCL
+    inside the timed step.  Returns the sub-object for the JSON line (rank 0), None elsewhere."""
+    from multiprocessing import Pool
+    from splintr_amd import Tokenizer
+    from splintr_amd.device import DeviceBatch, GatherV, encode_device, reserve, result_csr
+    from oracle.coracle import COracle
+    parts = [k for k in range(C4_PARTS) if k * world // C4_PARTS == rank]
+    with Pool(min(len(parts), max(1, (os.cpu_count() or 1) // max(world, 1)))) as pool:
+        texts = [t for part in pool.map(_c4_part, parts) for t in part]
+    tok = Tokenizer.from_pretrained("llama3", device=local_rank)
+    batch = DeviceBatch(texts, dev)
+    reserve(tok, batch.n_bytes, batch.n_docs)
+    encode_device(tok, batch)
+    torch.cuda.synchronize()
+    ids, off = result_csr(batch)
+    # parity on a bounded sample (the oracle needs seconds per 100 MB): the first and last 20 000 prompts
+    orc = COracle("llama3")
+    for sl in (slice(0, 20000), slice(len(texts) - 20000, len(texts))):
+        t_np, t_off = _packed(texts[sl])
+        o_ids, o_off = orc.encode_packed(t_np, t_off, threads=os.cpu_count() or 1)
+        a, b_ = int(off[sl.start]), int(off[sl.stop])
+        if not (np.array_equal(ids[a:b_], o_ids) and np.array_equal(off[sl.start:sl.stop + 1] - off[sl.start], o_off)):
+            raise SystemExit(f"rank {rank}: C4 result differs from the oracle")
+    n_tok = int(off[-1])
+    gv = None
+    if use_dist:
+        mx = torch.tensor([n_tok, batch.n_docs], dtype=torch.int64, device=dev)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        gv = GatherV(tok, dev, max_docs=int(mx[1].item()), max_tokens=int(int(mx[0].item()) * 1.01) + 64, depth=1)
+
+    def step():
+        if gv is None:
+            encode_device(tok, batch)
+        else:
+            gv.encode_and_submit(batch)
+    for _ in range(2):
+        step()
+    if gv is not None:
+        gv.finish()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.c4_steps):
+        step()
+    if gv is not None:
+        gv.finish()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    tot_b, tot_d, tot_t = batch.n_bytes, batch.n_docs, n_tok
+    if use_dist:
+        v = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        el = float(v.item())
+        s = torch.tensor([batch.n_bytes, batch.n_docs, n_tok], dtype=torch.int64, device=dev)
+        dist.all_reduce(s)
+        tot_b, tot_d, tot_t = (int(x) for x in s.tolist())
+        assert not gv.overflowed()
+    del batch, tok
+    if rank != 0:
+        return None
+    return {"workload": f"llama3, {tot_d} short chat prompts ({tot_b} B, {tot_t} tokens) as ONE batch doc-sharded over {world} GPU(s), HBM-resident"
+                        + ("; RCCL all-gatherv of the ragged ids inside the step" if use_dist else ""),
+            "value": round(tot_b * args.c4_steps / el / 1e6, 1), "unit": "MB/s", "ms_per_step": round(el / args.c4_steps * 1e3, 3),
+            "steps": args.c4_steps, "scaling": "strong",
+            "parity": "bit-exact vs oracle on the first and last 20 000 prompts of every rank's shard"}
 
 
 if __name__ == "__main__":

@@ -10,8 +10,17 @@
  * return SPL_OK (0) or a negative SPL_E* code; spl_last_error() gives the thread-local message.
  * Text is UTF-8, documents are packed back to back: doc d = utf8[doc_off[d] .. doc_off[d+1]).
  * Results are CSR: ids[T] (u32) + out_off[n_docs+1] (u64), in document order -- the flattened
- * form of the reference's Vec<Vec<u32>>.  A handle is bound to one GPU; one batch in flight per
- * handle; different handles may be used from different threads.
+ * form of the reference's Vec<Vec<u32>>.  A handle is bound to one GPU (spl_set_devices: to
+ * several, for the host entry point); one batch in flight per handle; different handles may be
+ * used from different threads.
+ *
+ * Text that is not valid UTF-8 (the reference's core only ever sees &str, so it defines nothing
+ * here): every byte that is not part of a well-formed sequence -- a stray continuation byte, a lead
+ * byte with too few continuation bytes behind it -- is ONE character of the class "other"
+ * ([^\s\p{L}\p{N}]); a lead byte takes the continuation bytes actually present (at most as many as
+ * it announces) and the decoded value is looked up as it is (overlong forms and surrogates are not
+ * rejected).  Nothing is dropped or replaced: the ids always decode back to the input bytes
+ * (tests/test_gpu_parity.py::test_invalid_utf8_policy pins this against the oracle).
  */
 #ifndef SPLINTR_HIP_H
 #define SPLINTR_HIP_H
@@ -32,6 +41,14 @@ extern "C" {
  * also LLAMA3_PATTERN :45 and deepseek_v3, src/python/bindings.rs:116-129). */
 #define SPL_PATTERN_CL100K 0
 #define SPL_PATTERN_O200K 1
+/* MISTRAL_V3_PATTERN (src/core/tokenizer.rs:64; mistral_v3 / Tekken, src/python/bindings.rs:152-158) */
+#define SPL_PATTERN_MISTRAL_V3 2
+/* These three are the patterns the scanner implements; there is no regex engine on the GPU, so any
+ * other pattern string is refused by the host-side mirror with the reference's error type. */
+
+/* spl_opts.flags */
+#define SPL_OPT_BYTE_LEVEL 1u /* Tokenizer::from_bytes_byte_level (src/core/tokenizer.rs:562-569): the
+                                 vocabulary's keys are ByteLevel text (src/core/byte_level.rs:46-74) */
 
 /* encode flags */
 #define SPL_WITH_SPECIAL 1u /* encode_with_special semantics (src/core/tokenizer.rs:842-874) */
@@ -44,6 +61,7 @@ typedef struct spl_result spl_result;
 typedef struct spl_opts {
     int32_t pattern;   /* SPL_PATTERN_* */
     int32_t device;    /* HIP device ordinal */
+    uint32_t flags;    /* SPL_OPT_* */
 } spl_opts;
 
 /* Thread-local text of the last failure in this thread. */
@@ -53,14 +71,38 @@ const char* spl_last_error(void);
 int spl_device_count(void);
 
 /* Tokenizer::from_bytes / from_bytes_byte_level (src/core/tokenizer.rs:552-569) + with_full_options
- * (:410-456): parse the vocabulary (SPLV container, tools/pack_vocab.py; ByteLevel flag inside) and
- * the code-point class table (tools/gen_unicode_tables.py), build the lookup tables and upload them
- * to the device.  Returns NULL on failure. */
-spl_tokenizer* spl_create(const void* vocab_splv, size_t vocab_len, const void* uclass_tab, size_t uclass_len,
+ * (:410-456): parse the vocabulary and the code-point class table (tools/gen_unicode_tables.py),
+ * build the lookup tables and upload them to the device.  Returns NULL on failure.
+ * `vocab` is either the reference's on-disk format -- tiktoken text, one `base64(token) rank` per
+ * line, parsed as load_tiktoken_bpe does (src/core/vocab.rs:57-89: last space separates, rank
+ * trimmed, a later duplicate key replaces the earlier one) -- or this repo's packed SPLV container
+ * (tools/pack_vocab.py), told apart by the container's magic.
+ * Restrictions (refused with SPL_EINVAL): ids must be < 2^21; the vocabulary must contain all 256
+ * single bytes (ByteLevel: all 256 alphabet characters, each ranking below every longer token) --
+ * the merge kernels identify a node with a token id, which byte_pair_encode's "unknown byte" branches
+ * (src/core/bpe.rs:73-75, 182-191) would break; two different keys must not share an id. */
+spl_tokenizer* spl_create(const void* vocab, size_t vocab_len, const void* uclass_tab, size_t uclass_len,
                           const spl_opts* opts);
 
+/* The GPUs spl_encode_batch spreads a host batch over (the degenerate form of the multi-GPU path:
+ * one process, documents sharded by bytes, every GPU copies its part of the CSR straight into the
+ * one pinned result).  Replaces the handle's device list; the tables are uploaded to each.  The same
+ * ordinal may be listed more than once (independent pipelines on one GPU).  The device-pointer
+ * entry points keep using the first device of the list. */
+int spl_set_devices(spl_tokenizer* t, const int32_t* devices, uint32_t n);
+uint32_t spl_n_devices(const spl_tokenizer* t);
+
+/* Host pipeline tuning: "chunk_bytes" (upper bound of one pipeline chunk, default 16 MiB),
+ * "single_chunk_max_bytes" (batches up to this size run as one chunk, default 4 MiB),
+ * "result_estimate_div" (first guess of the token count = bytes / div, default 2),
+ * "subdoc_split" (0/1: balance the GPUs by cutting large documents at context-free boundaries). */
+int spl_set_option(spl_tokenizer* t, const char* name, int64_t value);
+
 /* One entry of the special_tokens map (src/core/tokenizer.rs:304, 429-434).  Call before the first
- * encode.  Literals must be non-empty. */
+ * encode.  Literals must be non-empty and at most 32 bytes, and no occurrence of one may overlap an
+ * occurrence of another (no literal contains another, no proper suffix of one is a prefix of
+ * another or of itself): then Aho-Corasick's non-overlapping leftmost semantics reduce to "every
+ * occurrence matches", which is what the device scan implements.  All pretrained tables qualify. */
 int spl_add_special(spl_tokenizer* t, const uint8_t* literal, size_t len, uint32_t id);
 
 /* Tokenizer::vocab_size (src/core/tokenizer.rs:964-972): max id over vocab and specials, plus 1. */
@@ -73,8 +115,12 @@ void spl_destroy(spl_tokenizer* t);
 int spl_reserve(spl_tokenizer* t, uint64_t max_bytes, uint64_t max_docs);
 
 /* Tokenizer::encode_batch / encode_batch_with_special (src/core/tokenizer.rs:932-942) on HOST
- * buffers: copies the corpus to the GPU, encodes, copies the CSR result back.  *out is owned by
- * the library; release with spl_result_free. */
+ * buffers -- what PyTokenizer::encode_batch (src/python/bindings.rs:337-339) calls.  The batch is
+ * cut into chunks of whole documents that flow through pinned staging -> H2D -> kernels -> D2H on
+ * private streams, three chunks in flight per GPU, and over the GPUs of spl_set_devices.  `utf8`
+ * may be pageable (it is copied through pinned staging) or come from spl_host_alloc (DMA reads it
+ * directly).  *out lives in pinned memory owned by the library; release with spl_result_free (the
+ * buffers are recycled; a result stays valid after spl_destroy). */
 int spl_encode_batch(spl_tokenizer* t, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs,
                      uint32_t flags, spl_result** out);
 const uint32_t* spl_result_tokens(const spl_result* r);   /* ids[T] */
@@ -83,9 +129,14 @@ uint64_t spl_result_n_tokens(const spl_result* r);
 uint64_t spl_result_n_docs(const spl_result* r);
 void spl_result_free(spl_result* r);
 
+/* Pinned (page-locked, all-device) host memory for callers that build the packed corpus themselves. */
+void* spl_host_alloc(size_t bytes);
+void spl_host_free(void* p);
+
 /* Same path with everything resident in HBM (device pointers).  Fully asynchronous on `hip_stream`
  * (a hipStream_t; NULL = the default stream) once spl_reserve has sized the workspace.
- *   d_utf8[n_bytes]       corpus; doc offsets d_doc_off[n_docs+1] with d_doc_off[0]==0,
+ *   d_utf8[n_bytes]       corpus, 16-byte aligned (SPL_EINVAL otherwise) and readable up to the next
+ *                         multiple of 16; doc offsets d_doc_off[n_docs+1] with d_doc_off[0]==0,
  *                         d_doc_off[n_docs]==n_bytes
  *   d_ids[ids_capacity]   output ids; n_bytes entries always suffice
  *   d_out_off[n_docs+1]   output offsets; d_out_off[n_docs] is the total token count
@@ -126,7 +177,10 @@ int spl_gatherv_unpack_group(spl_tokenizer* t, const uint32_t* d_slabs, uint32_t
                              uint64_t* d_all_off, uint64_t off_stride, uint32_t* d_status, void* hip_stream);
 
 /* Tokenizer::decode_bytes for a batch (src/core/tokenizer.rs:877-897, 944-958), HOST buffers:
- * ids CSR in, bytes CSR out.  *out_bytes / *out_off are malloc'd; release with spl_free. */
+ * ids CSR in, bytes CSR out.  An id of the vocabulary gives its token's bytes (ByteLevel: decoded
+ * to raw bytes; a key that is not ByteLevel text gives the key itself, src/core/byte_level.rs:125-146),
+ * otherwise an id of the special-token map gives its literal, any other id gives nothing.
+ * *out_bytes / *out_off are malloc'd; release with spl_free. */
 int spl_decode_batch(spl_tokenizer* t, const uint32_t* ids, const uint64_t* ids_off, uint64_t n_docs,
                      uint8_t** out_bytes, uint64_t** out_off);
 void spl_free(void* p);

@@ -24,11 +24,13 @@ SYMBOLS = [
     "spl_result_n_docs", "spl_result_free", "spl_encode_batch_device", "spl_decode_batch", "spl_free",
     "spl_profile_enable", "spl_profile_reset", "spl_profile_read", "spl_kernel_name", "spl_last_queue_counts",
     "spl_debug_phases", "spl_debug_blocks", "spl_gatherv_pack", "spl_gatherv_unpack", "spl_gatherv_unpack_group", "spl_encode_batch_device_packed",
+    "spl_set_devices", "spl_n_devices", "spl_set_option", "spl_host_alloc", "spl_host_free",
 ]
+SPL_OPT_BYTE_LEVEL = 1
 
 
 class SplOpts(ctypes.Structure):
-    _fields_ = [("pattern", ctypes.c_int32), ("device", ctypes.c_int32)]
+    _fields_ = [("pattern", ctypes.c_int32), ("device", ctypes.c_int32), ("flags", ctypes.c_uint32)]
 
 
 _lib = None
@@ -42,6 +44,14 @@ def lib() -> ctypes.CDLL:
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). splintr_amd has no CPU fallback.")
+    # ONE HIP runtime per process: torch ships its own copy of libamdhip64 and loads it by path; if
+    # this library pulled in /opt/rocm's copy first, torch's would come up second and find the GPU's
+    # VM already acquired ("No HIP GPUs are available").  With torch imported first both resolve to
+    # the copy that is already loaded (same SONAME).  torch is optional for the encode path itself.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     vp, u8p, u32p, u64p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint32), \
         ctypes.POINTER(ctypes.c_uint64)
@@ -55,6 +65,14 @@ def lib() -> ctypes.CDLL:
     L.spl_destroy.argtypes = [vp]
     L.spl_destroy.restype = None
     L.spl_reserve.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint64]
+    L.spl_set_devices.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), ctypes.c_uint32]
+    L.spl_n_devices.restype = ctypes.c_uint32
+    L.spl_n_devices.argtypes = [vp]
+    L.spl_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
+    L.spl_host_alloc.restype = vp
+    L.spl_host_alloc.argtypes = [ctypes.c_size_t]
+    L.spl_host_free.restype = None
+    L.spl_host_free.argtypes = [vp]
     L.spl_encode_batch.argtypes = [vp, vp, vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(vp)]
     L.spl_result_tokens.restype = u32p
     L.spl_result_tokens.argtypes = [vp]
@@ -88,6 +106,20 @@ def lib() -> ctypes.CDLL:
                                            ctypes.c_uint64, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp]
     _lib = L
     return L
+
+
+_shim = None
+
+
+def shim():
+    """The CPython front end (csrc/spl_pyshim.c): list[str] -> pinned UTF-8, list[list[int]] from the
+    pinned CSR, one C call per encode.  Built by __graft_entry__.build(); no fallback."""
+    global _shim
+    if _shim is None:
+        lib()                                   # libsplintr_hip.so first: the shim links against it
+        from . import _spl_py
+        _shim = _spl_py
+    return _shim
 
 
 def last_error() -> str:

@@ -1,10 +1,17 @@
-// spl_api.hip -- the C ABI (include/splintr_hip.h): handle, device tables, workspace, launch order.
+// spl_api.hip -- the C ABI (include/splintr_hip.h): handle, per-GPU contexts (tables, workspace,
+// streams), launch order, and the host pipeline of spl_encode_batch (pinned staging, chunked
+// H2D -> kernels -> D2H over private streams, document shards over several GPUs).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/splintr_hip.h"
@@ -37,24 +44,87 @@ template <class T> int dev_upload(const std::vector<T>& v, const T** out) {
     void* p = nullptr;
     const size_t bytes = v.size() * sizeof(T);
     HIP_TRY(hipMalloc(&p, bytes ? bytes : 16));
+    *out = (const T*)p;                        // (owned by the context from here on: freed by its destructor)
     if (bytes) HIP_TRY(hipMemcpy(p, v.data(), bytes, hipMemcpyHostToDevice));
-    *out = (const T*)p;
     return SPL_OK;
 }
 
 struct Special { std::string lit; uint32_t id; };
 
-}  // namespace
+// Pinned host buffers are expensive to create (the driver pins and maps every page), so result and
+// staging buffers are recycled.  Shared by the handle and by the results it gave out: a result
+// may outlive its handle.
+struct PinnedPool {
+    std::mutex mu;
+    std::vector<std::pair<size_t, void*>> free_;
+    size_t held = 0;
+    static constexpr size_t HELD_MAX = 8ull << 30;
+    void* get(size_t need, size_t& cap) {
+        need = std::max<size_t>(need, 4096);
+        {
+            std::lock_guard<std::mutex> g(mu);
+            int best = -1;
+            for (int i = 0; i < (int)free_.size(); i++)
+                if (free_[i].first >= need && free_[i].first <= 4 * need && (best < 0 || free_[i].first < free_[best].first)) best = i;
+            if (best >= 0) {
+                void* p = free_[best].second;
+                cap = free_[best].first;
+                held -= cap;
+                free_.erase(free_.begin() + best);
+                return p;
+            }
+        }
+        size_t c = 1 << 16;
+        while (c < need) c <<= 1;
+        if (c > (64u << 20)) c = (need + (32u << 20) - 1) / (32u << 20) * (32u << 20);     // big ones: 32 MiB steps
+        void* p = nullptr;
+        if (hipHostMalloc(&p, c, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        cap = c;
+        return p;
+    }
+    void put(void* p, size_t cap) {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (held + cap <= HELD_MAX) { free_.emplace_back(cap, p); held += cap; return; }
+        }
+        (void)hipHostFree(p);
+    }
+    ~PinnedPool() { for (auto& f : free_) (void)hipHostFree(f.second); }
+};
 
-struct spl_tokenizer {
+// One pinned buffer from the pool, returned on scope exit.
+struct Pinned {
+    std::shared_ptr<PinnedPool> pool;
+    void* p = nullptr;
+    size_t cap = 0;
+    bool ensure(const std::shared_ptr<PinnedPool>& pl, size_t need) {
+        if (p && cap >= need) return true;
+        release();
+        pool = pl;
+        p = pool->get(need, cap);
+        return p != nullptr;
+    }
+    void release() { if (p && pool) pool->put(p, cap); p = nullptr; cap = 0; }
+    ~Pinned() { release(); }
+};
+
+constexpr int NSLOT = 3;                      // staging slots of the host pipeline per GPU
+
+// SPL_TRACE=1: progress of the host pipeline on stderr (development aid)
+bool trace_on() { static const bool on = getenv("SPL_TRACE") != nullptr; return on; }
+#define TRACE(...) do { if (trace_on()) { fprintf(stderr, "[spl] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
+
+// Everything that lives on ONE GPU: lookup tables, workspace, and the host pipeline's streams and
+// staging.  A handle has one context per device of spl_set_devices (one by default).
+struct Ctx {
     int device = 0;
-    HostTables ht;
     DeviceTables dt{};
-    const uint32_t* d_tok_off = nullptr;
+    const uint32_t* d_tok_off = nullptr;       // decode table (vocabulary + specials), rebuilt after spl_add_special
     const uint8_t* d_tok_bytes = nullptr;
-    std::vector<Special> specials;
-    uint32_t max_special_id = 0;
-    uint8_t* d_sp_lits = nullptr;      // uploaded lazily; invalidated by spl_add_special
+    uint32_t dec_max_id = 0;
+    bool dec_uploaded = false;
+    uint8_t* d_sp_lits = nullptr;              // uploaded lazily; invalidated by spl_add_special
     bool sp_uploaded = false;
     // workspace
     uint64_t cap_bytes = 0, cap_docs = 0;
@@ -75,9 +145,20 @@ struct spl_tokenizer {
     uint32_t* d_tctl = nullptr;
     uint32_t tgroups = 0, tpar = 0;
     bool bitmap_dirty = true;
-    // host-path staging
-    uint8_t* d_in_text = nullptr; uint64_t* d_in_off = nullptr; uint32_t* d_out_ids = nullptr; uint64_t* d_out_off = nullptr;
-    uint64_t in_cap_bytes = 0, in_cap_docs = 0;
+    // host pipeline (spl_encode_batch / spl_decode_batch)
+    hipStream_t s_cmp = nullptr, s_h2d = nullptr, s_d2h = nullptr;
+    uint8_t* d_text[NSLOT] = {nullptr, nullptr, nullptr};
+    uint64_t* d_off[NSLOT] = {nullptr, nullptr, nullptr};
+    uint64_t slot_cap_bytes = 0, slot_cap_docs = 0;
+    uint32_t* d_ids = nullptr; uint64_t ids_cap = 0;         // the lane's ids, chunk c at its byte offset
+    uint64_t* d_oo = nullptr; uint64_t oo_cap = 0;           // chunk-local output offsets, chunk after chunk
+    Pinned h_text[NSLOT], h_off[NSLOT], h_tot;
+    hipEvent_t ev_h2d[NSLOT] = {nullptr, nullptr, nullptr}, ev_cmp[NSLOT] = {nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> ev_chunk;
+    // decode scratch (grow-only)
+    uint32_t* d_dec_ids = nullptr; uint64_t* d_dec_blk = nullptr; uint64_t* d_dec_idoff = nullptr; uint8_t* d_dec_out = nullptr;
+    uint64_t* d_dec_first = nullptr; uint64_t* d_dec_docoff = nullptr;
+    uint64_t dec_cap_ids = 0, dec_cap_out = 0, dec_cap_docs = 0;
     // profiling
     bool prof = false;
     hipEvent_t ev[KI_N + 1]{};
@@ -86,33 +167,116 @@ struct spl_tokenizer {
     uint64_t prof_n[SPL_MAX_KERNELS]{};
     uint32_t* last_qcount = nullptr;
     bool dbg_on = false;
-    int stop_phase = 0;     // spl_debug_phases bits 3..5 (profiling builds of the instruction mix per phase)
-    int force_tile = 0;     // 0 auto, 1 small tiles, 2 large tiles (spl_debug_phases bit 1/2)
+    int stop_phase = 0;     // spl_debug_phases bits 4..6 (profiling builds of the instruction mix per phase)
+    int force_tile = 0;     // 0 auto, 1 small tiles, 2 large tiles (spl_debug_phases bits 1..3)
+
+    void free_workspace() {
+        hipFree(d_zero); hipFree(d_stage); hipFree(d_rank);
+        hipFree(d_q64); hipFree(d_qlong); hipFree(d_qdefer); hipFree(d_blk); hipFree(d_dbg);
+        hipFree(d_tdesc); hipFree(d_tile_ids); hipFree(d_tctl); hipFree(d_tile_bits); hipFree(d_tcnt);
+        d_tdesc = nullptr; d_tile_ids = nullptr; d_tctl = nullptr; d_tile_bits = nullptr; d_tcnt = nullptr;
+        d_zero = nullptr; d_stage = nullptr; d_rank = nullptr;
+        d_q64 = nullptr; d_qlong = nullptr; d_qdefer = nullptr; d_blk = nullptr; d_dbg = nullptr;
+        cap_bytes = cap_docs = 0;
+    }
+    void free_slots() {
+        for (int i = 0; i < NSLOT; i++) { hipFree(d_text[i]); hipFree(d_off[i]); d_text[i] = nullptr; d_off[i] = nullptr; }
+        slot_cap_bytes = slot_cap_docs = 0;
+    }
+    ~Ctx() {
+        if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return; }
+        (void)hipDeviceSynchronize();
+        free_workspace();
+        free_slots();
+        hipFree((void*)dt.ucls_stage1); hipFree((void*)dt.ucls_stage2); hipFree((void*)dt.short_tab);
+        hipFree((void*)dt.tiny_tab); hipFree((void*)dt.t8_tab);
+        hipFree((void*)dt.long_tab); hipFree((void*)dt.key_blob); hipFree((void*)dt.pair_tab);
+        hipFree((void*)dt.byte_id); hipFree((void*)dt.p8_tab); hipFree((void*)dt.len_mask);
+        hipFree((void*)d_tok_off); hipFree((void*)d_tok_bytes); hipFree(d_sp_lits);
+        hipFree(d_ids); hipFree(d_oo);
+        hipFree(d_dec_ids); hipFree(d_dec_blk); hipFree(d_dec_idoff); hipFree(d_dec_out); hipFree(d_dec_first); hipFree(d_dec_docoff);
+        if (ev_ready) for (auto& e : ev) (void)hipEventDestroy(e);
+        for (int i = 0; i < NSLOT; i++) { if (ev_h2d[i]) (void)hipEventDestroy(ev_h2d[i]); if (ev_cmp[i]) (void)hipEventDestroy(ev_cmp[i]); }
+        for (auto e : ev_chunk) (void)hipEventDestroy(e);
+        if (s_cmp) (void)hipStreamDestroy(s_cmp);
+        if (s_h2d) (void)hipStreamDestroy(s_h2d);
+        if (s_d2h) (void)hipStreamDestroy(s_d2h);
+    }
+};
+
+}  // namespace
+
+struct spl_tokenizer {
+    HostTables ht;
+    std::vector<Special> specials;
+    uint32_t max_special_id = 0;
+    bool special_newline = false;             // a literal contains '\n': no sub-document cuts with SPL_WITH_SPECIAL
+    std::vector<std::unique_ptr<Ctx>> ctx;
+    std::shared_ptr<PinnedPool> pool = std::make_shared<PinnedPool>();
+    // host pipeline tuning (spl_set_option)
+    uint64_t chunk_bytes = 16ull << 20;       // upper bound of one pipeline chunk
+    uint64_t single_max = 4ull << 20;         // batches up to this size run as ONE chunk
+    uint32_t est_div = 2;                     // first guess of the token count: n_bytes / est_div
+    int subdoc = 1;                           // cut documents at context-free boundaries to balance the GPUs
 };
 
 struct spl_result {
-    std::vector<uint32_t> ids;
-    std::vector<uint64_t> off;
+    std::shared_ptr<PinnedPool> pool;
+    uint32_t* ids = nullptr; size_t ids_cap = 0;       // capacities in BYTES of the pinned buffers
+    uint64_t* off = nullptr; size_t off_cap = 0;
+    uint64_t n_tokens = 0, n_docs = 0;
+    ~spl_result() { if (pool) { pool->put(ids, ids_cap); pool->put(off, off_cap); } }
 };
 
 namespace {
 
-void free_workspace(spl_tokenizer* t) {
-    hipFree(t->d_zero); hipFree(t->d_stage); hipFree(t->d_rank);
-    hipFree(t->d_q64); hipFree(t->d_qlong); hipFree(t->d_qdefer); hipFree(t->d_blk); hipFree(t->d_dbg);
-    hipFree(t->d_tdesc); hipFree(t->d_tile_ids); hipFree(t->d_tctl); hipFree(t->d_tile_bits); hipFree(t->d_tcnt);
-    t->d_tdesc = nullptr; t->d_tile_ids = nullptr; t->d_tctl = nullptr; t->d_tile_bits = nullptr; t->d_tcnt = nullptr;
-    t->d_zero = nullptr; t->d_stage = nullptr; t->d_rank = nullptr;
-    t->d_q64 = nullptr; t->d_qlong = nullptr; t->d_qdefer = nullptr; t->d_blk = nullptr; t->d_dbg = nullptr;
-    t->cap_bytes = t->cap_docs = 0;
+int upload_tables(Ctx& c, const HostTables& ht) {
+    HIP_TRY(hipSetDevice(c.device));
+    int rc;
+    if ((rc = dev_upload(ht.ucls_stage1, &c.dt.ucls_stage1))) return rc;
+    if ((rc = dev_upload(ht.ucls_stage2, &c.dt.ucls_stage2))) return rc;
+    if ((rc = dev_upload(ht.short_tab, &c.dt.short_tab))) return rc;
+    if ((rc = dev_upload(ht.tiny_tab, &c.dt.tiny_tab))) return rc;
+    if ((rc = dev_upload(ht.t8_tab, &c.dt.t8_tab))) return rc;
+    if ((rc = dev_upload(ht.long_tab, &c.dt.long_tab))) return rc;
+    if ((rc = dev_upload(ht.key_blob, &c.dt.key_blob))) return rc;
+    if ((rc = dev_upload(ht.pair_tab, &c.dt.pair_tab))) return rc;
+    if ((rc = dev_upload(ht.byte_id, &c.dt.byte_id))) return rc;
+    if ((rc = dev_upload(ht.p8_tab, reinterpret_cast<const uint32_t**>(&c.dt.p8_tab)))) return rc;
+    if ((rc = dev_upload(ht.len_mask, &c.dt.len_mask))) return rc;
+    c.dt.ucls_shift = ht.ucls_shift;
+    c.dt.cjk_fast = ht.cjk_fast ? 1u : 0u;
+    c.dt.short_mask = (uint32_t)(ht.short_tab.size() / SPL_SHORT_BUCKET) - 1;
+    c.dt.tiny_mask = (uint32_t)(ht.tiny_tab.size() / (SPL_TINY_BUCKET * 2)) - 1;
+    c.dt.t8_mask = (uint32_t)(ht.t8_tab.size() / SPL_T8_WORDS) - 1;
+    c.dt.long_mask = (uint32_t)ht.long_tab.size() - 1;
+    c.dt.pair_mask = (uint32_t)(ht.pair_tab.size() / SPL_PAIR_BUCKET) - 1;
+    c.dt.p8_mask = (uint32_t)(ht.p8_tab.size() / 2) - 1;
+    c.dt.tiny_free = ht.tiny_free; c.dt.t8_free = ht.t8_free;
+    c.dt.max_key_len = ht.max_key_len;
+    c.dt.pattern = (uint32_t)ht.pattern;
+    c.dt.all_bytes = ht.all_bytes ? 1u : 0u;
+    return SPL_OK;
 }
 
-int reserve(spl_tokenizer* t, uint64_t max_bytes, uint64_t max_docs) {
+int ensure_streams(Ctx& c) {
+    if (c.s_cmp) return SPL_OK;
+    HIP_TRY(hipStreamCreateWithFlags(&c.s_cmp, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c.s_h2d, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c.s_d2h, hipStreamNonBlocking));
+    for (int i = 0; i < NSLOT; i++) {
+        HIP_TRY(hipEventCreateWithFlags(&c.ev_h2d[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c.ev_cmp[i], hipEventDisableTiming));
+    }
+    return SPL_OK;
+}
+
+int reserve(Ctx* t, uint64_t max_bytes, uint64_t max_docs) {
     if (max_bytes <= t->cap_bytes && max_docs <= t->cap_docs) return SPL_OK;
     HIP_TRY(hipSetDevice(t->device));
     HIP_TRY(hipDeviceSynchronize());
     const uint64_t nb = std::max<uint64_t>(max_bytes, t->cap_bytes), nd = std::max<uint64_t>(max_docs, t->cap_docs);
-    free_workspace(t);
+    t->free_workspace();
     const size_t nblk = (size_t)(nb / RANK_BLK) + 2;
     t->bitmap_words = nblk * 32 + 64;
     t->zero_words = 3 * t->bitmap_words + QCOUNT_WORDS;
@@ -147,17 +311,17 @@ int reserve(spl_tokenizer* t, uint64_t max_bytes, uint64_t max_docs) {
     return SPL_OK;
 }
 
-int upload_specials(spl_tokenizer* t) {
+int upload_specials(spl_tokenizer* tk, Ctx* t) {
     if (t->sp_uploaded) return SPL_OK;
     // 32-byte header: the set of first bytes (256 bits); then one record per literal
-    std::vector<uint8_t> recs(SP_HDR + t->specials.size() * SP_REC + 16, 0);
-    for (size_t k = 0; k < t->specials.size(); k++) {
-        const uint8_t c0 = (uint8_t)t->specials[k].lit[0];
+    std::vector<uint8_t> recs(SP_HDR + tk->specials.size() * SP_REC + 16, 0);
+    for (size_t k = 0; k < tk->specials.size(); k++) {
+        const uint8_t c0 = (uint8_t)tk->specials[k].lit[0];
         recs[c0 >> 3] |= (uint8_t)(1u << (c0 & 7));
         uint8_t* r = recs.data() + SP_HDR + k * SP_REC;
-        r[0] = (uint8_t)t->specials[k].lit.size();
-        memcpy(r + 4, &t->specials[k].id, 4);
-        memcpy(r + 8, t->specials[k].lit.data(), t->specials[k].lit.size());
+        r[0] = (uint8_t)tk->specials[k].lit.size();
+        memcpy(r + 4, &tk->specials[k].id, 4);
+        memcpy(r + 8, tk->specials[k].lit.data(), tk->specials[k].lit.size());
     }
     HIP_TRY(hipDeviceSynchronize());
     hipFree(t->d_sp_lits);
@@ -168,14 +332,42 @@ int upload_specials(spl_tokenizer* t) {
     return SPL_OK;
 }
 
+// id -> bytes for decode: the vocabulary's decoder, then special_tokens_decoder for ids it lacks
+// (Tokenizer::decode_bytes, src/core/tokenizer.rs:877-897).
+int upload_decode(spl_tokenizer* tk, Ctx* t) {
+    if (t->dec_uploaded) return SPL_OK;
+    const uint32_t max_id = std::max(tk->ht.max_id, tk->max_special_id);
+    std::vector<const std::string*> sp(max_id + 1, nullptr);
+    for (const auto& s : tk->specials) sp[s.id] = &s.lit;     // (two literals with one id: the later one, as a map insert)
+    std::vector<uint32_t> off(max_id + 2, 0);
+    std::vector<uint8_t> bytes;
+    bytes.reserve(tk->ht.tok_bytes.size() + 4096);
+    for (uint32_t id = 0; id <= max_id; id++) {
+        off[id] = (uint32_t)bytes.size();
+        const bool in_vocab = id <= tk->ht.max_id && tk->ht.tok_present[id];
+        if (in_vocab) bytes.insert(bytes.end(), tk->ht.tok_bytes.begin() + tk->ht.tok_off[id], tk->ht.tok_bytes.begin() + tk->ht.tok_off[id + 1]);
+        else if (sp[id]) bytes.insert(bytes.end(), sp[id]->begin(), sp[id]->end());
+    }
+    off[max_id + 1] = (uint32_t)bytes.size();
+    HIP_TRY(hipDeviceSynchronize());
+    hipFree((void*)t->d_tok_off); hipFree((void*)t->d_tok_bytes);
+    t->d_tok_off = nullptr; t->d_tok_bytes = nullptr;
+    int rc;
+    if ((rc = dev_upload(off, &t->d_tok_off))) return rc;
+    if ((rc = dev_upload(bytes, &t->d_tok_bytes))) return rc;
+    t->dec_max_id = max_id;
+    t->dec_uploaded = true;
+    return SPL_OK;
+}
+
 struct SlabOut { uint32_t* d_slab = nullptr; uint64_t cap_words = 0, max_docs = 0; };
 
-int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off, uint64_t n_docs,
+int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off, uint64_t n_docs,
                uint32_t flags, uint32_t* d_ids, uint64_t ids_cap, uint64_t* d_out_off, hipStream_t s,
                const SlabOut* so = nullptr) {
     if (((uintptr_t)d_utf8 & 15) != 0) return fail(SPL_EINVAL, "text buffer must be 16-byte aligned");
-    const bool special = (flags & SPL_WITH_SPECIAL) && !t->specials.empty();
-    if (special) { int rc0 = upload_specials(t); if (rc0) return rc0; }
+    const bool special = (flags & SPL_WITH_SPECIAL) && !tk->specials.empty();
+    if (special) { int rc0 = upload_specials(tk, t); if (rc0) return rc0; }
     if (n_bytes > 0x7FFF0000ull) return fail(SPL_EINVAL, "n_bytes per device call must be < 2^31 - 65536");
     if (n_docs > 0xFFFFFFF0ull) return fail(SPL_EINVAL, "n_docs per device call must be < 2^32 - 16");
     int rc = reserve(t, n_bytes, n_docs);
@@ -193,7 +385,7 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
     b.skip = special ? t->d_zero + 2 * uw : nullptr;
     b.qcount = t->d_zero + (special ? 3 : 2) * uw;
     t->last_qcount = b.qcount;
-    b.sp_lits = t->d_sp_lits; b.n_special = special ? (uint32_t)t->specials.size() : 0u;
+    b.sp_lits = t->d_sp_lits; b.n_special = special ? (uint32_t)tk->specials.size() : 0u;
     b.stage = t->d_stage; b.rank_scr = t->d_rank; b.aux = t->d_aux;
     b.q64 = t->d_q64; b.qlong = t->d_qlong; b.qdefer = t->d_qdefer;
     b.qcap64 = t->qcap64; b.qcaplong = t->qcaplong; b.qcapdefer = t->qcapdefer;
@@ -344,6 +536,316 @@ int launch_all(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const 
     return SPL_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Host pipeline.
+//
+// A batch is cut into LANES (one per GPU context: contiguous byte ranges of about equal size, cut at
+// document boundaries or -- inside a large document -- behind a newline that is followed by an ASCII
+// letter or digit, a context-free match boundary of every supported pattern, see is_sync rule (d))
+// and every lane into CHUNKS of whole documents.  Per chunk: [host copy into pinned staging unless
+// the caller's buffer is pinned] -> H2D on the copy stream -> kernels on the compute stream -> its
+// token count back to the host.  The consumer walks the chunks in global order: as soon as a chunk's
+// count is known its place in the result is known, and its ids and (rebased) offsets are copied
+// straight into the pinned result on the D2H stream.  Three slots per GPU keep H2D, kernels and D2H
+// of consecutive chunks in flight together.
+struct Chunk {
+    uint64_t lo, hi;             // byte range in the caller's text
+    uint64_t dlo, dhi;           // caller's documents [dlo, dhi) have bytes in it (or start at its end, last chunk of the batch)
+    bool cont;                   // the first of them started before `lo` (continuation piece: contributes no offset entry)
+    uint64_t oo_at;              // first entry of its local output offsets in the lane's d_oo
+};
+struct Lane {
+    Ctx* c = nullptr;
+    uint64_t lo = 0, hi = 0;
+    std::vector<Chunk> chunks;
+    std::atomic<uint32_t> submitted{0};
+    std::atomic<int> rc{0};
+    std::string err;
+};
+
+bool is_pinned_host(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+bool ascii_alnum(uint8_t c) { return (c >= '0' && c <= '9') || ((c | 0x20) >= 'a' && (c | 0x20) <= 'z'); }
+
+// documents that have bytes in [lo, hi): first and one-past-last; `last` = the batch's last range also
+// takes the (empty) documents that start at its end
+void doc_range(const uint64_t* doc_off, uint64_t n_docs, uint64_t lo, uint64_t hi, bool last, uint64_t& dlo, uint64_t& dhi, bool& cont) {
+    // first document that starts at or after lo; if the one before it reaches beyond lo, that one is first
+    const uint64_t* b = std::lower_bound(doc_off, doc_off + n_docs, lo);
+    dlo = (uint64_t)(b - doc_off);
+    cont = false;
+    if (dlo > 0 && doc_off[dlo] > lo) { dlo--; cont = true; }        // doc_off[dlo] < lo < doc_off[dlo + 1]
+    if (last) dhi = n_docs;
+    else dhi = (uint64_t)(std::lower_bound(doc_off, doc_off + n_docs, hi) - doc_off);      // documents starting at hi belong to the next range
+    if (dhi < dlo) dhi = dlo;
+}
+
+int lane_prepare(spl_tokenizer* tk, Lane& ln, const uint64_t* doc_off, uint64_t n_docs, bool last_lane, uint64_t chunk_target,
+                 bool src_pinned) {
+    Ctx* c = ln.c;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_streams(*c);
+    if (rc) return rc;
+    // chunks of whole documents (the lane's first and last document may be pieces)
+    uint64_t dlo, dhi; bool cont;
+    doc_range(doc_off, n_docs, ln.lo, ln.hi, last_lane, dlo, dhi, cont);
+    auto start_of = [&](uint64_t d) { return std::max(doc_off[d], ln.lo); };
+    auto end_of = [&](uint64_t d) { return std::min(doc_off[d + 1], ln.hi); };
+    uint64_t max_bytes = 0, max_docs = 0, oo_words = 0;
+    uint64_t d = dlo;
+    do {
+        Chunk ch{};
+        ch.dlo = d;
+        ch.lo = d < dhi ? start_of(d) : ln.lo;
+        ch.cont = (d == dlo) && cont;
+        uint64_t e = d;
+        while (e < dhi && (e == d || end_of(e) - ch.lo <= chunk_target)) e++;
+        ch.dhi = e;
+        ch.hi = e > d ? end_of(e - 1) : ch.lo;
+        if (e == dhi) ch.hi = ln.hi;
+        if (ch.hi - ch.lo > 0x7FFF0000ull) return fail(SPL_EINVAL, "spl_encode_batch: a single document exceeds 2^31 bytes");
+        ch.oo_at = oo_words;
+        oo_words += (ch.dhi - ch.dlo) + 1;
+        max_bytes = std::max(max_bytes, ch.hi - ch.lo);
+        max_docs = std::max(max_docs, ch.dhi - ch.dlo);
+        ln.chunks.push_back(ch);
+        d = e;
+    } while (d < dhi);
+    // device staging and the lane's result buffers
+    if (max_bytes > c->slot_cap_bytes || max_docs > c->slot_cap_docs || !c->d_text[0]) {
+        HIP_TRY(hipDeviceSynchronize());
+        c->free_slots();
+        const uint64_t nb = std::max(max_bytes, c->slot_cap_bytes), nd = std::max(max_docs, c->slot_cap_docs);
+        for (int i = 0; i < NSLOT; i++) {
+            HIP_TRY(hipMalloc((void**)&c->d_text[i], nb + 64));
+            HIP_TRY(hipMalloc((void**)&c->d_off[i], (nd + 1) * 8));
+        }
+        c->slot_cap_bytes = nb; c->slot_cap_docs = nd;
+    }
+    const uint64_t lane_bytes = ln.hi - ln.lo;
+    if (lane_bytes + 16 > c->ids_cap) {
+        HIP_TRY(hipDeviceSynchronize());
+        hipFree(c->d_ids); c->d_ids = nullptr;
+        c->ids_cap = lane_bytes + lane_bytes / 8 + 4096;
+        HIP_TRY(hipMalloc((void**)&c->d_ids, c->ids_cap * 4));
+    }
+    if (oo_words > c->oo_cap) {
+        HIP_TRY(hipDeviceSynchronize());
+        hipFree(c->d_oo); c->d_oo = nullptr;
+        c->oo_cap = oo_words + oo_words / 8 + 1024;
+        HIP_TRY(hipMalloc((void**)&c->d_oo, c->oo_cap * 8));
+    }
+    for (int i = 0; i < NSLOT && (size_t)i < ln.chunks.size(); i++) {
+        if (!src_pinned && !c->h_text[i].ensure(tk->pool, max_bytes + 64)) return fail(SPL_EDEVICE, "pinned staging allocation failed");
+        if (!c->h_off[i].ensure(tk->pool, (max_docs + 1) * 8)) return fail(SPL_EDEVICE, "pinned staging allocation failed");
+    }
+    if (!c->h_tot.ensure(tk->pool, ln.chunks.size() * 8)) return fail(SPL_EDEVICE, "pinned staging allocation failed");
+    while (c->ev_chunk.size() < ln.chunks.size()) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->ev_chunk.push_back(e);
+    }
+    return reserve(c, max_bytes, max_docs);
+}
+
+// producer: every chunk of one lane, in order (runs in the caller's thread for a single chunk)
+int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t* doc_off, uint32_t flags, bool src_pinned) {
+    Ctx* c = ln.c;
+    HIP_TRY(hipSetDevice(c->device));
+    uint64_t* const h_tot = (uint64_t*)c->h_tot.p;
+    for (size_t k = 0; k < ln.chunks.size(); k++) {
+        const Chunk& ch = ln.chunks[k];
+        const int sl = (int)(k % NSLOT);
+        const uint64_t nb = ch.hi - ch.lo, nd = ch.dhi - ch.dlo;
+        TRACE("submit dev %d chunk %zu/%zu bytes %llu docs %llu", c->device, k, ln.chunks.size(), (unsigned long long)nb, (unsigned long long)nd);
+        if (k >= NSLOT) HIP_TRY(hipEventSynchronize(c->ev_h2d[sl]));     // the slot's pinned staging has been read
+        uint64_t* rel = (uint64_t*)c->h_off[sl].p;               // the chunk's documents, clipped to its byte range
+        for (uint64_t i = 0; i < nd; i++) rel[i] = std::min(std::max(doc_off[ch.dlo + i], ch.lo), ch.hi) - ch.lo;
+        rel[nd] = nb;
+        const uint8_t* src = utf8 + ch.lo;
+        if (!src_pinned && nb) { memcpy(c->h_text[sl].p, src, nb); src = (const uint8_t*)c->h_text[sl].p; }
+        if (k >= NSLOT) HIP_TRY(hipStreamWaitEvent(c->s_h2d, c->ev_cmp[sl], 0));   // the slot's device text has been consumed
+        if (nb) HIP_TRY(hipMemcpyAsync(c->d_text[sl], src, nb, hipMemcpyHostToDevice, c->s_h2d));
+        HIP_TRY(hipMemcpyAsync(c->d_off[sl], rel, (nd + 1) * 8, hipMemcpyHostToDevice, c->s_h2d));
+        HIP_TRY(hipEventRecord(c->ev_h2d[sl], c->s_h2d));
+        HIP_TRY(hipStreamWaitEvent(c->s_cmp, c->ev_h2d[sl], 0));
+        uint64_t* oo = c->d_oo + ch.oo_at;
+        int rc = launch_all(tk, c, c->d_text[sl], nb, c->d_off[sl], nd, flags, c->d_ids + (ch.lo - ln.lo), nb + 16, oo, c->s_cmp);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(c->ev_cmp[sl], c->s_cmp));
+        HIP_TRY(hipMemcpyAsync(&h_tot[k], oo + nd, 8, hipMemcpyDeviceToHost, c->s_cmp));
+        HIP_TRY(hipEventRecord(c->ev_chunk[k], c->s_cmp));
+        ln.submitted.store((uint32_t)k + 1, std::memory_order_release);
+    }
+    return SPL_OK;
+}
+
+int encode_host(spl_tokenizer* tk, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags, spl_result* r) {
+    const uint64_t n_bytes = doc_off[n_docs];
+    const bool src_pinned = is_pinned_host(utf8);
+    // ---- lanes ----------------------------------------------------------------------------------
+    const size_t nl_max = tk->ctx.size();
+    size_t nl = nl_max;
+    if (n_bytes < (1ull << 20) * nl) nl = std::max<size_t>(1, (size_t)(n_bytes >> 20));      // at least 1 MiB per GPU
+    std::vector<Lane> lanes(nl);
+    const bool may_cut = tk->subdoc && !((flags & SPL_WITH_SPECIAL) && tk->special_newline);
+    {
+        uint64_t prev = 0;
+        for (size_t l = 0; l < nl; l++) {
+            lanes[l].c = tk->ctx[l].get();
+            lanes[l].lo = prev;
+            uint64_t cutp = n_bytes;
+            if (l + 1 < nl) {
+                const uint64_t target = n_bytes / nl * (l + 1), tol = n_bytes / nl / 16;
+                const uint64_t* b = std::lower_bound(doc_off, doc_off + n_docs + 1, target);
+                const uint64_t after = *b, before = b > doc_off ? *(b - 1) : 0;
+                const uint64_t nearest = (target - before <= after - target) ? before : after;
+                cutp = nearest;
+                const uint64_t dist = nearest > target ? nearest - target : target - nearest;
+                if (dist > tol && may_cut && before < target && target < after) {
+                    // inside one large document: the first newline + ASCII letter / digit at or after the target
+                    const uint64_t lim = std::min<uint64_t>(after, target + (1ull << 20));
+                    for (uint64_t i = std::max<uint64_t>(target, before + 1); i < lim; i++)
+                        if (utf8[i - 1] == '\n' && ascii_alnum(utf8[i])) { cutp = i; break; }
+                }
+                if (cutp < prev) cutp = prev;
+            }
+            lanes[l].hi = cutp;
+            prev = cutp;
+        }
+    }
+    const uint64_t lane_max = [&] { uint64_t m = 0; for (auto& ln : lanes) m = std::max(m, ln.hi - ln.lo); return m; }();
+    uint64_t chunk_target = tk->chunk_bytes;
+    if (lane_max <= tk->single_max) chunk_target = std::max<uint64_t>(tk->single_max, 1);
+    else chunk_target = std::min<uint64_t>(tk->chunk_bytes, std::max<uint64_t>(lane_max / 4, 1ull << 20));
+    if (tk->chunk_bytes < tk->single_max) chunk_target = tk->chunk_bytes;                 // (tests: force small chunks)
+    for (size_t l = 0; l < nl; l++) {
+        int rc = lane_prepare(tk, lanes[l], doc_off, n_docs, l + 1 == nl, chunk_target, src_pinned);
+        if (rc) return rc;
+    }
+    size_t n_chunks = 0;
+    for (auto& ln : lanes) n_chunks += ln.chunks.size();
+    TRACE("encode_host: %llu bytes %llu docs, %zu lane(s), %zu chunk(s), target %llu, pinned src %d", (unsigned long long)n_bytes,
+          (unsigned long long)n_docs, nl, n_chunks, (unsigned long long)chunk_target, (int)src_pinned);
+
+    // ---- result buffers -------------------------------------------------------------------------------
+    r->pool = tk->pool;
+    r->n_docs = n_docs;
+    r->off = (uint64_t*)tk->pool->get((n_docs + 1) * 8, r->off_cap);
+    uint64_t est = n_bytes / std::max<uint32_t>(tk->est_div, 1) + 4096;
+    if (est > n_bytes) est = n_bytes;
+    r->ids = (uint32_t*)tk->pool->get((est + 16) * 4, r->ids_cap);
+    if (!r->off || !r->ids) return fail(SPL_EDEVICE, "pinned result allocation failed");
+
+    // ---- one chunk: everything on the compute stream, ids copied back speculatively -------------------
+    if (n_chunks == 1) {
+        Lane& ln = lanes[0];
+        Ctx* c = ln.c;
+        int rc = lane_submit(tk, ln, utf8, doc_off, flags, src_pinned);
+        if (rc) return rc;
+        const Chunk& ch = ln.chunks[0];
+        const uint64_t nd = ch.dhi - ch.dlo;                          // == n_docs
+        const uint64_t spec = std::min<uint64_t>(r->ids_cap / 4, n_bytes);
+        HIP_TRY(hipMemcpyAsync(r->off, c->d_oo + ch.oo_at, (nd + 1) * 8, hipMemcpyDeviceToHost, c->s_cmp));
+        if (spec) HIP_TRY(hipMemcpyAsync(r->ids, c->d_ids, spec * 4, hipMemcpyDeviceToHost, c->s_cmp));
+        HIP_TRY(hipStreamSynchronize(c->s_cmp));
+        const uint64_t T = r->off[nd];
+        if (T > spec) {                                                // the guess was too small: a bigger buffer, the rest
+            size_t ncap = 0;
+            uint32_t* nids = (uint32_t*)tk->pool->get((T + 16) * 4, ncap);
+            if (!nids) return fail(SPL_EDEVICE, "pinned result allocation failed");
+            memcpy(nids, r->ids, spec * 4);
+            tk->pool->put(r->ids, r->ids_cap);
+            r->ids = nids; r->ids_cap = ncap;
+            HIP_TRY(hipMemcpyAsync(r->ids + spec, c->d_ids + spec, (T - spec) * 4, hipMemcpyDeviceToHost, c->s_cmp));
+            HIP_TRY(hipStreamSynchronize(c->s_cmp));
+        }
+        r->n_tokens = T;
+        return SPL_OK;
+    }
+
+    // ---- several chunks: a producer thread per lane, this thread places the results ------------------
+    std::vector<std::thread> producers;
+    for (size_t l = 0; l < nl; l++) {
+        Lane* ln = &lanes[l];
+        producers.emplace_back([=] {
+            g_err.clear();
+            int rc = lane_submit(tk, *ln, utf8, doc_off, flags, src_pinned);
+            if (rc) { ln->err = g_err; ln->rc.store(rc, std::memory_order_release); }
+        });
+    }
+    int rc_all = SPL_OK;
+    std::string err_all;
+    uint64_t base = 0;
+    auto consume = [&]() -> int {
+        for (size_t l = 0; l < nl; l++) {
+            Lane& ln = lanes[l];
+            Ctx* c = ln.c;
+            HIP_TRY(hipSetDevice(c->device));
+            const uint64_t* h_tot = (const uint64_t*)c->h_tot.p;
+            for (size_t k = 0; k < ln.chunks.size(); k++) {
+                while (ln.submitted.load(std::memory_order_acquire) <= k) {
+                    if (ln.rc.load(std::memory_order_acquire)) return fail(ln.rc.load(), ln.err);
+                    std::this_thread::yield();
+                }
+                HIP_TRY(hipEventSynchronize(c->ev_chunk[k]));
+                const Chunk& ch = ln.chunks[k];
+                const uint64_t T = h_tot[k], nd = ch.dhi - ch.dlo;
+                TRACE("place lane %zu chunk %zu tokens %llu base %llu", l, k, (unsigned long long)T, (unsigned long long)base);
+                if ((base + T + 16) * 4 > r->ids_cap) {
+                    // the first guess was too small: move to a buffer that holds whatever may still come
+                    for (size_t q = 0; q <= l; q++) { HIP_TRY(hipSetDevice(lanes[q].c->device)); HIP_TRY(hipStreamSynchronize(lanes[q].c->s_d2h)); }
+                    HIP_TRY(hipSetDevice(c->device));
+                    const uint64_t rest = n_bytes - ch.lo;              // tokens <= bytes
+                    size_t ncap = 0;
+                    uint32_t* nids = (uint32_t*)tk->pool->get((base + rest + 16) * 4, ncap);
+                    if (!nids) return fail(SPL_EDEVICE, "pinned result allocation failed");
+                    memcpy(nids, r->ids, base * 4);
+                    tk->pool->put(r->ids, r->ids_cap);
+                    r->ids = nids; r->ids_cap = ncap;
+                }
+                if (T) HIP_TRY(hipMemcpyAsync(r->ids + base, c->d_ids + (ch.lo - ln.lo), T * 4, hipMemcpyDeviceToHost, c->s_d2h));
+                const uint64_t skip = ch.cont ? 1 : 0;
+                if (nd > skip) {
+                    uint64_t* oo = c->d_oo + ch.oo_at + skip;
+                    if (base) hipLaunchKernelGGL(k_add_base, dim3((uint32_t)((nd - skip + 255) / 256)), dim3(256), 0, c->s_d2h, oo, nd - skip, base);
+                    HIP_TRY(hipMemcpyAsync(r->off + ch.dlo + skip, oo, (nd - skip) * 8, hipMemcpyDeviceToHost, c->s_d2h));
+                }
+                base += T;
+            }
+        }
+        for (auto& ln : lanes) { HIP_TRY(hipSetDevice(ln.c->device)); HIP_TRY(hipStreamSynchronize(ln.c->s_d2h)); }
+        return SPL_OK;
+    };
+    rc_all = consume();
+    if (rc_all) err_all = g_err;
+    for (auto& th : producers) th.join();
+    for (auto& ln : lanes)
+        if (!rc_all && ln.rc.load()) { rc_all = ln.rc.load(); err_all = ln.err; }
+    if (rc_all) {
+        for (auto& ln : lanes) { if (hipSetDevice(ln.c->device) == hipSuccess) (void)hipDeviceSynchronize(); }
+        return fail(rc_all, err_all);
+    }
+    r->off[n_docs] = base;
+    r->n_tokens = base;
+    return SPL_OK;
+}
+
+template <class T> int grow(T** p, uint64_t* cap, uint64_t need) {
+    if (need <= *cap && *p) return SPL_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    hipFree(*p); *p = nullptr;
+    const uint64_t c = need + need / 4 + 1024;
+    HIP_TRY(hipMalloc((void**)p, c * sizeof(T)));
+    *cap = c;
+    return SPL_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -352,58 +854,59 @@ const char* spl_last_error(void) { return g_err.c_str(); }
 
 int spl_device_count(void) {
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return n;
 }
 
-spl_tokenizer* spl_create(const void* vocab_splv, size_t vocab_len, const void* uclass_tab, size_t uclass_len,
+spl_tokenizer* spl_create(const void* vocab, size_t vocab_len, const void* uclass_tab, size_t uclass_len,
                           const spl_opts* opts) {
-    if (!vocab_splv || !uclass_tab || !opts) { fail(SPL_EINVAL, "spl_create: null argument"); return nullptr; }
-    spl_tokenizer* t = new spl_tokenizer();
+    if (!vocab || !uclass_tab || !opts) { fail(SPL_EINVAL, "spl_create: null argument"); return nullptr; }
+    std::unique_ptr<spl_tokenizer> t(new spl_tokenizer());
     std::string err;
-    if (build_tables((const uint8_t*)vocab_splv, vocab_len, (const uint8_t*)uclass_tab, uclass_len, opts->pattern, t->ht, err)) {
+    if (build_tables((const uint8_t*)vocab, vocab_len, (const uint8_t*)uclass_tab, uclass_len, opts->pattern,
+                     (opts->flags & SPL_OPT_BYTE_LEVEL) != 0, t->ht, err)) {
         fail(SPL_EINVAL, "spl_create: " + err);
-        delete t;
         return nullptr;
     }
-    t->device = opts->device;
-    auto up = [&]() -> int {
-        HIP_TRY(hipSetDevice(t->device));
-        int rc;
-        if ((rc = dev_upload(t->ht.ucls_stage1, &t->dt.ucls_stage1))) return rc;
-        if ((rc = dev_upload(t->ht.ucls_stage2, &t->dt.ucls_stage2))) return rc;
-        if ((rc = dev_upload(t->ht.short_tab, &t->dt.short_tab))) return rc;
-        if ((rc = dev_upload(t->ht.tiny_tab, &t->dt.tiny_tab))) return rc;
-        if ((rc = dev_upload(t->ht.t8_tab, &t->dt.t8_tab))) return rc;
-        if ((rc = dev_upload(t->ht.long_tab, &t->dt.long_tab))) return rc;
-        if ((rc = dev_upload(t->ht.key_blob, &t->dt.key_blob))) return rc;
-        if ((rc = dev_upload(t->ht.pair_tab, &t->dt.pair_tab))) return rc;
-        if ((rc = dev_upload(t->ht.byte_id, &t->dt.byte_id))) return rc;
-        if ((rc = dev_upload(t->ht.p8_tab, reinterpret_cast<const uint32_t**>(&t->dt.p8_tab)))) return rc;
-        if ((rc = dev_upload(t->ht.len_mask, &t->dt.len_mask))) return rc;
-        if ((rc = dev_upload(t->ht.tok_off, &t->d_tok_off))) return rc;
-        if ((rc = dev_upload(t->ht.tok_bytes, &t->d_tok_bytes))) return rc;
-        return SPL_OK;
-    };
-    if (up() != SPL_OK) { delete t; return nullptr; }
-    t->dt.ucls_shift = t->ht.ucls_shift;
-    t->dt.cjk_fast = t->ht.cjk_fast ? 1u : 0u;
-    t->dt.short_mask = (uint32_t)(t->ht.short_tab.size() / SPL_SHORT_BUCKET) - 1;
-    t->dt.tiny_mask = (uint32_t)(t->ht.tiny_tab.size() / (SPL_TINY_BUCKET * 2)) - 1;
-    t->dt.t8_mask = (uint32_t)(t->ht.t8_tab.size() / SPL_T8_WORDS) - 1;
-    t->dt.long_mask = (uint32_t)t->ht.long_tab.size() - 1;
-    t->dt.pair_mask = (uint32_t)(t->ht.pair_tab.size() / SPL_PAIR_BUCKET) - 1;
-    t->dt.p8_mask = (uint32_t)(t->ht.p8_tab.size() / 2) - 1;
-    t->dt.tiny_free = t->ht.tiny_free; t->dt.t8_free = t->ht.t8_free;
-    t->dt.max_key_len = t->ht.max_key_len;
-    t->dt.pattern = (uint32_t)t->ht.pattern;
-    t->dt.all_bytes = t->ht.all_bytes ? 1u : 0u;
-    return t;
+    t->ctx.emplace_back(new Ctx());
+    t->ctx[0]->device = opts->device;
+    if (upload_tables(*t->ctx[0], t->ht) != SPL_OK) return nullptr;      // (the context's destructor frees what was uploaded)
+    return t.release();
+}
+
+int spl_set_devices(spl_tokenizer* t, const int32_t* devices, uint32_t n) {
+    if (!t || !devices || n == 0 || n > 64) return fail(SPL_EINVAL, "spl_set_devices: bad argument");
+    const int have = spl_device_count();
+    for (uint32_t i = 0; i < n; i++)
+        if (devices[i] < 0 || devices[i] >= have) return fail(SPL_EINVAL, "spl_set_devices: no such device");
+    std::vector<std::unique_ptr<Ctx>> nc;
+    for (uint32_t i = 0; i < n; i++) {
+        nc.emplace_back(new Ctx());
+        nc.back()->device = devices[i];
+        int rc = upload_tables(*nc.back(), t->ht);
+        if (rc) return rc;
+    }
+    t->ctx.swap(nc);
+    return SPL_OK;
+}
+
+uint32_t spl_n_devices(const spl_tokenizer* t) { return t ? (uint32_t)t->ctx.size() : 0u; }
+
+int spl_set_option(spl_tokenizer* t, const char* name, int64_t value) {
+    if (!t || !name) return fail(SPL_EINVAL, "spl_set_option: null argument");
+    const std::string k(name);
+    if (k == "chunk_bytes" && value >= 1) t->chunk_bytes = (uint64_t)value;
+    else if (k == "single_chunk_max_bytes" && value >= 0) t->single_max = (uint64_t)value;
+    else if (k == "result_estimate_div" && value >= 1) t->est_div = (uint32_t)value;
+    else if (k == "subdoc_split") t->subdoc = value != 0;
+    else return fail(SPL_EINVAL, "spl_set_option: unknown option or bad value: " + k);
+    return SPL_OK;
 }
 
 int spl_add_special(spl_tokenizer* t, const uint8_t* literal, size_t len, uint32_t id) {
     if (!t || !literal || len == 0) return fail(SPL_EINVAL, "spl_add_special: bad argument");
     if (len > (size_t)SP_MAXLEN) return fail(SPL_EINVAL, "spl_add_special: literal longer than 32 bytes");
+    if (id > 0x7FFFFFFFu) return fail(SPL_EINVAL, "spl_add_special: id out of range");
     const std::string lit((const char*)literal, len);
     // The device scan treats every occurrence as a match, which equals Aho-Corasick's
     // non-overlapping Standard semantics only if no two occurrences can ever overlap.
@@ -421,8 +924,9 @@ int spl_add_special(spl_tokenizer* t, const uint8_t* literal, size_t len, uint32
     for (const auto& sp : t->specials)
         if (overlaps(sp.lit, lit)) return fail(SPL_EINVAL, "spl_add_special: literal can overlap '" + sp.lit + "'");
     t->specials.push_back(Special{lit, id});
-    t->sp_uploaded = false;
+    for (auto& c : t->ctx) { c->sp_uploaded = false; c->dec_uploaded = false; }
     t->max_special_id = std::max(t->max_special_id, id);
+    if (lit.find('\n') != std::string::npos) t->special_newline = true;
     return SPL_OK;
 }
 
@@ -431,23 +935,11 @@ uint32_t spl_vocab_size(const spl_tokenizer* t) {
     return std::max(t->ht.max_id, t->max_special_id) + 1;
 }
 
-void spl_destroy(spl_tokenizer* t) {
-    if (!t) return;
-    hipSetDevice(t->device);
-    hipDeviceSynchronize();
-    free_workspace(t);
-    hipFree((void*)t->dt.ucls_stage1); hipFree((void*)t->dt.ucls_stage2); hipFree((void*)t->dt.short_tab);
-    hipFree((void*)t->dt.tiny_tab); hipFree((void*)t->dt.t8_tab);
-    hipFree((void*)t->dt.long_tab); hipFree((void*)t->dt.key_blob); hipFree((void*)t->dt.pair_tab);
-    hipFree((void*)t->dt.byte_id); hipFree((void*)t->dt.p8_tab); hipFree((void*)t->dt.len_mask); hipFree((void*)t->d_tok_off); hipFree((void*)t->d_tok_bytes);
-    hipFree(t->d_in_text); hipFree(t->d_in_off); hipFree(t->d_out_ids); hipFree(t->d_out_off); hipFree(t->d_sp_lits);
-    if (t->ev_ready) for (auto& e : t->ev) hipEventDestroy(e);
-    delete t;
-}
+void spl_destroy(spl_tokenizer* t) { delete t; }
 
 int spl_reserve(spl_tokenizer* t, uint64_t max_bytes, uint64_t max_docs) {
     if (!t) return fail(SPL_EINVAL, "spl_reserve: null handle");
-    return reserve(t, max_bytes, max_docs);
+    return reserve(t->ctx[0].get(), max_bytes, max_docs);
 }
 
 int spl_encode_batch_device(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
@@ -455,8 +947,8 @@ int spl_encode_batch_device(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_
                             uint64_t* d_out_off, void* hip_stream) {
     if (!t || !d_doc_off || !d_out_off || (n_bytes && (!d_utf8 || !d_ids)))
         return fail(SPL_EINVAL, "spl_encode_batch_device: null argument");
-    HIP_TRY(hipSetDevice(t->device));
-    return launch_all(t, d_utf8, n_bytes, d_doc_off, n_docs, flags, d_ids, ids_capacity, d_out_off, (hipStream_t)hip_stream);
+    HIP_TRY(hipSetDevice(t->ctx[0]->device));
+    return launch_all(t, t->ctx[0].get(), d_utf8, n_bytes, d_doc_off, n_docs, flags, d_ids, ids_capacity, d_out_off, (hipStream_t)hip_stream);
 }
 
 int spl_encode_batch_device_packed(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
@@ -465,11 +957,12 @@ int spl_encode_batch_device_packed(spl_tokenizer* t, const uint8_t* d_utf8, uint
                                    void* hip_stream) {
     if (!t || !d_doc_off || !d_out_off || !d_slab || (n_bytes && (!d_utf8 || !d_ids)))
         return fail(SPL_EINVAL, "spl_encode_batch_device_packed: null argument");
-    if (cap_words < max_docs + 4 || n_docs > max_docs) return fail(SPL_EINVAL, "spl_encode_batch_device_packed: slab too small");
-    HIP_TRY(hipSetDevice(t->device));
+    if (cap_words < max_docs + 4 || n_docs > max_docs || cap_words > 0xFFFFFFFFull)
+        return fail(SPL_EINVAL, "spl_encode_batch_device_packed: slab too small or beyond 2^32 words");
+    HIP_TRY(hipSetDevice(t->ctx[0]->device));
     SlabOut so;
     so.d_slab = d_slab; so.cap_words = cap_words; so.max_docs = max_docs;
-    return launch_all(t, d_utf8, n_bytes, d_doc_off, n_docs, flags, d_ids, ids_capacity, d_out_off, (hipStream_t)hip_stream, &so);
+    return launch_all(t, t->ctx[0].get(), d_utf8, n_bytes, d_doc_off, n_docs, flags, d_ids, ids_capacity, d_out_off, (hipStream_t)hip_stream, &so);
 }
 
 int spl_encode_batch(spl_tokenizer* t, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,
@@ -478,97 +971,93 @@ int spl_encode_batch(spl_tokenizer* t, const uint8_t* utf8, const uint64_t* doc_
     if (doc_off[0] != 0) return fail(SPL_EINVAL, "spl_encode_batch: doc_off[0] must be 0");
     for (uint64_t d = 0; d < n_docs; d++)
         if (doc_off[d + 1] < doc_off[d]) return fail(SPL_EINVAL, "spl_encode_batch: doc_off must be non-decreasing");
-    const uint64_t n_bytes = doc_off[n_docs];
-    if (n_bytes && !utf8) return fail(SPL_EINVAL, "spl_encode_batch: null text");
-    HIP_TRY(hipSetDevice(t->device));
-
-    spl_result* r = new spl_result();
-    r->off.assign(n_docs + 1, 0);
-    // a device call takes < 2^31 bytes: walk the documents in slabs of about 1 GiB
-    const uint64_t SLAB = 1ull << 30;
-    uint64_t d0 = 0;
-    while (d0 < n_docs) {
-        uint64_t d1 = d0;
-        while (d1 < n_docs && (d1 == d0 || doc_off[d1 + 1] - doc_off[d0] <= SLAB)) d1++;
-        const uint64_t nb = doc_off[d1] - doc_off[d0], nd = d1 - d0;
-        if (nb > 0x7FFF0000ull) { delete r; return fail(SPL_EINVAL, "spl_encode_batch: a single document exceeds 2^31 bytes"); }
-        if (nb > t->in_cap_bytes || nd > t->in_cap_docs || !t->d_in_off) {
-            HIP_TRY(hipDeviceSynchronize());
-            hipFree(t->d_in_text); hipFree(t->d_in_off); hipFree(t->d_out_ids); hipFree(t->d_out_off);
-            t->in_cap_bytes = std::max<uint64_t>(nb, t->in_cap_bytes);
-            t->in_cap_docs = std::max<uint64_t>(nd, t->in_cap_docs);
-            HIP_TRY(hipMalloc((void**)&t->d_in_text, t->in_cap_bytes + 64));
-            HIP_TRY(hipMalloc((void**)&t->d_in_off, (t->in_cap_docs + 1) * 8));
-            HIP_TRY(hipMalloc((void**)&t->d_out_ids, (t->in_cap_bytes + 16) * 4));
-            HIP_TRY(hipMalloc((void**)&t->d_out_off, (t->in_cap_docs + 1) * 8));
-        }
-        std::vector<uint64_t> rel(nd + 1);
-        for (uint64_t k = 0; k <= nd; k++) rel[k] = doc_off[d0 + k] - doc_off[d0];
-        if (nb) HIP_TRY(hipMemcpyAsync(t->d_in_text, utf8 + doc_off[d0], nb, hipMemcpyHostToDevice, 0));
-        HIP_TRY(hipMemcpyAsync(t->d_in_off, rel.data(), (nd + 1) * 8, hipMemcpyHostToDevice, 0));
-        int rc = launch_all(t, t->d_in_text, nb, t->d_in_off, nd, flags, t->d_out_ids, nb, t->d_out_off, 0);
-        if (rc) { delete r; return rc; }
-        std::vector<uint64_t> oo(nd + 1);
-        HIP_TRY(hipMemcpy(oo.data(), t->d_out_off, (nd + 1) * 8, hipMemcpyDeviceToHost));
-        const uint64_t total = oo[nd], base = r->ids.size();
-        r->ids.resize(base + total);
-        if (total) HIP_TRY(hipMemcpy(r->ids.data() + base, t->d_out_ids, total * 4, hipMemcpyDeviceToHost));
-        for (uint64_t k = 0; k <= nd; k++) r->off[d0 + k] = base + oo[k];
-        d0 = d1;
-    }
-    *out = r;
+    if (doc_off[n_docs] && !utf8) return fail(SPL_EINVAL, "spl_encode_batch: null text");
+    std::unique_ptr<spl_result> r(new spl_result());
+    int rc = encode_host(t, utf8, doc_off, n_docs, flags, r.get());
+    if (rc) return rc;
+    *out = r.release();
     return SPL_OK;
 }
 
-const uint32_t* spl_result_tokens(const spl_result* r) { return r ? r->ids.data() : nullptr; }
-const uint64_t* spl_result_offsets(const spl_result* r) { return r ? r->off.data() : nullptr; }
-uint64_t spl_result_n_tokens(const spl_result* r) { return r ? r->ids.size() : 0; }
-uint64_t spl_result_n_docs(const spl_result* r) { return r ? r->off.size() - 1 : 0; }
+const uint32_t* spl_result_tokens(const spl_result* r) { return r ? r->ids : nullptr; }
+const uint64_t* spl_result_offsets(const spl_result* r) { return r ? r->off : nullptr; }
+uint64_t spl_result_n_tokens(const spl_result* r) { return r ? r->n_tokens : 0; }
+uint64_t spl_result_n_docs(const spl_result* r) { return r ? r->n_docs : 0; }
 void spl_result_free(spl_result* r) { delete r; }
+
+void* spl_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocPortable) != hipSuccess) {
+        fail(SPL_EDEVICE, "spl_host_alloc: hipHostMalloc failed");
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+void spl_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 int spl_decode_batch(spl_tokenizer* t, const uint32_t* ids, const uint64_t* ids_off, uint64_t n_docs, uint8_t** out_bytes,
                      uint64_t** out_off) {
     if (!t || !ids_off || !out_bytes || !out_off) return fail(SPL_EINVAL, "spl_decode_batch: null argument");
-    HIP_TRY(hipSetDevice(t->device));
+    for (uint64_t d = 0; d < n_docs; d++)
+        if (ids_off[d + 1] < ids_off[d]) return fail(SPL_EINVAL, "spl_decode_batch: ids_off must be non-decreasing");
+    Ctx* c = t->ctx[0].get();
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_streams(*c);
+    if (rc) return rc;
+    if ((rc = upload_decode(t, c))) return rc;
     const uint64_t n = ids_off[n_docs] - ids_off[0];
-    const uint32_t* src = ids + ids_off[0];
-    // special ids decode to their literal on the host side (few); vocabulary ids gather on the GPU
-    uint32_t* d_ids = nullptr; uint64_t* d_len = nullptr; uint8_t* d_out = nullptr;
-    std::vector<uint64_t> len(n + 1, 0);
+    if (n && !ids) return fail(SPL_EINVAL, "spl_decode_batch: null ids");
+    const uint64_t n_blk = (n + DEC_BLK - 1) / DEC_BLK;
+    struct Out { uint8_t* b = nullptr; uint64_t* o = nullptr; ~Out() { free(b); free(o); } } o;   // freed on every error path
+    o.o = (uint64_t*)malloc((n_docs + 1) * 8);
+    if (!o.o) return fail(SPL_EDEVICE, "spl_decode_batch: out of host memory");
+    uint64_t total = 0;
     if (n) {
-        HIP_TRY(hipMalloc((void**)&d_ids, n * 4));
-        HIP_TRY(hipMalloc((void**)&d_len, n * 8));
-        HIP_TRY(hipMemcpy(d_ids, src, n * 4, hipMemcpyHostToDevice));
-        DecodeArgs a{d_ids, n, t->d_tok_off, t->d_tok_bytes, t->ht.max_id, d_len, nullptr};
-        hipLaunchKernelGGL(k_decode_len, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, a);
-        HIP_TRY(hipMemcpy(len.data(), d_len, n * 8, hipMemcpyDeviceToHost));
+        // scratch grows, never shrinks: a steady stream of calls allocates nothing
+        if (n > c->dec_cap_ids || !c->d_dec_ids) {
+            HIP_TRY(hipDeviceSynchronize());
+            hipFree(c->d_dec_ids); hipFree(c->d_dec_blk); hipFree(c->d_dec_idoff);
+            c->d_dec_ids = nullptr; c->d_dec_blk = nullptr; c->d_dec_idoff = nullptr;
+            c->dec_cap_ids = n + n / 4 + 4096;
+            HIP_TRY(hipMalloc((void**)&c->d_dec_ids, c->dec_cap_ids * 4));
+            HIP_TRY(hipMalloc((void**)&c->d_dec_blk, (c->dec_cap_ids / DEC_BLK + 4) * 8));
+            HIP_TRY(hipMalloc((void**)&c->d_dec_idoff, (c->dec_cap_ids + 1) * 8));
+        }
+        if (n_docs + 1 > c->dec_cap_docs || !c->d_dec_first) {
+            HIP_TRY(hipDeviceSynchronize());
+            hipFree(c->d_dec_first); hipFree(c->d_dec_docoff);
+            c->d_dec_first = nullptr; c->d_dec_docoff = nullptr;
+            c->dec_cap_docs = n_docs + 1 + n_docs / 4 + 1024;
+            HIP_TRY(hipMalloc((void**)&c->d_dec_first, c->dec_cap_docs * 8));
+            HIP_TRY(hipMalloc((void**)&c->d_dec_docoff, c->dec_cap_docs * 8));
+        }
+        HIP_TRY(hipMemcpyAsync(c->d_dec_ids, ids + ids_off[0], n * 4, hipMemcpyHostToDevice, c->s_cmp));
+        HIP_TRY(hipMemcpyAsync(c->d_dec_first, ids_off, (n_docs + 1) * 8, hipMemcpyHostToDevice, c->s_cmp));
+        DecodeArgs a{};
+        a.ids = c->d_dec_ids; a.n_ids = n; a.tok_off = c->d_tok_off; a.tok_bytes = c->d_tok_bytes; a.max_id = c->dec_max_id;
+        a.blk = c->d_dec_blk; a.id_off = c->d_dec_idoff; a.doc_first = c->d_dec_first; a.n_docs = n_docs; a.doc_off = c->d_dec_docoff;
+        hipLaunchKernelGGL(k_decode_len, dim3((uint32_t)n_blk), dim3(NT), 0, c->s_cmp, a);
+        hipLaunchKernelGGL(k_decode_scan, dim3(1), dim3(1024), 0, c->s_cmp, c->d_dec_blk, n_blk);
+        HIP_TRY(hipMemcpyAsync(&total, c->d_dec_blk + n_blk, 8, hipMemcpyDeviceToHost, c->s_cmp));
+        HIP_TRY(hipStreamSynchronize(c->s_cmp));                  // the output size: the one host round trip
+        if ((rc = grow(&c->d_dec_out, &c->dec_cap_out, total + 16))) return rc;
+        a.out = c->d_dec_out;
+        hipLaunchKernelGGL(k_decode_copy, dim3((uint32_t)n_blk), dim3(NT), 0, c->s_cmp, a);
+        hipLaunchKernelGGL(k_decode_docs, dim3((uint32_t)((n_docs + 1 + 255) / 256)), dim3(256), 0, c->s_cmp, a);
+        HIP_TRY(hipGetLastError());
+        o.b = (uint8_t*)malloc(total ? total : 1);
+        if (!o.b) return fail(SPL_EDEVICE, "spl_decode_batch: out of host memory");
+        if (total) HIP_TRY(hipMemcpyAsync(o.b, c->d_dec_out, total, hipMemcpyDeviceToHost, c->s_cmp));
+        HIP_TRY(hipMemcpyAsync(o.o, c->d_dec_docoff, (n_docs + 1) * 8, hipMemcpyDeviceToHost, c->s_cmp));
+        HIP_TRY(hipStreamSynchronize(c->s_cmp));
+    } else {
+        o.b = (uint8_t*)malloc(1);
+        if (!o.b) return fail(SPL_EDEVICE, "spl_decode_batch: out of host memory");
+        for (uint64_t d = 0; d <= n_docs; d++) o.o[d] = 0;
     }
-    // splice special literals: they are not in the device table (id > max_id or unmapped)
-    std::vector<const std::string*> sp_of(n, nullptr);
-    for (uint64_t i = 0; i < n; i++) {
-        const bool in_vocab = src[i] <= t->ht.max_id && t->ht.tok_off[src[i] + 1] > t->ht.tok_off[src[i]];
-        if (!in_vocab)
-            for (const auto& s : t->specials)
-                if (s.id == src[i]) { sp_of[i] = &s.lit; len[i] = s.lit.size(); break; }
-    }
-    uint64_t acc = 0;
-    for (uint64_t i = 0; i < n; i++) { const uint64_t l = len[i]; len[i] = acc; acc += l; }
-    len[n] = acc;
-    uint8_t* ob = (uint8_t*)malloc(acc ? acc : 1);
-    uint64_t* oo = (uint64_t*)malloc((n_docs + 1) * 8);
-    if (n) {
-        HIP_TRY(hipMalloc((void**)&d_out, acc ? acc : 16));
-        HIP_TRY(hipMemcpy(d_len, len.data(), n * 8, hipMemcpyHostToDevice));
-        DecodeArgs a{d_ids, n, t->d_tok_off, t->d_tok_bytes, t->ht.max_id, d_len, d_out};
-        hipLaunchKernelGGL(k_decode_copy, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, a);
-        if (acc) HIP_TRY(hipMemcpy(ob, d_out, acc, hipMemcpyDeviceToHost));
-        for (uint64_t i = 0; i < n; i++)
-            if (sp_of[i]) memcpy(ob + len[i], sp_of[i]->data(), sp_of[i]->size());
-        hipFree(d_ids); hipFree(d_len); hipFree(d_out);
-    }
-    for (uint64_t d = 0; d <= n_docs; d++) oo[d] = len[ids_off[d] - ids_off[0]];
-    *out_bytes = ob;
-    *out_off = oo;
+    *out_bytes = o.b; *out_off = o.o;
+    o.b = nullptr; o.o = nullptr;
     return SPL_OK;
 }
 
@@ -576,19 +1065,19 @@ void spl_free(void* p) { free(p); }
 
 int spl_profile_enable(spl_tokenizer* t, int on) {
     if (!t) return fail(SPL_EINVAL, "null handle");
-    t->prof = on != 0;
+    t->ctx[0]->prof = on != 0;
     return SPL_OK;
 }
 int spl_profile_reset(spl_tokenizer* t) {
     if (!t) return fail(SPL_EINVAL, "null handle");
-    memset(t->prof_ms, 0, sizeof t->prof_ms);
-    memset(t->prof_n, 0, sizeof t->prof_n);
+    memset(t->ctx[0]->prof_ms, 0, sizeof t->ctx[0]->prof_ms);
+    memset(t->ctx[0]->prof_n, 0, sizeof t->ctx[0]->prof_n);
     return SPL_OK;
 }
 int spl_profile_read(spl_tokenizer* t, double ms_out[SPL_MAX_KERNELS], uint64_t launches_out[SPL_MAX_KERNELS]) {
     if (!t) return fail(SPL_EINVAL, "null handle");
-    memcpy(ms_out, t->prof_ms, sizeof t->prof_ms);
-    memcpy(launches_out, t->prof_n, sizeof t->prof_n);
+    memcpy(ms_out, t->ctx[0]->prof_ms, sizeof t->ctx[0]->prof_ms);
+    memcpy(launches_out, t->ctx[0]->prof_n, sizeof t->ctx[0]->prof_n);
     return SPL_OK;
 }
 const char* spl_kernel_name(int index) { return (index >= 0 && index < KI_N) ? k_names[index] : nullptr; }
@@ -598,7 +1087,7 @@ int spl_gatherv_pack(spl_tokenizer* t, const uint32_t* d_ids, const uint64_t* d_
     if (!t || !d_ids || !d_out_off || !d_slab) return fail(SPL_EINVAL, "spl_gatherv_pack: null argument");
     if (n_docs > max_docs || cap_words < max_docs + 4 || cap_words > 0xFFFFFFFFull)
         return fail(SPL_EINVAL, "spl_gatherv_pack: slab too small for the document table");
-    HIP_TRY(hipSetDevice(t->device));
+    HIP_TRY(hipSetDevice(t->ctx[0]->device));
     hipLaunchKernelGGL(k_gatherv_pack, dim3(256), dim3(256), 0, (hipStream_t)hip_stream, d_ids, d_out_off, (uint32_t)n_docs,
                        d_slab, (uint32_t)cap_words, (uint32_t)max_docs);
     HIP_TRY(hipGetLastError());
@@ -609,7 +1098,7 @@ int spl_gatherv_unpack(spl_tokenizer* t, const uint32_t* d_slabs, uint32_t world
                        uint32_t* d_all_ids, uint64_t all_ids_cap, uint64_t* d_all_off, uint32_t* d_status, void* hip_stream) {
     if (!t || !d_slabs || !d_all_ids || !d_all_off || !d_status || world == 0)
         return fail(SPL_EINVAL, "spl_gatherv_unpack: bad argument");
-    HIP_TRY(hipSetDevice(t->device));
+    HIP_TRY(hipSetDevice(t->ctx[0]->device));
     hipLaunchKernelGGL(k_gatherv_unpack, dim3(128, world), dim3(256), 0, (hipStream_t)hip_stream, d_slabs, world,
                        (uint32_t)cap_words, (uint32_t)max_docs, d_all_ids, all_ids_cap, d_all_off, d_status,
                        (uint64_t)cap_words, (uint64_t)0);
@@ -623,7 +1112,7 @@ int spl_gatherv_unpack_group(spl_tokenizer* t, const uint32_t* d_slabs, uint32_t
     if (!t || !d_slabs || !d_all_ids || !d_all_off || !d_status || world == 0 || depth == 0 || n_batches > depth)
         return fail(SPL_EINVAL, "spl_gatherv_unpack_group: bad argument");
     if (n_batches == 0) return SPL_OK;
-    HIP_TRY(hipSetDevice(t->device));
+    HIP_TRY(hipSetDevice(t->ctx[0]->device));
     hipLaunchKernelGGL(k_gatherv_unpack, dim3(128, world, n_batches), dim3(256), 0, (hipStream_t)hip_stream, d_slabs, world,
                        (uint32_t)cap_words, (uint32_t)max_docs, d_all_ids, all_ids_cap, d_all_off, d_status,
                        (uint64_t)depth * cap_words, off_stride);
@@ -633,22 +1122,26 @@ int spl_gatherv_unpack_group(spl_tokenizer* t, const uint32_t* d_slabs, uint32_t
 
 int spl_debug_blocks(spl_tokenizer* t, unsigned long long* out, int max_blocks) {
     if (!t || !out) return fail(SPL_EINVAL, "null argument");
-    HIP_TRY(hipSetDevice(t->device));
+    Ctx* c = t->ctx[0].get();
+    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());
-    if (!t->d_dbg) return 0;
+    if (!c->d_dbg) return 0;
     const int n = max_blocks < SPL_DEBUG_BLOCKS ? max_blocks : SPL_DEBUG_BLOCKS;
-    HIP_TRY(hipMemcpy(out, t->d_dbg + 16, (size_t)n * 32, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, c->d_dbg + 16, (size_t)n * 32, hipMemcpyDeviceToHost));
     return n;
 }
 
 int spl_debug_phases(spl_tokenizer* t, int enable, unsigned long long stamps_out[16]) {
     if (!t) return fail(SPL_EINVAL, "null handle");
-    HIP_TRY(hipSetDevice(t->device));
-    HIP_TRY(hipDeviceSynchronize());
-    if (stamps_out && t->d_dbg) HIP_TRY(hipMemcpy(stamps_out, t->d_dbg, 16 * 8, hipMemcpyDeviceToHost));
-    t->dbg_on = (enable & 1) != 0;
-    t->stop_phase = (enable >> 4) & 7;
-    t->force_tile = (enable >> 1) & 7;      // development: 1 = small tiles, 2 = large tiles, 3 = small tiles + multi-pass, 4 = queue mode
+    for (auto& cp : t->ctx) {
+        Ctx* c = cp.get();
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipDeviceSynchronize());
+        if (c == t->ctx[0].get() && stamps_out && c->d_dbg) HIP_TRY(hipMemcpy(stamps_out, c->d_dbg, 16 * 8, hipMemcpyDeviceToHost));
+        c->dbg_on = (enable & 1) != 0;
+        c->stop_phase = (enable >> 4) & 7;
+        c->force_tile = (enable >> 1) & 7;      // development: 1 = small tiles, 2 = large tiles, 3 = small tiles + multi-pass, 4 = queue mode
+    }
     return SPL_OK;
 }
 
@@ -662,15 +1155,16 @@ int spl_debug_merge_timing(unsigned long long out[8], int reset) {
 #endif
 
 int spl_last_queue_counts(spl_tokenizer* t, uint32_t counts_out[4]) {
-    if (!t || !t->d_zero) return fail(SPL_EINVAL, "no batch has run");
-    HIP_TRY(hipSetDevice(t->device));
+    if (!t || !t->ctx[0]->d_zero) return fail(SPL_EINVAL, "no batch has run");
+    Ctx* c = t->ctx[0].get();
+    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());
-    if (!t->last_qcount) {       // single-pass call: no global queues exist
+    if (!c->last_qcount) {       // single-pass call: no global queues exist
         for (int i = 0; i < 4; i++) counts_out[i] = 0;
         return SPL_OK;
     }
     uint32_t q[8];
-    HIP_TRY(hipMemcpy(q, t->last_qcount, 32, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(q, c->last_qcount, 32, hipMemcpyDeviceToHost));
     counts_out[0] = q[0]; counts_out[1] = q[1]; counts_out[3] = q[3];
     counts_out[2] = q[2] + q[4];             // the long-chunk queue is filled from both ends
     return SPL_OK;

@@ -1501,6 +1501,12 @@ template <int TB_, int RH_> struct TileGeom {
 #ifndef SPL_PRETOK_WAVES
 #define SPL_PRETOK_WAVES 6
 #endif
+#ifndef SPL_TILE_MISS_LIST
+#define SPL_TILE_MISS_LIST 0      /* 1: EVERY miss of a tile through the workgroup-wide segment pass of the tail instead of the
+                                     per-wavefront merge loops.  Measured on the bench batch: 60 us against 42 us per launch --
+                                     fewer instructions, but the tail's ~20 workgroup barriers serialise what the wavefronts
+                                     otherwise do independently (profiles/r02_notes.md).  Kept for A/B builds. */
+#endif
 constexpr int DIRECT_LQ_MEDIUM = 16;      // of which, from the back: medium chunks of multi-byte text
 constexpr int DIRECT_LQCAP = 32;          // long-chunk list of one workgroup (refilled while a chain is continued)
 constexpr int DIRECT_WIN = 2048;           // bytes staged per turn for a chain that continues beyond the window
@@ -1542,7 +1548,8 @@ constexpr int SG_CTL = 91;       // [8] packed chunks, long segments, chunks to 
 constexpr int SG_ID = 100;       // [SEG_ROWS] id of each row's byte
 constexpr int SG_MID = SG_ID + SEG_ROWS;     // [32] segments of 9..16 bytes
 constexpr int SG_XSEG = SG_MID + 32;          // [4] segments of 65 .. 64 XNPL bytes
-constexpr int SG_WORDS = SG_XSEG + 4;
+constexpr int SG_SBITS = SG_XSEG + 4;         // [8] bit r: row r is the first row of a packed chunk
+constexpr int SG_WORDS = SG_SBITS + 8;
 template <int XNPL, class EmitG>
 __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, const Batch& b, uint32_t* s_lq, uint32_t nl,
                                                       uint32_t* slab, uint32_t* scr, uint32_t* s_wsum4, const uint8_t* win_txt,
@@ -1560,9 +1567,19 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
         const int w = pos >> 5, sh = pos & 31;
         return (hard[w] >> sh) | (sh ? hard[w + 1] << (32 - sh) : 0u);
     };
+    uint32_t* const sbits = scr + SG_SBITS;
+    auto chunk_of = [&](int row) {                           // packing slot of the chunk that owns a row:
+        uint32_t k = 0;                                      // chunk starts at or below it, minus one
+        const int rw = row >> 5;
+#pragma unroll
+        for (int w = 0; w < SEG_ROWS / 32; w++) {
+            const uint32_t x = sbits[w];
+            k += w < rw ? __popc(x) : w == rw ? __popc(x & (0xFFFFFFFFu >> (31 - (row & 31)))) : 0u;
+        }
+        return k - 1u;
+    };
     auto first_byte_of = [&](int row) {                      // global position of a row's byte
-        uint32_t k = 0;
-        while (off[k + 1] <= (uint32_t)row) k++;
+        const uint32_t k = chunk_of(row);
         return s_lq[2 * item[k]] + ((uint32_t)row - off[k]);
     };
     if (tid == 0) { ctl[3] = 0; ctl[5] = 0; hard[8] = 0; hard[9] = 0; }
@@ -1589,7 +1606,9 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
             }
             const unsigned long long tm = __ballot(take);
             const uint32_t k = mbcnt64(tm), nk = (uint32_t)__popcll(tm);
-            if (take) { off[k] = offv; item[k] = (uint32_t)lane; }
+            if (lane < SEG_ROWS / 32) sbits[lane] = 0u;
+            wave_lds_sync();
+            if (take) { off[k] = offv; item[k] = (uint32_t)lane; atomicOr(&sbits[offv >> 5], 1u << (offv & 31)); }
             const uint32_t endv = offv + (n < (uint32_t)SEG_ROWS ? n : (uint32_t)SEG_ROWS);
             const uint32_t total = tm ? (uint32_t)__builtin_amdgcn_readlane((int)endv, 63 - __builtin_clzll(tm)) : 0u;
             if (lane == 0) {
@@ -1607,15 +1626,15 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
         int maxlen = 0, cap = 0;                             // cap: bytes left in the row's chunk
         uint32_t w0 = 0, w1 = 0, bid = SPL_DEAD, lm = 0;
         if (own) {
-            uint32_t k = 0;
-            while (off[k + 1] <= (uint32_t)tid) k++;
+            const uint32_t k = chunk_of(tid);
             const uint32_t ci = (uint32_t)tid - off[k], cn = s_lq[2 * item[k] + 1];
             const uint64_t g = (uint64_t)s_lq[2 * item[k]] + ci, B = b.n_bytes;
             cap = (int)(cn - ci);
             maxlen = cn - ci < (uint32_t)SUB_LMAX ? (int)(cn - ci) : SUB_LMAX;
             if ((int64_t)g >= win_lo && (int64_t)g + 8 <= win_hi) {        // staged with the tile's window: no trip to HBM
-                const uint8_t* const t8 = win_txt + ((int64_t)g - win_lo);
-                for (int q = 0; q < 4; q++) { w0 |= (uint32_t)t8[q] << (8 * q); w1 |= (uint32_t)t8[4 + q] << (8 * q); }
+                const LdsAcc wt{nullptr, win_txt};
+                const int q = (int)((int64_t)g - win_lo);
+                w0 = wt.load32(q); w1 = wt.load32(q + 4);
             } else if (g + 8 <= B) { __builtin_memcpy(&w0, b.text + g, 4); __builtin_memcpy(&w1, b.text + g + 4, 4); }
             else for (int q = 0; q < 8; q++) if (g + q < B) (q < 4 ? w0 : w1) |= (uint32_t)b.text[g + q] << (8 * (q & 3));
             bid = T.byte_id[w0 & 0xFFu];
@@ -1731,9 +1750,7 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
                         s_lq[2 * qi + 1] = l3;
                         atomicOr(&ctl[3], 1u << qi);         // (not to be packed again)
                     } else {                                 // no room: the whole chunk stays on the list
-                        uint32_t k = 0;
-                        while (off[k + 1] <= (uint32_t)tid) k++;
-                        atomicOr(&ctl[2], 1u << k);
+                        atomicOr(&ctl[2], 1u << chunk_of(tid));
                     }
                 }
             }
@@ -1814,7 +1831,10 @@ void k_pretok(DeviceTables T, Batch b) {
     // single-pass state
     __shared__ uint32_t s_ids[DIRECT ? Wv : 1];          // id of the token that starts at this window index
     __shared__ uint32_t s_wpre[DIRECT ? G::NBW + 2 : 1]; // exclusive token counts of the window's bitmap words
-    __shared__ uint32_t s_lq[DIRECT ? 2 * DIRECT_LQCAP : 1];   // (global position, length) of chunks > 64 bytes
+    __shared__ uint32_t s_lq[DIRECT ? 2 * DIRECT_LQCAP : 1];   // (global position, length): the tail's working list
+    constexpr bool TILE_LIST = DIRECT && SPL_TILE_MISS_LIST;
+    __shared__ uint32_t s_tmiss[TILE_LIST ? G::C16 : 1]; // tile-owned: EVERY miss of the tile, p | n << 16 (outside the union:
+                                                         // the tail's slab overlays the scanner's arrays)
     __shared__ uint32_t s_dq[12];                        // [0] long-list fill [1] deferred count [2],[3] deferred starts
                                                          // [4] end of the overflow range [5] chain cursor [6] chain done
     __shared__ unsigned long long s_red[NT / 64];
@@ -2122,13 +2142,19 @@ void k_pretok(DeviceTables T, Batch b) {
                 else b.stage[w0 + p] = id;
                 atomicOr(&s_tbits[p >> 5], 1u << (p & 31));
             } else if (n > 1) {
-                // misses: short and medium chunks are merged right here by this workgroup (list in
-                // LDS); long ones go to the global queue for k_bpe_long
                 const uint32_t item = (uint32_t)p | ((uint32_t)n << 16);
-                if (n <= 16) s_miss[atomicAdd(&s_nq[0], 1u)] = item;
+                if (TILE_LIST) {
+                    // tile-owned: every miss goes on ONE list and through the segment pass of the tail
+                    // (bpe_tail_segments: all of them tabulated together, merged side by side); queue
+                    // mode keeps chunks of more than 64 bytes for the global queue
+                    if (n <= 64 || !b.qcount) s_tmiss[atomicAdd(&s_nq[0], 1u)] = item;
+                    else push_long(b, (uint32_t)(w0 + p), (uint32_t)n);
+                }
+                // multi-pass: short and medium chunks are merged right here by this workgroup (list in
+                // LDS); long ones go to the global queue for k_bpe_long
+                else if (n <= 16) s_miss[atomicAdd(&s_nq[0], 1u)] = item;
                 else if (n <= 64) {
-                    // multi-byte text of the single-pass tile: to the back of the long list, whose
-                    // chunks are merged together, segment by segment (bpe_tail_segments)
+                    // (round-1 routing) multi-byte text of the single-pass tile: to the back of the long list
                     bool sent = false;
                     if (DIRECT && !b.qcount && ((s_txt[p] | s_txt[p + 1]) & 0x80u)) {
                         const uint32_t m = atomicAdd(&s_dq[11], 1u);
@@ -2154,7 +2180,7 @@ void k_pretok(DeviceTables T, Batch b) {
     // (scanner phases run at high priority, the merge loops below them: a workgroup that is still
     // scanning is never starved by older workgroups that already merge; +3 % on the bench batch)
     if (DIRECT) __builtin_amdgcn_s_setprio(SPL_MERGE_PRIO);
-    {
+    if (!TILE_LIST) {
         const uint32_t m16 = s_nq[0], m64 = s_nq[1];
         // Short misses sorted by length, longest first (counting sort into s_cpos, which is free
         // until the tile record): the four chunks a wavefront merges in lock step then have similar
@@ -2281,11 +2307,32 @@ void k_pretok(DeviceTables T, Batch b) {
                 atomicMax(&s_dq[4], q + 1u);
             }
         };
-        // ---- rare: chunks of more than 64 bytes, and the chain that outgrew the window -----------
-        if (s_dq[0] | s_dq[1] | s_dq[11]) {                // workgroup-uniform
+        // ---- the tile's misses (and, rarely, the chain that outgrew the window) ---------------------
+        // Every chunk the whole-chunk probe missed is merged here, up to DIRECT_LQCAP of them at a time:
+        // bpe_tail_segments lays them end to end over the table rows, fills the rows with two batches of
+        // probes for ALL of them together and merges their segments side by side -- one lane per
+        // segment of up to 8 bytes, 16 lanes up to 16, a wavefront beyond -- where the per-chunk route
+        // paid a fill and a lock-step loop per group of four chunks.
+        const uint32_t n_tm = TILE_LIST ? s_nq[0] : 0u;
+        if (n_tm | s_dq[0] | s_dq[1] | s_dq[11]) {         // workgroup-uniform
+            uint32_t mcur = 0;
             for (;;) {
-                // (medium chunks sit at the back of the list, unused entries have length 0)
-                const uint32_t nl0 = (s_dq[11] || s_dq[0] > (uint32_t)DIRECT_LQCAP) ? (uint32_t)DIRECT_LQCAP : s_dq[0];
+                {
+                    const uint32_t have = s_dq[0];           // entries the chain continuation left on the list
+                    uint32_t m = n_tm - mcur;
+                    if (m > (uint32_t)DIRECT_LQCAP - have) m = (uint32_t)DIRECT_LQCAP - have;
+                    if ((uint32_t)tid < m) {
+                        const uint32_t item = s_tmiss[mcur + tid];
+                        s_lq[2 * (have + tid)] = (uint32_t)(w0 + (item & 0xFFFFu));
+                        s_lq[2 * (have + tid) + 1] = item >> 16;
+                    }
+                    __syncthreads();
+                    if (tid == 0) s_dq[0] = have + m;
+                    mcur += m;
+                    __syncthreads();
+                }
+                // (round-1 routing: medium chunks sit at the back of the list, unused entries have length 0)
+                const uint32_t nl0 = (!TILE_LIST && (s_dq[11] || s_dq[0] > (uint32_t)DIRECT_LQCAP)) ? (uint32_t)DIRECT_LQCAP : s_dq[0];
                 const uint32_t nl = bpe_tail_segments<2>(T, b, s_lq, nl0, s_u.t.slab[0], reinterpret_cast<uint32_t*>(s_cpos), s_wsum,
                                                       s_txt, w0, w0 + iT, emit_g);
                 for (uint32_t it = wv; it < nl; it += NT / 64) {         // one wavefront per chunk
@@ -2491,7 +2538,7 @@ void k_pretok(DeviceTables T, Batch b) {
                 }
                 __syncthreads();
                 const uint32_t nd = s_dq[1] < 2u ? s_dq[1] : 2u;
-                if (s_dq[0] == 0 && s_dq[6] >= nd) break;
+                if (s_dq[0] == 0 && s_dq[6] >= nd && mcur >= n_tm) break;
             }
         }
         // SPL_WITH_SPECIAL: the literals that start in this tile are tokens of this tile (k_special_scan
@@ -3009,27 +3056,98 @@ __global__ __launch_bounds__(NT) void k_compact_docs(Batch b, uint32_t n_compact
 }
 
 // ------------------------------------------------------------------------------------------
-// decode_bytes (reference src/core/tokenizer.rs:877-897): gather token byte strings.
+// decode_bytes (reference src/core/tokenizer.rs:877-897, batch form :945-958): gather token byte
+// strings.  The id -> bytes table covers the vocabulary AND the special tokens (the reference looks
+// an id up in `decoder` first, then in `special_tokens_decoder`; an id in neither contributes
+// nothing).  Three launches, no host round trip in between:
+//   k_decode_len    length of every id + sums per block of DEC_BLK ids
+//   k_decode_scan   exclusive scan of the block sums (one workgroup)
+//   k_decode_copy   offset of every id (block base + scan inside the block), byte copy, and the
+//                   byte offset of every document (doc d starts at id ids_off[d])
+constexpr int DEC_BLK = 1024;
 struct DecodeArgs {
     const uint32_t* ids; uint64_t n_ids;
     const uint32_t* tok_off; const uint8_t* tok_bytes; uint32_t max_id;
-    uint64_t* len_or_off;   // per id: length, then exclusive offsets
+    uint64_t* blk;          // [n_blk + 1] block sums, then exclusive offsets (+ total)
+    uint64_t* id_off;       // [n_ids + 1] byte offset of every id (+ total)
     uint8_t* out;
+    const uint64_t* doc_first; uint64_t n_docs; uint64_t* doc_off;   // doc d = ids [doc_first[d] - doc_first[0], ...)
 };
-__global__ void k_decode_len(DecodeArgs a) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n_ids) return;
+__device__ __forceinline__ uint32_t dec_len(const DecodeArgs& a, uint64_t i) {
+    if (i >= a.n_ids) return 0u;
     const uint32_t id = a.ids[i];
-    a.len_or_off[i] = id <= a.max_id ? (uint64_t)(a.tok_off[id + 1] - a.tok_off[id]) : 0ull;
+    return id <= a.max_id ? a.tok_off[id + 1] - a.tok_off[id] : 0u;
 }
-__global__ void k_decode_copy(DecodeArgs a) {
+__global__ __launch_bounds__(NT) void k_decode_len(DecodeArgs a) {
+    __shared__ uint32_t s_w[NT / 64];
+    uint32_t sum = 0;
+    const uint64_t base = (uint64_t)blockIdx.x * DEC_BLK;
+    for (int k = 0; k < DEC_BLK / NT; k++) sum += dec_len(a, base + (uint64_t)k * NT + threadIdx.x);
+    sum = wave_scan_incl(sum);
+    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0;
+        for (int w = 0; w < NT / 64; w++) t += s_w[w];
+        a.blk[blockIdx.x] = t;
+    }
+}
+__global__ __launch_bounds__(1024) void k_decode_scan(uint64_t* blk, uint64_t n_blk) {
+    __shared__ uint64_t s_w[16];
+    __shared__ uint64_t s_carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (uint64_t base = 0; base < n_blk; base += 1024) {
+        const uint64_t i = base + tid;
+        const uint64_t v = i < n_blk ? blk[i] : 0ull;
+        uint64_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint64_t y = __shfl_up(x, d); if ((tid & 63) >= d) x += y; }
+        if ((tid & 63) == 63) s_w[tid >> 6] = x;
+        __syncthreads();
+        uint64_t pre = s_carry;
+        for (int w = 0; w < (tid >> 6); w++) pre += s_w[w];
+        if (i < n_blk) blk[i] = pre + x - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = pre + x;
+        __syncthreads();
+    }
+    if (tid == 0) blk[n_blk] = s_carry;
+}
+__global__ __launch_bounds__(NT) void k_decode_copy(DecodeArgs a) {
+    __shared__ uint32_t s_w[NT / 64];
+    const uint64_t base = (uint64_t)blockIdx.x * DEC_BLK;
+    uint64_t run = a.blk[blockIdx.x];
+    for (int k = 0; k < DEC_BLK / NT; k++) {
+        const uint64_t i = base + (uint64_t)k * NT + threadIdx.x;
+        const uint32_t len = dec_len(a, i);
+        const uint32_t x = wave_scan_incl(len);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = x;
+        __syncthreads();
+        uint64_t o = run + (x - len);
+        uint32_t all = 0;
+        for (int w = 0; w < NT / 64; w++) { if (w < (int)(threadIdx.x >> 6)) o += s_w[w]; all += s_w[w]; }
+        if (i < a.n_ids) {
+            a.id_off[i] = o;
+            const uint8_t* src = a.tok_bytes + a.tok_off[a.ids[i] <= a.max_id ? a.ids[i] : 0u];
+            for (uint32_t q = 0; q < len; q++) a.out[o + q] = src[q];
+        }
+        run += all;
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) a.id_off[a.n_ids] = run;
+}
+__global__ void k_decode_docs(DecodeArgs a) {
+    const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d > a.n_docs) return;
+    a.doc_off[d] = a.id_off[a.doc_first[d] - a.doc_first[0]];
+}
+
+// Host pipeline (spl_encode_batch): chunk-local output offsets -> offsets in the whole result.
+__global__ void k_add_base(uint64_t* p, uint64_t n, uint64_t base) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n_ids) return;
-    const uint32_t id = a.ids[i];
-    if (id > a.max_id) return;
-    const uint32_t s = a.tok_off[id], e = a.tok_off[id + 1];
-    uint8_t* o = a.out + a.len_or_off[i];
-    for (uint32_t k = s; k < e; k++) o[k - s] = a.tok_bytes[k];
+    if (i < n) p[i] += base;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -39,7 +39,9 @@ bool byte_level_to_raw(const std::string& key, const std::unordered_map<uint32_t
         uint32_t cp;
         size_t l;
         if (b < 0x80) { cp = b; l = 1; }
-        else if (b >= 0xC0 && b < 0xE0 && i + 1 < key.size()) { cp = ((b & 0x1Fu) << 6) | ((uint8_t)key[i + 1] & 0x3Fu); l = 2; }
+        else if (b >= 0xC2 && b < 0xE0 && i + 1 < key.size() && ((uint8_t)key[i + 1] & 0xC0u) == 0x80u) {
+            cp = ((b & 0x1Fu) << 6) | ((uint8_t)key[i + 1] & 0x3Fu); l = 2;
+        }
         else return false;                              // alphabet is U+0021..U+0143: at most 2 bytes
         auto it = byte_of_cp.find(cp);
         if (it == byte_of_cp.end()) return false;
@@ -64,7 +66,7 @@ uint32_t host_cp_class(const HostTables& t, uint32_t cp) {
 }
 
 int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size_t ucls_len, int pattern,
-                 HostTables& out, std::string& err) {
+                 bool force_byte_level, HostTables& out, std::string& err) {
     // ---- class table -------------------------------------------------------------------
     if (ucls_len < 32 || memcmp(ucls, "SPLU", 4) != 0 || rd32(ucls + 4) != 1) { err = "bad unicode class table"; return 1; }
     out.ucls_shift = rd32(ucls + 8);
@@ -83,12 +85,14 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
     out.pattern = pattern;
 
     // ---- vocabulary (reference src/core/vocab.rs:57-89: later duplicate wins) ---------------
-    if (splv_len < 20 || memcmp(splv, "SPLV", 4) != 0 || rd32(splv + 4) != 1) { err = "bad vocabulary container"; return 1; }
-    const uint32_t nrec = rd32(splv + 8);
-    out.byte_level = (rd32(splv + 12) & 1u) != 0;
     std::unordered_map<std::string, uint32_t> enc;
-    enc.reserve(nrec * 2);
-    {
+    uint32_t max_rank_seen = 0;
+    if (splv_len >= 4 && memcmp(splv, "SPLV", 4) == 0) {
+        // this repo's packed container (tools/pack_vocab.py); the ByteLevel flag travels inside
+        if (splv_len < 20 || rd32(splv + 4) != 1) { err = "bad vocabulary container"; return 1; }
+        const uint32_t nrec = rd32(splv + 8);
+        out.byte_level = (rd32(splv + 12) & 1u) != 0 || force_byte_level;
+        enc.reserve(nrec * 2);
         size_t off = 20;
         for (uint32_t i = 0; i < nrec; i++) {
             if (off + 6 > splv_len) { err = "truncated vocabulary container"; return 1; }
@@ -99,7 +103,78 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
             enc[std::string((const char*)splv + off, len)] = rank;
             off += len;
         }
+    } else {
+        // the reference's on-disk format: tiktoken text, one `base64(token bytes) rank` per line
+        // (load_tiktoken_bpe, src/core/vocab.rs:57-89: lines split at \n, empty lines skipped, the LAST
+        // space separates token and rank, the rank is trimmed and parsed as u32, a later duplicate
+        // key replaces the earlier one)
+        out.byte_level = force_byte_level;
+        static int8_t b64[256];
+        static bool b64_init = false;
+        if (!b64_init) {
+            for (int i = 0; i < 256; i++) b64[i] = -1;
+            const char* al = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+            for (int i = 0; i < 64; i++) b64[(uint8_t)al[i]] = (int8_t)i;
+            b64_init = true;
+        }
+        enc.reserve(splv_len / 12 + 16);
+        std::string key;
+        size_t ln = 1;
+        for (size_t a = 0; a < splv_len; ln++) {
+            size_t e = a;
+            while (e < splv_len && splv[e] != '\n') e++;
+            const uint8_t* line = splv + a;
+            const size_t n = e - a;
+            a = e + 1;
+            if (n == 0) continue;
+            size_t sp = n;
+            while (sp > 0 && line[sp - 1] != ' ') sp--;
+            if (sp == 0) { err = "Invalid line format: Missing space separator (line " + std::to_string(ln) + ")"; return 1; }
+            const size_t nb = sp - 1;                           // base64 text = line[0, nb)
+            // base64, standard alphabet, canonical padding (base64::engine::general_purpose::STANDARD)
+            key.clear();
+            if (nb % 4 != 0) { err = "Invalid base64 encoding (line " + std::to_string(ln) + ")"; return 1; }
+            for (size_t i = 0; i < nb; i += 4) {
+                int v[4], pad = 0;
+                for (int k = 0; k < 4; k++) {
+                    const uint8_t c = line[i + k];
+                    if (c == '=' && i + 4 == nb && k >= 2) { v[k] = 0; pad++; }
+                    else if (b64[c] < 0 || pad) { err = "Invalid base64 encoding (line " + std::to_string(ln) + ")"; return 1; }
+                    else v[k] = b64[c];
+                }
+                const uint32_t w = (uint32_t)v[0] << 18 | (uint32_t)v[1] << 12 | (uint32_t)v[2] << 6 | (uint32_t)v[3];
+                if ((pad == 1 && (v[2] & 3)) || (pad == 2 && (v[1] & 15))) {      // non-canonical trailing bits
+                    err = "Invalid base64 encoding (line " + std::to_string(ln) + ")"; return 1;
+                }
+                key.push_back((char)(w >> 16));
+                if (pad < 2) key.push_back((char)(w >> 8));
+                if (pad < 1) key.push_back((char)w);
+            }
+            // rank: str::trim + parse::<u32> (an optional leading '+', decimal digits, no overflow)
+            size_t r0 = sp, r1 = n;
+            auto is_ws = [](uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); };
+            while (r0 < r1 && is_ws(line[r0])) r0++;
+            while (r1 > r0 && is_ws(line[r1 - 1])) r1--;
+            if (r0 < r1 && line[r0] == '+') r0++;
+            uint64_t rank = 0;
+            bool ok = r0 < r1;
+            for (size_t i = r0; i < r1 && ok; i++) {
+                ok = line[i] >= '0' && line[i] <= '9';
+                rank = rank * 10 + (uint64_t)(line[i] - '0');
+                if (rank > 0xFFFFFFFFull) ok = false;
+            }
+            if (!ok) { err = "Invalid line format: Invalid rank: " + std::string((const char*)line + sp, n - sp); return 1; }
+            enc[key] = (uint32_t)rank;
+        }
     }
+    for (const auto& kv : enc) max_rank_seen = std::max(max_rank_seen, kv.second);   // vocab_size: max id of the map as loaded
+    enc.erase(std::string());          // an empty key can never match a chunk
+    // decoder side (build_decoder, src/core/vocab.rs:146-148, + Tokenizer::decode_bytes,
+    // src/core/tokenizer.rs:877-897): id -> the bytes decode_bytes emits for it.  ByteLevel: the key
+    // decoded to raw bytes, or the key itself where it is not ByteLevel text (byte_level.rs:125-146).
+    std::unordered_map<uint32_t, std::string> dec;
+    dec.reserve(enc.size() * 2);
+    if (!out.byte_level) for (const auto& kv : enc) dec[kv.second] = kv.first;
     if (out.byte_level) {
         // Re-key into raw-byte space.  Exact iff every alphabet char is a token and all of them
         // rank below every multi-char token (then the reference's merge loop completes all
@@ -113,7 +188,11 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
         uint32_t max_char_rank = 0, min_multi_rank = 0xFFFFFFFFu;
         std::string raw;
         for (const auto& kv : enc) {
-            if (!byte_level_to_raw(kv.first, byte_of_cp, raw)) continue;   // unreachable from encoded text
+            if (!byte_level_to_raw(kv.first, byte_of_cp, raw)) {           // unreachable from encoded text
+                dec[kv.second] = kv.first;
+                continue;
+            }
+            dec[kv.second] = raw;
             if (raw.empty()) continue;
             raw_enc[raw] = kv.second;
             if (raw.size() == 1) max_char_rank = std::max(max_char_rank, kv.second);
@@ -125,13 +204,10 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
         enc.swap(raw_enc);
     }
     if (enc.empty()) { err = "empty vocabulary"; return 1; }
-    out.max_id = 0;
+    out.max_id = max_rank_seen;
     out.max_key_len = 0;
-    for (const auto& kv : enc) {
-        if (kv.second > SPL_ID_MASK) { err = "token id does not fit 21 bits"; return 1; }
-        out.max_id = std::max(out.max_id, kv.second);
-        out.max_key_len = std::max<uint32_t>(out.max_key_len, (uint32_t)kv.first.size());
-    }
+    if (max_rank_seen > SPL_ID_MASK) { err = "token id does not fit 21 bits"; return 1; }
+    for (const auto& kv : enc) out.max_key_len = std::max<uint32_t>(out.max_key_len, (uint32_t)kv.first.size());
     out.n_keys = (uint32_t)enc.size();
     out.byte_id.assign(256, SPL_NO_RANK);
     out.all_bytes = true;
@@ -276,12 +352,13 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
 
     // ---- decoder CSR (id -> raw bytes) ---------------------------------------------------------
     std::vector<const std::string*> by_id(out.max_id + 1, nullptr);
-    for (const auto& kv : enc) by_id[kv.second] = &kv.first;   // duplicate ids: arbitrary, as build_decoder
+    for (const auto& kv : dec) by_id[kv.first] = &kv.second;   // (two keys with one id: arbitrary, as build_decoder)
     out.tok_off.assign(out.max_id + 2, 0);
+    out.tok_present.assign(out.max_id + 1, 0);
     out.tok_bytes.clear();
     for (uint32_t id = 0; id <= out.max_id; id++) {
         out.tok_off[id] = (uint32_t)out.tok_bytes.size();
-        if (by_id[id]) out.tok_bytes.insert(out.tok_bytes.end(), by_id[id]->begin(), by_id[id]->end());
+        if (by_id[id]) { out.tok_present[id] = 1; out.tok_bytes.insert(out.tok_bytes.end(), by_id[id]->begin(), by_id[id]->end()); }
     }
     out.tok_off[out.max_id + 1] = (uint32_t)out.tok_bytes.size();
     // a bucket with a free last slot in each of the two small-key tables (load factors are below 0.4)

@@ -39,11 +39,14 @@ struct HostTables {
     // decoder side: id -> raw bytes (CSR); ids with no entry have empty spans
     std::vector<uint32_t> tok_off;      // max_id + 2
     std::vector<uint8_t> tok_bytes;
+    std::vector<uint8_t> tok_present;   // max_id + 1: the id is a key of the decoder map
 };
 
 // Returns 0 on success; on failure fills err.
-int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size_t ucls_len, int pattern,
-                 HostTables& out, std::string& err);
+// `vocab` is either this repo's SPLV container or the reference's tiktoken text (autodetected by the
+// magic); force_byte_level = the reference's from_bytes_byte_level (tokenizer.rs:562-569).
+int build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* ucls, size_t ucls_len, int pattern,
+                 bool force_byte_level, HostTables& out, std::string& err);
 
 // Host mirror of the device two-stage lookup (used by build checks and tests/hostsim).
 uint32_t host_cp_class(const HostTables& t, uint32_t cp);

@@ -59,11 +59,18 @@ class GatherV:
     Every batch is packed into a slab right after its encode (HIP kernel, same stream).  `depth`
     consecutive slabs form one bucket; a full bucket is handed to an exchange stream of its own:
     ONE all_gather_into_tensor of world x depth equal slabs (RCCL over xGMI) and ONE unpack launch
-    that rebuilds the global CSR of each of the bucket's batches on every rank.  Two bucket sets
-    alternate, so the exchange of one bucket overlaps the encodes of the next and no cross-stream
-    wait sits between two encodes.  Fewer, larger collectives on purpose: xGMI rings are per-link
-    bound and a collective costs tens of microseconds of launch work, as much as encoding a whole
-    1 MB batch.  `finish()` flushes a partial bucket and drains.  No host synchronisation per batch.
+    that rebuilds the global CSR of each of the bucket's batches on every rank.  Two bucket SETS
+    alternate -- each with its own send, receive and result buffers -- so the exchange of one bucket
+    overlaps the encodes of the next and no cross-stream wait sits between two encodes.  Fewer,
+    larger collectives on purpose: xGMI rings are per-link bound and a collective costs tens of
+    microseconds of launch work, as much as encoding a whole 1 MB batch.
+
+    Results: `on_bucket(results)` -- if set -- is called for every exchanged bucket with a list of
+    (ids, off) views, one per batch in submission order (ids int32, the first off[-1] entries valid;
+    off int64[world * max_docs + 1], entries past the global document count unspecified).  It runs
+    with the exchange stream current: whatever it enqueues is ordered behind the unpack, and the
+    set's buffers are reused only after that work.  `finish()` flushes a partial bucket, drains,
+    and returns the views of the LAST submitted batch.  No host synchronisation per batch.
     """
 
     def __init__(self, tok: Tokenizer, device: torch.device, max_docs: int, max_tokens: int, group=None, depth: int = 8):
@@ -74,76 +81,105 @@ class GatherV:
         self.max_docs = int(max_docs)
         self.max_tokens = int(max_tokens)
         self.cap_words = self.max_tokens + self.max_docs + 4
+        if self.cap_words >= 1 << 32:
+            raise ValueError("GatherV: a slab must stay below 2**32 words")
         self.off_stride = self.world * self.max_docs + 1
-        self.send = [torch.zeros(self.depth * self.cap_words, dtype=torch.int32, device=device) for _ in range(2)]
-        self.recv = [torch.zeros(self.world * self.depth * self.cap_words, dtype=torch.int32, device=device)
-                     for _ in range(2)]
-        # global CSR of each batch of the last exchanged bucket
-        self.all_ids = torch.zeros(self.depth * self.world * self.max_tokens, dtype=torch.int32, device=device)
-        self.all_off = torch.zeros(self.depth * self.off_stride, dtype=torch.int64, device=device)
-        self.status = torch.zeros(1, dtype=torch.int32, device=device)
-        self.exch = torch.cuda.Stream(device=device)
-        self.packed = [torch.cuda.Event() for _ in range(2)]      # the bucket in set s is fully packed
-        self.drained = [torch.cuda.Event() for _ in range(2)]     # the exchange of the bucket in set s is through
+        self.ids_stride = self.world * self.max_tokens
+        kw = dict(device=device)
+        self.send = [torch.zeros(self.depth * self.cap_words, dtype=torch.int32, **kw) for _ in range(2)]
+        self.recv = [torch.zeros(self.world * self.depth * self.cap_words, dtype=torch.int32, **kw) for _ in range(2)]
+        # global CSR of each batch of the set's last exchanged bucket
+        self.all_ids = [torch.zeros(self.depth * self.ids_stride, dtype=torch.int32, **kw) for _ in range(2)]
+        self.all_off = [torch.zeros(self.depth * self.off_stride, dtype=torch.int64, **kw) for _ in range(2)]
+        self.status = torch.zeros(1, dtype=torch.int32, **kw)
+        self.exch = self._new_stream()
+        self.packed = [self._new_event() for _ in range(2)]       # the bucket in set s is fully packed
+        self.drained = [self._new_event() for _ in range(2)]      # the exchange of the bucket in set s is through
         self.in_flight = [False, False]
         self.cur, self.fill = 0, 0
-        self.last_n = 0
+        self.last = None                                          # (set, batches) of the last exchanged bucket
+        self.on_bucket = None
+
+    # (overridable: the CPU test drives the bucket / event logic with a stub encoder on gloo)
+    def _new_stream(self):
+        return torch.cuda.Stream(device=self.dev)
+
+    def _new_event(self):
+        return torch.cuda.Event()
+
+    def _main_stream(self):
+        return torch.cuda.current_stream(self.dev)
+
+    def _stream_ctx(self, st):
+        return torch.cuda.stream(st)
 
     def _open_slab(self) -> torch.Tensor:
-        main = torch.cuda.current_stream(self.dev)
+        main = self._main_stream()
         s = self.cur
         if self.fill == 0 and self.in_flight[s]:
             main.wait_event(self.drained[s])      # the set's previous exchange: normally long through
             self.in_flight[s] = False
-        return self.send[s][self.fill * self.cap_words:]
+        return self.send[s][self.fill * self.cap_words:(self.fill + 1) * self.cap_words]
 
     def _close_slab(self) -> None:
         self.fill += 1
         if self.fill == self.depth:
             self._exchange()
 
+    def _pack(self, batch, slab, stream_ptr) -> None:
+        rc = _ffi.lib().spl_gatherv_pack(self.tok.handle, batch.ids.data_ptr(), batch.out_off.data_ptr(), batch.n_docs,
+                                         slab.data_ptr(), self.cap_words, self.max_docs, stream_ptr)
+        if rc != 0:
+            raise RuntimeError(_ffi.last_error())
+
+    def _encode_packed(self, batch, slab, with_special, stream_ptr) -> None:
+        rc = _ffi.lib().spl_encode_batch_device_packed(
+            self.tok.handle, batch.text.data_ptr(), batch.n_bytes, batch.doc_off.data_ptr(), batch.n_docs,
+            _ffi.SPL_WITH_SPECIAL if with_special else 0, batch.ids.data_ptr(), batch.ids.numel(),
+            batch.out_off.data_ptr(), slab.data_ptr(), self.cap_words, self.max_docs, stream_ptr)
+        if rc != 0:
+            raise RuntimeError(f"spl_encode_batch_device_packed failed ({rc}): {_ffi.last_error()}")
+
+    def _unpack(self, s, n, stream_ptr) -> None:
+        rc = _ffi.lib().spl_gatherv_unpack_group(self.tok.handle, self.recv[s].data_ptr(), self.world, self.depth, n,
+                                                 self.cap_words, self.max_docs, self.all_ids[s].data_ptr(),
+                                                 self.ids_stride, self.all_off[s].data_ptr(), self.off_stride,
+                                                 self.status.data_ptr(), stream_ptr)
+        if rc != 0:
+            raise RuntimeError(_ffi.last_error())
+
     def submit(self, batch: "DeviceBatch") -> None:
         """Pack `batch`'s current result into the open bucket (call right after encode_device on the
         same stream); a full bucket goes out."""
         slab = self._open_slab()
-        main = torch.cuda.current_stream(self.dev)
-        rc = _ffi.lib().spl_gatherv_pack(self.tok.handle, batch.ids.data_ptr(), batch.out_off.data_ptr(), batch.n_docs,
-                                         slab.data_ptr(), self.cap_words, self.max_docs, main.cuda_stream)
-        if rc != 0:
-            raise RuntimeError(_ffi.last_error())
+        self._pack(batch, slab, self._main_stream().cuda_stream)
         self._close_slab()
 
     def encode_and_submit(self, batch: "DeviceBatch", with_special: bool = False) -> None:
         """encode_device + submit in ONE call: the encoder's last kernel writes the slab itself
         (spl_encode_batch_device_packed), no separate pack launch."""
         slab = self._open_slab()
-        main = torch.cuda.current_stream(self.dev)
-        rc = _ffi.lib().spl_encode_batch_device_packed(
-            self.tok.handle, batch.text.data_ptr(), batch.n_bytes, batch.doc_off.data_ptr(), batch.n_docs,
-            _ffi.SPL_WITH_SPECIAL if with_special else 0, batch.ids.data_ptr(), batch.ids.numel(),
-            batch.out_off.data_ptr(), slab.data_ptr(), self.cap_words, self.max_docs, main.cuda_stream)
-        if rc != 0:
-            raise RuntimeError(f"spl_encode_batch_device_packed failed ({rc}): {_ffi.last_error()}")
+        self._encode_packed(batch, slab, with_special, self._main_stream().cuda_stream)
         self._close_slab()
 
+    def _views(self, s, j):
+        return (self.all_ids[s][j * self.ids_stride:(j + 1) * self.ids_stride],
+                self.all_off[s][j * self.off_stride:(j + 1) * self.off_stride])
+
     def _exchange(self) -> None:
-        L = _ffi.lib()
-        main = torch.cuda.current_stream(self.dev)
+        main = self._main_stream()
         s, n = self.cur, self.fill
         self.packed[s].record(main)
-        with torch.cuda.stream(self.exch):
+        with self._stream_ctx(self.exch):
             self.exch.wait_event(self.packed[s])
             work = self.dist.all_gather_into_tensor(self.recv[s], self.send[s], group=self.group, async_op=True)
-            work.wait()                       # the exchange stream (not the encode stream) waits for RCCL
-            rc = L.spl_gatherv_unpack_group(self.tok.handle, self.recv[s].data_ptr(), self.world, self.depth, n,
-                                            self.cap_words, self.max_docs, self.all_ids.data_ptr(),
-                                            self.world * self.max_tokens, self.all_off.data_ptr(), self.off_stride,
-                                            self.status.data_ptr(), self.exch.cuda_stream)
-            if rc != 0:
-                raise RuntimeError(_ffi.last_error())
+            work.wait()                       # the exchange stream (not the encode stream) waits for the collective
+            self._unpack(s, n, self.exch.cuda_stream)
+            if self.on_bucket is not None:
+                self.on_bucket([self._views(s, j) for j in range(n)])
             self.drained[s].record(self.exch)
         self.in_flight[s] = True
-        self.last_n = n
+        self.last = (s, n)
         self.cur ^= 1
         self.fill = 0
 
@@ -152,15 +188,15 @@ class GatherV:
         first all_off[-1] entries are valid) and int64 offsets [world * max_docs + 1]."""
         if self.fill:
             self._exchange()
-        main = torch.cuda.current_stream(self.dev)
+        main = self._main_stream()
         for s in (0, 1):
             if self.in_flight[s]:
                 main.wait_event(self.drained[s])
                 self.in_flight[s] = False
-        j = max(self.last_n - 1, 0)
-        ids = self.all_ids[j * self.world * self.max_tokens:(j + 1) * self.world * self.max_tokens]
-        off = self.all_off[j * self.off_stride:(j + 1) * self.off_stride]
-        return ids, off
+        if self.last is None:
+            return self._views(0, 0)
+        s, n = self.last
+        return self._views(s, max(n - 1, 0))
 
     def overflowed(self) -> bool:
         return bool(self.status.item())

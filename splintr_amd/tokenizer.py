@@ -30,9 +30,15 @@ O200K_BASE_PATTERN = (
     r"|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+"
 )
 LLAMA3_PATTERN = O200K_BASE_PATTERN
-_PATTERN_ID = {CL100K_BASE_PATTERN: 0, O200K_BASE_PATTERN: 1}
+MISTRAL_V3_PATTERN = (
+    r"[^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]*[\p{Ll}\p{Lm}\p{Lo}\p{M}]+"
+    r"|[^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]+[\p{Ll}\p{Lm}\p{Lo}\p{M}]*"
+    r"|\p{N}| ?[^\s\p{L}\p{N}]+[\r\n/]*|\s*[\r\n]+|\s+(?!\S)|\s+"
+)
+# The scanner implements exactly these patterns (there is no regex engine on the GPU).
+_PATTERN_ID = {CL100K_BASE_PATTERN: 0, O200K_BASE_PATTERN: 1, MISTRAL_V3_PATTERN: 2}
 
-# name -> (vocab container, pattern, special-token table key)      src/python/bindings.rs:101-129
+# name -> (vocab container, pattern, special-token table key)      src/python/bindings.rs:101-160
 _PRETRAINED = {
     "cl100k_base": ("cl100k_base.splv", CL100K_BASE_PATTERN, "cl100k_base"),
     "o200k_base": ("o200k_base.splv", O200K_BASE_PATTERN, "o200k_base"),
@@ -42,6 +48,7 @@ _PRETRAINED = {
     "llama3.3": ("llama3.splv", LLAMA3_PATTERN, "llama3"),
     "deepseek_v3": ("deepseek_v3.splv", LLAMA3_PATTERN, "deepseek_v3"),
     "deepseek-v3": ("deepseek_v3.splv", LLAMA3_PATTERN, "deepseek_v3"),
+    "mistral_v3": ("mistral_v3.splv", MISTRAL_V3_PATTERN, "mistral_v3"),
 }
 
 
@@ -51,8 +58,9 @@ def _read(path: str) -> bytes:
 
 
 def _pack(texts: Sequence[str]):
-    """list[str] -> (uint8 buffer, uint64 offsets).  TypeError for anything that is not a
-    sequence of str (PyO3 refuses a bare str for Vec<String>; src/python/bindings.rs:337)."""
+    """list[str] -> (uint8 buffer, uint64 offsets), plain Python (DeviceBatch, tests).  TypeError for
+    anything that is not a sequence of str (PyO3 refuses a bare str for Vec<String>;
+    src/python/bindings.rs:337)."""
     if isinstance(texts, (str, bytes)):
         raise TypeError("Can't extract `str` to `Vec`")
     parts = []
@@ -68,24 +76,37 @@ def _pack(texts: Sequence[str]):
 
 
 class Tokenizer:
-    """Drop-in for `splintr.Tokenizer` on the encode path (MI355X backend)."""
+    """The reference's `splintr.Tokenizer` surface on the MI355X backend: same constructor
+    arguments (a tiktoken-format vocabulary file, a pattern, a special-token map), same methods.
+
+    Differences from the reference, all refused loudly rather than approximated:
+    * `pattern` must be one of CL100K_BASE_PATTERN, O200K_BASE_PATTERN (= LLAMA3_PATTERN) or
+      MISTRAL_V3_PATTERN -- the GPU scanner implements these, there is no regex engine;
+    * the vocabulary must contain all 256 single bytes and ids below 2**21;
+    * special-token literals are at most 32 bytes and must not be able to overlap each other
+      (all pretrained tables qualify).
+    Extensions: `device=` / `devices=` select the GPU(s), `byte_level=True` is the reference's
+    `from_bytes_byte_level`; the vocabulary may also be this repo's packed SPLV container.
+    """
 
     def __init__(self, vocab_path: str, pattern: str, special_tokens: Optional[Dict[str, int]] = None, *,
-                 device: int = 0):
+                 device: int = 0, byte_level: bool = False):
+        # src/python/bindings.rs:70-83: every failure of from_file surfaces as IOError
         try:
             blob = _read(vocab_path)
-        except OSError as e:                      # PyIOError in the reference (bindings.rs:80)
+            self._init_from_blob(blob, pattern, special_tokens or {}, device, byte_level)
+        except (OSError, ValueError) as e:
             raise IOError(str(e)) from None
-        self._init_from_blob(blob, pattern, special_tokens or {}, device)
 
     # ------------------------------------------------------------------ construction
-    def _init_from_blob(self, blob: bytes, pattern: str, special_tokens: Dict[str, int], device: int):
+    def _init_from_blob(self, blob: bytes, pattern: str, special_tokens: Dict[str, int], device: int,
+                        byte_level: bool = False):
         if pattern not in _PATTERN_ID:
-            raise ValueError("Regex compilation error: the HIP backend implements CL100K_BASE_PATTERN and "
-                             "O200K_BASE_PATTERN/LLAMA3_PATTERN only")
+            raise ValueError("Regex error: the HIP backend implements CL100K_BASE_PATTERN, O200K_BASE_PATTERN / "
+                             "LLAMA3_PATTERN and MISTRAL_V3_PATTERN only (no regex engine on the GPU)")
         L = _ffi.lib()
         ucls = _read(os.path.join(_DATA, "unicode_classes.bin"))
-        opts = _ffi.SplOpts(_PATTERN_ID[pattern], device)
+        opts = _ffi.SplOpts(_PATTERN_ID[pattern], device, _ffi.SPL_OPT_BYTE_LEVEL if byte_level else 0)
         self._h = L.spl_create(blob, len(blob), ucls, len(ucls), ctypes.byref(opts))
         if not self._h:
             raise ValueError(_ffi.last_error())
@@ -98,9 +119,10 @@ class Tokenizer:
                 raise ValueError(_ffi.last_error())
 
     @classmethod
-    def _from_blob(cls, blob: bytes, pattern: str, special_tokens: Dict[str, int], device: int = 0) -> "Tokenizer":
+    def _from_blob(cls, blob: bytes, pattern: str, special_tokens: Dict[str, int], device: int = 0,
+                   byte_level: bool = False) -> "Tokenizer":
         self = cls.__new__(cls)
-        self._init_from_blob(blob, pattern, special_tokens, device)
+        self._init_from_blob(blob, pattern, special_tokens, device, byte_level)
         return self
 
     @staticmethod
@@ -121,9 +143,24 @@ class Tokenizer:
     @staticmethod
     def from_bytes(vocab_data: bytes, pattern: str, special_tokens: Optional[Dict[str, int]] = None,
                    device: int = 0) -> "Tokenizer":
-        """src/python/bindings.rs:174-187.  `vocab_data` is this repo's SPLV container
-        (tools/pack_vocab.py); the tiktoken text format is a "next" row."""
+        """src/python/bindings.rs:174-187: `vocab_data` is tiktoken text (`base64 rank` lines), as in
+        the reference; this repo's SPLV container is accepted as well."""
         return Tokenizer._from_blob(bytes(vocab_data), pattern, special_tokens or {}, device)
+
+    @staticmethod
+    def from_bytes_byte_level(vocab_data: bytes, pattern: str, special_tokens: Optional[Dict[str, int]] = None,
+                              device: int = 0) -> "Tokenizer":
+        """src/core/tokenizer.rs:562-569 (not exposed by the reference's Python class; used by its
+        from_pretrained for deepseek_v3 and mistral_v3)."""
+        return Tokenizer._from_blob(bytes(vocab_data), pattern, special_tokens or {}, device, True)
+
+    def set_devices(self, devices: Sequence[int]) -> "Tokenizer":
+        """Extension: spread `encode_batch` over several GPUs from this one process
+        (spl_set_devices: documents sharded by bytes, one pinned CSR result)."""
+        arr = (ctypes.c_int32 * len(devices))(*[int(d) for d in devices])
+        if _ffi.lib().spl_set_devices(self._h, arr, len(devices)) != 0:
+            raise ValueError(_ffi.last_error())
+        return self
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -135,12 +172,12 @@ class Tokenizer:
             self._h = None
 
     # ------------------------------------------------------------------ encode path
-    def _encode_packed(self, buf: bytes, off: np.ndarray, flags: int):
-        """C-ABI call: packed UTF-8 + offsets in, CSR (ids uint32, offsets uint64) out."""
+    def _encode_packed(self, buf, off, nd: int, flags: int):
+        """C-ABI call: packed UTF-8 + offsets in (objects or addresses), CSR (ids uint32, offsets
+        uint64) out as numpy arrays."""
         L = _ffi.lib()
         res = ctypes.c_void_p()
-        nd = len(off) - 1
-        rc = L.spl_encode_batch(self._h, buf, off.ctypes.data, nd, flags, ctypes.byref(res))
+        rc = L.spl_encode_batch(self._h, buf, off, nd, flags, ctypes.byref(res))
         if rc != 0:
             raise RuntimeError(f"spl_encode_batch failed ({rc}): {_ffi.last_error()}")
         try:
@@ -152,19 +189,20 @@ class Tokenizer:
             L.spl_result_free(res)
         return ids, oo
 
+    def encode_packed(self, utf8: bytes, offsets: np.ndarray, with_special: bool = False):
+        """Extension: the C-ABI call on an already packed corpus (bytes + uint64 offsets[N+1])."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        return self._encode_packed(utf8, offsets.ctypes.data, len(offsets) - 1,
+                                   _ffi.SPL_WITH_SPECIAL if with_special else 0)
+
     def encode_batch_csr(self, texts: Sequence[str], with_special: bool = False):
         """Extension: the batch result as CSR numpy arrays (ids uint32[T], offsets uint64[N+1])
         without materialising Python lists."""
-        buf, off = _pack(texts)
-        return self._encode_packed(buf, off, _ffi.SPL_WITH_SPECIAL if with_special else 0)
+        addr, _n_bytes, off_addr, nd = _ffi.shim().pack(texts)      # pinned staging, valid until the next pack
+        return self._encode_packed(addr, off_addr, nd, _ffi.SPL_WITH_SPECIAL if with_special else 0)
 
     def _encode_one(self, text: str, flags: int) -> List[int]:
-        if not isinstance(text, str):
-            raise TypeError(f"argument 'text': '{type(text).__name__}' object cannot be converted to 'PyString'")
-        buf = text.encode("utf-8")
-        off = np.array([0, len(buf)], dtype=np.uint64)
-        ids, _ = self._encode_packed(buf, off, flags)
-        return ids.tolist()
+        return _ffi.shim().encode(self._h, text, flags)
 
     def encode(self, text: str) -> List[int]:
         """src/python/bindings.rs:254-256."""
@@ -180,11 +218,8 @@ class Tokenizer:
         return self._encode_one(text, _ffi.SPL_WITH_SPECIAL)
 
     def _batch(self, texts: Sequence[str], flags: int) -> List[List[int]]:
-        buf, off = _pack(texts)
-        ids, oo = self._encode_packed(buf, off, flags)
-        flat = ids.tolist()
-        o = oo.tolist()
-        return [flat[o[i]:o[i + 1]] for i in range(len(o) - 1)]
+        # ONE C call: UTF-8 straight into pinned staging, spl_encode_batch, lists from the pinned CSR
+        return _ffi.shim().encode_batch(self._h, texts, flags)
 
     def encode_batch(self, texts: Sequence[str]) -> List[List[int]]:
         """src/python/bindings.rs:337-339."""

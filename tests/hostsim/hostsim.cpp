@@ -72,7 +72,7 @@ void* hs_create(const char* splv, const char* ucls, int pattern, char* errbuf, i
     Sim* s = new Sim();
     auto v = slurp(splv), u = slurp(ucls);
     std::string err;
-    if (build_tables(v.data(), v.size(), u.data(), u.size(), pattern, s->ht, err)) {
+    if (build_tables(v.data(), v.size(), u.data(), u.size(), pattern, false, s->ht, err)) {
         snprintf(errbuf, errlen, "%s", err.c_str());
         delete s;
         return nullptr;

@@ -1,0 +1,144 @@
+"""GPU tests (-m gpu) of the host entry point a user calls -- spl_encode_batch behind
+Tokenizer.encode_batch (reference src/python/bindings.rs:337-339): the chunked pinned pipeline,
+several pipelines at once (spl_set_devices, here all on GPU 0), sub-document cuts, the result
+buffer's growth path, pinned and pageable input.  Every result bit-exact against the oracle."""
+import ctypes
+import random
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import oracle_csr
+
+pytestmark = pytest.mark.gpu
+
+
+def fresh(name, **opts):
+    from splintr_amd import Tokenizer, _ffi
+    t = Tokenizer.from_pretrained(name)
+    for k, v in opts.items():
+        assert _ffi.lib().spl_set_option(t.handle, k.encode(), int(v)) == 0, _ffi.last_error()
+    return t
+
+
+def check(t, name, texts, coracle, special=False):
+    ids, off = t.encode_batch_csr(texts, with_special=special)
+    o_ids, o_off = oracle_csr(coracle(name), texts, special)
+    assert np.array_equal(off, o_off), name
+    assert np.array_equal(ids, o_ids), name
+    return ids, off
+
+
+def mixed_docs(seed, n, lo=0, hi=3000):
+    from splintr_amd import corpus
+    rng = random.Random(seed)
+    base = corpus.c3(64, seed=seed)
+    out = []
+    for i in range(n):
+        d = base[i % len(base)]
+        k = rng.randint(lo, hi)
+        out.append(d[:k] if rng.random() < 0.8 else "")
+    return out
+
+
+@pytest.mark.parametrize("name", ["cl100k_base", "o200k_base", "deepseek_v3"])
+@pytest.mark.parametrize("chunk", [1 << 12, 1 << 16, 1 << 20])
+def test_chunked_pipeline_equals_oracle(coracle, name, chunk):
+    """Tiny chunks force every batch through the multi-chunk path (producer thread, three slots,
+    per-chunk placement) including chunks of empty documents and documents larger than a chunk."""
+    t = fresh(name, chunk_bytes=chunk)
+    texts = mixed_docs(7 + chunk, 700) + ["", "", "x" * 70000, ""]
+    check(t, name, texts, coracle)
+    check(t, name, [""] * 50, coracle)
+    check(t, name, [], coracle)
+    check(t, name, ["only one"], coracle)
+
+
+def test_result_buffer_growth(coracle):
+    """A far too small first guess of the token count: the result moves to a larger pinned buffer
+    in both the single-chunk and the multi-chunk path (digits: one token per 1..3 bytes)."""
+    texts = ["7 8 9 1 2 3 4 5 6 " * 400 for _ in range(200)]
+    check(fresh("cl100k_base", result_estimate_div=64), "cl100k_base", texts, coracle)
+    check(fresh("cl100k_base", result_estimate_div=64, chunk_bytes=1 << 16), "cl100k_base", texts, coracle)
+
+
+@pytest.mark.parametrize("ndev", [2, 3, 8])
+def test_several_pipelines_one_result(coracle, ndev):
+    """spl_set_devices with GPU 0 listed several times: independent contexts (tables, workspace,
+    streams) shard the batch by bytes and place their parts into one pinned CSR."""
+    from splintr_amd import corpus
+    t = fresh("o200k_base", chunk_bytes=1 << 20).set_devices([0] * ndev)
+    texts = corpus.c3(3000, seed=99)                    # ~12 MB: every lane gets >= 1 MiB
+    check(t, "o200k_base", texts, coracle)
+    check(t, "o200k_base", texts[:3], coracle)          # too small to shard: one lane
+    check(t, "o200k_base", texts, coracle, special=True)
+
+
+def test_sub_document_cuts(coracle):
+    """Two huge documents over four pipelines: lanes are cut INSIDE a document, behind a newline that
+    is followed by a letter or digit (a context-free match boundary); ids and offsets as the oracle's."""
+    from splintr_amd import corpus, _ffi
+    docs = corpus.c5(2, seed=5, doc_bytes=5 << 20)
+    t = fresh("deepseek_v3").set_devices([0, 0, 0, 0])
+    ids, off = check(t, "deepseek_v3", docs, coracle)
+    assert len(off) == 3
+    # the same with the cuts switched off (whole documents per lane): same result
+    assert _ffi.lib().spl_set_option(t.handle, b"subdoc_split", 0) == 0
+    ids2, off2 = t.encode_batch_csr(docs)
+    assert np.array_equal(ids, ids2) and np.array_equal(off, off2)
+    # a document without any cut point (no newline) stays whole
+    t2 = fresh("cl100k_base").set_devices([0, 0])
+    check(t2, "cl100k_base", ["word " * (600 << 10), "b " * (1 << 20)], coracle)
+
+
+def test_pinned_and_pageable_input_and_result_lifetime(coracle):
+    from splintr_amd import Tokenizer, corpus, _ffi
+    L = _ffi.lib()
+    texts = corpus.c2(300, seed=3)
+    bs = [x.encode() for x in texts]
+    off = np.zeros(len(bs) + 1, dtype=np.uint64)
+    np.cumsum([len(b) for b in bs], out=off[1:])
+    blob = b"".join(bs)
+    t = Tokenizer.from_pretrained("cl100k_base")
+    want_ids, want_off = oracle_csr(coracle("cl100k_base"), texts)
+    ids, oo = t.encode_packed(blob, off)                               # pageable input
+    assert np.array_equal(ids, want_ids) and np.array_equal(oo, want_off)
+    p = L.spl_host_alloc(len(blob) + 64)
+    assert p
+    ctypes.memmove(p, blob, len(blob))
+    ids, oo = t._encode_packed(p, off.ctypes.data, len(bs), 0)        # pinned input: DMA straight from it
+    assert np.array_equal(ids, want_ids) and np.array_equal(oo, want_off)
+    # two results alive at once, one of them outliving the handle
+    r1, r2 = ctypes.c_void_p(), ctypes.c_void_p()
+    assert L.spl_encode_batch(t.handle, p, off.ctypes.data, len(bs), 0, ctypes.byref(r1)) == 0
+    assert L.spl_encode_batch(t.handle, blob, off.ctypes.data, len(bs), 0, ctypes.byref(r2)) == 0
+    del t
+    import gc
+    gc.collect()
+    for r in (r1, r2):
+        n = L.spl_result_n_tokens(r)
+        assert np.array_equal(np.ctypeslib.as_array(L.spl_result_tokens(r), shape=(n,)), want_ids)
+        L.spl_result_free(r)
+    L.spl_host_free(p)
+
+
+def test_python_surface_types_and_errors():
+    from splintr_amd import Tokenizer
+    t = Tokenizer.from_pretrained("cl100k_base")
+    assert t.encode_batch(["Hello, world!", "", "你好世界"]) == [[9906, 11, 1917, 0], [], [57668, 53901, 3574, 244, 98220]]
+    assert t.encode_batch(("Hello world",)) == [[9906, 1917]]
+    assert t.encode_batch([]) == []
+    out = t.encode_batch(["a"] * 3)
+    assert all(type(x) is int for l in out for x in l)
+    with pytest.raises(TypeError):
+        t.encode_batch("a bare string")
+    with pytest.raises(TypeError):
+        t.encode_batch([b"bytes"])
+    with pytest.raises(TypeError):
+        t.encode(5)
+    with pytest.raises(UnicodeEncodeError):
+        t.encode_batch(["ok", "\ud800"])
+    # latin-1, UCS-2 and UCS-4 strings take three different packing paths
+    for s in ["café naïve", "你好，世界", "Hello \U0001F30D World!", "é你\U0001F30D" * 50]:
+        assert t.encode_batch([s, s])[1] == t.encode(s)
+        assert t.decode(t.encode(s)) == s

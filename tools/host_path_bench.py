@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""The three throughputs of SURVEY 8d for one config: kernels only (corpus resident in HBM),
+C ABI host -> host (spl_encode_batch on pinned and on pageable input), and the Python surface
+(Tokenizer.encode_batch: list[str] -> list[list[int]]).  Imported by bench.py; runnable alone:
+    python tools/host_path_bench.py [c2|c3|c4|c5] [docs]
+"""
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+CONFIGS = {
+    "c2": ("cl100k_base", "c2", 1000),
+    "c3": ("o200k_base", "c3", 10000),
+    "c4": ("llama3", "c4", 250000),
+    "c5": ("deepseek_v3", "c5", 25),
+}
+
+
+def timed(fn, min_s=0.4, min_reps=3):
+    fn()
+    reps, t0 = 0, time.perf_counter()
+    while reps < min_reps or time.perf_counter() - t0 < min_s:
+        fn()
+        reps += 1
+    return (time.perf_counter() - t0) / reps
+
+
+def measure(cfg: str, docs=None, python_surface=True, devices=None):
+    import torch
+    from splintr_amd import Tokenizer, corpus, _ffi
+    from splintr_amd.device import DeviceBatch, encode_device, reserve
+    vocab, gen, n_def = CONFIGS[cfg]
+    n = docs or n_def
+    texts = getattr(corpus, gen)(n)
+    tok = Tokenizer.from_pretrained(vocab)
+    if devices:
+        tok.set_devices(devices)
+    L = _ffi.lib()
+    bs = [t.encode("utf-8") for t in texts]
+    off = np.zeros(len(bs) + 1, dtype=np.uint64)
+    np.cumsum([len(b) for b in bs], out=off[1:])
+    blob = b"".join(bs)
+    nb = len(blob)
+    out = {"config": cfg, "vocab": vocab, "docs": n, "bytes": nb, "unit": "MB/s"}
+
+    # (1) kernels only
+    dev = torch.device("cuda", 0)
+    batch = DeviceBatch(texts, dev)
+    reserve(tok, batch.n_bytes, batch.n_docs)
+
+    def k():
+        encode_device(tok, batch)
+        torch.cuda.synchronize()
+    out["kernel_hbm"] = round(nb / timed(k) / 1e6, 1)
+    out["tokens"] = int(batch.out_off[-1].item())
+    del batch
+
+    # (2) C ABI, host bytes -> host CSR
+    def c_abi(ptr):
+        def f():
+            r = ctypes.c_void_p()
+            rc = L.spl_encode_batch(tok.handle, ptr, off.ctypes.data, len(bs), 0, ctypes.byref(r))
+            assert rc == 0, _ffi.last_error()
+            L.spl_result_free(r)
+        return f
+    out["c_abi_host_pageable"] = round(nb / timed(c_abi(blob)) / 1e6, 1)
+    p = L.spl_host_alloc(nb + 64)
+    ctypes.memmove(p, blob, nb)
+    out["c_abi_host"] = round(nb / timed(c_abi(p)) / 1e6, 1)
+    L.spl_host_free(p)
+
+    # (3) Python surface
+    if python_surface:
+        got = tok.encode_batch(texts)
+        assert sum(map(len, got)) == out["tokens"]
+        del got
+        out["python_surface"] = round(nb / timed(lambda: tok.encode_batch(texts), min_s=1.0) / 1e6, 1)
+    return out
+
+
+if __name__ == "__main__":
+    cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
+    docs = int(sys.argv[2]) if len(sys.argv) > 2 else None
+    print(json.dumps(measure(cfg, docs)))
