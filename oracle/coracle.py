@@ -19,6 +19,7 @@ _REG = {
     "o200k_base": ("o200k_base.splv", 1, 0, "o200k_base"),
     "llama3": ("llama3.splv", 1, 0, "llama3"),
     "deepseek_v3": ("deepseek_v3.splv", 1, 1, "deepseek_v3"),
+    "mistral_v3": ("mistral_v3.splv", 2, 1, "mistral_v3"),
 }
 
 

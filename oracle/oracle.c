@@ -99,7 +99,7 @@ static inline size_t u8_prev(const uint8_t *s, size_t pos) { /* start of the cha
 
 /* ---------------------------------------------------------------- mini regex */
 enum { IT_SET, IT_CONTR, IT_NOT_NONSPACE_AHEAD };
-typedef struct { int kind; uint32_t mask; int min, max; /* max<0: unbounded */ } item_t;
+typedef struct { int kind; uint32_t mask; int min, max; /* max<0: unbounded */ uint32_t lit; /* extra code point in the set, 0: none */ } item_t;
 typedef struct { int nitems; item_t it[6]; } alt_t;
 typedef struct { int nalts; alt_t alt[8]; } pattern_t;
 
@@ -159,8 +159,9 @@ static size_t match_items(const subj_t *S, const alt_t *A, int i, size_t pos) {
     size_t p = pos;
     while ((it->max < 0 || cnt < it->max) && p < S->n) {
         size_t l;
-        int c = uclass_of(S->u, u8_decode(S->s, S->n, p, &l));
-        if (!(BIT(c) & it->mask)) break;
+        uint32_t cp = u8_decode(S->s, S->n, p, &l);
+        int c = uclass_of(S->u, cp);
+        if (!(BIT(c) & it->mask) && !(it->lit && cp == it->lit)) break;
         p += l;
         cnt++;
     }
@@ -183,7 +184,8 @@ static size_t match_at(const subj_t *S, const pattern_t *P, size_t pos) {
     return (size_t)-1;
 }
 
-#define SET(m, lo, hi) { IT_SET, (m), (lo), (hi) }
+#define SET(m, lo, hi) { IT_SET, (m), (lo), (hi), 0 }
+#define SETL(m, lo, hi, lit) { IT_SET, (m), (lo), (hi), (lit) }
 static void tail_alts(pattern_t *P) { /* \p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+ */
     alt_t a3 = {1, {SET(BIT(C_N), 1, 3)}};
     alt_t a4 = {3, {SET(BIT(C_SP), 0, 1), SET(M_ALL & ~(M_S | M_L | BIT(C_N)), 1, -1), SET(BIT(C_NL), 0, -1)}};
@@ -203,6 +205,21 @@ static void pattern_cl100k(pattern_t *P) { /* tokenizer.rs:39 */
     P->alt[P->nalts++] = a1;
     P->alt[P->nalts++] = a2;
     tail_alts(P);
+}
+static void pattern_mistral_v3(pattern_t *P) { /* tokenizer.rs:64: no contractions, \p{N} single, [\r\n/]* */
+    P->nalts = 0;
+    const uint32_t X = M_ALL & ~(BIT(C_NL) | M_L | BIT(C_N));
+    const uint32_t U = BIT(C_LU) | BIT(C_LT) | BIT(C_LM) | BIT(C_LO) | BIT(C_M);
+    const uint32_t W = BIT(C_LL) | BIT(C_LM) | BIT(C_LO) | BIT(C_M);
+    alt_t a1 = {3, {SET(X, 0, 1), SET(U, 0, -1), SET(W, 1, -1)}};
+    alt_t a2 = {3, {SET(X, 0, 1), SET(U, 1, -1), SET(W, 0, -1)}};
+    alt_t a3 = {1, {SET(BIT(C_N), 1, 1)}};
+    alt_t a4 = {3, {SET(BIT(C_SP), 0, 1), SET(M_ALL & ~(M_S | M_L | BIT(C_N)), 1, -1), SETL(BIT(C_NL), 0, -1, '/')}};
+    alt_t a5 = {2, {SET(M_S, 0, -1), SET(BIT(C_NL), 1, -1)}};
+    alt_t a6 = {2, {SET(M_S, 1, -1), {IT_NOT_NONSPACE_AHEAD, 0, 0, 0, 0}}};
+    alt_t a7 = {1, {SET(M_S, 1, -1)}};
+    P->alt[P->nalts++] = a1; P->alt[P->nalts++] = a2; P->alt[P->nalts++] = a3; P->alt[P->nalts++] = a4;
+    P->alt[P->nalts++] = a5; P->alt[P->nalts++] = a6; P->alt[P->nalts++] = a7;
 }
 static void pattern_o200k(pattern_t *P) { /* tokenizer.rs:42 */
     P->nalts = 0;
@@ -323,7 +340,7 @@ orc_t *orc_create(const char *splv_path, const char *uclass_path, int pattern_id
         if (rank > t->map.max_rank) t->map.max_rank = rank;
         off += len;
     }
-    if (pattern_id == 0) pattern_cl100k(&t->pat); else pattern_o200k(&t->pat);
+    if (pattern_id == 0) pattern_cl100k(&t->pat); else if (pattern_id == 2) pattern_mistral_v3(&t->pat); else pattern_o200k(&t->pat);
     t->byte_level = byte_level;
     byte_level_init(t);
     pthread_mutex_init(&t->memo_mu, NULL);

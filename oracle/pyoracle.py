@@ -47,6 +47,12 @@ O200K_BASE_PATTERN = (
     r"|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+"
 )
 LLAMA3_PATTERN = O200K_BASE_PATTERN
+# src/core/tokenizer.rs:64
+MISTRAL_V3_PATTERN = (
+    r"[^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]*[\p{Ll}\p{Lm}\p{Lo}\p{M}]+"
+    r"|[^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]+[\p{Ll}\p{Lm}\p{Lo}\p{M}]*"
+    r"|\p{N}| ?[^\s\p{L}\p{N}]+[\r\n/]*|\s*[\r\n]+|\s+(?!\S)|\s+"
+)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _DATA = os.path.join(os.path.dirname(_HERE), "splintr_amd", "data")
@@ -61,11 +67,12 @@ PRETRAINED = {
     "llama3.3": ("llama3.splv", LLAMA3_PATTERN, False),
     "deepseek_v3": ("deepseek_v3.splv", LLAMA3_PATTERN, True),
     "deepseek-v3": ("deepseek_v3.splv", LLAMA3_PATTERN, True),
+    "mistral_v3": ("mistral_v3.splv", MISTRAL_V3_PATTERN, True),       # src/python/bindings.rs:152-158
 }
 _SPECIAL_KEY = {
     "cl100k_base": "cl100k_base", "o200k_base": "o200k_base", "llama3": "llama3",
     "llama3.1": "llama3", "llama3.2": "llama3", "llama3.3": "llama3",
-    "deepseek_v3": "deepseek_v3", "deepseek-v3": "deepseek_v3",
+    "deepseek_v3": "deepseek_v3", "deepseek-v3": "deepseek_v3", "mistral_v3": "mistral_v3",
 }
 
 

@@ -46,7 +46,7 @@ constexpr uint32_t M_UW = SPL_BIT(C_LM) | SPL_BIT(C_LO) | SPL_BIT(C_M);         
 //   here: look-ahead from the left must see end-of-text), bits 6-7 UTF-8 length - 1.
 constexpr uint32_t CB_CLASS = 0x0F, CB_SYNC = 0x10, CB_TSTART = 0x20, CB_LEN_SHIFT = 6;
 
-enum : int { PAT_CL100K = 0, PAT_O200K = 1 };
+enum : int { PAT_CL100K = 0, PAT_O200K = 1, PAT_MISTRAL_V3 = 2 };
 
 // ----------------------------------------------------------------------------------------
 // Lookup tables in HBM (built on the host by spl_tables.cpp, probed by the kernels).

@@ -1,8 +1,10 @@
 // spl_scan.h -- the split patterns as a deterministic, backtracking-free scanner.
 //
-// Replaces RegexBackend::find_iter (reference src/core/tokenizer.rs:244-257) for the two
-// in-scope patterns CL100K_BASE_PATTERN (:39) and O200K_BASE_PATTERN (:42, also llama3 :45 and
-// deepseek_v3, src/python/bindings.rs:116-129).  `match_end(p)` returns the end of the
+// Replaces RegexBackend::find_iter (reference src/core/tokenizer.rs:244-257) for the
+// in-scope patterns CL100K_BASE_PATTERN (:39), O200K_BASE_PATTERN (:42, also llama3 :45 and
+// deepseek_v3, src/python/bindings.rs:116-129) and MISTRAL_V3_PATTERN (:64: the o200k letter
+// alternatives without the contraction suffix, ONE \p{N} per match, and [\r\n/]* behind the
+// "other" run).  `match_end(p)` returns the end of the
 // leftmost-first match that starts at p; because the patterns tile the text, the match
 // starts of a text are the orbit of 0 under match_end.  Each alternative's greedy /
 // backtracking behaviour has been reduced to a closed form over character classes (derivation
@@ -71,10 +73,21 @@ template <class A> SPL_HD int contraction(const A& a, int ap) {
 // Alternatives 3..7, identical in both patterns:
 //   \p{N}{1,3} | ?[^\s\p{L}\p{N}]+[\r\n]* | \s*[\r\n]+ | \s+(?!\S) | \s+
 // c = real class at p (not L), q1/c1/l1 = next position, its look-ahead class and length.
-template <class A> SPL_HD int match_tail(const A& a, int p, uint32_t c, int q1, uint32_t c1, int l1) {
+// MISTRAL_V3_PATTERN's  ?[^\s\p{L}\p{N}]+[\r\n/]* : behind the maximal "other" run (which ends before q
+// and took every '/' it could) the longest stretch of CR, LF and '/'.
+template <class A> SPL_HD int run_nl_slash(const A& a, int q, uint32_t& stopc) {
+    for (;;) {
+        int l;
+        const uint32_t c = peek(a, q, l);
+        if (c == C_NL || (c == C_P && a.txt(q) == '/')) { q += l; continue; }
+        stopc = c;
+        return q;
+    }
+}
+template <class A> SPL_HD int match_tail(const A& a, int p, uint32_t c, int q1, uint32_t c1, int l1, bool mistral = false) {
     uint32_t stopc;
-    if (c == C_N) {                                  // up to three numbers
-        if (c1 != C_N) return q1;
+    if (c == C_N) {                                  // up to three numbers (mistral: exactly one)
+        if (mistral || c1 != C_N) return q1;
         const int q2 = q1 + l1;
         int l2;
         const uint32_t c2 = peek(a, q2, l2);
@@ -86,7 +99,7 @@ template <class A> SPL_HD int match_tail(const A& a, int p, uint32_t c, int q1, 
     else if (c == C_SP && (SPL_BIT(c1) & M_OTHER)) start = q1 + l1;        // " ?" took the space
     if (start >= 0) {
         int q = run_mask(a, start, M_OTHER, stopc);
-        if (stopc == C_NL) q = run_mask(a, q, SPL_BIT(C_NL), stopc);
+        if (stopc == C_NL) q = mistral ? run_nl_slash(a, q, stopc) : run_mask(a, q, SPL_BIT(C_NL), stopc);
         return stopc == C_WEND ? SPL_DEFER : q;
     }
     // c is whitespace.  One pass over the maximal \s run [p, q) remembering the end of its
@@ -162,7 +175,8 @@ template <class A> SPL_HD int with_contraction(const A& a, int e) {
     return ce == 0 ? e : ce;
 }
 
-template <class A> SPL_HD int match_end_o200k(const A& a, int p) {
+// (mistral: MISTRAL_V3_PATTERN -- no contraction suffix, single numbers, [\r\n/]* tail)
+template <class A> SPL_HD int match_end_o200k(const A& a, int p, bool mistral = false) {
     const uint32_t r0 = a.rec(p);
     const uint32_t c = r0 & CB_CLASS;
     const int l0 = (int)(r0 >> CB_LEN_SHIFT) + 1;
@@ -175,27 +189,27 @@ template <class A> SPL_HD int match_end_o200k(const A& a, int p) {
         if (SPL_BIT(c1) & M_LM) {
             const int e = letters_o200k(a, q1, c1, l1, true);   // never fails for c1 in L|M
             if (e == SPL_DEFER) return e;
-            if (e > 0) return with_contraction(a, e);
+            if (e > 0) return mistral ? e : with_contraction(a, e);
         }
     } else if (c == C_M) {                           // a mark is a legal prefix AND a legal body char
         if (SPL_BIT(c1) & M_LM) {
             const int e = letters_o200k(a, q1, c1, l1, false);  // alt1 with the mark as prefix
             if (e == SPL_DEFER) return e;
-            if (e > 0) return with_contraction(a, e);
+            if (e > 0) return mistral ? e : with_contraction(a, e);
         }
         const int e = letters_o200k(a, p, c, l0, false);        // alt1, empty prefix: always matches
         if (e == SPL_DEFER) return e;
-        return with_contraction(a, e);
+        return mistral ? e : with_contraction(a, e);
     } else if (SPL_BIT(c) & M_L) {
         const int e = letters_o200k(a, p, c, l0, true);
         if (e == SPL_DEFER) return e;
-        return with_contraction(a, e);
+        return mistral ? e : with_contraction(a, e);
     }
-    return match_tail(a, p, c, q1, c1, l1);
+    return match_tail(a, p, c, q1, c1, l1, mistral);
 }
 
 template <class A> SPL_HD int match_end(const A& a, int p, int pattern) {
-    return pattern == PAT_CL100K ? match_end_cl100k(a, p) : match_end_o200k(a, p);
+    return pattern == PAT_CL100K ? match_end_cl100k(a, p) : match_end_o200k(a, p, pattern == PAT_MISTRAL_V3);
 }
 
 // Context-free match starts.  prev = class of the previous character of the SAME text, cur =
@@ -203,14 +217,17 @@ template <class A> SPL_HD int match_end(const A& a, int p, int pattern) {
 // checked against PCRE2 in tests/test_hostsim.py.)
 SPL_HD bool is_sync(int pattern, uint32_t prev, uint32_t cur) {
     const uint32_t pb = SPL_BIT(prev), cb = SPL_BIT(cur);
+    // mistral_v3: \p{N} matches ONE number, so every number starts a match and ends one
+    if (pattern == PAT_MISTRAL_V3 && prev < C_EOT && (cur == C_N || prev == C_N)) return true;
     // (f) a number after anything but a number: no alternative has a digit behind a non-digit
     //     inside one match (only \p{N}{1,3} consumes digits, and it starts with one)
     if (cur == C_N && prev < C_EOT) return prev != C_N;
     // (g) cl100k: "other" after a newline -- every match that consumes a newline ends with its
     //     newline run (o200k's [\r\n/]* may go on with '/', so not there)
     if (pattern == PAT_CL100K && prev == C_NL && (cb & M_OTHER)) return true;
-    if (pb & M_L)
-        return pattern == PAT_CL100K ? !(cb & M_L) : !(cb & (M_L | SPL_BIT(C_M) | SPL_BIT(C_AP)));
+    if (pb & M_L)      // (o200k: a contraction suffix may follow the letters; mistral_v3 has none)
+        return pattern == PAT_CL100K ? !(cb & M_L)
+             : pattern == PAT_O200K  ? !(cb & (M_L | SPL_BIT(C_M) | SPL_BIT(C_AP))) : !(cb & (M_L | SPL_BIT(C_M)));
     if (prev == C_N) return cur != C_N;
     if (prev == C_NL) return (cb & (M_L | SPL_BIT(C_N))) != 0;
     if ((pb & (SPL_BIT(C_P) | SPL_BIT(C_AP))) || (pattern == PAT_CL100K && prev == C_M))

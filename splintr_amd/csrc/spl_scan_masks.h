@@ -90,9 +90,9 @@ template <class MA> SPL_HD uint32_t peek_m(const MA& m, int q, int& len) {
 #define SPL_RUN_OR_DEFER(e) do { if ((e) >= m.wbits() && !m.end_is_eot()) return SPL_DEFER; } while (0)
 
 // Alternatives 3..7 (see match_tail in spl_scan.h) on masks.
-template <class MA> SPL_HD int match_tail_m(const MA& m, int p, uint32_t c, int q1, uint32_t c1, int l1) {
+template <class MA> SPL_HD int match_tail_m(const MA& m, int p, uint32_t c, int q1, uint32_t c1, int l1, bool mistral = false) {
     if (c == C_N) {
-        if (c1 != C_N) return q1;
+        if (mistral || c1 != C_N) return q1;
         const int q2 = q1 + l1;
         int l2;
         const uint32_t c2 = peek_m(m, q2, l2);
@@ -105,6 +105,12 @@ template <class MA> SPL_HD int match_tail_m(const MA& m, int p, uint32_t c, int 
     if (start >= 0) {
         int e = run_end_m(m, MK_O, start);
         e = run_end_m(m, MK_NL, e);                      // [\r\n]* (no-op when the next char is no newline)
+        if (mistral) {                                   // [\r\n/]*: newline runs and '/' in turn (rare)
+            while (e < m.wbits() && !bit_m(m, MK_TS, e) && m.txt(e) == '/') {
+                do e++; while (e < m.wbits() && !bit_m(m, MK_TS, e) && m.txt(e) == '/');
+                e = run_end_m(m, MK_NL, e);
+            }
+        }
         SPL_RUN_OR_DEFER(e);
         return e;
     }
@@ -170,7 +176,7 @@ template <class MA> SPL_HD int match_end_cl100k_m(const MA& m, int p) {
 
 // o200k: letter bodies keep the character-wise closed form of spl_scan.h (case structure inside
 // a run is not a run-end query); everything else goes through the masks.
-template <class MA> SPL_HD int match_end_o200k_m(const MA& m, int p) {
+template <class MA> SPL_HD int match_end_o200k_m(const MA& m, int p, bool mistral = false) {
     const uint32_t r0 = m.rec(p);
     const uint32_t c = r0 & CB_CLASS;
     const int l0 = (int)(r0 >> CB_LEN_SHIFT) + 1;
@@ -183,27 +189,27 @@ template <class MA> SPL_HD int match_end_o200k_m(const MA& m, int p) {
         if (SPL_BIT(c1) & M_LM) {
             const int e = letters_o200k(m, q1, c1, l1, true);
             if (e == SPL_DEFER) return e;
-            if (e > 0) return with_contraction(m, e);
+            if (e > 0) return mistral ? e : with_contraction(m, e);
         }
     } else if (c == C_M) {
         if (SPL_BIT(c1) & M_LM) {
             const int e = letters_o200k(m, q1, c1, l1, false);
             if (e == SPL_DEFER) return e;
-            if (e > 0) return with_contraction(m, e);
+            if (e > 0) return mistral ? e : with_contraction(m, e);
         }
         const int e = letters_o200k(m, p, c, l0, false);
         if (e == SPL_DEFER) return e;
-        return with_contraction(m, e);
+        return mistral ? e : with_contraction(m, e);
     } else if (SPL_BIT(c) & M_L) {
         const int e = letters_o200k(m, p, c, l0, true);
         if (e == SPL_DEFER) return e;
-        return with_contraction(m, e);
+        return mistral ? e : with_contraction(m, e);
     }
-    return match_tail_m(m, p, c, q1, c1, l1);
+    return match_tail_m(m, p, c, q1, c1, l1, mistral);
 }
 
 template <class MA> SPL_HD int match_end_m(const MA& m, int p, int pattern) {
-    return pattern == PAT_CL100K ? match_end_cl100k_m(m, p) : match_end_o200k_m(m, p);
+    return pattern == PAT_CL100K ? match_end_cl100k_m(m, p) : match_end_o200k_m(m, p, pattern == PAT_MISTRAL_V3);
 }
 
 // One word of the sync-point mask from the kind masks (same rules as is_sync):
@@ -216,8 +222,10 @@ SPL_HD uint32_t sync_word(int pattern, const uint32_t (&kw)[MK_COUNT], const uin
     uint32_t sy;
     if (pattern == PAT_CL100K) {
         sy = (pL & ~L) | (pN & ~N) | (pNL & (L | N)) | (pO & (S & ~NL)) | (N & ~pN) | (pNL & kw[MK_O]);
-    } else {
+    } else if (pattern == PAT_O200K) {
         sy = (pL & ~(L | kw[MK_M] | kw[MK_AP])) | (pN & ~N) | (pNL & (L | N)) | ((pO & ~pM) & (S & ~NL)) | (N & ~pN);
+    } else {     // mistral_v3: no contraction suffix behind letters; every number is a match of its own
+        sy = (pL & ~(L | kw[MK_M])) | pN | N | (pNL & L) | ((pO & ~pM) & (S & ~NL));
     }
     // only real character starts can be sync points; a text start always is one
     const uint32_t real = kw[MK_CS];

@@ -51,6 +51,22 @@ bool byte_level_to_raw(const std::string& key, const std::unordered_map<uint32_t
     return true;
 }
 
+bool valid_utf8(const std::string& s) {
+    size_t i = 0;
+    while (i < s.size()) {
+        const uint8_t b = (uint8_t)s[i];
+        size_t l = b < 0x80 ? 1 : (b >= 0xC2 && b < 0xE0) ? 2 : (b >= 0xE0 && b < 0xF0) ? 3 : (b >= 0xF0 && b < 0xF5) ? 4 : 0;
+        if (l == 0 || i + l > s.size()) return false;
+        for (size_t k = 1; k < l; k++) if (((uint8_t)s[i + k] & 0xC0u) != 0x80u) return false;
+        if (l == 3 && b == 0xE0 && (uint8_t)s[i + 1] < 0xA0) return false;
+        if (l == 3 && b == 0xED && (uint8_t)s[i + 1] >= 0xA0) return false;
+        if (l == 4 && b == 0xF0 && (uint8_t)s[i + 1] < 0x90) return false;
+        if (l == 4 && b == 0xF4 && (uint8_t)s[i + 1] >= 0x90) return false;
+        i += l;
+    }
+    return true;
+}
+
 uint32_t load_le(const std::string& s, size_t off) {      // up to 4 bytes, zero padded
     uint32_t w = 0;
     for (size_t i = 0; i < 4 && off + i < s.size(); i++) w |= (uint32_t)(uint8_t)s[off + i] << (8 * i);
@@ -81,7 +97,7 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
     out.cjk_fast = true;
     for (uint32_t cp = 0x4E00; cp < 0xA000 && out.cjk_fast; cp++) out.cjk_fast = host_cp_class(out, cp) == C_LO;
     for (uint32_t cp = 0xAC00; cp < 0xD7A4 && out.cjk_fast; cp++) out.cjk_fast = host_cp_class(out, cp) == C_LO;
-    if (pattern != PAT_CL100K && pattern != PAT_O200K) { err = "unknown pattern id"; return 1; }
+    if (pattern != PAT_CL100K && pattern != PAT_O200K && pattern != PAT_MISTRAL_V3) { err = "unknown pattern id"; return 1; }
     out.pattern = pattern;
 
     // ---- vocabulary (reference src/core/vocab.rs:57-89: later duplicate wins) ---------------
@@ -176,9 +192,13 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
     dec.reserve(enc.size() * 2);
     if (!out.byte_level) for (const auto& kv : enc) dec[kv.second] = kv.first;
     if (out.byte_level) {
-        // Re-key into raw-byte space.  Exact iff every alphabet char is a token and all of them
-        // rank below every multi-char token (then the reference's merge loop completes all
-        // intra-char merges first; DESIGN.md "ByteLevel equivalence").
+        // Re-key into raw-byte space.  The reference merges over the UTF-8 bytes of the ByteLevel
+        // text, where a byte whose alphabet char is U+0080 or above starts out as TWO nodes that only
+        // the char's own token joins (neither half is a key).  Working on raw bytes -- those chars
+        // joined from the start -- is exact iff every alphabet char is a token and every longer
+        // token that CONTAINS such a two-byte char ranks above all of them: then no merge the
+        // reference makes before a char is whole can involve it (DESIGN.md "ByteLevel equivalence").
+        // Tokens made of one-byte chars only may rank anywhere (mistral_v3's control tokens, ids 0..999).
         uint32_t cp_of_byte[256];
         byte_level_alphabet(cp_of_byte);
         std::unordered_map<uint32_t, uint8_t> byte_of_cp;
@@ -188,19 +208,27 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
         uint32_t max_char_rank = 0, min_multi_rank = 0xFFFFFFFFu;
         std::string raw;
         for (const auto& kv : enc) {
-            if (!byte_level_to_raw(kv.first, byte_of_cp, raw)) {           // unreachable from encoded text
+            if (!byte_level_to_raw(kv.first, byte_of_cp, raw)) {
+                // Text with a char outside the alphabet can never equal a stretch of encoded text
+                // (deepseek_v3 ids 0..2).  A key that is no UTF-8 text at all could: the reference's nodes
+                // start as the single UTF-8 BYTES of the ByteLevel text, and a stretch of them need not be
+                // whole chars -- such a vocabulary is outside what the raw-byte re-keying reproduces.
+                if (!valid_utf8(kv.first)) { err = "ByteLevel vocabulary: a key is not UTF-8 text"; return 1; }
                 dec[kv.second] = kv.first;
                 continue;
             }
             dec[kv.second] = raw;
             if (raw.empty()) continue;
             raw_enc[raw] = kv.second;
+            bool wide = false;
+            for (char ch : raw) wide = wide || cp_of_byte[(uint8_t)ch] >= 0x80u;
+            if (!wide) continue;
             if (raw.size() == 1) max_char_rank = std::max(max_char_rank, kv.second);
             else min_multi_rank = std::min(min_multi_rank, kv.second);
         }
         for (int b = 0; b < 256; b++)
             if (!raw_enc.count(std::string(1, (char)b))) { err = "ByteLevel vocabulary lacks an alphabet character"; return 1; }
-        if (max_char_rank >= min_multi_rank) { err = "ByteLevel vocabulary: a merge outranks an alphabet character"; return 1; }
+        if (max_char_rank >= min_multi_rank) { err = "ByteLevel vocabulary: a token outranks an alphabet character it contains"; return 1; }
         enc.swap(raw_enc);
     }
     if (enc.empty()) { err = "empty vocabulary"; return 1; }

@@ -8,7 +8,7 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "hostsi
     if p not in sys.path:
         sys.path.insert(0, p)
 
-VOCABS = ["cl100k_base", "o200k_base", "llama3", "deepseek_v3"]
+VOCABS = ["cl100k_base", "o200k_base", "llama3", "deepseek_v3", "mistral_v3"]
 
 
 def pytest_configure(config):
@@ -40,6 +40,13 @@ def golden():
     with open(os.path.join(ROOT, "tests", "golden", "reference_vectors.json"), encoding="utf-8") as f:
         g = json.load(f)
     return {k: v for k, v in g.items() if not k.startswith("_")}
+
+
+@pytest.fixture(scope="session")
+def golden_all():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "reference_vectors.json"), encoding="utf-8") as f:
+        return json.load(f)
 
 
 _coracles = {}

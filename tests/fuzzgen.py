@@ -22,7 +22,7 @@ ATOMS = [
     "'", "'", "'s", "'t", "'re", "'ve", "'m", "'ll", "'d", "'S", "'RE", "'ſ", "’", "`",
     # punctuation / symbols / controls / format chars (all class "other")
     ".", ",", "!", "?", "-", "_", "(", ")", "{", "}", "[", "]", "\"", "/", "\\", "=", "==", "+", "#", "$", "%",
-    ":", ";", "<", ">", "|", "<|", "|>", "\x00", "\x1f", "\x7f", "‍", "​", "﻿", "。",
+    ":", ";", "<", ">", "|", "<|", "|>", "//", "/\n", "\n/", "\x00", "\x1f", "\x7f", "‍", "​", "﻿", "。",
     "，", "§", "€", "—",
     # letters: Lu/Ll non-ASCII, Lt, Lm, Lo (several scripts), caseless oddities
     "É", "é", "ß", "ſ", "K", "İ", "ı", "ǅ", "ǈ", "ʰ", "ˠ",

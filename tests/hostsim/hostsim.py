@@ -11,7 +11,7 @@ _DATA = os.path.join(_ROOT, "splintr_amd", "data")
 _CSRC = os.path.join(_ROOT, "splintr_amd", "csrc")
 _LIB = os.path.join(_HERE, "libhostsim.so")
 _REG = {"cl100k_base": ("cl100k_base.splv", 0), "o200k_base": ("o200k_base.splv", 1),
-        "llama3": ("llama3.splv", 1), "deepseek_v3": ("deepseek_v3.splv", 1)}
+        "llama3": ("llama3.splv", 1), "deepseek_v3": ("deepseek_v3.splv", 1), "mistral_v3": ("mistral_v3.splv", 2)}
 
 
 def build():

@@ -36,6 +36,15 @@ def test_c_oracle_reference_vectors(golden, coracle, name):
         assert c.encode(text) == ids, (name, text)
 
 
+def test_mistral_v3_special_ids_held_by_the_reference(golden_all, coracle):
+    # tests/mistral_v3.rs:27-150
+    py = O.Oracle.from_pretrained("mistral_v3", engine="pcre2" if O.pcre2_available() else "regex")
+    c = coracle("mistral_v3")
+    for text, ids in golden_all["_mistral_v3_with_special"]:
+        assert py.encode_with_special(text) == ids and c.encode_with_special(text) == ids, text
+    assert py.vocab_size == 131126                       # tests/mistral_v3.rs:75-79
+
+
 def test_bpe_toy_vocab_known_answers():
     # src/core/bpe.rs:203-250
     enc = {b"a": 0, b"b": 1, b"c": 2, b"ab": 3, b"bc": 4, b"abc": 5}
@@ -63,13 +72,14 @@ def test_byte_level_table():
     assert O.byte_level_decode_bytes(O.byte_level_encode(bytes(range(256)))) == bytes(range(256))
 
 
-@pytest.mark.parametrize("pattern_name", ["cl100k", "o200k"])
+@pytest.mark.parametrize("pattern_name", ["cl100k", "o200k", "mistral_v3"])
 def test_split_engines_agree_on_fuzz(coracle, pattern_name):
     if not O.pcre2_available():
         pytest.skip("libpcre2-8 not loadable")
-    pat = O.CL100K_BASE_PATTERN if pattern_name == "cl100k" else O.O200K_BASE_PATTERN
-    c = coracle("cl100k_base" if pattern_name == "cl100k" else "o200k_base")
-    for s in fuzz_corpus(20260928, 6000):
+    pat = {"cl100k": O.CL100K_BASE_PATTERN, "o200k": O.O200K_BASE_PATTERN, "mistral_v3": O.MISTRAL_V3_PATTERN}[pattern_name]
+    c = coracle({"cl100k": "cl100k_base", "o200k": "o200k_base", "mistral_v3": "mistral_v3"}[pattern_name])
+    slashy = ["a!\n/b", "x.\r\n//\n/y", "?/\n", " ;\n\n/ z", "/\n/\n1", "12 3", "a1b22c333", "it's DON'T"]
+    for s in fuzz_corpus(20260928, 6000) + slashy:
         b = s.encode("utf-8")
         p = O.split_pcre2(pat, b)
         # tiling: matches cover the text with no gaps

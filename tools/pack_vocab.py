@@ -10,7 +10,7 @@ container ``splintr_amd/data/<name>.splv``, and extracts the special-token id ta
 SPLV v1 layout (little endian):
     char[4] "SPLV" | u32 version=1 | u32 n_records | u32 flags | u32 max_key_len
     n_records x { u32 rank | u16 key_len | u8 key[key_len] }      (file order preserved)
-flags bit0 = keys are in ByteLevel space (deepseek_v3; src/python/bindings.rs:122-129).
+flags bit0 = keys are in ByteLevel space (deepseek_v3, mistral_v3; src/python/bindings.rs:122-129, 152-158).
 """
 import base64
 import json
@@ -27,6 +27,7 @@ VOCABS = {  # name -> (file, byte_level)
     "o200k_base": ("o200k_base.tiktoken", False),
     "llama3": ("llama3.tiktoken", False),
     "deepseek_v3": ("deepseek_v3.tiktoken", True),
+    "mistral_v3": ("mistral_v3_tekken.tiktoken", True),
 }
 
 
@@ -100,6 +101,7 @@ def special_tokens():
         "o200k_base": run("o200k_base_special_tokens"),
         "llama3": run("llama3_special_tokens"),
         "deepseek_v3": run("deepseek_v3_special_tokens"),
+        "mistral_v3": run("mistral_v3_special_tokens"),
     }
     for k, v in table.items():
         print(f"special[{k}]: {len(v)} literals, ids {min(v.values())}..{max(v.values())}")
