@@ -71,15 +71,81 @@ def all_gather_csr(ids: torch.Tensor, n_tokens, doc_counts: torch.Tensor,
     return all_ids, all_off
 
 
-def encode_batch_sharded(encode_csr, texts: Sequence[str], device: torch.device, group=None):
-    """encode_batch over the process group: rank r encodes its byte-balanced document range with
-    `encode_csr(list[str]) -> (ids uint32 ndarray, off uint64 ndarray)` and the ragged result is
-    all-gathered.  Returns (ids, off) numpy arrays for ALL documents on every rank."""
+_ALNUM = frozenset(b"0123456789abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ")
+
+
+def plan_shards(docs: Sequence[bytes], world: int, split_docs: bool = True,
+                search: int = 1 << 20) -> List[List[Tuple[int, int, int]]]:
+    """Cut a batch into `world` contiguous shards of about equal BYTES.  Returns, per rank, a list of
+    pieces (doc index, lo, hi): whole documents, except that a shard boundary falling inside a large
+    document is moved forward to the next newline that is followed by an ASCII letter or digit -- a
+    context-free match boundary of every supported split pattern (spl_scan.h is_sync rule
+    (d)), so the ids of the two pieces concatenate to the ids of the document.  This is what lets
+    100 equal 2 MiB documents (BASELINE config 5), or ONE huge document (the reference's
+    encode_rayon case, src/core/tokenizer.rs:815-837), spread evenly over 8 GPUs."""
+    n = len(docs)
+    lens = np.fromiter((len(d) for d in docs), dtype=np.int64, count=n)
+    csum = np.concatenate([[0], np.cumsum(lens)])
+    total = int(csum[-1])
+    cuts: List[Tuple[int, int]] = [(0, 0)]                  # (doc, offset inside it); (n, 0) = the end
+    for r in range(1, world):
+        target = total * r // world
+        d = int(np.searchsorted(csum, target, side="right")) - 1       # csum[d] <= target < csum[d + 1]
+        d = min(max(d, 0), n - 1) if n else 0
+        lo_b, hi_b = int(csum[d]), int(csum[d + 1]) if n else 0
+        tol = total // world // 16
+        near = (d, 0) if target - lo_b <= hi_b - target else (d + 1, 0)
+        dist_b = min(target - lo_b, hi_b - target)
+        cut = near
+        if split_docs and n and dist_b > tol and lo_b < target < hi_b:
+            doc = docs[d]
+            i = target - lo_b
+            end = min(len(doc), i + search)
+            while True:
+                j = doc.find(b"\n", i, end)
+                if j < 0 or j + 1 >= len(doc):
+                    break
+                if doc[j + 1] in _ALNUM:
+                    cut = (d, j + 1)
+                    break
+                i = j + 1
+        cut = max(cut, cuts[-1])                            # monotone
+        cuts.append(cut)
+    cuts.append((n, 0))
+    shards: List[List[Tuple[int, int, int]]] = []
+    for r in range(world):
+        (d0, o0), (d1, o1) = cuts[r], cuts[r + 1]
+        pieces: List[Tuple[int, int, int]] = []
+        for d in range(d0, min(d1 + (1 if o1 else 0), n)):
+            lo = o0 if d == d0 else 0
+            hi = o1 if (d == d1 and o1) else len(docs[d])
+            if d == d1 and not o1:
+                break
+            pieces.append((d, lo, hi))
+        shards.append(pieces)
+    return shards
+
+
+def encode_batch_sharded(encode_csr, texts: Sequence[str], device: torch.device, group=None, split_docs: bool = True):
+    """encode_batch over the process group (strong scaling of ONE batch): rank r encodes its
+    byte-balanced shard -- whole documents and, at the shard's ends, pieces of documents cut at
+    context-free boundaries (plan_shards) -- with `encode_csr(list[str]) -> (ids uint32 ndarray,
+    off uint64 ndarray)`, and the ragged result is all-gathered.  Returns (ids, off) numpy arrays
+    for ALL documents on every rank."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    bounds = shard_bounds([len(t.encode("utf-8")) for t in texts], world)
-    local = texts[bounds[rank]:bounds[rank + 1]]
+    docs = [t.encode("utf-8") for t in texts]
+    shards = plan_shards(docs, world, split_docs)
+    local = [docs[d][lo:hi].decode("utf-8") for d, lo, hi in shards[rank]]     # cuts sit in front of ASCII bytes
     ids, off = encode_csr(local)
     t_ids = torch.from_numpy(ids.astype(np.int32, copy=False).copy()).to(device)
     dc = torch.from_numpy(np.diff(off.astype(np.int64))).to(device)
     all_ids, all_off = all_gather_csr(t_ids, int(off[-1]), dc, group)
-    return all_ids.cpu().numpy().view(np.uint32), all_off.cpu().numpy().astype(np.uint64)
+    # one offset entry per PIECE so far; a piece that continues a document contributes none
+    keep = np.ones(sum(len(s) for s in shards) + 1, dtype=bool)
+    k = 0
+    for s in shards:
+        for _, lo, _ in s:
+            if lo != 0:
+                keep[k] = False
+            k += 1
+    return all_ids.cpu().numpy().view(np.uint32), all_off.cpu().numpy().astype(np.uint64)[keep]

@@ -30,7 +30,8 @@ def _worker(rank, world, port, q):
     from splintr_amd import corpus
     from splintr_amd.distributed import encode_batch_sharded
     orc = COracle("cl100k_base")
-    texts = corpus.c2(37) + ["", "x"] + corpus.c4(50)
+    # the last documents are large: shard boundaries fall inside them and are moved to a newline + letter/digit
+    texts = corpus.c2(37) + ["", "x"] + corpus.c4(50) + corpus.c5(2, seed=3, doc_bytes=60000)
 
     def encode_csr(local):
         bs = [t.encode("utf-8") for t in local]
@@ -59,6 +60,145 @@ def test_sharded_encode_allgatherv_gloo(world):
         p.join(timeout=60)
     assert all(ok for _, ok, _, _ in res), res
     assert len({(n, t) for _, _, n, t in res}) == 1
+
+
+class _Ev:
+    def record(self, stream=None):
+        pass
+
+
+class _St:
+    cuda_stream = 0
+
+    def wait_event(self, ev):
+        pass
+
+
+class _Ctx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def _gatherv_worker(rank, world, port, q):
+    """GatherV's bucket / set / callback logic with a stub encoder on CPU tensors: pack, exchange
+    (all_gather_into_tensor on gloo) and unpack follow the slab format of include/splintr_hip.h."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from splintr_amd.device import GatherV
+
+    class Batch:
+        def __init__(self, seed):
+            rng = np.random.default_rng(seed)
+            self.n_docs = int(rng.integers(0, 7))
+            counts = rng.integers(0, 9, size=self.n_docs)
+            self.off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+            self.ids = rng.integers(0, 1000, size=int(self.off[-1])).astype(np.int32)
+
+    class CpuGatherV(GatherV):
+        def _new_stream(self):
+            return _St()
+
+        def _new_event(self):
+            return _Ev()
+
+        def _main_stream(self):
+            return _St()
+
+        def _stream_ctx(self, st):
+            return _Ctx()
+
+        def _encode_packed(self, batch, slab, with_special, stream_ptr):
+            slab[0], slab[1] = int(batch.off[-1]), batch.n_docs
+            slab[2:2 + batch.n_docs + 1] = torch.from_numpy(batch.off.astype(np.int32))
+            at = 3 + self.max_docs
+            slab[at:at + len(batch.ids)] = torch.from_numpy(batch.ids)
+
+        def _unpack(self, s, n, stream_ptr):
+            recv = self.recv[s].view(self.world, self.depth, self.cap_words)
+            for j in range(n):
+                ids, off = self._views(s, j)
+                tb = db = 0
+                for r in range(self.world):
+                    sl = recv[r, j]
+                    T, N = int(sl[0]), int(sl[1])
+                    off[db:db + N] = sl[2:2 + N].to(torch.int64) + tb
+                    at = 3 + self.max_docs
+                    ids[tb:tb + T] = sl[at:at + T]
+                    tb += T
+                    db += N
+                off[db] = tb
+
+    depth, n_batches = 3, 8                     # 8 batches: two full buckets and a partial one
+    gv = CpuGatherV(None, torch.device("cpu"), max_docs=8, max_tokens=80, depth=depth)
+    got = []
+    gv.on_bucket = lambda res: got.extend((i.clone(), o.clone()) for i, o in res)
+    mine = [Batch(1000 * rank + k) for k in range(n_batches)]
+    for b in mine:
+        gv.encode_and_submit(b)
+    last_ids, last_off = gv.finish()
+    ok = len(got) == n_batches
+    for k in range(n_batches):                  # every rank can rebuild every rank's batch k
+        exp_ids, exp_off, tb = [], [0], 0
+        for r in range(world):
+            b = Batch(1000 * r + k)
+            exp_ids.append(b.ids)
+            exp_off.extend((b.off[1:] + tb).tolist())
+            tb += int(b.off[-1])
+        exp_ids = np.concatenate(exp_ids) if exp_ids else np.zeros(0, np.int32)
+        g_ids, g_off = got[k]
+        nd = len(exp_off) - 1
+        ok = ok and np.array_equal(g_ids[:tb].numpy(), exp_ids) and g_off[:nd + 1].tolist() == exp_off
+    ok = ok and torch.equal(last_ids, got[-1][0]) and torch.equal(last_off, got[-1][1])
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gatherv_buckets_and_sets_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_gatherv_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res), res
+
+
+def test_plan_shards_cuts_documents_at_context_free_boundaries(coracle):
+    from splintr_amd import corpus
+    from splintr_amd.distributed import plan_shards
+    docs = [t.encode() for t in corpus.c5(3, seed=11, doc_bytes=150000)] + [b"", b"tail"]
+    total = sum(map(len, docs))
+    orc = coracle("deepseek_v3")
+    for world in (1, 2, 4, 8):
+        shards = plan_shards(docs, world)
+        assert len(shards) == world
+        flat = [p for s in shards for p in s]
+        # the pieces tile every document in order
+        rebuilt = {}
+        for d, lo, hi in flat:
+            assert lo == len(rebuilt.get(d, b"")) and hi >= lo
+            rebuilt[d] = rebuilt.get(d, b"") + docs[d][lo:hi]
+        assert all(rebuilt.get(d, b"") == docs[d] for d in range(len(docs)) if docs[d] or d in rebuilt)
+        per = [sum(hi - lo for _, lo, hi in s) for s in shards]
+        assert max(per) - min(per) < total // world // 4 + 4096          # byte-balanced although 3 docs dominate
+        # ids of the pieces concatenate to the ids of the whole documents
+        for d in range(3):
+            pieces = [docs[d][lo:hi] for dd, lo, hi in flat if dd == d]
+            if len(pieces) > 1:
+                cat = [i for pc in pieces for i in orc.encode_bytes(pc)]
+                assert cat == orc.encode_bytes(docs[d])
+                assert all(pc[:1].isalnum() for pc in pieces[1:])
+    assert plan_shards(docs, 4, split_docs=False) != plan_shards(docs, 4)
+    assert plan_shards([], 3) == [[], [], []]
 
 
 def test_shard_bounds_balance():
