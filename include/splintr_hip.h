@@ -185,6 +185,16 @@ int spl_decode_batch(spl_tokenizer* t, const uint32_t* ids, const uint64_t* ids_
                      uint8_t** out_bytes, uint64_t** out_off);
 void spl_free(void* p);
 
+/* Host-side lookup of ONE id, for consumers that decode token by token on the CPU -- the streaming
+ * decoders (src/core/streaming.rs, src/python/bindings.rs:465-834 take clones of Tokenizer::decoder
+ * and special_tokens_decoder).  *bytes / *len = what decode_bytes emits for the id; the pointer
+ * stays valid until spl_destroy or the next spl_add_special.  Returns 0 unknown id, 1 vocabulary
+ * token, 2 vocabulary token of a ByteLevel vocabulary whose key is NOT ByteLevel text (the bytes
+ * are the key itself), 3 special token. */
+int spl_token_bytes(const spl_tokenizer* t, uint32_t id, const uint8_t** bytes, uint32_t* len);
+/* 1 if the vocabulary's keys are ByteLevel text (from_bytes_byte_level / the container's flag). */
+int spl_is_byte_level(const spl_tokenizer* t);
+
 /* Per-kernel timing (HIP events on the launch stream).  While enabled every encode call records
  * events around each kernel; spl_profile_read returns the accumulated milliseconds and launch
  * counts per kernel since the last spl_profile_reset and synchronises the stream. */

@@ -25,6 +25,7 @@ SYMBOLS = [
     "spl_profile_enable", "spl_profile_reset", "spl_profile_read", "spl_kernel_name", "spl_last_queue_counts",
     "spl_debug_phases", "spl_debug_blocks", "spl_gatherv_pack", "spl_gatherv_unpack", "spl_gatherv_unpack_group", "spl_encode_batch_device_packed",
     "spl_set_devices", "spl_n_devices", "spl_set_option", "spl_host_alloc", "spl_host_free",
+    "spl_token_bytes", "spl_is_byte_level",
 ]
 SPL_OPT_BYTE_LEVEL = 1
 
@@ -73,6 +74,8 @@ def lib() -> ctypes.CDLL:
     L.spl_host_alloc.argtypes = [ctypes.c_size_t]
     L.spl_host_free.restype = None
     L.spl_host_free.argtypes = [vp]
+    L.spl_token_bytes.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint32)]
+    L.spl_is_byte_level.argtypes = [vp]
     L.spl_encode_batch.argtypes = [vp, vp, vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(vp)]
     L.spl_result_tokens.restype = u32p
     L.spl_result_tokens.argtypes = [vp]

@@ -1063,6 +1063,23 @@ int spl_decode_batch(spl_tokenizer* t, const uint32_t* ids, const uint64_t* ids_
 
 void spl_free(void* p) { free(p); }
 
+int spl_token_bytes(const spl_tokenizer* t, uint32_t id, const uint8_t** bytes, uint32_t* len) {
+    if (!t || !bytes || !len) return 0;
+    if (id <= t->ht.max_id && t->ht.tok_present[id]) {
+        *bytes = t->ht.tok_bytes.data() + t->ht.tok_off[id];
+        *len = t->ht.tok_off[id + 1] - t->ht.tok_off[id];
+        return t->ht.tok_present[id];
+    }
+    for (size_t k = t->specials.size(); k-- > 0;)
+        if (t->specials[k].id == id) {
+            *bytes = (const uint8_t*)t->specials[k].lit.data();
+            *len = (uint32_t)t->specials[k].lit.size();
+            return 3;
+        }
+    return 0;
+}
+int spl_is_byte_level(const spl_tokenizer* t) { return t && t->ht.byte_level ? 1 : 0; }
+
 int spl_profile_enable(spl_tokenizer* t, int on) {
     if (!t) return fail(SPL_EINVAL, "null handle");
     t->ctx[0]->prof = on != 0;

@@ -729,7 +729,10 @@ __device__ __forceinline__ void bpe_wave64_tab(const DeviceTables& T, const LdsA
     // to 16 bytes then go through the 16-lane loop four at a time, on the rows already filled:
     // a few short loops side by side instead of one loop over every merge of the chunk.
     unsigned long long starts = 1ull;
-    if (__any(own && (w0 & 0x80u))) {
+#ifndef SPL_SEG_ASCII
+#define SPL_SEG_ASCII 0          /* 1: look for independent segments in ASCII chunks too (A/B) */
+#endif
+    if (SPL_SEG_ASCII || __any(own && (w0 & 0x80u))) {
         int ml = 1;
 #pragma unroll
         for (int k = 0; k < SUB_W; k++) ml = (k + 2 <= maxlen && row[k] != SPL_NO_RANK) ? k + 2 : ml;

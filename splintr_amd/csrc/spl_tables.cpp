@@ -189,6 +189,7 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
     // src/core/tokenizer.rs:877-897): id -> the bytes decode_bytes emits for it.  ByteLevel: the key
     // decoded to raw bytes, or the key itself where it is not ByteLevel text (byte_level.rs:125-146).
     std::unordered_map<uint32_t, std::string> dec;
+    std::vector<uint32_t> verbatim;               // ByteLevel: ids whose key is emitted as it is
     dec.reserve(enc.size() * 2);
     if (!out.byte_level) for (const auto& kv : enc) dec[kv.second] = kv.first;
     if (out.byte_level) {
@@ -215,6 +216,7 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
                 // whole chars -- such a vocabulary is outside what the raw-byte re-keying reproduces.
                 if (!valid_utf8(kv.first)) { err = "ByteLevel vocabulary: a key is not UTF-8 text"; return 1; }
                 dec[kv.second] = kv.first;
+                verbatim.push_back(kv.second);
                 continue;
             }
             dec[kv.second] = raw;
@@ -389,6 +391,7 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
         if (by_id[id]) { out.tok_present[id] = 1; out.tok_bytes.insert(out.tok_bytes.end(), by_id[id]->begin(), by_id[id]->end()); }
     }
     out.tok_off[out.max_id + 1] = (uint32_t)out.tok_bytes.size();
+    for (uint32_t id : verbatim) if (id <= out.max_id && out.tok_present[id]) out.tok_present[id] = 2;
     // a bucket with a free last slot in each of the two small-key tables (load factors are below 0.4)
     {
         const size_t tb = out.tiny_tab.size() / (SPL_TINY_BUCKET * 2), eb = out.t8_tab.size() / SPL_T8_WORDS;

@@ -39,7 +39,7 @@ struct HostTables {
     // decoder side: id -> raw bytes (CSR); ids with no entry have empty spans
     std::vector<uint32_t> tok_off;      // max_id + 2
     std::vector<uint8_t> tok_bytes;
-    std::vector<uint8_t> tok_present;   // max_id + 1: the id is a key of the decoder map
+    std::vector<uint8_t> tok_present;   // max_id + 1: 0 no such id, 1 a token, 2 (ByteLevel) a token whose key is emitted verbatim
 };
 
 // Returns 0 on success; on failure fills err.

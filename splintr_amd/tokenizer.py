@@ -52,6 +52,22 @@ _PRETRAINED = {
 }
 
 
+def _byte_level_alphabet() -> List[str]:
+    """byte -> char of the GPT-2 ByteLevel alphabet (src/core/byte_level.rs:46-74)."""
+    direct = set(range(33, 127)) | set(range(161, 173)) | set(range(174, 256))
+    out, nxt = [], 256
+    for b in range(256):
+        if b in direct:
+            out.append(chr(b))
+        else:
+            out.append(chr(nxt))
+            nxt += 1
+    return out
+
+
+_BYTE_TO_CHAR = _byte_level_alphabet()
+
+
 def _read(path: str) -> bytes:
     with open(path, "rb") as f:
         return f.read()
@@ -272,6 +288,32 @@ class Tokenizer:
 
     def decode_batch_lossy(self, token_lists: Sequence[Sequence[int]]) -> List[str]:
         return [b.decode("utf-8", "replace") for b in self._decode_batch_bytes(token_lists)]
+
+    # ------------------------------------------------------------------ streaming decoders (host side)
+    def _token_bytes(self, token_id: int, byte_level_decoded: bool) -> Optional[bytes]:
+        """What the reference's decoder / special_tokens_decoder maps give for one id.
+        byte_level_decoded False: the vocabulary KEY (ByteLevel text for ByteLevel vocabularies)."""
+        if not 0 <= token_id < (1 << 32):
+            return None
+        L = _ffi.lib()
+        p, n = ctypes.c_void_p(), ctypes.c_uint32()
+        kind = L.spl_token_bytes(self._h, token_id, ctypes.byref(p), ctypes.byref(n))
+        if kind == 0:
+            return None
+        b = ctypes.string_at(p, n.value) if n.value else b""
+        if kind == 1 and not byte_level_decoded and L.spl_is_byte_level(self._h):
+            b = "".join(_BYTE_TO_CHAR[x] for x in b).encode("utf-8")      # back to the key (byte_level.rs:105-107)
+        return b
+
+    def streaming_decoder(self):
+        """src/python/bindings.rs:386-405."""
+        from .streaming import StreamingDecoder
+        return StreamingDecoder(lambda t: self._token_bytes(t, False))
+
+    def byte_level_streaming_decoder(self):
+        """src/python/bindings.rs:407-427."""
+        from .streaming import ByteLevelStreamingDecoder
+        return ByteLevelStreamingDecoder(lambda t: self._token_bytes(t, True))
 
     # ------------------------------------------------------------------ cheap surface
     @property

@@ -62,6 +62,29 @@ def test_reference_vectors(golden, name):
 
 
 @pytest.mark.parametrize("name", VOCABS)
+def test_reference_test_strings(name):
+    """tests/golden/reference_test_strings.json through the HIP path: single, batch of 700, with special,
+    and the backend switches the reference's tests flip (all map to the one scanner)."""
+    with open(os.path.join(ROOT, "tests", "golden", "reference_test_strings.json"), encoding="utf-8") as f:
+        fx = json.load(f)
+    t = tok(name)
+    assert t.encode_batch(fx["plain"]) == fx["ids"][name]
+    for s, ids in zip(fx["plain"], fx["ids"][name]):
+        assert t.encode(s) == ids and t.pcre2(True).encode(s) == ids and t.jit(False).encode(s) == ids
+        assert t.decode(ids) == s
+    assert t.encode_batch_with_special(fx["special"]) == fx["ids_with_special"][name]
+    want = [fx["ids"][name][fx["plain"].index(s)] for s in fx["large_batch_base"]] * 100
+    assert t.encode_batch(fx["large_batch_base"] * 100) == want
+
+
+def test_mistral_v3_special_ids_held_by_the_reference(golden_all):
+    t = tok("mistral_v3")                                     # tests/mistral_v3.rs:27-150
+    for text, ids in golden_all["_mistral_v3_with_special"]:
+        assert t.encode_with_special(text) == ids, text
+        assert t.decode(ids) == text
+
+
+@pytest.mark.parametrize("name", VOCABS)
 def test_surface(name):
     t = tok(name)
     sizes = {"cl100k_base": 100331, "o200k_base": 200073, "llama3": 128354, "deepseek_v3": 128954, "mistral_v3": 131126}

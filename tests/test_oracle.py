@@ -45,6 +45,25 @@ def test_mistral_v3_special_ids_held_by_the_reference(golden_all, coracle):
     assert py.vocab_size == 131126                       # tests/mistral_v3.rs:75-79
 
 
+@pytest.mark.parametrize("name", VOCABS)
+def test_reference_test_strings(coracle, name):
+    """The strings the reference's Python tests run through regexr, PCRE2 and regexr-without-JIT and
+    require equal tokens for (python/tests/test_cl100k.py:436-570): the committed ids (PCRE2 oracle)
+    are reproduced by the independent `regex` engine and by the C oracle, and round-trip."""
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "reference_test_strings.json"), encoding="utf-8") as f:
+        fx = json.load(f)
+    py = O.Oracle.from_pretrained(name, engine="regex")
+    c = coracle(name)
+    for s, ids in zip(fx["plain"], fx["ids"][name]):
+        assert py.encode(s) == ids and c.encode(s) == ids, (name, s)
+        assert py.decode_bytes(ids).decode("utf-8") == s
+    for s, ids in zip(fx["special"], fx["ids_with_special"][name]):
+        assert py.encode_with_special(s) == ids and c.encode_with_special(s) == ids, (name, s)
+    batch = c.encode_batch(fx["large_batch_base"] * 100, threads=8)          # the 700-text batch
+    assert batch == [fx["ids"][name][fx["plain"].index(s)] for s in fx["large_batch_base"]] * 100
+
+
 def test_bpe_toy_vocab_known_answers():
     # src/core/bpe.rs:203-250
     enc = {b"a": 0, b"b": 1, b"c": 2, b"ab": 3, b"bc": 4, b"abc": 5}
