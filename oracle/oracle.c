@@ -75,25 +75,39 @@ static inline int uclass_of(const uclass_t *u, uint32_t cp) {
     return u->stage2[((size_t)u->stage1[cp >> u->shift] << u->shift) | (cp & ((1u << u->shift) - 1))];
 }
 
-/* ---------------------------------------------------------------- UTF-8 helpers (valid input) */
+/* ---------------------------------------------------------------- UTF-8 helpers
+ * The reference's core only ever sees &str (valid UTF-8).  For byte strings that are not, this
+ * restatement follows the policy the C ABI states (include/splintr_hip.h), one text at a time:
+ * a lead byte (0xC0..0xFF; 0xF0 and above announce four bytes) takes the continuation bytes that
+ * follow, at most as many as it announces -- all present: the character with the decoded value,
+ * looked up as it is; otherwise ONE character of class "other" made of the bytes it got; a
+ * continuation byte that no lead reaches is a character of class "other" by itself.
+ * Code point 0xFFFFFFFF stands for "class other" (uclass_of maps everything >= 0x110000 to C_P). */
+static inline size_t u8_want(uint8_t b) { return b < 0xC0 ? 1 : b < 0xE0 ? 2 : b < 0xF0 ? 3 : 4; }
 static inline uint32_t u8_decode(const uint8_t *s, size_t n, size_t pos, size_t *len) {
     uint8_t b = s[pos];
     if (b < 0x80) { *len = 1; return b; }
-    if (b < 0xE0 && pos + 1 < n) { *len = 2; return ((b & 0x1Fu) << 6) | (s[pos + 1] & 0x3Fu); }
-    if (b < 0xF0 && pos + 2 < n) {
-        *len = 3;
-        return ((b & 0x0Fu) << 12) | ((s[pos + 1] & 0x3Fu) << 6) | (s[pos + 2] & 0x3Fu);
+    if (b < 0xC0) { *len = 1; return 0xFFFFFFFFu; }             /* (callers only ask at character starts) */
+    size_t want = u8_want(b), l = 1;
+    while (l < want && pos + l < n && (s[pos + l] & 0xC0) == 0x80) l++;
+    *len = l;
+    if (l < want) return 0xFFFFFFFFu;
+    if (want == 2) return ((b & 0x1Fu) << 6) | (s[pos + 1] & 0x3Fu);
+    if (want == 3) return ((b & 0x0Fu) << 12) | ((s[pos + 1] & 0x3Fu) << 6) | (s[pos + 2] & 0x3Fu);
+    return ((b & 0x07u) << 18) | ((s[pos + 1] & 0x3Fu) << 12) | ((s[pos + 2] & 0x3Fu) << 6) | (s[pos + 3] & 0x3Fu);
+}
+static inline int u8_is_start(const uint8_t *s, size_t pos) { /* does a character start at pos? */
+    if ((s[pos] & 0xC0) != 0x80) return 1;
+    for (size_t k = 1; k <= 3; k++) {
+        if (pos < k) return 1;
+        uint8_t b = s[pos - k];
+        if (b >= 0xC0) return u8_want(b) <= k;
+        if (b < 0x80) return 1;
     }
-    if (pos + 3 < n) {
-        *len = 4;
-        return ((b & 0x07u) << 18) | ((s[pos + 1] & 0x3Fu) << 12) | ((s[pos + 2] & 0x3Fu) << 6) |
-               (s[pos + 3] & 0x3Fu);
-    }
-    *len = 1; /* truncated tail: treat as a lone byte (never reached for valid UTF-8) */
-    return 0xFFFD;
+    return 1;
 }
 static inline size_t u8_prev(const uint8_t *s, size_t pos) { /* start of the char ending at pos */
-    do { pos--; } while (pos > 0 && (s[pos] & 0xC0) == 0x80);
+    do { pos--; } while (pos > 0 && !u8_is_start(s, pos));
     return pos;
 }
 

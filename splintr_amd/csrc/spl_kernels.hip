@@ -791,16 +791,9 @@ struct GlobalAcc {
         const int64_t B = b->n_bytes;
         if (q >= B) return C_EOT | CB_TSTART | CB_SYNC;
         if (b->skip && ((b->skip[q >> 5] >> (q & 31)) & 1u)) return C_EOT | CB_TSTART;
-        const uint32_t c0 = b->text[q];
-        uint32_t r;
-        if (c0 < 0x80u) r = cp_class(*T, c0);
-        else if (c0 < 0xC0u) r = C_CONT;
-        else {
-            uint32_t want = utf8_len(c0), len = 1;
-            while (len < want && q + len < B && (b->text[q + len] & 0xC0u) == 0x80u) len++;
-            const uint32_t cls = (len == want) ? cp_class(*T, decode_at(*this, (int)q, c0)) : (uint32_t)C_P;
-            r = cls | ((len - 1) << CB_LEN_SHIFT);
-        }
+        const uint32_t* const tsb = b->tstart;
+        uint32_t r = byte_record(*T, *this, [&](int i) { return ((tsb[(uint32_t)i >> 5] >> (i & 31)) & 1u) != 0; },
+                                 [&](uint32_t c) { return cp_class(*T, c); }, qi, 0, (int)B);
         if ((b->tstart[q >> 5] >> (q & 31)) & 1u) r |= CB_TSTART | CB_SYNC;
         return r;
     }
@@ -813,6 +806,7 @@ struct DirectAcc {
     const DeviceTables* T;
     const Batch* b;
     uint32_t next_ts;          // first text start after the chain's start (n_bytes if none)
+    uint32_t lo;               // the chain's start (a character start: nothing before it matters)
     __device__ __forceinline__ uint32_t txt(int64_t q) const { return q < (int64_t)b->n_bytes ? b->text[q] : 0u; }
     __device__ __forceinline__ uint32_t txt(int q) const { return txt((int64_t)(uint32_t)q); }
     __device__ __forceinline__ uint32_t load32(int p) const {
@@ -824,16 +818,11 @@ struct DirectAcc {
         const int64_t B = b->n_bytes;
         if (q >= B) return C_EOT | CB_TSTART | CB_SYNC;
         if (b->skip && ((b->skip[q >> 5] >> (q & 31)) & 1u)) return C_EOT | CB_TSTART;          // inside a special literal
-        const uint32_t c0 = b->text[q];
-        uint32_t r;
-        if (c0 < 0x80u) r = cp_class(*T, c0);
-        else if (c0 < 0xC0u) r = C_CONT;
-        else {
-            uint32_t want = utf8_len(c0), len = 1;
-            while (len < want && q + len < B && (b->text[q + len] & 0xC0u) == 0x80u) len++;
-            const uint32_t cls = (len == want) ? cp_class(*T, decode_at(*this, (int)q, c0)) : (uint32_t)C_P;
-            r = cls | ((len - 1) << CB_LEN_SHIFT);
-        }
+        const uint32_t* const tsb = b->tstart;
+        const uint32_t nts = next_ts;
+        uint32_t r = byte_record(*T, *this,
+                                 [&](int i) { return (uint32_t)i == nts || (tsb && ((tsb[(uint32_t)i >> 5] >> (i & 31)) & 1u)); },
+                                 [&](uint32_t c) { return cp_class(*T, c); }, qi, (int)lo, (int)B);
         if ((uint32_t)q == next_ts) r |= CB_TSTART | CB_SYNC;
         if (b->tstart && ((b->tstart[q >> 5] >> (q & 31)) & 1u)) r |= CB_TSTART | CB_SYNC;    // behind a special literal
         return r;
@@ -889,16 +878,11 @@ __global__ __launch_bounds__(64) void k_deferred_wave(DeviceTables T, Batch b) {
                 if (g >= B) r = C_EOT | CB_TSTART | CB_SYNC;
                 else if (b.skip && ((b.skip[g >> 5] >> (g & 31)) & 1u)) r = C_EOT | CB_TSTART;
                 else {
-                    const uint32_t c0 = s_txt[i];
-                    if (c0 < 0x80u) r = s_ascii[c0];
-                    else if (c0 < 0xC0u) r = C_CONT;
-                    else {
-                        uint32_t want = utf8_len(c0), len = 1;
-                        while (len < want && i + (int)len < nst && (s_txt[i + len] & 0xC0u) == 0x80u) len++;
-                        const WinAcc tx{s_rec, s_txt, 0};
-                        const uint32_t cls = (len == want) ? cp_class(T, decode_at(tx, i, c0)) : (uint32_t)C_P;
-                        r = cls | ((len - 1) << CB_LEN_SHIFT);
-                    }
+                    // (window index i = global position base + i; look-back stops at the window's first byte:
+                    //  DEFER_BACK bytes precede the chain's start, which is a character start anyway)
+                    const WinAcc tx{s_rec, s_txt, 0};
+                    r = byte_record(T, tx, [&](int k) { const int64_t gg = base + k; return ((b.tstart[gg >> 5] >> (gg & 31)) & 1u) != 0; },
+                                    [&](uint32_t c) { return (uint32_t)s_ascii[c]; }, i, 0, nst);
                     if ((b.tstart[g >> 5] >> (g & 31)) & 1u) r |= CB_TSTART | CB_SYNC;
                 }
                 s_rec[i] = (uint8_t)r;
@@ -918,7 +902,7 @@ __global__ __launch_bounds__(64) void k_deferred_wave(DeviceTables T, Batch b) {
                         if (r == (uint32_t)C_WEND) { np = base + q; break; }       // need the next window to tell
                         if (r & (CB_SYNC | CB_TSTART)) { done = 1; break; }
                         int j = q - 1;
-                        while (j > 0 && (s_txt[j] & 0xC0u) == 0x80u && j > q - 4) j--;
+                        while (j > 0 && (acc.rec(j) & CB_CLASS) == C_CONT && j > q - 4) j--;
                         const uint32_t prev = acc.rec(j) & CB_CLASS;
                         if (prev < C_EOT && is_sync((int)T.pattern, prev, r & CB_CLASS)) { done = 1; break; }
                     }
@@ -1855,7 +1839,12 @@ void k_pretok(DeviceTables T, Batch b) {
 #define SPL_STAMP(i) do { } while (0)
 #endif
 
-    const int tid = threadIdx.x;
+#ifndef SPL_ROTATE_WAVES
+#define SPL_ROTATE_WAVES 0
+#endif
+    // (A/B) logical wavefront index rotated by the workgroup index: phases that only fill the low
+    // wavefronts (chains, probe list, per-word scans) then load different SIMDs in different workgroups
+    const int tid = SPL_ROTATE_WAVES ? (int)((threadIdx.x + ((blockIdx.x & 3u) << 6)) & (NT - 1)) : (int)threadIdx.x;
     if (DIRECT) __builtin_amdgcn_s_setprio(SPL_WORK_PRIO);
     const int64_t t0 = (int64_t)blockIdx.x * TB_;
     const int64_t w0 = t0 - LH;                       // global position of window index 0
@@ -1974,14 +1963,11 @@ void k_pretok(DeviceTables T, Batch b) {
             } else {
                 const uint32_t c0 = (tw >> (8 * k)) & 0xFFu;
                 if (c0 < 0x80u) r = s_ascii[c0];
-                else if (c0 < 0xC0u) r = C_CONT;
-                else {
-                    // clamp the length to the continuation bytes actually present
-                    uint32_t want = utf8_len(c0), len = 1;
-                    while (len < want && i + (int)len < iT && (s_txt[i + len] & 0xC0u) == 0x80u) len++;
-                    LdsAcc tx{s_rec, s_txt};
-                    const uint32_t cls = (len == want) ? cp_class(T, decode_at(tx, i, c0)) : (uint32_t)C_P;
-                    r = cls | ((len - 1) << CB_LEN_SHIFT);
+                else {      // (bytes before window index 0 do not exist for the look-back: that only concerns the
+                            //  first bytes of the left halo, whose records nothing in the tile depends on)
+                    const LdsAcc tx{s_rec, s_txt};
+                    r = byte_record(T, tx, [&](int j) { return ((s_ts[j >> 5] >> (j & 31)) & 1u) != 0; },
+                                    [](uint32_t) { return 0u; }, i, w0 < 0 ? (int)-w0 : 0, iT);
                 }
                 if ((ts4 >> k) & 1u) r |= CB_TSTART | CB_SYNC;
             }
@@ -2415,7 +2401,7 @@ void k_pretok(DeviceTables T, Batch b) {
                         if (tid == 0) {
                             uint32_t fill = s_dq[0];
                             const uint32_t np = (uint32_t)pc;
-                            const DirectAcc ga{&T, &b, next_ts};
+                            const DirectAcc ga{&T, &b, next_ts, np};
                             const int e = match_end(ga, (int)np, (int)T.pattern);
                             const uint32_t n = (uint32_t)e - np;
                             const uint32_t id = probe_chunk(T, ga, (int)np, (int)n);
@@ -2485,16 +2471,13 @@ void k_pretok(DeviceTables T, Batch b) {
                         if (g >= B) r = C_EOT | CB_TSTART | CB_SYNC;
                         else if (b.skip && ((b.skip[g >> 5] >> (g & 31)) & 1u)) r = C_EOT | CB_TSTART;
                         else {
-                            const uint32_t c0 = wtxt[i];
-                            if (c0 < 0x80u) r = s_ascii[c0];
-                            else if (c0 < 0xC0u) r = C_CONT;
-                            else {
-                                uint32_t want = utf8_len(c0), len = 1;
-                                while (len < want && i + (int)len < nst && (wtxt[i + len] & 0xC0u) == 0x80u) len++;
-                                const WinAcc tx{wrec, wtxt, 0};
-                                const uint32_t cls = (len == want) ? cp_class(T, decode_at(tx, i, c0)) : (uint32_t)C_P;
-                                r = cls | ((len - 1) << CB_LEN_SHIFT);
-                            }
+                            // (the cut of a periodic run removes whole characters of a run of identical ones, so
+                            //  the bytes on either side of it are what the look-back and the clamp would see anyway)
+                            const WinAcc tx{wrec, wtxt, 0};
+                            r = byte_record(T, tx,
+                                            [&](int k) { const int64_t gg = base + k + (k >= split ? (int64_t)removed : 0);
+                                                         return (uint32_t)gg == next_ts || (b.tstart && ((b.tstart[gg >> 5] >> (gg & 31)) & 1u)); },
+                                            [&](uint32_t c) { return (uint32_t)s_ascii[c]; }, i, i >= q0 ? q0 : 0, nst);
                             if ((uint32_t)g == next_ts) r |= CB_TSTART | CB_SYNC;
                             if (b.tstart && ((b.tstart[g >> 5] >> (g & 31)) & 1u)) r |= CB_TSTART | CB_SYNC;
                         }
@@ -2513,7 +2496,7 @@ void k_pretok(DeviceTables T, Batch b) {
                                 if (r == (uint32_t)C_WEND) break;                  // the next window will tell
                                 if (r & (CB_SYNC | CB_TSTART)) { finished = true; break; }
                                 int j = q - 1;
-                                while (j > 0 && (wtxt[j] & 0xC0u) == 0x80u && j > q - 4) j--;
+                                while (j > 0 && (acc.rec(j) & CB_CLASS) == C_CONT && j > q - 4) j--;
                                 const uint32_t prev = acc.rec(j) & CB_CLASS;
                                 if (prev < C_EOT && is_sync((int)T.pattern, prev, r & CB_CLASS)) { finished = true; break; }
                             }

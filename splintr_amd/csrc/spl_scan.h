@@ -250,4 +250,33 @@ template <class TX> SPL_HD uint32_t decode_at(const TX& tx, int q, uint32_t b0) 
            (tx.txt(q + 3) & 0x3Fu);
 }
 
+// Class record (class | (length - 1) << CB_LEN_SHIFT) of the byte at q -- the ONE place that decides what
+// a character is, including for text that is not valid UTF-8 (policy in include/splintr_hip.h):
+//   * a lead byte takes the continuation bytes that follow it IN THE SAME TEXT, at most as many as it
+//     announces; all of them present: the class of the decoded value (looked up as it is), otherwise
+//     the bytes it got form one character of class "other";
+//   * a continuation byte that no lead byte of its text reaches is a character of class "other";
+//     one that is reached is C_CONT (not a character start).
+// tx.txt(i): text byte; ts(i): a text starts at i; [lo, hi): the bytes that exist for this purpose
+// (ts is asked for positions in [lo, hi] only); ascii(c): record of an ASCII byte.
+template <class TX, class TS, class ASC>
+SPL_HD uint32_t byte_record(const DeviceTables& T, const TX& tx, const TS& ts, const ASC& ascii, int q, int lo, int hi) {
+    const uint32_t c0 = tx.txt(q);
+    if (c0 < 0x80u) return ascii(c0);
+    if (c0 < 0xC0u) {
+        for (int k = 1; k <= 3; k++) {
+            if (ts(q - k + 1) || q - k < lo) return C_P;
+            const uint32_t b = tx.txt(q - k);
+            if (b >= 0xC0u) return utf8_len(b) > (uint32_t)k ? (uint32_t)C_CONT : (uint32_t)C_P;
+            if (b < 0x80u) return C_P;
+        }
+        return C_P;
+    }
+    const uint32_t want = utf8_len(c0);
+    uint32_t len = 1;
+    while (len < want && q + (int)len < hi && !ts(q + (int)len) && (tx.txt(q + (int)len) & 0xC0u) == 0x80u) len++;
+    const uint32_t cls = len == want ? cp_class(T, decode_at(tx, q, c0)) : (uint32_t)C_P;
+    return cls | ((len - 1) << CB_LEN_SHIFT);
+}
+
 }  // namespace spl

@@ -64,3 +64,28 @@ def fuzz_string(rng: random.Random, max_atoms: int = 40) -> str:
 def fuzz_corpus(seed: int, count: int, max_atoms: int = 40) -> List[str]:
     rng = random.Random(seed)
     return [fuzz_string(rng, max_atoms) for _ in range(count)]
+
+
+def invalid_utf8_corpus(seed: int, count: int) -> List[bytes]:
+    """Byte strings that are NOT valid UTF-8: fuzz text with stray continuation bytes, truncated and
+    over-long sequences, lead bytes of every length (incl. 0xF8..0xFF), and runs of each."""
+    rng = random.Random(seed)
+    junk = [b"\x80", b"\xbf", b"\x80\x80\x80\x80\x80", b"\xc0", b"\xc1\x81", b"\xc3", b"\xe4", b"\xe4\xb8", b"\xe4\xb8\x96\x96",
+            b"\xf0", b"\xf0\x9f", b"\xf0\x9f\x8c", b"\xf0\x9f\x8c\x8d\x8d", b"\xf8\x88\x80\x80\x80", b"\xff", b"\xfe\xff",
+            b"\xed\xa0\x80", b"\xc0\x80", b"\xe0\x80\x80", b"\xf4\x90\x80\x80", b"\xc3\x28", b"\xa0\xa1", b"\xe2\x28\xa1"]
+    out = []
+    for _ in range(count):
+        parts = []
+        for _ in range(rng.randint(1, 12)):
+            r = rng.random()
+            if r < 0.45:
+                parts.append(fuzz_string(rng, 6).encode("utf-8"))
+            elif r < 0.85:
+                parts.append(rng.choice(junk) * rng.randint(1, 3))
+            else:
+                parts.append(bytes(rng.randrange(256) for _ in range(rng.randint(1, 6))))
+        b = b"".join(parts)
+        if rng.random() < 0.3 and b:
+            b = b[:rng.randrange(len(b)) + 1]                 # cut anywhere, also inside a character
+        out.append(b)
+    return out

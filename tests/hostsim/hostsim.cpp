@@ -42,20 +42,13 @@ struct WinAcc {   // class records of one window [0, n), sentinel at n; text rea
     }
 };
 
-// class records for text[0,n) treated as ONE text that starts at 0
+// class records for text[0,n) treated as ONE text that starts at 0: every byte through byte_record
+// (spl_scan.h), exactly as the kernels classify -- in parallel, each byte on its own
 static void classify(const Sim& s, const uint8_t* text, int n, std::vector<uint8_t>& recs) {
     recs.assign(n, 0);
     WinAcc tx{nullptr, text, n, 0, n};
-    for (int q = 0; q < n;) {
-        uint32_t b = text[q];
-        uint32_t len = utf8_len(b);
-        if (b >= 0x80 && b < 0xC0) len = 1;
-        if (q + (int)len > n) len = 1;
-        uint32_t cls = b < 0x80 ? cp_class(s.dt, b) : (len == 1 ? (uint32_t)C_P : cp_class(s.dt, decode_at(tx, q, b)));
-        recs[q] = (uint8_t)(cls | ((len - 1) << CB_LEN_SHIFT));
-        for (uint32_t i = 1; i < len; i++) recs[q + i] = C_CONT;
-        q += len;
-    }
+    for (int q = 0; q < n; q++)
+        recs[q] = (uint8_t)byte_record(s.dt, tx, [](int i) { return i == 0; }, [&](uint32_t c) { return cp_class(s.dt, c); }, q, 0, n);
     if (n) recs[0] |= CB_TSTART | CB_SYNC;
     uint32_t prev = C_EOT;
     for (int q = 0; q < n; q++) {
@@ -66,7 +59,38 @@ static void classify(const Sim& s, const uint8_t* text, int n, std::vector<uint8
     }
 }
 
+// the policy as a sequential definition (what oracle.c restates): for the cross-check of byte_record
+static void classify_seq(const Sim& s, const uint8_t* text, int n, std::vector<uint8_t>& recs) {
+    recs.assign(n, 0);
+    WinAcc tx{nullptr, text, n, 0, n};
+    for (int q = 0; q < n;) {
+        const uint32_t b = text[q];
+        uint32_t len = 1, cls;
+        if (b < 0x80) cls = cp_class(s.dt, b);
+        else if (b < 0xC0) cls = C_P;
+        else {
+            const uint32_t want = utf8_len(b);
+            while (len < want && q + (int)len < n && (text[q + len] & 0xC0) == 0x80) len++;
+            cls = len == want ? cp_class(s.dt, decode_at(tx, q, b)) : (uint32_t)C_P;
+        }
+        recs[q] = (uint8_t)(cls | ((len - 1) << CB_LEN_SHIFT));
+        for (uint32_t i = 1; i < len; i++) recs[q + i] = C_CONT;
+        q += len;
+    }
+}
+
 extern "C" {
+
+// 1 if the per-byte classification equals the sequential definition on this text
+int hs_classify_check(void* p, const uint8_t* text, int n) {
+    Sim* s = (Sim*)p;
+    std::vector<uint8_t> a, b;
+    classify(*s, text, n, a);
+    classify_seq(*s, text, n, b);
+    if (n) b[0] |= CB_TSTART | CB_SYNC;
+    for (int q = 0; q < n; q++) if ((a[q] & ~CB_SYNC) != (b[q] & ~CB_SYNC)) return 0;
+    return 1;
+}
 
 void* hs_create(const char* splv, const char* ucls, int pattern, char* errbuf, int errlen) {
     Sim* s = new Sim();

@@ -39,6 +39,8 @@ def lib():
         L.hs_split_sync.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         L.hs_split_masks.restype = ctypes.c_int
         L.hs_split_masks.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.hs_classify_check.restype = ctypes.c_int
+        L.hs_classify_check.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
         L.hs_encode.restype = ctypes.c_int
         L.hs_encode.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         _lib = L
@@ -53,6 +55,9 @@ class HostSim:
                                   pid, err, 256)
         if not self._h:
             raise ValueError(err.value.decode())
+
+    def classify_check(self, data: bytes) -> bool:
+        return bool(lib().hs_classify_check(self._h, data, len(data)))
 
     def info(self):
         a = np.zeros(8, dtype=np.uint32)

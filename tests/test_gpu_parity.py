@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from conftest import ROOT, VOCABS
-from fuzzgen import fuzz_corpus
+from fuzzgen import fuzz_corpus, invalid_utf8_corpus
 
 pytestmark = pytest.mark.gpu
 
@@ -82,6 +82,31 @@ def test_mistral_v3_special_ids_held_by_the_reference(golden_all):
     for text, ids in golden_all["_mistral_v3_with_special"]:
         assert t.encode_with_special(text) == ids, text
         assert t.decode(ids) == text
+
+
+@pytest.mark.parametrize("name", VOCABS)
+@pytest.mark.parametrize("geom", [0, 3, 4])
+def test_invalid_utf8_policy(coracle, name, geom):
+    """include/splintr_hip.h, "Text that is not valid UTF-8": the C ABI takes raw bytes; stray continuation
+    bytes, truncated / over-long sequences and impossible lead bytes -- also right at document boundaries
+    (a document ending in a truncated character followed by one that starts with continuation bytes) --
+    give the ids of the oracle's restatement of the policy, in every execution mode, and decode back to
+    the input bytes."""
+    from splintr_amd import Tokenizer, _ffi
+    t = Tokenizer.from_pretrained(name)
+    _ffi.lib().spl_debug_phases(t.handle, geom << 1, None)
+    docs = invalid_utf8_corpus(31415 + geom, 3000)
+    docs += [b"abc\xe4\xb8", b"\x96\x96 def", b"\xf0\x9f", b"\x8c\x8d", b"", b"\x80", b"\xe4", b"\xb8\x96"]
+    docs += [b"\x80" * 3000, b"\xe4\xb8" * 1500, (b"ab\xc3" * 400) + b"\n" + b"\xbf" * 700]
+    off = np.zeros(len(docs) + 1, dtype=np.uint64)
+    np.cumsum([len(d) for d in docs], out=off[1:])
+    blob = b"".join(docs)
+    ids, oo = t.encode_packed(blob, off)
+    o_ids, o_off = coracle(name).encode_packed(np.frombuffer(blob, dtype=np.uint8), off, threads=os.cpu_count() or 8)
+    assert np.array_equal(oo, o_off)
+    assert np.array_equal(ids, o_ids)
+    got = t._decode_batch_bytes([ids[int(oo[i]):int(oo[i + 1])].tolist() for i in range(len(docs))])
+    assert got == docs
 
 
 @pytest.mark.parametrize("name", VOCABS)

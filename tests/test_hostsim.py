@@ -4,7 +4,7 @@ forms, deferral contract at tiny windows, sync-point rules, table formats, the l
 import pytest
 
 from conftest import VOCABS
-from fuzzgen import fuzz_corpus
+from fuzzgen import fuzz_corpus, invalid_utf8_corpus
 from hostsim import HostSim
 
 _sims = {}
@@ -72,3 +72,22 @@ def test_mask_scanner_tiled_like_the_kernel(coracle, name):
         ref = c.split_bytes(b)
         for tb, rh in ((32, 32), (64, 32), (96, 64), (768, 224)):
             assert h.split_masks(b, tb, rh) == ref, (tb, rh, s)
+
+
+@pytest.mark.parametrize("name", ["cl100k_base", "o200k_base", "mistral_v3"])
+def test_invalid_utf8_policy(coracle, name):
+    """Bytes that are not UTF-8 (include/splintr_hip.h states the policy): the per-byte classification of
+    spl_scan.h equals the sequential definition, the scanner -- char-wise and on masks, tiled like the
+    kernel -- splits as the oracle's restatement of the policy does, ids agree, nothing is lost."""
+    from oracle import pyoracle as O
+    h, c = sim(name), coracle(name)
+    py = O.Oracle.from_pretrained(name, engine="regex")
+    for b in invalid_utf8_corpus(2718, 4000):
+        assert h.classify_check(b), b
+        ref = c.split_bytes(b)
+        assert h.split(b) == ref, b
+        assert h.split(b, 5) == ref, b
+        assert h.split_masks(b, 64, 32) == ref, b
+        ids = c.encode_bytes(b)
+        assert h.encode(b) == ids, b
+        assert py.decode_bytes(ids) == b, b

@@ -1,12 +1,11 @@
 #!/bin/bash
-# Build kernel variants for A/B runs on the GPU box:  tools/ab_build.sh name "-DFOO=1 ..." [name flags]...
-# Libraries land in _ab/<name>.so (git-ignored, shipped by gpurun); select with SPL_LIB_PATH.
+# Build A/B variants of the library into _ab/:  tools/ab_build.sh name "-DFLAG=1 ..." [name2 "flags2" ...]
+# (the default build is always made as _ab/lib_default.so as well)
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p _ab
-while [ $# -ge 2 ]; do
-  n=$1; f=$2; shift 2
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value $f -o _ab/$n.so splintr_amd/csrc/spl_api.hip splintr_amd/csrc/spl_tables.cpp &
-done
+build() { hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value $2 -o _ab/lib_$1.so splintr_amd/csrc/spl_api.hip splintr_amd/csrc/spl_tables.cpp 2>&1 | grep -E "error" || true; }
+build default "" &
+while [ $# -ge 2 ]; do build "$1" "$2" & shift 2; done
 wait
-ls -la _ab
+ls -la _ab/*.so
