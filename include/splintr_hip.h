@@ -94,8 +94,10 @@ uint32_t spl_n_devices(const spl_tokenizer* t);
 
 /* Host pipeline tuning: "chunk_bytes" (upper bound of one pipeline chunk, default 16 MiB),
  * "single_chunk_max_bytes" (batches up to this size run as one chunk, default 4 MiB),
- * "result_estimate_div" (first guess of the token count = bytes / div, default 2),
- * "subdoc_split" (0/1: balance the GPUs by cutting large documents at context-free boundaries). */
+ * "result_estimate_div" (first guess of the token count = bytes / div; default 0.375 tokens per byte),
+ * "subdoc_split" (0/1: balance the GPUs by cutting large documents at context-free boundaries),
+ * "direct_write" (0/1, default 1: one-chunk batches have the last kernel write the ids straight into
+ * the pinned result instead of copying them back). */
 int spl_set_option(spl_tokenizer* t, const char* name, int64_t value);
 
 /* One entry of the special_tokens map (src/core/tokenizer.rs:304, 429-434).  Call before the first

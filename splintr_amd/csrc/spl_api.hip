@@ -218,6 +218,7 @@ struct spl_tokenizer {
     uint64_t single_max = 4ull << 20;         // batches up to this size run as ONE chunk
     uint32_t est_div = 2;                     // first guess of the token count: n_bytes / est_div
     int subdoc = 1;                           // cut documents at context-free boundaries to balance the GPUs
+    int direct_write = 1;                     // one-chunk batches: the last kernel writes the ids straight into the pinned result
 };
 
 struct spl_result {
@@ -654,7 +655,8 @@ int lane_prepare(spl_tokenizer* tk, Lane& ln, const uint64_t* doc_off, uint64_t 
 }
 
 // producer: every chunk of one lane, in order (runs in the caller's thread for a single chunk)
-int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t* doc_off, uint32_t flags, bool src_pinned) {
+int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t* doc_off, uint32_t flags, bool src_pinned,
+                bool solo = false, uint32_t* ids_direct = nullptr) {
     Ctx* c = ln.c;
     HIP_TRY(hipSetDevice(c->device));
     uint64_t* const h_tot = (uint64_t*)c->h_tot.p;
@@ -675,8 +677,10 @@ int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t
         HIP_TRY(hipEventRecord(c->ev_h2d[sl], c->s_h2d));
         HIP_TRY(hipStreamWaitEvent(c->s_cmp, c->ev_h2d[sl], 0));
         uint64_t* oo = c->d_oo + ch.oo_at;
-        int rc = launch_all(tk, c, c->d_text[sl], nb, c->d_off[sl], nd, flags, c->d_ids + (ch.lo - ln.lo), nb + 16, oo, c->s_cmp);
+        int rc = launch_all(tk, c, c->d_text[sl], nb, c->d_off[sl], nd, flags, ids_direct ? ids_direct : c->d_ids + (ch.lo - ln.lo),
+                            nb + 16, oo, c->s_cmp);
         if (rc) return rc;
+        if (solo) break;                                   // (the batch is ONE chunk: the caller finishes on the compute stream itself)
         HIP_TRY(hipEventRecord(c->ev_cmp[sl], c->s_cmp));
         HIP_TRY(hipMemcpyAsync(&h_tot[k], oo + nd, 8, hipMemcpyDeviceToHost, c->s_cmp));
         HIP_TRY(hipEventRecord(c->ev_chunk[k], c->s_cmp));
@@ -737,19 +741,38 @@ int encode_host(spl_tokenizer* tk, const uint8_t* utf8, const uint64_t* doc_off,
     r->pool = tk->pool;
     r->n_docs = n_docs;
     r->off = (uint64_t*)tk->pool->get((n_docs + 1) * 8, r->off_cap);
-    uint64_t est = n_bytes / std::max<uint32_t>(tk->est_div, 1) + 4096;
+    uint64_t est = (tk->est_div == 2 ? n_bytes * 3 / 8 : n_bytes / std::max<uint32_t>(tk->est_div, 1)) + 4096;   // default: 0.375 tokens per byte
     if (est > n_bytes) est = n_bytes;
     r->ids = (uint32_t*)tk->pool->get((est + 16) * 4, r->ids_cap);
     if (!r->off || !r->ids) return fail(SPL_EDEVICE, "pinned result allocation failed");
 
-    // ---- one chunk: everything on the compute stream, ids copied back speculatively -------------------
+    // ---- one chunk: everything on the compute stream ---------------------------------------------------
     if (n_chunks == 1) {
         Lane& ln = lanes[0];
         Ctx* c = ln.c;
-        int rc = lane_submit(tk, ln, utf8, doc_off, flags, src_pinned);
-        if (rc) return rc;
         const Chunk& ch = ln.chunks[0];
         const uint64_t nd = ch.dhi - ch.dlo;                          // == n_docs
+        if (tk->direct_write && n_bytes) {
+            // the encoder's last kernel writes the ids straight into the pinned result over PCIe (posted,
+            // coalesced writes that overlap the kernel itself): no D2H copy of the ids, ONE synchronisation.
+            // The result must hold the worst case, one token per byte (the pool recycles it).
+            if (r->ids_cap < (n_bytes + 16) * 4) {
+                tk->pool->put(r->ids, r->ids_cap);
+                r->ids = (uint32_t*)tk->pool->get((n_bytes + 16) * 4, r->ids_cap);
+                if (!r->ids) return fail(SPL_EDEVICE, "pinned result allocation failed");
+            }
+            void* dptr = nullptr;
+            HIP_TRY(hipHostGetDevicePointer(&dptr, r->ids, 0));
+            int rc = lane_submit(tk, ln, utf8, doc_off, flags, src_pinned, true, (uint32_t*)dptr);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(r->off, c->d_oo + ch.oo_at, (nd + 1) * 8, hipMemcpyDeviceToHost, c->s_cmp));
+            HIP_TRY(hipStreamSynchronize(c->s_cmp));
+            r->n_tokens = r->off[nd];
+            return SPL_OK;
+        }
+        // ids copied back speculatively (a guess of their number), the rest -- if any -- after the count is known
+        int rc = lane_submit(tk, ln, utf8, doc_off, flags, src_pinned, true);
+        if (rc) return rc;
         const uint64_t spec = std::min<uint64_t>(r->ids_cap / 4, n_bytes);
         HIP_TRY(hipMemcpyAsync(r->off, c->d_oo + ch.oo_at, (nd + 1) * 8, hipMemcpyDeviceToHost, c->s_cmp));
         if (spec) HIP_TRY(hipMemcpyAsync(r->ids, c->d_ids, spec * 4, hipMemcpyDeviceToHost, c->s_cmp));
@@ -899,6 +922,7 @@ int spl_set_option(spl_tokenizer* t, const char* name, int64_t value) {
     else if (k == "single_chunk_max_bytes" && value >= 0) t->single_max = (uint64_t)value;
     else if (k == "result_estimate_div" && value >= 1) t->est_div = (uint32_t)value;
     else if (k == "subdoc_split") t->subdoc = value != 0;
+    else if (k == "direct_write") t->direct_write = value != 0;
     else return fail(SPL_EINVAL, "spl_set_option: unknown option or bad value: " + k);
     return SPL_OK;
 }

@@ -58,8 +58,11 @@ def test_result_buffer_growth(coracle):
     """A far too small first guess of the token count: the result moves to a larger pinned buffer
     in both the single-chunk and the multi-chunk path (digits: one token per 1..3 bytes)."""
     texts = ["7 8 9 1 2 3 4 5 6 " * 400 for _ in range(200)]
-    check(fresh("cl100k_base", result_estimate_div=64), "cl100k_base", texts, coracle)
+    check(fresh("cl100k_base", result_estimate_div=64, direct_write=0), "cl100k_base", texts, coracle)
     check(fresh("cl100k_base", result_estimate_div=64, chunk_bytes=1 << 16), "cl100k_base", texts, coracle)
+    # one-chunk batches by default have the last kernel write the ids straight into the pinned result
+    check(fresh("cl100k_base"), "cl100k_base", texts, coracle)
+    check(fresh("cl100k_base", direct_write=0), "cl100k_base", texts[:7], coracle)
 
 
 @pytest.mark.parametrize("ndev", [2, 3, 8])

@@ -31,7 +31,7 @@ def timed(fn, min_s=0.4, min_reps=3):
     return (time.perf_counter() - t0) / reps
 
 
-def measure(cfg: str, docs=None, python_surface=True, devices=None):
+def measure(cfg: str, docs=None, python_surface=True, devices=None, options=None):
     import torch
     from splintr_amd import Tokenizer, corpus, _ffi
     from splintr_amd.device import DeviceBatch, encode_device, reserve
@@ -42,6 +42,8 @@ def measure(cfg: str, docs=None, python_surface=True, devices=None):
     if devices:
         tok.set_devices(devices)
     L = _ffi.lib()
+    for k, v in (options or {}).items():
+        assert L.spl_set_option(tok.handle, k.encode(), int(v)) == 0, _ffi.last_error()
     bs = [t.encode("utf-8") for t in texts]
     off = np.zeros(len(bs) + 1, dtype=np.uint64)
     np.cumsum([len(b) for b in bs], out=off[1:])
@@ -86,5 +88,8 @@ def measure(cfg: str, docs=None, python_surface=True, devices=None):
 
 if __name__ == "__main__":
     cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
-    docs = int(sys.argv[2]) if len(sys.argv) > 2 else None
-    print(json.dumps(measure(cfg, docs)))
+    docs = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2] != "-" else None
+    opts = dict(a.split("=") for a in sys.argv[3:])
+    out = measure(cfg, docs, options=opts)
+    out["options"] = opts
+    print(json.dumps(out))
