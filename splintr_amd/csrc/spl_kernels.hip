@@ -544,9 +544,16 @@ __device__ __forceinline__ void group16_merge(const DeviceTables& T, const uint3
     if (own && ((alive >> gl) & 1u) && id != SPL_NO_RANK) emit(gl, id);
 }
 
+#ifdef SPL_DEBUG_STAMPS
+#define SPL_WT(i) do { if (wt && (threadIdx.x & 63) == 0) wt[i] = clock64(); } while (0)
+#else
+#define SPL_WT(i) do { } while (0)
+#endif
 template <class Emit>
 __device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const LdsAcc& tx, int p, int n, uint32_t* sub,
-                                                Emit emit) {
+                                                Emit emit, long long* wt = nullptr) {
+    (void)wt;
+    SPL_WT(0);
     const int lane = threadIdx.x & 63;
     const int gl = lane & 15;
     const int gbase = lane - gl;
@@ -559,6 +566,7 @@ __device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const Lds
     // which token lengths exist at all behind the lane's first two bytes: the other probes go to the
     // spare bucket (28 % fewer table lines for English text, 85 % for CJK)
     const uint32_t lm = own ? T.len_mask[w0 & 0xFFFFu] : 0u;
+    SPL_WT(1);
     {
         Quad qa[2], qb[2], qc[2], qd[3];
         const uint32_t ka = w0 & 0xFFFFu, kb = w0 & 0xFFFFFFu, ha = w1 & 0xFFu;
@@ -576,6 +584,7 @@ __device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const Lds
             row[3] = t8_finish(T, w0, ha, 5u, qd);
         }
     }
+    SPL_WT(2);
     if (SUB_LMAX >= 6 && __any(maxlen >= 6 && (lm & 0x70u))) {
         Quad qa[3], qb[3], qc[3];
         const uint32_t hb = w1 & 0xFFFFu, hc = w1 & 0xFFFFFFu;
@@ -590,7 +599,9 @@ __device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const Lds
     } else if (maxlen >= 6) {                                // nothing of 6..8 bytes starts in this wavefront's chunks
         row[4] = SPL_NO_RANK; row[5] = SPL_NO_RANK; row[6] = SPL_NO_RANK;
     }
+    SPL_WT(3);
     group16_merge(T, row, id, n, emit);
+    SPL_WT(4);
 }
 
 // The same merge loop for ONE chunk of up to 64 bytes per WAVEFRONT, one node per lane.  Everything
@@ -2222,11 +2233,19 @@ void k_pretok(DeviceTables T, Batch b) {
         // (tile-owned mode: always -- with the ranks tabulated a wavefront per chunk also wins on tiles
         //  dense with such chunks: 8 MB of the C3 mix 1.19 ms against 1.25 ms)
         const bool few_medium = DIRECT || m64 <= 2 * (NT / 64);
+#ifdef SPL_DEBUG_STAMPS
+        const long long ws_t0 = clock64();
+        uint32_t ws_nmed = 0, ws_nshort = 0;
+        long long ws_wt[5] = {0, 0, 0, 0, 0};
+#endif
         for (; !EXPORT_MEDIUM && few_medium;) {
             uint32_t it = 0;
             if (lane == 0) it = atomicAdd(&s_nq[3], 1u);
             it = __builtin_amdgcn_readfirstlane(it);
             if (it >= m64) break;
+#ifdef SPL_DEBUG_STAMPS
+            ws_nmed++;
+#endif
             if (DIRECT && SPL_MEDIUM_PRIO != SPL_MERGE_PRIO) __builtin_amdgcn_s_setprio(SPL_MEDIUM_PRIO);
             const uint32_t item = s_miss[G::C16 + it];
             const int p = (int)(item & 0xFFFFu);
@@ -2237,6 +2256,9 @@ void k_pretok(DeviceTables T, Batch b) {
         }
         if (DIRECT && SPL_MEDIUM_PRIO != SPL_MERGE_PRIO) __builtin_amdgcn_s_setprio(SPL_MERGE_PRIO);
         SPL_STAMP(9);
+#ifdef SPL_DEBUG_STAMPS
+        const long long ws_t1 = clock64();
+#endif
         // every 16-lane group pulls its own work: first the 17..64-byte chunks (four nodes per
         // lane), then the short ones (one node per lane)
         for (; !EXPORT_MEDIUM && !few_medium;) {
@@ -2258,17 +2280,40 @@ void k_pretok(DeviceTables T, Batch b) {
             it = __shfl(it, lane & ~15);
             const bool has = it < m16;
             if (!__any(has)) break;
+#ifdef SPL_DEBUG_STAMPS
+            ws_nshort++;
+#endif
             uint32_t item = 0;
             if (has) {
                 if (SORT_SHORT) { const uint32_t c = s_cpos[it]; item = (c & 0x3FFu) | (((c >> 10) + 1u) << 16); }
                 else item = s_miss[it];
             }
             const int p = (int)(item & 0xFFFFu);
+#ifdef SPL_DEBUG_STAMPS
+            long long* const wtp = (b.dbg && blockIdx.x == gridDim.x / 2 && ws_nshort == 1) ? ws_wt : nullptr;
+#else
+            long long* const wtp = nullptr;
+#endif
             bpe_group16_tab(T, LdsAcc{s_rec, s_txt}, p, has ? (int)(item >> 16) : 0, s_sub[tid >> 4],
                             [&](int i, uint32_t id) {
                                 put(p + i, id);
-                            });
+                            }, wtp);
         }
+#ifdef SPL_DEBUG_STAMPS
+        if (b.dbg && blockIdx.x == gridDim.x / 2 && (tid & 63) == 0) {
+            unsigned long long* r2 = b.dbg + 16 + 4 * (SPL_DEBUG_BLOCKS - 16 + 2 * (tid >> 6));
+            for (int k = 0; k < 5; k++) r2[k] = (unsigned long long)(ws_wt[k] - ws_t1);
+        }
+#endif
+#ifdef SPL_DEBUG_STAMPS
+        if (b.dbg && blockIdx.x == gridDim.x / 2 && (tid & 63) == 0) {      // per-wavefront record of the middle workgroup
+            unsigned long long* r = b.dbg + 16 + 4 * (SPL_DEBUG_BLOCKS - 8 + (tid >> 6));
+            r[0] = (unsigned long long)(ws_t1 - ws_t0);
+            r[1] = (unsigned long long)(clock64() - ws_t1);
+            r[2] = (unsigned long long)ws_nmed | ((unsigned long long)ws_nshort << 32);
+            r[3] = (unsigned long long)m16 | ((unsigned long long)m64 << 32);
+        }
+#endif
     }
     SPL_STAMP(10);
     __syncthreads();

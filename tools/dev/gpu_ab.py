@@ -1,6 +1,6 @@
 """Dev aid: step time of the bench batch (and optionally C3-like batches) for the library in SPL_LIB_PATH."""
 import ctypes, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

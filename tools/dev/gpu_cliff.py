@@ -1,6 +1,6 @@
 """Dev aid: cost of one pathological document (a 64 KB single-class run) inside the bench batch."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from splintr_amd import Tokenizer, corpus

@@ -1,5 +1,5 @@
 import os, sys, ctypes
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from splintr_amd import Tokenizer, _ffi

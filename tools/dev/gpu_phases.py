@@ -1,6 +1,6 @@
 """Dev aid: phase cycle stamps of one k_pretok workgroup + per-kernel event times on the bench batch."""
 import ctypes, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from splintr_amd import Tokenizer, corpus, _ffi
@@ -63,3 +63,12 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(200): encode_device(tok, batch)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 200
 print(f"step {dt * 1e6:.1f} us  -> {batch.n_bytes / dt / 1e6:.1f} MB/s")
+# per-wavefront merge-phase record of the middle workgroup (stamps builds)
+W = np.ctypeslib.as_array(rec).reshape(nb_, 4)[nb_ - 8:nb_ - 4]
+print("merge phase per wavefront of the middle workgroup (cycles): medium loop, short loop, #medium, #short pulls; misses m16 m64")
+for w in range(4):
+    print("   wave %d: %7d %7d   %d %d   (%d, %d)" % (w, W[w][0], W[w][1], W[w][2] & 0xFFFFFFFF, W[w][2] >> 32, W[w][3] & 0xFFFFFFFF, W[w][3] >> 32))
+W2 = np.ctypeslib.as_array(rec).reshape(nb_, 4)[nb_ - 16:nb_ - 8].reshape(4, 8).astype(np.int64)
+print("first short pull per wavefront, cycles since the short loop began: enter, bytes+len_mask loaded, batch 1 done, batch 2 done, merges done")
+for w in range(4):
+    print("   wave %d: %s" % (w, " ".join("%7d" % x for x in W2[w][:5])))

@@ -1,6 +1,6 @@
 """Dev aid: phase stamps of k_pretok (debug build) on a pure-CJK / pure-JSON batch."""
 import ctypes, os, sys, random
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from splintr_amd import Tokenizer, corpus, _ffi

@@ -1,6 +1,6 @@
 """Ad-hoc GPU bring-up script (run through gpurun); the real suite is tests/test_gpu_*.py."""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from splintr_amd import Tokenizer, corpus

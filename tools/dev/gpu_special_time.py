@@ -1,6 +1,6 @@
 """Dev aid: step time of encode_batch vs encode_batch_with_special on the bench batch."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from splintr_amd import Tokenizer, corpus

@@ -1,7 +1,7 @@
 """Dev aid for counter passes: run the bench batch with k_pretok cut off at a phase boundary
 (results are garbage by construction; only the instruction mix up to that phase is of interest)."""
 import ctypes, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from splintr_amd import Tokenizer, corpus, _ffi

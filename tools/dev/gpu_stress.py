@@ -1,6 +1,6 @@
 """Dev aid: randomized parity stress beyond the fixed seeds of the test suite (every mode, every vocabulary)."""
 import json, os, random, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import test_gpu_parity as tg

@@ -1,6 +1,6 @@
 """Dev aid: bench batch, steps alternating over TWO handles on two streams (consecutive steps overlap)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from splintr_amd import Tokenizer, corpus
