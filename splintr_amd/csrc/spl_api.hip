@@ -605,6 +605,9 @@ int lane_prepare(spl_tokenizer* tk, Lane& ln, const uint64_t* doc_off, uint64_t 
         ch.lo = d < dhi ? start_of(d) : ln.lo;
         ch.cont = (d == dlo) && cont;
         uint64_t e = d;
+        // (chunk sizes that ramp up at the start and down at the end -- a shorter first H2D and last D2H --
+        //  measured no better: C3 15.1 vs 15.8 GB/s, C4 17.2 vs 16.6, C5 14.9 vs 15.9; a chunk costs ~80 us of
+        //  host-side API work, so fewer, equal chunks win)
         while (e < dhi && (e == d || end_of(e) - ch.lo <= chunk_target)) e++;
         ch.dhi = e;
         ch.hi = e > d ? end_of(e - 1) : ch.lo;
