@@ -314,6 +314,7 @@ def main():
                          f"{'with' if best[2] else 'without'} the mutex-guarded 4096-entry memo that stands in for the "
                          f"reference's LRU); persistent pool pulling documents off a shared counter, CSR in/out"}
 
+    out = None
     if rank == 0:
         out = {
             "metric": "encode_batch MB/s (bytes in)", "value": round(value, 2), "unit": "MB/s",
@@ -330,9 +331,17 @@ def main():
             "roofline": roofline, "roofline_valu": roofline_valu, "throughputs": throughputs, "c4_strong": c4,
             "cpu_baseline": cpu, "pipelined": pipelined,
         }
-        print(json.dumps(out))
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+    # the JSON line is the LAST thing on stdout: whatever the C runtime still buffers (RCCL prints a
+    # version banner through stdio) goes out first
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 def run_c4(args, rank, world, local_rank, dev, use_dist):

@@ -7,8 +7,8 @@
  *   pack(texts)                        -> (text_addr, n_bytes, off_addr, n_docs)   pinned, valid until the next call
  *
  * The texts are UTF-8 encoded straight into a pinned staging buffer (spl_host_alloc: the GPU's
- * DMA engine reads it without another host copy); the result lists are filled from the pinned CSR
- * with cached int objects (ints are immutable, so sharing one object per id is unobservable).
+ * DMA engine reads it without another host copy); the result lists are filled from the pinned CSR,
+ * frequent ids with cached int objects (ints are immutable, so sharing one object per id is unobservable).
  * The GIL is held throughout, as in the reference (no allow_threads in src/python/bindings.rs).
  */
 #define PY_SSIZE_T_CLEAN
@@ -122,11 +122,15 @@ static Py_ssize_t pack_texts(PyObject* texts, const char* argname) {
     return n;
 }
 
+/* Token ids are ranks, and ranks follow frequency: the low ids are the tokens a text is mostly made of.
+ * Those get ONE shared int object each (a cache hit is an INCREF on a line that is hot in L2); a rare,
+ * high id gets a fresh object -- sharing would turn every use into a cache miss on a cold object. */
+#define INT_CACHE_MAX (1u << 16)
 static PyObject* int_of(uint32_t id) {      /* new reference */
+    if (id >= INT_CACHE_MAX) return PyLong_FromUnsignedLong(id);
     if ((size_t)id >= g_ints_cap) {
         size_t c = g_ints_cap ? g_ints_cap : 4096;
         while (c <= (size_t)id) c *= 2;
-        if (c > (1u << 22)) return PyLong_FromUnsignedLong(id);       /* ids are < 2^21 + specials: never taken */
         PyObject** q = (PyObject**)realloc(g_ints, c * sizeof(PyObject*));
         if (!q) return PyErr_NoMemory();
         memset(q + g_ints_cap, 0, (c - g_ints_cap) * sizeof(PyObject*));
