@@ -204,7 +204,7 @@ static void tail_alts(pattern_t *P) { /* \p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s
     alt_t a3 = {1, {SET(BIT(C_N), 1, 3)}};
     alt_t a4 = {3, {SET(BIT(C_SP), 0, 1), SET(M_ALL & ~(M_S | M_L | BIT(C_N)), 1, -1), SET(BIT(C_NL), 0, -1)}};
     alt_t a5 = {2, {SET(M_S, 0, -1), SET(BIT(C_NL), 1, -1)}};
-    alt_t a6 = {2, {SET(M_S, 1, -1), {IT_NOT_NONSPACE_AHEAD, 0, 0, 0}}};
+    alt_t a6 = {2, {SET(M_S, 1, -1), {IT_NOT_NONSPACE_AHEAD, 0, 0, 0, 0}}};
     alt_t a7 = {1, {SET(M_S, 1, -1)}};
     P->alt[P->nalts++] = a3;
     P->alt[P->nalts++] = a4;
@@ -214,7 +214,7 @@ static void tail_alts(pattern_t *P) { /* \p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s
 }
 static void pattern_cl100k(pattern_t *P) { /* tokenizer.rs:39 */
     P->nalts = 0;
-    alt_t a1 = {1, {{IT_CONTR, 0, 1, 1}}};
+    alt_t a1 = {1, {{IT_CONTR, 0, 1, 1, 0}}};
     alt_t a2 = {2, {SET(M_ALL & ~(BIT(C_NL) | M_L | BIT(C_N)), 0, 1), SET(M_L, 1, -1)}};
     P->alt[P->nalts++] = a1;
     P->alt[P->nalts++] = a2;
@@ -240,8 +240,8 @@ static void pattern_o200k(pattern_t *P) { /* tokenizer.rs:42 */
     uint32_t X = M_ALL & ~(BIT(C_NL) | M_L | BIT(C_N));
     uint32_t U = BIT(C_LU) | BIT(C_LT) | BIT(C_LM) | BIT(C_LO) | BIT(C_M);
     uint32_t W = BIT(C_LL) | BIT(C_LM) | BIT(C_LO) | BIT(C_M);
-    alt_t a1 = {4, {SET(X, 0, 1), SET(U, 0, -1), SET(W, 1, -1), {IT_CONTR, 0, 0, 1}}};
-    alt_t a2 = {4, {SET(X, 0, 1), SET(U, 1, -1), SET(W, 0, -1), {IT_CONTR, 0, 0, 1}}};
+    alt_t a1 = {4, {SET(X, 0, 1), SET(U, 0, -1), SET(W, 1, -1), {IT_CONTR, 0, 0, 1, 0}}};
+    alt_t a2 = {4, {SET(X, 0, 1), SET(U, 1, -1), SET(W, 0, -1), {IT_CONTR, 0, 0, 1, 0}}};
     P->alt[P->nalts++] = a1;
     P->alt[P->nalts++] = a2;
     tail_alts(P);
