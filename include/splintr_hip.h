@@ -101,10 +101,13 @@ uint32_t spl_n_devices(const spl_tokenizer* t);
 int spl_set_option(spl_tokenizer* t, const char* name, int64_t value);
 
 /* One entry of the special_tokens map (src/core/tokenizer.rs:304, 429-434).  Call before the first
- * encode.  Literals must be non-empty and at most 32 bytes, and no occurrence of one may overlap an
- * occurrence of another (no literal contains another, no proper suffix of one is a prefix of
- * another or of itself): then Aho-Corasick's non-overlapping leftmost semantics reduce to "every
- * occurrence matches", which is what the device scan implements.  All pretrained tables qualify. */
+ * encode.  Literals are non-empty and at most 255 bytes; adding a literal again replaces its id.
+ * Matching follows the reference's matcher (Aho-Corasick, MatchKind::Standard, non-overlapping
+ * find_iter, tokenizer.rs:849-869): from the end of the previous match, the occurrence that ends
+ * first, the longest one on a tie.  Sets in which no two occurrences can overlap (no literal
+ * contains another, no proper suffix of one is a prefix of another or of itself, all literals <= 32
+ * bytes -- every pretrained table) take a one-launch scan in which every occurrence is a match; any
+ * other set takes a two-launch matcher (candidate ends, then a per-document walk). */
 int spl_add_special(spl_tokenizer* t, const uint8_t* literal, size_t len, uint32_t id);
 
 /* Tokenizer::vocab_size (src/core/tokenizer.rs:964-972): max id over vocab and specials, plus 1. */

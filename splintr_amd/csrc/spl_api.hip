@@ -211,6 +211,7 @@ struct spl_tokenizer {
     std::vector<Special> specials;
     uint32_t max_special_id = 0;
     bool special_newline = false;             // a literal contains '\n': no sub-document cuts with SPL_WITH_SPECIAL
+    bool special_general = false;             // occurrences can overlap, or a literal exceeds SP_MAXLEN: the two-launch general matcher
     std::vector<std::unique_ptr<Ctx>> ctx;
     std::shared_ptr<PinnedPool> pool = std::make_shared<PinnedPool>();
     // host pipeline tuning (spl_set_option)
@@ -280,7 +281,7 @@ int reserve(Ctx* t, uint64_t max_bytes, uint64_t max_docs) {
     t->free_workspace();
     const size_t nblk = (size_t)(nb / RANK_BLK) + 2;
     t->bitmap_words = nblk * 32 + 64;
-    t->zero_words = 3 * t->bitmap_words + QCOUNT_WORDS;
+    t->zero_words = 4 * t->bitmap_words + QCOUNT_WORDS;      // tbits | tstart | skip | spcand, then the queue counters
     HIP_TRY(hipMalloc((void**)&t->d_zero, t->zero_words * 4));
     HIP_TRY(hipMalloc((void**)&t->d_stage, (nb + 8192) * 4));
     HIP_TRY(hipMalloc((void**)&t->d_rank, (nb + 8192) * 12));   // ranks + two words of aux per byte
@@ -314,15 +315,32 @@ int reserve(Ctx* t, uint64_t max_bytes, uint64_t max_docs) {
 
 int upload_specials(spl_tokenizer* tk, Ctx* t) {
     if (t->sp_uploaded) return SPL_OK;
-    // 32-byte header: the set of first bytes (256 bits); then one record per literal
-    std::vector<uint8_t> recs(SP_HDR + tk->specials.size() * SP_REC + 16, 0);
-    for (size_t k = 0; k < tk->specials.size(); k++) {
-        const uint8_t c0 = (uint8_t)tk->specials[k].lit[0];
-        recs[c0 >> 3] |= (uint8_t)(1u << (c0 & 7));
-        uint8_t* r = recs.data() + SP_HDR + k * SP_REC;
-        r[0] = (uint8_t)tk->specials[k].lit.size();
-        memcpy(r + 4, &tk->specials[k].id, 4);
-        memcpy(r + 8, tk->specials[k].lit.data(), tk->specials[k].lit.size());
+    std::vector<uint8_t> recs;
+    if (!tk->special_general) {
+        // 32-byte header: the set of FIRST bytes (256 bits); then one record per literal
+        recs.assign(SP_HDR + tk->specials.size() * SP_REC + 16, 0);
+        for (size_t k = 0; k < tk->specials.size(); k++) {
+            const uint8_t c0 = (uint8_t)tk->specials[k].lit[0];
+            recs[c0 >> 3] |= (uint8_t)(1u << (c0 & 7));
+            uint8_t* r = recs.data() + SP_HDR + k * SP_REC;
+            r[0] = (uint8_t)tk->specials[k].lit.size();
+            memcpy(r + 4, &tk->specials[k].id, 4);
+            memcpy(r + 8, tk->specials[k].lit.data(), tk->specials[k].lit.size());
+        }
+    } else {
+        // general sets (k_special_ends / k_special_select): header = set of LAST bytes, records
+        // {len, id, blob offset, last byte}, then the literal bytes
+        const size_t n = tk->specials.size();
+        recs.assign(SP_HDR + n * SPG_REC, 0);
+        for (size_t k = 0; k < n; k++) {
+            const std::string& lit = tk->specials[k].lit;
+            const uint8_t cl = (uint8_t)lit.back();
+            recs[cl >> 3] |= (uint8_t)(1u << (cl & 7));
+            const uint32_t rec[4] = {(uint32_t)lit.size(), tk->specials[k].id, (uint32_t)(recs.size() - (SP_HDR + n * SPG_REC)), cl};
+            memcpy(recs.data() + SP_HDR + k * SPG_REC, rec, 16);
+            recs.insert(recs.end(), lit.begin(), lit.end());
+        }
+        recs.resize(recs.size() + 16, 0);
     }
     HIP_TRY(hipDeviceSynchronize());
     hipFree(t->d_sp_lits);
@@ -383,8 +401,11 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
     const size_t uw = (size_t)b.n_blk * 32 + 32;
     // bitmaps and queue counters packed back to back for THIS batch size: one memset clears them
     b.tbits = t->d_zero; b.tstart = t->d_zero + uw;
+    const bool general = special && tk->special_general;
+    const size_t nbm = special ? (general ? 4 : 3) : 2;             // bitmaps in use for THIS call
     b.skip = special ? t->d_zero + 2 * uw : nullptr;
-    b.qcount = t->d_zero + (special ? 3 : 2) * uw;
+    b.spcand = general ? t->d_zero + 3 * uw : nullptr;
+    b.qcount = t->d_zero + nbm * uw;
     t->last_qcount = b.qcount;
     b.sp_lits = t->d_sp_lits; b.n_special = special ? (uint32_t)tk->specials.size() : 0u;
     b.stage = t->d_stage; b.rank_scr = t->d_rank; b.aux = t->d_aux;
@@ -441,7 +462,7 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
         if (special) {
             // the three bitmaps are cleared per call; documents and literals are marked by the
             // multi-pass kernels, the tile kernel reads the bitmaps on top of its document search
-            HIP_TRY(hipMemsetAsync(t->d_zero, 0, (3 * uw + QCOUNT_WORDS) * 4, s));
+            HIP_TRY(hipMemsetAsync(t->d_zero, 0, (nbm * uw + QCOUNT_WORDS) * 4, s));
             t->bitmap_dirty = true;
         } else if (t->bitmap_dirty) {
             HIP_TRY(hipMemsetAsync(t->d_zero, 0, t->zero_words * 4, s));
@@ -458,7 +479,11 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
         if (special && n_docs) hipLaunchKernelGGL(k_mark_docs, dim3((uint32_t)((n_docs + 255) / 256)), dim3(256), 0, s, b);
         MARK(KI_SPECIAL);
         if (special && n_bytes) {
-            hipLaunchKernelGGL(k_special_scan, dim3((uint32_t)((n_bytes + 255) / 256)), dim3(256), 0, s, b);
+            if (!general) hipLaunchKernelGGL(k_special_scan, dim3((uint32_t)((n_bytes + 255) / 256)), dim3(256), 0, s, b);
+            else {
+                hipLaunchKernelGGL(k_special_ends, dim3((uint32_t)((n_bytes + 255) / 256)), dim3(256), 0, s, b);
+                hipLaunchKernelGGL(k_special_select, dim3((uint32_t)((n_docs + 255) / 256)), dim3(256), 0, s, b);
+            }
         }
         MARK(KI_PRETOK);
         if (ntiles) hipLaunchKernelGGL((k_pretok<SPL_TILE_SMALL, false, true>), dim3(ntiles), dim3(NT), 0, s, t->dt, b);
@@ -469,11 +494,15 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
     } else {
     t->bitmap_dirty = true;
     MARK(KI_MARK);
-    HIP_TRY(hipMemsetAsync(t->d_zero, 0, ((special ? 3 : 2) * uw + QCOUNT_WORDS) * 4, s));
+    HIP_TRY(hipMemsetAsync(t->d_zero, 0, (nbm * uw + QCOUNT_WORDS) * 4, s));
     if (n_docs) hipLaunchKernelGGL(k_mark_docs, dim3((uint32_t)((n_docs + 255) / 256)), dim3(256), 0, s, b);
     MARK(KI_SPECIAL);
     if (special && n_bytes) {
-        hipLaunchKernelGGL(k_special_scan, dim3((uint32_t)((n_bytes + 255) / 256)), dim3(256), 0, s, b);
+        if (!general) hipLaunchKernelGGL(k_special_scan, dim3((uint32_t)((n_bytes + 255) / 256)), dim3(256), 0, s, b);
+        else {
+            hipLaunchKernelGGL(k_special_ends, dim3((uint32_t)((n_bytes + 255) / 256)), dim3(256), 0, s, b);
+            hipLaunchKernelGGL(k_special_select, dim3((uint32_t)((n_docs + 255) / 256)), dim3(256), 0, s, b);
+        }
     }
     MARK(KI_PRETOK);
     if (ntiles) {
@@ -932,27 +961,36 @@ int spl_set_option(spl_tokenizer* t, const char* name, int64_t value) {
 
 int spl_add_special(spl_tokenizer* t, const uint8_t* literal, size_t len, uint32_t id) {
     if (!t || !literal || len == 0) return fail(SPL_EINVAL, "spl_add_special: bad argument");
-    if (len > (size_t)SP_MAXLEN) return fail(SPL_EINVAL, "spl_add_special: literal longer than 32 bytes");
+    if (len > 255) return fail(SPL_EINVAL, "spl_add_special: literal longer than 255 bytes");
     if (id > 0x7FFFFFFFu) return fail(SPL_EINVAL, "spl_add_special: id out of range");
     const std::string lit((const char*)literal, len);
-    // The device scan treats every occurrence as a match, which equals Aho-Corasick's
-    // non-overlapping Standard semantics only if no two occurrences can ever overlap.
-    auto overlaps = [](const std::string& a, const std::string& b) {
-        if (a.find(b) != std::string::npos || b.find(a) != std::string::npos) return true;
-        for (size_t k = 1; k < a.size() && k < b.size(); k++) {
-            if (a.compare(a.size() - k, k, b, 0, k) == 0) return true;   // suffix of a == prefix of b
-            if (b.compare(b.size() - k, k, a, 0, k) == 0) return true;
-        }
-        return false;
-    };
-    for (size_t k = 1; k < lit.size(); k++)
-        if (lit.compare(lit.size() - k, k, lit, 0, k) == 0)
-            return fail(SPL_EINVAL, "spl_add_special: literal can overlap itself");
-    for (const auto& sp : t->specials)
-        if (overlaps(sp.lit, lit)) return fail(SPL_EINVAL, "spl_add_special: literal can overlap '" + sp.lit + "'");
-    t->specials.push_back(Special{lit, id});
+    bool replaced = false;
+    for (auto& sp : t->specials)
+        if (sp.lit == lit) { sp.id = id; replaced = true; }       // a map: the later insert wins
+    if (!replaced) {
+        // The one-launch scan (k_special_scan) treats every occurrence as a match, which equals
+        // Aho-Corasick's non-overlapping Standard semantics only if no two occurrences can ever overlap
+        // (no literal contains another, no proper suffix of one is a prefix of another or of itself);
+        // any other set -- or a literal beyond SP_MAXLEN bytes -- takes the general two-launch matcher.
+        auto overlaps = [](const std::string& a, const std::string& b) {
+            if (a.find(b) != std::string::npos || b.find(a) != std::string::npos) return true;
+            for (size_t k = 1; k < a.size() && k < b.size(); k++) {
+                if (a.compare(a.size() - k, k, b, 0, k) == 0) return true;   // suffix of a == prefix of b
+                if (b.compare(b.size() - k, k, a, 0, k) == 0) return true;
+            }
+            return false;
+        };
+        bool general = len > (size_t)SP_MAXLEN;
+        for (size_t k = 1; k < lit.size() && !general; k++)
+            general = lit.compare(lit.size() - k, k, lit, 0, k) == 0;    // the literal can overlap itself
+        for (const auto& sp : t->specials)
+            if (!general && overlaps(sp.lit, lit)) general = true;
+        if (general) t->special_general = true;
+        t->specials.push_back(Special{lit, id});
+    }
     for (auto& c : t->ctx) { c->sp_uploaded = false; c->dec_uploaded = false; }
-    t->max_special_id = std::max(t->max_special_id, id);
+    t->max_special_id = 0;
+    for (const auto& sp : t->specials) t->max_special_id = std::max(t->max_special_id, sp.id);
     if (lit.find('\n') != std::string::npos) t->special_newline = true;
     return SPL_OK;
 }

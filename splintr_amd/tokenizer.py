@@ -99,8 +99,8 @@ class Tokenizer:
     * `pattern` must be one of CL100K_BASE_PATTERN, O200K_BASE_PATTERN (= LLAMA3_PATTERN) or
       MISTRAL_V3_PATTERN -- the GPU scanner implements these, there is no regex engine;
     * the vocabulary must contain all 256 single bytes and ids below 2**21;
-    * special-token literals are at most 32 bytes and must not be able to overlap each other
-      (all pretrained tables qualify).
+    * special-token literals are at most 255 bytes (any set: literals that contain or chain into one
+      another are matched as the reference's Aho-Corasick matcher does).
     Extensions: `device=` / `devices=` select the GPU(s), `byte_level=True` is the reference's
     `from_bytes_byte_level`; the vocabulary may also be this repo's packed SPLV container.
     """

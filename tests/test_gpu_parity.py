@@ -109,6 +109,38 @@ def test_invalid_utf8_policy(coracle, name, geom):
     assert got == docs
 
 
+@pytest.mark.parametrize("geom", [0, 3])
+def test_special_token_sets_whose_occurrences_overlap(geom):
+    """A user-supplied special-token map is arbitrary (src/core/tokenizer.rs:304, 429-434): literals that
+    contain one another, that chain (a suffix of one is a prefix of another or of itself), and literals
+    longer than the fast scan's 32 bytes take the general matcher (k_special_ends / k_special_select) and
+    give what Aho-Corasick's Standard, non-overlapping find_iter gives: the earliest-ending occurrence from
+    the end of the previous match, the longest one on a tie (restated in oracle/pyoracle.py)."""
+    from splintr_amd import Tokenizer, _ffi, CL100K_BASE_PATTERN
+    from oracle import pyoracle as O
+    special = {"<|a|>": 100300, "<|a|>x": 100301, "a|><": 100302, "|>": 100303, "ab": 100304, "abc": 100305,
+               "bcd": 100306, "aa": 100307, "aaa": 100308, "<|" + "long" * 20 + "|>": 100309, "\n\n": 100310, "é": 100311}
+    with open(os.path.join(ROOT, "splintr_amd", "data", "cl100k_base.splv"), "rb") as f:
+        blob = f.read()
+    t = Tokenizer.from_bytes(blob, CL100K_BASE_PATTERN, special)
+    _ffi.lib().spl_debug_phases(t.handle, geom << 1, None)
+    enc, _ = O.load_splv(os.path.join(ROOT, "splintr_amd", "data", "cl100k_base.splv"))
+    o = O.Oracle(enc, O.CL100K_BASE_PATTERN, False, special, engine="regex")
+    rng = random.Random(99 + geom)
+    atoms = list(special) + ["a", "b", "c", "d", "x", "<", "|", ">", " ", "\n", "hello ", "é", "世界", "<|a", "|>x", "aaaa", "abcd", "<|a|"]
+    texts = ["".join(rng.choice(atoms) for _ in range(rng.randint(0, 40))) for _ in range(1500)]
+    texts += ["<|a|>x<|a|>", "abcd", "aaaaa", "aaaaaa", "<|a|><|a|>x|>", "a|><|a|>", "<|" + "long" * 20 + "|>!", "", "|>"]
+    got = t.encode_batch_with_special(texts)
+    for s_, g in zip(texts, got):
+        assert g == o.encode_with_special(s_), s_
+    # without the flag the literals are plain text, and decode gives the literal back for a special id
+    assert t.encode_batch(texts[:50]) == [o.encode(s_) for s_ in texts[:50]]
+    assert t.decode([100309]) == "<|" + "long" * 20 + "|>"
+    # a literal given twice keeps the later id (a map)
+    assert _ffi.lib().spl_add_special(t.handle, b"ab", 2, 100399) == 0
+    assert t.encode_with_special("ab") == [100399]
+
+
 @pytest.mark.parametrize("name", VOCABS)
 def test_surface(name):
     t = tok(name)

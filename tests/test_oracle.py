@@ -155,6 +155,26 @@ def test_special_literals_cannot_overlap():
                         assert a[-k:] != b[:k], (name, a, b)
 
 
+def test_overlapping_special_sets_two_restatements_agree():
+    """Literal sets whose occurrences can overlap (user maps): the Python and the C restatement of the
+    reference's matcher (earliest end from the previous match's end, longest on a tie) agree."""
+    import random
+    from oracle import coracle as C
+    extra = {"<|a|>": 100300, "<|a|>x": 100301, "a|><": 100302, "|>": 100303, "ab": 100304, "abc": 100305,
+             "bcd": 100306, "aa": 100307, "aaa": 100308, "\n\n": 100310}
+    c = C.COracle("cl100k_base")
+    for lit, tid in extra.items():
+        b = lit.encode()
+        C.lib().orc_add_special(c._h, b, len(b), tid)
+    py = O.Oracle.from_pretrained("cl100k_base", engine="regex")
+    py.special_tokens.update(extra)
+    rng = random.Random(5)
+    atoms = list(extra) + ["a", "b", "c", "d", "x", "<", "|", ">", " ", "\n", "hello ", "<|endoftext|>", "<|a", "aaaa"]
+    for _ in range(800):
+        s = "".join(rng.choice(atoms) for _ in range(rng.randint(0, 30)))
+        assert c.encode_with_special(s) == py.encode_with_special(s), s
+
+
 def test_special_tokens(coracle):
     c = coracle("cl100k_base")                         # tests/cl100k.rs:104-186
     t = c.encode_with_special("Hello<|endoftext|>World")
