@@ -826,6 +826,10 @@ int encode_host(spl_tokenizer* tk, const uint8_t* utf8, const uint64_t* doc_off,
 
     // ---- several chunks: a producer thread per lane, this thread places the results ------------------
     std::vector<std::thread> producers;
+    struct Joiner {                                         // whatever happens below, no producer outlives the lanes
+        std::vector<std::thread>& v;
+        ~Joiner() { for (auto& th : v) if (th.joinable()) th.join(); }
+    } joiner{producers};
     for (size_t l = 0; l < nl; l++) {
         Lane* ln = &lanes[l];
         producers.emplace_back([=] {
@@ -1037,11 +1041,15 @@ int spl_encode_batch(spl_tokenizer* t, const uint8_t* utf8, const uint64_t* doc_
     for (uint64_t d = 0; d < n_docs; d++)
         if (doc_off[d + 1] < doc_off[d]) return fail(SPL_EINVAL, "spl_encode_batch: doc_off must be non-decreasing");
     if (doc_off[n_docs] && !utf8) return fail(SPL_EINVAL, "spl_encode_batch: null text");
-    std::unique_ptr<spl_result> r(new spl_result());
-    int rc = encode_host(t, utf8, doc_off, n_docs, flags, r.get());
-    if (rc) return rc;
-    *out = r.release();
-    return SPL_OK;
+    try {
+        std::unique_ptr<spl_result> r(new spl_result());
+        int rc = encode_host(t, utf8, doc_off, n_docs, flags, r.get());
+        if (rc) return rc;
+        *out = r.release();
+        return SPL_OK;
+    } catch (const std::exception& e) {                      // std::bad_alloc, std::system_error (thread creation): no exception crosses the C ABI
+        return fail(SPL_EDEVICE, std::string("spl_encode_batch: ") + e.what());
+    }
 }
 
 const uint32_t* spl_result_tokens(const spl_result* r) { return r ? r->ids : nullptr; }
