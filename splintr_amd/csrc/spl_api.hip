@@ -152,7 +152,6 @@ struct Ctx {
     uint64_t slot_cap_bytes = 0, slot_cap_docs = 0;
     uint32_t* d_ids = nullptr; uint64_t ids_cap = 0;         // the lane's ids, chunk c at its byte offset
     uint64_t* d_oo = nullptr; uint64_t oo_cap = 0;           // chunk-local output offsets, chunk after chunk
-    unsigned long long* d_gbase = nullptr;                   // [2] running token count of a streamed batch (two parities)
     Pinned h_text[NSLOT], h_off[NSLOT], h_tot;
     hipEvent_t ev_h2d[NSLOT] = {nullptr, nullptr, nullptr}, ev_cmp[NSLOT] = {nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ev_chunk;
@@ -194,7 +193,7 @@ struct Ctx {
         hipFree((void*)dt.long_tab); hipFree((void*)dt.key_blob); hipFree((void*)dt.pair_tab);
         hipFree((void*)dt.byte_id); hipFree((void*)dt.p8_tab); hipFree((void*)dt.len_mask);
         hipFree((void*)d_tok_off); hipFree((void*)d_tok_bytes); hipFree(d_sp_lits);
-        hipFree(d_ids); hipFree(d_oo); hipFree(d_gbase);
+        hipFree(d_ids); hipFree(d_oo);
         hipFree(d_dec_ids); hipFree(d_dec_blk); hipFree(d_dec_idoff); hipFree(d_dec_out); hipFree(d_dec_first); hipFree(d_dec_docoff);
         if (ev_ready) for (auto& e : ev) (void)hipEventDestroy(e);
         for (int i = 0; i < NSLOT; i++) { if (ev_h2d[i]) (void)hipEventDestroy(ev_h2d[i]); if (ev_cmp[i]) (void)hipEventDestroy(ev_cmp[i]); }
@@ -381,12 +380,10 @@ int upload_decode(spl_tokenizer* tk, Ctx* t) {
 }
 
 struct SlabOut { uint32_t* d_slab = nullptr; uint64_t cap_words = 0, max_docs = 0; };
-// host pipeline on one GPU: the chunk's place in the whole result is known ON THE DEVICE (see Batch::gbase_in)
-struct StreamOut { const unsigned long long* gbase_in = nullptr; unsigned long long* gbase_out = nullptr; uint64_t* off_host = nullptr; };
 
 int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off, uint64_t n_docs,
                uint32_t flags, uint32_t* d_ids, uint64_t ids_cap, uint64_t* d_out_off, hipStream_t s,
-               const SlabOut* so = nullptr, const StreamOut* st = nullptr) {
+               const SlabOut* so = nullptr) {
     if (((uintptr_t)d_utf8 & 15) != 0) return fail(SPL_EINVAL, "text buffer must be 16-byte aligned");
     const bool special = (flags & SPL_WITH_SPECIAL) && !tk->specials.empty();
     if (special) { int rc0 = upload_specials(tk, t); if (rc0) return rc0; }
@@ -398,7 +395,6 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
         for (auto& e : t->ev) HIP_TRY(hipEventCreate(&e));
         t->ev_ready = true;
     }
-    if (st && (t->force_tile != 0 || n_bytes > SPL_DIRECT_MAX_BYTES)) return fail(SPL_EINVAL, "streamed chunks need tile-owned mode");
     Batch b{};
     b.text = d_utf8; b.n_bytes = (uint32_t)n_bytes; b.doc_off = d_doc_off; b.n_docs = (uint32_t)n_docs;
     b.n_blk = (uint32_t)(n_bytes / RANK_BLK + 1);
@@ -475,10 +471,6 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
         b.tdesc = t->d_tdesc; b.tile_ids = t->d_tile_ids; b.tctl = t->d_tctl;
         b.tgroups = t->tgroups; b.tpar = t->tpar; b.tslot = (uint32_t)TileGeom<SPL_TILE_SMALL>::Wv + 1u;
         if (so && ntiles) { b.slab = so->d_slab; b.slab_cap = (uint32_t)so->cap_words; b.slab_max_docs = (uint32_t)so->max_docs; }
-        if (st) {
-            if (!ntiles) return fail(SPL_EINVAL, "streamed chunks must not be empty");
-            b.gbase_in = st->gbase_in; b.gbase_out = st->gbase_out; b.off_host = st->off_host;
-        }
         if (ntiles) t->tpar ^= 1u;              // k_tile_out zeroes the other parity's sums for the next call
         if (!special) b.tstart = nullptr;
         b.qcount = nullptr;
@@ -696,7 +688,7 @@ int lane_prepare(spl_tokenizer* tk, Lane& ln, const uint64_t* doc_off, uint64_t 
 
 // producer: every chunk of one lane, in order (runs in the caller's thread for a single chunk)
 int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t* doc_off, uint32_t flags, bool src_pinned,
-                bool solo = false, uint32_t* ids_direct = nullptr, uint64_t ids_direct_cap = 0, uint64_t* off_direct = nullptr) {
+                bool solo = false, uint32_t* ids_direct = nullptr) {
     Ctx* c = ln.c;
     HIP_TRY(hipSetDevice(c->device));
     uint64_t* const h_tot = (uint64_t*)c->h_tot.p;
@@ -717,17 +709,8 @@ int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t
         HIP_TRY(hipEventRecord(c->ev_h2d[sl], c->s_h2d));
         HIP_TRY(hipStreamWaitEvent(c->s_cmp, c->ev_h2d[sl], 0));
         uint64_t* oo = c->d_oo + ch.oo_at;
-        int rc;
-        if (off_direct) {          // streamed: ids and offsets of every chunk go straight to their place in the pinned result
-            StreamOut st;
-            st.gbase_in = c->d_gbase + (k & 1); st.gbase_out = c->d_gbase + ((k + 1) & 1); st.off_host = off_direct + ch.dlo;
-            rc = launch_all(tk, c, c->d_text[sl], nb, c->d_off[sl], nd, flags, ids_direct, ids_direct_cap, oo, c->s_cmp, nullptr, &st);
-            if (rc) return rc;
-            HIP_TRY(hipEventRecord(c->ev_cmp[sl], c->s_cmp));
-            continue;
-        }
-        rc = launch_all(tk, c, c->d_text[sl], nb, c->d_off[sl], nd, flags, ids_direct ? ids_direct : c->d_ids + (ch.lo - ln.lo),
-                        nb + 16, oo, c->s_cmp);
+        int rc = launch_all(tk, c, c->d_text[sl], nb, c->d_off[sl], nd, flags, ids_direct ? ids_direct : c->d_ids + (ch.lo - ln.lo),
+                            nb + 16, oo, c->s_cmp);
         if (rc) return rc;
         if (solo) break;                                   // (the batch is ONE chunk: the caller finishes on the compute stream itself)
         HIP_TRY(hipEventRecord(c->ev_cmp[sl], c->s_cmp));
@@ -841,39 +824,7 @@ int encode_host(spl_tokenizer* tk, const uint8_t* utf8, const uint64_t* doc_off,
         return SPL_OK;
     }
 
-    // ---- several chunks on ONE GPU: streamed ---------------------------------------------------------------
-    // Every chunk's last kernel knows, on the device, how many tokens the chunks before it produced (the
-    // previous chunk's k_tile_out leaves the running count), so it writes its ids and its documents' offsets
-    // straight to their place in the pinned result over PCIe.  No per-chunk synchronisation, no D2H copies,
-    // no rebasing launch, no second thread: the host only feeds H2D copies and launches and waits ONCE.
-    {
-        bool streamable = nl == 1 && tk->direct_write && lanes[0].c->force_tile == 0;
-        for (const Chunk& ch : lanes[0].chunks) streamable = streamable && ch.hi > ch.lo && ch.hi - ch.lo <= SPL_DIRECT_MAX_BYTES && !ch.cont;
-        if (streamable) {
-            Lane& ln = lanes[0];
-            Ctx* c = ln.c;
-            if (r->ids_cap < (n_bytes + 16) * 4) {                      // worst case: one token per byte
-                tk->pool->put(r->ids, r->ids_cap);
-                r->ids = (uint32_t*)tk->pool->get((n_bytes + 16) * 4, r->ids_cap);
-                if (!r->ids) return fail(SPL_EDEVICE, "pinned result allocation failed");
-            }
-            if (!c->d_gbase) HIP_TRY(hipMalloc((void**)&c->d_gbase, 16));
-            void *dids = nullptr, *doff = nullptr;
-            HIP_TRY(hipHostGetDevicePointer(&dids, r->ids, 0));
-            HIP_TRY(hipHostGetDevicePointer(&doff, r->off, 0));
-            HIP_TRY(hipMemsetAsync(c->d_gbase, 0, 16, c->s_cmp));
-            int rc = lane_submit(tk, ln, utf8, doc_off, flags, src_pinned, false, (uint32_t*)dids, n_bytes + 16, (uint64_t*)doff);
-            if (rc) { (void)hipStreamSynchronize(c->s_cmp); return rc; }
-            uint64_t* const h_tot = (uint64_t*)c->h_tot.p;
-            HIP_TRY(hipMemcpyAsync(&h_tot[0], c->d_gbase + (ln.chunks.size() & 1), 8, hipMemcpyDeviceToHost, c->s_cmp));
-            HIP_TRY(hipStreamSynchronize(c->s_cmp));
-            r->off[n_docs] = h_tot[0];
-            r->n_tokens = h_tot[0];
-            return SPL_OK;
-        }
-    }
-
-    // ---- several chunks, several GPUs: a producer thread per lane, this thread places the results -----------
+    // ---- several chunks: a producer thread per lane, this thread places the results ------------------
     std::vector<std::thread> producers;
     struct Joiner {                                         // whatever happens below, no producer outlives the lanes
         std::vector<std::thread>& v;

@@ -99,11 +99,6 @@ struct Batch {
     // optional second copy of the result, laid out as a ragged all-gather slab (k_gatherv_pack's
     // format): k_tile_out writes it in the same pass, the separate pack launch goes away
     uint32_t* slab; uint32_t slab_cap, slab_max_docs;
-    // host pipeline, one GPU: consecutive chunks of ONE batch stream their results straight into the pinned
-    // result.  gbase_in = tokens of the chunks before this one (device memory, written by the previous chunk's
-    // k_tile_out), gbase_out = where this chunk leaves the count for the next one, off_host = the result's offset
-    // entries of this chunk's documents.  ids_out / ids_cap then address the WHOLE result.
-    const unsigned long long* gbase_in; unsigned long long* gbase_out; uint64_t* off_host;
     uint32_t tpar;             // parity of this call
 };
 
@@ -2820,21 +2815,18 @@ __global__ __launch_bounds__(NT) void k_tile_out(Batch b) {
     __syncthreads();
     unsigned long long base = 0;
     for (int k = 0; k < NT / 64; k++) base += s_part[k];
-    const unsigned long long g0 = b.gbase_in ? *b.gbase_in : 0ull;     // tokens of the batch's earlier chunks (host pipeline)
     const uint32_t s_ids_at = 3 + b.slab_max_docs, s_ids_cap = b.slab ? b.slab_cap - s_ids_at : 0u;
     for (uint32_t k = tid; k < td.c_win; k += NT) {
         const unsigned long long r = base + k;
         const uint32_t id = k < (uint32_t)NT ? first_id : b.tile_ids[td.slot + k];
-        if (g0 + r < b.ids_cap) b.ids_out[g0 + r] = id;
+        if (r < b.ids_cap) b.ids_out[r] = id;
         if (r < s_ids_cap) b.slab[s_ids_at + r] = id;
     }
     for (uint32_t k = tid; k < td.d_cnt; k += NT) {
         const unsigned long long v = b.off_out[td.d_first + k] + base;
         b.off_out[td.d_first + k] = v;
-        if (b.off_host) b.off_host[td.d_first + k] = g0 + v;
         if (b.slab && td.d_first + k <= b.slab_max_docs) b.slab[2 + td.d_first + k] = (uint32_t)v;
     }
-    if (b.gbase_out && t == gridDim.x - 1 && tid == 0) *b.gbase_out = g0 + base + td.c_win + td.c_ovf;
     if (b.slab && t == gridDim.x - 1 && tid == 0) {        // header: T (the last tile ends the corpus), N
         b.slab[0] = (uint32_t)(base + td.c_win + td.c_ovf);
         b.slab[1] = b.n_docs;
@@ -2859,7 +2851,7 @@ __global__ __launch_bounds__(NT) void k_tile_out(Batch b) {
             while (word) {
                 const int bit = __ffs(word) - 1;
                 word &= word - 1;
-                if (g0 + r < b.ids_cap) b.ids_out[g0 + r] = b.stage[w * 32 + bit];
+                if (r < b.ids_cap) b.ids_out[r] = b.stage[w * 32 + bit];
                 if (r < s_ids_cap) b.slab[s_ids_at + r] = b.stage[w * 32 + bit];
                 r++;
             }
