@@ -52,6 +52,8 @@ def test_chunked_pipeline_equals_oracle(coracle, name, chunk):
     check(t, name, [""] * 50, coracle)
     check(t, name, [], coracle)
     check(t, name, ["only one"], coracle)
+    check(t, name, [""] * 9 + ["a b c"] + [""] * 9 + ["x" * 9000] + [""] * 9, coracle)
+    check(t, name, texts[:40], coracle, special=True)
 
 
 def test_result_buffer_growth(coracle):
