@@ -1881,6 +1881,11 @@ template <int TB_, int RH_, bool EXPORT_MEDIUM, bool DIRECT = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPL_PRETOK_WAVES)))
 void k_pretok(DeviceTables T, Batch b) {
     using G = TileGeom<TB_, RH_>;
+#ifdef SPL_FIXED_PATTERN
+    constexpr int KPAT = SPL_FIXED_PATTERN;              // (A/B: the kernel specialised for one split pattern)
+#else
+    const int KPAT = (int)T.pattern;
+#endif
     constexpr int Wv = G::Wv;
     __shared__ __attribute__((aligned(16))) uint32_t s_txt32[G::NW32];
     __shared__ __attribute__((aligned(16))) union {
@@ -2104,7 +2109,7 @@ void k_pretok(DeviceTables T, Batch b) {
             kw[k] = k < MK_SY ? s_mk[k * NBW1 + tid] : 0u;
             kp[k] = (k < MK_SY && tid > 0) ? s_mk[k * NBW1 + tid - 1] : 0u;
         }
-        s_mk[MK_SY * NBW1 + tid] = sync_word((int)T.pattern, kw, kp);
+        s_mk[MK_SY * NBW1 + tid] = sync_word(KPAT, kw, kp);
     }
     __syncthreads();
     SPL_STAMP(3);
@@ -2155,7 +2160,7 @@ void k_pretok(DeviceTables T, Batch b) {
             int p = s_cpos[k];
             for (;;) {
                 if (!LIST_CHUNKS) atomicOr(&s_cbits[p >> 5], 1u << (p & 31));
-                const int e = match_end_m(acc, p, (int)T.pattern);
+                const int e = match_end_m(acc, p, KPAT);
                 if (e == SPL_DEFER) {                 // the match outgrows the window
                     push_defer((uint32_t)(w0 + p));
                     break;
@@ -2524,7 +2529,7 @@ void k_pretok(DeviceTables T, Batch b) {
                             uint32_t fill = s_dq[0];
                             const uint32_t np = (uint32_t)pc;
                             const DirectAcc ga{&T, &b, next_ts, np};
-                            const int e = match_end(ga, (int)np, (int)T.pattern);
+                            const int e = match_end(ga, (int)np, KPAT);
                             const uint32_t n = (uint32_t)e - np;
                             const uint32_t id = probe_chunk(T, ga, (int)np, (int)n);
                             if (id != SPL_NO_RANK) emit_g(np, id);
@@ -2620,10 +2625,10 @@ void k_pretok(DeviceTables T, Batch b) {
                                 int j = q - 1;
                                 while (j > 0 && (acc.rec(j) & CB_CLASS) == C_CONT && j > q - 4) j--;
                                 const uint32_t prev = acc.rec(j) & CB_CLASS;
-                                if (prev < C_EOT && is_sync((int)T.pattern, prev, r & CB_CLASS)) { finished = true; break; }
+                                if (prev < C_EOT && is_sync(KPAT, prev, r & CB_CLASS)) { finished = true; break; }
                             }
                             if (fill >= (uint32_t)DIRECT_LQCAP) break;
-                            const int e = match_end(acc, q, (int)T.pattern);
+                            const int e = match_end(acc, q, KPAT);
                             if (e == SPL_DEFER) { whole = q == q0; break; }       // (longer than a whole window: below)
                             fc = false;
                             const bool spans = q < split && e > split;             // the chunk the cut was made for
