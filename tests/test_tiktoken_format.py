@@ -89,9 +89,12 @@ def test_constructors_on_tiktoken_text(tmp_path, name):
         assert t.encode_batch(texts) == want and t.encode_batch_with_special(texts) == want_s
         assert t.decode_batch(want[:50]) == texts[:50]
     # a later duplicate key replaces the earlier one (vocab.rs:86: encoder.insert)
-    dup = blob + base64.b64encode(b"Hello") + b" 77\n"
+    # (a FRESH id: two different keys sharing one id is what spl_create refuses, see the header)
+    dup = blob + base64.b64encode(b"Hello") + b" 250000\n"
     t = (Tokenizer.from_bytes_byte_level if byte_level else Tokenizer.from_bytes)(dup, pattern)
-    assert t.encode("Hello") == [77]
+    assert t.encode("Hello") == [250000] and t.vocab_size == 250001
+    with pytest.raises(ValueError):
+        Tokenizer.from_bytes(blob + base64.b64encode(b"Hello") + b" 77\n", pattern)   # id 77 already names another key
     # errors: the constructor raises IOError for everything (bindings.rs:79-80), from_bytes ValueError (:183-184)
     with pytest.raises(IOError):
         Tokenizer(str(tmp_path / "missing.tiktoken"), pattern)
