@@ -184,6 +184,7 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
         }
     }
     for (const auto& kv : enc) max_rank_seen = std::max(max_rank_seen, kv.second);   // vocab_size: max id of the map as loaded
+    if (max_rank_seen > SPL_ID_MASK) { err = "token id does not fit 21 bits"; return 1; }
     enc.erase(std::string());          // an empty key can never match a chunk
     // decoder side (build_decoder, src/core/vocab.rs:146-148, + Tokenizer::decode_bytes,
     // src/core/tokenizer.rs:877-897): id -> the bytes decode_bytes emits for it.  ByteLevel: the key
@@ -234,9 +235,15 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
         enc.swap(raw_enc);
     }
     if (enc.empty()) { err = "empty vocabulary"; return 1; }
+    {   // the merge kernels identify a node with its token id: an id must name ONE key
+        std::vector<uint8_t> seen((size_t)max_rank_seen + 1, 0);
+        for (const auto& kv : enc) {
+            if (seen[kv.second]) { err = "two keys share the id " + std::to_string(kv.second); return 1; }
+            seen[kv.second] = 1;
+        }
+    }
     out.max_id = max_rank_seen;
     out.max_key_len = 0;
-    if (max_rank_seen > SPL_ID_MASK) { err = "token id does not fit 21 bits"; return 1; }
     for (const auto& kv : enc) out.max_key_len = std::max<uint32_t>(out.max_key_len, (uint32_t)kv.first.size());
     out.n_keys = (uint32_t)enc.size();
     out.byte_id.assign(256, SPL_NO_RANK);

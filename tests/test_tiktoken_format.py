@@ -48,6 +48,10 @@ def test_parser_errors_are_the_reference_s():
     assert not ok and "empty vocabulary" in err
     ok, err = _create(b"SGVsbG8= 0\n")                                 # parses, but is no usable vocabulary here
     assert not ok and "256 single-byte" in err
+    ok, err = _create(b"YQ== 5\nYg== 5\n")                              # two keys, one id: refused (see the header)
+    assert not ok and "share the id 5" in err
+    ok, err = _create(b"YQ== 3000000\n")
+    assert not ok and "21 bits" in err
     ok, err = _create(b"SPLVjunkjunkjunkjunkjunk")
     assert not ok and "container" in err
 
