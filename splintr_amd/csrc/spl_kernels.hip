@@ -2042,6 +2042,30 @@ void k_pretok(DeviceTables T, Batch b) {
         const uint32_t tw = s_txt32[wi];
         const uint32_t ts4 = i0 < Wv ? (s_ts[i0 >> 5] >> (i0 & 31)) & 0xFu : 0u;
         const uint32_t sk4 = i0 < Wv ? (s_sk[i0 >> 5] >> (i0 & 31)) & 0xFu : 0u;
+        // A word with a byte beyond ASCII: the neighbouring words and the text-start bits of [i0 - 4, i0 + 12)
+        // go into registers once, so that the look-back / look-ahead of byte_record (at most 3 bytes either
+        // way, plus the decode) costs no LDS round trips per byte.
+        struct RegWin {
+            uint32_t wp, tw, wn; int base;               // bytes [base, base + 12), base = i0 - 4
+            __device__ __forceinline__ uint32_t txt(int j) const {
+                const int d = j - base;
+                const uint32_t w = d < 4 ? wp : d < 8 ? tw : wn;
+                return (w >> (8 * (d & 3))) & 0xFFu;
+            }
+        };
+        RegWin rw{0u, tw, 0u, i0 - 4};
+        uint32_t ts16 = 0;
+        if (tw & 0x80808080u) {
+            rw.wp = wi > 0 ? s_txt32[wi - 1] : 0u;
+            rw.wn = s_txt32[wi + 1];
+            const int b0 = i0 - 4;                        // (a multiple of 4; negative only for the first word)
+            if (b0 < 0) ts16 = s_ts[0] << 4;
+            else {
+                const int sh = b0 & 31;
+                ts16 = s_ts[b0 >> 5] >> sh;
+                if (sh > 16) ts16 |= s_ts[(b0 >> 5) + 1] << (32 - sh);
+            }
+        }
         uint32_t out = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -2058,8 +2082,7 @@ void k_pretok(DeviceTables T, Batch b) {
                 if (c0 < 0x80u) r = s_ascii[c0];
                 else {      // (bytes before window index 0 do not exist for the look-back: that only concerns the
                             //  first bytes of the left halo, whose records nothing in the tile depends on)
-                    const LdsAcc tx{s_rec, s_txt};
-                    r = byte_record(T, tx, [&](int j) { return ((s_ts[j >> 5] >> (j & 31)) & 1u) != 0; },
+                    r = byte_record(T, rw, [&](int j) { return ((ts16 >> (j - (i0 - 4))) & 1u) != 0; },
                                     [](uint32_t) { return 0u; }, i, w0 < 0 ? (int)-w0 : 0, iT);
                 }
                 if ((ts4 >> k) & 1u) r |= CB_TSTART | CB_SYNC;
