@@ -147,3 +147,42 @@ def test_python_surface_types_and_errors():
     for s in ["café naïve", "你好，世界", "Hello \U0001F30D World!", "é你\U0001F30D" * 50]:
         assert t.encode_batch([s, s])[1] == t.encode(s)
         assert t.decode(t.encode(s)) == s
+
+
+def test_option_and_device_errors():
+    from splintr_amd import Tokenizer, _ffi
+    L = _ffi.lib()
+    t = Tokenizer.from_pretrained("cl100k_base")
+    assert L.spl_set_option(t.handle, b"no_such_option", 1) != 0 and "unknown option" in _ffi.last_error()
+    assert L.spl_set_option(t.handle, b"chunk_bytes", 0) != 0
+    with pytest.raises(ValueError):
+        t.set_devices([L.spl_device_count()])            # one past the last device
+    with pytest.raises(ValueError):
+        t.set_devices([])
+    assert L.spl_n_devices(t.handle) == 1
+    t.set_devices([0, 0])
+    assert L.spl_n_devices(t.handle) == 2 and t.encode("Hello, world!") == [9906, 11, 1917, 0]
+
+
+def test_round_trip_property_on_arbitrary_unicode():
+    """decode(encode(t)) == t, and a document's ids do not depend on its neighbours, for batches drawn by
+    hypothesis from all of Unicode (no surrogates) -- the structural pins the reference's tests apply to a
+    handful of strings (python/tests/test_cl100k.py:56-71, tests/cl100k.rs:191-214), at scale and for every
+    vocabulary.  Derandomised: the same examples every run."""
+    from hypothesis import given, settings, strategies as st
+    from conftest import VOCABS
+    from splintr_amd import Tokenizer
+    toks = {name: Tokenizer.from_pretrained(name) for name in VOCABS}
+    text = st.text(alphabet=st.characters(blacklist_categories=("Cs",)), max_size=120)
+
+    @settings(max_examples=150, derandomize=True, deadline=None)
+    @given(st.lists(text, max_size=24), st.sampled_from(VOCABS))
+    def prop(texts, name):
+        t = toks[name]
+        enc = t.encode_batch(texts)
+        assert t.decode_batch(enc) == texts
+        assert t.encode_batch(texts[::-1]) == enc[::-1]
+        if texts:
+            assert t.encode(texts[0]) == enc[0]
+
+    prop()
