@@ -526,13 +526,18 @@ constexpr int SUB_W = SUB_LMAX - 1;          // table width: lengths 2..8
 // split probes of the tiny table (keys of 2..4 bytes) and of the t8 table (5..8 bytes)
 // (`on` false: the key is known to miss -- the lane loads the table's spare bucket instead, one
 //  cache line for all such lanes, and the finish step finds nothing there)
+#ifdef SPL_FAKE_FILL      /* timing experiment only (wrong ids): every tabulation probe reads the spare bucket, i.e. always hits */
+#define SPL_FILL_ON(on) false
+#else
+#define SPL_FILL_ON(on) (on)
+#endif
 __device__ __forceinline__ void tiny_issue_if(const DeviceTables& T, bool on, uint32_t k0, uint32_t n, Quad (&q)[2]) {
-    const uint32_t bkt = on ? hash_tiny(k0, n) & T.tiny_mask : T.tiny_free;
+    const uint32_t bkt = SPL_FILL_ON(on) ? hash_tiny(k0, n) & T.tiny_mask : T.tiny_free;
     const Quad* src = reinterpret_cast<const Quad*>(T.tiny_tab + (size_t)bkt * (SPL_TINY_BUCKET * 2));
     q[0] = src[0]; q[1] = src[1];
 }
 __device__ __forceinline__ void t8_issue_if(const DeviceTables& T, bool on, uint32_t k0, uint32_t k1, uint32_t n, Quad (&q)[3]) {
-    const uint32_t bkt = on ? hash_t8(k0, k1, n) & T.t8_mask : T.t8_free;
+    const uint32_t bkt = SPL_FILL_ON(on) ? hash_t8(k0, k1, n) & T.t8_mask : T.t8_free;
     const Quad* src = reinterpret_cast<const Quad*>(T.t8_tab + (size_t)bkt * SPL_T8_WORDS);
     q[0] = src[0]; q[1] = src[1]; q[2] = src[2];
 }
