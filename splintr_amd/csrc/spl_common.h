@@ -54,8 +54,11 @@ enum : int { PAT_CL100K = 0, PAT_O200K = 1, PAT_MISTRAL_V3 = 2 };
 // Both big tables are BUCKETED: a probe fetches one whole bucket with back-to-back 16-byte loads
 // (one memory round trip) and almost never needs a second bucket, because a wavefront waits for
 // its slowest lane and linear probing by single entries made that lane take 3-5 dependent trips.
-// Buckets fill left to right and nothing is ever deleted, so "last slot empty" == "bucket not
-// full" == "the key cannot have overflowed into the next bucket".
+// Buckets fill left to right and nothing is ever deleted; a key that finds its bucket full goes to
+// the next one and marks the full bucket (SPL_OVF_BIT), so a probe knows from ONE bucket whether it is
+// settled.  The builder salts the hashes per two-byte key prefix (DeviceTables::len_mask) so that no
+// key of the shipped vocabularies has to go on at all; the walk to the next bucket stays in the
+// probes for vocabularies where it does not manage that.
 struct alignas(16) Quad { uint32_t x, y, z, w; };       // one dwordx4 load
 // Short-key table: vocabulary entries whose key is <= 12 bytes, key stored inline.
 struct ShortEnt {            // 16 B
@@ -93,6 +96,9 @@ constexpr int SPL_PAIR_BUCKET = 4;
 constexpr uint32_t SPL_ID_BITS = 21;
 constexpr uint32_t SPL_ID_MASK = (1u << SPL_ID_BITS) - 1;
 constexpr uint32_t SPL_NO_RANK = 0xFFFFFFFFu;
+// tiny / t8 / short tables, id word (id | len << 24) of a bucket's LAST slot: a key went on from this
+// (full) bucket to the next one.  Without it a probe that misses is settled by this bucket alone.
+constexpr uint32_t SPL_OVF_BIT = 1u << 23;
 
 struct P8Bucket { uint32_t a, b; };
 
@@ -118,10 +124,15 @@ struct DeviceTables {
     // tag 0xFFFFFF matches every key (a third prefix met in the bucket).  A miss is exact, a hit may
     // be too long (another prefix with the same 24-bit tag).
     const P8Bucket* p8_tab;    uint32_t p8_mask;
-    // len_mask[b0 | b1 << 8]: bit L-2 set iff some token of exactly L bytes (L = 2..8) starts with
-    // these two bytes, bit 7 iff a longer one does.  tiny_free / t8_free: a bucket of each table
-    // with a free slot -- where probes known to miss are sent (one cache line for all of them).
-    const uint8_t* len_mask;   uint32_t tiny_free, t8_free;
+    // len_mask[b0 | b1 << 8], low byte: bit L-2 set iff some token of exactly L bytes (L = 2..8) starts
+    // with these two bytes, bit 7 iff a longer one does.  High byte: the SALT of the bucket hashes of
+    // every key of up to 12 bytes that starts with these two bytes (a one-byte key: b1 = 0) -- chosen
+    // by the builder so that no bucket of the tiny / t8 / short tables is ever full: a probe then never
+    // needs a second bucket, hit or miss (a wavefront waits for its slowest lane; with plain hashing
+    // 2-7 % of the buckets were full and nearly every wavefront had a lane that went on to the next).
+    // tiny_free / t8_free: a bucket of each table with a free slot -- where probes known to miss are
+    // sent (one cache line for all of them).
+    const uint16_t* len_mask;  uint32_t tiny_free, t8_free;
 };
 
 // ----------------------------------------------------------------------------------------
@@ -131,9 +142,13 @@ SPL_HD uint32_t mix32(uint32_t h) {
     h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
     return h;
 }
-SPL_HD uint32_t hash_tiny(uint32_t k0, uint32_t len) { return mix32(k0 * 0x9E3779B1u ^ (len * 0x27D4EB2Fu)); }
-SPL_HD uint32_t hash_t8(uint32_t k0, uint32_t k1, uint32_t len) {
-    return mix32(k0 * 0x9E3779B1u ^ (k1 * 0x85EBCA77u + 0x165667B1u) ^ (len * 0x27D4EB2Fu));
+// `salt` (tiny, t8 and short tables): a byte the table builder chose for all keys that begin with the
+// same two bytes so that none of them lands in a bucket that is full (DeviceTables::len_mask).
+SPL_HD uint32_t hash_tiny(uint32_t k0, uint32_t len, uint32_t salt = 0) {
+    return mix32(k0 * 0x9E3779B1u ^ (len * 0x27D4EB2Fu) ^ (salt * 0xC2B2AE3Du));
+}
+SPL_HD uint32_t hash_t8(uint32_t k0, uint32_t k1, uint32_t len, uint32_t salt = 0) {
+    return mix32(k0 * 0x9E3779B1u ^ (k1 * 0x85EBCA77u + 0x165667B1u) ^ (len * 0x27D4EB2Fu) ^ (salt * 0xC2B2AE3Du));
 }
 SPL_HD uint32_t hash_p8(uint32_t k0, uint32_t k1) { return hash_t8(k0, k1, 9u); }
 SPL_HD uint32_t p8_tag(uint32_t k0, uint32_t k1) {                                   // 1 .. 0xFFFFFE
@@ -146,8 +161,8 @@ SPL_HD uint32_t p8_match(uint32_t e0, uint32_t e1, uint32_t tag) {              
     if (e1 != 0 && (t1 == tag || t1 == 0xFFFFFFu) && (e1 & 0xFFu) > l) l = e1 & 0xFFu;
     return l;
 }
-SPL_HD uint32_t hash_short(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len) {
-    uint32_t h = k0 * 0x9E3779B1u ^ (k1 * 0x85EBCA77u + 0x165667B1u) ^ (k2 * 0xC2B2AE3Du) ^ (len * 0x27D4EB2Fu);
+SPL_HD uint32_t hash_short(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len, uint32_t salt = 0) {
+    uint32_t h = k0 * 0x9E3779B1u ^ (k1 * 0x85EBCA77u + 0x165667B1u) ^ (k2 * 0xC2B2AE3Du) ^ (len * 0x27D4EB2Fu) ^ (salt * 0x165667B1u);
     return mix32(h);
 }
 // long keys: word-at-a-time over the zero-padded little-endian words of the key

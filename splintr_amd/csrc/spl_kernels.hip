@@ -29,6 +29,11 @@
 #include "spl_lookup.h"
 #include "spl_scan.h"
 #include "spl_scan_masks.h"
+#include "spl_scan_starts.h"
+
+#ifndef SPL_NO_SLOWPATH
+#define SPL_NO_SLOWPATH 0      /* 1: timing experiment only (wrong ids for keys that overflowed their bucket): a full bucket never sends a probe on to the next one */
+#endif
 
 namespace spl {
 
@@ -243,6 +248,24 @@ struct LdsAcc {
         const uint32_t* w = reinterpret_cast<const uint32_t*>(txt_) + (p >> 2);
         return __builtin_amdgcn_alignbyte(w[1], w[0], p & 3);
     }
+};
+
+// Window-wide bit vector for spl_scan_starts.h: one 32-bit word per lane of ONE wavefront (all 64 lanes
+// active; lanes past the window hold zero words).  Shifts take the neighbour lane's word by DPP.
+struct WaveBV {
+    uint32_t x;
+    __device__ __forceinline__ WaveBV operator&(const WaveBV& o) const { return WaveBV{x & o.x}; }
+    __device__ __forceinline__ WaveBV operator|(const WaveBV& o) const { return WaveBV{x | o.x}; }
+    __device__ __forceinline__ WaveBV operator~() const { return WaveBV{~x}; }
+    __device__ __forceinline__ WaveBV shl1() const {       // bit i <- bit i - 1
+        const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xF, 0xF, true);   // wave_shr:1
+        return WaveBV{(x << 1) | (prev >> 31)};
+    }
+    __device__ __forceinline__ WaveBV shr1() const {       // bit i <- bit i + 1
+        const uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xF, 0xF, true);   // wave_shl:1
+        return WaveBV{(x >> 1) | (next << 31)};
+    }
+    __device__ __forceinline__ bool any() const { return __any(x != 0u); }
 };
 
 // LdsAcc plus the window's class bitmasks (spl_scan_masks.h)
@@ -463,7 +486,11 @@ __device__ __forceinline__ void bpe_group16(const DeviceTables& T, int n, ByteAt
 __device__ __forceinline__ uint32_t probe_short_mixed(const DeviceTables& T, uint32_t k0, uint32_t k1, uint32_t k2,
                                                       uint32_t n) {
     const bool tiny = n <= (uint32_t)SPL_TINY_MAX, t8 = !tiny && n <= (uint32_t)SPL_T8_MAX;
-    const uint32_t h = tiny ? hash_tiny(k0, n) : t8 ? hash_t8(k0, k1, n) : hash_short(k0, k1, k2, n);
+    // the key's two-byte prefix: which token lengths exist behind it at all (no probe for the others)
+    // and the salt of its bucket hashes
+    const uint32_t lm = T.len_mask[k0 & 0xFFFFu], salt = lm >> 8;
+    if (n >= 2u && !((lm >> (n <= (uint32_t)SPL_T8_MAX ? n - 2u : 7u)) & 1u)) return SPL_NO_RANK;
+    const uint32_t h = tiny ? hash_tiny(k0, n, salt) : t8 ? hash_t8(k0, k1, n, salt) : hash_short(k0, k1, k2, n, salt);
     const Quad* src = tiny ? reinterpret_cast<const Quad*>(T.tiny_tab + (size_t)(h & T.tiny_mask) * (SPL_TINY_BUCKET * 2))
                     : t8   ? reinterpret_cast<const Quad*>(T.t8_tab + (size_t)(h & T.t8_mask) * SPL_T8_WORDS)
                            : reinterpret_cast<const Quad*>(T.short_tab + (size_t)(h & T.short_mask) * SPL_SHORT_BUCKET);
@@ -475,28 +502,28 @@ __device__ __forceinline__ uint32_t probe_short_mixed(const DeviceTables& T, uin
     if (tiny) {
         const bool f0 = (q0.x == k0) & ((q0.y >> 24) == n), f1 = (q0.z == k0) & ((q0.w >> 24) == n);
         const bool f2 = (q1.x == k0) & ((q1.y >> 24) == n), f3 = (q1.z == k0) & ((q1.w >> 24) == n);
-        r = f3 ? (q1.w & 0xFFFFFFu) : r; r = f2 ? (q1.y & 0xFFFFFFu) : r;
-        r = f1 ? (q0.w & 0xFFFFFFu) : r; r = f0 ? (q0.y & 0xFFFFFFu) : r;
-        settled = (f0 | f1 | f2 | f3) | (q1.w == SPL_EMPTY);
+        r = f3 ? (q1.w & SPL_ID_MASK) : r; r = f2 ? (q1.y & SPL_ID_MASK) : r;
+        r = f1 ? (q0.w & SPL_ID_MASK) : r; r = f0 ? (q0.y & SPL_ID_MASK) : r;
+        settled = (f0 | f1 | f2 | f3) | !bucket_overflowed(q1.w);
     } else if (t8) {
         const bool f0 = (q0.x == k0) & (q0.y == k1) & ((q0.z >> 24) == n);
         const bool f1 = (q0.w == k0) & (q1.x == k1) & ((q1.y >> 24) == n);
         const bool f2 = (q1.z == k0) & (q1.w == k1) & ((q2.x >> 24) == n);
         const bool f3 = (q2.y == k0) & (q2.z == k1) & ((q2.w >> 24) == n);
-        r = f3 ? (q2.w & 0xFFFFFFu) : r; r = f2 ? (q2.x & 0xFFFFFFu) : r;
-        r = f1 ? (q1.y & 0xFFFFFFu) : r; r = f0 ? (q0.z & 0xFFFFFFu) : r;
-        settled = (f0 | f1 | f2 | f3) | (q2.w == SPL_EMPTY);
+        r = f3 ? (q2.w & SPL_ID_MASK) : r; r = f2 ? (q2.x & SPL_ID_MASK) : r;
+        r = f1 ? (q1.y & SPL_ID_MASK) : r; r = f0 ? (q0.z & SPL_ID_MASK) : r;
+        settled = (f0 | f1 | f2 | f3) | !bucket_overflowed(q2.w);
     } else {
         const bool f0 = (q0.x == k0) & (q0.y == k1) & (q0.z == k2) & ((q0.w >> 24) == n);
         const bool f1 = (q1.x == k0) & (q1.y == k1) & (q1.z == k2) & ((q1.w >> 24) == n);
         const bool f2 = (q2.x == k0) & (q2.y == k1) & (q2.z == k2) & ((q2.w >> 24) == n);
         const bool f3 = (q3.x == k0) & (q3.y == k1) & (q3.z == k2) & ((q3.w >> 24) == n);
-        r = f3 ? (q3.w & 0xFFFFFFu) : r; r = f2 ? (q2.w & 0xFFFFFFu) : r;
-        r = f1 ? (q1.w & 0xFFFFFFu) : r; r = f0 ? (q0.w & 0xFFFFFFu) : r;
-        settled = (f0 | f1 | f2 | f3) | (q3.w == SPL_EMPTY);
+        r = f3 ? (q3.w & SPL_ID_MASK) : r; r = f2 ? (q2.w & SPL_ID_MASK) : r;
+        r = f1 ? (q1.w & SPL_ID_MASK) : r; r = f0 ? (q0.w & SPL_ID_MASK) : r;
+        settled = (f0 | f1 | f2 | f3) | !bucket_overflowed(q3.w);
     }
-    if (settled) return r;
-    return probe_short(T, k0, k1, k2, n);       // home bucket full without a match (rare): generic probe
+    if (SPL_NO_SLOWPATH || settled) return r;
+    return probe_short(T, k0, k1, k2, n, salt); // home bucket full without a match (never with salted tables): generic probe
 }
 template <class TX>
 __device__ __forceinline__ uint32_t probe_chunk_tile(const DeviceTables& T, const TX& tx, int p, int n) {
@@ -531,51 +558,41 @@ constexpr int SUB_W = SUB_LMAX - 1;          // table width: lengths 2..8
 #else
 #define SPL_FILL_ON(on) (on)
 #endif
-__device__ __forceinline__ void tiny_issue_if(const DeviceTables& T, bool on, uint32_t k0, uint32_t n, Quad (&q)[2]) {
-    const uint32_t bkt = SPL_FILL_ON(on) ? hash_tiny(k0, n) & T.tiny_mask : T.tiny_free;
+__device__ __forceinline__ void tiny_issue_if(const DeviceTables& T, bool on, uint32_t k0, uint32_t n, uint32_t salt, Quad (&q)[2]) {
+    const uint32_t bkt = SPL_FILL_ON(on) ? hash_tiny(k0, n, salt) & T.tiny_mask : T.tiny_free;
     const Quad* src = reinterpret_cast<const Quad*>(T.tiny_tab + (size_t)bkt * (SPL_TINY_BUCKET * 2));
     q[0] = src[0]; q[1] = src[1];
 }
-__device__ __forceinline__ void t8_issue_if(const DeviceTables& T, bool on, uint32_t k0, uint32_t k1, uint32_t n, Quad (&q)[3]) {
-    const uint32_t bkt = SPL_FILL_ON(on) ? hash_t8(k0, k1, n) & T.t8_mask : T.t8_free;
+__device__ __forceinline__ void t8_issue_if(const DeviceTables& T, bool on, uint32_t k0, uint32_t k1, uint32_t n, uint32_t salt, Quad (&q)[3]) {
+    const uint32_t bkt = SPL_FILL_ON(on) ? hash_t8(k0, k1, n, salt) & T.t8_mask : T.t8_free;
     const Quad* src = reinterpret_cast<const Quad*>(T.t8_tab + (size_t)bkt * SPL_T8_WORDS);
     q[0] = src[0]; q[1] = src[1]; q[2] = src[2];
 }
-__device__ __forceinline__ void tiny_issue(const DeviceTables& T, uint32_t k0, uint32_t n, Quad (&q)[2]) {
-    const uint32_t bkt = hash_tiny(k0, n) & T.tiny_mask;
-    const Quad* src = reinterpret_cast<const Quad*>(T.tiny_tab + (size_t)bkt * (SPL_TINY_BUCKET * 2));
-    q[0] = src[0]; q[1] = src[1];
-}
-__device__ __forceinline__ uint32_t tiny_finish(const DeviceTables& T, uint32_t k0, uint32_t n, const Quad (&q)[2]) {
+__device__ __forceinline__ uint32_t tiny_finish(const DeviceTables& T, uint32_t k0, uint32_t n, uint32_t salt, const Quad (&q)[2]) {
     const bool f0 = (q[0].x == k0) & ((q[0].y >> 24) == n);
     const bool f1 = (q[0].z == k0) & ((q[0].w >> 24) == n);
     const bool f2 = (q[1].x == k0) & ((q[1].y >> 24) == n);
     const bool f3 = (q[1].z == k0) & ((q[1].w >> 24) == n);
     uint32_t r = SPL_NO_RANK;
-    r = f3 ? (q[1].w & 0xFFFFFFu) : r;
-    r = f2 ? (q[1].y & 0xFFFFFFu) : r;
-    r = f1 ? (q[0].w & 0xFFFFFFu) : r;
-    r = f0 ? (q[0].y & 0xFFFFFFu) : r;
-    if ((f0 | f1 | f2 | f3) | (q[1].w == SPL_EMPTY)) return r;
-    return probe_tiny(T, k0, n);               // home bucket full without a match (rare): generic probe
+    r = f3 ? (q[1].w & SPL_ID_MASK) : r;
+    r = f2 ? (q[1].y & SPL_ID_MASK) : r;
+    r = f1 ? (q[0].w & SPL_ID_MASK) : r;
+    r = f0 ? (q[0].y & SPL_ID_MASK) : r;
+    if (SPL_NO_SLOWPATH || ((f0 | f1 | f2 | f3) | !bucket_overflowed(q[1].w))) return r;
+    return probe_tiny(T, k0, n, salt);         // home bucket full without a match (never with salted tables): generic probe
 }
-__device__ __forceinline__ void t8_issue(const DeviceTables& T, uint32_t k0, uint32_t k1, uint32_t n, Quad (&q)[3]) {
-    const uint32_t bkt = hash_t8(k0, k1, n) & T.t8_mask;
-    const Quad* src = reinterpret_cast<const Quad*>(T.t8_tab + (size_t)bkt * SPL_T8_WORDS);
-    q[0] = src[0]; q[1] = src[1]; q[2] = src[2];
-}
-__device__ __forceinline__ uint32_t t8_finish(const DeviceTables& T, uint32_t k0, uint32_t k1, uint32_t n, const Quad (&q)[3]) {
+__device__ __forceinline__ uint32_t t8_finish(const DeviceTables& T, uint32_t k0, uint32_t k1, uint32_t n, uint32_t salt, const Quad (&q)[3]) {
     const bool f0 = (q[0].x == k0) & (q[0].y == k1) & ((q[0].z >> 24) == n);
     const bool f1 = (q[0].w == k0) & (q[1].x == k1) & ((q[1].y >> 24) == n);
     const bool f2 = (q[1].z == k0) & (q[1].w == k1) & ((q[2].x >> 24) == n);
     const bool f3 = (q[2].y == k0) & (q[2].z == k1) & ((q[2].w >> 24) == n);
     uint32_t r = SPL_NO_RANK;
-    r = f3 ? (q[2].w & 0xFFFFFFu) : r;
-    r = f2 ? (q[2].x & 0xFFFFFFu) : r;
-    r = f1 ? (q[1].y & 0xFFFFFFu) : r;
-    r = f0 ? (q[0].z & 0xFFFFFFu) : r;
-    if ((f0 | f1 | f2 | f3) | (q[2].w == SPL_EMPTY)) return r;
-    return probe_t8(T, k0, k1, n);
+    r = f3 ? (q[2].w & SPL_ID_MASK) : r;
+    r = f2 ? (q[2].x & SPL_ID_MASK) : r;
+    r = f1 ? (q[1].y & SPL_ID_MASK) : r;
+    r = f0 ? (q[0].z & SPL_ID_MASK) : r;
+    if (SPL_NO_SLOWPATH || ((f0 | f1 | f2 | f3) | !bucket_overflowed(q[2].w))) return r;
+    return probe_t8(T, k0, k1, n, salt);
 }
 
 // The merge loop of one 16-lane group over `n` <= 16 nodes whose substring ids are tabulated: lane
@@ -656,14 +673,14 @@ __device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const Lds
         //  the lanes need no per-length predicate -- with one, the compiler waits after every
         //  single probe instead of keeping all the bucket loads in flight together)
         if (maxlen >= 2) {
-            tiny_issue_if(T, (lm & 1u) != 0, ka, 2u, qa);
-            tiny_issue_if(T, (lm & 2u) != 0, kb, 3u, qb);
-            tiny_issue_if(T, (lm & 4u) != 0, w0, 4u, qc);
-            t8_issue_if(T, (lm & 8u) != 0, w0, ha, 5u, qd);
-            row[0] = tiny_finish(T, ka, 2u, qa);
-            row[1] = tiny_finish(T, kb, 3u, qb);
-            row[2] = tiny_finish(T, w0, 4u, qc);
-            row[3] = t8_finish(T, w0, ha, 5u, qd);
+            tiny_issue_if(T, (lm & 1u) != 0, ka, 2u, lm >> 8, qa);
+            tiny_issue_if(T, (lm & 2u) != 0, kb, 3u, lm >> 8, qb);
+            tiny_issue_if(T, (lm & 4u) != 0, w0, 4u, lm >> 8, qc);
+            t8_issue_if(T, (lm & 8u) != 0, w0, ha, 5u, lm >> 8, qd);
+            row[0] = tiny_finish(T, ka, 2u, lm >> 8, qa);
+            row[1] = tiny_finish(T, kb, 3u, lm >> 8, qb);
+            row[2] = tiny_finish(T, w0, 4u, lm >> 8, qc);
+            row[3] = t8_finish(T, w0, ha, 5u, lm >> 8, qd);
         }
     }
     SPL_WT(2);
@@ -671,12 +688,12 @@ __device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const Lds
         Quad qa[3], qb[3], qc[3];
         const uint32_t hb = w1 & 0xFFFFu, hc = w1 & 0xFFFFFFu;
         if (maxlen >= 6) {
-            t8_issue_if(T, (lm & 0x10u) != 0, w0, hb, 6u, qa);
-            t8_issue_if(T, (lm & 0x20u) != 0, w0, hc, 7u, qb);
-            t8_issue_if(T, (lm & 0x40u) != 0, w0, w1, 8u, qc);
-            row[4] = t8_finish(T, w0, hb, 6u, qa);
-            row[5] = t8_finish(T, w0, hc, 7u, qb);
-            if (SUB_LMAX >= 8) row[6] = t8_finish(T, w0, w1, 8u, qc);
+            t8_issue_if(T, (lm & 0x10u) != 0, w0, hb, 6u, lm >> 8, qa);
+            t8_issue_if(T, (lm & 0x20u) != 0, w0, hc, 7u, lm >> 8, qb);
+            t8_issue_if(T, (lm & 0x40u) != 0, w0, w1, 8u, lm >> 8, qc);
+            row[4] = t8_finish(T, w0, hb, 6u, lm >> 8, qa);
+            row[5] = t8_finish(T, w0, hc, 7u, lm >> 8, qb);
+            if (SUB_LMAX >= 8) row[6] = t8_finish(T, w0, w1, 8u, lm >> 8, qc);
         }
     } else if (maxlen >= 6) {                                // nothing of 6..8 bytes starts in this wavefront's chunks
         row[4] = SPL_NO_RANK; row[5] = SPL_NO_RANK; row[6] = SPL_NO_RANK;
@@ -789,26 +806,26 @@ __device__ __forceinline__ void bpe_wave64_tab(const DeviceTables& T, const LdsA
         //  the lanes need no per-length predicate -- with one, the compiler waits after every
         //  single probe instead of keeping all the bucket loads in flight together)
         if (maxlen >= 2) {
-            tiny_issue_if(T, (lm & 1u) != 0, ka, 2u, qa);
-            tiny_issue_if(T, (lm & 2u) != 0, kb, 3u, qb);
-            tiny_issue_if(T, (lm & 4u) != 0, w0, 4u, qc);
-            t8_issue_if(T, (lm & 8u) != 0, w0, ha, 5u, qd);
-            row[0] = tiny_finish(T, ka, 2u, qa);
-            row[1] = tiny_finish(T, kb, 3u, qb);
-            row[2] = tiny_finish(T, w0, 4u, qc);
-            row[3] = t8_finish(T, w0, ha, 5u, qd);
+            tiny_issue_if(T, (lm & 1u) != 0, ka, 2u, lm >> 8, qa);
+            tiny_issue_if(T, (lm & 2u) != 0, kb, 3u, lm >> 8, qb);
+            tiny_issue_if(T, (lm & 4u) != 0, w0, 4u, lm >> 8, qc);
+            t8_issue_if(T, (lm & 8u) != 0, w0, ha, 5u, lm >> 8, qd);
+            row[0] = tiny_finish(T, ka, 2u, lm >> 8, qa);
+            row[1] = tiny_finish(T, kb, 3u, lm >> 8, qb);
+            row[2] = tiny_finish(T, w0, 4u, lm >> 8, qc);
+            row[3] = t8_finish(T, w0, ha, 5u, lm >> 8, qd);
         }
     }
     if (SUB_LMAX >= 6 && __any(maxlen >= 6 && (lm & 0x70u))) {
         Quad qa[3], qb[3], qc[3];
         const uint32_t hb = w1 & 0xFFFFu, hc = w1 & 0xFFFFFFu;
         if (maxlen >= 6) {
-            t8_issue_if(T, (lm & 0x10u) != 0, w0, hb, 6u, qa);
-            t8_issue_if(T, (lm & 0x20u) != 0, w0, hc, 7u, qb);
-            t8_issue_if(T, (lm & 0x40u) != 0, w0, w1, 8u, qc);
-            row[4] = t8_finish(T, w0, hb, 6u, qa);
-            row[5] = t8_finish(T, w0, hc, 7u, qb);
-            if (SUB_LMAX >= 8) row[6] = t8_finish(T, w0, w1, 8u, qc);
+            t8_issue_if(T, (lm & 0x10u) != 0, w0, hb, 6u, lm >> 8, qa);
+            t8_issue_if(T, (lm & 0x20u) != 0, w0, hc, 7u, lm >> 8, qb);
+            t8_issue_if(T, (lm & 0x40u) != 0, w0, w1, 8u, lm >> 8, qc);
+            row[4] = t8_finish(T, w0, hb, 6u, lm >> 8, qa);
+            row[5] = t8_finish(T, w0, hc, 7u, lm >> 8, qb);
+            if (SUB_LMAX >= 8) row[6] = t8_finish(T, w0, w1, 8u, lm >> 8, qc);
         }
     } else if (maxlen >= 6) {
         row[4] = SPL_NO_RANK; row[5] = SPL_NO_RANK; row[6] = SPL_NO_RANK;
@@ -1581,6 +1598,9 @@ template <int TB_, int RH_> struct TileGeom {
 #ifndef SPL_PRETOK_WAVES
 #define SPL_PRETOK_WAVES 6
 #endif
+#ifndef SPL_MASK_STARTS
+#define SPL_MASK_STARTS 1         /* 1: cl100k tiles take their match starts from the bit-vector computation of spl_scan_starts.h */
+#endif
 #ifndef SPL_TILE_MISS_LIST
 #define SPL_TILE_MISS_LIST 0      /* 1: EVERY miss of a tile through the workgroup-wide segment pass of the tail instead of the
                                      per-wavefront merge loops.  Measured on the bench batch: 60 us against 42 us per launch --
@@ -1731,12 +1751,12 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
             Quad qa[2], qb[2], qc[2], qd[3];
             const uint32_t ka = w0 & 0xFFFFu, kb = w0 & 0xFFFFFFu, ha = w1 & 0xFFu;
             if (maxlen >= 2) {                               // (one predicate per batch: see bpe_group16_tab)
-                tiny_issue_if(T, (lm & 1u) != 0, ka, 2u, qa);
-                tiny_issue_if(T, (lm & 2u) != 0, kb, 3u, qb);
-                tiny_issue_if(T, (lm & 4u) != 0, w0, 4u, qc);
-                t8_issue_if(T, (lm & 8u) != 0, w0, ha, 5u, qd);
-                const uint32_t r2 = tiny_finish(T, ka, 2u, qa), r3 = tiny_finish(T, kb, 3u, qb);
-                const uint32_t r4 = tiny_finish(T, w0, 4u, qc), r5 = t8_finish(T, w0, ha, 5u, qd);
+                tiny_issue_if(T, (lm & 1u) != 0, ka, 2u, lm >> 8, qa);
+                tiny_issue_if(T, (lm & 2u) != 0, kb, 3u, lm >> 8, qb);
+                tiny_issue_if(T, (lm & 4u) != 0, w0, 4u, lm >> 8, qc);
+                t8_issue_if(T, (lm & 8u) != 0, w0, ha, 5u, lm >> 8, qd);
+                const uint32_t r2 = tiny_finish(T, ka, 2u, lm >> 8, qa), r3 = tiny_finish(T, kb, 3u, lm >> 8, qb);
+                const uint32_t r4 = tiny_finish(T, w0, 4u, lm >> 8, qc), r5 = t8_finish(T, w0, ha, 5u, lm >> 8, qd);
                 row[0] = r2; row[1] = r3; row[2] = r4; row[3] = r5;
                 ml = r2 != SPL_NO_RANK ? 2 : ml;
                 ml = (r3 != SPL_NO_RANK && maxlen >= 3) ? 3 : ml;
@@ -1752,11 +1772,11 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
                 Quad qa[3], qb[3], qc[3];
                 const uint32_t hb = w1 & 0xFFFFu, hc = w1 & 0xFFFFFFu;
                 if (maxlen >= 6) {
-                    t8_issue_if(T, (lm & 0x10u) != 0, w0, hb, 6u, qa);
-                    t8_issue_if(T, (lm & 0x20u) != 0, w0, hc, 7u, qb);
-                    t8_issue_if(T, (lm & 0x40u) != 0, w0, w1, 8u, qc);
-                    const uint32_t r6 = t8_finish(T, w0, hb, 6u, qa), r7 = t8_finish(T, w0, hc, 7u, qb);
-                    const uint32_t r8 = t8_finish(T, w0, w1, 8u, qc);
+                    t8_issue_if(T, (lm & 0x10u) != 0, w0, hb, 6u, lm >> 8, qa);
+                    t8_issue_if(T, (lm & 0x20u) != 0, w0, hc, 7u, lm >> 8, qb);
+                    t8_issue_if(T, (lm & 0x40u) != 0, w0, w1, 8u, lm >> 8, qc);
+                    const uint32_t r6 = t8_finish(T, w0, hb, 6u, lm >> 8, qa), r7 = t8_finish(T, w0, hc, 7u, lm >> 8, qb);
+                    const uint32_t r8 = t8_finish(T, w0, w1, 8u, lm >> 8, qc);
                     row[4] = r6; row[5] = r7; row[6] = r8;
                     ml = r6 != SPL_NO_RANK ? 6 : ml;
                     ml = (r7 != SPL_NO_RANK && maxlen >= 7) ? 7 : ml;
@@ -1916,6 +1936,7 @@ void k_pretok(DeviceTables T, Batch b) {
     __shared__ uint32_t s_wsum[NT / 64];
     __shared__ uint32_t s_total;
     __shared__ uint32_t s_nch;                           // chunks on the probe list (small windows)
+    __shared__ uint32_t s_fast;                          // the tile's starts came from the bit-vector computation
     __shared__ uint32_t s_scnt[17];                      // counting sort of the short misses by length
     __shared__ uint32_t s_nq[4];                         // miss counts [0] (<= 16 B) [1] (17..64 B), work cursors [2] [3]
     // single-pass state
@@ -2117,7 +2138,10 @@ void k_pretok(DeviceTables T, Batch b) {
             while (j >= 0 && (s_rec[j] & CB_CLASS) == C_CONT && j > i - 3) j--;
             kc = j >= 0 ? (s_rec[j] & CB_CLASS) : (uint32_t)C_CONT;
         }
-        const uint32_t kb = kc < C_EOT ? kind_bits(kc) : 0u;
+        uint32_t kb = kc < C_EOT ? kind_bits(kc) : 0u;
+        // what keeps a window off the bit-vector start computation: a multi-byte character that is no
+        // letter, a span without text (special literal)
+        if (((cls == C_CONT || (r >> CB_LEN_SHIFT) != 0u) && !(kb & (1u << MK_L))) || (cls == C_EOT && i < iB)) kb |= 1u << MK_BAD;
         unsigned long long bal[MK_SY];
 #pragma unroll
         for (int k = 0; k < MK_CS; k++) bal[k] = __ballot((kb >> k) & 1u);
@@ -2145,6 +2169,67 @@ void k_pretok(DeviceTables T, Batch b) {
         s_mk[MK_SY * NBW1 + tid] = sync_word(KPAT, kw, kp);
     }
     __syncthreads();
+    // ---- cl100k: ALL match starts of the tile by bit-vector arithmetic (spl_scan_starts.h) ---------
+    // One wavefront, one mask word per lane.  The tile owns [fs, fe): fs = its first sync point, fe = the
+    // first sync point or text start at or behind the tile's end.  Needs fe inside the window and no
+    // disqualifying byte (MK_BAD) in the range; otherwise the chains below do the work as before.
+    if (SPL_MASK_STARTS && DIRECT && tid < 64) {
+        uint32_t fast = 0;
+        if (KPAT == PAT_CL100K) {
+            const bool in = tid < G::NBW;
+            auto ld = [&](int k) { return in ? s_mk[k * NBW1 + tid] : 0u; };
+            const uint32_t sy = ld(MK_SY), ts = ld(MK_TS);
+            // first sync point of the tile; first sync point / text start behind it
+            auto first_in = [&](uint32_t word, int from, int to) -> int {    // first set bit in [from, to), -1 if none
+                const int lo = from - tid * 32, hi = to - tid * 32;
+                if (hi <= 0 || lo >= 32) word = 0;
+                else {
+                    if (lo > 0) word &= ~0u << lo;
+                    if (hi < 32) word &= (1u << hi) - 1u;
+                }
+                const unsigned long long bl = __ballot(word != 0u);
+                if (!bl) return -1;
+                const int l0 = __ffsll((long long)bl) - 1;
+                return l0 * 32 + __ffs((int)__builtin_amdgcn_readlane(word, l0)) - 1;
+            };
+            const int fs = first_in(sy, LH, LH + TB_);
+            const int fe = first_in(sy | ts, iB < LH + TB_ ? iB : LH + TB_, Wv + 1);   // (a text that ends in the tile: its end)
+            if (fs < 0) fast = 1;                              // nothing owned
+            else if (fe >= 0) {
+                auto range_word = [&](int from, int to) -> uint32_t {
+                    const int lo = from - tid * 32, hi = to - tid * 32;
+                    if (hi <= 0 || lo >= 32) return 0u;
+                    uint32_t w = ~0u;
+                    if (lo > 0) w &= ~0u << lo;
+                    if (hi < 32) w &= (1u << hi) - 1u;
+                    return w;
+                };
+                const uint32_t own = range_word(fs, fe);
+                if (!__any((ld(MK_BAD) & own) != 0u)) {
+                    Cl100kStartMasks<WaveBV> cm{WaveBV{ld(MK_L)}, WaveBV{ld(MK_N)}, WaveBV{ld(MK_S)}, WaveBV{ld(MK_NL)},
+                                                WaveBV{ld(MK_O)}, WaveBV{ld(MK_AP)}, WaveBV{ld(MK_SP)}, WaveBV{ts}};
+                    WaveBV CA;
+                    bool ok;
+                    const WaveBV Bv = cl100k_starts(cm, CA, ok, 16);
+                    if (ok) {
+                        fast = 1;
+                        if (in) s_cbits[tid] = (Bv.x & own) | (range_word(fe, fe + 1));
+                        uint32_t ca = CA.x & own;
+                        const LdsAcc acc{s_rec, s_txt};
+                        while (ca) {                           // the few apostrophes that start a match
+                            const int ap = tid * 32 + __ffs((int)ca) - 1;
+                            ca &= ca - 1;
+                            const int e = contraction(acc, ap);
+                            if (e > 0 && e < fe) atomicOr(&s_cbits[e >> 5], 1u << (e & 31));
+                        }
+                    }
+                }
+            }
+        }
+        if (tid == 0) s_fast = fast;
+    }
+    if (SPL_MASK_STARTS && DIRECT) __syncthreads();
+    const bool fast_starts = SPL_MASK_STARTS && DIRECT && s_fast != 0u;
     SPL_STAMP(3);
 
     // ---- chains: each sync point inside the tile scans to the next sync point -------------------
@@ -2153,7 +2238,9 @@ void k_pretok(DeviceTables T, Batch b) {
     // otherwise serialise them while their neighbours idle.
     {
         uint32_t word = 0;
-        if (tid < G::NBW) {
+        if (fast_starts) {
+            if (tid < G::NBW) word = s_cbits[tid];                        // the tile's starts and their terminator
+        } else if (tid < G::NBW) {
             word = s_mk[MK_SY * NBW1 + tid];
             const int lo = LH - tid * 32, hi = LH + TB_ - tid * 32;       // tile range inside this word
             if (hi <= 0 || lo >= 32) word = 0;
@@ -2178,7 +2265,7 @@ void k_pretok(DeviceTables T, Batch b) {
     }
     {
         const MaskLdsAcc acc{s_rec, s_txt, s_mk, NBW1, Wv, (B - w0) <= (int64_t)Wv};
-        const int nsync = (int)s_total;
+        const int nsync = fast_starts ? 0 : (int)s_total;
         // only the LAST chain of a tile can reach the window end, so at most one start is recorded
         auto push_defer = [&](uint32_t gpos) {
             if (DIRECT && !b.qcount) {
@@ -2240,10 +2327,11 @@ void k_pretok(DeviceTables T, Batch b) {
     // ---- whole-chunk probe (large windows: the last marked position is only a terminator) -------------
     {
         LdsAcc tx{s_rec, s_txt};
-        const int K = LIST_CHUNKS ? (int)s_nch + 1 : (int)s_total;
+        const bool from_list = LIST_CHUNKS && !fast_starts;
+        const int K = from_list ? (int)s_nch + 1 : (int)s_total;
         for (int k = tid; k + 1 < K; k += NT) {
             int p, n;
-            if (LIST_CHUNKS) {
+            if (from_list) {
                 const uint32_t c = s_chunk[k];
                 p = (int)(c & 0xFFFFu); n = (int)(c >> 16);
             } else {

@@ -26,8 +26,15 @@ SPL_HD uint32_t mask_tail(uint32_t w, int nbytes) {     // keep the low nbytes (
 // sinks the later loads into the "not found yet" branches and a miss costs several DEPENDENT
 // memory round trips; with selects every load of the bucket is issued before the first wait.
 // keys of 1..4 bytes: two dwordx4 loads per bucket
-SPL_HD uint32_t probe_tiny(const DeviceTables& T, uint32_t k0, uint32_t n) {
-    uint32_t bkt = hash_tiny(k0, n) & T.tiny_mask;
+// last = the id word of a bucket's last slot: did a key that belongs here (or passed through) go on to
+// the next bucket?  (The builder sets SPL_OVF_BIT there; an empty slot is all-ones.)
+SPL_HD bool bucket_overflowed(uint32_t last) { return last != SPL_EMPTY && (last & SPL_OVF_BIT) != 0u; }
+
+// (k0 & 0xFFFF = the key's first two bytes, the second one zero for a one-byte key)
+SPL_HD uint32_t key_salt(const DeviceTables& T, uint32_t k0) { return (uint32_t)T.len_mask[k0 & 0xFFFFu] >> 8; }
+
+SPL_HD uint32_t probe_tiny(const DeviceTables& T, uint32_t k0, uint32_t n, uint32_t salt) {
+    uint32_t bkt = hash_tiny(k0, n, salt) & T.tiny_mask;
     for (;;) {
         const Quad* q = reinterpret_cast<const Quad*>(T.tiny_tab + (size_t)bkt * (SPL_TINY_BUCKET * 2));
         const Quad a = q[0], c = q[1];
@@ -36,17 +43,17 @@ SPL_HD uint32_t probe_tiny(const DeviceTables& T, uint32_t k0, uint32_t n) {
         const bool f2 = (c.x == k0) & ((c.y >> 24) == n);
         const bool f3 = (c.z == k0) & ((c.w >> 24) == n);
         uint32_t r = SPL_NO_RANK;
-        r = f3 ? (c.w & 0xFFFFFFu) : r;
-        r = f2 ? (c.y & 0xFFFFFFu) : r;
-        r = f1 ? (a.w & 0xFFFFFFu) : r;
-        r = f0 ? (a.y & 0xFFFFFFu) : r;
-        if ((f0 | f1 | f2 | f3) | (c.w == SPL_EMPTY)) return r;
+        r = f3 ? (c.w & SPL_ID_MASK) : r;
+        r = f2 ? (c.y & SPL_ID_MASK) : r;
+        r = f1 ? (a.w & SPL_ID_MASK) : r;
+        r = f0 ? (a.y & SPL_ID_MASK) : r;
+        if ((f0 | f1 | f2 | f3) | !bucket_overflowed(c.w)) return r;
         bkt = (bkt + 1) & T.tiny_mask;
     }
 }
 // keys of 5..8 bytes: three dwordx4 loads per bucket (entries of three words straddle them)
-SPL_HD uint32_t probe_t8(const DeviceTables& T, uint32_t k0, uint32_t k1, uint32_t n) {
-    uint32_t bkt = hash_t8(k0, k1, n) & T.t8_mask;
+SPL_HD uint32_t probe_t8(const DeviceTables& T, uint32_t k0, uint32_t k1, uint32_t n, uint32_t salt) {
+    uint32_t bkt = hash_t8(k0, k1, n, salt) & T.t8_mask;
     for (;;) {
         const Quad* q = reinterpret_cast<const Quad*>(T.t8_tab + (size_t)bkt * SPL_T8_WORDS);
         const Quad a = q[0], c = q[1], d = q[2];
@@ -55,19 +62,19 @@ SPL_HD uint32_t probe_t8(const DeviceTables& T, uint32_t k0, uint32_t k1, uint32
         const bool f2 = (c.z == k0) & (c.w == k1) & ((d.x >> 24) == n);
         const bool f3 = (d.y == k0) & (d.z == k1) & ((d.w >> 24) == n);
         uint32_t r = SPL_NO_RANK;
-        r = f3 ? (d.w & 0xFFFFFFu) : r;
-        r = f2 ? (d.x & 0xFFFFFFu) : r;
-        r = f1 ? (c.y & 0xFFFFFFu) : r;
-        r = f0 ? (a.z & 0xFFFFFFu) : r;
-        if ((f0 | f1 | f2 | f3) | (d.w == SPL_EMPTY)) return r;
+        r = f3 ? (d.w & SPL_ID_MASK) : r;
+        r = f2 ? (d.x & SPL_ID_MASK) : r;
+        r = f1 ? (c.y & SPL_ID_MASK) : r;
+        r = f0 ? (a.z & SPL_ID_MASK) : r;
+        if ((f0 | f1 | f2 | f3) | !bucket_overflowed(d.w)) return r;
         bkt = (bkt + 1) & T.t8_mask;
     }
 }
 // keys of up to 12 bytes, by length class
-SPL_HD uint32_t probe_short(const DeviceTables& T, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t n) {
-    if (n <= (uint32_t)SPL_TINY_MAX) return probe_tiny(T, k0, n);
-    if (n <= (uint32_t)SPL_T8_MAX) return probe_t8(T, k0, k1, n);
-    uint32_t bkt = hash_short(k0, k1, k2, n) & T.short_mask;
+SPL_HD uint32_t probe_short(const DeviceTables& T, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t n, uint32_t salt) {
+    if (n <= (uint32_t)SPL_TINY_MAX) return probe_tiny(T, k0, n, salt);
+    if (n <= (uint32_t)SPL_T8_MAX) return probe_t8(T, k0, k1, n, salt);
+    uint32_t bkt = hash_short(k0, k1, k2, n, salt) & T.short_mask;
     for (;;) {
         const Quad* q = reinterpret_cast<const Quad*>(T.short_tab + (size_t)bkt * SPL_SHORT_BUCKET);
         const Quad e0 = q[0], e1 = q[1], e2 = q[2], e3 = q[3];     // four independent 16-byte loads
@@ -76,13 +83,17 @@ SPL_HD uint32_t probe_short(const DeviceTables& T, uint32_t k0, uint32_t k1, uin
         const bool f2 = (e2.x == k0) & (e2.y == k1) & (e2.z == k2) & ((e2.w >> 24) == n);
         const bool f3 = (e3.x == k0) & (e3.y == k1) & (e3.z == k2) & ((e3.w >> 24) == n);
         uint32_t r = SPL_NO_RANK;
-        r = f3 ? (e3.w & 0xFFFFFFu) : r;
-        r = f2 ? (e2.w & 0xFFFFFFu) : r;
-        r = f1 ? (e1.w & 0xFFFFFFu) : r;
-        r = f0 ? (e0.w & 0xFFFFFFu) : r;
-        if ((f0 | f1 | f2 | f3) | (e3.w == SPL_EMPTY)) return r;   // found, or bucket not full: no overflow
+        r = f3 ? (e3.w & SPL_ID_MASK) : r;
+        r = f2 ? (e2.w & SPL_ID_MASK) : r;
+        r = f1 ? (e1.w & SPL_ID_MASK) : r;
+        r = f0 ? (e0.w & SPL_ID_MASK) : r;
+        if ((f0 | f1 | f2 | f3) | !bucket_overflowed(e3.w)) return r;   // found, or nothing overflowed from here
         bkt = (bkt + 1) & T.short_mask;
     }
+}
+
+SPL_HD uint32_t probe_short(const DeviceTables& T, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t n) {
+    return probe_short(T, k0, k1, k2, n, key_salt(T, k0));
 }
 
 template <class TX> SPL_HD uint32_t probe_long(const DeviceTables& T, const TX& tx, int p, int n) {

@@ -19,7 +19,9 @@
 
 namespace spl {
 
-enum : int { MK_L = 0, MK_N, MK_S, MK_NL, MK_O, MK_M, MK_AP, MK_CS, MK_TS, MK_SY, MK_COUNT };
+// (MK_SP: U+0020 only.  MK_BAD: bytes that keep a window off the bit-vector start computation of
+//  spl_scan_starts.h -- set by the mask builder, not a kind of a class)
+enum : int { MK_L = 0, MK_N, MK_S, MK_NL, MK_O, MK_M, MK_AP, MK_SP, MK_BAD, MK_CS, MK_TS, MK_SY, MK_COUNT };
 
 // kind of one class code, as mask membership bits (bit MK_x)
 SPL_HD uint32_t kind_bits(uint32_t cls) {
@@ -32,6 +34,7 @@ SPL_HD uint32_t kind_bits(uint32_t cls) {
     if (b & M_OTHER) k |= 1u << MK_O;
     if (cls == C_M) k |= 1u << MK_M;
     if (cls == C_AP) k |= 1u << MK_AP;
+    if (cls == C_SP) k |= 1u << MK_SP;
     return k;
 }
 

@@ -278,7 +278,7 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
     for (const auto& kv : enc) {
         const std::string& k = kv.first;
         if (k.size() < 2) continue;
-        out.len_mask[(uint8_t)k[0] | (uint32_t)(uint8_t)k[1] << 8] |= (uint8_t)(1u << (k.size() > (size_t)SPL_T8_MAX ? 7 : k.size() - 2));
+        out.len_mask[(uint8_t)k[0] | (uint32_t)(uint8_t)k[1] << 8] |= (uint16_t)(1u << (k.size() > (size_t)SPL_T8_MAX ? 7 : k.size() - 2));
     }
     {   // p8: for every 8-byte prefix of a longer token, the longest such token
         size_t n9 = 0;
@@ -303,39 +303,98 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
             }
         }
     }
+    // ---- tiny / t8 / short tables: one SALT per two-byte key prefix (DeviceTables::len_mask) ------------
+    // Keys are placed group by group (a group = all keys of up to 12 bytes with the same first two
+    // bytes, largest group first); a group takes the first salt under which each of its keys finds its
+    // home bucket with a free slot.  No key then ever overflows, so no probe -- hit or miss -- goes on to a
+    // second bucket.  A group that finds no salt (a large group late in a well-filled table: one group of
+    // o200k_base, 5 of its keys; none in the other shipped vocabularies) keeps salt 0 and overflows into
+    // the next bucket, marking the full one (SPL_OVF_BIT); the probes walk on from a marked bucket, so
+    // this costs speed only -- and only for the probes that land on those few buckets.
+    {
+        constexpr int SPL_BUCKET_FILL = 4;
+        struct KeyRef { const std::string* k; uint32_t id; };
+        std::vector<std::vector<KeyRef>> groups(65536);
+        for (const auto& kv : enc) {
+            const std::string& k = kv.first;
+            if (k.size() > (size_t)SPL_SHORT_MAX) continue;
+            groups[(uint8_t)k[0] | (k.size() > 1 ? (uint32_t)(uint8_t)k[1] << 8 : 0u)].push_back(KeyRef{&k, kv.second});
+        }
+        std::vector<uint32_t> order;
+        for (uint32_t g = 0; g < 65536; g++) if (!groups[g].empty()) order.push_back(g);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return groups[a].size() > groups[b].size(); });
+        std::vector<uint8_t> cnt_t(tbuckets, 0), cnt_e(ebuckets, 0), cnt_s(sbuckets, 0);
+        auto home = [&](const std::string& k, uint32_t salt, int& which) -> uint32_t {
+            const uint32_t n = (uint32_t)k.size();
+            if (n <= (uint32_t)SPL_TINY_MAX) { which = 0; return hash_tiny(load_le(k, 0), n, salt) & (tbuckets - 1); }
+            if (n <= (uint32_t)SPL_T8_MAX) { which = 1; return hash_t8(load_le(k, 0), load_le(k, 4), n, salt) & (ebuckets - 1); }
+            which = 2;
+            return hash_short(load_le(k, 0), load_le(k, 4), load_le(k, 8), n, salt) & (sbuckets - 1);
+        };
+        auto put = [&](const std::string& k, uint32_t id, uint32_t bkt, int which) {      // first bucket at or behind bkt with a free slot
+            const uint32_t n = (uint32_t)k.size();
+            if (which == 0) {
+                for (;;) {
+                    uint32_t* e = &out.tiny_tab[(size_t)bkt * SPL_TINY_BUCKET * 2];
+                    int f = 0;
+                    while (f < SPL_TINY_BUCKET && e[2 * f + 1] != SPL_EMPTY) f++;
+                    if (f < SPL_TINY_BUCKET) { e[2 * f] = load_le(k, 0); e[2 * f + 1] = id | (n << 24); cnt_t[bkt]++; return; }
+                    e[2 * (SPL_TINY_BUCKET - 1) + 1] |= SPL_OVF_BIT;
+                    bkt = (bkt + 1) & (tbuckets - 1);
+                }
+            } else if (which == 1) {
+                for (;;) {
+                    uint32_t* e = &out.t8_tab[(size_t)bkt * SPL_T8_WORDS];
+                    int f = 0;
+                    while (f < SPL_T8_BUCKET && e[3 * f + 2] != SPL_EMPTY) f++;
+                    if (f < SPL_T8_BUCKET) { e[3 * f] = load_le(k, 0); e[3 * f + 1] = load_le(k, 4); e[3 * f + 2] = id | (n << 24); cnt_e[bkt]++; return; }
+                    e[3 * (SPL_T8_BUCKET - 1) + 2] |= SPL_OVF_BIT;
+                    bkt = (bkt + 1) & (ebuckets - 1);
+                }
+            } else {
+                for (;;) {
+                    ShortEnt* e = &out.short_tab[(size_t)bkt * SPL_SHORT_BUCKET];
+                    int f = 0;
+                    while (f < SPL_SHORT_BUCKET && e[f].id_len != SPL_EMPTY) f++;
+                    if (f < SPL_SHORT_BUCKET) { e[f] = ShortEnt{load_le(k, 0), load_le(k, 4), load_le(k, 8), id | (n << 24)}; cnt_s[bkt]++; return; }
+                    e[SPL_SHORT_BUCKET - 1].id_len |= SPL_OVF_BIT;
+                    bkt = (bkt + 1) & (sbuckets - 1);
+                }
+            }
+        };
+        std::vector<std::pair<int, uint32_t>> touched;
+        for (uint32_t g : order) {
+            const auto& keys = groups[g];
+            uint32_t salt = 0;
+            bool found = false;
+            for (; salt < 256 && !found; salt++) {
+                touched.clear();
+                bool ok = true;
+                for (const KeyRef& kr : keys) {
+                    int which;
+                    const uint32_t bkt = home(*kr.k, salt, which);
+                    uint8_t& c = which == 0 ? cnt_t[bkt] : which == 1 ? cnt_e[bkt] : cnt_s[bkt];
+                    if (c >= SPL_BUCKET_FILL) { ok = false; break; }
+                    c++;
+                    touched.emplace_back(which, bkt);
+                }
+                for (const auto& t : touched) (t.first == 0 ? cnt_t[t.second] : t.first == 1 ? cnt_e[t.second] : cnt_s[t.second])--;
+                if (ok) { found = true; break; }
+            }
+            if (!found) { salt = 0; out.unsalted_groups++; }
+            out.len_mask[g] = (uint16_t)((out.len_mask[g] & 0xFFu) | (salt << 8));
+            for (const KeyRef& kr : keys) {
+                int which;
+                const uint32_t bkt = home(*kr.k, salt, which);
+                put(*kr.k, kr.id, bkt, which);
+            }
+        }
+    }
     for (const auto& kv : enc) {
         const std::string& k = kv.first;
         const uint32_t n = (uint32_t)k.size();
-        if (n <= (uint32_t)SPL_TINY_MAX) {
-            const uint32_t k0 = load_le(k, 0);
-            uint32_t bkt = hash_tiny(k0, n) & (tbuckets - 1);
-            for (;;) {
-                uint32_t* e = &out.tiny_tab[(size_t)bkt * SPL_TINY_BUCKET * 2];
-                int f = 0;
-                while (f < SPL_TINY_BUCKET && e[2 * f + 1] != SPL_EMPTY) f++;
-                if (f < SPL_TINY_BUCKET) { e[2 * f] = k0; e[2 * f + 1] = kv.second | (n << 24); break; }
-                bkt = (bkt + 1) & (tbuckets - 1);
-            }
-        } else if (n <= (uint32_t)SPL_T8_MAX) {
-            const uint32_t k0 = load_le(k, 0), k1 = load_le(k, 4);
-            uint32_t bkt = hash_t8(k0, k1, n) & (ebuckets - 1);
-            for (;;) {
-                uint32_t* e = &out.t8_tab[(size_t)bkt * SPL_T8_WORDS];
-                int f = 0;
-                while (f < SPL_T8_BUCKET && e[3 * f + 2] != SPL_EMPTY) f++;
-                if (f < SPL_T8_BUCKET) { e[3 * f] = k0; e[3 * f + 1] = k1; e[3 * f + 2] = kv.second | (n << 24); break; }
-                bkt = (bkt + 1) & (ebuckets - 1);
-            }
-        } else if (n <= (uint32_t)SPL_SHORT_MAX) {
-            const uint32_t k0 = load_le(k, 0), k1 = load_le(k, 4), k2 = load_le(k, 8);
-            uint32_t bkt = hash_short(k0, k1, k2, n) & (sbuckets - 1);
-            for (;;) {                                   // first bucket with a free slot, slots left to right
-                ShortEnt* e = &out.short_tab[(size_t)bkt * SPL_SHORT_BUCKET];
-                int f = 0;
-                while (f < SPL_SHORT_BUCKET && e[f].id_len != SPL_EMPTY) f++;
-                if (f < SPL_SHORT_BUCKET) { e[f] = ShortEnt{k0, k1, k2, kv.second | (n << 24)}; break; }
-                bkt = (bkt + 1) & (sbuckets - 1);
-            }
+        if (n <= (uint32_t)SPL_SHORT_MAX) {
+            continue;                                    // placed above
         } else {
             uint32_t h = 0;
             for (uint32_t i = 0; i < n; i += 4) h = hash_long_step(h, load_le(k, i));

@@ -28,7 +28,8 @@ struct HostTables {
     std::vector<uint64_t> pair_tab;
     std::vector<uint32_t> byte_id;      // 256
     std::vector<uint32_t> p8_tab;       // DeviceTables::p8_tab (two words per bucket)
-    std::vector<uint8_t> len_mask;      // DeviceTables::len_mask (65536)
+    std::vector<uint16_t> len_mask;     // DeviceTables::len_mask (65536): length mask | salt << 8
+    uint32_t unsalted_groups = 0;       // two-byte key prefixes for which no salt kept every bucket below full (0 for the shipped vocabularies)
     uint32_t tiny_free = 0, t8_free = 0;
     uint32_t max_key_len = 0;           // in the key space the kernels see (raw bytes)
     uint32_t n_keys = 0, n_pairs = 0;

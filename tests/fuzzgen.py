@@ -89,3 +89,17 @@ def invalid_utf8_corpus(seed: int, count: int) -> List[bytes]:
             b = b[:rng.randrange(len(b)) + 1]                 # cut anywhere, also inside a character
         out.append(b)
     return out
+
+
+_LATIN_ATOMS = [" ", " ", "  ", "\n", "\n\n", "\r\n", "\t", " \n", "\n ", "   ", "\x0b", "\x0c", "a", "b", "Hello", "world", "é", "ü", "ſ",
+                "Ünï", "日本", "'", "'s", "'S", "'t", "'re", "'RE", "'ve", "'ll", "'lL", "'d", "'m", "'ſ", "'l", "'r", "'x", "1", "12", "123",
+                "1234", "12345678", "!", "!!", ".", ",", "()", "{", "}\n", ";\n", "/", "//", "#", "x=1", "->", "_", "__", "-", "\"", "`",
+                "~", "\x00", "\x7f", "\x1f"]
+
+
+def latin_corpus(seed: int, count: int, max_atoms: int = 120) -> List[str]:
+    """ASCII text with letters beyond ASCII and nothing else multi-byte: the windows the bit-vector start
+    computation (spl_scan_starts.h) takes -- whitespace runs with and without newlines, contractions in
+    either case and with U+017F, number runs of every length mod 3, "other" runs before letters."""
+    rng = random.Random(seed)
+    return ["".join(rng.choice(_LATIN_ATOMS) for _ in range(rng.randint(0, max_atoms))) for _ in range(count)]

@@ -310,3 +310,158 @@ extern "C" int hs_split_masks(void* p, const uint8_t* text, int n, uint32_t* sta
     for (int q = 0; q < n; q++) if (mark[q]) starts[k++] = q;
     return k;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Bit-vector start computation (spl_scan_starts.h) driven the way k_pretok drives it: several
+// documents packed back to back, tiles of `tb` bytes with a 32-byte left halo and `rh` bytes of right
+// halo.  A tile whose window qualifies (no MK_BAD byte from its first sync point to its end
+// sync point, end sync point inside the window, loops converged) takes its starts from the masks;
+// any other tile runs the chains over the whole text.  stats: [0] tiles, [1] tiles on the fast path.
+#include "../../splintr_amd/csrc/spl_scan_starts.h"
+
+struct HostBV {
+    std::vector<uint32_t> w;
+    HostBV() {}
+    explicit HostBV(size_t n) : w(n, 0u) {}
+    HostBV operator&(const HostBV& o) const { HostBV r(w.size()); for (size_t i = 0; i < w.size(); i++) r.w[i] = w[i] & o.w[i]; return r; }
+    HostBV operator|(const HostBV& o) const { HostBV r(w.size()); for (size_t i = 0; i < w.size(); i++) r.w[i] = w[i] | o.w[i]; return r; }
+    HostBV operator~() const { HostBV r(w.size()); for (size_t i = 0; i < w.size(); i++) r.w[i] = ~w[i]; return r; }
+    HostBV shl1() const { HostBV r(w.size()); for (size_t i = 0; i < w.size(); i++) r.w[i] = (w[i] << 1) | (i ? w[i - 1] >> 31 : 0u); return r; }
+    HostBV shr1() const { HostBV r(w.size()); for (size_t i = 0; i < w.size(); i++) r.w[i] = (w[i] >> 1) | (i + 1 < w.size() ? w[i + 1] << 31 : 0u); return r; }
+    bool any() const { for (uint32_t x : w) if (x) return true; return false; }
+    bool bit(int i) const { return (w[i >> 5] >> (i & 31)) & 1u; }
+};
+
+extern "C" int hs_split_starts(void* p, const uint8_t* text, int n, const int* doc_off, int n_docs, uint32_t* starts,
+                               int tb, int rh, int max_iter, uint32_t* stats) {
+    Sim* s = (Sim*)p;
+    if (s->ht.pattern != PAT_CL100K) return -10;
+    std::vector<uint8_t> recs(n + 64, 0);
+    for (int d = 0; d < n_docs; d++) {
+        std::vector<uint8_t> r;
+        classify(*s, text + doc_off[d], doc_off[d + 1] - doc_off[d], r);
+        std::copy(r.begin(), r.end(), recs.begin() + doc_off[d]);
+    }
+    std::vector<uint8_t> mark(n + 1, 0);
+    const int LHv = 32;
+    uint32_t n_tiles = 0, n_fast = 0, n_nofe = 0, n_bad = 0, n_iter = 0;
+    for (int t0 = 0; t0 < n; t0 += tb) {
+        n_tiles++;
+        const int w0 = t0 - LHv;
+        const int W = LHv + tb + rh;
+        const int iB = (n - w0 < W) ? n - w0 : W;
+        std::vector<uint8_t> wrec(W + 64, (uint8_t)C_WEND);
+        std::vector<uint8_t> wtxt(W + 64, 0);
+        for (int i = 0; i < W + 32; i++) {
+            const int g = w0 + i;
+            if (g >= 0 && g < n) wtxt[i] = text[g];
+            if (i >= iB) continue;
+            wrec[i] = g < 0 ? (uint8_t)C_CONT : (uint8_t)(recs[g] & ~CB_SYNC);
+        }
+        if (iB < W) wrec[iB] = (uint8_t)(C_EOT | CB_TSTART);
+        MaskWin m;
+        m.recs = wrec.data(); m.text = wtxt.data(); m.W = W; m.eot = (n - w0 <= W); m.text_n_rel = W + 32;
+        const int nw = W / 32 + 1;
+        for (int k = 0; k < MK_COUNT; k++) m.mk[k].assign(nw, 0);
+        for (int i = 0; i <= iB && i <= W; i++) {
+            if (i == W && iB == W) break;
+            const uint32_t r = wrec[i];
+            const uint32_t cls = r & CB_CLASS;
+            if (r & CB_TSTART) m.mk[MK_TS][i >> 5] |= 1u << (i & 31);
+            if (i == iB) break;
+            uint32_t kc = cls;
+            if (cls == C_CONT) {
+                int j = i - 1;
+                while (j >= 0 && (wrec[j] & CB_CLASS) == C_CONT && j > i - 3) j--;
+                kc = j >= 0 ? (wrec[j] & CB_CLASS) : (uint32_t)C_CONT;
+            } else if (cls < C_EOT) {
+                m.mk[MK_CS][i >> 5] |= 1u << (i & 31);
+            }
+            uint32_t kb = kc < C_EOT ? kind_bits(kc) : 0u;
+            // what keeps a window off the fast path: a multi-byte character that is no letter, a span
+            // without text (special literal), a byte before the first text
+            const bool multi = cls == C_CONT || ((r >> CB_LEN_SHIFT) & 3u) != 0;
+            if ((multi && !(kb & (1u << MK_L))) || cls == C_EOT || cls == C_WEND) kb |= 1u << MK_BAD;
+            for (int k = 0; k < MK_CS; k++) if ((kb >> k) & 1u) m.mk[k][i >> 5] |= 1u << (i & 31);
+        }
+        for (int w = 0; w < nw; w++) {
+            uint32_t kw[MK_COUNT], kp[MK_COUNT];
+            for (int k = 0; k < MK_COUNT; k++) { kw[k] = m.mk[k][w]; kp[k] = w ? m.mk[k][w - 1] : 0u; }
+            m.mk[MK_SY][w] = sync_word(s->ht.pattern, kw, kp);
+        }
+        // ---- fast path ----
+        bool fast = false;
+        {
+            int fs = -1, fe = -1;
+            for (int i = LHv; i < LHv + tb && i < iB; i++) if (bit_m(m, MK_SY, i)) { fs = i; break; }
+            for (int i = LHv + tb; i <= iB && i <= W; i++) if (bit_m(m, MK_SY, i) || bit_m(m, MK_TS, i)) { fe = i; break; }
+            if (LHv + tb >= iB) fe = iB;                   // the text ends inside the tile
+            if (fs < 0) fast = true;                       // nothing owned
+            else if (fe >= 0) {
+                bool bad = false;
+                for (int i = fs; i < fe; i++) if (bit_m(m, MK_BAD, i)) bad = true;
+                if (bad) n_bad++;
+                if (!bad) {
+                    Cl100kStartMasks<HostBV> cm;
+                    auto mkbv = [&](int k) { HostBV b(nw); b.w = m.mk[k]; return b; };
+                    cm.L = mkbv(MK_L); cm.N = mkbv(MK_N); cm.S = mkbv(MK_S); cm.NL = mkbv(MK_NL); cm.O = mkbv(MK_O);
+                    cm.AP = mkbv(MK_AP); cm.SP = mkbv(MK_SP); cm.TS = mkbv(MK_TS);
+                    HostBV CA; bool ok;
+                    HostBV Bv = cl100k_starts(cm, CA, ok, max_iter);
+                    if (ok) {
+                        for (int i = fs; i < fe; i++) {
+                            if (Bv.bit(i)) mark[w0 + i] = 1;
+                            if (CA.bit(i)) {
+                                const int e = contraction(m, i);
+                                if (e == SPL_DEFER) return -3;
+                                if (e > 0 && e < fe) mark[w0 + e] = 1;
+                                if (e > fe) return -4;
+                            }
+                        }
+                        fast = true;
+                    } else n_iter++;
+                }
+            } else n_nofe++;
+        }
+        if (fast) { n_fast++; continue; }
+        // ---- chains over the whole text (the kernel's chain phase + deferral) ----
+        for (int i = LHv; i < LHv + tb && i < iB; i++) {
+            if (!bit_m(m, MK_SY, i)) continue;
+            WinAcc g{recs.data(), text, n, (uint32_t)(C_EOT | CB_TSTART | CB_SYNC), n};
+            int gp = w0 + i;
+            // end of this document
+            int dend = n;
+            for (int d = 0; d < n_docs; d++) if (doc_off[d] <= gp && gp < doc_off[d + 1]) dend = doc_off[d + 1];
+            WinAcc gd{recs.data(), text, dend, (uint32_t)(C_EOT | CB_TSTART | CB_SYNC), dend};
+            for (;;) {
+                mark[gp] = 1;
+                int ge = match_end(gd, gp, s->ht.pattern);
+                if (ge <= gp) return -1;
+                gp = ge;
+                if (gp >= dend || (recs[gp] & (CB_SYNC | CB_TSTART))) break;
+            }
+        }
+    }
+    if (stats) { stats[0] = n_tiles; stats[1] = n_fast; stats[2] = n_nofe; stats[3] = n_bad; stats[4] = n_iter; }
+    int k = 0;
+    for (int q = 0; q < n; q++) if (mark[q]) starts[k++] = q;
+    return k;
+}
+
+// buckets from which a key went on to the next one (a probe that misses there takes the generic path)
+extern "C" void hs_bucket_stats(void* p, uint32_t* out) {
+    Sim* s = (Sim*)p;
+    const HostTables& h = s->ht;
+    uint32_t nb = (uint32_t)(h.tiny_tab.size() / (SPL_TINY_BUCKET * 2)), full = 0;
+    for (uint32_t b = 0; b < nb; b++) if (bucket_overflowed(h.tiny_tab[(size_t)b * SPL_TINY_BUCKET * 2 + SPL_TINY_BUCKET * 2 - 1])) full++;
+    out[0] = nb; out[1] = full;
+    nb = (uint32_t)(h.t8_tab.size() / SPL_T8_WORDS); full = 0;
+    for (uint32_t b = 0; b < nb; b++) if (bucket_overflowed(h.t8_tab[(size_t)b * SPL_T8_WORDS + 11])) full++;
+    out[2] = nb; out[3] = full;
+    nb = (uint32_t)(h.short_tab.size() / SPL_SHORT_BUCKET); full = 0;
+    const uint32_t* st = reinterpret_cast<const uint32_t*>(h.short_tab.data());
+    const size_t wpb = sizeof(h.short_tab[0]) * SPL_SHORT_BUCKET / 4;
+    for (uint32_t b = 0; b < nb; b++) if (bucket_overflowed(st[(size_t)b * wpb + wpb - 1])) full++;
+    out[4] = nb; out[5] = full;
+    out[6] = h.unsalted_groups;
+}

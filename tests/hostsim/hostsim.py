@@ -16,7 +16,7 @@ _REG = {"cl100k_base": ("cl100k_base.splv", 0), "o200k_base": ("o200k_base.splv"
 
 def build():
     srcs = [os.path.join(_HERE, "hostsim.cpp"), os.path.join(_CSRC, "spl_tables.cpp")]
-    deps = srcs + [os.path.join(_CSRC, h) for h in ("spl_common.h", "spl_scan.h", "spl_scan_masks.h", "spl_lookup.h", "spl_tables.h")]
+    deps = srcs + [os.path.join(_CSRC, h) for h in ("spl_common.h", "spl_scan.h", "spl_scan_masks.h", "spl_scan_starts.h", "spl_lookup.h", "spl_tables.h")]
     if not os.path.exists(_LIB) or any(os.path.getmtime(d) > os.path.getmtime(_LIB) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", _LIB] + srcs)
     return _LIB
@@ -39,6 +39,10 @@ def lib():
         L.hs_split_sync.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         L.hs_split_masks.restype = ctypes.c_int
         L.hs_split_masks.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.hs_split_starts.restype = ctypes.c_int
+        L.hs_split_starts.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                      ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.hs_bucket_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.hs_classify_check.restype = ctypes.c_int
         L.hs_classify_check.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
         L.hs_encode.restype = ctypes.c_int
@@ -65,6 +69,12 @@ class HostSim:
         return dict(zip(["n_keys", "n_pairs", "max_key_len", "max_id", "short_cap", "long_cap", "pair_cap", "cjk_fast"],
                         a.tolist()))
 
+    def bucket_stats(self):
+        """(buckets, full buckets) of the tiny, t8 and short tables, and the key groups that found no salt."""
+        a = np.zeros(7, dtype=np.uint32)
+        lib().hs_bucket_stats(self._h, a.ctypes.data)
+        return {"tiny": (int(a[0]), int(a[1])), "t8": (int(a[2]), int(a[3])), "short": (int(a[4]), int(a[5])), "unsalted_groups": int(a[6])}
+
     def split(self, data: bytes, window: int = 0):
         out = np.zeros(len(data) + 1, dtype=np.uint32)
         k = lib().hs_split(self._h, data, len(data), out.ctypes.data, window)
@@ -79,6 +89,25 @@ class HostSim:
         if k < 0:
             raise RuntimeError(f"hs_split_sync failed: {k}")
         return out[:k].tolist(), int(st[0]), int(st[1])
+
+    def split_starts(self, docs, tb: int = 768, rh: int = 224, max_iter: int = 64):
+        """Per-document start lists from the bit-vector start computation (cl100k), and (tiles, fast tiles, no end sync
+        point, disqualifying bytes, loops not converged)."""
+        data = b"".join(docs)
+        off = np.zeros(len(docs) + 1, dtype=np.int32)
+        off[1:] = np.cumsum([len(d) for d in docs])
+        out = np.zeros(len(data) + 1, dtype=np.uint32)
+        st = np.zeros(5, dtype=np.uint32)
+        k = lib().hs_split_starts(self._h, data, len(data), off.ctypes.data, len(docs), out.ctypes.data, tb, rh, max_iter,
+                                  st.ctypes.data)
+        if k < 0:
+            raise RuntimeError(f"hs_split_starts failed: {k}")
+        starts = out[:k].astype(np.int64)
+        res = []
+        for d in range(len(docs)):
+            a = starts[(starts >= off[d]) & (starts < off[d + 1])] - off[d]
+            res.append(a.tolist())
+        return res, tuple(int(x) for x in st)
 
     def split_masks(self, data: bytes, tb: int = 64, rh: int = 32):
         out = np.zeros(len(data) + 1, dtype=np.uint32)

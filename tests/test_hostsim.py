@@ -4,7 +4,7 @@ forms, deferral contract at tiny windows, sync-point rules, table formats, the l
 import pytest
 
 from conftest import VOCABS
-from fuzzgen import fuzz_corpus, invalid_utf8_corpus
+from fuzzgen import fuzz_corpus, invalid_utf8_corpus, latin_corpus
 from hostsim import HostSim
 
 _sims = {}
@@ -72,6 +72,41 @@ def test_mask_scanner_tiled_like_the_kernel(coracle, name):
         ref = c.split_bytes(b)
         for tb, rh in ((32, 32), (64, 32), (96, 64), (768, 224)):
             assert h.split_masks(b, tb, rh) == ref, (tb, rh, s)
+
+
+@pytest.mark.parametrize("name", VOCABS)
+def test_salted_tables_have_no_overflow(name):
+    """The builder salts the bucket hashes per two-byte key prefix so that (almost) no key leaves its home
+    bucket: a probe -- hit or miss -- is then settled by one bucket (a wavefront waits for its slowest lane)."""
+    st = sim(name).bucket_stats()
+    for tab in ("tiny", "t8", "short"):
+        buckets, marked = st[tab]
+        assert marked <= buckets // 4096, (tab, st)            # plain hashing marked 1.6 % / 6.7 % / 2.5 % (cl100k)
+    assert st["unsalted_groups"] <= 1, st
+
+
+def test_bitvector_starts_tiled_like_the_kernel(coracle):
+    """spl_scan_starts.h (cl100k match starts by bit-vector arithmetic on the class masks) driven tile by
+    tile as k_pretok drives it, several documents per buffer; tiles that do not qualify (multi-byte
+    characters other than letters, no end sync point in the window, loops not converged) take the chains."""
+    import random
+    h, c = sim("cl100k_base"), coracle("cl100k_base")
+    rng = random.Random(5)
+    for corp, min_fast in ((latin_corpus(11, 2500), 1.0), (fuzz_corpus(777, 3000, 60), 0.1)):
+        docs_all = [s.encode("utf-8") for s in corp]
+        i, tiles, fast = 0, 0, 0
+        while i < len(docs_all):
+            k = rng.randint(1, 8)
+            docs = docs_all[i:i + k]
+            i += k
+            ref = [c.split_bytes(d) for d in docs]
+            for tb, rh, mi in ((32, 32, 64), (64, 32, 64), (96, 64, 2), (768, 224, 16)):
+                got, st = h.split_starts(docs, tb, rh, mi)
+                assert got == ref, (tb, rh, docs)
+                if mi > 2:
+                    tiles += st[0]
+                    fast += st[1]
+        assert fast >= min_fast * tiles, (fast, tiles)
 
 
 @pytest.mark.parametrize("name", ["cl100k_base", "o200k_base", "mistral_v3"])
