@@ -247,6 +247,7 @@ int upload_tables(Ctx& c, const HostTables& ht) {
     if ((rc = dev_upload(ht.p8_tab, reinterpret_cast<const uint32_t**>(&c.dt.p8_tab)))) return rc;
     if ((rc = dev_upload(ht.len_mask, &c.dt.len_mask))) return rc;
     c.dt.ucls_shift = ht.ucls_shift;
+    c.dt.ascii_base = (uint32_t)ht.ucls_stage1[0] << ht.ucls_shift;
     c.dt.cjk_fast = ht.cjk_fast ? 1u : 0u;
     c.dt.short_mask = (uint32_t)(ht.short_tab.size() / SPL_SHORT_BUCKET) - 1;
     c.dt.tiny_mask = (uint32_t)(ht.tiny_tab.size() / (SPL_TINY_BUCKET * 2)) - 1;

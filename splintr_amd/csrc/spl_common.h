@@ -133,6 +133,7 @@ struct DeviceTables {
     // tiny_free / t8_free: a bucket of each table with a free slot -- where probes known to miss are
     // sent (one cache line for all of them).
     const uint16_t* len_mask;  uint32_t tiny_free, t8_free;
+    uint32_t ascii_base;      // ucls_stage1[0] << ucls_shift: where the classes of U+0000..U+007F start in ucls_stage2
 };
 
 // ----------------------------------------------------------------------------------------

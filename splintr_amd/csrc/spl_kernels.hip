@@ -597,8 +597,11 @@ __device__ __forceinline__ uint32_t t8_finish(const DeviceTables& T, uint32_t k0
 
 // The merge loop of one 16-lane group over `n` <= 16 nodes whose substring ids are tabulated: lane
 // gl owns node gl, `row` is ITS table row, `id` its byte's id.  Survivors go to emit(gl, id).
+// far_max (per lane): the longest token of more than SUB_LMAX bytes that can start at this lane's byte
+// (p8 table: an upper bound; 0 = none) -- longer spans rank SPL_NO_RANK without a trip to the pair table.
+constexpr int FAR_UNBOUNDED = 1 << 20;
 template <class Emit>
-__device__ __forceinline__ void group16_merge(const DeviceTables& T, const uint32_t* row, uint32_t id, int n, Emit emit) {
+__device__ __forceinline__ void group16_merge(const DeviceTables& T, const uint32_t* row, uint32_t id, int n, int far_max, Emit emit) {
     const int lane = threadIdx.x & 63;
     const int gl = lane & 15;
     const int gbase = lane - gl;
@@ -628,9 +631,9 @@ __device__ __forceinline__ void group16_merge(const DeviceTables& T, const uint3
         // the table (rare) take the branch to the pair table.
         const bool is_mi = gl == mi, is_h = gl == h;
         const int len = is_mi ? len_r : len_h;
-        const bool far = active && len > SUB_LMAX && ((is_mi && j2 >= 0) || is_h);
+        const bool far = active && len > SUB_LMAX && len <= far_max && ((is_mi && j2 >= 0) || is_h);
         const int cell = len - 2 < 0 ? 0 : len - 2 > SUB_W - 1 ? SUB_W - 1 : len - 2;
-        uint32_t nr = row[cell];
+        uint32_t nr = len > SUB_LMAX ? SPL_NO_RANK : row[cell];
         if (__any(far)) {
             const uint32_t id_j2 = __shfl(id, gbase + (j2 & 15));     // only long spans need neighbour ids
             if (far) nr = is_mi ? pair_rank(T, mn, id_j2) : pair_rank(T, id, mn);
@@ -666,6 +669,7 @@ __device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const Lds
     // spare bucket (28 % fewer table lines for English text, 85 % for CJK)
     const uint32_t lm = own ? T.len_mask[w0 & 0xFFFFu] : 0u;
     SPL_WT(1);
+    int far_max = 0;
     {
         Quad qa[2], qb[2], qc[2], qd[3];
         const uint32_t ka = w0 & 0xFFFFu, kb = w0 & 0xFFFFFFu, ha = w1 & 0xFFu;
@@ -677,6 +681,14 @@ __device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const Lds
             tiny_issue_if(T, (lm & 2u) != 0, kb, 3u, lm >> 8, qb);
             tiny_issue_if(T, (lm & 4u) != 0, w0, 4u, lm >> 8, qc);
             t8_issue_if(T, (lm & 8u) != 0, w0, ha, 5u, lm >> 8, qd);
+            // spans of more than 8 bytes (the last merges of a chunk of 9..16 bytes): can a token that long
+            // start at this byte at all?  Almost never -- and then its rank is known without the pair table,
+            // whose round trip every lane of the wavefront would wait for, merge round after merge round.
+            if (n - gl > SUB_LMAX && (lm & 0x80u)) {
+                const P8Bucket e8 = T.p8_tab[hash_p8(w0, w1) & T.p8_mask];
+                const int l8 = (int)p8_match(e8.a, e8.b, p8_tag(w0, w1));
+                far_max = l8 == 255 ? FAR_UNBOUNDED : l8;
+            }
             row[0] = tiny_finish(T, ka, 2u, lm >> 8, qa);
             row[1] = tiny_finish(T, kb, 3u, lm >> 8, qb);
             row[2] = tiny_finish(T, w0, 4u, lm >> 8, qc);
@@ -699,7 +711,7 @@ __device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const Lds
         row[4] = SPL_NO_RANK; row[5] = SPL_NO_RANK; row[6] = SPL_NO_RANK;
     }
     SPL_WT(3);
-    group16_merge(T, row, id, n, emit);
+    group16_merge(T, row, id, n, far_max, emit);
     SPL_WT(4);
 }
 
@@ -871,7 +883,7 @@ __device__ __forceinline__ void bpe_wave64_tab(const DeviceTables& T, const LdsA
             }
         }
         const uint32_t gid = __shfl(id, gs + gl);
-        group16_merge(T, sub + (gl < glen ? gs + gl : 0) * SUB_W, gl < glen ? gid : SPL_DEAD, glen,
+        group16_merge(T, sub + (gl < glen ? gs + gl : 0) * SUB_W, gl < glen ? gid : SPL_DEAD, glen, FAR_UNBOUNDED,
                       [&](int i, uint32_t tid_) { emit(gs + i, tid_); });
     }
     while (longsegs) {
@@ -1870,7 +1882,7 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
                 const int s0 = q < nmid ? (int)(mseg[q] & 0xFFFFu) : 0, len = q < nmid ? (int)(mseg[q] >> 16) : 0;
                 const uint32_t gpos = len ? first_byte_of(s0) : 0u;
                 const bool gown = gl < len;
-                group16_merge(T, slab + (gown ? s0 + gl : 0) * SUB_W, gown ? sid[s0 + gl] : SPL_DEAD, len,
+                group16_merge(T, slab + (gown ? s0 + gl : 0) * SUB_W, gown ? sid[s0 + gl] : SPL_DEAD, len, FAR_UNBOUNDED,
                               [&](int i, uint32_t id) { emit_g(gpos + (uint32_t)i, id); });
             }
         }
@@ -2006,7 +2018,7 @@ void k_pretok(DeviceTables T, Batch b) {
         s_cbits[tid] = 0;
         s_tbits[tid] = 0;
     }
-    if (tid < 128) s_ascii[tid] = T.ucls_stage2[((uint32_t)T.ucls_stage1[0] << T.ucls_shift) + tid];
+    if (tid < 128) s_ascii[tid] = T.ucls_stage2[T.ascii_base + tid];
     if (tid < 4) s_nq[tid] = 0;
     if (tid < 12) s_dq[tid] = 0;
     if (DIRECT) {                                            // (length 0: no entry)
@@ -2014,7 +2026,7 @@ void k_pretok(DeviceTables T, Batch b) {
         asm volatile("" : "+v"(t_early));                    // s_lq[2 * tid], it would be kept -- spilled -- until then
         if (t_early < DIRECT_LQCAP) s_lq[2 * t_early + 1] = 0;
     }
-    if (tid == 0) s_nch = 0;
+    if (tid == 0) { s_nch = 0; s_fast = 0; }
     // single pass: the window's text starts straight from doc_off.  NT-ary search for the first
     // document that starts at or after the window (two rounds up to 65 536 documents), then the
     // documents of the window set their bits.
@@ -2022,19 +2034,24 @@ void k_pretok(DeviceTables T, Batch b) {
     if (DIRECT) {
         uint32_t lo = 0, hi = b.n_docs;
         const uint64_t target = w0 > 0 ? (uint64_t)w0 : 0ull;
+        uint64_t p_held = ~0ull;                        // doc_off[d_held] from the first round, if it settled the search
+        uint32_t d_held = 0xFFFFFFFFu, d_held_end = 0;
         if (target != 0 && hi > (uint32_t)NT) {
             // first round by interpolation: with documents of similar size the answer lies within NT
             // entries of target * n_docs / n_bytes, and ONE round of loads finds it; otherwise this
-            // round only narrows [lo, hi] for the search below
-            const uint64_t g = target * (uint64_t)hi / (uint64_t)B;
-            const uint32_t glo = g > (uint64_t)(NT / 2) ? (uint32_t)g - NT / 2 : 0u;
+            // round only narrows [lo, hi] for the search below.  (The guess in float: it only has to be
+            // near, and a 64-bit division costs a wavefront more than a hundred instructions.)
+            const float gf = (float)target * ((float)hi * __builtin_amdgcn_rcpf((float)B));
+            const uint32_t g = gf >= (float)hi ? hi : (uint32_t)gf;
+            const uint32_t glo = g > (uint32_t)(NT / 2) ? g - NT / 2 : 0u;
             const uint32_t ghi = glo + NT < hi ? glo + NT : hi;
             const uint32_t idx = glo + (uint32_t)tid;
-            const bool below = idx < ghi && b.doc_off[idx] < target;
+            const uint64_t p1 = idx < ghi ? b.doc_off[idx] : ~0ull;
+            const bool below = idx < ghi && p1 < target;
             const uint32_t c = (uint32_t)__syncthreads_count(below);
             if (c == 0) hi = glo;                           // entry glo (if any) is not below the target
             else if (c == ghi - glo) lo = ghi;              // every probed entry is
-            else lo = hi = glo + c;
+            else { lo = hi = glo + c; p_held = p1; d_held = idx; d_held_end = ghi; }   // found: the entries behind it are already here
         }
         while (target != 0 && lo < hi) {
             const uint32_t span = hi - lo, st = (span + NT - 1) / NT;
@@ -2049,7 +2066,14 @@ void k_pretok(DeviceTables T, Batch b) {
         dw = lo;
         __syncthreads();                               // s_ts zeroed by all before any bit is set
         const uint64_t lim = (uint64_t)(w0 + (int64_t)(G::NBW + 1) * 32);
-        for (uint32_t base = dw;; base += NT) {
+        uint32_t base = dw;
+        if (d_held_end > dw) {                         // the window's documents from the first round's loads
+            const bool in = d_held >= dw && d_held < d_held_end && p_held < lim && p_held < (uint64_t)B;
+            if (in) { const uint32_t i = (uint32_t)(p_held - (uint64_t)w0); atomicOr(&s_ts[i >> 5], 1u << (i & 31)); }
+            // more only if the last entry fetched is still inside the window
+            base = __syncthreads_or(d_held == d_held_end - 1u && in) ? d_held_end : 0xFFFFFFFFu;
+        }
+        for (; base != 0xFFFFFFFFu; base += NT) {
             const uint64_t d = (uint64_t)base + tid;
             uint64_t p = ~0ull;
             if (d < b.n_docs) p = b.doc_off[d];
@@ -2170,23 +2194,29 @@ void k_pretok(DeviceTables T, Batch b) {
     }
     __syncthreads();
     // ---- cl100k: ALL match starts of the tile by bit-vector arithmetic (spl_scan_starts.h) ---------
-    // One wavefront, one mask word per lane.  The tile owns [fs, fe): fs = its first sync point, fe = the
+    // One mask word per lane.  The tile owns [fs, fe): fs = its first sync point, fe = the
     // first sync point or text start at or behind the tile's end.  Needs fe inside the window and no
     // disqualifying byte (MK_BAD) in the range; otherwise the chains below do the work as before.
-    if (SPL_MASK_STARTS && DIRECT && tid < 64) {
-        uint32_t fast = 0;
+    // Three wavefronts share the work (letters and numbers / "other" runs and contractions / whitespace);
+    // each finds the range for itself and ORs its starts into s_cbits; the tile is "fast" if all three agree.
+    static_assert(!DIRECT || LIST_CHUNKS, "the chains must not share s_cbits with the start masks");
+    if (SPL_MASK_STARTS && DIRECT && tid < 192) {
+        const int part = tid >> 6, ln = tid & 63;           // lane ln owns mask word ln
+        uint32_t fine = 0;
         if (KPAT == PAT_CL100K) {
-            const bool in = tid < G::NBW;
-            auto ld = [&](int k) { return in ? s_mk[k * NBW1 + tid] : 0u; };
+            const bool in = ln < G::NBW;
+            auto ld = [&](int k) { return in ? s_mk[k * NBW1 + ln] : 0u; };
             const uint32_t sy = ld(MK_SY), ts = ld(MK_TS);
-            // first sync point of the tile; first sync point / text start behind it
+            auto range_word = [&](int from, int to) -> uint32_t {             // bits [from, to) of this lane's word
+                const int lo = from - ln * 32, hi = to - ln * 32;
+                if (hi <= 0 || lo >= 32) return 0u;
+                uint32_t w = ~0u;
+                if (lo > 0) w &= ~0u << lo;
+                if (hi < 32) w &= (1u << hi) - 1u;
+                return w;
+            };
             auto first_in = [&](uint32_t word, int from, int to) -> int {    // first set bit in [from, to), -1 if none
-                const int lo = from - tid * 32, hi = to - tid * 32;
-                if (hi <= 0 || lo >= 32) word = 0;
-                else {
-                    if (lo > 0) word &= ~0u << lo;
-                    if (hi < 32) word &= (1u << hi) - 1u;
-                }
+                word &= range_word(from, to);
                 const unsigned long long bl = __ballot(word != 0u);
                 if (!bl) return -1;
                 const int l0 = __ffsll((long long)bl) - 1;
@@ -2194,42 +2224,40 @@ void k_pretok(DeviceTables T, Batch b) {
             };
             const int fs = first_in(sy, LH, LH + TB_);
             const int fe = first_in(sy | ts, iB < LH + TB_ ? iB : LH + TB_, Wv + 1);   // (a text that ends in the tile: its end)
-            if (fs < 0) fast = 1;                              // nothing owned
+            if (fs < 0) fine = 1;                              // nothing owned
             else if (fe >= 0) {
-                auto range_word = [&](int from, int to) -> uint32_t {
-                    const int lo = from - tid * 32, hi = to - tid * 32;
-                    if (hi <= 0 || lo >= 32) return 0u;
-                    uint32_t w = ~0u;
-                    if (lo > 0) w &= ~0u << lo;
-                    if (hi < 32) w &= (1u << hi) - 1u;
-                    return w;
-                };
                 const uint32_t own = range_word(fs, fe);
                 if (!__any((ld(MK_BAD) & own) != 0u)) {
-                    Cl100kStartMasks<WaveBV> cm{WaveBV{ld(MK_L)}, WaveBV{ld(MK_N)}, WaveBV{ld(MK_S)}, WaveBV{ld(MK_NL)},
-                                                WaveBV{ld(MK_O)}, WaveBV{ld(MK_AP)}, WaveBV{ld(MK_SP)}, WaveBV{ts}};
-                    WaveBV CA;
-                    bool ok;
-                    const WaveBV Bv = cl100k_starts(cm, CA, ok, 16);
-                    if (ok) {
-                        fast = 1;
-                        if (in) s_cbits[tid] = (Bv.x & own) | (range_word(fe, fe + 1));
+                    const Cl100kStartMasks<WaveBV> cm{WaveBV{ld(MK_L)}, WaveBV{ld(MK_N)}, WaveBV{ld(MK_S)}, WaveBV{ld(MK_NL)},
+                                                      WaveBV{ld(MK_O)}, WaveBV{ld(MK_AP)}, WaveBV{ld(MK_SP)}, WaveBV{ts}};
+                    bool ok = true;
+                    uint32_t bits;
+                    if (part == 0) bits = cl100k_starts_ln(cm, ok, 16).x | ts | range_word(fe, fe + 1);   // + text starts, terminator
+                    else if (part == 2) bits = cl100k_starts_s(cm, ok, 16).x;
+                    else {
+                        WaveBV CA;
+                        bits = cl100k_starts_o(cm, CA).x;
                         uint32_t ca = CA.x & own;
                         const LdsAcc acc{s_rec, s_txt};
                         while (ca) {                           // the few apostrophes that start a match
-                            const int ap = tid * 32 + __ffs((int)ca) - 1;
+                            const int ap = ln * 32 + __ffs((int)ca) - 1;
                             ca &= ca - 1;
                             const int e = contraction(acc, ap);
                             if (e > 0 && e < fe) atomicOr(&s_cbits[e >> 5], 1u << (e & 31));
                         }
                     }
+                    bits &= range_word(fs, fe + 1);
+                    if (ok) {
+                        fine = 1;
+                        if (bits) atomicOr(&s_cbits[ln], bits);
+                    }
                 }
             }
         }
-        if (tid == 0) s_fast = fast;
+        if (ln == 0 && fine) atomicAdd(&s_fast, 1u);
     }
     if (SPL_MASK_STARTS && DIRECT) __syncthreads();
-    const bool fast_starts = SPL_MASK_STARTS && DIRECT && s_fast != 0u;
+    const bool fast_starts = SPL_MASK_STARTS && DIRECT && s_fast == 3u;
     SPL_STAMP(3);
 
     // ---- chains: each sync point inside the tile scans to the next sync point -------------------

@@ -28,7 +28,7 @@
 // depends on what follows it -- which is what lets a tile use only its window.
 //
 // BV is a window-wide bit vector: one 32-bit word per lane on the device (shifts fetch the neighbour
-// lane's word), a vector of words in tests/hostsim.  Required: operator& | ~, shl1(), shr1(), any().
+// lane's word), a vector of words in tests/hostsim.  Required: copying, operator& | ~, shl1(), shr1(), any().
 #pragma once
 #include "spl_common.h"
 
@@ -38,45 +38,67 @@ template <class BV> struct Cl100kStartMasks {
     BV L, N, S, NL, O, AP, SP, TS;      // class masks of the window (SP = U+0020 only; S = all whitespace)
 };
 
-// Returns the start mask B; CA = apostrophes that start a match (candidates for a contraction).
-// `max_iter` bounds the three propagation loops (number thirds, newlines behind "other", "a newline
-// follows in this run"); the return value of `ok` tells whether they all converged within it.
+// The computation in three independent parts (the kernel gives each to a wavefront of its own; their
+// union, with the text starts, is the start mask).  `max_iter` bounds the propagation loops (number
+// thirds, newlines behind "other", "a newline follows in this run"); `ok` tells whether they converged.
+template <class BV> struct Cl100kShift {
+    const BV& TS; BV nTS;
+    SPL_HD explicit Cl100kShift(const BV& ts) : TS(ts), nTS(~ts) {}
+    SPL_HD BV p(const BV& x) const { return x.shl1() & nTS; }                // previous byte, same text
+    SPL_HD BV n(const BV& x) const { return (x & nTS).shr1(); }              // next byte, same text
+};
+
+// letters and numbers
 template <class BV>
-SPL_HD BV cl100k_starts(const Cl100kStartMasks<BV>& m, BV& CA, bool& ok, int max_iter = 64) {
-    const BV nTS = ~m.TS;
-    auto p = [&](const BV& x) { return x.shl1() & nTS; };                 // previous byte, same text
-    auto n = [&](const BV& x) { return (x & nTS).shr1(); };               // next byte, same text
+SPL_HD BV cl100k_starts_ln(const Cl100kStartMasks<BV>& m, bool& ok, int max_iter) {
+    const Cl100kShift<BV> sh(m.TS);
     ok = true;
-    const BV pL = p(m.L), pN = p(m.N), pO = p(m.O), pSP = p(m.SP), pNL = p(m.NL);
-    // letters
+    const BV pL = sh.p(m.L), pN = sh.p(m.N), pO = sh.p(m.O), pSP = sh.p(m.SP), pNL = sh.p(m.NL);
     const BV Lf = m.L & ~pL;
-    const BV BL = Lf & (pNL | pN | (pO & (p(pO) | p(pSP))));
-    // numbers: run starts, then every third
+    const BV BL = Lf & (pNL | pN | (pO & (sh.p(pO) | sh.p(pSP))));
     const BV Nf = m.N & ~pN;
-    const BV N3 = m.N & pN & p(pN);                                        // bytes i-2 .. i are numbers of one text
+    const BV N3 = m.N & pN & sh.p(pN);                                     // bytes i-2 .. i are numbers of one text
     BV BN = Nf, X = Nf;
-    for (int it = 0;; it++) {
-        X = p(p(p(X))) & N3;
+    for (int it = 0;; it++) {                                              // run starts, then every third
+        X = sh.p(sh.p(sh.p(X))) & N3;
         if (!X.any()) break;
         if (it >= max_iter) { ok = false; break; }
         BN = BN | X;
     }
-    // other
-    const BV Of = m.O & ~pO;
-    const BV BO = Of & ~pSP;
-    CA = m.AP & BO;
-    // newlines that an "other" run takes with it
-    BV ONL = m.NL & pO, Y = ONL;
+    return BL | BN;
+}
+
+// newlines that an "other" run takes with it
+template <class BV>
+SPL_HD BV cl100k_onl(const Cl100kStartMasks<BV>& m, const Cl100kShift<BV>& sh, bool& ok, int max_iter) {
+    BV ONL = m.NL & sh.p(m.O), Y = ONL;
     for (int it = 0;; it++) {
-        Y = m.NL & p(Y) & ~ONL;
+        Y = m.NL & sh.p(Y) & ~ONL;
         if (!Y.any()) break;
         if (it >= max_iter) { ok = false; break; }
         ONL = ONL | Y;
     }
-    // whitespace runs (without those newlines)
+    return ONL;
+}
+
+// "other" runs; CA = apostrophes that start a match (candidates for a contraction)
+template <class BV>
+SPL_HD BV cl100k_starts_o(const Cl100kStartMasks<BV>& m, BV& CA) {
+    const Cl100kShift<BV> sh(m.TS);
+    const BV BO = m.O & ~sh.p(m.O) & ~sh.p(m.SP);
+    CA = m.AP & BO;
+    return BO;
+}
+
+// whitespace runs (without the newlines behind "other" runs)
+template <class BV>
+SPL_HD BV cl100k_starts_s(const Cl100kStartMasks<BV>& m, bool& ok, int max_iter) {
+    const Cl100kShift<BV> sh(m.TS);
+    ok = true;
+    const BV ONL = cl100k_onl(m, sh, ok, max_iter);
     const BV S1 = m.S & ~ONL, NL1 = m.NL & S1;
-    const BV Sf = S1 & ~p(S1);
-    auto nS = [&](const BV& x) { return n(x) & S1; };                      // x holds for the next byte, which is of the same run
+    const BV Sf = S1 & ~sh.p(S1);
+    auto nS = [&](const BV& x) { return sh.n(x) & S1; };                   // x holds for the next byte, which is of the same run
     BV H = nS(NL1);                                                        // a newline follows in this run
     for (int it = 0;; it++) {
         const BV H2 = nS(H) & ~H;
@@ -85,10 +107,20 @@ SPL_HD BV cl100k_starts(const Cl100kStartMasks<BV>& m, BV& CA, bool& ok, int max
         H = H | H2;
     }
     const BV NLlast = NL1 & ~H;
-    const BV BS2 = S1 & p(NLlast);
-    const BV Sl = S1 & ~n(S1);
-    const BV BS3 = Sl & ~NL1 & p(S1 & ~NL1) & ~m.TS.shr1();
-    return m.TS | BL | BN | BO | Sf | BS2 | BS3;
+    const BV BS2 = S1 & sh.p(NLlast);
+    const BV Sl = S1 & ~sh.n(S1);
+    const BV BS3 = Sl & ~NL1 & sh.p(S1 & ~NL1) & ~m.TS.shr1();
+    return Sf | BS2 | BS3;
+}
+
+// Returns the start mask B; CA = apostrophes that start a match.
+template <class BV>
+SPL_HD BV cl100k_starts(const Cl100kStartMasks<BV>& m, BV& CA, bool& ok, int max_iter = 64) {
+    bool ok1, ok2;
+    const BV a = cl100k_starts_ln(m, ok1, max_iter);
+    const BV c = cl100k_starts_s(m, ok2, max_iter);
+    ok = ok1 && ok2;
+    return m.TS | a | cl100k_starts_o(m, CA) | c;
 }
 
 // End of the contraction that starts at the apostrophe `ap` (text bytes through txt(i), `is_ts(i)` = a
