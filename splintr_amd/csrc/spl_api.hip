@@ -414,6 +414,7 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
     b.qcap64 = t->qcap64; b.qcaplong = t->qcaplong; b.qcapdefer = t->qcapdefer;
     b.dbg = (t->dbg_on || t->prof) ? t->d_dbg : nullptr;
     b.stop_phase = (uint32_t)t->stop_phase;
+    { const char* e = getenv("SPL_DEBUG_WG"); b.dbg_wg = e ? (uint32_t)strtoul(e, nullptr, 10) : 0xFFFFFFFFu; }
     if (t->prof) {
         const unsigned long long init[2] = {~0ull, 0ull};
         HIP_TRY(hipMemcpyAsync(t->d_dbg + 14, init, 16, hipMemcpyHostToDevice, s));

@@ -31,6 +31,8 @@
 #include "spl_scan_masks.h"
 #include "spl_scan_starts.h"
 
+#define SPL_DBG_WG (b.dbg_wg == 0xFFFFFFFFu ? gridDim.x / 2 : b.dbg_wg)
+
 #ifndef SPL_NO_SLOWPATH
 #define SPL_NO_SLOWPATH 0      /* 1: timing experiment only (wrong ids for keys that overflowed their bucket): a full bucket never sends a probe on to the next one */
 #endif
@@ -88,6 +90,7 @@ struct Batch {
     uint32_t qcap64, qcaplong, qcapdefer;
     unsigned long long* dbg;   // optional phase cycle stamps of one k_pretok workgroup
     uint32_t stop_phase;       // profiling only: k_pretok returns at this phase boundary (0 = never)
+    uint32_t dbg_wg;           // profiling only: the workgroup whose stamps are recorded (0xFFFFFFFF: the middle one)
     uint32_t* blk_base;    // exclusive token count per RANK_BLK block (+1 entry: total)
     uint32_t n_blk;
     uint32_t* ids_out; uint64_t ids_cap; uint64_t* off_out;
@@ -328,6 +331,15 @@ __device__ __forceinline__ uint32_t row16_min(uint32_t x) {
     x = step(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xF, 0xF, false));   // row_mirror
     return x;
 #endif
+}
+// all-reduce(min) over a group of GW = 16 or 32 lanes (32: the two rows of a half exchanged by ds_swizzle)
+template <int GW> __device__ __forceinline__ uint32_t group_min(uint32_t x) {
+    x = row16_min(x);
+    if (GW == 32) {
+        const uint32_t y = (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, 0x401F);   // lane ^ 16
+        x = y < x ? y : x;
+    }
+    return x;
 }
 
 // Inclusive prefix sum over the 64 lanes of a wavefront with DPP row shifts and row broadcasts
@@ -600,17 +612,18 @@ __device__ __forceinline__ uint32_t t8_finish(const DeviceTables& T, uint32_t k0
 // far_max (per lane): the longest token of more than SUB_LMAX bytes that can start at this lane's byte
 // (p8 table: an upper bound; 0 = none) -- longer spans rank SPL_NO_RANK without a trip to the pair table.
 constexpr int FAR_UNBOUNDED = 1 << 20;
-template <class Emit>
-__device__ __forceinline__ void group16_merge(const DeviceTables& T, const uint32_t* row, uint32_t id, int n, int far_max, Emit emit) {
+template <int GW, class Emit>
+__device__ __forceinline__ void group_merge(const DeviceTables& T, const uint32_t* row, uint32_t id, int n, int far_max, Emit emit) {
+    static_assert(GW == 16 || GW == 32, "groups of 16 or 32 lanes");
     const int lane = threadIdx.x & 63;
-    const int gl = lane & 15;
+    const int gl = lane & (GW - 1);
     const int gbase = lane - gl;
     const bool own = gl < n;
     uint32_t rk = (gl + 1 < n) ? row[0] : SPL_NO_RANK;          // initial ranks (bpe.rs:114-116)
-    uint32_t alive = n >= 16 ? 0xFFFFu : ((1u << n) - 1u);       // group-uniform, kept by every lane
+    uint32_t alive = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);   // group-uniform, kept by every lane
     for (;;) {
         const uint32_t key = rk == SPL_NO_RANK ? 0xFFFFFFFFu : ((rk << 8) | (uint32_t)gl);
-        const uint32_t m = row16_min(key);
+        const uint32_t m = group_min<GW>(key);
         const bool active = m != 0xFFFFFFFFu;
         if (!__any(active)) break;
         const int mi = (int)(m & 255u);
@@ -635,7 +648,7 @@ __device__ __forceinline__ void group16_merge(const DeviceTables& T, const uint3
         const int cell = len - 2 < 0 ? 0 : len - 2 > SUB_W - 1 ? SUB_W - 1 : len - 2;
         uint32_t nr = len > SUB_LMAX ? SPL_NO_RANK : row[cell];
         if (__any(far)) {
-            const uint32_t id_j2 = __shfl(id, gbase + (j2 & 15));     // only long spans need neighbour ids
+            const uint32_t id_j2 = __shfl(id, gbase + (j2 & (GW - 1)));     // only long spans need neighbour ids
             if (far) nr = is_mi ? pair_rank(T, mn, id_j2) : pair_rank(T, id, mn);
         }
         nr = (is_mi && j2 < 0) ? SPL_NO_RANK : nr;
@@ -646,18 +659,24 @@ __device__ __forceinline__ void group16_merge(const DeviceTables& T, const uint3
     if (own && ((alive >> gl) & 1u) && id != SPL_NO_RANK) emit(gl, id);
 }
 
+
+template <class Emit>
+__device__ __forceinline__ void group16_merge(const DeviceTables& T, const uint32_t* row, uint32_t id, int n, int far_max, Emit emit) {
+    group_merge<16>(T, row, id, n, far_max, emit);
+}
+
 #ifdef SPL_DEBUG_STAMPS
 #define SPL_WT(i) do { if (wt && (threadIdx.x & 63) == 0) wt[i] = clock64(); } while (0)
 #else
 #define SPL_WT(i) do { } while (0)
 #endif
-template <class Emit>
-__device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const LdsAcc& tx, int p, int n, uint32_t* sub,
-                                                Emit emit, long long* wt = nullptr) {
+template <int GW, class Emit>
+__device__ __forceinline__ void bpe_group_tab(const DeviceTables& T, const LdsAcc& tx, int p, int n, uint32_t* sub,
+                                              Emit emit, long long* wt = nullptr) {
     (void)wt;
     SPL_WT(0);
     const int lane = threadIdx.x & 63;
-    const int gl = lane & 15;
+    const int gl = lane & (GW - 1);
     const int gbase = lane - gl;
     const bool own = gl < n;
     const int maxlen = own ? (n - gl < SUB_LMAX ? n - gl : SUB_LMAX) : 0;
@@ -711,8 +730,13 @@ __device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const Lds
         row[4] = SPL_NO_RANK; row[5] = SPL_NO_RANK; row[6] = SPL_NO_RANK;
     }
     SPL_WT(3);
-    group16_merge(T, row, id, n, far_max, emit);
+    group_merge<GW>(T, row, id, n, far_max, emit);
     SPL_WT(4);
+}
+template <class Emit>
+__device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const LdsAcc& tx, int p, int n, uint32_t* sub,
+                                                Emit emit, long long* wt = nullptr) {
+    bpe_group_tab<16>(T, tx, p, n, sub, emit, wt);
 }
 
 // The same merge loop for ONE chunk of up to 64 bytes per WAVEFRONT, one node per lane.  Everything
@@ -758,9 +782,10 @@ __device__ __forceinline__ void bpe_wave64_regs(const DeviceTables& T, int n, By
 
 // The merge loop of one WAVEFRONT over the nodes in `alive` (lanes of a range that ends at `end`),
 // with tabulated substring ids: `row` is the lane's own table row, `rk` its pair's rank, `idv` its id.
+// (far_max: as in group16_merge)
 template <class Emit>
 __device__ __forceinline__ void wave64_merge(const DeviceTables& T, const uint32_t* row, unsigned long long alive, int end,
-                                             uint32_t rk, uint32_t idv, Emit emit) {
+                                             uint32_t rk, uint32_t idv, int far_max, Emit emit) {
     const int lane = threadIdx.x & 63;
     for (;;) {
         const uint32_t key = rk == SPL_NO_RANK ? 0xFFFFFFFFu : ((rk << 6) | (uint32_t)lane);
@@ -785,9 +810,9 @@ __device__ __forceinline__ void wave64_merge(const DeviceTables& T, const uint32
         const uint32_t id_j2 = (j2 >= 0 && len_r > SUB_LMAX) ? __builtin_amdgcn_readlane(idv, j2) : 0u;
         if (lane == mi) {
             idv = mn;
-            rk = j2 < 0 ? SPL_NO_RANK : len_r <= SUB_LMAX ? row[len_r - 2] : pair_rank(T, mn, id_j2);
+            rk = j2 < 0 ? SPL_NO_RANK : len_r <= SUB_LMAX ? row[len_r - 2] : len_r <= far_max ? pair_rank(T, mn, id_j2) : SPL_NO_RANK;
         } else if (lane == h) {
-            rk = len_h <= SUB_LMAX ? row[len_h - 2] : pair_rank(T, idv, mn);
+            rk = len_h <= SUB_LMAX ? row[len_h - 2] : len_h <= far_max ? pair_rank(T, idv, mn) : SPL_NO_RANK;
         } else if (lane == j) {
             rk = SPL_NO_RANK;
         }
@@ -854,13 +879,19 @@ __device__ __forceinline__ void bpe_wave64_tab(const DeviceTables& T, const LdsA
 #ifndef SPL_SEG_ASCII
 #define SPL_SEG_ASCII 0          /* 1: look for independent segments in ASCII chunks too (A/B) */
 #endif
+    // the longest token of more than 8 bytes that can start at this lane's byte (p8 table: an upper bound)
+    int l8 = 0;
+    if (own && n - lane > SUB_LMAX && (lm & 0x80u)) {
+        const P8Bucket e8 = T.p8_tab[hash_p8(w0, w1) & T.p8_mask];
+        l8 = (int)p8_match(e8.a, e8.b, p8_tag(w0, w1));
+    }
+    const int far_max = l8 == 255 ? FAR_UNBOUNDED : l8;
     if (SPL_SEG_ASCII || __any(own && (w0 & 0x80u))) {
         int ml = 1;
 #pragma unroll
         for (int k = 0; k < SUB_W; k++) ml = (k + 2 <= maxlen && row[k] != SPL_NO_RANK) ? k + 2 : ml;
         if (own && n - lane > SUB_LMAX) {
-            const P8Bucket e8 = T.p8_tab[hash_p8(w0, w1) & T.p8_mask];
-            const int l8 = (int)p8_match(e8.a, e8.b, p8_tag(w0, w1)), cap = n - lane;
+            const int cap = n - lane;
             ml = l8 == 0 ? ml : (l8 == 255 || l8 > cap) ? cap : l8;
         }
         const uint32_t cover = wave_scan_max(own ? (uint32_t)(lane + ml - 1) : 0u);
@@ -883,7 +914,8 @@ __device__ __forceinline__ void bpe_wave64_tab(const DeviceTables& T, const LdsA
             }
         }
         const uint32_t gid = __shfl(id, gs + gl);
-        group16_merge(T, sub + (gl < glen ? gs + gl : 0) * SUB_W, gl < glen ? gid : SPL_DEAD, glen, FAR_UNBOUNDED,
+        const int gfar = __shfl(far_max, gs + gl);
+        group16_merge(T, sub + (gl < glen ? gs + gl : 0) * SUB_W, gl < glen ? gid : SPL_DEAD, glen, gfar,
                       [&](int i, uint32_t tid_) { emit(gs + i, tid_); });
     }
     while (longsegs) {
@@ -892,7 +924,7 @@ __device__ __forceinline__ void bpe_wave64_tab(const DeviceTables& T, const LdsA
         const unsigned long long later = starts & ~((2ull << sk) - 1ull);
         const int ek = later ? __builtin_ctzll(later) : n;
         const unsigned long long seg = (ek >= 64 ? ~0ull : ((1ull << ek) - 1ull)) & ~((1ull << sk) - 1ull);
-        wave64_merge(T, row, seg, ek, (lane >= sk && lane + 1 < ek) ? row[0] : SPL_NO_RANK, id, emit);
+        wave64_merge(T, row, seg, ek, (lane >= sk && lane + 1 < ek) ? row[0] : SPL_NO_RANK, id, far_max, emit);
     }
 }
 
@@ -1610,6 +1642,9 @@ template <int TB_, int RH_> struct TileGeom {
 #ifndef SPL_PRETOK_WAVES
 #define SPL_PRETOK_WAVES 6
 #endif
+#ifndef SPL_MEDIUM_PAIRS
+#define SPL_MEDIUM_PAIRS 1        /* 1: chunks of 17..32 bytes merge two to a wavefront (32 lanes each) */
+#endif
 #ifndef SPL_MASK_STARTS
 #define SPL_MASK_STARTS 1         /* 1: cl100k tiles take their match starts from the bit-vector computation of spl_scan_starts.h */
 #endif
@@ -1893,7 +1928,7 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
             const bool lown = lane < len;
             const uint32_t* const lrow = slab + (lown ? s0 + lane : 0) * SUB_W;
             wave64_merge(T, lrow, len >= 64 ? ~0ull : ((1ull << len) - 1ull), len, lane + 1 < len ? lrow[0] : SPL_NO_RANK,
-                         lown ? sid[s0 + lane] : SPL_DEAD,
+                         lown ? sid[s0 + lane] : SPL_DEAD, FAR_UNBOUNDED,
                          [&](int i, uint32_t id) { emit_g(gpos + (uint32_t)i, id); });
         }
         for (uint32_t q = (uint32_t)wv; q < ctl[7]; q += NT / 64) {          // 65 .. 64 XNPL bytes
@@ -1969,7 +2004,7 @@ void k_pretok(DeviceTables T, Batch b) {
     // Phase stamps, per-workgroup records and the phase cut-off are compiled in only with
     // -DSPL_DEBUG_STAMPS (tools/ab_build.sh): their live values cost the product kernel registers.
 #ifdef SPL_DEBUG_STAMPS
-#define SPL_STAMP(i) do { if (b.dbg && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) b.dbg[i] = clock64(); \
+#define SPL_STAMP(i) do { if (b.dbg && blockIdx.x == SPL_DBG_WG && threadIdx.x == 0) b.dbg[i] = clock64(); \
                           if ((i) >= 1 && (i) <= 7 && b.stop_phase == (uint32_t)(i)) return; } while (0)
 #else
 #define SPL_STAMP(i) do { } while (0)
@@ -1989,7 +2024,7 @@ void k_pretok(DeviceTables T, Batch b) {
     // over all workgroups) -- what a kernel trace reports, without host-side event overhead
     if (b.dbg && tid == 0 && blockIdx.x == 0) b.dbg[14] = (unsigned long long)wall_clock64();   // dispatched first
 #ifdef SPL_DEBUG_STAMPS
-    if (b.dbg && tid == 0 && blockIdx.x == gridDim.x / 2) b.dbg[11] = (unsigned long long)wall_clock64();
+    if (b.dbg && tid == 0 && blockIdx.x == SPL_DBG_WG) b.dbg[11] = (unsigned long long)wall_clock64();
     const unsigned long long blk_t0 = b.dbg ? (unsigned long long)wall_clock64() : 0ull;
     unsigned long long blk_w1 = 0, blk_w2 = 0;
     if (b.dbg && tid == 0 && blockIdx.x == gridDim.x - 1) b.dbg[13] = (unsigned long long)wall_clock64();
@@ -2467,23 +2502,50 @@ void k_pretok(DeviceTables T, Batch b) {
 #ifdef SPL_DEBUG_STAMPS
         const long long ws_t0 = clock64();
         uint32_t ws_nmed = 0, ws_nshort = 0;
-        long long ws_wt[5] = {0, 0, 0, 0, 0};
+        long long ws_wt[6] = {0, 0, 0, 0, 0, 0};
 #endif
         for (; !EXPORT_MEDIUM && few_medium;) {
+            // A wavefront takes TWO chunks per pull: if both have at most 32 bytes (of ASCII: no independent
+            // segments to look for) each gets a half of the wavefront and they merge side by side -- a tile
+            // with several long words (the slowest tiles of the bench batch are those) needs half the pulls.
             uint32_t it = 0;
-            if (lane == 0) it = atomicAdd(&s_nq[3], 1u);
+            if (lane == 0) it = atomicAdd(&s_nq[3], SPL_MEDIUM_PAIRS ? 2u : 1u);
             it = __builtin_amdgcn_readfirstlane(it);
             if (it >= m64) break;
 #ifdef SPL_DEBUG_STAMPS
             ws_nmed++;
 #endif
             if (DIRECT && SPL_MEDIUM_PRIO != SPL_MERGE_PRIO) __builtin_amdgcn_s_setprio(SPL_MEDIUM_PRIO);
-            const uint32_t item = s_miss[G::C16 + it];
-            const int p = (int)(item & 0xFFFFu);
-            bpe_wave64_tab(T, LdsAcc{s_rec, s_txt}, p, (int)(item >> 16), s_sub[(tid >> 6) * 4],
-                           [&](int i, uint32_t id) {
-                               put(p + i, id);
-                           });
+            const uint32_t itemA = s_miss[G::C16 + it];
+            const uint32_t itemB = (SPL_MEDIUM_PAIRS && it + 1u < m64) ? s_miss[G::C16 + it + 1u] : 0u;
+            const int pA = (int)(itemA & 0xFFFFu), nA = (int)(itemA >> 16), pB = (int)(itemB & 0xFFFFu), nB = (int)(itemB >> 16);
+            bool pair = SPL_MEDIUM_PAIRS && nA <= 32 && nB <= 32;
+            if (pair) {
+                const int half = lane >> 5, hl = lane & 31;
+                const int p = half ? pB : pA, n = half ? nB : nA;
+                if (__any(hl < n && (s_txt[p + hl] & 0x80u))) pair = false;
+                else {
+#if defined(SPL_DEBUG_STAMPS) && defined(SPL_STAMP_MEDIUM)
+                    long long* const wtm = (b.dbg && blockIdx.x == SPL_DBG_WG && ws_nmed == 1) ? ws_wt : nullptr;
+#else
+                    long long* const wtm = nullptr;
+#endif
+                    bpe_group_tab<32>(T, LdsAcc{s_rec, s_txt}, p, n, s_sub[(tid >> 6) * 4 + half * 2],
+                                      [&](int i, uint32_t id) {
+                                          put(p + i, id);
+                                      }, wtm);
+                }
+            }
+            if (!pair) {
+                bpe_wave64_tab(T, LdsAcc{s_rec, s_txt}, pA, nA, s_sub[(tid >> 6) * 4],
+                               [&](int i, uint32_t id) {
+                                   put(pA + i, id);
+                               });
+                if (nB) bpe_wave64_tab(T, LdsAcc{s_rec, s_txt}, pB, nB, s_sub[(tid >> 6) * 4],
+                                       [&](int i, uint32_t id) {
+                                           put(pB + i, id);
+                                       });
+            }
         }
         if (DIRECT && SPL_MEDIUM_PRIO != SPL_MERGE_PRIO) __builtin_amdgcn_s_setprio(SPL_MERGE_PRIO);
         SPL_STAMP(9);
@@ -2520,8 +2582,8 @@ void k_pretok(DeviceTables T, Batch b) {
                 else item = s_miss[it];
             }
             const int p = (int)(item & 0xFFFFu);
-#ifdef SPL_DEBUG_STAMPS
-            long long* const wtp = (b.dbg && blockIdx.x == gridDim.x / 2 && ws_nshort == 1) ? ws_wt : nullptr;
+#if defined(SPL_DEBUG_STAMPS) && !defined(SPL_STAMP_MEDIUM)
+            long long* const wtp = (b.dbg && blockIdx.x == SPL_DBG_WG && ws_nshort == 1) ? ws_wt : nullptr;
 #else
             long long* const wtp = nullptr;
 #endif
@@ -2531,13 +2593,17 @@ void k_pretok(DeviceTables T, Batch b) {
                             }, wtp);
         }
 #ifdef SPL_DEBUG_STAMPS
-        if (b.dbg && blockIdx.x == gridDim.x / 2 && (tid & 63) == 0) {
+        if (b.dbg && blockIdx.x == SPL_DBG_WG && (tid & 63) == 0) {
             unsigned long long* r2 = b.dbg + 16 + 4 * (SPL_DEBUG_BLOCKS - 16 + 2 * (tid >> 6));
-            for (int k = 0; k < 5; k++) r2[k] = (unsigned long long)(ws_wt[k] - ws_t1);
+#ifdef SPL_STAMP_MEDIUM
+            for (int k = 0; k < 6; k++) r2[k] = (unsigned long long)(ws_wt[k] - ws_t0);     // the first MEDIUM pull, since the medium loop began
+#else
+            for (int k = 0; k < 6; k++) r2[k] = (unsigned long long)(ws_wt[k] - ws_t1);
+#endif
         }
 #endif
 #ifdef SPL_DEBUG_STAMPS
-        if (b.dbg && blockIdx.x == gridDim.x / 2 && (tid & 63) == 0) {      // per-wavefront record of the middle workgroup
+        if (b.dbg && blockIdx.x == SPL_DBG_WG && (tid & 63) == 0) {      // per-wavefront record of the middle workgroup
             unsigned long long* r = b.dbg + 16 + 4 * (SPL_DEBUG_BLOCKS - 8 + (tid >> 6));
             r[0] = (unsigned long long)(ws_t1 - ws_t0);
             r[1] = (unsigned long long)(clock64() - ws_t1);
@@ -2921,7 +2987,7 @@ void k_pretok(DeviceTables T, Batch b) {
     }
     SPL_STAMP(8);
 #ifdef SPL_DEBUG_STAMPS
-    if (b.dbg && tid == 0 && blockIdx.x == gridDim.x / 2) b.dbg[12] = (unsigned long long)wall_clock64();
+    if (b.dbg && tid == 0 && blockIdx.x == SPL_DBG_WG) b.dbg[12] = (unsigned long long)wall_clock64();
     if (b.dbg && tid == 0 && blockIdx.x < SPL_DEBUG_BLOCKS) {
         // wall-clock ticks: start, end of the merge phase, counts done, end
         unsigned long long* r = b.dbg + 16 + 4 * blockIdx.x;

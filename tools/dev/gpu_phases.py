@@ -69,6 +69,6 @@ print("merge phase per wavefront of the middle workgroup (cycles): medium loop, 
 for w in range(4):
     print("   wave %d: %7d %7d   %d %d   (%d, %d)" % (w, W[w][0], W[w][1], W[w][2] & 0xFFFFFFFF, W[w][2] >> 32, W[w][3] & 0xFFFFFFFF, W[w][3] >> 32))
 W2 = np.ctypeslib.as_array(rec).reshape(nb_, 4)[nb_ - 16:nb_ - 8].reshape(4, 8).astype(np.int64)
-print("first short pull per wavefront, cycles since the short loop began: enter, bytes+len_mask loaded, batch 1 done, batch 2 done, merges done")
+print("first short pull per wavefront (-DSPL_STAMP_MEDIUM: first medium pull, since the medium loop began), cycles: enter, bytes+len_mask loaded, batch 1 done, batch 2 done, merges done, far spans tabulated")
 for w in range(4):
-    print("   wave %d: %s" % (w, " ".join("%7d" % x for x in W2[w][:5])))
+    print("   wave %d: %s" % (w, " ".join("%7d" % x for x in W2[w][:6])))
