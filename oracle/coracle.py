@@ -81,7 +81,10 @@ class COracle:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().orc_destroy(self._h)
+            try:
+                lib().orc_destroy(self._h)
+            except TypeError:          # interpreter shutdown: module globals are gone already
+                pass
             self._h = None
 
     def encode_bytes(self, data: bytes, with_special: bool = False) -> List[int]:

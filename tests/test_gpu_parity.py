@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from conftest import ROOT, VOCABS
-from fuzzgen import fuzz_corpus, invalid_utf8_corpus
+from fuzzgen import fuzz_corpus, invalid_utf8_corpus, latin_corpus
 
 pytestmark = pytest.mark.gpu
 
@@ -158,6 +158,49 @@ def test_surface(name):
 @pytest.mark.parametrize("name", VOCABS)
 def test_fuzz_batch(coracle, name):
     assert_batch_equal(name, fuzz_corpus(101, 20000, 60), coracle)
+
+
+@pytest.mark.parametrize("name", VOCABS)
+def test_bitvector_starts_latin_text(coracle, name):
+    """Text whose multi-byte characters are all letters: cl100k tiles take their match starts from the
+    bit-vector computation (spl_scan_starts.h) -- whitespace runs with and without newlines, contractions
+    in either case and with U+017F, number runs of every length mod 3, documents from empty to several
+    tiles, so that text starts and ends fall everywhere in the windows.  (The other patterns: the chains.)"""
+    rng = random.Random(7)
+    texts = latin_corpus(23, 12000, 60) + latin_corpus(24, 300, 1500)
+    texts += ["".join(rng.choice(texts[:2000]) for _ in range(40)) for _ in range(50)]
+    assert_batch_equal(name, texts, coracle)
+    assert_batch_equal(name, ["".join(texts[:3000])], coracle)          # one document over many tiles
+
+
+def _long_word_texts(seed, n_docs):
+    """Words of 9..64 letters that are no tokens (and some that are), alone and in pairs within a tile."""
+    rng = random.Random(seed)
+    stems = ["international", "counter", "intuitive", "thermo", "dynamics", "mis", "understand", "ing", "ization", "electro",
+             "encephalo", "graphy", "pseudo", "hypo", "para", "thyroid", "ism", "anti", "dis", "establishment", "arian",
+             "über", "straße", "ación", "xqzj", "Qwrtp", "_snake_case_", "CamelCase", "0x", "deadbeef", "==", "--"]
+    out = []
+    for _ in range(n_docs):
+        words = []
+        for _ in range(rng.randint(1, 60)):
+            w = "".join(rng.choice(stems) for _ in range(rng.randint(1, 5)))
+            words.append(w[:rng.randint(9, 64)] if len(w) > 9 else w)
+            if rng.random() < 0.5:
+                words.append(rng.choice(["the", "of", "a", "and", "\n", "to"]))
+        out.append(rng.choice(["", " "]) + " ".join(words))
+    return out
+
+
+@pytest.mark.parametrize("geom", [0, 3])
+@pytest.mark.parametrize("name", VOCABS)
+def test_long_words_merge_two_to_a_wavefront(coracle, name, geom):
+    """Chunks of 17..32 bytes share a wavefront two by two (32 lanes each), longer ones take one alone, spans
+    of more than 8 bytes rank through the p8 bound or the pair table: tiles with many such words."""
+    _force_tiles(name, geom)
+    try:
+        assert_batch_equal(name, _long_word_texts(5, 1500), coracle)
+    finally:
+        _force_tiles(name, 0)
 
 
 @pytest.mark.parametrize("name", VOCABS)
