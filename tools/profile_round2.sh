@@ -23,7 +23,7 @@ done
 i=0
 for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_MISS_sum TCC_HIT_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
   i=$((i+1)); d=$O/cal_$i; mkdir -p $d
-  timeout 200 rocprofv3 --pmc $c --kernel-trace -d $d -o p -- gpurun_out/calib_fetch > $d/log.txt 2>&1
+  timeout 200 rocprofv3 --pmc $c --kernel-trace -d $d -o p -- _ab/calib_fetch > $d/log.txt 2>&1
   echo "== calibration pass $i ($c) rc=$?" >> $O/calib.txt
   python tools/pmc_summary.py $(find $d -name "*.db" | head -1) 2>&1 >> $O/calib.txt
 done
