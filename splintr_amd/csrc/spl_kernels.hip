@@ -670,25 +670,21 @@ __device__ __forceinline__ void group16_merge(const DeviceTables& T, const uint3
 #else
 #define SPL_WT(i) do { } while (0)
 #endif
-template <int GW, class Emit>
-__device__ __forceinline__ void bpe_group_tab(const DeviceTables& T, const LdsAcc& tx, int p, int n, uint32_t* sub,
-                                              Emit emit, long long* wt = nullptr) {
+// Tabulation of ONE table row: the lane probes the ids of text[pos, pos + len), len = 2 .. min(rem, 8), in two
+// batches whose bucket loads are all in flight together, into `row`; returns the id of its byte and, in
+// far_max, the longest token of more than 8 bytes that can start there (p8 bound).  `own` false: idle lane.
+__device__ __forceinline__ uint32_t tab_row(const DeviceTables& T, const LdsAcc& tx, bool own, int pos, int rem, uint32_t* row,
+                                            int& far_max, long long* wt = nullptr) {
     (void)wt;
-    SPL_WT(0);
-    const int lane = threadIdx.x & 63;
-    const int gl = lane & (GW - 1);
-    const int gbase = lane - gl;
-    const bool own = gl < n;
-    const int maxlen = own ? (n - gl < SUB_LMAX ? n - gl : SUB_LMAX) : 0;
-    const uint32_t w0 = own ? tx.load32(p + gl) : 0u;
-    const uint32_t w1 = own ? tx.load32(p + gl + 4) : 0u;
-    uint32_t id = own ? T.byte_id[w0 & 0xFFu] : SPL_DEAD;
-    uint32_t* row = sub + gl * SUB_W;
+    const int maxlen = own ? (rem < SUB_LMAX ? rem : SUB_LMAX) : 0;
+    const uint32_t w0 = own ? tx.load32(pos) : 0u;
+    const uint32_t w1 = own ? tx.load32(pos + 4) : 0u;
+    const uint32_t id = own ? T.byte_id[w0 & 0xFFu] : SPL_DEAD;
     // which token lengths exist at all behind the lane's first two bytes: the other probes go to the
     // spare bucket (28 % fewer table lines for English text, 85 % for CJK)
     const uint32_t lm = own ? T.len_mask[w0 & 0xFFFFu] : 0u;
     SPL_WT(1);
-    int far_max = 0;
+    far_max = 0;
     {
         Quad qa[2], qb[2], qc[2], qd[3];
         const uint32_t ka = w0 & 0xFFFFu, kb = w0 & 0xFFFFFFu, ha = w1 & 0xFFu;
@@ -703,7 +699,7 @@ __device__ __forceinline__ void bpe_group_tab(const DeviceTables& T, const LdsAc
             // spans of more than 8 bytes (the last merges of a chunk of 9..16 bytes): can a token that long
             // start at this byte at all?  Almost never -- and then its rank is known without the pair table,
             // whose round trip every lane of the wavefront would wait for, merge round after merge round.
-            if (n - gl > SUB_LMAX && (lm & 0x80u)) {
+            if (rem > SUB_LMAX && (lm & 0x80u)) {
                 const P8Bucket e8 = T.p8_tab[hash_p8(w0, w1) & T.p8_mask];
                 const int l8 = (int)p8_match(e8.a, e8.b, p8_tag(w0, w1));
                 far_max = l8 == 255 ? FAR_UNBOUNDED : l8;
@@ -730,6 +726,18 @@ __device__ __forceinline__ void bpe_group_tab(const DeviceTables& T, const LdsAc
         row[4] = SPL_NO_RANK; row[5] = SPL_NO_RANK; row[6] = SPL_NO_RANK;
     }
     SPL_WT(3);
+    return id;
+}
+
+template <int GW, class Emit>
+__device__ __forceinline__ void bpe_group_tab(const DeviceTables& T, const LdsAcc& tx, int p, int n, uint32_t* sub,
+                                              Emit emit, long long* wt = nullptr) {
+    (void)wt;
+    SPL_WT(0);
+    const int gl = (threadIdx.x & 63) & (GW - 1);
+    uint32_t* row = sub + gl * SUB_W;
+    int far_max;
+    const uint32_t id = tab_row(T, tx, gl < n, p + gl, n - gl, row, far_max, wt);
     group_merge<GW>(T, row, id, n, far_max, emit);
     SPL_WT(4);
 }
