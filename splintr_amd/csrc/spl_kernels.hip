@@ -253,6 +253,11 @@ struct LdsAcc {
     }
 };
 
+// v_writelane_b32: lane `lane` of `old` takes the wave-uniform value src.  (This compiler has no builtin for the
+// intrinsic; through inline asm the hazard between a v_cmp that writes the SGPR and the read here went unhandled.)
+extern "C" __device__ int spl_writelane(int src, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+#define write_lane(v, s, lane_) spl_writelane((int)(s), (lane_), (v))
+
 // Window-wide bit vector for spl_scan_starts.h: one 32-bit word per lane of ONE wavefront (all 64 lanes
 // active; lanes past the window hold zero words).  Shifts take the neighbour lane's word by DPP.
 struct WaveBV {
@@ -2028,6 +2033,7 @@ void k_pretok(DeviceTables T, Batch b) {
     __shared__ uint32_t s_ts[G::NBW + 1];                // text-start bits of the window
     __shared__ uint32_t s_sk[G::NBW + 1];                // special-literal bits of the window
     __shared__ uint32_t s_cbits[G::NBW + 1];
+    __shared__ uint32_t s_kill[G::NBW + 1], s_add[G::NBW + 1];   // o200k contraction suffixes: starts to drop / to add
     __shared__ uint32_t s_tbits[G::NBW + 1];
     static_assert(!DIRECT || (Wv + 2) / 2 >= SG_WORDS, "bpe_tail_segments' scratch must fit s_cpos");
     __shared__ __attribute__((aligned(16))) uint16_t s_cpos[Wv + 2];   // (the single-pass tail borrows it: bpe_tail_segments)
@@ -2103,6 +2109,7 @@ void k_pretok(DeviceTables T, Batch b) {
         s_ts[tid] = (in && (!DIRECT || b.tstart)) ? b.tstart[wi] : 0u;
         s_sk[tid] = (in && b.skip) ? b.skip[wi] : 0u;
         s_cbits[tid] = 0;
+        s_kill[tid] = 0; s_add[tid] = 0;
         s_tbits[tid] = 0;
     }
     if (tid < 128) s_ascii[tid] = T.ucls_stage2[T.ascii_base + tid];
@@ -2250,21 +2257,21 @@ void k_pretok(DeviceTables T, Batch b) {
             kc = j >= 0 ? (s_rec[j] & CB_CLASS) : (uint32_t)C_CONT;
         }
         uint32_t kb = kc < C_EOT ? kind_bits(kc) : 0u;
-        // what keeps a window off the bit-vector start computation: a multi-byte character that is no
-        // letter, a span without text (special literal)
-        if (((cls == C_CONT || (r >> CB_LEN_SHIFT) != 0u) && !(kb & (1u << MK_L))) || (cls == C_EOT && i < iB)) kb |= 1u << MK_BAD;
-        unsigned long long bal[MK_SY];
+        if (bad_for_starts(KPAT, r, kc, i < iB)) kb |= 1u << MK_BAD;      // keeps the window off the bit-vector start computation
+        if (KPAT == PAT_MISTRAL_V3 && s_txt[i] == '/') kb |= 1u << MK_SL;  // (only mistral's [\r\n/]* asks)
+        // lane 2k / 2k + 1 of `v` receive the two halves of kind k's ballot (v_writelane: one instruction per
+        // half; a select chain over all kinds cost three per kind); kinds the pattern never asks for stay zero
+        int v = 0;
 #pragma unroll
-        for (int k = 0; k < MK_CS; k++) bal[k] = __ballot((kb >> k) & 1u);
-        bal[MK_CS] = __ballot(cls < C_EOT);
-        bal[MK_TS] = __ballot((r & CB_TSTART) != 0);
-        if (lane < 2 * MK_SY) {
-            const int which = lane >> 1;
-            unsigned long long v = bal[0];
-#pragma unroll
-            for (int k = 1; k < MK_SY; k++) v = which == k ? bal[k] : v;
-            s_mk[which * NBW1 + row * 2 + (lane & 1)] = (lane & 1) ? (uint32_t)(v >> 32) : (uint32_t)v;
+        for (int k = 0; k < MK_SY; k++) {
+            if ((k == MK_M || k == MK_UP) && KPAT == PAT_CL100K) continue;
+            if (k == MK_SL && KPAT != PAT_MISTRAL_V3) continue;
+            const unsigned long long bk = k == MK_CS ? __ballot(cls < C_EOT) : k == MK_TS ? __ballot((r & CB_TSTART) != 0)
+                                                                              : __ballot((kb >> k) & 1u);
+            v = write_lane(v, (uint32_t)bk, 2 * k);
+            v = write_lane(v, (uint32_t)(bk >> 32), 2 * k + 1);
         }
+        if (lane < 2 * MK_SY) s_mk[(lane >> 1) * NBW1 + row * 2 + (lane & 1)] = (uint32_t)v;
     }
     if (tid < MK_COUNT) s_mk[tid * NBW1 + G::NBW - 1] = 0;   // the word of position W (never a real byte)
     if (tid < MK_COUNT) s_mk[tid * NBW1 + G::NBW] = 0;
@@ -2280,7 +2287,7 @@ void k_pretok(DeviceTables T, Batch b) {
         s_mk[MK_SY * NBW1 + tid] = sync_word(KPAT, kw, kp);
     }
     __syncthreads();
-    // ---- cl100k: ALL match starts of the tile by bit-vector arithmetic (spl_scan_starts.h) ---------
+    // ---- ALL match starts of the tile by bit-vector arithmetic (spl_scan_starts.h), every pattern ------
     // One mask word per lane.  The tile owns [fs, fe): fs = its first sync point, fe = the
     // first sync point or text start at or behind the tile's end.  Needs fe inside the window and no
     // disqualifying byte (MK_BAD) in the range; otherwise the chains below do the work as before.
@@ -2290,7 +2297,7 @@ void k_pretok(DeviceTables T, Batch b) {
     if (SPL_MASK_STARTS && DIRECT && tid < 192) {
         const int part = tid >> 6, ln = tid & 63;           // lane ln owns mask word ln
         uint32_t fine = 0;
-        if (KPAT == PAT_CL100K) {
+        {
             const bool in = ln < G::NBW;
             auto ld = [&](int k) { return in ? s_mk[k * NBW1 + ln] : 0u; };
             const uint32_t sy = ld(MK_SY), ts = ld(MK_TS);
@@ -2314,7 +2321,41 @@ void k_pretok(DeviceTables T, Batch b) {
             if (fs < 0) fine = 1;                              // nothing owned
             else if (fe >= 0) {
                 const uint32_t own = range_word(fs, fe);
-                if (!__any((ld(MK_BAD) & own) != 0u)) {
+                if (__any((ld(MK_BAD) & own) != 0u)) {
+                } else if (KPAT != PAT_CL100K) {
+                    // o200k family: letters + numbers / "other" runs and contraction suffixes / whitespace
+                    const bool mistral = KPAT == PAT_MISTRAL_V3;
+                    const O200kStartMasks<WaveBV> om{WaveBV{ld(MK_L)}, WaveBV{ld(MK_UP)}, WaveBV{ld(MK_N)}, WaveBV{ld(MK_S)},
+                                                     WaveBV{ld(MK_NL)}, WaveBV{ld(MK_O)}, WaveBV{ld(MK_AP)}, WaveBV{ld(MK_SP)},
+                                                     WaveBV{ld(MK_SL)}, WaveBV{ld(MK_CS)}, WaveBV{ts}};
+                    bool ok = true;
+                    uint32_t bits;
+                    if (part == 0) bits = o200k_starts_ln(om, mistral, ok, 16).x | range_word(fe, fe + 1);          // + the terminator
+                    else if (part == 2) bits = o200k_starts_s(om, mistral, ok, 16).x;
+                    else {
+                        WaveBV CAND;
+                        bits = o200k_starts_o(om, mistral, CAND, ok, 16).x;
+                        uint32_t ca = mistral ? 0u : CAND.x & own;
+                        const LdsAcc acc{s_rec, s_txt};
+                        bool chain = false;
+                        while (ca) {                           // the few apostrophes behind a letter
+                            const int ap = ln * 32 + __ffs((int)ca) - 1;
+                            ca &= ca - 1;
+                            int e;
+                            if (!o200k_contraction_at(acc, ap, e)) chain = true;
+                            else if (e > 0) {                  // the suffix starts nothing, the byte behind it does
+                                for (int q = ap; q < e; q++) atomicOr(&s_kill[q >> 5], 1u << (q & 31));
+                                if (e < fe) atomicOr(&s_add[e >> 5], 1u << (e & 31));
+                            }
+                        }
+                        if (__any(chain)) ok = false;
+                    }
+                    bits &= range_word(fs, fe + 1);
+                    if (ok) {
+                        fine = 1;
+                        if (bits) atomicOr(&s_cbits[ln], bits);
+                    }
+                } else {
                     const Cl100kStartMasks<WaveBV> cm{WaveBV{ld(MK_L)}, WaveBV{ld(MK_N)}, WaveBV{ld(MK_S)}, WaveBV{ld(MK_NL)},
                                                       WaveBV{ld(MK_O)}, WaveBV{ld(MK_AP)}, WaveBV{ld(MK_SP)}, WaveBV{ts}};
                     bool ok = true;
@@ -2354,7 +2395,7 @@ void k_pretok(DeviceTables T, Batch b) {
     {
         uint32_t word = 0;
         if (fast_starts) {
-            if (tid < G::NBW) word = s_cbits[tid];                        // the tile's starts and their terminator
+            if (tid < G::NBW) word = (s_cbits[tid] & ~s_kill[tid]) | s_add[tid];   // the tile's starts and their terminator
         } else if (tid < G::NBW) {
             word = s_mk[MK_SY * NBW1 + tid];
             const int lo = LH - tid * 32, hi = LH + TB_ - tid * 32;       // tile range inside this word

@@ -30,7 +30,7 @@
 // BV is a window-wide bit vector: one 32-bit word per lane on the device (shifts fetch the neighbour
 // lane's word), a vector of words in tests/hostsim.  Required: copying, operator& | ~, shl1(), shr1(), any().
 #pragma once
-#include "spl_common.h"
+#include "spl_scan.h"
 
 namespace spl {
 
@@ -121,6 +121,122 @@ SPL_HD BV cl100k_starts(const Cl100kStartMasks<BV>& m, BV& CA, bool& ok, int max
     const BV c = cl100k_starts_s(m, ok2, max_iter);
     ok = ok1 && ok2;
     return m.TS | a | cl100k_starts_o(m, CA) | c;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// O200K_BASE_PATTERN / MISTRAL_V3_PATTERN (reference src/core/tokenizer.rs:42, :64) on the same terms, for
+// windows whose letters are all of class Lu, Lt or Ll (no Lm / Lo / marks: bad_for_starts).  Against cl100k:
+//   letters   a letter run is cut where an upper-case letter follows a lower-case one (U* W+ | U+ W*: a
+//             match is upper-case letters, then lower-case ones): UP & CS & p(L & ~UP).  The one-character
+//             prefix joins iff it starts a match: any non-newline whitespace, or an "other" character in BO.
+//   suffix    o200k: letters may take a contraction with them ('s 't 're 've 'm 'll 'd): the apostrophe
+//             and the letter behind it then start nothing, the byte behind the contraction does
+//             (o200k_contractions, from the text bytes; mistral has no such suffix)
+//   other     behind an "other" run the match takes newlines AND '/' ([\r\n/]*): the absorbed bytes A start
+//             nothing, an "other" character right behind them starts a match
+//   numbers   mistral: every number is a match of its own
+template <class BV> struct O200kStartMasks {
+    BV L, UP, N, S, NL, O, AP, SP, SL, CS, TS;
+};
+
+// bytes that the [\r\n/]* behind an "other" run takes: a newline behind an "other" byte, then newlines and '/'
+template <class BV>
+SPL_HD BV o200k_absorbed(const O200kStartMasks<BV>& m, const Cl100kShift<BV>& sh, bool slash, bool& ok, int max_iter) {
+    const BV Z = slash ? (m.NL | m.SL) : m.NL;
+    BV A = m.NL & sh.p(m.O), Y = A;
+    for (int it = 0;; it++) {
+        Y = Z & sh.p(Y) & ~A;
+        if (!Y.any()) break;
+        if (it >= max_iter) { ok = false; break; }
+        A = A | Y;
+    }
+    return A;
+}
+// "other" bytes that start a match (a contraction's apostrophe still among them)
+template <class BV>
+SPL_HD BV o200k_other_starts(const O200kStartMasks<BV>& m, const Cl100kShift<BV>& sh, const BV& A) {
+    return m.O & ~A & (~sh.p(m.O) | sh.p(A)) & ~sh.p(m.SP);
+}
+
+// letters and numbers (with the text starts)
+template <class BV>
+SPL_HD BV o200k_starts_ln(const O200kStartMasks<BV>& m, bool mistral, bool& ok, int max_iter) {
+    const Cl100kShift<BV> sh(m.TS);
+    ok = true;
+    const BV A = o200k_absorbed(m, sh, mistral, ok, max_iter);
+    const BV BO = o200k_other_starts(m, sh, A);
+    const BV pL = sh.p(m.L), pN = sh.p(m.N);
+    const BV Lf = m.L & ~pL;
+    const BV BL = Lf & (sh.p(m.NL) | pN | sh.p(m.O & ~BO));
+    const BV BC = m.UP & m.CS & sh.p(m.L & ~m.UP);
+    BV BN = m.N;                                                           // mistral: \p{N}, one at a time
+    if (!mistral) {
+        const BV Nf = m.N & ~pN;
+        const BV N3 = m.N & pN & sh.p(pN);
+        BV X = Nf;
+        BN = Nf;
+        for (int it = 0;; it++) {
+            X = sh.p(sh.p(sh.p(X))) & N3;
+            if (!X.any()) break;
+            if (it >= max_iter) { ok = false; break; }
+            BN = BN | X;
+        }
+    }
+    return m.TS | BL | BC | BN;
+}
+
+// "other" runs; CAND = apostrophes behind a letter (o200k: candidates for a contraction suffix)
+template <class BV>
+SPL_HD BV o200k_starts_o(const O200kStartMasks<BV>& m, bool mistral, BV& CAND, bool& ok, int max_iter) {
+    const Cl100kShift<BV> sh(m.TS);
+    ok = true;
+    const BV A = o200k_absorbed(m, sh, mistral, ok, max_iter);
+    CAND = m.AP & sh.p(m.L);
+    return o200k_other_starts(m, sh, A);
+}
+
+// whitespace runs (without the absorbed newlines)
+template <class BV>
+SPL_HD BV o200k_starts_s(const O200kStartMasks<BV>& m, bool mistral, bool& ok, int max_iter) {
+    const Cl100kShift<BV> sh(m.TS);
+    ok = true;
+    const BV A = o200k_absorbed(m, sh, mistral, ok, max_iter);
+    const BV S1 = m.S & ~A, NL1 = m.NL & S1;
+    const BV Sf = S1 & ~sh.p(S1);
+    auto nS = [&](const BV& x) { return sh.n(x) & S1; };
+    BV H = nS(NL1);
+    for (int it = 0;; it++) {
+        const BV H2 = nS(H) & ~H;
+        if (!H2.any()) break;
+        if (it >= max_iter) { ok = false; break; }
+        H = H | H2;
+    }
+    const BV NLlast = NL1 & ~H;
+    const BV BS2 = S1 & sh.p(NLlast);
+    const BV Sl = S1 & ~sh.n(S1);
+    const BV BS3 = Sl & ~NL1 & sh.p(S1 & ~NL1) & ~m.TS.shr1();
+    return Sf | BS2 | BS3;
+}
+
+// One candidate of o200k's contraction suffix: the apostrophe at `ap` stands behind a letter.  end = where
+// contraction(a, ap) says the suffix ends (0: none).  Returns false if the candidate itself stands right
+// behind another suffix ("it's's": the second apostrophe starts a match -- the caller keeps the chains then).
+// acc: rec(q), txt(q) as in spl_scan.h.
+template <class A>
+SPL_HD bool o200k_contraction_at(const A& acc, int ap, int& end) {
+    end = contraction(acc, ap);
+    if (end <= 0) { end = 0; return true; }
+    for (int back = 2; back <= 3; back++) {                               // a suffix of one or two characters ending here?
+        const int q = ap - back;
+        if (q < 1) break;
+        if ((acc.rec(q) & CB_CLASS) != C_AP) continue;
+        if (acc.rec(q + 1) & CB_TSTART) continue;
+        const uint32_t pl = acc.rec(q - 1) & CB_CLASS;
+        if (acc.rec(q) & CB_TSTART) continue;                              // (no letter of the same text before it)
+        if (pl != C_CONT && !(SPL_BIT(pl) & M_L)) continue;               // (a continuation byte: of a letter, in a window that qualifies)
+        if (contraction(acc, q) == ap) return false;
+    }
+    return true;
 }
 
 // End of the contraction that starts at the apostrophe `ap` (text bytes through txt(i), `is_ts(i)` = a

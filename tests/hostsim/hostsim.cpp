@@ -335,7 +335,7 @@ struct HostBV {
 extern "C" int hs_split_starts(void* p, const uint8_t* text, int n, const int* doc_off, int n_docs, uint32_t* starts,
                                int tb, int rh, int max_iter, uint32_t* stats) {
     Sim* s = (Sim*)p;
-    if (s->ht.pattern != PAT_CL100K) return -10;
+    const int pat = s->ht.pattern;
     std::vector<uint8_t> recs(n + 64, 0);
     for (int d = 0; d < n_docs; d++) {
         std::vector<uint8_t> r;
@@ -378,10 +378,8 @@ extern "C" int hs_split_starts(void* p, const uint8_t* text, int n, const int* d
                 m.mk[MK_CS][i >> 5] |= 1u << (i & 31);
             }
             uint32_t kb = kc < C_EOT ? kind_bits(kc) : 0u;
-            // what keeps a window off the fast path: a multi-byte character that is no letter, a span
-            // without text (special literal), a byte before the first text
-            const bool multi = cls == C_CONT || ((r >> CB_LEN_SHIFT) & 3u) != 0;
-            if ((multi && !(kb & (1u << MK_L))) || cls == C_EOT || cls == C_WEND) kb |= 1u << MK_BAD;
+            if (bad_for_starts(pat, r, kc, true)) kb |= 1u << MK_BAD;
+            if (wtxt[i] == '/') kb |= 1u << MK_SL;
             for (int k = 0; k < MK_CS; k++) if ((kb >> k) & 1u) m.mk[k][i >> 5] |= 1u << (i & 31);
         }
         for (int w = 0; w < nw; w++) {
@@ -401,9 +399,30 @@ extern "C" int hs_split_starts(void* p, const uint8_t* text, int n, const int* d
                 bool bad = false;
                 for (int i = fs; i < fe; i++) if (bit_m(m, MK_BAD, i)) bad = true;
                 if (bad) n_bad++;
-                if (!bad) {
+                auto mkbv = [&](int k) { HostBV b(nw); b.w = m.mk[k]; return b; };
+                if (!bad && pat != PAT_CL100K) {
+                    O200kStartMasks<HostBV> om{mkbv(MK_L), mkbv(MK_UP), mkbv(MK_N), mkbv(MK_S), mkbv(MK_NL), mkbv(MK_O), mkbv(MK_AP),
+                                               mkbv(MK_SP), mkbv(MK_SL), mkbv(MK_CS), mkbv(MK_TS)};
+                    bool ok1, ok2, ok3;
+                    HostBV CAND;
+                    HostBV Bv = o200k_starts_ln(om, pat == PAT_MISTRAL_V3, ok1, max_iter) | o200k_starts_o(om, pat == PAT_MISTRAL_V3, CAND, ok2, max_iter) |
+                                o200k_starts_s(om, pat == PAT_MISTRAL_V3, ok3, max_iter);
+                    bool ok = ok1 && ok2 && ok3;
+                    std::vector<uint8_t> kill(W + 2, 0), add(W + 2, 0);
+                    if (ok && pat == PAT_O200K)
+                        for (int i = fs; i < fe && ok; i++) {
+                            if (!CAND.bit(i)) continue;
+                            int e;
+                            if (!o200k_contraction_at(m, i, e)) { ok = false; break; }
+                            if (e == SPL_DEFER) return -3;
+                            if (e > 0) { for (int q = i; q < e; q++) kill[q] = 1; add[e] = 1; if (e > fe) return -4; }
+                        }
+                    if (ok) {
+                        for (int i = fs; i < fe; i++) if ((Bv.bit(i) && !kill[i]) || add[i]) mark[w0 + i] = 1;
+                        fast = true;
+                    } else n_iter++;
+                } else if (!bad) {
                     Cl100kStartMasks<HostBV> cm;
-                    auto mkbv = [&](int k) { HostBV b(nw); b.w = m.mk[k]; return b; };
                     cm.L = mkbv(MK_L); cm.N = mkbv(MK_N); cm.S = mkbv(MK_S); cm.NL = mkbv(MK_NL); cm.O = mkbv(MK_O);
                     cm.AP = mkbv(MK_AP); cm.SP = mkbv(MK_SP); cm.TS = mkbv(MK_TS);
                     HostBV CA; bool ok;

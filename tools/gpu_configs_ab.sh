@@ -1,0 +1,8 @@
+# kernel-only throughput of the larger configurations for the given library variants (interleaved twice)
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+mkdir -p gpurun_out; rm -f gpurun_out/configs_ab.log
+for rep in 1 2; do for v in "$@"; do
+  cp _ab/lib_$v.so splintr_amd/libsplintr_hip.so
+  timeout 300 python tools/dev/gpu_time_configs.py $v 2>/dev/null >> gpurun_out/configs_ab.log
+done; done
+cp _ab/lib_default.so splintr_amd/libsplintr_hip.so
