@@ -2264,7 +2264,7 @@ void k_pretok(DeviceTables T, Batch b) {
         int v = 0;
 #pragma unroll
         for (int k = 0; k < MK_SY; k++) {
-            if ((k == MK_M || k == MK_UP) && KPAT == PAT_CL100K) continue;
+            if ((k == MK_M || k == MK_UP || k == MK_LB) && KPAT == PAT_CL100K) continue;
             if (k == MK_SL && KPAT != PAT_MISTRAL_V3) continue;
             const unsigned long long bk = k == MK_CS ? __ballot(cls < C_EOT) : k == MK_TS ? __ballot((r & CB_TSTART) != 0)
                                                                               : __ballot((kb >> k) & 1u);
@@ -2325,7 +2325,7 @@ void k_pretok(DeviceTables T, Batch b) {
                 } else if (KPAT != PAT_CL100K) {
                     // o200k family: letters + numbers / "other" runs and contraction suffixes / whitespace
                     const bool mistral = KPAT == PAT_MISTRAL_V3;
-                    const O200kStartMasks<WaveBV> om{WaveBV{ld(MK_L)}, WaveBV{ld(MK_UP)}, WaveBV{ld(MK_N)}, WaveBV{ld(MK_S)},
+                    const O200kStartMasks<WaveBV> om{WaveBV{ld(MK_L)}, WaveBV{ld(MK_UP)}, WaveBV{ld(MK_LB)}, WaveBV{ld(MK_N)}, WaveBV{ld(MK_S)},
                                                      WaveBV{ld(MK_NL)}, WaveBV{ld(MK_O)}, WaveBV{ld(MK_AP)}, WaveBV{ld(MK_SP)},
                                                      WaveBV{ld(MK_SL)}, WaveBV{ld(MK_CS)}, WaveBV{ts}};
                     bool ok = true;
@@ -2357,7 +2357,7 @@ void k_pretok(DeviceTables T, Batch b) {
                     }
                 } else {
                     const Cl100kStartMasks<WaveBV> cm{WaveBV{ld(MK_L)}, WaveBV{ld(MK_N)}, WaveBV{ld(MK_S)}, WaveBV{ld(MK_NL)},
-                                                      WaveBV{ld(MK_O)}, WaveBV{ld(MK_AP)}, WaveBV{ld(MK_SP)}, WaveBV{ts}};
+                                                      WaveBV{ld(MK_O)}, WaveBV{ld(MK_AP)}, WaveBV{ld(MK_SP)}, WaveBV{ld(MK_CS)}, WaveBV{ts}};
                     bool ok = true;
                     uint32_t bits;
                     if (part == 0) bits = cl100k_starts_ln(cm, ok, 16).x | ts | range_word(fe, fe + 1);   // + text starts, terminator

@@ -19,9 +19,9 @@
 
 namespace spl {
 
-// (MK_SP: U+0020 only.  MK_UP: Lu and Lt.  Set by the mask builder, not kinds of a class: MK_SL: the byte '/';
+// (MK_SP: U+0020 only.  MK_UP: Lu and Lt.  MK_LB: Lm and Lo.  Set by the mask builder, not kinds of a class: MK_SL: the byte '/';
 //  MK_BAD: bytes that keep a window off the bit-vector start computation of spl_scan_starts.h, see bad_for_starts)
-enum : int { MK_L = 0, MK_N, MK_S, MK_NL, MK_O, MK_M, MK_AP, MK_SP, MK_UP, MK_SL, MK_BAD, MK_CS, MK_TS, MK_SY, MK_COUNT };
+enum : int { MK_L = 0, MK_N, MK_S, MK_NL, MK_O, MK_M, MK_AP, MK_SP, MK_UP, MK_LB, MK_SL, MK_BAD, MK_CS, MK_TS, MK_SY, MK_COUNT };
 
 // kind of one class code, as mask membership bits (bit MK_x)
 SPL_HD uint32_t kind_bits(uint32_t cls) {
@@ -36,21 +36,22 @@ SPL_HD uint32_t kind_bits(uint32_t cls) {
     if (cls == C_AP) k |= 1u << MK_AP;
     if (cls == C_SP) k |= 1u << MK_SP;
     if (cls == C_LU || cls == C_LT) k |= 1u << MK_UP;
+    if (cls == C_LM || cls == C_LO) k |= 1u << MK_LB;
     return k;
 }
 
 // Does this byte keep its window off the bit-vector start computation?  r = its class record, kc = the class
 // of its character (a continuation byte: of its lead), in_text = the byte lies before the end of the text.
-//   all patterns : a multi-byte character that is no letter (the formulas count bytes, only run logic
-//                  survives characters of several bytes); a span without text (special-token literal)
-//   o200k family : also letters of class Lm / Lo and marks (in both of the pattern's letter sets: the
-//                  U* W+ split then backs off inside the run; spl_scan.h letters_o200k)
+//   all patterns : a multi-byte number or whitespace character (the formulas count those by bytes; letters
+//                  and "other" characters only enter through run logic and whole-character masks);
+//                  a span without text (special-token literal)
+//   o200k family : also marks (a mark is a body character of the letter alternatives AND a legal prefix)
 SPL_HD bool bad_for_starts(int pattern, uint32_t r, uint32_t kc, bool in_text) {
     const uint32_t cls = r & CB_CLASS;
     const bool multi = cls == C_CONT || (r >> CB_LEN_SHIFT) != 0u;
-    if (multi && !(kc < C_EOT && (SPL_BIT(kc) & M_L))) return true;
+    if (multi && !(kc < C_EOT && (SPL_BIT(kc) & (M_L | M_OTHER)))) return true;
     if (cls == C_EOT && in_text) return true;
-    if (pattern != PAT_CL100K && kc < C_EOT && (SPL_BIT(kc) & (SPL_BIT(C_LM) | SPL_BIT(C_LO) | SPL_BIT(C_M)))) return true;
+    if (pattern != PAT_CL100K && kc == C_M) return true;
     return false;
 }
 

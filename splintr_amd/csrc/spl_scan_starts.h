@@ -4,14 +4,15 @@
 // Replaces the chain phase of k_pretok (spl_scan_masks.h: one chain per sync point, each lane walking
 // its matches one after the other) for the windows it applies to; the same RegexBackend::find_iter
 // (reference src/core/tokenizer.rs:244-257, pattern :39) is what it restates.  A window qualifies if
-// it is ASCII throughout (then a character is a byte and the masks need no inheritance), holds no
-// special-token span, and the pattern is cl100k; any other window keeps the chains.
+// its numbers and whitespace are single bytes (letters and "other" characters may be of any width:
+// continuation bytes inherit their lead's kind) and it holds no special-token span (bad_for_starts,
+// spl_scan_masks.h); any other window keeps the chains.  The o200k family: further down.
 //
 // With p(X) = "the previous byte of the same text is in X" and n(X) = "the next byte of the same
 // text is in X", the starts are (derivation in DESIGN.md 4.1a):
 //   text starts                      TS
 //   letters   first of a letter run, unless a one-character prefix joins it:
-//             Lf & (p(NL) | p(N) | p(O) & (pp(O) | pp(SP)))          (Lf = L & ~p(L))
+//             Lf & (p(NL) | p(N) | p(O & ~BOx))      (Lf = L & ~p(L); BOx: "other" characters that start a match, whole)
 //             (a prefix joins when it starts a match itself: any non-newline whitespace does -- it is
 //              the last whitespace before a non-space --, an "other" character does iff it is alone
 //              and not behind U+0020)
@@ -35,7 +36,7 @@
 namespace spl {
 
 template <class BV> struct Cl100kStartMasks {
-    BV L, N, S, NL, O, AP, SP, TS;      // class masks of the window (SP = U+0020 only; S = all whitespace)
+    BV L, N, S, NL, O, AP, SP, CS, TS;  // class masks of the window (SP = U+0020 only; S = all whitespace; CS = character starts)
 };
 
 // The computation in three independent parts (the kernel gives each to a wavefront of its own; their
@@ -48,14 +49,23 @@ template <class BV> struct Cl100kShift {
     SPL_HD BV n(const BV& x) const { return (x & nTS).shr1(); }              // next byte, same text
 };
 
+// the characters whose first bytes are in X, with their continuation bytes (K = their kind's mask)
+template <class BV>
+SPL_HD BV whole_chars(const Cl100kShift<BV>& sh, const BV& X, const BV& K, const BV& CS) {
+    BV R = X;
+    for (int it = 0; it < 3; it++) R = R | (sh.p(R) & K & ~CS);
+    return R;
+}
+
 // letters and numbers
 template <class BV>
 SPL_HD BV cl100k_starts_ln(const Cl100kStartMasks<BV>& m, bool& ok, int max_iter) {
     const Cl100kShift<BV> sh(m.TS);
     ok = true;
-    const BV pL = sh.p(m.L), pN = sh.p(m.N), pO = sh.p(m.O), pSP = sh.p(m.SP), pNL = sh.p(m.NL);
+    const BV pL = sh.p(m.L), pN = sh.p(m.N), pNL = sh.p(m.NL);
     const BV Lf = m.L & ~pL;
-    const BV BL = Lf & (pNL | pN | (pO & (sh.p(pO) | sh.p(pSP))));
+    // (the "other" character before the run joins it iff it starts a match: all of its bytes, then)
+    const BV BL = Lf & (pNL | pN | sh.p(m.O & ~whole_chars(sh, m.O & ~sh.p(m.O) & ~sh.p(m.SP), m.O, m.CS)));
     const BV Nf = m.N & ~pN;
     const BV N3 = m.N & pN & sh.p(pN);                                     // bytes i-2 .. i are numbers of one text
     BV BN = Nf, X = Nf;
@@ -124,8 +134,9 @@ SPL_HD BV cl100k_starts(const Cl100kStartMasks<BV>& m, BV& CA, bool& ok, int max
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// O200K_BASE_PATTERN / MISTRAL_V3_PATTERN (reference src/core/tokenizer.rs:42, :64) on the same terms, for
-// windows whose letters are all of class Lu, Lt or Ll (no Lm / Lo / marks: bad_for_starts).  Against cl100k:
+// O200K_BASE_PATTERN / MISTRAL_V3_PATTERN (reference src/core/tokenizer.rs:42, :64) on the same terms (no marks
+// in the window: bad_for_starts; caseless letters -- Lm, Lo -- count as lower case, which is exact unless
+// an upper-case letter stands right behind one).  Against cl100k:
 //   letters   a letter run is cut where an upper-case letter follows a lower-case one (U* W+ | U+ W*: a
 //             match is upper-case letters, then lower-case ones): UP & CS & p(L & ~UP).  The one-character
 //             prefix joins iff it starts a match: any non-newline whitespace, or an "other" character in BO.
@@ -136,7 +147,7 @@ SPL_HD BV cl100k_starts(const Cl100kStartMasks<BV>& m, BV& CA, bool& ok, int max
 //             nothing, an "other" character right behind them starts a match
 //   numbers   mistral: every number is a match of its own
 template <class BV> struct O200kStartMasks {
-    BV L, UP, N, S, NL, O, AP, SP, SL, CS, TS;
+    BV L, UP, LB, N, S, NL, O, AP, SP, SL, CS, TS;   // UP = Lu | Lt, LB = Lm | Lo (in both letter sets of the pattern)
 };
 
 // bytes that the [\r\n/]* behind an "other" run takes: a newline behind an "other" byte, then newlines and '/'
@@ -167,8 +178,12 @@ SPL_HD BV o200k_starts_ln(const O200kStartMasks<BV>& m, bool mistral, bool& ok, 
     const BV BO = o200k_other_starts(m, sh, A);
     const BV pL = sh.p(m.L), pN = sh.p(m.N);
     const BV Lf = m.L & ~pL;
-    const BV BL = Lf & (sh.p(m.NL) | pN | sh.p(m.O & ~BO));
+    const BV BL = Lf & (sh.p(m.NL) | pN | sh.p(m.O & ~whole_chars(sh, BO, m.O, m.CS)));
     const BV BC = m.UP & m.CS & sh.p(m.L & ~m.UP);
+    // An upper-case letter right behind a caseless one: whether a match ends between them depends on what
+    // follows the whole run of upper-case and caseless letters (U* W+ backs off to its last caseless
+    // member unless a lower-case letter follows) -- not decided here: the tile keeps the chains.
+    if ((m.UP & m.CS & sh.p(m.LB)).any()) ok = false;
     BV BN = m.N;                                                           // mistral: \p{N}, one at a time
     if (!mistral) {
         const BV Nf = m.N & ~pN;

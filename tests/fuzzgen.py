@@ -103,3 +103,14 @@ def latin_corpus(seed: int, count: int, max_atoms: int = 120) -> List[str]:
     either case and with U+017F, number runs of every length mod 3, "other" runs before letters."""
     rng = random.Random(seed)
     return ["".join(rng.choice(_LATIN_ATOMS) for _ in range(rng.randint(0, max_atoms))) for _ in range(count)]
+
+
+_CASE_ATOMS = ["HelloWorld", "ABCdef", "aB", "XMLParser", "it's's", "don't", "DON'T", "we'Re", "x'rE", "'s", "a'", "É", "éÉ", "Ünï", "ǅ",
+               "!\n/", "/\n/", "//\n//x", "\n/", "a/\n/b", ";\n/?", "}\n\n/", "ſ", "'ſ", "A'ſB", "1", "12", "1234567", " ", "\n", "a", "B", "'", "/", "!"]
+
+
+def cased_corpus(seed: int, count: int, max_atoms: int = 80) -> List[str]:
+    """What the o200k family's start masks must get right: case changes inside a letter run, contraction
+    suffixes (also back to back, in either case, with U+017F), newlines and '/' behind "other" runs."""
+    rng = random.Random(seed)
+    return ["".join(rng.choice(_CASE_ATOMS) for _ in range(rng.randint(0, max_atoms))) for _ in range(count)]

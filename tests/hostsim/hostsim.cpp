@@ -401,7 +401,7 @@ extern "C" int hs_split_starts(void* p, const uint8_t* text, int n, const int* d
                 if (bad) n_bad++;
                 auto mkbv = [&](int k) { HostBV b(nw); b.w = m.mk[k]; return b; };
                 if (!bad && pat != PAT_CL100K) {
-                    O200kStartMasks<HostBV> om{mkbv(MK_L), mkbv(MK_UP), mkbv(MK_N), mkbv(MK_S), mkbv(MK_NL), mkbv(MK_O), mkbv(MK_AP),
+                    O200kStartMasks<HostBV> om{mkbv(MK_L), mkbv(MK_UP), mkbv(MK_LB), mkbv(MK_N), mkbv(MK_S), mkbv(MK_NL), mkbv(MK_O), mkbv(MK_AP),
                                                mkbv(MK_SP), mkbv(MK_SL), mkbv(MK_CS), mkbv(MK_TS)};
                     bool ok1, ok2, ok3;
                     HostBV CAND;
@@ -424,7 +424,7 @@ extern "C" int hs_split_starts(void* p, const uint8_t* text, int n, const int* d
                 } else if (!bad) {
                     Cl100kStartMasks<HostBV> cm;
                     cm.L = mkbv(MK_L); cm.N = mkbv(MK_N); cm.S = mkbv(MK_S); cm.NL = mkbv(MK_NL); cm.O = mkbv(MK_O);
-                    cm.AP = mkbv(MK_AP); cm.SP = mkbv(MK_SP); cm.TS = mkbv(MK_TS);
+                    cm.AP = mkbv(MK_AP); cm.SP = mkbv(MK_SP); cm.CS = mkbv(MK_CS); cm.TS = mkbv(MK_TS);
                     HostBV CA; bool ok;
                     HostBV Bv = cl100k_starts(cm, CA, ok, max_iter);
                     if (ok) {

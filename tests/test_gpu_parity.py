@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from conftest import ROOT, VOCABS
-from fuzzgen import fuzz_corpus, invalid_utf8_corpus, latin_corpus
+from fuzzgen import cased_corpus, fuzz_corpus, invalid_utf8_corpus, latin_corpus
 
 pytestmark = pytest.mark.gpu
 
@@ -162,12 +162,14 @@ def test_fuzz_batch(coracle, name):
 
 @pytest.mark.parametrize("name", VOCABS)
 def test_bitvector_starts_latin_text(coracle, name):
-    """Text whose multi-byte characters are all letters: cl100k tiles take their match starts from the
+    """Text whose multi-byte characters are all letters: the tiles take their match starts from the
     bit-vector computation (spl_scan_starts.h) -- whitespace runs with and without newlines, contractions
-    in either case and with U+017F, number runs of every length mod 3, documents from empty to several
-    tiles, so that text starts and ends fall everywhere in the windows.  (The other patterns: the chains.)"""
+    in either case and with U+017F (cl100k: a match of their own; o200k family: a suffix of the letters,
+    also back to back), case changes inside a word, newlines and '/' behind "other" runs, number runs of
+    every length mod 3, documents from empty to several tiles, so that text starts and ends fall
+    everywhere in the windows."""
     rng = random.Random(7)
-    texts = latin_corpus(23, 12000, 60) + latin_corpus(24, 300, 1500)
+    texts = latin_corpus(23, 12000, 60) + latin_corpus(24, 300, 1500) + cased_corpus(25, 6000) + cased_corpus(26, 200, 2000)
     texts += ["".join(rng.choice(texts[:2000]) for _ in range(40)) for _ in range(50)]
     assert_batch_equal(name, texts, coracle)
     assert_batch_equal(name, ["".join(texts[:3000])], coracle)          # one document over many tiles

@@ -4,7 +4,7 @@ forms, deferral contract at tiny windows, sync-point rules, table formats, the l
 import pytest
 
 from conftest import VOCABS
-from fuzzgen import fuzz_corpus, invalid_utf8_corpus, latin_corpus
+from fuzzgen import cased_corpus, fuzz_corpus, invalid_utf8_corpus, latin_corpus
 from hostsim import HostSim
 
 _sims = {}
@@ -85,10 +85,6 @@ def test_salted_tables_have_no_overflow(name):
     assert st["unsalted_groups"] <= 1, st
 
 
-_CASE_ATOMS = ["HelloWorld", "ABCdef", "aB", "XMLParser", "it's's", "don't", "DON'T", "we'Re", "x'rE", "'s", "a'", "É", "éÉ", "Ünï", "ǅ",
-               "!\n/", "/\n/", "//\n//x", "\n/", "a/\n/b", ";\n/?", "}\n\n/", "ſ", "'ſ", "A'ſB", "1", "12", "1234567", " ", "\n", "a", "B", "'", "/", "!"]
-
-
 @pytest.mark.parametrize("name", ["cl100k_base", "o200k_base", "mistral_v3"])
 def test_bitvector_starts_tiled_like_the_kernel(coracle, name):
     """spl_scan_starts.h (match starts by bit-vector arithmetic on the class masks, all three patterns) driven
@@ -98,7 +94,7 @@ def test_bitvector_starts_tiled_like_the_kernel(coracle, name):
     import random
     h, c = sim(name), coracle(name)
     rng = random.Random(5)
-    cased = ["".join(rng.choice(_CASE_ATOMS) for _ in range(rng.randint(0, 80))) for _ in range(2000)]
+    cased = cased_corpus(9, 2000)
     for corp, min_fast in ((latin_corpus(11, 2500), 1.0 if name == "cl100k_base" else 0.5), (cased, 0.2), (fuzz_corpus(777, 3000, 60), 0.05)):
         docs_all = [s.encode("utf-8") for s in corp]
         i, tiles, fast = 0, 0, 0
