@@ -168,7 +168,7 @@ struct Ctx {
     uint32_t* last_qcount = nullptr;
     bool dbg_on = false;
     int stop_phase = 0;     // spl_debug_phases bits 4..6 (profiling builds of the instruction mix per phase)
-    int force_tile = 0;     // 0 auto, 1 small tiles, 2 large tiles (spl_debug_phases bits 1..3)
+    int force_tile = 0;     // 0 auto, 1 small tiles, 2 large tiles, 3 multi-pass, 4 queue mode, 5 tile-owned geometry B (spl_debug_phases bits 1..3)
 
     void free_workspace() {
         hipFree(d_zero); hipFree(d_stage); hipFree(d_rank);
@@ -428,9 +428,16 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
     // queue mode: tile-owned tiles + global queues for what is long, for batches beyond the two-launch limit
     const bool queue_mode = !special && (t->force_tile == 4 || (t->force_tile == 0 && n_bytes > SPL_DIRECT_MAX_BYTES)) &&
                             n_bytes <= SPL_QUEUE_MAX_BYTES;
-    const bool small_tiles = queue_mode || t->force_tile == 1 || t->force_tile == 3 ||
+    const bool small_tiles = queue_mode || t->force_tile == 1 || t->force_tile == 3 || t->force_tile == 5 ||
                              (t->force_tile == 0 && n_bytes <= SPL_DIRECT_MAX_BYTES);
-    const uint32_t tile_bytes = small_tiles ? TileGeom<SPL_TILE_SMALL>::TBv : TileGeom<SPL_TILE_LARGE>::TBv;
+    const bool direct = !queue_mode && small_tiles && t->force_tile != 3 && n_bytes <= SPL_DIRECT_MAX_BYTES;
+    // tile-owned mode: two geometries of the same window (spl_kernels.hip SPL_TILE_DIRECT_A / _B; force 5: B at any size)
+    static_assert(TileGeom<SPL_TILE_DIRECT_A>::Wv == TileGeom<SPL_TILE_SMALL>::Wv && TileGeom<SPL_TILE_DIRECT_B>::Wv == TileGeom<SPL_TILE_SMALL>::Wv &&
+                  TileGeom<SPL_TILE_DIRECT_A>::TBv >= TileGeom<SPL_TILE_SMALL>::TBv && TileGeom<SPL_TILE_DIRECT_B>::TBv >= TileGeom<SPL_TILE_SMALL>::TBv,
+                  "the workspace is sized for SPL_TILE_SMALL's window and tile count");
+    const bool direct_b = direct && (t->force_tile == 5 || n_bytes > SPL_DIRECT_A_MAX_BYTES);
+    const uint32_t tile_bytes = direct ? (direct_b ? TileGeom<SPL_TILE_DIRECT_B>::TBv : TileGeom<SPL_TILE_DIRECT_A>::TBv)
+                              : small_tiles ? TileGeom<SPL_TILE_SMALL>::TBv : TileGeom<SPL_TILE_LARGE>::TBv;
     const uint32_t ntiles = (uint32_t)((n_bytes + tile_bytes - 1) / tile_bytes);
     // (A/B on the 1 MB bench batch: folding these launches together -- clean-after-use bitmaps, one
     //  tail kernel with a grid barrier and a last-workgroup scan -- was SLOWER than this plain
@@ -438,7 +445,6 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
     //  single-workgroup tails and agent-scope fences sit on the critical path.)
     // Single pass: small batches without special tokens are finished by ONE kernel.
     bool fused_scan_used = false;
-    const bool direct = !queue_mode && small_tiles && t->force_tile != 3 && n_bytes <= SPL_DIRECT_MAX_BYTES;
     if (queue_mode) {
         t->bitmap_dirty = true;
         HIP_TRY(hipMemsetAsync(t->d_zero, 0, (2 * uw + QCOUNT_WORDS) * 4, s));
@@ -488,7 +494,8 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
             }
         }
         MARK(KI_PRETOK);
-        if (ntiles) hipLaunchKernelGGL((k_pretok<SPL_TILE_SMALL, false, true>), dim3(ntiles), dim3(NT), 0, s, t->dt, b);
+        if (ntiles && direct_b) hipLaunchKernelGGL((k_pretok<SPL_TILE_DIRECT_B, false, true>), dim3(ntiles), dim3(NT), 0, s, t->dt, b);
+        else if (ntiles) hipLaunchKernelGGL((k_pretok<SPL_TILE_DIRECT_A, false, true>), dim3(ntiles), dim3(NT), 0, s, t->dt, b);
         else HIP_TRY(hipMemsetAsync(d_out_off, 0, (n_docs + 1) * 8, s));
         MARK(KI_DEFER); MARK(KI_BPELANES); MARK(KI_BPELONG); MARK(KI_COUNT); MARK(KI_SCAN); MARK(KI_COMPACT);
         if (ntiles) hipLaunchKernelGGL(k_tile_out, dim3(ntiles), dim3(NT), 0, s, b);
@@ -1238,7 +1245,7 @@ int spl_debug_phases(spl_tokenizer* t, int enable, unsigned long long stamps_out
         if (c == t->ctx[0].get() && stamps_out && c->d_dbg) HIP_TRY(hipMemcpy(stamps_out, c->d_dbg, 16 * 8, hipMemcpyDeviceToHost));
         c->dbg_on = (enable & 1) != 0;
         c->stop_phase = (enable >> 4) & 7;
-        c->force_tile = (enable >> 1) & 7;      // development: 1 = small tiles, 2 = large tiles, 3 = small tiles + multi-pass, 4 = queue mode
+        c->force_tile = (enable >> 1) & 7;      // development: 1 = small tiles, 2 = large tiles, 3 = small tiles + multi-pass, 4 = queue mode, 5 = tile-owned with geometry B
     }
     return SPL_OK;
 }

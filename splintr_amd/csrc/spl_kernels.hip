@@ -48,6 +48,20 @@ constexpr int RANK_BLK = 1024;           // positions per rank block (32 bitmap 
 #define SPL_TILE_SMALL 768, 224          /* window 1024 B: one 4-byte word per lane */
 #endif
 #define SPL_TILE_LARGE 4096, 480         /* window 4608 B */
+// Tile-owned mode: the same 1024-byte window with more of it owned.  The halo only has to hold the chunk that
+// straddles the tile's end and the next sync point (anything longer is finished from a moving window), and every
+// byte of halo is classified and masked twice: batches that fill the GPU several times over gain 3-10 % from
+// 864 + 128 (English / code most); a batch of about 1 MB -- every tile resident at once, the step ends with
+// k_tile_out, whose work grows with the tile -- is best at 800 + 192 (profiles/r02_tile_geometry.txt).
+#ifndef SPL_TILE_DIRECT_A
+#define SPL_TILE_DIRECT_A 800, 192       /* batches up to SPL_DIRECT_A_MAX_BYTES */
+#endif
+#ifndef SPL_TILE_DIRECT_B
+#define SPL_TILE_DIRECT_B 864, 128
+#endif
+#ifndef SPL_DIRECT_A_MAX_BYTES
+#define SPL_DIRECT_A_MAX_BYTES (1280u * 1024u)
+#endif
 #ifndef SPL_DIRECT_MAX_MB
 #define SPL_DIRECT_MAX_MB 256
 #endif

@@ -85,7 +85,7 @@ def test_mistral_v3_special_ids_held_by_the_reference(golden_all):
 
 
 @pytest.mark.parametrize("name", VOCABS)
-@pytest.mark.parametrize("geom", [0, 3, 4])
+@pytest.mark.parametrize("geom", [0, 3, 4, 5])
 def test_invalid_utf8_policy(coracle, name, geom):
     """include/splintr_hip.h, "Text that is not valid UTF-8": the C ABI takes raw bytes; stray continuation
     bytes, truncated / over-long sequences and impossible lead bytes -- also right at document boundaries
@@ -193,7 +193,7 @@ def _long_word_texts(seed, n_docs):
     return out
 
 
-@pytest.mark.parametrize("geom", [0, 3])
+@pytest.mark.parametrize("geom", [0, 3, 5])
 @pytest.mark.parametrize("name", VOCABS)
 def test_long_words_merge_two_to_a_wavefront(coracle, name, geom):
     """Chunks of 17..32 bytes share a wavefront two by two (32 lanes each), longer ones take one alone, spans
@@ -228,24 +228,27 @@ def test_corpus_fixtures_sha256():
 
 
 def _force_tiles(name, mode):
-    """Development hook of the C ABI: 0 auto, 1 small tiles (768+224; single pass when the batch
-    qualifies), 2 large tiles (4096+480), 3 small tiles with the multi-pass pipeline, 4 queue mode."""
+    """Development hook of the C ABI: 0 auto, 1 small tiles (tile-owned mode when the batch qualifies: 800+192
+    up to 1.25 MB, 864+128 beyond), 2 large tiles (4096+480), 3 small tiles (768+224) with the multi-pass
+    pipeline, 4 queue mode, 5 tile-owned mode with 864+128 at any size."""
     import ctypes
     from splintr_amd import _ffi
     st = (ctypes.c_uint64 * 16)()
     assert _ffi.lib().spl_debug_phases(tok(name).handle, mode << 1, st) == 0
 
 
-@pytest.mark.parametrize("geom", [1, 2, 3])
+@pytest.mark.parametrize("geom", [1, 2, 3, 5])
 @pytest.mark.parametrize("name", ["cl100k_base", "o200k_base"])
 def test_tile_and_window_edges(coracle, name, geom):
-    """Documents and runs placed around the tile edge and the right halo of BOTH tile geometries."""
+    """Documents and runs placed around the tile edge and the right halo of EVERY tile geometry (tile-owned
+    mode: 800 + 192 at this size, 864 + 128 forced by 5; multi-pass: 768 + 224 and 4096 + 480)."""
     rng = random.Random(5)
     texts = []
-    for size in (1, 2, 31, 32, 33, 767, 768, 769, 991, 992, 993, 1023, 1024, 1025, 1535, 1536, 1537,
+    for size in (1, 2, 31, 32, 33, 767, 768, 769, 799, 800, 801, 863, 864, 865, 991, 992, 993, 1023, 1024, 1025, 1535, 1536, 1537,
+                 1599, 1600, 1601, 1727, 1728, 1729,
                  4095, 4096, 4097, 4575, 4576, 4577, 4607, 4608, 4609, 8191, 8192, 8193):
         texts.append(("ab cd, " * (size // 7 + 1))[:size])
-    for lead in (700, 760, 768, 770, 900, 990, 4000, 4090, 4096, 4100, 4500, 4570):
+    for lead in (700, 760, 768, 770, 795, 800, 805, 860, 864, 870, 900, 990, 4000, 4090, 4096, 4100, 4500, 4570):
         for run in (" " * 600, "a" * 700, "1" * 500, "=" * 490, "\n" * 481, "你" * 200, " \n" * 300, "x'" * 300,
                     "A" * 500 + "b", "é́" * 200):
             filler = ("lorem ipsum 12 " * 400)[:lead]
@@ -275,7 +278,7 @@ def test_huge_single_chunk(coracle):
         assert_batch_equal("cl100k_base", [t, "after"], coracle)
 
 
-@pytest.mark.parametrize("geom", [1, 3])
+@pytest.mark.parametrize("geom", [1, 3, 5])
 @pytest.mark.parametrize("name", VOCABS)
 def test_oversize_chunks_merge_by_rounds(coracle, name, geom):
     """Chunks beyond the LDS node lists are merged a whole rank at a time (bpe_block_rounds): low-entropy
