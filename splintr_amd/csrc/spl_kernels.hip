@@ -2270,9 +2270,10 @@ void k_pretok(DeviceTables T, Batch b) {
             while (j >= 0 && (s_rec[j] & CB_CLASS) == C_CONT && j > i - 3) j--;
             kc = j >= 0 ? (s_rec[j] & CB_CLASS) : (uint32_t)C_CONT;
         }
-        uint32_t kb = kc < C_EOT ? kind_bits(kc) : 0u;
-        if (bad_for_starts(KPAT, r, kc, i < iB)) kb |= 1u << MK_BAD;      // keeps the window off the bit-vector start computation
-        if (KPAT == PAT_MISTRAL_V3 && s_txt[i] == '/') kb |= 1u << MK_SL;  // (only mistral's [\r\n/]* asks)
+        // one compare per kind: the class as a one-hot word against the kind's set of classes
+        const uint32_t oh = kc < C_EOT ? 1u << kc : 0u;
+        const bool bad = bad_for_starts(KPAT, r, kc, i < iB);            // keeps the window off the bit-vector start computation
+        const bool slash = KPAT == PAT_MISTRAL_V3 && s_txt[i] == '/';    // (only mistral's [\r\n/]* asks)
         // lane 2k / 2k + 1 of `v` receive the two halves of kind k's ballot (v_writelane: one instruction per
         // half; a select chain over all kinds cost three per kind); kinds the pattern never asks for stay zero
         int v = 0;
@@ -2281,7 +2282,8 @@ void k_pretok(DeviceTables T, Batch b) {
             if ((k == MK_M || k == MK_UP || k == MK_LB) && KPAT == PAT_CL100K) continue;
             if (k == MK_SL && KPAT != PAT_MISTRAL_V3) continue;
             const unsigned long long bk = k == MK_CS ? __ballot(cls < C_EOT) : k == MK_TS ? __ballot((r & CB_TSTART) != 0)
-                                                                              : __ballot((kb >> k) & 1u);
+                                        : k == MK_BAD ? __ballot(bad) : k == MK_SL ? __ballot(slash)
+                                        : __ballot((oh & kind_classes(k)) != 0u);
             v = write_lane(v, (uint32_t)bk, 2 * k);
             v = write_lane(v, (uint32_t)(bk >> 32), 2 * k + 1);
         }

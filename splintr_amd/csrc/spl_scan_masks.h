@@ -55,6 +55,13 @@ SPL_HD bool bad_for_starts(int pattern, uint32_t r, uint32_t kc, bool in_text) {
     return false;
 }
 
+// The classes of each kind as a set (bit c = class c): a byte's kind bit is (1 << class) & kind_classes(k).
+SPL_HD constexpr uint32_t kind_classes(int k) {
+    return k == MK_L ? M_L : k == MK_N ? SPL_BIT(C_N) : k == MK_S ? M_S : k == MK_NL ? SPL_BIT(C_NL) : k == MK_O ? M_OTHER
+         : k == MK_M ? SPL_BIT(C_M) : k == MK_AP ? SPL_BIT(C_AP) : k == MK_SP ? SPL_BIT(C_SP)
+         : k == MK_UP ? (SPL_BIT(C_LU) | SPL_BIT(C_LT)) : k == MK_LB ? (SPL_BIT(C_LM) | SPL_BIT(C_LO)) : 0u;
+}
+
 SPL_HD int ctz32(uint32_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __ffs((int)x) - 1;
