@@ -3120,19 +3120,23 @@ void k_pretok(DeviceTables T, Batch b) {
 // group (accumulated by k_pretok with one atomic per tile) plus the counts of the earlier tiles of
 // its own group -- every workgroup computes its own base, there is no scan pass and nothing waits.
 // Workgroup 0 also re-arms the next call: packing cursor and the OTHER parity's group sums to zero.
-__global__ __launch_bounds__(NT) void k_tile_out(Batch b) {
-    __shared__ unsigned long long s_part[NT / 64];
-    __shared__ uint32_t s_wsum[NT / 64];
+#ifndef SPL_TILE_OUT_NT
+#define SPL_TILE_OUT_NT 128
+#endif
+constexpr int TOUT_NT = SPL_TILE_OUT_NT;               // threads of a k_tile_out workgroup (a tile has a few hundred tokens)
+__global__ __launch_bounds__(TOUT_NT) void k_tile_out(Batch b) {
+    __shared__ unsigned long long s_part[TOUT_NT / 64];
+    __shared__ uint32_t s_wsum[TOUT_NT / 64];
     const uint32_t t = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t* gs = b.tctl + 16 + b.tpar * b.tgroups;
     const uint32_t g = t >> 6;
-    // the tile's slot is fixed, so its first NT tokens are fetched before the counts are known
+    // the tile's slot is fixed, so its first TOUT_NT tokens are fetched before the counts are known
     // (most tiles hold fewer): the copy below then depends on ONE round of loads, not two
     const uint32_t slot0 = t * b.tslot;
     const uint32_t first_id = b.tile_ids[slot0 + tid];
     unsigned long long mine = 0;
-    for (uint32_t k = tid; k < g; k += NT) mine += gs[k];
+    for (uint32_t k = tid; k < g; k += TOUT_NT) mine += gs[k];
     {
         const uint32_t u = (g << 6) + (uint32_t)tid;
         if (tid < 64 && u < t) { const TileDesc q = b.tdesc[u]; mine += (unsigned long long)q.c_win + q.c_ovf; }
@@ -3143,15 +3147,15 @@ __global__ __launch_bounds__(NT) void k_tile_out(Batch b) {
     if (lane == 0) s_part[wv] = mine;
     __syncthreads();
     unsigned long long base = 0;
-    for (int k = 0; k < NT / 64; k++) base += s_part[k];
+    for (int k = 0; k < TOUT_NT / 64; k++) base += s_part[k];
     const uint32_t s_ids_at = 3 + b.slab_max_docs, s_ids_cap = b.slab ? b.slab_cap - s_ids_at : 0u;
-    for (uint32_t k = tid; k < td.c_win; k += NT) {
+    for (uint32_t k = tid; k < td.c_win; k += TOUT_NT) {
         const unsigned long long r = base + k;
-        const uint32_t id = k < (uint32_t)NT ? first_id : b.tile_ids[td.slot + k];
+        const uint32_t id = k < (uint32_t)TOUT_NT ? first_id : b.tile_ids[td.slot + k];
         if (r < b.ids_cap) b.ids_out[r] = id;
         if (r < s_ids_cap) b.slab[s_ids_at + r] = id;
     }
-    for (uint32_t k = tid; k < td.d_cnt; k += NT) {
+    for (uint32_t k = tid; k < td.d_cnt; k += TOUT_NT) {
         const unsigned long long v = b.off_out[td.d_first + k] + base;
         b.off_out[td.d_first + k] = v;
         if (b.slab && td.d_first + k <= b.slab_max_docs) b.slab[2 + td.d_first + k] = (uint32_t)v;
@@ -3163,7 +3167,7 @@ __global__ __launch_bounds__(NT) void k_tile_out(Batch b) {
     if (td.ovf_hi > td.ovf_lo) {                             // rare: tokens that start beyond the window
         const uint32_t wlo = td.ovf_lo >> 5, whi = (td.ovf_hi + 31) >> 5;
         unsigned long long running = base + td.c_win;
-        for (uint32_t wb = wlo; wb < whi; wb += NT) {
+        for (uint32_t wb = wlo; wb < whi; wb += TOUT_NT) {
             const uint32_t w = wb + tid;
             uint32_t word = w < whi ? b.tbits[w] : 0u;
             if (w == whi - 1u && (td.ovf_hi & 31u)) word &= (1u << (td.ovf_hi & 31u)) - 1u;     // (as in k_pretok's count)
@@ -3174,7 +3178,7 @@ __global__ __launch_bounds__(NT) void k_tile_out(Batch b) {
             __syncthreads();
             unsigned long long r = running + (x - cnt);
             uint32_t all = 0;
-            for (int k = 0; k < NT / 64; k++) { if (k < wv) r += s_wsum[k]; all += s_wsum[k]; }
+            for (int k = 0; k < TOUT_NT / 64; k++) { if (k < wv) r += s_wsum[k]; all += s_wsum[k]; }
             if (word && !b.skip) b.tbits[w] = 0u;           // clean after use: the bitmap is all-zero between calls
                                                             // (with special tokens it is cleared per call instead)
             while (word) {
@@ -3189,7 +3193,7 @@ __global__ __launch_bounds__(NT) void k_tile_out(Batch b) {
     }
     if (t == 0) {
         uint32_t* other = b.tctl + 16 + (b.tpar ^ 1u) * b.tgroups;
-        for (uint32_t k = tid; k < b.tgroups; k += NT) other[k] = 0u;
+        for (uint32_t k = tid; k < b.tgroups; k += TOUT_NT) other[k] = 0u;
     }
 }
 
