@@ -713,10 +713,14 @@ int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t
         const uint8_t* src = utf8 + ch.lo;
         if (!src_pinned && nb) { memcpy(c->h_text[sl].p, src, nb); src = (const uint8_t*)c->h_text[sl].p; }
         if (k >= NSLOT) HIP_TRY(hipStreamWaitEvent(c->s_h2d, c->ev_cmp[sl], 0));   // the slot's device text has been consumed
-        if (nb) HIP_TRY(hipMemcpyAsync(c->d_text[sl], src, nb, hipMemcpyHostToDevice, c->s_h2d));
-        HIP_TRY(hipMemcpyAsync(c->d_off[sl], rel, (nd + 1) * 8, hipMemcpyHostToDevice, c->s_h2d));
-        HIP_TRY(hipEventRecord(c->ev_h2d[sl], c->s_h2d));
-        HIP_TRY(hipStreamWaitEvent(c->s_cmp, c->ev_h2d[sl], 0));
+        // (a batch of ONE chunk has nothing to overlap: its copies go on the compute stream, no event in between)
+        hipStream_t hs = solo ? c->s_cmp : c->s_h2d;
+        if (nb) HIP_TRY(hipMemcpyAsync(c->d_text[sl], src, nb, hipMemcpyHostToDevice, hs));
+        HIP_TRY(hipMemcpyAsync(c->d_off[sl], rel, (nd + 1) * 8, hipMemcpyHostToDevice, hs));
+        if (!solo) {
+            HIP_TRY(hipEventRecord(c->ev_h2d[sl], c->s_h2d));
+            HIP_TRY(hipStreamWaitEvent(c->s_cmp, c->ev_h2d[sl], 0));
+        }
         uint64_t* oo = c->d_oo + ch.oo_at;
         int rc = launch_all(tk, c, c->d_text[sl], nb, c->d_off[sl], nd, flags, ids_direct ? ids_direct : c->d_ids + (ch.lo - ln.lo),
                             nb + 16, oo, c->s_cmp);
