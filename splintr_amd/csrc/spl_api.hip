@@ -144,6 +144,8 @@ struct Ctx {
     uint32_t* d_tile_ids = nullptr;
     uint32_t* d_tctl = nullptr;
     uint32_t tgroups = 0, tpar = 0;
+    uint64_t* off_host = nullptr;             // set by the caller of launch_all: where k_tile_out also stores the offsets (one-chunk host batches)
+    bool off_host_written = false;            // launch_all: the tile-owned mode did so
     bool bitmap_dirty = true;
     // host pipeline (spl_encode_batch / spl_decode_batch)
     hipStream_t s_cmp = nullptr, s_h2d = nullptr, s_d2h = nullptr;
@@ -480,6 +482,7 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
         b.tgroups = t->tgroups; b.tpar = t->tpar; b.tslot = (uint32_t)TileGeom<SPL_TILE_SMALL>::Wv + 1u;
         if (so && ntiles) { b.slab = so->d_slab; b.slab_cap = (uint32_t)so->cap_words; b.slab_max_docs = (uint32_t)so->max_docs; }
         if (ntiles) t->tpar ^= 1u;              // k_tile_out zeroes the other parity's sums for the next call
+        if (ntiles && t->off_host) { b.off_out2 = t->off_host; t->off_host_written = true; }
         if (!special) b.tstart = nullptr;
         b.qcount = nullptr;
         t->last_qcount = nullptr;
@@ -808,9 +811,14 @@ int encode_host(spl_tokenizer* tk, const uint8_t* utf8, const uint64_t* doc_off,
             }
             void* dptr = nullptr;
             HIP_TRY(hipHostGetDevicePointer(&dptr, r->ids, 0));
+            // ... and the offsets into the pinned result as well: no copy back at all
+            void* optr = nullptr;
+            HIP_TRY(hipHostGetDevicePointer(&optr, r->off, 0));
+            c->off_host = (uint64_t*)optr; c->off_host_written = false;
             int rc = lane_submit(tk, ln, utf8, doc_off, flags, src_pinned, true, (uint32_t*)dptr);
+            c->off_host = nullptr;
             if (rc) return rc;
-            HIP_TRY(hipMemcpyAsync(r->off, c->d_oo + ch.oo_at, (nd + 1) * 8, hipMemcpyDeviceToHost, c->s_cmp));
+            if (!c->off_host_written) HIP_TRY(hipMemcpyAsync(r->off, c->d_oo + ch.oo_at, (nd + 1) * 8, hipMemcpyDeviceToHost, c->s_cmp));
             HIP_TRY(hipStreamSynchronize(c->s_cmp));
             r->n_tokens = r->off[nd];
             return SPL_OK;

@@ -122,6 +122,7 @@ struct Batch {
     // format): k_tile_out writes it in the same pass, the separate pack launch goes away
     uint32_t* slab; uint32_t slab_cap, slab_max_docs;
     uint32_t tpar;             // parity of this call
+    uint64_t* off_out2;        // tile-owned mode, optional: k_tile_out stores the final offsets here as well (pinned host memory)
 };
 
 // LDS hand-over between the lanes of ONE wavefront (no workgroup barrier)
@@ -3158,6 +3159,7 @@ __global__ __launch_bounds__(TOUT_NT) void k_tile_out(Batch b) {
     for (uint32_t k = tid; k < td.d_cnt; k += TOUT_NT) {
         const unsigned long long v = b.off_out[td.d_first + k] + base;
         b.off_out[td.d_first + k] = v;
+        if (b.off_out2) b.off_out2[td.d_first + k] = v;
         if (b.slab && td.d_first + k <= b.slab_max_docs) b.slab[2 + td.d_first + k] = (uint32_t)v;
     }
     if (b.slab && t == gridDim.x - 1 && tid == 0) {        // header: T (the last tile ends the corpus), N
