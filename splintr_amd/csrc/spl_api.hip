@@ -64,8 +64,11 @@ struct PinnedPool {
         {
             std::lock_guard<std::mutex> g(mu);
             int best = -1;
+            // (no buffer is smaller than 64 KiB: a request below that must still find the one it returned last
+            //  time -- it did not, and every call with a small offsets array paid a hipHostMalloc, 20 us)
+            const size_t lim = 4 * std::max<size_t>(need, (size_t)1 << 16);
             for (int i = 0; i < (int)free_.size(); i++)
-                if (free_[i].first >= need && free_[i].first <= 4 * need && (best < 0 || free_[i].first < free_[best].first)) best = i;
+                if (free_[i].first >= need && free_[i].first <= lim && (best < 0 || free_[i].first < free_[best].first)) best = i;
             if (best >= 0) {
                 void* p = free_[best].second;
                 cap = free_[best].first;
@@ -113,6 +116,15 @@ constexpr int NSLOT = 3;                      // staging slots of the host pipel
 
 // SPL_TRACE=1: progress of the host pipeline on stderr (development aid)
 bool trace_on() { static const bool on = getenv("SPL_TRACE") != nullptr; return on; }
+#ifdef SPL_HOST_TIMING   /* dev build: average host time between marks of the one-chunk path, printed every 256 calls */
+#include <chrono>
+static double g_ht[8]; static int g_htn;
+#define HT_T(v) const auto v = std::chrono::steady_clock::now()
+#define HT_ACC(i, a, b_) g_ht[i] += std::chrono::duration<double, std::micro>((b_) - (a)).count()
+#else
+#define HT_T(v) do { } while (0)
+#define HT_ACC(i, a, b_) do { } while (0)
+#endif
 #define TRACE(...) do { if (trace_on()) { fprintf(stderr, "[spl] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 
 // Everything that lives on ONE GPU: lookup tables, workspace, and the host pipeline's streams and
@@ -738,8 +750,11 @@ int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t
 }
 
 int encode_host(spl_tokenizer* tk, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags, spl_result* r) {
+    HT_T(ht0);
     const uint64_t n_bytes = doc_off[n_docs];
     const bool src_pinned = is_pinned_host(utf8);
+    HT_T(hta);
+    HT_ACC(3, ht0, hta);
     // ---- lanes ----------------------------------------------------------------------------------
     const size_t nl_max = tk->ctx.size();
     size_t nl = nl_max;
@@ -782,6 +797,8 @@ int encode_host(spl_tokenizer* tk, const uint8_t* utf8, const uint64_t* doc_off,
     }
     size_t n_chunks = 0;
     for (auto& ln : lanes) n_chunks += ln.chunks.size();
+    HT_T(htb);
+    HT_ACC(4, hta, htb);
     TRACE("encode_host: %llu bytes %llu docs, %zu lane(s), %zu chunk(s), target %llu, pinned src %d", (unsigned long long)n_bytes,
           (unsigned long long)n_docs, nl, n_chunks, (unsigned long long)chunk_target, (int)src_pinned);
 
@@ -795,6 +812,8 @@ int encode_host(spl_tokenizer* tk, const uint8_t* utf8, const uint64_t* doc_off,
     if (!r->off || !r->ids) return fail(SPL_EDEVICE, "pinned result allocation failed");
 
     // ---- one chunk: everything on the compute stream ---------------------------------------------------
+    HT_T(ht1);
+    HT_ACC(0, ht0, ht1);
     if (n_chunks == 1) {
         Lane& ln = lanes[0];
         Ctx* c = ln.c;
@@ -819,7 +838,17 @@ int encode_host(spl_tokenizer* tk, const uint8_t* utf8, const uint64_t* doc_off,
             c->off_host = nullptr;
             if (rc) return rc;
             if (!c->off_host_written) HIP_TRY(hipMemcpyAsync(r->off, c->d_oo + ch.oo_at, (nd + 1) * 8, hipMemcpyDeviceToHost, c->s_cmp));
+            HT_T(ht2);
+            HT_ACC(1, ht1, ht2);
             HIP_TRY(hipStreamSynchronize(c->s_cmp));
+            HT_T(ht3);
+            HT_ACC(2, ht2, ht3);
+#ifdef SPL_HOST_TIMING
+            if (++g_htn % 256 == 0) {
+                fprintf(stderr, "[spl host timing] setup %.1f us (pinned? %.1f, lanes %.1f), submit %.1f us, sync wait %.1f us (avg of 256 calls)\n", g_ht[0] / 256, g_ht[3] / 256, g_ht[4] / 256, g_ht[1] / 256, g_ht[2] / 256);
+                for (auto& x : g_ht) x = 0;
+            }
+#endif
             r->n_tokens = r->off[nd];
             return SPL_OK;
         }
