@@ -1,38 +1,27 @@
 #!/usr/bin/env python3
-"""Per-step GPU timeline from a rocprofv3 kernel trace (rocpd SQLite): for every kernel of the
-encode sequence, its average duration and the average idle gap between the end of the previous
-dispatch and its start (steady state = the last 60% of the dispatches).  usage: rocpd_timeline.py results.db"""
+"""Dev aid: the last N kernel dispatches and memory copies of a rocprofv3 rocpd result as a timeline (us since the first of them).
+usage: rocpd_timeline.py results.db [N]"""
 import sqlite3
 import sys
-from collections import defaultdict
 
 
-def main(path):
+def main(path, n):
     db = sqlite3.connect(path)
     tabs = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
     kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
     ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
-    rows = list(db.execute(f"select s.kernel_name, d.start, d.end from {kd} d join {ks} s on d.kernel_id=s.id order by d.start"))
-    rows = rows[int(len(rows) * 0.4):]
-    dur, gap, n = defaultdict(float), defaultdict(float), defaultdict(int)
-    order = []
-    prev_end = None
-    for name, st, en in rows:
-        short = name.split("(")[0].split("<")[0].split("::")[-1]
-        if short not in order:
-            order.append(short)
-        dur[short] += en - st
-        if prev_end is not None:
-            gap[short] += st - prev_end
-        n[short] += 1
-        prev_end = max(prev_end or 0, en)
-    print(f"{'kernel':40s} {'calls':>6s} {'avg_us':>9s} {'gap_before_us':>14s}")
-    tot = 0.0
-    for k in order:
-        print(f"{k:40s} {n[k]:6d} {dur[k] / n[k] / 1e3:9.2f} {gap[k] / n[k] / 1e3:14.2f}")
-        tot += (dur[k] + gap[k]) / n[k] / 1e3
-    print(f"sum of (duration + gap) per step: {tot:.2f} us")
+    ev = [(s, e, name[:40]) for s, e, name in db.execute(f"select d.start, d.end, s.kernel_name from {kd} d join {ks} s on d.kernel_id=s.id")]
+    mc = [t for t in tabs if t.startswith("rocpd_memory_copy")]
+    if mc:
+        cols = [r[1] for r in db.execute(f"pragma table_info({mc[0]})")]
+        size = "size" if "size" in cols else cols[-1]
+        ev += [(s, e, f"copy {sz} B") for s, e, sz in db.execute(f"select start, end, {size} from {mc[0]}")]
+    ev.sort()
+    ev = ev[-n:]
+    t0 = ev[0][0]
+    for s, e, name in ev:
+        print(f"{(s - t0) / 1e3:10.1f} {(e - t0) / 1e3:10.1f}  {(e - s) / 1e3:8.1f} us  {name}")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 24)
