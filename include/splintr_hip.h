@@ -92,7 +92,7 @@ spl_tokenizer* spl_create(const void* vocab, size_t vocab_len, const void* uclas
 int spl_set_devices(spl_tokenizer* t, const int32_t* devices, uint32_t n);
 uint32_t spl_n_devices(const spl_tokenizer* t);
 
-/* Host pipeline tuning: "chunk_bytes" (upper bound of one pipeline chunk, default 16 MiB),
+/* Host pipeline tuning: "chunk_bytes" (upper bound of one pipeline chunk, default 8 MiB),
  * "single_chunk_max_bytes" (batches up to this size run as one chunk, default 4 MiB),
  * "result_estimate_div" (first guess of the token count = bytes / div; default 0.375 tokens per byte),
  * "subdoc_split" (0/1: balance the GPUs by cutting large documents at context-free boundaries),

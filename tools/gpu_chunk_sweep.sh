@@ -1,7 +1,7 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out; rm -f gpurun_out/chunk_sweep.txt
-for cb in 2097152 4194304 8388608 16777216; do
-  for c in c3 c5; do
+for cb in ${CBS:-2097152 4194304 8388608 16777216}; do
+  for c in ${CFGS:-c3 c5}; do
     timeout 300 python - "$c" "$cb" >> gpurun_out/chunk_sweep.txt 2>&1 <<'PY'
 import sys, json
 sys.path.insert(0, "tools")
