@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import test_gpu_parity as tg
-from fuzzgen import fuzz_corpus
+from fuzzgen import cased_corpus, fuzz_corpus, latin_corpus
 from oracle.coracle import COracle
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
@@ -16,9 +16,10 @@ lits = json.load(open(os.path.join(ROOT, "splintr_amd", "data", "special_tokens.
 t0 = time.time(); runs = 0; bad = 0; seed = seed0
 while time.time() - t0 < budget:
     rng = random.Random(seed)
-    name = rng.choice(tg.VOCABS); geom = rng.choice([0, 0, 1, 2, 3, 4]); special = rng.random() < 0.35
+    name = rng.choice(tg.VOCABS); geom = rng.choice([0, 0, 0, 1, 2, 3, 4, 5, 5]); special = rng.random() < 0.35
     kind = rng.random()
-    if kind < 0.4: texts = fuzz_corpus(seed, rng.randint(50, 1500), rng.choice([10, 40, 120]))
+    if kind < 0.25: texts = fuzz_corpus(seed, rng.randint(50, 1500), rng.choice([10, 40, 120]))
+    elif kind < 0.4: texts = latin_corpus(seed, rng.randint(50, 1500), rng.choice([20, 120, 600])) + cased_corpus(seed, rng.randint(50, 800), rng.choice([20, 80, 400]))
     elif kind < 0.8: texts = tg._multibyte_texts(seed, rng.randint(5, 120), rng.choice([150, 700, 3000, 12000]))
     else: texts = fuzz_corpus(seed, 300, 60) + tg._multibyte_texts(seed + 1, 60, 2000)
     if rng.random() < 0.5:                                   # runs of one character (or a short period) of any length
@@ -29,7 +30,7 @@ while time.time() - t0 < budget:
             texts[i] = t[:c] + run + t[c:]
     if rng.random() < 0.3:                                   # documents that end around tile and window edges
         for _ in range(rng.randint(1, 20)):
-            n = rng.choice([767, 768, 769, 991, 992, 993, 1535, 1536, 1537]) + rng.randint(-2, 2)
+            n = rng.choice([767, 768, 769, 799, 800, 801, 863, 864, 865, 991, 992, 993, 1535, 1536, 1537, 1599, 1600, 1601, 1727, 1728, 1729]) + rng.randint(-2, 2)
             texts.insert(rng.randrange(len(texts) + 1), ("lorem ipsum 12 " * 200)[:n])
     if special:
         ls = list(lits[name])
