@@ -1087,8 +1087,9 @@ __global__ __launch_bounds__(64) void k_deferred_wave(DeviceTables T, Batch b) {
     const int64_t B = b.n_bytes;
     for (int k = lane; k < 128; k += 64) s_ascii[k] = T.ucls_stage2[((uint32_t)T.ucls_stage1[0] << T.ucls_shift) + k];
     for (uint32_t it = blockIdx.x; it < nq; it += gridDim.x) {
-        int64_t p = b.qdefer[it];                               // wave-uniform: start of the next chunk
-        bool first_chunk = true;
+        const uint32_t pent = b.qdefer[it];
+        int64_t p = pent & 0x7FFFFFFFu;                         // wave-uniform: start of the next chunk
+        bool first_chunk = !(pent >> 31);                       // (bit 31: a chunk starts there only if it is no sync point)
         for (;;) {                                              // one window per pass
             if (p >= B) break;
             const int64_t base = p >= DEFER_BACK ? p - DEFER_BACK : 0;
@@ -2462,9 +2463,13 @@ void k_pretok(DeviceTables T, Batch b) {
                 // tokens are identified by their position) -- no marks, no second enumeration
                 if (LIST_CHUNKS) s_chunk[atomicAdd(&s_nch, 1u)] = (uint32_t)p | ((uint32_t)(e - p) << 16);
                 p = e;
-                if (p >= Wv) {                         // ended exactly on the window edge
-                    if (!LIST_CHUNKS) atomicOr(&s_cbits[Wv >> 5], 1u << (Wv & 31));
-                    if (w0 + Wv < B) push_defer((uint32_t)(w0 + Wv));
+                if (p >= Wv) {                         // ended on the window edge, or up to WPAD bytes behind it (a straddling character)
+                    // The chain goes on from p -- IF a chunk starts there: p may be a sync point, which the tile that
+                    // holds it works itself (bit 31: "check first").  (It used to go on from the window's end
+                    // whatever p was, as a certain chunk start: a chunk that ended behind the edge was then partly
+                    // worked twice, and a sync point exactly on the edge got its chunk from both tiles.)
+                    if (!LIST_CHUNKS) atomicOr(&s_cbits[p >> 5], 1u << (p & 31));
+                    if (w0 + p < B) push_defer((uint32_t)(w0 + p) | 0x80000000u);
                     break;
                 }
                 if (((s_mk[MK_SY * NBW1 + (p >> 5)] | s_mk[MK_TS * NBW1 + (p >> 5)]) >> (p & 31)) & 1u) {
@@ -2588,7 +2593,18 @@ void k_pretok(DeviceTables T, Batch b) {
             __syncthreads();
         }
         uint32_t* const stage_w0 = b.stage + w0;          // window index -> global position
+        // (A chunk may reach up to WPAD bytes beyond the window -- a character that straddles its end --, so a token
+        //  inside it may START there: tile-owned mode keeps ids only for window positions, such a token goes the way
+        //  of the tail's tokens beyond the window.  It used to be written behind s_ids and counted as a window token:
+        //  a garbage id, found by the randomized stress run, seed 22739.)
         auto put = [&](int q, uint32_t id) {
+            if (DIRECT && q >= Wv) {
+                const uint32_t g = (uint32_t)(w0 + q);
+                __hip_atomic_store(&b.stage[g], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicOr(&b.tbits[g >> 5], 1u << (g & 31));
+                atomicMax(&s_dq[4], g + 1u);
+                return;
+            }
             if (DIRECT) s_ids[q] = id;
             else stage_w0[q] = id;
             atomicOr(&s_tbits[q >> 5], 1u << (q & 31));
@@ -2831,7 +2847,7 @@ void k_pretok(DeviceTables T, Batch b) {
                     const uint32_t ndc = s_dq[1] < 2u ? s_dq[1] : 2u;
                     if (s_dq[6] >= ndc || s_dq[0] >= (uint32_t)DIRECT_LQCAP) break;
                     if (tid == 0 && s_dq[7] == 0) {
-                        const uint32_t pc = s_dq[2 + s_dq[6]];
+                        const uint32_t pent = s_dq[2 + s_dq[6]], pc = pent & 0x7FFFFFFFu;   // (bit 31: only a chunk start if no sync point)
                         uint32_t lo = 0, hi = b.n_docs;         // first text start after the chain's start
                         while (lo < hi) {
                             const uint32_t mid = lo + (hi - lo) / 2;
@@ -2839,7 +2855,7 @@ void k_pretok(DeviceTables T, Batch b) {
                         }
                         s_dq[5] = pc;
                         s_dq[8] = lo < b.n_docs ? (uint32_t)b.doc_off[lo] : b.n_bytes;
-                        s_dq[7] = 1;
+                        s_dq[7] = (pent >> 31) ? 2u : 1u;
                     }
                     __syncthreads();
                     const int64_t pc = s_dq[5];

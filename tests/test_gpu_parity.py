@@ -262,6 +262,26 @@ def test_tile_and_window_edges(coracle, name, geom):
         _force_tiles(name, 0)
 
 
+@pytest.mark.parametrize("geom", [0, 3, 4, 5])
+@pytest.mark.parametrize("name", ["cl100k_base", "o200k_base"])
+def test_chunk_that_straddles_the_window_end(coracle, name, geom):
+    """A chain that outgrows its window and ends in a multi-byte character on the window's edge: a run of numbers
+    (three to a chunk) closed by U+2167, at every alignment.  The last chunk then reaches up to two bytes beyond
+    the window -- its last token may START there --, or ends exactly on the edge, where the next chunk is a sync
+    point of the neighbouring tile.  (Found by tools/dev/gpu_stress.py, seed 22739: a token id read from behind
+    the tile's id array, a chunk worked twice.)"""
+    pad = lambda n: ("lorem ipsum " * 400)[:n]
+    _force_tiles(name, geom)
+    try:
+        for nz, head in ((130, "ⅧⅧⅧⅧ"), (130, "Ⅷ"), (200, "ⅧⅧ"), (240, "ⅧⅧⅧⅧ"), (240, "Ⅷ"), (400, "ⅧⅧⅧⅧ")):
+            run = head + "0" * nz + "ⅧⅧ"
+            assert_batch_equal(name, [pad(k) + run + " and the end" for k in range(0, 1000)], coracle)
+        assert_batch_equal(name, [pad(k) + "a" * 300 + "éé" + " x" for k in range(0, 900)], coracle)
+        assert_batch_equal(name, [pad(k) + "-" * 300 + "——" + "\nx" for k in range(0, 900)], coracle)
+    finally:
+        _force_tiles(name, 0)
+
+
 @pytest.mark.parametrize("name", VOCABS)
 def test_many_tiny_and_empty_documents(coracle, name):
     rng = random.Random(9)
