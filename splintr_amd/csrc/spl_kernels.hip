@@ -2848,10 +2848,10 @@ void k_pretok(DeviceTables T, Batch b) {
                     if (s_dq[6] >= ndc || s_dq[0] >= (uint32_t)DIRECT_LQCAP) break;
                     if (tid == 0 && s_dq[7] == 0) {
                         const uint32_t pent = s_dq[2 + s_dq[6]], pc = pent & 0x7FFFFFFFu;   // (bit 31: only a chunk start if no sync point)
-                        uint32_t lo = 0, hi = b.n_docs;         // first text start after the chain's start
-                        while (lo < hi) {
+                        uint32_t lo = 0, hi = b.n_docs;         // first text start after the chain's start -- or AT it, if whether
+                        while (lo < hi) {                        // a chunk of this chain starts there is still to be seen
                             const uint32_t mid = lo + (hi - lo) / 2;
-                            if (b.doc_off[mid] <= (uint64_t)pc) lo = mid + 1; else hi = mid;
+                            if (b.doc_off[mid] + (uint64_t)(pent >> 31) <= (uint64_t)pc) lo = mid + 1; else hi = mid;
                         }
                         s_dq[5] = pc;
                         s_dq[8] = lo < b.n_docs ? (uint32_t)b.doc_off[lo] : b.n_bytes;

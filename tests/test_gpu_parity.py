@@ -282,6 +282,21 @@ def test_chunk_that_straddles_the_window_end(coracle, name, geom):
         _force_tiles(name, 0)
 
 
+@pytest.mark.parametrize("geom", [0, 5])
+@pytest.mark.parametrize("name", ["cl100k_base", "o200k_base", "mistral_v3"])
+def test_text_that_ends_just_behind_the_window_end(coracle, name, geom):
+    """The chain's last chunk straddles the window's end and the TEXT ends with it, so that the position the chain
+    is continued from is the next text's start: nothing of this chain is left there.  (Found by
+    tools/dev/gpu_edge_sweep.py: the next text's first tokens came out twice.)"""
+    pad = lambda n: ("lorem ipsum " * 400)[:n]
+    _force_tiles(name, geom)
+    try:
+        for run in ("x'" * 100 + "'ſ'ſ", "'x" * 120 + "'’s'ſ", "0" * 130 + "ⅧⅧ", "a" * 300 + "éé", "-" * 260 + "——"):
+            assert_batch_equal(name, [pad(k) + run for k in range(0, 1000)], coracle)
+    finally:
+        _force_tiles(name, 0)
+
+
 @pytest.mark.parametrize("name", VOCABS)
 def test_many_tiny_and_empty_documents(coracle, name):
     rng = random.Random(9)
