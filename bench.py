@@ -10,6 +10,8 @@ holds its own eight 1000-document shards (weak scaling) and the step also all-ga
 ids over RCCL so that every rank ends up with the whole CSR result of every batch.
 
     python bench.py --gpus 1 --steps 500 --warmup 50
+    python bench.py --gpus N ...          (no WORLD_SIZE in the environment: re-executes itself under
+                                           torch.distributed.run, one rank per GPU, and relays rank 0's line)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -18,6 +20,8 @@ Prints ONE JSON line on rank 0.  Beside the contract's keys it carries
   roofline_valu  the binding one: VALU issue (counters from the committed rocprofv3 pass it names)
   throughputs    SURVEY 8d's three figures for C2 and C3: kernels only / C ABI host->host / Python surface
   c4_strong      BASELINE config 4 (llama3, 1 M short prompts) doc-sharded over the N ranks (strong scaling)
+  c5_strong      BASELINE config 5 (deepseek_v3, 100 x 2 MiB documents) byte-sharded over the N ranks, documents
+                 cut at context-free boundaries where a shard boundary falls inside one (encode_rayon's case)
   cpu_baseline   the oracle's C port of the reference's Rayon path on this box's host cores
 The oracle (oracle/) is used only as the checker of the untimed verification passes and as the timed
 CPU baseline ("port"); it is never on the measured path.
@@ -43,9 +47,54 @@ C4_PARTS = 8            # the C4 batch is generated as 8 x 125 000 prompts (seed
 C4_PART_DOCS = 125_000
 
 
+C5_DOCS = 100           # BASELINE config 5: 100 documents of 2 MiB (seed 1005 + document index)
+
+
 def _c4_part(k):
     from splintr_amd import corpus
     return corpus.c4(C4_PART_DOCS, seed=1004 + k)
+
+
+def _c5_doc(k):
+    from splintr_amd import corpus
+    return corpus.c5(1, seed=1005 + k)[0]
+
+
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: this process becomes the launcher --
+    it re-executes bench.py under torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1) and relays
+    the ranks' output; rank 0 prints the one JSON line."""
+    import subprocess
+    if not args.launch_selftest:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus} needs {args.gpus} GPUs, this box has {have}")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+def launch_selftest(rank, world):
+    """CPU-side check of the launcher (tests/test_bench_launcher.py): the ranks rendezvous on gloo, agree on
+    the world size and rank 0 prints one JSON line -- everything self_launch() sets up, without a GPU."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([rank + 1], dtype=torch.int64)
+    dist.all_reduce(t)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"launcher": "ok", "n_gpus": world, "rank_sum": int(t.item())}), flush=True)
 
 
 def _packed(texts):
@@ -69,20 +118,27 @@ def main():
     ap.add_argument("--no-throughputs", action="store_true", help="skip the C-ABI / Python-surface figures (C2, C3)")
     ap.add_argument("--no-c4", action="store_true", help="skip the doc-sharded 1 M-prompt run (BASELINE config 4)")
     ap.add_argument("--c4-steps", type=int, default=5)
+    ap.add_argument("--no-c5", action="store_true", help="skip the 100 x 2 MiB run (BASELINE config 5)")
+    ap.add_argument("--c5-steps", type=int, default=5)
+    ap.add_argument("--launch-selftest", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args, sys.argv[1:]))
+    if args.launch_selftest:
+        return launch_selftest(rank, world)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
         args.gpus = world
     # the C4 prompts are generated by forked workers BEFORE anything initialises the GPU or RCCL: a fork of a
     # process that already runs HIP / RCCL threads is not something to rely on
-    c4_texts = None
+    c4_texts = c5_pieces = None
     if not args.no_c4:
         c4_texts = gen_c4_texts(rank, world)
+    if not args.no_c5:
+        c5_pieces = gen_c5_pieces(rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     torch.cuda.set_device(local_rank)
@@ -289,35 +345,50 @@ def main():
                                "python_surface: Tokenizer.encode_batch(list[str]) -> list[list[int]]")
 
     # ---- BASELINE config 4: llama3, 1 M short prompts, doc-sharded over the ranks (strong scaling) -------
-    c4 = None
+    c4 = c5 = None
     if not args.no_c4:
         c4 = run_c4(args, rank, world, local_rank, dev, use_dist, c4_texts)
+        del c4_texts
+    if not args.no_c5:
+        c5 = run_c5(args, rank, world, local_rank, dev, use_dist, c5_pieces)
+        del c5_pieces
 
     # ---- CPU baseline: the oracle (a port of the reference's Rayon path) on the host cores ---------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # sweep the thread count and the LRU-style memo, keep the best: the GPU is compared with the
-        # strongest configuration of the port on this host, not with an arbitrary one
-        best = None
-        text_np, _ = _packed(text_sets[0])
-        cands = sorted({t for t in (16, 32, 64, ncpu) if t <= ncpu} | {min(8, ncpu)})
+        # The whole rotation as ONE call (8 x 1000 documents, ~8 MB: a call of ~20 ms instead of 2.5 ms, so the
+        # pool's wake-up is not what is measured), a FIXED number of repetitions per configuration, the MEDIAN.
+        # Thread counts 8 .. all host CPUs x memo on/off; `value` = the best median (the GPU is compared with the
+        # strongest configuration of the port on this host), the 24-thread figure SURVEY 8d asks for beside it.
+        all_texts = [t for ts in text_sets for t in ts]
+        text_np, off_np = _packed(all_texts)
+        nb_cpu = int(off_np[-1])
+        cands = sorted({t for t in (8, 16, 24, 32, 64, ncpu) if t <= ncpu})
+        REPS = 15
+        table = {}
         for memo in (False, True):
             orc_t = COracle("cl100k_base", memo=memo)
             for th in cands:
-                orc_t.encode_packed(text_np, batches[0].host_offsets, threads=th)
-                reps, c0 = 0, time.perf_counter()
-                while time.perf_counter() - c0 < 1.2 or reps < 3:
-                    orc_t.encode_packed(text_np, batches[0].host_offsets, threads=th)
-                    reps += 1
-                rate = batches[0].n_bytes * reps / (time.perf_counter() - c0) / 1e6
-                if best is None or rate > best[0]:
-                    best = (rate, th, memo, reps)
-        cpu = {"value": round(best[0], 2), "unit": "MB/s", "cores": best[1], "kind": "port",
-               "host_cpus": ncpu,
-               "sample": f"the first batch of the rotation ({batches[0].n_docs} docs, {batches[0].n_bytes} B) x {best[3]} repetitions; "
-                         f"best of threads in {cands} x memo on/off (best: {best[1]} threads, "
-                         f"{'with' if best[2] else 'without'} the mutex-guarded 4096-entry memo that stands in for the "
-                         f"reference's LRU); persistent pool pulling documents off a shared counter, CSR in/out"}
+                for _ in range(3):
+                    orc_t.encode_packed(text_np, off_np, threads=th)
+                ts_ = []
+                for _ in range(REPS):
+                    c0 = time.perf_counter()
+                    orc_t.encode_packed(text_np, off_np, threads=th)
+                    ts_.append(time.perf_counter() - c0)
+                ts_.sort()
+                table[(th, memo)] = (nb_cpu / ts_[REPS // 2] / 1e6, nb_cpu / ts_[-1] / 1e6, nb_cpu / ts_[0] / 1e6)
+        (bth, bmemo), bv = max(table.items(), key=lambda kv: kv[1][0])
+        t24 = max((table[(24, m)][0] for m in (False, True) if (24, m) in table), default=None)
+        cpu = {"value": round(bv[0], 2), "unit": "MB/s", "cores": bth, "kind": "port", "host_cpus": ncpu,
+               "spread": [round(bv[1], 2), round(bv[2], 2)],
+               "threads_24": round(t24, 2) if t24 is not None else None,
+               "all_medians": {f"{th}t{'+memo' if m else ''}": round(v[0], 1) for (th, m), v in sorted(table.items())},
+               "sample": f"the {N_ROT} batches of the rotation as ONE call ({len(all_texts)} docs, {nb_cpu} B), 3 warm-ups + {REPS} timed "
+                         f"repetitions per configuration, MEDIAN (spread = slowest / fastest repetition of the best configuration); "
+                         f"threads in {cands} x memo on/off -- best: {bth} threads "
+                         f"{'with' if bmemo else 'without'} the mutex-guarded 4096-entry memo that stands in for the "
+                         f"reference's LRU; persistent pool pulling documents off a shared counter, CSR in/out"}
 
     out = None
     if rank == 0:
@@ -327,13 +398,14 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": f"cl100k_base, {args.docs} x ~1 KB mixed English/code per batch and GPU, {N_ROT} distinct batches in rotation "
-                                   f"(splintr_amd.corpus.c2, seeds 1002 + 100 rank + k), HBM-resident, CSR out"
+                                   f"(splintr_amd.corpus.c2, seeds 1002 + 100 rank + k); KERNEL-ONLY: corpus HBM-resident, CSR left in HBM "
+                                   f"(the host->host and Python-surface rates of the same batch are in `throughputs`)"
                                    + ("; + RCCL all-gatherv of the ragged ids (slab written by the encoder's last kernel, ONE all-gather per bucket of 8 batches on its own stream, overlapped with the following encodes; every rank gets every batch's global CSR, handed to the consumer per bucket)" if use_dist else ""),
                        "vocab": "cl100k_base", "docs_per_batch": args.docs, "bytes_per_batch": round(bytes_rot / N_ROT),
                        "tokens_per_batch": round(sum(n_tokens) / N_ROT), "distinct_batches": N_ROT,
                        "parallelism": f"doc-shard x{world}"},
             "parity": "bit-exact vs oracle (untimed verification pass over every batch of the rotation)",
-            "roofline": roofline, "roofline_valu": roofline_valu, "throughputs": throughputs, "c4_strong": c4,
+            "roofline": roofline, "roofline_valu": roofline_valu, "throughputs": throughputs, "c4_strong": c4, "c5_strong": c5,
             "cpu_baseline": cpu, "pipelined": pipelined,
         }
     if use_dist:
@@ -359,29 +431,81 @@ def gen_c4_texts(rank, world):
         return [t for part in pool.map(_c4_part, parts) for t in part]
 
 
+def _c5_cut(doc_bytes, frac_num, frac_den):
+    """Byte offset of the shard boundary inside a document: the first position at or behind the proportional
+    target that follows a newline and holds an ASCII letter or digit -- a context-free match boundary of every
+    supported split pattern (splintr_amd.distributed.plan_shards, spl_api.hip encode_host use the same rule)."""
+    i = len(doc_bytes) * frac_num // frac_den
+    while True:
+        j = doc_bytes.find(b"\n", max(i - 1, 0))
+        if j < 0 or j + 1 >= len(doc_bytes):
+            return len(doc_bytes)
+        c = doc_bytes[j + 1]
+        if (48 <= c <= 57) or (65 <= c <= 90) or (97 <= c <= 122):
+            return j + 1
+        i = j + 2
+
+
+def gen_c5_pieces(rank, world):
+    """This rank's share of BASELINE config 5 (deepseek_v3, 100 documents of 2 MiB, seeds 1005 + d): the byte range
+    [100 r / W, 100 (r + 1) / W) in units of documents; where a boundary falls inside a document (W = 8: 12.5
+    documents per rank) the document is cut at a context-free boundary, so the ids of the two pieces concatenate
+    to the ids of the document (the intra-document parallelism encode_rayon stands for,
+    src/core/tokenizer.rs:815-837).  Both neighbours generate the shared document and find the same cut."""
+    from multiprocessing import Pool
+    lo_n, hi_n = C5_DOCS * rank, C5_DOCS * (rank + 1)           # numerators over `world`
+    d_lo, d_hi = lo_n // world, (hi_n + world - 1) // world     # documents this rank touches
+    with Pool(min(d_hi - d_lo, max(1, (os.cpu_count() or 1) // max(world, 1)))) as pool:
+        docs = pool.map(_c5_doc, range(d_lo, d_hi))
+    pieces = []
+    for d, text in zip(range(d_lo, d_hi), docs):
+        raw = text.encode("utf-8")
+        a = _c5_cut(raw, lo_n - d * world, world) if (d == d_lo and lo_n % world) else 0
+        e = _c5_cut(raw, hi_n - d * world, world) if (d == d_hi - 1 and hi_n % world) else len(raw)
+        if e > a:
+            pieces.append(raw[a:e].decode("utf-8"))             # (cuts sit in front of ASCII bytes)
+    return pieces
+
+
 def run_c4(args, rank, world, local_rank, dev, use_dist, texts):
     """BASELINE config 4 as stated: llama3, 1 000 000 short chat prompts (8 x 125 000, seeds 1004..1011),
     ONE global batch doc-sharded over the ranks (strong scaling: rank r of W encodes parts
     [8 r / W, 8 (r + 1) / W)), HBM-resident; with W > 1 the ragged ids are all-gathered over RCCL
     inside the timed step.  Returns the sub-object for the JSON line (rank 0), None elsewhere."""
+    return run_strong("llama3", texts, args.c4_steps, rank, world, local_rank, dev, use_dist, 20000,
+                      "llama3, {docs} short chat prompts ({bytes} B, {tokens} tokens) as ONE batch doc-sharded over {world} GPU(s), HBM-resident",
+                      "bit-exact vs oracle on the first and last 20 000 prompts of every rank's shard")
+
+
+def run_c5(args, rank, world, local_rank, dev, use_dist, pieces):
+    """BASELINE config 5 as stated: deepseek_v3, 100 documents of 2 MiB as ONE batch byte-sharded over the ranks,
+    documents cut at context-free boundaries (gen_c5_pieces), HBM-resident; with W > 1 the ragged ids are
+    all-gathered over RCCL inside the timed step."""
+    return run_strong("deepseek_v3", pieces, args.c5_steps, rank, world, local_rank, dev, use_dist, 1,
+                      "deepseek_v3, 100 x 2 MiB documents as {docs} piece(s) ({bytes} B, {tokens} tokens): ONE batch byte-sharded over {world} GPU(s), "
+                      "cut inside a document at a newline + ASCII letter/digit where a shard boundary falls there, HBM-resident",
+                      "bit-exact vs oracle on the first and last piece of every rank's shard")
+
+
+def run_strong(vocab, texts, steps, rank, world, local_rank, dev, use_dist, nchk, workload, parity):
     from splintr_amd import Tokenizer
     from splintr_amd.device import DeviceBatch, GatherV, encode_device, reserve, result_csr
     from oracle.coracle import COracle
-    tok = Tokenizer.from_pretrained("llama3", device=local_rank)
+    tok = Tokenizer.from_pretrained(vocab, device=local_rank)
     batch = DeviceBatch(texts, dev)
     reserve(tok, batch.n_bytes, batch.n_docs)
     encode_device(tok, batch)
     torch.cuda.synchronize()
     ids, off = result_csr(batch)
-    # parity on a bounded sample (the oracle needs seconds per 100 MB): the first and last 20 000 prompts
-    orc = COracle("llama3")
-    nchk = min(20000, len(texts))
+    # parity on a bounded sample (the oracle needs seconds per 100 MB): the first and last `nchk` documents
+    orc = COracle(vocab)
+    nchk = min(nchk, len(texts))
     for sl in ((slice(0, nchk), slice(len(texts) - nchk, len(texts))) if nchk else ()):
         t_np, t_off = _packed(texts[sl])
         o_ids, o_off = orc.encode_packed(t_np, t_off, threads=os.cpu_count() or 1)
         a, b_ = int(off[sl.start]), int(off[sl.stop])
         if not (np.array_equal(ids[a:b_], o_ids) and np.array_equal(off[sl.start:sl.stop + 1] - off[sl.start], o_off)):
-            raise SystemExit(f"rank {rank}: C4 result differs from the oracle")
+            raise SystemExit(f"rank {rank}: {vocab} strong-scaling result differs from the oracle")
     n_tok = int(off[-1])
     gv = None
     if use_dist:
@@ -402,7 +526,7 @@ def run_c4(args, rank, world, local_rank, dev, use_dist, texts):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.c4_steps):
+    for _ in range(steps):
         step()
     if gv is not None:
         gv.finish()
@@ -419,14 +543,14 @@ def run_c4(args, rank, world, local_rank, dev, use_dist, texts):
         dist.all_reduce(s)
         tot_b, tot_d, tot_t = (int(x) for x in s.tolist())
         assert not gv.overflowed()
-    del batch, tok
+    del batch, tok, gv
+    torch.cuda.empty_cache()
     if rank != 0:
         return None
-    return {"workload": f"llama3, {tot_d} short chat prompts ({tot_b} B, {tot_t} tokens) as ONE batch doc-sharded over {world} GPU(s), HBM-resident"
+    return {"workload": workload.format(docs=tot_d, bytes=tot_b, tokens=tot_t, world=world)
                         + ("; RCCL all-gatherv of the ragged ids inside the step" if use_dist else ""),
-            "value": round(tot_b * args.c4_steps / el / 1e6, 1), "unit": "MB/s", "ms_per_step": round(el / args.c4_steps * 1e3, 3),
-            "steps": args.c4_steps, "scaling": "strong",
-            "parity": "bit-exact vs oracle on the first and last 20 000 prompts of every rank's shard"}
+            "value": round(tot_b * steps / el / 1e6, 1), "unit": "MB/s", "ms_per_step": round(el / steps * 1e3, 3),
+            "steps": steps, "scaling": "strong", "parity": parity}
 
 
 if __name__ == "__main__":

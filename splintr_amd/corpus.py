@@ -6,6 +6,8 @@ play (PCRE2/Unicode 14, Python `regex`, the class table) agrees on all of them.
 
     c1(n)  cl100k   English prose, ~1 KB docs                    seed 1001
     c2(n)  cl100k   50 % prose / 50 % code, ~1 KB docs           seed 1002   (the bench workload)
+    c2_wide(n)      the same mix over a WIDE lexicon: >= 20 000 distinct words from a syllable grammar,
+                    Zipf-distributed (natural 1 MB English/code has ~10x the distinct words of c2)  seed 2002
     c3(n)  o200k    40 % prose / 30 % JSON / 30 % CJK, ~4 KB     seed 1003
     c4(n)  llama3   short chat prompts, 64-512 B log-uniform     seed 1004
     c5(n)  deepseek long documents (default 2 MiB) of mixed paragraphs   seed 1005
@@ -46,6 +48,140 @@ _FW_PUNCT = "，。！？；：「」（）、"
 _EMOJI = ["\U0001f600", "\U0001f30d", "\U0001f680", "❤️", "\U0001f468‍\U0001f469‍\U0001f467", "\U0001f44d\U0001f3fd"]
 
 
+# ---- wide lexicon (c2_wide): words from a syllable grammar, rank-frequency ~ 1 / rank -----------------
+_ONSETS = ("b c d f g h j k l m n p r s t v w y z bl br ch cl cr dr fl fr gl gr pl pr qu sc sh sk sl sm sn sp st "
+           "str sw th tr tw wh wr").split() + [""]
+_VOWELS = "a e i o u ai au ea ee ie io oa oo ou ue y".split()
+_CODAS = ("b d f g k l m n p r s t x ck ct ft ld lf lk ll lm lp lt mp nd ng nk nt pt rd rk rm rn rt sk sp ss st "
+          "th").split() + ["", "", "", ""]
+_STEMS = ("act add age air allow answer appear apply arm art ask back ball bank base bear beat bed begin believe bill "
+          "bit black blood blue board boat body book born box boy break bring brother build burn business buy call camp "
+          "car card care carry case catch cause cell center chance change charge check child choose church circle city "
+          "claim class clean clear close cloud coast cold color common company compare complete condition connect consider "
+          "contain control cook copy corner cost count country course cover create cross crowd cry cut dance dark data "
+          "deal decide deep design detail develop differ direct discover divide doctor door double draw dream dress drink "
+          "drive drop dry early earth ease east eat edge effect eight electric end enemy energy engine enter equal even "
+          "event ever exact example except excite exercise expect experience explain express face fact fair fall family "
+          "farm fast father fear feed feel field fight figure fill final find fine finger finish fire fish fit five flat "
+          "floor flow flower fly follow food foot force forest form forward found four free fresh friend front fruit full "
+          "game garden gather general gentle girl give glass gold govern grand grass gray green ground group grow guess "
+          "guide hair half hand happen hard hat head hear heart heat heavy help high hill history hit hold hole home hope "
+          "horse hot hour house human hundred hunt hurry ice idea include industry inform insect interest iron island join "
+          "joy jump keep key kill kind king knew land language large late laugh law lay lead learn leave left leg length "
+          "level lie lift light line list listen live locate lock log lone look lost loud love low machine magnet main "
+          "major map mark market mass master match material matter mean measure meat meet melody metal method middle milk "
+          "million mind mine minute miss mix modern moment money month moon morning mother motion mount mouth move music "
+          "name nation nature near need neighbor new night nine noise noon north nose note nothing notice noun number "
+          "object observe ocean offer office oil open operate opposite order organ original paint paper paragraph parent "
+          "part party pass past path pattern pay people perhaps person phrase pick picture piece place plain plan plane "
+          "plant play please plural poem point poor populate port pose position possible post pound power practice prepare "
+          "present press pretty print probable problem process produce product proper protect prove provide pull push "
+          "quart question quick quiet quite race radio rail rain raise range rather reach read ready real reason receive "
+          "record red region remember repeat reply represent require rest result rich ride ring rise river road rock roll "
+          "room root rope rose round row rule run safe sail salt sand save scale school science score sea search season "
+          "seat second section seed seem segment select self sell send sense sentence separate serve set settle seven "
+          "shape share sharp shell shine ship shoe shop shore short shoulder shout show side sight sign silent silver "
+          "similar simple sing single sister sit size skill skin sky sleep slip slow small smell smile snow soft soil "
+          "soldier solution solve son song soon sound south space speak special speech speed spell spend spoke spot spread "
+          "spring square stand star start station stay stead steam steel step stick stone stood stop store story straight "
+          "strange stream street stretch string strong student study subject substance subtract success sudden suffix sugar "
+          "suggest suit summer sun supply support sure surface surprise swim syllable symbol system table tail talk tall "
+          "teach team teeth tell temperature term test thank thick thin thing think third thought thousand thus tie time "
+          "tiny tire together tone tool top total touch toward town track trade train travel tree triangle trip trouble "
+          "truck true try tube turn twenty type unit until usual valley value vary verb view village visit voice vowel "
+          "wait walk wall want war warm wash watch water wave wear weather week weight west wheel white whole wide wife "
+          "wild win wind window wing winter wire wish woman wonder wood word write wrong yard yellow young").split()
+_PREFIXES = "un re pre dis over under inter mis non out sub super anti co de en fore mid semi trans up".split()
+_SUFFIXES = ("s ed ing er ers ly ness ment ments tion tions able ful less ist ists ism ize ized ity al ic ous ive "
+             "ship hood ward wise like").split()
+_WIDE_N = 32768
+
+
+class _Lexicon:
+    """_WIDE_N distinct words, drawn with probability ~ 1 / (rank + 2.7) (Zipf-Mandelbrot): the head is real
+    English (the c2 word list, then common stems), the body is derived forms and compounds of those stems
+    (prefix + stem + suffix: words a BPE vocabulary covers in two or three tokens, as it does natural derived
+    words), the tail pseudo-words from a syllable grammar (names, jargon)."""
+
+    def __init__(self, seed: int = 20020):
+        import bisect
+        rng = random.Random(seed)
+        seen, words = set(), []
+
+        def add(w):
+            if len(w) >= 2 and w not in seen:
+                seen.add(w)
+                words.append(w)
+        for w in _COMMON:
+            add(w)
+        stems = list(_STEMS)
+        rng.shuffle(stems)
+        for w in stems:
+            add(w)
+        while len(words) < _WIDE_N:
+            r = rng.random()
+            if r < 0.55:                               # derived form
+                w = rng.choice(_STEMS)
+                if rng.random() < 0.35:
+                    w = rng.choice(_PREFIXES) + w
+                if rng.random() < 0.8:
+                    sfx = rng.choice(_SUFFIXES)
+                    if w.endswith("e") and sfx[0] in "aeiou":
+                        w = w[:-1]
+                    w += sfx
+            elif r < 0.8:                              # compound
+                w = rng.choice(_STEMS) + rng.choice(_STEMS)
+            else:                                      # pseudo-word
+                nsyl = 1 + min(int(rng.paretovariate(1.6)) - 1, 2)
+                w = "".join(rng.choice(_ONSETS) + rng.choice(_VOWELS) + rng.choice(_CODAS) for _ in range(nsyl))
+            add(w)
+        self.words = words
+        acc, cum = 0.0, []
+        for r in range(len(words)):
+            acc += 1.0 / (r + 2.7)
+            cum.append(acc)
+        self.cum, self.total, self._bisect = cum, acc, bisect.bisect_left
+
+    def draw(self, rng: random.Random) -> str:
+        return self.words[min(self._bisect(self.cum, rng.random() * self.total), len(self.words) - 1)]
+
+
+_LEX = None
+
+
+def _lexicon() -> "_Lexicon":
+    global _LEX
+    if _LEX is None:
+        _LEX = _Lexicon()
+    return _LEX
+
+
+def _word_wide(rng: random.Random) -> str:
+    r = rng.random()
+    if r < 0.92:
+        return _lexicon().draw(rng)
+    if r < 0.96:
+        return rng.choice(_CONTR)
+    if r < 0.98:
+        return str(rng.randint(0, 10 ** rng.randint(1, 7)))
+    return _lexicon().draw(rng).capitalize()
+
+
+def _ident_wide(rng: random.Random) -> str:
+    """identifiers composed from lexicon words: snake_case, camelCase, PascalCase, plain"""
+    lex = _lexicon()
+    k = 1 + min(int(rng.paretovariate(1.3)) - 1, 3)
+    parts = [lex.draw(rng) for _ in range(k)]
+    r = rng.random()
+    if r < 0.4:
+        return "_".join(parts)
+    if r < 0.75:
+        return parts[0] + "".join(p.capitalize() for p in parts[1:])
+    if r < 0.9:
+        return "".join(p.capitalize() for p in parts)
+    return parts[0]
+
+
 def _word(rng: random.Random) -> str:
     r = rng.random()
     if r < 0.80:
@@ -60,12 +196,13 @@ def _word(rng: random.Random) -> str:
     return rng.choice(_COMMON).capitalize()
 
 
-def prose(rng: random.Random, nbytes: int) -> str:
+def prose(rng: random.Random, nbytes: int, word=None) -> str:
+    word = word or _word
     out: List[str] = []
     size = 0
     cap = True
     while size < nbytes:
-        w = _word(rng)
+        w = word(rng)
         if cap:
             w = w[:1].upper() + w[1:]
             cap = False
@@ -79,26 +216,29 @@ def prose(rng: random.Random, nbytes: int) -> str:
     return "".join(out)
 
 
-def code(rng: random.Random, nbytes: int) -> str:
+def code(rng: random.Random, nbytes: int, ident=None, word=None) -> str:
     out: List[str] = []
     size = 0
     indent = 0
     style = rng.choice(["py", "c", "json"])
     while size < nbytes:
         ind = ("\t" * indent) if rng.random() < 0.2 else ("    " * indent)
-        a, b, c = rng.choice(_IDENT), rng.choice(_IDENT), rng.choice(_IDENT)
+        if ident is None:
+            a, b, c = rng.choice(_IDENT), rng.choice(_IDENT), rng.choice(_IDENT)
+        else:
+            a, b, c = ident(rng), ident(rng), ident(rng)
         k = rng.random()
         if style == "py":
             if k < 0.2:
                 line = f"{ind}def {a}({b}, {c}=None):"
                 indent = min(indent + 1, 4)
             elif k < 0.4:
-                line = f"{ind}{a} = {b}[{rng.randint(0, 4096)}] + {c}.{rng.choice(_IDENT)}({rng.random():.4f})"
+                line = f"{ind}{a} = {b}[{rng.randint(0, 4096)}] + {c}.{(ident(rng) if ident else rng.choice(_IDENT))}({rng.random():.4f})"
             elif k < 0.55:
                 line = f"{ind}{rng.choice(_KEYW)} {a} {rng.choice(['==', '!=', '<=', 'in', 'is not'])} {b}:"
                 indent = min(indent + 1, 4)
             elif k < 0.7:
-                line = f"{ind}return {a} if {b} else '{c}_{rng.randint(0, 99)}'  # {prose(rng, 20).strip()}"
+                line = f"{ind}return {a} if {b} else '{c}_{rng.randint(0, 99)}'  # {prose(rng, 20, word).strip()}"
                 indent = max(indent - 1, 0)
             elif k < 0.8:
                 line = f'{ind}print(f"{{{a}}}: {{{b}:>8.3f}}\\n")'
@@ -118,7 +258,7 @@ def code(rng: random.Random, nbytes: int) -> str:
                 line = f"{ind}}}"
                 indent = max(indent - 1, 0)
             else:
-                line = f"{ind}/* {prose(rng, 30).strip()} */"
+                line = f"{ind}/* {prose(rng, 30, word).strip()} */"
         else:
             if k < 0.5:
                 line = f'{ind}"{a}": {rng.choice([str(rng.randint(-999, 99999)), f"{rng.random() * 1000:.3f}", "true", "null", chr(34) + b + chr(34)])},'
@@ -194,6 +334,18 @@ def c2(n: int = 1000, seed: int = 1002) -> List[str]:
     for i in range(n):
         size = rng.randint(900, 1100)
         docs.append(_trim(prose(rng, size + 100) if i % 2 == 0 else code(rng, size + 100), size))
+    return docs
+
+
+def c2_wide(n: int = 1000, seed: int = 2002) -> List[str]:
+    """C2's mix (50 % prose / 50 % code, ~1 KB documents) over the wide lexicon: the whole-chunk hit rate, the
+    misses per tile and the table traffic of natural text instead of a 2 k-word vocabulary's."""
+    rng = random.Random(seed)
+    docs = []
+    for i in range(n):
+        size = rng.randint(900, 1100)
+        docs.append(_trim(prose(rng, size + 100, _word_wide) if i % 2 == 0
+                          else code(rng, size + 100, _ident_wide, _word_wide), size))
     return docs
 
 

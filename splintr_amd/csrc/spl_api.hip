@@ -12,6 +12,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/splintr_hip.h"
@@ -112,6 +113,27 @@ struct Pinned {
     ~Pinned() { release(); }
 };
 
+// Pinned buffers handed to the caller as plain pointers (spl_decode_batch's outputs): spl_free finds the pool
+// they go back to here; a pointer it does not know is malloc'd memory.
+struct LooseBuffers {
+    std::mutex mu;
+    std::unordered_map<void*, std::pair<std::shared_ptr<PinnedPool>, size_t>> m;
+    void add(void* p, const std::shared_ptr<PinnedPool>& pool, size_t cap) { std::lock_guard<std::mutex> g(mu); m[p] = {pool, cap}; }
+    bool release(void* p) {
+        std::pair<std::shared_ptr<PinnedPool>, size_t> e;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            auto it = m.find(p);
+            if (it == m.end()) return false;
+            e = it->second;
+            m.erase(it);
+        }
+        e.first->put(p, e.second);
+        return true;
+    }
+};
+LooseBuffers& loose() { static LooseBuffers* l = new LooseBuffers(); return *l; }   // (never destroyed: results may outlive every handle)
+
 constexpr int NSLOT = 3;                      // staging slots of the host pipeline per GPU
 
 // SPL_TRACE=1: progress of the host pipeline on stderr (development aid)
@@ -135,6 +157,7 @@ struct Ctx {
     const uint32_t* d_tok_off = nullptr;       // decode table (vocabulary + specials), rebuilt after spl_add_special
     const uint8_t* d_tok_bytes = nullptr;
     uint32_t dec_max_id = 0;
+    const uint32_t* d_dec_sp_ids = nullptr; const uint32_t* d_dec_sp_off = nullptr; uint32_t dec_n_sp = 0;   // specials beyond the vocabulary's ids
     bool dec_uploaded = false;
     uint8_t* d_sp_lits = nullptr;              // uploaded lazily; invalidated by spl_add_special
     bool sp_uploaded = false;
@@ -207,6 +230,7 @@ struct Ctx {
         hipFree((void*)dt.long_tab); hipFree((void*)dt.key_blob); hipFree((void*)dt.pair_tab);
         hipFree((void*)dt.byte_id); hipFree((void*)dt.p8_tab); hipFree((void*)dt.len_mask);
         hipFree((void*)d_tok_off); hipFree((void*)d_tok_bytes); hipFree(d_sp_lits);
+        hipFree((void*)d_dec_sp_ids); hipFree((void*)d_dec_sp_off);
         hipFree(d_ids); hipFree(d_oo);
         hipFree(d_dec_ids); hipFree(d_dec_blk); hipFree(d_dec_idoff); hipFree(d_dec_out); hipFree(d_dec_first); hipFree(d_dec_docoff);
         if (ev_ready) for (auto& e : ev) (void)hipEventDestroy(e);
@@ -370,25 +394,46 @@ int upload_specials(spl_tokenizer* tk, Ctx* t) {
 // (Tokenizer::decode_bytes, src/core/tokenizer.rs:877-897).
 int upload_decode(spl_tokenizer* tk, Ctx* t) {
     if (t->dec_uploaded) return SPL_OK;
-    const uint32_t max_id = std::max(tk->ht.max_id, tk->max_special_id);
-    std::vector<const std::string*> sp(max_id + 1, nullptr);
-    for (const auto& s : tk->specials) sp[s.id] = &s.lit;     // (two literals with one id: the later one, as a map insert)
+    // dense id -> bytes table over the VOCABULARY's id range (special tokens fill the ids it lacks there);
+    // special tokens beyond it go into a small sorted side table
+    const uint32_t max_id = tk->ht.max_id;
+    std::vector<const Special*> sp(max_id + 1, nullptr);
+    std::vector<const Special*> far;
+    for (const auto& s : tk->specials) {                      // (two literals with one id: the later one, as a map insert)
+        if (s.id <= max_id) sp[s.id] = &s;
+        else {
+            bool seen = false;
+            for (auto& f : far) if (f->id == s.id) { f = &s; seen = true; }
+            if (!seen) far.push_back(&s);
+        }
+    }
+    std::sort(far.begin(), far.end(), [](const Special* a, const Special* b) { return a->id < b->id; });
     std::vector<uint32_t> off(max_id + 2, 0);
     std::vector<uint8_t> bytes;
     bytes.reserve(tk->ht.tok_bytes.size() + 4096);
     for (uint32_t id = 0; id <= max_id; id++) {
         off[id] = (uint32_t)bytes.size();
-        const bool in_vocab = id <= tk->ht.max_id && tk->ht.tok_present[id];
+        const bool in_vocab = tk->ht.tok_present[id];
         if (in_vocab) bytes.insert(bytes.end(), tk->ht.tok_bytes.begin() + tk->ht.tok_off[id], tk->ht.tok_bytes.begin() + tk->ht.tok_off[id + 1]);
-        else if (sp[id]) bytes.insert(bytes.end(), sp[id]->begin(), sp[id]->end());
+        else if (sp[id]) bytes.insert(bytes.end(), sp[id]->lit.begin(), sp[id]->lit.end());
     }
     off[max_id + 1] = (uint32_t)bytes.size();
+    std::vector<uint32_t> sp_ids, sp_off;
+    for (const Special* f : far) {
+        sp_ids.push_back(f->id);
+        sp_off.push_back((uint32_t)bytes.size());
+        bytes.insert(bytes.end(), f->lit.begin(), f->lit.end());
+    }
+    sp_off.push_back((uint32_t)bytes.size());
     HIP_TRY(hipDeviceSynchronize());
-    hipFree((void*)t->d_tok_off); hipFree((void*)t->d_tok_bytes);
-    t->d_tok_off = nullptr; t->d_tok_bytes = nullptr;
+    hipFree((void*)t->d_tok_off); hipFree((void*)t->d_tok_bytes); hipFree((void*)t->d_dec_sp_ids); hipFree((void*)t->d_dec_sp_off);
+    t->d_tok_off = nullptr; t->d_tok_bytes = nullptr; t->d_dec_sp_ids = nullptr; t->d_dec_sp_off = nullptr;
     int rc;
     if ((rc = dev_upload(off, &t->d_tok_off))) return rc;
     if ((rc = dev_upload(bytes, &t->d_tok_bytes))) return rc;
+    if ((rc = dev_upload(sp_ids, &t->d_dec_sp_ids))) return rc;
+    if ((rc = dev_upload(sp_off, &t->d_dec_sp_off))) return rc;
+    t->dec_n_sp = (uint32_t)sp_ids.size();
     t->dec_max_id = max_id;
     t->dec_uploaded = true;
     return SPL_OK;
@@ -1138,9 +1183,15 @@ int spl_decode_batch(spl_tokenizer* t, const uint32_t* ids, const uint64_t* ids_
     const uint64_t n = ids_off[n_docs] - ids_off[0];
     if (n && !ids) return fail(SPL_EINVAL, "spl_decode_batch: null ids");
     const uint64_t n_blk = (n + DEC_BLK - 1) / DEC_BLK;
-    struct Out { uint8_t* b = nullptr; uint64_t* o = nullptr; ~Out() { free(b); free(o); } } o;   // freed on every error path
-    o.o = (uint64_t*)malloc((n_docs + 1) * 8);
-    if (!o.o) return fail(SPL_EDEVICE, "spl_decode_batch: out of host memory");
+    // outputs in pinned memory from the handle's pool (the D2H copies run at PCIe speed into it; pageable
+    // memory would be staged by the runtime page by page); returned to the pool on every error path
+    struct Out {
+        std::shared_ptr<PinnedPool> pool; uint8_t* b = nullptr; uint64_t* o = nullptr; size_t bcap = 0, ocap = 0;
+        ~Out() { if (b) pool->put(b, bcap); if (o) pool->put(o, ocap); }
+    } o;
+    o.pool = t->pool;
+    o.o = (uint64_t*)t->pool->get((n_docs + 1) * 8, o.ocap);
+    if (!o.o) return fail(SPL_EDEVICE, "spl_decode_batch: pinned allocation failed");
     uint64_t total = 0;
     if (n) {
         // scratch grows, never shrinks: a steady stream of calls allocates nothing
@@ -1165,32 +1216,37 @@ int spl_decode_batch(spl_tokenizer* t, const uint32_t* ids, const uint64_t* ids_
         HIP_TRY(hipMemcpyAsync(c->d_dec_first, ids_off, (n_docs + 1) * 8, hipMemcpyHostToDevice, c->s_cmp));
         DecodeArgs a{};
         a.ids = c->d_dec_ids; a.n_ids = n; a.tok_off = c->d_tok_off; a.tok_bytes = c->d_tok_bytes; a.max_id = c->dec_max_id;
+        a.sp_ids = c->d_dec_sp_ids; a.sp_off = c->d_dec_sp_off; a.n_sp = c->dec_n_sp;
         a.blk = c->d_dec_blk; a.id_off = c->d_dec_idoff; a.doc_first = c->d_dec_first; a.n_docs = n_docs; a.doc_off = c->d_dec_docoff;
         hipLaunchKernelGGL(k_decode_len, dim3((uint32_t)n_blk), dim3(NT), 0, c->s_cmp, a);
         hipLaunchKernelGGL(k_decode_scan, dim3(1), dim3(1024), 0, c->s_cmp, c->d_dec_blk, n_blk);
-        HIP_TRY(hipMemcpyAsync(&total, c->d_dec_blk + n_blk, 8, hipMemcpyDeviceToHost, c->s_cmp));
+        uint64_t* h_total = (uint64_t*)o.o;                       // (pinned: the count lands without a staging copy)
+        HIP_TRY(hipMemcpyAsync(h_total, c->d_dec_blk + n_blk, 8, hipMemcpyDeviceToHost, c->s_cmp));
         HIP_TRY(hipStreamSynchronize(c->s_cmp));                  // the output size: the one host round trip
+        total = *h_total;
         if ((rc = grow(&c->d_dec_out, &c->dec_cap_out, total + 16))) return rc;
         a.out = c->d_dec_out;
         hipLaunchKernelGGL(k_decode_copy, dim3((uint32_t)n_blk), dim3(NT), 0, c->s_cmp, a);
         hipLaunchKernelGGL(k_decode_docs, dim3((uint32_t)((n_docs + 1 + 255) / 256)), dim3(256), 0, c->s_cmp, a);
         HIP_TRY(hipGetLastError());
-        o.b = (uint8_t*)malloc(total ? total : 1);
-        if (!o.b) return fail(SPL_EDEVICE, "spl_decode_batch: out of host memory");
+        o.b = (uint8_t*)t->pool->get(total ? total : 1, o.bcap);
+        if (!o.b) return fail(SPL_EDEVICE, "spl_decode_batch: pinned allocation failed");
         if (total) HIP_TRY(hipMemcpyAsync(o.b, c->d_dec_out, total, hipMemcpyDeviceToHost, c->s_cmp));
         HIP_TRY(hipMemcpyAsync(o.o, c->d_dec_docoff, (n_docs + 1) * 8, hipMemcpyDeviceToHost, c->s_cmp));
         HIP_TRY(hipStreamSynchronize(c->s_cmp));
     } else {
-        o.b = (uint8_t*)malloc(1);
-        if (!o.b) return fail(SPL_EDEVICE, "spl_decode_batch: out of host memory");
+        o.b = (uint8_t*)t->pool->get(1, o.bcap);
+        if (!o.b) return fail(SPL_EDEVICE, "spl_decode_batch: pinned allocation failed");
         for (uint64_t d = 0; d <= n_docs; d++) o.o[d] = 0;
     }
+    loose().add(o.b, t->pool, o.bcap);
+    loose().add(o.o, t->pool, o.ocap);
     *out_bytes = o.b; *out_off = o.o;
     o.b = nullptr; o.o = nullptr;
     return SPL_OK;
 }
 
-void spl_free(void* p) { free(p); }
+void spl_free(void* p) { if (p && !loose().release(p)) free(p); }
 
 int spl_token_bytes(const spl_tokenizer* t, uint32_t id, const uint8_t** bytes, uint32_t* len) {
     if (!t || !bytes || !len) return 0;

@@ -3527,15 +3527,26 @@ constexpr int DEC_BLK = 1024;
 struct DecodeArgs {
     const uint32_t* ids; uint64_t n_ids;
     const uint32_t* tok_off; const uint8_t* tok_bytes; uint32_t max_id;
+    // special tokens whose ids lie beyond the vocabulary's largest id: sorted ids, byte spans sp_off[k] .. sp_off[k + 1]
+    // of tok_bytes (a dense table up to the largest SPECIAL id would be O(that id): spl_add_special takes any id < 2^31)
+    const uint32_t* sp_ids; const uint32_t* sp_off; uint32_t n_sp;
     uint64_t* blk;          // [n_blk + 1] block sums, then exclusive offsets (+ total)
     uint64_t* id_off;       // [n_ids + 1] byte offset of every id (+ total)
     uint8_t* out;
     const uint64_t* doc_first; uint64_t n_docs; uint64_t* doc_off;   // doc d = ids [doc_first[d] - doc_first[0], ...)
 };
+__device__ __forceinline__ uint32_t dec_span(const DecodeArgs& a, uint32_t id, uint32_t& off) {
+    if (id <= a.max_id) { off = a.tok_off[id]; return a.tok_off[id + 1] - off; }
+    uint32_t lo = 0, hi = a.n_sp;                        // (a few dozen entries at most; ids of real text never get here)
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a.sp_ids[mid] < id) lo = mid + 1; else hi = mid; }
+    if (lo < a.n_sp && a.sp_ids[lo] == id) { off = a.sp_off[lo]; return a.sp_off[lo + 1] - off; }
+    off = 0;
+    return 0u;
+}
 __device__ __forceinline__ uint32_t dec_len(const DecodeArgs& a, uint64_t i) {
     if (i >= a.n_ids) return 0u;
-    const uint32_t id = a.ids[i];
-    return id <= a.max_id ? a.tok_off[id + 1] - a.tok_off[id] : 0u;
+    uint32_t off;
+    return dec_span(a, a.ids[i], off);
 }
 __global__ __launch_bounds__(NT) void k_decode_len(DecodeArgs a) {
     __shared__ uint32_t s_w[NT / 64];
@@ -3590,7 +3601,9 @@ __global__ __launch_bounds__(NT) void k_decode_copy(DecodeArgs a) {
         for (int w = 0; w < NT / 64; w++) { if (w < (int)(threadIdx.x >> 6)) o += s_w[w]; all += s_w[w]; }
         if (i < a.n_ids) {
             a.id_off[i] = o;
-            const uint8_t* src = a.tok_bytes + a.tok_off[a.ids[i] <= a.max_id ? a.ids[i] : 0u];
+            uint32_t soff;
+            (void)dec_span(a, a.ids[i], soff);
+            const uint8_t* src = a.tok_bytes + soff;
             for (uint32_t q = 0; q < len; q++) a.out[o + q] = src[q];
         }
         run += all;

@@ -1,0 +1,54 @@
+"""Randomized parity stress in the driver-run suite (-m gpu): fixed seeds of the two generators that found
+round 2's window-edge bugs (tests/stressgen.py), every vocabulary, the execution modes a BASELINE config can
+reach (0 the size decides / 4 queue mode / 5 tile-owned geometry B) and every forced geometry that is compiled
+in.  Bounded: every test stops drawing new seeds after its time budget, but never before its required seeds
+(the regression seeds among them) are through."""
+import time
+
+import pytest
+
+import test_gpu_parity as tg
+from stressgen import edge_batch, random_batch
+
+pytestmark = pytest.mark.gpu
+
+REACHABLE = [0, 0, 0, 4, 5, 5]            # modes a BASELINE config reaches (and their forced forms)
+BUDGET_S = 25.0
+
+
+def _run(gen, seeds, required, coracle, modes):
+    t0 = time.time()
+    done = 0
+    for k, seed in enumerate(seeds):
+        if k >= required and time.time() - t0 > BUDGET_S:
+            break
+        name, geom, special, texts = gen(seed, modes)
+        tg._force_tiles(name, geom)
+        try:
+            tg.assert_batch_equal(name, texts, coracle, special=special)
+        except AssertionError as e:
+            raise AssertionError(f"seed {seed} ({gen.__name__}, {name}, mode {geom}, special {special}): {e}") from None
+        finally:
+            tg._force_tiles(name, 0)
+        done += 1
+    assert done >= required
+
+
+def test_random_stress_fixed_seeds(coracle):
+    # 22739: the chunk that straddles the window's end (commit 32e0a5b), in the mode the size picks and forced
+    for mode in (0, 4, 5):
+        _run(random_batch, [22739], 1, coracle, [mode])
+    _run(random_batch, list(range(1000, 1400)), 10, coracle, REACHABLE)
+
+
+def test_random_stress_every_compiled_mode(coracle):
+    _run(random_batch, list(range(5000, 5400)), 10, coracle, [0, 1, 2, 3, 4, 5])
+
+
+def test_edge_sweep_fixed_seeds(coracle):
+    # special tokens and empty texts right behind the window's end are part of the generator (commit 6a09bab)
+    _run(edge_batch, list(range(1, 400)), 20, coracle, REACHABLE)
+
+
+def test_edge_sweep_every_compiled_mode(coracle):
+    _run(edge_batch, list(range(7000, 7400)), 12, coracle, [0, 1, 3, 4, 5])

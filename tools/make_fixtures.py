@@ -17,6 +17,7 @@ from splintr_amd import corpus  # noqa: E402
 SPECS = {
     "c1_cl100k": dict(vocab="cl100k_base", generator="c1", n=200),
     "c2_cl100k": dict(vocab="cl100k_base", generator="c2", n=1000),
+    "c2_wide_cl100k": dict(vocab="cl100k_base", generator="c2_wide", n=1000),
     "c3_o200k": dict(vocab="o200k_base", generator="c3", n=150),
     "c4_llama3": dict(vocab="llama3", generator="c4", n=3000),
     "c5_deepseek": dict(vocab="deepseek_v3", generator="c5", n=2, kwargs={"doc_bytes": 1 << 18}),
