@@ -59,9 +59,11 @@ typedef struct spl_tokenizer spl_tokenizer;
 typedef struct spl_result spl_result;
 
 typedef struct spl_opts {
-    int32_t pattern;   /* SPL_PATTERN_* */
-    int32_t device;    /* HIP device ordinal */
-    uint32_t flags;    /* SPL_OPT_* */
+    uint32_t struct_size; /* sizeof(spl_opts) as the CALLER was compiled: fields beyond it read as 0, so the struct
+                             can grow without breaking callers built against an earlier header (ABI versioning) */
+    int32_t pattern;      /* SPL_PATTERN_* */
+    int32_t device;       /* HIP device ordinal */
+    uint32_t flags;       /* SPL_OPT_* */
 } spl_opts;
 
 /* Thread-local text of the last failure in this thread. */
@@ -185,7 +187,8 @@ int spl_gatherv_unpack_group(spl_tokenizer* t, const uint32_t* d_slabs, uint32_t
  * ids CSR in, bytes CSR out.  An id of the vocabulary gives its token's bytes (ByteLevel: decoded
  * to raw bytes; a key that is not ByteLevel text gives the key itself, src/core/byte_level.rs:125-146),
  * otherwise an id of the special-token map gives its literal, any other id gives nothing.
- * *out_bytes / *out_off are malloc'd; release with spl_free. */
+ * *out_bytes / *out_off are library-owned (pinned host memory from the handle's pool: the copies back run at
+ * PCIe speed); release each with spl_free. */
 int spl_decode_batch(spl_tokenizer* t, const uint32_t* ids, const uint64_t* ids_off, uint64_t n_docs,
                      uint8_t** out_bytes, uint64_t** out_off);
 void spl_free(void* p);

@@ -31,7 +31,11 @@ SPL_OPT_BYTE_LEVEL = 1
 
 
 class SplOpts(ctypes.Structure):
-    _fields_ = [("pattern", ctypes.c_int32), ("device", ctypes.c_int32), ("flags", ctypes.c_uint32)]
+    _fields_ = [("struct_size", ctypes.c_uint32), ("pattern", ctypes.c_int32), ("device", ctypes.c_int32),
+                ("flags", ctypes.c_uint32)]
+
+    def __init__(self, pattern=0, device=0, flags=0):
+        super().__init__(ctypes.sizeof(SplOpts), pattern, device, flags)
 
 
 _lib = None

@@ -1008,6 +1008,16 @@ template <class T> int grow(T** p, uint64_t* cap, uint64_t need) {
 
 }  // namespace
 
+namespace {
+// No exception crosses the C ABI: every entry point that allocates (std::bad_alloc), starts threads or grows
+// containers runs inside this guard and reports SPL_EDEVICE instead.
+template <class F> int guarded(const char* what, F f) {
+    try { return f(); }
+    catch (const std::exception& e) { return fail(SPL_EDEVICE, std::string(what) + ": " + e.what()); }
+    catch (...) { return fail(SPL_EDEVICE, std::string(what) + ": unknown exception"); }
+}
+}  // namespace
+
 extern "C" {
 
 const char* spl_last_error(void) { return g_err.c_str(); }
@@ -1019,22 +1029,33 @@ int spl_device_count(void) {
 }
 
 spl_tokenizer* spl_create(const void* vocab, size_t vocab_len, const void* uclass_tab, size_t uclass_len,
-                          const spl_opts* opts) {
-    if (!vocab || !uclass_tab || !opts) { fail(SPL_EINVAL, "spl_create: null argument"); return nullptr; }
-    std::unique_ptr<spl_tokenizer> t(new spl_tokenizer());
-    std::string err;
-    if (build_tables((const uint8_t*)vocab, vocab_len, (const uint8_t*)uclass_tab, uclass_len, opts->pattern,
-                     (opts->flags & SPL_OPT_BYTE_LEVEL) != 0, t->ht, err)) {
-        fail(SPL_EINVAL, "spl_create: " + err);
+                          const spl_opts* opts_in) {
+    if (!vocab || !uclass_tab || !opts_in) { fail(SPL_EINVAL, "spl_create: null argument"); return nullptr; }
+    // the caller's struct may be older (smaller) than this library's: only the bytes it has are read
+    spl_opts o{};
+    const uint32_t have = opts_in->struct_size;
+    if (have < 8 || have > 4096) { fail(SPL_EINVAL, "spl_create: spl_opts.struct_size is not set"); return nullptr; }
+    memcpy(&o, opts_in, std::min<size_t>(have, sizeof o));
+    const spl_opts* opts = &o;
+    try {
+        std::unique_ptr<spl_tokenizer> t(new spl_tokenizer());
+        std::string err;
+        if (build_tables((const uint8_t*)vocab, vocab_len, (const uint8_t*)uclass_tab, uclass_len, opts->pattern,
+                         (opts->flags & SPL_OPT_BYTE_LEVEL) != 0, t->ht, err)) {
+            fail(SPL_EINVAL, "spl_create: " + err);
+            return nullptr;
+        }
+        t->ctx.emplace_back(new Ctx());
+        t->ctx[0]->device = opts->device;
+        if (upload_tables(*t->ctx[0], t->ht) != SPL_OK) return nullptr;      // (the context's destructor frees what was uploaded)
+        return t.release();
+    } catch (const std::exception& e) {                      // no exception crosses the C ABI
+        fail(SPL_EDEVICE, std::string("spl_create: ") + e.what());
         return nullptr;
     }
-    t->ctx.emplace_back(new Ctx());
-    t->ctx[0]->device = opts->device;
-    if (upload_tables(*t->ctx[0], t->ht) != SPL_OK) return nullptr;      // (the context's destructor frees what was uploaded)
-    return t.release();
 }
 
-int spl_set_devices(spl_tokenizer* t, const int32_t* devices, uint32_t n) {
+static int spl_set_devices_impl(spl_tokenizer* t, const int32_t* devices, uint32_t n) {
     if (!t || !devices || n == 0 || n > 64) return fail(SPL_EINVAL, "spl_set_devices: bad argument");
     const int have = spl_device_count();
     for (uint32_t i = 0; i < n; i++)
@@ -1064,7 +1085,7 @@ int spl_set_option(spl_tokenizer* t, const char* name, int64_t value) {
     return SPL_OK;
 }
 
-int spl_add_special(spl_tokenizer* t, const uint8_t* literal, size_t len, uint32_t id) {
+static int spl_add_special_impl(spl_tokenizer* t, const uint8_t* literal, size_t len, uint32_t id) {
     if (!t || !literal || len == 0) return fail(SPL_EINVAL, "spl_add_special: bad argument");
     if (len > 255) return fail(SPL_EINVAL, "spl_add_special: literal longer than 255 bytes");
     if (id > 0x7FFFFFFFu) return fail(SPL_EINVAL, "spl_add_special: id out of range");
@@ -1107,12 +1128,12 @@ uint32_t spl_vocab_size(const spl_tokenizer* t) {
 
 void spl_destroy(spl_tokenizer* t) { delete t; }
 
-int spl_reserve(spl_tokenizer* t, uint64_t max_bytes, uint64_t max_docs) {
+static int spl_reserve_impl(spl_tokenizer* t, uint64_t max_bytes, uint64_t max_docs) {
     if (!t) return fail(SPL_EINVAL, "spl_reserve: null handle");
     return reserve(t->ctx[0].get(), max_bytes, max_docs);
 }
 
-int spl_encode_batch_device(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
+static int spl_encode_batch_device_impl(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
                             uint64_t n_docs, uint32_t flags, uint32_t* d_ids, uint64_t ids_capacity,
                             uint64_t* d_out_off, void* hip_stream) {
     if (!t || !d_doc_off || !d_out_off || (n_bytes && (!d_utf8 || !d_ids)))
@@ -1121,7 +1142,7 @@ int spl_encode_batch_device(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_
     return launch_all(t, t->ctx[0].get(), d_utf8, n_bytes, d_doc_off, n_docs, flags, d_ids, ids_capacity, d_out_off, (hipStream_t)hip_stream);
 }
 
-int spl_encode_batch_device_packed(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
+static int spl_encode_batch_device_packed_impl(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
                                    uint64_t n_docs, uint32_t flags, uint32_t* d_ids, uint64_t ids_capacity,
                                    uint64_t* d_out_off, uint32_t* d_slab, uint64_t cap_words, uint64_t max_docs,
                                    void* hip_stream) {
@@ -1170,7 +1191,7 @@ void* spl_host_alloc(size_t bytes) {
 }
 void spl_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
-int spl_decode_batch(spl_tokenizer* t, const uint32_t* ids, const uint64_t* ids_off, uint64_t n_docs, uint8_t** out_bytes,
+static int spl_decode_batch_impl(spl_tokenizer* t, const uint32_t* ids, const uint64_t* ids_off, uint64_t n_docs, uint8_t** out_bytes,
                      uint64_t** out_off) {
     if (!t || !ids_off || !out_bytes || !out_off) return fail(SPL_EINVAL, "spl_decode_batch: null argument");
     for (uint64_t d = 0; d < n_docs; d++)
@@ -1372,4 +1393,33 @@ int spl_last_queue_counts(spl_tokenizer* t, uint32_t counts_out[4]) {
     return SPL_OK;
 }
 
+int spl_set_devices(spl_tokenizer* t, const int32_t* devices, uint32_t n) {
+    return guarded("spl_set_devices", [&] { return spl_set_devices_impl(t, devices, n); });
+}
+int spl_add_special(spl_tokenizer* t, const uint8_t* literal, size_t len, uint32_t id) {
+    return guarded("spl_add_special", [&] { return spl_add_special_impl(t, literal, len, id); });
+}
+int spl_reserve(spl_tokenizer* t, uint64_t max_bytes, uint64_t max_docs) {
+    return guarded("spl_reserve", [&] { return spl_reserve_impl(t, max_bytes, max_docs); });
+}
+int spl_encode_batch_device(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
+                            uint64_t n_docs, uint32_t flags, uint32_t* d_ids, uint64_t ids_capacity,
+                            uint64_t* d_out_off, void* hip_stream) {
+    return guarded("spl_encode_batch_device", [&] {
+        return spl_encode_batch_device_impl(t, d_utf8, n_bytes, d_doc_off, n_docs, flags, d_ids, ids_capacity, d_out_off, hip_stream); });
+}
+int spl_encode_batch_device_packed(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
+                                   uint64_t n_docs, uint32_t flags, uint32_t* d_ids, uint64_t ids_capacity,
+                                   uint64_t* d_out_off, uint32_t* d_slab, uint64_t cap_words, uint64_t max_docs,
+                                   void* hip_stream) {
+    return guarded("spl_encode_batch_device_packed", [&] {
+        return spl_encode_batch_device_packed_impl(t, d_utf8, n_bytes, d_doc_off, n_docs, flags, d_ids, ids_capacity, d_out_off,
+                                                   d_slab, cap_words, max_docs, hip_stream); });
+}
+int spl_decode_batch(spl_tokenizer* t, const uint32_t* ids, const uint64_t* ids_off, uint64_t n_docs, uint8_t** out_bytes,
+                     uint64_t** out_off) {
+    return guarded("spl_decode_batch", [&] { return spl_decode_batch_impl(t, ids, ids_off, n_docs, out_bytes, out_off); });
+}
+
 }  // extern "C"
+

@@ -72,8 +72,8 @@ constexpr int SPL_SHORT_BUCKET = 4;                     // entries per 64-byte b
 //   tiny table: keys of 1..4 bytes, 8-byte entries {key, id | len << 24}, buckets of 4 = 32 bytes
 //   t8 table  : keys of 5..8 bytes, 12-byte entries {k0, k1, id | len << 24}, 4 per 64-byte bucket
 //               (48 bytes used: three dwordx4 loads)
-// Same bucket discipline as the short table (fill left to right, never delete, last slot empty ==
-// bucket not full).  The short table keeps the keys of 9..12 bytes.
+// Same bucket discipline as the short table (fill left to right, never delete; SPL_OVF_BIT in the last
+// slot's id word == a key went on from this full bucket).  The short table keeps the keys of 9..12 bytes.
 constexpr int SPL_TINY_BUCKET = 4;                      // entries per 32-byte bucket
 constexpr int SPL_TINY_MAX = 4;
 constexpr int SPL_T8_BUCKET = 4;                        // entries per 64-byte bucket
@@ -127,7 +127,8 @@ struct DeviceTables {
     // len_mask[b0 | b1 << 8], low byte: bit L-2 set iff some token of exactly L bytes (L = 2..8) starts
     // with these two bytes, bit 7 iff a longer one does.  High byte: the SALT of the bucket hashes of
     // every key of up to 12 bytes that starts with these two bytes (a one-byte key: b1 = 0) -- chosen
-    // by the builder so that no bucket of the tiny / t8 / short tables is ever full: a probe then never
+    // by the builder so that no key of the tiny / t8 / short tables ever overflows its home bucket (a bucket
+    // may be full; SPL_OVF_BIT alone says whether anything went on from it): a probe then never
     // needs a second bucket, hit or miss (a wavefront waits for its slowest lane; with plain hashing
     // 2-7 % of the buckets were full and nearly every wavefront had a lane that went on to the next).
     // tiny_free / t8_free: a bucket of each table with a free slot -- where probes known to miss are

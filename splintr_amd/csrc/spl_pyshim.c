@@ -2,14 +2,17 @@
  * PyTokenizer (src/python/bindings.rs:254-350: extract Vec<String> from the argument, call the core,
  * convert Vec<Vec<u32>> to list[list[int]]), as ONE C call around spl_encode_batch.
  *
- *   encode_batch(handle, texts, flags) -> list[list[int]]
- *   encode(handle, text, flags)        -> list[int]
- *   pack(texts)                        -> (text_addr, n_bytes, off_addr, n_docs)   pinned, valid until the next call
+ *   encode_batch(handle, texts, flags)     -> list[list[int]]
+ *   encode_batch_csr(handle, texts, flags) -> (ids as u32 bytes, offsets as u64 bytes)
+ *   encode(handle, text, flags)            -> list[int]
+ *   pack_bytes(texts) / lists_from_csr(ids, off): the two halves on their own (CPU-side tests, measurements)
  *
  * The texts are UTF-8 encoded straight into a pinned staging buffer (spl_host_alloc: the GPU's
- * DMA engine reads it without another host copy); the result lists are filled from the pinned CSR,
- * frequent ids with cached int objects (ints are immutable, so sharing one object per id is unobservable).
- * The GIL is held throughout, as in the reference (no allow_threads in src/python/bindings.rs).
+ * DMA engine reads it without another host copy); the result lists are filled from the pinned CSR with
+ * cached int objects (ints are immutable, so sharing one object per id is unobservable).
+ * The GIL is held throughout, as in the reference (no allow_threads in src/python/bindings.rs): the staging
+ * buffers below are process-wide and safe for exactly that reason -- no entry point releases the GIL between
+ * staging a batch and copying its result out.
  */
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
@@ -25,15 +28,21 @@ static size_t g_off_cap = 0;
 static PyObject** g_ints = NULL;    /* id -> int object (lazily created, owned) */
 static size_t g_ints_cap = 0;
 
-static int ensure(void** p, size_t* cap, size_t need) {
+/* g_pageable: pack_bytes() on a box without a GPU (CPU-side tests of the packing code) -- staging then comes from
+ * malloc.  The encode entry points never set it: without a GPU they fail in spl_create long before. */
+static int g_pageable = 0, g_text_malloced = 0, g_off_malloced = 0;
+static int ensure(void** p, size_t* cap, size_t need, int* malloced) {
     if (*p && *cap >= need) return 0;
     size_t c = *cap ? *cap : (1u << 16);
     while (c < need) c += c / 2 + 4096;
+    int m = 0;
     void* q = spl_host_alloc(c);
+    if (!q && g_pageable) { q = malloc(c); m = 1; }
     if (!q) { PyErr_SetString(PyExc_MemoryError, "splintr_amd: pinned host allocation failed"); return -1; }
-    spl_host_free(*p);
+    if (*malloced) free(*p); else spl_host_free(*p);
     *p = q;
     *cap = c;
+    *malloced = m;
     return 0;
 }
 
@@ -83,7 +92,66 @@ static void utf8_write(PyObject* s, uint8_t* o) {
     else { const Py_UCS4* p = (const Py_UCS4*)d; for (Py_ssize_t i = 0; i < n; i++) o = put_cp(o, p[i]); }
 }
 
-/* list[str] -> packed UTF-8 + offsets in the pinned staging buffers.  Returns the document count or -1. */
+/* ---- packing: list[str] -> packed UTF-8 + offsets in the pinned staging buffers ------------------------------
+ * Two passes over the strings (sizes, then bytes).  A batch of a few hundred thousand strings is tens of
+ * megabytes scattered over the heap: one thread moves ~1 GB/s of it (a cache miss per object), so big batches
+ * are packed by a handful of helper threads.  They only READ immutable str objects that the calling thread
+ * keeps alive while it holds the GIL for the whole call; anything unusual (a non-str item, a str that is not in
+ * canonical form, a lone surrogate) is left to the calling thread, which raises what PyO3's extraction raises. */
+#include <pthread.h>
+#include <unistd.h>
+
+#define PACK_THREADS_MAX 8
+#define PACK_PAR_MIN_ITEMS 8192          /* sizes in parallel from this many strings on */
+#define PACK_PAR_MIN_BYTES (2u << 20)    /* bytes in parallel from this many bytes on */
+
+typedef struct {
+    PyObject** items; Py_ssize_t lo, hi;
+    uint64_t* off;          /* sizes pass: off[i + 1] = size of item i;  write pass: off[i] = its place */
+    uint8_t* text;
+    int write;              /* 0 sizes, 1 bytes */
+    int bad;                /* sizes pass: an item this thread must not judge */
+} pack_job;
+
+static void* pack_worker(void* arg) {
+    pack_job* j = (pack_job*)arg;
+    if (!j->write) {
+        for (Py_ssize_t i = j->lo; i < j->hi; i++) {
+            PyObject* s = j->items[i];
+            if (!PyUnicode_Check(s) || !PyUnicode_IS_READY(s)) { j->bad = 1; return NULL; }
+            const Py_ssize_t l = utf8_size(s);
+            if (l < 0) { j->bad = 1; return NULL; }
+            j->off[i + 1] = (uint64_t)l;
+        }
+    } else {
+        for (Py_ssize_t i = j->lo; i < j->hi; i++) utf8_write(j->items[i], j->text + j->off[i]);
+    }
+    return NULL;
+}
+
+static int pack_threads(void) {
+    static int n = 0;
+    if (!n) {
+        long c = sysconf(_SC_NPROCESSORS_ONLN);
+        n = c < 2 ? 1 : c > PACK_THREADS_MAX ? PACK_THREADS_MAX : (int)c;
+    }
+    return n;
+}
+
+/* run `jobs` (the first one on this thread); returns 0, or -1 if a thread could not be started (then all of
+ * the remaining jobs ran here) */
+static void run_jobs(pack_job* jobs, int nj) {
+    pthread_t th[PACK_THREADS_MAX];
+    int started[PACK_THREADS_MAX] = {0};
+    for (int k = 1; k < nj; k++) started[k] = pthread_create(&th[k], NULL, pack_worker, &jobs[k]) == 0;
+    pack_worker(&jobs[0]);
+    for (int k = 1; k < nj; k++) {
+        if (started[k]) pthread_join(th[k], NULL);
+        else pack_worker(&jobs[k]);
+    }
+}
+
+/* Returns the document count or -1 (exception set). */
 static Py_ssize_t pack_texts(PyObject* texts, const char* argname) {
     if (PyUnicode_Check(texts) || PyBytes_Check(texts)) {
         /* PyO3 refuses a bare str for Vec<String> (src/python/bindings.rs:337) */
@@ -94,43 +162,77 @@ static Py_ssize_t pack_texts(PyObject* texts, const char* argname) {
     if (!seq) { PyErr_Clear(); PyErr_Format(PyExc_TypeError, "argument '%s': '%s' object cannot be converted to 'Sequence'", argname, Py_TYPE(texts)->tp_name); return -1; }
     const Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
     PyObject** items = PySequence_Fast_ITEMS(seq);
-    if (ensure((void**)&g_off, &g_off_cap, ((size_t)n + 1) * 8)) { Py_DECREF(seq); return -1; }
-    uint64_t total = 0;
-    for (Py_ssize_t i = 0; i < n; i++) {
-        PyObject* s = items[i];
-        if (!PyUnicode_Check(s)) {
-            PyErr_Format(PyExc_TypeError, "argument '%s': '%s' object cannot be converted to 'PyString'", argname, Py_TYPE(s)->tp_name);
-            Py_DECREF(seq);
-            return -1;
+    if (ensure((void**)&g_off, &g_off_cap, ((size_t)n + 1) * 8, &g_off_malloced)) { Py_DECREF(seq); return -1; }
+    const int nt = pack_threads();
+    pack_job jobs[PACK_THREADS_MAX];
+    /* ---- sizes ---- */
+    int need_serial = 1;
+    if (nt > 1 && n >= PACK_PAR_MIN_ITEMS) {
+        for (int k = 0; k < nt; k++) {
+            jobs[k].items = items; jobs[k].lo = n * k / nt; jobs[k].hi = n * (k + 1) / nt;
+            jobs[k].off = g_off; jobs[k].text = NULL; jobs[k].write = 0; jobs[k].bad = 0;
         }
-        if (PyUnicode_READY(s) < 0) { Py_DECREF(seq); return -1; }
-        const Py_ssize_t l = utf8_size(s);
-        if (l < 0) {                         /* lone surrogate: let the codec raise UnicodeEncodeError, as PyO3's extraction does */
-            PyObject* b = PyUnicode_AsUTF8String(s);
-            Py_XDECREF(b);
-            if (!PyErr_Occurred()) PyErr_SetString(PyExc_UnicodeEncodeError, "surrogates not allowed");
-            Py_DECREF(seq);
-            return -1;
-        }
-        g_off[i] = total;
-        total += (uint64_t)l;
+        run_jobs(jobs, nt);
+        need_serial = 0;
+        for (int k = 0; k < nt; k++) need_serial |= jobs[k].bad;
     }
-    g_off[n] = total;
-    if (ensure((void**)&g_text, &g_text_cap, (size_t)total + 64)) { Py_DECREF(seq); return -1; }
-    for (Py_ssize_t i = 0; i < n; i++) utf8_write(items[i], g_text + g_off[i]);
+    if (need_serial) {
+        for (Py_ssize_t i = 0; i < n; i++) {
+            PyObject* s = items[i];
+            if (!PyUnicode_Check(s)) {
+                PyErr_Format(PyExc_TypeError, "argument '%s': '%s' object cannot be converted to 'PyString'", argname, Py_TYPE(s)->tp_name);
+                Py_DECREF(seq);
+                return -1;
+            }
+            if (PyUnicode_READY(s) < 0) { Py_DECREF(seq); return -1; }
+            const Py_ssize_t l = utf8_size(s);
+            if (l < 0) {                         /* lone surrogate: let the codec raise UnicodeEncodeError, as PyO3's extraction does */
+                PyObject* b = PyUnicode_AsUTF8String(s);
+                Py_XDECREF(b);
+                if (!PyErr_Occurred()) PyErr_SetString(PyExc_UnicodeEncodeError, "surrogates not allowed");
+                Py_DECREF(seq);
+                return -1;
+            }
+            g_off[i + 1] = (uint64_t)l;
+        }
+    }
+    uint64_t total = 0;
+    g_off[0] = 0;
+    for (Py_ssize_t i = 0; i < n; i++) { total += g_off[i + 1]; g_off[i + 1] = total; }
+    if (ensure((void**)&g_text, &g_text_cap, (size_t)total + 64, &g_text_malloced)) { Py_DECREF(seq); return -1; }
+    /* ---- bytes ---- */
+    if (nt > 1 && total >= PACK_PAR_MIN_BYTES && n >= 2 * nt) {
+        Py_ssize_t lo = 0;
+        int nj = 0;
+        for (int k = 0; k < nt && lo < n; k++) {                 /* ranges of about equal BYTES */
+            const uint64_t target = total / (uint64_t)nt * (uint64_t)(k + 1);
+            Py_ssize_t hi = lo;
+            if (k == nt - 1) hi = n;
+            else { Py_ssize_t a = lo, b = n; while (a < b) { const Py_ssize_t m = a + (b - a) / 2; if (g_off[m] < target) a = m + 1; else b = m; } hi = a > lo ? a : lo + 1; if (hi > n) hi = n; }
+            jobs[nj].items = items; jobs[nj].lo = lo; jobs[nj].hi = hi; jobs[nj].off = g_off; jobs[nj].text = g_text;
+            jobs[nj].write = 1; jobs[nj].bad = 0;
+            nj++;
+            lo = hi;
+        }
+        run_jobs(jobs, nj);
+    } else {
+        for (Py_ssize_t i = 0; i < n; i++) utf8_write(items[i], g_text + g_off[i]);
+    }
     Py_DECREF(seq);
     return n;
 }
 
-/* Token ids are ranks, and ranks follow frequency: the low ids are the tokens a text is mostly made of.
- * Those get ONE shared int object each (a cache hit is an INCREF on a line that is hot in L2); a rare,
- * high id gets a fresh object -- sharing would turn every use into a cache miss on a cold object. */
-#define INT_CACHE_MAX (1u << 16)
+/* ---- results: list[list[int]] from the CSR ---------------------------------------------------------------------
+ * One shared int object per id, created on first use (ints are immutable: sharing is unobservable, CPython does
+ * the same for -5..256).  A list element then costs an INCREF instead of an allocation.  The cyclic collector is
+ * held off while the lists are built: every 700 new lists trigger a young collection and, with hundreds of
+ * thousands of lists alive, full collections that walk every element of every list built so far -- on 250 000
+ * short documents that was more than half of the call (the lists hold only ints: there is nothing to collect). */
 static PyObject* int_of(uint32_t id) {      /* new reference */
-    if (id >= INT_CACHE_MAX) return PyLong_FromUnsignedLong(id);
     if ((size_t)id >= g_ints_cap) {
         size_t c = g_ints_cap ? g_ints_cap : 4096;
         while (c <= (size_t)id) c *= 2;
+        if (c > ((size_t)1 << 24)) return PyLong_FromUnsignedLong(id);     /* (ids beyond 2^24: never from this library) */
         PyObject** q = (PyObject**)realloc(g_ints, c * sizeof(PyObject*));
         if (!q) return PyErr_NoMemory();
         memset(q + g_ints_cap, 0, (c - g_ints_cap) * sizeof(PyObject*));
@@ -158,6 +260,18 @@ static PyObject* list_of(const uint32_t* ids, uint64_t n) {
     return l;
 }
 
+static PyObject* lists_of(const uint32_t* ids, const uint64_t* off, Py_ssize_t n) {
+    const int gc_was_on = PyGC_Disable();
+    PyObject* out = PyList_New(n);
+    for (Py_ssize_t d = 0; out && d < n; d++) {
+        PyObject* l = list_of(ids + off[d], off[d + 1] - off[d]);
+        if (!l) { Py_CLEAR(out); break; }
+        PyList_SET_ITEM(out, d, l);
+    }
+    if (gc_was_on) PyGC_Enable();
+    return out;
+}
+
 static spl_result* run(unsigned long long handle, uint64_t n_docs, unsigned flags) {
     spl_result* res = NULL;
     const int rc = spl_encode_batch((spl_tokenizer*)(uintptr_t)handle, g_text, g_off, n_docs, flags, &res);
@@ -172,15 +286,28 @@ static PyObject* py_encode_batch(PyObject* self, PyObject* args) {
     if (n < 0) return NULL;
     spl_result* res = run(handle, (uint64_t)n, flags);
     if (!res) return NULL;
-    const uint32_t* ids = spl_result_tokens(res);
-    const uint64_t* off = spl_result_offsets(res);
-    PyObject* out = PyList_New(n);
-    for (Py_ssize_t d = 0; out && d < n; d++) {
-        PyObject* l = list_of(ids + off[d], off[d + 1] - off[d]);
-        if (!l) { Py_CLEAR(out); break; }
-        PyList_SET_ITEM(out, d, l);
-    }
+    PyObject* out = lists_of(spl_result_tokens(res), spl_result_offsets(res), n);
     spl_result_free(res);
+    return out;
+}
+
+/* The same call with the CSR itself as the result: (ids as bytes of u32, offsets as bytes of u64).  Staging,
+ * encode and the copy out of the pinned result all happen inside this one call, with the GIL held: two
+ * threads can never see each other's staging buffers (the earlier pack() + ctypes pair could). */
+static PyObject* py_encode_batch_csr(PyObject* self, PyObject* args) {
+    unsigned long long handle; PyObject* texts; unsigned flags;
+    if (!PyArg_ParseTuple(args, "KOI", &handle, &texts, &flags)) return NULL;
+    const Py_ssize_t n = pack_texts(texts, "texts");
+    if (n < 0) return NULL;
+    spl_result* res = run(handle, (uint64_t)n, flags);
+    if (!res) return NULL;
+    const uint64_t nt = spl_result_n_tokens(res);
+    PyObject* ids = PyBytes_FromStringAndSize((const char*)spl_result_tokens(res), (Py_ssize_t)(nt * 4));
+    PyObject* off = PyBytes_FromStringAndSize((const char*)spl_result_offsets(res), (Py_ssize_t)(((uint64_t)n + 1) * 8));
+    spl_result_free(res);
+    if (!ids || !off) { Py_XDECREF(ids); Py_XDECREF(off); return NULL; }
+    PyObject* out = PyTuple_Pack(2, ids, off);
+    Py_DECREF(ids); Py_DECREF(off);
     return out;
 }
 
@@ -203,19 +330,41 @@ static PyObject* py_encode(PyObject* self, PyObject* args) {
     return l;
 }
 
-static PyObject* py_pack(PyObject* self, PyObject* args) {
+/* The two halves of the surface on their own, for tests and measurements that have no GPU:
+ * pack_bytes(texts) -> (bytes, offsets bytes) as the staging buffers hold them; lists_from_csr(ids, off). */
+static PyObject* py_pack_bytes(PyObject* self, PyObject* args) {
     PyObject* texts;
     if (!PyArg_ParseTuple(args, "O", &texts)) return NULL;
+    g_pageable = spl_device_count() == 0;
     const Py_ssize_t n = pack_texts(texts, "texts");
+    g_pageable = 0;
     if (n < 0) return NULL;
-    return Py_BuildValue("KKKn", (unsigned long long)(uintptr_t)g_text, (unsigned long long)g_off[n],
-                         (unsigned long long)(uintptr_t)g_off, n);
+    return Py_BuildValue("y#y#", (const char*)g_text, (Py_ssize_t)g_off[n], (const char*)g_off, (Py_ssize_t)((n + 1) * 8));
+}
+
+static PyObject* py_lists_from_csr(PyObject* self, PyObject* args) {
+    Py_buffer ids, off;
+    if (!PyArg_ParseTuple(args, "y*y*", &ids, &off)) return NULL;
+    PyObject* out = NULL;
+    if (off.len < 8 || off.len % 8 || ids.len % 4) PyErr_SetString(PyExc_ValueError, "lists_from_csr: u32 ids, u64 offsets[N + 1]");
+    else {
+        const Py_ssize_t n = off.len / 8 - 1;
+        const uint64_t* o = (const uint64_t*)off.buf;
+        int ok = o[0] == 0 && o[n] * 4 == (uint64_t)ids.len;
+        for (Py_ssize_t d = 0; ok && d < n; d++) ok = o[d] <= o[d + 1];
+        if (!ok) PyErr_SetString(PyExc_ValueError, "lists_from_csr: offsets do not describe the ids");
+        else out = lists_of((const uint32_t*)ids.buf, o, n);
+    }
+    PyBuffer_Release(&ids); PyBuffer_Release(&off);
+    return out;
 }
 
 static PyMethodDef methods[] = {
     {"encode_batch", py_encode_batch, METH_VARARGS, "encode_batch(handle, texts, flags) -> list[list[int]]"},
     {"encode", py_encode, METH_VARARGS, "encode(handle, text, flags) -> list[int]"},
-    {"pack", py_pack, METH_VARARGS, "pack(texts) -> (text_addr, n_bytes, off_addr, n_docs) in pinned staging"},
+    {"encode_batch_csr", py_encode_batch_csr, METH_VARARGS, "encode_batch_csr(handle, texts, flags) -> (ids u32 bytes, offsets u64 bytes)"},
+    {"pack_bytes", py_pack_bytes, METH_VARARGS, "pack_bytes(texts) -> (utf8 bytes, offsets u64 bytes)"},
+    {"lists_from_csr", py_lists_from_csr, METH_VARARGS, "lists_from_csr(ids u32 bytes, offsets u64 bytes) -> list[list[int]]"},
     {NULL, NULL, 0, NULL}};
 
 static struct PyModuleDef mod = {PyModuleDef_HEAD_INIT, "_spl_py", "CPython front end of libsplintr_hip", -1, methods};

@@ -167,10 +167,29 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
                 if (pad < 1) key.push_back((char)w);
             }
             // rank: str::trim + parse::<u32> (an optional leading '+', decimal digits, no overflow)
+            // (str::trim trims Unicode White_Space, not only ASCII: U+0085, U+00A0, U+1680, U+2000..200A, U+2028,
+            //  U+2029, U+202F, U+205F, U+3000 as well -- a rank field "12\xc2\xa0" loads in the reference)
             size_t r0 = sp, r1 = n;
-            auto is_ws = [](uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); };
-            while (r0 < r1 && is_ws(line[r0])) r0++;
-            while (r1 > r0 && is_ws(line[r1 - 1])) r1--;
+            auto ws_at = [&](size_t i, size_t end) -> size_t {       // bytes of the White_Space character at line[i], 0 if none
+                const uint8_t c = line[i];
+                if (c == ' ' || (c >= 9 && c <= 13)) return 1;
+                if (c == 0xC2 && i + 1 < end && (line[i + 1] == 0x85 || line[i + 1] == 0xA0)) return 2;
+                if (i + 2 < end) {
+                    const uint8_t d = line[i + 1], f = line[i + 2];
+                    if (c == 0xE1 && d == 0x9A && f == 0x80) return 3;
+                    if (c == 0xE2 && d == 0x80 && ((f >= 0x80 && f <= 0x8A) || f == 0xA8 || f == 0xA9 || f == 0xAF)) return 3;
+                    if (c == 0xE2 && d == 0x81 && f == 0x9F) return 3;
+                    if (c == 0xE3 && d == 0x80 && f == 0x80) return 3;
+                }
+                return 0;
+            };
+            for (size_t w; r0 < r1 && (w = ws_at(r0, r1)) != 0;) r0 += w;
+            for (;;) {
+                bool cut = false;
+                for (size_t w = 1; w <= 3 && !cut; w++)
+                    if (r1 >= r0 + w && ws_at(r1 - w, r1) == w) { r1 -= w; cut = true; }
+                if (!cut) break;
+            }
             if (r0 < r1 && line[r0] == '+') r0++;
             uint64_t rank = 0;
             bool ok = r0 < r1;
@@ -311,6 +330,8 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
     // o200k_base, 5 of its keys; none in the other shipped vocabularies) keeps salt 0 and overflows into
     // the next bucket, marking the full one (SPL_OVF_BIT); the probes walk on from a marked bucket, so
     // this costs speed only -- and only for the probes that land on those few buckets.
+    // (SPL_BUCKET_FILL = the bucket size: a salted bucket may become completely FULL; what the salts guarantee
+    //  is that no key OVERFLOWS.  Probes are settled by SPL_OVF_BIT alone, never by "the last slot is empty".)
     {
         constexpr int SPL_BUCKET_FILL = 4;
         struct KeyRef { const std::string* k; uint32_t id; };

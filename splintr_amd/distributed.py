@@ -126,13 +126,20 @@ def plan_shards(docs: Sequence[bytes], world: int, split_docs: bool = True,
     return shards
 
 
-def encode_batch_sharded(encode_csr, texts: Sequence[str], device: torch.device, group=None, split_docs: bool = True):
+def encode_batch_sharded(encode_csr, texts: Sequence[str], device: torch.device, group=None, split_docs: bool = True,
+                         special_literals: Sequence[str] = ()):
     """encode_batch over the process group (strong scaling of ONE batch): rank r encodes its
     byte-balanced shard -- whole documents and, at the shard's ends, pieces of documents cut at
     context-free boundaries (plan_shards) -- with `encode_csr(list[str]) -> (ids uint32 ndarray,
     off uint64 ndarray)`, and the ragged result is all-gathered.  Returns (ids, off) numpy arrays
-    for ALL documents on every rank."""
+    for ALL documents on every rank.
+
+    `special_literals`: when `encode_csr` encodes WITH special tokens, pass the literals of its map.  A cut
+    sits directly behind a newline, so it can only fall inside a literal that contains one; if any does,
+    documents are not cut at all (what spl_encode_batch's host path does: `special_newline`, spl_api.hip)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if any("\n" in lit for lit in special_literals):
+        split_docs = False
     docs = [t.encode("utf-8") for t in texts]
     shards = plan_shards(docs, world, split_docs)
     local = [docs[d][lo:hi].decode("utf-8") for d, lo, hi in shards[rank]]     # cuts sit in front of ASCII bytes

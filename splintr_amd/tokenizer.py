@@ -214,8 +214,9 @@ class Tokenizer:
     def encode_batch_csr(self, texts: Sequence[str], with_special: bool = False):
         """Extension: the batch result as CSR numpy arrays (ids uint32[T], offsets uint64[N+1])
         without materialising Python lists."""
-        addr, _n_bytes, off_addr, nd = _ffi.shim().pack(texts)      # pinned staging, valid until the next pack
-        return self._encode_packed(addr, off_addr, nd, _ffi.SPL_WITH_SPECIAL if with_special else 0)
+        # ONE C call with the GIL held (staging, spl_encode_batch, copy out): safe from several threads
+        ids, off = _ffi.shim().encode_batch_csr(self._h, texts, _ffi.SPL_WITH_SPECIAL if with_special else 0)
+        return np.frombuffer(ids, dtype=np.uint32), np.frombuffer(off, dtype=np.uint64)
 
     def _encode_one(self, text: str, flags: int) -> List[int]:
         return _ffi.shim().encode(self._h, text, flags)

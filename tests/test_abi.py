@@ -39,6 +39,14 @@ def test_errors_without_gpu_or_bad_input(built):
     opts = built.SplOpts(0, 0)
     assert not L.spl_create(b"junk", 4, b"junk", 4, ctypes.byref(opts))
     assert b"spl_create" in L.spl_last_error()
+    # spl_opts is versioned by its first member: a caller that does not set it is refused, one built against a
+    # LONGER struct than this library knows is accepted (the tail is ignored)
+    raw = (ctypes.c_uint32 * 4)(0, 0, 0, 0)
+    assert not L.spl_create(b"junk", 4, b"junk", 4, ctypes.cast(raw, ctypes.POINTER(built.SplOpts)))
+    assert b"struct_size" in L.spl_last_error()
+    big = (ctypes.c_uint32 * 16)(64, 0, 0, 0)
+    assert not L.spl_create(b"junk", 4, b"junk", 4, ctypes.cast(big, ctypes.POINTER(built.SplOpts)))
+    assert b"struct_size" not in L.spl_last_error()
     assert L.spl_kernel_name(0) and L.spl_kernel_name(99) is None
     assert L.spl_vocab_size(None) == 0
 

@@ -97,3 +97,21 @@ def test_deepseek_ids_that_are_not_byte_level_text():
     for i in range(3):
         assert t.decode_bytes([i]) == o.decode_bytes([i]) and len(t.decode_bytes([i])) > 3
     assert t.decode([0]) == "<｜begin▁of▁sentence｜>"
+
+
+def test_special_ids_far_beyond_the_vocabulary_cost_nothing():
+    """spl_add_special takes any id below 2**31: the decode table stays O(vocabulary) -- such ids live in a small
+    sorted side table (a dense table up to the largest special id was tens of GB)."""
+    from splintr_amd import Tokenizer, CL100K_BASE_PATTERN
+    import os
+    from conftest import ROOT
+    with open(os.path.join(ROOT, "splintr_amd", "data", "cl100k_base.splv"), "rb") as f:
+        blob = f.read()
+    sp = {"<|far|>": 2 ** 31 - 1, "<|mid|>": 5_000_000, "<|near|>": 100300, "<|dup|>": 5_000_000}
+    t = Tokenizer.from_bytes(blob, CL100K_BASE_PATTERN, sp)
+    assert t.vocab_size == 2 ** 31
+    ids = t.encode_with_special("a<|far|>b<|near|>c<|dup|>")
+    assert ids == t.encode("a") + [2 ** 31 - 1] + t.encode("b") + [100300] + t.encode("c") + [5_000_000]
+    assert t.decode_bytes(ids) == b"a<|far|>b<|near|>c<|dup|>"          # the later literal of a shared id wins, as a map insert
+    assert t.decode_bytes([4_999_999, 5_000_001, 2 ** 31 - 2]) == b""
+    assert t.decode_batch([[2 ** 31 - 1], [], [100300, 5_000_000]]) == ["<|far|>", "", "<|near|><|dup|>"]
