@@ -44,7 +44,7 @@ def test_parser_errors_are_the_reference_s():
     assert not ok and "Invalid rank" in err                            # vocab.rs:80-83
     ok, err = _create(b"SGVsbG8= 12\xc2\xa0\n")                        # str::trim takes Unicode White_Space (NBSP) off the rank:
     assert not ok and "256 single-byte" in err                         # the line parses (and the vocabulary is then too small)
-    ok, err = _create("SGVsbG8= \u3000\u2003 12\u2028\n".encode())
+    ok, err = _create("SGVsbG8= \u3000\u200312\u2028\n".encode())
     assert not ok and "256 single-byte" in err
     ok, err = _create(b"SGVsbG8= 1\xc2\xa02\n")                        # ... but not out of its middle
     assert not ok and "Invalid rank" in err
