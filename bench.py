@@ -155,7 +155,7 @@ def main():
     if use_dist:
         dist.barrier()
     from splintr_amd import Tokenizer, corpus, _ffi
-    from splintr_amd.device import DeviceBatch, GatherV, encode_device, reserve, result_csr
+    from splintr_amd.device import Comm, DeviceBatch, GatherV, encode_device, reserve, result_csr
     from oracle.coracle import COracle
 
     ncpu = os.cpu_count() or 1
@@ -198,7 +198,8 @@ def main():
         # reproduces this rank's ids and offsets at its place in the global CSR of every batch
         mx = torch.tensor([max(n_tokens), max(b.n_docs for b in batches)], dtype=torch.int64, device=dev)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        gv = GatherV(tok, dev, max_docs=int(mx[1].item()), max_tokens=int(int(mx[0].item()) * 1.02) + 64)
+        comm = Comm.from_torch_group(dev)       # the library's own RCCL communicator (spl_comm_*): torch only carries its 128-byte id
+        gv = GatherV(tok, dev, max_docs=int(mx[1].item()), max_tokens=int(int(mx[0].item()) * 1.02) + 64, comm=comm)
         got = []
         gv.on_bucket = lambda res: got.extend((i.clone(), o.clone()) for i, o in res)
         for _ in range(N_ROT):
@@ -334,7 +335,7 @@ def main():
     if rank == 0 and world == 1 and not use_dist and not args.no_throughputs:
         import host_path_bench
         throughputs = {}
-        for cfg in ("c2", "c3"):
+        for cfg in ("c2", "c2_wide", "c3"):
             try:
                 throughputs[cfg] = host_path_bench.measure(cfg)
             except Exception as e:          # a failure here must not cost the headline line
@@ -342,7 +343,9 @@ def main():
         throughputs["note"] = ("MB/s of input bytes. kernel_hbm: corpus resident in HBM (one batch, re-encoded); c_abi_host: "
                                "spl_encode_batch host bytes -> host CSR incl. H2D/D2H, input from spl_host_alloc; "
                                "c_abi_host_pageable: the same from pageable memory (one extra host copy into pinned staging); "
-                               "python_surface: Tokenizer.encode_batch(list[str]) -> list[list[int]]")
+                               "python_surface: Tokenizer.encode_batch(list[str]) -> list[list[int]]; decode_host: spl_decode_batch, ids CSR on the host -> "
+                               "bytes CSR on the host (pinned in and out), MB/s of decoded bytes; c2_wide: C2's mix over a >= 20 000-word "
+                               "lexicon (splintr_amd.corpus.c2_wide)")
 
     # ---- BASELINE config 4: llama3, 1 M short prompts, doc-sharded over the ranks (strong scaling) -------
     c4 = c5 = None
@@ -356,35 +359,49 @@ def main():
     # ---- CPU baseline: the oracle (a port of the reference's Rayon path) on the host cores ---------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # The whole rotation as ONE call (8 x 1000 documents, ~8 MB: a call of ~20 ms instead of 2.5 ms, so the
-        # pool's wake-up is not what is measured), a FIXED number of repetitions per configuration, the MEDIAN.
-        # Thread counts 8 .. all host CPUs x memo on/off; `value` = the best median (the GPU is compared with the
-        # strongest configuration of the port on this host), the 24-thread figure SURVEY 8d asks for beside it.
+        # `value`: ONE batch of the rotation per call (1000 documents, ~1 MB: what the GPU's step is and what
+        # north_star's ">= 10x on 1000 x 1 KB" is about), a FIXED number of repetitions per configuration, the
+        # MEDIAN.  Beside it the whole rotation as ONE call (8000 documents, ~8 MB: a call of ~10 ms, where the
+        # pool's wake-up no longer shows) and the 24-thread figure SURVEY 8d asks for.  Thread counts 8 .. all
+        # host CPUs x memo on/off; the best median of each is reported (the GPU is compared with the strongest
+        # configuration of the port on this host).
+        one_np, one_off = _packed(text_sets[0])
         all_texts = [t for ts in text_sets for t in ts]
-        text_np, off_np = _packed(all_texts)
-        nb_cpu = int(off_np[-1])
+        all_np, all_off = _packed(all_texts)
         cands = sorted({t for t in (8, 16, 24, 32, 64, ncpu) if t <= ncpu})
-        REPS = 15
-        table = {}
-        for memo in (False, True):
-            orc_t = COracle("cl100k_base", memo=memo)
-            for th in cands:
-                for _ in range(3):
-                    orc_t.encode_packed(text_np, off_np, threads=th)
-                ts_ = []
-                for _ in range(REPS):
-                    c0 = time.perf_counter()
-                    orc_t.encode_packed(text_np, off_np, threads=th)
-                    ts_.append(time.perf_counter() - c0)
-                ts_.sort()
-                table[(th, memo)] = (nb_cpu / ts_[REPS // 2] / 1e6, nb_cpu / ts_[-1] / 1e6, nb_cpu / ts_[0] / 1e6)
-        (bth, bmemo), bv = max(table.items(), key=lambda kv: kv[1][0])
-        t24 = max((table[(24, m)][0] for m in (False, True) if (24, m) in table), default=None)
+
+        def sweep(t_np, t_off, reps):
+            nb_ = int(t_off[-1])
+            table = {}
+            for memo in (False, True):
+                orc_t = COracle("cl100k_base", memo=memo)
+                for th in cands:
+                    if memo and th > 24:          # (the mutex-guarded memo only loses ground with more threads: 13 MB/s at 256)
+                        continue
+                    for _ in range(3):
+                        orc_t.encode_packed(t_np, t_off, threads=th)
+                    ts_ = []
+                    for _ in range(reps):
+                        c0 = time.perf_counter()
+                        orc_t.encode_packed(t_np, t_off, threads=th)
+                        ts_.append(time.perf_counter() - c0)
+                    ts_.sort()
+                    table[(th, memo)] = (nb_ / ts_[reps // 2] / 1e6, nb_ / ts_[-1] / 1e6, nb_ / ts_[0] / 1e6)
+            return table
+        REPS1, REPS8 = 61, 15
+        t1 = sweep(one_np, one_off, REPS1)
+        t8 = sweep(all_np, all_off, REPS8)
+        (bth, bmemo), bv = max(t1.items(), key=lambda kv: kv[1][0])
+        (b8th, b8memo), b8v = max(t8.items(), key=lambda kv: kv[1][0])
+        t24 = max((t1[(24, m)][0] for m in (False, True) if (24, m) in t1), default=None)
+        fmt = lambda tb: {f"{th}t{'+memo' if m else ''}": round(v[0], 1) for (th, m), v in sorted(tb.items())}
         cpu = {"value": round(bv[0], 2), "unit": "MB/s", "cores": bth, "kind": "port", "host_cpus": ncpu,
                "spread": [round(bv[1], 2), round(bv[2], 2)],
                "threads_24": round(t24, 2) if t24 is not None else None,
-               "all_medians": {f"{th}t{'+memo' if m else ''}": round(v[0], 1) for (th, m), v in sorted(table.items())},
-               "sample": f"the {N_ROT} batches of the rotation as ONE call ({len(all_texts)} docs, {nb_cpu} B), 3 warm-ups + {REPS} timed "
+               "rotation_as_one_call": {"value": round(b8v[0], 2), "cores": b8th, "memo": b8memo, "docs": len(all_texts),
+                                        "bytes": int(all_off[-1]), "repetitions": REPS8, "all_medians": fmt(t8)},
+               "all_medians": fmt(t1),
+               "sample": f"the first batch of the rotation ({batches[0].n_docs} docs, {batches[0].n_bytes} B) per call, 3 warm-ups + {REPS1} timed "
                          f"repetitions per configuration, MEDIAN (spread = slowest / fastest repetition of the best configuration); "
                          f"threads in {cands} x memo on/off -- best: {bth} threads "
                          f"{'with' if bmemo else 'without'} the mutex-guarded 4096-entry memo that stands in for the "
@@ -489,7 +506,7 @@ def run_c5(args, rank, world, local_rank, dev, use_dist, pieces):
 
 def run_strong(vocab, texts, steps, rank, world, local_rank, dev, use_dist, nchk, workload, parity):
     from splintr_amd import Tokenizer
-    from splintr_amd.device import DeviceBatch, GatherV, encode_device, reserve, result_csr
+    from splintr_amd.device import Comm, DeviceBatch, encode_device, reserve, result_csr
     from oracle.coracle import COracle
     tok = Tokenizer.from_pretrained(vocab, device=local_rank)
     batch = DeviceBatch(texts, dev)
@@ -507,29 +524,37 @@ def run_strong(vocab, texts, steps, rank, world, local_rank, dev, use_dist, nchk
         if not (np.array_equal(ids[a:b_], o_ids) and np.array_equal(off[sl.start:sl.stop + 1] - off[sl.start], o_off)):
             raise SystemExit(f"rank {rank}: {vocab} strong-scaling result differs from the oracle")
     n_tok = int(off[-1])
-    gv = None
+    comm = all_ids = all_off = None
     if use_dist:
-        mx = torch.tensor([n_tok, batch.n_docs], dtype=torch.int64, device=dev)
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        gv = GatherV(tok, dev, max_docs=int(mx[1].item()), max_tokens=int(int(mx[0].item()) * 1.01) + 64, depth=1)
+        # the exact ragged all-gather behind the C ABI (spl_allgatherv_csr): {T, N} of every rank first, then
+        # exactly T_r ids and N_r offsets per rank by grouped ncclSend / ncclRecv, straight into the global CSR
+        comm = Comm.from_torch_group(dev)
+        tot = torch.tensor([n_tok, batch.n_docs], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot)
+        all_ids = torch.empty(int(tot[0].item()) + 64, dtype=torch.int32, device=dev)
+        all_off = torch.empty(int(tot[1].item()) + 1, dtype=torch.int64, device=dev)
 
     def step():
-        if gv is None:
-            encode_device(tok, batch)
-        else:
-            gv.encode_and_submit(batch)
+        encode_device(tok, batch)
+        if comm is not None:
+            return comm.allgatherv_csr(batch.ids, batch.out_off, batch.n_docs, all_ids, all_off)
     for _ in range(2):
-        step()
-    if gv is not None:
-        gv.finish()
+        got = step()
     if use_dist:
+        # every rank holds the whole result: totals, and this rank's ids and offsets at their place
+        assert got == (int(tot[0].item()), int(tot[1].item())), got
+        pre = torch.tensor([n_tok, batch.n_docs], dtype=torch.int64, device=dev)
+        allc = [torch.zeros_like(pre) for _ in range(world)]
+        dist.all_gather(allc, pre)
+        allc = torch.stack(allc).cpu().numpy()
+        t0_, d0_ = int(allc[:rank, 0].sum()), int(allc[:rank, 1].sum())
+        assert np.array_equal(all_ids[t0_:t0_ + n_tok].cpu().numpy().view(np.uint32), ids)
+        assert np.array_equal((all_off[d0_:d0_ + batch.n_docs + 1] - t0_).cpu().numpy().astype(np.uint64), off)
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
-    if gv is not None:
-        gv.finish()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -542,13 +567,12 @@ def run_strong(vocab, texts, steps, rank, world, local_rank, dev, use_dist, nchk
         s = torch.tensor([batch.n_bytes, batch.n_docs, n_tok], dtype=torch.int64, device=dev)
         dist.all_reduce(s)
         tot_b, tot_d, tot_t = (int(x) for x in s.tolist())
-        assert not gv.overflowed()
-    del batch, tok, gv
+    del batch, tok, comm, all_ids, all_off
     torch.cuda.empty_cache()
     if rank != 0:
         return None
     return {"workload": workload.format(docs=tot_d, bytes=tot_b, tokens=tot_t, world=world)
-                        + ("; RCCL all-gatherv of the ragged ids inside the step" if use_dist else ""),
+                        + ("; RCCL all-gatherv of the ragged result inside the step (spl_allgatherv_csr: counts, then exactly T_r ids and N_r offsets per rank by grouped send/recv)" if use_dist else ""),
             "value": round(tot_b * steps / el / 1e6, 1), "unit": "MB/s", "ms_per_step": round(el / steps * 1e3, 3),
             "steps": steps, "scaling": "strong", "parity": parity}
 

@@ -155,8 +155,8 @@ int spl_encode_batch_device(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_
 /* Ragged all-gather of the CSR result across the GPUs of a node (north_star: "RCCL all-gatherv
  * over xGMI"; the reference has nothing distributed).  RCCL has no all-gatherv, so every rank
  * packs {T, N, local offsets, ids} into a fixed-capacity slab of u32 words, ONE all-gather of
- * equal-sized slabs moves them (the caller's collective, e.g. torch.distributed
- * all_gather_into_tensor on RCCL), and every rank unpacks the `world` slabs into the global CSR in
+ * equal-sized slabs moves them (spl_allgather_slabs below, or the caller's own collective, e.g.
+ * torch.distributed all_gather_into_tensor), and every rank unpacks the `world` slabs into the global CSR in
  * rank order.  Both kernels are asynchronous on `hip_stream`; no host synchronisation is needed
  * because the counts travel inside the slabs.
  *   slab: [0] T, [1] N, [2 .. 2+max_docs] local out_off, then ids; cap_words >= max_docs + 4.
@@ -182,6 +182,36 @@ int spl_encode_batch_device_packed(spl_tokenizer* t, const uint8_t* d_utf8, uint
 int spl_gatherv_unpack_group(spl_tokenizer* t, const uint32_t* d_slabs, uint32_t world, uint32_t depth, uint32_t n_batches,
                              uint64_t cap_words, uint64_t max_docs, uint32_t* d_all_ids, uint64_t all_ids_cap,
                              uint64_t* d_all_off, uint64_t off_stride, uint32_t* d_status, void* hip_stream);
+
+/* The collective itself behind the C ABI (north_star: "an RCCL all-gatherv over xGMI to reassemble the ragged
+ * token-id output"; the reference has nothing distributed -- src/core/tokenizer.rs:932-934 is a Rayon par_iter on
+ * one host -- so these are this build's own entry points).  One process per GPU.  RCCL is bound at run time
+ * (dlopen of librccl.so.1: a process that already holds a copy, e.g. PyTorch's, keeps using that one; a
+ * single-GPU caller needs no RCCL).
+ *   spl_comm_unique_id   one rank makes the 128-byte id (ncclGetUniqueId); the caller hands it to the others
+ *                        (MPI, a file, a key-value store -- no transport is imposed)
+ *   spl_comm_create      ncclCommInitRank on `device`; collective: every rank of `world` must call it
+ *   spl_allgather_slabs  ONE ncclAllGather of equal-sized u32 slabs (the padded, synchronisation-free form:
+ *                        slabs from spl_gatherv_pack / spl_encode_batch_device_packed, results through
+ *                        spl_gatherv_unpack[_group]); asynchronous on hip_stream
+ *   spl_allgatherv_csr   the exact form: every rank's {T, N} first (16 bytes per rank, ONE host
+ *                        synchronisation), then exactly T_r ids and N_r offsets per rank land at their place of
+ *                        the global CSR by grouped ncclSend / ncclRecv -- one message per peer and direction,
+ *                        every xGMI link busy at once, nothing padded -- and the offsets are rebased on the
+ *                        device.  d_all_ids[all_ids_cap], d_all_off[all_off_cap >= N_total + 1]; the totals are
+ *                        returned; SPL_ECAPACITY (on every rank alike) if they do not fit.  Rank order ==
+ *                        document order when rank r holds the r-th contiguous shard. */
+#define SPL_COMM_ID_BYTES 128
+typedef struct spl_comm spl_comm;
+int spl_comm_unique_id(uint8_t id_out[SPL_COMM_ID_BYTES]);
+spl_comm* spl_comm_create(const uint8_t id[SPL_COMM_ID_BYTES], int rank, int world, int device);
+void spl_comm_destroy(spl_comm* c);
+int spl_comm_rank(const spl_comm* c);
+int spl_comm_world(const spl_comm* c);
+int spl_allgather_slabs(spl_comm* c, const uint32_t* d_send, uint32_t* d_recv, uint64_t words_per_rank, void* hip_stream);
+int spl_allgatherv_csr(spl_comm* c, const uint32_t* d_ids, const uint64_t* d_out_off, uint64_t n_docs, uint32_t* d_all_ids,
+                       uint64_t all_ids_cap, uint64_t* d_all_off, uint64_t all_off_cap, uint64_t* n_tokens_total,
+                       uint64_t* n_docs_total, void* hip_stream);
 
 /* Tokenizer::decode_bytes for a batch (src/core/tokenizer.rs:877-897, 944-958), HOST buffers:
  * ids CSR in, bytes CSR out.  An id of the vocabulary gives its token's bytes (ByteLevel: decoded

@@ -26,6 +26,8 @@ SYMBOLS = [
     "spl_debug_phases", "spl_debug_blocks", "spl_gatherv_pack", "spl_gatherv_unpack", "spl_gatherv_unpack_group", "spl_encode_batch_device_packed",
     "spl_set_devices", "spl_n_devices", "spl_set_option", "spl_host_alloc", "spl_host_free",
     "spl_token_bytes", "spl_is_byte_level",
+    "spl_comm_unique_id", "spl_comm_create", "spl_comm_destroy", "spl_comm_rank", "spl_comm_world",
+    "spl_allgather_slabs", "spl_allgatherv_csr",
 ]
 SPL_OPT_BYTE_LEVEL = 1
 
@@ -111,6 +113,16 @@ def lib() -> ctypes.CDLL:
                                                  ctypes.c_uint64, vp, vp, ctypes.c_uint64, ctypes.c_uint64, vp]
     L.spl_gatherv_unpack_group.argtypes = [vp, vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64,
                                            ctypes.c_uint64, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp]
+    L.spl_comm_unique_id.argtypes = [ctypes.c_char_p]
+    L.spl_comm_create.restype = vp
+    L.spl_comm_create.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.spl_comm_destroy.restype = None
+    L.spl_comm_destroy.argtypes = [vp]
+    L.spl_comm_rank.argtypes = [vp]
+    L.spl_comm_world.argtypes = [vp]
+    L.spl_allgather_slabs.argtypes = [vp, vp, vp, ctypes.c_uint64, vp]
+    L.spl_allgatherv_csr.argtypes = [vp, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, ctypes.c_uint64,
+                                     u64p, u64p, vp]
     _lib = L
     return L
 

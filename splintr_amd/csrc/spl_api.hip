@@ -18,6 +18,7 @@
 #include "../../include/splintr_hip.h"
 #include "spl_kernels.hip"
 #include "spl_tables.h"
+#include "spl_comm.h"
 
 using namespace spl;
 
@@ -258,6 +259,15 @@ struct spl_tokenizer {
     uint32_t est_div = 2;                     // first guess of the token count: n_bytes / est_div
     int subdoc = 1;                           // cut documents at context-free boundaries to balance the GPUs
     int direct_write = 1;                     // one-chunk batches: the last kernel writes the ids straight into the pinned result
+};
+
+// One rank of a node-wide communicator (one process per GPU; RCCL over xGMI).
+struct spl_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1, device = 0;
+    uint64_t* d_cnt = nullptr;        // [2] this rank's {T, N}
+    uint64_t* d_cnts = nullptr;       // [2 * world] every rank's
+    uint64_t* h_cnts = nullptr;       // pinned copy
 };
 
 struct spl_result {
@@ -1009,6 +1019,74 @@ template <class T> int grow(T** p, uint64_t* cap, uint64_t need) {
 }  // namespace
 
 namespace {
+#define NCCL_TRY(expr)                                                                             \
+    do {                                                                                           \
+        ncclResult_t r_ = (expr);                                                                  \
+        if (r_ != ncclSuccess)                                                                     \
+            return fail(SPL_EDEVICE, std::string(#expr) + ": " + rccl().GetErrorString(r_));       \
+    } while (0)
+
+int comm_create(const uint8_t* id, int rank, int world, int device, spl_comm** out) {
+    Rccl& R = rccl();
+    if (!R.lib) return fail(SPL_EDEVICE, "spl_comm_create: " + R.err);
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<spl_comm> c(new spl_comm());
+    c->rank = rank; c->world = world; c->device = device;
+    ncclUniqueId uid;
+    static_assert(sizeof uid.internal == SPL_COMM_ID_BYTES, "SPL_COMM_ID_BYTES must be RCCL's NCCL_UNIQUE_ID_BYTES");
+    memcpy(uid.internal, id, SPL_COMM_ID_BYTES);
+    NCCL_TRY(R.CommInitRank(&c->comm, world, uid, rank));
+    HIP_TRY(hipMalloc((void**)&c->d_cnt, 16));
+    HIP_TRY(hipMalloc((void**)&c->d_cnts, 16 * (size_t)world));
+    HIP_TRY(hipHostMalloc((void**)&c->h_cnts, 16 * (size_t)world, hipHostMallocPortable));
+    *out = c.release();
+    return SPL_OK;
+}
+
+int allgatherv_csr(spl_comm* c, const uint32_t* d_ids, const uint64_t* d_out_off, uint64_t n_docs, uint32_t* d_all_ids,
+                   uint64_t all_ids_cap, uint64_t* d_all_off, uint64_t all_off_cap, uint64_t* n_tokens_total, uint64_t* n_docs_total,
+                   hipStream_t s) {
+    Rccl& R = rccl();
+    HIP_TRY(hipSetDevice(c->device));
+    const int W = c->world;
+    // (1) every rank's {T, N}: 16 bytes per rank, then the one host synchronisation of the exchange
+    hipLaunchKernelGGL(k_csr_counts, dim3(1), dim3(64), 0, s, d_out_off, n_docs, c->d_cnt);
+    NCCL_TRY(R.AllGather(c->d_cnt, c->d_cnts, 2, ncclUint64, c->comm, s));
+    HIP_TRY(hipMemcpyAsync(c->h_cnts, c->d_cnts, 16 * (size_t)W, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    RankTable tab{};
+    for (int p = 0; p < W; p++) {
+        tab.t_pre[p + 1] = tab.t_pre[p] + c->h_cnts[2 * p];
+        tab.n_pre[p + 1] = tab.n_pre[p] + c->h_cnts[2 * p + 1];
+    }
+    if (n_tokens_total) *n_tokens_total = tab.t_pre[W];
+    if (n_docs_total) *n_docs_total = tab.n_pre[W];
+    // (every rank sees the same totals, so every rank takes the same branch: nobody is left waiting in a collective)
+    if (tab.t_pre[W] > all_ids_cap || tab.n_pre[W] + 1 > all_off_cap)
+        return fail(SPL_ECAPACITY, "spl_allgatherv_csr: the global CSR does not fit the buffers given (" + std::to_string(tab.t_pre[W]) +
+                                   " tokens, " + std::to_string(tab.n_pre[W]) + " documents)");
+    // (2) exactly T_r ids and N_r offsets from every rank, each straight to its place: one message per peer and
+    // direction, all links busy at once (xGMI is point to point; no ring, no padding)
+    const uint64_t T = c->h_cnts[2 * c->rank], N = c->h_cnts[2 * c->rank + 1];
+    NCCL_TRY(R.GroupStart());
+    for (int p = 0; p < W; p++) {
+        if (T) NCCL_TRY(R.Send(d_ids, T, ncclUint32, p, c->comm, s));
+        if (N) NCCL_TRY(R.Send(d_out_off, N, ncclUint64, p, c->comm, s));
+        const uint64_t Tp = c->h_cnts[2 * p], Np = c->h_cnts[2 * p + 1];
+        if (Tp) NCCL_TRY(R.Recv(d_all_ids + tab.t_pre[p], Tp, ncclUint32, p, c->comm, s));
+        if (Np) NCCL_TRY(R.Recv(d_all_off + tab.n_pre[p], Np, ncclUint64, p, c->comm, s));
+    }
+    NCCL_TRY(R.GroupEnd());
+    // (3) local offsets -> offsets in the global id array, and the closing entry
+    const uint64_t nmax = [&] { uint64_t m = 1; for (int p = 0; p < W; p++) m = std::max<uint64_t>(m, c->h_cnts[2 * p + 1]); return m; }();
+    hipLaunchKernelGGL(k_rebase_offsets, dim3((uint32_t)std::min<uint64_t>((nmax + 255) / 256, 1024), (uint32_t)W), dim3(256), 0, s,
+                       d_all_off, tab, (uint32_t)W);
+    HIP_TRY(hipGetLastError());
+    return SPL_OK;
+}
+}  // namespace
+
+namespace {
 // No exception crosses the C ABI: every entry point that allocates (std::bad_alloc), starts threads or grows
 // containers runs inside this guard and reports SPL_EDEVICE instead.
 template <class F> int guarded(const char* what, F f) {
@@ -1421,5 +1499,52 @@ int spl_decode_batch(spl_tokenizer* t, const uint32_t* ids, const uint64_t* ids_
     return guarded("spl_decode_batch", [&] { return spl_decode_batch_impl(t, ids, ids_off, n_docs, out_bytes, out_off); });
 }
 
+int spl_comm_unique_id(uint8_t id_out[SPL_COMM_ID_BYTES]) {
+    if (!id_out) return fail(SPL_EINVAL, "spl_comm_unique_id: null argument");
+    return guarded("spl_comm_unique_id", [&] {
+        Rccl& R = rccl();
+        if (!R.lib) return fail(SPL_EDEVICE, "spl_comm_unique_id: " + R.err);
+        ncclUniqueId uid;
+        NCCL_TRY(R.GetUniqueId(&uid));
+        memcpy(id_out, uid.internal, SPL_COMM_ID_BYTES);
+        return SPL_OK;
+    });
+}
+spl_comm* spl_comm_create(const uint8_t id[SPL_COMM_ID_BYTES], int rank, int world, int device) {
+    if (!id || world < 1 || world > COMM_MAX_WORLD || rank < 0 || rank >= world) { fail(SPL_EINVAL, "spl_comm_create: bad argument"); return nullptr; }
+    spl_comm* c = nullptr;
+    if (guarded("spl_comm_create", [&] { return comm_create(id, rank, world, device, &c); }) != SPL_OK) return nullptr;
+    return c;
+}
+void spl_comm_destroy(spl_comm* c) {
+    if (!c) return;
+    if (hipSetDevice(c->device) == hipSuccess) {
+        (void)hipDeviceSynchronize();
+        if (c->comm) (void)rccl().CommDestroy(c->comm);
+        (void)hipFree(c->d_cnt); (void)hipFree(c->d_cnts); (void)hipHostFree(c->h_cnts);
+    }
+    delete c;
+}
+int spl_comm_rank(const spl_comm* c) { return c ? c->rank : -1; }
+int spl_comm_world(const spl_comm* c) { return c ? c->world : 0; }
+int spl_allgather_slabs(spl_comm* c, const uint32_t* d_send, uint32_t* d_recv, uint64_t words_per_rank, void* hip_stream) {
+    if (!c || !d_send || !d_recv) return fail(SPL_EINVAL, "spl_allgather_slabs: null argument");
+    return guarded("spl_allgather_slabs", [&] {
+        HIP_TRY(hipSetDevice(c->device));
+        NCCL_TRY(rccl().AllGather(d_send, d_recv, words_per_rank, ncclUint32, c->comm, (hipStream_t)hip_stream));
+        return SPL_OK;
+    });
+}
+int spl_allgatherv_csr(spl_comm* c, const uint32_t* d_ids, const uint64_t* d_out_off, uint64_t n_docs, uint32_t* d_all_ids,
+                       uint64_t all_ids_cap, uint64_t* d_all_off, uint64_t all_off_cap, uint64_t* n_tokens_total,
+                       uint64_t* n_docs_total, void* hip_stream) {
+    if (!c || !d_out_off || !d_all_ids || !d_all_off) return fail(SPL_EINVAL, "spl_allgatherv_csr: null argument");
+    return guarded("spl_allgatherv_csr", [&] {
+        return allgatherv_csr(c, d_ids, d_out_off, n_docs, d_all_ids, all_ids_cap, d_all_off, all_off_cap, n_tokens_total, n_docs_total,
+                              (hipStream_t)hip_stream);
+    });
+}
+
 }  // extern "C"
+
 

@@ -3662,4 +3662,20 @@ __global__ void k_gatherv_unpack(const uint32_t* slabs_all, uint32_t world, uint
         if (tbase + k < all_ids_cap) all_ids[tbase + k] = slab[ids_at + k];
 }
 
+// Exact ragged all-gather (spl_allgatherv_csr): every rank's {T, N} travel first, then exactly T ids and N
+// offsets per rank land at their place of the global CSR by grouped send / recv.  These two kernels are the
+// device side: the counts as the collective's input, and the received LOCAL offsets rebased by the tokens of the
+// ranks before (+ the closing entry).
+constexpr int COMM_MAX_WORLD = 64;
+struct RankTable { uint64_t n_pre[COMM_MAX_WORLD + 1], t_pre[COMM_MAX_WORLD + 1]; };
+__global__ void k_csr_counts(const uint64_t* out_off, uint64_t n_docs, uint64_t* cnt) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { cnt[0] = out_off[n_docs]; cnt[1] = n_docs; }
+}
+__global__ void k_rebase_offsets(uint64_t* all_off, RankTable tab, uint32_t world) {
+    const uint32_t r = blockIdx.y;
+    const uint64_t lo = tab.n_pre[r], hi = tab.n_pre[r + 1], add = tab.t_pre[r];
+    for (uint64_t d = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; d < hi; d += (uint64_t)gridDim.x * blockDim.x) all_off[d] += add;
+    if (r == world - 1 && blockIdx.x == 0 && threadIdx.x == 0) all_off[tab.n_pre[world]] = tab.t_pre[world];
+}
+
 }  // namespace spl

@@ -5,6 +5,7 @@ PyTorch is plumbing here (device memory, streams, torch.distributed); the work i
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Sequence, Tuple
 
 import numpy as np
@@ -53,12 +54,70 @@ def result_csr(batch: DeviceBatch) -> Tuple[np.ndarray, np.ndarray]:
     return ids, off
 
 
+class Comm:
+    """One rank of the library's own RCCL communicator (include/splintr_hip.h: spl_comm_*).  The 128-byte id is
+    made by rank 0 and handed to the others by whatever the caller has; `from_torch_group` uses an existing
+    torch.distributed group (any backend: it only carries 128 bytes) for that."""
+
+    def __init__(self, unique_id: bytes, rank: int, world: int, device: int):
+        L = _ffi.lib()
+        self._h = L.spl_comm_create(unique_id, rank, world, device)
+        if not self._h:
+            raise RuntimeError(f"spl_comm_create failed: {_ffi.last_error()}")
+        self.rank, self.world, self.device = rank, world, device
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        if _ffi.lib().spl_comm_unique_id(buf) != 0:
+            raise RuntimeError(f"spl_comm_unique_id failed: {_ffi.last_error()}")
+        return buf.raw
+
+    @classmethod
+    def from_torch_group(cls, device: torch.device, group=None) -> "Comm":
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(box[0], rank, world, device.index if device.index is not None else torch.cuda.current_device())
+
+    @property
+    def handle(self) -> int:
+        return self._h
+
+    def allgatherv_csr(self, ids: torch.Tensor, out_off: torch.Tensor, n_docs: int, all_ids: torch.Tensor,
+                       all_off: torch.Tensor) -> Tuple[int, int]:
+        """spl_allgatherv_csr on torch's current stream: exactly T_r ids and N_r offsets per rank, straight to
+        their place of the global CSR.  Returns (total tokens, total documents); one host synchronisation."""
+        nt, nd = ctypes.c_uint64(), ctypes.c_uint64()
+        stream = torch.cuda.current_stream(ids.device).cuda_stream
+        rc = _ffi.lib().spl_allgatherv_csr(self._h, ids.data_ptr(), out_off.data_ptr(), n_docs, all_ids.data_ptr(),
+                                           all_ids.numel(), all_off.data_ptr(), all_off.numel(), ctypes.byref(nt),
+                                           ctypes.byref(nd), stream)
+        if rc != 0:
+            raise RuntimeError(f"spl_allgatherv_csr failed ({rc}): {_ffi.last_error()}")
+        return int(nt.value), int(nd.value)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            _ffi.lib().spl_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class GatherV:
     """Pipelined, bucketed ragged all-gather of per-rank CSR results.
 
     Every batch is packed into a slab right after its encode (HIP kernel, same stream).  `depth`
     consecutive slabs form one bucket; a full bucket is handed to an exchange stream of its own:
-    ONE all_gather_into_tensor of world x depth equal slabs (RCCL over xGMI) and ONE unpack launch
+    ONE all-gather of world x depth equal slabs (RCCL over xGMI: spl_allgather_slabs on the library's own
+    communicator when `comm` is given, torch.distributed's all_gather_into_tensor otherwise) and ONE unpack launch
     that rebuilds the global CSR of each of the bucket's batches on every rank.  Two bucket SETS
     alternate -- each with its own send, receive and result buffers -- so the exchange of one bucket
     overlaps the encodes of the next and no cross-stream wait sits between two encodes.  Fewer,
@@ -73,10 +132,11 @@ class GatherV:
     and returns the views of the LAST submitted batch.  No host synchronisation per batch.
     """
 
-    def __init__(self, tok: Tokenizer, device: torch.device, max_docs: int, max_tokens: int, group=None, depth: int = 8):
+    def __init__(self, tok: Tokenizer, device: torch.device, max_docs: int, max_tokens: int, group=None, depth: int = 8,
+                 comm: "Comm" = None):
         import torch.distributed as dist
-        self.tok, self.dev, self.group, self.dist = tok, device, group, dist
-        self.world = dist.get_world_size(group)
+        self.tok, self.dev, self.group, self.dist, self.comm = tok, device, group, dist, comm
+        self.world = comm.world if comm is not None else dist.get_world_size(group)
         self.depth = int(depth)
         self.max_docs = int(max_docs)
         self.max_tokens = int(max_tokens)
@@ -148,6 +208,17 @@ class GatherV:
         if rc != 0:
             raise RuntimeError(_ffi.last_error())
 
+    def _allgather(self, s) -> None:
+        """world x depth slabs, on the exchange stream (current here)."""
+        if self.comm is not None:             # the collective behind the C ABI (librccl bound by the library)
+            rc = _ffi.lib().spl_allgather_slabs(self.comm.handle, self.send[s].data_ptr(), self.recv[s].data_ptr(),
+                                                self.depth * self.cap_words, self.exch.cuda_stream)
+            if rc != 0:
+                raise RuntimeError(f"spl_allgather_slabs failed ({rc}): {_ffi.last_error()}")
+            return
+        work = self.dist.all_gather_into_tensor(self.recv[s], self.send[s], group=self.group, async_op=True)
+        work.wait()                           # the exchange stream (not the encode stream) waits for the collective
+
     def submit(self, batch: "DeviceBatch") -> None:
         """Pack `batch`'s current result into the open bucket (call right after encode_device on the
         same stream); a full bucket goes out."""
@@ -172,8 +243,7 @@ class GatherV:
         self.packed[s].record(main)
         with self._stream_ctx(self.exch):
             self.exch.wait_event(self.packed[s])
-            work = self.dist.all_gather_into_tensor(self.recv[s], self.send[s], group=self.group, async_op=True)
-            work.wait()                       # the exchange stream (not the encode stream) waits for the collective
+            self._allgather(s)
             self._unpack(s, n, self.exch.cuda_stream)
             if self.on_bucket is not None:
                 self.on_bucket([self._views(s, j) for j in range(n)])

@@ -73,3 +73,63 @@ def test_gatherv_pipeline_one_rank_rccl(coracle):
         assert small.overflowed()
     finally:
         dist.destroy_process_group()
+
+
+def test_collective_behind_the_c_abi_one_rank(coracle):
+    """spl_comm_* / spl_allgather_slabs / spl_allgatherv_csr (include/splintr_hip.h) on a one-rank communicator the
+    LIBRARY creates (librccl bound by dlopen, no torch.distributed anywhere): the bucketed GatherV pipeline through
+    spl_allgather_slabs and the exact all-gatherv (counts, then send/recv of exactly T ids and N offsets -- to
+    itself here) against the oracle."""
+    import torch
+    from splintr_amd import Tokenizer, corpus, _ffi
+    from splintr_amd.device import Comm, DeviceBatch, GatherV, encode_device, reserve
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    comm = Comm(Comm.unique_id(), 0, 1, 0)
+    try:
+        L = _ffi.lib()
+        assert L.spl_comm_rank(comm.handle) == 0 and L.spl_comm_world(comm.handle) == 1
+        tok = Tokenizer.from_pretrained("o200k_base")
+        sets = [corpus.c3(40, seed=70 + k) + ["", "x"] for k in range(3)]
+        batches = [DeviceBatch(t, dev) for t in sets]
+        reserve(tok, max(b.n_bytes for b in batches), max(b.n_docs for b in batches))
+        want = [oracle_csr(coracle("o200k_base"), t) for t in sets]
+        gv = GatherV(tok, dev, max_docs=max(b.n_docs for b in batches), max_tokens=max(int(w[1][-1]) for w in want) + 64,
+                     depth=2, comm=comm)
+        got = []
+        gv.on_bucket = lambda res: got.extend((i.clone(), o.clone()) for i, o in res)
+        order = [0, 1, 2, 1, 0]
+        for k in order:
+            gv.encode_and_submit(batches[k])
+        gv.finish()
+        torch.cuda.synchronize()
+        assert not gv.overflowed() and len(got) == len(order)
+        for (g_ids, g_off), k in zip(got, order):
+            w_ids, w_off = want[k]
+            assert np.array_equal(g_off[:batches[k].n_docs + 1].cpu().numpy().astype(np.uint64), w_off)
+            assert np.array_equal(g_ids[:int(w_off[-1])].cpu().numpy().view(np.uint32), w_ids)
+        # the exact form
+        for k in (2, 0):
+            b = batches[k]
+            w_ids, w_off = want[k]
+            encode_device(tok, b)
+            all_ids = torch.full((int(w_off[-1]) + 7,), -1, dtype=torch.int32, device=dev)
+            all_off = torch.full((b.n_docs + 1,), -1, dtype=torch.int64, device=dev)
+            nt, nd = comm.allgatherv_csr(b.ids, b.out_off, b.n_docs, all_ids, all_off)
+            torch.cuda.synchronize()
+            assert (nt, nd) == (int(w_off[-1]), b.n_docs)
+            assert np.array_equal(all_ids[:nt].cpu().numpy().view(np.uint32), w_ids)
+            assert np.array_equal(all_off.cpu().numpy().astype(np.uint64), w_off)
+            assert int(all_ids[nt].item()) == -1                      # nothing written behind the last token
+        # buffers that cannot hold the result: refused with SPL_ECAPACITY, nothing hangs
+        with pytest.raises(RuntimeError, match="does not fit"):
+            comm.allgatherv_csr(batches[0].ids, batches[0].out_off, batches[0].n_docs,
+                                torch.empty(8, dtype=torch.int32, device=dev), torch.empty(4, dtype=torch.int64, device=dev))
+        # an empty shard
+        e = DeviceBatch([], dev)
+        encode_device(tok, e)
+        nt, nd = comm.allgatherv_csr(e.ids, e.out_off, 0, torch.empty(8, dtype=torch.int32, device=dev),
+                                     torch.full((1,), -1, dtype=torch.int64, device=dev))
+        assert (nt, nd) == (0, 0)
+    finally:
+        comm.close()

@@ -16,6 +16,7 @@ import numpy as np  # noqa: E402
 
 CONFIGS = {
     "c2": ("cl100k_base", "c2", 1000),
+    "c2_wide": ("cl100k_base", "c2_wide", 1000),       # C2's mix over a >= 20 000-word lexicon (natural miss rates)
     "c3": ("o200k_base", "c3", 10000),
     "c4": ("llama3", "c4", 250000),
     "c5": ("deepseek_v3", "c5", 25),
@@ -76,6 +77,26 @@ def measure(cfg: str, docs=None, python_surface=True, devices=None, options=None
     ctypes.memmove(p, blob, nb)
     out["c_abi_host"] = round(nb / timed(c_abi(p)) / 1e6, 1)
     L.spl_host_free(p)
+
+    # (2b) decode_batch: ids CSR on the host -> bytes CSR on the host, MB/s of OUTPUT bytes
+    r = ctypes.c_void_p()
+    assert L.spl_encode_batch(tok.handle, blob, off.ctypes.data, len(bs), 0, ctypes.byref(r)) == 0, _ffi.last_error()
+    nt = L.spl_result_n_tokens(r)
+    ids = np.ctypeslib.as_array(L.spl_result_tokens(r), shape=(max(nt, 1),))[:nt].copy()
+    ioff = np.ctypeslib.as_array(L.spl_result_offsets(r), shape=(len(bs) + 1,)).copy()
+    L.spl_result_free(r)
+    pin = L.spl_host_alloc(ids.nbytes + 64)
+    ctypes.memmove(pin, ids.ctypes.data, ids.nbytes)
+
+    def dec():
+        ob, oo = ctypes.POINTER(ctypes.c_uint8)(), ctypes.POINTER(ctypes.c_uint64)()
+        rc = L.spl_decode_batch(tok.handle, pin, ioff.ctypes.data, len(bs), ctypes.byref(ob), ctypes.byref(oo))
+        assert rc == 0, _ffi.last_error()
+        assert oo[len(bs)] == nb
+        L.spl_free(ob)
+        L.spl_free(oo)
+    out["decode_host"] = round(nb / timed(dec) / 1e6, 1)
+    L.spl_host_free(pin)
 
     # (3) Python surface
     if python_surface:
