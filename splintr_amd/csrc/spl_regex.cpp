@@ -1,0 +1,529 @@
+// spl_regex.cpp -- restricted regex compiler + backtracking matcher of the host splitter (spl_regex.h).
+#include "spl_regex.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace spl {
+namespace {
+
+constexpr uint32_t CP_INVALID = 0xFFFFFFFFu;     // a byte sequence that is no character: class "other", equals no literal
+
+struct ClassSet {
+    uint32_t codes = 0;                                   // bit c: every code point of class code c (spl_common.h C_*)
+    std::vector<std::pair<uint32_t, uint32_t>> ranges;    // inclusive code-point ranges
+    bool neg = false;
+};
+
+enum Op : uint8_t { OP_CHAR, OP_CHAR_FOLD, OP_CLASS, OP_ANY, OP_SPLIT, OP_JMP, OP_MATCH, OP_LOOK, OP_NLOOK };
+struct Inst { Op op; uint32_t x, y; };                  // CHAR: x = cp; CLASS: x = set; SPLIT: x first, y second; JMP: x;
+                                                          // LOOK / NLOOK: sub-program at pc + 1 (ends in MATCH), x = continuation
+
+struct Node {
+    enum Kind { CHAR, CLASS, ANY, CAT, ALT, REP, LOOK, EMPTY } kind = EMPTY;
+    uint32_t cp = 0; bool fold = false;                  // CHAR
+    uint32_t set = 0;                                    // CLASS
+    std::vector<std::unique_ptr<Node>> kids;             // CAT / ALT; REP, LOOK: one
+    uint32_t lo = 0, hi = 0; bool lazy = false;          // REP: hi == UINT32_MAX: unbounded
+    bool neg = false;                                    // LOOK
+};
+
+}  // namespace
+
+struct RegexProg {
+    std::vector<Inst> code;
+    std::vector<ClassSet> sets;
+    const HostTables* ht = nullptr;
+};
+void RegexDeleter::operator()(RegexProg* p) const { delete p; }
+
+namespace {
+
+struct Parser {
+    const std::string& s;
+    size_t i = 0;
+    std::string err;
+    RegexProg& prog;
+    Parser(const std::string& p, RegexProg& pr) : s(p), prog(pr) {}
+
+    bool fail(const std::string& what, size_t at) {
+        if (err.empty()) err = "unsupported or malformed construct in the split pattern at byte " + std::to_string(at) + ": " + what;
+        return false;
+    }
+    bool eof() const { return i >= s.size(); }
+
+    // one code point of the PATTERN text (which is valid UTF-8: it comes from a str)
+    bool next_cp(uint32_t& cp) {
+        const uint8_t b = (uint8_t)s[i];
+        uint32_t len = b < 0x80 ? 1 : b < 0xE0 ? 2 : b < 0xF0 ? 3 : 4;
+        if (b >= 0x80 && b < 0xC0) return fail("stray UTF-8 continuation byte in the pattern", i);
+        if (i + len > s.size()) return fail("truncated UTF-8 in the pattern", i);
+        cp = len == 1 ? b : b & (0xFFu >> (len + 1));
+        for (uint32_t k = 1; k < len; k++) cp = (cp << 6) | ((uint8_t)s[i + k] & 0x3Fu);
+        i += len;
+        return true;
+    }
+
+    bool property(ClassSet& cs, bool negate_item, size_t at) {            // after \p or \P: {Name} or a single letter
+        std::string name;
+        if (!eof() && s[i] == '{') {
+            const size_t e = s.find('}', i);
+            if (e == std::string::npos) return fail("\\p{ without }", at);
+            name = s.substr(i + 1, e - i - 1);
+            i = e + 1;
+        } else if (!eof()) name = std::string(1, s[i++]);
+        bool inner_neg = false;
+        if (!name.empty() && name[0] == '^') { inner_neg = true; name = name.substr(1); }
+        uint32_t m = 0;
+        if (name == "L" || name == "Letter") m = M_L;
+        else if (name == "Lu") m = SPL_BIT(C_LU);
+        else if (name == "Ll") m = SPL_BIT(C_LL);
+        else if (name == "Lt") m = SPL_BIT(C_LT);
+        else if (name == "Lm") m = SPL_BIT(C_LM);
+        else if (name == "Lo") m = SPL_BIT(C_LO);
+        else if (name == "M" || name == "Mark") m = SPL_BIT(C_M);
+        else if (name == "N" || name == "Number") m = SPL_BIT(C_N);
+        else return fail("\\p{" + name + "}: the class table knows L, Lu, Ll, Lt, Lm, Lo, M and N (and \\s)", at);
+        if (negate_item != inner_neg) m = ~m & ((1u << C_EOT) - 1u);
+        cs.codes |= m;
+        return true;
+    }
+
+    // escape after the backslash.  in_class: inside [...].  Either a single code point (is_cp) or a class item
+    // added to `cs`.
+    bool escape(bool in_class, bool& is_cp, uint32_t& cp, ClassSet& cs, size_t at) {
+        if (eof()) return fail("pattern ends in a backslash", at);
+        const char c = s[i++];
+        is_cp = true;
+        switch (c) {
+            case 'r': cp = '\r'; return true;
+            case 'n': cp = '\n'; return true;
+            case 't': cp = '\t'; return true;
+            case 'f': cp = '\f'; return true;
+            case 'v': cp = 0x0B; return true;
+            case 'e': cp = 0x1B; return true;
+            case 'a': cp = 0x07; return true;
+            case '0': cp = 0; return true;
+            case 'x': case 'u': {
+                uint32_t v = 0; int nd = 0;
+                if (!eof() && s[i] == '{') {
+                    const size_t e = s.find('}', i);
+                    if (e == std::string::npos) return fail("\\x{ without }", at);
+                    for (size_t k = i + 1; k < e; k++, nd++) {
+                        const int h = std::isxdigit((unsigned char)s[k]) ? (std::isdigit((unsigned char)s[k]) ? s[k] - '0' : (s[k] | 0x20) - 'a' + 10) : -1;
+                        if (h < 0) return fail("bad hex digit in \\x{...}", at);
+                        v = v * 16 + (uint32_t)h;
+                    }
+                    i = e + 1;
+                } else {
+                    const int want = c == 'x' ? 2 : 4;
+                    for (; nd < want && !eof() && std::isxdigit((unsigned char)s[i]); nd++, i++)
+                        v = v * 16 + (uint32_t)(std::isdigit((unsigned char)s[i]) ? s[i] - '0' : (s[i] | 0x20) - 'a' + 10);
+                    if (nd != want) return fail("\\x / \\u need 2 / 4 hex digits", at);
+                }
+                if (nd == 0 || v > 0x10FFFF) return fail("code point out of range", at);
+                cp = v;
+                return true;
+            }
+            case 's': is_cp = false; cs.codes |= M_S; return true;
+            case 'S': is_cp = false; cs.codes |= ~M_S & ((1u << C_EOT) - 1u); return true;
+            case 'p': is_cp = false; return property(cs, false, at);
+            case 'P': is_cp = false; return property(cs, true, at);
+            default: break;
+        }
+        if (std::isalnum((unsigned char)c))
+            return fail(std::string("\\") + c + " (anchors, \\b, \\d, \\w, back-references and the other letter escapes are not implemented; "
+                        "\\d and \\w would need Nd / Pc, which the class table does not single out)", at);
+        if ((uint8_t)c >= 0x80) { i--; return next_cp(cp); }            // an escaped non-ASCII character: itself
+        cp = (uint8_t)c;                                                // escaped punctuation
+        (void)in_class;
+        return true;
+    }
+
+    std::unique_ptr<Node> char_node(uint32_t cp, bool fold) {
+        auto n = std::make_unique<Node>();
+        n->kind = Node::CHAR; n->cp = cp;
+        n->fold = fold && cp < 0x80 && std::isalpha((int)cp);
+        return n;
+    }
+    std::unique_ptr<Node> set_node(ClassSet&& cs) {
+        auto n = std::make_unique<Node>();
+        n->kind = Node::CLASS; n->set = (uint32_t)prog.sets.size();
+        prog.sets.push_back(std::move(cs));
+        return n;
+    }
+
+    std::unique_ptr<Node> bracket(bool fold, size_t at) {                // after '['
+        ClassSet cs;
+        if (!eof() && s[i] == '^') { cs.neg = true; i++; }
+        bool first = true;
+        for (;;) {
+            if (eof()) { fail("[ without ]", at); return nullptr; }
+            if (s[i] == ']' && !first) { i++; break; }
+            first = false;
+            if (s[i] == '[' && i + 1 < s.size() && s[i + 1] == ':') { fail("POSIX classes [:name:]", i); return nullptr; }
+            uint32_t lo;
+            bool is_cp = true;
+            const size_t item_at = i;
+            if (s[i] == '\\') { i++; if (!escape(true, is_cp, lo, cs, item_at)) return nullptr; }
+            else if (!next_cp(lo)) return nullptr;
+            if (!is_cp) continue;
+            uint32_t hi = lo;
+            if (i + 1 < s.size() && s[i] == '-' && s[i + 1] != ']') {
+                i++;
+                bool hi_cp = true;
+                ClassSet dummy;
+                if (s[i] == '\\') { i++; if (!escape(true, hi_cp, hi, dummy, item_at)) return nullptr; if (!hi_cp) { fail("a class escape as the end of a range", item_at); return nullptr; } }
+                else if (!next_cp(hi)) return nullptr;
+                if (hi < lo) { fail("range out of order", item_at); return nullptr; }
+            }
+            if (fold) {
+                for (uint32_t c = lo; c <= hi && c < 0x80; c++)
+                    if (std::isalpha((int)c)) { fail("letters in a bracket class under (?i)", item_at); return nullptr; }
+                if (hi >= 0x80) { fail("non-ASCII characters in a bracket class under (?i)", item_at); return nullptr; }
+            }
+            cs.ranges.emplace_back(lo, hi);
+        }
+        return set_node(std::move(cs));
+    }
+
+    std::unique_ptr<Node> atom(bool& fold) {
+        const size_t at = i;
+        const char c = s[i];
+        if (c == '(') {
+            i++;
+            bool sub_fold = fold;
+            bool look = false, neg = false;
+            if (!eof() && s[i] == '?') {
+                i++;
+                if (eof()) { fail("(? at the end", at); return nullptr; }
+                if (s[i] == ':') i++;
+                else if (s[i] == '=') { i++; look = true; }
+                else if (s[i] == '!') { i++; look = true; neg = true; }
+                else if (s[i] == 'i' && i + 1 < s.size() && s[i + 1] == ':') { i += 2; sub_fold = true; }
+                else if (s[i] == 'i' && i + 1 < s.size() && s[i + 1] == ')') {     // (?i): the rest of the enclosing group
+                    i += 2;
+                    fold = true;
+                    auto n = std::make_unique<Node>();
+                    n->kind = Node::EMPTY;
+                    return n;
+                }
+                else if (s[i] == '<' && i + 1 < s.size() && (s[i + 1] == '=' || s[i + 1] == '!')) { fail("look-behind", at); return nullptr; }
+                else if (s[i] == '>') { fail("atomic group (?>", at); return nullptr; }
+                else if (s[i] == '<' || s[i] == 'P' || s[i] == '\'') {             // named group: groups only
+                    const char close = s[i] == '\'' ? '\'' : '>';
+                    const size_t e = s.find(close, i + 1);
+                    if (e == std::string::npos) { fail("unterminated group name", at); return nullptr; }
+                    i = e + 1;
+                }
+                else { fail(std::string("group option (?") + s[i], at); return nullptr; }
+            }
+            auto inner = alternation(sub_fold);
+            if (!inner) return nullptr;
+            if (eof() || s[i] != ')') { fail("( without )", at); return nullptr; }
+            i++;
+            if (look) {
+                auto n = std::make_unique<Node>();
+                n->kind = Node::LOOK; n->neg = neg;
+                n->kids.push_back(std::move(inner));
+                return n;
+            }
+            return inner;
+        }
+        if (c == '[') { i++; return bracket(fold, at); }
+        if (c == '.') {
+            i++;
+            auto n = std::make_unique<Node>();
+            n->kind = Node::ANY;
+            return n;
+        }
+        if (c == '^' || c == '$') { fail(std::string("anchor ") + c, at); return nullptr; }
+        if (c == '*' || c == '+' || c == '?' || c == '{') { fail(std::string("quantifier ") + c + " without an operand", at); return nullptr; }
+        if (c == '\\') {
+            i++;
+            bool is_cp;
+            uint32_t cp = 0;
+            ClassSet cs;
+            if (!escape(false, is_cp, cp, cs, at)) return nullptr;
+            if (is_cp) return char_node(cp, fold);
+            return set_node(std::move(cs));
+        }
+        uint32_t cp;
+        if (!next_cp(cp)) return nullptr;
+        if (fold && cp >= 0x80) { fail("non-ASCII literal under (?i) (only ASCII case pairs, U+017F and U+212A are folded)", at); return nullptr; }
+        return char_node(cp, fold);
+    }
+
+    static bool nullable(const Node& n) {
+        switch (n.kind) {
+            case Node::CHAR: case Node::CLASS: case Node::ANY: return false;
+            case Node::EMPTY: case Node::LOOK: return true;
+            case Node::CAT: for (auto& k : n.kids) if (!nullable(*k)) return false; return true;
+            case Node::ALT: for (auto& k : n.kids) if (nullable(*k)) return true; return false;
+            case Node::REP: return n.lo == 0 || nullable(*n.kids[0]);
+        }
+        return true;
+    }
+
+    std::unique_ptr<Node> repeat(bool& fold) {
+        auto a = atom(fold);
+        if (!a) return nullptr;
+        while (!eof()) {
+            const size_t at = i;
+            uint32_t lo, hi;
+            const char c = s[i];
+            if (c == '?') { lo = 0; hi = 1; i++; }
+            else if (c == '*') { lo = 0; hi = UINT32_MAX; i++; }
+            else if (c == '+') { lo = 1; hi = UINT32_MAX; i++; }
+            else if (c == '{') {
+                size_t k = i + 1;
+                auto num = [&](uint32_t& v) { size_t k0 = k; v = 0; while (k < s.size() && std::isdigit((unsigned char)s[k]) && v < 100000) v = v * 10 + (uint32_t)(s[k++] - '0'); return k > k0; };
+                if (!num(lo)) break;                                     // a literal '{' (as in PCRE2): handled as a character below
+                hi = lo;
+                if (k < s.size() && s[k] == ',') { k++; if (!num(hi)) hi = UINT32_MAX; }
+                if (k >= s.size() || s[k] != '}') break;
+                i = k + 1;
+                if (hi < lo) { fail("{m,n} with n < m", at); return nullptr; }
+                if (lo > 1000 || (hi != UINT32_MAX && hi > 1000)) { fail("counted repeat beyond 1000", at); return nullptr; }
+            } else break;
+            bool lazy = false;
+            if (!eof() && s[i] == '?') { lazy = true; i++; }
+            else if (!eof() && s[i] == '+') { fail("possessive quantifier", at); return nullptr; }
+            if (a->kind == Node::EMPTY || a->kind == Node::LOOK) { fail("a quantifier on an assertion", at); return nullptr; }
+            if (hi == UINT32_MAX && nullable(*a)) { fail("an unbounded quantifier over an expression that can match the empty string", at); return nullptr; }
+            auto r = std::make_unique<Node>();
+            r->kind = Node::REP; r->lo = lo; r->hi = hi; r->lazy = lazy;
+            r->kids.push_back(std::move(a));
+            a = std::move(r);
+        }
+        if (!eof() && s[i] == '{') {                                     // not a quantifier: the caller's next atom reads it as a literal
+        }
+        return a;
+    }
+
+    std::unique_ptr<Node> concat(bool fold) {
+        auto n = std::make_unique<Node>();
+        n->kind = Node::CAT;
+        while (!eof() && s[i] != '|' && s[i] != ')') {
+            std::unique_ptr<Node> r;
+            if (s[i] == '{') {                                           // literal brace (no valid quantifier follows an atom here)
+                i++;
+                r = char_node('{', fold);
+            } else r = repeat(fold);
+            if (!r) return nullptr;
+            n->kids.push_back(std::move(r));
+        }
+        return n;
+    }
+
+    std::unique_ptr<Node> alternation(bool fold) {
+        auto first = concat(fold);
+        if (!first) return nullptr;
+        if (eof() || s[i] != '|') return first;
+        auto n = std::make_unique<Node>();
+        n->kind = Node::ALT;
+        n->kids.push_back(std::move(first));
+        while (!eof() && s[i] == '|') {
+            i++;
+            auto k = concat(fold);
+            if (!k) return nullptr;
+            n->kids.push_back(std::move(k));
+        }
+        return n;
+    }
+};
+
+struct Emitter {
+    RegexProg& p;
+    bool too_big = false;
+    uint32_t emit(Op op, uint32_t x = 0, uint32_t y = 0) {
+        if (p.code.size() > 200000) too_big = true;
+        p.code.push_back(Inst{op, x, y});
+        return (uint32_t)p.code.size() - 1;
+    }
+    void gen(const Node& n) {
+        if (too_big) return;
+        switch (n.kind) {
+            case Node::EMPTY: break;
+            case Node::CHAR: emit(n.fold ? OP_CHAR_FOLD : OP_CHAR, n.cp); break;
+            case Node::CLASS: emit(OP_CLASS, n.set); break;
+            case Node::ANY: emit(OP_ANY); break;
+            case Node::CAT: for (auto& k : n.kids) gen(*k); break;
+            case Node::ALT: {
+                std::vector<uint32_t> jumps;
+                for (size_t k = 0; k < n.kids.size(); k++) {
+                    if (k + 1 < n.kids.size()) {
+                        const uint32_t sp = emit(OP_SPLIT);
+                        p.code[sp].x = sp + 1;
+                        gen(*n.kids[k]);
+                        jumps.push_back(emit(OP_JMP));
+                        p.code[sp].y = (uint32_t)p.code.size();
+                    } else gen(*n.kids[k]);
+                }
+                for (uint32_t j : jumps) p.code[j].x = (uint32_t)p.code.size();
+                break;
+            }
+            case Node::REP: {
+                const Node& e = *n.kids[0];
+                for (uint32_t k = 0; k < n.lo; k++) gen(e);
+                if (n.hi == UINT32_MAX) {                               // e*: L0: SPLIT L1, end; L1: e; JMP L0
+                    const uint32_t l0 = emit(OP_SPLIT);
+                    gen(e);
+                    emit(OP_JMP, l0);
+                    const uint32_t end = (uint32_t)p.code.size();
+                    p.code[l0].x = n.lazy ? end : l0 + 1;
+                    p.code[l0].y = n.lazy ? l0 + 1 : end;
+                } else {                                                // (e (e (e)?)?)?: every SPLIT's way out is the common end
+                    std::vector<uint32_t> splits;
+                    for (uint32_t k = n.lo; k < n.hi; k++) { splits.push_back(emit(OP_SPLIT)); gen(e); }
+                    const uint32_t end = (uint32_t)p.code.size();
+                    for (uint32_t sp : splits) {
+                        p.code[sp].x = n.lazy ? end : sp + 1;
+                        p.code[sp].y = n.lazy ? sp + 1 : end;
+                    }
+                }
+                break;
+            }
+            case Node::LOOK: {
+                const uint32_t l = emit(n.neg ? OP_NLOOK : OP_LOOK);
+                gen(*n.kids[0]);
+                emit(OP_MATCH);
+                p.code[l].x = (uint32_t)p.code.size();
+                break;
+            }
+        }
+    }
+};
+
+// ---- matching -------------------------------------------------------------------------------------------
+struct Ch { uint32_t cp, len, cls; };
+
+// One character of the TEXT (raw bytes; the kernels' policy for bytes that are no UTF-8, include/splintr_hip.h:
+// a lead byte takes the continuation bytes actually present, at most as many as it announces -- complete: the
+// decoded value, otherwise ONE character of class "other"; a stray continuation byte is such a character itself).
+inline Ch decode(const HostTables& ht, const uint8_t* t, size_t pos, size_t n) {
+    const uint32_t b = t[pos];
+    if (b < 0x80) return Ch{b, 1, (uint32_t)ht.ucls_stage2[((uint32_t)ht.ucls_stage1[0] << ht.ucls_shift) | b]};
+    if (b < 0xC0) return Ch{CP_INVALID, 1, C_P};
+    const uint32_t want = b < 0xE0 ? 2 : b < 0xF0 ? 3 : 4;
+    uint32_t len = 1;
+    while (len < want && pos + len < n && (t[pos + len] & 0xC0u) == 0x80u) len++;
+    if (len != want) return Ch{CP_INVALID, len, C_P};
+    uint32_t cp = b & (0xFFu >> (want + 1));
+    for (uint32_t k = 1; k < want; k++) cp = (cp << 6) | (t[pos + k] & 0x3Fu);
+    return Ch{cp, want, host_cp_class(ht, cp)};
+}
+
+inline bool in_set(const ClassSet& cs, const Ch& c) {
+    bool in = ((cs.codes >> c.cls) & 1u) != 0;
+    if (!in && c.cp != CP_INVALID)
+        for (const auto& r : cs.ranges) if (c.cp >= r.first && c.cp <= r.second) { in = true; break; }
+    return in != cs.neg;
+}
+
+// caseless partners of an ASCII letter under Unicode simple case folding: the other case, U+017F for s, U+212A for k
+inline bool fold_eq(uint32_t pat, uint32_t cp) {
+    const uint32_t lo = pat | 0x20u;
+    if (cp < 0x80) return (cp | 0x20u) == lo && std::isalpha((int)cp);
+    return (lo == 's' && cp == 0x17F) || (lo == 'k' && cp == 0x212A);
+}
+
+struct Matcher {
+    const RegexProg& p;
+    const uint8_t* t;
+    size_t n;
+    uint64_t steps = 0;
+    static constexpr uint64_t STEP_MAX = 50'000'000ull;                  // per match attempt
+    std::vector<std::pair<uint32_t, size_t>> stack;
+
+    // longest-by-priority match of the program that starts at `pc0`, anchored at `pos`; SIZE_MAX: no match
+    size_t run(uint32_t pc0, size_t pos0) {
+        const size_t floor = stack.size();
+        stack.emplace_back(pc0, pos0);
+        while (stack.size() > floor) {
+            uint32_t pc = stack.back().first;
+            size_t pos = stack.back().second;
+            stack.pop_back();
+            for (;;) {
+                if (++steps > STEP_MAX) { stack.resize(floor); return SIZE_MAX - 1; }
+                const Inst& in = p.code[pc];
+                if (in.op == OP_MATCH) { stack.resize(floor); return pos; }
+                if (in.op == OP_JMP) { pc = in.x; continue; }
+                if (in.op == OP_SPLIT) { stack.emplace_back(in.y, pos); pc = in.x; continue; }
+                if (in.op == OP_LOOK || in.op == OP_NLOOK) {
+                    const size_t r = run(pc + 1, pos);
+                    if (r == SIZE_MAX - 1) { stack.resize(floor); return r; }
+                    if ((r != SIZE_MAX) == (in.op == OP_LOOK)) { pc = in.x; continue; }
+                    break;
+                }
+                if (pos >= n) break;
+                const Ch c = decode(*p.ht, t, pos, n);
+                bool ok;
+                if (in.op == OP_CHAR) ok = c.cp == in.x;
+                else if (in.op == OP_CHAR_FOLD) ok = c.cp != CP_INVALID && fold_eq(in.x, c.cp);
+                else if (in.op == OP_ANY) ok = c.cp != '\n';
+                else ok = in_set(p.sets[in.x], c);
+                if (!ok) break;
+                pos += c.len;
+                pc++;
+            }
+        }
+        return SIZE_MAX;
+    }
+};
+
+template <class F> bool split_text(const RegexProg& prog, const uint8_t* text, size_t n, F on_span) {
+    Matcher m{prog, text, n};
+    size_t pos = 0;
+    while (pos < n) {
+        m.steps = 0;
+        const size_t e = m.run(0, pos);
+        if (e == SIZE_MAX - 1) return false;
+        if (e == SIZE_MAX || e == pos) {                                 // no match here / an empty one: the character is skipped
+            pos += decode(*prog.ht, text, pos, n).len;
+            continue;
+        }
+        on_span(pos, e);
+        pos = e;
+    }
+    return true;
+}
+
+inline void or_bit(uint32_t* bm, uint64_t pos) { __atomic_fetch_or(&bm[pos >> 5], 1u << (pos & 31), __ATOMIC_RELAXED); }
+
+}  // namespace
+
+RegexPtr regex_compile(const std::string& pattern, const HostTables& ht, std::string& err) {
+    RegexPtr prog(new RegexProg());
+    prog->ht = &ht;
+    Parser ps(pattern, *prog);
+    auto ast = ps.alternation(false);
+    if (ast && !ps.eof()) { ps.fail("unbalanced )", ps.i); ast = nullptr; }
+    if (!ast) { err = ps.err.empty() ? "malformed split pattern" : ps.err; return nullptr; }
+    Emitter em{*prog};
+    em.gen(*ast);
+    em.emit(OP_MATCH);
+    if (em.too_big) { err = "the split pattern expands to more than 200 000 matcher instructions"; return nullptr; }
+    return prog;
+}
+
+bool regex_split_spans(const RegexProg& prog, const uint8_t* text, size_t n, std::vector<std::pair<uint32_t, uint32_t>>& out) {
+    return split_text(prog, text, n, [&](size_t a, size_t e) { out.emplace_back((uint32_t)a, (uint32_t)e); });
+}
+
+bool regex_split_bits(const RegexProg& prog, const uint8_t* text, size_t n, uint64_t base, uint32_t* start_bits, uint32_t* gap_bits) {
+    size_t covered = 0;                                                  // end of the previous match
+    auto gap = [&](size_t a, size_t e) {                                 // bytes no match covers: dropped (tokenizer.rs:729-808 only walks the matches)
+        or_bit(start_bits, base + a);
+        for (size_t q = a; q < e; q++) or_bit(gap_bits, base + q);
+    };
+    const bool ok = split_text(prog, text, n, [&](size_t a, size_t e) {
+        if (a > covered) gap(covered, a);
+        or_bit(start_bits, base + a);
+        covered = e;
+    });
+    if (ok && covered < n) gap(covered, n);
+    return ok;
+}
+
+}  // namespace spl
