@@ -43,8 +43,15 @@ extern "C" {
 #define SPL_PATTERN_O200K 1
 /* MISTRAL_V3_PATTERN (src/core/tokenizer.rs:64; mistral_v3 / Tekken, src/python/bindings.rs:152-158) */
 #define SPL_PATTERN_MISTRAL_V3 2
-/* These three are the patterns the scanner implements; there is no regex engine on the GPU, so any
- * other pattern string is refused by the host-side mirror with the reference's error type. */
+/* These three are the patterns the GPU scanner implements.  ANY OTHER pattern (Tokenizer::new compiles whatever it
+ * is given, src/core/tokenizer.rs:410-456): SPL_PATTERN_CUSTOM with the pattern text in spl_opts -- there is no
+ * regex engine on the GPU, so its split runs on the host cores (a restricted backtracking matcher over the same
+ * code-point class table, csrc/spl_regex.h: literals, classes, \s, \p{L} \p{Lu} \p{Ll} \p{Lt} \p{Lm} \p{Lo} \p{M}
+ * \p{N}, groups, (?i:), alternation, greedy / lazy quantifiers, look-ahead) and the chunk boundaries feed the same
+ * probe / merge kernels.  What the matcher cannot express (anchors, \b, \d, \w, other properties, look-behind,
+ * back-references, possessive quantifiers, a pattern that can match the empty string) is refused by spl_create with
+ * the construct named. */
+#define SPL_PATTERN_CUSTOM 3
 
 /* spl_opts.flags */
 #define SPL_OPT_BYTE_LEVEL 1u /* Tokenizer::from_bytes_byte_level (src/core/tokenizer.rs:562-569): the
@@ -64,6 +71,8 @@ typedef struct spl_opts {
     int32_t pattern;      /* SPL_PATTERN_* */
     int32_t device;       /* HIP device ordinal */
     uint32_t flags;       /* SPL_OPT_* */
+    const char* pattern_text; /* SPL_PATTERN_CUSTOM: the split pattern, UTF-8, pattern_len bytes (no terminator needed) */
+    uint64_t pattern_len;
 } spl_opts;
 
 /* Thread-local text of the last failure in this thread. */
@@ -151,6 +160,21 @@ void spl_host_free(void* p);
 int spl_encode_batch_device(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
                             uint64_t n_docs, uint32_t flags, uint32_t* d_ids, uint64_t ids_capacity,
                             uint64_t* d_out_off, void* hip_stream);
+
+/* Handles with SPL_PATTERN_CUSTOM: spl_encode_batch / spl_decode_batch work as for every other handle (the split of
+ * each pipeline chunk runs on the host cores while the previous chunk is on the GPU); spl_encode_batch_device is
+ * refused (the text is not on the host).  For text that IS on the device the two halves are available separately:
+ *   spl_split_host          the matches of the handle's pattern over a packed HOST corpus as two bitmaps of
+ *                           n_bytes / 32 + 2 words each (zeroed here): bit p of start_bits -- a chunk, or a stretch of
+ *                           bytes no match covers, starts at byte p; bit p of gap_bits -- byte p is dropped
+ *                           (find_iter semantics, tokenizer.rs:729-808).  Multi-threaded over documents.
+ *   spl_encode_chunks_device  spl_encode_batch_device with the chunk boundaries GIVEN (device copies of the two
+ *                           bitmaps; any handle: the handle's own pattern is not consulted).  Up to 256 MB per call. */
+int spl_split_host(spl_tokenizer* t, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, uint32_t* start_bits,
+                   uint32_t* gap_bits);
+int spl_encode_chunks_device(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
+                             uint64_t n_docs, const uint32_t* d_start_bits, const uint32_t* d_gap_bits, uint32_t* d_ids,
+                             uint64_t ids_capacity, uint64_t* d_out_off, void* hip_stream);
 
 /* Ragged all-gather of the CSR result across the GPUs of a node (north_star: "RCCL all-gatherv
  * over xGMI"; the reference has nothing distributed).  RCCL has no all-gatherv, so every rank

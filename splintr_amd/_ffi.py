@@ -27,17 +27,18 @@ SYMBOLS = [
     "spl_set_devices", "spl_n_devices", "spl_set_option", "spl_host_alloc", "spl_host_free",
     "spl_token_bytes", "spl_is_byte_level",
     "spl_comm_unique_id", "spl_comm_create", "spl_comm_destroy", "spl_comm_rank", "spl_comm_world",
-    "spl_allgather_slabs", "spl_allgatherv_csr",
+    "spl_allgather_slabs", "spl_allgatherv_csr", "spl_split_host", "spl_encode_chunks_device",
 ]
+SPL_PATTERN_CUSTOM = 3
 SPL_OPT_BYTE_LEVEL = 1
 
 
 class SplOpts(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("pattern", ctypes.c_int32), ("device", ctypes.c_int32),
-                ("flags", ctypes.c_uint32)]
+                ("flags", ctypes.c_uint32), ("pattern_text", ctypes.c_char_p), ("pattern_len", ctypes.c_uint64)]
 
-    def __init__(self, pattern=0, device=0, flags=0):
-        super().__init__(ctypes.sizeof(SplOpts), pattern, device, flags)
+    def __init__(self, pattern=0, device=0, flags=0, pattern_text=None):
+        super().__init__(ctypes.sizeof(SplOpts), pattern, device, flags, pattern_text, len(pattern_text) if pattern_text else 0)
 
 
 _lib = None
@@ -113,6 +114,8 @@ def lib() -> ctypes.CDLL:
                                                  ctypes.c_uint64, vp, vp, ctypes.c_uint64, ctypes.c_uint64, vp]
     L.spl_gatherv_unpack_group.argtypes = [vp, vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64,
                                            ctypes.c_uint64, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp]
+    L.spl_split_host.argtypes = [vp, vp, vp, ctypes.c_uint64, vp, vp]
+    L.spl_encode_chunks_device.argtypes = [vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp, vp, ctypes.c_uint64, vp, vp]
     L.spl_comm_unique_id.argtypes = [ctypes.c_char_p]
     L.spl_comm_create.restype = vp
     L.spl_comm_create.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]

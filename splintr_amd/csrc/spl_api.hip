@@ -19,6 +19,7 @@
 #include "spl_kernels.hip"
 #include "spl_tables.h"
 #include "spl_comm.h"
+#include "spl_regex.h"
 
 using namespace spl;
 
@@ -191,6 +192,11 @@ struct Ctx {
     uint32_t* d_ids = nullptr; uint64_t ids_cap = 0;         // the lane's ids, chunk c at its byte offset
     uint64_t* d_oo = nullptr; uint64_t oo_cap = 0;           // chunk-local output offsets, chunk after chunk
     Pinned h_text[NSLOT], h_off[NSLOT], h_tot;
+    // custom split patterns: the chunk's boundary bitmaps (starts | gaps, back to back) and the special tokens the
+    // host splitter found (positions | ids), per staging slot
+    Pinned h_ext[NSLOT], h_extsp[NSLOT];
+    uint32_t* d_ext[NSLOT] = {nullptr, nullptr, nullptr}; uint64_t ext_cap_words = 0;
+    uint32_t* d_extsp[NSLOT] = {nullptr, nullptr, nullptr}; uint64_t extsp_cap = 0;
     hipEvent_t ev_h2d[NSLOT] = {nullptr, nullptr, nullptr}, ev_cmp[NSLOT] = {nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ev_chunk;
     // decode scratch (grow-only)
@@ -218,8 +224,11 @@ struct Ctx {
         cap_bytes = cap_docs = 0;
     }
     void free_slots() {
-        for (int i = 0; i < NSLOT; i++) { hipFree(d_text[i]); hipFree(d_off[i]); d_text[i] = nullptr; d_off[i] = nullptr; }
-        slot_cap_bytes = slot_cap_docs = 0;
+        for (int i = 0; i < NSLOT; i++) {
+            hipFree(d_text[i]); hipFree(d_off[i]); hipFree(d_ext[i]); hipFree(d_extsp[i]);
+            d_text[i] = nullptr; d_off[i] = nullptr; d_ext[i] = nullptr; d_extsp[i] = nullptr;
+        }
+        slot_cap_bytes = slot_cap_docs = 0; ext_cap_words = 0; extsp_cap = 0;
     }
     ~Ctx() {
         if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return; }
@@ -251,6 +260,7 @@ struct spl_tokenizer {
     uint32_t max_special_id = 0;
     bool special_newline = false;             // a literal contains '\n': no sub-document cuts with SPL_WITH_SPECIAL
     bool special_general = false;             // occurrences can overlap, or a literal exceeds SP_MAXLEN: the two-launch general matcher
+    RegexPtr regex;                           // SPL_PATTERN_CUSTOM: the host splitter's program (null: one of the GPU scanner's patterns)
     std::vector<std::unique_ptr<Ctx>> ctx;
     std::shared_ptr<PinnedPool> pool = std::make_shared<PinnedPool>();
     // host pipeline tuning (spl_set_option)
@@ -450,12 +460,16 @@ int upload_decode(spl_tokenizer* tk, Ctx* t) {
 }
 
 struct SlabOut { uint32_t* d_slab = nullptr; uint64_t cap_words = 0, max_docs = 0; };
+// chunk boundaries given from outside (host splitter): device bitmaps, and the special tokens found on the host
+struct ExtIn { const uint32_t* d_starts = nullptr; const uint32_t* d_gaps = nullptr; const uint32_t* d_sp_pos = nullptr; const uint32_t* d_sp_id = nullptr; uint32_t n_sp = 0; };
 
 int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off, uint64_t n_docs,
                uint32_t flags, uint32_t* d_ids, uint64_t ids_cap, uint64_t* d_out_off, hipStream_t s,
-               const SlabOut* so = nullptr) {
+               const SlabOut* so = nullptr, const ExtIn* ext = nullptr) {
     if (((uintptr_t)d_utf8 & 15) != 0) return fail(SPL_EINVAL, "text buffer must be 16-byte aligned");
-    const bool special = (flags & SPL_WITH_SPECIAL) && !tk->specials.empty();
+    if (ext && n_bytes > SPL_DIRECT_MAX_BYTES) return fail(SPL_EINVAL, "external chunk boundaries: at most 256 MB per device call");
+    // (external boundaries: the special tokens -- if any -- were found by the host splitter; the GPU's literal scan stays off)
+    const bool special = !ext && (flags & SPL_WITH_SPECIAL) && !tk->specials.empty();
     if (special) { int rc0 = upload_specials(tk, t); if (rc0) return rc0; }
     if (n_bytes > 0x7FFF0000ull) return fail(SPL_EINVAL, "n_bytes per device call must be < 2^31 - 65536");
     if (n_docs > 0xFFFFFFF0ull) return fail(SPL_EINVAL, "n_docs per device call must be < 2^32 - 16");
@@ -495,11 +509,11 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
 #define MARK(i) do { if (pf) HIP_TRY(hipEventRecord(t->ev[i], s)); } while (0)
     // small batches: small tiles (occupancy hides latency); large batches: 4 KiB tiles
     // queue mode: tile-owned tiles + global queues for what is long, for batches beyond the two-launch limit
-    const bool queue_mode = !special && (t->force_tile == 4 || (t->force_tile == 0 && n_bytes > SPL_DIRECT_MAX_BYTES)) &&
+    const bool queue_mode = !ext && !special && (t->force_tile == 4 || (t->force_tile == 0 && n_bytes > SPL_DIRECT_MAX_BYTES)) &&
                             n_bytes <= SPL_QUEUE_MAX_BYTES;
-    const bool small_tiles = queue_mode || t->force_tile == 1 || t->force_tile == 3 || t->force_tile == 5 ||
+    const bool small_tiles = ext || queue_mode || t->force_tile == 1 || t->force_tile == 3 || t->force_tile == 5 ||
                              (t->force_tile == 0 && n_bytes <= SPL_DIRECT_MAX_BYTES);
-    const bool direct = !queue_mode && small_tiles && t->force_tile != 3 && n_bytes <= SPL_DIRECT_MAX_BYTES;
+    const bool direct = ext || (!queue_mode && small_tiles && t->force_tile != 3 && n_bytes <= SPL_DIRECT_MAX_BYTES);
     // tile-owned mode: two geometries of the same window (spl_kernels.hip SPL_TILE_DIRECT_A / _B; force 5: B at any size)
     static_assert(TileGeom<SPL_TILE_DIRECT_A>::Wv == TileGeom<SPL_TILE_SMALL>::Wv && TileGeom<SPL_TILE_DIRECT_B>::Wv == TileGeom<SPL_TILE_SMALL>::Wv &&
                   TileGeom<SPL_TILE_DIRECT_A>::TBv >= TileGeom<SPL_TILE_SMALL>::TBv && TileGeom<SPL_TILE_DIRECT_B>::TBv >= TileGeom<SPL_TILE_SMALL>::TBv,
@@ -536,10 +550,14 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
         hipLaunchKernelGGL((k_range_out<SPL_TILE_SMALL>), dim3(ntiles), dim3(64), 0, s, b);
         MARK(KI_N);
     } else if (direct) {
+        const bool ext_sp = ext && ext->n_sp > 0;
         if (special) {
             // the three bitmaps are cleared per call; documents and literals are marked by the
             // multi-pass kernels, the tile kernel reads the bitmaps on top of its document search
             HIP_TRY(hipMemsetAsync(t->d_zero, 0, (nbm * uw + QCOUNT_WORDS) * 4, s));
+            t->bitmap_dirty = true;
+        } else if (ext_sp) {                   // the token bitmap takes the host-found literals: cleared per call
+            HIP_TRY(hipMemsetAsync(t->d_zero, 0, uw * 4, s));
             t->bitmap_dirty = true;
         } else if (t->bitmap_dirty) {
             HIP_TRY(hipMemsetAsync(t->d_zero, 0, t->zero_words * 4, s));
@@ -553,6 +571,13 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
         if (!special) b.tstart = nullptr;
         b.qcount = nullptr;
         t->last_qcount = nullptr;
+        if (ext) {
+            b.ext_starts = ext->d_starts; b.ext_gaps = ext->d_gaps;
+            if (ext_sp) {
+                b.skip = const_cast<uint32_t*>(ext->d_gaps);     // (read-only here: the spans the literals' tokens lie in)
+                hipLaunchKernelGGL(k_ext_specials, dim3((ext->n_sp + 255) / 256), dim3(256), 0, s, b, ext->d_sp_pos, ext->d_sp_id, ext->n_sp);
+            }
+        }
         MARK(KI_MARK);
         if (special && n_docs) hipLaunchKernelGGL(k_mark_docs, dim3((uint32_t)((n_docs + 255) / 256)), dim3(256), 0, s, b);
         MARK(KI_SPECIAL);
@@ -641,6 +666,85 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
             t->prof_ms[i] += ms;
             t->prof_n[i] += 1;
         }
+    }
+    return SPL_OK;
+}
+
+// ---- custom split patterns: the host splitter over the documents of one pipeline chunk ------------------------
+// Special-token literals on the host, with the reference matcher's semantics (Aho-Corasick, MatchKind::Standard,
+// non-overlapping find_iter, tokenizer.rs:849-869; the same rule k_special_select implements): from the end of the
+// previous match, the occurrence that ENDS first, the longest one on a tie.
+struct SpHit { uint32_t start, len, id; };
+void host_special_find(const spl_tokenizer* tk, const uint8_t* text, size_t n, std::vector<SpHit>& out) {
+    uint8_t last_set[32] = {0};
+    for (const auto& sp : tk->specials) { const uint8_t c = (uint8_t)sp.lit.back(); last_set[c >> 3] |= (uint8_t)(1u << (c & 7)); }
+    size_t last = 0;
+    for (size_t e = 1; e <= n; e++) {
+        const uint8_t c = text[e - 1];
+        if (!((last_set[c >> 3] >> (c & 7)) & 1u)) continue;
+        const Special* best = nullptr;
+        for (const auto& sp : tk->specials) {
+            const size_t len = sp.lit.size();
+            if ((uint8_t)sp.lit.back() != c || len > e - last || (best && len <= best->lit.size())) continue;
+            if (memcmp(text + e - len, sp.lit.data(), len) == 0) best = &sp;
+        }
+        if (!best) continue;
+        out.push_back(SpHit{(uint32_t)(e - best->lit.size()), (uint32_t)best->lit.size(), best->id});
+        last = e;
+    }
+}
+
+inline void host_or_bit(uint32_t* bm, uint64_t pos) { __atomic_fetch_or(&bm[pos >> 5], 1u << (pos & 31), __ATOMIC_RELAXED); }
+
+// One document [lo, hi) of `text` (positions relative to the bitmaps' origin): chunk starts and gaps; with
+// `special`, the literals first -- each a gap with a start bit at either end, its token on `hits` -- and the
+// pattern over the stretches between them (encode_with_special, tokenizer.rs:842-874).
+bool host_split_doc(const spl_tokenizer* tk, const uint8_t* text, uint64_t lo, uint64_t hi, bool special, uint32_t* starts,
+                    uint32_t* gaps, std::vector<SpHit>* hits) {
+    if (hi <= lo) return true;
+    if (!special) return regex_split_bits(*tk->regex, text + lo, (size_t)(hi - lo), lo, starts, gaps);
+    std::vector<SpHit> found;
+    host_special_find(tk, text + lo, (size_t)(hi - lo), found);
+    uint64_t at = lo;
+    for (const SpHit& h : found) {
+        const uint64_t a = lo + h.start, e = a + h.len;
+        if (a > at && !regex_split_bits(*tk->regex, text + at, (size_t)(a - at), at, starts, gaps)) return false;
+        host_or_bit(starts, a);
+        for (uint64_t q = a; q < e; q++) host_or_bit(gaps, q);
+        if (e < hi) host_or_bit(starts, e);
+        hits->push_back(SpHit{(uint32_t)a, h.len, h.id});
+        at = e;
+    }
+    if (hi > at && !regex_split_bits(*tk->regex, text + at, (size_t)(hi - at), at, starts, gaps)) return false;
+    return true;
+}
+
+// All documents of a packed text (offsets relative to `text`), on up to `max_threads` threads pulling documents
+// off a shared counter.  The bitmaps must be zeroed and hold n_bytes / 32 + 2 words.
+int host_split_docs(const spl_tokenizer* tk, const uint8_t* text, const uint64_t* off, uint64_t nd, bool special, uint32_t* starts,
+                    uint32_t* gaps, std::vector<SpHit>* hits, unsigned max_threads) {
+    const uint64_t n_bytes = nd ? off[nd] - off[0] : 0;
+    unsigned nt = std::max(1u, std::min<unsigned>(max_threads, std::thread::hardware_concurrency()));
+    nt = (unsigned)std::min<uint64_t>(nt, std::max<uint64_t>(1, std::min<uint64_t>(nd, n_bytes >> 14)));    // >= 16 KiB of text per thread
+    std::atomic<uint64_t> next{0};
+    std::atomic<int> bad{0};
+    std::vector<std::vector<SpHit>> part(nt);
+    auto work = [&](unsigned k) {
+        for (;;) {
+            const uint64_t d0 = next.fetch_add(16, std::memory_order_relaxed);      // documents in runs of 16
+            if (d0 >= nd || bad.load(std::memory_order_relaxed)) return;
+            for (uint64_t d = d0; d < std::min(nd, d0 + 16); d++)
+                if (!host_split_doc(tk, text, off[d] - off[0], off[d + 1] - off[0], special, starts, gaps, &part[k])) { bad.store(1); return; }
+        }
+    };
+    std::vector<std::thread> ths;
+    for (unsigned k = 1; k < nt; k++) ths.emplace_back(work, k);
+    work(0);
+    for (auto& th : ths) th.join();
+    if (bad.load()) return fail(SPL_EINVAL, "the split pattern ran out of its matching budget on this text (catastrophic backtracking)");
+    if (hits) {
+        for (auto& p : part) hits->insert(hits->end(), p.begin(), p.end());
+        std::sort(hits->begin(), hits->end(), [](const SpHit& a, const SpHit& b) { return a.start < b.start; });
     }
     return SPL_OK;
 }
@@ -757,6 +861,16 @@ int lane_prepare(spl_tokenizer* tk, Lane& ln, const uint64_t* doc_off, uint64_t 
         if (!c->h_off[i].ensure(tk->pool, (max_docs + 1) * 8)) return fail(SPL_EDEVICE, "pinned staging allocation failed");
     }
     if (!c->h_tot.ensure(tk->pool, ln.chunks.size() * 8)) return fail(SPL_EDEVICE, "pinned staging allocation failed");
+    if (tk->regex) {                                         // boundary bitmaps of a chunk: starts | gaps
+        const uint64_t words = 2 * (max_bytes / 32 + 4);
+        if (words > c->ext_cap_words) {
+            HIP_TRY(hipDeviceSynchronize());
+            for (int i = 0; i < NSLOT; i++) { hipFree(c->d_ext[i]); c->d_ext[i] = nullptr; HIP_TRY(hipMalloc((void**)&c->d_ext[i], words * 4)); }
+            c->ext_cap_words = words;
+        }
+        for (int i = 0; i < NSLOT && (size_t)i < ln.chunks.size(); i++)
+            if (!c->h_ext[i].ensure(tk->pool, words * 4)) return fail(SPL_EDEVICE, "pinned staging allocation failed");
+    }
     while (c->ev_chunk.size() < ln.chunks.size()) {
         hipEvent_t e;
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -792,8 +906,40 @@ int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t
             HIP_TRY(hipStreamWaitEvent(c->s_cmp, c->ev_h2d[sl], 0));
         }
         uint64_t* oo = c->d_oo + ch.oo_at;
+        ExtIn ext;
+        if (tk->regex) {
+            // custom pattern: the chunk's boundaries from the host splitter (this lane's producer thread plus helpers,
+            // while the previous chunks are on the GPU), uploaded behind the text
+            const uint64_t bw = nb / 32 + 4;
+            uint32_t* hb = (uint32_t*)c->h_ext[sl].p;
+            memset(hb, 0, 2 * bw * 4);
+            const bool special = (flags & SPL_WITH_SPECIAL) && !tk->specials.empty();
+            std::vector<SpHit> hits;
+            int rcs = host_split_docs(tk, utf8 + ch.lo, rel, nd, special, hb, hb + bw, &hits, 32);
+            if (rcs) return rcs;
+            HIP_TRY(hipMemcpyAsync(c->d_ext[sl], hb, 2 * bw * 4, hipMemcpyHostToDevice, hs));
+            ext.d_starts = c->d_ext[sl]; ext.d_gaps = c->d_ext[sl] + bw;
+            if (!hits.empty()) {
+                const uint64_t n = hits.size();
+                if (n > c->extsp_cap) {
+                    HIP_TRY(hipDeviceSynchronize());
+                    const uint64_t cap = n + n / 2 + 1024;
+                    for (int i = 0; i < NSLOT; i++) { hipFree(c->d_extsp[i]); c->d_extsp[i] = nullptr; HIP_TRY(hipMalloc((void**)&c->d_extsp[i], cap * 8)); }
+                    c->extsp_cap = cap;
+                }
+                if (!c->h_extsp[sl].ensure(tk->pool, c->extsp_cap * 8)) return fail(SPL_EDEVICE, "pinned staging allocation failed");
+                uint32_t* hp = (uint32_t*)c->h_extsp[sl].p;
+                for (uint64_t i = 0; i < n; i++) { hp[i] = hits[i].start; hp[n + i] = hits[i].id; }
+                HIP_TRY(hipMemcpyAsync(c->d_extsp[sl], hp, n * 8, hipMemcpyHostToDevice, hs));
+                ext.d_sp_pos = c->d_extsp[sl]; ext.d_sp_id = c->d_extsp[sl] + n; ext.n_sp = (uint32_t)n;
+            }
+            if (!solo) {                                         // (the bitmaps went out behind the text's event: a second one)
+                HIP_TRY(hipEventRecord(c->ev_h2d[sl], c->s_h2d));
+                HIP_TRY(hipStreamWaitEvent(c->s_cmp, c->ev_h2d[sl], 0));
+            }
+        }
         int rc = launch_all(tk, c, c->d_text[sl], nb, c->d_off[sl], nd, flags, ids_direct ? ids_direct : c->d_ids + (ch.lo - ln.lo),
-                            nb + 16, oo, c->s_cmp);
+                            nb + 16, oo, c->s_cmp, nullptr, tk->regex ? &ext : nullptr);
         if (rc) return rc;
         if (solo) break;                                   // (the batch is ONE chunk: the caller finishes on the compute stream itself)
         HIP_TRY(hipEventRecord(c->ev_cmp[sl], c->s_cmp));
@@ -815,7 +961,7 @@ int encode_host(spl_tokenizer* tk, const uint8_t* utf8, const uint64_t* doc_off,
     size_t nl = nl_max;
     if (n_bytes < (1ull << 20) * nl) nl = std::max<size_t>(1, (size_t)(n_bytes >> 20));      // at least 1 MiB per GPU
     std::vector<Lane> lanes(nl);
-    const bool may_cut = tk->subdoc && !((flags & SPL_WITH_SPECIAL) && tk->special_newline);
+    const bool may_cut = tk->subdoc && !tk->regex && !((flags & SPL_WITH_SPECIAL) && tk->special_newline);   // (a custom pattern's context-free boundaries are unknown)
     {
         uint64_t prev = 0;
         for (size_t l = 0; l < nl; l++) {
@@ -1118,10 +1264,20 @@ spl_tokenizer* spl_create(const void* vocab, size_t vocab_len, const void* uclas
     try {
         std::unique_ptr<spl_tokenizer> t(new spl_tokenizer());
         std::string err;
-        if (build_tables((const uint8_t*)vocab, vocab_len, (const uint8_t*)uclass_tab, uclass_len, opts->pattern,
+        const bool custom = opts->pattern == SPL_PATTERN_CUSTOM;
+        if (custom && (have < sizeof(spl_opts) || !opts->pattern_text || !opts->pattern_len)) {
+            fail(SPL_EINVAL, "spl_create: SPL_PATTERN_CUSTOM needs spl_opts.pattern_text / pattern_len");
+            return nullptr;
+        }
+        if (build_tables((const uint8_t*)vocab, vocab_len, (const uint8_t*)uclass_tab, uclass_len, custom ? SPL_PATTERN_CL100K : opts->pattern,
                          (opts->flags & SPL_OPT_BYTE_LEVEL) != 0, t->ht, err)) {
             fail(SPL_EINVAL, "spl_create: " + err);
             return nullptr;
+        }
+        if (custom) {
+            // Tokenizer::new compiles the pattern (tokenizer.rs:426); a pattern this matcher cannot express is refused here
+            t->regex = regex_compile(std::string(opts->pattern_text, (size_t)opts->pattern_len), t->ht, err);
+            if (!t->regex) { fail(SPL_EINVAL, "spl_create: Regex error: " + err); return nullptr; }
         }
         t->ctx.emplace_back(new Ctx());
         t->ctx[0]->device = opts->device;
@@ -1216,6 +1372,8 @@ static int spl_encode_batch_device_impl(spl_tokenizer* t, const uint8_t* d_utf8,
                             uint64_t* d_out_off, void* hip_stream) {
     if (!t || !d_doc_off || !d_out_off || (n_bytes && (!d_utf8 || !d_ids)))
         return fail(SPL_EINVAL, "spl_encode_batch_device: null argument");
+    if (t->regex) return fail(SPL_EINVAL, "spl_encode_batch_device: this handle has a custom split pattern, whose split runs on the host: "
+                                          "use spl_encode_batch, or spl_split_host + spl_encode_chunks_device");
     HIP_TRY(hipSetDevice(t->ctx[0]->device));
     return launch_all(t, t->ctx[0].get(), d_utf8, n_bytes, d_doc_off, n_docs, flags, d_ids, ids_capacity, d_out_off, (hipStream_t)hip_stream);
 }
@@ -1228,6 +1386,7 @@ static int spl_encode_batch_device_packed_impl(spl_tokenizer* t, const uint8_t* 
         return fail(SPL_EINVAL, "spl_encode_batch_device_packed: null argument");
     if (cap_words < max_docs + 4 || n_docs > max_docs || cap_words > 0xFFFFFFFFull)
         return fail(SPL_EINVAL, "spl_encode_batch_device_packed: slab too small or beyond 2^32 words");
+    if (t->regex) return fail(SPL_EINVAL, "spl_encode_batch_device_packed: this handle has a custom split pattern (see spl_encode_batch_device)");
     HIP_TRY(hipSetDevice(t->ctx[0]->device));
     SlabOut so;
     so.d_slab = d_slab; so.cap_words = cap_words; so.max_docs = max_docs;
@@ -1545,6 +1704,37 @@ int spl_allgatherv_csr(spl_comm* c, const uint32_t* d_ids, const uint64_t* d_out
     });
 }
 
+int spl_split_host(spl_tokenizer* t, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, uint32_t* start_bits,
+                   uint32_t* gap_bits) {
+    if (!t || !doc_off || !start_bits || !gap_bits) return fail(SPL_EINVAL, "spl_split_host: null argument");
+    if (!t->regex) return fail(SPL_EINVAL, "spl_split_host: the handle has no custom split pattern (its pattern runs on the GPU)");
+    if (doc_off[0] != 0) return fail(SPL_EINVAL, "spl_split_host: doc_off[0] must be 0");
+    for (uint64_t d = 0; d < n_docs; d++)
+        if (doc_off[d + 1] < doc_off[d]) return fail(SPL_EINVAL, "spl_split_host: doc_off must be non-decreasing");
+    if (doc_off[n_docs] && !utf8) return fail(SPL_EINVAL, "spl_split_host: null text");
+    return guarded("spl_split_host", [&] {
+        const uint64_t words = doc_off[n_docs] / 32 + 2;
+        memset(start_bits, 0, words * 4);
+        memset(gap_bits, 0, words * 4);
+        return host_split_docs(t, utf8, doc_off, n_docs, false, start_bits, gap_bits, nullptr, 64);
+    });
+}
+
+int spl_encode_chunks_device(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
+                             uint64_t n_docs, const uint32_t* d_start_bits, const uint32_t* d_gap_bits, uint32_t* d_ids,
+                             uint64_t ids_capacity, uint64_t* d_out_off, void* hip_stream) {
+    if (!t || !d_doc_off || !d_out_off || !d_start_bits || !d_gap_bits || (n_bytes && (!d_utf8 || !d_ids)))
+        return fail(SPL_EINVAL, "spl_encode_chunks_device: null argument");
+    return guarded("spl_encode_chunks_device", [&] {
+        HIP_TRY(hipSetDevice(t->ctx[0]->device));
+        ExtIn ext;
+        ext.d_starts = d_start_bits; ext.d_gaps = d_gap_bits;
+        return launch_all(t, t->ctx[0].get(), d_utf8, n_bytes, d_doc_off, n_docs, 0, d_ids, ids_capacity, d_out_off,
+                          (hipStream_t)hip_stream, nullptr, &ext);
+    });
+}
+
 }  // extern "C"
+
 
 

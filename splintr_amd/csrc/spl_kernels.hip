@@ -123,6 +123,10 @@ struct Batch {
     uint32_t* slab; uint32_t slab_cap, slab_max_docs;
     uint32_t tpar;             // parity of this call
     uint64_t* off_out2;        // tile-owned mode, optional: k_tile_out stores the final offsets here as well (pinned host memory)
+    // EXTERNAL chunk boundaries (split patterns the scanner does not implement: the host splitter, spl_regex.h):
+    // bit p of ext_starts: a chunk -- or a stretch of dropped bytes -- starts at byte p; bit p of ext_gaps: byte p is
+    // dropped (no match covers it).  Tile-owned mode only; the scanner phases are skipped.
+    const uint32_t* ext_starts; const uint32_t* ext_gaps;
 };
 
 // LDS hand-over between the lanes of ONE wavefront (no workgroup barrier)
@@ -2123,7 +2127,7 @@ void k_pretok(DeviceTables T, Batch b) {
         // (tile-owned mode has these bitmaps only for SPL_WITH_SPECIAL: document starts come from
         //  the search below, the bitmap adds the text starts behind special literals)
         s_ts[tid] = (in && (!DIRECT || b.tstart)) ? b.tstart[wi] : 0u;
-        s_sk[tid] = (in && b.skip) ? b.skip[wi] : 0u;
+        s_sk[tid] = ((in && b.skip) ? b.skip[wi] : 0u) | ((DIRECT && in && b.ext_gaps) ? b.ext_gaps[wi] : 0u);
         s_cbits[tid] = 0;
         s_kill[tid] = 0; s_add[tid] = 0;
         s_tbits[tid] = 0;
@@ -2196,9 +2200,64 @@ void k_pretok(DeviceTables T, Batch b) {
     __syncthreads();
     SPL_STAMP(1);
 
-    // ---- classify: one record per byte, one word per lane -----------------------------------------
     const int iB = (B - w0 < (int64_t)Wv) ? (int)(B - w0) : Wv;   // first index past the text
     const int iT = (B - w0 < (int64_t)(Wv + WPAD)) ? (int)(B - w0) : Wv + WPAD;   // staged text end
+    constexpr int NBW1 = G::NBW + 1;
+    const bool ext = DIRECT && b.ext_starts != nullptr;     // chunk boundaries come from the host splitter
+    if (ext) {
+        // The tile owns the chunks that START in its own range [LH, LH + TB): their starts (and the terminator of
+        // the last one: the first start at or behind the tile's end, a document start, or the end of the corpus)
+        // are the window's bits of the external bitmap -- the "fast starts" path takes them from s_cbits as it
+        // takes the bit-vector starts.  A last chunk whose end lies beyond the window is finished by the tail
+        // from global memory (one deferred start, as a chain that outgrows the window).
+        if (tid < 64) {
+            const int ln = tid;
+            const bool in = ln < G::NBW;
+            uint32_t ew = 0;
+            if (in) {
+                const int64_t wi = (w0 >> 5) + ln;
+                if (wi >= 0 && wi * 32 < B) ew = b.ext_starts[wi];
+                ew |= s_ts[ln];
+                if (B - w0 <= (int64_t)Wv && (iB >> 5) == ln) ew |= 1u << (iB & 31);      // the corpus ends inside the window
+                if ((iB >> 5) == ln && (iB & 31) != 31) ew &= (2u << (iB & 31)) - 1u;      // nothing behind its end
+                if ((iB >> 5) < ln) ew = 0;
+            }
+            auto range_word = [&](int from, int to) -> uint32_t {             // bits [from, to) of this lane's word
+                const int lo = from - ln * 32, hi = to - ln * 32;
+                if (hi <= 0 || lo >= 32) return 0u;
+                uint32_t w = ~0u;
+                if (lo > 0) w &= ~0u << lo;
+                if (hi < 32) w &= (1u << hi) - 1u;
+                return w;
+            };
+            auto first_in = [&](int from, int to) -> int {
+                const uint32_t word = ew & range_word(from, to);
+                const unsigned long long bl = __ballot(word != 0u);
+                if (!bl) return -1;
+                const int l0 = __ffsll((long long)bl) - 1;
+                return l0 * 32 + __ffs((int)__builtin_amdgcn_readlane(word, l0)) - 1;
+            };
+            auto last_in = [&](int from, int to) -> int {
+                const uint32_t word = ew & range_word(from, to);
+                const unsigned long long bl = __ballot(word != 0u);
+                if (!bl) return -1;
+                const int l0 = 63 - __builtin_clzll(bl);
+                return l0 * 32 + 31 - __clz((int)__builtin_amdgcn_readlane(word, l0));
+            };
+            const int fs = first_in(LH, LH + TB_);
+            if (fs >= 0) {
+                const int ls = last_in(LH, LH + TB_);
+                const int fe = first_in(LH + TB_, Wv + 1);
+                const uint32_t bits = ew & range_word(fs, (fe >= 0 ? fe : ls) + 1);
+                if (in && bits) s_cbits[ln] = bits;
+                if (fe < 0 && ln == 0) { s_dq[1] = 1u; s_dq[2] = (uint32_t)(w0 + ls); }   // the chunk at ls outgrows the window
+            }
+            if (ln == 0) s_fast = 3u;
+        }
+        SPL_STAMP(2);
+        __syncthreads();
+    } else {
+    // ---- classify: one record per byte, one word per lane -----------------------------------------
     // (records past the window are all "window end": written directly, so that no wavefront runs a
     //  second pass of the loop body for the WPAD / 4 extra words)
     for (int wi = Wv / 4 + tid; wi < G::NW32; wi += NT) s_rec32[wi] = (uint32_t)C_WEND * 0x01010101u;
@@ -2260,7 +2319,6 @@ void k_pretok(DeviceTables T, Batch b) {
     SPL_STAMP(2);
 
     // ---- class bitmasks: one ballot per kind and 64-byte row; continuation bytes inherit their lead --
-    constexpr int NBW1 = G::NBW + 1;
     for (int row = tid >> 6; row < Wv / 64; row += NT / 64) {
         const int lane = tid & 63;
         const int i = row * 64 + lane;
@@ -2402,6 +2460,7 @@ void k_pretok(DeviceTables T, Batch b) {
         }
         if (ln == 0 && fine) atomicAdd(&s_fast, 1u);
     }
+    }   // !ext
     if (SPL_MASK_STARTS && DIRECT) __syncthreads();
     const bool fast_starts = SPL_MASK_STARTS && DIRECT && s_fast == 3u;
     SPL_STAMP(3);
@@ -2514,7 +2573,7 @@ void k_pretok(DeviceTables T, Batch b) {
                 p = (int)(c & 0xFFFFu); n = (int)(c >> 16);
             } else {
                 p = s_cpos[k];
-                if ((s_rec[p] & CB_CLASS) >= C_EOT) continue;   // terminator on a special-literal span
+                if (ext ? ((s_sk[p >> 5] >> (p & 31)) & 1u) != 0u : (s_rec[p] & CB_CLASS) >= C_EOT) continue;   // a special-literal span / dropped bytes
                 n = (int)s_cpos[k + 1] - p;
             }
             const uint32_t id = probe_chunk_tile(T, tx, p, n);
@@ -2846,6 +2905,34 @@ void k_pretok(DeviceTables T, Batch b) {
                     __syncthreads();
                     const uint32_t ndc = s_dq[1] < 2u ? s_dq[1] : 2u;
                     if (s_dq[6] >= ndc || s_dq[0] >= (uint32_t)DIRECT_LQCAP) break;
+                    if (ext) {
+                        // external boundaries: the ONE chunk that starts at the deferred position ends at the next start
+                        // bit, the next document, or the end of the corpus -- nothing to scan for
+                        if (tid == 0) {
+                            const uint32_t pc = s_dq[2 + s_dq[6]] & 0x7FFFFFFFu;
+                            uint32_t lo = 0, hi = b.n_docs;             // first document that starts behind pc
+                            while (lo < hi) {
+                                const uint32_t mid = lo + (hi - lo) / 2;
+                                if (b.doc_off[mid] <= (uint64_t)pc) lo = mid + 1; else hi = mid;
+                            }
+                            const uint32_t lim = lo < b.n_docs ? (uint32_t)b.doc_off[lo] : b.n_bytes;
+                            uint32_t e = lim;
+                            for (uint32_t w = (pc + 1u) >> 5; w * 32u < lim; w++) {
+                                uint32_t word = b.ext_starts[w];
+                                if (w == ((pc + 1u) >> 5)) word &= ~0u << ((pc + 1u) & 31u);
+                                if (word) { const uint32_t q = w * 32u + (uint32_t)(__ffs((int)word) - 1); if (q < lim) e = q; break; }
+                            }
+                            const uint32_t n = e - pc;
+                            const DirectAcc ga{&T, &b, lim, pc};
+                            const uint32_t id = probe_chunk(T, ga, (int)pc, (int)n);
+                            uint32_t fill = s_dq[0];
+                            if (id != SPL_NO_RANK) emit_g(pc, id);
+                            else if (n > 1) { s_lq[2 * fill] = pc; s_lq[2 * fill + 1] = n; fill++; }
+                            s_dq[0] = fill;
+                            s_dq[6] += 1;
+                        }
+                        continue;
+                    }
                     if (tid == 0 && s_dq[7] == 0) {
                         const uint32_t pent = s_dq[2 + s_dq[6]], pc = pent & 0x7FFFFFFFu;   // (bit 31: only a chunk start if no sync point)
                         uint32_t lo = 0, hi = b.n_docs;         // first text start after the chain's start -- or AT it, if whether
@@ -3614,6 +3701,16 @@ __global__ void k_decode_docs(DecodeArgs a) {
     const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d > a.n_docs) return;
     a.doc_off[d] = a.id_off[a.doc_first[d] - a.doc_first[0]];
+}
+
+// External chunk boundaries with special tokens: the host splitter found the literals too; their ids go where
+// k_special_scan would have put them (the tile that owns a literal's first byte takes it as its token).
+__global__ void k_ext_specials(Batch b, const uint32_t* pos, const uint32_t* id, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = pos[i];
+    b.stage[p] = id[i];
+    atomicOr(&b.tbits[p >> 5], 1u << (p & 31));
 }
 
 // Host pipeline (spl_encode_batch): chunk-local output offsets -> offsets in the whole result.

@@ -2,6 +2,7 @@
 #include "spl_regex.h"
 
 #include <algorithm>
+#include <cctype>
 #include <cstring>
 
 namespace spl {
@@ -301,7 +302,7 @@ struct Parser {
         return a;
     }
 
-    std::unique_ptr<Node> concat(bool fold) {
+    std::unique_ptr<Node> concat(bool& fold) {
         auto n = std::make_unique<Node>();
         n->kind = Node::CAT;
         while (!eof() && s[i] != '|' && s[i] != ')') {
@@ -316,7 +317,7 @@ struct Parser {
         return n;
     }
 
-    std::unique_ptr<Node> alternation(bool fold) {
+    std::unique_ptr<Node> alternation(bool fold) {                       // (by value: an inline (?i) lasts to the end of ITS group)
         auto first = concat(fold);
         if (!first) return nullptr;
         if (eof() || s[i] != '|') return first;
@@ -433,7 +434,7 @@ struct Matcher {
     const uint8_t* t;
     size_t n;
     uint64_t steps = 0;
-    static constexpr uint64_t STEP_MAX = 50'000'000ull;                  // per match attempt
+    uint64_t step_max = 0;                                               // per match attempt
     std::vector<std::pair<uint32_t, size_t>> stack;
 
     // longest-by-priority match of the program that starts at `pc0`, anchored at `pos`; SIZE_MAX: no match
@@ -445,7 +446,7 @@ struct Matcher {
             size_t pos = stack.back().second;
             stack.pop_back();
             for (;;) {
-                if (++steps > STEP_MAX) { stack.resize(floor); return SIZE_MAX - 1; }
+                if (++steps > step_max) { stack.resize(floor); return SIZE_MAX - 1; }
                 const Inst& in = p.code[pc];
                 if (in.op == OP_MATCH) { stack.resize(floor); return pos; }
                 if (in.op == OP_JMP) { pc = in.x; continue; }
@@ -474,6 +475,7 @@ struct Matcher {
 
 template <class F> bool split_text(const RegexProg& prog, const uint8_t* text, size_t n, F on_span) {
     Matcher m{prog, text, n};
+    m.step_max = 64ull * n + 1'000'000ull;                                // (linear for sane patterns; a safety net for the others)
     size_t pos = 0;
     while (pos < n) {
         m.steps = 0;
@@ -499,6 +501,8 @@ RegexPtr regex_compile(const std::string& pattern, const HostTables& ht, std::st
     Parser ps(pattern, *prog);
     auto ast = ps.alternation(false);
     if (ast && !ps.eof()) { ps.fail("unbalanced )", ps.i); ast = nullptr; }
+    if (ast && Parser::nullable(*ast))
+        ps.fail("the pattern can match the empty string (what find_iter does behind an empty match differs between the reference's regex back ends)", 0), ast = nullptr;
     if (!ast) { err = ps.err.empty() ? "malformed split pattern" : ps.err; return nullptr; }
     Emitter em{*prog};
     em.gen(*ast);

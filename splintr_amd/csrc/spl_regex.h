@@ -6,7 +6,7 @@
 // are dropped).  There is no regex engine on the GPU; for such a pattern the split runs here, on the host
 // cores, and the chunk boundaries go to the same probe / merge kernels as two bitmaps (chunk starts, gaps).
 //
-// This is a small backtracking matcher of its own (product code: it shares nothing with oracle/), over the
+// This is a small backtracking matcher of its own (product code, not shared with the test infrastructure), over the
 // code-point classes of splintr_amd/data/unicode_classes.bin -- the table the GPU scanner classifies with.
 // Supported: literals, `.`, escapes (\r \n \t \f \v \e \0 \xHH \x{H..} \uHHHH and escaped punctuation),
 // \s \S, \p{L} \p{Lu} \p{Ll} \p{Lt} \p{Lm} \p{Lo} \p{M} \p{N} and \P{..}, bracket classes with ranges,

@@ -35,7 +35,8 @@ MISTRAL_V3_PATTERN = (
     r"|[^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]+[\p{Ll}\p{Lm}\p{Lo}\p{M}]*"
     r"|\p{N}| ?[^\s\p{L}\p{N}]+[\r\n/]*|\s*[\r\n]+|\s+(?!\S)|\s+"
 )
-# The scanner implements exactly these patterns (there is no regex engine on the GPU).
+# The GPU scanner implements exactly these patterns; any other pattern is SPL_PATTERN_CUSTOM: its split runs on the
+# host cores (csrc/spl_regex.cpp) and feeds the same probe / merge kernels.
 _PATTERN_ID = {CL100K_BASE_PATTERN: 0, O200K_BASE_PATTERN: 1, MISTRAL_V3_PATTERN: 2}
 
 # name -> (vocab container, pattern, special-token table key)      src/python/bindings.rs:101-160
@@ -96,8 +97,12 @@ class Tokenizer:
     arguments (a tiktoken-format vocabulary file, a pattern, a special-token map), same methods.
 
     Differences from the reference, all refused loudly rather than approximated:
-    * `pattern` must be one of CL100K_BASE_PATTERN, O200K_BASE_PATTERN (= LLAMA3_PATTERN) or
-      MISTRAL_V3_PATTERN -- the GPU scanner implements these, there is no regex engine;
+    * `pattern`: CL100K_BASE_PATTERN, O200K_BASE_PATTERN (= LLAMA3_PATTERN) and MISTRAL_V3_PATTERN are split on the
+      GPU; any other pattern is split on the host cores by a restricted regex matcher (literals, classes, \s,
+      \p{L} \p{Lu} \p{Ll} \p{Lt} \p{Lm} \p{Lo} \p{M} \p{N}, groups, (?i:), alternation, greedy / lazy
+      quantifiers, look-ahead) and merged on the GPU; a pattern with anything else in it (anchors, \b, \d, \w,
+      other Unicode properties, look-behind, back-references, possessive quantifiers) or one that can match the
+      empty string raises the reference's "Regex error" ValueError naming the construct;
     * the vocabulary must contain all 256 single bytes and ids below 2**21;
     * special-token literals are at most 255 bytes (any set: literals that contain or chain into one
       another are matched as the reference's Aho-Corasick matcher does).
@@ -117,12 +122,16 @@ class Tokenizer:
     # ------------------------------------------------------------------ construction
     def _init_from_blob(self, blob: bytes, pattern: str, special_tokens: Dict[str, int], device: int,
                         byte_level: bool = False):
-        if pattern not in _PATTERN_ID:
-            raise ValueError("Regex error: the HIP backend implements CL100K_BASE_PATTERN, O200K_BASE_PATTERN / "
-                             "LLAMA3_PATTERN and MISTRAL_V3_PATTERN only (no regex engine on the GPU)")
+        if not isinstance(pattern, str):
+            raise TypeError("argument 'pattern': object cannot be converted to 'PyString'")
         L = _ffi.lib()
         ucls = _read(os.path.join(_DATA, "unicode_classes.bin"))
-        opts = _ffi.SplOpts(_PATTERN_ID[pattern], device, _ffi.SPL_OPT_BYTE_LEVEL if byte_level else 0)
+        flags = _ffi.SPL_OPT_BYTE_LEVEL if byte_level else 0
+        if pattern in _PATTERN_ID:
+            opts = _ffi.SplOpts(_PATTERN_ID[pattern], device, flags)
+        else:                                   # src/core/tokenizer.rs:426: any pattern is compiled
+            self._pattern_bytes = pattern.encode("utf-8")
+            opts = _ffi.SplOpts(_ffi.SPL_PATTERN_CUSTOM, device, flags, self._pattern_bytes)
         self._h = L.spl_create(blob, len(blob), ucls, len(ucls), ctypes.byref(opts))
         if not self._h:
             raise ValueError(_ffi.last_error())

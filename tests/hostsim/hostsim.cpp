@@ -484,3 +484,25 @@ extern "C" void hs_bucket_stats(void* p, uint32_t* out) {
     out[4] = nb; out[5] = full;
     out[6] = h.unsalted_groups;
 }
+
+// ---------------------------------------------------------------------------------------------
+// The host splitter for custom patterns (spl_regex.h), driven directly: compile, split one text.
+#include "../../splintr_amd/csrc/spl_regex.h"
+extern "C" void* hs_regex_compile(void* p, const char* pattern, int plen, char* err, int errcap) {
+    Sim* s = (Sim*)p;
+    std::string e;
+    spl::RegexPtr r = spl::regex_compile(std::string(pattern, (size_t)plen), s->ht, e);
+    if (!r) { snprintf(err, (size_t)errcap, "%s", e.c_str()); return nullptr; }
+    return r.release();
+}
+extern "C" void hs_regex_free(void* r) { spl::RegexDeleter()((spl::RegexProg*)r); }
+// spans_out: up to cap (start, end) pairs; returns the count, -1 if the step budget ran out
+extern "C" int hs_regex_split(void* r, const uint8_t* text, int n, uint32_t* spans_out, int cap) {
+    std::vector<std::pair<uint32_t, uint32_t>> v;
+    if (!spl::regex_split_spans(*(spl::RegexProg*)r, text, (size_t)n, v)) return -1;
+    for (int k = 0; k < (int)v.size() && k < cap; k++) { spans_out[2 * k] = v[k].first; spans_out[2 * k + 1] = v[k].second; }
+    return (int)v.size();
+}
+extern "C" int hs_regex_split_bits(void* r, const uint8_t* text, int n, uint64_t base, uint32_t* starts, uint32_t* gaps) {
+    return spl::regex_split_bits(*(spl::RegexProg*)r, text, (size_t)n, base, starts, gaps) ? 0 : -1;
+}

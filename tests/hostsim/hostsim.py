@@ -15,8 +15,8 @@ _REG = {"cl100k_base": ("cl100k_base.splv", 0), "o200k_base": ("o200k_base.splv"
 
 
 def build():
-    srcs = [os.path.join(_HERE, "hostsim.cpp"), os.path.join(_CSRC, "spl_tables.cpp")]
-    deps = srcs + [os.path.join(_CSRC, h) for h in ("spl_common.h", "spl_scan.h", "spl_scan_masks.h", "spl_scan_starts.h", "spl_lookup.h", "spl_tables.h")]
+    srcs = [os.path.join(_HERE, "hostsim.cpp"), os.path.join(_CSRC, "spl_tables.cpp"), os.path.join(_CSRC, "spl_regex.cpp")]
+    deps = srcs + [os.path.join(_CSRC, h) for h in ("spl_regex.h", "spl_common.h", "spl_scan.h", "spl_scan_masks.h", "spl_scan_starts.h", "spl_lookup.h", "spl_tables.h")]
     if not os.path.exists(_LIB) or any(os.path.getmtime(d) > os.path.getmtime(_LIB) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", _LIB] + srcs)
     return _LIB
@@ -47,6 +47,13 @@ def lib():
         L.hs_classify_check.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
         L.hs_encode.restype = ctypes.c_int
         L.hs_encode.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.hs_regex_compile.restype = ctypes.c_void_p
+        L.hs_regex_compile.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
+        L.hs_regex_free.argtypes = [ctypes.c_void_p]
+        L.hs_regex_split.restype = ctypes.c_int
+        L.hs_regex_split.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        L.hs_regex_split_bits.restype = ctypes.c_int
+        L.hs_regex_split_bits.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
         _lib = L
     return _lib
 
@@ -123,3 +130,33 @@ class HostSim:
         if k < 0:
             raise RuntimeError(f"hs_encode failed: {k}")
         return out[:k].tolist()
+
+
+class HostRegex:
+    """The product's host splitter for custom split patterns (splintr_amd/csrc/spl_regex.cpp), driven directly."""
+
+    def __init__(self, pattern: str, sim: "HostSim" = None):
+        self._sim = sim or HostSim("cl100k_base")         # (only its code-point class table matters here)
+        err = ctypes.create_string_buffer(512)
+        pb = pattern.encode("utf-8")
+        self._r = lib().hs_regex_compile(self._sim._h, pb, len(pb), err, 512)
+        if not self._r:
+            raise ValueError(err.value.decode())
+
+    def __del__(self):
+        if getattr(self, "_r", None):
+            lib().hs_regex_free(self._r)
+            self._r = None
+
+    def split(self, data: bytes):
+        out = np.zeros(2 * (len(data) + 1), dtype=np.uint32)
+        k = lib().hs_regex_split(self._r, data, len(data), out.ctypes.data, len(data) + 1)
+        if k < 0:
+            raise RuntimeError("step budget exhausted")
+        return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(k)]
+
+    def split_bits(self, data: bytes, base: int = 0):
+        nw = (base + len(data)) // 32 + 2
+        st, gp = np.zeros(nw, dtype=np.uint32), np.zeros(nw, dtype=np.uint32)
+        assert lib().hs_regex_split_bits(self._r, data, len(data), base, st.ctypes.data, gp.ctypes.data) == 0
+        return st, gp

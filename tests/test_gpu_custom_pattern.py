@@ -1,0 +1,160 @@
+"""SURVEY 8f rank 2 "with arbitrary pattern" on the GPU (-m gpu): Tokenizer(vocab, pattern, special_tokens) /
+Tokenizer.from_bytes with patterns the GPU scanner does NOT implement -- the split runs on the host cores
+(csrc/spl_regex.cpp), the chunk boundaries feed the tile kernel's probe / merge phases -- against the Python
+oracle with the very same pattern on PCRE2 (UTF | UCP), bit-exact.
+Reference: Tokenizer::new / with_full_options compile any pattern (src/core/tokenizer.rs:410-456), encode walks
+its matches (:729-808), encode_with_special the stretches between special tokens (:842-874)."""
+import ctypes
+import os
+import random
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from fuzzgen import cased_corpus, fuzz_corpus, latin_corpus
+from test_host_regex import GPT2_PATTERN, MIXED, SPARSE, VARIANT_A, VARIANT_B
+
+pytestmark = pytest.mark.gpu
+DATA = os.path.join(ROOT, "splintr_amd", "data")
+
+
+def _blob(name):
+    with open(os.path.join(DATA, name + ".splv"), "rb") as f:
+        return f.read()
+
+
+def _pair(vocab, pattern, special=None, byte_level=False):
+    """(HIP tokenizer, Python oracle) over one vocabulary and one pattern"""
+    from splintr_amd import Tokenizer
+    from oracle import pyoracle as O
+    if not O.pcre2_available():
+        pytest.skip("libpcre2-8 not present")
+    enc, _ = O.load_splv(os.path.join(DATA, vocab + ".splv"))
+    t = (Tokenizer.from_bytes_byte_level if byte_level else Tokenizer.from_bytes)(_blob(vocab), pattern, special or {})
+    return t, O.Oracle(enc, pattern, byte_level, special or {}, "pcre2")
+
+
+def _check(t, orc, texts, special=False):
+    got = t.encode_batch_with_special(texts) if special else t.encode_batch(texts)
+    for i, text in enumerate(texts):
+        want = orc.encode_with_special(text) if special else orc.encode(text)
+        assert got[i] == want, (i, text[:80], got[i][:16], want[:16])
+
+
+def _texts(seed):
+    from splintr_amd import corpus
+    from test_gpu_parity import _multibyte_texts
+    return (fuzz_corpus(seed, 1200, 40) + latin_corpus(seed, 200, 80) + cased_corpus(seed, 200, 60)
+            + corpus.c2(40, seed=seed) + corpus.c3(8, seed=seed) + _multibyte_texts(seed, 6, 1500)
+            + ["", " ", "a", "'s", "x" * 70, " " * 300, "\n" * 90, "1234567890" * 30, "你好" * 200])
+
+
+@pytest.mark.parametrize("key, vocab, pattern, bl", [
+    ("gpt2", "cl100k_base", GPT2_PATTERN, False),
+    ("variant_b", "cl100k_base", VARIANT_B, False),
+    ("variant_a", "mistral_v3", VARIANT_A, True),
+    ("gpt2_o200k", "o200k_base", GPT2_PATTERN, False),
+    ("mixed", "llama3", MIXED, False),
+])
+def test_custom_patterns_bit_exact(key, vocab, pattern, bl):
+    t, orc = _pair(vocab, pattern, byte_level=bl)
+    texts = _texts(100 + len(key))
+    _check(t, orc, texts)
+    assert t.encode(texts[7]) == orc.encode(texts[7])
+    _check(t, orc, ["".join(texts[:300])])                      # one long document
+
+
+def test_pattern_that_does_not_tile_the_text_drops_the_gaps():
+    t, orc = _pair("cl100k_base", SPARSE)
+    texts = _texts(5) + ["...", "  ab, 12x!", "no gaps", "???a???", "a???", "???"]
+    _check(t, orc, texts)
+    assert t.encode("...") == [] and t.encode("  ab, 12x!") == orc.encode("ab") + orc.encode("12") + orc.encode("x")
+
+
+def test_chunks_longer_than_a_window_and_at_every_alignment():
+    """A chunk that starts in one tile and ends far behind its window (the tail finishes it from global memory), at
+    300 consecutive alignments against the tile and window edges; 64 KB single-class runs."""
+    t, orc = _pair("cl100k_base", GPT2_PATTERN)
+    pad = ("lorem ipsum " * 400)
+    for unit, L in (("a", 1300), (" ", 240), ("é", 700), ("-", 1100), ("你", 400), ("7", 2500)):
+        k0 = random.Random(L).randrange(0, 700)
+        texts = [pad[:k] + unit * L + " tail" for k in range(k0, k0 + 300)]
+        _check(t, orc, texts)
+        _check(t, orc, ["".join(texts)])
+    _check(t, orc, ["a" * 65536, " " * 65536 + "x", "word " * 3000 + "=" * 40000])
+
+
+def test_multi_chunk_pipeline_and_special_tokens():
+    from splintr_amd import _ffi
+    sp = {"<|endoftext|>": 100257, "<|fim|>": 100258, "<|a|>": 100300, "<|a|>x": 100301}
+    t, orc = _pair("cl100k_base", GPT2_PATTERN, sp)
+    texts = _texts(77)
+    rng = random.Random(3)
+    lits = list(sp)
+    mixed = []
+    for i, x in enumerate(texts):
+        if i % 2 == 0:
+            c = rng.randrange(len(x) + 1)
+            x = x[:c] + rng.choice(lits) + x[c:]
+        mixed.append(x)
+    mixed += ["<|endoftext|>", "<|a|>x<|a|>", "a<|fim|>", "<|fim|>a", "<|fi", "<|a|><|a|>x<|endoftext|>tail"]
+    _check(t, orc, mixed, special=True)
+    _check(t, orc, mixed)                                        # without the flag the literals are plain text
+    # the host pipeline in many small chunks (split of chunk k+1 while chunk k is on the GPU)
+    L = _ffi.lib()
+    assert L.spl_set_option(t.handle, b"chunk_bytes", 64 << 10) == 0 and L.spl_set_option(t.handle, b"single_chunk_max_bytes", 0) == 0
+    _check(t, orc, mixed, special=True)
+    _check(t, orc, texts)
+
+
+def test_a_scanner_pattern_through_the_host_splitter_gives_the_scanner_s_ids(coracle):
+    """CL100K_BASE_PATTERN wrapped in a group is a different STRING, so it takes the host splitter: same ids as the
+    GPU scanner (and the C oracle) on the same text."""
+    from splintr_amd import Tokenizer, CL100K_BASE_PATTERN, O200K_BASE_PATTERN
+    from test_gpu_parity import assert_batch_equal, tok
+    texts = _texts(9)
+    for name, pat in (("cl100k_base", CL100K_BASE_PATTERN), ("o200k_base", O200K_BASE_PATTERN)):
+        t = Tokenizer.from_bytes(_blob(name), "(?:" + pat + ")")
+        ids, off = t.encode_batch_csr(texts)
+        w_ids, w_off = tok(name).encode_batch_csr(texts)
+        assert np.array_equal(off, w_off) and np.array_equal(ids, w_ids)
+
+
+def test_split_on_the_host_encode_on_the_device_entry_points():
+    """spl_split_host + spl_encode_chunks_device (text already in HBM) == spl_encode_batch; the device-text entry
+    point of a custom-pattern handle is refused with a message that says where to go."""
+    import torch
+    from splintr_amd import Tokenizer, _ffi
+    from splintr_amd.device import DeviceBatch
+    t = Tokenizer.from_bytes(_blob("cl100k_base"), GPT2_PATTERN)
+    texts = _texts(21)
+    want_ids, want_off = t.encode_batch_csr(texts)
+    L = _ffi.lib()
+    dev = torch.device("cuda", 0)
+    b = DeviceBatch(texts, dev)
+    blob = b"".join(x.encode("utf-8") for x in texts)
+    words = len(blob) // 32 + 2
+    st, gp = np.zeros(words, dtype=np.uint32), np.zeros(words, dtype=np.uint32)
+    assert L.spl_split_host(t.handle, blob, b.host_offsets.ctypes.data, b.n_docs, st.ctypes.data, gp.ctypes.data) == 0, _ffi.last_error()
+    d_st, d_gp = torch.from_numpy(st.view(np.int32)).to(dev), torch.from_numpy(gp.view(np.int32)).to(dev)
+    rc = L.spl_encode_chunks_device(t.handle, b.text.data_ptr(), b.n_bytes, b.doc_off.data_ptr(), b.n_docs, d_st.data_ptr(), d_gp.data_ptr(),
+                                    b.ids.data_ptr(), b.ids.numel(), b.out_off.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, _ffi.last_error()
+    torch.cuda.synchronize()
+    off = b.out_off.cpu().numpy().astype(np.uint64)
+    assert np.array_equal(off, want_off)
+    assert np.array_equal(b.ids[:int(off[-1])].cpu().numpy().view(np.uint32), want_ids)
+    rc = L.spl_encode_batch_device(t.handle, b.text.data_ptr(), b.n_bytes, b.doc_off.data_ptr(), b.n_docs, 0, b.ids.data_ptr(), b.ids.numel(),
+                                   b.out_off.data_ptr(), None)
+    assert rc != 0 and "spl_split_host" in _ffi.last_error()
+
+
+def test_unsupported_patterns_raise_the_reference_s_error_type():
+    from splintr_amd import Tokenizer
+    with pytest.raises(ValueError, match=r"Regex error.*\\w"):
+        Tokenizer.from_bytes(_blob("cl100k_base"), r"\w+|\s+")
+    with pytest.raises(ValueError, match="empty string"):
+        Tokenizer.from_bytes(_blob("cl100k_base"), r"a*")
+    with pytest.raises(IOError, match="look-behind"):
+        Tokenizer(os.path.join(DATA, "cl100k_base.splv"), r"(?<=a)b|.")

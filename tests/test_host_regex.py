@@ -1,0 +1,80 @@
+"""SURVEY 8f rank 2, "arbitrary pattern": the product's host splitter (splintr_amd/csrc/spl_regex.cpp) against
+PCRE2 with UTF | UCP -- the back end the reference itself declares equivalent to its default one
+(src/core/tokenizer.rs:470-488, python/tests/test_cl100k.py:436-454) -- on adversarial fuzz, for the three
+patterns the GPU scanner implements AND patterns it does not (GPT-2's, variants of the reference's own).  What
+the splitter cannot express is refused at construction with the construct named.
+Reference: Tokenizer::new compiles any pattern (src/core/tokenizer.rs:410-456)."""
+import pytest
+
+from fuzzgen import cased_corpus, fuzz_corpus, latin_corpus
+
+GPT2_PATTERN = r"'s|'t|'re|'ve|'m|'ll|'d| ?\p{L}+| ?\p{N}+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+"
+# a Tekken-like variant: single digits, no contractions, '/' joins the newline tail, {1,2} counted repeat
+VARIANT_A = r"[^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]*[\p{Ll}\p{Lm}\p{Lo}\p{M}]+|[^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]+[\p{Ll}\p{Lm}\p{Lo}\p{M}]*|\p{N}{1,2}| ?[^\s\p{L}\p{N}]+[\r\n/]*|\s*[\r\n]+|\s+(?!\S)|\s+"
+# cl100k with the contraction group spelt (?i) ... and numbers of up to four, lazy whitespace tail
+VARIANT_B = r"(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}{1,4}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+?(?=\S)|\s+"
+# a pattern that does NOT tile the text: only letter runs and digit runs are chunks, everything else is dropped
+SPARSE = r"\p{L}+|[0-9]+"
+# literals, escapes, \x{..}, a class with a range and an escaped bracket, '.' (no newline), alternation in a group
+MIXED = r"(?:https?://|www\.)[^\s]+|[A-Za-z_][A-Za-z0-9_]*|\x{4f60}\x{597d}|[\[\]{}()]|.|\n"
+
+
+def _patterns():
+    from splintr_amd import CL100K_BASE_PATTERN, O200K_BASE_PATTERN, MISTRAL_V3_PATTERN
+    return {"cl100k": CL100K_BASE_PATTERN, "o200k": O200K_BASE_PATTERN, "mistral_v3": MISTRAL_V3_PATTERN, "gpt2": GPT2_PATTERN,
+            "variant_a": VARIANT_A, "variant_b": VARIANT_B, "sparse": SPARSE, "mixed": MIXED}
+
+
+@pytest.fixture(scope="module")
+def sim():
+    from hostsim import HostSim
+    return HostSim("cl100k_base")
+
+
+@pytest.mark.parametrize("key", ["cl100k", "o200k", "mistral_v3", "gpt2", "variant_a", "variant_b", "sparse", "mixed"])
+def test_host_splitter_equals_pcre2(sim, key):
+    from hostsim import HostRegex
+    from oracle import pyoracle as O
+    if not O.pcre2_available():
+        pytest.skip("libpcre2-8 not present")
+    pat = _patterns()[key]
+    hr = HostRegex(pat, sim)
+    pc = O.Pcre2Pattern(pat)
+    texts = fuzz_corpus(4242, 2500, 40) + latin_corpus(7, 400, 80) + cased_corpus(9, 400, 60)
+    texts += ["", " ", "\n", "a", "'", "'s", "x's'S'ſ'K'K", "http://a.b/c?d=e www.x.y z", "你好你好 你 好", "a\nb\r\nc", "{[()]}", "12345678901"]
+    bad = 0
+    for t in texts:
+        b = t.encode("utf-8")
+        want = [(a, e) for a, e in pc.find_iter(b) if e > a]
+        got = hr.split(b)
+        if got != want:
+            bad += 1
+            if bad <= 3:
+                print(repr(t), got[:12], want[:12])
+    assert bad == 0
+
+
+def test_split_bits_mark_chunks_and_gaps(sim):
+    from hostsim import HostRegex
+    import numpy as np
+    hr = HostRegex(SPARSE, sim)
+    data = "  ab, 12x!".encode()
+    st, gp = hr.split_bits(data, base=37)
+    bit = lambda bm, p: (int(bm[(37 + p) >> 5]) >> ((37 + p) & 31)) & 1
+    # chunks: "ab" [2,4) "12" [6,8) "x" [8,9); gaps [0,2) [4,6) [9,10)
+    assert [p for p in range(len(data)) if bit(st, p)] == [0, 2, 4, 6, 8, 9]
+    assert [p for p in range(len(data)) if bit(gp, p)] == [0, 1, 4, 5, 9]
+    assert int(np.sum(st[:1])) == 0                     # nothing before the base
+
+
+@pytest.mark.parametrize("pattern, what", [
+    (r"\w+", r"\w"), (r"\d+|\s+", r"\d"), (r"^a", "anchor"), (r"a$", "anchor"), (r"\bfoo", r"\b"), (r"(?<=a)b", "look-behind"),
+    (r"(a)\1", r"\1"), (r"a*+", "possessive"), (r"(?>a)", "atomic"), (r"\p{Nd}+", "Nd"), (r"\p{P}", "P}"), (r"[[:alpha:]]", "POSIX"),
+    (r"(a", "without )"), (r"a)", "unbalanced"), (r"[a", "without ]"), (r"a{5,2}", "n < m"), (r"(?i:é)", "non-ASCII literal"),
+    (r"a*", "empty string"), (r"(a|b*)c?", "empty string"), (r"(a*)*", "empty string"), (r"x{2000}", "beyond 1000"),
+])
+def test_unsupported_constructs_are_named(sim, pattern, what):
+    from hostsim import HostRegex
+    with pytest.raises(ValueError) as e:
+        HostRegex(pattern, sim)
+    assert what in str(e.value), str(e.value)
