@@ -93,7 +93,7 @@ def _pack(texts: Sequence[str]):
 
 
 class Tokenizer:
-    """The reference's `splintr.Tokenizer` surface on the MI355X backend: same constructor
+    r"""The reference's `splintr.Tokenizer` surface on the MI355X backend: same constructor
     arguments (a tiktoken-format vocabulary file, a pattern, a special-token map), same methods.
 
     Differences from the reference, all refused loudly rather than approximated:
