@@ -1,11 +1,10 @@
 #!/bin/bash
 # Build A/B variants of the library into _ab/:  tools/ab_build.sh name "-DFLAG=1 ..." [name2 "flags2" ...]
-# (the default build is always made as _ab/lib_default.so as well)
+# (_ab/ is scratch: git-ignored; it ships to the GPU box with a gpurun call, so delete it when the comparison is done)
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p _ab
-build() { hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value $2 -o _ab/lib_$1.so splintr_amd/csrc/spl_api.hip splintr_amd/csrc/spl_tables.cpp 2>&1 | grep -E "error" || true; }
-build default "" &
+build() { hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value $2 -o _ab/lib_$1.so splintr_amd/csrc/spl_api.hip splintr_amd/csrc/spl_tables.cpp splintr_amd/csrc/spl_regex.cpp 2>&1 | grep -E " error" || true; }
 while [ $# -ge 2 ]; do build "$1" "$2" & shift 2; done
 wait
 ls -la _ab/*.so
