@@ -284,13 +284,21 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
         const size_t n = kv.first.size();
         (n <= (size_t)SPL_TINY_MAX ? n_tiny : n <= (size_t)SPL_T8_MAX ? n_t8 : n <= (size_t)SPL_SHORT_MAX ? n_short : n_long)++;
     }
-    // tiny / t8 tables: buckets of 4, at most about 1.5 entries per bucket on average
-    const uint32_t tbuckets = pow2_at_least(n_tiny * 2 / 3 + 2), ebuckets = pow2_at_least(n_t8 * 2 / 3 + 2);
-    out.tiny_tab.assign((size_t)tbuckets * SPL_TINY_BUCKET * 2, SPL_EMPTY);
-    out.t8_tab.assign((size_t)ebuckets * SPL_T8_WORDS, SPL_EMPTY);
-    // short table: buckets of 4, about 1.5 entries per bucket on average
-    const uint32_t sbuckets = pow2_at_least(n_short * 2 / 3 + 2), lcap = pow2_at_least(n_long * 2 + 2);
-    out.short_tab.assign((size_t)sbuckets * SPL_SHORT_BUCKET, ShortEnt{0, 0, 0, SPL_EMPTY});
+    // tiny / t8 / short tables: buckets of 4, sized by load.  Level 0 (dense): the smallest power of two that keeps
+    // the load at or below 55 % (short table: 40 %) -- the tables a tile kernel probes all the time (tiny + t8 + short +
+    // p8 + length masks) then take 4.1 instead of 5.1 MiB for cl100k_base, against 4 MiB of L2 per XCD; level 1: round 2's
+    // sizes (at most ~37 %).  The dense level is kept only if the salts below still place EVERY key in its home bucket
+    // (cl100k_base, llama3); otherwise the placement is redone at level 1.
+    uint32_t tbuckets = 0, ebuckets = 0, sbuckets = 0;
+    auto size_tables = [&](int level) {
+        auto nb = [&](size_t keys, int pct) { return level == 0 ? pow2_at_least(keys * 100 / (4 * (size_t)pct) + 2) : pow2_at_least(keys * 2 / 3 + 2); };
+        tbuckets = nb(n_tiny, 55); ebuckets = nb(n_t8, 55); sbuckets = nb(n_short, 40);
+        out.tiny_tab.assign((size_t)tbuckets * SPL_TINY_BUCKET * 2, SPL_EMPTY);
+        out.t8_tab.assign((size_t)ebuckets * SPL_T8_WORDS, SPL_EMPTY);
+        out.short_tab.assign((size_t)sbuckets * SPL_SHORT_BUCKET, ShortEnt{0, 0, 0, SPL_EMPTY});
+        out.unsalted_groups = 0;
+    };
+    const uint32_t lcap = pow2_at_least(n_long * 2 + 2);
     out.long_tab.assign(lcap, LongEnt{0, SPL_EMPTY, 0, 0});
     out.key_blob.clear();
     out.len_mask.assign(65536, 0);
@@ -302,7 +310,7 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
     {   // p8: for every 8-byte prefix of a longer token, the longest such token
         size_t n9 = 0;
         for (const auto& kv : enc) n9 += kv.first.size() > (size_t)SPL_T8_MAX;
-        const uint32_t buckets = std::max<uint32_t>(1u << 14, pow2_at_least(n9 * 4 + 2));   // sparse: a false hit costs parallelism
+        const uint32_t buckets = std::max<uint32_t>(1u << 14, pow2_at_least(n9 * 2 + 2));   // sparse: a false hit costs parallelism
         out.p8_tab.assign((size_t)buckets * 2, 0);
         for (const auto& kv : enc) {
             const std::string& k = kv.first;
@@ -332,7 +340,8 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
     // this costs speed only -- and only for the probes that land on those few buckets.
     // (SPL_BUCKET_FILL = the bucket size: a salted bucket may become completely FULL; what the salts guarantee
     //  is that no key OVERFLOWS.  Probes are settled by SPL_OVF_BIT alone, never by "the last slot is empty".)
-    {
+    for (int level = 0; level < 2; level++) {
+        size_tables(level);
         constexpr int SPL_BUCKET_FILL = 4;
         struct KeyRef { const std::string* k; uint32_t id; };
         std::vector<std::vector<KeyRef>> groups(65536);
@@ -410,6 +419,7 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
                 put(*kr.k, kr.id, bkt, which);
             }
         }
+        if (out.unsalted_groups == 0) break;             // every key in its home bucket: keep this density
     }
     for (const auto& kv : enc) {
         const std::string& k = kv.first;
