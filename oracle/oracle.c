@@ -459,7 +459,12 @@ static void orc_encode_chunk(orc_t *t, const uint8_t *sl, size_t n, ivec_t *out)
     uint32_t rk;
     if (bmap_get(&t->map, p, pn, &rk)) { iv_push(out, rk); goto done; }
     if (t->use_memo) {
-        uint64_t h = fx_hash(p, pn) | 1;
+        /* hash_slice (tokenizer.rs:643-647) is `slice.hash(&mut FxHasher)`: the LENGTH goes into the hasher before
+         * the bytes.  Without it "\0" and "\0\0" (h stays 0) collide and the memo hands out the wrong ids
+         * (tests/test_sanitizers.py found it: 4 configurations, 3 different token counts).  Like the reference's
+         * LruCache<u64, Vec<u32>>, the memo is keyed by the 64-bit hash alone. */
+        const uint64_t K = 0x517cc1b727220a95ull;
+        uint64_t h = (fx_hash(p, pn) ^ (((uint64_t)pn * K) << 5 | ((uint64_t)pn * K) >> 59)) * K | 1;
         memo_t *m = &t->memo[(h >> 32) % MEMO_SLOTS];
         pthread_mutex_lock(&t->memo_mu);
         if (m->key == h) {

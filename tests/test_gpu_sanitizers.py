@@ -1,0 +1,29 @@
+"""-m gpu: the host pipeline of spl_encode_batch under ThreadSanitizer (VERDICT r02 missing #6).
+tools/build_sanitizers.sh rebuilds the library's host side with -fsanitize=thread (the device code is unchanged) and
+tests/san/hostpath_driver.cpp, which drives a two-pipeline handle and a custom-pattern handle (host splitter
+threads) from two caller threads at once in many small chunks and checks every result.  Frames inside the
+uninstrumented HIP / HSA runtimes are suppressed (tests/san/tsan.supp); anything in this repo's code is reported."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+B = os.path.join(ROOT, "tests", "san", "_build")
+DATA = os.path.join(ROOT, "splintr_amd", "data")
+
+
+def test_host_pipeline_under_thread_sanitizer():
+    exe = os.path.join(B, "hostpath_tsan")
+    if not (os.path.exists(exe) and os.path.exists(os.path.join(B, "libsplintr_hip_tsan.so"))):
+        subprocess.check_call([os.path.join(ROOT, "tools", "build_sanitizers.sh")], timeout=900)
+    env = dict(os.environ, TSAN_OPTIONS=f"suppressions={os.path.join(ROOT, 'tests', 'san', 'tsan.supp')} halt_on_error=0 report_signal_unsafe=0")
+    p = subprocess.run([exe, os.path.join(DATA, "cl100k_base.splv"), os.path.join(DATA, "unicode_classes.bin")],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, (p.returncode, p.stdout[-1000:], p.stderr[-4000:])
+    assert "consistent" in p.stdout
+    ours = [blk for blk in p.stderr.split("==================") if "WARNING: ThreadSanitizer" in blk
+            and ("spl_" in blk or "splintr" in blk or "hostpath_driver" in blk)]
+    assert not ours, ours[0][-4000:]
