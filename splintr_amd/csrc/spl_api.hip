@@ -596,6 +596,7 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
         if (ntiles) hipLaunchKernelGGL(k_tile_out, dim3(ntiles), dim3(TOUT_NT), 0, s, b);
         MARK(KI_N);
     } else {
+#if SPL_MULTIPASS
     t->bitmap_dirty = true;
     MARK(KI_MARK);
     HIP_TRY(hipMemsetAsync(t->d_zero, 0, (nbm * uw + QCOUNT_WORDS) * 4, s));
@@ -634,6 +635,11 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
         hipLaunchKernelGGL(k_compact_docs, dim3(n_compact + n_docblk), dim3(NT), 0, s, b, n_compact);
     }
     MARK(KI_N);
+#else
+        (void)fused_scan_used;
+        return fail(SPL_EINVAL, "this call needs the multi-pass pipeline, which this build leaves out (-DSPL_MULTIPASS=1): a device call with "
+                                "SPL_WITH_SPECIAL beyond 256 MB, or a forced geometry; split the call -- spl_encode_batch does that by itself");
+#endif
     }
 #undef MARK
     {
@@ -1593,6 +1599,10 @@ int spl_debug_blocks(spl_tokenizer* t, unsigned long long* out, int max_blocks) 
 
 int spl_debug_phases(spl_tokenizer* t, int enable, unsigned long long stamps_out[16]) {
     if (!t) return fail(SPL_EINVAL, "null handle");
+#if !SPL_MULTIPASS
+    if (((enable >> 1) & 7) == 2 || ((enable >> 1) & 7) == 3)
+        return fail(SPL_EINVAL, "spl_debug_phases: geometries 2 and 3 are the multi-pass pipeline, which this build leaves out (-DSPL_MULTIPASS=1)");
+#endif
     for (auto& cp : t->ctx) {
         Ctx* c = cp.get();
         HIP_TRY(hipSetDevice(c->device));

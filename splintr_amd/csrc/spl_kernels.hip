@@ -33,6 +33,14 @@
 
 #define SPL_DBG_WG (b.dbg_wg == 0xFFFFFFFFu ? gridDim.x / 2 : b.dbg_wg)
 
+#ifndef SPL_MULTIPASS
+#define SPL_MULTIPASS 0        /* 1: also build the multi-pass pipeline (k_pretok without tile records -> k_deferred_wave -> k_bpe_lanes64 /
+                                  k_bpe_segments -> k_bpe_long -> k_count -> k_scan -> k_compact_docs; forced geometries 2 and 3, and
+                                  SPL_WITH_SPECIAL device calls beyond 256 MB).  No BASELINE configuration reaches it -- the host
+                                  pipeline feeds chunks of at most 8 MiB, tile-owned and queue mode cover device calls up to 2 GiB without
+                                  special tokens -- so the shipped library leaves it out: two instantiations of the
+                                  tile kernel and four kernels fewer to build and to keep correct in every fix. */
+#endif
 #ifndef SPL_NO_SLOWPATH
 #define SPL_NO_SLOWPATH 0      /* 1: timing experiment only (wrong ids for keys that overflowed their bucket): a full bucket never sends a probe on to the next one */
 #endif
@@ -1180,6 +1188,7 @@ __global__ __launch_bounds__(64) void k_deferred_wave(DeviceTables T, Batch b) {
 // in LDS (node-major, lane-minor: conflict-free when lanes touch the same node index), merge loop
 // = bpe_serial (spl_lookup.h).  Slow per chunk, but every lane carries its own chain of dependent
 // pair-table probes, so a CU keeps hundreds of them in flight.
+#if SPL_MULTIPASS
 template <int NMAX, int THREADS> struct LaneStore {
     uint32_t* ids;
     uint32_t* rks;
@@ -1219,6 +1228,7 @@ __global__ __launch_bounds__(64) void k_bpe_lanes64(DeviceTables T, Batch b) {
 // affected pairs concurrently.  No workgroup barrier: the four wavefronts of a workgroup work
 // on four different chunks.
 // Beyond WAVE_NMAX (pathological single-class runs): bpe_block_lds, then bpe_block_rounds.
+#endif  // SPL_MULTIPASS
 constexpr int GROUP_NMAX = 128;       // 16 lanes x 8 register slots
 constexpr int WAVE_NMAX = 512;
 constexpr uint32_t NIL16 = 0xFFFFu;
@@ -3508,6 +3518,7 @@ __global__ __launch_bounds__(NT) void k_bpe_long(DeviceTables T, Batch b, int su
         }
 }
 
+#if SPL_MULTIPASS
 // ------------------------------------------------------------------------------------------
 // Rank structure over the token-start bitmap.
 __global__ void k_count(Batch b) {
@@ -3600,6 +3611,8 @@ __global__ __launch_bounds__(NT) void k_compact_docs(Batch b, uint32_t n_compact
     r += __popc(b.tbits[wlast] & ((1u << (p & 31)) - 1u));
     b.off_out[d] = r;
 }
+
+#endif  // SPL_MULTIPASS
 
 // ------------------------------------------------------------------------------------------
 // decode_bytes (reference src/core/tokenizer.rs:877-897, batch form :945-958): gather token byte

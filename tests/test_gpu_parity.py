@@ -94,7 +94,8 @@ def test_invalid_utf8_policy(coracle, name, geom):
     the input bytes."""
     from splintr_amd import Tokenizer, _ffi
     t = Tokenizer.from_pretrained(name)
-    _ffi.lib().spl_debug_phases(t.handle, geom << 1, None)
+    if _ffi.lib().spl_debug_phases(t.handle, geom << 1, None) != 0:
+        pytest.skip("the multi-pass pipeline is not compiled into this build (-DSPL_MULTIPASS=1)")
     docs = invalid_utf8_corpus(31415 + geom, 3000)
     docs += [b"abc\xe4\xb8", b"\x96\x96 def", b"\xf0\x9f", b"\x8c\x8d", b"", b"\x80", b"\xe4", b"\xb8\x96"]
     docs += [b"\x80" * 3000, b"\xe4\xb8" * 1500, (b"ab\xc3" * 400) + b"\n" + b"\xbf" * 700]
@@ -234,7 +235,10 @@ def _force_tiles(name, mode):
     import ctypes
     from splintr_amd import _ffi
     st = (ctypes.c_uint64 * 16)()
-    assert _ffi.lib().spl_debug_phases(tok(name).handle, mode << 1, st) == 0
+    rc = _ffi.lib().spl_debug_phases(tok(name).handle, mode << 1, st)
+    if rc != 0 and mode in (2, 3):
+        pytest.skip("the multi-pass pipeline is not compiled into this build (-DSPL_MULTIPASS=1)")
+    assert rc == 0
 
 
 @pytest.mark.parametrize("geom", [1, 2, 3, 5])
@@ -538,7 +542,7 @@ def test_gatherv_bucketed_unpack_two_simulated_ranks(coracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("geom", [0, 2])
+@pytest.mark.parametrize("geom", [0, 2, 4])
 def test_encode_packed_slab_equals_pack_kernel(geom):
     """spl_encode_batch_device_packed must leave the same slab as encode + spl_gatherv_pack, in
     tile-owned mode (the last kernel writes it) and in multi-pass mode (pack kernel queued)."""

@@ -16,7 +16,19 @@ REACHABLE = [0, 0, 0, 4, 5, 5]            # modes a BASELINE config reaches (and
 BUDGET_S = 25.0
 
 
+def _compiled(modes):
+    """forced geometries 2 and 3 are the multi-pass pipeline: only in -DSPL_MULTIPASS=1 builds"""
+    import ctypes
+    from splintr_amd import _ffi
+    st = (ctypes.c_uint64 * 16)()
+    h = tg.tok("cl100k_base").handle
+    ok = [m for m in modes if _ffi.lib().spl_debug_phases(h, m << 1, st) == 0]
+    _ffi.lib().spl_debug_phases(h, 0, st)
+    return ok
+
+
 def _run(gen, seeds, required, coracle, modes):
+    modes = _compiled(modes)
     t0 = time.time()
     done = 0
     for k, seed in enumerate(seeds):
