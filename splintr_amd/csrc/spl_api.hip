@@ -512,6 +512,7 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
     const bool queue_mode = !ext && !special && (t->force_tile == 4 || (t->force_tile == 0 && n_bytes > SPL_DIRECT_MAX_BYTES)) &&
                             n_bytes <= SPL_QUEUE_MAX_BYTES;
     const bool small_tiles = ext || queue_mode || t->force_tile == 1 || t->force_tile == 3 || t->force_tile == 5 ||
+                             (t->force_tile == 4 && special) ||          // (queue mode has no special-token form: tile-owned)
                              (t->force_tile == 0 && n_bytes <= SPL_DIRECT_MAX_BYTES);
     const bool direct = ext || (!queue_mode && small_tiles && t->force_tile != 3 && n_bytes <= SPL_DIRECT_MAX_BYTES);
     // tile-owned mode: two geometries of the same window (spl_kernels.hip SPL_TILE_DIRECT_A / _B; force 5: B at any size)
