@@ -299,7 +299,7 @@ def main():
         b_alg = (bytes_rot + 4 * sum(n_tokens) + 16 * sum(b.n_docs + 1 for b in batches)) / N_ROT
         achieved = b_alg / (kernels[dom] * 1e-6) / 1e9
         traffic, tsrc = None, None
-        for cand in ("r02_hbm_traffic.json", "hbm_traffic.json"):
+        for cand in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "hbm_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", cand)
             if os.path.exists(tpath):
                 try:
@@ -316,8 +316,9 @@ def main():
                     "all_kernels_us": kernels}
         # the roofline that binds this kernel: VALU issue.  Counters come from rocprofv3 --pmc (not
         # available inside a plain run): the committed pass over this very command.
-        vpath = os.path.join(ROOT, "profiles", "r02_pmc_sq.json")
-        if os.path.exists(vpath):
+        vname = next((n for n in ("r03_pmc_sq.json", "r02_pmc_sq.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
+        vpath = os.path.join(ROOT, "profiles", vname) if vname else ""
+        if vname:
             try:
                 v = json.load(open(vpath)).get(dom)
                 if v:
@@ -326,7 +327,7 @@ def main():
                                      "kernel_cycles": v["kernel_cycles"], "simds": 1024,
                                      "frac": round(v["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * v["kernel_cycles"]), 4),
                                      "lane_utilisation": v.get("lane_utilisation"),
-                                     "source": "profiles/r02_pmc_sq.json (rocprofv3 --pmc passes of this command, committed; NOT measured by this run)"}
+                                     "source": f"profiles/{vname} (rocprofv3 --pmc passes of this command, committed; NOT measured by this run)"}
             except Exception:
                 roofline_valu = None
 
