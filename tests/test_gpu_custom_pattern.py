@@ -111,14 +111,24 @@ def test_multi_chunk_pipeline_and_special_tokens():
 def test_a_scanner_pattern_through_the_host_splitter_gives_the_scanner_s_ids(coracle):
     """CL100K_BASE_PATTERN wrapped in a group is a different STRING, so it takes the host splitter: same ids as the
     GPU scanner (and the C oracle) on the same text."""
-    from splintr_amd import Tokenizer, CL100K_BASE_PATTERN, O200K_BASE_PATTERN
+    from splintr_amd import Tokenizer, CL100K_BASE_PATTERN, O200K_BASE_PATTERN, MISTRAL_V3_PATTERN
     from test_gpu_parity import assert_batch_equal, tok
+    from splintr_amd import corpus
+    from test_gpu_parity import _multibyte_texts
     texts = _texts(9)
-    for name, pat in (("cl100k_base", CL100K_BASE_PATTERN), ("o200k_base", O200K_BASE_PATTERN)):
+    # ... and batches large enough for the second tile geometry (864 + 128 beyond 1.25 MiB), for several pipeline
+    # chunks (beyond 4 MiB) and with long multi-byte chunks; the scanner's own parity is established elsewhere, so
+    # GPU against GPU is the check here and the oracle's speed no limit
+    big = corpus.c2(1500, seed=5) + corpus.c3(300, seed=6) + _multibyte_texts(8, 40, 20000)
+    huge = corpus.c2(3000, seed=7) + corpus.c3(900, seed=8)
+    assert sum(len(x.encode()) for x in big) > (2 << 20) and sum(len(x.encode()) for x in huge) > (6 << 20)
+    for name, pat in (("cl100k_base", CL100K_BASE_PATTERN), ("o200k_base", O200K_BASE_PATTERN),
+                      ("deepseek_v3", O200K_BASE_PATTERN), ("mistral_v3", MISTRAL_V3_PATTERN)):      # (the last two: ByteLevel vocabularies)
         t = Tokenizer.from_bytes(_blob(name), "(?:" + pat + ")")
-        ids, off = t.encode_batch_csr(texts)
-        w_ids, w_off = tok(name).encode_batch_csr(texts)
-        assert np.array_equal(off, w_off) and np.array_equal(ids, w_ids)
+        for batch in (texts, big, huge, ["".join(big)]):
+            ids, off = t.encode_batch_csr(batch)
+            w_ids, w_off = tok(name).encode_batch_csr(batch)
+            assert np.array_equal(off, w_off) and np.array_equal(ids, w_ids)
 
 
 def test_split_on_the_host_encode_on_the_device_entry_points():
