@@ -346,7 +346,8 @@ def main():
                                "c_abi_host_pageable: the same from pageable memory (one extra host copy into pinned staging); "
                                "python_surface: Tokenizer.encode_batch(list[str]) -> list[list[int]]; decode_host: spl_decode_batch, ids CSR on the host -> "
                                "bytes CSR on the host (pinned in and out), MB/s of decoded bytes; c2_wide: C2's mix over a >= 20 000-word "
-                               "lexicon (splintr_amd.corpus.c2_wide)")
+                               "lexicon (splintr_amd.corpus.c2_wide); encode_one_call_us: Tokenizer.encode(text) on the batch's first document -- one GPU "
+                               "round trip per call, a latency figure")
 
     # ---- BASELINE config 4: llama3, 1 M short prompts, doc-sharded over the ranks (strong scaling) -------
     c4 = c5 = None

@@ -104,6 +104,10 @@ def measure(cfg: str, docs=None, python_surface=True, devices=None, options=None
         assert sum(map(len, got)) == out["tokens"]
         del got
         out["python_surface"] = round(nb / timed(lambda: tok.encode_batch(texts), min_s=1.0) / 1e6, 1)
+        # one text per call (Tokenizer.encode, src/python/bindings.rs:254-256): a GPU round trip per call, latency not throughput
+        one = texts[0]
+        out["encode_one_call_us"] = round(timed(lambda: tok.encode(one), min_s=0.3) * 1e6, 1)
+        out["encode_one_call_bytes"] = len(one.encode("utf-8"))
     return out
 
 
