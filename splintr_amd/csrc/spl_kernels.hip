@@ -364,8 +364,24 @@ __device__ __forceinline__ uint32_t row16_min(uint32_t x) {
     return x;
 #endif
 }
+#ifndef SPL_PAIR_SHORT
+#define SPL_PAIR_SHORT 1         /* 1: two chunks of up to 8 bytes share a 16-lane group, each in a half (a tile with 17..32 short misses
+                                    then needs ONE pull per group more often: its shortest misses are the ones beyond the sixteenth) */
+#endif
+// The same with the group's width chosen per 16-lane row at run time: 8 lanes (two chunks of up to 8 bytes share a row,
+// each in a half) or 16.  Three steps reduce inside the halves; the fourth joins them where the row is one group.
+__device__ __forceinline__ uint32_t row_min_sub(uint32_t x, bool whole_row) {
+    asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf"
+                 : "+v"(x));
+    uint32_t y = x;
+    asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(y));
+    return whole_row ? y : x;
+}
 // all-reduce(min) over a group of GW = 16 or 32 lanes (32: the two rows of a half exchanged by ds_swizzle)
-template <int GW> __device__ __forceinline__ uint32_t group_min(uint32_t x) {
+template <int GW> __device__ __forceinline__ uint32_t group_min(uint32_t x, int sub = GW) {
+    if (GW == 16 && SPL_PAIR_SHORT) return row_min_sub(x, sub == 16);     // (one instruction stream for both widths: rows of a wavefront differ)
     x = row16_min(x);
     if (GW == 32) {
         const uint32_t y = (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, 0x401F);   // lane ^ 16
@@ -644,18 +660,19 @@ __device__ __forceinline__ uint32_t t8_finish(const DeviceTables& T, uint32_t k0
 // far_max (per lane): the longest token of more than SUB_LMAX bytes that can start at this lane's byte
 // (p8 table: an upper bound; 0 = none) -- longer spans rank SPL_NO_RANK without a trip to the pair table.
 constexpr int FAR_UNBOUNDED = 1 << 20;
+// sub (GW == 16 only): 8 if the row holds TWO chunks of up to 8 bytes, one per half, else 16 -- uniform per 16-lane row.
 template <int GW, class Emit>
-__device__ __forceinline__ void group_merge(const DeviceTables& T, const uint32_t* row, uint32_t id, int n, int far_max, Emit emit) {
+__device__ __forceinline__ void group_merge(const DeviceTables& T, const uint32_t* row, uint32_t id, int n, int far_max, Emit emit, int sub = GW) {
     static_assert(GW == 16 || GW == 32, "groups of 16 or 32 lanes");
     const int lane = threadIdx.x & 63;
-    const int gl = lane & (GW - 1);
+    const int gl = lane & (sub - 1);
     const int gbase = lane - gl;
     const bool own = gl < n;
     uint32_t rk = (gl + 1 < n) ? row[0] : SPL_NO_RANK;          // initial ranks (bpe.rs:114-116)
     uint32_t alive = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);   // group-uniform, kept by every lane
     for (;;) {
         const uint32_t key = rk == SPL_NO_RANK ? 0xFFFFFFFFu : ((rk << 8) | (uint32_t)gl);
-        const uint32_t m = group_min<GW>(key);
+        const uint32_t m = group_min<GW>(key, sub);
         const bool active = m != 0xFFFFFFFFu;
         if (!__any(active)) break;
         const int mi = (int)(m & 255u);
@@ -680,7 +697,7 @@ __device__ __forceinline__ void group_merge(const DeviceTables& T, const uint32_
         const int cell = len - 2 < 0 ? 0 : len - 2 > SUB_W - 1 ? SUB_W - 1 : len - 2;
         uint32_t nr = len > SUB_LMAX ? SPL_NO_RANK : row[cell];
         if (__any(far)) {
-            const uint32_t id_j2 = __shfl(id, gbase + (j2 & (GW - 1)));     // only long spans need neighbour ids
+            const uint32_t id_j2 = __shfl(id, gbase + (j2 & (sub - 1)));     // only long spans need neighbour ids
             if (far) nr = is_mi ? pair_rank(T, mn, id_j2) : pair_rank(T, id, mn);
         }
         nr = (is_mi && j2 < 0) ? SPL_NO_RANK : nr;
@@ -701,12 +718,12 @@ __device__ __forceinline__ void group_merge(const DeviceTables& T, const uint32_
 #define SPL_MERGE_NEAR 1
 #endif
 template <int GW, class Emit>
-__device__ __forceinline__ void group_merge_near(const uint32_t* row, uint32_t id, int n, Emit emit) {
-    const int gl = (threadIdx.x & 63) & (GW - 1);
+__device__ __forceinline__ void group_merge_near(const uint32_t* row, uint32_t id, int n, Emit emit, int sub = GW) {
+    const int gl = (threadIdx.x & 63) & (sub - 1);
     uint32_t rk = (gl + 1 < n) ? row[0] : SPL_NO_RANK;
     uint32_t alive = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
     for (;;) {
-        const uint32_t m = group_min<GW>((rk << 8) | (uint32_t)gl);     // (SPL_NO_RANK << 8 is beyond every real key)
+        const uint32_t m = group_min<GW>((rk << 8) | (uint32_t)gl, sub);     // (SPL_NO_RANK << 8 is beyond every real key)
         const bool active = m < 0xFFFFFF00u;
         if (!__any(active)) break;
         // an idle group "merges" at index 31: nothing lies above it, nobody owns it, bit 31 of alive goes (GW = 16)
@@ -804,23 +821,24 @@ __device__ __forceinline__ uint32_t tab_row(const DeviceTables& T, const LdsAcc&
     return id;
 }
 
+// width (GW == 16): 8 if this 16-lane row holds TWO chunks of up to 8 bytes (p, n: per half), else 16
 template <int GW, class Emit>
 __device__ __forceinline__ void bpe_group_tab(const DeviceTables& T, const LdsAcc& tx, int p, int n, uint32_t* sub,
-                                              Emit emit, long long* wt = nullptr) {
+                                              Emit emit, long long* wt = nullptr, int width = GW) {
     (void)wt;
     SPL_WT(0);
-    const int gl = (threadIdx.x & 63) & (GW - 1);
-    uint32_t* row = sub + gl * SUB_W;
+    const int gl = (threadIdx.x & 63) & (width - 1);
+    uint32_t* row = sub + ((threadIdx.x & 63) & (GW - 1)) * SUB_W;
     int far_max;
     const uint32_t id = tab_row(T, tx, gl < n, p + gl, n - gl, row, far_max, wt);
-    if (SPL_MERGE_NEAR && !__any(far_max > 0)) group_merge_near<GW>(row, id, n, emit);
-    else group_merge<GW>(T, row, id, n, far_max, emit);
+    if (SPL_MERGE_NEAR && !__any(far_max > 0)) group_merge_near<GW>(row, id, n, emit, width);
+    else group_merge<GW>(T, row, id, n, far_max, emit, width);
     SPL_WT(4);
 }
 template <class Emit>
 __device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const LdsAcc& tx, int p, int n, uint32_t* sub,
-                                                Emit emit, long long* wt = nullptr) {
-    bpe_group_tab<16>(T, tx, p, n, sub, emit, wt);
+                                                Emit emit, long long* wt = nullptr, int width = 16) {
+    bpe_group_tab<16>(T, tx, p, n, sub, emit, wt, width);
 }
 
 // The same merge loop for ONE chunk of up to 64 bytes per WAVEFRONT, one node per lane.  Everything
@@ -2762,19 +2780,26 @@ void k_pretok(DeviceTables T, Batch b) {
                                put(p + i, id);
                            });
         }
+        // The sorted list holds the chunks of 9..16 bytes first (items [0, first8)), then those of up to 8.  A SLOT is one
+        // 16-lane group's work of a pull: one chunk of the first kind, or two of the second, one per half of the group.
+        const uint32_t first8 = (SPL_PAIR_SHORT && SORT_SHORT) ? s_scnt[8] : m16;
+        const uint32_t nslots = first8 + (m16 - first8 + 1u) / 2u;
         for (;;) {
             uint32_t it = 0;
             if ((lane & 15) == 0) it = atomicAdd(&s_nq[2], 1u);
             it = __shfl(it, lane & ~15);
-            const bool has = it < m16;
-            if (!__any(has)) break;
+            const bool slot = it < nslots;
+            if (!__any(slot)) break;
 #ifdef SPL_DEBUG_STAMPS
             ws_nshort++;
 #endif
+            const bool paired = slot && it >= first8;
+            const uint32_t k = paired ? first8 + 2u * (it - first8) + (uint32_t)((lane >> 3) & 1) : it;
+            const bool has = slot && k < m16;
             uint32_t item = 0;
             if (has) {
-                if (SORT_SHORT) { const uint32_t c = s_cpos[it]; item = (c & 0x3FFu) | (((c >> 10) + 1u) << 16); }
-                else item = s_miss[it];
+                if (SORT_SHORT) { const uint32_t c = s_cpos[k]; item = (c & 0x3FFu) | (((c >> 10) + 1u) << 16); }
+                else item = s_miss[k];
             }
             const int p = (int)(item & 0xFFFFu);
 #if defined(SPL_DEBUG_STAMPS) && !defined(SPL_STAMP_MEDIUM)
@@ -2785,7 +2810,7 @@ void k_pretok(DeviceTables T, Batch b) {
             bpe_group16_tab(T, LdsAcc{s_rec, s_txt}, p, has ? (int)(item >> 16) : 0, s_sub[tid >> 4],
                             [&](int i, uint32_t id) {
                                 put(p + i, id);
-                            }, wtp);
+                            }, wtp, paired ? 8 : 16);
         }
 #ifdef SPL_DEBUG_STAMPS
         if (b.dbg && blockIdx.x == SPL_DBG_WG && (tid & 63) == 0) {
