@@ -384,8 +384,17 @@ template <int GW> __device__ __forceinline__ uint32_t group_min(uint32_t x, int 
     if (GW == 16 && SPL_PAIR_SHORT) return row_min_sub(x, sub == 16);     // (one instruction stream for both widths: rows of a wavefront differ)
     x = row16_min(x);
     if (GW == 32) {
+#ifndef SPL_NO_PERMLANE_SWAP
+        // gfx950: v_permlane16_swap_b32 exchanges the odd rows of one operand with the even rows of the other -- with both
+        // operands holding x, one result has every row pair's even row twice, the other its odd row twice: one VALU
+        // instruction where ds_swizzle (lane ^ 16) went through the LDS crossbar, in every round of a 17..32-byte word's merge
+        const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+        const uint32_t a = r[0], c = r[1];
+        x = a < c ? a : c;
+#else
         const uint32_t y = (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, 0x401F);   // lane ^ 16
         x = y < x ? y : x;
+#endif
     }
     return x;
 }
