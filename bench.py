@@ -341,13 +341,19 @@ def main():
                 throughputs[cfg] = host_path_bench.measure(cfg)
             except Exception as e:          # a failure here must not cost the headline line
                 throughputs[cfg] = {"error": repr(e)}
+        try:
+            throughputs["c2_custom_pattern"] = host_path_bench.measure_custom()
+        except Exception as e:
+            throughputs["c2_custom_pattern"] = {"error": repr(e)}
         throughputs["note"] = ("MB/s of input bytes. kernel_hbm: corpus resident in HBM (one batch, re-encoded); c_abi_host: "
                                "spl_encode_batch host bytes -> host CSR incl. H2D/D2H, input from spl_host_alloc; "
                                "c_abi_host_pageable: the same from pageable memory (one extra host copy into pinned staging); "
                                "python_surface: Tokenizer.encode_batch(list[str]) -> list[list[int]]; decode_host: spl_decode_batch, ids CSR on the host -> "
                                "bytes CSR on the host (pinned in and out), MB/s of decoded bytes; c2_wide: C2's mix over a >= 20 000-word "
                                "lexicon (splintr_amd.corpus.c2_wide); encode_one_call_us: Tokenizer.encode(text) on the batch's first document -- one GPU "
-                               "round trip per call, a latency figure")
+                               "round trip per call, a latency figure; c2_custom_pattern: the C2 batch through a handle with GPT-2's split pattern, which the "
+                               "GPU scanner does not implement -- split_host: the host splitter alone, kernel_hbm_given_boundaries: the tile kernel on given "
+                               "chunk boundaries (spl_encode_chunks_device), c_abi_host / python_surface: the calls a user makes")
 
     # ---- BASELINE config 4: llama3, 1 M short prompts, doc-sharded over the ranks (strong scaling) -------
     c4 = c5 = None

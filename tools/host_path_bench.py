@@ -111,7 +111,66 @@ def measure(cfg: str, docs=None, python_surface=True, devices=None, options=None
     return out
 
 
+GPT2_PATTERN = r"'s|'t|'re|'ve|'m|'ll|'d| ?\p{L}+| ?\p{N}+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+"
+
+
+def measure_custom(docs=1000):
+    """A split pattern the GPU scanner does not implement (GPT-2's, over the cl100k vocabulary) on the C2 batch: the
+    host splitter alone (spl_split_host), the tile kernel on GIVEN boundaries (spl_encode_chunks_device, kernel-only),
+    and the calls a user makes (host splitter + pipeline)."""
+    import torch
+    from splintr_amd import Tokenizer, corpus, _ffi
+    from splintr_amd.device import DeviceBatch
+    import os as _os
+    here = _os.path.join(ROOT, "splintr_amd", "data", "cl100k_base.splv")
+    tok = Tokenizer(here, GPT2_PATTERN)
+    L = _ffi.lib()
+    texts = corpus.c2(docs)
+    bs = [t.encode("utf-8") for t in texts]
+    off = np.zeros(len(bs) + 1, dtype=np.uint64)
+    np.cumsum([len(b) for b in bs], out=off[1:])
+    blob = b"".join(bs)
+    nb = len(blob)
+    out = {"config": "c2 batch, GPT-2 split pattern (host splitter)", "vocab": "cl100k_base", "docs": docs, "bytes": nb, "unit": "MB/s",
+           "host_threads": _os.cpu_count()}
+    words = nb // 32 + 2
+    st, gp = np.zeros(words, dtype=np.uint32), np.zeros(words, dtype=np.uint32)
+
+    def split():
+        assert L.spl_split_host(tok.handle, blob, off.ctypes.data, len(bs), st.ctypes.data, gp.ctypes.data) == 0, _ffi.last_error()
+    out["split_host"] = round(nb / timed(split) / 1e6, 1)
+    dev = torch.device("cuda", 0)
+    b = DeviceBatch(texts, dev)
+    d_st, d_gp = torch.from_numpy(st.view(np.int32)).to(dev), torch.from_numpy(gp.view(np.int32)).to(dev)
+    assert L.spl_reserve(tok.handle, b.n_bytes, b.n_docs) == 0
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def k():
+        rc = L.spl_encode_chunks_device(tok.handle, b.text.data_ptr(), b.n_bytes, b.doc_off.data_ptr(), b.n_docs, d_st.data_ptr(), d_gp.data_ptr(),
+                                        b.ids.data_ptr(), b.ids.numel(), b.out_off.data_ptr(), stream)
+        assert rc == 0, _ffi.last_error()
+        torch.cuda.synchronize()
+    out["kernel_hbm_given_boundaries"] = round(nb / timed(k) / 1e6, 1)
+    out["tokens"] = int(b.out_off[-1].item())
+
+    def c_abi(ptr):
+        def f():
+            r = ctypes.c_void_p()
+            assert L.spl_encode_batch(tok.handle, ptr, off.ctypes.data, len(bs), 0, ctypes.byref(r)) == 0, _ffi.last_error()
+            L.spl_result_free(r)
+        return f
+    p = L.spl_host_alloc(nb + 64)
+    ctypes.memmove(p, blob, nb)
+    out["c_abi_host"] = round(nb / timed(c_abi(p)) / 1e6, 1)
+    L.spl_host_free(p)
+    out["python_surface"] = round(nb / timed(lambda: tok.encode_batch(texts), min_s=1.0) / 1e6, 1)
+    return out
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "custom":
+        print(json.dumps(measure_custom()))
+        sys.exit(0)
     cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
     docs = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2] != "-" else None
     opts = dict(a.split("=") for a in sys.argv[3:])
