@@ -960,7 +960,7 @@ int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t
             memset(hb, 0, 2 * bw * 4);
             const bool special = (flags & SPL_WITH_SPECIAL) && !tk->specials.empty();
             std::vector<SpHit> hits;
-            int rcs = host_split_docs(tk, utf8 + ch.lo, rel, nd, special, hb, hb + bw, &hits, 32);
+            int rcs = host_split_docs(tk, utf8 + ch.lo, rel, nd, special, hb, hb + bw, &hits, 128);
             if (rcs) return rcs;
             HIP_TRY(hipMemcpyAsync(c->d_ext[sl], hb, 2 * bw * 4, hipMemcpyHostToDevice, hs));
             ext.d_starts = c->d_ext[sl]; ext.d_gaps = c->d_ext[sl] + bw;
@@ -1765,7 +1765,7 @@ int spl_split_host(spl_tokenizer* t, const uint8_t* utf8, const uint64_t* doc_of
         const uint64_t words = doc_off[n_docs] / 32 + 2;
         memset(start_bits, 0, words * 4);
         memset(gap_bits, 0, words * 4);
-        return host_split_docs(t, utf8, doc_off, n_docs, false, start_bits, gap_bits, nullptr, 64);
+        return host_split_docs(t, utf8, doc_off, n_docs, false, start_bits, gap_bits, nullptr, 128);
     });
 }
 

@@ -14,11 +14,16 @@ struct ClassSet {
     uint32_t codes = 0;                                   // bit c: every code point of class code c (spl_common.h C_*)
     std::vector<std::pair<uint32_t, uint32_t>> ranges;    // inclusive code-point ranges
     bool neg = false;
+    uint64_t ascii[2] = {0, 0};                           // membership of U+0000..U+007F, precomputed (regex_compile)
 };
 
-enum Op : uint8_t { OP_CHAR, OP_CHAR_FOLD, OP_CLASS, OP_ANY, OP_SPLIT, OP_JMP, OP_MATCH, OP_LOOK, OP_NLOOK };
-struct Inst { Op op; uint32_t x, y; };                  // CHAR: x = cp; CLASS: x = set; SPLIT: x first, y second; JMP: x;
+enum Op : uint8_t { OP_CHAR, OP_CHAR_FOLD, OP_CLASS, OP_ANY, OP_SPLIT, OP_JMP, OP_MATCH, OP_LOOK, OP_NLOOK, OP_REP1 };
+struct Inst { Op op; uint32_t x, y; uint32_t f = 0xFFFFFFFFu; };   // f (SPLIT of an alternation): first-character filter of branch x
+// which characters can START a match of an alternative: 128 bits for ASCII, one flag for everything else (conservative)
+struct FirstSet { uint64_t ascii[2] = {0, 0}; bool other = false; };                  // CHAR: x = cp; CLASS: x = set; SPLIT: x first, y second; JMP: x;
                                                           // LOOK / NLOOK: sub-program at pc + 1 (ends in MATCH), x = continuation
+                                                          // REP1: greedy x..y (y == UINT32_MAX: unbounded) repeats of the ONE-character
+                                                          //       instruction at pc + 1; goes on at pc + 2
 
 struct Node {
     enum Kind { CHAR, CLASS, ANY, CAT, ALT, REP, LOOK, EMPTY } kind = EMPTY;
@@ -34,6 +39,7 @@ struct Node {
 struct RegexProg {
     std::vector<Inst> code;
     std::vector<ClassSet> sets;
+    std::vector<FirstSet> firsts;
     const HostTables* ht = nullptr;
 };
 void RegexDeleter::operator()(RegexProg* p) const { delete p; }
@@ -342,6 +348,45 @@ struct Emitter {
         p.code.push_back(Inst{op, x, y});
         return (uint32_t)p.code.size() - 1;
     }
+    // The characters a match of `n` can start with, OR-ed into fs; returns whether n can match without consuming one
+    // (then whatever follows it contributes too).  Exact for ASCII, one conservative flag for everything beyond.
+    bool first_of(const Node& n, FirstSet& fs) const {
+        auto add = [&](uint32_t c) { fs.ascii[c >> 6] |= 1ull << (c & 63); };
+        switch (n.kind) {
+            case Node::EMPTY: case Node::LOOK: return true;
+            case Node::CHAR:
+                if (n.cp < 0x80) { add(n.cp); if (n.fold) { add(n.cp ^ 0x20u); fs.other = true; } }      // (fold: U+017F, U+212A)
+                else fs.other = true;
+                return false;
+            case Node::ANY:
+                fs.ascii[0] = ~0ull & ~(1ull << '\n'); fs.ascii[1] = ~0ull; fs.other = true;
+                return false;
+            case Node::CLASS: {
+                const ClassSet& cs = p.sets[n.set];
+                for (uint32_t c = 0; c < 128; c++) {
+                    const uint32_t cls = p.ht->ucls_stage2[((uint32_t)p.ht->ucls_stage1[0] << p.ht->ucls_shift) | c];
+                    bool in = ((cs.codes >> cls) & 1u) != 0;
+                    for (const auto& r : cs.ranges) in = in || (c >= r.first && c <= r.second);
+                    if (in != cs.neg) add(c);
+                }
+                fs.other = true;
+                return false;
+            }
+            case Node::CAT:
+                for (const auto& k : n.kids) if (!first_of(*k, fs)) return false;
+                return true;
+            case Node::ALT: {
+                bool nul = false;
+                for (const auto& k : n.kids) nul = first_of(*k, fs) || nul;
+                return nul;
+            }
+            case Node::REP: {
+                const bool nul = first_of(*n.kids[0], fs);
+                return nul || n.lo == 0;
+            }
+        }
+        return true;
+    }
     void gen(const Node& n) {
         if (too_big) return;
         switch (n.kind) {
@@ -356,6 +401,11 @@ struct Emitter {
                     if (k + 1 < n.kids.size()) {
                         const uint32_t sp = emit(OP_SPLIT);
                         p.code[sp].x = sp + 1;
+                        FirstSet fs;
+                        if (!first_of(*n.kids[k], fs)) {                // (an alternative that can match the empty string is always tried)
+                            p.code[sp].f = (uint32_t)p.firsts.size();
+                            p.firsts.push_back(fs);
+                        }
                         gen(*n.kids[k]);
                         jumps.push_back(emit(OP_JMP));
                         p.code[sp].y = (uint32_t)p.code.size();
@@ -366,6 +416,13 @@ struct Emitter {
             }
             case Node::REP: {
                 const Node& e = *n.kids[0];
+                if (!n.lazy && (e.kind == Node::CHAR || e.kind == Node::CLASS || e.kind == Node::ANY)) {
+                    // a greedy run of ONE-character items (\p{L}+, \s*, [\r\n]*, ' ?'): taken in one go with ONE way back
+                    // on the stack (give one character back, re-counted from the run's start) instead of one per character
+                    emit(OP_REP1, n.lo, n.hi);
+                    gen(e);
+                    break;
+                }
                 for (uint32_t k = 0; k < n.lo; k++) gen(e);
                 if (n.hi == UINT32_MAX) {                               // e*: L0: SPLIT L1, end; L1: e; JMP L0
                     const uint32_t l0 = emit(OP_SPLIT);
@@ -435,37 +492,94 @@ struct Matcher {
     size_t n;
     uint64_t steps = 0;
     uint64_t step_max = 0;                                               // per match attempt
-    std::vector<std::pair<uint32_t, size_t>> stack;
+    struct Frame { uint32_t pc, k; size_t pos; };                        // k == NO_K: go on at pc; else: REP1 at pc, retry with k characters
+    static constexpr uint32_t NO_K = 0xFFFFFFFFu;
+    std::vector<Frame> stack;
 
+    bool one_ascii(const Inst& in, uint32_t b) const {                   // ... an ASCII byte (no decoding, no class lookup)
+        if (in.op == OP_CHAR) return b == in.x;
+        if (in.op == OP_CHAR_FOLD) return (b | 0x20u) == (in.x | 0x20u) && ((b | 0x20u) - 'a') < 26u;
+        if (in.op == OP_ANY) return b != '\n';
+        return ((p.sets[in.x].ascii[b >> 6] >> (b & 63)) & 1ull) != 0;
+    }
+    bool one(const Inst& in, const Ch& c) const {                        // does the one-character instruction take c?
+        if (in.op == OP_CHAR) return c.cp == in.x;
+        if (in.op == OP_CHAR_FOLD) return c.cp != CP_INVALID && fold_eq(in.x, c.cp);
+        if (in.op == OP_ANY) return c.cp != '\n';
+        return in_set(p.sets[in.x], c);
+    }
     // longest-by-priority match of the program that starts at `pc0`, anchored at `pos`; SIZE_MAX: no match
     size_t run(uint32_t pc0, size_t pos0) {
         const size_t floor = stack.size();
-        stack.emplace_back(pc0, pos0);
+        stack.push_back(Frame{pc0, NO_K, pos0});
         while (stack.size() > floor) {
-            uint32_t pc = stack.back().first;
-            size_t pos = stack.back().second;
+            uint32_t pc = stack.back().pc;
+            size_t pos = stack.back().pos;
+            const uint32_t retry_k = stack.back().k;
             stack.pop_back();
+            if (retry_k != NO_K) {                                        // a REP1 gives a character back: k of them from the run's start
+                const Inst& in = p.code[pc];
+                if (retry_k > in.x) stack.push_back(Frame{pc, retry_k - 1, pos});
+                for (uint32_t k = 0; k < retry_k; k++) pos += t[pos] < 0x80 ? 1u : decode(*p.ht, t, pos, n).len;
+                steps += retry_k;
+                pc += 2;
+            }
             for (;;) {
                 if (++steps > step_max) { stack.resize(floor); return SIZE_MAX - 1; }
                 const Inst& in = p.code[pc];
                 if (in.op == OP_MATCH) { stack.resize(floor); return pos; }
                 if (in.op == OP_JMP) { pc = in.x; continue; }
-                if (in.op == OP_SPLIT) { stack.emplace_back(in.y, pos); pc = in.x; continue; }
+                if (in.op == OP_SPLIT) {
+                    if (in.f != 0xFFFFFFFFu) {                            // an alternative that cannot start with this character: the next one
+                        bool can = false;
+                        if (pos < n) {
+                            const uint32_t b = t[pos];
+                            const FirstSet& fs = p.firsts[in.f];
+                            can = b < 0x80 ? ((fs.ascii[b >> 6] >> (b & 63)) & 1ull) != 0 : fs.other;
+                        }
+                        if (!can) { pc = in.y; continue; }
+                    }
+                    stack.push_back(Frame{in.y, NO_K, pos});
+                    pc = in.x;
+                    continue;
+                }
                 if (in.op == OP_LOOK || in.op == OP_NLOOK) {
                     const size_t r = run(pc + 1, pos);
                     if (r == SIZE_MAX - 1) { stack.resize(floor); return r; }
                     if ((r != SIZE_MAX) == (in.op == OP_LOOK)) { pc = in.x; continue; }
                     break;
                 }
+                if (in.op == OP_REP1) {
+                    const Inst& a = p.code[pc + 1];
+                    size_t q = pos;
+                    uint32_t k = 0;
+                    while (k < in.y && q < n) {
+                        if (t[q] < 0x80) {
+                            if (!one_ascii(a, t[q])) break;
+                            q++;
+                        } else {
+                            const Ch c = decode(*p.ht, t, q, n);
+                            if (!one(a, c)) break;
+                            q += c.len;
+                        }
+                        k++;
+                    }
+                    steps += k;
+                    if (k < in.x) break;
+                    if (k > in.x) stack.push_back(Frame{pc, k - 1, pos});
+                    pos = q;
+                    pc += 2;
+                    continue;
+                }
                 if (pos >= n) break;
-                const Ch c = decode(*p.ht, t, pos, n);
-                bool ok;
-                if (in.op == OP_CHAR) ok = c.cp == in.x;
-                else if (in.op == OP_CHAR_FOLD) ok = c.cp != CP_INVALID && fold_eq(in.x, c.cp);
-                else if (in.op == OP_ANY) ok = c.cp != '\n';
-                else ok = in_set(p.sets[in.x], c);
-                if (!ok) break;
-                pos += c.len;
+                if (t[pos] < 0x80) {
+                    if (!one_ascii(in, t[pos])) break;
+                    pos++;
+                } else {
+                    const Ch c = decode(*p.ht, t, pos, n);
+                    if (!one(in, c)) break;
+                    pos += c.len;
+                }
                 pc++;
             }
         }
@@ -504,6 +618,13 @@ RegexPtr regex_compile(const std::string& pattern, const HostTables& ht, std::st
     if (ast && Parser::nullable(*ast))
         ps.fail("the pattern can match the empty string (what find_iter does behind an empty match differs between the reference's regex back ends)", 0), ast = nullptr;
     if (!ast) { err = ps.err.empty() ? "malformed split pattern" : ps.err; return nullptr; }
+    for (ClassSet& cs : prog->sets)                                       // ASCII membership of every class, once
+        for (uint32_t c = 0; c < 128; c++) {
+            const uint32_t cls = ht.ucls_stage2[((uint32_t)ht.ucls_stage1[0] << ht.ucls_shift) | c];
+            bool in = ((cs.codes >> cls) & 1u) != 0;
+            for (const auto& r : cs.ranges) in = in || (c >= r.first && c <= r.second);
+            if (in != cs.neg) cs.ascii[c >> 6] |= 1ull << (c & 63);
+        }
     Emitter em{*prog};
     em.gen(*ast);
     em.emit(OP_MATCH);
@@ -517,16 +638,26 @@ bool regex_split_spans(const RegexProg& prog, const uint8_t* text, size_t n, std
 
 bool regex_split_bits(const RegexProg& prog, const uint8_t* text, size_t n, uint64_t base, uint32_t* start_bits, uint32_t* gap_bits) {
     size_t covered = 0;                                                  // end of the previous match
+    // start bits are collected per bitmap word and OR-ed in when the word is left (positions only grow): one atomic
+    // per 32 bytes of text instead of one per chunk
+    uint64_t cur_w = ~0ull;
+    uint32_t cur_bits = 0;
+    auto flush = [&] { if (cur_bits) __atomic_fetch_or(&start_bits[cur_w], cur_bits, __ATOMIC_RELAXED); cur_bits = 0; };
+    auto start = [&](uint64_t pos) {
+        if ((pos >> 5) != cur_w) { flush(); cur_w = pos >> 5; }
+        cur_bits |= 1u << (pos & 31);
+    };
     auto gap = [&](size_t a, size_t e) {                                 // bytes no match covers: dropped (tokenizer.rs:729-808 only walks the matches)
-        or_bit(start_bits, base + a);
+        start(base + a);
         for (size_t q = a; q < e; q++) or_bit(gap_bits, base + q);
     };
     const bool ok = split_text(prog, text, n, [&](size_t a, size_t e) {
         if (a > covered) gap(covered, a);
-        or_bit(start_bits, base + a);
+        start(base + a);
         covered = e;
     });
     if (ok && covered < n) gap(covered, n);
+    flush();
     return ok;
 }
 
