@@ -778,14 +778,17 @@ int host_split_docs(const spl_tokenizer* tk, const uint8_t* text, const uint64_t
     std::atomic<int> bad{0};
     std::vector<std::vector<SpHit>> part(nt);
     const std::function<void(unsigned)> work = [&](unsigned k) {
-        for (;;) {
-            const uint64_t d0 = next.fetch_add(16, std::memory_order_relaxed);      // documents in runs of 16
-            if (d0 >= nd || bad.load(std::memory_order_relaxed)) return;
-            for (uint64_t d = d0; d < std::min(nd, d0 + 16); d++)
-                if (!host_split_doc(tk, text, off[d] - off[0], off[d + 1] - off[0], special, starts, gaps, &part[k])) { bad.store(1); return; }
-        }
+        try {
+            for (;;) {
+                const uint64_t d0 = next.fetch_add(16, std::memory_order_relaxed);      // documents in runs of 16
+                if (d0 >= nd || bad.load(std::memory_order_relaxed)) return;
+                for (uint64_t d = d0; d < std::min(nd, d0 + 16); d++)
+                    if (!host_split_doc(tk, text, off[d] - off[0], off[d + 1] - off[0], special, starts, gaps, &part[k])) { bad.store(1); return; }
+            }
+        } catch (...) { bad.store(2); }                                 // (std::bad_alloc on a worker: reported, never thrown across the pool)
     };
     work_pool().run(nt, work);
+    if (bad.load() == 2) return fail(SPL_EDEVICE, "the host splitter ran out of memory");
     if (bad.load()) return fail(SPL_EINVAL, "the split pattern ran out of its matching budget on this text (catastrophic backtracking)");
     if (hits) {
         for (auto& p : part) hits->insert(hits->end(), p.begin(), p.end());
