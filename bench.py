@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--docs", type=int, default=1000, help="documents per batch (BASELINE config: 1000)")
+    ap.add_argument("--corpus", choices=("c2", "c2_wide"), default="c2",
+                    help="c2 = BASELINE config 2 (the headline); c2_wide = the same mix over a >= 20 000-word lexicon (profiles only: the line then says so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-throughputs", action="store_true", help="skip the C-ABI / Python-surface figures (C2, C3)")
     ap.add_argument("--no-c4", action="store_true", help="skip the doc-sharded 1 M-prompt run (BASELINE config 4)")
@@ -161,7 +163,8 @@ def main():
     ncpu = os.cpu_count() or 1
     tok = Tokenizer.from_pretrained("cl100k_base", device=local_rank)
     # eight rank-distinct batches of the same distribution
-    text_sets = [corpus.c2(args.docs, seed=1002 + 100 * rank + k) for k in range(N_ROT)]
+    gen_, seed0_ = (corpus.c2, 1002) if args.corpus == "c2" else (corpus.c2_wide, 2002)
+    text_sets = [gen_(args.docs, seed=seed0_ + 100 * rank + k) for k in range(N_ROT)]
     batches = [DeviceBatch(t, dev) for t in text_sets]
     reserve(tok, max(b.n_bytes for b in batches), max(b.n_docs for b in batches))
     L = _ffi.lib()
@@ -423,7 +426,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": f"cl100k_base, {args.docs} x ~1 KB mixed English/code per batch and GPU, {N_ROT} distinct batches in rotation "
-                                   f"(splintr_amd.corpus.c2, seeds 1002 + 100 rank + k); KERNEL-ONLY: corpus HBM-resident, CSR left in HBM "
+                                   f"(splintr_amd.corpus.{args.corpus}, seeds {seed0_} + 100 rank + k{'' if args.corpus == 'c2' else '; NOT the BASELINE corpus: the lexically wide variant'}); KERNEL-ONLY: corpus HBM-resident, CSR left in HBM "
                                    f"(the host->host and Python-surface rates of the same batch are in `throughputs`)"
                                    + ("; + RCCL all-gatherv of the ragged ids (slab written by the encoder's last kernel, ONE all-gather per bucket of 8 batches on its own stream, overlapped with the following encodes; every rank gets every batch's global CSR, handed to the consumer per bucket)" if use_dist else ""),
                        "vocab": "cl100k_base", "docs_per_batch": args.docs, "bytes_per_batch": round(bytes_rot / N_ROT),

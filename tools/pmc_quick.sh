@@ -8,7 +8,7 @@ out=$R/gpurun_out/pmcq_$L.txt; : > $out
 i=0
 for c in "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1)); d=$R/gpurun_out/pmcq_${L}_$i; rm -rf $d; mkdir -p $d
-  (cd $R && timeout 300 rocprofv3 --pmc $c --kernel-trace -d $d -o p -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-throughputs --no-c4 --no-c5 > $d/log.txt 2>&1)
+  (cd $R && timeout 300 rocprofv3 --pmc $c --kernel-trace -d $d -o p -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-throughputs --no-c4 --no-c5 $BENCH_ARGS > $d/log.txt 2>&1)
   (cd $R && python tools/pmc_summary.py $(find $d -name "*.db" | head -1) --kernel k_pretok >> $out 2>&1)
   rm -rf $d
 done
