@@ -46,26 +46,38 @@ static int ensure(void** p, size_t* cap, size_t need, int* malloced) {
     return 0;
 }
 
-/* UTF-8 length of a str; -1 if it holds a lone surrogate (then the standard codec raises) */
+/* UTF-8 length of a str; -1 if it holds a lone surrogate (then the standard codec raises).
+ * Text that is not pure ASCII is still MOSTLY ASCII (a few accented letters, dashes, quotes per document): the
+ * one- and two-byte representations are walked eight / four characters at a time while those are all ASCII. */
 static Py_ssize_t utf8_size(PyObject* s) {
     const Py_ssize_t n = PyUnicode_GET_LENGTH(s);
     if (PyUnicode_IS_ASCII(s)) return n;
     const int kind = PyUnicode_KIND(s);
     const void* d = PyUnicode_DATA(s);
-    Py_ssize_t t = 0;
+    Py_ssize_t t = 0, i = 0;
     if (kind == PyUnicode_1BYTE_KIND) {
         const Py_UCS1* p = (const Py_UCS1*)d;
-        for (Py_ssize_t i = 0; i < n; i++) t += 1 + (p[i] >> 7);
+        for (; i + 8 <= n; i += 8) {
+            uint64_t w;
+            memcpy(&w, p + i, 8);
+            t += 8 + (Py_ssize_t)__builtin_popcountll(w & 0x8080808080808080ull);
+        }
+        for (; i < n; i++) t += 1 + (p[i] >> 7);
     } else if (kind == PyUnicode_2BYTE_KIND) {
         const Py_UCS2* p = (const Py_UCS2*)d;
-        for (Py_ssize_t i = 0; i < n; i++) {
+        for (; i < n; i++) {
+            if (i + 4 <= n) {
+                uint64_t w;
+                memcpy(&w, p + i, 8);
+                if (!(w & 0xFF80FF80FF80FF80ull)) { t += 4; i += 3; continue; }
+            }
             const Py_UCS2 c = p[i];
             if (c >= 0xD800 && c <= 0xDFFF) return -1;
             t += 1 + (c >= 0x80) + (c >= 0x800);
         }
     } else {
         const Py_UCS4* p = (const Py_UCS4*)d;
-        for (Py_ssize_t i = 0; i < n; i++) {
+        for (; i < n; i++) {
             const Py_UCS4 c = p[i];
             if (c >= 0xD800 && c <= 0xDFFF) return -1;
             t += 1 + (c >= 0x80) + (c >= 0x800) + (c >= 0x10000);
@@ -87,9 +99,32 @@ static void utf8_write(PyObject* s, uint8_t* o) {
     const void* d = PyUnicode_DATA(s);
     if (PyUnicode_IS_ASCII(s)) { memcpy(o, d, (size_t)n); return; }
     const int kind = PyUnicode_KIND(s);
-    if (kind == PyUnicode_1BYTE_KIND) { const Py_UCS1* p = (const Py_UCS1*)d; for (Py_ssize_t i = 0; i < n; i++) o = put_cp(o, p[i]); }
-    else if (kind == PyUnicode_2BYTE_KIND) { const Py_UCS2* p = (const Py_UCS2*)d; for (Py_ssize_t i = 0; i < n; i++) o = put_cp(o, p[i]); }
-    else { const Py_UCS4* p = (const Py_UCS4*)d; for (Py_ssize_t i = 0; i < n; i++) o = put_cp(o, p[i]); }
+    Py_ssize_t i = 0;
+    if (kind == PyUnicode_1BYTE_KIND) {
+        const Py_UCS1* p = (const Py_UCS1*)d;
+        for (; i < n; i++) {
+            if (i + 8 <= n) {
+                uint64_t w;
+                memcpy(&w, p + i, 8);
+                if (!(w & 0x8080808080808080ull)) { memcpy(o, &w, 8); o += 8; i += 7; continue; }     /* eight ASCII characters */
+            }
+            o = put_cp(o, p[i]);
+        }
+    } else if (kind == PyUnicode_2BYTE_KIND) {
+        const Py_UCS2* p = (const Py_UCS2*)d;
+        for (; i < n; i++) {
+            if (i + 4 <= n) {
+                uint64_t w;
+                memcpy(&w, p + i, 8);
+                if (!(w & 0xFF80FF80FF80FF80ull)) {                                                    /* four ASCII characters */
+                    o[0] = (uint8_t)w; o[1] = (uint8_t)(w >> 16); o[2] = (uint8_t)(w >> 32); o[3] = (uint8_t)(w >> 48);
+                    o += 4; i += 3;
+                    continue;
+                }
+            }
+            o = put_cp(o, p[i]);
+        }
+    } else { const Py_UCS4* p = (const Py_UCS4*)d; for (; i < n; i++) o = put_cp(o, p[i]); }
 }
 
 /* ---- packing: list[str] -> packed UTF-8 + offsets in the pinned staging buffers ------------------------------
