@@ -72,6 +72,20 @@ def test_pattern_that_does_not_tile_the_text_drops_the_gaps():
     assert t.encode("...") == [] and t.encode("  ab, 12x!") == orc.encode("ab") + orc.encode("12") + orc.encode("x")
 
 
+def test_dropped_stretches_longer_than_a_window():
+    """A pattern that does not tile the text leaves GAPS; one that outgrows a tile's window is deferred like a long chunk
+    -- and must still encode to nothing (tools/dev/gpu_custom_stress.py, seed 2736: its bytes came out as tokens).  Runs
+    of newlines / NEL / punctuation of 90..1100 bytes under `\\p{L}+|[0-9]+`, at 300 alignments, alone and joined."""
+    t, orc = _pair("cl100k_base", SPARSE)
+    pad = ("lorem ipsum " * 400)
+    for unit, tail, L in (("\n", "\x85\x85\x85", 700), ("-", "\u2014\u3002", 1100), (" ", "\u3000", 240), ("=", "", 2500), ("\n", "", 130)):
+        k0 = random.Random(L).randrange(0, 700)
+        texts = [pad[:k] + unit * L + tail + "9 and on" for k in range(k0, k0 + 300)]
+        _check(t, orc, texts)
+        _check(t, orc, ["".join(texts)])
+    _check(t, orc, ["=" * 70000 + "a", "a" + "\n" * 70000, "." * 5000])
+
+
 def test_chunks_longer_than_a_window_and_at_every_alignment():
     """A chunk that starts in one tile and ends far behind its window (the tail finishes it from global memory), at
     300 consecutive alignments against the tile and window edges; 64 KB single-class runs."""

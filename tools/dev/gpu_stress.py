@@ -4,7 +4,8 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_parity as tg
-from stressgen import random_batch
+from stressgen import random_batch, MODES_ALL
+from test_gpu_stress import _compiled
 from oracle.coracle import COracle
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
@@ -12,9 +13,10 @@ orcs = {}
 def coracle(name):
     if name not in orcs: orcs[name] = COracle(name)
     return orcs[name]
+MODES = [m for m in MODES_ALL if m in _compiled(sorted(set(MODES_ALL)))]
 t0 = time.time(); runs = 0; bad = 0; seed = seed0
 while time.time() - t0 < budget:
-    name, geom, special, texts = random_batch(seed)
+    name, geom, special, texts = random_batch(seed, MODES)
     tg._force_tiles(name, geom)
     try:
         tg.assert_batch_equal(name, texts, coracle, special=special)
