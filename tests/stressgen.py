@@ -114,3 +114,45 @@ def edge_batch(seed, modes=EDGE_MODES):
     elif mix < 0.5:
         texts = [x for t in texts for x in (t, rng.choice(["", "", "a", "é"]))]   # empty / tiny texts behind the edge
     return name, geom, special, texts
+
+
+# ---- custom split patterns (host splitter + external chunk boundaries) ------------------------------------------------
+CUSTOM_VOCABS = [("cl100k_base", False), ("o200k_base", False), ("llama3", False), ("mistral_v3", True), ("deepseek_v3", True)]
+
+
+def custom_patterns():
+    from test_host_regex import GPT2_PATTERN, MIXED, SPARSE, VARIANT_A, VARIANT_B
+    return [GPT2_PATTERN, VARIANT_A, VARIANT_B, SPARSE, MIXED, r"\p{L}+(?:'\p{L}+)?|\p{N}{1,4}|\s+|.",
+            r" ?[A-Za-z]+| ?[0-9]+|\s*[\r\n]+|\s+(?!\S)|\s+|[^\sA-Za-z0-9]+"]
+
+
+def custom_batch(seed):
+    """-> (vocabulary, byte_level, pattern, special-token map, with_special, texts, (chunk_bytes, single_chunk_max_bytes))
+    Patterns that tile the text and patterns that do not (gaps), special-token sets with and without overlaps, fuzz /
+    Latin / edge-run texts, one-chunk and many-chunk host pipelines."""
+    rng = random.Random(seed)
+    vocab, bl = rng.choice(CUSTOM_VOCABS)
+    pat = rng.choice(custom_patterns())
+    special = rng.random() < 0.3
+    sp = {}
+    if special:
+        sp = {lit: 300000 + i for i, lit in enumerate(rng.sample(literals(vocab), 4))}
+        if rng.random() < 0.3:
+            sp.update({"<|a|>": 300100, "<|a|>x": 300101, "|>": 300102})
+    kind = rng.random()
+    if kind < 0.4:
+        texts = fuzz_corpus(seed, rng.randint(30, 400), rng.choice([10, 40, 120]))
+    elif kind < 0.6:
+        texts = latin_corpus(seed, rng.randint(30, 300), 80) + cased_corpus(seed, rng.randint(30, 200), 60)
+    else:
+        texts = edge_batch(seed)[3][:rng.choice([40, 120, 300])]
+    if special:
+        ls = list(sp)
+        for i in range(0, len(texts), 2):
+            x = texts[i]
+            c = rng.randrange(len(x) + 1)
+            texts[i] = x[:c] + rng.choice(ls) + x[c:]
+    if rng.random() < 0.25:
+        texts = ["".join(texts)]
+    opts = (rng.choice([16, 64, 256]) << 10, 0) if rng.random() < 0.3 else (8 << 20, 4 << 20)
+    return vocab, bl, pat, sp, special, texts, opts

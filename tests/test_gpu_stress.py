@@ -8,7 +8,7 @@ import time
 import pytest
 
 import test_gpu_parity as tg
-from stressgen import edge_batch, random_batch
+from stressgen import custom_batch, edge_batch, random_batch
 
 pytestmark = pytest.mark.gpu
 
@@ -64,3 +64,48 @@ def test_edge_sweep_fixed_seeds(coracle):
 
 def test_edge_sweep_every_compiled_mode(coracle):
     _run(edge_batch, list(range(7000, 7400)), 12, coracle, [0, 1, 3, 4, 5])
+
+
+_custom = {}
+
+
+def check_custom(seed):
+    """One batch of stressgen.custom_batch through the HIP path and through the Python oracle (same pattern, PCRE2);
+    returns None or a description of the first difference."""
+    import os
+    from conftest import ROOT
+    from splintr_amd import Tokenizer, _ffi
+    from oracle import pyoracle as O
+    vocab, bl, pat, sp, special, texts, (chunk_bytes, single_max) = custom_batch(seed)
+    key = (vocab, pat, tuple(sorted(sp.items())))
+    if key not in _custom:
+        if len(_custom) > 12:
+            _custom.clear()
+        path = os.path.join(ROOT, "splintr_amd", "data", vocab + ".splv")
+        with open(path, "rb") as f:
+            blob = f.read()
+        enc, _ = O.load_splv(path)
+        t = (Tokenizer.from_bytes_byte_level if bl else Tokenizer.from_bytes)(blob, pat, sp)
+        _custom[key] = (t, O.Oracle(enc, pat, bl, sp, "pcre2"))
+    t, orc = _custom[key]
+    L = _ffi.lib()
+    assert L.spl_set_option(t.handle, b"chunk_bytes", chunk_bytes) == 0 and L.spl_set_option(t.handle, b"single_chunk_max_bytes", single_max) == 0
+    got = t.encode_batch_with_special(texts) if special else t.encode_batch(texts)
+    for i, x in enumerate(texts):
+        want = orc.encode_with_special(x) if special else orc.encode(x)
+        if got[i] != want:
+            return f"{vocab} special {special} pattern {pat[:40]!a} text #{i} {x[:60]!a}: {got[i][:12]} vs {want[:12]}"
+    return None
+
+
+def test_custom_pattern_stress_fixed_seeds():
+    """2736: a gap (dropped bytes) that outgrows the window was tokenised (round 3); then a fixed block of seeds."""
+    from oracle import pyoracle as O
+    if not O.pcre2_available():
+        pytest.skip("libpcre2-8 not present")
+    t0 = time.time()
+    for k, seed in enumerate([2736, 2839, 2862] + list(range(1, 400))):
+        if k >= 40 and time.time() - t0 > BUDGET_S:
+            break
+        err = check_custom(seed)
+        assert err is None, f"seed {seed}: {err}"
