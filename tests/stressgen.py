@@ -154,5 +154,8 @@ def custom_batch(seed):
             texts[i] = x[:c] + rng.choice(ls) + x[c:]
     if rng.random() < 0.25:
         texts = ["".join(texts)]
+    if seed % 23 == 0:                                       # now and then a batch beyond 1.25 MiB: the second tile geometry
+        from splintr_amd import corpus
+        texts = texts + corpus.c2(1400, seed=seed) + corpus.c3(40, seed=seed)
     opts = (rng.choice([16, 64, 256]) << 10, 0) if rng.random() < 0.3 else (8 << 20, 4 << 20)
     return vocab, bl, pat, sp, special, texts, opts
