@@ -241,6 +241,7 @@ struct Ctx {
         hipFree((void*)dt.tiny_tab); hipFree((void*)dt.t8_tab);
         hipFree((void*)dt.long_tab); hipFree((void*)dt.key_blob); hipFree((void*)dt.pair_tab);
         hipFree((void*)dt.byte_id); hipFree((void*)dt.p8_tab); hipFree((void*)dt.len_mask);
+        hipFree((void*)dt.pfx); hipFree((void*)dt.filt4);
         hipFree((void*)d_tok_off); hipFree((void*)d_tok_bytes); hipFree(d_sp_lits);
         hipFree((void*)d_dec_sp_ids); hipFree((void*)d_dec_sp_off);
         hipFree(d_ids); hipFree(d_oo);
@@ -306,6 +307,9 @@ int upload_tables(Ctx& c, const HostTables& ht) {
     if ((rc = dev_upload(ht.byte_id, &c.dt.byte_id))) return rc;
     if ((rc = dev_upload(ht.p8_tab, reinterpret_cast<const uint32_t**>(&c.dt.p8_tab)))) return rc;
     if ((rc = dev_upload(ht.len_mask, &c.dt.len_mask))) return rc;
+    if ((rc = dev_upload(ht.pfx, &c.dt.pfx))) return rc;
+    if ((rc = dev_upload(ht.filt4, &c.dt.filt4))) return rc;
+    c.dt.filt4_shift = ht.filt4_shift;
     c.dt.ucls_shift = ht.ucls_shift;
     c.dt.ascii_base = (uint32_t)ht.ucls_stage1[0] << ht.ucls_shift;
     c.dt.cjk_fast = ht.cjk_fast ? 1u : 0u;

@@ -101,6 +101,10 @@ constexpr uint32_t SPL_NO_RANK = 0xFFFFFFFFu;
 constexpr uint32_t SPL_OVF_BIT = 1u << 23;
 
 struct P8Bucket { uint32_t a, b; };
+// Prefix table entry (one dwordx2 load): what the first TWO bytes of a key say about it.
+//   lm : low byte = length mask, next byte = salt (exactly DeviceTables::len_mask's entry);
+//   id2: the id of the token that IS those two bytes, or SPL_NO_RANK -- a two-byte key needs no bucket probe at all.
+struct alignas(8) PfxEnt { uint32_t lm, id2; };
 
 struct DeviceTables {
     // code-point classes
@@ -135,7 +139,17 @@ struct DeviceTables {
     // sent (one cache line for all of them).
     const uint16_t* len_mask;  uint32_t tiny_free, t8_free;
     uint32_t ascii_base;      // ucls_stage1[0] << ucls_shift: where the classes of U+0000..U+007F start in ucls_stage2
+    // pfx[b0 | b1 << 8]: len_mask's entry and the id of the two-byte token in one 8-byte load (the substring
+    // tabulation and the whole-chunk probe read this one; len_mask stays for the generic probes).
+    // filt4[hash_f4(first four bytes) >> filt4_shift]: bit k (k = 0..4) set iff SOME token of exactly 4 + k bytes
+    // begins with four bytes that hash there, bit 5 iff a longer one does -- a Bloom-style filter (no false
+    // negatives; a false positive costs one probe that misses).  The length mask of a two-byte prefix says which
+    // lengths exist behind " t" -- all of them; the filter says which exist behind " tzq" -- none: 60 % of the
+    // 5..8-byte probes of the substring tabulation (C2's missed chunks) are never issued.
+    const PfxEnt* pfx;
+    const uint8_t* filt4;     uint32_t filt4_shift;
 };
+SPL_HD uint32_t hash_f4(uint32_t w0) { return w0 * 0x9E3779B1u; }      // (index = the upper bits: >> filt4_shift)
 
 // ----------------------------------------------------------------------------------------
 // Hashes (host builder and device probes use these very functions).

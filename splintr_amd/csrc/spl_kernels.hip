@@ -557,8 +557,10 @@ __device__ __forceinline__ uint32_t probe_short_mixed(const DeviceTables& T, uin
     const bool tiny = n <= (uint32_t)SPL_TINY_MAX, t8 = !tiny && n <= (uint32_t)SPL_T8_MAX;
     // the key's two-byte prefix: which token lengths exist behind it at all (no probe for the others)
     // and the salt of its bucket hashes
-    const uint32_t lm = T.len_mask[k0 & 0xFFFFu], salt = lm >> 8;
+    const PfxEnt pe = T.pfx[k0 & 0xFFFFu];
+    const uint32_t lm = pe.lm, salt = lm >> 8;
     if (n >= 2u && !((lm >> (n <= (uint32_t)SPL_T8_MAX ? n - 2u : 7u)) & 1u)) return SPL_NO_RANK;
+    if (n == 2u) return pe.id2;                  // the prefix entry carries the two-byte token's id: no bucket to read
     const uint32_t h = tiny ? hash_tiny(k0, n, salt) : t8 ? hash_t8(k0, k1, n, salt) : hash_short(k0, k1, k2, n, salt);
     const Quad* src = tiny ? reinterpret_cast<const Quad*>(T.tiny_tab + (size_t)(h & T.tiny_mask) * (SPL_TINY_BUCKET * 2))
                     : t8   ? reinterpret_cast<const Quad*>(T.t8_tab + (size_t)(h & T.t8_mask) * SPL_T8_WORDS)
@@ -771,6 +773,25 @@ __device__ __forceinline__ void group16_merge(const DeviceTables& T, const uint3
 #else
 #define SPL_WT(i) do { } while (0)
 #endif
+// What a table row starts from, in ONE round trip (both loads depend on the text alone): the prefix entry of the
+// lane's first two bytes -- length mask, salt, the id of the two-byte token (no probe for length 2) -- and the
+// four-byte-prefix filter, which takes the lengths 4..8 (and "longer") that no token with these four bytes has
+// out of the mask: their probes go to the spare bucket like those of the lengths the two-byte prefix rules out.
+#ifndef SPL_ROW_FILTER
+#define SPL_ROW_FILTER 1
+#endif
+struct RowHead { uint32_t lm, id2; };
+__device__ __forceinline__ RowHead row_head(const DeviceTables& T, bool own, uint32_t w0, int maxlen) {
+    RowHead h{0u, SPL_NO_RANK};
+    if (own) {
+        const PfxEnt pe = T.pfx[w0 & 0xFFFFu];
+        uint32_t f4 = 0x3Fu;
+        if (SPL_ROW_FILTER) f4 = maxlen >= 4 ? (uint32_t)T.filt4[hash_f4(w0) >> T.filt4_shift] : 0u;
+        h.lm = pe.lm & (0xFF03u | (f4 << 2));
+        h.id2 = pe.id2;
+    }
+    return h;
+}
 // Tabulation of ONE table row: the lane probes the ids of text[pos, pos + len), len = 2 .. min(rem, 8), in two
 // batches whose bucket loads are all in flight together, into `row`; returns the id of its byte and, in
 // far_max, the longest token of more than 8 bytes that can start there (p8 bound).  `own` false: idle lane.
@@ -783,17 +804,17 @@ __device__ __forceinline__ uint32_t tab_row(const DeviceTables& T, const LdsAcc&
     const uint32_t id = own ? T.byte_id[w0 & 0xFFu] : SPL_DEAD;
     // which token lengths exist at all behind the lane's first two bytes: the other probes go to the
     // spare bucket (28 % fewer table lines for English text, 85 % for CJK)
-    const uint32_t lm = own ? T.len_mask[w0 & 0xFFFFu] : 0u;
+    const RowHead rh = row_head(T, own, w0, maxlen);
+    const uint32_t lm = rh.lm;
     SPL_WT(1);
     far_max = 0;
     {
-        Quad qa[2], qb[2], qc[2], qd[3];
-        const uint32_t ka = w0 & 0xFFFFu, kb = w0 & 0xFFFFFFu, ha = w1 & 0xFFu;
+        Quad qb[2], qc[2], qd[3];
+        const uint32_t kb = w0 & 0xFFFFFFu, ha = w1 & 0xFFu;
         // (ONE predicate for the four probes: cells for lengths beyond maxlen are never read, so
         //  the lanes need no per-length predicate -- with one, the compiler waits after every
         //  single probe instead of keeping all the bucket loads in flight together)
         if (maxlen >= 2) {
-            tiny_issue_if(T, (lm & 1u) != 0, ka, 2u, lm >> 8, qa);
             tiny_issue_if(T, (lm & 2u) != 0, kb, 3u, lm >> 8, qb);
             tiny_issue_if(T, (lm & 4u) != 0, w0, 4u, lm >> 8, qc);
             t8_issue_if(T, (lm & 8u) != 0, w0, ha, 5u, lm >> 8, qd);
@@ -805,7 +826,7 @@ __device__ __forceinline__ uint32_t tab_row(const DeviceTables& T, const LdsAcc&
                 const int l8 = (int)p8_match(e8.a, e8.b, p8_tag(w0, w1));
                 far_max = l8 == 255 ? FAR_UNBOUNDED : l8;
             }
-            row[0] = tiny_finish(T, ka, 2u, lm >> 8, qa);
+            row[0] = rh.id2;
             row[1] = tiny_finish(T, kb, 3u, lm >> 8, qb);
             row[2] = tiny_finish(T, w0, 4u, lm >> 8, qc);
             row[3] = t8_finish(T, w0, ha, 5u, lm >> 8, qd);
@@ -946,19 +967,19 @@ __device__ __forceinline__ void bpe_wave64_tab(const DeviceTables& T, const LdsA
     uint32_t* row = sub + lane * SUB_W;
     // which token lengths exist at all behind the lane's first two bytes: the other probes go to the
     // spare bucket (28 % fewer table lines for English text, 85 % for CJK)
-    const uint32_t lm = own ? T.len_mask[w0 & 0xFFFFu] : 0u;
+    const RowHead rh = row_head(T, own, w0, maxlen);
+    const uint32_t lm = rh.lm;
     {
-        Quad qa[2], qb[2], qc[2], qd[3];
-        const uint32_t ka = w0 & 0xFFFFu, kb = w0 & 0xFFFFFFu, ha = w1 & 0xFFu;
+        Quad qb[2], qc[2], qd[3];
+        const uint32_t kb = w0 & 0xFFFFFFu, ha = w1 & 0xFFu;
         // (ONE predicate for the four probes: cells for lengths beyond maxlen are never read, so
         //  the lanes need no per-length predicate -- with one, the compiler waits after every
         //  single probe instead of keeping all the bucket loads in flight together)
         if (maxlen >= 2) {
-            tiny_issue_if(T, (lm & 1u) != 0, ka, 2u, lm >> 8, qa);
             tiny_issue_if(T, (lm & 2u) != 0, kb, 3u, lm >> 8, qb);
             tiny_issue_if(T, (lm & 4u) != 0, w0, 4u, lm >> 8, qc);
             t8_issue_if(T, (lm & 8u) != 0, w0, ha, 5u, lm >> 8, qd);
-            row[0] = tiny_finish(T, ka, 2u, lm >> 8, qa);
+            row[0] = rh.id2;
             row[1] = tiny_finish(T, kb, 3u, lm >> 8, qb);
             row[2] = tiny_finish(T, w0, 4u, lm >> 8, qc);
             row[3] = t8_finish(T, w0, ha, 5u, lm >> 8, qd);
@@ -1904,19 +1925,19 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
             } else if (g + 8 <= B) { __builtin_memcpy(&w0, b.text + g, 4); __builtin_memcpy(&w1, b.text + g + 4, 4); }
             else for (int q = 0; q < 8; q++) if (g + q < B) (q < 4 ? w0 : w1) |= (uint32_t)b.text[g + q] << (8 * (q & 3));
             bid = T.byte_id[w0 & 0xFFu];
-            lm = T.len_mask[w0 & 0xFFFFu];                   // which token lengths exist at all behind these two bytes
         }
+        const RowHead rh = row_head(T, own, w0, maxlen);     // which token lengths exist at all behind these bytes
+        lm = rh.lm;
         uint32_t* const row = slab + tid * SUB_W;
         int ml = 1;
         {
-            Quad qa[2], qb[2], qc[2], qd[3];
-            const uint32_t ka = w0 & 0xFFFFu, kb = w0 & 0xFFFFFFu, ha = w1 & 0xFFu;
+            Quad qb[2], qc[2], qd[3];
+            const uint32_t kb = w0 & 0xFFFFFFu, ha = w1 & 0xFFu;
             if (maxlen >= 2) {                               // (one predicate per batch: see bpe_group16_tab)
-                tiny_issue_if(T, (lm & 1u) != 0, ka, 2u, lm >> 8, qa);
                 tiny_issue_if(T, (lm & 2u) != 0, kb, 3u, lm >> 8, qb);
                 tiny_issue_if(T, (lm & 4u) != 0, w0, 4u, lm >> 8, qc);
                 t8_issue_if(T, (lm & 8u) != 0, w0, ha, 5u, lm >> 8, qd);
-                const uint32_t r2 = tiny_finish(T, ka, 2u, lm >> 8, qa), r3 = tiny_finish(T, kb, 3u, lm >> 8, qb);
+                const uint32_t r2 = rh.id2, r3 = tiny_finish(T, kb, 3u, lm >> 8, qb);
                 const uint32_t r4 = tiny_finish(T, w0, 4u, lm >> 8, qc), r5 = t8_finish(T, w0, ha, 5u, lm >> 8, qd);
                 row[0] = r2; row[1] = r3; row[2] = r4; row[3] = r5;
                 ml = r2 != SPL_NO_RANK ? 2 : ml;

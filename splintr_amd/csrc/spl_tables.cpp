@@ -421,6 +421,26 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
         }
         if (out.unsalted_groups == 0) break;             // every key in its home bucket: keep this density
     }
+    {   // prefix entries (length mask + salt + the two-byte token's id) and the four-byte-prefix length filter
+        out.pfx.assign(65536, PfxEnt{0u, SPL_NO_RANK});
+        for (uint32_t g = 0; g < 65536; g++) out.pfx[g].lm = out.len_mask[g];
+        size_t n4 = 0;
+        for (const auto& kv : enc) {
+            const std::string& k = kv.first;
+            if (k.size() == 2) out.pfx[(uint8_t)k[0] | (uint32_t)(uint8_t)k[1] << 8].id2 = kv.second;
+            n4 += k.size() >= 4;
+        }
+        // one byte per slot, about one key in ten slots (distinct prefixes are fewer still): 256 KiB for cl100k_base
+        uint32_t bits = 16;
+        while (bits < 22 && ((size_t)1 << bits) < n4 * 4) bits++;
+        out.filt4_shift = 32 - bits;
+        out.filt4.assign((size_t)1 << bits, 0);
+        for (const auto& kv : enc) {
+            const std::string& k = kv.first;
+            if (k.size() < 4) continue;
+            out.filt4[hash_f4(load_le(k, 0)) >> out.filt4_shift] |= (uint8_t)(1u << (k.size() > (size_t)SPL_T8_MAX ? 5 : k.size() - 4));
+        }
+    }
     for (const auto& kv : enc) {
         const std::string& k = kv.first;
         const uint32_t n = (uint32_t)k.size();

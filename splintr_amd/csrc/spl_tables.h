@@ -29,6 +29,9 @@ struct HostTables {
     std::vector<uint32_t> byte_id;      // 256
     std::vector<uint32_t> p8_tab;       // DeviceTables::p8_tab (two words per bucket)
     std::vector<uint16_t> len_mask;     // DeviceTables::len_mask (65536): length mask | salt << 8
+    std::vector<PfxEnt> pfx;            // DeviceTables::pfx (65536): len_mask's entry + the id of the two-byte token
+    std::vector<uint8_t> filt4;         // DeviceTables::filt4: token lengths by (hashed) four-byte prefix
+    uint32_t filt4_shift = 0;
     uint32_t unsalted_groups = 0;       // two-byte key prefixes for which no salt kept every bucket below full (0 for the shipped vocabularies)
     uint32_t tiny_free = 0, t8_free = 0;
     uint32_t max_key_len = 0;           // in the key space the kernels see (raw bytes)

@@ -485,6 +485,43 @@ extern "C" void hs_bucket_stats(void* p, uint32_t* out) {
     out[6] = h.unsalted_groups;
 }
 
+// The tables a substring-tabulation row starts from (DeviceTables::pfx, ::filt4), checked against the key tables
+// themselves: every key of the tiny / t8 / short / long tables must pass the four-byte-prefix filter at its length
+// (no false negatives -- a cleared bit means "no probe"), every two-byte key must be its prefix entry's id2, and no
+// prefix entry may name an id2 that is not a two-byte key.  out: [0] keys checked, [1] violations,
+// [2] filter slots, [3] non-zero slots.
+extern "C" void hs_row_head_check(void* p, uint32_t* out) {
+    Sim* s = (Sim*)p;
+    const HostTables& h = s->ht;
+    uint32_t keys = 0, bad = 0, two = 0;
+    auto check = [&](uint32_t k0, uint32_t n, uint32_t id) {
+        keys++;
+        const PfxEnt pe = h.pfx[k0 & 0xFFFFu];
+        if (pe.lm != h.len_mask[k0 & 0xFFFFu]) bad++;
+        if (n >= 2 && !((pe.lm >> (n <= (uint32_t)SPL_T8_MAX ? n - 2 : 7)) & 1u)) bad++;
+        if (n == 2) { two++; if (pe.id2 != id) bad++; }
+        if (n >= 4) {
+            const uint32_t f = h.filt4[hash_f4(k0) >> h.filt4_shift];
+            if (!((f >> (n <= (uint32_t)SPL_T8_MAX ? n - 4 : 5)) & 1u)) bad++;
+        }
+    };
+    for (size_t e = 0; e < h.tiny_tab.size() / 2; e++)
+        if (h.tiny_tab[2 * e + 1] != SPL_EMPTY) check(h.tiny_tab[2 * e], (h.tiny_tab[2 * e + 1] >> 24) & 0x7Fu, h.tiny_tab[2 * e + 1] & SPL_ID_MASK);
+    for (size_t b = 0; b < h.t8_tab.size() / SPL_T8_WORDS; b++)
+        for (int f = 0; f < SPL_T8_BUCKET; f++) {
+            const uint32_t* e = &h.t8_tab[b * SPL_T8_WORDS + 3 * f];
+            if (e[2] != SPL_EMPTY) check(e[0], (e[2] >> 24) & 0x7Fu, e[2] & SPL_ID_MASK);
+        }
+    for (const ShortEnt& e : h.short_tab) if (e.id_len != SPL_EMPTY) check(e.k0, (e.id_len >> 24) & 0x7Fu, e.id_len & SPL_ID_MASK);
+    for (const LongEnt& e : h.long_tab)
+        if (e.id != SPL_EMPTY) { uint32_t k0; memcpy(&k0, h.key_blob.data() + e.off, 4); check(k0, e.len, e.id); }
+    uint32_t named = 0, nz = 0;
+    for (const PfxEnt& pe : h.pfx) { named += pe.id2 != SPL_NO_RANK; if ((pe.id2 != SPL_NO_RANK) != ((pe.lm & 1u) != 0u)) bad++; }
+    if (named != two) bad++;
+    for (uint8_t f : h.filt4) nz += f != 0;
+    out[0] = keys; out[1] = bad; out[2] = (uint32_t)h.filt4.size(); out[3] = nz;
+}
+
 // ---------------------------------------------------------------------------------------------
 // The host splitter for custom patterns (spl_regex.h), driven directly: compile, split one text.
 #include "../../splintr_amd/csrc/spl_regex.h"

@@ -43,6 +43,7 @@ def lib():
         L.hs_split_starts.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         L.hs_bucket_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.hs_row_head_check.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.hs_classify_check.restype = ctypes.c_int
         L.hs_classify_check.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
         L.hs_encode.restype = ctypes.c_int
@@ -81,6 +82,12 @@ class HostSim:
         a = np.zeros(7, dtype=np.uint32)
         lib().hs_bucket_stats(self._h, a.ctypes.data)
         return {"tiny": (int(a[0]), int(a[1])), "t8": (int(a[2]), int(a[3])), "short": (int(a[4]), int(a[5])), "unsalted_groups": int(a[6])}
+
+    def row_head_check(self):
+        """Prefix entries and the four-byte-prefix filter against the key tables: keys checked, violations, filter fill."""
+        a = np.zeros(4, dtype=np.uint32)
+        lib().hs_row_head_check(self._h, a.ctypes.data)
+        return {"keys": int(a[0]), "violations": int(a[1]), "filter_slots": int(a[2]), "filter_nonzero": int(a[3])}
 
     def split(self, data: bytes, window: int = 0):
         out = np.zeros(len(data) + 1, dtype=np.uint32)

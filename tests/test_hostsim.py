@@ -85,6 +85,16 @@ def test_salted_tables_have_no_overflow(name):
     assert st["unsalted_groups"] <= 1, st
 
 
+@pytest.mark.parametrize("name", VOCABS)
+def test_row_head_tables_have_no_false_negative(name):
+    """What a tabulation row starts from (round 3): the prefix entry's id2 IS the two-byte token's id (no bucket probe
+    for length 2), and the four-byte-prefix filter may only ever ADD probes -- every key of the vocabulary must pass it
+    at its own length, or the kernels would rank a pair that exists as missing."""
+    st = sim(name).row_head_check()
+    assert st["violations"] == 0, st
+    assert st["keys"] > 100_000 and st["filter_nonzero"] * 5 < st["filter_slots"], st     # sparse: few false positives
+
+
 @pytest.mark.parametrize("name", ["cl100k_base", "o200k_base", "mistral_v3"])
 def test_bitvector_starts_tiled_like_the_kernel(coracle, name):
     """spl_scan_starts.h (match starts by bit-vector arithmetic on the class masks, all three patterns) driven
