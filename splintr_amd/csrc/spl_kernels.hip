@@ -2089,14 +2089,35 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
     return nl2 < (uint32_t)DIRECT_LQCAP ? nl2 : (uint32_t)DIRECT_LQCAP;
 }
 
+// e_flags of k_pretok: which optional inputs exist, and the split pattern
+constexpr uint32_t PRETOK_E_TSTART = 1u, PRETOK_E_SKIP = 2u, PRETOK_E_GAPS = 4u, PRETOK_E_EXT = 8u;
+inline uint32_t pretok_flags(const DeviceTables& T, const Batch& b) {
+    return (b.tstart ? PRETOK_E_TSTART : 0u) | (b.skip ? PRETOK_E_SKIP : 0u) | (b.ext_gaps ? PRETOK_E_GAPS : 0u) |
+           (b.ext_starts ? PRETOK_E_EXT : 0u) | (T.pattern << 4);
+}
+// the kernel-argument segment of k_pretok as the ABI lays it out (every argument at its natural alignment, in order)
+struct PretokKernargs {
+    const uint8_t* e_text; const uint64_t* e_doc_off; uint32_t e_n_bytes, e_n_docs; unsigned long long* e_dbg;
+    const uint8_t* e_ascii; uint32_t e_flags; DeviceTables T; Batch b;
+};
+#define PRETOK_EARLY(T, b) (b).text, (b).doc_off, (b).n_bytes, (b).n_docs, (b).dbg, (T).ucls_stage2 + (T).ascii_base, pretok_flags(T, b)
 template <int TB_, int RH_, bool EXPORT_MEDIUM, bool DIRECT = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPL_PRETOK_WAVES)))
-void k_pretok(DeviceTables T, Batch b) {
+void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_bytes, uint32_t e_n_docs, unsigned long long* e_dbg,
+              const uint8_t* e_ascii, uint32_t e_flags, DeviceTables T_ka, Batch b_ka) {
+    // The e_* arguments repeat what the first phase needs (text, offsets, sizes, which optional bitmaps exist, the
+    // pattern, the ASCII class table) as LEADING SCALARS -- the first line of the argument segment -- so that the text
+    // and offset loads go out before the two structs are touched: 0.5 KB that five thousand wavefronts ask the same
+    // few L2 lines for at the same moment (profiles/r03_launch_probes.txt).  The structs themselves are read through
+    // the kernel-argument segment pointer, laundered BEHIND the first text loads (T and b below): left to itself the
+    // compiler hoists all their loads to the kernel's first instructions, waits for them there and parks the values
+    // in VGPR lanes (153 spilled SGPRs, 74 this way).  Built with -mllvm -amdgpu-kernarg-preload-count=16 the
+    // scalars would arrive in SGPRs with the wavefront; measured, that is no faster (the wave launch waits instead).
     using G = TileGeom<TB_, RH_>;
 #ifdef SPL_FIXED_PATTERN
     constexpr int KPAT = SPL_FIXED_PATTERN;              // (A/B: the kernel specialised for one split pattern)
 #else
-    const int KPAT = (int)T.pattern;
+    const int KPAT = (int)((e_flags >> 4) & 3u);
 #endif
     constexpr int Wv = G::Wv;
     __shared__ __attribute__((aligned(16))) uint32_t s_txt32[G::NW32];
@@ -2139,8 +2160,13 @@ void k_pretok(DeviceTables T, Batch b) {
     uint32_t* const s_chunk = &s_sub[0][0];
     // Phase stamps, per-workgroup records and the phase cut-off are compiled in only with
     // -DSPL_DEBUG_STAMPS (tools/ab_build.sh): their live values cost the product kernel registers.
-#ifdef SPL_DEBUG_STAMPS
-#define SPL_STAMP(i) do { if (b.dbg && blockIdx.x == SPL_DBG_WG && threadIdx.x == 0) b.dbg[i] = clock64(); \
+#if defined(SPL_DEBUG_STAMPS) && defined(SPL_STAMP_ALL)
+    // every workgroup's wall clock at the phase boundaries (tools/dev/gpu_phase_walls.py): eight words per workgroup
+    // in the per-workgroup record area -- start, stamps 1 2 3 4 6 7, end
+#define SPL_STAMP(i) do { if (e_dbg && threadIdx.x == 0 && SPL_REC_BLK < SPL_DEBUG_BLOCKS / 2 && (i) >= 1 && (i) <= 7 && (i) != 5) \
+                              e_dbg[16 + 8 * SPL_REC_BLK + ((i) < 5 ? (i) : (i) - 1)] = (unsigned long long)wall_clock64(); } while (0)
+#elif defined(SPL_DEBUG_STAMPS)
+#define SPL_STAMP(i) do { if (e_dbg && blockIdx.x == SPL_DBG_WG && threadIdx.x == 0) e_dbg[i] = clock64(); \
                           if ((i) >= 1 && (i) <= 7 && b.stop_phase == (uint32_t)(i)) return; } while (0)
 #else
 #define SPL_STAMP(i) do { } while (0)
@@ -2152,45 +2178,72 @@ void k_pretok(DeviceTables T, Batch b) {
     // (A/B) logical wavefront index rotated by the workgroup index: phases that only fill the low
     // wavefronts (chains, probe list, per-word scans) then load different SIMDs in different workgroups
     const int tid = SPL_ROTATE_WAVES ? (int)((threadIdx.x + ((blockIdx.x & 3u) << 6)) & (NT - 1)) : (int)threadIdx.x;
+#ifdef SPL_PASSES      /* timing experiment only (group sums wrong): every workgroup works its tile SPL_PASSES times -- the later
+                          passes find the kernel's code in the instruction cache (tools/dev/gpu_phase_walls.py) */
+    for (int spl_pass = 0; spl_pass < SPL_PASSES; spl_pass++) {
+    __syncthreads();
+#define SPL_REC_BLK (blockIdx.x + 1024u * (uint32_t)spl_pass)
+#else
+#define SPL_REC_BLK blockIdx.x
+#endif
     if (DIRECT) __builtin_amdgcn_s_setprio(SPL_WORK_PRIO);
     const int64_t t0 = (int64_t)blockIdx.x * TB_;
     const int64_t w0 = t0 - LH;                       // global position of window index 0
-    const int64_t B = b.n_bytes;
+    const int64_t B = e_n_bytes;
     // profiling: span of this kernel on the constant-rate wall clock (start of workgroup 0, max end
     // over all workgroups) -- what a kernel trace reports, without host-side event overhead
-    if (b.dbg && tid == 0 && blockIdx.x == 0) b.dbg[14] = (unsigned long long)wall_clock64();   // dispatched first
+    if (e_dbg && tid == 0 && blockIdx.x == 0) e_dbg[14] = (unsigned long long)wall_clock64();   // dispatched first
 #ifdef SPL_DEBUG_STAMPS
-    if (b.dbg && tid == 0 && blockIdx.x == SPL_DBG_WG) b.dbg[11] = (unsigned long long)wall_clock64();
-    const unsigned long long blk_t0 = b.dbg ? (unsigned long long)wall_clock64() : 0ull;
+    const unsigned long long blk_t0 = e_dbg ? (unsigned long long)wall_clock64() : 0ull;
     unsigned long long blk_w1 = 0, blk_w2 = 0;
-    if (b.dbg && tid == 0 && blockIdx.x == gridDim.x - 1) b.dbg[13] = (unsigned long long)wall_clock64();
 #endif
 
-    // ---- stage text (coalesced 16 B per lane) and the window's flag bits ------------------------
-    for (int v = tid; v < (Wv + WPAD) / 16; v += NT) {
+    // ---- stage text (coalesced 16 B per lane): the loads go out before anything else ------------
+    auto text16 = [&](int v) {
         const int64_t g = w0 + (int64_t)v * 16;
         uint4 x = make_uint4(0, 0, 0, 0);
-        if (g >= 0 && g + 16 <= B) x = *reinterpret_cast<const uint4*>(b.text + g);
+        if (g >= 0 && g + 16 <= B) x = *reinterpret_cast<const uint4*>(e_text + g);
         else if (g >= 0 && g < B) {
             uint32_t tmp[4] = {0, 0, 0, 0};
             for (int k = 0; k < 16; k++)
-                if (g + k < B) tmp[k >> 2] |= (uint32_t)b.text[g + k] << (8 * (k & 3));
+                if (g + k < B) tmp[k >> 2] |= (uint32_t)e_text[g + k] << (8 * (k & 3));
             x = make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]);
         }
-        *reinterpret_cast<uint4*>(s_txt32 + v * 4) = x;
+        return x;
+    };
+    constexpr bool ONE_ROUND = (Wv + WPAD) / 16 <= NT;           // small windows: at most one 16-byte load per lane
+    uint4 x_first = make_uint4(0, 0, 0, 0);
+    if (ONE_ROUND && tid < (Wv + WPAD) / 16) x_first = text16(tid);
+    // the two argument structs, from here on (see the head of the kernel)
+#ifndef SPL_LATE_KERNARGS
+#define SPL_LATE_KERNARGS 1
+#endif
+    typedef const PretokKernargs __attribute__((address_space(4))) KernargsK;
+    KernargsK* ka = (KernargsK*)__builtin_amdgcn_kernarg_segment_ptr();
+    if (SPL_LATE_KERNARGS) asm volatile("" : "+s"(ka) : : "memory");
+    const DeviceTables& T = SPL_LATE_KERNARGS ? *(const DeviceTables*)&ka->T : T_ka;
+    const Batch& b = SPL_LATE_KERNARGS ? *(const Batch*)&ka->b : b_ka;
+#ifdef SPL_DEBUG_STAMPS
+    if (e_dbg && tid == 0 && blockIdx.x == SPL_DBG_WG) e_dbg[11] = (unsigned long long)wall_clock64();
+    if (e_dbg && tid == 0 && blockIdx.x == gridDim.x - 1) e_dbg[13] = (unsigned long long)wall_clock64();
+#endif
+    if (ONE_ROUND) {
+        if (tid < (Wv + WPAD) / 16) *reinterpret_cast<uint4*>(s_txt32 + tid * 4) = x_first;
+    } else {
+        for (int v = tid; v < (Wv + WPAD) / 16; v += NT) *reinterpret_cast<uint4*>(s_txt32 + v * 4) = text16(v);
     }
     if (tid < G::NBW + 1) {
         const int64_t wi = (w0 >> 5) + tid;           // w0 is a multiple of 32
         const bool in = wi >= 0 && wi * 32 < B;
         // (tile-owned mode has these bitmaps only for SPL_WITH_SPECIAL: document starts come from
         //  the search below, the bitmap adds the text starts behind special literals)
-        s_ts[tid] = (in && (!DIRECT || b.tstart)) ? b.tstart[wi] : 0u;
-        s_sk[tid] = ((in && b.skip) ? b.skip[wi] : 0u) | ((DIRECT && in && b.ext_gaps) ? b.ext_gaps[wi] : 0u);
+        s_ts[tid] = (in && (!DIRECT || (e_flags & PRETOK_E_TSTART))) ? b.tstart[wi] : 0u;
+        s_sk[tid] = ((in && (e_flags & PRETOK_E_SKIP)) ? b.skip[wi] : 0u) | ((DIRECT && in && (e_flags & PRETOK_E_GAPS)) ? b.ext_gaps[wi] : 0u);
         s_cbits[tid] = 0;
         s_kill[tid] = 0; s_add[tid] = 0;
         s_tbits[tid] = 0;
     }
-    if (tid < 128) s_ascii[tid] = T.ucls_stage2[T.ascii_base + tid];
+    if (tid < 128) s_ascii[tid] = e_ascii[tid];
     if (tid < 4) s_nq[tid] = 0;
     if (tid < 12) s_dq[tid] = 0;
     if (DIRECT) {                                            // (length 0: no entry)
@@ -2204,7 +2257,7 @@ void k_pretok(DeviceTables T, Batch b) {
     // documents of the window set their bits.
     uint32_t dw = 0;                                   // first document with doc_off >= max(w0, 0)
     if (DIRECT) {
-        uint32_t lo = 0, hi = b.n_docs;
+        uint32_t lo = 0, hi = e_n_docs;
         const uint64_t target = w0 > 0 ? (uint64_t)w0 : 0ull;
         uint64_t p_held = ~0ull;                        // doc_off[d_held] from the first round, if it settled the search
         uint32_t d_held = 0xFFFFFFFFu, d_held_end = 0;
@@ -2218,7 +2271,7 @@ void k_pretok(DeviceTables T, Batch b) {
             const uint32_t glo = g > (uint32_t)(NT / 2) ? g - NT / 2 : 0u;
             const uint32_t ghi = glo + NT < hi ? glo + NT : hi;
             const uint32_t idx = glo + (uint32_t)tid;
-            const uint64_t p1 = idx < ghi ? b.doc_off[idx] : ~0ull;
+            const uint64_t p1 = idx < ghi ? e_doc_off[idx] : ~0ull;
             const bool below = idx < ghi && p1 < target;
             const uint32_t c = (uint32_t)__syncthreads_count(below);
             if (c == 0) hi = glo;                           // entry glo (if any) is not below the target
@@ -2228,7 +2281,7 @@ void k_pretok(DeviceTables T, Batch b) {
         while (target != 0 && lo < hi) {
             const uint32_t span = hi - lo, st = (span + NT - 1) / NT;
             const uint64_t idx = (uint64_t)lo + (uint64_t)tid * st;
-            const bool below = idx < hi && b.doc_off[idx] < target;
+            const bool below = idx < hi && e_doc_off[idx] < target;
             const uint32_t c = (uint32_t)__syncthreads_count(below);
             if (c == 0) { hi = lo; break; }
             const uint64_t nhi = (uint64_t)lo + (uint64_t)c * st;
@@ -2248,7 +2301,7 @@ void k_pretok(DeviceTables T, Batch b) {
         for (; base != 0xFFFFFFFFu; base += NT) {
             const uint64_t d = (uint64_t)base + tid;
             uint64_t p = ~0ull;
-            if (d < b.n_docs) p = b.doc_off[d];
+            if (d < e_n_docs) p = e_doc_off[d];
             const bool in = p < lim && p < (uint64_t)B;
             if (in) { const uint32_t i = (uint32_t)(p - (uint64_t)w0); atomicOr(&s_ts[i >> 5], 1u << (i & 31)); }
             if (!__syncthreads_or(tid == NT - 1 && in)) break;
@@ -2261,7 +2314,7 @@ void k_pretok(DeviceTables T, Batch b) {
     const int iB = (B - w0 < (int64_t)Wv) ? (int)(B - w0) : Wv;   // first index past the text
     const int iT = (B - w0 < (int64_t)(Wv + WPAD)) ? (int)(B - w0) : Wv + WPAD;   // staged text end
     constexpr int NBW1 = G::NBW + 1;
-    const bool ext = DIRECT && b.ext_starts != nullptr;     // chunk boundaries come from the host splitter
+    const bool ext = DIRECT && (e_flags & PRETOK_E_EXT) != 0u;     // chunk boundaries come from the host splitter
     if (ext) {
         // The tile owns the chunks that START in its own range [LH, LH + TB): their starts (and the terminator of
         // the last one: the first start at or behind the tile's end, a document start, or the end of the corpus)
@@ -2769,7 +2822,7 @@ void k_pretok(DeviceTables T, Batch b) {
                 if (__any(hl < n && (s_txt[p + hl] & 0x80u))) pair = false;
                 else {
 #if defined(SPL_DEBUG_STAMPS) && defined(SPL_STAMP_MEDIUM)
-                    long long* const wtm = (b.dbg && blockIdx.x == SPL_DBG_WG && ws_nmed == 1) ? ws_wt : nullptr;
+                    long long* const wtm = (e_dbg && blockIdx.x == SPL_DBG_WG && ws_nmed == 1) ? ws_wt : nullptr;
 #else
                     long long* const wtm = nullptr;
 #endif
@@ -2833,7 +2886,7 @@ void k_pretok(DeviceTables T, Batch b) {
             }
             const int p = (int)(item & 0xFFFFu);
 #if defined(SPL_DEBUG_STAMPS) && !defined(SPL_STAMP_MEDIUM)
-            long long* const wtp = (b.dbg && blockIdx.x == SPL_DBG_WG && ws_nshort == 1) ? ws_wt : nullptr;
+            long long* const wtp = (e_dbg && blockIdx.x == SPL_DBG_WG && ws_nshort == 1) ? ws_wt : nullptr;
 #else
             long long* const wtp = nullptr;
 #endif
@@ -2843,8 +2896,8 @@ void k_pretok(DeviceTables T, Batch b) {
                             }, wtp, paired ? 8 : 16);
         }
 #ifdef SPL_DEBUG_STAMPS
-        if (b.dbg && blockIdx.x == SPL_DBG_WG && (tid & 63) == 0) {
-            unsigned long long* r2 = b.dbg + 16 + 4 * (SPL_DEBUG_BLOCKS - 16 + 2 * (tid >> 6));
+        if (e_dbg && blockIdx.x == SPL_DBG_WG && (tid & 63) == 0) {
+            unsigned long long* r2 = e_dbg + 16 + 4 * (SPL_DEBUG_BLOCKS - 16 + 2 * (tid >> 6));
 #ifdef SPL_STAMP_MEDIUM
             for (int k = 0; k < 6; k++) r2[k] = (unsigned long long)(ws_wt[k] - ws_t0);     // the first MEDIUM pull, since the medium loop began
 #else
@@ -2853,8 +2906,8 @@ void k_pretok(DeviceTables T, Batch b) {
         }
 #endif
 #ifdef SPL_DEBUG_STAMPS
-        if (b.dbg && blockIdx.x == SPL_DBG_WG && (tid & 63) == 0) {      // per-wavefront record of the middle workgroup
-            unsigned long long* r = b.dbg + 16 + 4 * (SPL_DEBUG_BLOCKS - 8 + (tid >> 6));
+        if (e_dbg && blockIdx.x == SPL_DBG_WG && (tid & 63) == 0) {      // per-wavefront record of the middle workgroup
+            unsigned long long* r = e_dbg + 16 + 4 * (SPL_DEBUG_BLOCKS - 8 + (tid >> 6));
             r[0] = (unsigned long long)(ws_t1 - ws_t0);
             r[1] = (unsigned long long)(clock64() - ws_t1);
             r[2] = (unsigned long long)ws_nmed | ((unsigned long long)ws_nshort << 32);
@@ -2866,7 +2919,7 @@ void k_pretok(DeviceTables T, Batch b) {
     __syncthreads();
     SPL_STAMP(7);
 #ifdef SPL_DEBUG_STAMPS
-    if (b.dbg) blk_w1 = blk_w2 = (unsigned long long)wall_clock64();
+    if (e_dbg) blk_w1 = blk_w2 = (unsigned long long)wall_clock64();
 #endif
     if (!DIRECT) {
         if (tid < G::NBW) {
@@ -2925,8 +2978,8 @@ void k_pretok(DeviceTables T, Batch b) {
                             [&](int q) {
                                 const uint64_t g = (uint64_t)pos + (uint32_t)q;
                                 uint32_t w = 0;
-                                if (g + 4 <= (uint64_t)B) __builtin_memcpy(&w, b.text + g, 4);
-                                else for (int k = 0; k < 4; k++) if (g + k < (uint64_t)B) w |= (uint32_t)b.text[g + k] << (8 * k);
+                                if (g + 4 <= (uint64_t)B) __builtin_memcpy(&w, e_text + g, 4);
+                                else for (int k = 0; k < 4; k++) if (g + k < (uint64_t)B) w |= (uint32_t)e_text[g + k] << (8 * k);
                                 return w;
                             },
                             [&](int i, uint32_t id) { emit_g(pos + (uint32_t)i, id); });
@@ -2975,12 +3028,12 @@ void k_pretok(DeviceTables T, Batch b) {
                         // bit, the next document, or the end of the corpus -- nothing to scan for
                         if (tid == 0) {
                             const uint32_t pc = s_dq[2 + s_dq[6]] & 0x7FFFFFFFu;
-                            uint32_t lo = 0, hi = b.n_docs;             // first document that starts behind pc
+                            uint32_t lo = 0, hi = e_n_docs;             // first document that starts behind pc
                             while (lo < hi) {
                                 const uint32_t mid = lo + (hi - lo) / 2;
-                                if (b.doc_off[mid] <= (uint64_t)pc) lo = mid + 1; else hi = mid;
+                                if (e_doc_off[mid] <= (uint64_t)pc) lo = mid + 1; else hi = mid;
                             }
-                            const uint32_t lim = lo < b.n_docs ? (uint32_t)b.doc_off[lo] : b.n_bytes;
+                            const uint32_t lim = lo < e_n_docs ? (uint32_t)e_doc_off[lo] : e_n_bytes;
                             uint32_t e = lim;
                             for (uint32_t w = (pc + 1u) >> 5; w * 32u < lim; w++) {
                                 uint32_t word = b.ext_starts[w];
@@ -3006,13 +3059,13 @@ void k_pretok(DeviceTables T, Batch b) {
                     }
                     if (tid == 0 && s_dq[7] == 0) {
                         const uint32_t pent = s_dq[2 + s_dq[6]], pc = pent & 0x7FFFFFFFu;   // (bit 31: only a chunk start if no sync point)
-                        uint32_t lo = 0, hi = b.n_docs;         // first text start after the chain's start -- or AT it, if whether
+                        uint32_t lo = 0, hi = e_n_docs;         // first text start after the chain's start -- or AT it, if whether
                         while (lo < hi) {                        // a chunk of this chain starts there is still to be seen
                             const uint32_t mid = lo + (hi - lo) / 2;
-                            if (b.doc_off[mid] + (uint64_t)(pent >> 31) <= (uint64_t)pc) lo = mid + 1; else hi = mid;
+                            if (e_doc_off[mid] + (uint64_t)(pent >> 31) <= (uint64_t)pc) lo = mid + 1; else hi = mid;
                         }
                         s_dq[5] = pc;
-                        s_dq[8] = lo < b.n_docs ? (uint32_t)b.doc_off[lo] : b.n_bytes;
+                        s_dq[8] = lo < e_n_docs ? (uint32_t)e_doc_off[lo] : e_n_bytes;
                         s_dq[7] = (pent >> 31) ? 2u : 1u;
                     }
                     __syncthreads();
@@ -3035,7 +3088,7 @@ void k_pretok(DeviceTables T, Batch b) {
                             else if (n > 1) { s_lq[2 * fill] = np; s_lq[2 * fill + 1] = n; fill++; }
                             s_dq[0] = fill;
                             s_dq[5] = (uint32_t)e;
-                            if ((uint32_t)e >= b.n_bytes) { s_dq[6] += 1; s_dq[7] = 0; }
+                            if ((uint32_t)e >= e_n_bytes) { s_dq[6] += 1; s_dq[7] = 0; }
                             else s_dq[7] = 2u;
                         }
                         continue;
@@ -3053,15 +3106,15 @@ void k_pretok(DeviceTables T, Batch b) {
                         int tid_s = tid;                      // (as tid_late below: no 64-bit value derived from tid
                         asm volatile("" : "+v"(tid_s));      //  is kept from the kernel's start for this rare path)
                         int64_t g0 = pc + DIRECT_WIN / 2;
-                        while (g0 > pc && (b.text[g0] & 0xC0u) == 0x80u) g0--;
-                        const int P = (int)utf8_len(b.text[g0]);
+                        while (g0 > pc && (e_text[g0] & 0xC0u) == 0x80u) g0--;
+                        const int P = (int)utf8_len(e_text[g0]);
                         if (tid == 0) { s_dq[9] = 0xFFFFFFFFu; s_dq[10] = 0; }
                         __syncthreads();
                         for (int64_t blk = g0;; blk += NT * 16) {       // first byte that differs from the one P further on
                             uint32_t bad = 0xFFFFFFFFu;
                             for (int k = 0; k < 16 && bad == 0xFFFFFFFFu; k++) {
                                 const int64_t i = blk + tid_s * 16 + k;
-                                if (i + P >= lim || b.text[i] != b.text[i + P]) bad = (uint32_t)i;
+                                if (i + P >= lim || e_text[i] != e_text[i + P]) bad = (uint32_t)i;
                             }
                             if (bad != 0xFFFFFFFFu) atomicMin(&s_dq[9], bad);
                             __syncthreads();
@@ -3070,7 +3123,7 @@ void k_pretok(DeviceTables T, Batch b) {
                             if (found) break;
                         }
                         for (int64_t i = g0 - 1 - tid_s; i >= pc; i -= NT)  // and the last such byte before g0
-                            if (i + P >= lim || b.text[i] != b.text[i + P]) { atomicMax(&s_dq[10], (uint32_t)(i - pc) + 1u); break; }
+                            if (i + P >= lim || e_text[i] != e_text[i + P]) { atomicMax(&s_dq[10], (uint32_t)(i - pc) + 1u); break; }
                         __syncthreads();
                         const int64_t e_per = (int64_t)s_dq[9] + P;      // the periodic text is [a_per, e_per)
                         const int64_t a_per = pc + (int64_t)s_dq[10];
@@ -3089,7 +3142,7 @@ void k_pretok(DeviceTables T, Batch b) {
                     const int nst = (int)((Bv - base) < (int64_t)(DIRECT_WIN + 16) ? (Bv - base) : (int64_t)(DIRECT_WIN + 16));
                     const int nrec = nst < DIRECT_WIN ? nst + 1 : DIRECT_WIN;
                     for (int i = tid; i < DIRECT_WIN + 32; i += NT)
-                        wtxt[i] = i < nst ? b.text[base + i + (i >= split ? (int64_t)removed : 0)] : (uint8_t)0;
+                        wtxt[i] = i < nst ? e_text[base + i + (i >= split ? (int64_t)removed : 0)] : (uint8_t)0;
                     __syncthreads();
                     for (int i = tid; i < nrec; i += NT) {
                         const int64_t g = base + i + (i >= split ? (int64_t)removed : 0);
@@ -3181,7 +3234,7 @@ void k_pretok(DeviceTables T, Batch b) {
         const uint64_t own_lo = (uint64_t)t0, own_hi = (uint64_t)(t0 + TB_);
         const uint64_t d_first = (uint64_t)dw + (uint32_t)tid_late;
         uint64_t p_first = ~0ull;
-        if (d_first <= b.n_docs) p_first = b.doc_off[d_first];      // entry n_docs is the end of the corpus
+        if (d_first <= e_n_docs) p_first = e_doc_off[d_first];      // entry n_docs is the end of the corpus
         // ---- token count of the tile: window bitmap + overflow range --------------------------------
         uint32_t c_win;
         {
@@ -3230,7 +3283,7 @@ void k_pretok(DeviceTables T, Batch b) {
         if (queue_mode && tid_late < TILE_BITS_W)
             b.tile_bits[(size_t)blockIdx.x * TILE_BITS_W + tid_late] = tid_late < G::NBW + 1 ? s_tbits[tid_late] : 0u;
 #ifdef SPL_DEBUG_STAMPS
-        if (b.dbg) blk_w2 = (unsigned long long)wall_clock64();
+        if (e_dbg) blk_w2 = (unsigned long long)wall_clock64();
 #endif
         const uint32_t slot = blockIdx.x * b.tslot;                // fixed slots: nothing to wait for
         for (uint32_t k = tid_late; k < c_win; k += NT) b.tile_ids[slot + k] = s_ids[s_cpos[k]];
@@ -3238,8 +3291,8 @@ void k_pretok(DeviceTables T, Batch b) {
         for (uint32_t db = dw;; db += NT) {
             const uint64_t d = (uint64_t)db + tid_late;
             uint64_t p = p_first;
-            if (db != dw) { p = ~0ull; if (d <= b.n_docs) p = b.doc_off[d]; }
-            const bool in = d <= b.n_docs && (p < own_hi || last_tile);
+            if (db != dw) { p = ~0ull; if (d <= e_n_docs) p = e_doc_off[d]; }
+            const bool in = d <= e_n_docs && (p < own_hi || last_tile);
             const bool own = in && p >= own_lo;
             if (own && !queue_mode) {
                 const uint32_t i = (uint32_t)(p - (uint64_t)w0);
@@ -3271,10 +3324,18 @@ void k_pretok(DeviceTables T, Batch b) {
     }
     SPL_STAMP(8);
 #ifdef SPL_DEBUG_STAMPS
-    if (b.dbg && tid == 0 && blockIdx.x == SPL_DBG_WG) b.dbg[12] = (unsigned long long)wall_clock64();
-    if (b.dbg && tid == 0 && blockIdx.x < SPL_DEBUG_BLOCKS) {
+    if (e_dbg && tid == 0 && blockIdx.x == SPL_DBG_WG) e_dbg[12] = (unsigned long long)wall_clock64();
+#ifdef SPL_STAMP_ALL
+    if (e_dbg && tid == 0 && SPL_REC_BLK < SPL_DEBUG_BLOCKS / 2) {
+        e_dbg[16 + 8 * SPL_REC_BLK] = blk_t0;
+        e_dbg[16 + 8 * SPL_REC_BLK + 7] = (unsigned long long)wall_clock64();
+    }
+    if (false) {
+#else
+    if (e_dbg && tid == 0 && blockIdx.x < SPL_DEBUG_BLOCKS) {
+#endif
         // wall-clock ticks: start, end of the merge phase, counts done, end
-        unsigned long long* r = b.dbg + 16 + 4 * blockIdx.x;
+        unsigned long long* r = e_dbg + 16 + 4 * blockIdx.x;
         r[0] = blk_t0;
         r[1] = blk_w1;
         r[2] = blk_w2;
@@ -3284,8 +3345,12 @@ void k_pretok(DeviceTables T, Batch b) {
     {
         int tid_end = tid;                                   // (as tid_late: nothing tid-derived kept for this)
         asm volatile("" : "+v"(tid_end));
-        if (b.dbg && tid_end == 0) atomicMax(&b.dbg[15], (unsigned long long)wall_clock64());
+        if (e_dbg && tid_end == 0) atomicMax(&e_dbg[15], (unsigned long long)wall_clock64());
     }
+#ifdef SPL_PASSES
+    }
+#endif
+#undef SPL_REC_BLK
 #undef SPL_STAMP
 }
 
