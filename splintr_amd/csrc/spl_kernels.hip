@@ -2089,6 +2089,17 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
     return nl2 < (uint32_t)DIRECT_LQCAP ? nl2 : (uint32_t)DIRECT_LQCAP;
 }
 
+// Workgroup -> tile.  Workgroups go to the eight XCDs round robin; with SPL_XCD_MAP each XCD works a CONTIGUOUS eighth
+// of the tiles (a bijection for any grid size), so that neighbouring tiles share their halo lines -- and k_tile_out
+// finds a tile's ids -- in that XCD's own L2.
+#ifndef SPL_XCD_MAP
+#define SPL_XCD_MAP 1            /* 0: workgroup i works tile i (A/B) */
+#endif
+__device__ __forceinline__ uint32_t xcd_tile() {
+    if (!SPL_XCD_MAP) return blockIdx.x;
+    const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3, q = gridDim.x >> 3, r = gridDim.x & 7u;
+    return x * q + (x < r ? x : r) + j;
+}
 // e_flags of k_pretok: which optional inputs exist, and the split pattern
 constexpr uint32_t PRETOK_E_TSTART = 1u, PRETOK_E_SKIP = 2u, PRETOK_E_GAPS = 4u, PRETOK_E_EXT = 8u;
 inline uint32_t pretok_flags(const DeviceTables& T, const Batch& b) {
@@ -2187,7 +2198,8 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
 #define SPL_REC_BLK blockIdx.x
 #endif
     if (DIRECT) __builtin_amdgcn_s_setprio(SPL_WORK_PRIO);
-    const int64_t t0 = (int64_t)blockIdx.x * TB_;
+    const uint32_t tile_ix = xcd_tile();
+    const int64_t t0 = (int64_t)tile_ix * TB_;
     const int64_t w0 = t0 - LH;                       // global position of window index 0
     const int64_t B = e_n_bytes;
     // profiling: span of this kernel on the constant-rate wall clock (start of workgroup 0, max end
@@ -3230,7 +3242,7 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
             __syncthreads();
         }
         // the first NT documents of the window are fetched now: their load overlaps the count below
-        const bool last_tile = blockIdx.x == gridDim.x - 1;
+        const bool last_tile = tile_ix == gridDim.x - 1;
         const uint64_t own_lo = (uint64_t)t0, own_hi = (uint64_t)(t0 + TB_);
         const uint64_t d_first = (uint64_t)dw + (uint32_t)tid_late;
         uint64_t p_first = ~0ull;
@@ -3279,13 +3291,13 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
         //  waits for another workgroup, so a tile that is slow -- long chunks, a chain that runs far
         //  beyond the window -- only delays itself)
         const bool queue_mode = b.qcount != nullptr;          // long chunks / chains went to the global queues
-        if (tid_late == 0 && !queue_mode) atomicAdd(&b.tctl[16 + b.tpar * b.tgroups + (blockIdx.x >> 6)], (uint32_t)total);
+        if (tid_late == 0 && !queue_mode) atomicAdd(&b.tctl[16 + b.tpar * b.tgroups + (tile_ix >> 6)], (uint32_t)total);
         if (queue_mode && tid_late < TILE_BITS_W)
-            b.tile_bits[(size_t)blockIdx.x * TILE_BITS_W + tid_late] = tid_late < G::NBW + 1 ? s_tbits[tid_late] : 0u;
+            b.tile_bits[(size_t)tile_ix * TILE_BITS_W + tid_late] = tid_late < G::NBW + 1 ? s_tbits[tid_late] : 0u;
 #ifdef SPL_DEBUG_STAMPS
         if (e_dbg) blk_w2 = (unsigned long long)wall_clock64();
 #endif
-        const uint32_t slot = blockIdx.x * b.tslot;                // fixed slots: nothing to wait for
+        const uint32_t slot = tile_ix * b.tslot;                // fixed slots: nothing to wait for
         for (uint32_t k = tid_late; k < c_win; k += NT) b.tile_ids[slot + k] = s_ids[s_cpos[k]];
         uint32_t d_lo = 0xFFFFFFFFu, d_n = 0;
         for (uint32_t db = dw;; db += NT) {
@@ -3319,7 +3331,7 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
             td.slot = slot; td.c_win = c_win; td.c_ovf = c_ovf; td.ovf_hi = whi > wlo ? ovf_hi : 0u;
             td.d_first = d_lo == 0xFFFFFFFFu ? 0u : d_lo; td.d_cnt = d_n; td.ovf_lo = ovf_lo;
             td.c_own = s_wpre[DIRECT ? (LH + TB_) >> 5 : 0];             // tile range ends on a word boundary
-            b.tdesc[blockIdx.x] = td;
+            b.tdesc[tile_ix] = td;
         }
     }
     SPL_STAMP(8);
@@ -3367,7 +3379,7 @@ constexpr int TOUT_NT = SPL_TILE_OUT_NT;               // threads of a k_tile_ou
 __global__ __launch_bounds__(TOUT_NT) void k_tile_out(Batch b) {
     __shared__ unsigned long long s_part[TOUT_NT / 64];
     __shared__ uint32_t s_wsum[TOUT_NT / 64];
-    const uint32_t t = blockIdx.x;
+    const uint32_t t = xcd_tile();
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t* gs = b.tctl + 16 + b.tpar * b.tgroups;
     const uint32_t g = t >> 6;
