@@ -561,6 +561,8 @@ __device__ __forceinline__ uint32_t probe_short_mixed(const DeviceTables& T, uin
     const uint32_t lm = pe.lm, salt = lm >> 8;
     if (n >= 2u && !((lm >> (n <= (uint32_t)SPL_T8_MAX ? n - 2u : 7u)) & 1u)) return SPL_NO_RANK;
     if (n == 2u) return pe.id2;                  // the prefix entry carries the two-byte token's id: no bucket to read
+    // (one-byte chunks from the 1 KB byte table instead of the tiny table, loaded in the prefix entries' round trip:
+    //  measured, no faster -- 34.9 against 34.9 us on C2, 50.8 against 50.3 on c2_wide)
     const uint32_t h = tiny ? hash_tiny(k0, n, salt) : t8 ? hash_t8(k0, k1, n, salt) : hash_short(k0, k1, k2, n, salt);
     const Quad* src = tiny ? reinterpret_cast<const Quad*>(T.tiny_tab + (size_t)(h & T.tiny_mask) * (SPL_TINY_BUCKET * 2))
                     : t8   ? reinterpret_cast<const Quad*>(T.t8_tab + (size_t)(h & T.t8_mask) * SPL_T8_WORDS)
@@ -2257,6 +2259,7 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
     }
     if (tid < 128) s_ascii[tid] = e_ascii[tid];
     if (tid < 4) s_nq[tid] = 0;
+    if (tid < 17) s_scnt[tid] = 0;                    // (the counting sort of the merge phase: zeroed here, one barrier less there)
     if (tid < 12) s_dq[tid] = 0;
     if (DIRECT) {                                            // (length 0: no entry)
         int t_early = tid;                                   // an index of its own: shared with the tail's uses of
@@ -2750,8 +2753,6 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
         // lengths -- a round lasts as long as its longest chunk -- and the longest chains start first.
         constexpr bool SORT_SHORT = Wv <= 1024;            // window index (10 bits) | n - 1 (4 bits) in 16 bits
         if (SORT_SHORT) {
-            if (tid < 17) s_scnt[tid] = 0;
-            __syncthreads();
             uint32_t my_item[(G::C16 + NT - 1) / NT], my_r[(G::C16 + NT - 1) / NT];
 #pragma unroll
             for (int q = 0; q < (G::C16 + NT - 1) / NT; q++) {
@@ -2759,9 +2760,10 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
                 if (k < m16) { my_item[q] = s_miss[k]; my_r[q] = atomicAdd(&s_scnt[16 - (my_item[q] >> 16)], 1u); }
             }
             __syncthreads();
-            if (tid == 0) {
-                uint32_t acc = 0;
-                for (int k = 0; k < 17; k++) { const uint32_t c = s_scnt[k]; s_scnt[k] = acc; acc += c; }
+            if (tid < 64) {                                // exclusive prefix sums of the 17 counts: one wavefront scan
+                const uint32_t c = tid < 17 ? s_scnt[tid] : 0u;
+                const uint32_t x = wave_scan_incl(c);
+                if (tid < 17) s_scnt[tid] = x - c;
             }
             __syncthreads();
 #pragma unroll
