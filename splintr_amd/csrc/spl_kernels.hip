@@ -1872,7 +1872,19 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
         return s_lq[2 * item[k]] + ((uint32_t)row - off[k]);
     };
     if (tid == 0) { ctl[3] = 0; ctl[5] = 0; hard[8] = 0; hard[9] = 0; }
+#ifdef SPL_STAMP_TAIL      /* profiling: wall clock of a pass's steps as thread 0 sees them, summed over all workgroups and passes of
+                              a launch of at most ~4000 tiles (tools/dev/gpu_tail_steps.py; the atomics inflate every step) */
+    unsigned long long tt_prev = 0;
+#define TT(k) do { if (b.dbg && tid == 0) { const unsigned long long tt_now = wall_clock64(); \
+                   if ((k) >= 0) atomicAdd(&b.dbg[16 + 4 * (SPL_DEBUG_BLOCKS - 32) + (k)], tt_now - tt_prev); tt_prev = tt_now; } } while (0)
+#define TT_COUNT() do { if (b.dbg && tid == 0) { atomicAdd(&b.dbg[16 + 4 * (SPL_DEBUG_BLOCKS - 32) + 7], 1ull); \
+                        atomicAdd(&b.dbg[16 + 4 * (SPL_DEBUG_BLOCKS - 32) + 6], (unsigned long long)total); } } while (0)
+#else
+#define TT(k) do { } while (0)
+#define TT_COUNT() do { } while (0)
+#endif
     for (;;) {
+        TT(-1);
         __syncthreads();
         if (wv == 0) {
             // pack: the untried chunks in list order while they fit (lane = list index); a chunk beyond
@@ -1908,6 +1920,7 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
         __syncthreads();
         const uint32_t nk = ctl[0];
         if (nk == 0) break;
+        TT(0);                                               // pack (and the wait for the previous pass's stragglers)
         const uint32_t total = off[nk];
         // ---- table rows, longest token per row, boundaries ------------------------------------------
         const bool own = (uint32_t)tid < total;
@@ -1930,6 +1943,9 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
         }
         const RowHead rh = row_head(T, own, w0, maxlen);     // which token lengths exist at all behind these bytes
         lm = rh.lm;
+#if defined(SPL_TAIL_CUT)
+        if (SPL_TAIL_CUT >= 2) { lm = 0; maxlen = maxlen < 2 ? maxlen : 2; }
+#endif
         uint32_t* const row = slab + tid * SUB_W;
         int ml = 1;
         {
@@ -1972,6 +1988,7 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
             const int l8 = (int)p8_match(e8.a, e8.b, p8_tag(w0, w1));
             if (l8) ml = (l8 == 255 || l8 > cap) ? cap : l8;
         }
+        TT(1);                                               // rows filled (three dependent round trips)
         {
             uint32_t cover = wave_scan_max(own ? (uint32_t)(tid + ml - 1) : 0u);
             if (lane == 63) s_wsum4[wv] = cover;
@@ -1981,6 +1998,7 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
             if (lane == 0) { hard[2 * wv] = (uint32_t)hb; hard[2 * wv + 1] = (uint32_t)(hb >> 32); }
         }
         __syncthreads();
+        TT(2);                                               // boundaries
         // a cut chunk: only what lies before the last boundary among the rows is complete; the rest
         // goes back on the list as a chunk of its own (nothing spans that boundary)
         uint32_t rows = total;
@@ -1992,7 +2010,10 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
         }
         // ---- every row that starts a segment: up to 8 bytes are merged by the row's own lane (all spans
         //      are in the table), longer ones go to a group of 16 lanes, a wavefront, or back on the list
-        if ((uint32_t)tid < rows && (tid == 0 || ((hard[(tid - 1) >> 5] >> ((tid - 1) & 31)) & 1u))) {
+#ifndef SPL_TAIL_CUT
+#define SPL_TAIL_CUT 0           /* timing experiments only (tokens missing): 1 no segment merges, 2 no table probes either */
+#endif
+        if (SPL_TAIL_CUT < 1 && (uint32_t)tid < rows && (tid == 0 || ((hard[(tid - 1) >> 5] >> ((tid - 1) & 31)) & 1u))) {
             const uint32_t h0 = hbits(tid);                  // the first boundary at or after the start ends the segment
             if (h0 & 0xFFu) {
                 const int len = __ffs((int)h0);
@@ -2045,6 +2066,7 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
             }
         }
         __syncthreads();
+        TT(3);                                               // segments of up to 8 bytes, classification of the rest
         // ---- segments of 9..16 bytes: a group of 16 lanes each ------------------------------------------
         {
             const int gi = tid >> 4, gl = tid & 15;
@@ -2058,6 +2080,7 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
                               [&](int i, uint32_t id) { emit_g(gpos + (uint32_t)i, id); });
             }
         }
+        TT(4);                                               // 9..16 (thread 0's wavefront)
         // ---- segments of 17..64 bytes: one wavefront each ------------------------------------------
         for (uint32_t q = (uint32_t)wv; q < ctl[1]; q += NT / 64) {
             const int s0 = (int)(lseg[q] & 0xFFFFu), len = (int)(lseg[q] >> 16);
@@ -2075,6 +2098,8 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
                                  [&](int i, uint32_t id) { emit_g(gpos + (uint32_t)i, id); });
         }
         __syncthreads();
+        TT(5);                                               // 17..64, 65.. and the wait for the other wavefronts
+        TT_COUNT();
         if ((uint32_t)tid < nk && !((ctl[2] >> tid) & 1u)) {
             if (!cut) s_lq[2 * item[tid] + 1] = 0;          // done: off the list
             else {                                           // the rest of a cut chunk: to be packed again
@@ -2087,6 +2112,8 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
         }
     }
     __syncthreads();
+#undef TT
+#undef TT_COUNT
     const uint32_t nl2 = nl + ctl[5];                       // the list grew by the segments set aside
     return nl2 < (uint32_t)DIRECT_LQCAP ? nl2 : (uint32_t)DIRECT_LQCAP;
 }
@@ -2962,7 +2989,10 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
         // segment of up to 8 bytes, 16 lanes up to 16, a wavefront beyond -- where the per-chunk route
         // paid a fill and a lock-step loop per group of four chunks.
         const uint32_t n_tm = TILE_LIST ? s_nq[0] : 0u;
-        if (n_tm | s_dq[0] | s_dq[1] | s_dq[11]) {         // workgroup-uniform
+#ifndef SPL_SKIP_TAIL
+#define SPL_SKIP_TAIL 0          /* timing experiment only (tokens missing): the tile-owned tail does nothing */
+#endif
+        if (!SPL_SKIP_TAIL && (n_tm | s_dq[0] | s_dq[1] | s_dq[11])) {         // workgroup-uniform
             uint32_t mcur = 0;
             for (;;) {
                 {

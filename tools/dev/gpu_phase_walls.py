@@ -11,7 +11,7 @@ ndocs = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 TB = 800
 PASS = int(os.environ.get("SPL_WALLS_PASS", "0"))
 L = _ffi.lib()
-tok = Tokenizer.from_pretrained("cl100k_base")
+tok = Tokenizer.from_pretrained(os.environ.get("SPL_WALLS_VOCAB", "cl100k_base"))
 texts = getattr(corpus, gen)(ndocs)
 batch = DeviceBatch(texts, torch.device("cuda", 0))
 reserve(tok, batch.n_bytes, batch.n_docs)
