@@ -1791,7 +1791,10 @@ template <int TB_, int RH_> struct TileGeom {
                                      fewer instructions, but the tail's ~20 workgroup barriers serialise what the wavefronts
                                      otherwise do independently (profiles/r02_notes.md).  Kept for A/B builds. */
 #endif
-constexpr int DIRECT_LQ_MEDIUM = 16;      // of which, from the back: medium chunks of multi-byte text
+#ifndef SPL_LQ_MEDIUM
+#define SPL_LQ_MEDIUM 16
+#endif
+constexpr int DIRECT_LQ_MEDIUM = SPL_LQ_MEDIUM;      // of which, from the back: medium chunks of multi-byte text
 constexpr int DIRECT_LQCAP = 32;          // long-chunk list of one workgroup (refilled while a chain is continued)
 constexpr int DIRECT_WIN = 2048;           // bytes staged per turn for a chain that continues beyond the window
 constexpr int DIRECT_WAVE_NMAX = 256;     // nodes of one wavefront's LDS slab in the single-pass tail
@@ -1822,7 +1825,10 @@ static_assert((NT / 64) * DIRECT_TAB_NMAX * SUB_W >= 3 * DIRECT_BLOCK_NMAX, "the
 // left on the list for the merge loops below.  Chinese text is chunks of 60..200 bytes made of
 // 3-byte segments: two memory round trips and a few two-step loops per tile, where the node-list
 // loops pay a round trip per merge.
-constexpr int SEG_ROWS = NT;
+#ifndef SPL_SEG_ROWS
+#define SPL_SEG_ROWS NT
+#endif
+constexpr int SEG_ROWS = SPL_SEG_ROWS;     // rows of a pass: one per thread ((A/B) 128: twice the passes -- what a pass costs)
 constexpr int SG_OFF = 0;        // [33] row of each packed chunk's first byte (+ total)
 constexpr int SG_ITEM = 33;      // [32] its index on the long list
 constexpr int SG_HARD = 65;      // [8 + 2 zero words] bit r: nothing spans the boundary after row r
