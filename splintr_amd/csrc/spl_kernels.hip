@@ -1828,12 +1828,15 @@ static_assert((NT / 64) * DIRECT_TAB_NMAX * SUB_W >= 3 * DIRECT_BLOCK_NMAX, "the
 #ifndef SPL_SEG_ROWS
 #define SPL_SEG_ROWS NT
 #endif
+#ifndef SPL_TAIL_SKIP_EMPTY
+#define SPL_TAIL_SKIP_EMPTY 1    /* 1: no chunk left behind the segment passes (nearly always): none of the caller's three node-list loops, nor their barriers */
+#endif
 constexpr int SEG_ROWS = SPL_SEG_ROWS;     // rows of a pass: one per thread ((A/B) 128: twice the passes -- what a pass costs)
 constexpr int SG_OFF = 0;        // [33] row of each packed chunk's first byte (+ total)
 constexpr int SG_ITEM = 33;      // [32] its index on the long list
 constexpr int SG_HARD = 65;      // [8 + 2 zero words] bit r: nothing spans the boundary after row r
 constexpr int SG_LONG = 75;      // [16] segments of 17..64 bytes: first row | length << 16
-constexpr int SG_CTL = 91;       // [8] packed chunks, long segments, chunks to leave (bit = packing slot), chunks tried
+constexpr int SG_CTL = 91;       // [9] packed chunks, long segments, chunks to leave (bit = packing slot), chunks tried
                                  //     (bit = list index), cut, chunks appended, mid segments
 constexpr int SG_ID = 100;       // [SEG_ROWS] id of each row's byte
 constexpr int SG_MID = SG_ID + SEG_ROWS;     // [32] segments of 9..16 bytes
@@ -1918,9 +1921,15 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
             if (take) { off[k] = offv; item[k] = (uint32_t)lane; atomicOr(&sbits[offv >> 5], 1u << (offv & 31)); }
             const uint32_t endv = offv + (n < (uint32_t)SEG_ROWS ? n : (uint32_t)SEG_ROWS);
             const uint32_t total = tm ? (uint32_t)__builtin_amdgcn_readlane((int)endv, 63 - __builtin_clzll(tm)) : 0u;
+            // (for the caller: is ANY chunk of two bytes or more on the list -- packed now, left by an earlier pass, or a long
+            //  segment set aside behind its end?  Nearly always not once the last pass is done, and the caller then skips
+            //  its three node-list loops and their barriers.)
+            const uint32_t nl_now = nl + ctl[5] < (uint32_t)DIRECT_LQCAP ? nl + ctl[5] : (uint32_t)DIRECT_LQCAP;
+            const unsigned long long any_m = __ballot(lane < 32 && (uint32_t)lane < nl_now && s_lq[2 * lane + 1] >= 2u);
             if (lane == 0) {
                 off[nk] = total;
                 ctl[0] = nk; ctl[1] = 0; ctl[2] = 0; ctl[3] = tried | (uint32_t)tm; ctl[4] = cut; ctl[6] = 0; ctl[7] = 0;
+                ctl[8] = any_m != 0ull;
             }
         }
         __syncthreads();
@@ -1954,42 +1963,53 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
 #endif
         uint32_t* const row = slab + tid * SUB_W;
         int ml = 1;
+#ifndef SPL_TAIL_LEAD6
+#define SPL_TAIL_LEAD6 1         /* 1: a row that starts a three-byte character probes length 6 in the first batch and 5 in the second (A/B: 0) */
+#endif
+        // Which of the lengths 5 and 6 goes out with the first batch: behind the lead byte of a three-byte character the
+        // likely longer token is the two-character word (6 bytes), and with it in the first batch -- and the p8 bucket too
+        // -- a wavefront of CJK rows mostly has nothing left for the second one: two dependent round trips per pass
+        // instead of three.  (The t8 probe takes any length: only the key mask and the row's cell depend on it.)
+        const bool lead3 = SPL_TAIL_LEAD6 && (w0 & 0xF0u) == 0xE0u;
+        const uint32_t La = lead3 ? 6u : 5u, Lb = lead3 ? 5u : 6u;
+        const uint32_t ka1 = lead3 ? (w1 & 0xFFFFu) : (w1 & 0xFFu), kb1 = lead3 ? (w1 & 0xFFu) : (w1 & 0xFFFFu);
+        P8Bucket e8{0u, 0u};
         {
             Quad qb[2], qc[2], qd[3];
-            const uint32_t kb = w0 & 0xFFFFFFu, ha = w1 & 0xFFu;
+            const uint32_t kb = w0 & 0xFFFFFFu;
             if (maxlen >= 2) {                               // (one predicate per batch: see bpe_group16_tab)
                 tiny_issue_if(T, (lm & 2u) != 0, kb, 3u, lm >> 8, qb);
                 tiny_issue_if(T, (lm & 4u) != 0, w0, 4u, lm >> 8, qc);
-                t8_issue_if(T, (lm & 8u) != 0, w0, ha, 5u, lm >> 8, qd);
+                t8_issue_if(T, ((lm >> (La - 2u)) & 1u) != 0, w0, ka1, La, lm >> 8, qd);
+                if (cap > SUB_LMAX && (lm & 0x80u)) e8 = T.p8_tab[hash_p8(w0, w1) & T.p8_mask];
                 const uint32_t r2 = rh.id2, r3 = tiny_finish(T, kb, 3u, lm >> 8, qb);
-                const uint32_t r4 = tiny_finish(T, w0, 4u, lm >> 8, qc), r5 = t8_finish(T, w0, ha, 5u, lm >> 8, qd);
-                row[0] = r2; row[1] = r3; row[2] = r4; row[3] = r5;
+                const uint32_t r4 = tiny_finish(T, w0, 4u, lm >> 8, qc), ra = t8_finish(T, w0, ka1, La, lm >> 8, qd);
+                row[0] = r2; row[1] = r3; row[2] = r4; row[La - 2u] = ra;
                 ml = r2 != SPL_NO_RANK ? 2 : ml;
                 ml = (r3 != SPL_NO_RANK && maxlen >= 3) ? 3 : ml;
                 ml = (r4 != SPL_NO_RANK && maxlen >= 4) ? 4 : ml;
-                ml = (r5 != SPL_NO_RANK && maxlen >= 5) ? 5 : ml;
+                ml = (ra != SPL_NO_RANK && maxlen >= (int)La) ? (int)La : ml;
             }
         }
         sid[tid] = bid;
         {
-            P8Bucket e8{0u, 0u};                               // the p8 bucket travels with the second batch
-            if (cap > SUB_LMAX && (lm & 0x80u)) e8 = T.p8_tab[hash_p8(w0, w1) & T.p8_mask];
-            if (__any(maxlen >= 6 && (lm & 0x70u))) {
+            const uint32_t rest_bits = (1u << (Lb - 2u)) | 0x60u;          // the lengths of the second batch: Lb, 7, 8
+            if (__any(maxlen >= (int)Lb && (lm & rest_bits))) {
                 Quad qa[3], qb[3], qc[3];
-                const uint32_t hb = w1 & 0xFFFFu, hc = w1 & 0xFFFFFFu;
-                if (maxlen >= 6) {
-                    t8_issue_if(T, (lm & 0x10u) != 0, w0, hb, 6u, lm >> 8, qa);
+                const uint32_t hc = w1 & 0xFFFFFFu;
+                if (maxlen >= (int)Lb) {
+                    t8_issue_if(T, ((lm >> (Lb - 2u)) & 1u) != 0, w0, kb1, Lb, lm >> 8, qa);
                     t8_issue_if(T, (lm & 0x20u) != 0, w0, hc, 7u, lm >> 8, qb);
                     t8_issue_if(T, (lm & 0x40u) != 0, w0, w1, 8u, lm >> 8, qc);
-                    const uint32_t r6 = t8_finish(T, w0, hb, 6u, lm >> 8, qa), r7 = t8_finish(T, w0, hc, 7u, lm >> 8, qb);
+                    const uint32_t rb = t8_finish(T, w0, kb1, Lb, lm >> 8, qa), r7 = t8_finish(T, w0, hc, 7u, lm >> 8, qb);
                     const uint32_t r8 = t8_finish(T, w0, w1, 8u, lm >> 8, qc);
-                    row[4] = r6; row[5] = r7; row[6] = r8;
-                    ml = r6 != SPL_NO_RANK ? 6 : ml;
+                    row[Lb - 2u] = rb; row[5] = r7; row[6] = r8;
+                    ml = (rb != SPL_NO_RANK && maxlen >= (int)Lb && (int)Lb > ml) ? (int)Lb : ml;
                     ml = (r7 != SPL_NO_RANK && maxlen >= 7) ? 7 : ml;
                     ml = (r8 != SPL_NO_RANK && maxlen >= 8) ? 8 : ml;
                 }
-            } else if (maxlen >= 6) {                        // nothing of 6..8 bytes starts in this wavefront's rows
-                row[4] = SPL_NO_RANK; row[5] = SPL_NO_RANK; row[6] = SPL_NO_RANK;
+            } else if (maxlen >= (int)Lb) {                  // nothing of the second batch's lengths starts in this wavefront's rows
+                row[Lb - 2u] = SPL_NO_RANK; row[5] = SPL_NO_RANK; row[6] = SPL_NO_RANK;
             }
             const int l8 = (int)p8_match(e8.a, e8.b, p8_tag(w0, w1));
             if (l8) ml = (l8 == 255 || l8 > cap) ? cap : l8;
@@ -2121,6 +2141,7 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
 #undef TT
 #undef TT_COUNT
     const uint32_t nl2 = nl + ctl[5];                       // the list grew by the segments set aside
+    if (SPL_TAIL_SKIP_EMPTY && !ctl[8]) return 0u;          // (as of the last, empty pass: nothing of two bytes or more is left)
     return nl2 < (uint32_t)DIRECT_LQCAP ? nl2 : (uint32_t)DIRECT_LQCAP;
 }
 
@@ -3001,7 +3022,10 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
         if (!SPL_SKIP_TAIL && (n_tm | s_dq[0] | s_dq[1] | s_dq[11])) {         // workgroup-uniform
             uint32_t mcur = 0;
             for (;;) {
-                {
+#ifndef SPL_TAIL_LISTFILL_ALWAYS
+#define SPL_TAIL_LISTFILL_ALWAYS 0
+#endif
+                if (TILE_LIST || SPL_TAIL_LISTFILL_ALWAYS) { // (only the tile-miss-list build moves misses onto the list here: two barriers)
                     const uint32_t have = s_dq[0];           // entries the chain continuation left on the list
                     uint32_t m = n_tm - mcur;
                     if (m > (uint32_t)DIRECT_LQCAP - have) m = (uint32_t)DIRECT_LQCAP - have;
@@ -3017,8 +3041,11 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
                 }
                 // (round-1 routing: medium chunks sit at the back of the list, unused entries have length 0)
                 const uint32_t nl0 = (!TILE_LIST && (s_dq[11] || s_dq[0] > (uint32_t)DIRECT_LQCAP)) ? (uint32_t)DIRECT_LQCAP : s_dq[0];
-                const uint32_t nl = bpe_tail_segments<2>(T, b, s_lq, nl0, s_u.t.slab[0], reinterpret_cast<uint32_t*>(s_cpos), s_wsum,
-                                                      s_txt, w0, w0 + iT, emit_g);
+                // (the same value in every lane, read from LDS behind a barrier: as a scalar, so that the branch below is one)
+                const uint32_t nl = (uint32_t)__builtin_amdgcn_readfirstlane((int)bpe_tail_segments<2>(
+                    T, b, s_lq, nl0, s_u.t.slab[0], reinterpret_cast<uint32_t*>(s_cpos), s_wsum, s_txt, w0, w0 + iT, emit_g));
+                // (nl: the list's length, finished entries -- length 0 -- included; 0 if no chunk is left at all)
+                if (!SPL_TAIL_SKIP_EMPTY || nl) {
                 for (uint32_t it = wv; it < nl; it += NT / 64) {         // one wavefront per chunk
                     const int n = (int)s_lq[2 * it + 1];
                     const uint32_t pos = s_lq[2 * it];
@@ -3063,6 +3090,7 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
                     if (n > WAVE_NMAX) bpe_block_rounds(T, b, s_lq[2 * it], n, s_wsum, emit_g);
                 }
                 __syncthreads();
+                }
                 // continue the chain(s) that ran beyond the window: the workgroup stages the next DIRECT_WIN
                 // bytes and their class records in LDS (in parallel), thread 0 walks the chain there --
                 // whole-chunk hits become tokens at once, misses of ANY length refill the list for the
