@@ -1942,10 +1942,12 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
         const bool cut = ctl[4] != 0;                        // the (one) chunk continues beyond the rows
         int maxlen = 0, cap = 0;                             // cap: bytes left in the row's chunk
         uint32_t w0 = 0, w1 = 0, bid = SPL_DEAD, lm = 0;
+        uint32_t my_gpos = 0;                                // global position of this row's byte (kept: the row's segment starts there)
         if (own) {
             const uint32_t k = chunk_of(tid);
             const uint32_t ci = (uint32_t)tid - off[k], cn = s_lq[2 * item[k] + 1];
             const uint64_t g = (uint64_t)s_lq[2 * item[k]] + ci, B = b.n_bytes;
+            my_gpos = (uint32_t)g;
             cap = (int)(cn - ci);
             maxlen = cn - ci < (uint32_t)SUB_LMAX ? (int)(cn - ci) : SUB_LMAX;
             if ((int64_t)g >= win_lo && (int64_t)g + 8 <= win_hi) {        // staged with the tile's window: no trip to HBM
@@ -2043,7 +2045,7 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
             const uint32_t h0 = hbits(tid);                  // the first boundary at or after the start ends the segment
             if (h0 & 0xFFu) {
                 const int len = __ffs((int)h0);
-                const uint32_t gpos = first_byte_of(tid);
+                const uint32_t gpos = my_gpos;                         // (= first_byte_of(tid), without the search for the row's chunk)
                 const uint32_t* const cells = slab + tid * SUB_W;      // node x of the segment: cells + x * SUB_W
                 uint32_t alive = (1u << len) - 1u;
                 for (;;) {                                   // bpe.rs:118-190 on at most 8 nodes in a bit mask
@@ -2082,7 +2084,7 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
                     const uint32_t qi = nl + (l3 <= 64u * XNPL ? 0u : atomicAdd(&ctl[5], 1u));
                     if (l3 <= 64u * XNPL) xseg[atomicAdd(&ctl[7], 1u)] = (uint32_t)tid | l3 << 16;   // a wavefront, several nodes per lane
                     else if (qi < (uint32_t)DIRECT_LQCAP) {  // longer still: a chunk of its own for the loops below
-                        s_lq[2 * qi] = first_byte_of(tid);
+                        s_lq[2 * qi] = my_gpos;
                         s_lq[2 * qi + 1] = l3;
                         atomicOr(&ctl[3], 1u << qi);         // (not to be packed again)
                     } else {                                 // no room: the whole chunk stays on the list
