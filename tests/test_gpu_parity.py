@@ -301,6 +301,25 @@ def test_text_that_ends_just_behind_the_window_end(coracle, name, geom):
         _force_tiles(name, 0)
 
 
+@pytest.mark.parametrize("name", ["cl100k_base", "o200k_base"])
+def test_every_grid_size_of_the_xcd_tile_map(coracle, name):
+    """Round 3: workgroup -> tile is a map that gives each of the eight XCDs a contiguous eighth of the tiles, in both
+    kernels of the tile-owned mode (`xcd_tile()`); it must be a bijection for ANY tile count.  Batches of 1..41 tiles and
+    around 8 x 156 tiles -- every residue of the count mod 8, tile counts below 8 (some XCDs get nothing) -- of the C3 mix
+    (English, JSON, CJK: tiles that take the tail and tiles that do not), cut at arbitrary byte counts."""
+    from splintr_amd import corpus
+    blob = "".join(corpus.c3(420, seed=77, doc_bytes=2600))
+    sizes = [800 * k - 137 for k in range(1, 42)] + [800 * k + 311 for k in range(1244, 1254)]
+    rng = random.Random(3)
+    for nb in sizes:
+        at = rng.randrange(0, 4000)
+        text = blob.encode("utf-8")[at:at + nb].decode("utf-8", "ignore")
+        # a few documents per batch, so that document starts fall into first, middle and last tiles
+        cuts = sorted(rng.sample(range(1, max(2, len(text))), min(3, max(0, len(text) - 1))))
+        docs = [text[a:b] for a, b in zip([0] + cuts, cuts + [len(text)])]
+        assert_batch_equal(name, docs, coracle)
+
+
 @pytest.mark.parametrize("name", VOCABS)
 def test_many_tiny_and_empty_documents(coracle, name):
     rng = random.Random(9)
