@@ -156,7 +156,11 @@ void spl_host_free(void* p);
  *                         d_doc_off[n_docs]==n_bytes
  *   d_ids[ids_capacity]   output ids; n_bytes entries always suffice
  *   d_out_off[n_docs+1]   output offsets; d_out_off[n_docs] is the total token count
- * Tokens beyond ids_capacity are dropped (compare d_out_off[n_docs] with the capacity). */
+ * Tokens beyond ids_capacity are dropped (compare d_out_off[n_docs] with the capacity).
+ * Size limits of ONE device call (SPL_EINVAL beyond them; spl_encode_batch on host buffers has none, it feeds
+ * chunks of at most 8 MiB): n_bytes <= 2047 MiB without SPL_WITH_SPECIAL, n_bytes <= 256 MB with it (the
+ * special-token scan of larger calls belongs to the multi-pass pipeline, which only -DSPL_MULTIPASS=1 builds
+ * carry).  Split a larger corpus at document boundaries. */
 int spl_encode_batch_device(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
                             uint64_t n_docs, uint32_t flags, uint32_t* d_ids, uint64_t ids_capacity,
                             uint64_t* d_out_off, void* hip_stream);
@@ -218,13 +222,15 @@ int spl_gatherv_unpack_group(spl_tokenizer* t, const uint32_t* d_slabs, uint32_t
  *   spl_allgather_slabs  ONE ncclAllGather of equal-sized u32 slabs (the padded, synchronisation-free form:
  *                        slabs from spl_gatherv_pack / spl_encode_batch_device_packed, results through
  *                        spl_gatherv_unpack[_group]); asynchronous on hip_stream
- *   spl_allgatherv_csr   the exact form: every rank's {T, N} first (16 bytes per rank, ONE host
- *                        synchronisation), then exactly T_r ids and N_r offsets per rank land at their place of
+ *   spl_allgatherv_csr   the exact form: every rank's {T, N} and the capacities of its result buffers first
+ *                        (32 bytes per rank, ONE host synchronisation), then exactly T_r ids and N_r offsets per rank land at their place of
  *                        the global CSR by grouped ncclSend / ncclRecv -- one message per peer and direction,
  *                        every xGMI link busy at once, nothing padded -- and the offsets are rebased on the
  *                        device.  d_all_ids[all_ids_cap], d_all_off[all_off_cap >= N_total + 1]; the totals are
- *                        returned; SPL_ECAPACITY (on every rank alike) if they do not fit.  Rank order ==
- *                        document order when rank r holds the r-th contiguous shard. */
+ *                        returned; SPL_ECAPACITY if they do not fit the SMALLEST buffers any rank passed -- decided
+ *                        from the gathered capacities, so every rank returns it alike and none is left waiting
+ *                        in the exchange.  Rank order == document order when rank r holds the r-th contiguous
+ *                        shard. */
 #define SPL_COMM_ID_BYTES 128
 typedef struct spl_comm spl_comm;
 int spl_comm_unique_id(uint8_t id_out[SPL_COMM_ID_BYTES]);

@@ -278,8 +278,8 @@ struct spl_tokenizer {
 struct spl_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1, device = 0;
-    uint64_t* d_cnt = nullptr;        // [2] this rank's {T, N}
-    uint64_t* d_cnts = nullptr;       // [2 * world] every rank's
+    uint64_t* d_cnt = nullptr;        // [4] this rank's {T, N, capacity of its all_ids, of its all_off}
+    uint64_t* d_cnts = nullptr;       // [4 * world] every rank's
     uint64_t* h_cnts = nullptr;       // pinned copy
 };
 
@@ -1234,9 +1234,9 @@ int comm_create(const uint8_t* id, int rank, int world, int device, spl_comm** o
     static_assert(sizeof uid.internal == SPL_COMM_ID_BYTES, "SPL_COMM_ID_BYTES must be RCCL's NCCL_UNIQUE_ID_BYTES");
     memcpy(uid.internal, id, SPL_COMM_ID_BYTES);
     NCCL_TRY(R.CommInitRank(&c->comm, world, uid, rank));
-    HIP_TRY(hipMalloc((void**)&c->d_cnt, 16));
-    HIP_TRY(hipMalloc((void**)&c->d_cnts, 16 * (size_t)world));
-    HIP_TRY(hipHostMalloc((void**)&c->h_cnts, 16 * (size_t)world, hipHostMallocPortable));
+    HIP_TRY(hipMalloc((void**)&c->d_cnt, 32));
+    HIP_TRY(hipMalloc((void**)&c->d_cnts, 32 * (size_t)world));
+    HIP_TRY(hipHostMalloc((void**)&c->h_cnts, 32 * (size_t)world, hipHostMallocPortable));
     *out = c.release();
     return SPL_OK;
 }
@@ -1247,36 +1247,42 @@ int allgatherv_csr(spl_comm* c, const uint32_t* d_ids, const uint64_t* d_out_off
     Rccl& R = rccl();
     HIP_TRY(hipSetDevice(c->device));
     const int W = c->world;
-    // (1) every rank's {T, N}: 16 bytes per rank, then the one host synchronisation of the exchange
-    hipLaunchKernelGGL(k_csr_counts, dim3(1), dim3(64), 0, s, d_out_off, n_docs, c->d_cnt);
-    NCCL_TRY(R.AllGather(c->d_cnt, c->d_cnts, 2, ncclUint64, c->comm, s));
-    HIP_TRY(hipMemcpyAsync(c->h_cnts, c->d_cnts, 16 * (size_t)W, hipMemcpyDeviceToHost, s));
+    // (1) every rank's {T, N} and the capacities of ITS result buffers: 32 bytes per rank, then the one host
+    // synchronisation of the exchange
+    hipLaunchKernelGGL(k_csr_counts, dim3(1), dim3(64), 0, s, d_out_off, n_docs, all_ids_cap, all_off_cap, c->d_cnt);
+    NCCL_TRY(R.AllGather(c->d_cnt, c->d_cnts, 4, ncclUint64, c->comm, s));
+    HIP_TRY(hipMemcpyAsync(c->h_cnts, c->d_cnts, 32 * (size_t)W, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     RankTable tab{};
+    uint64_t min_ids_cap = ~0ull, min_off_cap = ~0ull;
     for (int p = 0; p < W; p++) {
-        tab.t_pre[p + 1] = tab.t_pre[p] + c->h_cnts[2 * p];
-        tab.n_pre[p + 1] = tab.n_pre[p] + c->h_cnts[2 * p + 1];
+        tab.t_pre[p + 1] = tab.t_pre[p] + c->h_cnts[4 * p];
+        tab.n_pre[p + 1] = tab.n_pre[p] + c->h_cnts[4 * p + 1];
+        min_ids_cap = std::min(min_ids_cap, c->h_cnts[4 * p + 2]);
+        min_off_cap = std::min(min_off_cap, c->h_cnts[4 * p + 3]);
     }
     if (n_tokens_total) *n_tokens_total = tab.t_pre[W];
     if (n_docs_total) *n_docs_total = tab.n_pre[W];
-    // (every rank sees the same totals, so every rank takes the same branch: nobody is left waiting in a collective)
-    if (tab.t_pre[W] > all_ids_cap || tab.n_pre[W] + 1 > all_off_cap)
-        return fail(SPL_ECAPACITY, "spl_allgatherv_csr: the global CSR does not fit the buffers given (" + std::to_string(tab.t_pre[W]) +
-                                   " tokens, " + std::to_string(tab.n_pre[W]) + " documents)");
+    // Every rank sees the same totals AND the same (smallest) capacities, so every rank takes the same branch even when
+    // the ranks passed buffers of different sizes: nobody is left waiting in a collective its peer never entered.
+    if (tab.t_pre[W] > min_ids_cap || tab.n_pre[W] + 1 > min_off_cap)
+        return fail(SPL_ECAPACITY, "spl_allgatherv_csr: the global CSR does not fit the smallest buffers any rank gave (" +
+                                   std::to_string(tab.t_pre[W]) + " tokens, " + std::to_string(tab.n_pre[W]) + " documents; capacities " +
+                                   std::to_string(min_ids_cap) + " ids, " + std::to_string(min_off_cap) + " offsets)");
     // (2) exactly T_r ids and N_r offsets from every rank, each straight to its place: one message per peer and
     // direction, all links busy at once (xGMI is point to point; no ring, no padding)
-    const uint64_t T = c->h_cnts[2 * c->rank], N = c->h_cnts[2 * c->rank + 1];
+    const uint64_t T = c->h_cnts[4 * c->rank], N = c->h_cnts[4 * c->rank + 1];
     NCCL_TRY(R.GroupStart());
     for (int p = 0; p < W; p++) {
         if (T) NCCL_TRY(R.Send(d_ids, T, ncclUint32, p, c->comm, s));
         if (N) NCCL_TRY(R.Send(d_out_off, N, ncclUint64, p, c->comm, s));
-        const uint64_t Tp = c->h_cnts[2 * p], Np = c->h_cnts[2 * p + 1];
+        const uint64_t Tp = c->h_cnts[4 * p], Np = c->h_cnts[4 * p + 1];
         if (Tp) NCCL_TRY(R.Recv(d_all_ids + tab.t_pre[p], Tp, ncclUint32, p, c->comm, s));
         if (Np) NCCL_TRY(R.Recv(d_all_off + tab.n_pre[p], Np, ncclUint64, p, c->comm, s));
     }
     NCCL_TRY(R.GroupEnd());
     // (3) local offsets -> offsets in the global id array, and the closing entry
-    const uint64_t nmax = [&] { uint64_t m = 1; for (int p = 0; p < W; p++) m = std::max<uint64_t>(m, c->h_cnts[2 * p + 1]); return m; }();
+    const uint64_t nmax = [&] { uint64_t m = 1; for (int p = 0; p < W; p++) m = std::max<uint64_t>(m, c->h_cnts[4 * p + 1]); return m; }();
     hipLaunchKernelGGL(k_rebase_offsets, dim3((uint32_t)std::min<uint64_t>((nmax + 255) / 256, 1024), (uint32_t)W), dim3(256), 0, s,
                        d_all_off, tab, (uint32_t)W);
     HIP_TRY(hipGetLastError());

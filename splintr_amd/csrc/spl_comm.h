@@ -12,6 +12,7 @@
 // single-GPU user of the library needs no RCCL at all.
 #pragma once
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <rccl/rccl.h>
 
 #include <mutex>
@@ -34,13 +35,24 @@ struct Rccl {
 
     bool load() {
         if (lib) return true;
-        // an already loaded copy first (same SONAME: the loader hands back the one the process has)
+        err.clear();                                  // a failed attempt must not poison the next one
+        // an already loaded copy first (same SONAME: the loader hands back the one the process has).
+        // SPL_RCCL_LIB names ONE library to try instead (tests point it at a path that does not exist).
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char* n : names) {
-            lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-            if (lib) break;
+        const char* only = getenv("SPL_RCCL_LIB");
+        if (only && *only) {
+            lib = dlopen(only, RTLD_NOW | RTLD_GLOBAL);
+        } else {
+            for (const char* n : names) {
+                lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+                if (lib) break;
+            }
         }
-        if (!lib) { err = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return false; }
+        if (!lib) {
+            const char* e = dlerror();                // ONE call: dlerror() clears the message it returns
+            err = std::string("librccl not found: ") + (e ? e : "");
+            return false;
+        }
         auto sym = [&](const char* s) -> void* {
             void* p = dlsym(lib, s);
             if (!p && err.empty()) err = std::string("librccl lacks ") + s;

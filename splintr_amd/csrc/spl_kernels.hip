@@ -3984,8 +3984,8 @@ __global__ void k_gatherv_unpack(const uint32_t* slabs_all, uint32_t world, uint
 // ranks before (+ the closing entry).
 constexpr int COMM_MAX_WORLD = 64;
 struct RankTable { uint64_t n_pre[COMM_MAX_WORLD + 1], t_pre[COMM_MAX_WORLD + 1]; };
-__global__ void k_csr_counts(const uint64_t* out_off, uint64_t n_docs, uint64_t* cnt) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) { cnt[0] = out_off[n_docs]; cnt[1] = n_docs; }
+__global__ void k_csr_counts(const uint64_t* out_off, uint64_t n_docs, uint64_t ids_cap, uint64_t off_cap, uint64_t* cnt) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { cnt[0] = out_off[n_docs]; cnt[1] = n_docs; cnt[2] = ids_cap; cnt[3] = off_cap; }
 }
 __global__ void k_rebase_offsets(uint64_t* all_off, RankTable tab, uint32_t world) {
     const uint32_t r = blockIdx.y;

@@ -79,8 +79,11 @@ def plan_shards(docs: Sequence[bytes], world: int, split_docs: bool = True,
     """Cut a batch into `world` contiguous shards of about equal BYTES.  Returns, per rank, a list of
     pieces (doc index, lo, hi): whole documents, except that a shard boundary falling inside a large
     document is moved forward to the next newline that is followed by an ASCII letter or digit -- a
-    context-free match boundary of every supported split pattern (spl_scan.h is_sync rule
-    (d)), so the ids of the two pieces concatenate to the ids of the document.  This is what lets
+    context-free match boundary of the three BUILT-IN split patterns (cl100k, o200k / llama3 / deepseek_v3,
+    mistral_v3: SURVEY 8e; spl_scan.h is_sync rule (d)), so the ids of the two pieces concatenate to the ids of
+    the document.  It is NOT one for an arbitrary pattern (`[^\n]+\n*\p{L}+` matches across it): callers whose
+    tokenizer has a custom pattern pass split_docs=False (encode_batch_sharded does so by itself; the C host
+    path likewise, `may_cut`, spl_api.hip).  This is what lets
     100 equal 2 MiB documents (BASELINE config 5), or ONE huge document (the reference's
     encode_rayon case, src/core/tokenizer.rs:815-837), spread evenly over 8 GPUs."""
     n = len(docs)
@@ -127,7 +130,7 @@ def plan_shards(docs: Sequence[bytes], world: int, split_docs: bool = True,
 
 
 def encode_batch_sharded(encode_csr, texts: Sequence[str], device: torch.device, group=None, split_docs: bool = True,
-                         special_literals: Sequence[str] = ()):
+                         special_literals: Sequence[str] = (), context_free_cuts=None):
     """encode_batch over the process group (strong scaling of ONE batch): rank r encodes its
     byte-balanced shard -- whole documents and, at the shard's ends, pieces of documents cut at
     context-free boundaries (plan_shards) -- with `encode_csr(list[str]) -> (ids uint32 ndarray,
@@ -136,9 +139,18 @@ def encode_batch_sharded(encode_csr, texts: Sequence[str], device: torch.device,
 
     `special_literals`: when `encode_csr` encodes WITH special tokens, pass the literals of its map.  A cut
     sits directly behind a newline, so it can only fall inside a literal that contains one; if any does,
-    documents are not cut at all (what spl_encode_batch's host path does: `special_newline`, spl_api.hip)."""
+    documents are not cut at all (what spl_encode_batch's host path does: `special_newline`, spl_api.hip).
+
+    `context_free_cuts`: whether "behind a newline, in front of an ASCII letter or digit" is a match boundary of the
+    encoder's split pattern whatever surrounds it.  True for the three built-in patterns, unknown for a custom one
+    (src/core/tokenizer.rs:410-456 compiles any pattern), so False there: documents then stay whole.  None (default)
+    asks the encoder: a bound method of a `Tokenizer` (or any object with `has_custom_pattern`) answers for itself;
+    an opaque callable is taken to use a built-in pattern."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    if any("\n" in lit for lit in special_literals):
+    if context_free_cuts is None:
+        owner = getattr(encode_csr, "__self__", None)
+        context_free_cuts = not bool(getattr(owner, "has_custom_pattern", False))
+    if not context_free_cuts or any("\n" in lit for lit in special_literals):
         split_docs = False
     docs = [t.encode("utf-8") for t in texts]
     shards = plan_shards(docs, world, split_docs)

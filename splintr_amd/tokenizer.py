@@ -340,6 +340,13 @@ class Tokenizer:
     def clear_cache(self) -> None:
         return None
 
+    @property
+    def has_custom_pattern(self) -> bool:
+        """Extension: True when the split pattern is not one of the three the GPU scanner implements (its split then
+        runs on the host cores, and no context-free cut position is known for it: splintr_amd.distributed keeps
+        such a tokenizer's documents whole)."""
+        return self._pattern not in _PATTERN_ID
+
     def pcre2(self, use_pcre2: bool = True) -> "Tokenizer":
         """Backend switches (src/python/bindings.rs:207-242) select between regex engines that
         the reference's tests require to agree; here both map to the one scanner."""

@@ -79,3 +79,32 @@ def test_python_surface_argument_errors(built):
         _pack(["\ud800"])
     buf, off = _pack(["ab", "", "é"])
     assert buf == b"ab\xc3\xa9" and off.tolist() == [0, 2, 2, 4]
+
+
+def test_missing_librccl_is_an_error_code_not_a_crash(built):
+    """with librccl hidden the communicator entry points return SPL_EDEVICE with a message (the error
+    string used to be built from a second dlerror() call, which returns NULL: a segfault no guard catches), and a
+    failed load does not poison a later one.  Own process: the loader state is a process-wide static."""
+    import subprocess
+    import sys
+    code = r"""
+import ctypes, os, sys
+sys.path.insert(0, %r)
+os.environ["SPL_RCCL_LIB"] = "/nonexistent/librccl-hidden.so"
+from splintr_amd import _ffi
+L = _ffi.lib()
+buf = ctypes.create_string_buffer(128)
+rc = L.spl_comm_unique_id(buf)
+msg = L.spl_last_error().decode()
+assert rc == -2 and "librccl not found" in msg, (rc, msg)
+assert not L.spl_comm_create(buf, 0, 1, 0)
+assert "librccl not found" in L.spl_last_error().decode()
+# a second attempt starts from a clean slate: with the override gone the message must not be the stale one
+os.environ["SPL_RCCL_LIB"] = ""
+rc2 = L.spl_comm_unique_id(buf)
+msg2 = L.spl_last_error().decode() if rc2 else ""
+assert "librccl-hidden" not in msg2, msg2
+print("ok", rc2)
+""" % ROOT
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "ok" in p.stdout, (p.returncode, p.stdout[-500:], p.stderr[-1500:])

@@ -62,6 +62,60 @@ def test_sharded_encode_allgatherv_gloo(world):
     assert len({(n, t) for _, _, n, t in res}) == 1
 
 
+class _CustomEncoder:
+    """Stands in for a Tokenizer with a custom split pattern: the Python oracle with a pattern whose matches span
+    "newline + letter" -- the position plan_shards cuts at -- so that a cut inside a document changes the ids."""
+    has_custom_pattern = True
+    PATTERN = r"[^\n]+\n*\p{L}+|\s+|[^\s]+"
+
+    def __init__(self):
+        from oracle import pyoracle as O
+        enc, _ = O.load_splv(os.path.join(ROOT, "splintr_amd", "data", "cl100k_base.splv"))
+        self.orc = O.Oracle(enc, self.PATTERN, False, {}, "regex")
+
+    def encode_csr(self, local):
+        rows = [self.orc.encode(t) for t in local]
+        off = np.zeros(len(rows) + 1, dtype=np.uint64)
+        if rows:
+            np.cumsum([len(r) for r in rows], out=off[1:])
+        return np.asarray([i for r in rows for i in r], dtype=np.uint32), off
+
+
+def _custom_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from splintr_amd.distributed import encode_batch_sharded
+    e = _CustomEncoder()
+    # two large documents made of "line\nWord" joints: every cut candidate sits inside a match of the pattern
+    texts = ["ab cd;\nEf gh. " * 900, "", "x);\ny " * 1500, "tail"]
+    want = [e.orc.encode(t) for t in texts]
+    ids, off = encode_batch_sharded(e.encode_csr, texts, torch.device("cpu"))          # bound method: asks the encoder
+    got = [ids[int(off[i]):int(off[i + 1])].tolist() for i in range(len(texts))]
+    # and the same call told (wrongly) that the cuts are context-free does diverge: the guard is what keeps it equal
+    ids2, off2 = encode_batch_sharded(e.encode_csr, texts, torch.device("cpu"), context_free_cuts=True)
+    got2 = [ids2[int(off2[i]):int(off2[i + 1])].tolist() for i in range(len(texts))]
+    q.put((rank, got == want, got2 != want))
+    dist.destroy_process_group()
+
+
+def test_custom_pattern_documents_are_never_cut_gloo():
+    """a custom pattern has no known context-free cut; sharded == unsharded only with whole documents."""
+    pytest.importorskip("regex")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_custom_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=180) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res
+    assert all(div for _, _, div in res), "the test corpus no longer exercises the guard"
+
+
 class _Ev:
     def record(self, stream=None):
         pass

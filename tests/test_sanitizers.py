@@ -56,7 +56,17 @@ def test_product_host_code_under_sanitizers(corpus_file, kind, flags):
     csrc = os.path.join(ROOT, "splintr_amd", "csrc")
     srcs = [os.path.join(SAN, "host_san.cpp"), os.path.join(csrc, "spl_tables.cpp"), os.path.join(csrc, "spl_regex.cpp")]
     deps = srcs + [os.path.join(csrc, h) for h in ("spl_regex.h", "spl_tables.h", "spl_common.h")]
-    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
+    # staleness by content, not by modification time (arbitrary after a checkout or a snapshot copy)
+    import hashlib
+    h = hashlib.sha256(" ".join(flags).encode())
+    for d in deps:
+        with open(d, "rb") as f:
+            h.update(f.read())
+    stamp, want = exe + ".srchash", h.hexdigest()
+    have = open(stamp).read().strip() if os.path.exists(stamp) else ""
+    if not os.path.exists(exe) or have != want:
         subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fno-omit-frame-pointer"] + flags + ["-o", exe] + srcs)
+        with open(stamp, "w") as f:
+            f.write(want + "\n")
     out = _run(exe, corpus_file, {"ASAN_OPTIONS": "detect_leaks=1"})
     assert out.count("pattern ok") == 2 and "unsalted groups 0" in out

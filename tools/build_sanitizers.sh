@@ -5,9 +5,14 @@ set -e
 cd "$(dirname "$0")/.."
 B=tests/san/_build; mkdir -p $B
 C=splintr_amd/csrc
-if [ ! -f $B/libsplintr_hip_tsan.so ] || [ -n "$(find $C include -newer $B/libsplintr_hip_tsan.so -type f | head -1)" ]; then
+# staleness by CONTENT (a modification time proves nothing about a file that travelled or was checked out)
+H=$(cat $C/* include/splintr_hip.h tests/san/hostpath_driver.cpp | sha256sum | cut -d' ' -f1)
+if [ ! -f $B/libsplintr_hip_tsan.so ] || [ "$(cat $B/tsan.srchash 2>/dev/null)" != "$H" ]; then
+  # a failed build fails the script (and with it the test): no filter that could swallow the compiler's exit code
   hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -Wno-unused-value -Xarch_host -fsanitize=thread \
-        -o $B/libsplintr_hip_tsan.so $C/spl_api.hip $C/spl_tables.cpp $C/spl_regex.cpp 2>&1 | grep -E " error" || true
+        -o $B/libsplintr_hip_tsan.so $C/spl_api.hip $C/spl_tables.cpp $C/spl_regex.cpp > $B/tsan_build.log 2>&1 \
+        || { tail -40 $B/tsan_build.log; exit 1; }
+  echo "$H" > $B/tsan.srchash
 fi
 hipcc -O1 -g -std=c++17 -fsanitize=thread -x c++ tests/san/hostpath_driver.cpp -o $B/hostpath_tsan -L$B -lsplintr_hip_tsan -Wl,-rpath,'$ORIGIN' -pthread
 ls -la $B
