@@ -48,6 +48,7 @@ C4_PART_DOCS = 125_000
 
 
 C5_DOCS = 100           # BASELINE config 5: 100 documents of 2 MiB (seed 1005 + document index)
+C5_DOC_BYTES = 2 << 20
 
 
 def _c4_part(k):
@@ -57,7 +58,7 @@ def _c4_part(k):
 
 def _c5_doc(k):
     from splintr_amd import corpus
-    return corpus.c5(1, seed=1005 + k)[0]
+    return corpus.c5(1, seed=1005 + k, doc_bytes=C5_DOC_BYTES)[0]
 
 
 def _free_port():
@@ -123,7 +124,14 @@ def main():
     ap.add_argument("--no-c5", action="store_true", help="skip the 100 x 2 MiB run (BASELINE config 5)")
     ap.add_argument("--c5-steps", type=int, default=5)
     ap.add_argument("--launch-selftest", action="store_true", help=argparse.SUPPRESS)
+    # rehearsal sizes (tests/test_gpu_dist.py runs the distributed branches at world 1 with small shards; the line then
+    # carries "rehearsal": true -- the BASELINE configurations are the defaults)
+    ap.add_argument("--c4-part-docs", type=int, default=C4_PART_DOCS, help=argparse.SUPPRESS)
+    ap.add_argument("--c5-docs", type=int, default=C5_DOCS, help=argparse.SUPPRESS)
+    ap.add_argument("--c5-doc-bytes", type=int, default=C5_DOC_BYTES, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    rehearsal = (args.c4_part_docs, args.c5_docs, args.c5_doc_bytes) != (C4_PART_DOCS, C5_DOCS, C5_DOC_BYTES)
+    globals().update(C4_PART_DOCS=args.c4_part_docs, C5_DOCS=args.c5_docs, C5_DOC_BYTES=args.c5_doc_bytes)   # (forked generators read them)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -241,6 +249,7 @@ def main():
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     my_bytes = sum(batches[(i0 + j) % N_ROT].n_bytes for j in range(args.steps))
     if use_dist:
         et = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -253,6 +262,44 @@ def main():
         total_bytes = my_bytes
     ms_per_step = elapsed / args.steps * 1e3
     value = total_bytes / elapsed / 1e6
+
+    # ---- distributed runs: what a rank's step is made of (untimed repeats of the same steps) -------------
+    # encode_only_ms: the same steps without the exchange; exchange_stream_ms: what the exchange stream spent in the
+    # collective + unpack, per step; exposed = step - encode-only.  Per rank, so that a first N-GPU curve says whether a
+    # rank is encode-bound, link-bound, or waiting for a slower peer.
+    dist_info = None
+    if use_dist:
+        local_ms = elapsed_local / args.steps * 1e3
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0 = time.perf_counter()
+        for j in range(args.steps):
+            encode_device(tok, batches[(i0 + j) % N_ROT])
+        torch.cuda.synchronize()
+        enc_ms = (time.perf_counter() - e0) / args.steps * 1e3
+        dist.barrier()
+        gv.enable_timing()
+        for _ in range(args.steps):
+            step()
+        gv.finish()
+        ex_total, ex_buckets = gv.exchange_ms()
+        gv.enable_timing(False)
+        mine = torch.tensor([local_ms, enc_ms, ex_total / args.steps], dtype=torch.float64, device=dev)
+        allm = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allm, mine)
+        allm = torch.stack(allm).cpu().numpy()
+        sent, recvd = gv.bytes_per_bucket()
+        tok_b = sum(n_tokens) / N_ROT
+        dist_info = {"rccl_ranks": comm.ranks(), "torch_world": world,
+                     "per_rank": {"step_ms": [round(float(x), 5) for x in allm[:, 0]],
+                                  "encode_only_ms": [round(float(x), 5) for x in allm[:, 1]],
+                                  "exchange_stream_ms_per_step": [round(float(x), 5) for x in allm[:, 2]]},
+                     "exposed_exchange_ms": round(float(allm[:, 0].max() - allm[:, 1].max()), 5),
+                     "bucket_depth": gv.depth, "buckets_timed": ex_buckets,
+                     "slab_bytes_sent_per_batch": sent // gv.depth, "bytes_received_per_batch": recvd // gv.depth,
+                     "ids_bytes_per_batch_4T": round(4 * tok_b), "slab_over_4T": round(sent / gv.depth / (4 * tok_b), 4),
+                     "note": "per batch and rank: one slab of cap_words u32 (T, N, local offsets, ids; sized 1.02 x the largest shard) out, "
+                             "world slabs in; ONE all-gather per bucket of `bucket_depth` batches on its own stream"}
 
     # ---- supplementary: the same steps with several batches in flight --------------------------------
     pipelined = None
@@ -434,8 +481,10 @@ def main():
                        "parallelism": f"doc-shard x{world}"},
             "parity": "bit-exact vs oracle (untimed verification pass over every batch of the rotation)",
             "roofline": roofline, "roofline_valu": roofline_valu, "throughputs": throughputs, "c4_strong": c4, "c5_strong": c5,
-            "cpu_baseline": cpu, "pipelined": pipelined,
+            "cpu_baseline": cpu, "pipelined": pipelined, "dist": dist_info,
         }
+        if rehearsal:
+            out["rehearsal"] = True
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -571,13 +620,40 @@ def run_strong(vocab, texts, steps, rank, world, local_rank, dev, use_dist, nchk
         dist.barrier()
     el = time.perf_counter() - t0
     tot_b, tot_d, tot_t = batch.n_bytes, batch.n_docs, n_tok
+    dist_info = None
     if use_dist:
+        local_ms = el / steps * 1e3
+        # untimed repeats: the encode alone, and the exchange alone (events around spl_allgatherv_csr on its stream)
+        e0 = time.perf_counter()
+        for _ in range(steps):
+            encode_device(tok, batch)
+        torch.cuda.synchronize()
+        enc_ms = (time.perf_counter() - e0) / steps * 1e3
+        dist.barrier()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for a, b_ in ev:
+            a.record()
+            comm.allgatherv_csr(batch.ids, batch.out_off, batch.n_docs, all_ids, all_off)
+            b_.record()
+        torch.cuda.synchronize()
+        ex_ms = sum(a.elapsed_time(b_) for a, b_ in ev) / steps
+        mine = torch.tensor([local_ms, enc_ms, ex_ms], dtype=torch.float64, device=dev)
+        allm = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allm, mine)
+        allm = torch.stack(allm).cpu().numpy()
         v = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(v, op=dist.ReduceOp.MAX)
         el = float(v.item())
         s = torch.tensor([batch.n_bytes, batch.n_docs, n_tok], dtype=torch.int64, device=dev)
         dist.all_reduce(s)
         tot_b, tot_d, tot_t = (int(x) for x in s.tolist())
+        dist_info = {"rccl_ranks": comm.ranks(), "torch_world": world,
+                     "per_rank": {"step_ms": [round(float(x), 4) for x in allm[:, 0]],
+                                  "encode_only_ms": [round(float(x), 4) for x in allm[:, 1]],
+                                  "exchange_ms": [round(float(x), 4) for x in allm[:, 2]]},
+                     "exposed_exchange_ms": round(float(allm[:, 0].max() - allm[:, 1].max()), 4),
+                     "bytes_received_per_rank": 4 * tot_t + 8 * tot_d + 32 * world,
+                     "note": "spl_allgatherv_csr: 32 B of counts per rank, then exactly 4 T_r + 8 N_r bytes from every rank (nothing padded)"}
     del batch, tok, comm, all_ids, all_off
     torch.cuda.empty_cache()
     if rank != 0:
@@ -585,7 +661,7 @@ def run_strong(vocab, texts, steps, rank, world, local_rank, dev, use_dist, nchk
     return {"workload": workload.format(docs=tot_d, bytes=tot_b, tokens=tot_t, world=world)
                         + ("; RCCL all-gatherv of the ragged result inside the step (spl_allgatherv_csr: counts, then exactly T_r ids and N_r offsets per rank by grouped send/recv)" if use_dist else ""),
             "value": round(tot_b * steps / el / 1e6, 1), "unit": "MB/s", "ms_per_step": round(el / steps * 1e3, 3),
-            "steps": steps, "scaling": "strong", "parity": parity}
+            "steps": steps, "scaling": "strong", "parity": parity, "dist": dist_info}
 
 
 if __name__ == "__main__":

@@ -30,6 +30,7 @@
 #include "spl_scan.h"
 #include "spl_scan_masks.h"
 #include "spl_scan_starts.h"
+#include "spl_scan_words.h"
 
 #define SPL_DBG_WG (b.dbg_wg == 0xFFFFFFFFu ? gridDim.x / 2 : b.dbg_wg)
 
@@ -421,6 +422,33 @@ __device__ __forceinline__ uint32_t wave_scan_max(uint32_t x) {
     x = mx(x, __builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false));
     x = mx(x, __builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false));
     return x;
+}
+
+// 8 x 8 NIBBLE transpose across each group of 8 neighbouring lanes (spl_scan_words.h): in, nibble j of lane l; out,
+// nibble l of lane j.  Three butterfly stages (lane ^ 4 / ^ 2 / ^ 1 with 16 / 8 / 4 bits): the partner's word by DPP, rotated
+// so that the nibbles to take line up (v_alignbit), merged under a per-lane mask (v_bfi).  All 64 lanes must be active.
+__device__ __forceinline__ uint32_t nib_transpose8(uint32_t v) {
+    const uint32_t l = threadIdx.x & 7u;
+    {   // stride 4: lanes with bit 2 clear keep nibbles 0-3 and take the partner's 0-3 as their 4-7; the others the mirror image
+        uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xF, 0x5, false);     // row_shl:4 -> banks 0, 2 (lane + 4)
+        t = (uint32_t)__builtin_amdgcn_update_dpp((int)t, (int)v, 0x114, 0xF, 0xA, false);               // row_shr:4 -> banks 1, 3 (lane - 4)
+        const uint32_t km = (l & 4u) ? 0xFFFF0000u : 0x0000FFFFu;
+        const uint32_t y = __builtin_amdgcn_alignbit(t, t, 16);
+        v = (v & km) | (y & ~km);
+    }
+    {   // stride 2
+        const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+        const uint32_t km = (l & 2u) ? 0xFF00FF00u : 0x00FF00FFu;
+        const uint32_t y = __builtin_amdgcn_alignbit(t, t, (l & 2u) ? 8u : 24u);
+        v = (v & km) | (y & ~km);
+    }
+    {   // stride 1
+        const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+        const uint32_t km = (l & 1u) ? 0xF0F0F0F0u : 0x0F0F0F0Fu;
+        const uint32_t y = __builtin_amdgcn_alignbit(t, t, (l & 1u) ? 4u : 28u);
+        v = (v & km) | (y & ~km);
+    }
+    return v;
 }
 
 // Alive bitmaps are arrays of 32-bit words (64-bit shifts and bit scans are multi-instruction
@@ -2206,6 +2234,8 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
     static_assert(!DIRECT || (Wv + 2) / 2 >= SG_WORDS, "bpe_tail_segments' scratch must fit s_cpos");
     __shared__ __attribute__((aligned(16))) uint16_t s_cpos[Wv + 2];   // (the single-pass tail borrows it: bpe_tail_segments)
     __shared__ uint8_t s_ascii[128];
+    __shared__ __attribute__((aligned(8))) KindEnt s_aent[128];   // ASCII byte -> kind nibbles | class (spl_scan_words.h)
+    __shared__ __attribute__((aligned(8))) KindEnt s_kent[16];    // class -> kind nibbles
     __shared__ uint32_t s_wsum[NT / 64];
     __shared__ uint32_t s_total;
     __shared__ uint32_t s_nch;                           // chunks on the probe list (small windows)
@@ -2293,6 +2323,12 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
     if (SPL_LATE_KERNARGS) asm volatile("" : "+s"(ka) : : "memory");
     const DeviceTables& T = SPL_LATE_KERNARGS ? *(const DeviceTables*)&ka->T : T_ka;
     const Batch& b = SPL_LATE_KERNARGS ? *(const Batch*)&ka->b : b_ka;
+#ifndef SPL_KERNARG_PREFETCH
+#define SPL_KERNARG_PREFETCH 0   /* (A/B) 1: one lane per 64-byte line of the argument segment touches it with a vector load right behind the text loads */
+#endif
+    uint32_t ka_pf = 0;
+    if (SPL_KERNARG_PREFETCH && tid < (int)((sizeof(PretokKernargs) + 63) / 64))
+        ka_pf = *reinterpret_cast<const volatile uint32_t*>((uintptr_t)ka + 64u * (uint32_t)tid);
 #ifdef SPL_DEBUG_STAMPS
     if (e_dbg && tid == 0 && blockIdx.x == SPL_DBG_WG) e_dbg[11] = (unsigned long long)wall_clock64();
     if (e_dbg && tid == 0 && blockIdx.x == gridDim.x - 1) e_dbg[13] = (unsigned long long)wall_clock64();
@@ -2313,7 +2349,11 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
         s_kill[tid] = 0; s_add[tid] = 0;
         s_tbits[tid] = 0;
     }
-    if (tid < 128) s_ascii[tid] = e_ascii[tid];
+    if (tid < 128) {
+        const uint32_t cls = e_ascii[tid];
+        s_ascii[tid] = (uint8_t)cls;
+        s_aent[tid] = ascii_entry(KPAT, (uint32_t)tid, cls);        // (spl_scan_words.h: kind nibbles + record of an ASCII byte)
+    } else if (tid < 144) s_kent[tid - 128] = kind_entry((uint32_t)tid - 128u);
     if (tid < 4) s_nq[tid] = 0;
     if (tid < 17) s_scnt[tid] = 0;                    // (the counting sort of the merge phase: zeroed here, one barrier less there)
     if (tid < 12) s_dq[tid] = 0;
@@ -2380,6 +2420,7 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
     }
     SPL_STAMP(0);
     __syncthreads();
+    if (SPL_KERNARG_PREFETCH) asm volatile("" : : "v"(ka_pf));
     SPL_STAMP(1);
 
     const int iB = (B - w0 < (int64_t)Wv) ? (int)(B - w0) : Wv;   // first index past the text
@@ -2439,102 +2480,58 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
         SPL_STAMP(2);
         __syncthreads();
     } else {
-    // ---- classify: one record per byte, one word per lane -----------------------------------------
-    // (records past the window are all "window end": written directly, so that no wavefront runs a
-    //  second pass of the loop body for the WPAD / 4 extra words)
+    // ---- classify + class bitmasks in ONE pass, four bytes per lane (spl_scan_words.h) -------------------
+    // Each lane turns its word into the four class records and into two words of kind NIBBLES (bit k of nibble j: byte k is
+    // of kind j); ASCII words -- nearly all of English / code -- through a 128-entry LDS table.  Eight neighbouring lanes
+    // then transpose their nibbles (three DPP exchanges per word) and lane 8w + j holds mask word w of kind j.  Up to round
+    // 3 this was two steps with a barrier between them -- records first, then one byte per lane and a dozen ballots per
+    // 64-byte row -- and a fifth of the kernel's vector instructions (profiles/r04_phase_instruction_mix.txt).
+    // (records past the window are all "window end": written directly)
     for (int wi = Wv / 4 + tid; wi < G::NW32; wi += NT) s_rec32[wi] = (uint32_t)C_WEND * 0x01010101u;
-    for (int wi = tid; wi < Wv / 4; wi += NT) {
-        const int i0 = wi * 4;
-        const uint32_t tw = s_txt32[wi];
-        const uint32_t ts4 = i0 < Wv ? (s_ts[i0 >> 5] >> (i0 & 31)) & 0xFu : 0u;
-        const uint32_t sk4 = i0 < Wv ? (s_sk[i0 >> 5] >> (i0 & 31)) & 0xFu : 0u;
-        // A word with a byte beyond ASCII: the neighbouring words and the text-start bits of [i0 - 4, i0 + 12)
-        // go into registers once, so that the look-back / look-ahead of byte_record (at most 3 bytes either
-        // way, plus the decode) costs no LDS round trips per byte.
-        struct RegWin {
-            uint32_t wp, tw, wn; int base;               // bytes [base, base + 12), base = i0 - 4
-            __device__ __forceinline__ uint32_t txt(int j) const {
-                const int d = j - base;
-                const uint32_t w = d < 4 ? wp : d < 8 ? tw : wn;
-                return (w >> (8 * (d & 3))) & 0xFFu;
-            }
-        };
-        RegWin rw{0u, tw, 0u, i0 - 4};
-        uint32_t ts16 = 0;
-        if (tw & 0x80808080u) {
-            rw.wp = wi > 0 ? s_txt32[wi - 1] : 0u;
-            rw.wn = s_txt32[wi + 1];
-            const int b0 = i0 - 4;                        // (a multiple of 4; negative only for the first word)
-            if (b0 < 0) ts16 = s_ts[0] << 4;
-            else {
-                const int sh = b0 & 31;
-                ts16 = s_ts[b0 >> 5] >> sh;
-                if (sh > 16) ts16 |= s_ts[(b0 >> 5) + 1] << (32 - sh);
-            }
-        }
-        uint32_t out = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int i = i0 + k;
-            uint32_t r;
-            if (i >= iB) {
-                r = (i == iB && iB < Wv) ? (uint32_t)(C_EOT | CB_TSTART | CB_SYNC) : (uint32_t)C_WEND;
-            } else if (w0 + i < 0) {
-                r = C_CONT;
-            } else if ((sk4 >> k) & 1u) {
-                r = C_EOT | CB_TSTART;                 // inside a special literal: no text here
+    if (tid < MK_COUNT) s_mk[tid * NBW1 + G::NBW - 1] = 0;   // the word of position W (never a real byte)
+    if (tid < MK_COUNT) s_mk[tid * NBW1 + G::NBW] = 0;
+    for (int wbase = 0; wbase < Wv / 4; wbase += NT) {       // (uniform trip count: every lane takes part in the exchanges)
+        const int wi = wbase + tid;
+        WordKinds wk{0u, 0u, 0u};
+        if (wi < Wv / 4) {
+            const int i0 = wi * 4;
+            const uint32_t tw = s_txt32[wi];
+            const uint32_t ts4 = (s_ts[i0 >> 5] >> (i0 & 31)) & 0xFu;
+            const uint32_t sk4 = (s_sk[i0 >> 5] >> (i0 & 31)) & 0xFu;
+            if (!(tw & 0x80808080u) && sk4 == 0u && i0 + 3 < iB && w0 + i0 >= 0) {
+                const KindEnt e[4] = {s_aent[tw & 0xFFu], s_aent[(tw >> 8) & 0xFFu], s_aent[(tw >> 16) & 0xFFu], s_aent[tw >> 24]};
+                wk = classify_word_ascii(e, ts4);
             } else {
-                const uint32_t c0 = (tw >> (8 * k)) & 0xFFu;
-                if (c0 < 0x80u) r = s_ascii[c0];
-                else {      // (bytes before window index 0 do not exist for the look-back: that only concerns the
-                            //  first bytes of the left halo, whose records nothing in the tile depends on)
-                    r = byte_record(T, rw, [&](int j) { return ((ts16 >> (j - (i0 - 4))) & 1u) != 0; },
-                                    [](uint32_t) { return 0u; }, i, w0 < 0 ? (int)-w0 : 0, iT);
+                // A word with a byte beyond ASCII (or at an edge of the text): the neighbouring words and the text-start bits
+                // of [i0 - 4, i0 + 12) go into registers once; the look-back / look-ahead (at most 3 bytes either way, plus
+                // the decode) is arithmetic on them.  (Bytes before window index 0 do not exist for the look-back: that
+                // only concerns the first bytes of the left halo, whose records nothing in the tile depends on.)
+                uint32_t ts16;
+                const int b0 = i0 - 4;                        // (a multiple of 4; negative only for the first word)
+                if (b0 < 0) ts16 = s_ts[0] << 4;
+                else {
+                    const int sh = b0 & 31;
+                    ts16 = s_ts[b0 >> 5] >> sh;
+                    if (sh > 16) ts16 |= s_ts[(b0 >> 5) + 1] << (32 - sh);
                 }
-                if ((ts4 >> k) & 1u) r |= CB_TSTART | CB_SYNC;
+                wk = classify_word(T, KPAT, wi > 0 ? s_txt32[wi - 1] : 0u, tw, s_txt32[wi + 1], ts16,
+                                   [&](uint32_t c) { return s_kent[c]; }, [&](uint32_t c) { return (uint32_t)s_ascii[c]; },
+                                   ts4, sk4, i0, iB, Wv, w0 < 0 ? (int)-w0 : 0, iT);
             }
-            out |= r << (8 * k);
+            s_rec32[wi] = wk.rec;
         }
-        s_rec32[wi] = out;
+        const uint32_t t0k = nib_transpose8(wk.v0), t1k = nib_transpose8(wk.v1);
+        const uint32_t g8 = (uint32_t)tid & 7u;
+        if (wi < Wv / 4) {
+            s_mk[((V0_KINDS >> (4u * g8)) & 15u) * NBW1 + (wi >> 3)] = t0k;
+            if (g8 < (uint32_t)V1_NKINDS) s_mk[((V1_KINDS >> (4u * g8)) & 15u) * NBW1 + (wi >> 3)] = t1k;
+        }
     }
     __syncthreads();
     SPL_STAMP(2);
-
-    // ---- class bitmasks: one ballot per kind and 64-byte row; continuation bytes inherit their lead --
-    for (int row = tid >> 6; row < Wv / 64; row += NT / 64) {
-        const int lane = tid & 63;
-        const int i = row * 64 + lane;
-        const uint32_t r = s_rec[i];
-        const uint32_t cls = r & CB_CLASS;
-        uint32_t kc = cls;
-        if (cls == C_CONT) {
-            int j = i - 1;
-            while (j >= 0 && (s_rec[j] & CB_CLASS) == C_CONT && j > i - 3) j--;
-            kc = j >= 0 ? (s_rec[j] & CB_CLASS) : (uint32_t)C_CONT;
-        }
-        // one compare per kind: the class as a one-hot word against the kind's set of classes
-        const uint32_t oh = kc < C_EOT ? 1u << kc : 0u;
-        const bool bad = bad_for_starts(KPAT, r, kc, i < iB);            // keeps the window off the bit-vector start computation
-        const bool slash = KPAT == PAT_MISTRAL_V3 && s_txt[i] == '/';    // (only mistral's [\r\n/]* asks)
-        // lane 2k / 2k + 1 of `v` receive the two halves of kind k's ballot (v_writelane: one instruction per
-        // half; a select chain over all kinds cost three per kind); kinds the pattern never asks for stay zero
-        int v = 0;
-#pragma unroll
-        for (int k = 0; k < MK_SY; k++) {
-            if ((k == MK_M || k == MK_UP || k == MK_LB) && KPAT == PAT_CL100K) continue;
-            if (k == MK_SL && KPAT != PAT_MISTRAL_V3) continue;
-            const unsigned long long bk = k == MK_CS ? __ballot(cls < C_EOT) : k == MK_TS ? __ballot((r & CB_TSTART) != 0)
-                                        : k == MK_BAD ? __ballot(bad) : k == MK_SL ? __ballot(slash)
-                                        : __ballot((oh & kind_classes(k)) != 0u);
-            v = write_lane(v, (uint32_t)bk, 2 * k);
-            v = write_lane(v, (uint32_t)(bk >> 32), 2 * k + 1);
-        }
-        if (lane < 2 * MK_SY) s_mk[(lane >> 1) * NBW1 + row * 2 + (lane & 1)] = (uint32_t)v;
-    }
-    if (tid < MK_COUNT) s_mk[tid * NBW1 + G::NBW - 1] = 0;   // the word of position W (never a real byte)
-    if (tid < MK_COUNT) s_mk[tid * NBW1 + G::NBW] = 0;
-    __syncthreads();
-    // ---- sync-point mask: word operations on the kind masks (same rules as is_sync) -------------
+    if (!DIRECT) {
+    // ---- sync-point mask: word operations on the kind masks (same rules as is_sync).  Tile-owned and queue mode:
+    //      the wavefronts that compute the starts below make it themselves, one barrier less -----------------------
     if (tid < G::NBW) {
         uint32_t kw[MK_COUNT], kp[MK_COUNT];
 #pragma unroll
@@ -2545,6 +2542,7 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
         s_mk[MK_SY * NBW1 + tid] = sync_word(KPAT, kw, kp);
     }
     __syncthreads();
+    }
     // ---- ALL match starts of the tile by bit-vector arithmetic (spl_scan_starts.h), every pattern ------
     // One mask word per lane.  The tile owns [fs, fe): fs = its first sync point, fe = the
     // first sync point or text start at or behind the tile's end.  Needs fe inside the window and no
@@ -2558,7 +2556,22 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
         {
             const bool in = ln < G::NBW;
             auto ld = [&](int k) { return in ? s_mk[k * NBW1 + ln] : 0u; };
-            const uint32_t sy = ld(MK_SY), ts = ld(MK_TS);
+            // the sync-point mask of this lane's word, from the kind words and their left neighbours' top bits
+            const uint32_t ts = ld(MK_TS);
+            uint32_t sy;
+            {
+                uint32_t kw[MK_COUNT], kp[MK_COUNT];
+#pragma unroll
+                for (int k = 0; k < MK_COUNT; k++) {
+                    const bool used = k == MK_L || k == MK_N || k == MK_S || k == MK_NL || k == MK_O || k == MK_CS || k == MK_TS ||
+                                      (KPAT != PAT_CL100K && (k == MK_M || k == MK_AP));
+                    const bool shifted = k == MK_L || k == MK_N || k == MK_NL || k == MK_O || (KPAT != PAT_CL100K && k == MK_M);
+                    kw[k] = used ? ld(k) : 0u;
+                    kp[k] = shifted ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)kw[k], 0x138, 0xF, 0xF, true) : 0u;   // wave_shr:1: lane - 1's word
+                }
+                sy = sync_word(KPAT, kw, kp);
+                if (part == 0 && in) s_mk[MK_SY * NBW1 + ln] = sy;      // (the chains of a tile that does not qualify read it)
+            }
             auto range_word = [&](int from, int to) -> uint32_t {             // bits [from, to) of this lane's word
                 const int lo = from - ln * 32, hi = to - ln * 32;
                 if (hi <= 0 || lo >= 32) return 0u;

@@ -99,6 +99,11 @@ class Comm:
             raise RuntimeError(f"spl_allgatherv_csr failed ({rc}): {_ffi.last_error()}")
         return int(nt.value), int(nd.value)
 
+    def ranks(self) -> int:
+        """spl_comm_world: the number of ranks of the RCCL communicator the LIBRARY holds (what a scaling run checks
+        against torch's world size)."""
+        return int(_ffi.lib().spl_comm_world(self._h))
+
     def close(self) -> None:
         if getattr(self, "_h", None):
             _ffi.lib().spl_comm_destroy(self._h)
@@ -159,6 +164,7 @@ class GatherV:
         self.cur, self.fill = 0, 0
         self.last = None                                          # (set, batches) of the last exchanged bucket
         self.on_bucket = None
+        self._timing = None                                       # enable_timing(): [(start, end)] events per exchanged bucket
 
     # (overridable: the CPU test drives the bucket / event logic with a stub encoder on gloo)
     def _new_stream(self):
@@ -172,6 +178,27 @@ class GatherV:
 
     def _stream_ctx(self, st):
         return torch.cuda.stream(st)
+
+    def enable_timing(self, on: bool = True) -> None:
+        """Diagnostics for a scaling run: bracket every bucket's exchange (collective + unpack) with events on the
+        exchange stream.  `exchange_ms()` then gives the time that stream spent in them -- beside the step time with
+        and without the exchange that tells whether a rank is encode-bound or link-bound."""
+        self._timing = [] if on else None
+
+    def exchange_ms(self):
+        """(total milliseconds, buckets) of the exchanges recorded since enable_timing(); synchronises."""
+        if not self._timing:
+            return 0.0, 0
+        torch.cuda.synchronize(self.dev)
+        total = sum(a.elapsed_time(b) for a, b in self._timing)
+        n = len(self._timing)
+        self._timing = []
+        return float(total), n
+
+    def bytes_per_bucket(self):
+        """(bytes every rank SENDS per full bucket, bytes it RECEIVES): depth slabs of cap_words words out, world x that in."""
+        sent = self.depth * self.cap_words * 4
+        return sent, sent * self.world
 
     def _open_slab(self) -> torch.Tensor:
         main = self._main_stream()
@@ -243,8 +270,14 @@ class GatherV:
         self.packed[s].record(main)
         with self._stream_ctx(self.exch):
             self.exch.wait_event(self.packed[s])
+            if self._timing is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record(self.exch)
             self._allgather(s)
             self._unpack(s, n, self.exch.cuda_stream)
+            if self._timing is not None:
+                ev[1].record(self.exch)
+                self._timing.append(ev)
             if self.on_bucket is not None:
                 self.on_bucket([self._views(s, j) for j in range(n)])
             self.drained[s].record(self.exch)

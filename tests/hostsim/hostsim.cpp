@@ -5,6 +5,7 @@
 // sync-point rules, the table formats and the lane-serial merge loop can be checked against the
 // oracle on a machine without a GPU.  The kernels run the very same inline functions.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <string>
@@ -318,6 +319,7 @@ extern "C" int hs_split_masks(void* p, const uint8_t* text, int n, uint32_t* sta
 // sync point, end sync point inside the window, loops converged) takes its starts from the masks;
 // any other tile runs the chains over the whole text.  stats: [0] tiles, [1] tiles on the fast path.
 #include "../../splintr_amd/csrc/spl_scan_starts.h"
+#include "../../splintr_amd/csrc/spl_scan_words.h"
 
 struct HostBV {
     std::vector<uint32_t> w;
@@ -386,6 +388,60 @@ extern "C" int hs_split_starts(void* p, const uint8_t* text, int n, const int* d
             uint32_t kw[MK_COUNT], kp[MK_COUNT];
             for (int k = 0; k < MK_COUNT; k++) { kw[k] = m.mk[k][w]; kp[k] = w ? m.mk[k][w - 1] : 0u; }
             m.mk[MK_SY][w] = sync_word(s->ht.pattern, kw, kp);
+        }
+        // ---- the one-pass word classifier of the kernel (spl_scan_words.h) must give these very masks and records ----
+        {
+            KindEnt aent[128], kent[16];
+            for (uint32_t c = 0; c < 128; c++) aent[c] = ascii_entry(pat, c, cp_class(s->dt, c));
+            for (uint32_t c = 0; c < 16; c++) kent[c] = kind_entry(c);
+            std::vector<uint32_t> nm[MK_COUNT];
+            for (int k = 0; k < MK_COUNT; k++) nm[k].assign(nw, 0);
+            const int lo = w0 < 0 ? -w0 : 0;
+            const int iT = (n - w0 < W + 16) ? n - w0 : W + 16;
+            struct RW { const uint8_t* t; uint32_t txt(int j) const { return j < 0 ? 0u : t[j]; } };
+            const RW rw{wtxt.data()};
+            // (the kernel's s_ts: the document starts of the window and of the word behind it, from doc_off)
+            auto tsbit = [&](int j) { const int g = w0 + j; return g >= 0 && g < n && (recs[g] & CB_TSTART) != 0; };
+            for (int wi = 0; wi < W / 4; wi++) {
+                const int i0 = wi * 4;
+                uint32_t tw = 0, ts4 = 0;
+                for (int k = 0; k < 4; k++) {
+                    tw |= (uint32_t)wtxt[i0 + k] << (8 * k);
+                    // (the kernel's s_ts holds document starts only; the end-of-text mark at iB is the classifier's own)
+                    if (i0 + k < iB && tsbit(i0 + k)) ts4 |= 1u << k;
+                }
+                WordKinds wk;
+                if (!(tw & 0x80808080u) && i0 + 3 < iB && w0 + i0 >= 0) {
+                    const KindEnt e[4] = {aent[tw & 0xFF], aent[(tw >> 8) & 0xFF], aent[(tw >> 16) & 0xFF], aent[tw >> 24]};
+                    wk = classify_word_ascii(e, ts4);
+                } else {
+                    auto word = [&](int wj) { uint32_t x = 0; if (wj >= 0) for (int k = 0; k < 4; k++) x |= (uint32_t)wtxt[wj * 4 + k] << (8 * k); return x; };
+                    uint32_t ts16 = 0;
+                    for (int d2 = 0; d2 < 16; d2++) if (i0 - 4 + d2 >= 0 && tsbit(i0 - 4 + d2)) ts16 |= 1u << d2;
+                    wk = classify_word(s->dt, pat, word(wi - 1), tw, word(wi + 1), ts16, [&](uint32_t c) { return kent[c]; },
+                                       [&](uint32_t c) { return cp_class(s->dt, c); }, ts4, 0u, i0, iB, W, lo, iT);
+                }
+                for (int k = 0; k < 4; k++) {
+                    const int i = i0 + k;
+                    for (int j = 0; j < 8; j++) if ((wk.v0 >> (4 * j + k)) & 1u) nm[(V0_KINDS >> (4 * j)) & 15][i >> 5] |= 1u << (i & 31);
+                    for (int j = 0; j < V1_NKINDS; j++) if ((wk.v1 >> (4 * j + k)) & 1u) nm[(V1_KINDS >> (4 * j)) & 15][i >> 5] |= 1u << (i & 31);
+                    // records: the window's first bytes may begin inside a character whose lead the window does not hold
+                    const uint32_t want = (i == iB && iB < W) ? (uint32_t)(C_EOT | CB_TSTART | CB_SYNC) : i > iB ? (uint32_t)C_WEND
+                                        : (uint32_t)wrec[i] | ((wrec[i] & CB_TSTART) ? (uint32_t)CB_SYNC : 0u);
+                    const uint32_t got = (wk.rec >> (8 * k)) & 0xFFu;
+                    if ((i >= 4 || w0 <= 0) && got != want) { if (getenv("HS_DEBUG")) fprintf(stderr, "rec mismatch w0=%d i=%d iB=%d W=%d got=%02x want=%02x tw=%08x ts4=%x lo=%d\n", w0, i, iB, W, got, want, tw, ts4, lo); return -7; }
+                }
+            }
+            for (int k = 0; k < MK_SY; k++) {
+                if (pat == PAT_CL100K && (k == MK_M || k == MK_UP || k == MK_LB)) continue;     // (never asked for)
+                if (pat != PAT_MISTRAL_V3 && k == MK_SL) continue;
+                for (int w = 0; w < nw; w++) {
+                    uint32_t a = m.mk[k][w], b2 = nm[k][w];
+                    if (w == 0 && w0 > 0) { a &= ~0xFu; b2 &= ~0xFu; }
+                    if (w * 32 > iB) { a = 0; b2 = 0; }
+                    if (a != b2) return -8 - k;
+                }
+            }
         }
         // ---- fast path ----
         bool fast = false;

@@ -16,7 +16,7 @@ _REG = {"cl100k_base": ("cl100k_base.splv", 0), "o200k_base": ("o200k_base.splv"
 
 def build():
     srcs = [os.path.join(_HERE, "hostsim.cpp"), os.path.join(_CSRC, "spl_tables.cpp"), os.path.join(_CSRC, "spl_regex.cpp")]
-    deps = srcs + [os.path.join(_CSRC, h) for h in ("spl_regex.h", "spl_common.h", "spl_scan.h", "spl_scan_masks.h", "spl_scan_starts.h", "spl_lookup.h", "spl_tables.h")]
+    deps = srcs + [os.path.join(_CSRC, h) for h in ("spl_regex.h", "spl_common.h", "spl_scan.h", "spl_scan_masks.h", "spl_scan_starts.h", "spl_scan_words.h", "spl_lookup.h", "spl_tables.h")]
     if not os.path.exists(_LIB) or any(os.path.getmtime(d) > os.path.getmtime(_LIB) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", _LIB] + srcs)
     return _LIB

@@ -139,3 +139,13 @@ def test_invalid_utf8_policy(coracle, name):
         ids = c.encode_bytes(b)
         assert h.encode(b) == ids, b
         assert py.decode_bytes(ids) == b, b
+    # packed several to a buffer and tiled like the kernel: the bit-vector starts where a tile qualifies, and -- inside
+    # split_starts -- the kernel's one-pass word classifier (spl_scan_words.h: records and kind nibbles, four bytes at a
+    # time) against the record-based mask builder on every window
+    docs = invalid_utf8_corpus(31415, 1500)
+    for i in range(0, len(docs), 7):
+        grp = docs[i:i + 7]
+        ref = [c.split_bytes(d) for d in grp]
+        for tb, rh in ((64, 32), (800, 192)):
+            got, _ = h.split_starts(grp, tb, rh, 16)
+            assert got == ref, (tb, rh, grp)
