@@ -423,10 +423,19 @@ def main():
         # pool's wake-up no longer shows) and the 24-thread figure SURVEY 8d asks for.  Thread counts 8 .. all
         # host CPUs x memo on/off; the best median of each is reported (the GPU is compared with the strongest
         # configuration of the port on this host).
+        from oracle.coracle import pool_pin
+        from splintr_amd import _ffi as _f
+        shim = _f.shim()
         one_np, one_off = _packed(text_sets[0])
         all_texts = [t for ts in text_sets for t in ts]
         all_np, all_off = _packed(all_texts)
         cands = sorted({t for t in (8, 16, 24, 32, 64, ncpu) if t <= ncpu})
+        pool_pin(True)                 # one CPU per pool thread: unpinned, a 1 ms call scattered 50x between repetitions
+
+        def pct(ts_, nb_):
+            ts_ = sorted(ts_)
+            q = lambda f: nb_ / ts_[min(len(ts_) - 1, int(f * len(ts_)))] / 1e6
+            return {"p50": q(0.5), "p10": q(0.9), "p90": q(0.1)}       # (MB/s: the 10th percentile of the RATE is the 90th of the time)
 
         def sweep(t_np, t_off, reps):
             nb_ = int(t_off[-1])
@@ -443,24 +452,68 @@ def main():
                         c0 = time.perf_counter()
                         orc_t.encode_packed(t_np, t_off, threads=th)
                         ts_.append(time.perf_counter() - c0)
-                    ts_.sort()
-                    table[(th, memo)] = (nb_ / ts_[reps // 2] / 1e6, nb_ / ts_[-1] / 1e6, nb_ / ts_[0] / 1e6)
+                    table[(th, memo)] = pct(ts_, nb_)
             return table
+
+        def surface(texts_, th, memo):
+            """The port at the surface the reference's published numbers are quoted on (benchmarks/benchmark_batch.py:45-83:
+            3 warm-ups, 10 timed calls of encode_batch(list[str]) -> list[list[int]], mean): the product's own shim halves
+            (UTF-8 packing, list building) around the oracle's batch call."""
+            orc_t = COracle("cl100k_base", memo=memo)
+
+            def call():
+                b_, o_ = shim.pack_bytes(texts_)
+                ids_, off_ = orc_t.encode_packed(np.frombuffer(b_, dtype=np.uint8), np.frombuffer(o_, dtype=np.uint64), threads=th)
+                return shim.lists_from_csr(ids_.tobytes(), off_.tobytes())
+            for _ in range(3):
+                call()
+            ts_ = []
+            for _ in range(10):
+                c0 = time.perf_counter()
+                r_ = call()
+                ts_.append(time.perf_counter() - c0)
+                del r_
+            nb_ = sum(len(t.encode("utf-8")) for t in texts_)
+            return {"mean": round(nb_ / (sum(ts_) / len(ts_)) / 1e6, 1), **{k_: round(v_, 1) for k_, v_ in pct(ts_, nb_).items()}}
         REPS1, REPS8 = 61, 15
         t1 = sweep(one_np, one_off, REPS1)
         t8 = sweep(all_np, all_off, REPS8)
-        (bth, bmemo), bv = max(t1.items(), key=lambda kv: kv[1][0])
-        (b8th, b8memo), b8v = max(t8.items(), key=lambda kv: kv[1][0])
-        t24 = max((t1[(24, m)][0] for m in (False, True) if (24, m) in t1), default=None)
-        fmt = lambda tb: {f"{th}t{'+memo' if m else ''}": round(v[0], 1) for (th, m), v in sorted(tb.items())}
-        cpu = {"value": round(bv[0], 2), "unit": "MB/s", "cores": bth, "kind": "port", "host_cpus": ncpu,
-               "spread": [round(bv[1], 2), round(bv[2], 2)],
+        (bth, bmemo), bv = max(t1.items(), key=lambda kv: kv[1]["p50"])
+        (b8th, b8memo), b8v = max(t8.items(), key=lambda kv: kv[1]["p50"])
+        t24 = max((t1[(24, m)]["p50"] for m in (False, True) if (24, m) in t1), default=None)
+        fmt = lambda tb: {f"{th}t{'+memo' if m else ''}": round(v["p50"], 1) for (th, m), v in sorted(tb.items())}
+        py_c2 = surface(text_sets[0], bth, bmemo)
+        # BASELINE config 1 (the reference's own CPU-runnable case): 1000 short English texts, CSR level and Python surface
+        c1_texts = corpus.c1(1000)
+        c1_np, c1_off = _packed(c1_texts)
+        orc_c1 = COracle("cl100k_base", memo=bmemo)
+        for _ in range(3):
+            orc_c1.encode_packed(c1_np, c1_off, threads=bth)
+        ts_c1 = []
+        for _ in range(31):
+            c0 = time.perf_counter()
+            orc_c1.encode_packed(c1_np, c1_off, threads=bth)
+            ts_c1.append(time.perf_counter() - c0)
+        c1_csr = pct(ts_c1, int(c1_off[-1]))
+        py_c1 = surface(c1_texts, bth, bmemo)
+        pool_pin(False)
+        gpu_py = (throughputs or {}).get("c2", {}).get("python_surface")
+        cpu = {"value": round(bv["p50"], 2), "unit": "MB/s", "cores": bth, "kind": "port", "host_cpus": ncpu,
+               "p10_p50_p90": [round(bv["p10"], 2), round(bv["p50"], 2), round(bv["p90"], 2)],
+               "threads_pinned": True,
                "threads_24": round(t24, 2) if t24 is not None else None,
-               "rotation_as_one_call": {"value": round(b8v[0], 2), "cores": b8th, "memo": b8memo, "docs": len(all_texts),
+               "python_surface": {"value": py_c2["mean"], "unit": "MB/s", "stats": py_c2, "cores": bth,
+                                  "recipe": "list[str] -> list[list[int]]: shim.pack_bytes + the port's batch call + shim.lists_from_csr; 3 warm-ups, 10 timed calls, mean (benchmarks/benchmark_batch.py:45-83)",
+                                  "gpu_python_surface": gpu_py,
+                                  "gpu_over_cpu": round(gpu_py / py_c2["mean"], 2) if gpu_py else None},
+               "c1": {"workload": "BASELINE config 1: cl100k_base, 1000 short English texts (splintr_amd.corpus.c1, seed 1001)",
+                      "bytes": int(c1_off[-1]), "csr_level": {k_: round(v_, 1) for k_, v_ in c1_csr.items()}, "python_surface": py_c1,
+                      "cores": bth, "memo": bmemo},
+               "rotation_as_one_call": {"value": round(b8v["p50"], 2), "cores": b8th, "memo": b8memo, "docs": len(all_texts),
                                         "bytes": int(all_off[-1]), "repetitions": REPS8, "all_medians": fmt(t8)},
                "all_medians": fmt(t1),
                "sample": f"the first batch of the rotation ({batches[0].n_docs} docs, {batches[0].n_bytes} B) per call, 3 warm-ups + {REPS1} timed "
-                         f"repetitions per configuration, MEDIAN (spread = slowest / fastest repetition of the best configuration); "
+                         f"repetitions per configuration, MEDIAN (p10 / p50 / p90 of the best configuration beside it); pool threads pinned one per CPU; "
                          f"threads in {cands} x memo on/off -- best: {bth} threads "
                          f"{'with' if bmemo else 'without'} the mutex-guarded 4096-entry memo that stands in for the "
                          f"reference's LRU; persistent pool pulling documents off a shared counter, CSR in/out"}

@@ -45,12 +45,12 @@ extern "C" {
 #define SPL_PATTERN_MISTRAL_V3 2
 /* These three are the patterns the GPU scanner implements.  ANY OTHER pattern (Tokenizer::new compiles whatever it
  * is given, src/core/tokenizer.rs:410-456): SPL_PATTERN_CUSTOM with the pattern text in spl_opts -- there is no
- * regex engine on the GPU, so its split runs on the host cores (a restricted backtracking matcher over the same
- * code-point class table, csrc/spl_regex.h: literals, classes, \s, \p{L} \p{Lu} \p{Ll} \p{Lt} \p{Lm} \p{Lo} \p{M}
- * \p{N}, groups, (?i:), alternation, greedy / lazy quantifiers, look-ahead) and the chunk boundaries feed the same
- * probe / merge kernels.  What the matcher cannot express (anchors, \b, \d, \w, other properties, look-behind,
- * back-references, possessive quantifiers, a pattern that can match the empty string) is refused by spl_create with
- * the construct named. */
+ * regex engine on the GPU, so its split runs on the host cores (a backtracking matcher over the same code-point class
+ * table, csrc/spl_regex.h: literals, classes, \s \d \w, every general category as \p{..}, groups, (?i:), (?>), alternation,
+ * greedy / lazy / possessive quantifiers, look-ahead, ^ $ \A \Z \z \b \B -- upstream tiktoken's cl100k_base / o200k_base
+ * strings, Qwen2's and GPT-2's are accepted as they are) and the chunk boundaries feed the same probe / merge kernels.
+ * What the matcher cannot express (scripts, look-behind, back-references, \p{Lu} under (?i), a pattern that can match
+ * the empty string) is refused by spl_create with the construct named. */
 #define SPL_PATTERN_CUSTOM 3
 
 /* spl_opts.flags */

@@ -53,10 +53,17 @@ def lib():
         L.orc_encode_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
                                        ctypes.c_int, ctypes.c_int,
                                        ctypes.POINTER(ctypes.POINTER(ctypes.c_uint32)), ctypes.c_void_p]
+        L.orc_pool_pin.argtypes = [ctypes.c_int]
+        L.orc_pool_pin.restype = None
         L.orc_class_of.restype = ctypes.c_int
         L.orc_class_of.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
         _lib = L
     return _lib
+
+
+def pool_pin(on: bool = True) -> None:
+    """Pin the batch pool's threads (and the calling thread) to one CPU each: bench.py's cpu_baseline legs."""
+    lib().orc_pool_pin(1 if on else 0)
 
 
 class COracle:

@@ -30,6 +30,7 @@
  */
 #define _GNU_SOURCE
 #include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -57,7 +58,7 @@ static int uclass_load(uclass_t *u, const char *path) {
     uint32_t ver;
     char uver[16];
     if (fread(magic, 1, 4, f) != 4 || memcmp(magic, "SPLU", 4)) { fclose(f); return -2; }
-    if (fread(&ver, 4, 1, f) != 1 || ver != 1) { fclose(f); return -2; }
+    if (fread(&ver, 4, 1, f) != 1 || (ver != 1 && ver != 2)) { fclose(f); return -2; }   /* (version 2 appends general categories: not used here) */
     if (fread(&u->shift, 4, 1, f) != 1 || fread(&u->nblocks, 4, 1, f) != 1 ||
         fread(uver, 1, 16, f) != 16) { fclose(f); return -2; }
     size_t n1 = 0x110000u >> u->shift, n2 = (size_t)u->nblocks << u->shift;
@@ -598,6 +599,49 @@ static void *pool_main(void *arg) {
         pthread_mutex_unlock(&g_pool.mu);
     }
 }
+/* Affinity (bench.py's cpu_baseline): worker i on the (i + 1)-th CPU this process may run on, the caller on the first.
+ * Unpinned, the 1 ms calls of a 1000-document batch scattered 50x between repetitions (threads woken on busy or
+ * sleeping cores); pinned they stay within a few per cent.  Off by default: tests do not care. */
+static int g_pin = 0;
+static void pin_self(int k) {
+    cpu_set_t all, one;
+    if (sched_getaffinity(0, sizeof all, &all) != 0) return;
+    int n = CPU_COUNT(&all), want = n ? k % n : 0, seen = 0;
+    for (int c = 0; c < CPU_SETSIZE; c++) {
+        if (!CPU_ISSET(c, &all)) continue;
+        if (seen++ == want) { CPU_ZERO(&one); CPU_SET(c, &one); pthread_setaffinity_np(pthread_self(), sizeof one, &one); return; }
+    }
+}
+static cpu_set_t g_home;
+static int g_home_valid = 0;
+void orc_pool_pin(int on) {
+    if (on && !g_home_valid) { g_home_valid = sched_getaffinity(0, sizeof g_home, &g_home) == 0; }
+    if (on == g_pin) return;
+    g_pin = on;
+    if (on) pin_self(0);
+    else if (g_home_valid) pthread_setaffinity_np(pthread_self(), sizeof g_home, &g_home);
+    /* the pool is rebuilt by the next call with threads */
+    if (g_pool.n) {
+        pthread_mutex_lock(&g_pool.mu);
+        g_pool.stop = 1;
+        pthread_cond_broadcast(&g_pool.cv_work);
+        pthread_mutex_unlock(&g_pool.mu);
+        for (int i = 0; i < g_pool.n; i++) pthread_join(g_pool.th[i], NULL);
+        free(g_pool.th);
+        g_pool.th = NULL; g_pool.n = 0; g_pool.stop = 0;
+    }
+}
+typedef struct { uint64_t gen; int index; } pool_arg_t;
+static void *pool_entry(void *arg) {
+    pool_arg_t a = *(pool_arg_t *)arg;
+    free(arg);
+    if (g_pin) {
+        /* workers inherit the caller's one-CPU mask: widen to the process's home set first, then take their own CPU */
+        if (g_home_valid) pthread_setaffinity_np(pthread_self(), sizeof g_home, &g_home);
+        pin_self(a.index + 1);
+    }
+    return pool_main((void *)(uintptr_t)a.gen);
+}
 static void pool_resize(int n) {
     if (g_pool.n == n) return;
     if (g_pool.n) {
@@ -611,7 +655,11 @@ static void pool_resize(int n) {
     }
     g_pool.n = n;
     g_pool.th = malloc(sizeof(pthread_t) * (n ? n : 1));
-    for (int i = 0; i < n; i++) pthread_create(&g_pool.th[i], NULL, pool_main, (void *)(uintptr_t)g_pool.gen);
+    for (int i = 0; i < n; i++) {
+        pool_arg_t *a = malloc(sizeof *a);
+        a->gen = g_pool.gen; a->index = i;
+        pthread_create(&g_pool.th[i], NULL, pool_entry, a);
+    }
 }
 
 /* Batch encode (tokenizer.rs:932-942).  text = concatenated UTF-8, off[ndocs+1].

@@ -10,14 +10,23 @@ namespace {
 
 constexpr uint32_t CP_INVALID = 0xFFFFFFFFu;     // a byte sequence that is no character: class "other", equals no literal
 
+// general categories (tools/gen_unicode_tables.py GC_NAMES; class table version 2)
+enum : uint32_t { GC_Cn = 0, GC_Lu, GC_Ll, GC_Lt, GC_Lm, GC_Lo, GC_Mn, GC_Mc, GC_Me, GC_Nd, GC_Nl, GC_No, GC_Pc, GC_Pd, GC_Ps, GC_Pe, GC_Pi, GC_Pf,
+                  GC_Po, GC_Sm, GC_Sc, GC_Sk, GC_So, GC_Zs, GC_Zl, GC_Zp, GC_Cc, GC_Cf, GC_Cs, GC_Co, GC_COUNT };
+constexpr uint32_t GC_ALL = (1u << GC_COUNT) - 1u;
+
 struct ClassSet {
     uint32_t codes = 0;                                   // bit c: every code point of class code c (spl_common.h C_*)
+    uint32_t gcs = 0;                                     // bit g: every code point of general category g (properties the class codes do not single out)
     std::vector<std::pair<uint32_t, uint32_t>> ranges;    // inclusive code-point ranges
     bool neg = false;
     uint64_t ascii[2] = {0, 0};                           // membership of U+0000..U+007F, precomputed (regex_compile)
 };
 
-enum Op : uint8_t { OP_CHAR, OP_CHAR_FOLD, OP_CLASS, OP_ANY, OP_SPLIT, OP_JMP, OP_MATCH, OP_LOOK, OP_NLOOK, OP_REP1 };
+enum Op : uint8_t { OP_CHAR, OP_CHAR_FOLD, OP_CLASS, OP_ANY, OP_SPLIT, OP_JMP, OP_MATCH, OP_LOOK, OP_NLOOK, OP_REP1,
+                    OP_ATOMIC,      // (?>...) and the possessive quantifiers: sub-program at pc + 1 (ends in MATCH), its FIRST match is final; x = continuation
+                    OP_ASSERT };    // x = AS_*: a position test that consumes nothing
+enum : uint32_t { AS_BOL, AS_EOL, AS_EOT, AS_WORDB, AS_NWORDB };     // ^ \A | $ \Z | \z | \b | \B
 struct Inst { Op op; uint32_t x, y; uint32_t f = 0xFFFFFFFFu; };   // f (SPLIT of an alternation): first-character filter of branch x
 // which characters can START a match of an alternative: 128 bits for ASCII, one flag for everything else (conservative)
 struct FirstSet { uint64_t ascii[2] = {0, 0}; bool other = false; };                  // CHAR: x = cp; CLASS: x = set; SPLIT: x first, y second; JMP: x;
@@ -26,7 +35,9 @@ struct FirstSet { uint64_t ascii[2] = {0, 0}; bool other = false; };            
                                                           //       instruction at pc + 1; goes on at pc + 2
 
 struct Node {
-    enum Kind { CHAR, CLASS, ANY, CAT, ALT, REP, LOOK, EMPTY } kind = EMPTY;
+    enum Kind { CHAR, CLASS, ANY, CAT, ALT, REP, LOOK, EMPTY, ATOMIC, ASSERT } kind = EMPTY;
+    uint32_t as = 0;                                     // ASSERT: AS_*
+    bool possessive = false;                             // REP of a one-character item: no way back into the run
     uint32_t cp = 0; bool fold = false;                  // CHAR
     uint32_t set = 0;                                    // CLASS
     std::vector<std::unique_ptr<Node>> kids;             // CAT / ALT; REP, LOOK: one
@@ -81,18 +92,42 @@ struct Parser {
         } else if (!eof()) name = std::string(1, s[i++]);
         bool inner_neg = false;
         if (!name.empty() && name[0] == '^') { inner_neg = true; name = name.substr(1); }
-        uint32_t m = 0;
+        uint32_t m = 0, g = 0;
+        bool by_code = true;
         if (name == "L" || name == "Letter") m = M_L;
         else if (name == "Lu") m = SPL_BIT(C_LU);
         else if (name == "Ll") m = SPL_BIT(C_LL);
         else if (name == "Lt") m = SPL_BIT(C_LT);
         else if (name == "Lm") m = SPL_BIT(C_LM);
         else if (name == "Lo") m = SPL_BIT(C_LO);
+        else if (name == "L&" || name == "Lc") m = SPL_BIT(C_LU) | SPL_BIT(C_LL) | SPL_BIT(C_LT);
         else if (name == "M" || name == "Mark") m = SPL_BIT(C_M);
         else if (name == "N" || name == "Number") m = SPL_BIT(C_N);
-        else return fail("\\p{" + name + "}: the class table knows L, Lu, Ll, Lt, Lm, Lo, M and N (and \\s)", at);
-        if (negate_item != inner_neg) m = ~m & ((1u << C_EOT) - 1u);
-        cs.codes |= m;
+        else {
+            // properties the class codes do not single out: by general category (class table version 2)
+            by_code = false;
+            static const struct { const char* n; uint32_t g; } GCS[] = {
+                {"Mn", 1u << GC_Mn}, {"Mc", 1u << GC_Mc}, {"Me", 1u << GC_Me}, {"Nd", 1u << GC_Nd}, {"Nl", 1u << GC_Nl}, {"No", 1u << GC_No},
+                {"Pc", 1u << GC_Pc}, {"Pd", 1u << GC_Pd}, {"Ps", 1u << GC_Ps}, {"Pe", 1u << GC_Pe}, {"Pi", 1u << GC_Pi}, {"Pf", 1u << GC_Pf},
+                {"Po", 1u << GC_Po}, {"P", (1u << GC_Pc) | (1u << GC_Pd) | (1u << GC_Ps) | (1u << GC_Pe) | (1u << GC_Pi) | (1u << GC_Pf) | (1u << GC_Po)},
+                {"Sm", 1u << GC_Sm}, {"Sc", 1u << GC_Sc}, {"Sk", 1u << GC_Sk}, {"So", 1u << GC_So},
+                {"S", (1u << GC_Sm) | (1u << GC_Sc) | (1u << GC_Sk) | (1u << GC_So)},
+                {"Zs", 1u << GC_Zs}, {"Zl", 1u << GC_Zl}, {"Zp", 1u << GC_Zp}, {"Z", (1u << GC_Zs) | (1u << GC_Zl) | (1u << GC_Zp)},
+                {"Cc", 1u << GC_Cc}, {"Cf", 1u << GC_Cf}, {"Cs", 1u << GC_Cs}, {"Co", 1u << GC_Co}, {"Cn", 1u << GC_Cn},
+                {"C", (1u << GC_Cc) | (1u << GC_Cf) | (1u << GC_Cs) | (1u << GC_Co) | (1u << GC_Cn)}};
+            for (const auto& e : GCS) if (name == e.n) g = e.g;
+            if (!g) return fail("\\p{" + name + "}: general categories (L, Lu .. Lo, L&, M, Mn .. Me, N, Nd .. No, P, Pc .. Po, S, Sm .. So, Z, Zs .. Zp, C, Cc .. Cn) "
+                                "are the properties implemented; scripts and binary properties are not", at);
+            if (prog.ht->gc_stage1.empty())
+                return fail("\\p{" + name + "} needs the general-category table (a version-2 class table: splintr_amd/data/unicode_classes.bin)", at);
+        }
+        if (by_code) {
+            if (negate_item != inner_neg) m = ~m & ((1u << C_EOT) - 1u);
+            cs.codes |= m;
+        } else {
+            if (negate_item != inner_neg) g = ~g & GC_ALL;
+            cs.gcs |= g;
+        }
         return true;
     }
 
@@ -132,6 +167,18 @@ struct Parser {
                 cp = v;
                 return true;
             }
+            case 'd': case 'D': {                                        // \d = \p{Nd} under UCP
+                is_cp = false;
+                if (prog.ht->gc_stage1.empty()) return fail("\\d needs the general-category table (a version-2 class table)", at);
+                cs.gcs |= c == 'd' ? (1u << GC_Nd) : (~(1u << GC_Nd) & GC_ALL);
+                return true;
+            }
+            case 'w':                                                    // \w = [\p{L}\p{N}_] (PCRE2 10.39 with UCP)
+                is_cp = false; cs.codes |= M_L | SPL_BIT(C_N); cs.ranges.emplace_back('_', '_'); return true;
+            case 'W':
+                if (in_class) return fail("\\W inside a bracket class", at);
+                is_cp = false; cs.codes |= M_L | SPL_BIT(C_N); cs.ranges.emplace_back('_', '_'); cs.neg = true; return true;
+            case 'b': if (in_class) { cp = 0x08; return true; } break;  // (outside a class: the word boundary, atom())
             case 's': is_cp = false; cs.codes |= M_S; return true;
             case 'S': is_cp = false; cs.codes |= ~M_S & ((1u << C_EOT) - 1u); return true;
             case 'p': is_cp = false; return property(cs, false, at);
@@ -139,8 +186,7 @@ struct Parser {
             default: break;
         }
         if (std::isalnum((unsigned char)c))
-            return fail(std::string("\\") + c + " (anchors, \\b, \\d, \\w, back-references and the other letter escapes are not implemented; "
-                        "\\d and \\w would need Nd / Pc, which the class table does not single out)", at);
+            return fail(std::string("\\") + c + " (back-references, \\G, \\K, \\R, \\X, \\h, \\N and the other letter escapes are not implemented)", at);
         if ((uint8_t)c >= 0x80) { i--; return next_cp(cp); }            // an escaped non-ASCII character: itself
         cp = (uint8_t)c;                                                // escaped punctuation
         (void)in_class;
@@ -185,13 +231,31 @@ struct Parser {
                 if (hi < lo) { fail("range out of order", item_at); return nullptr; }
             }
             if (fold) {
-                for (uint32_t c = lo; c <= hi && c < 0x80; c++)
-                    if (std::isalpha((int)c)) { fail("letters in a bracket class under (?i)", item_at); return nullptr; }
+                // caseless: the other case of every ASCII letter of the range, U+017F for s, U+212A for k (what PCRE2's
+                // UTF | UCP caseless matching adds for ASCII letters; ranges beyond ASCII would need the full case folding)
                 if (hi >= 0x80) { fail("non-ASCII characters in a bracket class under (?i)", item_at); return nullptr; }
+                for (uint32_t c = lo; c <= hi; c++)
+                    if (std::isalpha((int)c)) {
+                        cs.ranges.emplace_back(c ^ 0x20u, c ^ 0x20u);
+                        if ((c | 0x20u) == 's') cs.ranges.emplace_back(0x17F, 0x17F);
+                        if ((c | 0x20u) == 'k') cs.ranges.emplace_back(0x212A, 0x212A);
+                    }
             }
             cs.ranges.emplace_back(lo, hi);
         }
+        if (!case_props_ok(cs, fold, at)) return nullptr;
         return set_node(std::move(cs));
+    }
+    // \p{Lu} \p{Ll} \p{Lt} under (?i): what caseless matching does to them differs between engines and versions -- refused
+    bool case_props_ok(const ClassSet& cs, bool fold, size_t at) {
+        const uint32_t k = cs.codes & (SPL_BIT(C_LU) | SPL_BIT(C_LL) | SPL_BIT(C_LT));
+        if (fold && k != 0 && k != (SPL_BIT(C_LU) | SPL_BIT(C_LL) | SPL_BIT(C_LT))) return fail("\\p{Lu} / \\p{Ll} / \\p{Lt} under (?i)", at);
+        return true;
+    }
+    std::unique_ptr<Node> assert_node(uint32_t as) {
+        auto n = std::make_unique<Node>();
+        n->kind = Node::ASSERT; n->as = as;
+        return n;
     }
 
     std::unique_ptr<Node> atom(bool& fold) {
@@ -216,7 +280,17 @@ struct Parser {
                     return n;
                 }
                 else if (s[i] == '<' && i + 1 < s.size() && (s[i + 1] == '=' || s[i + 1] == '!')) { fail("look-behind", at); return nullptr; }
-                else if (s[i] == '>') { fail("atomic group (?>", at); return nullptr; }
+                else if (s[i] == '>') {                                            // atomic group: its first match is final
+                    i++;
+                    auto inner = alternation(sub_fold);
+                    if (!inner) return nullptr;
+                    if (eof() || s[i] != ')') { fail("( without )", at); return nullptr; }
+                    i++;
+                    auto n = std::make_unique<Node>();
+                    n->kind = Node::ATOMIC;
+                    n->kids.push_back(std::move(inner));
+                    return n;
+                }
                 else if (s[i] == '<' || s[i] == 'P' || s[i] == '\'') {             // named group: groups only
                     const char close = s[i] == '\'' ? '\'' : '>';
                     const size_t e = s.find(close, i + 1);
@@ -244,15 +318,22 @@ struct Parser {
             n->kind = Node::ANY;
             return n;
         }
-        if (c == '^' || c == '$') { fail(std::string("anchor ") + c, at); return nullptr; }
+        if (c == '^') { i++; return assert_node(AS_BOL); }                // (no multi-line mode: the start / end of the text)
+        if (c == '$') { i++; return assert_node(AS_EOL); }
         if (c == '*' || c == '+' || c == '?' || c == '{') { fail(std::string("quantifier ") + c + " without an operand", at); return nullptr; }
         if (c == '\\') {
             i++;
+            if (!eof()) {
+                const char e = s[i];
+                const int as = e == 'b' ? (int)AS_WORDB : e == 'B' ? (int)AS_NWORDB : e == 'A' ? (int)AS_BOL : e == 'Z' ? (int)AS_EOL : e == 'z' ? (int)AS_EOT : -1;
+                if (as >= 0) { i++; return assert_node((uint32_t)as); }
+            }
             bool is_cp;
             uint32_t cp = 0;
             ClassSet cs;
             if (!escape(false, is_cp, cp, cs, at)) return nullptr;
             if (is_cp) return char_node(cp, fold);
+            if (!case_props_ok(cs, fold, at)) return nullptr;
             return set_node(std::move(cs));
         }
         uint32_t cp;
@@ -264,7 +345,8 @@ struct Parser {
     static bool nullable(const Node& n) {
         switch (n.kind) {
             case Node::CHAR: case Node::CLASS: case Node::ANY: return false;
-            case Node::EMPTY: case Node::LOOK: return true;
+            case Node::EMPTY: case Node::LOOK: case Node::ASSERT: return true;
+            case Node::ATOMIC: return nullable(*n.kids[0]);
             case Node::CAT: for (auto& k : n.kids) if (!nullable(*k)) return false; return true;
             case Node::ALT: for (auto& k : n.kids) if (nullable(*k)) return true; return false;
             case Node::REP: return n.lo == 0 || nullable(*n.kids[0]);
@@ -293,15 +375,23 @@ struct Parser {
                 if (hi < lo) { fail("{m,n} with n < m", at); return nullptr; }
                 if (lo > 1000 || (hi != UINT32_MAX && hi > 1000)) { fail("counted repeat beyond 1000", at); return nullptr; }
             } else break;
-            bool lazy = false;
+            bool lazy = false, possessive = false;
             if (!eof() && s[i] == '?') { lazy = true; i++; }
-            else if (!eof() && s[i] == '+') { fail("possessive quantifier", at); return nullptr; }
-            if (a->kind == Node::EMPTY || a->kind == Node::LOOK) { fail("a quantifier on an assertion", at); return nullptr; }
+            else if (!eof() && s[i] == '+') { possessive = true; i++; }   // X*+ == (?>X*): what the run took stays taken
+            if (a->kind == Node::EMPTY || a->kind == Node::LOOK || a->kind == Node::ASSERT) { fail("a quantifier on an assertion", at); return nullptr; }
             if (hi == UINT32_MAX && nullable(*a)) { fail("an unbounded quantifier over an expression that can match the empty string", at); return nullptr; }
+            const bool one_char = a->kind == Node::CHAR || a->kind == Node::CLASS || a->kind == Node::ANY;
             auto r = std::make_unique<Node>();
             r->kind = Node::REP; r->lo = lo; r->hi = hi; r->lazy = lazy;
+            r->possessive = possessive && one_char;
             r->kids.push_back(std::move(a));
             a = std::move(r);
+            if (possessive && !one_char) {
+                auto g = std::make_unique<Node>();
+                g->kind = Node::ATOMIC;
+                g->kids.push_back(std::move(a));
+                a = std::move(g);
+            }
         }
         if (!eof() && s[i] == '{') {                                     // not a quantifier: the caller's next atom reads it as a literal
         }
@@ -353,7 +443,8 @@ struct Emitter {
     bool first_of(const Node& n, FirstSet& fs) const {
         auto add = [&](uint32_t c) { fs.ascii[c >> 6] |= 1ull << (c & 63); };
         switch (n.kind) {
-            case Node::EMPTY: case Node::LOOK: return true;
+            case Node::EMPTY: case Node::LOOK: case Node::ASSERT: return true;
+            case Node::ATOMIC: return first_of(*n.kids[0], fs);
             case Node::CHAR:
                 if (n.cp < 0x80) { add(n.cp); if (n.fold) { add(n.cp ^ 0x20u); fs.other = true; } }      // (fold: U+017F, U+212A)
                 else fs.other = true;
@@ -366,6 +457,7 @@ struct Emitter {
                 for (uint32_t c = 0; c < 128; c++) {
                     const uint32_t cls = p.ht->ucls_stage2[((uint32_t)p.ht->ucls_stage1[0] << p.ht->ucls_shift) | c];
                     bool in = ((cs.codes >> cls) & 1u) != 0;
+                    if (!in && cs.gcs) in = ((cs.gcs >> host_cp_category(*p.ht, c)) & 1u) != 0;
                     for (const auto& r : cs.ranges) in = in || (c >= r.first && c <= r.second);
                     if (in != cs.neg) add(c);
                 }
@@ -418,8 +510,10 @@ struct Emitter {
                 const Node& e = *n.kids[0];
                 if (!n.lazy && (e.kind == Node::CHAR || e.kind == Node::CLASS || e.kind == Node::ANY)) {
                     // a greedy run of ONE-character items (\p{L}+, \s*, [\r\n]*, ' ?'): taken in one go with ONE way back
-                    // on the stack (give one character back, re-counted from the run's start) instead of one per character
-                    emit(OP_REP1, n.lo, n.hi);
+                    // on the stack (give one character back, re-counted from the run's start) instead of one per character;
+                    // possessive (f == 1): no way back at all
+                    const uint32_t r1 = emit(OP_REP1, n.lo, n.hi);
+                    if (n.possessive) p.code[r1].f = 1u;
                     gen(e);
                     break;
                 }
@@ -440,6 +534,14 @@ struct Emitter {
                         p.code[sp].y = n.lazy ? sp + 1 : end;
                     }
                 }
+                break;
+            }
+            case Node::ASSERT: emit(OP_ASSERT, n.as); break;
+            case Node::ATOMIC: {
+                const uint32_t l = emit(OP_ATOMIC);
+                gen(*n.kids[0]);
+                emit(OP_MATCH);
+                p.code[l].x = (uint32_t)p.code.size();
                 break;
             }
             case Node::LOOK: {
@@ -472,8 +574,10 @@ inline Ch decode(const HostTables& ht, const uint8_t* t, size_t pos, size_t n) {
     return Ch{cp, want, host_cp_class(ht, cp)};
 }
 
-inline bool in_set(const ClassSet& cs, const Ch& c) {
+inline bool in_set(const HostTables& ht, const ClassSet& cs, const Ch& c) {
     bool in = ((cs.codes >> c.cls) & 1u) != 0;
+    // (bytes that are no character: general category Cn, as they are class "other")
+    if (!in && cs.gcs) in = ((cs.gcs >> (c.cp == CP_INVALID ? (uint32_t)GC_Cn : host_cp_category(ht, c.cp))) & 1u) != 0;
     if (!in && c.cp != CP_INVALID)
         for (const auto& r : cs.ranges) if (c.cp >= r.first && c.cp <= r.second) { in = true; break; }
     return in != cs.neg;
@@ -506,7 +610,11 @@ struct Matcher {
         if (in.op == OP_CHAR) return c.cp == in.x;
         if (in.op == OP_CHAR_FOLD) return c.cp != CP_INVALID && fold_eq(in.x, c.cp);
         if (in.op == OP_ANY) return c.cp != '\n';
-        return in_set(p.sets[in.x], c);
+        return in_set(*p.ht, p.sets[in.x], c);
+    }
+    bool is_word(size_t q) const {                                       // \w at q: a letter, a number or '_'
+        const Ch c = decode(*p.ht, t, q, n);
+        return c.cp == '_' || ((SPL_BIT(c.cls) & (M_L | SPL_BIT(C_N))) != 0 && c.cp != CP_INVALID);
     }
     // longest-by-priority match of the program that starts at `pc0`, anchored at `pos`; SIZE_MAX: no match
     size_t run(uint32_t pc0, size_t pos0) {
@@ -549,6 +657,32 @@ struct Matcher {
                     if ((r != SIZE_MAX) == (in.op == OP_LOOK)) { pc = in.x; continue; }
                     break;
                 }
+                if (in.op == OP_ATOMIC) {                                  // the sub-program's FIRST match, and no way back into it
+                    const size_t r = run(pc + 1, pos);
+                    if (r == SIZE_MAX - 1) { stack.resize(floor); return r; }
+                    if (r == SIZE_MAX) break;
+                    pos = r; pc = in.x;
+                    continue;
+                }
+                if (in.op == OP_ASSERT) {
+                    bool ok;
+                    if (in.x == AS_BOL) ok = pos == 0;
+                    else if (in.x == AS_EOT) ok = pos == n;
+                    else if (in.x == AS_EOL) ok = pos == n || (pos + 1 == n && t[pos] == '\n');
+                    else {
+                        const bool after = pos < n && is_word(pos);
+                        bool before = false;
+                        if (pos > 0) {
+                            size_t q = pos - 1;
+                            while (q > 0 && pos - q < 4 && (t[q] & 0xC0u) == 0x80u) q--;
+                            if (q + decode(*p.ht, t, q, n).len == pos) before = is_word(q);     // (else: a stray byte, no word character)
+                        }
+                        ok = (before != after) == (in.x == AS_WORDB);
+                    }
+                    if (!ok) break;
+                    pc++;
+                    continue;
+                }
                 if (in.op == OP_REP1) {
                     const Inst& a = p.code[pc + 1];
                     size_t q = pos;
@@ -566,7 +700,7 @@ struct Matcher {
                     }
                     steps += k;
                     if (k < in.x) break;
-                    if (k > in.x) stack.push_back(Frame{pc, k - 1, pos});
+                    if (k > in.x && in.f != 1u) stack.push_back(Frame{pc, k - 1, pos});
                     pos = q;
                     pc += 2;
                     continue;
@@ -622,6 +756,7 @@ RegexPtr regex_compile(const std::string& pattern, const HostTables& ht, std::st
         for (uint32_t c = 0; c < 128; c++) {
             const uint32_t cls = ht.ucls_stage2[((uint32_t)ht.ucls_stage1[0] << ht.ucls_shift) | c];
             bool in = ((cs.codes >> cls) & 1u) != 0;
+            if (!in && cs.gcs) in = ((cs.gcs >> host_cp_category(ht, c)) & 1u) != 0;
             for (const auto& r : cs.ranges) in = in || (c >= r.first && c <= r.second);
             if (in != cs.neg) cs.ascii[c >> 6] |= 1ull << (c & 63);
         }

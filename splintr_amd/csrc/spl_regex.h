@@ -9,12 +9,16 @@
 // This is a small backtracking matcher of its own (product code, not shared with the test infrastructure), over the
 // code-point classes of splintr_amd/data/unicode_classes.bin -- the table the GPU scanner classifies with.
 // Supported: literals, `.`, escapes (\r \n \t \f \v \e \0 \xHH \x{H..} \uHHHH and escaped punctuation),
-// \s \S, \p{L} \p{Lu} \p{Ll} \p{Lt} \p{Lm} \p{Lo} \p{M} \p{N} and \P{..}, bracket classes with ranges,
-// negation and those escapes inside, groups (capturing groups group only), (?: ) (?i: ) (?i), alternation,
-// the quantifiers ? * + {m} {m,} {m,n} greedy or lazy, and the look-aheads (?= ) (?! ).  Anything else --
-// anchors, \b, \d, \w, other Unicode properties (the class table does not split N or the "other" characters
-// further), back-references, look-behind, possessive quantifiers, atomic groups -- is refused at
-// construction with the construct named, never approximated.
+// \s \S \d \D \w \W, \p{..} / \P{..} for every GENERAL CATEGORY (L Lu Ll Lt Lm Lo L& M Mn Mc Me N Nd Nl No P Pc Pd Ps Pe
+// Pi Pf Po S Sm Sc Sk So Z Zs Zl Zp C Cc Cf Cs Co Cn; the ones beyond L* / M / N from the general-category part of a
+// version-2 class table), bracket classes with ranges, negation and those escapes inside (caseless under (?i): ASCII
+// case pairs, U+017F, U+212A), groups (capturing groups group only), (?: ) (?i: ) (?i) (?> ), alternation, the
+// quantifiers ? * + {m} {m,} {m,n} greedy, lazy or POSSESSIVE, the look-aheads (?= ) (?! ), and the assertions
+// ^ $ \A \Z \z \b \B (no multi-line mode: a text is one subject).  Semantics are PCRE2's with UTF | UCP (10.39: \d =
+// \p{Nd}, \w = [\p{L}\p{N}_]); tests/test_host_regex.py compares thirteen patterns -- upstream tiktoken's cl100k_base
+// and o200k_base strings, Qwen2's, GPT-2's among them -- against that engine.  Anything else -- scripts and binary
+// properties, back-references, look-behind, \G \K \R \X, \p{Lu} under (?i), non-ASCII ranges under (?i), a pattern that
+// can match the empty string -- is refused at construction with the construct named, never approximated.
 #pragma once
 #include <cstdint>
 #include <memory>

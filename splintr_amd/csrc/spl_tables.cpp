@@ -81,10 +81,17 @@ uint32_t host_cp_class(const HostTables& t, uint32_t cp) {
     return t.ucls_stage2[(blk << t.ucls_shift) | (cp & ((1u << t.ucls_shift) - 1u))];
 }
 
+uint32_t host_cp_category(const HostTables& t, uint32_t cp) {
+    if (cp >= 0x110000u || t.gc_stage1.empty()) return 0;
+    const uint32_t blk = t.gc_stage1[cp >> t.ucls_shift];
+    return t.gc_stage2[(blk << t.ucls_shift) | (cp & ((1u << t.ucls_shift) - 1u))];
+}
+
 int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size_t ucls_len, int pattern,
                  bool force_byte_level, HostTables& out, std::string& err) {
     // ---- class table -------------------------------------------------------------------
-    if (ucls_len < 32 || memcmp(ucls, "SPLU", 4) != 0 || rd32(ucls + 4) != 1) { err = "bad unicode class table"; return 1; }
+    if (ucls_len < 32 || memcmp(ucls, "SPLU", 4) != 0 || (rd32(ucls + 4) != 1 && rd32(ucls + 4) != 2)) { err = "bad unicode class table"; return 1; }
+    const uint32_t ucls_version = rd32(ucls + 4);
     out.ucls_shift = rd32(ucls + 8);
     const uint32_t nblocks = rd32(ucls + 12);
     const size_t n1 = 0x110000u >> out.ucls_shift, n2 = (size_t)nblocks << out.ucls_shift;
@@ -94,6 +101,24 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
     out.ucls_stage2.assign(ucls + 32 + n1 * 2, ucls + 32 + n1 * 2 + n2);
     for (uint16_t b : out.ucls_stage1)
         if (b >= nblocks) { err = "unicode class table: block index out of range"; return 1; }
+    // version 2: behind the caseless partners, the GENERAL CATEGORY of every code point (tools/gen_unicode_tables.py) --
+    // host only: the splitter's \p{P} \p{S} \p{Z} \p{Nd} ... \d (spl_regex.cpp); the kernels never see it
+    out.gc_stage1.clear(); out.gc_stage2.clear();
+    if (ucls_version >= 2) {
+        size_t at = 32 + n1 * 2 + n2;
+        if (ucls_len < at + 4) { err = "truncated unicode class table"; return 1; }
+        at += 4 + (size_t)rd32(ucls + at) * 8;
+        if (ucls_len < at + 4) { err = "truncated unicode class table"; return 1; }
+        const uint32_t gnb = rd32(ucls + at);
+        at += 4;
+        const size_t g2 = (size_t)gnb << out.ucls_shift;
+        if (ucls_len < at + n1 * 2 + g2) { err = "truncated unicode class table (general categories)"; return 1; }
+        out.gc_stage1.resize(n1);
+        memcpy(out.gc_stage1.data(), ucls + at, n1 * 2);
+        out.gc_stage2.assign(ucls + at + n1 * 2, ucls + at + n1 * 2 + g2);
+        for (uint16_t b : out.gc_stage1)
+            if (b >= gnb) { err = "unicode class table: category block index out of range"; return 1; }
+    }
     out.cjk_fast = true;
     for (uint32_t cp = 0x4E00; cp < 0xA000 && out.cjk_fast; cp++) out.cjk_fast = host_cp_class(out, cp) == C_LO;
     for (uint32_t cp = 0xAC00; cp < 0xD7A4 && out.cjk_fast; cp++) out.cjk_fast = host_cp_class(out, cp) == C_LO;

@@ -17,6 +17,8 @@ struct HostTables {
     // code-point classes
     std::vector<uint16_t> ucls_stage1;
     std::vector<uint8_t> ucls_stage2;
+    std::vector<uint16_t> gc_stage1;      // general categories (class table version 2; empty otherwise): host splitter only
+    std::vector<uint8_t> gc_stage2;
     uint32_t ucls_shift = 7;
     bool cjk_fast = false;
     // vocabulary
@@ -54,5 +56,7 @@ int build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* ucls, si
 
 // Host mirror of the device two-stage lookup (used by build checks and tests/hostsim).
 uint32_t host_cp_class(const HostTables& t, uint32_t cp);
+// General category code of a code point (tools/gen_unicode_tables.py GC_NAMES: 0 Cn, 1 Lu, 2 Ll, ...); 0 without the table.
+uint32_t host_cp_category(const HostTables& t, uint32_t cp);
 
 }  // namespace spl

@@ -69,6 +69,14 @@ def _byte_level_alphabet() -> List[str]:
 _BYTE_TO_CHAR = _byte_level_alphabet()
 
 
+def _unicode_table_path(which: str) -> str:
+    if which == "pcre2":
+        return os.path.join(_DATA, "unicode_classes.bin")
+    if which == "regex":
+        return os.path.join(_DATA, "unicode_classes_regex.bin")
+    return which
+
+
 def _read(path: str) -> bytes:
     with open(path, "rb") as f:
         return f.read()
@@ -98,34 +106,39 @@ class Tokenizer:
 
     Differences from the reference, all refused loudly rather than approximated:
     * `pattern`: CL100K_BASE_PATTERN, O200K_BASE_PATTERN (= LLAMA3_PATTERN) and MISTRAL_V3_PATTERN are split on the
-      GPU; any other pattern is split on the host cores by a restricted regex matcher (literals, classes, \s,
-      \p{L} \p{Lu} \p{Ll} \p{Lt} \p{Lm} \p{Lo} \p{M} \p{N}, groups, (?i:), alternation, greedy / lazy
-      quantifiers, look-ahead) and merged on the GPU; a pattern with anything else in it (anchors, \b, \d, \w,
-      other Unicode properties, look-behind, back-references, possessive quantifiers) or one that can match the
-      empty string raises the reference's "Regex error" ValueError naming the construct;
+      GPU; any other pattern is split on the host cores by the library's own regex matcher (literals, classes, \s \d \w,
+      every general category as \p{..}, groups, (?i:), (?>), alternation, greedy / lazy / possessive quantifiers,
+      look-ahead, ^ $ \A \Z \z \b \B: upstream tiktoken's cl100k_base / o200k_base strings, Qwen2's and GPT-2's are accepted as
+      they are) and merged on the GPU; a pattern with anything else in it (scripts, look-behind, back-references, \p{Lu}
+      under (?i)) or one that can match the empty string raises the reference's "Regex error" ValueError naming the construct;
     * the vocabulary must contain all 256 single bytes and ids below 2**21;
     * special-token literals are at most 255 bytes (any set: literals that contain or chain into one
       another are matched as the reference's Aho-Corasick matcher does).
     Extensions: `device=` / `devices=` select the GPU(s), `byte_level=True` is the reference's
     `from_bytes_byte_level`; the vocabulary may also be this repo's packed SPLV container.
+    `unicode_tables=`: which Unicode character data \p{L} \p{N} \s ... mean -- "pcre2" (default: probed from PCRE2 10.39,
+    Unicode 14.0, the engine the reference's own tests declare equivalent to its default one), "regex" (probed from the
+    Python `regex` module, a newer Unicode: 14 186 code points are classed differently, U+180E among them), or the path
+    of a table made by tools/gen_unicode_tables.py.  The reference's default engine (regexr, Cargo.toml:41) ships tables
+    of a version that cannot be determined here; nothing in the reference pins the difference.
     """
 
     def __init__(self, vocab_path: str, pattern: str, special_tokens: Optional[Dict[str, int]] = None, *,
-                 device: int = 0, byte_level: bool = False):
+                 device: int = 0, byte_level: bool = False, unicode_tables: str = "pcre2"):
         # src/python/bindings.rs:70-83: every failure of from_file surfaces as IOError
         try:
             blob = _read(vocab_path)
-            self._init_from_blob(blob, pattern, special_tokens or {}, device, byte_level)
+            self._init_from_blob(blob, pattern, special_tokens or {}, device, byte_level, unicode_tables)
         except (OSError, ValueError) as e:
             raise IOError(str(e)) from None
 
     # ------------------------------------------------------------------ construction
     def _init_from_blob(self, blob: bytes, pattern: str, special_tokens: Dict[str, int], device: int,
-                        byte_level: bool = False):
+                        byte_level: bool = False, unicode_tables: str = "pcre2"):
         if not isinstance(pattern, str):
             raise TypeError("argument 'pattern': object cannot be converted to 'PyString'")
         L = _ffi.lib()
-        ucls = _read(os.path.join(_DATA, "unicode_classes.bin"))
+        ucls = _read(_unicode_table_path(unicode_tables))
         flags = _ffi.SPL_OPT_BYTE_LEVEL if byte_level else 0
         if pattern in _PATTERN_ID:
             opts = _ffi.SplOpts(_PATTERN_ID[pattern], device, flags)
@@ -145,13 +158,13 @@ class Tokenizer:
 
     @classmethod
     def _from_blob(cls, blob: bytes, pattern: str, special_tokens: Dict[str, int], device: int = 0,
-                   byte_level: bool = False) -> "Tokenizer":
+                   byte_level: bool = False, unicode_tables: str = "pcre2") -> "Tokenizer":
         self = cls.__new__(cls)
-        self._init_from_blob(blob, pattern, special_tokens, device, byte_level)
+        self._init_from_blob(blob, pattern, special_tokens, device, byte_level, unicode_tables)
         return self
 
     @staticmethod
-    def from_pretrained(name: str, device: int = 0) -> "Tokenizer":
+    def from_pretrained(name: str, device: int = 0, unicode_tables: str = "pcre2") -> "Tokenizer":
         """src/python/bindings.rs:101-166 (in-scope names: cl100k_base, o200k_base, llama3*,
         deepseek_v3 / deepseek-v3)."""
         if not isinstance(name, str):
@@ -163,21 +176,21 @@ class Tokenizer:
         fn, pattern, skey = ent
         with open(os.path.join(_DATA, "special_tokens.json"), encoding="utf-8") as f:
             special = json.load(f)[skey]
-        return Tokenizer._from_blob(_read(os.path.join(_DATA, fn)), pattern, special, device)
+        return Tokenizer._from_blob(_read(os.path.join(_DATA, fn)), pattern, special, device, False, unicode_tables)
 
     @staticmethod
     def from_bytes(vocab_data: bytes, pattern: str, special_tokens: Optional[Dict[str, int]] = None,
-                   device: int = 0) -> "Tokenizer":
+                   device: int = 0, unicode_tables: str = "pcre2") -> "Tokenizer":
         """src/python/bindings.rs:174-187: `vocab_data` is tiktoken text (`base64 rank` lines), as in
         the reference; this repo's SPLV container is accepted as well."""
-        return Tokenizer._from_blob(bytes(vocab_data), pattern, special_tokens or {}, device)
+        return Tokenizer._from_blob(bytes(vocab_data), pattern, special_tokens or {}, device, False, unicode_tables)
 
     @staticmethod
     def from_bytes_byte_level(vocab_data: bytes, pattern: str, special_tokens: Optional[Dict[str, int]] = None,
-                              device: int = 0) -> "Tokenizer":
+                              device: int = 0, unicode_tables: str = "pcre2") -> "Tokenizer":
         """src/core/tokenizer.rs:562-569 (not exposed by the reference's Python class; used by its
         from_pretrained for deepseek_v3 and mistral_v3)."""
-        return Tokenizer._from_blob(bytes(vocab_data), pattern, special_tokens or {}, device, True)
+        return Tokenizer._from_blob(bytes(vocab_data), pattern, special_tokens or {}, device, True, unicode_tables)
 
     def set_devices(self, devices: Sequence[int]) -> "Tokenizer":
         """Extension: spread `encode_batch` over several GPUs from this one process

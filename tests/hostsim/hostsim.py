@@ -60,10 +60,10 @@ def lib():
 
 
 class HostSim:
-    def __init__(self, name):
+    def __init__(self, name, ucls="unicode_classes.bin"):
         fn, pid = _REG[name]
         err = ctypes.create_string_buffer(256)
-        self._h = lib().hs_create(os.path.join(_DATA, fn).encode(), os.path.join(_DATA, "unicode_classes.bin").encode(),
+        self._h = lib().hs_create(os.path.join(_DATA, fn).encode(), os.path.join(_DATA, ucls).encode(),
                                   pid, err, 256)
         if not self._h:
             raise ValueError(err.value.decode())

@@ -57,7 +57,7 @@ int main(int argc, char** argv) {
         printf("pattern ok: %llu start bits over %llu bytes\n", (unsigned long long)chunks, (unsigned long long)off[nd]);
     }
     // refused patterns must fail cleanly
-    for (const char* pat : {"\\w+", "(a", "a*", "[z-a]", "\\p{Foo}", "(?<=x)y"}) {
+    for (const char* pat : {"\\p{Han}+", "(a", "a*", "[z-a]", "\\p{Foo}", "(?<=x)y", "(?i:\\p{Lu})", "\\b+"}) {
         spl::RegexPtr re = spl::regex_compile(pat, ht, err);
         if (re) { fprintf(stderr, "pattern %s should have been refused\n", pat); return 7; }
     }

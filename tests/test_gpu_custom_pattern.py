@@ -13,7 +13,8 @@ import pytest
 
 from conftest import ROOT
 from fuzzgen import cased_corpus, fuzz_corpus, latin_corpus
-from test_host_regex import GPT2_PATTERN, MIXED, SPARSE, VARIANT_A, VARIANT_B
+from test_host_regex import (DEEPSEEK_LIKE, GPT2_PATTERN, MIXED, QWEN2, SPARSE, TIKTOKEN_CL100K, TIKTOKEN_O200K, VARIANT_A, VARIANT_B,
+                             WORDS_DIGITS)
 
 pytestmark = pytest.mark.gpu
 DATA = os.path.join(ROOT, "splintr_amd", "data")
@@ -56,6 +57,13 @@ def _texts(seed):
     ("variant_a", "mistral_v3", VARIANT_A, True),
     ("gpt2_o200k", "o200k_base", GPT2_PATTERN, False),
     ("mixed", "llama3", MIXED, False),
+    # round 4 (VERDICT r03 #5a): the pattern strings upstream tokenizers ship -- possessive quantifiers, `$`, a caseless
+    # bracket class (tiktoken's cl100k_base), Qwen2's, a DeepSeek-style pattern with \p{P} \p{S}, and \d \w \b atomic groups
+    ("tiktoken_cl100k", "cl100k_base", TIKTOKEN_CL100K, False),
+    ("tiktoken_o200k", "o200k_base", TIKTOKEN_O200K, False),
+    ("qwen2", "cl100k_base", QWEN2, False),
+    ("deepseek_like", "deepseek_v3", DEEPSEEK_LIKE, True),
+    ("words_digits", "llama3", WORDS_DIGITS, False),
 ])
 def test_custom_patterns_bit_exact(key, vocab, pattern, bl):
     t, orc = _pair(vocab, pattern, byte_level=bl)

@@ -19,10 +19,25 @@ SPARSE = r"\p{L}+|[0-9]+"
 MIXED = r"(?:https?://|www\.)[^\s]+|[A-Za-z_][A-Za-z0-9_]*|\x{4f60}\x{597d}|[\[\]{}()]|.|\n"
 
 
+# round 4: what upstream tokenizers actually ship.  tiktoken's cl100k_base pattern string (possessive quantifiers, a caseless
+# bracket class, the `$` anchor), Qwen2's, a DeepSeek-style pattern with \p{P} \p{S} and an explicit CJK range, and a
+# pattern of \d \w \b atomic-group pieces
+TIKTOKEN_CL100K = r"'(?i:[sdmt]|ll|ve|re)|[^\r\n\p{L}\p{N}]?+\p{L}++|\p{N}{1,3}+| ?[^\s\p{L}\p{N}]++[\r\n]*+|\s++$|\s*[\r\n]|\s+(?!\S)|\s"
+TIKTOKEN_O200K = "|".join([
+    r"[^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]*[\p{Ll}\p{Lm}\p{Lo}\p{M}]+(?i:'s|'t|'re|'ve|'m|'ll|'d)?",
+    r"[^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]+[\p{Ll}\p{Lm}\p{Lo}\p{M}]*(?i:'s|'t|'re|'ve|'m|'ll|'d)?",
+    r"\p{N}{1,3}", r" ?[^\s\p{L}\p{N}]+[\r\n/]*", r"\s*[\r\n]+", r"\s+(?!\S)", r"\s+"])
+QWEN2 = r"(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+"
+DEEPSEEK_LIKE = (r"\p{N}{1,3}|[\x{4e00}-\x{9fa5}\x{3040}-\x{309f}\x{30a0}-\x{30ff}]+|[!-/:-@\[-`{-~][A-Za-z]+|[^\r\n\p{L}\p{P}\p{S}]?[\p{L}\p{M}]+|"
+                 r" ?[\p{P}\p{S}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+")
+WORDS_DIGITS = r"\b\w+\b|\d++|(?>\s+)(?=\S)|\p{Zs}+|\p{Sc}\d*|\p{Pd}+|\A\W|\W\z|[^\w\s]"
+
+
 def _patterns():
     from splintr_amd import CL100K_BASE_PATTERN, O200K_BASE_PATTERN, MISTRAL_V3_PATTERN
     return {"cl100k": CL100K_BASE_PATTERN, "o200k": O200K_BASE_PATTERN, "mistral_v3": MISTRAL_V3_PATTERN, "gpt2": GPT2_PATTERN,
-            "variant_a": VARIANT_A, "variant_b": VARIANT_B, "sparse": SPARSE, "mixed": MIXED}
+            "variant_a": VARIANT_A, "variant_b": VARIANT_B, "sparse": SPARSE, "mixed": MIXED, "tiktoken_cl100k": TIKTOKEN_CL100K,
+            "tiktoken_o200k": TIKTOKEN_O200K, "qwen2": QWEN2, "deepseek_like": DEEPSEEK_LIKE, "words_digits": WORDS_DIGITS}
 
 
 @pytest.fixture(scope="module")
@@ -31,7 +46,8 @@ def sim():
     return HostSim("cl100k_base")
 
 
-@pytest.mark.parametrize("key", ["cl100k", "o200k", "mistral_v3", "gpt2", "variant_a", "variant_b", "sparse", "mixed"])
+@pytest.mark.parametrize("key", ["cl100k", "o200k", "mistral_v3", "gpt2", "variant_a", "variant_b", "sparse", "mixed", "tiktoken_cl100k",
+                                 "tiktoken_o200k", "qwen2", "deepseek_like", "words_digits"])
 def test_host_splitter_equals_pcre2(sim, key):
     from hostsim import HostRegex
     from oracle import pyoracle as O
@@ -41,7 +57,9 @@ def test_host_splitter_equals_pcre2(sim, key):
     hr = HostRegex(pat, sim)
     pc = O.Pcre2Pattern(pat)
     texts = fuzz_corpus(4242, 2500, 40) + latin_corpus(7, 400, 80) + cased_corpus(9, 400, 60)
-    texts += ["", " ", "\n", "a", "'", "'s", "x's'S'ſ'K'K", "http://a.b/c?d=e www.x.y z", "你好你好 你 好", "a\nb\r\nc", "{[()]}", "12345678901"]
+    texts += ["", " ", "\n", "a", "'", "'s", "x's'S'ſ'K'K", "http://a.b/c?d=e www.x.y z", "你好你好 你 好", "a\nb\r\nc", "{[()]}", "12345678901",
+              "a  ", "a \n", "  \n", "x  \n\n", "it'S 'LL 'ſ 'Ve", "$12 €3 £ -- — ―", "٣٤٥ ⅷ ² 12", "foo_bar1 baz", "ひらがな カタカナ 漢字 한글", "a b c",
+              "«quoted» “x” ‘y’", "±×÷ ^ ` ~", "́x ⃝", "end\n", "end  \n"]
     bad = 0
     for t in texts:
         b = t.encode("utf-8")
@@ -68,10 +86,11 @@ def test_split_bits_mark_chunks_and_gaps(sim):
 
 
 @pytest.mark.parametrize("pattern, what", [
-    (r"\w+", r"\w"), (r"\d+|\s+", r"\d"), (r"^a", "anchor"), (r"a$", "anchor"), (r"\bfoo", r"\b"), (r"(?<=a)b", "look-behind"),
-    (r"(a)\1", r"\1"), (r"a*+", "possessive"), (r"(?>a)", "atomic"), (r"\p{Nd}+", "Nd"), (r"\p{P}", "P}"), (r"[[:alpha:]]", "POSIX"),
+    (r"(?<=a)b", "look-behind"), (r"(a)\1", r"\1"), (r"\p{Han}+", "Han"), (r"\p{Greek}", "Greek"), (r"[[:alpha:]]", "POSIX"), (r"\Gx", r"\G"),
+    (r"a\Kb", r"\K"), (r"[\W]", r"\W inside"), (r"(?i:\p{Lu}+)", "under (?i)"), (r"(?i:[à-ÿ])", "non-ASCII"),
     (r"(a", "without )"), (r"a)", "unbalanced"), (r"[a", "without ]"), (r"a{5,2}", "n < m"), (r"(?i:é)", "non-ASCII literal"),
-    (r"a*", "empty string"), (r"(a|b*)c?", "empty string"), (r"(a*)*", "empty string"), (r"x{2000}", "beyond 1000"),
+    (r"a*", "empty string"), (r"(a|b*)c?", "empty string"), (r"(a*)*", "empty string"), (r"x{2000}", "beyond 1000"), (r"^", "empty string"),
+    (r"a|$", "empty string"), (r"\b+", "on an assertion"),
 ])
 def test_unsupported_constructs_are_named(sim, pattern, what):
     from hostsim import HostRegex

@@ -1,9 +1,11 @@
 """The product's host/device-shared code (spl_scan.h, spl_lookup.h, spl_tables.cpp) driven
 serially on the CPU by tests/hostsim (a TEST TOOL, g++-built) against the oracle: scanner closed
 forms, deferral contract at tiny windows, sync-point rules, table formats, the lane-serial merge."""
+import os
+
 import pytest
 
-from conftest import VOCABS
+from conftest import ROOT, VOCABS
 from fuzzgen import cased_corpus, fuzz_corpus, invalid_utf8_corpus, latin_corpus
 from hostsim import HostSim
 
@@ -149,3 +151,55 @@ def test_invalid_utf8_policy(coracle, name):
         for tb, rh in ((64, 32), (800, 192)):
             got, _ = h.split_starts(grp, tb, rh, 16)
             assert got == ref, (tb, rh, grp)
+
+
+def _post14_corpus(seed, n):
+    """Strings over code points the two shipped class tables DISAGREE on (assigned or re-categorised after Unicode 14,
+    U+180E) mixed with ordinary atoms: where "which Unicode" decides the split."""
+    import random
+    import struct
+    def load(fn):
+        b = open(os.path.join(ROOT, "splintr_amd", "data", fn), "rb").read()
+        sh, nb = struct.unpack_from("<II", b, 8)
+        n1 = 0x110000 >> sh
+        s1 = struct.unpack_from(f"<{n1}H", b, 32)
+        s2 = b[32 + n1 * 2:32 + n1 * 2 + (nb << sh)]
+        return lambda c: s2[(s1[c >> sh] << sh) | (c & ((1 << sh) - 1))]
+    a, r = load("unicode_classes.bin"), load("unicode_classes_regex.bin")
+    diff = [c for c in range(0x110000) if not 0xD800 <= c <= 0xDFFF and a(c) != r(c)]
+    assert len(diff) > 10000 and 0x180E in diff
+    rng = random.Random(seed)
+    pick = [0x180E] + rng.sample(diff, 400)
+    atoms = ["a", "B", " ", "  ", "\n", "1", "22", ".", "'s", "é", "你", "x y", "\t"]
+    out = []
+    for _ in range(n):
+        k = rng.randint(1, 12)
+        out.append("".join(chr(rng.choice(pick)) if rng.random() < 0.4 else rng.choice(atoms) for _ in range(k)))
+    return out
+
+
+@pytest.mark.parametrize("name", ["cl100k_base", "o200k_base"])
+def test_second_class_table_splits_as_its_engine(name):
+    """the class table is an ARGUMENT (spl_create's uclass_tab).  With the table probed from the Python
+    `regex` module the scanner must split exactly as that engine does -- also over the 14 186 code points on which it
+    disagrees with the default table (PCRE2 10.39 / Unicode 14.0) -- and with the default table as PCRE2 does."""
+    regex = pytest.importorskip("regex")
+    from hostsim import HostSim
+    from oracle import pyoracle as O
+    from splintr_amd import CL100K_BASE_PATTERN, O200K_BASE_PATTERN
+    pat = CL100K_BASE_PATTERN if name == "cl100k_base" else O200K_BASE_PATTERN
+    h_re = HostSim(name, "unicode_classes_regex.bin")
+    h_pc = HostSim(name)
+    texts = _post14_corpus(99, 1500)
+    differ = 0
+    for t in texts:
+        b = t.encode("utf-8")
+        want_re = [a for a, _ in O.split_regex(pat, t)]
+        assert h_re.split(b) == want_re, t
+        assert h_re.split_masks(b, 64, 32) == want_re, t
+        if O.pcre2_available():
+            want_pc = [a for a, _ in O.split_pcre2(pat, b)]
+            assert h_pc.split(b) == want_pc, t
+            differ += want_pc != want_re
+    if O.pcre2_available():
+        assert differ > 50          # the corpus does exercise the difference between the two tables

@@ -8,11 +8,18 @@ oracle's split engine applies (PCRE2 10.39 => Unicode 14.0.0).  Also probes whic
 caseless contraction letters ``(?i:s|t|r|e|v|m|l|d)`` match under UTF|UCP.
 
 Output: ``splintr_amd/data/unicode_classes.bin``
-    char[4] "SPLU" | u32 version=1 | u32 block_shift | u32 n_blocks | char[16] unicode_version
+    char[4] "SPLU" | u32 version=2 | u32 block_shift | u32 n_blocks | char[16] unicode_version
     u16 stage1[0x110000 >> block_shift]      block index per code-point block
     u8  stage2[n_blocks << block_shift]      class code per code point
     u32 n_fold | n_fold x { u32 code_point | u32 ascii_lower }   caseless partners of s,t,r,e,v,m,l,d
+    (version 2) u32 gc_n_blocks | u16 gc_stage1[0x110000 >> block_shift] | u8 gc_stage2[gc_n_blocks << block_shift]
+                the GENERAL CATEGORY of every code point (GC_NAMES), for the host splitter's \p{P} \p{S} \p{Z}
+                \p{Nd} ... \d (csrc/spl_regex.cpp); the GPU scanner only needs the classes above
 Class codes: see CLASS_NAMES (shared with splintr_amd/csrc/spl_scan.h).
+
+``--engine regex``: the same tables probed from the Python ``regex`` module instead (its Unicode version is newer than
+PCRE2 10.39's 14.0) -> ``unicode_classes_regex.bin``: the second table VERDICT r03 #8 asks for; the reference's default
+engine (regexr, Cargo.toml:41) ships tables of an unknown version, so a caller who knows better can choose.
 """
 import os
 import struct
@@ -24,6 +31,9 @@ from oracle.pyoracle import Pcre2Pattern, pcre2_versions  # noqa: E402
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "splintr_amd", "data")
 
 CLASS_NAMES = ["P", "AP", "SP", "WS", "NL", "N", "Lu", "Ll", "Lt", "Lm", "Lo", "M"]
+# general categories, code = index (csrc/spl_regex.cpp GC_*); Cn = everything no other category claims
+GC_NAMES = ["Cn", "Lu", "Ll", "Lt", "Lm", "Lo", "Mn", "Mc", "Me", "Nd", "Nl", "No", "Pc", "Pd", "Ps", "Pe", "Pi", "Pf", "Po",
+            "Sm", "Sc", "Sk", "So", "Zs", "Zl", "Zp", "Cc", "Cf", "Cs", "Co"]
 C = {n: i for i, n in enumerate(CLASS_NAMES)}
 BLOCK_SHIFT = 7
 
@@ -41,8 +51,17 @@ def all_codepoints_utf8():
     return data, offs
 
 
+ENGINE = "pcre2"
+
+
 def members(pattern, data, offs):
     s = set()
+    if ENGINE == "regex":
+        import regex
+        text = data.decode("utf-8")
+        for m in regex.finditer(pattern, text):
+            s.update(map(ord, m.group(0)))
+        return s
     for a, b in Pcre2Pattern(pattern).find_iter(data):
         o = a
         while o < b:
@@ -52,9 +71,31 @@ def members(pattern, data, offs):
     return s
 
 
+def two_stage(cls):
+    bs = 1 << BLOCK_SHIFT
+    blocks, stage1, stage2 = {}, [], bytearray()
+    for b in range(0x110000 >> BLOCK_SHIFT):
+        blk = bytes(cls[b * bs:(b + 1) * bs])
+        idx = blocks.get(blk)
+        if idx is None:
+            idx = blocks[blk] = len(blocks)
+            stage2 += blk
+        stage1.append(idx)
+    return stage1, stage2, len(blocks)
+
+
 def main():
-    ver, uver = pcre2_versions()
-    print("PCRE2", ver, "Unicode", uver)
+    global ENGINE
+    if "--engine" in sys.argv:
+        ENGINE = sys.argv[sys.argv.index("--engine") + 1]
+    if ENGINE == "regex":
+        import regex
+        import unicodedata
+        ver, uver = regex.__version__, "regex-" + regex.__version__[:9]
+        print("Python regex", ver, "(unicodedata of this interpreter:", unicodedata.unidata_version + ")")
+    else:
+        ver, uver = pcre2_versions()
+        print("PCRE2", ver, "Unicode", uver)
     data, offs = all_codepoints_utf8()
     sets = {k: members(p, data, offs) for k, p in {
         "Lu": r"\p{Lu}", "Ll": r"\p{Ll}", "Lt": r"\p{Lt}", "Lm": r"\p{Lm}", "Lo": r"\p{Lo}",
@@ -87,18 +128,29 @@ def main():
     cls[0x0D] = C["NL"]
     cls[0x27] = C["AP"]
 
-    bs = 1 << BLOCK_SHIFT
-    blocks = {}
-    stage1 = []
-    stage2 = bytearray()
-    for b in range(0x110000 >> BLOCK_SHIFT):
-        blk = bytes(cls[b * bs:(b + 1) * bs])
-        idx = blocks.get(blk)
-        if idx is None:
-            idx = blocks[blk] = len(blocks)
-            stage2 += blk
-        stage1.append(idx)
-    print(f"blocks: {len(blocks)} x {bs} B = {len(stage2)} B; stage1 {len(stage1) * 2} B")
+    stage1, stage2, nblocks = two_stage(cls)
+    print(f"blocks: {nblocks} x {1 << BLOCK_SHIFT} B = {len(stage2)} B; stage1 {len(stage1) * 2} B")
+
+    # general categories: one probe per category, runs of members per match
+    gc = bytearray(0x110000)
+    seen = set()
+    for code, name in enumerate(GC_NAMES):
+        if name in ("Cn", "Cs"):
+            continue                                   # (surrogates never occur in UTF-8; unassigned = the rest)
+        m = members(r"\p{%s}+" % name, data, offs)
+        assert not (m & seen), name
+        seen |= m
+        for cp in m:
+            gc[cp] = code
+    for cp in range(0xD800, 0xE000):
+        gc[cp] = GC_NAMES.index("Cs")
+    for grp, parts in (("L", ("Lu", "Ll", "Lt", "Lm", "Lo")), ("M", ("Mn", "Mc", "Me")), ("N", ("Nd", "Nl", "No"))):
+        u = set()
+        for nm in parts:
+            u |= {cp for cp in sets[grp] if gc[cp] == GC_NAMES.index(nm)}
+        assert u == sets[grp], grp                     # the class table and the categories agree
+    g1, g2, gnb = two_stage(gc)
+    print(f"general categories: {gnb} blocks = {len(g2)} B; unassigned (Cn): {sum(1 for cp in allcp if gc[cp] == 0)}")
 
     folds = []
     for ch in "stremvld":
@@ -107,13 +159,16 @@ def main():
             folds.append((cp, ord(ch)))
         print(f"(?i:{ch}) ->", [f"U+{c:04X}" for c in sorted(m)])
 
-    out = bytearray(struct.pack("<4sIII16s", b"SPLU", 1, BLOCK_SHIFT, len(blocks), uver.encode()))
+    out = bytearray(struct.pack("<4sIII16s", b"SPLU", 2, BLOCK_SHIFT, nblocks, uver.encode()[:16]))
     out += struct.pack(f"<{len(stage1)}H", *stage1)
     out += stage2
     out += struct.pack("<I", len(folds))
     for cp, lo in folds:
         out += struct.pack("<II", cp, lo)
-    path = os.path.join(OUT, "unicode_classes.bin")
+    out += struct.pack("<I", gnb)
+    out += struct.pack(f"<{len(g1)}H", *g1)
+    out += g2
+    path = os.path.join(OUT, "unicode_classes.bin" if ENGINE == "pcre2" else "unicode_classes_regex.bin")
     with open(path, "wb") as f:
         f.write(out)
     print("wrote", path, len(out), "B")
