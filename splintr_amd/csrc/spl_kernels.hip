@@ -2514,9 +2514,16 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
                     ts16 = s_ts[b0 >> 5] >> sh;
                     if (sh > 16) ts16 |= s_ts[(b0 >> 5) + 1] << (32 - sh);
                 }
-                wk = classify_word(T, KPAT, wi > 0 ? s_txt32[wi - 1] : 0u, tw, s_txt32[wi + 1], ts16,
-                                   [&](uint32_t c) { return s_kent[c]; }, [&](uint32_t c) { return (uint32_t)s_ascii[c]; },
-                                   ts4, sk4, i0, iB, Wv, w0 < 0 ? (int)-w0 : 0, iT);
+                const uint32_t wp = wi > 0 ? s_txt32[wi - 1] : 0u, wn = s_txt32[wi + 1];
+                const int lo_i = w0 < 0 ? (int)-w0 : 0;
+                // well-formed text away from every edge (an accented letter, a dash, CJK): the lean form; else the general one
+                bool done = false;
+                if (sk4 == 0u && i0 + 3 < iB && i0 >= lo_i)
+                    done = classify_word_text(T, KPAT, wp, tw, wn, ts16, [&](uint32_t c) { return s_aent[c]; },
+                                              [&](uint32_t c) { return s_kent[c]; }, i0, lo_i, iT, wk);
+                if (!done)
+                    wk = classify_word(T, KPAT, wp, tw, wn, ts16, [&](uint32_t c) { return s_kent[c]; },
+                                       [&](uint32_t c) { return (uint32_t)s_ascii[c]; }, ts4, sk4, i0, iB, Wv, lo_i, iT);
             }
             s_rec32[wi] = wk.rec;
         }

@@ -199,4 +199,96 @@ SPL_HD WordKinds classify_word(const DeviceTables& T, int pattern, uint32_t wp, 
     return o;
 }
 
+// the four byte flags x & 0x80808080 as a 4-bit mask (bit k = byte k)
+SPL_HD uint32_t flags4(uint32_t x) { return (((x >> 7) & 0x01010101u) * 0x00204081u >> 21) & 0xFu; }
+// a 4-bit mask spread to the bytes of a word: bit k -> 0x01 in byte k
+SPL_HD uint32_t spread4(uint32_t m4) { return (m4 * 0x00204081u) & 0x01010101u; }
+
+// The COMMON word beyond ASCII: well-formed UTF-8, away from every edge -- an accented letter, a dash, a run of CJK.  The
+// general path above decides each of its five byte slots on its own (every one a lead byte? a continuation byte of what?),
+// nine hundred instructions that every wavefront with ONE such word walks through; here the word is taken as what it
+// nearly always is: ASCII bytes from the table, plus at most three whole characters -- the one the word begins inside
+// (A) and up to two that start in it (B, C).  Anything else -- a text start or an edge within three bytes, a stray
+// continuation byte, an incomplete character -- returns false, and the caller takes the general path: same results,
+// checked against each other on every window of the host simulation's corpora (tests/hostsim).
+//   precondition (caller): no special-literal span in the word, i0 + 3 < iB, i0 >= lo
+//   aent(b): the ASCII table entry of byte b < 0x80 (ascii_entry); kent(c): kind_entry of class c
+template <class AENT, class KENT>
+SPL_HD bool classify_word_text(const DeviceTables& T, int pattern, uint32_t wp, uint32_t tw, uint32_t wn, uint32_t ts16, const AENT& aent,
+                               const KENT& kent, int i0, int lo, int iT, WordKinds& o) {
+    if (((ts16 >> 1) & 0x3FFu) != 0u || i0 - 3 < lo || i0 + 7 > iT) return false;    // window indices i0 - 3 .. i0 + 6: one text, all staged
+    const uint32_t hi_t = tw & 0x80808080u, lead_t = tw & (tw << 1) & 0x80808080u;
+    const uint32_t non4 = flags4(hi_t), lead4 = flags4(lead_t);
+    const uint32_t lead_p = flags4(wp & (wp << 1) & 0x80808080u), cont_p = flags4(wp & ~(wp << 1) & 0x80808080u);
+    // the (at most three) characters: first own byte offset (A: negative), the word that holds the lead in byte 0
+    uint32_t dist = 0;                                          // A: lead `dist` bytes before the word
+    if (non4 & ~lead4 & 1u) {
+        dist = (lead_p & 8u) ? 1u : ((cont_p & 8u) && (lead_p & 4u)) ? 2u : ((cont_p & 12u) == 12u && (lead_p & 2u)) ? 3u : 0u;
+        if (!dist) return false;
+    }
+    const uint32_t k1 = lead4 ? (uint32_t)ctz32(lead4) : 0u;
+    const uint32_t rest = lead4 & (lead4 - 1u);
+    const uint32_t k2 = rest ? (uint32_t)ctz32(rest) : 0u;
+    if (rest & (rest - 1u)) return false;                       // three lead bytes in four: no well-formed text
+    const bool hasA = dist != 0u, hasB = lead4 != 0u, hasC = rest != 0u;
+    const ByteDec dA = lead_decode(bytes_at(wp, tw, 4u - dist), 0u, 0, 1 << 20);
+    const ByteDec dB = lead_decode(bytes_at(tw, wn, k1), 0u, 0, 1 << 20);
+    const ByteDec dC = lead_decode(bytes_at(tw, wn, k2), 0u, 0, 1 << 20);
+    if ((hasA && !dA.need) || (hasB && !dB.need) || (hasC && !dC.need)) return false;
+    const uint32_t lenA = (dA.rec >> CB_LEN_SHIFT) + 1u, lenB = (dB.rec >> CB_LEN_SHIFT) + 1u, lenC = (dC.rec >> CB_LEN_SHIFT) + 1u;
+    if (hasA && lenA <= dist) return false;                     // (the lead before the word does not reach it)
+    const uint32_t mA = hasA ? ((1u << (lenA - dist)) - 1u) & 0xFu : 0u;
+    const uint32_t mB = hasB ? (((1u << lenB) - 1u) << k1) & 0xFu : 0u;
+    const uint32_t mC = hasC ? (((1u << lenC) - 1u) << k2) & 0xFu : 0u;
+    if ((mA | mB | mC) != non4 || (mA & mB) || (mB & mC) || (mA & mC)) return false;     // every byte beyond ASCII belongs to exactly one of them
+    // their classes: the lookups of the word in flight together
+    uint32_t cls[3];
+    const uint32_t cp[3] = {dA.cp, dB.cp, dC.cp};
+    const bool has[3] = {hasA, hasB, hasC};
+    bool lk[3], any = false;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const bool cjk = T.cjk_fast && ((cp[j] - 0x4E00u) < 0x5200u || (cp[j] - 0xAC00u) < 0x2BA4u);
+        cls[j] = cjk ? (uint32_t)C_LO : (uint32_t)C_P;
+        lk[j] = has[j] && !cjk && cp[j] < 0x110000u;
+        any = any || lk[j];
+    }
+    if (any) {
+        const uint32_t sh = T.ucls_shift, lowm = (1u << sh) - 1u;
+        uint32_t blk[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) blk[j] = T.ucls_stage1[lk[j] ? cp[j] >> sh : 0u];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const uint32_t c = T.ucls_stage2[(blk[j] << sh) | (lk[j] ? cp[j] & lowm : 0u)];
+            cls[j] = lk[j] ? c : cls[j];
+        }
+    }
+    // the ASCII bytes from the table (the other bytes' entries masked out)
+    const KindEnt e0 = aent(tw & 0x7Fu), e1 = aent((tw >> 8) & 0x7Fu), e2 = aent((tw >> 16) & 0x7Fu), e3 = aent((tw >> 24) & 0x7Fu);
+    const uint32_t asc4 = ~non4 & 0xFu, ascn = asc4 * 0x11111111u, ascb = spread4(asc4) * 0xFFu;
+    o.v0 = (e0.x | (e1.x << 1) | (e2.x << 2) | (e3.x << 3)) & ascn;
+    o.v1 = (e0.y | (e1.y << 1) | (e2.y << 2) | (e3.y << 3)) & ascn & 0x00FFFFFFu;
+    o.rec = ((e0.y >> 28) | ((e1.y >> 28) << 8) | ((e2.y >> 28) << 16) | ((e3.y >> 28) << 24)) & ascb;
+    // the characters: every byte the kinds of its character; BAD for all bytes of a multi-byte number / whitespace / (o200k
+    // family) mark; CS and the record's class and length on the lead byte, C_CONT on the others
+    const uint32_t mm[3] = {mA, mB, mC}, kk[3] = {0u, k1, k2};
+    const uint32_t lrec[3] = {0u, dB.rec, dC.rec};
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const uint32_t c = cls[j];
+        const KindEnt e = kent(c);
+        const bool bad = !(SPL_BIT(c) & (M_L | M_OTHER)) || (pattern != PAT_CL100K && c == C_M);
+        o.v0 |= e.x * mm[j];
+        o.v1 |= (e.y | (bad ? V1_BAD : 0u)) * mm[j];
+        uint32_t r = spread4(mm[j]) * (uint32_t)C_CONT;
+        if (j > 0 && has[j]) {
+            o.v1 |= V1_CS << kk[j];
+            r = (r & ~(0xFFu << (8u * kk[j]))) | ((lrec[j] | c) << (8u * kk[j]));
+        }
+        o.rec |= r;
+    }
+    return true;
+}
+
 }  // namespace spl

@@ -346,7 +346,7 @@ extern "C" int hs_split_starts(void* p, const uint8_t* text, int n, const int* d
     }
     std::vector<uint8_t> mark(n + 1, 0);
     const int LHv = 32;
-    uint32_t n_tiles = 0, n_fast = 0, n_nofe = 0, n_bad = 0, n_iter = 0;
+    uint32_t n_tiles = 0, n_fast = 0, n_nofe = 0, n_bad = 0, n_iter = 0, n_lean = 0, n_general = 0;
     for (int t0 = 0; t0 < n; t0 += tb) {
         n_tiles++;
         const int w0 = t0 - LHv;
@@ -418,8 +418,14 @@ extern "C" int hs_split_starts(void* p, const uint8_t* text, int n, const int* d
                     auto word = [&](int wj) { uint32_t x = 0; if (wj >= 0) for (int k = 0; k < 4; k++) x |= (uint32_t)wtxt[wj * 4 + k] << (8 * k); return x; };
                     uint32_t ts16 = 0;
                     for (int d2 = 0; d2 < 16; d2++) if (i0 - 4 + d2 >= 0 && tsbit(i0 - 4 + d2)) ts16 |= 1u << d2;
-                    wk = classify_word(s->dt, pat, word(wi - 1), tw, word(wi + 1), ts16, [&](uint32_t c) { return kent[c]; },
-                                       [&](uint32_t c) { return cp_class(s->dt, c); }, ts4, 0u, i0, iB, W, lo, iT);
+                    bool done = false;
+                    if (i0 + 3 < iB && i0 >= lo)
+                        done = classify_word_text(s->dt, pat, word(wi - 1), tw, word(wi + 1), ts16, [&](uint32_t c) { return aent[c]; },
+                                                  [&](uint32_t c) { return kent[c]; }, i0, lo, iT, wk);
+                    n_lean += done; n_general += (!done && (tw & 0x80808080u)) ? 1 : 0;
+                    if (!done)
+                        wk = classify_word(s->dt, pat, word(wi - 1), tw, word(wi + 1), ts16, [&](uint32_t c) { return kent[c]; },
+                                           [&](uint32_t c) { return cp_class(s->dt, c); }, ts4, 0u, i0, iB, W, lo, iT);
                 }
                 for (int k = 0; k < 4; k++) {
                     const int i = i0 + k;
@@ -517,7 +523,7 @@ extern "C" int hs_split_starts(void* p, const uint8_t* text, int n, const int* d
             }
         }
     }
-    if (stats) { stats[0] = n_tiles; stats[1] = n_fast; stats[2] = n_nofe; stats[3] = n_bad; stats[4] = n_iter; }
+    if (stats) { stats[0] = n_tiles; stats[1] = n_fast; stats[2] = n_nofe; stats[3] = n_bad; stats[4] = n_iter; stats[5] = n_lean; stats[6] = n_general; }
     int k = 0;
     for (int q = 0; q < n; q++) if (mark[q]) starts[k++] = q;
     return k;

@@ -111,7 +111,7 @@ class HostSim:
         off = np.zeros(len(docs) + 1, dtype=np.int32)
         off[1:] = np.cumsum([len(d) for d in docs])
         out = np.zeros(len(data) + 1, dtype=np.uint32)
-        st = np.zeros(5, dtype=np.uint32)
+        st = np.zeros(7, dtype=np.uint32)
         k = lib().hs_split_starts(self._h, data, len(data), off.ctypes.data, len(docs), out.ctypes.data, tb, rh, max_iter,
                                   st.ctypes.data)
         if k < 0:
