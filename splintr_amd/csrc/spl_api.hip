@@ -314,8 +314,8 @@ int upload_tables(Ctx& c, const HostTables& ht) {
     c.dt.ascii_base = (uint32_t)ht.ucls_stage1[0] << ht.ucls_shift;
     c.dt.cjk_fast = ht.cjk_fast ? 1u : 0u;
     c.dt.short_mask = (uint32_t)(ht.short_tab.size() / SPL_SHORT_BUCKET) - 1;
-    c.dt.tiny_mask = (uint32_t)(ht.tiny_tab.size() / (SPL_TINY_BUCKET * 2)) - 1;
-    c.dt.t8_mask = (uint32_t)(ht.t8_tab.size() / SPL_T8_WORDS) - 1;
+    c.dt.tiny_mask = (uint32_t)((ht.tiny_tab.size() - 4) / SPL_TINY_WORDS) - 1;      // (slots; 4 words of padding behind them)
+    c.dt.t8_mask = (uint32_t)((ht.t8_tab.size() - 4) / SPL_T8_WORDS) - 1;
     c.dt.long_mask = (uint32_t)ht.long_tab.size() - 1;
     c.dt.pair_mask = (uint32_t)(ht.pair_tab.size() / SPL_PAIR_BUCKET) - 1;
     c.dt.p8_mask = (uint32_t)(ht.p8_tab.size() / 2) - 1;

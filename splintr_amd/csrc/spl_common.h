@@ -66,19 +66,24 @@ struct ShortEnt {            // 16 B
     uint32_t id_len;         // id | len << 24 ; 0xFFFFFFFF = empty slot
 };
 constexpr int SPL_SHORT_BUCKET = 4;                     // entries per 64-byte bucket (one cache line)
-// Keys of up to 8 bytes -- nearly every probe of the hot path (whole chunks of a few bytes, the
-// substring tabulation of the merge loops) -- have two smaller tables of their own, so that those
-// probes move fewer bytes, need fewer registers and stay resident in L2:
-//   tiny table: keys of 1..4 bytes, 8-byte entries {key, id | len << 24}, buckets of 4 = 32 bytes
-//   t8 table  : keys of 5..8 bytes, 12-byte entries {k0, k1, id | len << 24}, 4 per 64-byte bucket
-//               (48 bytes used: three dwordx4 loads)
-// Same bucket discipline as the short table (fill left to right, never delete; SPL_OVF_BIT in the last
-// slot's id word == a key went on from this full bucket).  The short table keeps the keys of 9..12 bytes.
-constexpr int SPL_TINY_BUCKET = 4;                      // entries per 32-byte bucket
+// Keys of up to 8 bytes -- nearly every probe of the hot path (whole chunks of a few bytes, the substring tabulation of
+// the merge loops) -- have two tables of their own with ONE ENTRY PER SLOT (round 4): the builder places every key
+// in a slot of its own (a perfect hash by displacement: groups of keys share a salt that is chosen so that none of
+// them collides with anything placed before), so a probe loads exactly one entry -- 8 or 12 bytes instead of a
+// 32- / 48-byte bucket of four -- and compares once.  The tile kernel was bound, in its probe and merge phases, by the
+// rate at which a CU takes scattered load addresses and by instruction issue; both fall with the bytes and compares
+// per probe (profiles/r04_single_slot_tables.txt).
+//   tiny table: keys of 1..4 bytes, entries {key, id | len << 24}; slot = hash_tiny(key, len, salt) & tiny_mask with
+//               the salt of the key's first two bytes (16 bits, PfxEnt::lm >> 16)
+//   t8 table  : keys of 5..8 bytes, entries {k0, k1, id | len << 24} (12 bytes, packed); slot = hash_t8(..., salt) with
+//               the salt of the key's first FOUR bytes (10 bits, in the four-byte-prefix filter's entry: filt4 >> 6)
+// An empty slot is all-ones (its length byte, 0xFF, equals no key length).  The short table keeps the keys of 9..12 bytes
+// in buckets of four with the 8-bit salt of round 2.
+constexpr int SPL_TINY_WORDS = 2;                       // u32 words per tiny entry
 constexpr int SPL_TINY_MAX = 4;
-constexpr int SPL_T8_BUCKET = 4;                        // entries per 64-byte bucket
-constexpr int SPL_T8_WORDS = 16;                        // u32 words per bucket (12 used)
+constexpr int SPL_T8_WORDS = 3;                         // u32 words per t8 entry
 constexpr int SPL_T8_MAX = 8;
+constexpr int SPL_TINY_SALT_BITS = 16, SPL_T8_SALT_BITS = 10, SPL_F4_MASK_BITS = 6;
 // Long-key table: 13..max_key_len bytes; key bytes live in a 4-byte-aligned blob.
 struct LongEnt {             // 16 B
     uint32_t tag;            // second hash, filters almost every false candidate
@@ -96,13 +101,14 @@ constexpr int SPL_PAIR_BUCKET = 4;
 constexpr uint32_t SPL_ID_BITS = 21;
 constexpr uint32_t SPL_ID_MASK = (1u << SPL_ID_BITS) - 1;
 constexpr uint32_t SPL_NO_RANK = 0xFFFFFFFFu;
-// tiny / t8 / short tables, id word (id | len << 24) of a bucket's LAST slot: a key went on from this
-// (full) bucket to the next one.  Without it a probe that misses is settled by this bucket alone.
+// short table, id word (id | len << 24) of a bucket's LAST slot: a key went on from this (full) bucket to the next
+// one.  Without it a probe that misses is settled by this bucket alone.
 constexpr uint32_t SPL_OVF_BIT = 1u << 23;
 
 struct P8Bucket { uint32_t a, b; };
 // Prefix table entry (one dwordx2 load): what the first TWO bytes of a key say about it.
-//   lm : low byte = length mask, next byte = salt (exactly DeviceTables::len_mask's entry);
+//   lm : low byte = length mask, next byte = salt of the short table (exactly DeviceTables::len_mask's entry), upper half =
+//        salt of the tiny table for the keys that begin with these two bytes;
 //   id2: the id of the token that IS those two bytes, or SPL_NO_RANK -- a two-byte key needs no bucket probe at all.
 struct alignas(8) PfxEnt { uint32_t lm, id2; };
 
@@ -114,7 +120,7 @@ struct DeviceTables {
     uint32_t cjk_fast;        // 1 if U+4E00..U+9FFF and U+AC00..U+D7A3 are uniformly C_LO
     // vocabulary
     const ShortEnt* short_tab; uint32_t short_mask;   // masks index BUCKETS
-    const uint32_t* tiny_tab;  uint32_t tiny_mask;
+    const uint32_t* tiny_tab;  uint32_t tiny_mask;      // masks index SLOTS (one entry each)
     const uint32_t* t8_tab;    uint32_t t8_mask;
     const LongEnt* long_tab;   uint32_t long_mask;
     const uint8_t* key_blob;
@@ -135,8 +141,8 @@ struct DeviceTables {
     // may be full; SPL_OVF_BIT alone says whether anything went on from it): a probe then never
     // needs a second bucket, hit or miss (a wavefront waits for its slowest lane; with plain hashing
     // 2-7 % of the buckets were full and nearly every wavefront had a lane that went on to the next).
-    // tiny_free / t8_free: a bucket of each table with a free slot -- where probes known to miss are
-    // sent (one cache line for all of them).
+    // tiny_free / t8_free: an EMPTY slot of each table -- where probes known to miss are sent (one cache line for
+    // all of them).
     const uint16_t* len_mask;  uint32_t tiny_free, t8_free;
     uint32_t ascii_base;      // ucls_stage1[0] << ucls_shift: where the classes of U+0000..U+007F start in ucls_stage2
     // pfx[b0 | b1 << 8]: len_mask's entry and the id of the two-byte token in one 8-byte load (the substring
@@ -147,7 +153,8 @@ struct DeviceTables {
     // lengths exist behind " t" -- all of them; the filter says which exist behind " tzq" -- none: 60 % of the
     // 5..8-byte probes of the substring tabulation (C2's missed chunks) are never issued.
     const PfxEnt* pfx;
-    const uint8_t* filt4;     uint32_t filt4_shift;
+    // (round 4: 16-bit entries -- the six length bits below, the t8 table's salt for keys with these four bytes above)
+    const uint16_t* filt4;    uint32_t filt4_shift;
 };
 SPL_HD uint32_t hash_f4(uint32_t w0) { return w0 * 0x9E3779B1u; }      // (index = the upper bits: >> filt4_shift)
 

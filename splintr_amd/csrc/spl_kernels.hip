@@ -580,51 +580,33 @@ __device__ __forceinline__ void bpe_group16(const DeviceTables& T, int n, ByteAt
 // three tables, and a wavefront's lanes hold a mix of them.  All lanes first issue their bucket
 // loads (two quads always, a third / fourth by class -- predicated loads, no wait in between),
 // then compare by class; the wavefront pays ONE memory round trip instead of one per class.
+#ifndef SPL_ROW_FILTER
+#define SPL_ROW_FILTER 1
+#endif
+struct alignas(8) Ent2 { uint32_t x, y; };              // one tiny-table entry (dwordx2)
+struct alignas(4) Ent3 { uint32_t x, y, z; };           // one t8-table entry (dwordx3, packed at 12-byte stride)
 __device__ __forceinline__ uint32_t probe_short_mixed(const DeviceTables& T, uint32_t k0, uint32_t k1, uint32_t k2,
                                                       uint32_t n) {
     const bool tiny = n <= (uint32_t)SPL_TINY_MAX, t8 = !tiny && n <= (uint32_t)SPL_T8_MAX;
-    // the key's two-byte prefix: which token lengths exist behind it at all (no probe for the others)
-    // and the salt of its bucket hashes
+    // ONE round trip for what depends on the text alone: the key's two-byte prefix -- which token lengths exist behind it at
+    // all (no probe for the others), the salts of its tiny / short hashes, the two-byte token's id -- and the filter entry
+    // of its first four bytes (lengths 4..8 and "longer" that exist behind THOSE, and the salt of its t8 hash)
     const PfxEnt pe = T.pfx[k0 & 0xFFFFu];
-    const uint32_t lm = pe.lm, salt = lm >> 8;
+    const uint32_t f4 = T.filt4[hash_f4(k0) >> T.filt4_shift];
+    const uint32_t lm = pe.lm;
     if (n >= 2u && !((lm >> (n <= (uint32_t)SPL_T8_MAX ? n - 2u : 7u)) & 1u)) return SPL_NO_RANK;
-    if (n == 2u) return pe.id2;                  // the prefix entry carries the two-byte token's id: no bucket to read
-    // (one-byte chunks from the 1 KB byte table instead of the tiny table, loaded in the prefix entries' round trip:
-    //  measured, no faster -- 34.9 against 34.9 us on C2, 50.8 against 50.3 on c2_wide)
-    const uint32_t h = tiny ? hash_tiny(k0, n, salt) : t8 ? hash_t8(k0, k1, n, salt) : hash_short(k0, k1, k2, n, salt);
-    const Quad* src = tiny ? reinterpret_cast<const Quad*>(T.tiny_tab + (size_t)(h & T.tiny_mask) * (SPL_TINY_BUCKET * 2))
-                    : t8   ? reinterpret_cast<const Quad*>(T.t8_tab + (size_t)(h & T.t8_mask) * SPL_T8_WORDS)
-                           : reinterpret_cast<const Quad*>(T.short_tab + (size_t)(h & T.short_mask) * SPL_SHORT_BUCKET);
-    Quad q0 = src[0], q1 = src[1], q2 = Quad{0, 0, 0, 0}, q3 = Quad{0, 0, 0, 0};
-    if (!tiny) q2 = src[2];
-    if (!tiny && !t8) q3 = src[3];
-    uint32_t r = SPL_NO_RANK;
-    bool settled;
-    if (tiny) {
-        const bool f0 = (q0.x == k0) & ((q0.y >> 24) == n), f1 = (q0.z == k0) & ((q0.w >> 24) == n);
-        const bool f2 = (q1.x == k0) & ((q1.y >> 24) == n), f3 = (q1.z == k0) & ((q1.w >> 24) == n);
-        r = f3 ? (q1.w & SPL_ID_MASK) : r; r = f2 ? (q1.y & SPL_ID_MASK) : r;
-        r = f1 ? (q0.w & SPL_ID_MASK) : r; r = f0 ? (q0.y & SPL_ID_MASK) : r;
-        settled = (f0 | f1 | f2 | f3) | !bucket_overflowed(q1.w);
-    } else if (t8) {
-        const bool f0 = (q0.x == k0) & (q0.y == k1) & ((q0.z >> 24) == n);
-        const bool f1 = (q0.w == k0) & (q1.x == k1) & ((q1.y >> 24) == n);
-        const bool f2 = (q1.z == k0) & (q1.w == k1) & ((q2.x >> 24) == n);
-        const bool f3 = (q2.y == k0) & (q2.z == k1) & ((q2.w >> 24) == n);
-        r = f3 ? (q2.w & SPL_ID_MASK) : r; r = f2 ? (q2.x & SPL_ID_MASK) : r;
-        r = f1 ? (q1.y & SPL_ID_MASK) : r; r = f0 ? (q0.z & SPL_ID_MASK) : r;
-        settled = (f0 | f1 | f2 | f3) | !bucket_overflowed(q2.w);
-    } else {
-        const bool f0 = (q0.x == k0) & (q0.y == k1) & (q0.z == k2) & ((q0.w >> 24) == n);
-        const bool f1 = (q1.x == k0) & (q1.y == k1) & (q1.z == k2) & ((q1.w >> 24) == n);
-        const bool f2 = (q2.x == k0) & (q2.y == k1) & (q2.z == k2) & ((q2.w >> 24) == n);
-        const bool f3 = (q3.x == k0) & (q3.y == k1) & (q3.z == k2) & ((q3.w >> 24) == n);
-        r = f3 ? (q3.w & SPL_ID_MASK) : r; r = f2 ? (q2.w & SPL_ID_MASK) : r;
-        r = f1 ? (q1.w & SPL_ID_MASK) : r; r = f0 ? (q0.w & SPL_ID_MASK) : r;
-        settled = (f0 | f1 | f2 | f3) | !bucket_overflowed(q3.w);
+    if (n == 2u) return pe.id2;                  // the prefix entry carries the two-byte token's id: no table to read
+    if (SPL_ROW_FILTER && n >= 4u && !((f4 >> (n <= (uint32_t)SPL_T8_MAX ? n - 4u : 5u)) & 1u)) return SPL_NO_RANK;
+    if (tiny || t8) {
+        // one entry, one compare (the builder gave every key a slot of its own)
+        const uint32_t* e = tiny ? T.tiny_tab + (size_t)(hash_tiny(k0, n, lm >> 16) & T.tiny_mask) * SPL_TINY_WORDS
+                                 : T.t8_tab + (size_t)(hash_t8(k0, k1, n, f4 >> SPL_F4_MASK_BITS) & T.t8_mask) * SPL_T8_WORDS;
+        const Ent3 q = *reinterpret_cast<const Ent3*>(e);          // (a tiny entry and the first word of the next one: the tables are padded)
+        const uint32_t idw = tiny ? q.y : q.z;
+        const bool hit = (q.x == k0) & (tiny | (q.y == k1)) & ((idw >> 24) == n);
+        return hit ? (idw & SPL_ID_MASK) : SPL_NO_RANK;
     }
-    if (SPL_NO_SLOWPATH || settled) return r;
-    return probe_short(T, k0, k1, k2, n, salt); // home bucket full without a match (never with salted tables): generic probe
+    return probe_short12(T, k0, k1, k2, n, (lm >> 8) & 0xFFu);
 }
 template <class TX>
 __device__ __forceinline__ uint32_t probe_chunk_tile(const DeviceTables& T, const TX& tx, int p, int n) {
@@ -659,41 +641,19 @@ constexpr int SUB_W = SUB_LMAX - 1;          // table width: lengths 2..8
 #else
 #define SPL_FILL_ON(on) (on)
 #endif
-__device__ __forceinline__ void tiny_issue_if(const DeviceTables& T, bool on, uint32_t k0, uint32_t n, uint32_t salt, Quad (&q)[2]) {
-    const uint32_t bkt = SPL_FILL_ON(on) ? hash_tiny(k0, n, salt) & T.tiny_mask : T.tiny_free;
-    const Quad* src = reinterpret_cast<const Quad*>(T.tiny_tab + (size_t)bkt * (SPL_TINY_BUCKET * 2));
-    q[0] = src[0]; q[1] = src[1];
+__device__ __forceinline__ void tiny_issue_if(const DeviceTables& T, bool on, uint32_t k0, uint32_t n, uint32_t salt, Ent2& q) {
+    const uint32_t slot = SPL_FILL_ON(on) ? hash_tiny(k0, n, salt) & T.tiny_mask : T.tiny_free;
+    q = *reinterpret_cast<const Ent2*>(T.tiny_tab + (size_t)slot * SPL_TINY_WORDS);
 }
-__device__ __forceinline__ void t8_issue_if(const DeviceTables& T, bool on, uint32_t k0, uint32_t k1, uint32_t n, uint32_t salt, Quad (&q)[3]) {
-    const uint32_t bkt = SPL_FILL_ON(on) ? hash_t8(k0, k1, n, salt) & T.t8_mask : T.t8_free;
-    const Quad* src = reinterpret_cast<const Quad*>(T.t8_tab + (size_t)bkt * SPL_T8_WORDS);
-    q[0] = src[0]; q[1] = src[1]; q[2] = src[2];
+__device__ __forceinline__ void t8_issue_if(const DeviceTables& T, bool on, uint32_t k0, uint32_t k1, uint32_t n, uint32_t salt, Ent3& q) {
+    const uint32_t slot = SPL_FILL_ON(on) ? hash_t8(k0, k1, n, salt) & T.t8_mask : T.t8_free;
+    q = *reinterpret_cast<const Ent3*>(T.t8_tab + (size_t)slot * SPL_T8_WORDS);
 }
-__device__ __forceinline__ uint32_t tiny_finish(const DeviceTables& T, uint32_t k0, uint32_t n, uint32_t salt, const Quad (&q)[2]) {
-    const bool f0 = (q[0].x == k0) & ((q[0].y >> 24) == n);
-    const bool f1 = (q[0].z == k0) & ((q[0].w >> 24) == n);
-    const bool f2 = (q[1].x == k0) & ((q[1].y >> 24) == n);
-    const bool f3 = (q[1].z == k0) & ((q[1].w >> 24) == n);
-    uint32_t r = SPL_NO_RANK;
-    r = f3 ? (q[1].w & SPL_ID_MASK) : r;
-    r = f2 ? (q[1].y & SPL_ID_MASK) : r;
-    r = f1 ? (q[0].w & SPL_ID_MASK) : r;
-    r = f0 ? (q[0].y & SPL_ID_MASK) : r;
-    if (SPL_NO_SLOWPATH || ((f0 | f1 | f2 | f3) | !bucket_overflowed(q[1].w))) return r;
-    return probe_tiny(T, k0, n, salt);         // home bucket full without a match (never with salted tables): generic probe
+__device__ __forceinline__ uint32_t tiny_finish(uint32_t k0, uint32_t n, const Ent2& q) {
+    return (q.x == k0) & ((q.y >> 24) == n) ? (q.y & SPL_ID_MASK) : SPL_NO_RANK;
 }
-__device__ __forceinline__ uint32_t t8_finish(const DeviceTables& T, uint32_t k0, uint32_t k1, uint32_t n, uint32_t salt, const Quad (&q)[3]) {
-    const bool f0 = (q[0].x == k0) & (q[0].y == k1) & ((q[0].z >> 24) == n);
-    const bool f1 = (q[0].w == k0) & (q[1].x == k1) & ((q[1].y >> 24) == n);
-    const bool f2 = (q[1].z == k0) & (q[1].w == k1) & ((q[2].x >> 24) == n);
-    const bool f3 = (q[2].y == k0) & (q[2].z == k1) & ((q[2].w >> 24) == n);
-    uint32_t r = SPL_NO_RANK;
-    r = f3 ? (q[2].w & SPL_ID_MASK) : r;
-    r = f2 ? (q[2].x & SPL_ID_MASK) : r;
-    r = f1 ? (q[1].y & SPL_ID_MASK) : r;
-    r = f0 ? (q[0].z & SPL_ID_MASK) : r;
-    if (SPL_NO_SLOWPATH || ((f0 | f1 | f2 | f3) | !bucket_overflowed(q[2].w))) return r;
-    return probe_t8(T, k0, k1, n, salt);
+__device__ __forceinline__ uint32_t t8_finish(uint32_t k0, uint32_t k1, uint32_t n, const Ent3& q) {
+    return (q.x == k0) & (q.y == k1) & ((q.z >> 24) == n) ? (q.z & SPL_ID_MASK) : SPL_NO_RANK;
 }
 
 // The merge loop of one 16-lane group over `n` <= 16 nodes whose substring ids are tabulated: lane
@@ -807,24 +767,51 @@ __device__ __forceinline__ void group16_merge(const DeviceTables& T, const uint3
 // lane's first two bytes -- length mask, salt, the id of the two-byte token (no probe for length 2) -- and the
 // four-byte-prefix filter, which takes the lengths 4..8 (and "longer") that no token with these four bytes has
 // out of the mask: their probes go to the spare bucket like those of the lengths the two-byte prefix rules out.
-#ifndef SPL_ROW_FILTER
-#define SPL_ROW_FILTER 1
-#endif
-struct RowHead { uint32_t lm, id2; };
+struct RowHead { uint32_t lm, id2, tsalt, fsalt; };     // lm: the length mask (low byte); tsalt / fsalt: salts of the tiny / t8 hashes
 __device__ __forceinline__ RowHead row_head(const DeviceTables& T, bool own, uint32_t w0, int maxlen) {
-    RowHead h{0u, SPL_NO_RANK};
+    RowHead h{0u, SPL_NO_RANK, 0u, 0u};
     if (own) {
         const PfxEnt pe = T.pfx[w0 & 0xFFFFu];
-        uint32_t f4 = 0x3Fu;
-        if (SPL_ROW_FILTER) f4 = maxlen >= 4 ? (uint32_t)T.filt4[hash_f4(w0) >> T.filt4_shift] : 0u;
-        h.lm = pe.lm & (0xFF03u | (f4 << 2));
+        const uint32_t f = maxlen >= 4 ? (uint32_t)T.filt4[hash_f4(w0) >> T.filt4_shift] : 0u;
+        const uint32_t f4 = SPL_ROW_FILTER ? f & 0x3Fu : (maxlen >= 4 ? 0x3Fu : 0u);
+        h.lm = pe.lm & 0xFFu & (0x03u | (f4 << 2));
         h.id2 = pe.id2;
+        h.tsalt = pe.lm >> 16;
+        h.fsalt = f >> SPL_F4_MASK_BITS;
     }
     return h;
 }
-// Tabulation of ONE table row: the lane probes the ids of text[pos, pos + len), len = 2 .. min(rem, 8), in two
-// batches whose bucket loads are all in flight together, into `row`; returns the id of its byte and, in
-// far_max, the longest token of more than 8 bytes that can start there (p8 bound).  `own` false: idle lane.
+// The ids of text[pos, pos + len), len = 2..8, of one table row: ALL six probes in flight together -- one entry each
+// (round 4; up to round 3 two batches of buckets, a dependent round trip apart, for want of registers).  r[len - 2];
+// lengths the masks rule out, or beyond maxlen, read the table's empty slot (one cache line for all such lanes) and
+// give SPL_NO_RANK.  maxlen < 2: nothing is loaded.
+__device__ __forceinline__ void row_fill(const DeviceTables& T, const RowHead& rh, uint32_t w0, uint32_t w1, int maxlen, uint32_t (&r)[7]) {
+#pragma unroll
+    for (int k = 0; k < 7; k++) r[k] = SPL_NO_RANK;
+    // (ONE predicate for the six probes: with one per length the compiler waits after every single probe instead of
+    //  keeping all the loads in flight together)
+    if (maxlen >= 2) {
+        const uint32_t lm = rh.lm, k3 = w0 & 0xFFFFFFu, h5 = w1 & 0xFFu, h6 = w1 & 0xFFFFu, h7 = w1 & 0xFFFFFFu;
+        Ent2 q3, q4;
+        Ent3 q5, q6, q7, q8;
+        tiny_issue_if(T, (lm & 2u) != 0 && maxlen >= 3, k3, 3u, rh.tsalt, q3);
+        tiny_issue_if(T, (lm & 4u) != 0 && maxlen >= 4, w0, 4u, rh.tsalt, q4);
+        t8_issue_if(T, (lm & 8u) != 0 && maxlen >= 5, w0, h5, 5u, rh.fsalt, q5);
+        t8_issue_if(T, (lm & 0x10u) != 0 && maxlen >= 6, w0, h6, 6u, rh.fsalt, q6);
+        t8_issue_if(T, (lm & 0x20u) != 0 && maxlen >= 7, w0, h7, 7u, rh.fsalt, q7);
+        t8_issue_if(T, (lm & 0x40u) != 0 && maxlen >= 8, w0, w1, 8u, rh.fsalt, q8);
+        r[0] = rh.id2;
+        r[1] = tiny_finish(k3, 3u, q3);
+        r[2] = tiny_finish(w0, 4u, q4);
+        r[3] = t8_finish(w0, h5, 5u, q5);
+        r[4] = t8_finish(w0, h6, 6u, q6);
+        r[5] = t8_finish(w0, h7, 7u, q7);
+        r[6] = t8_finish(w0, w1, 8u, q8);
+    }
+}
+// Tabulation of ONE table row: the lane probes the ids of text[pos, pos + len), len = 2 .. min(rem, 8) -- six entries,
+// all in flight together (row_fill) -- into `row`; returns the id of its byte and, in far_max, the longest token of more
+// than 8 bytes that can start there (p8 bound; its load rides in the same round trip).  `own` false: idle lane.
 __device__ __forceinline__ uint32_t tab_row(const DeviceTables& T, const LdsAcc& tx, bool own, int pos, int rem, uint32_t* row,
                                             int& far_max, long long* wt = nullptr) {
     (void)wt;
@@ -832,50 +819,25 @@ __device__ __forceinline__ uint32_t tab_row(const DeviceTables& T, const LdsAcc&
     const uint32_t w0 = own ? tx.load32(pos) : 0u;
     const uint32_t w1 = own ? tx.load32(pos + 4) : 0u;
     const uint32_t id = own ? T.byte_id[w0 & 0xFFu] : SPL_DEAD;
-    // which token lengths exist at all behind the lane's first two bytes: the other probes go to the
-    // spare bucket (28 % fewer table lines for English text, 85 % for CJK)
+    // which token lengths exist at all behind the lane's first two / four bytes: the other probes go to the empty slot
     const RowHead rh = row_head(T, own, w0, maxlen);
-    const uint32_t lm = rh.lm;
     SPL_WT(1);
     far_max = 0;
-    {
-        Quad qb[2], qc[2], qd[3];
-        const uint32_t kb = w0 & 0xFFFFFFu, ha = w1 & 0xFFu;
-        // (ONE predicate for the four probes: cells for lengths beyond maxlen are never read, so
-        //  the lanes need no per-length predicate -- with one, the compiler waits after every
-        //  single probe instead of keeping all the bucket loads in flight together)
-        if (maxlen >= 2) {
-            tiny_issue_if(T, (lm & 2u) != 0, kb, 3u, lm >> 8, qb);
-            tiny_issue_if(T, (lm & 4u) != 0, w0, 4u, lm >> 8, qc);
-            t8_issue_if(T, (lm & 8u) != 0, w0, ha, 5u, lm >> 8, qd);
-            // spans of more than 8 bytes (the last merges of a chunk of 9..16 bytes): can a token that long
-            // start at this byte at all?  Almost never -- and then its rank is known without the pair table,
-            // whose round trip every lane of the wavefront would wait for, merge round after merge round.
-            if (rem > SUB_LMAX && (lm & 0x80u)) {
-                const P8Bucket e8 = T.p8_tab[hash_p8(w0, w1) & T.p8_mask];
-                const int l8 = (int)p8_match(e8.a, e8.b, p8_tag(w0, w1));
-                far_max = l8 == 255 ? FAR_UNBOUNDED : l8;
-            }
-            row[0] = rh.id2;
-            row[1] = tiny_finish(T, kb, 3u, lm >> 8, qb);
-            row[2] = tiny_finish(T, w0, 4u, lm >> 8, qc);
-            row[3] = t8_finish(T, w0, ha, 5u, lm >> 8, qd);
-        }
+    // spans of more than 8 bytes (the last merges of a chunk of 9..16 bytes): can a token that long start at this byte at
+    // all?  Almost never -- and then its rank is known without the pair table, whose round trip every lane of the wavefront
+    // would wait for, merge round after merge round.
+    P8Bucket e8{0u, 0u};
+    const bool want8 = maxlen >= 2 && rem > SUB_LMAX && (rh.lm & 0x80u);
+    if (want8) e8 = T.p8_tab[hash_p8(w0, w1) & T.p8_mask];
+    uint32_t r[7];
+    row_fill(T, rh, w0, w1, maxlen, r);
+    if (want8) {
+        const int l8 = (int)p8_match(e8.a, e8.b, p8_tag(w0, w1));
+        far_max = l8 == 255 ? FAR_UNBOUNDED : l8;
     }
-    SPL_WT(2);
-    if (SUB_LMAX >= 6 && __any(maxlen >= 6 && (lm & 0x70u))) {
-        Quad qa[3], qb[3], qc[3];
-        const uint32_t hb = w1 & 0xFFFFu, hc = w1 & 0xFFFFFFu;
-        if (maxlen >= 6) {
-            t8_issue_if(T, (lm & 0x10u) != 0, w0, hb, 6u, lm >> 8, qa);
-            t8_issue_if(T, (lm & 0x20u) != 0, w0, hc, 7u, lm >> 8, qb);
-            t8_issue_if(T, (lm & 0x40u) != 0, w0, w1, 8u, lm >> 8, qc);
-            row[4] = t8_finish(T, w0, hb, 6u, lm >> 8, qa);
-            row[5] = t8_finish(T, w0, hc, 7u, lm >> 8, qb);
-            if (SUB_LMAX >= 8) row[6] = t8_finish(T, w0, w1, 8u, lm >> 8, qc);
-        }
-    } else if (maxlen >= 6) {                                // nothing of 6..8 bytes starts in this wavefront's chunks
-        row[4] = SPL_NO_RANK; row[5] = SPL_NO_RANK; row[6] = SPL_NO_RANK;
+    if (maxlen >= 2) {
+#pragma unroll
+        for (int k = 0; k < SUB_W; k++) row[k] = r[k];
     }
     SPL_WT(3);
     return id;
@@ -1000,34 +962,12 @@ __device__ __forceinline__ void bpe_wave64_tab(const DeviceTables& T, const LdsA
     const RowHead rh = row_head(T, own, w0, maxlen);
     const uint32_t lm = rh.lm;
     {
-        Quad qb[2], qc[2], qd[3];
-        const uint32_t kb = w0 & 0xFFFFFFu, ha = w1 & 0xFFu;
-        // (ONE predicate for the four probes: cells for lengths beyond maxlen are never read, so
-        //  the lanes need no per-length predicate -- with one, the compiler waits after every
-        //  single probe instead of keeping all the bucket loads in flight together)
+        uint32_t r[7];
+        row_fill(T, rh, w0, w1, maxlen, r);
         if (maxlen >= 2) {
-            tiny_issue_if(T, (lm & 2u) != 0, kb, 3u, lm >> 8, qb);
-            tiny_issue_if(T, (lm & 4u) != 0, w0, 4u, lm >> 8, qc);
-            t8_issue_if(T, (lm & 8u) != 0, w0, ha, 5u, lm >> 8, qd);
-            row[0] = rh.id2;
-            row[1] = tiny_finish(T, kb, 3u, lm >> 8, qb);
-            row[2] = tiny_finish(T, w0, 4u, lm >> 8, qc);
-            row[3] = t8_finish(T, w0, ha, 5u, lm >> 8, qd);
+#pragma unroll
+            for (int k = 0; k < SUB_W; k++) row[k] = r[k];
         }
-    }
-    if (SUB_LMAX >= 6 && __any(maxlen >= 6 && (lm & 0x70u))) {
-        Quad qa[3], qb[3], qc[3];
-        const uint32_t hb = w1 & 0xFFFFu, hc = w1 & 0xFFFFFFu;
-        if (maxlen >= 6) {
-            t8_issue_if(T, (lm & 0x10u) != 0, w0, hb, 6u, lm >> 8, qa);
-            t8_issue_if(T, (lm & 0x20u) != 0, w0, hc, 7u, lm >> 8, qb);
-            t8_issue_if(T, (lm & 0x40u) != 0, w0, w1, 8u, lm >> 8, qc);
-            row[4] = t8_finish(T, w0, hb, 6u, lm >> 8, qa);
-            row[5] = t8_finish(T, w0, hc, 7u, lm >> 8, qb);
-            if (SUB_LMAX >= 8) row[6] = t8_finish(T, w0, w1, 8u, lm >> 8, qc);
-        }
-    } else if (maxlen >= 6) {
-        row[4] = SPL_NO_RANK; row[5] = SPL_NO_RANK; row[6] = SPL_NO_RANK;
     }
     const unsigned long long all = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
     // Independent segments.  A merge never crosses a byte boundary that no token spans, so the
@@ -1986,65 +1926,35 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
             else for (int q = 0; q < 8; q++) if (g + q < B) (q < 4 ? w0 : w1) |= (uint32_t)b.text[g + q] << (8 * (q & 3));
             bid = T.byte_id[w0 & 0xFFu];
         }
-        const RowHead rh = row_head(T, own, w0, maxlen);     // which token lengths exist at all behind these bytes
-        lm = rh.lm;
+        RowHead rh = row_head(T, own, w0, maxlen);           // which token lengths exist at all behind these bytes
 #if defined(SPL_TAIL_CUT)
-        if (SPL_TAIL_CUT >= 2) { lm = 0; maxlen = maxlen < 2 ? maxlen : 2; }
+        if (SPL_TAIL_CUT >= 2) { rh.lm = 0; maxlen = maxlen < 2 ? maxlen : 2; }
 #endif
+        lm = rh.lm;
         uint32_t* const row = slab + tid * SUB_W;
         int ml = 1;
-#ifndef SPL_TAIL_LEAD6
-#define SPL_TAIL_LEAD6 1         /* 1: a row that starts a three-byte character probes length 6 in the first batch and 5 in the second (A/B: 0) */
-#endif
-        // Which of the lengths 5 and 6 goes out with the first batch: behind the lead byte of a three-byte character the
-        // likely longer token is the two-character word (6 bytes), and with it in the first batch -- and the p8 bucket too
-        // -- a wavefront of CJK rows mostly has nothing left for the second one: two dependent round trips per pass
-        // instead of three.  (The t8 probe takes any length: only the key mask and the row's cell depend on it.)
-        const bool lead3 = SPL_TAIL_LEAD6 && (w0 & 0xF0u) == 0xE0u;
-        const uint32_t La = lead3 ? 6u : 5u, Lb = lead3 ? 5u : 6u;
-        const uint32_t ka1 = lead3 ? (w1 & 0xFFFFu) : (w1 & 0xFFu), kb1 = lead3 ? (w1 & 0xFFu) : (w1 & 0xFFFFu);
-        P8Bucket e8{0u, 0u};
         {
-            Quad qb[2], qc[2], qd[3];
-            const uint32_t kb = w0 & 0xFFFFFFu;
-            if (maxlen >= 2) {                               // (one predicate per batch: see bpe_group16_tab)
-                tiny_issue_if(T, (lm & 2u) != 0, kb, 3u, lm >> 8, qb);
-                tiny_issue_if(T, (lm & 4u) != 0, w0, 4u, lm >> 8, qc);
-                t8_issue_if(T, ((lm >> (La - 2u)) & 1u) != 0, w0, ka1, La, lm >> 8, qd);
-                if (cap > SUB_LMAX && (lm & 0x80u)) e8 = T.p8_tab[hash_p8(w0, w1) & T.p8_mask];
-                const uint32_t r2 = rh.id2, r3 = tiny_finish(T, kb, 3u, lm >> 8, qb);
-                const uint32_t r4 = tiny_finish(T, w0, 4u, lm >> 8, qc), ra = t8_finish(T, w0, ka1, La, lm >> 8, qd);
-                row[0] = r2; row[1] = r3; row[2] = r4; row[La - 2u] = ra;
-                ml = r2 != SPL_NO_RANK ? 2 : ml;
-                ml = (r3 != SPL_NO_RANK && maxlen >= 3) ? 3 : ml;
-                ml = (r4 != SPL_NO_RANK && maxlen >= 4) ? 4 : ml;
-                ml = (ra != SPL_NO_RANK && maxlen >= (int)La) ? (int)La : ml;
-            }
-        }
-        sid[tid] = bid;
-        {
-            const uint32_t rest_bits = (1u << (Lb - 2u)) | 0x60u;          // the lengths of the second batch: Lb, 7, 8
-            if (__any(maxlen >= (int)Lb && (lm & rest_bits))) {
-                Quad qa[3], qb[3], qc[3];
-                const uint32_t hc = w1 & 0xFFFFFFu;
-                if (maxlen >= (int)Lb) {
-                    t8_issue_if(T, ((lm >> (Lb - 2u)) & 1u) != 0, w0, kb1, Lb, lm >> 8, qa);
-                    t8_issue_if(T, (lm & 0x20u) != 0, w0, hc, 7u, lm >> 8, qb);
-                    t8_issue_if(T, (lm & 0x40u) != 0, w0, w1, 8u, lm >> 8, qc);
-                    const uint32_t rb = t8_finish(T, w0, kb1, Lb, lm >> 8, qa), r7 = t8_finish(T, w0, hc, 7u, lm >> 8, qb);
-                    const uint32_t r8 = t8_finish(T, w0, w1, 8u, lm >> 8, qc);
-                    row[Lb - 2u] = rb; row[5] = r7; row[6] = r8;
-                    ml = (rb != SPL_NO_RANK && maxlen >= (int)Lb && (int)Lb > ml) ? (int)Lb : ml;
-                    ml = (r7 != SPL_NO_RANK && maxlen >= 7) ? 7 : ml;
-                    ml = (r8 != SPL_NO_RANK && maxlen >= 8) ? 8 : ml;
+            // all six lengths and the p8 bucket in ONE round trip (row_fill: one entry per probe); up to round 3 two batches
+            // of buckets -- with the lengths 5 / 6 swapped between them for rows that start a three-byte character
+            P8Bucket e8{0u, 0u};
+            const bool want8 = maxlen >= 2 && cap > SUB_LMAX && (lm & 0x80u);
+            if (want8) e8 = T.p8_tab[hash_p8(w0, w1) & T.p8_mask];
+            uint32_t r[7];
+            row_fill(T, rh, w0, w1, maxlen, r);
+            if (maxlen >= 2) {
+#pragma unroll
+                for (int k = 0; k < SUB_W; k++) {
+                    row[k] = r[k];
+                    ml = (r[k] != SPL_NO_RANK && maxlen >= k + 2) ? k + 2 : ml;
                 }
-            } else if (maxlen >= (int)Lb) {                  // nothing of the second batch's lengths starts in this wavefront's rows
-                row[Lb - 2u] = SPL_NO_RANK; row[5] = SPL_NO_RANK; row[6] = SPL_NO_RANK;
             }
-            const int l8 = (int)p8_match(e8.a, e8.b, p8_tag(w0, w1));
-            if (l8) ml = (l8 == 255 || l8 > cap) ? cap : l8;
+            sid[tid] = bid;
+            if (want8) {
+                const int l8 = (int)p8_match(e8.a, e8.b, p8_tag(w0, w1));
+                if (l8) ml = (l8 == 255 || l8 > cap) ? cap : l8;
+            }
         }
-        TT(1);                                               // rows filled (three dependent round trips)
+        TT(1);                                               // rows filled (two dependent round trips: row head, entries)
         {
             uint32_t cover = wave_scan_max(own ? (uint32_t)(tid + ml - 1) : 0u);
             if (lane == 63) s_wsum4[wv] = cover;

@@ -22,58 +22,32 @@ SPL_HD uint32_t mask_tail(uint32_t w, int nbytes) {     // keep the low nbytes (
     return nbytes >= 4 ? w : nbytes <= 0 ? 0u : (w & ((1u << (8 * nbytes)) - 1u));
 }
 
-// NOTE: the bucket compares are written branch-free on purpose.  With early returns the compiler
-// sinks the later loads into the "not found yet" branches and a miss costs several DEPENDENT
-// memory round trips; with selects every load of the bucket is issued before the first wait.
-// keys of 1..4 bytes: two dwordx4 loads per bucket
+// NOTE: the bucket compares (short table, pair table) are written branch-free on purpose.  With early returns the
+// compiler sinks the later loads into the "not found yet" branches and a miss costs several DEPENDENT memory round
+// trips; with selects every load of the bucket is issued before the first wait.
 // last = the id word of a bucket's last slot: did a key that belongs here (or passed through) go on to
 // the next bucket?  (The builder sets SPL_OVF_BIT there; an empty slot is all-ones.)
 SPL_HD bool bucket_overflowed(uint32_t last) { return last != SPL_EMPTY && (last & SPL_OVF_BIT) != 0u; }
 
 // (k0 & 0xFFFF = the key's first two bytes, the second one zero for a one-byte key)
 SPL_HD uint32_t key_salt(const DeviceTables& T, uint32_t k0) { return (uint32_t)T.len_mask[k0 & 0xFFFFu] >> 8; }
+SPL_HD uint32_t tiny_salt(const DeviceTables& T, uint32_t k0) { return T.pfx[k0 & 0xFFFFu].lm >> 16; }
+SPL_HD uint32_t t8_salt(const DeviceTables& T, uint32_t k0) { return (uint32_t)T.filt4[hash_f4(k0) >> T.filt4_shift] >> SPL_F4_MASK_BITS; }
 
+// keys of 1..4 bytes: ONE entry (8 bytes); salt = tiny_salt(first two bytes)
 SPL_HD uint32_t probe_tiny(const DeviceTables& T, uint32_t k0, uint32_t n, uint32_t salt) {
-    uint32_t bkt = hash_tiny(k0, n, salt) & T.tiny_mask;
-    for (;;) {
-        const Quad* q = reinterpret_cast<const Quad*>(T.tiny_tab + (size_t)bkt * (SPL_TINY_BUCKET * 2));
-        const Quad a = q[0], c = q[1];
-        const bool f0 = (a.x == k0) & ((a.y >> 24) == n);
-        const bool f1 = (a.z == k0) & ((a.w >> 24) == n);
-        const bool f2 = (c.x == k0) & ((c.y >> 24) == n);
-        const bool f3 = (c.z == k0) & ((c.w >> 24) == n);
-        uint32_t r = SPL_NO_RANK;
-        r = f3 ? (c.w & SPL_ID_MASK) : r;
-        r = f2 ? (c.y & SPL_ID_MASK) : r;
-        r = f1 ? (a.w & SPL_ID_MASK) : r;
-        r = f0 ? (a.y & SPL_ID_MASK) : r;
-        if ((f0 | f1 | f2 | f3) | !bucket_overflowed(c.w)) return r;
-        bkt = (bkt + 1) & T.tiny_mask;
-    }
+    const uint32_t* e = T.tiny_tab + (size_t)(hash_tiny(k0, n, salt) & T.tiny_mask) * SPL_TINY_WORDS;
+    const uint32_t ek = e[0], ei = e[1];
+    return (ek == k0) & ((ei >> 24) == n) ? (ei & SPL_ID_MASK) : SPL_NO_RANK;
 }
-// keys of 5..8 bytes: three dwordx4 loads per bucket (entries of three words straddle them)
+// keys of 5..8 bytes: ONE entry (12 bytes); salt = t8_salt(first four bytes)
 SPL_HD uint32_t probe_t8(const DeviceTables& T, uint32_t k0, uint32_t k1, uint32_t n, uint32_t salt) {
-    uint32_t bkt = hash_t8(k0, k1, n, salt) & T.t8_mask;
-    for (;;) {
-        const Quad* q = reinterpret_cast<const Quad*>(T.t8_tab + (size_t)bkt * SPL_T8_WORDS);
-        const Quad a = q[0], c = q[1], d = q[2];
-        const bool f0 = (a.x == k0) & (a.y == k1) & ((a.z >> 24) == n);
-        const bool f1 = (a.w == k0) & (c.x == k1) & ((c.y >> 24) == n);
-        const bool f2 = (c.z == k0) & (c.w == k1) & ((d.x >> 24) == n);
-        const bool f3 = (d.y == k0) & (d.z == k1) & ((d.w >> 24) == n);
-        uint32_t r = SPL_NO_RANK;
-        r = f3 ? (d.w & SPL_ID_MASK) : r;
-        r = f2 ? (d.x & SPL_ID_MASK) : r;
-        r = f1 ? (c.y & SPL_ID_MASK) : r;
-        r = f0 ? (a.z & SPL_ID_MASK) : r;
-        if ((f0 | f1 | f2 | f3) | !bucket_overflowed(d.w)) return r;
-        bkt = (bkt + 1) & T.t8_mask;
-    }
+    const uint32_t* e = T.t8_tab + (size_t)(hash_t8(k0, k1, n, salt) & T.t8_mask) * SPL_T8_WORDS;
+    const uint32_t e0 = e[0], e1 = e[1], ei = e[2];
+    return (e0 == k0) & (e1 == k1) & ((ei >> 24) == n) ? (ei & SPL_ID_MASK) : SPL_NO_RANK;
 }
-// keys of up to 12 bytes, by length class
-SPL_HD uint32_t probe_short(const DeviceTables& T, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t n, uint32_t salt) {
-    if (n <= (uint32_t)SPL_TINY_MAX) return probe_tiny(T, k0, n, salt);
-    if (n <= (uint32_t)SPL_T8_MAX) return probe_t8(T, k0, k1, n, salt);
+// keys of 9..12 bytes: buckets of four, salt = key_salt(first two bytes)
+SPL_HD uint32_t probe_short12(const DeviceTables& T, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t n, uint32_t salt) {
     uint32_t bkt = hash_short(k0, k1, k2, n, salt) & T.short_mask;
     for (;;) {
         const Quad* q = reinterpret_cast<const Quad*>(T.short_tab + (size_t)bkt * SPL_SHORT_BUCKET);
@@ -91,9 +65,11 @@ SPL_HD uint32_t probe_short(const DeviceTables& T, uint32_t k0, uint32_t k1, uin
         bkt = (bkt + 1) & T.short_mask;
     }
 }
-
+// keys of up to 12 bytes, by length class (each class looks its own salt up)
 SPL_HD uint32_t probe_short(const DeviceTables& T, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t n) {
-    return probe_short(T, k0, k1, k2, n, key_salt(T, k0));
+    if (n <= (uint32_t)SPL_TINY_MAX) return probe_tiny(T, k0, n, tiny_salt(T, k0));
+    if (n <= (uint32_t)SPL_T8_MAX) return probe_t8(T, k0, k1, n, t8_salt(T, k0));
+    return probe_short12(T, k0, k1, k2, n, key_salt(T, k0));
 }
 
 template <class TX> SPL_HD uint32_t probe_long(const DeviceTables& T, const TX& tx, int p, int n) {

@@ -309,20 +309,11 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
         const size_t n = kv.first.size();
         (n <= (size_t)SPL_TINY_MAX ? n_tiny : n <= (size_t)SPL_T8_MAX ? n_t8 : n <= (size_t)SPL_SHORT_MAX ? n_short : n_long)++;
     }
-    // tiny / t8 / short tables: buckets of 4, sized by load.  Level 0 (dense): the smallest power of two that keeps
-    // the load at or below 55 % (short table: 40 %) -- the tables a tile kernel probes all the time (tiny + t8 + short +
-    // p8 + length masks) then take 4.1 instead of 5.1 MiB for cl100k_base, against 4 MiB of L2 per XCD; level 1: round 2's
-    // sizes (at most ~37 %).  The dense level is kept only if the salts below still place EVERY key in its home bucket
-    // (cl100k_base, llama3); otherwise the placement is redone at level 1.
-    uint32_t tbuckets = 0, ebuckets = 0, sbuckets = 0;
-    auto size_tables = [&](int level) {
-        auto nb = [&](size_t keys, int pct) { return level == 0 ? pow2_at_least(keys * 100 / (4 * (size_t)pct) + 2) : pow2_at_least(keys * 2 / 3 + 2); };
-        tbuckets = nb(n_tiny, 55); ebuckets = nb(n_t8, 55); sbuckets = nb(n_short, 40);
-        out.tiny_tab.assign((size_t)tbuckets * SPL_TINY_BUCKET * 2, SPL_EMPTY);
-        out.t8_tab.assign((size_t)ebuckets * SPL_T8_WORDS, SPL_EMPTY);
-        out.short_tab.assign((size_t)sbuckets * SPL_SHORT_BUCKET, ShortEnt{0, 0, 0, SPL_EMPTY});
-        out.unsalted_groups = 0;
-    };
+    // short table (keys of 9..12 bytes): buckets of 4, at most ~40 % full, an 8-bit salt per two-byte prefix (below).
+    // tiny / t8 tables: ONE entry per slot, placed by displacement (further below).
+    const uint32_t sbuckets = pow2_at_least(n_short * 100 / (4 * 40) + 2);
+    out.short_tab.assign((size_t)sbuckets * SPL_SHORT_BUCKET, ShortEnt{0, 0, 0, SPL_EMPTY});
+    out.unsalted_groups = 0;
     const uint32_t lcap = pow2_at_least(n_long * 2 + 2);
     out.long_tab.assign(lcap, LongEnt{0, SPL_EMPTY, 0, 0});
     out.key_blob.clear();
@@ -355,69 +346,28 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
             }
         }
     }
-    // ---- tiny / t8 / short tables: one SALT per two-byte key prefix (DeviceTables::len_mask) ------------
-    // Keys are placed group by group (a group = all keys of up to 12 bytes with the same first two
-    // bytes, largest group first); a group takes the first salt under which each of its keys finds its
-    // home bucket with a free slot.  No key then ever overflows, so no probe -- hit or miss -- goes on to a
-    // second bucket.  A group that finds no salt (a large group late in a well-filled table: one group of
-    // o200k_base, 5 of its keys; none in the other shipped vocabularies) keeps salt 0 and overflows into
-    // the next bucket, marking the full one (SPL_OVF_BIT); the probes walk on from a marked bucket, so
-    // this costs speed only -- and only for the probes that land on those few buckets.
-    // (SPL_BUCKET_FILL = the bucket size: a salted bucket may become completely FULL; what the salts guarantee
-    //  is that no key OVERFLOWS.  Probes are settled by SPL_OVF_BIT alone, never by "the last slot is empty".)
-    for (int level = 0; level < 2; level++) {
-        size_tables(level);
+    // ---- short table: one 8-bit SALT per two-byte key prefix (DeviceTables::len_mask) ---------------------
+    // Keys are placed group by group (a group = all keys of 9..12 bytes with the same first two bytes, largest group
+    // first); a group takes the first salt under which each of its keys finds its home bucket with a free slot.  No key
+    // then ever overflows, so no probe -- hit or miss -- goes on to a second bucket.  A group that finds no salt keeps salt
+    // 0 and overflows into the next bucket, marking the full one (SPL_OVF_BIT); the probes walk on from a marked bucket.
+    struct KeyRef { const std::string* k; uint32_t id; };
+    {
         constexpr int SPL_BUCKET_FILL = 4;
-        struct KeyRef { const std::string* k; uint32_t id; };
         std::vector<std::vector<KeyRef>> groups(65536);
         for (const auto& kv : enc) {
             const std::string& k = kv.first;
-            if (k.size() > (size_t)SPL_SHORT_MAX) continue;
-            groups[(uint8_t)k[0] | (k.size() > 1 ? (uint32_t)(uint8_t)k[1] << 8 : 0u)].push_back(KeyRef{&k, kv.second});
+            if (k.size() <= (size_t)SPL_T8_MAX || k.size() > (size_t)SPL_SHORT_MAX) continue;
+            groups[(uint8_t)k[0] | (uint32_t)(uint8_t)k[1] << 8].push_back(KeyRef{&k, kv.second});
         }
         std::vector<uint32_t> order;
         for (uint32_t g = 0; g < 65536; g++) if (!groups[g].empty()) order.push_back(g);
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return groups[a].size() > groups[b].size(); });
-        std::vector<uint8_t> cnt_t(tbuckets, 0), cnt_e(ebuckets, 0), cnt_s(sbuckets, 0);
-        auto home = [&](const std::string& k, uint32_t salt, int& which) -> uint32_t {
-            const uint32_t n = (uint32_t)k.size();
-            if (n <= (uint32_t)SPL_TINY_MAX) { which = 0; return hash_tiny(load_le(k, 0), n, salt) & (tbuckets - 1); }
-            if (n <= (uint32_t)SPL_T8_MAX) { which = 1; return hash_t8(load_le(k, 0), load_le(k, 4), n, salt) & (ebuckets - 1); }
-            which = 2;
-            return hash_short(load_le(k, 0), load_le(k, 4), load_le(k, 8), n, salt) & (sbuckets - 1);
+        std::vector<uint8_t> cnt_s(sbuckets, 0);
+        auto home = [&](const std::string& k, uint32_t salt) {
+            return hash_short(load_le(k, 0), load_le(k, 4), load_le(k, 8), (uint32_t)k.size(), salt) & (sbuckets - 1);
         };
-        auto put = [&](const std::string& k, uint32_t id, uint32_t bkt, int which) {      // first bucket at or behind bkt with a free slot
-            const uint32_t n = (uint32_t)k.size();
-            if (which == 0) {
-                for (;;) {
-                    uint32_t* e = &out.tiny_tab[(size_t)bkt * SPL_TINY_BUCKET * 2];
-                    int f = 0;
-                    while (f < SPL_TINY_BUCKET && e[2 * f + 1] != SPL_EMPTY) f++;
-                    if (f < SPL_TINY_BUCKET) { e[2 * f] = load_le(k, 0); e[2 * f + 1] = id | (n << 24); cnt_t[bkt]++; return; }
-                    e[2 * (SPL_TINY_BUCKET - 1) + 1] |= SPL_OVF_BIT;
-                    bkt = (bkt + 1) & (tbuckets - 1);
-                }
-            } else if (which == 1) {
-                for (;;) {
-                    uint32_t* e = &out.t8_tab[(size_t)bkt * SPL_T8_WORDS];
-                    int f = 0;
-                    while (f < SPL_T8_BUCKET && e[3 * f + 2] != SPL_EMPTY) f++;
-                    if (f < SPL_T8_BUCKET) { e[3 * f] = load_le(k, 0); e[3 * f + 1] = load_le(k, 4); e[3 * f + 2] = id | (n << 24); cnt_e[bkt]++; return; }
-                    e[3 * (SPL_T8_BUCKET - 1) + 2] |= SPL_OVF_BIT;
-                    bkt = (bkt + 1) & (ebuckets - 1);
-                }
-            } else {
-                for (;;) {
-                    ShortEnt* e = &out.short_tab[(size_t)bkt * SPL_SHORT_BUCKET];
-                    int f = 0;
-                    while (f < SPL_SHORT_BUCKET && e[f].id_len != SPL_EMPTY) f++;
-                    if (f < SPL_SHORT_BUCKET) { e[f] = ShortEnt{load_le(k, 0), load_le(k, 4), load_le(k, 8), id | (n << 24)}; cnt_s[bkt]++; return; }
-                    e[SPL_SHORT_BUCKET - 1].id_len |= SPL_OVF_BIT;
-                    bkt = (bkt + 1) & (sbuckets - 1);
-                }
-            }
-        };
-        std::vector<std::pair<int, uint32_t>> touched;
+        std::vector<uint32_t> touched;
         for (uint32_t g : order) {
             const auto& keys = groups[g];
             uint32_t salt = 0;
@@ -426,27 +376,35 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
                 touched.clear();
                 bool ok = true;
                 for (const KeyRef& kr : keys) {
-                    int which;
-                    const uint32_t bkt = home(*kr.k, salt, which);
-                    uint8_t& c = which == 0 ? cnt_t[bkt] : which == 1 ? cnt_e[bkt] : cnt_s[bkt];
-                    if (c >= SPL_BUCKET_FILL) { ok = false; break; }
-                    c++;
-                    touched.emplace_back(which, bkt);
+                    const uint32_t bkt = home(*kr.k, salt);
+                    if (cnt_s[bkt] >= SPL_BUCKET_FILL) { ok = false; break; }
+                    cnt_s[bkt]++;
+                    touched.push_back(bkt);
                 }
-                for (const auto& t : touched) (t.first == 0 ? cnt_t[t.second] : t.first == 1 ? cnt_e[t.second] : cnt_s[t.second])--;
+                for (uint32_t t : touched) cnt_s[t]--;
                 if (ok) { found = true; break; }
             }
             if (!found) { salt = 0; out.unsalted_groups++; }
             out.len_mask[g] = (uint16_t)((out.len_mask[g] & 0xFFu) | (salt << 8));
             for (const KeyRef& kr : keys) {
-                int which;
-                const uint32_t bkt = home(*kr.k, salt, which);
-                put(*kr.k, kr.id, bkt, which);
+                uint32_t bkt = home(*kr.k, salt);
+                for (;;) {
+                    ShortEnt* e = &out.short_tab[(size_t)bkt * SPL_SHORT_BUCKET];
+                    int f = 0;
+                    while (f < SPL_SHORT_BUCKET && e[f].id_len != SPL_EMPTY) f++;
+                    if (f < SPL_SHORT_BUCKET) {
+                        e[f] = ShortEnt{load_le(*kr.k, 0), load_le(*kr.k, 4), load_le(*kr.k, 8), kr.id | ((uint32_t)kr.k->size() << 24)};
+                        cnt_s[bkt]++;
+                        break;
+                    }
+                    e[SPL_SHORT_BUCKET - 1].id_len |= SPL_OVF_BIT;
+                    bkt = (bkt + 1) & (sbuckets - 1);
+                }
             }
         }
-        if (out.unsalted_groups == 0) break;             // every key in its home bucket: keep this density
     }
-    {   // prefix entries (length mask + salt + the two-byte token's id) and the four-byte-prefix length filter
+    // ---- prefix entries and the four-byte-prefix filter (the salts of the two tables below live in them) ---------
+    {
         out.pfx.assign(65536, PfxEnt{0u, SPL_NO_RANK});
         for (uint32_t g = 0; g < 65536; g++) out.pfx[g].lm = out.len_mask[g];
         size_t n4 = 0;
@@ -455,7 +413,7 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
             if (k.size() == 2) out.pfx[(uint8_t)k[0] | (uint32_t)(uint8_t)k[1] << 8].id2 = kv.second;
             n4 += k.size() >= 4;
         }
-        // one byte per slot, about one key in ten slots (distinct prefixes are fewer still): 256 KiB for cl100k_base
+        // about one key in ten slots (distinct prefixes are fewer still); 16-bit entries: six length bits, ten bits of salt
         uint32_t bits = 16;
         while (bits < 22 && ((size_t)1 << bits) < n4 * 4) bits++;
         out.filt4_shift = 32 - bits;
@@ -463,8 +421,86 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
         for (const auto& kv : enc) {
             const std::string& k = kv.first;
             if (k.size() < 4) continue;
-            out.filt4[hash_f4(load_le(k, 0)) >> out.filt4_shift] |= (uint8_t)(1u << (k.size() > (size_t)SPL_T8_MAX ? 5 : k.size() - 4));
+            out.filt4[hash_f4(load_le(k, 0)) >> out.filt4_shift] |= (uint16_t)(1u << (k.size() > (size_t)SPL_T8_MAX ? 5 : k.size() - 4));
         }
+    }
+    // ---- tiny / t8 tables: ONE ENTRY PER SLOT, by displacement ("hash and displace") ------------------------------
+    // A group of keys shares a salt: the keys of 1..4 bytes by their first two bytes (salt in the prefix entry, 16 bits), the
+    // keys of 5..8 bytes by the filter slot of their first four bytes (salt in the filter entry, 10 bits) -- both entries a
+    // probe has read anyway before it can hash.  Groups are placed largest first; a group takes the first salt under which
+    // every one of its keys lands in a slot that is still free, no two of them in the same one.  Large groups go in while
+    // the table is nearly empty, the thousands of one- and two-key groups fill what is left: cl100k_base places 27 000
+    // tiny keys in 2^16 slots and 48 600 t8 keys in 2^17, o200k_base 99 000 t8 keys in 2^17 slots (76 % full).  A table
+    // that cannot be completed is doubled (at most three times: by then it is four to eight times as sparse).
+    auto displace = [&](std::vector<std::vector<KeyRef>>& groups, int words, int salt_bits, size_t n_keys, size_t min_slots,
+                        std::vector<uint32_t>& tab, std::vector<uint32_t>& salts, const char* what) -> bool {
+        std::vector<uint32_t> order;
+        for (uint32_t g = 0; g < groups.size(); g++) if (!groups[g].empty()) order.push_back(g);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return groups[a].size() > groups[b].size(); });
+        uint32_t slots = pow2_at_least(std::max(n_keys + n_keys / 4 + 2, min_slots));
+        for (int attempt = 0; attempt < 4; attempt++, slots *= 2) {
+            std::vector<uint8_t> used(slots, 0);
+            salts.assign(groups.size(), 0);
+            std::vector<uint32_t> at;
+            bool all = true;
+            for (uint32_t g : order) {
+                const auto& keys = groups[g];
+                bool found = false;
+                for (uint32_t salt = 0; salt < (1u << salt_bits) && !found; salt++) {
+                    at.clear();
+                    bool ok = true;
+                    for (const KeyRef& kr : keys) {
+                        const uint32_t n = (uint32_t)kr.k->size();
+                        const uint32_t h = (words == SPL_TINY_WORDS ? hash_tiny(load_le(*kr.k, 0), n, salt)
+                                                                     : hash_t8(load_le(*kr.k, 0), load_le(*kr.k, 4), n, salt)) & (slots - 1);
+                        if (used[h]) { ok = false; break; }
+                        used[h] = 1;                     // (also catches two keys of the group in one slot)
+                        at.push_back(h);
+                    }
+                    if (ok) { found = true; salts[g] = salt; }
+                    else for (uint32_t h : at) used[h] = 0;
+                }
+                if (!found) { all = false; break; }
+            }
+            if (!all) continue;
+            // entries (+ 4 words of padding: a probe may read one word past its entry)
+            tab.assign((size_t)slots * words + 4, SPL_EMPTY);
+            for (uint32_t g : order)
+                for (const KeyRef& kr : groups[g]) {
+                    const uint32_t n = (uint32_t)kr.k->size();
+                    const uint32_t h = (words == SPL_TINY_WORDS ? hash_tiny(load_le(*kr.k, 0), n, salts[g])
+                                                                 : hash_t8(load_le(*kr.k, 0), load_le(*kr.k, 4), n, salts[g])) & (slots - 1);
+                    uint32_t* e = &tab[(size_t)h * words];
+                    e[0] = load_le(*kr.k, 0);
+                    if (words == SPL_T8_WORDS) e[1] = load_le(*kr.k, 4);
+                    e[words - 1] = kr.id | (n << 24);
+                }
+            return true;
+        }
+        err = std::string("could not give every key of the ") + what + " table a slot of its own (a two-byte / four-byte prefix shared by too many keys)";
+        return false;
+    };
+    {
+        std::vector<std::vector<KeyRef>> groups(65536);
+        for (const auto& kv : enc) {
+            const std::string& k = kv.first;
+            if (k.size() > (size_t)SPL_TINY_MAX) continue;
+            groups[(uint8_t)k[0] | (k.size() > 1 ? (uint32_t)(uint8_t)k[1] << 8 : 0u)].push_back(KeyRef{&k, kv.second});
+        }
+        std::vector<uint32_t> salts;
+        if (!displace(groups, SPL_TINY_WORDS, SPL_TINY_SALT_BITS, n_tiny, 1u << 12, out.tiny_tab, salts, "tiny")) return 1;
+        for (uint32_t g = 0; g < 65536; g++) out.pfx[g].lm = (out.pfx[g].lm & 0xFFFFu) | (salts[g] << 16);
+    }
+    {
+        std::vector<std::vector<KeyRef>> groups(out.filt4.size());
+        for (const auto& kv : enc) {
+            const std::string& k = kv.first;
+            if (k.size() <= (size_t)SPL_TINY_MAX || k.size() > (size_t)SPL_T8_MAX) continue;
+            groups[hash_f4(load_le(k, 0)) >> out.filt4_shift].push_back(KeyRef{&k, kv.second});
+        }
+        std::vector<uint32_t> salts;
+        if (!displace(groups, SPL_T8_WORDS, SPL_T8_SALT_BITS, n_t8, 1u << 12, out.t8_tab, salts, "t8")) return 1;
+        for (size_t g = 0; g < out.filt4.size(); g++) out.filt4[g] = (uint16_t)((out.filt4[g] & 0x3Fu) | (salts[g] << SPL_F4_MASK_BITS));
     }
     for (const auto& kv : enc) {
         const std::string& k = kv.first;
@@ -534,15 +570,15 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
     }
     out.tok_off[out.max_id + 1] = (uint32_t)out.tok_bytes.size();
     for (uint32_t id : verbatim) if (id <= out.max_id && out.tok_present[id]) out.tok_present[id] = 2;
-    // a bucket with a free last slot in each of the two small-key tables (load factors are below 0.4)
+    // an EMPTY slot in each of the two small-key tables: where probes known to miss are sent
     {
-        const size_t tb = out.tiny_tab.size() / (SPL_TINY_BUCKET * 2), eb = out.t8_tab.size() / SPL_T8_WORDS;
+        const size_t ts = (out.tiny_tab.size() - 4) / SPL_TINY_WORDS, es = (out.t8_tab.size() - 4) / SPL_T8_WORDS;
         bool ft = false, fe = false;
-        for (size_t i = 0; i < tb && !ft; i++)
-            if (out.tiny_tab[i * SPL_TINY_BUCKET * 2 + 2 * (SPL_TINY_BUCKET - 1) + 1] == SPL_EMPTY) { out.tiny_free = (uint32_t)i; ft = true; }
-        for (size_t i = 0; i < eb && !fe; i++)
-            if (out.t8_tab[i * SPL_T8_WORDS + 3 * (SPL_T8_BUCKET - 1) + 2] == SPL_EMPTY) { out.t8_free = (uint32_t)i; fe = true; }
-        if (!ft || !fe) { err = "small-key tables have no bucket with a free slot"; return 1; }
+        for (size_t i = 0; i < ts && !ft; i++)
+            if (out.tiny_tab[i * SPL_TINY_WORDS + 1] == SPL_EMPTY) { out.tiny_free = (uint32_t)i; ft = true; }
+        for (size_t i = 0; i < es && !fe; i++)
+            if (out.t8_tab[i * SPL_T8_WORDS + 2] == SPL_EMPTY) { out.t8_free = (uint32_t)i; fe = true; }
+        if (!ft || !fe) { err = "small-key tables have no empty slot"; return 1; }
     }
     return 0;
 }

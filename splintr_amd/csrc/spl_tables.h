@@ -23,8 +23,8 @@ struct HostTables {
     bool cjk_fast = false;
     // vocabulary
     std::vector<ShortEnt> short_tab;     // keys of 9..12 bytes
-    std::vector<uint32_t> tiny_tab;      // keys of 1..4 bytes: 2 words per entry, 4 entries per bucket
-    std::vector<uint32_t> t8_tab;        // keys of 5..8 bytes: 3 words per entry, SPL_T8_WORDS per bucket
+    std::vector<uint32_t> tiny_tab;      // keys of 1..4 bytes: 2 words per entry, ONE entry per slot (+ 4 words of padding)
+    std::vector<uint32_t> t8_tab;        // keys of 5..8 bytes: 3 words per entry, ONE entry per slot (+ 4 words of padding)
     std::vector<LongEnt> long_tab;
     std::vector<uint8_t> key_blob;
     std::vector<uint64_t> pair_tab;
@@ -32,9 +32,9 @@ struct HostTables {
     std::vector<uint32_t> p8_tab;       // DeviceTables::p8_tab (two words per bucket)
     std::vector<uint16_t> len_mask;     // DeviceTables::len_mask (65536): length mask | salt << 8
     std::vector<PfxEnt> pfx;            // DeviceTables::pfx (65536): len_mask's entry + the id of the two-byte token
-    std::vector<uint8_t> filt4;         // DeviceTables::filt4: token lengths by (hashed) four-byte prefix
+    std::vector<uint16_t> filt4;        // DeviceTables::filt4: token lengths by (hashed) four-byte prefix | t8 salt << 6
     uint32_t filt4_shift = 0;
-    uint32_t unsalted_groups = 0;       // two-byte key prefixes for which no salt kept every bucket below full (0 for the shipped vocabularies)
+    uint32_t unsalted_groups = 0;       // short table: two-byte key prefixes for which no salt kept every bucket below full (0 for the shipped vocabularies)
     uint32_t tiny_free = 0, t8_free = 0;
     uint32_t max_key_len = 0;           // in the key space the kernels see (raw bytes)
     uint32_t n_keys = 0, n_pairs = 0;

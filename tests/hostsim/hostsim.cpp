@@ -103,14 +103,19 @@ void* hs_create(const char* splv, const char* ucls, int pattern, char* errbuf, i
         return nullptr;
     }
     HostTables& h = s->ht;
-    s->dt = DeviceTables{h.ucls_stage1.data(), h.ucls_stage2.data(), h.ucls_shift, h.cjk_fast ? 1u : 0u,
-                         h.short_tab.data(), (uint32_t)(h.short_tab.size() / SPL_SHORT_BUCKET) - 1,
-                         h.tiny_tab.data(), (uint32_t)(h.tiny_tab.size() / (SPL_TINY_BUCKET * 2)) - 1,
-                         h.t8_tab.data(), (uint32_t)(h.t8_tab.size() / SPL_T8_WORDS) - 1, h.long_tab.data(),
-                         (uint32_t)h.long_tab.size() - 1, h.key_blob.data(), h.pair_tab.data(),
-                         (uint32_t)(h.pair_tab.size() / SPL_PAIR_BUCKET) - 1, h.byte_id.data(), h.max_key_len, (uint32_t)h.pattern,
-                         h.all_bytes ? 1u : 0u, reinterpret_cast<const P8Bucket*>(h.p8_tab.data()), (uint32_t)(h.p8_tab.size() / 2) - 1,
-                         h.len_mask.data(), h.tiny_free, h.t8_free};
+    s->dt = DeviceTables{};
+    DeviceTables& d = s->dt;
+    d.ucls_stage1 = h.ucls_stage1.data(); d.ucls_stage2 = h.ucls_stage2.data(); d.ucls_shift = h.ucls_shift; d.cjk_fast = h.cjk_fast ? 1u : 0u;
+    d.short_tab = h.short_tab.data(); d.short_mask = (uint32_t)(h.short_tab.size() / SPL_SHORT_BUCKET) - 1;
+    d.tiny_tab = h.tiny_tab.data(); d.tiny_mask = (uint32_t)((h.tiny_tab.size() - 4) / SPL_TINY_WORDS) - 1;
+    d.t8_tab = h.t8_tab.data(); d.t8_mask = (uint32_t)((h.t8_tab.size() - 4) / SPL_T8_WORDS) - 1;
+    d.long_tab = h.long_tab.data(); d.long_mask = (uint32_t)h.long_tab.size() - 1; d.key_blob = h.key_blob.data();
+    d.pair_tab = h.pair_tab.data(); d.pair_mask = (uint32_t)(h.pair_tab.size() / SPL_PAIR_BUCKET) - 1;
+    d.byte_id = h.byte_id.data(); d.max_key_len = h.max_key_len; d.pattern = (uint32_t)h.pattern; d.all_bytes = h.all_bytes ? 1u : 0u;
+    d.p8_tab = reinterpret_cast<const P8Bucket*>(h.p8_tab.data()); d.p8_mask = (uint32_t)(h.p8_tab.size() / 2) - 1;
+    d.len_mask = h.len_mask.data(); d.tiny_free = h.tiny_free; d.t8_free = h.t8_free;
+    d.ascii_base = (uint32_t)h.ucls_stage1[0] << h.ucls_shift;
+    d.pfx = h.pfx.data(); d.filt4 = h.filt4.data(); d.filt4_shift = h.filt4_shift;
     return s;
 }
 void hs_destroy(void* p) { delete (Sim*)p; }
@@ -529,17 +534,19 @@ extern "C" int hs_split_starts(void* p, const uint8_t* text, int n, const int* d
     return k;
 }
 
-// buckets from which a key went on to the next one (a probe that misses there takes the generic path)
+// table sizes, and short-table buckets from which a key went on to the next one (a probe that misses there walks on).
+// tiny / t8: slots, keys found by the single-slot probes (every key of the vocabulary must be: checked by the caller
+// through hs_row_head_check and the encode tests), empty slots.
 extern "C" void hs_bucket_stats(void* p, uint32_t* out) {
     Sim* s = (Sim*)p;
     const HostTables& h = s->ht;
-    uint32_t nb = (uint32_t)(h.tiny_tab.size() / (SPL_TINY_BUCKET * 2)), full = 0;
-    for (uint32_t b = 0; b < nb; b++) if (bucket_overflowed(h.tiny_tab[(size_t)b * SPL_TINY_BUCKET * 2 + SPL_TINY_BUCKET * 2 - 1])) full++;
-    out[0] = nb; out[1] = full;
-    nb = (uint32_t)(h.t8_tab.size() / SPL_T8_WORDS); full = 0;
-    for (uint32_t b = 0; b < nb; b++) if (bucket_overflowed(h.t8_tab[(size_t)b * SPL_T8_WORDS + 11])) full++;
-    out[2] = nb; out[3] = full;
-    nb = (uint32_t)(h.short_tab.size() / SPL_SHORT_BUCKET); full = 0;
+    uint32_t ns = (uint32_t)((h.tiny_tab.size() - 4) / SPL_TINY_WORDS), used = 0;
+    for (uint32_t i = 0; i < ns; i++) used += h.tiny_tab[(size_t)i * SPL_TINY_WORDS + 1] != SPL_EMPTY;
+    out[0] = ns; out[1] = used;
+    ns = (uint32_t)((h.t8_tab.size() - 4) / SPL_T8_WORDS); used = 0;
+    for (uint32_t i = 0; i < ns; i++) used += h.t8_tab[(size_t)i * SPL_T8_WORDS + 2] != SPL_EMPTY;
+    out[2] = ns; out[3] = used;
+    uint32_t nb = (uint32_t)(h.short_tab.size() / SPL_SHORT_BUCKET), full = 0;
     const uint32_t* st = reinterpret_cast<const uint32_t*>(h.short_tab.data());
     const size_t wpb = sizeof(h.short_tab[0]) * SPL_SHORT_BUCKET / 4;
     for (uint32_t b = 0; b < nb; b++) if (bucket_overflowed(st[(size_t)b * wpb + wpb - 1])) full++;
@@ -559,7 +566,7 @@ extern "C" void hs_row_head_check(void* p, uint32_t* out) {
     auto check = [&](uint32_t k0, uint32_t n, uint32_t id) {
         keys++;
         const PfxEnt pe = h.pfx[k0 & 0xFFFFu];
-        if (pe.lm != h.len_mask[k0 & 0xFFFFu]) bad++;
+        if ((pe.lm & 0xFFFFu) != h.len_mask[k0 & 0xFFFFu]) bad++;
         if (n >= 2 && !((pe.lm >> (n <= (uint32_t)SPL_T8_MAX ? n - 2 : 7)) & 1u)) bad++;
         if (n == 2) { two++; if (pe.id2 != id) bad++; }
         if (n >= 4) {
@@ -567,12 +574,19 @@ extern "C" void hs_row_head_check(void* p, uint32_t* out) {
             if (!((f >> (n <= (uint32_t)SPL_T8_MAX ? n - 4 : 5)) & 1u)) bad++;
         }
     };
-    for (size_t e = 0; e < h.tiny_tab.size() / 2; e++)
-        if (h.tiny_tab[2 * e + 1] != SPL_EMPTY) check(h.tiny_tab[2 * e], (h.tiny_tab[2 * e + 1] >> 24) & 0x7Fu, h.tiny_tab[2 * e + 1] & SPL_ID_MASK);
-    for (size_t b = 0; b < h.t8_tab.size() / SPL_T8_WORDS; b++)
-        for (int f = 0; f < SPL_T8_BUCKET; f++) {
-            const uint32_t* e = &h.t8_tab[b * SPL_T8_WORDS + 3 * f];
-            if (e[2] != SPL_EMPTY) check(e[0], (e[2] >> 24) & 0x7Fu, e[2] & SPL_ID_MASK);
+    // one entry per slot: every stored key must come back from the single-slot probes (its salt from the prefix entry /
+    // the filter entry), i.e. sit exactly where its hash says
+    for (size_t e = 0; e + 4 < h.tiny_tab.size(); e += SPL_TINY_WORDS)
+        if (h.tiny_tab[e + 1] != SPL_EMPTY) {
+            const uint32_t k0 = h.tiny_tab[e], n = (h.tiny_tab[e + 1] >> 24) & 0x7Fu, id = h.tiny_tab[e + 1] & SPL_ID_MASK;
+            check(k0, n, id);
+            if (probe_tiny(s->dt, k0, n, tiny_salt(s->dt, k0)) != id) bad++;
+        }
+    for (size_t e = 0; e + 4 < h.t8_tab.size(); e += SPL_T8_WORDS)
+        if (h.t8_tab[e + 2] != SPL_EMPTY) {
+            const uint32_t k0 = h.t8_tab[e], k1 = h.t8_tab[e + 1], n = (h.t8_tab[e + 2] >> 24) & 0x7Fu, id = h.t8_tab[e + 2] & SPL_ID_MASK;
+            check(k0, n, id);
+            if (probe_t8(s->dt, k0, k1, n, t8_salt(s->dt, k0)) != id) bad++;
         }
     for (const ShortEnt& e : h.short_tab) if (e.id_len != SPL_EMPTY) check(e.k0, (e.id_len >> 24) & 0x7Fu, e.id_len & SPL_ID_MASK);
     for (const LongEnt& e : h.long_tab)
@@ -580,7 +594,7 @@ extern "C" void hs_row_head_check(void* p, uint32_t* out) {
     uint32_t named = 0, nz = 0;
     for (const PfxEnt& pe : h.pfx) { named += pe.id2 != SPL_NO_RANK; if ((pe.id2 != SPL_NO_RANK) != ((pe.lm & 1u) != 0u)) bad++; }
     if (named != two) bad++;
-    for (uint8_t f : h.filt4) nz += f != 0;
+    for (uint16_t f : h.filt4) nz += (f & 0x3Fu) != 0;
     out[0] = keys; out[1] = bad; out[2] = (uint32_t)h.filt4.size(); out[3] = nz;
 }
 

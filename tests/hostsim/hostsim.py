@@ -78,7 +78,7 @@ class HostSim:
                         a.tolist()))
 
     def bucket_stats(self):
-        """(buckets, full buckets) of the tiny, t8 and short tables, and the key groups that found no salt."""
+        """(slots, keys) of the tiny and t8 tables, (buckets, overflowed buckets) of the short table, and the short-table key groups that found no salt."""
         a = np.zeros(7, dtype=np.uint32)
         lib().hs_bucket_stats(self._h, a.ctypes.data)
         return {"tiny": (int(a[0]), int(a[1])), "t8": (int(a[2]), int(a[3])), "short": (int(a[4]), int(a[5])), "unsalted_groups": int(a[6])}
