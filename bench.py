@@ -349,7 +349,7 @@ def main():
         b_alg = (bytes_rot + 4 * sum(n_tokens) + 16 * sum(b.n_docs + 1 for b in batches)) / N_ROT
         achieved = b_alg / (kernels[dom] * 1e-6) / 1e9
         traffic, tsrc = None, None
-        for cand in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "hbm_traffic.json"):
+        for cand in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "hbm_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", cand)
             if os.path.exists(tpath):
                 try:
@@ -366,7 +366,7 @@ def main():
                     "all_kernels_us": kernels}
         # the roofline that binds this kernel: VALU issue.  Counters come from rocprofv3 --pmc (not
         # available inside a plain run): the committed pass over this very command.
-        vname = next((n for n in ("r03_pmc_sq.json", "r02_pmc_sq.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
+        vname = next((n for n in ("r04_pmc_sq.json", "r03_pmc_sq.json", "r02_pmc_sq.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
         vpath = os.path.join(ROOT, "profiles", vname) if vname else ""
         if vname:
             try:

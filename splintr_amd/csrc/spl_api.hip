@@ -42,8 +42,8 @@ int fail(int code, const std::string& msg) {
 
 constexpr size_t QCOUNT_WORDS = 16;      // Batch::qcount
 enum { KI_MARK = 0, KI_SPECIAL, KI_PRETOK, KI_DEFER, KI_BPELANES, KI_BPELONG, KI_COUNT, KI_SCAN, KI_COMPACT, KI_N };
-const char* const k_names[KI_N] = {"memset+k_mark_docs", "k_special_scan", "k_pretok", "k_deferred_wave", "k_bpe_lanes64|k_bpe_segments",
-                                   "k_bpe_long", "k_count", "k_scan", "k_compact_docs|k_tile_out"};
+const char* const k_names[KI_N] = {"memset+k_mark_docs", "k_special_scan", "k_pretok", "k_deferred_wave", "k_bpe_segments",
+                                   "k_bpe_long", "k_range_count", "(unused)", "k_range_out|k_tile_out"};
 
 template <class T> int dev_upload(const std::vector<T>& v, const T** out) {
     void* p = nullptr;
@@ -603,50 +603,9 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
         if (ntiles) hipLaunchKernelGGL(k_tile_out, dim3(ntiles), dim3(TOUT_NT), 0, s, b);
         MARK(KI_N);
     } else {
-#if SPL_MULTIPASS
-    t->bitmap_dirty = true;
-    MARK(KI_MARK);
-    HIP_TRY(hipMemsetAsync(t->d_zero, 0, (nbm * uw + QCOUNT_WORDS) * 4, s));
-    if (n_docs) hipLaunchKernelGGL(k_mark_docs, dim3((uint32_t)((n_docs + 255) / 256)), dim3(256), 0, s, b);
-    MARK(KI_SPECIAL);
-    if (special && n_bytes) {
-        if (!general) hipLaunchKernelGGL(k_special_scan, dim3((uint32_t)((n_bytes + 255) / 256)), dim3(256), 0, s, b);
-        else {
-            hipLaunchKernelGGL(k_special_ends, dim3((uint32_t)((n_bytes + 255) / 256)), dim3(256), 0, s, b);
-            hipLaunchKernelGGL(k_special_select, dim3((uint32_t)((n_docs + 255) / 256)), dim3(256), 0, s, b);
-        }
-    }
-    MARK(KI_PRETOK);
-    if (ntiles) {
-        if (small_tiles) hipLaunchKernelGGL((k_pretok<SPL_TILE_SMALL, false>), dim3(ntiles), dim3(NT), 0, s, PRETOK_EARLY(t->dt, b), t->dt, b);
-        else hipLaunchKernelGGL((k_pretok<SPL_TILE_LARGE, true>), dim3(ntiles), dim3(NT), 0, s, PRETOK_EARLY(t->dt, b), t->dt, b);
-    }
-    MARK(KI_DEFER);
-    if (ntiles) hipLaunchKernelGGL(k_deferred_wave, dim3(256), dim3(64), 0, s, t->dt, b);
-    MARK(KI_BPELANES);
-    if (ntiles && !small_tiles) hipLaunchKernelGGL(k_bpe_lanes64, dim3(256 * 5), dim3(64), 0, s, t->dt, b);
-    if (ntiles && small_tiles) hipLaunchKernelGGL(k_bpe_segments, dim3(std::min<uint32_t>(2048, ntiles / 4 + 8)), dim3(NT), 0, s, t->dt, b);
-    MARK(KI_BPELONG);
-    if (ntiles) hipLaunchKernelGGL(k_bpe_long, dim3(std::min<uint32_t>(2048, ntiles / 4 + 8)), dim3(NT), 0, s, t->dt, b, small_tiles ? 1 : 0);
-    MARK(KI_COUNT);
-    const bool fused_scan = b.n_blk <= 8192;
-    fused_scan_used = fused_scan;
-    if (!fused_scan) hipLaunchKernelGGL(k_count, dim3((b.n_blk + 255) / 256), dim3(256), 0, s, b);
-    MARK(KI_SCAN);
-    if (fused_scan) hipLaunchKernelGGL(k_scan<true>, dim3(1), dim3(1024), 0, s, b);
-    else hipLaunchKernelGGL(k_scan<false>, dim3(1), dim3(1024), 0, s, b);
-    MARK(KI_COMPACT);
-    {
-        const uint32_t n_compact = (b.n_blk * 32 + NT - 1) / NT;
-        const uint32_t n_docblk = (uint32_t)((n_docs + 1 + NT - 1) / NT);
-        hipLaunchKernelGGL(k_compact_docs, dim3(n_compact + n_docblk), dim3(NT), 0, s, b, n_compact);
-    }
-    MARK(KI_N);
-#else
         (void)fused_scan_used;
-        return fail(SPL_EINVAL, "this call needs the multi-pass pipeline, which this build leaves out (-DSPL_MULTIPASS=1): a device call with "
-                                "SPL_WITH_SPECIAL beyond 256 MB, or a forced geometry; split the call -- spl_encode_batch does that by itself");
-#endif
+        return fail(SPL_EINVAL, "a device call with SPL_WITH_SPECIAL beyond 256 MB (or a forced multi-pass geometry) is not supported: the multi-pass "
+                                "pipeline was removed in round 4; split the call at document boundaries -- spl_encode_batch does that by itself");
     }
 #undef MARK
     {
@@ -1651,10 +1610,8 @@ int spl_debug_blocks(spl_tokenizer* t, unsigned long long* out, int max_blocks) 
 
 int spl_debug_phases(spl_tokenizer* t, int enable, unsigned long long stamps_out[16]) {
     if (!t) return fail(SPL_EINVAL, "null handle");
-#if !SPL_MULTIPASS
     if (((enable >> 1) & 7) == 2 || ((enable >> 1) & 7) == 3)
-        return fail(SPL_EINVAL, "spl_debug_phases: geometries 2 and 3 are the multi-pass pipeline, which this build leaves out (-DSPL_MULTIPASS=1)");
-#endif
+        return fail(SPL_EINVAL, "spl_debug_phases: geometries 2 and 3 were the multi-pass pipeline, removed in round 4");
     for (auto& cp : t->ctx) {
         Ctx* c = cp.get();
         HIP_TRY(hipSetDevice(c->device));

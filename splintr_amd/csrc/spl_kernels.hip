@@ -12,10 +12,12 @@
 //   k_tile_out      tile-owned mode: tile records -> dense ids[] and per-document offsets (CSR)
 //   k_mark_docs / k_special_scan
 //                   text-start bitmap from the document offsets; special-token literals
-//   k_deferred_wave, k_bpe_segments, k_bpe_long, k_bpe_lanes64
-//                   queue mode / multi-pass: chains and chunks that went to the global queues
-//   k_range_count / k_range_out (queue mode), k_count / k_scan / k_compact_docs (multi-pass)
+//   k_deferred_wave, k_bpe_segments, k_bpe_long
+//                   queue mode: chains and chunks that went to the global queues
+//   k_range_count / k_range_out (queue mode)
 //                   token bitmaps -> ranks -> CSR
+// (The multi-pass pipeline of rounds 1-3 -- k_bpe_lanes64, k_count, k_scan, k_compact_docs and the k_pretok
+//  instantiations without tile records -- was removed in round 4: no BASELINE configuration reached it.)
 //   k_gatherv_pack / k_gatherv_unpack, k_decode
 //                   slabs around the RCCL all-gather; id -> bytes gather
 //
@@ -34,14 +36,6 @@
 
 #define SPL_DBG_WG (b.dbg_wg == 0xFFFFFFFFu ? gridDim.x / 2 : b.dbg_wg)
 
-#ifndef SPL_MULTIPASS
-#define SPL_MULTIPASS 0        /* 1: also build the multi-pass pipeline (k_pretok without tile records -> k_deferred_wave -> k_bpe_lanes64 /
-                                  k_bpe_segments -> k_bpe_long -> k_count -> k_scan -> k_compact_docs; forced geometries 2 and 3, and
-                                  SPL_WITH_SPECIAL device calls beyond 256 MB).  No BASELINE configuration reaches it -- the host
-                                  pipeline feeds chunks of at most 8 MiB, tile-owned and queue mode cover device calls up to 2 GiB without
-                                  special tokens -- so the shipped library leaves it out: two instantiations of the
-                                  tile kernel and four kernels fewer to build and to keep correct in every fix. */
-#endif
 #ifndef SPL_NO_SLOWPATH
 #define SPL_NO_SLOWPATH 0      /* 1: timing experiment only (wrong ids for keys that overflowed their bucket): a full bucket never sends a probe on to the next one */
 #endif
@@ -1206,47 +1200,6 @@ __global__ __launch_bounds__(64) void k_deferred_wave(DeviceTables T, Batch b) {
 // in LDS (node-major, lane-minor: conflict-free when lanes touch the same node index), merge loop
 // = bpe_serial (spl_lookup.h).  Slow per chunk, but every lane carries its own chain of dependent
 // pair-table probes, so a CU keeps hundreds of them in flight.
-#if SPL_MULTIPASS
-template <int NMAX, int THREADS> struct LaneStore {
-    uint32_t* ids;
-    uint32_t* rks;
-    int lane;
-    __device__ __forceinline__ uint32_t& id(int i) { return ids[i * THREADS + lane]; }
-    __device__ __forceinline__ uint32_t& rk(int i) { return rks[i * THREADS + lane]; }
-};
-struct GlobalText {
-    const uint8_t* text;
-    __device__ __forceinline__ uint32_t txt(int q) const { return text[(uint32_t)q]; }
-};
-__global__ __launch_bounds__(64) void k_bpe_lanes64(DeviceTables T, Batch b) {
-    __shared__ uint32_t s_ids[64 * 64];
-    __shared__ uint32_t s_rks[64 * 64];
-    const uint32_t nq = min(b.qcount[0], b.qcap64);
-    LaneStore<64, 64> st{s_ids, s_rks, (int)threadIdx.x};
-    GlobalText tx{b.text};
-    for (uint32_t it = blockIdx.x * 64 + threadIdx.x; it < nq; it += gridDim.x * 64) {
-        const uint2 item = b.q64[it];
-        const int n = (int)item.y;
-        bpe_serial(T, st, tx, (int)item.x, n);
-        for (int i = 0; i < n; i++) {
-            const uint32_t id = st.id(i);
-            if (id != SPL_DEAD && id != SPL_NO_RANK) emit_token(b, item.x + i, id);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Long chunks (> 64 bytes; plus every miss of a deferred segment).
-//
-// bpe_wave: ONE WAVEFRONT per chunk of up to WAVE_NMAX bytes.  Nodes live in the wavefront's own
-// LDS slab as an index-linked list (id, rank of the pair with the next node, next, prev -- the
-// reference's Node, src/core/bpe.rs:43-54, minus start/len which are implied by the index); lane l
-// owns nodes l, l+64, ...  Per merge: each lane scans its <= 8 nodes, DPP min-reduction of
-// (rank << 9 | index) gives the leftmost minimum, lane 0 relinks, lanes 1 and 2 re-rank the two
-// affected pairs concurrently.  No workgroup barrier: the four wavefronts of a workgroup work
-// on four different chunks.
-// Beyond WAVE_NMAX (pathological single-class runs): bpe_block_lds, then bpe_block_rounds.
-#endif  // SPL_MULTIPASS
 constexpr int GROUP_NMAX = 128;       // 16 lanes x 8 register slots
 constexpr int WAVE_NMAX = 512;
 constexpr uint32_t NIL16 = 0xFFFFu;
@@ -3654,101 +3607,6 @@ __global__ __launch_bounds__(NT) void k_bpe_long(DeviceTables T, Batch b, int su
         }
 }
 
-#if SPL_MULTIPASS
-// ------------------------------------------------------------------------------------------
-// Rank structure over the token-start bitmap.
-__global__ void k_count(Batch b) {
-    const uint32_t blk = blockIdx.x * blockDim.x + threadIdx.x;
-    if (blk >= b.n_blk) return;
-    const uint4* w = reinterpret_cast<const uint4*>(b.tbits + (size_t)blk * 32);
-    uint32_t c = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const uint4 v = w[k];
-        c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
-    }
-    b.blk_base[blk] = c;
-}
-
-// single workgroup: exclusive scan of the per-block token counts; blk_base[n_blk] = total.
-// FUSED = true counts the bitmap words itself (small batches: saves the k_count launch).
-template <bool FUSED>
-__global__ __launch_bounds__(1024) void k_scan(Batch b) {
-    __shared__ uint32_t s_w[16];
-    __shared__ uint32_t s_carry;
-    const int tid = threadIdx.x;
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < b.n_blk; base += 1024) {
-        const uint32_t i = base + tid;
-        uint32_t v = 0;
-        if (i < b.n_blk) {
-            if (FUSED) {
-                const uint4* w = reinterpret_cast<const uint4*>(b.tbits + (size_t)i * 32);
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const uint4 q = w[k];
-                    v += __popc(q.x) + __popc(q.y) + __popc(q.z) + __popc(q.w);
-                }
-            } else {
-                v = b.blk_base[i];
-            }
-        }
-        uint32_t x = wave_scan_incl(v);
-        if ((tid & 63) == 63) s_w[tid >> 6] = x;
-        __syncthreads();
-        uint32_t pre = s_carry;
-        for (int wv = 0; wv < (tid >> 6); wv++) pre += s_w[wv];
-        if (i < b.n_blk) b.blk_base[i] = pre + x - v;
-        __syncthreads();
-        if (tid == 1023) s_carry = pre + x;
-        __syncthreads();
-    }
-    if (tid == 0) b.blk_base[b.n_blk] = s_carry;
-}
-
-// Final pass, two roles in one launch.  Blocks [0, n_compact): one lane per bitmap word (the 32
-// words of a rank block sit in one half-wave): ranks -> dense ids[].  Blocks [n_compact, ...): one
-// lane per document: out_off[d] = rank of the document's first byte.
-__global__ __launch_bounds__(NT) void k_compact_docs(Batch b, uint32_t n_compact) {
-    if (blockIdx.x < n_compact) {
-        const uint32_t w = blockIdx.x * NT + threadIdx.x;          // word index
-        const uint32_t nwords = b.n_blk * 32;
-        uint32_t word = w < nwords ? b.tbits[w] : 0u;
-        const uint32_t cnt = __popc(word);
-        uint32_t x = cnt;
-        const int l32 = threadIdx.x & 31;
-#pragma unroll
-        for (int d = 1; d < 32; d <<= 1) {
-            const uint32_t y = __shfl_up(x, d, 32);
-            if (l32 >= d) x += y;
-        }
-        if (w >= nwords || !word) return;
-        uint64_t r = (uint64_t)b.blk_base[w >> 5] + (x - cnt);
-        const uint32_t p0 = w * 32;
-        while (word) {
-            const int bit = __ffs(word) - 1;
-            word &= word - 1;
-            if (r < b.ids_cap) b.ids_out[r] = b.stage[p0 + bit];
-            r++;
-        }
-        return;
-    }
-    const uint32_t d = (blockIdx.x - n_compact) * NT + threadIdx.x;
-    if (d > b.n_docs) return;
-    if (d == b.n_docs) { b.off_out[d] = b.blk_base[b.n_blk]; return; }
-    const uint64_t p64 = b.doc_off[d];
-    if (p64 >= b.n_bytes) { b.off_out[d] = b.blk_base[b.n_blk]; return; }
-    const uint32_t p = (uint32_t)p64;
-    const uint32_t blk = p / RANK_BLK;
-    uint32_t r = b.blk_base[blk];
-    const uint32_t wfirst = blk * 32, wlast = p >> 5;
-    for (uint32_t w = wfirst; w < wlast; w++) r += __popc(b.tbits[w]);
-    r += __popc(b.tbits[wlast] & ((1u << (p & 31)) - 1u));
-    b.off_out[d] = r;
-}
-
-#endif  // SPL_MULTIPASS
 
 // ------------------------------------------------------------------------------------------
 // decode_bytes (reference src/core/tokenizer.rs:877-897, batch form :945-958): gather token byte

@@ -85,7 +85,7 @@ def test_mistral_v3_special_ids_held_by_the_reference(golden_all):
 
 
 @pytest.mark.parametrize("name", VOCABS)
-@pytest.mark.parametrize("geom", [0, 3, 4, 5])
+@pytest.mark.parametrize("geom", [0, 4, 5])
 def test_invalid_utf8_policy(coracle, name, geom):
     """include/splintr_hip.h, "Text that is not valid UTF-8": the C ABI takes raw bytes; stray continuation
     bytes, truncated / over-long sequences and impossible lead bytes -- also right at document boundaries
@@ -94,8 +94,7 @@ def test_invalid_utf8_policy(coracle, name, geom):
     the input bytes."""
     from splintr_amd import Tokenizer, _ffi
     t = Tokenizer.from_pretrained(name)
-    if _ffi.lib().spl_debug_phases(t.handle, geom << 1, None) != 0:
-        pytest.skip("the multi-pass pipeline is not compiled into this build (-DSPL_MULTIPASS=1)")
+    assert _ffi.lib().spl_debug_phases(t.handle, geom << 1, None) == 0
     docs = invalid_utf8_corpus(31415 + geom, 3000)
     docs += [b"abc\xe4\xb8", b"\x96\x96 def", b"\xf0\x9f", b"\x8c\x8d", b"", b"\x80", b"\xe4", b"\xb8\x96"]
     docs += [b"\x80" * 3000, b"\xe4\xb8" * 1500, (b"ab\xc3" * 400) + b"\n" + b"\xbf" * 700]
@@ -110,7 +109,7 @@ def test_invalid_utf8_policy(coracle, name, geom):
     assert got == docs
 
 
-@pytest.mark.parametrize("geom", [0, 3])
+@pytest.mark.parametrize("geom", [0, 4])
 def test_special_token_sets_whose_occurrences_overlap(geom):
     """A user-supplied special-token map is arbitrary (src/core/tokenizer.rs:304, 429-434): literals that
     contain one another, that chain (a suffix of one is a prefix of another or of itself), and literals
@@ -194,7 +193,7 @@ def _long_word_texts(seed, n_docs):
     return out
 
 
-@pytest.mark.parametrize("geom", [0, 3, 5])
+@pytest.mark.parametrize("geom", [0, 4, 5])
 @pytest.mark.parametrize("name", VOCABS)
 def test_long_words_merge_two_to_a_wavefront(coracle, name, geom):
     """Chunks of 17..32 bytes share a wavefront two by two (32 lanes each), longer ones take one alone, spans
@@ -230,22 +229,20 @@ def test_corpus_fixtures_sha256():
 
 def _force_tiles(name, mode):
     """Development hook of the C ABI: 0 auto, 1 small tiles (tile-owned mode when the batch qualifies: 800+192
-    up to 1.25 MB, 864+128 beyond), 2 large tiles (4096+480), 3 small tiles (768+224) with the multi-pass
-    pipeline, 4 queue mode, 5 tile-owned mode with 864+128 at any size."""
+    up to 1.25 MB, 864+128 beyond), 4 queue mode, 5 tile-owned mode with 864+128 at any size.  (2 and 3 were the
+    multi-pass pipeline, removed in round 4.)"""
     import ctypes
     from splintr_amd import _ffi
     st = (ctypes.c_uint64 * 16)()
     rc = _ffi.lib().spl_debug_phases(tok(name).handle, mode << 1, st)
-    if rc != 0 and mode in (2, 3):
-        pytest.skip("the multi-pass pipeline is not compiled into this build (-DSPL_MULTIPASS=1)")
     assert rc == 0
 
 
-@pytest.mark.parametrize("geom", [1, 2, 3, 5])
+@pytest.mark.parametrize("geom", [1, 5, 4])
 @pytest.mark.parametrize("name", ["cl100k_base", "o200k_base"])
 def test_tile_and_window_edges(coracle, name, geom):
     """Documents and runs placed around the tile edge and the right halo of EVERY tile geometry (tile-owned
-    mode: 800 + 192 at this size, 864 + 128 forced by 5; multi-pass: 768 + 224 and 4096 + 480)."""
+    mode: 800 + 192 at this size, 864 + 128 forced by 5; queue mode: 768 + 224)."""
     rng = random.Random(5)
     texts = []
     for size in (1, 2, 31, 32, 33, 767, 768, 769, 799, 800, 801, 863, 864, 865, 991, 992, 993, 1023, 1024, 1025, 1535, 1536, 1537,
@@ -266,7 +263,7 @@ def test_tile_and_window_edges(coracle, name, geom):
         _force_tiles(name, 0)
 
 
-@pytest.mark.parametrize("geom", [0, 3, 4, 5])
+@pytest.mark.parametrize("geom", [0, 4, 5])
 @pytest.mark.parametrize("name", ["cl100k_base", "o200k_base"])
 def test_chunk_that_straddles_the_window_end(coracle, name, geom):
     """A chain that outgrows its window and ends in a multi-byte character on the window's edge: a run of numbers
@@ -336,7 +333,7 @@ def test_huge_single_chunk(coracle):
         assert_batch_equal("cl100k_base", [t, "after"], coracle)
 
 
-@pytest.mark.parametrize("geom", [1, 3, 5])
+@pytest.mark.parametrize("geom", [1, 4, 5])
 @pytest.mark.parametrize("name", VOCABS)
 def test_oversize_chunks_merge_by_rounds(coracle, name, geom):
     """Chunks beyond the LDS node lists are merged a whole rank at a time (bpe_block_rounds): low-entropy
@@ -561,10 +558,10 @@ def test_gatherv_bucketed_unpack_two_simulated_ranks(coracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("geom", [0, 2, 4])
+@pytest.mark.parametrize("geom", [0, 5, 4])
 def test_encode_packed_slab_equals_pack_kernel(geom):
     """spl_encode_batch_device_packed must leave the same slab as encode + spl_gatherv_pack, in
-    tile-owned mode (the last kernel writes it) and in multi-pass mode (pack kernel queued)."""
+    tile-owned mode (the last kernel writes it) and in queue mode (pack kernel queued)."""
     import torch
     from splintr_amd import _ffi, corpus
     from splintr_amd.device import DeviceBatch, encode_device, reserve
@@ -698,11 +695,11 @@ def _multibyte_texts(seed, n_docs, doc_bytes):
     return out
 
 
-@pytest.mark.parametrize("geom", [0, 1, 3])
+@pytest.mark.parametrize("geom", [0, 1, 4])
 @pytest.mark.parametrize("name", VOCABS)
 def test_multibyte_text_merges_by_segments(coracle, name, geom):
     """Multi-byte text goes through the segment merge (bpe_wave64_tab's groups, bpe_tail_segments in the
-    tile tail, k_bpe_segments over the global queue in the multi-pass pipeline): ~1.5 MB of it, every
+    tile tail, k_bpe_segments over the global queue in queue mode): ~1.5 MB of it, every
     vocabulary, documents of 200 B to 20 KB so that tile and window edges fall everywhere."""
     texts = _multibyte_texts(41, 60, 20000) + _multibyte_texts(42, 400, 600) + _multibyte_texts(43, 300, 200)
     _force_tiles(name, geom)
@@ -726,11 +723,11 @@ def test_multibyte_text_in_queue_mode(coracle, name):
         _force_tiles(name, 0)
 
 
-@pytest.mark.parametrize("geom", [0, 3])
+@pytest.mark.parametrize("geom", [0, 4])
 @pytest.mark.parametrize("name", ["cl100k_base", "deepseek_v3"])
 def test_multibyte_text_with_special_tokens(coracle, name, geom):
     """Special-token literals inside multi-byte text: their spans cut the chunks that the segment merge
-    then works on (tile-owned mode with the skip bitmaps, and the multi-pass pipeline)."""
+    then works on (tile-owned mode with the skip bitmaps; queue mode has no special-token form and falls back to it)."""
     with open(os.path.join(ROOT, "splintr_amd", "data", "special_tokens.json"), encoding="utf-8") as f:
         lits = list(json.load(f)[name])
     rng = random.Random(61)
@@ -749,7 +746,7 @@ def test_multibyte_text_with_special_tokens(coracle, name, geom):
         _force_tiles(name, 0)
 
 
-@pytest.mark.parametrize("geom", [0, 3, 4])
+@pytest.mark.parametrize("geom", [0, 4])
 @pytest.mark.parametrize("name", VOCABS)
 def test_segment_pass_corner_cases(coracle, name, geom):
     """Crafted inputs for the corners of the segment pass: more multi-byte medium chunks in a tile than
@@ -795,7 +792,7 @@ def test_special_tokens_in_a_large_tile_owned_batch(coracle):
     assert_batch_equal(name, texts, coracle, special=True)
 
 
-@pytest.mark.parametrize("geom", [0, 3])
+@pytest.mark.parametrize("geom", [0, 4])
 @pytest.mark.parametrize("name", ["cl100k_base", "o200k_base"])
 def test_chunks_longer_than_a_chain_window(coracle, name, geom):
     """A chunk that no staged window holds (2 KiB) is a run of one repeated character: tile-owned mode finds

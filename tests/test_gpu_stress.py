@@ -17,7 +17,7 @@ BUDGET_S = 25.0
 
 
 def _compiled(modes):
-    """forced geometries 2 and 3 are the multi-pass pipeline: only in -DSPL_MULTIPASS=1 builds"""
+    """the forced geometries this build knows (2 and 3 were the multi-pass pipeline, removed in round 4)"""
     import ctypes
     from splintr_amd import _ffi
     st = (ctypes.c_uint64 * 16)()
