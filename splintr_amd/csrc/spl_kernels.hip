@@ -138,6 +138,17 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// threadIdx.x for the helpers k_pretok inlines: opaque, so that what is derived from it (lane and group indices, row
+// addresses, compare masks) is computed where it is used.  Left to common-subexpression elimination those values were kept
+// alive across the 46 000-instruction kernel: with this, k_pretok<800,192> has NO spilled VGPR (round 3: 20, 84 B of scratch
+// per lane) -- found while building the persistent-workgroup experiment (profiles/r04_persistent_workgroups.txt), whose loop
+// made LLVM hoist all of it.
+__device__ __forceinline__ uint32_t tidx() {
+    uint32_t x = threadIdx.x;
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 // ------------------------------------------------------------------------------------------
 __global__ void k_mark_docs(Batch b) {
     const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
@@ -422,7 +433,7 @@ __device__ __forceinline__ uint32_t wave_scan_max(uint32_t x) {
 // nibble l of lane j.  Three butterfly stages (lane ^ 4 / ^ 2 / ^ 1 with 16 / 8 / 4 bits): the partner's word by DPP, rotated
 // so that the nibbles to take line up (v_alignbit), merged under a per-lane mask (v_bfi).  All 64 lanes must be active.
 __device__ __forceinline__ uint32_t nib_transpose8(uint32_t v) {
-    const uint32_t l = threadIdx.x & 7u;
+    const uint32_t l = tidx() & 7u;
     {   // stride 4: lanes with bit 2 clear keep nibbles 0-3 and take the partner's 0-3 as their 4-7; the others the mirror image
         uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xF, 0x5, false);     // row_shl:4 -> banks 0, 2 (lane + 4)
         t = (uint32_t)__builtin_amdgcn_update_dpp((int)t, (int)v, 0x114, 0xF, 0xA, false);               // row_shr:4 -> banks 1, 3 (lane - 4)
@@ -475,7 +486,7 @@ template <int NW> __device__ __forceinline__ int prev_set_bit(const uint32_t (&a
 #ifdef SPL_MERGE_TIMING
 __device__ unsigned long long g_mt[8];
 #define MT_T(v) const long long v = clock64()
-#define MT_ACC(i, a, b_) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) g_mt[i] += (unsigned long long)((b_) - (a)); } while (0)
+#define MT_ACC(i, a, b_) do { if (tidx() == 0 && blockIdx.x == gridDim.x / 2) g_mt[i] += (unsigned long long)((b_) - (a)); } while (0)
 #else
 #define MT_T(v)
 #define MT_ACC(i, a, b_)
@@ -484,7 +495,7 @@ template <int NPL, class ByteAt, class Emit>
 __device__ __forceinline__ void bpe_group16(const DeviceTables& T, int n, ByteAt byte_at, Emit emit) {
     constexpr int NW = (16 * NPL + 31) / 32;
     MT_T(t_init0);
-    const int lane = threadIdx.x & 63;
+    const int lane = tidx() & 63;
     const int gl = lane & 15;
     const int gbase = lane - gl;
     uint32_t id[NPL], rk[NPL];
@@ -549,7 +560,7 @@ __device__ __forceinline__ void bpe_group16(const DeviceTables& T, int n, ByteAt
             if (NPL > 1 && h >= 0 && la == lh && gl == la) res2 = pair_rank(T, sel_h, mn);
 #ifdef SPL_MERGE_TIMING
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            { MT_T(t4); MT_ACC(4, t3, t4); if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) g_mt[6] += 1; }
+            { MT_T(t4); MT_ACC(4, t3, t4); if (tidx() == 0 && blockIdx.x == gridDim.x / 2) g_mt[6] += 1; }
 #endif
 #pragma unroll
             for (int w = 0; w < NW; w++)
@@ -659,7 +670,7 @@ constexpr int FAR_UNBOUNDED = 1 << 20;
 template <int GW, class Emit>
 __device__ __forceinline__ void group_merge(const DeviceTables& T, const uint32_t* row, uint32_t id, int n, int far_max, Emit emit, int sub = GW) {
     static_assert(GW == 16 || GW == 32, "groups of 16 or 32 lanes");
-    const int lane = threadIdx.x & 63;
+    const int lane = tidx() & 63;
     const int gl = lane & (sub - 1);
     const int gbase = lane - gl;
     const bool own = gl < n;
@@ -714,7 +725,7 @@ __device__ __forceinline__ void group_merge(const DeviceTables& T, const uint32_
 #endif
 template <int GW, class Emit>
 __device__ __forceinline__ void group_merge_near(const uint32_t* row, uint32_t id, int n, Emit emit, int sub = GW) {
-    const int gl = (threadIdx.x & 63) & (sub - 1);
+    const int gl = (tidx() & 63) & (sub - 1);
     uint32_t rk = (gl + 1 < n) ? row[0] : SPL_NO_RANK;
     uint32_t alive = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
     for (;;) {
@@ -753,7 +764,7 @@ __device__ __forceinline__ void group16_merge(const DeviceTables& T, const uint3
 }
 
 #ifdef SPL_DEBUG_STAMPS
-#define SPL_WT(i) do { if (wt && (threadIdx.x & 63) == 0) wt[i] = clock64(); } while (0)
+#define SPL_WT(i) do { if (wt && (tidx() & 63) == 0) wt[i] = clock64(); } while (0)
 #else
 #define SPL_WT(i) do { } while (0)
 #endif
@@ -843,8 +854,8 @@ __device__ __forceinline__ void bpe_group_tab(const DeviceTables& T, const LdsAc
                                               Emit emit, long long* wt = nullptr, int width = GW) {
     (void)wt;
     SPL_WT(0);
-    const int gl = (threadIdx.x & 63) & (width - 1);
-    uint32_t* row = sub + ((threadIdx.x & 63) & (GW - 1)) * SUB_W;
+    const int gl = (tidx() & 63) & (width - 1);
+    uint32_t* row = sub + ((tidx() & 63) & (GW - 1)) * SUB_W;
     int far_max;
     const uint32_t id = tab_row(T, tx, gl < n, p + gl, n - gl, row, far_max, wt);
     if (SPL_MERGE_NEAR && !__any(far_max > 0)) group_merge_near<GW>(row, id, n, emit, width);
@@ -864,7 +875,7 @@ __device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const Lds
 // 17..64-byte chunks, whose chains are the critical path of a small batch.
 template <class ByteAt, class Emit>
 __device__ __forceinline__ void bpe_wave64_regs(const DeviceTables& T, int n, ByteAt byte_at, Emit emit) {
-    const int lane = threadIdx.x & 63;
+    const int lane = tidx() & 63;
     uint32_t id = lane < n ? T.byte_id[byte_at(lane)] : SPL_DEAD;
     const uint32_t idn = __shfl(id, lane + 1);
     uint32_t rk = (lane + 1 < n) ? pair_rank(T, id, idn) : SPL_NO_RANK;
@@ -904,7 +915,7 @@ __device__ __forceinline__ void bpe_wave64_regs(const DeviceTables& T, int n, By
 template <class Emit>
 __device__ __forceinline__ void wave64_merge(const DeviceTables& T, const uint32_t* row, unsigned long long alive, int end,
                                              uint32_t rk, uint32_t idv, int far_max, Emit emit) {
-    const int lane = threadIdx.x & 63;
+    const int lane = tidx() & 63;
     for (;;) {
         const uint32_t key = rk == SPL_NO_RANK ? 0xFFFFFFFFu : ((rk << 6) | (uint32_t)lane);
         uint32_t m = row16_min(key);
@@ -944,7 +955,7 @@ __device__ __forceinline__ void wave64_merge(const DeviceTables& T, const uint32
 template <class Emit>
 __device__ __forceinline__ void bpe_wave64_tab(const DeviceTables& T, const LdsAcc& tx, int p, int n, uint32_t* sub,
                                                Emit emit) {
-    const int lane = threadIdx.x & 63;
+    const int lane = tidx() & 63;
     const bool own = lane < n;
     const int maxlen = own ? (n - lane < SUB_LMAX ? n - lane : SUB_LMAX) : 0;
     const uint32_t w0 = own ? tx.load32(p + lane) : 0u;
@@ -1106,7 +1117,7 @@ __global__ __launch_bounds__(64) void k_deferred_wave(DeviceTables T, Batch b) {
     __shared__ __attribute__((aligned(16))) uint8_t s_txt[DEFER_WIN + 32];
     __shared__ uint8_t s_rec[DEFER_WIN + 32];
     __shared__ uint8_t s_ascii[128];
-    const int lane = threadIdx.x;
+    const int lane = tidx();
     const uint32_t nq = min(b.qcount[3], b.qcapdefer);
     const int64_t B = b.n_bytes;
     for (int k = lane; k < 128; k += 64) s_ascii[k] = T.ucls_stage2[((uint32_t)T.ucls_stage1[0] << T.ucls_shift) + k];
@@ -1208,7 +1219,7 @@ constexpr uint32_t NIL16 = 0xFFFFu;
 template <class Emit>
 __device__ __forceinline__ void bpe_wave(const DeviceTables& T, const Batch& b, uint32_t pos, int n, uint32_t* s_id,
                                          uint32_t* s_rk, uint16_t* s_nx, uint16_t* s_pv, Emit emit) {
-    const int lane = threadIdx.x & 63;
+    const int lane = tidx() & 63;
     for (int i = lane; i < n; i += 64) {
         s_id[i] = T.byte_id[b.text[pos + i]];
         s_nx[i] = (uint16_t)(i + 1 < n ? i + 1 : (int)NIL16);
@@ -1266,7 +1277,7 @@ constexpr int BLOCK_LDS_NMAX = 2048;      // index bits in the reduction key
 template <class Emit>
 __device__ __forceinline__ void bpe_block_lds(const DeviceTables& T, const Batch& b, uint32_t pos, int n, uint32_t* s_id,
                                               uint32_t* s_rk, uint16_t* s_nx, uint16_t* s_pv, uint32_t* s_red4, Emit emit) {
-    const int tid = threadIdx.x;
+    const int tid = tidx();
     for (int i = tid; i < n; i += NT) {
         s_id[i] = T.byte_id[b.text[pos + i]];
         s_nx[i] = (uint16_t)(i + 1 < n ? i + 1 : (int)NIL16);
@@ -1344,7 +1355,7 @@ __device__ __forceinline__ uint32_t mbcnt64(unsigned long long mask) {      // s
 __device__ __forceinline__ void bpe_rounds_core(const uint8_t* text, const uint32_t* byte_id, const uint64_t* pair_tab,
                                                 uint32_t pair_mask, uint32_t* ids, uint32_t* rks, uint32_t* aux, const int n,
                                                 uint32_t* s_red4, int& n_out, const uint32_t*& pos_out) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = tidx(), lane = tid & 63, wv = tid >> 6;
     DeviceTables T{};
     T.pair_tab = pair_tab;
     T.pair_mask = pair_mask;
@@ -1526,11 +1537,11 @@ __device__ __forceinline__ void bpe_block_rounds(const DeviceTables& T, const Ba
     bpe_rounds_core(b.text + pos, T.byte_id, T.pair_tab, T.pair_mask, ids, b.rank_scr + pos, aux, n, s_red4, nc, posbuf);
     const uint32_t* from = ids;
     if (posbuf) {                                         // compacted: the ids leave stage[] before tokens are written there
-        for (int i = threadIdx.x; i < nc; i += NT) aux[i] = ids[i];
+        for (int i = tidx(); i < nc; i += NT) aux[i] = ids[i];
         __syncthreads();
         from = aux;
     }
-    for (int i = threadIdx.x; i < nc; i += NT) {          // survivors become tokens
+    for (int i = tidx(); i < nc; i += NT) {          // survivors become tokens
         const uint32_t id = from[i];
         if (id != SPL_DEAD && id != SPL_NO_RANK) emit(pos + (posbuf ? posbuf[i] : (uint32_t)i), id);
     }
@@ -1574,7 +1585,7 @@ template <int NPL, class IdAt, class Emit>
 __device__ __forceinline__ void wave_tab_merge(const DeviceTables& T, int n, const uint32_t* sub, IdAt id_at, Emit emit);
 template <int NPL, class WordAt, class Emit>
 __device__ __forceinline__ void bpe_wave_tab(const DeviceTables& T, int n, uint32_t* sub, WordAt word_at, Emit emit) {
-    const int lane = threadIdx.x & 63;
+    const int lane = tidx() & 63;
     const int slots = (n + 63) >> 6;
 #pragma nounroll
     for (int job = 0; job < slots * SUB_W; job++) {
@@ -1591,7 +1602,7 @@ __device__ __forceinline__ void bpe_wave_tab(const DeviceTables& T, int n, uint3
 // The merge loop of bpe_wave_tab over a filled table: `sub` is row 0, id_at(i) the id of byte i.
 template <int NPL, class IdAt, class Emit>
 __device__ __forceinline__ void wave_tab_merge(const DeviceTables& T, int n, const uint32_t* sub, IdAt id_at, Emit emit) {
-    const int lane = threadIdx.x & 63;
+    const int lane = tidx() & 63;
     uint32_t id[NPL], rk[NPL];
 #pragma unroll
     for (int k = 0; k < NPL; k++) {
@@ -1768,7 +1779,7 @@ template <int XNPL, class EmitG>
 __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, const Batch& b, uint32_t* s_lq, uint32_t nl,
                                                       uint32_t* slab, uint32_t* scr, uint32_t* s_wsum4, const uint8_t* win_txt,
                                                       int64_t win_lo, int64_t win_hi, EmitG emit_g) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = tidx(), lane = tid & 63, wv = tid >> 6;
     uint32_t* const off = scr + SG_OFF;
     uint32_t* const item = scr + SG_ITEM;
     uint32_t* const hard = scr + SG_HARD;
