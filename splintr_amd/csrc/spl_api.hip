@@ -241,7 +241,7 @@ struct Ctx {
         hipFree((void*)dt.tiny_tab); hipFree((void*)dt.t8_tab);
         hipFree((void*)dt.long_tab); hipFree((void*)dt.key_blob); hipFree((void*)dt.pair_tab);
         hipFree((void*)dt.byte_id); hipFree((void*)dt.p8_tab); hipFree((void*)dt.len_mask);
-        hipFree((void*)dt.pfx); hipFree((void*)dt.filt4);
+        hipFree((void*)dt.pfx); hipFree((void*)dt.filt4); hipFree((void*)dt.akind);
         hipFree((void*)d_tok_off); hipFree((void*)d_tok_bytes); hipFree(d_sp_lits);
         hipFree((void*)d_dec_sp_ids); hipFree((void*)d_dec_sp_off);
         hipFree(d_ids); hipFree(d_oo);
@@ -312,6 +312,14 @@ int upload_tables(Ctx& c, const HostTables& ht) {
     c.dt.filt4_shift = ht.filt4_shift;
     c.dt.ucls_shift = ht.ucls_shift;
     c.dt.ascii_base = (uint32_t)ht.ucls_stage1[0] << ht.ucls_shift;
+    {
+        std::vector<uint32_t> ak(256);
+        for (uint32_t ch = 0; ch < 128; ch++) {
+            const KindEnt e = ascii_entry(ht.pattern, ch, ht.ucls_stage2[c.dt.ascii_base + ch]);
+            ak[2 * ch] = e.x; ak[2 * ch + 1] = e.y;
+        }
+        if ((rc = dev_upload(ak, &c.dt.akind))) return rc;
+    }
     c.dt.cjk_fast = ht.cjk_fast ? 1u : 0u;
     c.dt.short_mask = (uint32_t)(ht.short_tab.size() / SPL_SHORT_BUCKET) - 1;
     c.dt.tiny_mask = (uint32_t)((ht.tiny_tab.size() - 4) / SPL_TINY_WORDS) - 1;      // (slots; 4 words of padding behind them)

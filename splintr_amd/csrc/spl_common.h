@@ -145,6 +145,10 @@ struct DeviceTables {
     // all of them).
     const uint16_t* len_mask;  uint32_t tiny_free, t8_free;
     uint32_t ascii_base;      // ucls_stage1[0] << ucls_shift: where the classes of U+0000..U+007F start in ucls_stage2
+    // akind[2 c], akind[2 c + 1]: the kind-nibble entry of the ASCII byte c for this handle's split pattern (spl_scan_words.h
+    // ascii_entry: what the byte adds to the two nibble words, its class code in the top nibble) -- built once on the host;
+    // k_pretok copies the 1 KB into LDS instead of deriving it from the class table in every workgroup
+    const uint32_t* akind;
     // pfx[b0 | b1 << 8]: len_mask's entry and the id of the two-byte token in one 8-byte load (the substring
     // tabulation and the whole-chunk probe read this one; len_mask stays for the generic probes).
     // filt4[hash_f4(first four bytes) >> filt4_shift]: bit k (k = 0..4) set iff SOME token of exactly 4 + k bytes
@@ -167,12 +171,11 @@ SPL_HD uint32_t mix32(uint32_t h) {
 }
 // `salt` (tiny, t8 and short tables): a byte the table builder chose for all keys that begin with the
 // same two bytes so that none of them lands in a bucket that is full (DeviceTables::len_mask).
-SPL_HD uint32_t hash_tiny(uint32_t k0, uint32_t len, uint32_t salt = 0) {
-    return mix32(k0 * 0x9E3779B1u ^ (len * 0x27D4EB2Fu) ^ (salt * 0xC2B2AE3Du));
-}
 SPL_HD uint32_t hash_t8(uint32_t k0, uint32_t k1, uint32_t len, uint32_t salt = 0) {
     return mix32(k0 * 0x9E3779B1u ^ (k1 * 0x85EBCA77u + 0x165667B1u) ^ (len * 0x27D4EB2Fu) ^ (salt * 0xC2B2AE3Du));
 }
+// (the t8 hash with no second word: a probe whose lanes hold keys of both tables computes ONE hash)
+SPL_HD uint32_t hash_tiny(uint32_t k0, uint32_t len, uint32_t salt = 0) { return hash_t8(k0, 0u, len, salt); }
 SPL_HD uint32_t hash_p8(uint32_t k0, uint32_t k1) { return hash_t8(k0, k1, 9u); }
 SPL_HD uint32_t p8_tag(uint32_t k0, uint32_t k1) {                                   // 1 .. 0xFFFFFE
     return mix32(k0 * 0x85EBCA77u ^ (k1 * 0xC2B2AE3Du + 0x27D4EB2Fu)) % 0xFFFFFEu + 1u;

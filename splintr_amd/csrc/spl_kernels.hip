@@ -604,8 +604,8 @@ __device__ __forceinline__ uint32_t probe_short_mixed(const DeviceTables& T, uin
     if (SPL_ROW_FILTER && n >= 4u && !((f4 >> (n <= (uint32_t)SPL_T8_MAX ? n - 4u : 5u)) & 1u)) return SPL_NO_RANK;
     if (tiny || t8) {
         // one entry, one compare (the builder gave every key a slot of its own)
-        const uint32_t* e = tiny ? T.tiny_tab + (size_t)(hash_tiny(k0, n, lm >> 16) & T.tiny_mask) * SPL_TINY_WORDS
-                                 : T.t8_tab + (size_t)(hash_t8(k0, k1, n, f4 >> SPL_F4_MASK_BITS) & T.t8_mask) * SPL_T8_WORDS;
+        const uint32_t h = hash_t8(k0, tiny ? 0u : k1, n, tiny ? lm >> 16 : f4 >> SPL_F4_MASK_BITS);     // (== hash_tiny for a tiny key)
+        const uint32_t* e = tiny ? T.tiny_tab + (size_t)(h & T.tiny_mask) * SPL_TINY_WORDS : T.t8_tab + (size_t)(h & T.t8_mask) * SPL_T8_WORDS;
         const Ent3 q = *reinterpret_cast<const Ent3*>(e);          // (a tiny entry and the first word of the next one: the tables are padded)
         const uint32_t idw = tiny ? q.y : q.z;
         const bool hit = (q.x == k0) & (tiny | (q.y == k1)) & ((idw >> 24) == n);
@@ -2069,15 +2069,15 @@ inline uint32_t pretok_flags(const DeviceTables& T, const Batch& b) {
 // the kernel-argument segment of k_pretok as the ABI lays it out (every argument at its natural alignment, in order)
 struct PretokKernargs {
     const uint8_t* e_text; const uint64_t* e_doc_off; uint32_t e_n_bytes, e_n_docs; unsigned long long* e_dbg;
-    const uint8_t* e_ascii; uint32_t e_flags; DeviceTables T; Batch b;
+    const uint32_t* e_akind; uint32_t e_flags; DeviceTables T; Batch b;
 };
-#define PRETOK_EARLY(T, b) (b).text, (b).doc_off, (b).n_bytes, (b).n_docs, (b).dbg, (T).ucls_stage2 + (T).ascii_base, pretok_flags(T, b)
+#define PRETOK_EARLY(T, b) (b).text, (b).doc_off, (b).n_bytes, (b).n_docs, (b).dbg, (T).akind, pretok_flags(T, b)
 template <int TB_, int RH_, bool EXPORT_MEDIUM, bool DIRECT = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPL_PRETOK_WAVES)))
 void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_bytes, uint32_t e_n_docs, unsigned long long* e_dbg,
-              const uint8_t* e_ascii, uint32_t e_flags, DeviceTables T_ka, Batch b_ka) {
+              const uint32_t* e_akind, uint32_t e_flags, DeviceTables T_ka, Batch b_ka) {
     // The e_* arguments repeat what the first phase needs (text, offsets, sizes, which optional bitmaps exist, the
-    // pattern, the ASCII class table) as LEADING SCALARS -- the first line of the argument segment -- so that the text
+    // pattern, the ASCII kind table) as LEADING SCALARS -- the first line of the argument segment -- so that the text
     // and offset loads go out before the two structs are touched: 0.5 KB that five thousand wavefronts ask the same
     // few L2 lines for at the same moment (profiles/r03_launch_probes.txt).  The structs themselves are read through
     // the kernel-argument segment pointer, laundered BEHIND the first text loads (T and b below): left to itself the
@@ -2223,10 +2223,10 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
         s_kill[tid] = 0; s_add[tid] = 0;
         s_tbits[tid] = 0;
     }
-    if (tid < 128) {
-        const uint32_t cls = e_ascii[tid];
-        s_ascii[tid] = (uint8_t)cls;
-        s_aent[tid] = ascii_entry(KPAT, (uint32_t)tid, cls);        // (spl_scan_words.h: kind nibbles + record of an ASCII byte)
+    if (tid < 128) {                                      // the ASCII kind table (spl_scan_words.h), built once per handle on the host: 1 KB
+        const uint2 e = reinterpret_cast<const uint2*>(e_akind)[tid];
+        s_aent[tid] = KindEnt{e.x, e.y};
+        s_ascii[tid] = (uint8_t)(e.y >> 28);              // (the byte's class code rides in the top nibble)
     } else if (tid < 144) s_kent[tid - 128] = kind_entry((uint32_t)tid - 128u);
     if (tid < 4) s_nq[tid] = 0;
     if (tid < 17) s_scnt[tid] = 0;                    // (the counting sort of the merge phase: zeroed here, one barrier less there)

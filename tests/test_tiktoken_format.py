@@ -115,6 +115,8 @@ def test_constructors_on_tiktoken_text(tmp_path, name):
     with pytest.raises(ValueError):
         Tokenizer.from_bytes(b"not base64!! 0\n", pattern)
     with pytest.raises(ValueError):
-        Tokenizer.from_bytes(blob, r"\w+|\s+")                          # a pattern the scanner does not implement
+        Tokenizer.from_bytes(blob, r"\p{Han}+|\s+")                     # a construct the host splitter refuses (scripts)
     with pytest.raises(IOError):
-        Tokenizer(str(path), r"\w+|\s+")
+        Tokenizer(str(path), r"(?<=a)b|\s+")
+    t = (Tokenizer.from_bytes_byte_level if byte_level else Tokenizer.from_bytes)(blob, r"\w+|\s+|[^\w\s]+")   # (round 4: \w is accepted; split on the host cores)
+    assert t.has_custom_pattern and t.decode(t.encode("snake_case x1, y")) == "snake_case x1, y"
