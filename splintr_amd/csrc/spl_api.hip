@@ -608,7 +608,7 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
         else if (ntiles) hipLaunchKernelGGL((k_pretok<SPL_TILE_DIRECT_A, false, true>), dim3(ntiles), dim3(NT), 0, s, PRETOK_EARLY(t->dt, b), t->dt, b);
         else HIP_TRY(hipMemsetAsync(d_out_off, 0, (n_docs + 1) * 8, s));
         MARK(KI_DEFER); MARK(KI_BPELANES); MARK(KI_BPELONG); MARK(KI_COUNT); MARK(KI_SCAN); MARK(KI_COMPACT);
-        if (ntiles) hipLaunchKernelGGL(k_tile_out, dim3(ntiles), dim3(TOUT_NT), 0, s, b);
+        if (ntiles) hipLaunchKernelGGL(k_tile_out, dim3(ntiles), dim3(TOUT_NT), 0, s, tile_out_args(b));
         MARK(KI_N);
     } else {
         (void)fused_scan_used;

@@ -3338,7 +3338,18 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
 #define SPL_TILE_OUT_NT 128
 #endif
 constexpr int TOUT_NT = SPL_TILE_OUT_NT;               // threads of a k_tile_out workgroup (a tile has a few hundred tokens)
-__global__ __launch_bounds__(TOUT_NT) void k_tile_out(Batch b) {
+// What k_tile_out reads of the batch: two lines of argument segment instead of the six of a whole Batch (every wavefront of a launch
+// waits for its freshly written arguments first: profiles/r03_launch_probes.txt)
+struct TileOutArgs {
+    uint32_t* tctl; const TileDesc* tdesc; const uint32_t* tile_ids; uint32_t* ids_out; uint64_t ids_cap; uint64_t* off_out; uint64_t* off_out2;
+    uint32_t* slab; uint32_t* tbits; const uint32_t* stage; const uint32_t* skip;
+    uint32_t tpar, tgroups, tslot, slab_cap, slab_max_docs, n_docs;
+};
+inline TileOutArgs tile_out_args(const Batch& b) {
+    return TileOutArgs{b.tctl, b.tdesc, b.tile_ids, b.ids_out, b.ids_cap, b.off_out, b.off_out2, b.slab, b.tbits, b.stage, b.skip,
+                       b.tpar, b.tgroups, b.tslot, b.slab_cap, b.slab_max_docs, b.n_docs};
+}
+__global__ __launch_bounds__(TOUT_NT) void k_tile_out(TileOutArgs b) {
     __shared__ unsigned long long s_part[TOUT_NT / 64];
     __shared__ uint32_t s_wsum[TOUT_NT / 64];
     const uint32_t t = xcd_tile();
