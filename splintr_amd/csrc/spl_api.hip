@@ -535,7 +535,7 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
                   "the workspace is sized for SPL_TILE_SMALL's window and tile count");
     const bool direct_b = direct && (t->force_tile == 5 || n_bytes > SPL_DIRECT_A_MAX_BYTES);
     const uint32_t tile_bytes = direct ? (direct_b ? TileGeom<SPL_TILE_DIRECT_B>::TBv : TileGeom<SPL_TILE_DIRECT_A>::TBv)
-                              : small_tiles ? TileGeom<SPL_TILE_SMALL>::TBv : TileGeom<SPL_TILE_LARGE>::TBv;
+                              : TileGeom<SPL_TILE_SMALL>::TBv;
     const uint32_t ntiles = (uint32_t)((n_bytes + tile_bytes - 1) / tile_bytes);
     // (A/B on the 1 MB bench batch: folding these launches together -- clean-after-use bitmaps, one
     //  tail kernel with a grid barrier and a last-workgroup scan -- was SLOWER than this plain
@@ -552,7 +552,7 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
         MARK(KI_MARK);
         if (n_docs) hipLaunchKernelGGL(k_mark_docs, dim3((uint32_t)((n_docs + 255) / 256)), dim3(256), 0, s, b);
         MARK(KI_SPECIAL); MARK(KI_PRETOK);
-        hipLaunchKernelGGL((k_pretok<SPL_TILE_SMALL, false, true>), dim3(ntiles), dim3(NT), 0, s, PRETOK_EARLY(t->dt, b), t->dt, b);
+        hipLaunchKernelGGL((k_pretok<SPL_TILE_SMALL>), dim3(ntiles), dim3(NT), 0, s, PRETOK_EARLY(t->dt, b), t->dt, b);
         MARK(KI_DEFER);
         hipLaunchKernelGGL(k_deferred_wave, dim3(256), dim3(64), 0, s, t->dt, b);
         MARK(KI_BPELANES);
@@ -604,8 +604,8 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
             }
         }
         MARK(KI_PRETOK);
-        if (ntiles && direct_b) hipLaunchKernelGGL((k_pretok<SPL_TILE_DIRECT_B, false, true>), dim3(ntiles), dim3(NT), 0, s, PRETOK_EARLY(t->dt, b), t->dt, b);
-        else if (ntiles) hipLaunchKernelGGL((k_pretok<SPL_TILE_DIRECT_A, false, true>), dim3(ntiles), dim3(NT), 0, s, PRETOK_EARLY(t->dt, b), t->dt, b);
+        if (ntiles && direct_b) hipLaunchKernelGGL((k_pretok<SPL_TILE_DIRECT_B>), dim3(ntiles), dim3(NT), 0, s, PRETOK_EARLY(t->dt, b), t->dt, b);
+        else if (ntiles) hipLaunchKernelGGL((k_pretok<SPL_TILE_DIRECT_A>), dim3(ntiles), dim3(NT), 0, s, PRETOK_EARLY(t->dt, b), t->dt, b);
         else HIP_TRY(hipMemsetAsync(d_out_off, 0, (n_docs + 1) * 8, s));
         MARK(KI_DEFER); MARK(KI_BPELANES); MARK(KI_BPELONG); MARK(KI_COUNT); MARK(KI_SCAN); MARK(KI_COMPACT);
         if (ntiles) hipLaunchKernelGGL(k_tile_out, dim3(ntiles), dim3(TOUT_NT), 0, s, tile_out_args(b));

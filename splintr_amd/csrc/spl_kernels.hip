@@ -1,6 +1,6 @@
 // spl_kernels.hip -- gfx950 kernels of the batch encode path (DESIGN.md 4 has the full table).
 //
-//   k_pretok<tile, halo, EXPORT_MEDIUM, DIRECT>
+//   k_pretok<tile, halo>
 //                   one workgroup per tile: stage the window in LDS, classify code points, class
 //                   bit masks and context-free sync points (spl_scan_masks.h), one scanner chain
 //                   per lane (spl_scan.h), whole-chunk vocabulary probe (spl_lookup.h), and
@@ -50,7 +50,6 @@ constexpr int RANK_BLK = 1024;           // positions per rank block (32 bitmap 
 #ifndef SPL_TILE_SMALL
 #define SPL_TILE_SMALL 768, 224          /* window 1024 B: one 4-byte word per lane */
 #endif
-#define SPL_TILE_LARGE 4096, 480         /* window 4608 B */
 // Tile-owned mode: the same 1024-byte window with more of it owned.  The halo only has to hold the chunk that
 // straddles the tile's end and the next sync point (anything longer is finished from a moving window), and every
 // byte of halo is classified and masked twice: batches that fill the GPU several times over gain 3-10 % from
@@ -655,10 +654,10 @@ __device__ __forceinline__ void t8_issue_if(const DeviceTables& T, bool on, uint
     q = *reinterpret_cast<const Ent3*>(T.t8_tab + (size_t)slot * SPL_T8_WORDS);
 }
 __device__ __forceinline__ uint32_t tiny_finish(uint32_t k0, uint32_t n, const Ent2& q) {
-    return (q.x == k0) & ((q.y >> 24) == n) ? (q.y & SPL_ID_MASK) : SPL_NO_RANK;
+    return ((q.x == k0) & ((q.y >> 24) == n)) ? (q.y & SPL_ID_MASK) : SPL_NO_RANK;
 }
 __device__ __forceinline__ uint32_t t8_finish(uint32_t k0, uint32_t k1, uint32_t n, const Ent3& q) {
-    return (q.x == k0) & (q.y == k1) & ((q.z >> 24) == n) ? (q.z & SPL_ID_MASK) : SPL_NO_RANK;
+    return ((q.x == k0) & (q.y == k1) & ((q.z >> 24) == n)) ? (q.z & SPL_ID_MASK) : SPL_NO_RANK;
 }
 
 // The merge loop of one 16-lane group over `n` <= 16 nodes whose substring ids are tabulated: lane
@@ -868,47 +867,6 @@ __device__ __forceinline__ void bpe_group16_tab(const DeviceTables& T, const Lds
     bpe_group_tab<16>(T, tx, p, n, sub, emit, wt, width);
 }
 
-// The same merge loop for ONE chunk of up to 64 bytes per WAVEFRONT, one node per lane.  Everything
-// that is per-chunk is wave-uniform here (the minimum, the alive bitmap, the neighbour indices), so
-// it lives in scalar registers: bit scans are single SALU ops and neighbour ids come from
-// v_readlane instead of an LDS permute.  Lowest latency per merge; used for a tile's few
-// 17..64-byte chunks, whose chains are the critical path of a small batch.
-template <class ByteAt, class Emit>
-__device__ __forceinline__ void bpe_wave64_regs(const DeviceTables& T, int n, ByteAt byte_at, Emit emit) {
-    const int lane = tidx() & 63;
-    uint32_t id = lane < n ? T.byte_id[byte_at(lane)] : SPL_DEAD;
-    const uint32_t idn = __shfl(id, lane + 1);
-    uint32_t rk = (lane + 1 < n) ? pair_rank(T, id, idn) : SPL_NO_RANK;
-    unsigned long long alive = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
-    for (;;) {
-        const uint32_t key = rk == SPL_NO_RANK ? 0xFFFFFFFFu : ((rk << 6) | (uint32_t)lane);
-        uint32_t m = row16_min(key);
-        const uint32_t r0 = __builtin_amdgcn_readlane(m, 0), r1 = __builtin_amdgcn_readlane(m, 16);
-        const uint32_t r2 = __builtin_amdgcn_readlane(m, 32), r3 = __builtin_amdgcn_readlane(m, 48);
-        const uint32_t a = r0 < r1 ? r0 : r1, c = r2 < r3 ? r2 : r3;
-        m = a < c ? a : c;                                  // wave-uniform
-        if (m == 0xFFFFFFFFu) break;
-        const int mi = (int)(m & 63u);
-        const uint32_t mn = m >> 6;
-        const unsigned long long above = alive & ~((2ull << mi) - 1ull);
-        const int j = __builtin_ctzll(above);                       // exists: rk(mi) is a rank
-        const unsigned long long above2 = above & (above - 1ull);
-        const int j2 = above2 ? __builtin_ctzll(above2) : -1;
-        const unsigned long long below = alive & ((1ull << mi) - 1ull);
-        const int h = below ? 63 - __builtin_clzll(below) : -1;
-        const uint32_t id_j2 = j2 >= 0 ? __builtin_amdgcn_readlane(id, j2) : 0u;
-        const uint32_t id_h = h >= 0 ? __builtin_amdgcn_readlane(id, h) : 0u;
-        uint32_t res = SPL_NO_RANK;
-        if (lane == mi) { if (j2 >= 0) res = pair_rank(T, mn, id_j2); }
-        else if (lane == h) res = pair_rank(T, id_h, mn);
-        if (lane == mi) { id = mn; rk = res; }
-        else if (lane == h) rk = res;
-        else if (lane == j) rk = SPL_NO_RANK;
-        alive &= ~(1ull << j);
-    }
-    if (lane < n && ((alive >> lane) & 1ull) && id != SPL_NO_RANK) emit(lane, id);
-}
-
 // The merge loop of one WAVEFRONT over the nodes in `alive` (lanes of a range that ends at `end`),
 // with tabulated substring ids: `row` is the lane's own table row, `rk` its pair's rank, `idv` its id.
 // (far_max: as in group16_merge)
@@ -950,7 +908,8 @@ __device__ __forceinline__ void wave64_merge(const DeviceTables& T, const uint32
     if (((alive >> lane) & 1ull) && idv != SPL_NO_RANK) emit(lane, idv);
 }
 
-// bpe_wave64_regs with tabulated pair ranks (see bpe_group16_tab): one chunk of 17..64 bytes per
+// One chunk of 17..64 bytes per WAVEFRONT with tabulated pair ranks (see bpe_group16_tab): everything per-chunk is wave-uniform (the minimum, the
+// alive bitmap, the neighbour indices) and lives in scalar registers; one chunk of 17..64 bytes per
 // wavefront, lane i owns node i and the ids of text[i, i+len), len = 2..8, in its LDS row.
 template <class Emit>
 __device__ __forceinline__ void bpe_wave64_tab(const DeviceTables& T, const LdsAcc& tx, int p, int n, uint32_t* sub,
@@ -2072,7 +2031,7 @@ struct PretokKernargs {
     const uint32_t* e_akind; uint32_t e_flags; DeviceTables T; Batch b;
 };
 #define PRETOK_EARLY(T, b) (b).text, (b).doc_off, (b).n_bytes, (b).n_docs, (b).dbg, (T).akind, pretok_flags(T, b)
-template <int TB_, int RH_, bool EXPORT_MEDIUM, bool DIRECT = false>
+template <int TB_, int RH_>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPL_PRETOK_WAVES)))
 void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_bytes, uint32_t e_n_docs, unsigned long long* e_dbg,
               const uint32_t* e_akind, uint32_t e_flags, DeviceTables T_ka, Batch b_ka) {
@@ -2085,6 +2044,8 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
     // in VGPR lanes (153 spilled SGPRs, 74 this way).  Built with -mllvm -amdgpu-kernarg-preload-count=16 the
     // scalars would arrive in SGPRs with the wavefront; measured, that is no faster (the wave launch waits instead).
     using G = TileGeom<TB_, RH_>;
+    constexpr bool DIRECT = true;                        // (every launch leaves tile records since round 4: tile-owned and queue mode; the
+                                                         //  instantiations without them belonged to the multi-pass pipeline)
 #ifdef SPL_FIXED_PATTERN
     constexpr int KPAT = SPL_FIXED_PATTERN;              // (A/B: the kernel specialised for one split pattern)
 #else
@@ -2410,27 +2371,14 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
     }
     __syncthreads();
     SPL_STAMP(2);
-    if (!DIRECT) {
-    // ---- sync-point mask: word operations on the kind masks (same rules as is_sync).  Tile-owned and queue mode:
-    //      the wavefronts that compute the starts below make it themselves, one barrier less -----------------------
-    if (tid < G::NBW) {
-        uint32_t kw[MK_COUNT], kp[MK_COUNT];
-#pragma unroll
-        for (int k = 0; k < MK_COUNT; k++) {
-            kw[k] = k < MK_SY ? s_mk[k * NBW1 + tid] : 0u;
-            kp[k] = (k < MK_SY && tid > 0) ? s_mk[k * NBW1 + tid - 1] : 0u;
-        }
-        s_mk[MK_SY * NBW1 + tid] = sync_word(KPAT, kw, kp);
-    }
-    __syncthreads();
-    }
+    // (the sync-point mask -- word operations on the kind masks, the rules of is_sync -- is made by the wavefronts that compute the starts)
     // ---- ALL match starts of the tile by bit-vector arithmetic (spl_scan_starts.h), every pattern ------
     // One mask word per lane.  The tile owns [fs, fe): fs = its first sync point, fe = the
     // first sync point or text start at or behind the tile's end.  Needs fe inside the window and no
     // disqualifying byte (MK_BAD) in the range; otherwise the chains below do the work as before.
     // Three wavefronts share the work (letters and numbers / "other" runs and contractions / whitespace);
     // each finds the range for itself and ORs its starts into s_cbits; the tile is "fast" if all three agree.
-    static_assert(!DIRECT || LIST_CHUNKS, "the chains must not share s_cbits with the start masks");
+    static_assert(LIST_CHUNKS, "the probe list lives in the substring table; the chains must not share s_cbits with the start masks");
     if (SPL_MASK_STARTS && DIRECT && tid < 192) {
         const int part = tid >> 6, ln = tid & 63;           // lane ln owns mask word ln
         uint32_t fine = 0;
@@ -2588,7 +2536,6 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
         for (int k = tid; k < nsync; k += NT) {
             int p = s_cpos[k];
             for (;;) {
-                if (!LIST_CHUNKS) atomicOr(&s_cbits[p >> 5], 1u << (p & 31));
                 const int e = match_end_m(acc, p, KPAT);
                 if (e == SPL_DEFER) {                 // the match outgrows the window
                     push_defer((uint32_t)(w0 + p));
@@ -2596,48 +2543,26 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
                 }
                 // small windows: the chunk goes straight onto the probe list (order is irrelevant:
                 // tokens are identified by their position) -- no marks, no second enumeration
-                if (LIST_CHUNKS) s_chunk[atomicAdd(&s_nch, 1u)] = (uint32_t)p | ((uint32_t)(e - p) << 16);
+                s_chunk[atomicAdd(&s_nch, 1u)] = (uint32_t)p | ((uint32_t)(e - p) << 16);
                 p = e;
                 if (p >= Wv) {                         // ended on the window edge, or up to WPAD bytes behind it (a straddling character)
                     // The chain goes on from p -- IF a chunk starts there: p may be a sync point, which the tile that
                     // holds it works itself (bit 31: "check first").  (It used to go on from the window's end
                     // whatever p was, as a certain chunk start: a chunk that ended behind the edge was then partly
                     // worked twice, and a sync point exactly on the edge got its chunk from both tiles.)
-                    if (!LIST_CHUNKS) atomicOr(&s_cbits[p >> 5], 1u << (p & 31));
                     if (w0 + p < B) push_defer((uint32_t)(w0 + p) | 0x80000000u);
                     break;
                 }
-                if (((s_mk[MK_SY * NBW1 + (p >> 5)] | s_mk[MK_TS * NBW1 + (p >> 5)]) >> (p & 31)) & 1u) {
-                    if (!LIST_CHUNKS) atomicOr(&s_cbits[p >> 5], 1u << (p & 31));   // next owner's start: terminator mark
-                    break;
-                }
+                if (((s_mk[MK_SY * NBW1 + (p >> 5)] | s_mk[MK_TS * NBW1 + (p >> 5)]) >> (p & 31)) & 1u) break;   // the next owner's start
             }
         }
     }
     __syncthreads();
     SPL_STAMP(4);
 
-    // ---- enumerate marked positions (large windows only) ---------------------------------------------
-    if (!LIST_CHUNKS) {
-        uint32_t word = tid < G::NBW ? s_cbits[tid] : 0u;
-        uint32_t cnt = __popc(word);
-        // inclusive scan over 256 threads: wave scan + cross-wave sums
-        uint32_t x = wave_scan_incl(cnt);
-        if ((tid & 63) == 63) s_wsum[tid >> 6] = x;
-        __syncthreads();
-        uint32_t base = x - cnt;
-        for (int wv = 0; wv < (tid >> 6); wv++) base += s_wsum[wv];
-        if (tid == NT - 1) s_total = base + cnt;
-        while (word) {
-            const int bit = __ffs(word) - 1;
-            word &= word - 1;
-            s_cpos[base++] = (uint16_t)(tid * 32 + bit);
-        }
-    }
-    if (!LIST_CHUNKS) __syncthreads();
     SPL_STAMP(5);
 
-    // ---- whole-chunk probe (large windows: the last marked position is only a terminator) -------------
+    // ---- whole-chunk probe (start masks: the last marked position is only a terminator) ----------------
     {
         LdsAcc tx{s_rec, s_txt};
         const bool from_list = LIST_CHUNKS && !fast_starts;
@@ -2701,7 +2626,10 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
         // Short misses sorted by length, longest first (counting sort into s_cpos, which is free
         // until the tile record): the four chunks a wavefront merges in lock step then have similar
         // lengths -- a round lasts as long as its longest chunk -- and the longest chains start first.
-        constexpr bool SORT_SHORT = Wv <= 1024;            // window index (10 bits) | n - 1 (4 bits) in 16 bits
+#ifndef SPL_SORT_SHORT
+#define SPL_SORT_SHORT 1         /* 0: the short misses in list order (A/B) */
+#endif
+        constexpr bool SORT_SHORT = SPL_SORT_SHORT && Wv <= 1024;            // window index (10 bits) | n - 1 (4 bits) in 16 bits
         if (SORT_SHORT) {
             uint32_t my_item[(G::C16 + NT - 1) / NT], my_r[(G::C16 + NT - 1) / NT];
 #pragma unroll
@@ -2744,27 +2672,15 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
             atomicOr(&s_tbits[q >> 5], 1u << (q & 31));
         };
         const int lane = tid & 63;
-        if (EXPORT_MEDIUM) {
-            if (tid == 0) s_total = m64 ? atomicAdd(&b.qcount[0], m64) : 0u;
-            __syncthreads();
-            const uint32_t base = s_total;
-            for (uint32_t k = tid; k < m64; k += NT) {
-                const uint32_t item = s_miss[G::C16 + k];
-                if (base + k < b.qcap64) b.q64[base + k] = make_uint2((uint32_t)(w0 + (item & 0xFFFFu)), item >> 16);
-            }
-        }
-        // A tile with only a few 17..64-byte chunks gives each of them a whole wavefront (lowest
-        // latency per merge: their chains are the critical path); a tile dense with them (CJK)
-        // uses the 16-lane groups below, four chunks per wavefront.
-        // (tile-owned mode: always -- with the ranks tabulated a wavefront per chunk also wins on tiles
-        //  dense with such chunks: 8 MB of the C3 mix 1.19 ms against 1.25 ms)
-        const bool few_medium = DIRECT || m64 <= 2 * (NT / 64);
+        // Every 17..64-byte chunk gets a whole wavefront (or half of one): lowest latency per merge -- their chains are the critical
+        // path -- and with the ranks tabulated also the faster form on tiles dense with such chunks (8 MB of the C3 mix 1.19 ms
+        // against 1.25 ms for 16-lane groups with four nodes per lane, the form of rounds 1-2, removed in round 4).
 #ifdef SPL_DEBUG_STAMPS
         const long long ws_t0 = clock64();
         uint32_t ws_nmed = 0, ws_nshort = 0;
         long long ws_wt[6] = {0, 0, 0, 0, 0, 0};
 #endif
-        for (; !EXPORT_MEDIUM && few_medium;) {
+        for (;;) {
             // A wavefront takes TWO chunks per pull: if both have at most 32 bytes (of ASCII: no independent
             // segments to look for) each gets a half of the wavefront and they merge side by side -- a tile
             // with several long words (the slowest tiles of the bench batch are those) needs half the pulls.
@@ -2812,21 +2728,7 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
 #ifdef SPL_DEBUG_STAMPS
         const long long ws_t1 = clock64();
 #endif
-        // every 16-lane group pulls its own work: first the 17..64-byte chunks (four nodes per
-        // lane), then the short ones (one node per lane)
-        for (; !EXPORT_MEDIUM && !few_medium;) {
-            uint32_t it = 0;
-            if ((lane & 15) == 0) it = atomicAdd(&s_nq[3], 1u);
-            it = __shfl(it, lane & ~15);
-            const bool has = it < m64;
-            if (!__any(has)) break;
-            const uint32_t item = has ? s_miss[G::C16 + it] : 0u;
-            const int p = (int)(item & 0xFFFFu);
-            bpe_group16<4>(T, has ? (int)(item >> 16) : 0, [&](int i) { return (uint32_t)s_txt[p + i]; },
-                           [&](int i, uint32_t id) {
-                               put(p + i, id);
-                           });
-        }
+        // every 16-lane group pulls its own short chunks (one node per lane)
         // The sorted list holds the chunks of 9..16 bytes first (items [0, first8)), then those of up to 8.  A SLOT is one
         // 16-lane group's work of a pull: one chunk of the first kind, or two of the second, one per half of the group.
         const uint32_t first8 = (SPL_PAIR_SHORT && SORT_SHORT) ? s_scnt[8] : m16;
@@ -2885,13 +2787,7 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
 #ifdef SPL_DEBUG_STAMPS
     if (e_dbg) blk_w1 = blk_w2 = (unsigned long long)wall_clock64();
 #endif
-    if (!DIRECT) {
-        if (tid < G::NBW) {
-            const uint32_t wv = s_tbits[tid];
-            if (wv) atomicOr(&b.tbits[(w0 >> 5) + tid], wv);
-        }
-    } else {
-        static_assert(!(DIRECT && EXPORT_MEDIUM), "the single-pass kernel merges everything itself");
+    {
         const int lane = tid & 63, wv = tid >> 6;
         const uint32_t ovf_lo = (uint32_t)(w0 + Wv);       // tokens from here on live in HBM (stage[] / tbits[])
         auto emit_g = [&](uint32_t q, uint32_t id) {

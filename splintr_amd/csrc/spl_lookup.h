@@ -38,13 +38,13 @@ SPL_HD uint32_t t8_salt(const DeviceTables& T, uint32_t k0) { return (uint32_t)T
 SPL_HD uint32_t probe_tiny(const DeviceTables& T, uint32_t k0, uint32_t n, uint32_t salt) {
     const uint32_t* e = T.tiny_tab + (size_t)(hash_tiny(k0, n, salt) & T.tiny_mask) * SPL_TINY_WORDS;
     const uint32_t ek = e[0], ei = e[1];
-    return (ek == k0) & ((ei >> 24) == n) ? (ei & SPL_ID_MASK) : SPL_NO_RANK;
+    return ((ek == k0) & ((ei >> 24) == n)) ? (ei & SPL_ID_MASK) : SPL_NO_RANK;
 }
 // keys of 5..8 bytes: ONE entry (12 bytes); salt = t8_salt(first four bytes)
 SPL_HD uint32_t probe_t8(const DeviceTables& T, uint32_t k0, uint32_t k1, uint32_t n, uint32_t salt) {
     const uint32_t* e = T.t8_tab + (size_t)(hash_t8(k0, k1, n, salt) & T.t8_mask) * SPL_T8_WORDS;
     const uint32_t e0 = e[0], e1 = e[1], ei = e[2];
-    return (e0 == k0) & (e1 == k1) & ((ei >> 24) == n) ? (ei & SPL_ID_MASK) : SPL_NO_RANK;
+    return ((e0 == k0) & (e1 == k1) & ((ei >> 24) == n)) ? (ei & SPL_ID_MASK) : SPL_NO_RANK;
 }
 // keys of 9..12 bytes: buckets of four, salt = key_salt(first two bytes)
 SPL_HD uint32_t probe_short12(const DeviceTables& T, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t n, uint32_t salt) {
