@@ -166,8 +166,12 @@ int spl_encode_batch_device(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_
                             uint64_t* d_out_off, void* hip_stream);
 
 /* Handles with SPL_PATTERN_CUSTOM: spl_encode_batch / spl_decode_batch work as for every other handle (the split of
- * each pipeline chunk runs on the host cores while the previous chunk is on the GPU); spl_encode_batch_device is
- * refused (the text is not on the host).  For text that IS on the device the two halves are available separately:
+ * each pipeline chunk runs on the device splitter, csrc/spl_rx_split.h -- or, for batches with SPL_WITH_SPECIAL and for
+ * what the device matcher gives up on, on the host cores while the previous chunk is on the GPU).  spl_encode_batch_device
+ * and spl_encode_batch_device_packed run the device splitter in front of the tile kernel: ONE synchronisation of
+ * `hip_stream` inside the call (the splitter's status word decides what is launched next; when it gave up the text goes to
+ * the host once and is split there); SPL_WITH_SPECIAL is refused for such a handle (the literals are found on the host:
+ * spl_encode_batch).  The halves are available separately:
  *   spl_split_host          the matches of the handle's pattern over a packed HOST corpus as two bitmaps of
  *                           n_bytes / 32 + 2 words each (zeroed here): bit p of start_bits -- a chunk, or a stretch of
  *                           bytes no match covers, starts at byte p; bit p of gap_bits -- byte p is dropped
@@ -176,6 +180,19 @@ int spl_encode_batch_device(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_
  *                           bitmaps; any handle: the handle's own pattern is not consulted).  Up to 256 MB per call. */
 int spl_split_host(spl_tokenizer* t, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, uint32_t* start_bits,
                    uint32_t* gap_bits);
+/*   spl_split_device        the same two bitmaps for a packed corpus that is in HBM, by the device splitter (the same matcher
+ *                           program, one text position per lane, then the walk from each document's start by pointer doubling:
+ *                           csrc/spl_rx_split.h), asynchronously on `hip_stream`.  Bitmaps of n_bytes / 32 + 2 words (zeroed
+ *                           here); *d_status (one word, device memory, cleared by the CALLER -- calls may share it) is non-zero
+ *                           afterwards if the text held something the device matcher gives up on (a match or look-ahead
+ *                           reaching more than ~1 KB beyond its start, a runaway attempt): the bitmaps are then incomplete
+ *                           and the split belongs to spl_split_host.  SPL_EINVAL if the pattern's program does not fit the
+ *                           device matcher.  spl_encode_batch uses it for every batch without SPL_WITH_SPECIAL and falls back
+ *                           by itself (spl_set_option "device_split" 0 keeps the split on the host cores;
+ *                           spl_device_split_fallbacks counts the batches that fell back).  Up to 256 MB per call. */
+int spl_split_device(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off, uint64_t n_docs,
+                     uint32_t* d_start_bits, uint32_t* d_gap_bits, uint32_t* d_status, void* hip_stream);
+uint64_t spl_device_split_fallbacks(const spl_tokenizer* t);
 int spl_encode_chunks_device(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
                              uint64_t n_docs, const uint32_t* d_start_bits, const uint32_t* d_gap_bits, uint32_t* d_ids,
                              uint64_t ids_capacity, uint64_t* d_out_off, void* hip_stream);

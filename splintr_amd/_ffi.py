@@ -28,6 +28,7 @@ SYMBOLS = [
     "spl_token_bytes", "spl_is_byte_level",
     "spl_comm_unique_id", "spl_comm_create", "spl_comm_destroy", "spl_comm_rank", "spl_comm_world",
     "spl_allgather_slabs", "spl_allgatherv_csr", "spl_split_host", "spl_encode_chunks_device",
+    "spl_split_device", "spl_device_split_fallbacks",
 ]
 SPL_PATTERN_CUSTOM = 3
 SPL_OPT_BYTE_LEVEL = 1
@@ -115,6 +116,9 @@ def lib() -> ctypes.CDLL:
     L.spl_gatherv_unpack_group.argtypes = [vp, vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64,
                                            ctypes.c_uint64, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp]
     L.spl_split_host.argtypes = [vp, vp, vp, ctypes.c_uint64, vp, vp]
+    L.spl_split_device.argtypes = [vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp, vp, vp]
+    L.spl_device_split_fallbacks.restype = ctypes.c_uint64
+    L.spl_device_split_fallbacks.argtypes = [vp]
     L.spl_encode_chunks_device.argtypes = [vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp, vp, ctypes.c_uint64, vp, vp]
     L.spl_comm_unique_id.argtypes = [ctypes.c_char_p]
     L.spl_comm_create.restype = vp

@@ -22,6 +22,7 @@
 #include "spl_tables.h"
 #include "spl_comm.h"
 #include "spl_regex.h"
+#include "spl_rx_split.h"
 
 using namespace spl;
 
@@ -199,6 +200,11 @@ struct Ctx {
     Pinned h_ext[NSLOT], h_extsp[NSLOT];
     uint32_t* d_ext[NSLOT] = {nullptr, nullptr, nullptr}; uint64_t ext_cap_words = 0;
     uint32_t* d_extsp[NSLOT] = {nullptr, nullptr, nullptr}; uint64_t extsp_cap = 0;
+    // custom split patterns on the device (spl_rx_split.h): the program image, general categories, workspace, status word
+    const uint32_t* d_rx_image = nullptr; const uint16_t* d_gc1 = nullptr; const uint8_t* d_gc2 = nullptr;
+    uint8_t* d_rx_ws = nullptr; uint64_t rx_ws_cap = 0;
+    uint32_t* d_rx_status = nullptr;
+    uint32_t* d_rx_bits = nullptr; uint64_t rx_bits_cap = 0;       // the two bitmaps of a device-text call (spl_encode_batch_device)
     hipEvent_t ev_h2d[NSLOT] = {nullptr, nullptr, nullptr}, ev_cmp[NSLOT] = {nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ev_chunk;
     // decode scratch (grow-only)
@@ -245,6 +251,7 @@ struct Ctx {
         hipFree((void*)d_tok_off); hipFree((void*)d_tok_bytes); hipFree(d_sp_lits);
         hipFree((void*)d_dec_sp_ids); hipFree((void*)d_dec_sp_off);
         hipFree(d_ids); hipFree(d_oo);
+        hipFree((void*)d_rx_image); hipFree((void*)d_gc1); hipFree((void*)d_gc2); hipFree(d_rx_ws); hipFree(d_rx_status); hipFree(d_rx_bits);
         hipFree(d_dec_ids); hipFree(d_dec_blk); hipFree(d_dec_idoff); hipFree(d_dec_out); hipFree(d_dec_first); hipFree(d_dec_docoff);
         if (ev_ready) for (auto& e : ev) (void)hipEventDestroy(e);
         for (int i = 0; i < NSLOT; i++) { if (ev_h2d[i]) (void)hipEventDestroy(ev_h2d[i]); if (ev_cmp[i]) (void)hipEventDestroy(ev_cmp[i]); }
@@ -264,6 +271,9 @@ struct spl_tokenizer {
     bool special_newline = false;             // a literal contains '\n': no sub-document cuts with SPL_WITH_SPECIAL
     bool special_general = false;             // occurrences can overlap, or a literal exceeds SP_MAXLEN: the two-launch general matcher
     RegexPtr regex;                           // SPL_PATTERN_CUSTOM: the host splitter's program (null: one of the GPU scanner's patterns)
+    std::vector<uint32_t> rx_image;           // ... and its image for the device splitter (empty: the program does not fit, the split stays on the host)
+    int rx_device = 1;                        // spl_set_option("device_split"): 0 keeps a custom pattern's split on the host cores
+    uint64_t rx_fallbacks = 0;                // batches the device splitter gave up on (spl_get_option("device_split_fallbacks"))
     std::vector<std::unique_ptr<Ctx>> ctx;
     std::shared_ptr<PinnedPool> pool = std::make_shared<PinnedPool>();
     // host pipeline tuning (spl_set_option)
@@ -650,6 +660,58 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
     return SPL_OK;
 }
 
+// ---- custom split patterns on the device (spl_rx_split.h) ---------------------------------------------------------
+// Uploads the program image (and the general-category table if a class set tests one) to this context once, grows the
+// workspace, and launches the two kernels on `s`: d_starts / d_gaps (n_bytes / 32 + 2 words each, at least) are zeroed here;
+// *d_status collects RXS_* bits (not cleared here: a batch of several chunks shares one word).
+bool rx_applies(const spl_tokenizer* tk, uint32_t flags) {
+    return tk->regex && tk->rx_device && !tk->rx_image.empty() && !((flags & SPL_WITH_SPECIAL) && !tk->specials.empty());
+}
+int rx_ensure(spl_tokenizer* tk, Ctx* c) {
+    if (c->d_rx_image) return SPL_OK;
+    int rc;
+    if (tk->rx_image[7] && !tk->ht.gc_stage1.empty()) {
+        if ((rc = dev_upload(tk->ht.gc_stage1, &c->d_gc1))) return rc;
+        if ((rc = dev_upload(tk->ht.gc_stage2, &c->d_gc2))) return rc;
+    }
+    HIP_TRY(hipMalloc((void**)&c->d_rx_status, 64));
+    HIP_TRY(hipMemset(c->d_rx_status, 0, 64));
+    return dev_upload(tk->rx_image, &c->d_rx_image);
+}
+int rx_launch(spl_tokenizer* tk, Ctx* c, const uint8_t* d_text, uint64_t n_bytes, const uint64_t* d_doc_off, uint64_t n_docs,
+              uint32_t* d_starts, uint32_t* d_gaps, uint32_t* d_status, hipStream_t s) {
+    if (n_bytes > SPL_DIRECT_MAX_BYTES) return fail(SPL_EINVAL, "device split: at most 256 MB per call");
+    if (((uintptr_t)d_text & 15) != 0) return fail(SPL_EINVAL, "text buffer must be 16-byte aligned");
+    int rc = rx_ensure(tk, c);
+    if (rc) return rc;
+    const uint64_t words = n_bytes / 32 + 2;
+    HIP_TRY(hipMemsetAsync(d_starts, 0, words * 4, s));
+    HIP_TRY(hipMemsetAsync(d_gaps, 0, words * 4, s));
+    if (!n_bytes) return SPL_OK;
+    const uint64_t nblk = (n_bytes + RXB - 1) / RXB;
+    const uint64_t need = 4 * nblk * RXB + 4 * nblk + 4 * (8 * nblk + 2) + 256;
+    if (need > c->rx_ws_cap) {
+        HIP_TRY(hipDeviceSynchronize());
+        hipFree(c->d_rx_ws); c->d_rx_ws = nullptr; c->rx_ws_cap = 0;
+        const uint64_t cap = need + need / 4;
+        HIP_TRY(hipMalloc((void**)&c->d_rx_ws, cap));
+        c->rx_ws_cap = cap;
+    }
+    RxArgs a{};
+    a.image = c->d_rx_image; a.image_words = (uint32_t)tk->rx_image.size();
+    a.text = d_text; a.doc_off = d_doc_off; a.n_bytes = (uint32_t)n_bytes; a.n_docs = (uint32_t)n_docs;
+    a.ucls1 = c->dt.ucls_stage1; a.ucls2 = c->dt.ucls_stage2; a.shift = c->dt.ucls_shift;
+    a.gc1 = c->d_gc1; a.gc2 = c->d_gc2;
+    a.nx = (uint16_t*)c->d_rx_ws; a.gx = a.nx + nblk * RXB;
+    a.blk = (uint32_t*)(a.gx + nblk * RXB); a.dstart = a.blk + nblk;
+    a.starts = d_starts; a.gaps = d_gaps; a.status = d_status;
+    HIP_TRY(hipMemsetAsync(a.blk, 0, nblk * 4, s));
+    hipLaunchKernelGGL(k_rx_match, dim3((uint32_t)nblk), dim3(RXB), 0, s, a);
+    hipLaunchKernelGGL(k_rx_mark, dim3((uint32_t)nblk), dim3(RXB), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    return SPL_OK;
+}
+
 // ---- custom split patterns: the host splitter over the documents of one pipeline chunk ------------------------
 // Special-token literals on the host, with the reference matcher's semantics (Aho-Corasick, MatchKind::Standard,
 // non-overlapping find_iter, tokenizer.rs:849-869; the same rule k_special_select implements): from the end of the
@@ -768,6 +830,50 @@ int host_split_docs(const spl_tokenizer* tk, const uint8_t* text, const uint64_t
     return SPL_OK;
 }
 
+// A custom-pattern handle with its text in HBM (spl_encode_batch_device): the chunk boundaries from the device splitter.  ONE
+// stream synchronisation in the middle of the call -- the status word decides what runs next -- and, when the matcher gave up,
+// the text goes to the host once, is split there, and the bitmaps come back (rare: a match longer than ~1 KB).
+int custom_bits_device(spl_tokenizer* t, Ctx* c, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off, uint64_t n_docs,
+                       uint32_t flags, hipStream_t s, ExtIn& ext) {
+    if ((flags & SPL_WITH_SPECIAL) && !t->specials.empty())
+        return fail(SPL_EINVAL, "spl_encode_batch_device: a custom split pattern with SPL_WITH_SPECIAL is split on the host (the literals are found "
+                                "there): use spl_encode_batch, or spl_split_host + spl_encode_chunks_device");
+    if (n_bytes > SPL_DIRECT_MAX_BYTES) return fail(SPL_EINVAL, "spl_encode_batch_device: a custom split pattern takes at most 256 MB per device call");
+    const uint64_t bw = n_bytes / 32 + 4;
+    if (2 * bw > c->rx_bits_cap) {
+        HIP_TRY(hipDeviceSynchronize());
+        hipFree(c->d_rx_bits); c->d_rx_bits = nullptr; c->rx_bits_cap = 0;
+        const uint64_t cap = 2 * bw + bw / 2;
+        HIP_TRY(hipMalloc((void**)&c->d_rx_bits, cap * 4));
+        c->rx_bits_cap = cap;
+    }
+    ext.d_starts = c->d_rx_bits; ext.d_gaps = c->d_rx_bits + bw;
+    uint32_t gave_up = 1;
+    if (t->rx_device && !t->rx_image.empty()) {
+        int rc = rx_ensure(t, c);
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(c->d_rx_status, 0, 4, s));
+        rc = rx_launch(t, c, d_utf8, n_bytes, d_doc_off, n_docs, c->d_rx_bits, c->d_rx_bits + bw, c->d_rx_status, s);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(&gave_up, c->d_rx_status, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (gave_up) t->rx_fallbacks++;
+    }
+    if (gave_up) {
+        std::vector<uint8_t> text(n_bytes + 16);
+        std::vector<uint64_t> off(n_docs + 1);
+        if (n_bytes) HIP_TRY(hipMemcpyAsync(text.data(), d_utf8, n_bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(off.data(), d_doc_off, (n_docs + 1) * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        std::vector<uint32_t> bits(2 * bw, 0u);
+        int rc = host_split_docs(t, text.data(), off.data(), n_docs, false, bits.data(), bits.data() + bw, nullptr, 128);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(c->d_rx_bits, bits.data(), 2 * bw * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));                   // (the vectors die with this frame)
+    }
+    return SPL_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Host pipeline.
 //
@@ -793,6 +899,7 @@ struct Lane {
     std::atomic<uint32_t> submitted{0};
     std::atomic<int> rc{0};
     std::string err;
+    bool host_split = true;      // custom pattern: the split of this lane's chunks runs on the host cores (false: k_rx_match / k_rx_mark)
 };
 
 bool is_pinned_host(const void* p) {
@@ -930,14 +1037,21 @@ int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t
             // custom pattern: the chunk's boundaries from the host splitter (this lane's producer thread plus helpers,
             // while the previous chunks are on the GPU), uploaded behind the text
             const uint64_t bw = nb / 32 + 4;
-            uint32_t* hb = (uint32_t*)c->h_ext[sl].p;
-            memset(hb, 0, 2 * bw * 4);
+            ext.d_starts = c->d_ext[sl]; ext.d_gaps = c->d_ext[sl] + bw;
             const bool special = (flags & SPL_WITH_SPECIAL) && !tk->specials.empty();
             std::vector<SpHit> hits;
+            if (!ln.host_split) {
+                // ... or from the device splitter, on the compute stream behind the text's arrival; what it gives up on is
+                // on the context's status word when the batch is done (encode_host then runs the batch again, split on the host)
+                int rcx = rx_launch(tk, c, c->d_text[sl], nb, c->d_off[sl], nd, c->d_ext[sl], c->d_ext[sl] + bw, c->d_rx_status, c->s_cmp);
+                if (rcx) return rcx;
+            } else {
+            uint32_t* hb = (uint32_t*)c->h_ext[sl].p;
+            memset(hb, 0, 2 * bw * 4);
             int rcs = host_split_docs(tk, utf8 + ch.lo, rel, nd, special, hb, hb + bw, &hits, 128);
             if (rcs) return rcs;
             HIP_TRY(hipMemcpyAsync(c->d_ext[sl], hb, 2 * bw * 4, hipMemcpyHostToDevice, hs));
-            ext.d_starts = c->d_ext[sl]; ext.d_gaps = c->d_ext[sl] + bw;
+            }
             if (!hits.empty()) {
                 const uint64_t n = hits.size();
                 if (n > c->extsp_cap) {
@@ -969,7 +1083,8 @@ int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t
     return SPL_OK;
 }
 
-int encode_host(spl_tokenizer* tk, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags, spl_result* r) {
+int encode_host(spl_tokenizer* tk, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags, spl_result* r,
+                bool host_split = true) {
     HT_T(ht0);
     const uint64_t n_bytes = doc_off[n_docs];
     const bool src_pinned = is_pinned_host(utf8);
@@ -985,6 +1100,7 @@ int encode_host(spl_tokenizer* tk, const uint8_t* utf8, const uint64_t* doc_off,
         uint64_t prev = 0;
         for (size_t l = 0; l < nl; l++) {
             lanes[l].c = tk->ctx[l].get();
+            lanes[l].host_split = host_split;
             lanes[l].lo = prev;
             uint64_t cutp = n_bytes;
             if (l + 1 < nl) {
@@ -1303,6 +1419,7 @@ spl_tokenizer* spl_create(const void* vocab, size_t vocab_len, const void* uclas
             // Tokenizer::new compiles the pattern (tokenizer.rs:426); a pattern this matcher cannot express is refused here
             t->regex = regex_compile(std::string(opts->pattern_text, (size_t)opts->pattern_len), t->ht, err);
             if (!t->regex) { fail(SPL_EINVAL, "spl_create: Regex error: " + err); return nullptr; }
+            if (!regex_device_image(*t->regex, t->rx_image)) t->rx_image.clear();
         }
         t->ctx.emplace_back(new Ctx());
         t->ctx[0]->device = opts->device;
@@ -1340,6 +1457,7 @@ int spl_set_option(spl_tokenizer* t, const char* name, int64_t value) {
     else if (k == "result_estimate_div" && value >= 1) t->est_div = (uint32_t)value;
     else if (k == "subdoc_split") t->subdoc = value != 0;
     else if (k == "direct_write") t->direct_write = value != 0;
+    else if (k == "device_split") t->rx_device = value != 0;
     else return fail(SPL_EINVAL, "spl_set_option: unknown option or bad value: " + k);
     return SPL_OK;
 }
@@ -1397,10 +1515,11 @@ static int spl_encode_batch_device_impl(spl_tokenizer* t, const uint8_t* d_utf8,
                             uint64_t* d_out_off, void* hip_stream) {
     if (!t || !d_doc_off || !d_out_off || (n_bytes && (!d_utf8 || !d_ids)))
         return fail(SPL_EINVAL, "spl_encode_batch_device: null argument");
-    if (t->regex) return fail(SPL_EINVAL, "spl_encode_batch_device: this handle has a custom split pattern, whose split runs on the host: "
-                                          "use spl_encode_batch, or spl_split_host + spl_encode_chunks_device");
     HIP_TRY(hipSetDevice(t->ctx[0]->device));
-    return launch_all(t, t->ctx[0].get(), d_utf8, n_bytes, d_doc_off, n_docs, flags, d_ids, ids_capacity, d_out_off, (hipStream_t)hip_stream);
+    ExtIn ext;
+    if (t->regex) { int rc = custom_bits_device(t, t->ctx[0].get(), d_utf8, n_bytes, d_doc_off, n_docs, flags, (hipStream_t)hip_stream, ext); if (rc) return rc; }
+    return launch_all(t, t->ctx[0].get(), d_utf8, n_bytes, d_doc_off, n_docs, flags, d_ids, ids_capacity, d_out_off, (hipStream_t)hip_stream,
+                      nullptr, t->regex ? &ext : nullptr);
 }
 
 static int spl_encode_batch_device_packed_impl(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
@@ -1411,11 +1530,13 @@ static int spl_encode_batch_device_packed_impl(spl_tokenizer* t, const uint8_t* 
         return fail(SPL_EINVAL, "spl_encode_batch_device_packed: null argument");
     if (cap_words < max_docs + 4 || n_docs > max_docs || cap_words > 0xFFFFFFFFull)
         return fail(SPL_EINVAL, "spl_encode_batch_device_packed: slab too small or beyond 2^32 words");
-    if (t->regex) return fail(SPL_EINVAL, "spl_encode_batch_device_packed: this handle has a custom split pattern (see spl_encode_batch_device)");
     HIP_TRY(hipSetDevice(t->ctx[0]->device));
     SlabOut so;
     so.d_slab = d_slab; so.cap_words = cap_words; so.max_docs = max_docs;
-    return launch_all(t, t->ctx[0].get(), d_utf8, n_bytes, d_doc_off, n_docs, flags, d_ids, ids_capacity, d_out_off, (hipStream_t)hip_stream, &so);
+    ExtIn ext;
+    if (t->regex) { int rc = custom_bits_device(t, t->ctx[0].get(), d_utf8, n_bytes, d_doc_off, n_docs, flags, (hipStream_t)hip_stream, ext); if (rc) return rc; }
+    return launch_all(t, t->ctx[0].get(), d_utf8, n_bytes, d_doc_off, n_docs, flags, d_ids, ids_capacity, d_out_off, (hipStream_t)hip_stream, &so,
+                      t->regex ? &ext : nullptr);
 }
 
 int spl_encode_batch(spl_tokenizer* t, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,
@@ -1427,8 +1548,34 @@ int spl_encode_batch(spl_tokenizer* t, const uint8_t* utf8, const uint64_t* doc_
     if (doc_off[n_docs] && !utf8) return fail(SPL_EINVAL, "spl_encode_batch: null text");
     try {
         std::unique_ptr<spl_result> r(new spl_result());
-        int rc = encode_host(t, utf8, doc_off, n_docs, flags, r.get());
+        const bool dev_split = rx_applies(t, flags);
+        if (dev_split)                                      // (the status words of the contexts the batch may use: cleared, in stream order)
+            for (auto& c : t->ctx) {
+                HIP_TRY(hipSetDevice(c->device));
+                int rcx = ensure_streams(*c);
+                if (!rcx) rcx = rx_ensure(t, c.get());
+                if (rcx) return rcx;
+                HIP_TRY(hipMemsetAsync(c->d_rx_status, 0, 4, c->s_cmp));
+            }
+        int rc = encode_host(t, utf8, doc_off, n_docs, flags, r.get(), !dev_split);
         if (rc) return rc;
+        if (dev_split) {
+            // what the device splitter gave up on (a match longer than RX_REACH, a runaway attempt): the batch again, split on the host
+            uint32_t gave_up = 0;
+            for (auto& c : t->ctx) {
+                uint32_t st = 0;
+                HIP_TRY(hipSetDevice(c->device));
+                HIP_TRY(hipMemcpyAsync(&st, c->d_rx_status, 4, hipMemcpyDeviceToHost, c->s_cmp));
+                HIP_TRY(hipStreamSynchronize(c->s_cmp));
+                gave_up |= st;
+            }
+            t->rx_fallbacks += gave_up ? 1 : 0;
+            if (gave_up) {
+                r.reset(new spl_result());
+                rc = encode_host(t, utf8, doc_off, n_docs, flags, r.get(), true);
+                if (rc) return rc;
+            }
+        }
         *out = r.release();
         return SPL_OK;
     } catch (const std::exception& e) {                      // std::bad_alloc, std::system_error (thread creation): no exception crosses the C ABI
@@ -1746,6 +1893,20 @@ int spl_split_host(spl_tokenizer* t, const uint8_t* utf8, const uint64_t* doc_of
         return host_split_docs(t, utf8, doc_off, n_docs, false, start_bits, gap_bits, nullptr, 128);
     });
 }
+
+int spl_split_device(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off, uint64_t n_docs,
+                     uint32_t* d_start_bits, uint32_t* d_gap_bits, uint32_t* d_status, void* hip_stream) {
+    if (!t || !d_doc_off || !d_start_bits || !d_gap_bits || !d_status || (n_bytes && !d_utf8))
+        return fail(SPL_EINVAL, "spl_split_device: null argument");
+    if (!t->regex) return fail(SPL_EINVAL, "spl_split_device: the handle has no custom split pattern (its pattern runs inside the tile kernel)");
+    if (t->rx_image.empty()) return fail(SPL_EINVAL, "spl_split_device: this pattern's program does not fit the device matcher (use spl_split_host)");
+    return guarded("spl_split_device", [&] {
+        HIP_TRY(hipSetDevice(t->ctx[0]->device));
+        return rx_launch(t, t->ctx[0].get(), d_utf8, n_bytes, d_doc_off, n_docs, d_start_bits, d_gap_bits, d_status, (hipStream_t)hip_stream);
+    });
+}
+
+uint64_t spl_device_split_fallbacks(const spl_tokenizer* t) { return t ? t->rx_fallbacks : 0; }
 
 int spl_encode_chunks_device(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
                              uint64_t n_docs, const uint32_t* d_start_bits, const uint32_t* d_gap_bits, uint32_t* d_ids,

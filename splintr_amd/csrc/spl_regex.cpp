@@ -27,6 +27,10 @@ enum Op : uint8_t { OP_CHAR, OP_CHAR_FOLD, OP_CLASS, OP_ANY, OP_SPLIT, OP_JMP, O
                     OP_ATOMIC,      // (?>...) and the possessive quantifiers: sub-program at pc + 1 (ends in MATCH), its FIRST match is final; x = continuation
                     OP_ASSERT };    // x = AS_*: a position test that consumes nothing
 enum : uint32_t { AS_BOL, AS_EOL, AS_EOT, AS_WORDB, AS_NWORDB };     // ^ \A | $ \Z | \z | \b | \B
+// (the device splitter reads these values from the program image: spl_rx_split.h RXO_* / RXA_*)
+static_assert(OP_CHAR == 0 && OP_CHAR_FOLD == 1 && OP_CLASS == 2 && OP_ANY == 3 && OP_SPLIT == 4 && OP_JMP == 5 && OP_MATCH == 6 && OP_LOOK == 7 &&
+              OP_NLOOK == 8 && OP_REP1 == 9 && OP_ATOMIC == 10 && OP_ASSERT == 11, "spl_rx_split.h RXO_*");
+static_assert(AS_BOL == 0 && AS_EOL == 1 && AS_EOT == 2 && AS_WORDB == 3 && AS_NWORDB == 4, "spl_rx_split.h RXA_*");
 struct Inst { Op op; uint32_t x, y; uint32_t f = 0xFFFFFFFFu; };   // f (SPLIT of an alternation): first-character filter of branch x
 // which characters can START a match of an alternative: 128 bits for ASCII, one flag for everything else (conservative)
 struct FirstSet { uint64_t ascii[2] = {0, 0}; bool other = false; };                  // CHAR: x = cp; CLASS: x = set; SPLIT: x first, y second; JMP: x;
@@ -765,6 +769,32 @@ RegexPtr regex_compile(const std::string& pattern, const HostTables& ht, std::st
     em.emit(OP_MATCH);
     if (em.too_big) { err = "the split pattern expands to more than 200 000 matcher instructions"; return nullptr; }
     return prog;
+}
+
+bool regex_device_image(const RegexProg& prog, std::vector<uint32_t>& w) {
+    w.assign(RX_HDR_WORDS, 0u);
+    if (prog.code.size() > 0xFFFFu) return false;                         // (a program counter is 16 bits of a stack word on the device)
+    w[0] = (uint32_t)prog.code.size();
+    for (const Inst& in : prog.code) { w.push_back((uint32_t)in.op); w.push_back(in.x); w.push_back(in.y); w.push_back(in.f); }
+    std::vector<uint32_t> ranges;
+    w[1] = (uint32_t)w.size(); w[2] = (uint32_t)prog.sets.size();
+    for (const ClassSet& cs : prog.sets) {
+        w.push_back(cs.codes); w.push_back(cs.gcs); w.push_back(cs.neg ? 1u : 0u);
+        w.push_back((uint32_t)cs.ascii[0]); w.push_back((uint32_t)(cs.ascii[0] >> 32));
+        w.push_back((uint32_t)cs.ascii[1]); w.push_back((uint32_t)(cs.ascii[1] >> 32));
+        w.push_back((uint32_t)(ranges.size() / 2)); w.push_back((uint32_t)cs.ranges.size());
+        for (const auto& r : cs.ranges) { ranges.push_back(r.first); ranges.push_back(r.second); }
+        if (cs.gcs) w[7] = 1u;
+    }
+    w[3] = (uint32_t)w.size(); w[4] = (uint32_t)prog.firsts.size();
+    for (const FirstSet& fs : prog.firsts) {
+        w.push_back((uint32_t)fs.ascii[0]); w.push_back((uint32_t)(fs.ascii[0] >> 32));
+        w.push_back((uint32_t)fs.ascii[1]); w.push_back((uint32_t)(fs.ascii[1] >> 32));
+        w.push_back(fs.other ? 1u : 0u);
+    }
+    w[5] = (uint32_t)w.size(); w[6] = (uint32_t)(ranges.size() / 2);
+    w.insert(w.end(), ranges.begin(), ranges.end());
+    return w.size() <= RX_IMAGE_MAX_WORDS;
 }
 
 bool regex_split_spans(const RegexProg& prog, const uint8_t* text, size_t n, std::vector<std::pair<uint32_t, uint32_t>>& out) {

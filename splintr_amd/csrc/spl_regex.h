@@ -42,6 +42,16 @@ RegexPtr regex_compile(const std::string& pattern, const HostTables& ht, std::st
 // bitmap words).  Returns false if the step budget of a match attempt ran out (a pathological pattern).
 bool regex_split_bits(const RegexProg& prog, const uint8_t* text, size_t n, uint64_t base, uint32_t* start_bits, uint32_t* gap_bits);
 
+// The program as a flat image of 32-bit words for the DEVICE splitter (spl_rx_split.h: the same matcher, one text position per
+// lane).  Layout: RX_HDR_WORDS header words -- [0] instructions, [1] word offset of the class sets, [2] sets, [3] offset of the
+// first-character filters, [4] filters, [5] offset of the ranges, [6] ranges, [7] 1 if a set tests general categories --; from
+// word RX_HDR_WORDS the instructions, RX_INST_WORDS words each (op, x, y, f); class sets of RX_SET_WORDS words (class-code bits,
+// general-category bits, negated, four words of ASCII membership, first range, ranges); filters of RX_FIRST_WORDS words (four
+// words of ASCII membership, "anything beyond ASCII"); ranges as (first, last) pairs.  Returns false if the program is larger
+// than the device matcher keeps in LDS (RX_IMAGE_MAX_WORDS): such a pattern is split on the host.
+constexpr uint32_t RX_HDR_WORDS = 8, RX_INST_WORDS = 4, RX_SET_WORDS = 9, RX_FIRST_WORDS = 5, RX_IMAGE_MAX_WORDS = 3072;
+bool regex_device_image(const RegexProg& prog, std::vector<uint32_t>& words);
+
 // The same as a list of (start, end) pairs (tests).
 bool regex_split_spans(const RegexProg& prog, const uint8_t* text, size_t n, std::vector<std::pair<uint32_t, uint32_t>>& out);
 

@@ -1,0 +1,458 @@
+// spl_rx_split.h -- custom split patterns ON THE DEVICE: the host splitter's matcher (spl_regex.cpp), one text position per lane.
+//
+// Tokenizer::new compiles any pattern and encode() walks find_iter's non-overlapping leftmost-first matches from the start of
+// each text (reference src/core/tokenizer.rs:410-456, 244-257, 729-808).  That walk is sequential: where match k + 1 starts is
+// where match k ended.  Position-parallel form:
+//
+//   k_rx_match   every byte position p runs the SAME backtracking program the host splitter runs (regex_device_image: the
+//                instruction list, class sets and first-character filters, copied to LDS), anchored at p, inside p's document:
+//                nx[p] = how far find_iter would move from p -- the length of the match, or the length of the ONE character it
+//                skips when nothing matches there (bit 15: those bytes are dropped).  Then the block of RXB positions composes
+//                its hops by pointer doubling: gx[p] = where the walk from p first leaves the block (offset behind the block's
+//                end; bit 15: the last hop was a skip).  A block is CLOSED if every one of its positions leaves it at the same
+//                place -- true almost everywhere: walks from different positions of ordinary text fall into step within a word
+//                or two.  A hop that crosses whole blocks marks them "maybe skipped".
+//   k_rx_mark    block b finds where the walk from position 0 enters it: the exit of the nearest closed, not-skipped block in
+//                front of it (usually b - 1: one load), carried forward through gx over the blocks in between; repeats the
+//                doubling keeping every level, marks the positions of its own stretch of the walk top-down (the node 2^k hops
+//                behind a marked node is on the walk), and ORs the result into the two bitmaps k_pretok takes in place of its
+//                own scanner: chunk starts and dropped bytes, bit for bit what regex_split_bits leaves.
+//
+// What the matcher gives up on is REPORTED, never approximated (status word != 0, the caller splits that batch on the host):
+// a match or a look-ahead that reaches RX_REACH bytes beyond its start (every position of a run scans to the run's end --
+// the work is quadratic in the run length, so it is bounded), RX_STEPS matcher steps in one attempt, RX_DEPTH entries on the
+// backtracking stack.  Special-token literals are not handled here (with SPL_WITH_SPECIAL the host splitter runs).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "spl_common.h"
+#include "spl_regex.h"
+
+namespace spl {
+
+constexpr int RXB = 256;                       // positions per block = threads per workgroup
+constexpr int RX_REACH = 1032;                 // bytes behind its start a match attempt may look at (a hop is at most RX_REACH - 8)
+constexpr int RX_BACK = 4;                     // staged bytes in front of the block (\b looks at the character before)
+constexpr int RX_LDS_TEXT = RX_BACK + RXB + 276;   // staged text; beyond it the matcher reads global memory
+constexpr int RX_DEPTH = 24;
+constexpr uint32_t RX_STEPS = 8192;
+constexpr uint32_t RX_FAIL = 0xFFFFFFFFu, RX_ABORT = 0xFFFFFFFEu, RX_NOK = 0xFFFFFFFFu;
+enum : uint32_t { RXS_REACH = 1, RXS_STEPS = 2, RXS_DEPTH = 4 };
+enum : uint32_t { RXO_CHAR = 0, RXO_CHAR_FOLD, RXO_CLASS, RXO_ANY, RXO_SPLIT, RXO_JMP, RXO_MATCH, RXO_LOOK, RXO_NLOOK, RXO_REP1, RXO_ATOMIC, RXO_ASSERT };
+enum : uint32_t { RXA_BOL = 0, RXA_EOL, RXA_EOT, RXA_WORDB, RXA_NWORDB };
+constexpr uint32_t RX_BLK_CLOSED = 1u << 31, RX_BLK_SKIPPED = 1u << 30;
+constexpr uint32_t RXJ_EXIT = 1u << 15, RXJ_GAP = 1u << 14, RXJ_VAL = 0x3FFFu;
+
+struct RxArgs {
+    const uint32_t* image; uint32_t image_words;
+    const uint8_t* text; const uint64_t* doc_off; uint32_t n_bytes, n_docs;
+    const uint16_t* ucls1; const uint8_t* ucls2; uint32_t shift;
+    const uint16_t* gc1; const uint8_t* gc2;
+    uint16_t* nx; uint16_t* gx; uint32_t* blk; uint32_t* dstart;      // workspace: per byte, per byte, per block (zeroed), bitmap
+    uint32_t* starts; uint32_t* gaps;                                  // out: the two bitmaps (zeroed by the caller)
+    uint32_t* status;                                                  // out: RXS_* bits, OR-ed
+};
+
+struct RxCh { uint32_t cp, len, cls; };
+
+// One lane's view of the text and of the program.
+struct RxCtx {
+    const uint32_t* img;              // LDS
+    const uint8_t* s_txt;             // LDS: text[wbase, wbase + RX_LDS_TEXT)
+    int64_t wbase;
+    const RxArgs* a;
+    uint32_t n;                       // end of this position's document
+    __device__ __forceinline__ uint32_t rd(uint32_t q) const {
+        const int64_t i = (int64_t)q - wbase;
+        return i < RX_LDS_TEXT ? (uint32_t)s_txt[i] : (uint32_t)a->text[q];
+    }
+    __device__ __forceinline__ uint32_t cls_of(uint32_t cp) const {
+        if (cp >= 0x110000u) return C_P;
+        const uint32_t blk = a->ucls1[cp >> a->shift];
+        return a->ucls2[(blk << a->shift) | (cp & ((1u << a->shift) - 1u))];
+    }
+    __device__ __forceinline__ uint32_t cat_of(uint32_t cp) const {
+        if (cp >= 0x110000u || !a->gc1) return 0;
+        const uint32_t blk = a->gc1[cp >> a->shift];
+        return a->gc2[(blk << a->shift) | (cp & ((1u << a->shift) - 1u))];
+    }
+    // (spl_regex.cpp decode: a lead byte takes the continuation bytes actually present, at most as many as it announces)
+    __device__ __forceinline__ RxCh decode(uint32_t pos) const {
+        const uint32_t b = rd(pos);
+        if (b < 0x80) return RxCh{b, 1, cls_of(b)};
+        if (b < 0xC0) return RxCh{0xFFFFFFFFu, 1, (uint32_t)C_P};
+        const uint32_t want = b < 0xE0 ? 2 : b < 0xF0 ? 3 : 4;
+        uint32_t len = 1, cp = b & (0xFFu >> (want + 1));
+        while (len < want && pos + len < n) {
+            const uint32_t c = rd(pos + len);
+            if ((c & 0xC0u) != 0x80u) break;
+            cp = (cp << 6) | (c & 0x3Fu);
+            len++;
+        }
+        if (len != want) return RxCh{0xFFFFFFFFu, len, (uint32_t)C_P};
+        return RxCh{cp, want, cls_of(cp)};
+    }
+    __device__ __forceinline__ uint32_t char_len(uint32_t pos) const { return rd(pos) < 0x80 ? 1u : decode(pos).len; }
+    __device__ __forceinline__ const uint32_t* inst(uint32_t pc) const { return img + RX_HDR_WORDS + RX_INST_WORDS * pc; }
+    __device__ __forceinline__ const uint32_t* set(uint32_t s) const { return img + img[1] + RX_SET_WORDS * s; }
+    __device__ __forceinline__ bool in_set(uint32_t s, const RxCh& c) const {
+        const uint32_t* cs = set(s);
+        bool in = ((cs[0] >> c.cls) & 1u) != 0;
+        if (!in && cs[1]) in = ((cs[1] >> (c.cp == 0xFFFFFFFFu ? 0u : cat_of(c.cp))) & 1u) != 0;
+        if (!in && c.cp != 0xFFFFFFFFu) {
+            const uint32_t* r = img + img[5] + 2 * cs[7];
+            for (uint32_t k = 0; k < cs[8]; k++) if (c.cp >= r[2 * k] && c.cp <= r[2 * k + 1]) { in = true; break; }
+        }
+        return in != (cs[2] != 0u);
+    }
+    __device__ __forceinline__ bool one_ascii(uint32_t op, uint32_t x, uint32_t b) const {
+        if (op == RXO_CHAR) return b == x;
+        if (op == RXO_CHAR_FOLD) return (b | 0x20u) == (x | 0x20u) && ((b | 0x20u) - 'a') < 26u;
+        if (op == RXO_ANY) return b != '\n';
+        return ((set(x)[3 + (b >> 5)] >> (b & 31)) & 1u) != 0;
+    }
+    __device__ __forceinline__ bool one(uint32_t op, uint32_t x, const RxCh& c) const {
+        if (op == RXO_CHAR) return c.cp == x;
+        if (op == RXO_CHAR_FOLD) {
+            const uint32_t lo = x | 0x20u;
+            if (c.cp == 0xFFFFFFFFu) return false;
+            if (c.cp < 0x80) return (c.cp | 0x20u) == lo && ((c.cp | 0x20u) - 'a') < 26u;
+            return (lo == 's' && c.cp == 0x17F) || (lo == 'k' && c.cp == 0x212A);
+        }
+        if (op == RXO_ANY) return c.cp != '\n';
+        return in_set(x, c);
+    }
+    __device__ __forceinline__ bool is_word(uint32_t q) const {
+        const RxCh c = decode(q);
+        return c.cp == '_' || ((SPL_BIT(c.cls) & (M_L | SPL_BIT(C_N))) != 0 && c.cp != 0xFFFFFFFFu);
+    }
+};
+
+// The match of the program anchored at p (spl_regex.cpp Matcher::run with its recursion for look-aheads and atomic groups
+// unrolled onto the one stack: a CALL entry below the sub-run's floor).  p_is_start: p is the first byte of its document;
+// `back`: how many bytes in front of p belong to the same document (up to RX_BACK).  Returns the end, RX_FAIL, or RX_ABORT
+// with `why` set.
+__device__ __noinline__ uint32_t rx_run(const RxCtx& c, uint32_t p, bool p_is_start, uint32_t back, uint32_t& why) {
+    uint32_t st[3 * RX_DEPTH];
+    int sp = 0, floor = 0;
+    uint32_t steps = 0;
+    const uint32_t n = c.n;
+    const bool trunc = n > p + (uint32_t)RX_REACH;
+    const uint32_t lim = p + (uint32_t)RX_REACH;
+    uint32_t pc = 0, pos = p;
+    bool run = true;
+#define RX_PUSH(A, B, C) do { if (sp == RX_DEPTH) { why = RXS_DEPTH; return RX_ABORT; } st[3 * sp] = (A); st[3 * sp + 1] = (B); st[3 * sp + 2] = (C); sp++; } while (0)
+    for (;;) {
+        bool ended = false;
+        uint32_t r = RX_FAIL;
+        if (run) {
+            for (;;) {
+                if (++steps > RX_STEPS) { why = RXS_STEPS; return RX_ABORT; }
+                if (trunc && pos + 8 > lim) { why = RXS_REACH; return RX_ABORT; }
+                const uint32_t* in = c.inst(pc);
+                const uint32_t op = in[0], x = in[1], y = in[2], f = in[3];
+                if (op == RXO_MATCH) { ended = true; r = pos; break; }
+                if (op == RXO_JMP) { pc = x; continue; }
+                if (op == RXO_SPLIT) {
+                    if (f != 0xFFFFFFFFu) {
+                        bool can = false;
+                        if (pos < n) {
+                            const uint32_t b = c.rd(pos);
+                            const uint32_t* fs = c.img + c.img[3] + RX_FIRST_WORDS * f;
+                            can = b < 0x80 ? ((fs[b >> 5] >> (b & 31)) & 1u) != 0 : fs[4] != 0u;
+                        }
+                        if (!can) { pc = y; continue; }
+                    }
+                    RX_PUSH(y, RX_NOK, pos);
+                    pc = x;
+                    continue;
+                }
+                if (op == RXO_LOOK || op == RXO_NLOOK || op == RXO_ATOMIC) {          // the sub-program at pc + 1 as a run of its own
+                    RX_PUSH(pc, (uint32_t)floor, pos);
+                    floor = sp;
+                    pc = pc + 1;
+                    continue;
+                }
+                if (op == RXO_ASSERT) {
+                    bool ok;
+                    if (x == RXA_BOL) ok = pos == p && p_is_start;
+                    else if (x == RXA_EOT) ok = pos == n;
+                    else if (x == RXA_EOL) ok = pos == n || (pos + 1 == n && c.rd(pos) == '\n');
+                    else {
+                        const bool after = pos < n && c.is_word(pos);
+                        bool before = false;
+                        const uint32_t room = pos - p + back;                       // bytes of the document in front of pos (as far as it matters)
+                        if (room > 0) {
+                            uint32_t q = pos - 1, went = 1;
+                            while (went < room && went < 4 && (c.rd(q) & 0xC0u) == 0x80u) { q--; went++; }
+                            if (q + c.decode(q).len == pos) before = c.is_word(q);
+                        }
+                        ok = (before != after) == (x == RXA_WORDB);
+                    }
+                    if (!ok) break;
+                    pc++;
+                    continue;
+                }
+                if (op == RXO_REP1) {
+                    const uint32_t* a1 = c.inst(pc + 1);
+                    const uint32_t aop = a1[0], ax = a1[1];
+                    uint32_t q = pos, k = 0;
+                    bool far = false;
+                    while (k < y && q < n) {
+                        if (trunc && q + 8 > lim) { far = true; break; }
+                        const uint32_t b = c.rd(q);
+                        if (b < 0x80) {
+                            if (!c.one_ascii(aop, ax, b)) break;
+                            q++;
+                        } else {
+                            const RxCh ch = c.decode(q);
+                            if (!c.one(aop, ax, ch)) break;
+                            q += ch.len;
+                        }
+                        k++;
+                    }
+                    if (far) { why = RXS_REACH; return RX_ABORT; }
+                    steps += k;
+                    if (k < x) break;
+                    if (k > x && f != 1u) RX_PUSH(pc, k - 1, pos);
+                    pos = q;
+                    pc += 2;
+                    continue;
+                }
+                if (pos >= n) break;
+                {
+                    const uint32_t b = c.rd(pos);
+                    if (b < 0x80) {
+                        if (!c.one_ascii(op, x, b)) break;
+                        pos++;
+                    } else {
+                        const RxCh ch = c.decode(pos);
+                        if (!c.one(op, x, ch)) break;
+                        pos += ch.len;
+                    }
+                }
+                pc++;
+            }
+        }
+        run = false;
+        if (!ended) {
+            if (sp > floor) {                                                          // the next way to go on
+                sp--;
+                pc = st[3 * sp]; pos = st[3 * sp + 2];
+                const uint32_t k = st[3 * sp + 1];
+                if (k != RX_NOK) {                                                     // a REP1 gives a character back: k of them from the run's start
+                    const uint32_t* in = c.inst(pc);
+                    if (k > in[1]) { st[3 * sp] = pc; st[3 * sp + 1] = k - 1; st[3 * sp + 2] = pos; sp++; }
+                    for (uint32_t j = 0; j < k; j++) pos += c.char_len(pos);
+                    steps += k;
+                    pc += 2;
+                }
+                run = true;
+                continue;
+            }
+            r = RX_FAIL;
+        }
+        // a run has ended with r: the top-level one, or the sub-run of the CALL entry below the floor
+        sp = floor;
+        if (floor == 0) return r;
+        sp--;
+        const uint32_t pcl = st[3 * sp];
+        floor = (int)st[3 * sp + 1];
+        const uint32_t psave = st[3 * sp + 2];
+        const uint32_t* in = c.inst(pcl);
+        if (in[0] == RXO_ATOMIC) {
+            if (r == RX_FAIL) continue;
+            pos = r; pc = in[1]; run = true;
+        } else if ((r != RX_FAIL) == (in[0] == RXO_LOOK)) {
+            pos = psave; pc = in[1]; run = true;
+        }
+    }
+#undef RX_PUSH
+}
+
+// Pointer doubling over one block: j[q] (a local index, or RXJ_EXIT | last-hop-was-a-skip | offset behind the block) becomes
+// the place where the walk from q leaves the block.  With `lev`, level k's pointers (before round k) are kept at lev[k * RXB + q].
+__device__ __forceinline__ void rx_double(uint16_t* j, uint16_t* lev, int q) {
+    for (int k = 0; k < 8; k++) {
+        const uint32_t v = j[q];
+        if (lev) lev[k * RXB + q] = (uint16_t)v;
+        const uint32_t v2 = (v & RXJ_EXIT) ? v : (uint32_t)j[v];
+        __syncthreads();
+        j[q] = (uint16_t)v2;
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ uint32_t rx_hop(uint32_t q, uint32_t nxv) {       // level-0 pointer of local position q
+    const uint32_t to = q + (nxv & 0x7FFFu);
+    return to < (uint32_t)RXB ? to : (RXJ_EXIT | ((nxv & 0x8000u) ? RXJ_GAP : 0u) | (to - (uint32_t)RXB));
+}
+
+__global__ __launch_bounds__(RXB) void k_rx_match(RxArgs a) {
+    __shared__ uint32_t s_img[RX_IMAGE_MAX_WORDS];
+    __shared__ __attribute__((aligned(4))) uint8_t s_txt[RX_LDS_TEXT + 4];
+    __shared__ uint32_t s_ds[(RX_BACK + RXB + RX_REACH) / 32 + 2];            // document starts of [wbase, wbase + RX_BACK + RXB + RX_REACH)
+    __shared__ uint16_t s_j[RXB];
+    const int tid = (int)threadIdx.x;
+    const uint32_t B = a.n_bytes;
+    const uint32_t start = blockIdx.x * (uint32_t)RXB;
+    const int64_t wbase = (int64_t)start - RX_BACK;
+    constexpr int DSW = (RX_BACK + RXB + RX_REACH) / 32 + 2;
+    for (int i = tid; i < (int)a.image_words; i += RXB) s_img[i] = a.image[i];
+    for (int i = tid; i < DSW; i += RXB) s_ds[i] = 0;
+    for (int w = tid; w < (RX_LDS_TEXT + 3) / 4; w += RXB) {
+        const int64_t g = wbase + 4 * (int64_t)w;
+        uint32_t v = 0;
+        if (g >= 0 && g + 4 <= (int64_t)B) v = *reinterpret_cast<const uint32_t*>(a.text + g);      // (the text buffer is 16-byte aligned, start a multiple of 256)
+        else for (int k = 0; k < 4; k++) if (g + k >= 0 && g + k < (int64_t)B) v |= (uint32_t)a.text[g + k] << (8 * k);
+        reinterpret_cast<uint32_t*>(s_txt)[w] = v;
+    }
+    // documents that start inside the window: RXB-ary search for the first one at or behind its begin, then their bits
+    const uint64_t wlo = wbase > 0 ? (uint64_t)wbase : 0ull, whi = (uint64_t)(wbase + RX_BACK + RXB + RX_REACH);
+    uint32_t lo = 0, hi = a.n_docs;
+    while (wlo != 0 && lo < hi) {
+        const uint32_t span = hi - lo, stp = (span + RXB - 1) / RXB;
+        const uint64_t idx = (uint64_t)lo + (uint64_t)tid * stp;
+        const bool below = idx < hi && a.doc_off[idx] < wlo;
+        const uint32_t cnt = (uint32_t)__syncthreads_count(below);
+        if (cnt == 0) { hi = lo; break; }
+        const uint64_t nhi = (uint64_t)lo + (uint64_t)cnt * stp;
+        lo = lo + (cnt - 1) * stp + 1;
+        hi = nhi < hi ? (uint32_t)nhi : hi;
+    }
+    __syncthreads();
+    for (uint32_t base = lo;; base += RXB) {
+        const uint64_t d = (uint64_t)base + tid;
+        uint64_t dp = ~0ull;
+        if (d < a.n_docs) dp = a.doc_off[d];
+        const bool in = dp < whi && dp < (uint64_t)B;
+        if (in) { const uint32_t i = (uint32_t)((int64_t)dp - wbase); atomicOr(&s_ds[i >> 5], 1u << (i & 31)); }
+        if (!__syncthreads_or(tid == RXB - 1 && in)) break;
+    }
+    const bool any_ds = __syncthreads_or(tid < DSW && s_ds[tid] != 0u) != 0;      // (long documents: nothing to scan for below)
+    const uint32_t p = start + (uint32_t)tid;
+    uint32_t nxv = 1u | 0x8000u;
+    bool is_start = false;
+    if (p < B) {
+        const uint32_t wi = (uint32_t)tid + RX_BACK;
+        auto ds_bit = [&](uint32_t i) { return (s_ds[i >> 5] >> (i & 31)) & 1u; };
+        is_start = ds_bit(wi) != 0u;
+        // the end of p's document: the next document start behind p (or the end of the corpus)
+        uint32_t n = B;
+        if (any_ds) {
+            uint32_t i = wi + 1, w = i >> 5;
+            uint32_t bits = s_ds[w] & (~0u << (i & 31));
+            while (!bits && ++w < (uint32_t)DSW) bits = s_ds[w];
+            if (bits) { const uint32_t e = (uint32_t)(wbase + (int64_t)(w * 32 + (uint32_t)__ffs((int)bits) - 1)); n = e < n ? e : n; }
+        }
+        uint32_t back = 0;                                        // bytes of the same document in front of p (up to RX_BACK)
+        if (!is_start) { back = 1; while (back < (uint32_t)RX_BACK && back < p && !ds_bit(wi - back)) back++; }
+        RxCtx c{s_img, s_txt, wbase, &a, n};
+        uint32_t why = 0;
+        const uint32_t e = rx_run(c, p, is_start, back, why);
+        if (e == RX_ABORT) atomicOr(a.status, why);
+        if (e < RX_ABORT && e > p) {
+            uint32_t d = e - p;
+            if (d > (uint32_t)RX_REACH - 8u) { atomicOr(a.status, RXS_REACH); d = RX_REACH - 8; }
+            nxv = d;
+            // a hop over whole blocks: they may not be touched by the walk at all
+            for (uint32_t k = (p >> 8) + 1; (k + 1) * (uint32_t)RXB <= p + d; k++) atomicOr(&a.blk[k], RX_BLK_SKIPPED);
+        } else {
+            nxv = c.char_len(p) | 0x8000u;                        // no match here (or an empty one): the character is skipped
+        }
+        a.nx[p] = (uint16_t)nxv;
+    }
+    // the block's own words of the document-start bitmap
+    {
+        const unsigned long long m = __ballot(is_start);
+        if ((tid & 63) == 0) { a.dstart[(start >> 5) + (tid >> 5)] = (uint32_t)m; a.dstart[(start >> 5) + (tid >> 5) + 1] = (uint32_t)(m >> 32); }
+    }
+    s_j[tid] = (uint16_t)(p < B ? rx_hop((uint32_t)tid, nxv) : (RXJ_EXIT | 0u));
+    __syncthreads();
+    rx_double(s_j, nullptr, tid);
+    const uint32_t g = s_j[tid];
+    if (p < B) a.gx[p] = (uint16_t)(((g & RXJ_GAP) ? 0x8000u : 0u) | (g & RXJ_VAL));
+    const uint32_t g0 = s_j[0];
+    const bool same = p >= B || g == g0;
+    if (__syncthreads_and(same) && tid == 0)
+        atomicOr(&a.blk[blockIdx.x], RX_BLK_CLOSED | ((g0 & RXJ_GAP) ? 0x8000u : 0u) | (g0 & RXJ_VAL));
+}
+
+__global__ __launch_bounds__(RXB) void k_rx_mark(RxArgs a) {
+    __shared__ uint16_t s_j[RXB];
+    __shared__ uint16_t s_lev[8 * RXB];
+    __shared__ uint8_t s_m[RXB];
+    __shared__ unsigned long long s_cm[RXB / 64], s_gm[RXB / 64];
+    __shared__ uint32_t s_gb[RXB / 32 + 1];
+    __shared__ uint32_t s_e[2];
+    const int tid = (int)threadIdx.x;
+    const uint32_t B = a.n_bytes;
+    const uint32_t b = blockIdx.x, start = b * (uint32_t)RXB;
+    const uint32_t p = start + (uint32_t)tid;
+    if (tid == 0) {
+        // where the walk from position 0 enters this block
+        int64_t k = (int64_t)b - 1;
+        uint32_t v = 0;
+        while (k >= 0) {
+            v = a.blk[k];
+            if ((v & RX_BLK_CLOSED) && !(v & RX_BLK_SKIPPED)) break;
+            k--;
+        }
+        uint32_t E = 0, pg = 0;
+        if (k >= 0) { E = ((uint32_t)k + 1u) * RXB + (v & 0x7FFFu); pg = (v >> 15) & 1u; }
+        for (uint32_t kk = (uint32_t)(k + 1); kk < b && E < B; kk++) {
+            if (E >= (kk + 1) * (uint32_t)RXB) continue;           // the walk jumps over block kk
+            const uint32_t g = a.gx[E];
+            E = (kk + 1) * (uint32_t)RXB + (g & 0x7FFFu);
+            pg = g >> 15;
+        }
+        s_e[0] = E; s_e[1] = pg;
+    }
+    const uint32_t nxv = p < B ? (uint32_t)a.nx[p] : (1u | 0x8000u);
+    s_j[tid] = (uint16_t)(p < B ? rx_hop((uint32_t)tid, nxv) : (RXJ_EXIT | 0u));
+    s_m[tid] = 0;
+    if (tid < RXB / 32 + 1) s_gb[tid] = 0;
+    __syncthreads();
+    rx_double(s_j, s_lev, tid);
+    const uint32_t E = s_e[0], pg_in = s_e[1];
+    if (E >= start + (uint32_t)RXB || E >= B) return;              // the walk does not touch this block (uniform)
+    if ((uint32_t)tid == E - start) s_m[tid] = 1;
+    __syncthreads();
+    for (int k = 7; k >= 0; k--) {
+        const uint32_t v = s_lev[k * RXB + tid];
+        if (s_m[tid] && !(v & RXJ_EXIT)) s_m[v] = 1;
+        __syncthreads();
+    }
+    const bool chain = s_m[tid] != 0 && p < B;
+    const bool gapn = chain && (nxv & 0x8000u) != 0u;
+    {
+        const unsigned long long cm = __ballot(chain), gm = __ballot(gapn);
+        if ((tid & 63) == 0) { s_cm[tid >> 6] = cm; s_gm[tid >> 6] = gm; }
+    }
+    if (gapn) {
+        const uint32_t len = nxv & 0x7FFFu;
+        for (uint32_t k = 0; k < len; k++) { const uint32_t i = (uint32_t)tid + k; atomicOr(&s_gb[i >> 5], 1u << (i & 31)); }
+    }
+    __syncthreads();
+    bool st = chain;
+    if (gapn) {
+        // a stretch of dropped bytes has ONE start bit: where it begins (behind a match, or at the start of a document)
+        uint32_t pgap = pg_in;
+        int w = tid >> 6;
+        unsigned long long below = s_cm[w] & ((1ull << (tid & 63)) - 1ull);
+        while (!below && --w >= 0) below = s_cm[w];
+        if (below) { const int l = 63 - __builtin_clzll(below); pgap = (uint32_t)((s_gm[w] >> l) & 1ull); }
+        const bool ds = ((a.dstart[p >> 5] >> (p & 31)) & 1u) != 0u;
+        st = !pgap || ds;
+    }
+    const unsigned long long sm = __ballot(st);
+    if ((tid & 63) == 0) {
+        const uint32_t w0 = (start >> 5) + (uint32_t)(tid >> 5);
+        if ((uint32_t)sm) atomicOr(&a.starts[w0], (uint32_t)sm);
+        if ((uint32_t)(sm >> 32)) atomicOr(&a.starts[w0 + 1], (uint32_t)(sm >> 32));
+    }
+    if (tid < RXB / 32 + 1 && s_gb[tid]) atomicOr(&a.gaps[(start >> 5) + (uint32_t)tid], s_gb[tid]);
+}
+
+}  // namespace spl

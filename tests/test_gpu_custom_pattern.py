@@ -177,8 +177,22 @@ def test_split_on_the_host_encode_on_the_device_entry_points():
     off = b.out_off.cpu().numpy().astype(np.uint64)
     assert np.array_equal(off, want_off)
     assert np.array_equal(b.ids[:int(off[-1])].cpu().numpy().view(np.uint32), want_ids)
-    rc = L.spl_encode_batch_device(t.handle, b.text.data_ptr(), b.n_bytes, b.doc_off.data_ptr(), b.n_docs, 0, b.ids.data_ptr(), b.ids.numel(),
-                                   b.out_off.data_ptr(), None)
+    # round 4: the device-text entry point of a custom-pattern handle runs the device splitter itself (and the host one for what that
+    # gives up on: the second batch holds a 5 KB word); with SPL_WITH_SPECIAL it says where to go
+    for batch in (texts, texts + ["q" * 5000 + " end"]):
+        want_ids, want_off = t.encode_batch_csr(batch)
+        b = DeviceBatch(batch, dev)
+        b.ids.fill_(-1)
+        rc = L.spl_encode_batch_device(t.handle, b.text.data_ptr(), b.n_bytes, b.doc_off.data_ptr(), b.n_docs, 0, b.ids.data_ptr(), b.ids.numel(),
+                                       b.out_off.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, _ffi.last_error()
+        torch.cuda.synchronize()
+        off = b.out_off.cpu().numpy().astype(np.uint64)
+        assert np.array_equal(off, want_off)
+        assert np.array_equal(b.ids[:int(off[-1])].cpu().numpy().view(np.uint32), want_ids)
+    ts = Tokenizer.from_bytes(_blob("cl100k_base"), GPT2_PATTERN, {"<|x|>": 100300})
+    rc = L.spl_encode_batch_device(ts.handle, b.text.data_ptr(), b.n_bytes, b.doc_off.data_ptr(), b.n_docs, _ffi.SPL_WITH_SPECIAL, b.ids.data_ptr(),
+                                   b.ids.numel(), b.out_off.data_ptr(), None)
     assert rc != 0 and "spl_split_host" in _ffi.last_error()
 
 

@@ -1,0 +1,136 @@
+"""SURVEY 8f rank 2, "arbitrary pattern", on the GPU: the device splitter (splintr_amd/csrc/spl_rx_split.h -- the host splitter's
+program run at every text position, then the walk from the start of the corpus by pointer doubling) leaves bit for bit the two
+bitmaps the host splitter leaves (which tests/test_host_regex.py pins to PCRE2), or says that it gave up.
+Reference: Tokenizer::new compiles any pattern and encode() walks find_iter's matches (src/core/tokenizer.rs:410-456, 729-808)."""
+import os
+
+import numpy as np
+import pytest
+
+from fuzzgen import cased_corpus, fuzz_corpus, latin_corpus
+from test_host_regex import (DEEPSEEK_LIKE, GPT2_PATTERN, MIXED, QWEN2, SPARSE, TIKTOKEN_CL100K, TIKTOKEN_O200K, VARIANT_A, VARIANT_B,
+                             WORDS_DIGITS)
+
+pytestmark = pytest.mark.gpu
+DATA = os.path.join(os.path.dirname(__file__), "..", "splintr_amd", "data")
+PATTERNS = {"gpt2": GPT2_PATTERN, "variant_a": VARIANT_A, "variant_b": VARIANT_B, "sparse": SPARSE, "mixed": MIXED,
+            "tiktoken_cl100k": TIKTOKEN_CL100K, "tiktoken_o200k": TIKTOKEN_O200K, "qwen2": QWEN2, "deepseek_like": DEEPSEEK_LIKE,
+            "words_digits": WORDS_DIGITS}
+
+
+def _blob(name):
+    with open(os.path.join(DATA, name + ".splv"), "rb") as f:
+        return f.read()
+
+
+def _both(t, texts):
+    """(host starts, host gaps, device starts, device gaps, status) for one packed batch"""
+    import torch
+    from splintr_amd import _ffi
+    L = _ffi.lib()
+    dev = torch.device("cuda", 0)
+    parts = [x.encode("utf-8") if isinstance(x, str) else x for x in texts]
+    blob = b"".join(parts)
+    off = np.zeros(len(parts) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(x) for x in parts], dtype=np.uint64)
+    d_text = torch.from_numpy(np.frombuffer(blob + b"\0" * ((-len(blob)) % 16 + 16), dtype=np.uint8).copy()).to(dev)
+    d_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+    words = len(blob) // 32 + 2
+    st, gp = np.zeros(words, dtype=np.uint32), np.zeros(words, dtype=np.uint32)
+    assert L.spl_split_host(t.handle, blob, off.ctypes.data, len(parts), st.ctypes.data, gp.ctypes.data) == 0, _ffi.last_error()
+    d_st = torch.full((words + 2,), -1, dtype=torch.int32, device=dev)
+    d_gp = torch.full((words + 2,), -1, dtype=torch.int32, device=dev)
+    d_status = torch.zeros(4, dtype=torch.int32, device=dev)
+    rc = L.spl_split_device(t.handle, d_text.data_ptr(), len(blob), d_off.data_ptr(), len(parts), d_st.data_ptr(), d_gp.data_ptr(),
+                            d_status.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, _ffi.last_error()
+    torch.cuda.synchronize()
+    return (st, gp, d_st[:words].cpu().numpy().view(np.uint32), d_gp[:words].cpu().numpy().view(np.uint32), int(d_status[0].item()))
+
+
+def _first_diff(a, b):
+    w = int(np.nonzero(a != b)[0][0])
+    return w * 32 + int(np.log2((int(a[w]) ^ int(b[w])) & -(int(a[w]) ^ int(b[w]))))
+
+
+@pytest.mark.parametrize("key", sorted(PATTERNS))
+def test_device_bitmaps_equal_the_host_splitter_s(key):
+    from splintr_amd import Tokenizer
+    t = Tokenizer.from_bytes(_blob("cl100k_base"), PATTERNS[key])
+    texts = fuzz_corpus(515, 3000, 40) + latin_corpus(3, 600, 90) + cased_corpus(5, 600, 70)
+    texts += ["", " ", "\n", "a", "'", "x's'S'ſ'K'K", "http://a.b/c?d=e www.x.y z", "你好你好 你 好", "a\nb\r\nc", "12345678901" * 9, "a  ", "  \n",
+              "it'S 'LL 'ſ 'Ve", "$12 €3 £ -- — ―", "foo_bar1 baz", "ひらがな カタカナ 漢字 한글" * 12, "end  \n", "", "", "x"]
+    for batch in (texts, texts[::-1], ["".join(texts[:400])], [x for x in texts if len(x) < 4]):
+        st, gp, dst, dgp, status = _both(t, batch)
+        assert status == 0, f"the device matcher gave up (status {status})"
+        assert np.array_equal(st, dst), f"start bits differ first at byte {_first_diff(st, dst)}"
+        assert np.array_equal(gp, dgp), f"gap bits differ first at byte {_first_diff(gp, dgp)}"
+
+
+def test_invalid_utf8_and_document_boundaries_inside_characters():
+    """raw bytes: stray continuation bytes, truncated sequences at document ends, documents of one byte"""
+    from splintr_amd import Tokenizer
+    rng = np.random.default_rng(99)
+    t = Tokenizer.from_bytes(_blob("cl100k_base"), TIKTOKEN_CL100K)
+    docs = []
+    for i in range(1500):
+        n = int(rng.integers(0, 60))
+        kind = i % 3
+        if kind == 0:
+            docs.append(bytes(rng.integers(0, 256, n, dtype=np.uint8)))
+        elif kind == 1:
+            docs.append(("héllo wörld 你好 " * 3).encode()[:n])                  # cut inside characters
+        else:
+            docs.append(bytes(rng.choice(np.frombuffer(b" a1\n\xe4\xbd\xa0\x80\xf0\x9f'sT", dtype=np.uint8), n)))
+    st, gp, dst, dgp, status = _both(t, docs)
+    assert status == 0
+    assert np.array_equal(st, dst), f"start bits differ first at byte {_first_diff(st, dst)}"
+    assert np.array_equal(gp, dgp), f"gap bits differ first at byte {_first_diff(gp, dgp)}"
+
+
+def test_long_matches_skip_blocks_and_longer_ones_are_reported():
+    """hops of 300..1000 bytes jump over whole 256-position blocks; beyond the matcher's reach the status word says so"""
+    from splintr_amd import Tokenizer
+    t = Tokenizer.from_bytes(_blob("cl100k_base"), GPT2_PATTERN)
+    rng = np.random.default_rng(5)
+    parts = []
+    for i in range(300):
+        n = int(rng.integers(200, 1000))
+        parts.append((" " * n, "a" * n, "7" * n, "-" * n, "漢" * (n // 3))[i % 5])
+        parts.append(" ab 12 ")
+    for batch in (["".join(parts)], parts, ["".join(parts[k:k + 7]) for k in range(0, len(parts), 7)]):
+        st, gp, dst, dgp, status = _both(t, batch)
+        assert status == 0
+        assert np.array_equal(st, dst), f"start bits differ first at byte {_first_diff(st, dst)}"
+        assert np.array_equal(gp, dgp)
+    # digits in pairs never fall into step: every block of a long digit run is open, the walk is carried through them
+    t3 = Tokenizer.from_bytes(_blob("cl100k_base"), VARIANT_A)
+    st, gp, dst, dgp, status = _both(t3, ["1" * 5000 + " x " + "23" * 3001, "9" * 1025])
+    assert status == 0 and np.array_equal(st, dst) and np.array_equal(gp, dgp)
+    _, _, _, _, status = _both(t, ["x" * 5000 + " tail"])
+    assert status != 0
+
+
+def test_encode_batch_uses_the_device_splitter_and_falls_back_by_itself():
+    from splintr_amd import Tokenizer, _ffi
+    L = _ffi.lib()
+    t = Tokenizer.from_bytes(_blob("cl100k_base"), GPT2_PATTERN)
+    h = Tokenizer.from_bytes(_blob("cl100k_base"), GPT2_PATTERN)
+    assert L.spl_set_option(h.handle, b"device_split", 0) == 0
+    texts = fuzz_corpus(8, 2000, 60) + latin_corpus(2, 500, 200)
+    a_ids, a_off = t.encode_batch_csr(texts)
+    b_ids, b_off = h.encode_batch_csr(texts)
+    assert np.array_equal(a_off, b_off) and np.array_equal(a_ids, b_ids)
+    assert L.spl_device_split_fallbacks(t.handle) == 0
+    long_texts = texts + ["y" * 70000 + " z"]
+    a_ids, a_off = t.encode_batch_csr(long_texts)
+    b_ids, b_off = h.encode_batch_csr(long_texts)
+    assert np.array_equal(a_off, b_off) and np.array_equal(a_ids, b_ids)
+    assert L.spl_device_split_fallbacks(t.handle) == 1
+    # several pipeline chunks
+    assert L.spl_set_option(t.handle, b"chunk_bytes", 1 << 16) == 0 and L.spl_set_option(t.handle, b"single_chunk_max_bytes", 1 << 16) == 0
+    big = texts * 6
+    a_ids, a_off = t.encode_batch_csr(big)
+    b_ids, b_off = h.encode_batch_csr(big)
+    assert np.array_equal(a_off, b_off) and np.array_equal(a_ids, b_ids)
+    assert L.spl_device_split_fallbacks(t.handle) == 1
