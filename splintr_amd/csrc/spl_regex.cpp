@@ -775,14 +775,31 @@ bool regex_device_image(const RegexProg& prog, std::vector<uint32_t>& w) {
     w.assign(RX_HDR_WORDS, 0u);
     if (prog.code.size() > 0xFFFFu) return false;                         // (a program counter is 16 bits of a stack word on the device)
     w[0] = (uint32_t)prog.code.size();
-    for (const Inst& in : prog.code) { w.push_back((uint32_t)in.op); w.push_back(in.x); w.push_back(in.y); w.push_back(in.f); }
+    for (const Inst& in0 : prog.code) {
+        Inst in = in0;
+        // (a jump to a jump, or to the end of the run, is that instruction itself: one matcher step less per match)
+        for (int hops = 0; in.op == OP_JMP && hops < 8; hops++) {
+            const Inst& to = prog.code[in.x];
+            if (to.op == OP_JMP || to.op == OP_MATCH) in = to; else break;
+        }
+        w.push_back((uint32_t)in.op); w.push_back(in.x); w.push_back(in.y); w.push_back(in.f);
+    }
+    // class sets that a run instruction repeats: a bitmap slot each (the first RX_MAX_RUNSETS of them)
+    std::vector<uint32_t> slot_of(prog.sets.size(), 0xFFFFFFFFu), run_sets;
+    for (size_t pc = 0; pc + 1 < prog.code.size(); pc++)
+        if (prog.code[pc].op == OP_REP1 && prog.code[pc + 1].op == OP_CLASS) {
+            const uint32_t sx = prog.code[pc + 1].x;
+            if (slot_of[sx] == 0xFFFFFFFFu && run_sets.size() < RX_MAX_RUNSETS) { slot_of[sx] = (uint32_t)run_sets.size(); run_sets.push_back(sx); }
+        }
     std::vector<uint32_t> ranges;
     w[1] = (uint32_t)w.size(); w[2] = (uint32_t)prog.sets.size();
-    for (const ClassSet& cs : prog.sets) {
+    for (size_t si = 0; si < prog.sets.size(); si++) {
+        const ClassSet& cs = prog.sets[si];
         w.push_back(cs.codes); w.push_back(cs.gcs); w.push_back(cs.neg ? 1u : 0u);
         w.push_back((uint32_t)cs.ascii[0]); w.push_back((uint32_t)(cs.ascii[0] >> 32));
         w.push_back((uint32_t)cs.ascii[1]); w.push_back((uint32_t)(cs.ascii[1] >> 32));
         w.push_back((uint32_t)(ranges.size() / 2)); w.push_back((uint32_t)cs.ranges.size());
+        w.push_back(slot_of[si]);
         for (const auto& r : cs.ranges) { ranges.push_back(r.first); ranges.push_back(r.second); }
         if (cs.gcs) w[7] = 1u;
     }
@@ -794,6 +811,21 @@ bool regex_device_image(const RegexProg& prog, std::vector<uint32_t>& w) {
     }
     w[5] = (uint32_t)w.size(); w[6] = (uint32_t)(ranges.size() / 2);
     w.insert(w.end(), ranges.begin(), ranges.end());
+    // first-byte dispatch: Matcher::run's first steps for an attempt that begins with byte b -- the SPLITs whose filter rules b out
+    w[8] = (uint32_t)w.size();
+    for (uint32_t b = 0; b <= 128; b++) {
+        uint32_t pc = 0;
+        while (prog.code[pc].op == OP_SPLIT && prog.code[pc].f != 0xFFFFFFFFu) {
+            const FirstSet& fs = prog.firsts[prog.code[pc].f];
+            const bool can = b < 128 ? ((fs.ascii[b >> 6] >> (b & 63)) & 1ull) != 0 : fs.other;
+            if (can) break;
+            pc = prog.code[pc].y;
+        }
+        w.push_back(pc);
+    }
+    w[9] = (uint32_t)run_sets.size(); w[10] = (uint32_t)w.size();
+    w.insert(w.end(), run_sets.begin(), run_sets.end());
+    while (w.size() % 4) w.push_back(0u);
     return w.size() <= RX_IMAGE_MAX_WORDS;
 }
 

@@ -35,7 +35,9 @@ constexpr int RXB = 256;                       // positions per block = threads 
 constexpr int RX_REACH = 1032;                 // bytes behind its start a match attempt may look at (a hop is at most RX_REACH - 8)
 constexpr int RX_BACK = 4;                     // staged bytes in front of the block (\b looks at the character before)
 constexpr int RX_LDS_TEXT = RX_BACK + RXB + 276;   // staged text; beyond it the matcher reads global memory
-constexpr int RX_DEPTH = 24;
+constexpr int RX_TAB = RX_LDS_TEXT - 4;         // window positions whose characters are tabulated (a character reads up to 3 bytes on)
+constexpr int RX_BMW = (RX_TAB + 63) / 64 * 2;  // words of one window bitmap
+constexpr int RX_DEPTH = 10;                     // entries of a lane's backtracking stack (LDS: two words each, RXB lanes)
 constexpr uint32_t RX_STEPS = 8192;
 constexpr uint32_t RX_FAIL = 0xFFFFFFFFu, RX_ABORT = 0xFFFFFFFEu, RX_NOK = 0xFFFFFFFFu;
 enum : uint32_t { RXS_REACH = 1, RXS_STEPS = 2, RXS_DEPTH = 4 };
@@ -60,12 +62,34 @@ struct RxCh { uint32_t cp, len, cls; };
 struct RxCtx {
     const uint32_t* img;              // LDS
     const uint8_t* s_txt;             // LDS: text[wbase, wbase + RX_LDS_TEXT)
-    int64_t wbase;
+    uint32_t wb;                      // wbase modulo 2^32 (-4 for block 0): q - wb is q's window index
     const RxArgs* a;
     uint32_t n;                       // end of this position's document
+    const uint32_t* bm;               // LDS: window bitmaps, RX_BMW words each -- slot s: the characters of run set s (every byte of such a
+                                      // character), slot RX_MAX_RUNSETS: the bytes that START a character
     __device__ __forceinline__ uint32_t rd(uint32_t q) const {
-        const int64_t i = (int64_t)q - wbase;
-        return i < RX_LDS_TEXT ? (uint32_t)s_txt[i] : (uint32_t)a->text[q];
+        const uint32_t i = q - wb;
+        return i < (uint32_t)RX_LDS_TEXT ? (uint32_t)s_txt[i] : (uint32_t)a->text[q];
+    }
+    // first 0 bit of bitmap m at or behind window index i0, below lim (lim if none)
+    __device__ __forceinline__ uint32_t first_zero(const uint32_t* m, uint32_t i0, uint32_t lim) const {
+        uint32_t w = i0 >> 5, bits = ~m[w] & (~0u << (i0 & 31));
+        while (!bits && (w + 1) * 32 < lim) bits = ~m[++w];
+        const uint32_t at = bits ? w * 32 + (uint32_t)__ffs((int)bits) - 1u : lim;
+        return at < lim ? at : lim;
+    }
+    __device__ __forceinline__ uint32_t last_set_below(const uint32_t* m, uint32_t i1) const {     // highest 1 bit below index i1 (one exists)
+        uint32_t w = (i1 - 1) >> 5, bits = m[w] & (0xFFFFFFFFu >> (31 - ((i1 - 1) & 31)));
+        while (!bits && w > 0) bits = m[--w];
+        return w * 32 + 31u - (uint32_t)__clz((int)bits);
+    }
+    __device__ __forceinline__ uint32_t count_set(const uint32_t* m, uint32_t i0, uint32_t i1) const {      // 1 bits in [i0, i1)
+        if (i1 <= i0) return 0;
+        uint32_t w = i0 >> 5, cnt = 0;
+        const uint32_t w1 = (i1 - 1) >> 5;
+        uint32_t bits = m[w] & (~0u << (i0 & 31));
+        while (w < w1) { cnt += (uint32_t)__popc(bits); bits = m[++w]; }
+        return cnt + (uint32_t)__popc(bits & (0xFFFFFFFFu >> (31 - ((i1 - 1) & 31))));
     }
     __device__ __forceinline__ uint32_t cls_of(uint32_t cp) const {
         if (cp >= 0x110000u) return C_P;
@@ -94,8 +118,23 @@ struct RxCtx {
         return RxCh{cp, want, cls_of(cp)};
     }
     __device__ __forceinline__ uint32_t char_len(uint32_t pos) const { return rd(pos) < 0x80 ? 1u : decode(pos).len; }
-    __device__ __forceinline__ const uint32_t* inst(uint32_t pc) const { return img + RX_HDR_WORDS + RX_INST_WORDS * pc; }
+    __device__ __forceinline__ uint4 inst(uint32_t pc) const { return *reinterpret_cast<const uint4*>(img + RX_HDR_WORDS + RX_INST_WORDS * pc); }
     __device__ __forceinline__ const uint32_t* set(uint32_t s) const { return img + img[1] + RX_SET_WORDS * s; }
+    __device__ __forceinline__ RxCh decode_win(uint32_t li, uint32_t B, const uint32_t* ds) const {      // the character at window index li (tabulation)
+        const uint32_t b = s_txt[li];
+        if (b < 0x80) return RxCh{b, 1, cls_of(b)};
+        if (b < 0xC0) return RxCh{0xFFFFFFFFu, 1, (uint32_t)C_P};
+        const uint32_t want = b < 0xE0 ? 2 : b < 0xF0 ? 3 : 4;
+        uint32_t len = 1, cp = b & (0xFFu >> (want + 1));
+        while (len < want && li + len + wb < B) {
+            const uint32_t i = li + len, c = s_txt[i];
+            if ((c & 0xC0u) != 0x80u || ((ds[i >> 5] >> (i & 31)) & 1u)) break;           // (a document that starts here ends the character)
+            cp = (cp << 6) | (c & 0x3Fu);
+            len++;
+        }
+        if (len != want) return RxCh{0xFFFFFFFFu, len, (uint32_t)C_P};
+        return RxCh{cp, want, cls_of(cp)};
+    }
     __device__ __forceinline__ bool in_set(uint32_t s, const RxCh& c) const {
         const uint32_t* cs = set(s);
         bool in = ((cs[0] >> c.cls) & 1u) != 0;
@@ -129,146 +168,228 @@ struct RxCtx {
     }
 };
 
-// The match of the program anchored at p (spl_regex.cpp Matcher::run with its recursion for look-aheads and atomic groups
-// unrolled onto the one stack: a CALL entry below the sub-run's floor).  p_is_start: p is the first byte of its document;
-// `back`: how many bytes in front of p belong to the same document (up to RX_BACK).  Returns the end, RX_FAIL, or RX_ABORT
-// with `why` set.
-__device__ __noinline__ uint32_t rx_run(const RxCtx& c, uint32_t p, bool p_is_start, uint32_t back, uint32_t& why) {
-    uint32_t st[3 * RX_DEPTH];
+// Every position of one block through the matcher (spl_regex.cpp Matcher::run with its recursion for look-aheads and atomic
+// groups unrolled onto the one stack: a CALL entry below the sub-run's floor).  ONE flat loop: a lane that has no attempt pulls
+// the next position of the block off a counter in LDS; a lane that has one executes ONE instruction of it, or takes the next
+// way on from its stack, or finishes.  Attempts differ in length by a factor of twenty (a letter inside a word: four steps;
+// a blank in front of a digit: every alternative); one position per lane for the whole kernel left a tenth of the lanes
+// working (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU, profiles/r04_device_split.txt).
+// Stack entry e of a lane: stk[(2 e) * RXB], stk[(2 e + 1) * RXB] (stk points at the lane's column: no bank conflicts) --
+// word 0: pc | (k + 1) << 16 for "REP1 at pc, retry with k characters" (0 in the upper half: go on at pc), or pc | floor << 16
+// for a CALL entry; word 1: text positions relative to the attempt's start (REP1: the run's start | its end << 16).
+struct RxBlock {
+    uint32_t start, B;
+    const uint32_t* s_ds;             // document starts of the window
+    bool any_ds;
+    uint32_t* s_next;                 // next position of the block nobody has taken
+    uint16_t* s_j;                    // out: level-0 pointers of the block's positions
+};
+
+__device__ __forceinline__ uint32_t rx_hop(uint32_t q, uint32_t nxv);
+
+__device__ __forceinline__ void rx_attempts(RxCtx& c, uint32_t* stk, const RxBlock& bk, const RxArgs& a) {
+    constexpr uint32_t NOTYET = 0xFFFFFFFDu;
+    constexpr int DSW = (RX_BACK + RXB + RX_REACH) / 32 + 2;
+    const uint32_t* const cs = c.bm + RX_MAX_RUNSETS * RX_BMW;
+    uint32_t p = 0, pl = 0, n = 0, lim = 0, back = 0, pc = 0, pos = 0, steps = 0;
     int sp = 0, floor = 0;
-    uint32_t steps = 0;
-    const uint32_t n = c.n;
-    const bool trunc = n > p + (uint32_t)RX_REACH;
-    const uint32_t lim = p + (uint32_t)RX_REACH;
-    uint32_t pc = 0, pos = p;
-    bool run = true;
-#define RX_PUSH(A, B, C) do { if (sp == RX_DEPTH) { why = RXS_DEPTH; return RX_ABORT; } st[3 * sp] = (A); st[3 * sp + 1] = (B); st[3 * sp + 2] = (C); sp++; } while (0)
-    for (;;) {
-        bool ended = false;
-        uint32_t r = RX_FAIL;
-        if (run) {
-            for (;;) {
-                if (++steps > RX_STEPS) { why = RXS_STEPS; return RX_ABORT; }
-                if (trunc && pos + 8 > lim) { why = RXS_REACH; return RX_ABORT; }
-                const uint32_t* in = c.inst(pc);
-                const uint32_t op = in[0], x = in[1], y = in[2], f = in[3];
-                if (op == RXO_MATCH) { ended = true; r = pos; break; }
-                if (op == RXO_JMP) { pc = x; continue; }
-                if (op == RXO_SPLIT) {
-                    if (f != 0xFFFFFFFFu) {
-                        bool can = false;
-                        if (pos < n) {
-                            const uint32_t b = c.rd(pos);
-                            const uint32_t* fs = c.img + c.img[3] + RX_FIRST_WORDS * f;
-                            can = b < 0x80 ? ((fs[b >> 5] >> (b & 31)) & 1u) != 0 : fs[4] != 0u;
-                        }
-                        if (!can) { pc = y; continue; }
-                    }
-                    RX_PUSH(y, RX_NOK, pos);
-                    pc = x;
-                    continue;
-                }
-                if (op == RXO_LOOK || op == RXO_NLOOK || op == RXO_ATOMIC) {          // the sub-program at pc + 1 as a run of its own
-                    RX_PUSH(pc, (uint32_t)floor, pos);
-                    floor = sp;
-                    pc = pc + 1;
-                    continue;
-                }
-                if (op == RXO_ASSERT) {
-                    bool ok;
-                    if (x == RXA_BOL) ok = pos == p && p_is_start;
-                    else if (x == RXA_EOT) ok = pos == n;
-                    else if (x == RXA_EOL) ok = pos == n || (pos + 1 == n && c.rd(pos) == '\n');
-                    else {
-                        const bool after = pos < n && c.is_word(pos);
-                        bool before = false;
-                        const uint32_t room = pos - p + back;                       // bytes of the document in front of pos (as far as it matters)
-                        if (room > 0) {
-                            uint32_t q = pos - 1, went = 1;
-                            while (went < room && went < 4 && (c.rd(q) & 0xC0u) == 0x80u) { q--; went++; }
-                            if (q + c.decode(q).len == pos) before = c.is_word(q);
-                        }
-                        ok = (before != after) == (x == RXA_WORDB);
-                    }
-                    if (!ok) break;
-                    pc++;
-                    continue;
-                }
-                if (op == RXO_REP1) {
-                    const uint32_t* a1 = c.inst(pc + 1);
-                    const uint32_t aop = a1[0], ax = a1[1];
-                    uint32_t q = pos, k = 0;
-                    bool far = false;
-                    while (k < y && q < n) {
-                        if (trunc && q + 8 > lim) { far = true; break; }
-                        const uint32_t b = c.rd(q);
-                        if (b < 0x80) {
-                            if (!c.one_ascii(aop, ax, b)) break;
-                            q++;
-                        } else {
-                            const RxCh ch = c.decode(q);
-                            if (!c.one(aop, ax, ch)) break;
-                            q += ch.len;
-                        }
-                        k++;
-                    }
-                    if (far) { why = RXS_REACH; return RX_ABORT; }
-                    steps += k;
-                    if (k < x) break;
-                    if (k > x && f != 1u) RX_PUSH(pc, k - 1, pos);
-                    pos = q;
-                    pc += 2;
-                    continue;
-                }
-                if (pos >= n) break;
-                {
-                    const uint32_t b = c.rd(pos);
-                    if (b < 0x80) {
-                        if (!c.one_ascii(op, x, b)) break;
-                        pos++;
-                    } else {
-                        const RxCh ch = c.decode(pos);
-                        if (!c.one(op, x, ch)) break;
-                        pos += ch.len;
-                    }
-                }
-                pc++;
-            }
+    bool trunc = false, p_is_start = false, run = false, have = false;
+    auto ds_bit = [&](uint32_t i) { return (bk.s_ds[i >> 5] >> (i & 31)) & 1u; };
+    auto finish = [&](uint32_t e) {                       // the attempt at p has ended with e: its hop
+        uint32_t nxv;
+        if (e < RX_ABORT && e > p) {
+            uint32_t d = e - p;
+            if (d > (uint32_t)RX_REACH - 8u) { atomicOr(a.status, RXS_REACH); d = RX_REACH - 8; }
+            nxv = d;
+            // a hop over whole blocks: they may not be touched by the walk at all
+            for (uint32_t k = (p >> 8) + 1; (k + 1) * (uint32_t)RXB <= p + d; k++) atomicOr(&a.blk[k], RX_BLK_SKIPPED);
+        } else {
+            nxv = c.char_len(p) | 0x8000u;                // no match here (or an empty one): the character is skipped
         }
-        run = false;
-        if (!ended) {
-            if (sp > floor) {                                                          // the next way to go on
-                sp--;
-                pc = st[3 * sp]; pos = st[3 * sp + 2];
-                const uint32_t k = st[3 * sp + 1];
-                if (k != RX_NOK) {                                                     // a REP1 gives a character back: k of them from the run's start
-                    const uint32_t* in = c.inst(pc);
-                    if (k > in[1]) { st[3 * sp] = pc; st[3 * sp + 1] = k - 1; st[3 * sp + 2] = pos; sp++; }
-                    for (uint32_t j = 0; j < k; j++) pos += c.char_len(pos);
-                    steps += k;
-                    pc += 2;
-                }
-                run = true;
+        a.nx[p] = (uint16_t)nxv;
+        bk.s_j[pl] = (uint16_t)rx_hop(pl, nxv);
+    };
+    for (;;) {
+        if (!have) {
+            pl = atomicAdd(bk.s_next, 1u);
+            if (pl >= (uint32_t)RXB) break;
+            p = bk.start + pl;
+            if (p >= bk.B) { bk.s_j[pl] = (uint16_t)(RXJ_EXIT | 0u); continue; }
+            const uint32_t wi = pl + RX_BACK;
+            if (!((cs[wi >> 5] >> (wi & 31)) & 1u)) {      // a byte inside a character: the walk never stands there, its hop is "one on"
+                a.nx[p] = (uint16_t)(1u | 0x8000u);
+                bk.s_j[pl] = (uint16_t)rx_hop(pl, 1u | 0x8000u);
                 continue;
             }
-            r = RX_FAIL;
+            p_is_start = ds_bit(wi) != 0u;
+            n = bk.B;                                      // the end of p's document: the next document start behind p (or the end of the corpus)
+            if (bk.any_ds) {
+                uint32_t i = wi + 1, w = i >> 5;
+                uint32_t bits = bk.s_ds[w] & (~0u << (i & 31));
+                while (!bits && ++w < (uint32_t)DSW) bits = bk.s_ds[w];
+                if (bits) { const uint32_t e = c.wb + w * 32 + (uint32_t)__ffs((int)bits) - 1u; n = e < n ? e : n; }
+            }
+            back = 0;                                      // bytes of the same document in front of p (up to RX_BACK)
+            if (!p_is_start) { back = 1; while (back < (uint32_t)RX_BACK && back < p && !ds_bit(wi - back)) back++; }
+            c.n = n;
+            trunc = n > p + (uint32_t)RX_REACH;
+            lim = p + (uint32_t)RX_REACH;
+            const uint32_t b0 = c.rd(p);                   // (p < n: the attempt begins with a byte)
+            pc = c.img[c.img[8] + (b0 < 0x80 ? b0 : 128u)];   // behind the alternatives this byte cannot start (regex_device_image)
+            pos = p; sp = 0; floor = 0; steps = 0;
+            run = true; have = true;
         }
-        // a run has ended with r: the top-level one, or the sub-run of the CALL entry below the floor
-        sp = floor;
-        if (floor == 0) return r;
-        sp--;
-        const uint32_t pcl = st[3 * sp];
-        floor = (int)st[3 * sp + 1];
-        const uint32_t psave = st[3 * sp + 2];
-        const uint32_t* in = c.inst(pcl);
-        if (in[0] == RXO_ATOMIC) {
-            if (r == RX_FAIL) continue;
-            pos = r; pc = in[1]; run = true;
-        } else if ((r != RX_FAIL) == (in[0] == RXO_LOOK)) {
-            pos = psave; pc = in[1]; run = true;
-        }
-    }
+        uint32_t fin = NOTYET, r = RX_FAIL;
+        bool ended = false;
+#define RX_PUSH(A, B) do { if (sp == RX_DEPTH) { atomicOr(a.status, RXS_DEPTH); fin = RX_ABORT; break; } stk[(2 * sp) * RXB] = (A); stk[(2 * sp + 1) * RXB] = (B); sp++; } while (0)
+        if (run) do {                                       // ONE instruction (break: done with it; run == false: this way has failed)
+            if (++steps > RX_STEPS) { atomicOr(a.status, RXS_STEPS); fin = RX_ABORT; break; }
+            if (trunc && pos + 8 > lim) { atomicOr(a.status, RXS_REACH); fin = RX_ABORT; break; }
+            const uint4 in = c.inst(pc);
+            const uint32_t op = in.x, x = in.y, y = in.z, f = in.w;
+            if (op == RXO_MATCH) { ended = true; r = pos; run = false; break; }
+            if (op == RXO_JMP) { pc = x; break; }
+            if (op == RXO_SPLIT) {
+                if (f != 0xFFFFFFFFu) {
+                    bool can = false;
+                    if (pos < n) {
+                        const uint32_t b = c.rd(pos);
+                        const uint32_t* fs = c.img + c.img[3] + RX_FIRST_WORDS * f;
+                        can = b < 0x80 ? ((fs[b >> 5] >> (b & 31)) & 1u) != 0 : fs[4] != 0u;
+                    }
+                    if (!can) { pc = y; break; }
+                }
+                RX_PUSH(y, pos - p);
+                if (fin != NOTYET) break;
+                pc = x;
+                break;
+            }
+            if (op == RXO_LOOK || op == RXO_NLOOK || op == RXO_ATOMIC) {          // the sub-program at pc + 1 as a run of its own
+                RX_PUSH(pc | ((uint32_t)floor << 16), pos - p);
+                if (fin != NOTYET) break;
+                floor = sp;
+                pc = pc + 1;
+                break;
+            }
+            if (op == RXO_ASSERT) {
+                bool ok;
+                if (x == RXA_BOL) ok = pos == p && p_is_start;
+                else if (x == RXA_EOT) ok = pos == n;
+                else if (x == RXA_EOL) ok = pos == n || (pos + 1 == n && c.rd(pos) == '\n');
+                else {
+                    const bool after = pos < n && c.is_word(pos);
+                    bool before = false;
+                    const uint32_t room = pos - p + back;                       // bytes of the document in front of pos (as far as it matters)
+                    if (room > 0) {
+                        uint32_t q = pos - 1, went = 1;
+                        while (went < room && went < 4 && (c.rd(q) & 0xC0u) == 0x80u) { q--; went++; }
+                        if (q + c.decode(q).len == pos) before = c.is_word(q);
+                    }
+                    ok = (before != after) == (x == RXA_WORDB);
+                }
+                if (ok) pc++; else run = false;
+                break;
+            }
+            if (op == RXO_REP1) {
+                const uint4 a1 = c.inst(pc + 1);
+                const uint32_t aop = a1.x, ax = a1.y;
+                uint32_t q = pos, k = 0;
+                bool far = false, more = true;
+                if (aop == RXO_CLASS && y > 8u && pos < n) {
+                    // a long run of a tabulated class: a bit scan over the window (every byte of a member character is a 1 bit)
+                    const uint32_t slot = c.set(ax)[9], i0 = pos - c.wb;
+                    if (slot != 0xFFFFFFFFu && i0 < (uint32_t)RX_TAB) {
+                        const uint32_t ni = n - c.wb;
+                        const uint32_t tl = ni < (uint32_t)RX_TAB ? ni : (uint32_t)RX_TAB;
+                        uint32_t e = c.first_zero(c.bm + slot * RX_BMW, i0, tl);
+                        const bool open_end = e == (uint32_t)RX_TAB && e < ni;          // the table ends here, perhaps inside a character:
+                        if (open_end && e > i0) e = c.last_set_below(cs, e);             // the loop below goes on from that character's start
+                        const uint32_t kk = c.count_set(cs, i0, e);
+                        if (kk <= y) { k = kk; q = pos + (e - i0); more = open_end; }
+                    }
+                }
+                while (more && k < y && q < n) {
+                    if (trunc && q + 8 > lim) { far = true; break; }
+                    const uint32_t b = c.rd(q);
+                    if (b < 0x80) {
+                        if (!c.one_ascii(aop, ax, b)) break;
+                        q++;
+                    } else {
+                        const RxCh ch = c.decode(q);
+                        if (!c.one(aop, ax, ch)) break;
+                        q += ch.len;
+                    }
+                    k++;
+                }
+                if (far) { atomicOr(a.status, RXS_REACH); fin = RX_ABORT; break; }
+                steps += k;
+                if (k < x) { run = false; break; }
+                if (k > x && f != 1u) {                      // (k - 1 characters next time: stored as (k - 1) + 1; the run's start and end)
+                    RX_PUSH(pc | (k << 16), (pos - p) | ((q - p) << 16));
+                    if (fin != NOTYET) break;
+                }
+                pos = q;
+                pc += 2;
+                break;
+            }
+            if (pos >= n) { run = false; break; }
+            {
+                const uint32_t b = c.rd(pos);
+                if (b < 0x80) {
+                    if (!c.one_ascii(op, x, b)) { run = false; break; }
+                    pos++;
+                } else {
+                    const RxCh ch = c.decode(pos);
+                    if (!c.one(op, x, ch)) { run = false; break; }
+                    pos += ch.len;
+                }
+            }
+            pc++;
+        } while (0);
 #undef RX_PUSH
+        if (fin == NOTYET && !run) {
+            if (!ended) {
+                if (sp > floor) {                                                          // the next way to go on
+                    sp--;
+                    const uint32_t w0 = stk[(2 * sp) * RXB], w1 = stk[(2 * sp + 1) * RXB];
+                    pos = p + (w1 & 0xFFFFu);
+                    pc = w0 & 0xFFFFu;
+                    if (w0 >> 16) {                                                        // a REP1 gives a character back: k of them from the run's start
+                        const uint32_t k = (w0 >> 16) - 1u;
+                        const uint32_t e_old = p + (w1 >> 16), ei = e_old - c.wb;
+                        uint32_t e_new;
+                        if (ei <= (uint32_t)RX_TAB) e_new = k ? c.wb + c.last_set_below(cs, ei) : pos;     // the start of the run's last character
+                        else { e_new = pos; for (uint32_t j = 0; j < k; j++) e_new += c.char_len(e_new); }
+                        if (k > c.inst(pc).y) { stk[(2 * sp) * RXB] = pc | (k << 16); stk[(2 * sp + 1) * RXB] = (pos - p) | ((e_new - p) << 16); sp++; }
+                        pos = e_new;
+                        steps += k;
+                        pc += 2;
+                    }
+                    run = true;
+                } else {
+                    ended = true; r = RX_FAIL;
+                }
+            }
+            if (ended) {
+                // a run has ended with r: the top-level one, or the sub-run of the CALL entry below the floor
+                sp = floor;
+                if (floor == 0) fin = r;
+                else {
+                    sp--;
+                    const uint32_t w0 = stk[(2 * sp) * RXB];
+                    const uint32_t psave = p + stk[(2 * sp + 1) * RXB];
+                    floor = (int)(w0 >> 16);
+                    const uint4 in = c.inst(w0 & 0xFFFFu);
+                    if (in.x == RXO_ATOMIC) {
+                        if (r != RX_FAIL) { pos = r; pc = in.y; run = true; }
+                    } else if ((r != RX_FAIL) == (in.x == RXO_LOOK)) {
+                        pos = psave; pc = in.y; run = true;
+                    }
+                }
+            }
+        }
+        if (fin != NOTYET) { finish(fin); have = false; run = false; }
+    }
 }
 
 // Pointer doubling over one block: j[q] (a local index, or RXJ_EXIT | last-hop-was-a-skip | offset behind the block) becomes
@@ -290,10 +411,13 @@ __device__ __forceinline__ uint32_t rx_hop(uint32_t q, uint32_t nxv) {       // 
 }
 
 __global__ __launch_bounds__(RXB) void k_rx_match(RxArgs a) {
-    __shared__ uint32_t s_img[RX_IMAGE_MAX_WORDS];
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_img[];         // the program image: image_words (dynamic: what the pattern needs)
+    __shared__ uint32_t s_stk[2 * RX_DEPTH * RXB];
     __shared__ __attribute__((aligned(4))) uint8_t s_txt[RX_LDS_TEXT + 4];
     __shared__ uint32_t s_ds[(RX_BACK + RXB + RX_REACH) / 32 + 2];            // document starts of [wbase, wbase + RX_BACK + RXB + RX_REACH)
     __shared__ uint16_t s_j[RXB];
+    __shared__ uint32_t s_bm[(RX_MAX_RUNSETS + 1) * RX_BMW];
+    __shared__ uint32_t s_next;
     const int tid = (int)threadIdx.x;
     const uint32_t B = a.n_bytes;
     const uint32_t start = blockIdx.x * (uint32_t)RXB;
@@ -301,6 +425,7 @@ __global__ __launch_bounds__(RXB) void k_rx_match(RxArgs a) {
     constexpr int DSW = (RX_BACK + RXB + RX_REACH) / 32 + 2;
     for (int i = tid; i < (int)a.image_words; i += RXB) s_img[i] = a.image[i];
     for (int i = tid; i < DSW; i += RXB) s_ds[i] = 0;
+    if (tid == 0) s_next = 0;
     for (int w = tid; w < (RX_LDS_TEXT + 3) / 4; w += RXB) {
         const int64_t g = wbase + 4 * (int64_t)w;
         uint32_t v = 0;
@@ -331,44 +456,56 @@ __global__ __launch_bounds__(RXB) void k_rx_match(RxArgs a) {
         if (!__syncthreads_or(tid == RXB - 1 && in)) break;
     }
     const bool any_ds = __syncthreads_or(tid < DSW && s_ds[tid] != 0u) != 0;      // (long documents: nothing to scan for below)
-    const uint32_t p = start + (uint32_t)tid;
-    uint32_t nxv = 1u | 0x8000u;
-    bool is_start = false;
-    if (p < B) {
-        const uint32_t wi = (uint32_t)tid + RX_BACK;
-        auto ds_bit = [&](uint32_t i) { return (s_ds[i >> 5] >> (i & 31)) & 1u; };
-        is_start = ds_bit(wi) != 0u;
-        // the end of p's document: the next document start behind p (or the end of the corpus)
-        uint32_t n = B;
-        if (any_ds) {
-            uint32_t i = wi + 1, w = i >> 5;
-            uint32_t bits = s_ds[w] & (~0u << (i & 31));
-            while (!bits && ++w < (uint32_t)DSW) bits = s_ds[w];
-            if (bits) { const uint32_t e = (uint32_t)(wbase + (int64_t)(w * 32 + (uint32_t)__ffs((int)bits) - 1)); n = e < n ? e : n; }
+    // ---- the window's characters, tabulated once for all 256 attempts: which bytes start a character (a continuation byte that
+    // a lead byte in front of it takes -- same document, as many as it announces -- does not; find_iter only ever stands on the
+    // others), and for every class set that a run instruction repeats, the bytes of its member characters
+    RxCtx c{s_img, s_txt, (uint32_t)wbase, &a, B, s_bm};
+    {
+        const uint32_t nrs = s_img[9];
+        const uint32_t* rs = s_img + s_img[10];
+        for (int r = 0; r * RXB < RX_BMW * 32; r++) {
+            const uint32_t i = (uint32_t)(r * RXB + tid);
+            const int64_t q = wbase + (int64_t)i;
+            const bool valid = i < (uint32_t)RX_TAB && q >= 0 && q < (int64_t)B;
+            uint32_t li = i;
+            if (valid && (s_txt[i] & 0xC0u) == 0x80u) {
+                for (uint32_t j = 1; j <= 3 && j <= i; j++) {
+                    if ((s_ds[(i - j + 1) >> 5] >> ((i - j + 1) & 31)) & 1u) break;       // a document starts between that byte and this one
+                    const uint32_t cb = s_txt[i - j];
+                    if ((cb & 0xC0u) == 0x80u) continue;
+                    if (cb >= 0xC0u && (cb < 0xE0u ? 2u : cb < 0xF0u ? 3u : 4u) > j) li = i - j;
+                    break;
+                }
+            }
+            RxCh ch{0, 1, 0};
+            if (valid) ch = c.decode_win(li, B, s_ds);
+            const unsigned long long mcs = __ballot(valid && li == i);
+            const uint32_t w0 = (uint32_t)(r * RXB + (tid & ~63)) >> 5;
+            const bool wr = (tid & 63) == 0 && w0 + 1 < (uint32_t)RX_BMW;
+            if (wr) { s_bm[RX_MAX_RUNSETS * RX_BMW + w0] = (uint32_t)mcs; s_bm[RX_MAX_RUNSETS * RX_BMW + w0 + 1] = (uint32_t)(mcs >> 32); }
+            for (uint32_t k = 0; k < nrs; k++) {
+                const unsigned long long m = __ballot(valid && c.in_set(rs[k], ch));
+                if (wr) { s_bm[k * RX_BMW + w0] = (uint32_t)m; s_bm[k * RX_BMW + w0 + 1] = (uint32_t)(m >> 32); }
+            }
         }
-        uint32_t back = 0;                                        // bytes of the same document in front of p (up to RX_BACK)
-        if (!is_start) { back = 1; while (back < (uint32_t)RX_BACK && back < p && !ds_bit(wi - back)) back++; }
-        RxCtx c{s_img, s_txt, wbase, &a, n};
-        uint32_t why = 0;
-        const uint32_t e = rx_run(c, p, is_start, back, why);
-        if (e == RX_ABORT) atomicOr(a.status, why);
-        if (e < RX_ABORT && e > p) {
-            uint32_t d = e - p;
-            if (d > (uint32_t)RX_REACH - 8u) { atomicOr(a.status, RXS_REACH); d = RX_REACH - 8; }
-            nxv = d;
-            // a hop over whole blocks: they may not be touched by the walk at all
-            for (uint32_t k = (p >> 8) + 1; (k + 1) * (uint32_t)RXB <= p + d; k++) atomicOr(&a.blk[k], RX_BLK_SKIPPED);
-        } else {
-            nxv = c.char_len(p) | 0x8000u;                        // no match here (or an empty one): the character is skipped
-        }
-        a.nx[p] = (uint16_t)nxv;
     }
+    __syncthreads();
+    const uint32_t p = start + (uint32_t)tid;
+    const bool is_start = p < B && ((s_ds[((uint32_t)tid + RX_BACK) >> 5] >> (((uint32_t)tid + RX_BACK) & 31)) & 1u) != 0u;
+#ifdef RX_NOVM
+    if (p < B) a.nx[p] = (uint16_t)(1u | 0x8000u);
+    s_j[tid] = (uint16_t)(p < B ? rx_hop((uint32_t)tid, 1u | 0x8000u) : (RXJ_EXIT | 0u));
+#else
+    {
+        RxBlock bk{start, B, s_ds, any_ds, &s_next, s_j};
+        rx_attempts(c, s_stk + tid, bk, a);
+    }
+#endif
     // the block's own words of the document-start bitmap
     {
         const unsigned long long m = __ballot(is_start);
         if ((tid & 63) == 0) { a.dstart[(start >> 5) + (tid >> 5)] = (uint32_t)m; a.dstart[(start >> 5) + (tid >> 5) + 1] = (uint32_t)(m >> 32); }
     }
-    s_j[tid] = (uint16_t)(p < B ? rx_hop((uint32_t)tid, nxv) : (RXJ_EXIT | 0u));
     __syncthreads();
     rx_double(s_j, nullptr, tid);
     const uint32_t g = s_j[tid];

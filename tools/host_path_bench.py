@@ -131,7 +131,7 @@ def measure_custom(docs=1000):
     np.cumsum([len(b) for b in bs], out=off[1:])
     blob = b"".join(bs)
     nb = len(blob)
-    out = {"config": "c2 batch, GPT-2 split pattern (host splitter)", "vocab": "cl100k_base", "docs": docs, "bytes": nb, "unit": "MB/s",
+    out = {"config": "c2 batch, GPT-2 split pattern (device splitter; host splitter beside it)", "vocab": "cl100k_base", "docs": docs, "bytes": nb, "unit": "MB/s",
            "host_threads": _os.cpu_count()}
     words = nb // 32 + 2
     st, gp = np.zeros(words, dtype=np.uint32), np.zeros(words, dtype=np.uint32)
@@ -152,6 +152,28 @@ def measure_custom(docs=1000):
         torch.cuda.synchronize()
     out["kernel_hbm_given_boundaries"] = round(nb / timed(k) / 1e6, 1)
     out["tokens"] = int(b.out_off[-1].item())
+    # round 4: the device splitter alone (spl_split_device) and in front of the tile kernel (spl_encode_batch_device)
+    d_st2, d_gp2 = torch.zeros(words + 2, dtype=torch.int32, device=dev), torch.zeros(words + 2, dtype=torch.int32, device=dev)
+    d_status = torch.zeros(4, dtype=torch.int32, device=dev)
+
+    def sd():
+        rc = L.spl_split_device(tok.handle, b.text.data_ptr(), b.n_bytes, b.doc_off.data_ptr(), b.n_docs, d_st2.data_ptr(), d_gp2.data_ptr(),
+                                d_status.data_ptr(), stream)
+        assert rc == 0, _ffi.last_error()
+        torch.cuda.synchronize()
+    out["split_device"] = round(nb / timed(sd) / 1e6, 1)
+    out["split_device_status"] = int(d_status[0].item())
+    out["split_device_equals_host"] = bool(np.array_equal(d_st2[:words].cpu().numpy().view(np.uint32), st) and
+                                           np.array_equal(d_gp2[:words].cpu().numpy().view(np.uint32), gp))
+
+    def kd():
+        rc = L.spl_encode_batch_device(tok.handle, b.text.data_ptr(), b.n_bytes, b.doc_off.data_ptr(), b.n_docs, 0,
+                                       b.ids.data_ptr(), b.ids.numel(), b.out_off.data_ptr(), stream)
+        assert rc == 0, _ffi.last_error()
+        torch.cuda.synchronize()
+    out["kernel_hbm_device_split"] = round(nb / timed(kd) / 1e6, 1)
+    assert L.spl_set_option(tok.handle, b"device_split", 0) == 0
+    out["c_abi_host_host_split"] = 0.0
 
     def c_abi(ptr):
         def f():
@@ -161,9 +183,12 @@ def measure_custom(docs=1000):
         return f
     p = L.spl_host_alloc(nb + 64)
     ctypes.memmove(p, blob, nb)
+    out["c_abi_host_host_split"] = round(nb / timed(c_abi(p)) / 1e6, 1)
+    assert L.spl_set_option(tok.handle, b"device_split", 1) == 0
     out["c_abi_host"] = round(nb / timed(c_abi(p)) / 1e6, 1)
     L.spl_host_free(p)
     out["python_surface"] = round(nb / timed(lambda: tok.encode_batch(texts), min_s=1.0) / 1e6, 1)
+    out["device_split_fallbacks"] = int(L.spl_device_split_fallbacks(tok.handle))
     return out
 
 
