@@ -706,7 +706,7 @@ int rx_launch(spl_tokenizer* tk, Ctx* c, const uint8_t* d_text, uint64_t n_bytes
     a.blk = (uint32_t*)(a.gx + nblk * RXB); a.dstart = a.blk + nblk;
     a.starts = d_starts; a.gaps = d_gaps; a.status = d_status;
     HIP_TRY(hipMemsetAsync(a.blk, 0, nblk * 4, s));
-    hipLaunchKernelGGL(k_rx_match, dim3((uint32_t)nblk), dim3(RXB), (a.image_words * 4 + 15) & ~15u, s, a);
+    hipLaunchKernelGGL(k_rx_match, dim3((uint32_t)nblk), dim3(RXT), (a.image_words * 4 + 15) & ~15u, s, a);
     hipLaunchKernelGGL(k_rx_mark, dim3((uint32_t)nblk), dim3(RXB), 0, s, a);
     HIP_TRY(hipGetLastError());
     return SPL_OK;

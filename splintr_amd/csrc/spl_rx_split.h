@@ -31,13 +31,16 @@
 
 namespace spl {
 
-constexpr int RXB = 256;                       // positions per block = threads per workgroup
+constexpr int RXB = 256;                       // positions per block (and threads of k_rx_mark)
+constexpr int RXT = 256;                       // threads of k_rx_match; they work the block's positions off a counter.  (Fewer threads, more
+                                               // attempts per lane: 64 -> 230 us, 128 -> 174 us, 256 -> 169 us for GPT-2's pattern on the C2 batch --
+                                               // an attempt is a chain of dependent LDS reads, and it is the number of chains in flight that pays)
 constexpr int RX_REACH = 1032;                 // bytes behind its start a match attempt may look at (a hop is at most RX_REACH - 8)
 constexpr int RX_BACK = 4;                     // staged bytes in front of the block (\b looks at the character before)
 constexpr int RX_LDS_TEXT = RX_BACK + RXB + 276;   // staged text; beyond it the matcher reads global memory
 constexpr int RX_TAB = RX_LDS_TEXT - 4;         // window positions whose characters are tabulated (a character reads up to 3 bytes on)
 constexpr int RX_BMW = (RX_TAB + 63) / 64 * 2;  // words of one window bitmap
-constexpr int RX_DEPTH = 10;                     // entries of a lane's backtracking stack (LDS: two words each, RXB lanes)
+constexpr int RX_DEPTH = 10;                     // entries of a lane's backtracking stack (LDS: two words each, RXT lanes)
 constexpr uint32_t RX_STEPS = 8192;
 constexpr uint32_t RX_FAIL = 0xFFFFFFFFu, RX_ABORT = 0xFFFFFFFEu, RX_NOK = 0xFFFFFFFFu;
 enum : uint32_t { RXS_REACH = 1, RXS_STEPS = 2, RXS_DEPTH = 4 };
@@ -174,7 +177,7 @@ struct RxCtx {
 // way on from its stack, or finishes.  Attempts differ in length by a factor of twenty (a letter inside a word: four steps;
 // a blank in front of a digit: every alternative); one position per lane for the whole kernel left a tenth of the lanes
 // working (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU, profiles/r04_device_split.txt).
-// Stack entry e of a lane: stk[(2 e) * RXB], stk[(2 e + 1) * RXB] (stk points at the lane's column: no bank conflicts) --
+// Stack entry e of a lane: stk[(2 e) * RXT], stk[(2 e + 1) * RXT] (stk points at the lane's column: no bank conflicts) --
 // word 0: pc | (k + 1) << 16 for "REP1 at pc, retry with k characters" (0 in the upper half: go on at pc), or pc | floor << 16
 // for a CALL entry; word 1: text positions relative to the attempt's start (REP1: the run's start | its end << 16).
 struct RxBlock {
@@ -241,7 +244,7 @@ __device__ __forceinline__ void rx_attempts(RxCtx& c, uint32_t* stk, const RxBlo
         }
         uint32_t fin = NOTYET, r = RX_FAIL;
         bool ended = false;
-#define RX_PUSH(A, B) do { if (sp == RX_DEPTH) { atomicOr(a.status, RXS_DEPTH); fin = RX_ABORT; break; } stk[(2 * sp) * RXB] = (A); stk[(2 * sp + 1) * RXB] = (B); sp++; } while (0)
+#define RX_PUSH(A, B) do { if (sp == RX_DEPTH) { atomicOr(a.status, RXS_DEPTH); fin = RX_ABORT; break; } stk[(2 * sp) * RXT] = (A); stk[(2 * sp + 1) * RXT] = (B); sp++; } while (0)
         if (run) do {                                       // ONE instruction (break: done with it; run == false: this way has failed)
             if (++steps > RX_STEPS) { atomicOr(a.status, RXS_STEPS); fin = RX_ABORT; break; }
             if (trunc && pos + 8 > lim) { atomicOr(a.status, RXS_REACH); fin = RX_ABORT; break; }
@@ -351,7 +354,7 @@ __device__ __forceinline__ void rx_attempts(RxCtx& c, uint32_t* stk, const RxBlo
             if (!ended) {
                 if (sp > floor) {                                                          // the next way to go on
                     sp--;
-                    const uint32_t w0 = stk[(2 * sp) * RXB], w1 = stk[(2 * sp + 1) * RXB];
+                    const uint32_t w0 = stk[(2 * sp) * RXT], w1 = stk[(2 * sp + 1) * RXT];
                     pos = p + (w1 & 0xFFFFu);
                     pc = w0 & 0xFFFFu;
                     if (w0 >> 16) {                                                        // a REP1 gives a character back: k of them from the run's start
@@ -360,7 +363,7 @@ __device__ __forceinline__ void rx_attempts(RxCtx& c, uint32_t* stk, const RxBlo
                         uint32_t e_new;
                         if (ei <= (uint32_t)RX_TAB) e_new = k ? c.wb + c.last_set_below(cs, ei) : pos;     // the start of the run's last character
                         else { e_new = pos; for (uint32_t j = 0; j < k; j++) e_new += c.char_len(e_new); }
-                        if (k > c.inst(pc).y) { stk[(2 * sp) * RXB] = pc | (k << 16); stk[(2 * sp + 1) * RXB] = (pos - p) | ((e_new - p) << 16); sp++; }
+                        if (k > c.inst(pc).y) { stk[(2 * sp) * RXT] = pc | (k << 16); stk[(2 * sp + 1) * RXT] = (pos - p) | ((e_new - p) << 16); sp++; }
                         pos = e_new;
                         steps += k;
                         pc += 2;
@@ -376,8 +379,8 @@ __device__ __forceinline__ void rx_attempts(RxCtx& c, uint32_t* stk, const RxBlo
                 if (floor == 0) fin = r;
                 else {
                     sp--;
-                    const uint32_t w0 = stk[(2 * sp) * RXB];
-                    const uint32_t psave = p + stk[(2 * sp + 1) * RXB];
+                    const uint32_t w0 = stk[(2 * sp) * RXT];
+                    const uint32_t psave = p + stk[(2 * sp + 1) * RXT];
                     floor = (int)(w0 >> 16);
                     const uint4 in = c.inst(w0 & 0xFFFFu);
                     if (in.x == RXO_ATOMIC) {
@@ -388,19 +391,27 @@ __device__ __forceinline__ void rx_attempts(RxCtx& c, uint32_t* stk, const RxBlo
                 }
             }
         }
+#ifdef RX_COUNT
+        if (fin != NOTYET) { atomicAdd(&a.status[1], steps); atomicAdd(&a.status[2], 1u); }
+        atomicAdd(&a.status[3], 1u);
+#endif
         if (fin != NOTYET) { finish(fin); have = false; run = false; }
     }
 }
 
 // Pointer doubling over one block: j[q] (a local index, or RXJ_EXIT | last-hop-was-a-skip | offset behind the block) becomes
 // the place where the walk from q leaves the block.  With `lev`, level k's pointers (before round k) are kept at lev[k * RXB + q].
-__device__ __forceinline__ void rx_double(uint16_t* j, uint16_t* lev, int q) {
+template <int NTH> __device__ __forceinline__ void rx_double(uint16_t* j, uint16_t* lev, int tid) {
     for (int k = 0; k < 8; k++) {
-        const uint32_t v = j[q];
-        if (lev) lev[k * RXB + q] = (uint16_t)v;
-        const uint32_t v2 = (v & RXJ_EXIT) ? v : (uint32_t)j[v];
+        uint32_t v2[RXB / NTH];
+        for (int e = 0; e < RXB / NTH; e++) {
+            const int q = tid + e * NTH;
+            const uint32_t v = j[q];
+            if (lev) lev[k * RXB + q] = (uint16_t)v;
+            v2[e] = (v & RXJ_EXIT) ? v : (uint32_t)j[v];
+        }
         __syncthreads();
-        j[q] = (uint16_t)v2;
+        for (int e = 0; e < RXB / NTH; e++) j[tid + e * NTH] = (uint16_t)v2[e];
         __syncthreads();
     }
 }
@@ -410,9 +421,9 @@ __device__ __forceinline__ uint32_t rx_hop(uint32_t q, uint32_t nxv) {       // 
     return to < (uint32_t)RXB ? to : (RXJ_EXIT | ((nxv & 0x8000u) ? RXJ_GAP : 0u) | (to - (uint32_t)RXB));
 }
 
-__global__ __launch_bounds__(RXB) void k_rx_match(RxArgs a) {
+__global__ __launch_bounds__(RXT) void k_rx_match(RxArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_img[];         // the program image: image_words (dynamic: what the pattern needs)
-    __shared__ uint32_t s_stk[2 * RX_DEPTH * RXB];
+    __shared__ uint32_t s_stk[2 * RX_DEPTH * RXT];
     __shared__ __attribute__((aligned(4))) uint8_t s_txt[RX_LDS_TEXT + 4];
     __shared__ uint32_t s_ds[(RX_BACK + RXB + RX_REACH) / 32 + 2];            // document starts of [wbase, wbase + RX_BACK + RXB + RX_REACH)
     __shared__ uint16_t s_j[RXB];
@@ -423,21 +434,21 @@ __global__ __launch_bounds__(RXB) void k_rx_match(RxArgs a) {
     const uint32_t start = blockIdx.x * (uint32_t)RXB;
     const int64_t wbase = (int64_t)start - RX_BACK;
     constexpr int DSW = (RX_BACK + RXB + RX_REACH) / 32 + 2;
-    for (int i = tid; i < (int)a.image_words; i += RXB) s_img[i] = a.image[i];
-    for (int i = tid; i < DSW; i += RXB) s_ds[i] = 0;
+    for (int i = tid; i < (int)a.image_words; i += RXT) s_img[i] = a.image[i];
+    for (int i = tid; i < DSW; i += RXT) s_ds[i] = 0;
     if (tid == 0) s_next = 0;
-    for (int w = tid; w < (RX_LDS_TEXT + 3) / 4; w += RXB) {
+    for (int w = tid; w < (RX_LDS_TEXT + 3) / 4; w += RXT) {
         const int64_t g = wbase + 4 * (int64_t)w;
         uint32_t v = 0;
         if (g >= 0 && g + 4 <= (int64_t)B) v = *reinterpret_cast<const uint32_t*>(a.text + g);      // (the text buffer is 16-byte aligned, start a multiple of 256)
         else for (int k = 0; k < 4; k++) if (g + k >= 0 && g + k < (int64_t)B) v |= (uint32_t)a.text[g + k] << (8 * k);
         reinterpret_cast<uint32_t*>(s_txt)[w] = v;
     }
-    // documents that start inside the window: RXB-ary search for the first one at or behind its begin, then their bits
+    // documents that start inside the window: RXT-ary search for the first one at or behind its begin, then their bits
     const uint64_t wlo = wbase > 0 ? (uint64_t)wbase : 0ull, whi = (uint64_t)(wbase + RX_BACK + RXB + RX_REACH);
     uint32_t lo = 0, hi = a.n_docs;
     while (wlo != 0 && lo < hi) {
-        const uint32_t span = hi - lo, stp = (span + RXB - 1) / RXB;
+        const uint32_t span = hi - lo, stp = (span + RXT - 1) / RXT;
         const uint64_t idx = (uint64_t)lo + (uint64_t)tid * stp;
         const bool below = idx < hi && a.doc_off[idx] < wlo;
         const uint32_t cnt = (uint32_t)__syncthreads_count(below);
@@ -447,15 +458,17 @@ __global__ __launch_bounds__(RXB) void k_rx_match(RxArgs a) {
         hi = nhi < hi ? (uint32_t)nhi : hi;
     }
     __syncthreads();
-    for (uint32_t base = lo;; base += RXB) {
+    for (uint32_t base = lo;; base += RXT) {
         const uint64_t d = (uint64_t)base + tid;
         uint64_t dp = ~0ull;
         if (d < a.n_docs) dp = a.doc_off[d];
         const bool in = dp < whi && dp < (uint64_t)B;
         if (in) { const uint32_t i = (uint32_t)((int64_t)dp - wbase); atomicOr(&s_ds[i >> 5], 1u << (i & 31)); }
-        if (!__syncthreads_or(tid == RXB - 1 && in)) break;
+        if (!__syncthreads_or(tid == RXT - 1 && in)) break;
     }
-    const bool any_ds = __syncthreads_or(tid < DSW && s_ds[tid] != 0u) != 0;      // (long documents: nothing to scan for below)
+    bool any_here = false;
+    for (int i = tid; i < DSW; i += RXT) any_here = any_here || s_ds[i] != 0u;
+    const bool any_ds = __syncthreads_or(any_here) != 0;      // (long documents: nothing to scan for below)
     // ---- the window's characters, tabulated once for all 256 attempts: which bytes start a character (a continuation byte that
     // a lead byte in front of it takes -- same document, as many as it announces -- does not; find_iter only ever stands on the
     // others), and for every class set that a run instruction repeats, the bytes of its member characters
@@ -463,8 +476,8 @@ __global__ __launch_bounds__(RXB) void k_rx_match(RxArgs a) {
     {
         const uint32_t nrs = s_img[9];
         const uint32_t* rs = s_img + s_img[10];
-        for (int r = 0; r * RXB < RX_BMW * 32; r++) {
-            const uint32_t i = (uint32_t)(r * RXB + tid);
+        for (int r = 0; r * RXT < RX_BMW * 32; r++) {
+            const uint32_t i = (uint32_t)(r * RXT + tid);
             const int64_t q = wbase + (int64_t)i;
             const bool valid = i < (uint32_t)RX_TAB && q >= 0 && q < (int64_t)B;
             uint32_t li = i;
@@ -480,7 +493,7 @@ __global__ __launch_bounds__(RXB) void k_rx_match(RxArgs a) {
             RxCh ch{0, 1, 0};
             if (valid) ch = c.decode_win(li, B, s_ds);
             const unsigned long long mcs = __ballot(valid && li == i);
-            const uint32_t w0 = (uint32_t)(r * RXB + (tid & ~63)) >> 5;
+            const uint32_t w0 = (uint32_t)(r * RXT + (tid & ~63)) >> 5;
             const bool wr = (tid & 63) == 0 && w0 + 1 < (uint32_t)RX_BMW;
             if (wr) { s_bm[RX_MAX_RUNSETS * RX_BMW + w0] = (uint32_t)mcs; s_bm[RX_MAX_RUNSETS * RX_BMW + w0 + 1] = (uint32_t)(mcs >> 32); }
             for (uint32_t k = 0; k < nrs; k++) {
@@ -490,11 +503,12 @@ __global__ __launch_bounds__(RXB) void k_rx_match(RxArgs a) {
         }
     }
     __syncthreads();
-    const uint32_t p = start + (uint32_t)tid;
-    const bool is_start = p < B && ((s_ds[((uint32_t)tid + RX_BACK) >> 5] >> (((uint32_t)tid + RX_BACK) & 31)) & 1u) != 0u;
 #ifdef RX_NOVM
-    if (p < B) a.nx[p] = (uint16_t)(1u | 0x8000u);
-    s_j[tid] = (uint16_t)(p < B ? rx_hop((uint32_t)tid, 1u | 0x8000u) : (RXJ_EXIT | 0u));
+    for (int e = 0; e < RXB / RXT; e++) {
+        const uint32_t q = (uint32_t)(tid + e * RXT), p = start + q;
+        if (p < B) a.nx[p] = (uint16_t)(1u | 0x8000u);
+        s_j[q] = (uint16_t)(p < B ? rx_hop(q, 1u | 0x8000u) : (RXJ_EXIT | 0u));
+    }
 #else
     {
         RxBlock bk{start, B, s_ds, any_ds, &s_next, s_j};
@@ -502,16 +516,22 @@ __global__ __launch_bounds__(RXB) void k_rx_match(RxArgs a) {
     }
 #endif
     // the block's own words of the document-start bitmap
-    {
+    for (int e = 0; e < RXB / RXT; e++) {
+        const uint32_t q = (uint32_t)(tid + e * RXT), wi = q + RX_BACK;
+        const bool is_start = start + q < B && ((s_ds[wi >> 5] >> (wi & 31)) & 1u) != 0u;
         const unsigned long long m = __ballot(is_start);
-        if ((tid & 63) == 0) { a.dstart[(start >> 5) + (tid >> 5)] = (uint32_t)m; a.dstart[(start >> 5) + (tid >> 5) + 1] = (uint32_t)(m >> 32); }
+        if ((tid & 63) == 0) { a.dstart[(start >> 5) + (q >> 5)] = (uint32_t)m; a.dstart[(start >> 5) + (q >> 5) + 1] = (uint32_t)(m >> 32); }
     }
     __syncthreads();
-    rx_double(s_j, nullptr, tid);
-    const uint32_t g = s_j[tid];
-    if (p < B) a.gx[p] = (uint16_t)(((g & RXJ_GAP) ? 0x8000u : 0u) | (g & RXJ_VAL));
+    rx_double<RXT>(s_j, nullptr, tid);
     const uint32_t g0 = s_j[0];
-    const bool same = p >= B || g == g0;
+    bool same = true;
+    for (int e = 0; e < RXB / RXT; e++) {
+        const uint32_t q = (uint32_t)(tid + e * RXT), p = start + q;
+        const uint32_t g = s_j[q];
+        if (p < B) a.gx[p] = (uint16_t)(((g & RXJ_GAP) ? 0x8000u : 0u) | (g & RXJ_VAL));
+        same = same && (p >= B || g == g0);
+    }
     if (__syncthreads_and(same) && tid == 0)
         atomicOr(&a.blk[blockIdx.x], RX_BLK_CLOSED | ((g0 & RXJ_GAP) ? 0x8000u : 0u) | (g0 & RXJ_VAL));
 }
@@ -551,7 +571,7 @@ __global__ __launch_bounds__(RXB) void k_rx_mark(RxArgs a) {
     s_m[tid] = 0;
     if (tid < RXB / 32 + 1) s_gb[tid] = 0;
     __syncthreads();
-    rx_double(s_j, s_lev, tid);
+    rx_double<RXB>(s_j, s_lev, tid);
     const uint32_t E = s_e[0], pg_in = s_e[1];
     if (E >= start + (uint32_t)RXB || E >= B) return;              // the walk does not touch this block (uniform)
     if ((uint32_t)tid == E - start) s_m[tid] = 1;

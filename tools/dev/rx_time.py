@@ -21,6 +21,8 @@ for pname, pat in (("gpt2", GPT2_PATTERN), ("tk_cl100k", TIKTOKEN_CL100K), ("tk_
         def f():
             assert L.spl_split_device(tok.handle, b.text.data_ptr(), b.n_bytes, b.doc_off.data_ptr(), b.n_docs, d_st.data_ptr(), d_gp.data_ptr(), d_status.data_ptr(), s) == 0
         for _ in range(3): f()
+        d_status.zero_(); f()
+        torch.cuda.synchronize(); cnt = d_status.cpu().tolist()
         torch.cuda.synchronize()
         best = 1e9
         for _ in range(5):
@@ -29,5 +31,5 @@ for pname, pat in (("gpt2", GPT2_PATTERN), ("tk_cl100k", TIKTOKEN_CL100K), ("tk_
             for _ in range(10): f()
             e1.record(); torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) * 100)
-        out.append(f"{pname}/{cname} {b.n_bytes/1e6:.2f}MB {best:.0f}us {b.n_bytes/best/1e3:.2f}GB/s st={int(d_status[0].item())}")
+        out.append(f"{pname}/{cname} {b.n_bytes/1e6:.2f}MB {best:.0f}us {b.n_bytes/best/1e3:.2f}GB/s st={cnt}")
 print(f"[{label}] " + " | ".join(out))
