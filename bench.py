@@ -402,8 +402,10 @@ def main():
                                "bytes CSR on the host (pinned in and out), MB/s of decoded bytes; c2_wide: C2's mix over a >= 20 000-word "
                                "lexicon (splintr_amd.corpus.c2_wide); encode_one_call_us: Tokenizer.encode(text) on the batch's first document -- one GPU "
                                "round trip per call, a latency figure; c2_custom_pattern: the C2 batch through a handle with GPT-2's split pattern, which the "
-                               "GPU scanner does not implement -- split_host: the host splitter alone, kernel_hbm_given_boundaries: the tile kernel on given "
-                               "chunk boundaries (spl_encode_chunks_device), c_abi_host / python_surface: the calls a user makes")
+                               "GPU scanner does not implement -- split_host: the host splitter alone, split_device: the device splitter alone (k_rx_match + "
+                               "k_rx_mark, text in HBM), kernel_hbm_given_boundaries: the tile kernel on given chunk boundaries "
+                               "(spl_encode_chunks_device), kernel_hbm_device_split: spl_encode_batch_device (device splitter + tile kernel), c_abi_host / "
+                               "python_surface: the calls a user makes (device splitter), c_abi_host_host_split: the same with the split kept on the host cores")
 
     # ---- BASELINE config 4: llama3, 1 M short prompts, doc-sharded over the ranks (strong scaling) -------
     c4 = c5 = None
