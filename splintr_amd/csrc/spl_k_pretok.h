@@ -1079,23 +1079,24 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
         const uint64_t own_lo = (uint64_t)t0, own_hi = (uint64_t)(t0 + TB_);
         const uint64_t d_first = (uint64_t)dw + (uint32_t)tid_late;
         uint64_t p_first = ~0ull;
-        if (d_first <= e_n_docs) p_first = e_doc_off[d_first];      // entry n_docs is the end of the corpus
+        if (tid_late < 64 && d_first <= e_n_docs) p_first = e_doc_off[d_first];      // entry n_docs is the end of the corpus
         // ---- token count of the tile: window bitmap + overflow range --------------------------------
+        // (the bitmap is 34 words: ONE wavefront counts, ranks and lists them -- no sums across wavefronts, one barrier)
+        static_assert(G::NBW + 2 <= 64, "the window's bitmap words must fit one wavefront");
         uint32_t c_win;
         {
-            uint32_t word = tid_late < G::NBW + 1 ? s_tbits[tid_late] : 0u;
-            const uint32_t cnt = __popc(word);
-            uint32_t x = wave_scan_incl(cnt);
-            if (lane == 63) s_wsum[wv] = x;
-            __syncthreads();
-            uint32_t basew = x - cnt;
-            for (int k = 0; k < wv; k++) basew += s_wsum[k];
-            if (tid_late == NT - 1) s_total = basew + cnt;
-            if (tid_late < G::NBW + 2) s_wpre[tid_late] = basew;
-            while (word) {                                  // token positions in order
-                const int bit = __ffs(word) - 1;
-                word &= word - 1;
-                s_cpos[basew++] = (uint16_t)(tid_late * 32 + bit);
+            if (tid_late < 64) {
+                uint32_t word = tid_late < G::NBW + 1 ? s_tbits[tid_late] : 0u;
+                const uint32_t cnt = __popc(word);
+                const uint32_t x = wave_scan_incl(cnt);
+                uint32_t basew = x - cnt;
+                if (tid_late == 63) s_total = x;
+                if (tid_late < G::NBW + 2) s_wpre[tid_late] = basew;
+                while (word) {                                  // token positions in order
+                    const int bit = __ffs(word) - 1;
+                    word &= word - 1;
+                    s_cpos[basew++] = (uint16_t)(tid_late * 32 + bit);
+                }
             }
             __syncthreads();
             c_win = s_total;
@@ -1132,39 +1133,35 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
 #endif
         const uint32_t slot = tile_ix * b.tslot;                // fixed slots: nothing to wait for
         for (uint32_t k = tid_late; k < c_win; k += NT) b.tile_ids[slot + k] = s_ids[s_cpos[k]];
-        uint32_t d_lo = 0xFFFFFFFFu, d_n = 0;
-        for (uint32_t db = dw;; db += NT) {
-            const uint64_t d = (uint64_t)db + tid_late;
-            uint64_t p = p_first;
-            if (db != dw) { p = ~0ull; if (d <= e_n_docs) p = e_doc_off[d]; }
-            const bool in = d <= e_n_docs && (p < own_hi || last_tile);
-            const bool own = in && p >= own_lo;
-            if (own && !queue_mode) {
-                const uint32_t i = (uint32_t)(p - (uint64_t)w0);
-                b.off_out[d] = (uint64_t)(s_wpre[i >> 5] + __popc(s_tbits[i >> 5] & ((1u << (i & 31)) - 1u)))
-                               + ((last_tile && p >= (uint64_t)B) ? c_ovf : 0u);
-            }
-            // owned documents are consecutive: first index and count by ballots (s_wsum as mailboxes)
-            const unsigned long long mo = __ballot(own);
-            if (lane == 0) { s_red[wv] = mo; }
-            __syncthreads();
-            for (int k = 0; k < NT / 64; k++) {
-                const unsigned long long mk = s_red[k];
-                if (mk) {
-                    if (d_lo == 0xFFFFFFFFu) d_lo = db + 64u * k + (uint32_t)(__ffsll((long long)mk) - 1);
-                    d_n += (uint32_t)__popcll(mk);
+        // the documents that start in the tile's own range: their output offsets, first index and count -- by wavefront 0 alone,
+        // 64 documents per round (a tile of ordinary text holds a handful; no barrier, the other wavefronts are done)
+        if (tid_late < 64) {
+            uint32_t d_lo = 0xFFFFFFFFu, d_n = 0;
+            for (uint32_t db = dw;; db += 64u) {
+                const uint64_t d = (uint64_t)db + tid_late;
+                uint64_t p = p_first;
+                if (db != dw) { p = ~0ull; if (d <= e_n_docs) p = e_doc_off[d]; }
+                const bool in = d <= e_n_docs && (p < own_hi || last_tile);
+                const bool own = in && p >= own_lo;
+                if (own && !queue_mode) {
+                    const uint32_t i = (uint32_t)(p - (uint64_t)w0);
+                    b.off_out[d] = (uint64_t)(s_wpre[i >> 5] + __popc(s_tbits[i >> 5] & ((1u << (i & 31)) - 1u)))
+                                   + ((last_tile && p >= (uint64_t)B) ? c_ovf : 0u);
                 }
+                const unsigned long long mo = __ballot(own);    // owned documents are consecutive
+                if (mo) {
+                    if (d_lo == 0xFFFFFFFFu) d_lo = db + (uint32_t)(__ffsll((long long)mo) - 1);
+                    d_n += (uint32_t)__popcll(mo);
+                }
+                if (!((__ballot(in) >> 63) & 1ull)) break;      // more documents beyond these 64?
             }
-            if (tid_late == NT - 1) s_dq[10] = in ? 1u : 0u;     // more documents beyond this batch of NT?
-            __syncthreads();
-            if (!s_dq[10]) break;
-        }
-        if (tid_late == 0) {
-            TileDesc td;
-            td.slot = slot; td.c_win = c_win; td.c_ovf = c_ovf; td.ovf_hi = whi > wlo ? ovf_hi : 0u;
-            td.d_first = d_lo == 0xFFFFFFFFu ? 0u : d_lo; td.d_cnt = d_n; td.ovf_lo = ovf_lo;
-            td.c_own = s_wpre[DIRECT ? (LH + TB_) >> 5 : 0];             // tile range ends on a word boundary
-            b.tdesc[tile_ix] = td;
+            if (tid_late == 0) {
+                TileDesc td;
+                td.slot = slot; td.c_win = c_win; td.c_ovf = c_ovf; td.ovf_hi = whi > wlo ? ovf_hi : 0u;
+                td.d_first = d_lo == 0xFFFFFFFFu ? 0u : d_lo; td.d_cnt = d_n; td.ovf_lo = ovf_lo;
+                td.c_own = s_wpre[DIRECT ? (LH + TB_) >> 5 : 0];             // tile range ends on a word boundary
+                b.tdesc[tile_ix] = td;
+            }
         }
     }
     SPL_STAMP(8);
