@@ -178,7 +178,20 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
     // document that starts at or after the window (two rounds up to 65 536 documents), then the
     // documents of the window set their bits.
     uint32_t dw = 0;                                   // first document with doc_off >= max(w0, 0)
+    const uint64_t lim = (uint64_t)(w0 + (int64_t)(G::NBW + 1) * 32);
+    auto more_documents = [&](uint32_t base) {         // documents base, base + 1, ... set their bits while they start inside the window
+        for (;; base += NT) {
+            const uint64_t d = (uint64_t)base + tid;
+            uint64_t p = ~0ull;
+            if (d < e_n_docs) p = e_doc_off[d];
+            const bool in = p < lim && p < (uint64_t)B;
+            if (in) { const uint32_t i = (uint32_t)(p - (uint64_t)w0); atomicOr(&s_ts[i >> 5], 1u << (i & 31)); }
+            if (!__syncthreads_or(tid == NT - 1 && in)) break;
+        }
+    };
+    uint32_t held_more = 0xFFFFFFFFu;                  // where the window's documents may go on behind the first round's loads
     if (DIRECT) {
+        bool searched = false;                         // a barrier of the search has passed (uniform)
         uint32_t lo = 0, hi = e_n_docs;
         const uint64_t target = w0 > 0 ? (uint64_t)w0 : 0ull;
         uint64_t p_held = ~0ull;                        // doc_off[d_held] from the first round, if it settled the search
@@ -196,6 +209,7 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
             const uint64_t p1 = idx < ghi ? e_doc_off[idx] : ~0ull;
             const bool below = idx < ghi && p1 < target;
             const uint32_t c = (uint32_t)__syncthreads_count(below);
+            searched = true;
             if (c == 0) hi = glo;                           // entry glo (if any) is not below the target
             else if (c == ghi - glo) lo = ghi;              // every probed entry is
             else { lo = hi = glo + c; p_held = p1; d_held = idx; d_held_end = ghi; }   // found: the entries behind it are already here
@@ -205,32 +219,32 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
             const uint64_t idx = (uint64_t)lo + (uint64_t)tid * st;
             const bool below = idx < hi && e_doc_off[idx] < target;
             const uint32_t c = (uint32_t)__syncthreads_count(below);
+            searched = true;
             if (c == 0) { hi = lo; break; }
             const uint64_t nhi = (uint64_t)lo + (uint64_t)c * st;
             lo = lo + (c - 1) * st + 1;                // element lo + (c-1)*st is below the target
             hi = nhi < hi ? (uint32_t)nhi : hi;        // element lo + c*st (if any) is not
         }
         dw = lo;
-        __syncthreads();                               // s_ts zeroed by all before any bit is set
-        const uint64_t lim = (uint64_t)(w0 + (int64_t)(G::NBW + 1) * 32);
-        uint32_t base = dw;
+        // (s_ts was zeroed before the search: any barrier of the search orders that in front of the bits set below)
+        if (!searched) __syncthreads();
         if (d_held_end > dw) {                         // the window's documents from the first round's loads
             const bool in = d_held >= dw && d_held < d_held_end && p_held < lim && p_held < (uint64_t)B;
             if (in) { const uint32_t i = (uint32_t)(p_held - (uint64_t)w0); atomicOr(&s_ts[i >> 5], 1u << (i & 31)); }
-            // more only if the last entry fetched is still inside the window
-            base = __syncthreads_or(d_held == d_held_end - 1u && in) ? d_held_end : 0xFFFFFFFFu;
-        }
-        for (; base != 0xFFFFFFFFu; base += NT) {
-            const uint64_t d = (uint64_t)base + tid;
-            uint64_t p = ~0ull;
-            if (d < e_n_docs) p = e_doc_off[d];
-            const bool in = p < lim && p < (uint64_t)B;
-            if (in) { const uint32_t i = (uint32_t)(p - (uint64_t)w0); atomicOr(&s_ts[i >> 5], 1u << (i & 31)); }
-            if (!__syncthreads_or(tid == NT - 1 && in)) break;
+            // more only if the last entry fetched is still inside the window: a flag that the phase's barrier publishes (a
+            // barrier of its own here, and one in front of the bits, cost every tile 0.3 us for what a tile in a thousand needs)
+            if (d_held == d_held_end - 1u && in) s_dq[10] = 1u;
+            held_more = d_held_end;
+        } else {
+            more_documents(dw);
         }
     }
     SPL_STAMP(0);
     __syncthreads();
+    if (held_more != 0xFFFFFFFFu && s_dq[10]) {        // (workgroup-uniform)
+        more_documents(held_more);
+        __syncthreads();
+    }
     SPL_STAMP(1);
 
     const int iB = (B - w0 < (int64_t)Wv) ? (int)(B - w0) : Wv;   // first index past the text

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests/test_gpu_parity.py tests/test_gpu_stress.py tests/test_gpu_hostpath.py tests/test_gpu_decode.py -x -q 2>&1 | tail -3
+timeout 2400 python -m pytest tests/test_gpu_parity.py tests/test_gpu_stress.py -x -q 2>&1 | tail -3
