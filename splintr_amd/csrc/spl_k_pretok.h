@@ -495,17 +495,18 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
                 if (hi < 32) word &= (1u << hi) - 1u;
             }
         }
-        const uint32_t cnt = __popc(word);
-        uint32_t x = wave_scan_incl(cnt);
-        if ((tid & 63) == 63) s_wsum[tid >> 6] = x;
-        __syncthreads();
-        uint32_t base = x - cnt;
-        for (int wv = 0; wv < (tid >> 6); wv++) base += s_wsum[wv];
-        if (tid == NT - 1) s_total = base + cnt;
-        while (word) {
-            const int bit = __ffs(word) - 1;
-            word &= word - 1;
-            s_cpos[base++] = (uint16_t)(tid * 32 + bit);
+        // (the bitmap is G::NBW <= 64 words: wavefront 0 holds them all -- one scan, no sums across wavefronts, one barrier)
+        static_assert(G::NBW <= 64, "the window's bitmap words must fit one wavefront");
+        if (tid < 64) {
+            const uint32_t cnt = __popc(word);
+            const uint32_t x = wave_scan_incl(cnt);
+            uint32_t base = x - cnt;
+            if (tid == 63) s_total = x;
+            while (word) {
+                const int bit = __ffs(word) - 1;
+                word &= word - 1;
+                s_cpos[base++] = (uint16_t)(tid * 32 + bit);
+            }
         }
         __syncthreads();
     }
@@ -545,8 +546,8 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
                 if (((s_mk[MK_SY * NBW1 + (p >> 5)] | s_mk[MK_TS * NBW1 + (p >> 5)]) >> (p & 31)) & 1u) break;   // the next owner's start
             }
         }
+        if (!fast_starts) __syncthreads();             // (start masks: no chain ran, the barrier behind the enumeration is the phase's)
     }
-    __syncthreads();
     SPL_STAMP(4);
 
     SPL_STAMP(5);
