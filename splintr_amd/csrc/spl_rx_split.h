@@ -219,7 +219,10 @@ __device__ __forceinline__ void rx_attempts(RxCtx& c, uint32_t* stk, const RxBlo
             p = bk.start + pl;
             if (p >= bk.B) { bk.s_j[pl] = (uint16_t)(RXJ_EXIT | 0u); continue; }
             const uint32_t wi = pl + RX_BACK;
-            if (!((cs[wi >> 5] >> (wi & 31)) & 1u)) {      // a byte inside a character: the walk never stands there, its hop is "one on"
+            // (something has been given up on already -- the batch will be split on the host --: no more attempts.  This bounds what a
+            //  pattern that backtracks without end can cost: the attempts in flight run into RX_STEPS, everything behind them is skipped)
+            const bool given_up = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            if (given_up || !((cs[wi >> 5] >> (wi & 31)) & 1u)) {      // a byte inside a character: the walk never stands there, its hop is "one on"
                 a.nx[p] = (uint16_t)(1u | 0x8000u);
                 bk.s_j[pl] = (uint16_t)rx_hop(pl, 1u | 0x8000u);
                 continue;

@@ -48,6 +48,28 @@ def _both(t, texts):
     return (st, gp, d_st[:words].cpu().numpy().view(np.uint32), d_gp[:words].cpu().numpy().view(np.uint32), int(d_status[0].item()))
 
 
+def _both_device_only(t, texts):
+    """the device half of _both (a text whose host split does not finish)"""
+    import torch
+    from splintr_amd import _ffi
+    L = _ffi.lib()
+    dev = torch.device("cuda", 0)
+    parts = [x.encode("utf-8") for x in texts]
+    blob = b"".join(parts)
+    off = np.zeros(len(parts) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(x) for x in parts], dtype=np.uint64)
+    d_text = torch.from_numpy(np.frombuffer(blob + b"\0" * ((-len(blob)) % 16 + 16), dtype=np.uint8).copy()).to(dev)
+    d_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+    words = len(blob) // 32 + 4
+    d_st, d_gp = torch.zeros(words, dtype=torch.int32, device=dev), torch.zeros(words, dtype=torch.int32, device=dev)
+    d_status = torch.zeros(4, dtype=torch.int32, device=dev)
+    rc = L.spl_split_device(t.handle, d_text.data_ptr(), len(blob), d_off.data_ptr(), len(parts), d_st.data_ptr(), d_gp.data_ptr(),
+                            d_status.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, _ffi.last_error()
+    torch.cuda.synchronize()
+    return None, None, None, None, int(d_status[0].item())
+
+
 def _first_diff(a, b):
     w = int(np.nonzero(a != b)[0][0])
     return w * 32 + int(np.log2((int(a[w]) ^ int(b[w])) & -(int(a[w]) ^ int(b[w]))))
@@ -134,3 +156,17 @@ def test_encode_batch_uses_the_device_splitter_and_falls_back_by_itself():
     b_ids, b_off = h.encode_batch_csr(big)
     assert np.array_equal(a_off, b_off) and np.array_equal(a_ids, b_ids)
     assert L.spl_device_split_fallbacks(t.handle) == 1
+
+
+def test_a_pattern_that_backtracks_without_end_is_given_up_quickly_and_reported_by_the_host():
+    """(?:a|aa)+b over a long run of a's: every attempt runs into the device matcher's step limit; the first one to do so stops the rest, and
+    the host splitter (its own budget: 64 n + 10^6 steps per attempt) raises the error the reference's engines would turn into a timeout"""
+    import time
+    from splintr_amd import Tokenizer
+    t = Tokenizer.from_bytes(_blob("cl100k_base"), r"(?:a|aa)+b|[^a]")
+    texts = ["a" * 60 + " x"] * 4000
+    t0 = time.time()
+    _, _, _, _, status = _both_device_only(t, texts)
+    assert status != 0 and time.time() - t0 < 20.0
+    with pytest.raises(Exception, match="matching budget|backtracking"):
+        t.encode_batch(texts[:50])
