@@ -21,7 +21,7 @@
 // What the matcher gives up on is REPORTED, never approximated (status word != 0, the caller splits that batch on the host):
 // a match or a look-ahead that reaches RX_REACH bytes beyond its start (every position of a run scans to the run's end --
 // the work is quadratic in the run length, so it is bounded), RX_STEPS matcher steps in one attempt, RX_DEPTH entries on the
-// backtracking stack.  Special-token literals are not handled here (with SPL_WITH_SPECIAL the host splitter runs).
+// backtracking stack, RX_MAX_OPEN blocks in a row whose walks never fall into step.  Special-token literals are not handled here (with SPL_WITH_SPECIAL the host splitter runs).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -42,6 +42,7 @@ constexpr int RX_TAB = RX_LDS_TEXT - 4;         // window positions whose charac
 constexpr int RX_BMW = (RX_TAB + 63) / 64 * 2;  // words of one window bitmap
 constexpr int RX_DEPTH = 10;                     // entries of a lane's backtracking stack (LDS: two words each, RXT lanes)
 constexpr uint32_t RX_STEPS = 8192;
+constexpr int RX_MAX_OPEN = 1024;                // blocks in a row that do not close (k_rx_mark carries the walk through them one by one)
 constexpr uint32_t RX_FAIL = 0xFFFFFFFFu, RX_ABORT = 0xFFFFFFFEu, RX_NOK = 0xFFFFFFFFu;
 enum : uint32_t { RXS_REACH = 1, RXS_STEPS = 2, RXS_DEPTH = 4 };
 enum : uint32_t { RXO_CHAR = 0, RXO_CHAR_FOLD, RXO_CLASS, RXO_ANY, RXO_SPLIT, RXO_JMP, RXO_MATCH, RXO_LOOK, RXO_NLOOK, RXO_REP1, RXO_ATOMIC, RXO_ASSERT };
@@ -554,11 +555,16 @@ __global__ __launch_bounds__(RXB) void k_rx_mark(RxArgs a) {
         // where the walk from position 0 enters this block
         int64_t k = (int64_t)b - 1;
         uint32_t v = 0;
-        while (k >= 0) {
+        // (nothing to do for a batch that goes to the host anyway; and a stretch of open blocks longer than RX_MAX_OPEN -- megabytes of
+        //  digits under \p{N}{1,2} -- is given up on: every block of it would walk back through all of it)
+        bool lost = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        while (k >= 0 && !lost) {
             v = a.blk[k];
             if ((v & RX_BLK_CLOSED) && !(v & RX_BLK_SKIPPED)) break;
             k--;
+            if ((int64_t)b - k > (int64_t)RX_MAX_OPEN) { atomicOr(a.status, RXS_REACH); lost = true; }
         }
+        if (lost) k = (int64_t)b - 1, v = RX_BLK_CLOSED;       // (any entry will do: the bitmaps are not used)
         uint32_t E = 0, pg = 0;
         if (k >= 0) { E = ((uint32_t)k + 1u) * RXB + (v & 0x7FFFu); pg = (v >> 15) & 1u; }
         for (uint32_t kk = (uint32_t)(k + 1); kk < b && E < B; kk++) {

@@ -131,6 +131,11 @@ def test_long_matches_skip_blocks_and_longer_ones_are_reported():
     assert status == 0 and np.array_equal(st, dst) and np.array_equal(gp, dgp)
     _, _, _, _, status = _both(t, ["x" * 5000 + " tail"])
     assert status != 0
+    # ... and so is a stretch of more than a thousand blocks that never close (every block would walk back through all of it)
+    _, _, _, _, status = _both(t3, ["7" * 400000 + " x"])
+    assert status != 0
+    ids, off = t3.encode_batch_csr(["7" * 400000 + " x", "ab 12"])
+    assert int(off[-1]) == len(ids) and len(ids) > 100000
 
 
 def test_encode_batch_uses_the_device_splitter_and_falls_back_by_itself():
