@@ -826,6 +826,105 @@ bool regex_device_image(const RegexProg& prog, std::vector<uint32_t>& w) {
     w[9] = (uint32_t)run_sets.size(); w[10] = (uint32_t)w.size();
     w.insert(w.end(), run_sets.begin(), run_sets.end());
     while (w.size() % 4) w.push_back(0u);
+    // ---- the alternatives of the top-level alternation, for the device matcher's lock-step evaluation ------------------
+    // An alternative is SIMPLE if it is a straight line of one-character / run items up to the end of the pattern (jumps followed:
+    // (a|b)c is the alternatives ac, bc -- the order of exploration is the same) in which giving characters back can never help:
+    // every run that could give some back is possessive, or its characters can be taken by none of the items behind it up to and
+    // including the first one that must take a character.  Greedy item by item is then exactly what the backtracking matcher finds.
+    struct Item { uint32_t op, x, mn, mx; bool gives_back; };
+    const HostTables& ht = *prog.ht;
+    auto takes = [&](const Item& it, const Ch& c) {
+        if (it.op == OP_CHAR) return c.cp == it.x;
+        if (it.op == OP_CHAR_FOLD) return c.cp != CP_INVALID && fold_eq(it.x, c.cp);
+        if (it.op == OP_ANY) return c.cp != '\n';
+        return in_set(ht, prog.sets[it.x], c);
+    };
+    auto disjoint = [&](const Item& a, const Item& b) {     // no character that both items take (every code point, and the byte that is none)
+        if (takes(a, Ch{CP_INVALID, 1, C_P}) && takes(b, Ch{CP_INVALID, 1, C_P})) return false;
+        for (uint32_t cp = 0; cp < 0x110000u; cp++) {
+            const Ch c{cp, 1, host_cp_class(ht, cp)};
+            if (takes(a, c) && takes(b, c)) return false;
+        }
+        return true;
+    };
+    // A simple alternative may END in a tail that is tried at every length of its last run, longest first (the one place where the
+    // backtracking matcher's way back is kept, as a loop): ONE one-character item whose characters the run may take too (\s*[\r\n]), a
+    // look-ahead of one one-character item (\s+(?!\S)), or the assertion $ / \z.  In front of a look-ahead or assertion tail no other item
+    // may give anything back (what it gave back could change where the tail is tested).
+    enum : uint32_t { TAIL_NONE = 0, TAIL_ITEM, TAIL_LOOK, TAIL_NLOOK, TAIL_EOL, TAIL_EOT };
+    struct Alt { uint32_t f, start; bool simple; std::vector<Item> items; uint32_t tail; Item tail_item; };
+    std::vector<Alt> alts;
+    {
+        uint32_t pc = 0;
+        while (prog.code[pc].op == OP_SPLIT && prog.code[pc].f != 0xFFFFFFFFu) { alts.push_back(Alt{prog.code[pc].f, prog.code[pc].x, false, {}, TAIL_NONE, Item{}}); pc = prog.code[pc].y; }
+        alts.push_back(Alt{0xFFFFFFFFu, pc, false, {}, TAIL_NONE, Item{}});
+    }
+    auto one_char = [](const Inst& in) { return in.op == OP_CHAR || in.op == OP_CHAR_FOLD || in.op == OP_CLASS || in.op == OP_ANY; };
+    for (Alt& al : alts) {
+        uint32_t pc = al.start;
+        bool ok = true;
+        for (int guard = 0; guard < 64 && ok; guard++) {
+            const Inst& in = prog.code[pc];
+            if (in.op == OP_MATCH) break;
+            if (in.op == OP_JMP) { pc = in.x; continue; }
+            if (al.tail != TAIL_NONE) { ok = false; break; }            // (a tail is the last thing of its alternative)
+            if (in.op == OP_REP1) {
+                const Inst& a1 = prog.code[pc + 1];
+                al.items.push_back(Item{(uint32_t)a1.op, a1.x, in.x, in.y, in.f != 1u && in.y > in.x});
+                pc += 2;
+            } else if (one_char(in)) {
+                al.items.push_back(Item{(uint32_t)in.op, in.x, 1u, 1u, false});
+                pc++;
+            } else if ((in.op == OP_LOOK || in.op == OP_NLOOK) && one_char(prog.code[pc + 1]) && prog.code[pc + 2].op == OP_MATCH) {
+                al.tail = in.op == OP_LOOK ? TAIL_LOOK : TAIL_NLOOK;
+                al.tail_item = Item{(uint32_t)prog.code[pc + 1].op, prog.code[pc + 1].x, 1u, 1u, false};
+                pc = in.x;
+            } else if (in.op == OP_ASSERT && (in.x == AS_EOL || in.x == AS_EOT)) {
+                al.tail = in.x == AS_EOL ? TAIL_EOL : TAIL_EOT;
+                pc++;
+            } else ok = false;
+            if (al.items.size() > 8) ok = false;
+        }
+        if (ok && prog.code[pc].op != OP_MATCH) ok = false;
+        if (ok && pc + 1 != prog.code.size()) ok = false;              // (the end of the PATTERN, not of a look-ahead's sub-program)
+        if (ok && al.items.empty()) ok = false;
+        // a last one-character item behind a run that gives back and shares characters with it: the tail of that run
+        if (ok && al.tail == TAIL_NONE && al.items.size() >= 2) {
+            const Item& last = al.items.back();
+            const Item& run = al.items[al.items.size() - 2];
+            if (last.mn == 1 && last.mx == 1 && run.gives_back && !disjoint(run, last)) {
+                al.tail = TAIL_ITEM; al.tail_item = last;
+                al.items.pop_back();
+            }
+        }
+        const size_t n_plain = al.tail == TAIL_NONE ? al.items.size() : al.items.size() - 1;      // items in front of the tail's run
+        for (size_t j = 0; j < n_plain && ok; j++) {
+            if (!al.items[j].gives_back) continue;
+            if (al.tail >= TAIL_LOOK) { ok = false; break; }
+            for (size_t k = j + 1; k < al.items.size() && ok; k++) {
+                if (!disjoint(al.items[j], al.items[k])) ok = false;
+                if (al.items[k].mn >= 1) break;
+                if (k + 1 == al.items.size() && al.tail == TAIL_ITEM && !disjoint(al.items[j], al.tail_item)) ok = false;
+            }
+        }
+        al.simple = ok;
+    }
+    w[11] = (uint32_t)w.size();
+    w.push_back((uint32_t)alts.size()); w.push_back(0u); w.push_back(0u); w.push_back(0u);
+    const size_t ent = w.size();
+    w.resize(ent + 4 * alts.size(), 0u);
+    for (size_t i = 0; i < alts.size(); i++) {
+        const Alt& al = alts[i];
+        const uint32_t off = (uint32_t)w.size();
+        if (al.simple) {
+            for (const Item& it : al.items) { w.push_back(it.op); w.push_back(it.x); w.push_back(it.mn); w.push_back(it.mx); }
+            // (the tail's item behind them; its last word: the fewest characters the run in front of it may be cut back to)
+            const Item& run = al.items.back();
+            w.push_back(al.tail_item.op); w.push_back(al.tail_item.x); w.push_back(0u); w.push_back(run.gives_back ? run.mn : 0xFFFFFFFFu);
+        }
+        w[ent + 4 * i] = al.f; w[ent + 4 * i + 1] = al.simple ? (1u | (al.tail << 8)) : 0u; w[ent + 4 * i + 2] = al.start;
+        w[ent + 4 * i + 3] = (al.simple ? (uint32_t)al.items.size() : 0u) | (off << 16);
+    }
     return w.size() <= RX_IMAGE_MAX_WORDS;
 }
 

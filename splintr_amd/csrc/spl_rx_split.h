@@ -191,61 +191,20 @@ struct RxBlock {
 
 __device__ __forceinline__ uint32_t rx_hop(uint32_t q, uint32_t nxv);
 
-__device__ __forceinline__ void rx_attempts(RxCtx& c, uint32_t* stk, const RxBlock& bk, const RxArgs& a) {
+// One run of the matcher program from pc0, anchored at p (a whole pattern, or ONE alternative of its top-level alternation: what is
+// on the stack when the run ends with nothing left to try are only its own entries).  Returns the end, RX_FAIL or RX_ABORT.
+struct RxAt { uint32_t p, n, back; bool p_is_start; };
+__device__ __forceinline__ uint32_t rx_vm(RxCtx& c, uint32_t* stk, const RxArgs& a, const RxAt& at, uint32_t pc0, uint32_t& steps) {
     constexpr uint32_t NOTYET = 0xFFFFFFFDu;
-    constexpr int DSW = (RX_BACK + RXB + RX_REACH) / 32 + 2;
     const uint32_t* const cs = c.bm + RX_MAX_RUNSETS * RX_BMW;
-    uint32_t p = 0, pl = 0, n = 0, lim = 0, back = 0, pc = 0, pos = 0, steps = 0;
+    const uint32_t p = at.p, n = at.n, back = at.back;
+    const bool p_is_start = at.p_is_start;
+    const bool trunc = n > p + (uint32_t)RX_REACH;
+    const uint32_t lim = p + (uint32_t)RX_REACH;
+    uint32_t pc = pc0, pos = p;
     int sp = 0, floor = 0;
-    bool trunc = false, p_is_start = false, run = false, have = false;
-    auto ds_bit = [&](uint32_t i) { return (bk.s_ds[i >> 5] >> (i & 31)) & 1u; };
-    auto finish = [&](uint32_t e) {                       // the attempt at p has ended with e: its hop
-        uint32_t nxv;
-        if (e < RX_ABORT && e > p) {
-            uint32_t d = e - p;
-            if (d > (uint32_t)RX_REACH - 8u) { atomicOr(a.status, RXS_REACH); d = RX_REACH - 8; }
-            nxv = d;
-            // a hop over whole blocks: they may not be touched by the walk at all
-            for (uint32_t k = (p >> 8) + 1; (k + 1) * (uint32_t)RXB <= p + d; k++) atomicOr(&a.blk[k], RX_BLK_SKIPPED);
-        } else {
-            nxv = c.char_len(p) | 0x8000u;                // no match here (or an empty one): the character is skipped
-        }
-        a.nx[p] = (uint16_t)nxv;
-        bk.s_j[pl] = (uint16_t)rx_hop(pl, nxv);
-    };
+    bool run = true;
     for (;;) {
-        if (!have) {
-            pl = atomicAdd(bk.s_next, 1u);
-            if (pl >= (uint32_t)RXB) break;
-            p = bk.start + pl;
-            if (p >= bk.B) { bk.s_j[pl] = (uint16_t)(RXJ_EXIT | 0u); continue; }
-            const uint32_t wi = pl + RX_BACK;
-            // (something has been given up on already -- the batch will be split on the host --: no more attempts.  This bounds what a
-            //  pattern that backtracks without end can cost: the attempts in flight run into RX_STEPS, everything behind them is skipped)
-            const bool given_up = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-            if (given_up || !((cs[wi >> 5] >> (wi & 31)) & 1u)) {      // a byte inside a character: the walk never stands there, its hop is "one on"
-                a.nx[p] = (uint16_t)(1u | 0x8000u);
-                bk.s_j[pl] = (uint16_t)rx_hop(pl, 1u | 0x8000u);
-                continue;
-            }
-            p_is_start = ds_bit(wi) != 0u;
-            n = bk.B;                                      // the end of p's document: the next document start behind p (or the end of the corpus)
-            if (bk.any_ds) {
-                uint32_t i = wi + 1, w = i >> 5;
-                uint32_t bits = bk.s_ds[w] & (~0u << (i & 31));
-                while (!bits && ++w < (uint32_t)DSW) bits = bk.s_ds[w];
-                if (bits) { const uint32_t e = c.wb + w * 32 + (uint32_t)__ffs((int)bits) - 1u; n = e < n ? e : n; }
-            }
-            back = 0;                                      // bytes of the same document in front of p (up to RX_BACK)
-            if (!p_is_start) { back = 1; while (back < (uint32_t)RX_BACK && back < p && !ds_bit(wi - back)) back++; }
-            c.n = n;
-            trunc = n > p + (uint32_t)RX_REACH;
-            lim = p + (uint32_t)RX_REACH;
-            const uint32_t b0 = c.rd(p);                   // (p < n: the attempt begins with a byte)
-            pc = c.img[c.img[8] + (b0 < 0x80 ? b0 : 128u)];   // behind the alternatives this byte cannot start (regex_device_image)
-            pos = p; sp = 0; floor = 0; steps = 0;
-            run = true; have = true;
-        }
         uint32_t fin = NOTYET, r = RX_FAIL;
         bool ended = false;
 #define RX_PUSH(A, B) do { if (sp == RX_DEPTH) { atomicOr(a.status, RXS_DEPTH); fin = RX_ABORT; break; } stk[(2 * sp) * RXT] = (A); stk[(2 * sp + 1) * RXT] = (B); sp++; } while (0)
@@ -395,11 +354,142 @@ __device__ __forceinline__ void rx_attempts(RxCtx& c, uint32_t* stk, const RxBlo
                 }
             }
         }
-#ifdef RX_COUNT
-        if (fin != NOTYET) { atomicAdd(&a.status[1], steps); atomicAdd(&a.status[2], 1u); }
-        atomicAdd(&a.status[3], 1u);
-#endif
-        if (fin != NOTYET) { finish(fin); have = false; run = false; }
+        if (fin != NOTYET) return fin;
+    }
+}
+
+// One SIMPLE alternative (regex_device_image: a straight line of one-character / run items in which giving characters back can never
+// help -- possessive, or the item's characters cannot be taken by what follows) at p: greedy, item by item, no stack.  Every lane of
+// the wavefront walks the same items: this is the code that runs at full width.
+__device__ __forceinline__ uint32_t rx_simple_alt(const RxCtx& c, const uint32_t* items, uint32_t n_items, uint32_t tail, uint32_t p, uint32_t n, bool on,
+                                                  uint32_t& why) {
+    const uint32_t* const cs = c.bm + RX_MAX_RUNSETS * RX_BMW;
+    const bool trunc = n > p + (uint32_t)RX_REACH;
+    const uint32_t lim = p + (uint32_t)RX_REACH;
+    uint32_t pos = p, rs = p, rk = 0;                       // rs, rk: where the last item began and how many characters it took
+    bool ok = on;
+    for (uint32_t it = 0; it < n_items; it++) {
+        const uint4 item = *reinterpret_cast<const uint4*>(items + 4 * it);       // op, x, min, max
+        if (!ok) continue;
+        const uint32_t op = item.x, x = item.y, mn = item.z, mx = item.w;
+        uint32_t q = pos, k = 0;
+        bool more = true;
+        if (op == RXO_CLASS && mx > 8u && pos < n) {
+            const uint32_t slot = c.set(x)[9], i0 = pos - c.wb;
+            if (slot != 0xFFFFFFFFu && i0 < (uint32_t)RX_TAB) {
+                const uint32_t ni = n - c.wb;
+                const uint32_t tl = ni < (uint32_t)RX_TAB ? ni : (uint32_t)RX_TAB;
+                uint32_t e = c.first_zero(c.bm + slot * RX_BMW, i0, tl);
+                const bool open_end = e == (uint32_t)RX_TAB && e < ni;
+                if (open_end && e > i0) e = c.last_set_below(cs, e);
+                const uint32_t kk = c.count_set(cs, i0, e);
+                if (kk <= mx) { k = kk; q = pos + (e - i0); more = open_end; }
+            }
+        }
+        while (more && k < mx && q < n) {
+            if (trunc && q + 8 > lim) { why = RXS_REACH; return RX_ABORT; }
+            const uint32_t b = c.rd(q);
+            if (b < 0x80) {
+                if (!c.one_ascii(op, x, b)) break;
+                q++;
+            } else {
+                const RxCh ch = c.decode(q);
+                if (!c.one(op, x, ch)) break;
+                q += ch.len;
+            }
+            k++;
+        }
+        if (k < mn) ok = false;
+        rs = pos; rk = k;
+        pos = q;
+    }
+    if (tail == 0u || !ok) return ok ? pos : RX_FAIL;
+    // the tail, at every length of the last run from the longest down to `cut` (the matcher's way back into that run, as a loop)
+    const uint4 tl = *reinterpret_cast<const uint4*>(items + 4 * n_items);          // op, x, -, the fewest characters the run may keep (~0: all of them)
+    const uint32_t cut = tl.w == 0xFFFFFFFFu ? rk : tl.w;
+    for (uint32_t t = rk;; t--) {
+        if (trunc && pos + 8 > lim) { why = RXS_REACH; return RX_ABORT; }
+        if (tail == 1u || tail == 2u || tail == 3u) {                                 // one character of the tail's item at pos?
+            bool takes = false;
+            uint32_t len = 1;
+            if (pos < n) {
+                const uint32_t b = c.rd(pos);
+                if (b < 0x80) takes = c.one_ascii(tl.x, tl.y, b);
+                else { const RxCh ch = c.decode(pos); takes = c.one(tl.x, tl.y, ch); len = ch.len; }
+            }
+            if (tail == 1u) { if (takes) return pos + len; }
+            else if (takes == (tail == 2u)) return pos;
+        } else if (tail == 4u) { if (pos == n || (pos + 1 == n && c.rd(pos) == '\n')) return pos; }
+        else if (pos == n) return pos;
+        if (t <= cut) return RX_FAIL;
+        // one character less: the start of the run's last character
+        const uint32_t ei = pos - c.wb;
+        if (ei <= (uint32_t)RX_TAB) pos = c.wb + c.last_set_below(cs, ei);
+        else { pos = rs; for (uint32_t j = 0; j + 1 < t; j++) pos += c.char_len(pos); }
+    }
+}
+
+// The attempt at every position of the block, one position per lane, the ALTERNATIVES of the pattern in step: all lanes try
+// alternative 0, then those it did not match try alternative 1, ... (leftmost-first: the first alternative that matches is the match).
+// A simple alternative is evaluated at full width; another one runs the matcher program from its first instruction for the lanes
+// that can start it (its first-character filter) -- on GPT-2's pattern that is `\s+(?!\S)` at blanks that no earlier alternative took.
+__device__ __forceinline__ void rx_attempts(RxCtx& c, uint32_t* stk, const RxBlock& bk, const RxArgs& a, uint32_t pl) {
+    constexpr int DSW = (RX_BACK + RXB + RX_REACH) / 32 + 2;
+    const uint32_t* const cs = c.bm + RX_MAX_RUNSETS * RX_BMW;
+    auto ds_bit = [&](uint32_t i) { return (bk.s_ds[i >> 5] >> (i & 31)) & 1u; };
+    const uint32_t p = bk.start + pl;
+    if (p >= bk.B) bk.s_j[pl] = (uint16_t)(RXJ_EXIT | 0u);
+    const uint32_t wi = pl + RX_BACK;
+    // (something has been given up on already -- the batch will be split on the host --: no more attempts.  This bounds what a
+    //  pattern that backtracks without end can cost: the attempts in flight run into RX_STEPS, everything behind them is skipped)
+    const bool given_up = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    // (a byte inside a character: the walk never stands there, its hop is "one on")
+    bool act = p < bk.B && !given_up && ((cs[wi >> 5] >> (wi & 31)) & 1u) != 0u;
+    RxAt at{p, bk.B, 0u, false};
+    uint32_t b0 = 0;
+    if (act) {
+        at.p_is_start = ds_bit(wi) != 0u;
+        if (bk.any_ds) {                                   // the end of p's document: the next document start behind p (or the end of the corpus)
+            uint32_t i = wi + 1, w = i >> 5;
+            uint32_t bits = bk.s_ds[w] & (~0u << (i & 31));
+            while (!bits && ++w < (uint32_t)DSW) bits = bk.s_ds[w];
+            if (bits) { const uint32_t e = c.wb + w * 32 + (uint32_t)__ffs((int)bits) - 1u; at.n = e < at.n ? e : at.n; }
+        }
+        if (!at.p_is_start) { at.back = 1; while (at.back < (uint32_t)RX_BACK && at.back < p && !ds_bit(wi - at.back)) at.back++; }
+        c.n = at.n;
+        b0 = c.rd(p);                                      // (p < n: the attempt begins with a byte)
+    }
+    const uint32_t* const alts = c.img + c.img[11];
+    const uint32_t n_alts = alts[0];
+    uint32_t e = RX_FAIL, steps = 0;
+    for (uint32_t ai = 0; ai < n_alts; ai++) {             // (uniform)
+        const uint4 alt = *reinterpret_cast<const uint4*>(alts + 4 + 4 * ai);     // filter, flags, first instruction, items (count | offset << 16)
+        bool can = act && e == RX_FAIL;
+        if (can && alt.x != 0xFFFFFFFFu) {
+            const uint32_t* fs = c.img + c.img[3] + RX_FIRST_WORDS * alt.x;
+            can = b0 < 0x80 ? ((fs[b0 >> 5] >> (b0 & 31)) & 1u) != 0 : fs[4] != 0u;
+        }
+        if (!__any(can)) continue;
+        uint32_t r = RX_FAIL, why = 0;
+        if (alt.y & 1u) r = rx_simple_alt(c, c.img + (alt.w >> 16), alt.w & 0xFFFFu, alt.y >> 8, p, at.n, can, why);
+        else if (can) r = rx_vm(c, stk, a, at, alt.z, steps);
+        if (can && r == RX_ABORT) { if (why) atomicOr(a.status, why); act = false; }
+        else if (can && r != RX_FAIL && r > p) e = r;
+        else if (can && r != RX_FAIL) act = false;         // (an empty match: find_iter skips the character, as behind no match)
+    }
+    if (p < bk.B) {                                        // the position's hop
+        uint32_t nxv = 1u | 0x8000u;
+        if (e != RX_FAIL) {
+            uint32_t d = e - p;
+            if (d > (uint32_t)RX_REACH - 8u) { atomicOr(a.status, RXS_REACH); d = RX_REACH - 8; }
+            nxv = d;
+            // a hop over whole blocks: they may not be touched by the walk at all
+            for (uint32_t k = (p >> 8) + 1; (k + 1) * (uint32_t)RXB <= p + d; k++) atomicOr(&a.blk[k], RX_BLK_SKIPPED);
+        } else if (!given_up && ((cs[wi >> 5] >> (wi & 31)) & 1u)) {
+            nxv = c.char_len(p) | 0x8000u;                 // no match here (or an empty one): the character is skipped
+        }
+        a.nx[p] = (uint16_t)nxv;
+        bk.s_j[pl] = (uint16_t)rx_hop(pl, nxv);
     }
 }
 
@@ -516,7 +606,7 @@ __global__ __launch_bounds__(RXT) void k_rx_match(RxArgs a) {
 #else
     {
         RxBlock bk{start, B, s_ds, any_ds, &s_next, s_j};
-        rx_attempts(c, s_stk + tid, bk, a);
+        rx_attempts(c, s_stk + tid, bk, a, (uint32_t)tid);
     }
 #endif
     // the block's own words of the document-start bitmap
