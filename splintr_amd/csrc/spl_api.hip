@@ -204,6 +204,7 @@ struct Ctx {
     const uint32_t* d_rx_image = nullptr; const uint16_t* d_gc1 = nullptr; const uint8_t* d_gc2 = nullptr;
     uint8_t* d_rx_ws = nullptr; uint64_t rx_ws_cap = 0;
     uint32_t* d_rx_status = nullptr;
+    uint32_t* h_rx_status = nullptr;                                // pinned copy: written behind every chunk's split, read when the batch is done
     uint32_t* d_rx_bits = nullptr; uint64_t rx_bits_cap = 0;       // the two bitmaps of a device-text call (spl_encode_batch_device)
     hipEvent_t ev_h2d[NSLOT] = {nullptr, nullptr, nullptr}, ev_cmp[NSLOT] = {nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ev_chunk;
@@ -251,7 +252,7 @@ struct Ctx {
         hipFree((void*)d_tok_off); hipFree((void*)d_tok_bytes); hipFree(d_sp_lits);
         hipFree((void*)d_dec_sp_ids); hipFree((void*)d_dec_sp_off);
         hipFree(d_ids); hipFree(d_oo);
-        hipFree((void*)d_rx_image); hipFree((void*)d_gc1); hipFree((void*)d_gc2); hipFree(d_rx_ws); hipFree(d_rx_status); hipFree(d_rx_bits);
+        hipFree((void*)d_rx_image); hipFree((void*)d_gc1); hipFree((void*)d_gc2); hipFree(d_rx_ws); hipFree(d_rx_status); hipFree(d_rx_bits); if (h_rx_status) (void)hipHostFree(h_rx_status);
         hipFree(d_dec_ids); hipFree(d_dec_blk); hipFree(d_dec_idoff); hipFree(d_dec_out); hipFree(d_dec_first); hipFree(d_dec_docoff);
         if (ev_ready) for (auto& e : ev) (void)hipEventDestroy(e);
         for (int i = 0; i < NSLOT; i++) { if (ev_h2d[i]) (void)hipEventDestroy(ev_h2d[i]); if (ev_cmp[i]) (void)hipEventDestroy(ev_cmp[i]); }
@@ -676,6 +677,8 @@ int rx_ensure(spl_tokenizer* tk, Ctx* c) {
     }
     HIP_TRY(hipMalloc((void**)&c->d_rx_status, 64));
     HIP_TRY(hipMemset(c->d_rx_status, 0, 64));
+    HIP_TRY(hipHostMalloc((void**)&c->h_rx_status, 64, hipHostMallocPortable));
+    c->h_rx_status[0] = 0;
     return dev_upload(tk->rx_image, &c->d_rx_image);
 }
 int rx_launch(spl_tokenizer* tk, Ctx* c, const uint8_t* d_text, uint64_t n_bytes, const uint64_t* d_doc_off, uint64_t n_docs,
@@ -685,8 +688,12 @@ int rx_launch(spl_tokenizer* tk, Ctx* c, const uint8_t* d_text, uint64_t n_bytes
     int rc = rx_ensure(tk, c);
     if (rc) return rc;
     const uint64_t words = n_bytes / 32 + 2;
-    HIP_TRY(hipMemsetAsync(d_starts, 0, words * 4, s));
-    HIP_TRY(hipMemsetAsync(d_gaps, 0, words * 4, s));
+    if (d_gaps > d_starts && (uint64_t)(d_gaps - d_starts) <= words + 8) {      // (back to back: one fill)
+        HIP_TRY(hipMemsetAsync(d_starts, 0, ((uint64_t)(d_gaps - d_starts) + words) * 4, s));
+    } else {
+        HIP_TRY(hipMemsetAsync(d_starts, 0, words * 4, s));
+        HIP_TRY(hipMemsetAsync(d_gaps, 0, words * 4, s));
+    }
     if (!n_bytes) return SPL_OK;
     const uint64_t nblk = (n_bytes + RXB - 1) / RXB;
     const uint64_t need = 4 * nblk * RXB + 4 * nblk + 4 * (8 * nblk + 2) + 256;
@@ -1045,6 +1052,7 @@ int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t
                 // on the context's status word when the batch is done (encode_host then runs the batch again, split on the host)
                 int rcx = rx_launch(tk, c, c->d_text[sl], nb, c->d_off[sl], nd, c->d_ext[sl], c->d_ext[sl] + bw, c->d_rx_status, c->s_cmp);
                 if (rcx) return rcx;
+                HIP_TRY(hipMemcpyAsync(c->h_rx_status, c->d_rx_status, 4, hipMemcpyDeviceToHost, c->s_cmp));    // (the word accumulates over the batch's chunks)
             } else {
             uint32_t* hb = (uint32_t*)c->h_ext[sl].p;
             memset(hb, 0, 2 * bw * 4);
@@ -1556,19 +1564,16 @@ int spl_encode_batch(spl_tokenizer* t, const uint8_t* utf8, const uint64_t* doc_
                 if (!rcx) rcx = rx_ensure(t, c.get());
                 if (rcx) return rcx;
                 HIP_TRY(hipMemsetAsync(c->d_rx_status, 0, 4, c->s_cmp));
+                c->h_rx_status[0] = 0;
             }
         int rc = encode_host(t, utf8, doc_off, n_docs, flags, r.get(), !dev_split);
         if (rc) return rc;
         if (dev_split) {
             // what the device splitter gave up on (a match longer than RX_REACH, a runaway attempt): the batch again, split on the host
+            // (every chunk's split left the status word in the context's pinned copy, in front of the kernels whose completion
+            //  encode_host has waited for: nothing to copy or wait for here)
             uint32_t gave_up = 0;
-            for (auto& c : t->ctx) {
-                uint32_t st = 0;
-                HIP_TRY(hipSetDevice(c->device));
-                HIP_TRY(hipMemcpyAsync(&st, c->d_rx_status, 4, hipMemcpyDeviceToHost, c->s_cmp));
-                HIP_TRY(hipStreamSynchronize(c->s_cmp));
-                gave_up |= st;
-            }
+            for (auto& c : t->ctx) gave_up |= c->h_rx_status[0];
             t->rx_fallbacks += gave_up ? 1 : 0;
             if (gave_up) {
                 r.reset(new spl_result());
