@@ -4,8 +4,12 @@
 // each text (reference src/core/tokenizer.rs:410-456, 244-257, 729-808).  That walk is sequential: where match k + 1 starts is
 // where match k ended.  Position-parallel form:
 //
-//   k_rx_match   every byte position p runs the SAME backtracking program the host splitter runs (regex_device_image: the
-//                instruction list, class sets and first-character filters, copied to LDS), anchored at p, inside p's document:
+//   k_rx_match   every byte position p that starts a character finds where a match anchored there ends, inside p's document, with the
+//                host compiler's own output (regex_device_image: instruction list, class sets, first-character filters, the table of
+//                the pattern's top-level alternatives -- copied to LDS).  One position per lane; the wavefront walks the ALTERNATIVES
+//                in step: a SIMPLE one (a straight line of items where giving characters back cannot help) is evaluated by all lanes
+//                at once, greedy item by item -- a run of a tabulated class is a bit scan over the window --; any other runs the SAME
+//                backtracking program the host splitter runs, from that alternative's first instruction.
 //                nx[p] = how far find_iter would move from p -- the length of the match, or the length of the ONE character it
 //                skips when nothing matches there (bit 15: those bytes are dropped).  Then the block of RXB positions composes
 //                its hops by pointer doubling: gx[p] = where the walk from p first leaves the block (offset behind the block's
@@ -32,9 +36,7 @@
 namespace spl {
 
 constexpr int RXB = 256;                       // positions per block (and threads of k_rx_mark)
-constexpr int RXT = 256;                       // threads of k_rx_match; they work the block's positions off a counter.  (Fewer threads, more
-                                               // attempts per lane: 64 -> 230 us, 128 -> 174 us, 256 -> 169 us for GPT-2's pattern on the C2 batch --
-                                               // an attempt is a chain of dependent LDS reads, and it is the number of chains in flight that pays)
+constexpr int RXT = 256;                       // threads of k_rx_match: a lane per position
 constexpr int RX_REACH = 1032;                 // bytes behind its start a match attempt may look at (a hop is at most RX_REACH - 8)
 constexpr int RX_BACK = 4;                     // staged bytes in front of the block (\b looks at the character before)
 constexpr int RX_LDS_TEXT = RX_BACK + RXB + 276;   // staged text; beyond it the matcher reads global memory
