@@ -175,3 +175,38 @@ def test_a_pattern_that_backtracks_without_end_is_given_up_quickly_and_reported_
     assert status != 0 and time.time() - t0 < 20.0
     with pytest.raises(Exception, match="matching budget|backtracking"):
         t.encode_batch(texts[:50])
+
+
+def test_random_patterns_device_bitmaps_equal_the_host_splitter_s():
+    """Random patterns (tests/patgen.py: the CPU suite pins the host splitter to PCRE2 on the same generator) -- what regex_device_image calls a
+    SIMPLE alternative, which tail it gives it and what it leaves to the matcher program is decided per pattern: here every accepted pattern's
+    device bitmaps are compared with the host's on texts that make overlapping class sets backtrack."""
+    import random
+    from splintr_amd import Tokenizer
+    from patgen import random_pattern, random_texts
+    rng = random.Random(424242)
+    blob = _blob("cl100k_base")
+    done = gave_up = 0
+    for _ in range(260):
+        pat = random_pattern(rng)
+        try:
+            t = Tokenizer.from_bytes(blob, pat)
+        except ValueError:
+            continue
+        if not t.has_custom_pattern:
+            continue
+        texts = random_texts(rng, 300, 30)
+        for batch in (texts, ["".join(texts)]):
+            try:
+                st, gp, dst, dgp, status = _both(t, batch)
+            except AssertionError as e:
+                assert "budget" in str(e), (pat, str(e)[:300])      # (a pattern that backtracks without end on this text: the host says so)
+                gave_up += 1
+                continue
+            if status != 0:
+                gave_up += 1                 # (a deep stack: reported, the host splitter's turn)
+                continue
+            assert np.array_equal(st, dst), f"{pat!r}: start bits differ first at byte {_first_diff(st, dst)}"
+            assert np.array_equal(gp, dgp), f"{pat!r}: gap bits differ first at byte {_first_diff(gp, dgp)}"
+        done += 1
+    assert done >= 100 and gave_up <= done // 4, (done, gave_up)

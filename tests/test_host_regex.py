@@ -97,3 +97,30 @@ def test_unsupported_constructs_are_named(sim, pattern, what):
     with pytest.raises(ValueError) as e:
         HostRegex(pattern, sim)
     assert what in str(e.value), str(e.value)
+
+
+def test_random_patterns_equal_pcre2(sim):
+    """round 4: 400 random patterns from tests/patgen.py (alternations of short item sequences, every quantifier flavour, groups, look-ahead and
+    assertion tails; class sets that overlap) on texts that make them backtrack: the host splitter == PCRE2, pattern by pattern"""
+    import random
+    from hostsim import HostRegex
+    from oracle import pyoracle as O
+    from patgen import random_pattern, random_texts
+    if not O.pcre2_available():
+        pytest.skip("libpcre2-8 not present")
+    rng = random.Random(20260930)
+    done = 0
+    for _ in range(400):
+        pat = random_pattern(rng)
+        try:
+            hr = HostRegex(pat, sim)
+        except ValueError:
+            continue                      # (can match the empty string, or a construct in a place the compiler refuses)
+        pc = O.Pcre2Pattern(pat)
+        texts = random_texts(rng, 40)
+        for t in texts + ["".join(texts)]:
+            b = t.encode("utf-8")
+            want = [(a, e) for a, e in pc.find_iter(b) if e > a]
+            assert hr.split(b) == want, (pat, t)
+        done += 1
+    assert done >= 150
