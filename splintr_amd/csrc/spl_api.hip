@@ -486,15 +486,21 @@ int upload_decode(spl_tokenizer* tk, Ctx* t) {
 
 struct SlabOut { uint32_t* d_slab = nullptr; uint64_t cap_words = 0, max_docs = 0; };
 // chunk boundaries given from outside (host splitter): device bitmaps, and the special tokens found on the host
-struct ExtIn { const uint32_t* d_starts = nullptr; const uint32_t* d_gaps = nullptr; const uint32_t* d_sp_pos = nullptr; const uint32_t* d_sp_id = nullptr; uint32_t n_sp = 0; };
+struct ExtIn {
+    const uint32_t* d_starts = nullptr; const uint32_t* d_gaps = nullptr; const uint32_t* d_sp_pos = nullptr; const uint32_t* d_sp_id = nullptr; uint32_t n_sp = 0;
+    // the two bitmaps are still to be made, by the device splitter, inside launch_all (behind the special-token kernels, whose bitmaps it reads):
+    uint32_t* d_status = nullptr;          // non-null: yes; the status word it reports to
+};
+int rx_launch(spl_tokenizer* tk, Ctx* c, const uint8_t* d_text, uint64_t n_bytes, const uint64_t* d_doc_off, uint64_t n_docs,
+              uint32_t* d_starts, uint32_t* d_gaps, uint32_t* d_status, hipStream_t s, const Batch* sp = nullptr, uint32_t sp_words = 0);
 
 int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off, uint64_t n_docs,
                uint32_t flags, uint32_t* d_ids, uint64_t ids_cap, uint64_t* d_out_off, hipStream_t s,
                const SlabOut* so = nullptr, const ExtIn* ext = nullptr) {
     if (((uintptr_t)d_utf8 & 15) != 0) return fail(SPL_EINVAL, "text buffer must be 16-byte aligned");
     if (ext && n_bytes > SPL_DIRECT_MAX_BYTES) return fail(SPL_EINVAL, "external chunk boundaries: at most 256 MB per device call");
-    // (external boundaries: the special tokens -- if any -- were found by the host splitter; the GPU's literal scan stays off)
-    const bool special = !ext && (flags & SPL_WITH_SPECIAL) && !tk->specials.empty();
+    // (external boundaries from the HOST splitter: the special tokens -- if any -- were found there; the GPU's literal scan stays off)
+    const bool special = (!ext || ext->d_status) && (flags & SPL_WITH_SPECIAL) && !tk->specials.empty();
     if (special) { int rc0 = upload_specials(tk, t); if (rc0) return rc0; }
     if (n_bytes > 0x7FFF0000ull) return fail(SPL_EINVAL, "n_bytes per device call must be < 2^31 - 65536");
     if (n_docs > 0xFFFFFFF0ull) return fail(SPL_EINVAL, "n_docs per device call must be < 2^32 - 16");
@@ -614,6 +620,11 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
                 hipLaunchKernelGGL(k_special_select, dim3((uint32_t)((n_docs + 255) / 256)), dim3(256), 0, s, b);
             }
         }
+        if (ext && ext->d_status) {            // the device splitter, behind the literal scan whose bitmaps it reads
+            int rcx = rx_launch(tk, t, d_utf8, n_bytes, d_doc_off, n_docs, const_cast<uint32_t*>(ext->d_starts), const_cast<uint32_t*>(ext->d_gaps),
+                                ext->d_status, s, special ? &b : nullptr, (uint32_t)uw);
+            if (rcx) return rcx;
+        }
         MARK(KI_PRETOK);
         if (ntiles && direct_b) hipLaunchKernelGGL((k_pretok<SPL_TILE_DIRECT_B>), dim3(ntiles), dim3(NT), 0, s, PRETOK_EARLY(t->dt, b), t->dt, b);
         else if (ntiles) hipLaunchKernelGGL((k_pretok<SPL_TILE_DIRECT_A>), dim3(ntiles), dim3(NT), 0, s, PRETOK_EARLY(t->dt, b), t->dt, b);
@@ -666,7 +677,8 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
 // workspace, and launches the two kernels on `s`: d_starts / d_gaps (n_bytes / 32 + 2 words each, at least) are zeroed here;
 // *d_status collects RXS_* bits (not cleared here: a batch of several chunks shares one word).
 bool rx_applies(const spl_tokenizer* tk, uint32_t flags) {
-    return tk->regex && tk->rx_device && !tk->rx_image.empty() && !((flags & SPL_WITH_SPECIAL) && !tk->specials.empty());
+    (void)flags;                           // (SPL_WITH_SPECIAL too: the literals are found by the GPU's own scan, as for the built-in patterns)
+    return tk->regex && tk->rx_device && !tk->rx_image.empty();
 }
 int rx_ensure(spl_tokenizer* tk, Ctx* c) {
     if (c->d_rx_image) return SPL_OK;
@@ -682,7 +694,7 @@ int rx_ensure(spl_tokenizer* tk, Ctx* c) {
     return dev_upload(tk->rx_image, &c->d_rx_image);
 }
 int rx_launch(spl_tokenizer* tk, Ctx* c, const uint8_t* d_text, uint64_t n_bytes, const uint64_t* d_doc_off, uint64_t n_docs,
-              uint32_t* d_starts, uint32_t* d_gaps, uint32_t* d_status, hipStream_t s) {
+              uint32_t* d_starts, uint32_t* d_gaps, uint32_t* d_status, hipStream_t s, const Batch* sp, uint32_t sp_words) {
     if (n_bytes > SPL_DIRECT_MAX_BYTES) return fail(SPL_EINVAL, "device split: at most 256 MB per call");
     if (((uintptr_t)d_text & 15) != 0) return fail(SPL_EINVAL, "text buffer must be 16-byte aligned");
     int rc = rx_ensure(tk, c);
@@ -712,6 +724,7 @@ int rx_launch(spl_tokenizer* tk, Ctx* c, const uint8_t* d_text, uint64_t n_bytes
     a.nx = (uint16_t*)c->d_rx_ws; a.gx = a.nx + nblk * RXB;
     a.blk = (uint32_t*)(a.gx + nblk * RXB); a.dstart = a.blk + nblk;
     a.starts = d_starts; a.gaps = d_gaps; a.status = d_status;
+    if (sp) { a.sp_tstart = sp->tstart; a.sp_tbits = sp->tbits; a.sp_words = sp_words; }
     HIP_TRY(hipMemsetAsync(a.blk, 0, nblk * 4, s));
     hipLaunchKernelGGL(k_rx_match, dim3((uint32_t)nblk), dim3(RXT), (a.image_words * 4 + 15) & ~15u, s, a);
     hipLaunchKernelGGL(k_rx_mark, dim3((uint32_t)nblk), dim3(RXB), 0, s, a);
@@ -1050,9 +1063,7 @@ int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t
             if (!ln.host_split) {
                 // ... or from the device splitter, on the compute stream behind the text's arrival; what it gives up on is
                 // on the context's status word when the batch is done (encode_host then runs the batch again, split on the host)
-                int rcx = rx_launch(tk, c, c->d_text[sl], nb, c->d_off[sl], nd, c->d_ext[sl], c->d_ext[sl] + bw, c->d_rx_status, c->s_cmp);
-                if (rcx) return rcx;
-                HIP_TRY(hipMemcpyAsync(c->h_rx_status, c->d_rx_status, 4, hipMemcpyDeviceToHost, c->s_cmp));    // (the word accumulates over the batch's chunks)
+                ext.d_status = c->d_rx_status;             // (launch_all runs the splitter, behind the special-token scan)
             } else {
             uint32_t* hb = (uint32_t*)c->h_ext[sl].p;
             memset(hb, 0, 2 * bw * 4);
@@ -1082,6 +1093,7 @@ int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t
         int rc = launch_all(tk, c, c->d_text[sl], nb, c->d_off[sl], nd, flags, ids_direct ? ids_direct : c->d_ids + (ch.lo - ln.lo),
                             nb + 16, oo, c->s_cmp, nullptr, tk->regex ? &ext : nullptr);
         if (rc) return rc;
+        if (ext.d_status) HIP_TRY(hipMemcpyAsync(c->h_rx_status, c->d_rx_status, 4, hipMemcpyDeviceToHost, c->s_cmp));    // (the word accumulates over the batch's chunks)
         if (solo) break;                                   // (the batch is ONE chunk: the caller finishes on the compute stream itself)
         HIP_TRY(hipEventRecord(c->ev_cmp[sl], c->s_cmp));
         HIP_TRY(hipMemcpyAsync(&h_tot[k], oo + nd, 8, hipMemcpyDeviceToHost, c->s_cmp));

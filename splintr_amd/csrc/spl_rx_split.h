@@ -25,7 +25,9 @@
 // What the matcher gives up on is REPORTED, never approximated (status word != 0, the caller splits that batch on the host):
 // a match or a look-ahead that reaches RX_REACH bytes beyond its start (every position of a run scans to the run's end --
 // the work is quadratic in the run length, so it is bounded), RX_STEPS matcher steps in one attempt, RX_DEPTH entries on the
-// backtracking stack, RX_MAX_OPEN blocks in a row whose walks never fall into step.  Special-token literals are not handled here (with SPL_WITH_SPECIAL the host splitter runs).
+// backtracking stack, RX_MAX_OPEN blocks in a row whose walks never fall into step.
+// With SPL_WITH_SPECIAL the literals come from the GPU's own scan (k_special_scan / the general matcher, spl_k_special.h: text-start and
+// token bitmaps); a literal is a position whose hop is its length, dropped, with the text ending in front of it and beginning anew behind it.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -60,6 +62,11 @@ struct RxArgs {
     uint16_t* nx; uint16_t* gx; uint32_t* blk; uint32_t* dstart;      // workspace: per byte, per byte, per block (zeroed), bitmap
     uint32_t* starts; uint32_t* gaps;                                  // out: the two bitmaps (zeroed by the caller)
     uint32_t* status;                                                  // out: RXS_* bits, OR-ed
+    // SPL_WITH_SPECIAL: the bitmaps k_mark_docs / k_special_scan have left (null: none) -- text starts (documents AND behind every literal),
+    // tokens so far (= where a literal starts); sp_words words each.  A literal is a stretch of dropped bytes with a start bit at either end
+    // (encode_with_special runs the pattern over the stretches between the literals, tokenizer.rs:842-874): here a position whose hop is
+    // the literal's length, with the text ending in front of it and beginning anew behind it.
+    const uint32_t* sp_tstart; const uint32_t* sp_tbits; uint32_t sp_words;
 };
 
 struct RxCh { uint32_t cp, len, cls; };
@@ -187,7 +194,7 @@ struct RxBlock {
     uint32_t start, B;
     const uint32_t* s_ds;             // document starts of the window
     bool any_ds;
-    uint32_t* s_next;                 // next position of the block nobody has taken
+    const uint32_t* s_ls;             // where special-token literals start (null: none)
     uint16_t* s_j;                    // out: level-0 pointers of the block's positions
 };
 
@@ -446,7 +453,8 @@ __device__ __forceinline__ void rx_attempts(RxCtx& c, uint32_t* stk, const RxBlo
     //  pattern that backtracks without end can cost: the attempts in flight run into RX_STEPS, everything behind them is skipped)
     const bool given_up = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
     // (a byte inside a character: the walk never stands there, its hop is "one on")
-    bool act = p < bk.B && !given_up && ((cs[wi >> 5] >> (wi & 31)) & 1u) != 0u;
+    const bool lit = p < bk.B && bk.s_ls && ((bk.s_ls[wi >> 5] >> (wi & 31)) & 1u) != 0u;       // a special-token literal starts here
+    bool act = p < bk.B && !given_up && !lit && ((cs[wi >> 5] >> (wi & 31)) & 1u) != 0u;
     RxAt at{p, bk.B, 0u, false};
     uint32_t b0 = 0;
     if (act) {
@@ -481,7 +489,13 @@ __device__ __forceinline__ void rx_attempts(RxCtx& c, uint32_t* stk, const RxBlo
     }
     if (p < bk.B) {                                        // the position's hop
         uint32_t nxv = 1u | 0x8000u;
-        if (e != RX_FAIL) {
+        if (lit) {                                         // the literal: to the next text start (the one behind it), dropped
+            uint32_t nn = bk.B, i = wi + 1, w = i >> 5;
+            uint32_t bits = bk.s_ds[w] & (~0u << (i & 31));
+            while (!bits && ++w < (uint32_t)DSW) bits = bk.s_ds[w];
+            if (bits) { const uint32_t en = c.wb + w * 32 + (uint32_t)__ffs((int)bits) - 1u; nn = en < nn ? en : nn; }
+            nxv = (nn - p) | 0x8000u;
+        } else if (e != RX_FAIL) {
             uint32_t d = e - p;
             if (d > (uint32_t)RX_REACH - 8u) { atomicOr(a.status, RXS_REACH); d = RX_REACH - 8; }
             nxv = d;
@@ -523,8 +537,8 @@ __global__ __launch_bounds__(RXT) void k_rx_match(RxArgs a) {
     __shared__ __attribute__((aligned(4))) uint8_t s_txt[RX_LDS_TEXT + 4];
     __shared__ uint32_t s_ds[(RX_BACK + RXB + RX_REACH) / 32 + 2];            // document starts of [wbase, wbase + RX_BACK + RXB + RX_REACH)
     __shared__ uint16_t s_j[RXB];
+    __shared__ uint32_t s_ls[(RX_BACK + RXB + RX_REACH) / 32 + 2];            // literal starts of the window (SPL_WITH_SPECIAL)
     __shared__ uint32_t s_bm[(RX_MAX_RUNSETS + 1) * RX_BMW];
-    __shared__ uint32_t s_next;
     const int tid = (int)threadIdx.x;
     const uint32_t B = a.n_bytes;
     const uint32_t start = blockIdx.x * (uint32_t)RXB;
@@ -532,7 +546,6 @@ __global__ __launch_bounds__(RXT) void k_rx_match(RxArgs a) {
     constexpr int DSW = (RX_BACK + RXB + RX_REACH) / 32 + 2;
     for (int i = tid; i < (int)a.image_words; i += RXT) s_img[i] = a.image[i];
     for (int i = tid; i < DSW; i += RXT) s_ds[i] = 0;
-    if (tid == 0) s_next = 0;
     for (int w = tid; w < (RX_LDS_TEXT + 3) / 4; w += RXT) {
         const int64_t g = wbase + 4 * (int64_t)w;
         uint32_t v = 0;
@@ -561,6 +574,26 @@ __global__ __launch_bounds__(RXT) void k_rx_match(RxArgs a) {
         const bool in = dp < whi && dp < (uint64_t)B;
         if (in) { const uint32_t i = (uint32_t)((int64_t)dp - wbase); atomicOr(&s_ds[i >> 5], 1u << (i & 31)); }
         if (!__syncthreads_or(tid == RXT - 1 && in)) break;
+    }
+    if (a.sp_tstart) {
+        // the window's words of the two bitmaps (the window begins 4 bits in front of a multiple of 256): text starts join the
+        // document starts, literal starts END the text in front of them and are kept apart as well
+        for (int w = tid; w < DSW; w += RXT) {
+            const int64_t g = wbase + 32 * (int64_t)w;
+            auto win = [&](const uint32_t* bm) -> uint32_t {
+                if (g + 32 <= 0) return 0u;
+                if (g < 0) return (0 < (int64_t)a.sp_words ? bm[0] : 0u) << (uint32_t)(-g);
+                const uint64_t wi0 = (uint64_t)g >> 5;
+                const uint32_t sh = (uint32_t)g & 31u;
+                uint32_t v = wi0 < a.sp_words ? bm[wi0] >> sh : 0u;
+                if (sh && wi0 + 1 < a.sp_words) v |= bm[wi0 + 1] << (32u - sh);
+                return v;
+            };
+            const uint32_t ls = win(a.sp_tbits);
+            s_ls[w] = ls;
+            s_ds[w] |= win(a.sp_tstart) | ls;
+        }
+        __syncthreads();
     }
     bool any_here = false;
     for (int i = tid; i < DSW; i += RXT) any_here = any_here || s_ds[i] != 0u;
@@ -607,7 +640,7 @@ __global__ __launch_bounds__(RXT) void k_rx_match(RxArgs a) {
     }
 #else
     {
-        RxBlock bk{start, B, s_ds, any_ds, &s_next, s_j};
+        RxBlock bk{start, B, s_ds, any_ds, a.sp_tstart ? s_ls : nullptr, s_j};
         rx_attempts(c, s_stk + tid, bk, a, (uint32_t)tid);
     }
 #endif
@@ -637,7 +670,7 @@ __global__ __launch_bounds__(RXB) void k_rx_mark(RxArgs a) {
     __shared__ uint16_t s_lev[8 * RXB];
     __shared__ uint8_t s_m[RXB];
     __shared__ unsigned long long s_cm[RXB / 64], s_gm[RXB / 64];
-    __shared__ uint32_t s_gb[RXB / 32 + 1];
+    __shared__ uint32_t s_gb[RXB / 32 + 9];              // dropped bytes of the block's nodes: a character's 4, a special-token literal's 255
     __shared__ uint32_t s_e[2];
     const int tid = (int)threadIdx.x;
     const uint32_t B = a.n_bytes;
@@ -670,7 +703,7 @@ __global__ __launch_bounds__(RXB) void k_rx_mark(RxArgs a) {
     const uint32_t nxv = p < B ? (uint32_t)a.nx[p] : (1u | 0x8000u);
     s_j[tid] = (uint16_t)(p < B ? rx_hop((uint32_t)tid, nxv) : (RXJ_EXIT | 0u));
     s_m[tid] = 0;
-    if (tid < RXB / 32 + 1) s_gb[tid] = 0;
+    if (tid < RXB / 32 + 9) s_gb[tid] = 0;
     __syncthreads();
     rx_double<RXB>(s_j, s_lev, tid);
     const uint32_t E = s_e[0], pg_in = s_e[1];
@@ -710,7 +743,7 @@ __global__ __launch_bounds__(RXB) void k_rx_mark(RxArgs a) {
         if ((uint32_t)sm) atomicOr(&a.starts[w0], (uint32_t)sm);
         if ((uint32_t)(sm >> 32)) atomicOr(&a.starts[w0 + 1], (uint32_t)(sm >> 32));
     }
-    if (tid < RXB / 32 + 1 && s_gb[tid]) atomicOr(&a.gaps[(start >> 5) + (uint32_t)tid], s_gb[tid]);
+    if (tid < RXB / 32 + 9 && s_gb[tid]) atomicOr(&a.gaps[(start >> 5) + (uint32_t)tid], s_gb[tid]);
 }
 
 }  // namespace spl

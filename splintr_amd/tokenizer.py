@@ -107,7 +107,7 @@ class Tokenizer:
     Differences from the reference, all refused loudly rather than approximated:
     * `pattern`: CL100K_BASE_PATTERN, O200K_BASE_PATTERN (= LLAMA3_PATTERN) and MISTRAL_V3_PATTERN are split on the
       GPU by closed-form scanners; any other pattern is compiled by the library's own regex matcher and run at every text position
-      on the GPU (csrc/spl_rx_split.h; on the host cores with special tokens, and for the rare batch the device matcher gives up
+      on the GPU (csrc/spl_rx_split.h; on the host cores for the rare batch the device matcher gives up
       on -- a match longer than ~1 KB) (literals, classes, \s \d \w,
       every general category as \p{..}, groups, (?i:), (?>), alternation, greedy / lazy / possessive quantifiers,
       look-ahead, ^ $ \A \Z \z \b \B: upstream tiktoken's cl100k_base / o200k_base strings, Qwen2's and GPT-2's are accepted as
@@ -358,7 +358,7 @@ class Tokenizer:
     @property
     def has_custom_pattern(self) -> bool:
         """Extension: True when the split pattern is not one of the three the GPU scanner implements (its split then
-        runs as a matcher program -- on the GPU, or on the host cores with special tokens --, and no context-free cut position is
+        runs as a matcher program -- on the GPU, or on the host cores for what the device matcher gives up on --, and no context-free cut position is
         known for it: splintr_amd.distributed keeps such a tokenizer's documents whole)."""
         return self._pattern not in _PATTERN_ID
 

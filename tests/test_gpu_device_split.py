@@ -210,3 +210,31 @@ def test_random_patterns_device_bitmaps_equal_the_host_splitter_s():
             assert np.array_equal(gp, dgp), f"{pat!r}: gap bits differ first at byte {_first_diff(gp, dgp)}"
         done += 1
     assert done >= 100 and gave_up <= done // 4, (done, gave_up)
+
+
+def test_special_tokens_are_found_by_the_gpu_scan_and_the_device_splitter_works_between_them():
+    """encode_batch_with_special on a custom-pattern handle: the literals come from the GPU's own scan (k_special_scan / the general matcher),
+    the device splitter takes each literal as a stretch of dropped bytes with the text ending in front of it and beginning anew behind it
+    (tokenizer.rs:842-874) -- same ids as with the split kept on the host, and nothing fell back"""
+    import random
+    from splintr_amd import Tokenizer, _ffi
+    L = _ffi.lib()
+    for sp in ({"<|endoftext|>": 100257, "<|fim|>": 100258}, {"<|a|>": 100300, "<|a|>x": 100301, "<|endoftext|>": 100257, "\n\n": 100302}):
+        t = Tokenizer.from_bytes(_blob("cl100k_base"), TIKTOKEN_CL100K, sp)
+        h = Tokenizer.from_bytes(_blob("cl100k_base"), TIKTOKEN_CL100K, sp)
+        assert L.spl_set_option(h.handle, b"device_split", 0) == 0
+        rng = random.Random(11)
+        lits = list(sp)
+        texts = []
+        for x in fuzz_corpus(31, 1500, 30) + latin_corpus(5, 300, 60):
+            for _ in range(rng.choice([0, 1, 1, 2])):
+                c = rng.randrange(len(x) + 1)
+                x = x[:c] + rng.choice(lits) + x[c:]
+            texts.append(x)
+        texts += ["<|endoftext|>", "<|a|>x<|a|>", "a<|fim|>", "<|fim|>a", "<|fi", "<|a|><|a|>x<|endoftext|>tail", "", "<|endoftext|>" * 40, " <|fim|> "]
+        for batch in (texts, ["".join(texts[:300])]):
+            a = t.encode_batch_with_special(batch)
+            b = h.encode_batch_with_special(batch)
+            assert a == b
+            assert t.encode_batch(batch) == h.encode_batch(batch)
+        assert L.spl_device_split_fallbacks(t.handle) == 0
