@@ -168,10 +168,9 @@ int spl_encode_batch_device(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_
 /* Handles with SPL_PATTERN_CUSTOM: spl_encode_batch / spl_decode_batch work as for every other handle (the split of
  * each pipeline chunk runs on the device splitter, csrc/spl_rx_split.h, behind the GPU's special-token scan with
  * SPL_WITH_SPECIAL -- or, for what the device matcher gives up on, on the host cores while the previous chunk is on the GPU).  spl_encode_batch_device
- * and spl_encode_batch_device_packed run the device splitter in front of the tile kernel: ONE synchronisation of
- * `hip_stream` inside the call (the splitter's status word decides what is launched next; when it gave up the text goes to
- * the host once and is split there); SPL_WITH_SPECIAL is refused by these two entry points for such a handle (their fallback finds no literals:
- * spl_encode_batch).  The halves are available separately:
+ * and spl_encode_batch_device_packed run the device splitter in front of the tile kernel (SPL_WITH_SPECIAL included) and
+ * synchronise `hip_stream` ONCE before they return, to read the splitter's status word; when it gave up the text goes to
+ * the host once, is split there, and the encode runs again on those boundaries.  The halves are available separately:
  *   spl_split_host          the matches of the handle's pattern over a packed HOST corpus as two bitmaps of
  *                           n_bytes / 32 + 2 words each (zeroed here): bit p of start_bits -- a chunk, or a stretch of
  *                           bytes no match covers, starts at byte p; bit p of gap_bits -- byte p is dropped

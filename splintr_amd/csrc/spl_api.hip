@@ -850,14 +850,11 @@ int host_split_docs(const spl_tokenizer* tk, const uint8_t* text, const uint64_t
     return SPL_OK;
 }
 
-// A custom-pattern handle with its text in HBM (spl_encode_batch_device): the chunk boundaries from the device splitter.  ONE
-// stream synchronisation in the middle of the call -- the status word decides what runs next -- and, when the matcher gave up,
-// the text goes to the host once, is split there, and the bitmaps come back (rare: a match longer than ~1 KB).
-int custom_bits_device(spl_tokenizer* t, Ctx* c, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off, uint64_t n_docs,
-                       uint32_t flags, hipStream_t s, ExtIn& ext) {
-    if ((flags & SPL_WITH_SPECIAL) && !t->specials.empty())
-        return fail(SPL_EINVAL, "spl_encode_batch_device: a custom split pattern with SPL_WITH_SPECIAL is split on the host (the literals are found "
-                                "there): use spl_encode_batch, or spl_split_host + spl_encode_chunks_device");
+// A custom-pattern handle with its text in HBM (spl_encode_batch_device / _packed): the device splitter and the tile kernel in one go,
+// then ONE stream synchronisation to read the splitter's status word; when the matcher gave up (rare: a match longer than ~1 KB) the text
+// goes to the host once, is split there (special-token literals included) and the encode runs again on those boundaries.
+int encode_device_custom(spl_tokenizer* t, Ctx* c, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off, uint64_t n_docs,
+                         uint32_t flags, uint32_t* d_ids, uint64_t ids_cap, uint64_t* d_out_off, hipStream_t s, const SlabOut* so) {
     if (n_bytes > SPL_DIRECT_MAX_BYTES) return fail(SPL_EINVAL, "spl_encode_batch_device: a custom split pattern takes at most 256 MB per device call");
     const uint64_t bw = n_bytes / 32 + 4;
     if (2 * bw > c->rx_bits_cap) {
@@ -867,30 +864,48 @@ int custom_bits_device(spl_tokenizer* t, Ctx* c, const uint8_t* d_utf8, uint64_t
         HIP_TRY(hipMalloc((void**)&c->d_rx_bits, cap * 4));
         c->rx_bits_cap = cap;
     }
+    ExtIn ext;
     ext.d_starts = c->d_rx_bits; ext.d_gaps = c->d_rx_bits + bw;
-    uint32_t gave_up = 1;
     if (t->rx_device && !t->rx_image.empty()) {
         int rc = rx_ensure(t, c);
         if (rc) return rc;
         HIP_TRY(hipMemsetAsync(c->d_rx_status, 0, 4, s));
-        rc = rx_launch(t, c, d_utf8, n_bytes, d_doc_off, n_docs, c->d_rx_bits, c->d_rx_bits + bw, c->d_rx_status, s);
+        ext.d_status = c->d_rx_status;
+        rc = launch_all(t, c, d_utf8, n_bytes, d_doc_off, n_docs, flags, d_ids, ids_cap, d_out_off, s, so, &ext);
         if (rc) return rc;
+        uint32_t gave_up = 1;
         HIP_TRY(hipMemcpyAsync(&gave_up, c->d_rx_status, 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        if (gave_up) t->rx_fallbacks++;
+        if (!gave_up) return SPL_OK;
+        t->rx_fallbacks++;
+        ext.d_status = nullptr;
     }
-    if (gave_up) {
-        std::vector<uint8_t> text(n_bytes + 16);
-        std::vector<uint64_t> off(n_docs + 1);
-        if (n_bytes) HIP_TRY(hipMemcpyAsync(text.data(), d_utf8, n_bytes, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(off.data(), d_doc_off, (n_docs + 1) * 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        std::vector<uint32_t> bits(2 * bw, 0u);
-        int rc = host_split_docs(t, text.data(), off.data(), n_docs, false, bits.data(), bits.data() + bw, nullptr, 128);
-        if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(c->d_rx_bits, bits.data(), 2 * bw * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipStreamSynchronize(s));                   // (the vectors die with this frame)
+    const bool special = (flags & SPL_WITH_SPECIAL) && !t->specials.empty();
+    std::vector<uint8_t> text(n_bytes + 16);
+    std::vector<uint64_t> off(n_docs + 1);
+    if (n_bytes) HIP_TRY(hipMemcpyAsync(text.data(), d_utf8, n_bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(off.data(), d_doc_off, (n_docs + 1) * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::vector<uint32_t> bits(2 * bw, 0u);
+    std::vector<SpHit> hits;
+    int rc = host_split_docs(t, text.data(), off.data(), n_docs, special, bits.data(), bits.data() + bw, &hits, 128);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_rx_bits, bits.data(), 2 * bw * 4, hipMemcpyHostToDevice, s));
+    uint32_t* d_hits = nullptr;
+    std::vector<uint32_t> hp;
+    if (!hits.empty()) {
+        const uint64_t n = hits.size();
+        hp.resize(2 * n);
+        for (uint64_t i = 0; i < n; i++) { hp[i] = hits[i].start; hp[n + i] = hits[i].id; }
+        HIP_TRY(hipMalloc((void**)&d_hits, n * 8));
+        if (hipMemcpyAsync(d_hits, hp.data(), n * 8, hipMemcpyHostToDevice, s) != hipSuccess) { hipFree(d_hits); return fail(SPL_EDEVICE, "hipMemcpyAsync failed"); }
+        ext.d_sp_pos = d_hits; ext.d_sp_id = d_hits + n; ext.n_sp = (uint32_t)n;
     }
+    rc = launch_all(t, c, d_utf8, n_bytes, d_doc_off, n_docs, flags, d_ids, ids_cap, d_out_off, s, so, &ext);
+    const hipError_t se = hipStreamSynchronize(s);           // (the vectors and the list die with this frame)
+    if (d_hits) hipFree(d_hits);
+    if (rc) return rc;
+    if (se != hipSuccess) return fail(SPL_EDEVICE, std::string("hipStreamSynchronize: ") + hipGetErrorString(se));
     return SPL_OK;
 }
 
@@ -1536,10 +1551,8 @@ static int spl_encode_batch_device_impl(spl_tokenizer* t, const uint8_t* d_utf8,
     if (!t || !d_doc_off || !d_out_off || (n_bytes && (!d_utf8 || !d_ids)))
         return fail(SPL_EINVAL, "spl_encode_batch_device: null argument");
     HIP_TRY(hipSetDevice(t->ctx[0]->device));
-    ExtIn ext;
-    if (t->regex) { int rc = custom_bits_device(t, t->ctx[0].get(), d_utf8, n_bytes, d_doc_off, n_docs, flags, (hipStream_t)hip_stream, ext); if (rc) return rc; }
-    return launch_all(t, t->ctx[0].get(), d_utf8, n_bytes, d_doc_off, n_docs, flags, d_ids, ids_capacity, d_out_off, (hipStream_t)hip_stream,
-                      nullptr, t->regex ? &ext : nullptr);
+    if (t->regex) return encode_device_custom(t, t->ctx[0].get(), d_utf8, n_bytes, d_doc_off, n_docs, flags, d_ids, ids_capacity, d_out_off, (hipStream_t)hip_stream, nullptr);
+    return launch_all(t, t->ctx[0].get(), d_utf8, n_bytes, d_doc_off, n_docs, flags, d_ids, ids_capacity, d_out_off, (hipStream_t)hip_stream);
 }
 
 static int spl_encode_batch_device_packed_impl(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
@@ -1553,10 +1566,8 @@ static int spl_encode_batch_device_packed_impl(spl_tokenizer* t, const uint8_t* 
     HIP_TRY(hipSetDevice(t->ctx[0]->device));
     SlabOut so;
     so.d_slab = d_slab; so.cap_words = cap_words; so.max_docs = max_docs;
-    ExtIn ext;
-    if (t->regex) { int rc = custom_bits_device(t, t->ctx[0].get(), d_utf8, n_bytes, d_doc_off, n_docs, flags, (hipStream_t)hip_stream, ext); if (rc) return rc; }
-    return launch_all(t, t->ctx[0].get(), d_utf8, n_bytes, d_doc_off, n_docs, flags, d_ids, ids_capacity, d_out_off, (hipStream_t)hip_stream, &so,
-                      t->regex ? &ext : nullptr);
+    if (t->regex) return encode_device_custom(t, t->ctx[0].get(), d_utf8, n_bytes, d_doc_off, n_docs, flags, d_ids, ids_capacity, d_out_off, (hipStream_t)hip_stream, &so);
+    return launch_all(t, t->ctx[0].get(), d_utf8, n_bytes, d_doc_off, n_docs, flags, d_ids, ids_capacity, d_out_off, (hipStream_t)hip_stream, &so);
 }
 
 int spl_encode_batch(spl_tokenizer* t, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,

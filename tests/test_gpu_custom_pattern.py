@@ -190,10 +190,19 @@ def test_split_on_the_host_encode_on_the_device_entry_points():
         off = b.out_off.cpu().numpy().astype(np.uint64)
         assert np.array_equal(off, want_off)
         assert np.array_equal(b.ids[:int(off[-1])].cpu().numpy().view(np.uint32), want_ids)
-    ts = Tokenizer.from_bytes(_blob("cl100k_base"), GPT2_PATTERN, {"<|x|>": 100300})
-    rc = L.spl_encode_batch_device(ts.handle, b.text.data_ptr(), b.n_bytes, b.doc_off.data_ptr(), b.n_docs, _ffi.SPL_WITH_SPECIAL, b.ids.data_ptr(),
-                                   b.ids.numel(), b.out_off.data_ptr(), None)
-    assert rc != 0 and "spl_split_host" in _ffi.last_error()
+    # ... with special tokens as well (the literals from the GPU's own scan; from the host splitter when the device matcher gave up)
+    ts = Tokenizer.from_bytes(_blob("cl100k_base"), GPT2_PATTERN, {"<|x|>": 100300, "<|endoftext|>": 100257})
+    for batch in ([x + "<|x|>" + x[:7] for x in texts] + ["<|endoftext|>", "a<|x|><|x|>b"], [x + "<|x|>" for x in texts] + ["w" * 5000 + "<|endoftext|>z"]):
+        want_ids, want_off = ts.encode_batch_csr(batch, with_special=True)
+        b = DeviceBatch(batch, dev)
+        b.ids.fill_(-1)
+        rc = L.spl_encode_batch_device(ts.handle, b.text.data_ptr(), b.n_bytes, b.doc_off.data_ptr(), b.n_docs, _ffi.SPL_WITH_SPECIAL, b.ids.data_ptr(),
+                                       b.ids.numel(), b.out_off.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, _ffi.last_error()
+        torch.cuda.synchronize()
+        off = b.out_off.cpu().numpy().astype(np.uint64)
+        assert np.array_equal(off, want_off)
+        assert np.array_equal(b.ids[:int(off[-1])].cpu().numpy().view(np.uint32), want_ids)
 
 
 def test_unsupported_patterns_raise_the_reference_s_error_type():
