@@ -379,8 +379,31 @@ __device__ __forceinline__ uint32_t rx_simple_alt(const RxCtx& c, const uint32_t
     bool ok = on;
     for (uint32_t it = 0; it < n_items; it++) {
         const uint4 item = *reinterpret_cast<const uint4*>(items + 4 * it);       // op, x, min, max
+        // (the same for every lane: in scalar registers the tests on them are scalar branches, not exec-mask detours)
+        const uint32_t op = __builtin_amdgcn_readfirstlane(item.x), x = __builtin_amdgcn_readfirstlane(item.y);
+        const uint32_t mn = __builtin_amdgcn_readfirstlane(item.z), mx = __builtin_amdgcn_readfirstlane(item.w);
+        if (op == RXO_CHAR && mx == 1u && x < 0x80u) {          // an ASCII literal, once or not at all: no branch per lane
+            const bool hit = ok && pos < n && c.rd(pos) == x;
+            ok = ok && (hit || mn == 0u);
+            rs = pos; rk = hit ? 1u : 0u;
+            pos += hit ? 1u : 0u;
+            continue;
+        }
+        if (mx == 1u) {                                        // one character, once or not at all: no loop
+            bool hit = false;
+            uint32_t len = 1;
+            if (ok && pos < n) {
+                if (trunc && pos + 8 > lim) { why = RXS_REACH; return RX_ABORT; }
+                const uint32_t b = c.rd(pos);
+                if (b < 0x80) hit = c.one_ascii(op, x, b);
+                else { const RxCh ch = c.decode(pos); hit = c.one(op, x, ch); len = ch.len; }
+            }
+            ok = ok && (hit || mn == 0u);
+            rs = pos; rk = hit ? 1u : 0u;
+            pos += hit ? len : 0u;
+            continue;
+        }
         if (!ok) continue;
-        const uint32_t op = item.x, x = item.y, mn = item.z, mx = item.w;
         uint32_t q = pos, k = 0;
         bool more = true;
         if (op == RXO_CLASS && mx > 8u && pos < n) {
@@ -388,11 +411,25 @@ __device__ __forceinline__ uint32_t rx_simple_alt(const RxCtx& c, const uint32_t
             if (slot != 0xFFFFFFFFu && i0 < (uint32_t)RX_TAB) {
                 const uint32_t ni = n - c.wb;
                 const uint32_t tl = ni < (uint32_t)RX_TAB ? ni : (uint32_t)RX_TAB;
-                uint32_t e = c.first_zero(c.bm + slot * RX_BMW, i0, tl);
-                const bool open_end = e == (uint32_t)RX_TAB && e < ni;
-                if (open_end && e > i0) e = c.last_set_below(cs, e);
-                const uint32_t kk = c.count_set(cs, i0, e);
-                if (kk <= mx) { k = kk; q = pos + (e - i0); more = open_end; }
+                // the 64 bits from i0 on, without a loop: nearly every run ends inside them (the words behind a bitmap's end that this may
+                // read belong to the next bitmap / the padding, and lie beyond tl)
+                const uint32_t* const m = c.bm + slot * RX_BMW + (i0 >> 5);
+                const uint32_t* const s3 = cs + (i0 >> 5);
+                const uint32_t sh = i0 & 31u;
+                const uint32_t mlo = __builtin_amdgcn_alignbit(m[1], m[0], sh), mhi = __builtin_amdgcn_alignbit(m[2], m[1], sh);
+                const uint32_t er = ~mlo ? (uint32_t)__ffs((int)~mlo) - 1u : ~mhi ? 32u + (uint32_t)__ffs((int)~mhi) - 1u : 64u;
+                if (er < 64u && i0 + er < tl) {
+                    const uint32_t clo = __builtin_amdgcn_alignbit(s3[1], s3[0], sh), chi = __builtin_amdgcn_alignbit(s3[2], s3[1], sh);
+                    const uint32_t kk = er >= 32u ? (uint32_t)__popc(clo) + (uint32_t)__popc(chi & ((1u << (er - 32u)) - 1u))
+                                                  : (uint32_t)__popc(clo & ((1u << er) - 1u));
+                    if (kk <= mx) { k = kk; q = pos + er; more = false; }
+                } else {
+                    uint32_t e = c.first_zero(c.bm + slot * RX_BMW, i0, tl);
+                    const bool open_end = e == (uint32_t)RX_TAB && e < ni;
+                    if (open_end && e > i0) e = c.last_set_below(cs, e);
+                    const uint32_t kk = c.count_set(cs, i0, e);
+                    if (kk <= mx) { k = kk; q = pos + (e - i0); more = open_end; }
+                }
             }
         }
         while (more && k < mx && q < n) {
@@ -469,15 +506,18 @@ __device__ __forceinline__ void rx_attempts(RxCtx& c, uint32_t* stk, const RxBlo
         c.n = at.n;
         b0 = c.rd(p);                                      // (p < n: the attempt begins with a byte)
     }
-    const uint32_t* const alts = c.img + c.img[11];
-    const uint32_t n_alts = alts[0];
+    const uint32_t* const alts = c.img + __builtin_amdgcn_readfirstlane(c.img[11]);
+    const uint32_t* const fsets = c.img + __builtin_amdgcn_readfirstlane(c.img[3]);
+    const uint32_t n_alts = __builtin_amdgcn_readfirstlane(alts[0]);
     uint32_t e = RX_FAIL, steps = 0;
     for (uint32_t ai = 0; ai < n_alts; ai++) {             // (uniform)
-        const uint4 alt = *reinterpret_cast<const uint4*>(alts + 4 + 4 * ai);     // filter, flags, first instruction, items (count | offset << 16)
+        uint4 alt = *reinterpret_cast<const uint4*>(alts + 4 + 4 * ai);           // filter, flags, first instruction, items (count | offset << 16)
+        alt.x = __builtin_amdgcn_readfirstlane(alt.x); alt.y = __builtin_amdgcn_readfirstlane(alt.y);     // (the same for every lane)
+        alt.z = __builtin_amdgcn_readfirstlane(alt.z); alt.w = __builtin_amdgcn_readfirstlane(alt.w);
         bool can = act && e == RX_FAIL;
-        if (can && alt.x != 0xFFFFFFFFu) {
-            const uint32_t* fs = c.img + c.img[3] + RX_FIRST_WORDS * alt.x;
-            can = b0 < 0x80 ? ((fs[b0 >> 5] >> (b0 & 31)) & 1u) != 0 : fs[4] != 0u;
+        if (alt.x != 0xFFFFFFFFu) {
+            const uint32_t* fs = fsets + RX_FIRST_WORDS * alt.x;
+            can = can && (b0 < 0x80 ? ((fs[b0 >> 5] >> (b0 & 31)) & 1u) != 0 : fs[4] != 0u);
         }
         if (!__any(can)) continue;
         uint32_t r = RX_FAIL, why = 0;
@@ -538,7 +578,7 @@ __global__ __launch_bounds__(RXT) void k_rx_match(RxArgs a) {
     __shared__ uint32_t s_ds[(RX_BACK + RXB + RX_REACH) / 32 + 2];            // document starts of [wbase, wbase + RX_BACK + RXB + RX_REACH)
     __shared__ uint16_t s_j[RXB];
     __shared__ uint32_t s_ls[(RX_BACK + RXB + RX_REACH) / 32 + 2];            // literal starts of the window (SPL_WITH_SPECIAL)
-    __shared__ uint32_t s_bm[(RX_MAX_RUNSETS + 1) * RX_BMW];
+    __shared__ uint32_t s_bm[(RX_MAX_RUNSETS + 1) * RX_BMW + 2];     // (+ 2: the 64-bit window of a run scan may read two words on)
     const int tid = (int)threadIdx.x;
     const uint32_t B = a.n_bytes;
     const uint32_t start = blockIdx.x * (uint32_t)RXB;
