@@ -811,18 +811,7 @@ bool regex_device_image(const RegexProg& prog, std::vector<uint32_t>& w) {
     }
     w[5] = (uint32_t)w.size(); w[6] = (uint32_t)(ranges.size() / 2);
     w.insert(w.end(), ranges.begin(), ranges.end());
-    // first-byte dispatch: Matcher::run's first steps for an attempt that begins with byte b -- the SPLITs whose filter rules b out
-    w[8] = (uint32_t)w.size();
-    for (uint32_t b = 0; b <= 128; b++) {
-        uint32_t pc = 0;
-        while (prog.code[pc].op == OP_SPLIT && prog.code[pc].f != 0xFFFFFFFFu) {
-            const FirstSet& fs = prog.firsts[prog.code[pc].f];
-            const bool can = b < 128 ? ((fs.ascii[b >> 6] >> (b & 63)) & 1ull) != 0 : fs.other;
-            if (can) break;
-            pc = prog.code[pc].y;
-        }
-        w.push_back(pc);
-    }
+    // (w[8]: the first-byte table, filled in below once the alternatives are known)
     w[9] = (uint32_t)run_sets.size(); w[10] = (uint32_t)w.size();
     w.insert(w.end(), run_sets.begin(), run_sets.end());
     while (w.size() % 4) w.push_back(0u);
@@ -909,6 +898,19 @@ bool regex_device_image(const RegexProg& prog, std::vector<uint32_t>& w) {
         }
         al.simple = ok;
     }
+    // for each ASCII byte and (entry 128) any other: which alternatives an attempt that begins with it can start -- bit i: alternative i's
+    // first-character filter lets it in (all bits if the pattern has more than 32 alternatives: the filters are then tested one by one)
+    w[8] = (uint32_t)w.size();
+    for (uint32_t b = 0; b <= 128; b++) {
+        uint32_t mask = 0;
+        for (size_t i = 0; i < alts.size() && i < 32; i++) {
+            bool can = true;
+            if (alts[i].f != 0xFFFFFFFFu) { const FirstSet& fs = prog.firsts[alts[i].f]; can = b < 128 ? ((fs.ascii[b >> 6] >> (b & 63)) & 1ull) != 0 : fs.other; }
+            if (can) mask |= 1u << i;
+        }
+        w.push_back(alts.size() > 32 ? 0xFFFFFFFFu : mask);
+    }
+    while (w.size() % 4) w.push_back(0u);
     w[11] = (uint32_t)w.size();
     w.push_back((uint32_t)alts.size()); w.push_back(0u); w.push_back(0u); w.push_back(0u);
     const size_t ent = w.size();

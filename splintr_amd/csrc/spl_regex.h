@@ -48,9 +48,8 @@ bool regex_split_bits(const RegexProg& prog, const uint8_t* text, size_t n, uint
 // of the first-byte dispatch, [9] class sets with a run bitmap, [10] offset of their list, [11] offset of the alternatives --; from word RX_HDR_WORDS the
 // instructions, RX_INST_WORDS words each (op, x, y, f); class sets of RX_SET_WORDS words (class-code bits, general-category bits,
 // negated, four words of ASCII membership, first range, ranges, run-bitmap slot or ~0); filters of RX_FIRST_WORDS words (four
-// words of ASCII membership, "anything beyond ASCII"); ranges as (first, last) pairs; the dispatch: for each ASCII byte and (entry
-// 128) for any other, where an attempt that begins with this byte starts in the program -- behind the alternatives of the
-// top-level alternation whose first-character filter rules the byte out; the list of the (at most RX_MAX_RUNSETS) class sets
+// words of ASCII membership, "anything beyond ASCII"); ranges as (first, last) pairs; the first-byte table: for each ASCII byte and (entry
+// 128) for any other, a bit per alternative of the top-level alternation whose first-character filter lets the byte in; the list of the (at most RX_MAX_RUNSETS) class sets
 // that a run instruction repeats: the device matcher tabulates their membership over its text window once per block and takes a
 // run as a bit scan; the alternatives of the top-level alternation (count, three words of padding, then four words each: first-
 // character filter or ~0, 1 if SIMPLE | its tail kind << 8, first instruction, items | word offset of the items << 16; a simple alternative's items are

@@ -509,17 +509,19 @@ __device__ __forceinline__ void rx_attempts(RxCtx& c, uint32_t* stk, const RxBlo
     const uint32_t* const alts = c.img + __builtin_amdgcn_readfirstlane(c.img[11]);
     const uint32_t* const fsets = c.img + __builtin_amdgcn_readfirstlane(c.img[3]);
     const uint32_t n_alts = __builtin_amdgcn_readfirstlane(alts[0]);
+    const uint32_t viable = act ? c.img[c.img[8] + (b0 < 0x80 ? b0 : 128u)] : 0u;
     uint32_t e = RX_FAIL, steps = 0;
     for (uint32_t ai = 0; ai < n_alts; ai++) {             // (uniform)
+        // (which alternatives the attempt's first byte can start: one word from the image's first-byte table instead of a filter per alternative)
+        bool can = act && e == RX_FAIL && ((viable >> (ai & 31u)) & 1u) != 0u;
+        if (n_alts > 32u && can && alts[4 + 4 * ai] != 0xFFFFFFFFu) {
+            const uint32_t* fs = fsets + RX_FIRST_WORDS * alts[4 + 4 * ai];
+            can = b0 < 0x80 ? ((fs[b0 >> 5] >> (b0 & 31)) & 1u) != 0 : fs[4] != 0u;
+        }
+        if (!__any(can)) continue;
         uint4 alt = *reinterpret_cast<const uint4*>(alts + 4 + 4 * ai);           // filter, flags, first instruction, items (count | offset << 16)
         alt.x = __builtin_amdgcn_readfirstlane(alt.x); alt.y = __builtin_amdgcn_readfirstlane(alt.y);     // (the same for every lane)
         alt.z = __builtin_amdgcn_readfirstlane(alt.z); alt.w = __builtin_amdgcn_readfirstlane(alt.w);
-        bool can = act && e == RX_FAIL;
-        if (alt.x != 0xFFFFFFFFu) {
-            const uint32_t* fs = fsets + RX_FIRST_WORDS * alt.x;
-            can = can && (b0 < 0x80 ? ((fs[b0 >> 5] >> (b0 & 31)) & 1u) != 0 : fs[4] != 0u);
-        }
-        if (!__any(can)) continue;
         uint32_t r = RX_FAIL, why = 0;
         if (alt.y & 1u) r = rx_simple_alt(c, c.img + (alt.w >> 16), alt.w & 0xFFFFu, alt.y >> 8, p, at.n, can, why);
         else if (can) r = rx_vm(c, stk, a, at, alt.z, steps);
@@ -643,7 +645,7 @@ __global__ __launch_bounds__(RXT) void k_rx_match(RxArgs a) {
     // others), and for every class set that a run instruction repeats, the bytes of its member characters
     RxCtx c{s_img, s_txt, (uint32_t)wbase, &a, B, s_bm};
     {
-        const uint32_t nrs = s_img[9];
+        const uint32_t nrs = __builtin_amdgcn_readfirstlane(s_img[9]);
         const uint32_t* rs = s_img + s_img[10];
         for (int r = 0; r * RXT < RX_BMW * 32; r++) {
             const uint32_t i = (uint32_t)(r * RXT + tid);
@@ -659,14 +661,20 @@ __global__ __launch_bounds__(RXT) void k_rx_match(RxArgs a) {
                     break;
                 }
             }
-            RxCh ch{0, 1, 0};
-            if (valid) ch = c.decode_win(li, B, s_ds);
+            // (an ASCII byte is a character by itself and its membership is a bit of the set's ASCII words: no decode, no class lookup --
+            //  only bytes beyond ASCII go through the two-stage table in global memory)
+            const uint32_t bv = valid ? (uint32_t)s_txt[li] : 0u;
+            const bool asc = bv < 0x80u;
+            RxCh ch{bv, 1, 0};
+            if (valid && !asc) ch = c.decode_win(li, B, s_ds);
             const unsigned long long mcs = __ballot(valid && li == i);
             const uint32_t w0 = (uint32_t)(r * RXT + (tid & ~63)) >> 5;
             const bool wr = (tid & 63) == 0 && w0 + 1 < (uint32_t)RX_BMW;
             if (wr) { s_bm[RX_MAX_RUNSETS * RX_BMW + w0] = (uint32_t)mcs; s_bm[RX_MAX_RUNSETS * RX_BMW + w0 + 1] = (uint32_t)(mcs >> 32); }
             for (uint32_t k = 0; k < nrs; k++) {
-                const unsigned long long m = __ballot(valid && c.in_set(rs[k], ch));
+                const uint32_t sx = __builtin_amdgcn_readfirstlane(rs[k]);
+                const bool in = asc ? ((c.set(sx)[3 + (bv >> 5)] >> (bv & 31)) & 1u) != 0u : c.in_set(sx, ch);
+                const unsigned long long m = __ballot(valid && in);
                 if (wr) { s_bm[k * RX_BMW + w0] = (uint32_t)m; s_bm[k * RX_BMW + w0 + 1] = (uint32_t)(m >> 32); }
             }
         }
