@@ -202,7 +202,7 @@ struct Ctx {
     uint32_t* d_extsp[NSLOT] = {nullptr, nullptr, nullptr}; uint64_t extsp_cap = 0;
     // custom split patterns on the device (spl_rx_split.h): the program image, general categories, workspace, status word
     const uint32_t* d_rx_image = nullptr; const uint16_t* d_gc1 = nullptr; const uint8_t* d_gc2 = nullptr;
-    uint8_t* d_rx_ws = nullptr; uint64_t rx_ws_cap = 0;
+    uint8_t* d_rx_ws = nullptr; uint64_t rx_ws_cap = 0, rx_cap_blk = 0; uint32_t rx_gen = 0xFFFFu;
     uint32_t* d_rx_status = nullptr;
     uint32_t* h_rx_status = nullptr;                                // pinned copy: written behind every chunk's split, read when the batch is done
     uint32_t* d_rx_bits = nullptr; uint64_t rx_bits_cap = 0;       // the two bitmaps of a device-text call (spl_encode_batch_device)
@@ -700,32 +700,39 @@ int rx_launch(spl_tokenizer* tk, Ctx* c, const uint8_t* d_text, uint64_t n_bytes
     int rc = rx_ensure(tk, c);
     if (rc) return rc;
     const uint64_t words = n_bytes / 32 + 2;
-    if (d_gaps > d_starts && (uint64_t)(d_gaps - d_starts) <= words + 8) {      // (back to back: one fill)
-        HIP_TRY(hipMemsetAsync(d_starts, 0, ((uint64_t)(d_gaps - d_starts) + words) * 4, s));
-    } else {
+    if (!n_bytes) {                                    // (no block, no kernel: the two closing words by a fill)
         HIP_TRY(hipMemsetAsync(d_starts, 0, words * 4, s));
         HIP_TRY(hipMemsetAsync(d_gaps, 0, words * 4, s));
+        return SPL_OK;
     }
-    if (!n_bytes) return SPL_OK;
     const uint64_t nblk = (n_bytes + RXB - 1) / RXB;
-    const uint64_t need = 4 * nblk * RXB + 4 * nblk + 4 * (8 * nblk + 2) + 256;
-    if (need > c->rx_ws_cap) {
+    // workspace, laid out by its CAPACITY in blocks (the per-block entries must stay where they are from call to call -- they are
+    // told apart by generation, not cleared): blk | bskip | dstart | nx | gx
+    if (nblk > c->rx_cap_blk) {
         HIP_TRY(hipDeviceSynchronize());
-        hipFree(c->d_rx_ws); c->d_rx_ws = nullptr; c->rx_ws_cap = 0;
-        const uint64_t cap = need + need / 4;
+        hipFree(c->d_rx_ws); c->d_rx_ws = nullptr; c->rx_ws_cap = 0; c->rx_cap_blk = 0;
+        const uint64_t cb = nblk + nblk / 4 + 16;
+        const uint64_t cap = 8 * cb + 4 * (8 * cb + 2) + 4 * cb * RXB + 256;
         HIP_TRY(hipMalloc((void**)&c->d_rx_ws, cap));
-        c->rx_ws_cap = cap;
+        c->rx_ws_cap = cap; c->rx_cap_blk = cb;
+        c->rx_gen = 0xFFFFu;                           // (fresh memory: cleared below)
+    }
+    // the per-block entries carry the call's generation instead of being cleared per call (two fills of ~5 us each in front of the
+    // kernels of a 1 MB batch); every 65 535 calls -- and on fresh memory -- the workspace is cleared once
+    if (++c->rx_gen > 0xFFFFu) {
+        HIP_TRY(hipMemsetAsync(c->d_rx_ws, 0, c->rx_ws_cap, s));
+        c->rx_gen = 1;
     }
     RxArgs a{};
     a.image = c->d_rx_image; a.image_words = (uint32_t)tk->rx_image.size();
     a.text = d_text; a.doc_off = d_doc_off; a.n_bytes = (uint32_t)n_bytes; a.n_docs = (uint32_t)n_docs;
     a.ucls1 = c->dt.ucls_stage1; a.ucls2 = c->dt.ucls_stage2; a.shift = c->dt.ucls_shift;
     a.gc1 = c->d_gc1; a.gc2 = c->d_gc2;
-    a.nx = (uint16_t*)c->d_rx_ws; a.gx = a.nx + nblk * RXB;
-    a.blk = (uint32_t*)(a.gx + nblk * RXB); a.dstart = a.blk + nblk;
+    a.blk = (uint32_t*)c->d_rx_ws; a.bskip = a.blk + c->rx_cap_blk; a.dstart = a.bskip + c->rx_cap_blk;
+    a.nx = (uint16_t*)(a.dstart + 8 * c->rx_cap_blk + 2); a.gx = a.nx + c->rx_cap_blk * RXB;
+    a.gen = c->rx_gen; a.bm_words = (uint32_t)words;
     a.starts = d_starts; a.gaps = d_gaps; a.status = d_status;
     if (sp) { a.sp_tstart = sp->tstart; a.sp_tbits = sp->tbits; a.sp_words = sp_words; }
-    HIP_TRY(hipMemsetAsync(a.blk, 0, nblk * 4, s));
     hipLaunchKernelGGL(k_rx_match, dim3((uint32_t)nblk), dim3(RXT), (a.image_words * 4 + 15) & ~15u, s, a);
     hipLaunchKernelGGL(k_rx_mark, dim3((uint32_t)nblk), dim3(RXB), 0, s, a);
     HIP_TRY(hipGetLastError());

@@ -51,7 +51,8 @@ constexpr uint32_t RX_FAIL = 0xFFFFFFFFu, RX_ABORT = 0xFFFFFFFEu, RX_NOK = 0xFFF
 enum : uint32_t { RXS_REACH = 1, RXS_STEPS = 2, RXS_DEPTH = 4 };
 enum : uint32_t { RXO_CHAR = 0, RXO_CHAR_FOLD, RXO_CLASS, RXO_ANY, RXO_SPLIT, RXO_JMP, RXO_MATCH, RXO_LOOK, RXO_NLOOK, RXO_REP1, RXO_ATOMIC, RXO_ASSERT };
 enum : uint32_t { RXA_BOL = 0, RXA_EOL, RXA_EOT, RXA_WORDB, RXA_NWORDB };
-constexpr uint32_t RX_BLK_CLOSED = 1u << 31, RX_BLK_SKIPPED = 1u << 30;
+// blk[k]: the call's generation << 16 | the last hop was a skip << 15 | where every walk leaves block k -- written (plainly) only if the block is CLOSED;
+// bskip[k]: the generation of the last call in which a hop jumped over block k.  Entries of other generations are stale: no fill per call.
 constexpr uint32_t RXJ_EXIT = 1u << 15, RXJ_GAP = 1u << 14, RXJ_VAL = 0x3FFFu;
 
 struct RxArgs {
@@ -59,8 +60,10 @@ struct RxArgs {
     const uint8_t* text; const uint64_t* doc_off; uint32_t n_bytes, n_docs;
     const uint16_t* ucls1; const uint8_t* ucls2; uint32_t shift;
     const uint16_t* gc1; const uint8_t* gc2;
-    uint16_t* nx; uint16_t* gx; uint32_t* blk; uint32_t* dstart;      // workspace: per byte, per byte, per block (zeroed), bitmap
-    uint32_t* starts; uint32_t* gaps;                                  // out: the two bitmaps (zeroed by the caller)
+    uint16_t* nx; uint16_t* gx; uint32_t* blk; uint32_t* bskip; uint32_t* dstart;      // workspace: per byte, per byte, per block x 2, bitmap
+    uint32_t gen;                                                      // this call's generation (1 .. 65535)
+    uint32_t bm_words;                                                 // words of each result bitmap (n_bytes / 32 + 2)
+    uint32_t* starts; uint32_t* gaps;                                  // out: the two bitmaps (every word written by k_rx_mark)
     uint32_t* status;                                                  // out: RXS_* bits, OR-ed
     // SPL_WITH_SPECIAL: the bitmaps k_mark_docs / k_special_scan have left (null: none) -- text starts (documents AND behind every literal),
     // tokens so far (= where a literal starts); sp_words words each.  A literal is a stretch of dropped bytes with a start bit at either end
@@ -542,7 +545,7 @@ __device__ __forceinline__ void rx_attempts(RxCtx& c, uint32_t* stk, const RxBlo
             if (d > (uint32_t)RX_REACH - 8u) { atomicOr(a.status, RXS_REACH); d = RX_REACH - 8; }
             nxv = d;
             // a hop over whole blocks: they may not be touched by the walk at all
-            for (uint32_t k = (p >> 8) + 1; (k + 1) * (uint32_t)RXB <= p + d; k++) atomicOr(&a.blk[k], RX_BLK_SKIPPED);
+            for (uint32_t k = (p >> 8) + 1; (k + 1) * (uint32_t)RXB <= p + d; k++) a.bskip[k] = a.gen;
         } else if (!given_up && ((cs[wi >> 5] >> (wi & 31)) & 1u)) {
             nxv = c.char_len(p) | 0x8000u;                 // no match here (or an empty one): the character is skipped
         }
@@ -710,7 +713,7 @@ __global__ __launch_bounds__(RXT) void k_rx_match(RxArgs a) {
         same = same && (p >= B || g == g0);
     }
     if (__syncthreads_and(same) && tid == 0)
-        atomicOr(&a.blk[blockIdx.x], RX_BLK_CLOSED | ((g0 & RXJ_GAP) ? 0x8000u : 0u) | (g0 & RXJ_VAL));
+        a.blk[blockIdx.x] = (a.gen << 16) | ((g0 & RXJ_GAP) ? 0x8000u : 0u) | (g0 & RXJ_VAL);
 }
 
 __global__ __launch_bounds__(RXB) void k_rx_mark(RxArgs a) {
@@ -733,11 +736,11 @@ __global__ __launch_bounds__(RXB) void k_rx_mark(RxArgs a) {
         bool lost = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
         while (k >= 0 && !lost) {
             v = a.blk[k];
-            if ((v & RX_BLK_CLOSED) && !(v & RX_BLK_SKIPPED)) break;
+            if ((v >> 16) == a.gen && a.bskip[k] != a.gen) break;            // closed, and no hop jumps over it
             k--;
             if ((int64_t)b - k > (int64_t)RX_MAX_OPEN) { atomicOr(a.status, RXS_REACH); lost = true; }
         }
-        if (lost) k = (int64_t)b - 1, v = RX_BLK_CLOSED;       // (any entry will do: the bitmaps are not used)
+        if (lost) k = (int64_t)b - 1, v = 0;                    // (any entry will do: the bitmaps are not used)
         uint32_t E = 0, pg = 0;
         if (k >= 0) { E = ((uint32_t)k + 1u) * RXB + (v & 0x7FFFu); pg = (v >> 15) & 1u; }
         for (uint32_t kk = (uint32_t)(k + 1); kk < b && E < B; kk++) {
@@ -755,8 +758,20 @@ __global__ __launch_bounds__(RXB) void k_rx_mark(RxArgs a) {
     __syncthreads();
     rx_double<RXB>(s_j, s_lev, tid);
     const uint32_t E = s_e[0], pg_in = s_e[1];
-    if (E >= start + (uint32_t)RXB || E >= B) return;              // the walk does not touch this block (uniform)
+    // The block writes its own eight words of either bitmap PLAINLY (no fill in front of the kernels, no atomics): the dropped bytes of a
+    // character -- or a special-token literal -- that reaches over from the block in front are this block's to set (the walk enters at E;
+    // if the hop that got there was a skip, [start, E) is the rest of it: a skip is shorter than a block), what its own nodes drop
+    // beyond its end is the next block's.  The last block also clears the bitmaps' closing words.
+    const uint32_t wb0 = start >> 5;
+    auto put = [&](uint32_t* bm, uint32_t w, uint32_t v) { if (w < a.bm_words) bm[w] = v; };
+    if (b == gridDim.x - 1)
+        for (uint32_t w = wb0 + RXB / 32 + (uint32_t)tid; w < a.bm_words; w += RXB) { a.starts[w] = 0u; a.gaps[w] = 0u; }
+    if (E >= start + (uint32_t)RXB || E >= B) {                    // the walk does not touch this block (uniform): nothing starts, nothing is dropped
+        if (tid < RXB / 32) { put(a.starts, wb0 + (uint32_t)tid, 0u); put(a.gaps, wb0 + (uint32_t)tid, 0u); }
+        return;
+    }
     if ((uint32_t)tid == E - start) s_m[tid] = 1;
+    if (pg_in && (uint32_t)tid < E - start) atomicOr(&s_gb[tid >> 5], 1u << (tid & 31));
     __syncthreads();
     for (int k = 7; k >= 0; k--) {
         const uint32_t v = s_lev[k * RXB + tid];
@@ -787,11 +802,11 @@ __global__ __launch_bounds__(RXB) void k_rx_mark(RxArgs a) {
     }
     const unsigned long long sm = __ballot(st);
     if ((tid & 63) == 0) {
-        const uint32_t w0 = (start >> 5) + (uint32_t)(tid >> 5);
-        if ((uint32_t)sm) atomicOr(&a.starts[w0], (uint32_t)sm);
-        if ((uint32_t)(sm >> 32)) atomicOr(&a.starts[w0 + 1], (uint32_t)(sm >> 32));
+        const uint32_t w0 = wb0 + (uint32_t)(tid >> 5);
+        put(a.starts, w0, (uint32_t)sm);
+        put(a.starts, w0 + 1, (uint32_t)(sm >> 32));
     }
-    if (tid < RXB / 32 + 9 && s_gb[tid]) atomicOr(&a.gaps[(start >> 5) + (uint32_t)tid], s_gb[tid]);
+    if (tid < RXB / 32) put(a.gaps, wb0 + (uint32_t)tid, s_gb[tid]);
 }
 
 }  // namespace spl
