@@ -196,7 +196,7 @@ struct RxCtx {
 struct RxBlock {
     uint32_t start, B;
     const uint32_t* s_ds;             // document starts of the window
-    bool any_ds;
+    unsigned long long ds_nz;         // bit w: word w of s_ds holds a document start (the window has at most 64 words)
     const uint32_t* s_ls;             // where special-token literals start (null: none)
     uint16_t* s_j;                    // out: level-0 pointers of the block's positions
 };
@@ -486,6 +486,20 @@ __device__ __forceinline__ void rx_attempts(RxCtx& c, uint32_t* stk, const RxBlo
     constexpr int DSW = (RX_BACK + RXB + RX_REACH) / 32 + 2;
     const uint32_t* const cs = c.bm + RX_MAX_RUNSETS * RX_BMW;
     auto ds_bit = [&](uint32_t i) { return (bk.s_ds[i >> 5] >> (i & 31)) & 1u; };
+    // the first document start behind window index wi0 (global position; `none` if the window holds none): the rest of wi0's word, then
+    // the next word that has one -- by the 64-bit map of such words, no loop
+    auto next_start = [&](uint32_t wi0, uint32_t none) -> uint32_t {
+        const uint32_t i = wi0 + 1, w = i >> 5;
+        uint32_t bits = bk.s_ds[w] & (~0u << (i & 31)), ww = w;
+        if (!bits) {
+            const unsigned long long rest = w + 1 < 64u ? bk.ds_nz >> (w + 1) : 0ull;
+            if (!rest) return none;
+            ww = w + 1 + (uint32_t)__builtin_ctzll(rest);
+            bits = bk.s_ds[ww];
+        }
+        const uint32_t e = c.wb + ww * 32 + (uint32_t)__ffs((int)bits) - 1u;
+        return e < none ? e : none;
+    };
     const uint32_t p = bk.start + pl;
     if (p >= bk.B) bk.s_j[pl] = (uint16_t)(RXJ_EXIT | 0u);
     const uint32_t wi = pl + RX_BACK;
@@ -499,13 +513,13 @@ __device__ __forceinline__ void rx_attempts(RxCtx& c, uint32_t* stk, const RxBlo
     uint32_t b0 = 0;
     if (act) {
         at.p_is_start = ds_bit(wi) != 0u;
-        if (bk.any_ds) {                                   // the end of p's document: the next document start behind p (or the end of the corpus)
-            uint32_t i = wi + 1, w = i >> 5;
-            uint32_t bits = bk.s_ds[w] & (~0u << (i & 31));
-            while (!bits && ++w < (uint32_t)DSW) bits = bk.s_ds[w];
-            if (bits) { const uint32_t e = c.wb + w * 32 + (uint32_t)__ffs((int)bits) - 1u; at.n = e < at.n ? e : at.n; }
+        at.n = next_start(wi, bk.B);                       // the end of p's document: the next document start behind p (or the end of the corpus)
+        if (!at.p_is_start) {                              // bytes of the same document in front of p, up to RX_BACK: the four start bits in front of wi
+            const uint32_t i4 = wi - RX_BACK;              // (wi >= RX_BACK)
+            const uint32_t prev4 = ((bk.s_ds[i4 >> 5] >> (i4 & 31)) | ((i4 & 31) > 28u ? bk.s_ds[(i4 >> 5) + 1] << (32u - (i4 & 31)) : 0u)) & 0xFu;
+            at.back = prev4 ? (uint32_t)__clz((int)(prev4 << 28)) + 1u : (uint32_t)RX_BACK;
+            at.back = at.back < p ? at.back : p;
         }
-        if (!at.p_is_start) { at.back = 1; while (at.back < (uint32_t)RX_BACK && at.back < p && !ds_bit(wi - at.back)) at.back++; }
         c.n = at.n;
         b0 = c.rd(p);                                      // (p < n: the attempt begins with a byte)
     }
@@ -535,11 +549,7 @@ __device__ __forceinline__ void rx_attempts(RxCtx& c, uint32_t* stk, const RxBlo
     if (p < bk.B) {                                        // the position's hop
         uint32_t nxv = 1u | 0x8000u;
         if (lit) {                                         // the literal: to the next text start (the one behind it), dropped
-            uint32_t nn = bk.B, i = wi + 1, w = i >> 5;
-            uint32_t bits = bk.s_ds[w] & (~0u << (i & 31));
-            while (!bits && ++w < (uint32_t)DSW) bits = bk.s_ds[w];
-            if (bits) { const uint32_t en = c.wb + w * 32 + (uint32_t)__ffs((int)bits) - 1u; nn = en < nn ? en : nn; }
-            nxv = (nn - p) | 0x8000u;
+            nxv = (next_start(wi, bk.B) - p) | 0x8000u;
         } else if (e != RX_FAIL) {
             uint32_t d = e - p;
             if (d > (uint32_t)RX_REACH - 8u) { atomicOr(a.status, RXS_REACH); d = RX_REACH - 8; }
@@ -582,6 +592,7 @@ __global__ __launch_bounds__(RXT) void k_rx_match(RxArgs a) {
     __shared__ __attribute__((aligned(4))) uint8_t s_txt[RX_LDS_TEXT + 4];
     __shared__ uint32_t s_ds[(RX_BACK + RXB + RX_REACH) / 32 + 2];            // document starts of [wbase, wbase + RX_BACK + RXB + RX_REACH)
     __shared__ uint16_t s_j[RXB];
+    __shared__ uint32_t s_nz[2];
     __shared__ uint32_t s_ls[(RX_BACK + RXB + RX_REACH) / 32 + 2];            // literal starts of the window (SPL_WITH_SPECIAL)
     __shared__ uint32_t s_bm[(RX_MAX_RUNSETS + 1) * RX_BMW + 2];     // (+ 2: the 64-bit window of a run scan may read two words on)
     const int tid = (int)threadIdx.x;
@@ -640,9 +651,13 @@ __global__ __launch_bounds__(RXT) void k_rx_match(RxArgs a) {
         }
         __syncthreads();
     }
-    bool any_here = false;
-    for (int i = tid; i < DSW; i += RXT) any_here = any_here || s_ds[i] != 0u;
-    const bool any_ds = __syncthreads_or(any_here) != 0;      // (long documents: nothing to scan for below)
+    static_assert(DSW <= 64, "the map of the window's words with a document start is one 64-bit word");
+    if (tid < 64) {
+        const unsigned long long nz = __ballot(tid < DSW && s_ds[tid] != 0u);
+        if (tid == 0) { s_nz[0] = (uint32_t)nz; s_nz[1] = (uint32_t)(nz >> 32); }
+    }
+    __syncthreads();
+    const unsigned long long ds_nz = (unsigned long long)s_nz[0] | ((unsigned long long)s_nz[1] << 32);
     // ---- the window's characters, tabulated once for all 256 attempts: which bytes start a character (a continuation byte that
     // a lead byte in front of it takes -- same document, as many as it announces -- does not; find_iter only ever stands on the
     // others), and for every class set that a run instruction repeats, the bytes of its member characters
@@ -691,7 +706,7 @@ __global__ __launch_bounds__(RXT) void k_rx_match(RxArgs a) {
     }
 #else
     {
-        RxBlock bk{start, B, s_ds, any_ds, a.sp_tstart ? s_ls : nullptr, s_j};
+        RxBlock bk{start, B, s_ds, ds_nz, a.sp_tstart ? s_ls : nullptr, s_j};
         rx_attempts(c, s_stk + tid, bk, a, (uint32_t)tid);
     }
 #endif
