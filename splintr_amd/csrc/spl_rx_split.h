@@ -612,6 +612,22 @@ __global__ __launch_bounds__(RXT) void k_rx_match(RxArgs a) {
     // documents that start inside the window: RXT-ary search for the first one at or behind its begin, then their bits
     const uint64_t wlo = wbase > 0 ? (uint64_t)wbase : 0ull, whi = (uint64_t)(wbase + RX_BACK + RXB + RX_REACH);
     uint32_t lo = 0, hi = a.n_docs;
+    uint64_t p_held = ~0ull;                            // doc_off[d_held] from the first round, if it settled the search
+    uint32_t d_held = 0xFFFFFFFFu, d_end = 0;
+    if (wlo != 0 && hi > (uint32_t)RXT) {
+        // first round by interpolation (as the tile kernel's): with documents of similar size the answer lies within RXT entries of
+        // wlo * n_docs / n_bytes, ONE round of loads finds it and already holds the window's documents
+        const float gf = (float)wlo * ((float)hi * __builtin_amdgcn_rcpf((float)B));
+        const uint32_t g = gf >= (float)hi ? hi : (uint32_t)gf;
+        const uint32_t glo = g > (uint32_t)(RXT / 2) ? g - RXT / 2 : 0u;
+        const uint32_t ghi = glo + RXT < hi ? glo + RXT : hi;
+        const uint32_t idx = glo + (uint32_t)tid;
+        const uint64_t p1 = idx < ghi ? a.doc_off[idx] : ~0ull;
+        const uint32_t cnt = (uint32_t)__syncthreads_count(idx < ghi && p1 < wlo);
+        if (cnt == 0) hi = glo;
+        else if (cnt == ghi - glo) lo = ghi;
+        else { lo = hi = glo + cnt; p_held = p1; d_held = idx; d_end = ghi; }
+    }
     while (wlo != 0 && lo < hi) {
         const uint32_t span = hi - lo, stp = (span + RXT - 1) / RXT;
         const uint64_t idx = (uint64_t)lo + (uint64_t)tid * stp;
@@ -623,7 +639,13 @@ __global__ __launch_bounds__(RXT) void k_rx_match(RxArgs a) {
         hi = nhi < hi ? (uint32_t)nhi : hi;
     }
     __syncthreads();
-    for (uint32_t base = lo;; base += RXT) {
+    uint32_t base = lo;
+    if (d_end > lo) {                                  // the window's documents from the first round's loads
+        const bool in = d_held >= lo && d_held < d_end && p_held < whi && p_held < (uint64_t)B;
+        if (in) { const uint32_t i = (uint32_t)((int64_t)p_held - wbase); atomicOr(&s_ds[i >> 5], 1u << (i & 31)); }
+        base = __syncthreads_or(d_held == d_end - 1u && in) ? d_end : 0xFFFFFFFFu;       // more only if the last entry fetched is still inside
+    }
+    for (; base != 0xFFFFFFFFu; base += RXT) {
         const uint64_t d = (uint64_t)base + tid;
         uint64_t dp = ~0ull;
         if (d < a.n_docs) dp = a.doc_off[d];
