@@ -108,7 +108,8 @@ uint32_t spl_n_devices(const spl_tokenizer* t);
  * "result_estimate_div" (first guess of the token count = bytes / div; default 0.375 tokens per byte),
  * "subdoc_split" (0/1: balance the GPUs by cutting large documents at context-free boundaries),
  * "direct_write" (0/1, default 1: one-chunk batches have the last kernel write the ids straight into
- * the pinned result instead of copying them back). */
+ * the pinned result instead of copying them back), "device_split" (0/1, default 1: a custom split pattern's
+ * split runs on the GPU, see spl_split_device; 0 keeps it on the host cores). */
 int spl_set_option(spl_tokenizer* t, const char* name, int64_t value);
 
 /* One entry of the special_tokens map (src/core/tokenizer.rs:304, 429-434).  Call before the first
