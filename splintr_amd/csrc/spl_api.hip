@@ -203,7 +203,8 @@ struct Ctx {
     // custom split patterns on the device (spl_rx_split.h): the program image, general categories, workspace, status word
     const uint32_t* d_rx_image = nullptr; const uint16_t* d_gc1 = nullptr; const uint8_t* d_gc2 = nullptr;
     uint8_t* d_rx_ws = nullptr; uint64_t rx_ws_cap = 0, rx_cap_blk = 0; uint32_t rx_gen = 0xFFFFu;
-    uint32_t* d_rx_status = nullptr;
+    uint32_t* d_rx_status = nullptr;                                // RX_STATUS_SLOTS words, one per batch in rotation: a batch's k_rx_mark clears the next one's
+    uint32_t rx_slot = 0;
     uint32_t* h_rx_status = nullptr;                                // pinned copy: written behind every chunk's split, read when the batch is done
     uint32_t* d_rx_bits = nullptr; uint64_t rx_bits_cap = 0;       // the two bitmaps of a device-text call (spl_encode_batch_device)
     hipEvent_t ev_h2d[NSLOT] = {nullptr, nullptr, nullptr}, ev_cmp[NSLOT] = {nullptr, nullptr, nullptr};
@@ -486,6 +487,7 @@ int upload_decode(spl_tokenizer* tk, Ctx* t) {
 
 struct SlabOut { uint32_t* d_slab = nullptr; uint64_t cap_words = 0, max_docs = 0; };
 // chunk boundaries given from outside (host splitter): device bitmaps, and the special tokens found on the host
+constexpr uint32_t RX_STATUS_SLOTS = 8;
 struct ExtIn {
     const uint32_t* d_starts = nullptr; const uint32_t* d_gaps = nullptr; const uint32_t* d_sp_pos = nullptr; const uint32_t* d_sp_id = nullptr; uint32_t n_sp = 0;
     // the two bitmaps are still to be made, by the device splitter, inside launch_all (behind the special-token kernels, whose bitmaps it reads):
@@ -732,6 +734,8 @@ int rx_launch(spl_tokenizer* tk, Ctx* c, const uint8_t* d_text, uint64_t n_bytes
     a.nx = (uint16_t*)(a.dstart + 8 * c->rx_cap_blk + 2); a.gx = a.nx + c->rx_cap_blk * RXB;
     a.gen = c->rx_gen; a.bm_words = (uint32_t)words;
     a.starts = d_starts; a.gaps = d_gaps; a.status = d_status;
+    if (d_status >= c->d_rx_status && d_status < c->d_rx_status + RX_STATUS_SLOTS)          // (one of the context's own words: the next one in the rotation)
+        a.status_next = c->d_rx_status + ((uint32_t)(d_status - c->d_rx_status) + 1) % RX_STATUS_SLOTS;
     if (sp) { a.sp_tstart = sp->tstart; a.sp_tbits = sp->tbits; a.sp_words = sp_words; }
     hipLaunchKernelGGL(k_rx_match, dim3((uint32_t)nblk), dim3(RXT), (a.image_words * 4 + 15) & ~15u, s, a);
     hipLaunchKernelGGL(k_rx_mark, dim3((uint32_t)nblk), dim3(RXB), 0, s, a);
@@ -876,12 +880,12 @@ int encode_device_custom(spl_tokenizer* t, Ctx* c, const uint8_t* d_utf8, uint64
     if (t->rx_device && !t->rx_image.empty()) {
         int rc = rx_ensure(t, c);
         if (rc) return rc;
-        HIP_TRY(hipMemsetAsync(c->d_rx_status, 0, 4, s));
-        ext.d_status = c->d_rx_status;
+        c->rx_slot = (c->rx_slot + 1) % RX_STATUS_SLOTS;
+        ext.d_status = c->d_rx_status + c->rx_slot;
         rc = launch_all(t, c, d_utf8, n_bytes, d_doc_off, n_docs, flags, d_ids, ids_cap, d_out_off, s, so, &ext);
         if (rc) return rc;
         uint32_t gave_up = 1;
-        HIP_TRY(hipMemcpyAsync(&gave_up, c->d_rx_status, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(&gave_up, c->d_rx_status + c->rx_slot, 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         if (!gave_up) return SPL_OK;
         t->rx_fallbacks++;
@@ -1085,7 +1089,7 @@ int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t
             if (!ln.host_split) {
                 // ... or from the device splitter, on the compute stream behind the text's arrival; what it gives up on is
                 // on the context's status word when the batch is done (encode_host then runs the batch again, split on the host)
-                ext.d_status = c->d_rx_status;             // (launch_all runs the splitter, behind the special-token scan)
+                ext.d_status = c->d_rx_status + c->rx_slot;    // (launch_all runs the splitter, behind the special-token scan)
             } else {
             uint32_t* hb = (uint32_t*)c->h_ext[sl].p;
             memset(hb, 0, 2 * bw * 4);
@@ -1115,7 +1119,7 @@ int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t
         int rc = launch_all(tk, c, c->d_text[sl], nb, c->d_off[sl], nd, flags, ids_direct ? ids_direct : c->d_ids + (ch.lo - ln.lo),
                             nb + 16, oo, c->s_cmp, nullptr, tk->regex ? &ext : nullptr);
         if (rc) return rc;
-        if (ext.d_status) HIP_TRY(hipMemcpyAsync(c->h_rx_status, c->d_rx_status, 4, hipMemcpyDeviceToHost, c->s_cmp));    // (the word accumulates over the batch's chunks)
+        if (ext.d_status) HIP_TRY(hipMemcpyAsync(c->h_rx_status, ext.d_status, 4, hipMemcpyDeviceToHost, c->s_cmp));    // (the word accumulates over the batch's chunks)
         if (solo) break;                                   // (the batch is ONE chunk: the caller finishes on the compute stream itself)
         HIP_TRY(hipEventRecord(c->ev_cmp[sl], c->s_cmp));
         HIP_TRY(hipMemcpyAsync(&h_tot[k], oo + nd, 8, hipMemcpyDeviceToHost, c->s_cmp));
@@ -1593,7 +1597,7 @@ int spl_encode_batch(spl_tokenizer* t, const uint8_t* utf8, const uint64_t* doc_
                 int rcx = ensure_streams(*c);
                 if (!rcx) rcx = rx_ensure(t, c.get());
                 if (rcx) return rcx;
-                HIP_TRY(hipMemsetAsync(c->d_rx_status, 0, 4, c->s_cmp));
+                c->rx_slot = (c->rx_slot + 1) % RX_STATUS_SLOTS;     // (this batch's status word: cleared by the previous batch's k_rx_mark)
                 c->h_rx_status[0] = 0;
             }
         int rc = encode_host(t, utf8, doc_off, n_docs, flags, r.get(), !dev_split);

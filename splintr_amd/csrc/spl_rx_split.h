@@ -65,6 +65,7 @@ struct RxArgs {
     uint32_t bm_words;                                                 // words of each result bitmap (n_bytes / 32 + 2)
     uint32_t* starts; uint32_t* gaps;                                  // out: the two bitmaps (every word written by k_rx_mark)
     uint32_t* status;                                                  // out: RXS_* bits, OR-ed
+    uint32_t* status_next;                                             // null, or a word k_rx_mark clears for the NEXT batch (the contexts rotate through a few status words: no fill per batch)
     // SPL_WITH_SPECIAL: the bitmaps k_mark_docs / k_special_scan have left (null: none) -- text starts (documents AND behind every literal),
     // tokens so far (= where a literal starts); sp_words words each.  A literal is a stretch of dropped bytes with a start bit at either end
     // (encode_with_special runs the pattern over the stretches between the literals, tokenizer.rs:842-874): here a position whose hop is
@@ -764,6 +765,7 @@ __global__ __launch_bounds__(RXB) void k_rx_mark(RxArgs a) {
     const uint32_t B = a.n_bytes;
     const uint32_t b = blockIdx.x, start = b * (uint32_t)RXB;
     const uint32_t p = start + (uint32_t)tid;
+    if (b == 0 && tid == 1 && a.status_next) *a.status_next = 0u;
     if (tid == 0) {
         // where the walk from position 0 enters this block
         int64_t k = (int64_t)b - 1;
