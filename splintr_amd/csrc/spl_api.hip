@@ -205,6 +205,7 @@ struct Ctx {
     uint8_t* d_rx_ws = nullptr; uint64_t rx_ws_cap = 0, rx_cap_blk = 0; uint32_t rx_gen = 0xFFFFu;
     uint32_t* d_rx_status = nullptr;                                // RX_STATUS_SLOTS words, one per batch in rotation: a batch's k_rx_mark clears the next one's
     uint32_t rx_slot = 0;
+    uint32_t* dh_rx_status = nullptr;                               // (its device pointer)
     uint32_t* h_rx_status = nullptr;                                // pinned copy: written behind every chunk's split, read when the batch is done
     uint32_t* d_rx_bits = nullptr; uint64_t rx_bits_cap = 0;       // the two bitmaps of a device-text call (spl_encode_batch_device)
     hipEvent_t ev_h2d[NSLOT] = {nullptr, nullptr, nullptr}, ev_cmp[NSLOT] = {nullptr, nullptr, nullptr};
@@ -492,9 +493,11 @@ struct ExtIn {
     const uint32_t* d_starts = nullptr; const uint32_t* d_gaps = nullptr; const uint32_t* d_sp_pos = nullptr; const uint32_t* d_sp_id = nullptr; uint32_t n_sp = 0;
     // the two bitmaps are still to be made, by the device splitter, inside launch_all (behind the special-token kernels, whose bitmaps it reads):
     uint32_t* d_status = nullptr;          // non-null: yes; the status word it reports to
+    uint32_t* d_status_host = nullptr;     // ... and (device pointer of) its pinned host copy, written by k_rx_mark itself
 };
 int rx_launch(spl_tokenizer* tk, Ctx* c, const uint8_t* d_text, uint64_t n_bytes, const uint64_t* d_doc_off, uint64_t n_docs,
-              uint32_t* d_starts, uint32_t* d_gaps, uint32_t* d_status, hipStream_t s, const Batch* sp = nullptr, uint32_t sp_words = 0);
+              uint32_t* d_starts, uint32_t* d_gaps, uint32_t* d_status, hipStream_t s, const Batch* sp = nullptr, uint32_t sp_words = 0,
+              uint32_t* d_status_host = nullptr);
 
 int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off, uint64_t n_docs,
                uint32_t flags, uint32_t* d_ids, uint64_t ids_cap, uint64_t* d_out_off, hipStream_t s,
@@ -624,7 +627,7 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
         }
         if (ext && ext->d_status) {            // the device splitter, behind the literal scan whose bitmaps it reads
             int rcx = rx_launch(tk, t, d_utf8, n_bytes, d_doc_off, n_docs, const_cast<uint32_t*>(ext->d_starts), const_cast<uint32_t*>(ext->d_gaps),
-                                ext->d_status, s, special ? &b : nullptr, (uint32_t)uw);
+                                ext->d_status, s, special ? &b : nullptr, (uint32_t)uw, ext->d_status_host);
             if (rcx) return rcx;
         }
         MARK(KI_PRETOK);
@@ -693,10 +696,11 @@ int rx_ensure(spl_tokenizer* tk, Ctx* c) {
     HIP_TRY(hipMemset(c->d_rx_status, 0, 64));
     HIP_TRY(hipHostMalloc((void**)&c->h_rx_status, 64, hipHostMallocPortable));
     c->h_rx_status[0] = 0;
+    { void* dp = nullptr; HIP_TRY(hipHostGetDevicePointer(&dp, c->h_rx_status, 0)); c->dh_rx_status = (uint32_t*)dp; }
     return dev_upload(tk->rx_image, &c->d_rx_image);
 }
 int rx_launch(spl_tokenizer* tk, Ctx* c, const uint8_t* d_text, uint64_t n_bytes, const uint64_t* d_doc_off, uint64_t n_docs,
-              uint32_t* d_starts, uint32_t* d_gaps, uint32_t* d_status, hipStream_t s, const Batch* sp, uint32_t sp_words) {
+              uint32_t* d_starts, uint32_t* d_gaps, uint32_t* d_status, hipStream_t s, const Batch* sp, uint32_t sp_words, uint32_t* d_status_host) {
     if (n_bytes > SPL_DIRECT_MAX_BYTES) return fail(SPL_EINVAL, "device split: at most 256 MB per call");
     if (((uintptr_t)d_text & 15) != 0) return fail(SPL_EINVAL, "text buffer must be 16-byte aligned");
     int rc = rx_ensure(tk, c);
@@ -733,7 +737,7 @@ int rx_launch(spl_tokenizer* tk, Ctx* c, const uint8_t* d_text, uint64_t n_bytes
     a.blk = (uint32_t*)c->d_rx_ws; a.bskip = a.blk + c->rx_cap_blk; a.dstart = a.bskip + c->rx_cap_blk;
     a.nx = (uint16_t*)(a.dstart + 8 * c->rx_cap_blk + 2); a.gx = a.nx + c->rx_cap_blk * RXB;
     a.gen = c->rx_gen; a.bm_words = (uint32_t)words;
-    a.starts = d_starts; a.gaps = d_gaps; a.status = d_status;
+    a.starts = d_starts; a.gaps = d_gaps; a.status = d_status; a.status_host = d_status_host;
     if (d_status >= c->d_rx_status && d_status < c->d_rx_status + RX_STATUS_SLOTS)          // (one of the context's own words: the next one in the rotation)
         a.status_next = c->d_rx_status + ((uint32_t)(d_status - c->d_rx_status) + 1) % RX_STATUS_SLOTS;
     if (sp) { a.sp_tstart = sp->tstart; a.sp_tbits = sp->tbits; a.sp_words = sp_words; }
@@ -1090,6 +1094,7 @@ int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t
                 // ... or from the device splitter, on the compute stream behind the text's arrival; what it gives up on is
                 // on the context's status word when the batch is done (encode_host then runs the batch again, split on the host)
                 ext.d_status = c->d_rx_status + c->rx_slot;    // (launch_all runs the splitter, behind the special-token scan)
+                ext.d_status_host = c->dh_rx_status;           // (k_rx_mark leaves what was given up on in the pinned word: no copy back)
             } else {
             uint32_t* hb = (uint32_t*)c->h_ext[sl].p;
             memset(hb, 0, 2 * bw * 4);
@@ -1119,7 +1124,6 @@ int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t
         int rc = launch_all(tk, c, c->d_text[sl], nb, c->d_off[sl], nd, flags, ids_direct ? ids_direct : c->d_ids + (ch.lo - ln.lo),
                             nb + 16, oo, c->s_cmp, nullptr, tk->regex ? &ext : nullptr);
         if (rc) return rc;
-        if (ext.d_status) HIP_TRY(hipMemcpyAsync(c->h_rx_status, ext.d_status, 4, hipMemcpyDeviceToHost, c->s_cmp));    // (the word accumulates over the batch's chunks)
         if (solo) break;                                   // (the batch is ONE chunk: the caller finishes on the compute stream itself)
         HIP_TRY(hipEventRecord(c->ev_cmp[sl], c->s_cmp));
         HIP_TRY(hipMemcpyAsync(&h_tot[k], oo + nd, 8, hipMemcpyDeviceToHost, c->s_cmp));

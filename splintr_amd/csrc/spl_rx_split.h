@@ -65,6 +65,7 @@ struct RxArgs {
     uint32_t bm_words;                                                 // words of each result bitmap (n_bytes / 32 + 2)
     uint32_t* starts; uint32_t* gaps;                                  // out: the two bitmaps (every word written by k_rx_mark)
     uint32_t* status;                                                  // out: RXS_* bits, OR-ed
+    uint32_t* status_host;                                             // null, or the status word's copy in pinned host memory: k_rx_mark leaves the word there (no copy back)
     uint32_t* status_next;                                             // null, or a word k_rx_mark clears for the NEXT batch (the contexts rotate through a few status words: no fill per batch)
     // SPL_WITH_SPECIAL: the bitmaps k_mark_docs / k_special_scan have left (null: none) -- text starts (documents AND behind every literal),
     // tokens so far (= where a literal starts); sp_words words each.  A literal is a stretch of dropped bytes with a start bit at either end
@@ -765,7 +766,11 @@ __global__ __launch_bounds__(RXB) void k_rx_mark(RxArgs a) {
     const uint32_t B = a.n_bytes;
     const uint32_t b = blockIdx.x, start = b * (uint32_t)RXB;
     const uint32_t p = start + (uint32_t)tid;
-    if (b == 0 && tid == 1 && a.status_next) *a.status_next = 0u;
+    if (b == 0 && tid == 1) {
+        if (a.status_next) *a.status_next = 0u;
+        // (k_rx_match is done: what it gave up on is final; what THIS kernel gives up on goes to the host word directly, below)
+        if (a.status_host) { const uint32_t st = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (st) *a.status_host = st; }
+    }
     if (tid == 0) {
         // where the walk from position 0 enters this block
         int64_t k = (int64_t)b - 1;
@@ -777,7 +782,7 @@ __global__ __launch_bounds__(RXB) void k_rx_mark(RxArgs a) {
             v = a.blk[k];
             if ((v >> 16) == a.gen && a.bskip[k] != a.gen) break;            // closed, and no hop jumps over it
             k--;
-            if ((int64_t)b - k > (int64_t)RX_MAX_OPEN) { atomicOr(a.status, RXS_REACH); lost = true; }
+            if ((int64_t)b - k > (int64_t)RX_MAX_OPEN) { atomicOr(a.status, RXS_REACH); if (a.status_host) *a.status_host = RXS_REACH; lost = true; }
         }
         if (lost) k = (int64_t)b - 1, v = 0;                    // (any entry will do: the bitmaps are not used)
         uint32_t E = 0, pg = 0;
