@@ -238,3 +238,28 @@ def test_special_tokens_are_found_by_the_gpu_scan_and_the_device_splitter_works_
             assert a == b
             assert t.encode_batch(batch) == h.encode_batch(batch)
         assert L.spl_device_split_fallbacks(t.handle) == 0
+
+
+def test_two_pipelines_on_one_gpu_each_with_its_own_splitter_state():
+    """spl_set_devices with the ordinal listed twice: two lanes, each context with its own image, workspace, status words and generation"""
+    from splintr_amd import Tokenizer, _ffi
+    L = _ffi.lib()
+    sp = {"<|endoftext|>": 100257}
+    t = Tokenizer.from_bytes(_blob("cl100k_base"), QWEN2, sp).set_devices([0, 0])
+    h = Tokenizer.from_bytes(_blob("cl100k_base"), QWEN2, sp)
+    assert L.spl_set_option(h.handle, b"device_split", 0) == 0
+    texts = (fuzz_corpus(77, 3000, 60) + latin_corpus(9, 2000, 300)) * 4
+    texts = [x + ("<|endoftext|>" if i % 7 == 0 else "") for i, x in enumerate(texts)]
+    assert sum(len(x.encode()) for x in texts) > (3 << 20)
+    for special in (False, True):
+        for _ in range(3):                                      # (the status words rotate, the generations advance)
+            a = t.encode_batch_csr(texts, with_special=special)
+            b = h.encode_batch_csr(texts, with_special=special)
+            assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
+    assert L.spl_device_split_fallbacks(t.handle) == 0
+    a = t.encode_batch_csr(texts + ["k" * 3000 + " end"])
+    b = h.encode_batch_csr(texts + ["k" * 3000 + " end"])
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
+    assert L.spl_device_split_fallbacks(t.handle) == 1
+    a = t.encode_batch_csr(texts)
+    assert np.array_equal(a[0], h.encode_batch_csr(texts)[0]) and L.spl_device_split_fallbacks(t.handle) == 1
