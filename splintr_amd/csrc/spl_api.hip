@@ -205,6 +205,7 @@ struct Ctx {
     uint8_t* d_rx_ws = nullptr; uint64_t rx_ws_cap = 0, rx_cap_blk = 0; uint32_t rx_gen = 0xFFFFu;
     uint32_t* d_rx_status = nullptr;                                // RX_STATUS_SLOTS words, one per batch in rotation: a batch's k_rx_mark clears the next one's
     uint32_t rx_slot = 0;
+    bool rx_next_clean = true;                                      // the next word of the rotation has been cleared (fresh memory; a k_rx_mark that ran)
     uint32_t* dh_rx_status = nullptr;                               // (its device pointer)
     uint32_t* h_rx_status = nullptr;                                // pinned copy: written behind every chunk's split, read when the batch is done
     uint32_t* d_rx_bits = nullptr; uint64_t rx_bits_cap = 0;       // the two bitmaps of a device-text call (spl_encode_batch_device)
@@ -688,16 +689,30 @@ bool rx_applies(const spl_tokenizer* tk, uint32_t flags) {
 int rx_ensure(spl_tokenizer* tk, Ctx* c) {
     if (c->d_rx_image) return SPL_OK;
     int rc;
+    // (every piece only if it is not there yet: a call that failed half-way is repeated without leaking what it had allocated)
     if (tk->rx_image[7] && !tk->ht.gc_stage1.empty()) {
-        if ((rc = dev_upload(tk->ht.gc_stage1, &c->d_gc1))) return rc;
-        if ((rc = dev_upload(tk->ht.gc_stage2, &c->d_gc2))) return rc;
+        if (!c->d_gc1 && (rc = dev_upload(tk->ht.gc_stage1, &c->d_gc1))) return rc;
+        if (!c->d_gc2 && (rc = dev_upload(tk->ht.gc_stage2, &c->d_gc2))) return rc;
     }
-    HIP_TRY(hipMalloc((void**)&c->d_rx_status, 64));
-    HIP_TRY(hipMemset(c->d_rx_status, 0, 64));
-    HIP_TRY(hipHostMalloc((void**)&c->h_rx_status, 64, hipHostMallocPortable));
-    c->h_rx_status[0] = 0;
-    { void* dp = nullptr; HIP_TRY(hipHostGetDevicePointer(&dp, c->h_rx_status, 0)); c->dh_rx_status = (uint32_t*)dp; }
+    if (!c->d_rx_status) {
+        HIP_TRY(hipMalloc((void**)&c->d_rx_status, 64));
+        HIP_TRY(hipMemset(c->d_rx_status, 0, 64));
+    }
+    if (!c->h_rx_status) {
+        HIP_TRY(hipHostMalloc((void**)&c->h_rx_status, 64, hipHostMallocPortable));
+        c->h_rx_status[0] = 0;
+        void* dp = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&dp, c->h_rx_status, 0));
+        c->dh_rx_status = (uint32_t*)dp;
+    }
     return dev_upload(tk->rx_image, &c->d_rx_image);
+}
+// This batch's status word: the next one of the context's rotation -- cleared by the previous batch's k_rx_mark, or here if that batch launched none
+int rx_next_status(Ctx* c, hipStream_t s) {
+    c->rx_slot = (c->rx_slot + 1) % RX_STATUS_SLOTS;
+    if (!c->rx_next_clean) HIP_TRY(hipMemsetAsync(c->d_rx_status + c->rx_slot, 0, 4, s));
+    c->rx_next_clean = false;
+    return SPL_OK;
 }
 int rx_launch(spl_tokenizer* tk, Ctx* c, const uint8_t* d_text, uint64_t n_bytes, const uint64_t* d_doc_off, uint64_t n_docs,
               uint32_t* d_starts, uint32_t* d_gaps, uint32_t* d_status, hipStream_t s, const Batch* sp, uint32_t sp_words, uint32_t* d_status_host) {
@@ -739,7 +754,10 @@ int rx_launch(spl_tokenizer* tk, Ctx* c, const uint8_t* d_text, uint64_t n_bytes
     a.gen = c->rx_gen; a.bm_words = (uint32_t)words;
     a.starts = d_starts; a.gaps = d_gaps; a.status = d_status; a.status_host = d_status_host;
     if (d_status >= c->d_rx_status && d_status < c->d_rx_status + RX_STATUS_SLOTS)          // (one of the context's own words: the next one in the rotation)
+    {
         a.status_next = c->d_rx_status + ((uint32_t)(d_status - c->d_rx_status) + 1) % RX_STATUS_SLOTS;
+        c->rx_next_clean = true;
+    }
     if (sp) { a.sp_tstart = sp->tstart; a.sp_tbits = sp->tbits; a.sp_words = sp_words; }
     hipLaunchKernelGGL(k_rx_match, dim3((uint32_t)nblk), dim3(RXT), (a.image_words * 4 + 15) & ~15u, s, a);
     hipLaunchKernelGGL(k_rx_mark, dim3((uint32_t)nblk), dim3(RXB), 0, s, a);
@@ -884,7 +902,8 @@ int encode_device_custom(spl_tokenizer* t, Ctx* c, const uint8_t* d_utf8, uint64
     if (t->rx_device && !t->rx_image.empty()) {
         int rc = rx_ensure(t, c);
         if (rc) return rc;
-        c->rx_slot = (c->rx_slot + 1) % RX_STATUS_SLOTS;
+        rc = rx_next_status(c, s);
+        if (rc) return rc;
         ext.d_status = c->d_rx_status + c->rx_slot;
         rc = launch_all(t, c, d_utf8, n_bytes, d_doc_off, n_docs, flags, d_ids, ids_cap, d_out_off, s, so, &ext);
         if (rc) return rc;
@@ -1601,7 +1620,8 @@ int spl_encode_batch(spl_tokenizer* t, const uint8_t* utf8, const uint64_t* doc_
                 int rcx = ensure_streams(*c);
                 if (!rcx) rcx = rx_ensure(t, c.get());
                 if (rcx) return rcx;
-                c->rx_slot = (c->rx_slot + 1) % RX_STATUS_SLOTS;     // (this batch's status word: cleared by the previous batch's k_rx_mark)
+                if (!rcx) rcx = rx_next_status(c.get(), c->s_cmp);   // (this batch's status word: cleared by the previous batch's k_rx_mark)
+                if (rcx) return rcx;
                 c->h_rx_status[0] = 0;
             }
         int rc = encode_host(t, utf8, doc_off, n_docs, flags, r.get(), !dev_split);

@@ -1,6 +1,8 @@
 // spl_regex.cpp -- restricted regex compiler + backtracking matcher of the host splitter (spl_regex.h).
 #include "spl_regex.h"
 
+#include <array>
+
 #include <algorithm>
 #include <cctype>
 #include <cstring>
@@ -828,13 +830,17 @@ bool regex_device_image(const RegexProg& prog, std::vector<uint32_t>& w) {
         if (it.op == OP_ANY) return c.cp != '\n';
         return in_set(ht, prog.sets[it.x], c);
     };
+    std::vector<std::pair<std::array<uint32_t, 4>, bool>> seen;       // (pairs already compared: a pattern repeats its few sets)
     auto disjoint = [&](const Item& a, const Item& b) {     // no character that both items take (every code point, and the byte that is none)
-        if (takes(a, Ch{CP_INVALID, 1, C_P}) && takes(b, Ch{CP_INVALID, 1, C_P})) return false;
-        for (uint32_t cp = 0; cp < 0x110000u; cp++) {
+        const std::array<uint32_t, 4> key{a.op, a.x, b.op, b.x};
+        for (const auto& kv : seen) if (kv.first == key) return kv.second;
+        bool dj = !(takes(a, Ch{CP_INVALID, 1, C_P}) && takes(b, Ch{CP_INVALID, 1, C_P}));
+        for (uint32_t cp = 0; cp < 0x110000u && dj; cp++) {
             const Ch c{cp, 1, host_cp_class(ht, cp)};
-            if (takes(a, c) && takes(b, c)) return false;
+            if (takes(a, c) && takes(b, c)) dj = false;
         }
-        return true;
+        seen.emplace_back(key, dj);
+        return dj;
     };
     // A simple alternative may END in a tail that is tried at every length of its last run, longest first (the one place where the
     // backtracking matcher's way back is kept, as a loop): ONE one-character item whose characters the run may take too (\s*[\r\n]), a
