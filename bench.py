@@ -114,10 +114,13 @@ def main():
                          "(\"pipelined\"; off by default so that a profile of the default command sees one batch at a time)")
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--regions", type=int, default=15,
+                    help="the timed region of --steps steps is run this many times back to back; `value` is the median region")
     ap.add_argument("--docs", type=int, default=1000, help="documents per batch (BASELINE config: 1000)")
     ap.add_argument("--corpus", choices=("c2", "c2_wide"), default="c2",
                     help="c2 = BASELINE config 2 (the headline); c2_wide = the same mix over a >= 20 000-word lexicon (profiles only: the line then says so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c2-wide", action="store_true", help="skip the c2_wide rotation leg")
     ap.add_argument("--no-throughputs", action="store_true", help="skip the C-ABI / Python-surface figures (C2, C3)")
     ap.add_argument("--no-c4", action="store_true", help="skip the doc-sharded 1 M-prompt run (BASELINE config 4)")
     ap.add_argument("--c4-steps", type=int, default=5)
@@ -232,36 +235,49 @@ def main():
         state["i"] = 0
 
     # ---- timed region ----------------------------------------------------------------------------
+    # The contract's region -- W warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides, the MAX
+    # over ranks -- is run R = --regions times back to back and `value` is the MEDIAN region (one 20-step
+    # region of a 30 us step is 0.6 ms of wall clock, and the first one behind an idle GPU came out 5 % low two rounds
+    # running).  Every region is reported (`regions`), with p10 / p90 beside the median.
     for _ in range(args.warmup):
         step()
-    if gv is not None:
-        gv.finish()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
+    reg_t, reg_b = [], []
     i0 = state["i"]
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    if gv is not None:
-        gv.finish()                   # the last batch's exchange completes inside the timed region
-    torch.cuda.synchronize()
+    for _ in range(max(1, args.regions)):
+        if gv is not None:
+            gv.finish()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        i0 = state["i"]
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        if gv is not None:
+            gv.finish()                   # the last batch's exchange completes inside the timed region
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        reg_t.append(time.perf_counter() - t0)
+        reg_b.append(sum(batches[(i0 + j) % N_ROT].n_bytes for j in range(args.steps)))
+    local_t = list(reg_t)
     if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed_local = elapsed
-    my_bytes = sum(batches[(i0 + j) % N_ROT].n_bytes for j in range(args.steps))
-    if use_dist:
-        et = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        et = torch.tensor(reg_t, dtype=torch.float64, device=dev)
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
-        elapsed = float(et.item())
-        nb = torch.tensor([my_bytes], dtype=torch.int64, device=dev)
+        reg_t = [float(x) for x in et.tolist()]
+        nb = torch.tensor(reg_b, dtype=torch.int64, device=dev)
         dist.all_reduce(nb)
-        total_bytes = int(nb.item())
-    else:
-        total_bytes = my_bytes
+        reg_b = [int(x) for x in nb.tolist()]
+    rates = sorted((b_ / t_ / 1e6, t_, k) for k, (t_, b_) in enumerate(zip(reg_t, reg_b)))
+    value, elapsed, k_med = rates[len(rates) // 2]           # the median region (R odd: a region that was measured, not an average)
+    elapsed_local = local_t[k_med]
     ms_per_step = elapsed / args.steps * 1e3
-    value = total_bytes / elapsed / 1e6
+    pq = lambda f: rates[min(len(rates) - 1, int(f * len(rates)))][0]
+    region_stats = {"regions": len(rates), "steps_per_region": args.steps,
+                    "value_p10_p90": [round(pq(0.1), 2), round(pq(0.9), 2)],
+                    "region_values": [round(b_ / t_ / 1e6, 1) for t_, b_ in zip(reg_t, reg_b)],
+                    "note": "`value` / `ms_per_step` are the MEDIAN of `regions` timed regions of `steps` steps each (every region bracketed by "
+                            "barrier + synchronize, MAX over ranks); region_values in run order"}
 
     # ---- distributed runs: what a rank's step is made of (untimed repeats of the same steps) -------------
     # encode_only_ms: the same steps without the exchange; exchange_stream_ms: what the exchange stream spent in the
@@ -300,6 +316,40 @@ def main():
                      "ids_bytes_per_batch_4T": round(4 * tok_b), "slab_over_4T": round(sent / gv.depth / (4 * tok_b), 4),
                      "note": "per batch and rank: one slab of cap_words u32 (T, N, local offsets, ids; sized 1.02 x the largest shard) out, "
                              "world slabs in; ONE all-gather per bucket of `bucket_depth` batches on its own stream"}
+
+    # ---- the lexically wide variant of the same mix, in rotation, timed the same way (single GPU) ---------
+    # C2's 925 distinct words flatter the vocabulary probe (every whole-chunk probe hits); c2_wide draws the same mix from a
+    # >= 20 000-word lexicon.  Reported in `c2_wide_rotation` and named in config.workload next to the headline.
+    c2_wide_rot = None
+    if rank == 0 and world == 1 and not use_dist and args.corpus == "c2" and not args.no_c2_wide:
+        w_sets = [corpus.c2_wide(args.docs, seed=2002 + k) for k in range(N_ROT)]
+        w_batches = [DeviceBatch(t, dev) for t in w_sets]
+        reserve(tok, max(b.n_bytes for b in w_batches + batches), max(b.n_docs for b in w_batches + batches))
+        for b, texts in zip(w_batches, w_sets):
+            encode_device(tok, b)
+            torch.cuda.synchronize()
+            ids, off = result_csr(b)
+            text_np, _ = _packed(texts)
+            o_ids, o_off = orc.encode_packed(text_np, b.host_offsets, threads=ncpu)
+            if not (np.array_equal(ids, o_ids) and np.array_equal(off, o_off)):
+                raise SystemExit("c2_wide: HIP result differs from the oracle")
+        for j in range(args.warmup):
+            encode_device(tok, w_batches[j % N_ROT])
+        w_rates = []
+        for _ in range(max(1, args.regions)):
+            torch.cuda.synchronize()
+            w0_ = time.perf_counter()
+            for j in range(args.steps):
+                encode_device(tok, w_batches[j % N_ROT])
+            torch.cuda.synchronize()
+            w_el = time.perf_counter() - w0_
+            w_rates.append(sum(w_batches[j % N_ROT].n_bytes for j in range(args.steps)) / w_el / 1e6)
+        w_rates.sort()
+        c2_wide_rot = {"value": round(w_rates[len(w_rates) // 2], 2), "unit": "MB/s",
+                       "p10_p90": [round(w_rates[int(0.1 * len(w_rates))], 2), round(w_rates[min(len(w_rates) - 1, int(0.9 * len(w_rates)))], 2)],
+                       "workload": f"splintr_amd.corpus.c2_wide, {args.docs} x ~1 KB, {N_ROT} batches in rotation (seeds 2002 + k), kernel-only, "
+                                   f"median of {len(w_rates)} regions of {args.steps} steps; bit-exact vs oracle"}
+        del w_batches, w_sets
 
     # ---- supplementary: the same steps with several batches in flight --------------------------------
     pipelined = None
@@ -532,13 +582,14 @@ def main():
             "config": {"workload": f"cl100k_base, {args.docs} x ~1 KB mixed English/code per batch and GPU, {N_ROT} distinct batches in rotation "
                                    f"(splintr_amd.corpus.{args.corpus}, seeds {seed0_} + 100 rank + k{'' if args.corpus == 'c2' else '; NOT the BASELINE corpus: the lexically wide variant'}); KERNEL-ONLY: corpus HBM-resident, CSR left in HBM "
                                    f"(the host->host and Python-surface rates of the same batch are in `throughputs`)"
+                                   + (f"; the same mix over a >= 20 000-word lexicon (c2_wide, in rotation, same timing): {c2_wide_rot['value']} MB/s" if c2_wide_rot else "")
                                    + ("; + RCCL all-gatherv of the ragged ids (slab written by the encoder's last kernel, ONE all-gather per bucket of 8 batches on its own stream, overlapped with the following encodes; every rank gets every batch's global CSR, handed to the consumer per bucket)" if use_dist else ""),
                        "vocab": "cl100k_base", "docs_per_batch": args.docs, "bytes_per_batch": round(bytes_rot / N_ROT),
                        "tokens_per_batch": round(sum(n_tokens) / N_ROT), "distinct_batches": N_ROT,
                        "parallelism": f"doc-shard x{world}"},
             "parity": "bit-exact vs oracle (untimed verification pass over every batch of the rotation)",
             "roofline": roofline, "roofline_valu": roofline_valu, "throughputs": throughputs, "c4_strong": c4, "c5_strong": c5,
-            "cpu_baseline": cpu, "pipelined": pipelined, "dist": dist_info,
+            "cpu_baseline": cpu, "pipelined": pipelined, "dist": dist_info, "timing": region_stats, "c2_wide_rotation": c2_wide_rot,
         }
         if rehearsal:
             out["rehearsal"] = True

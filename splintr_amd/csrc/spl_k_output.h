@@ -199,9 +199,11 @@ __global__ __launch_bounds__(NT) void k_bpe_segments(DeviceTables T, Batch b) {
     __shared__ __attribute__((aligned(16))) uint32_t s_slab[SEG_ROWS * SUB_W];
     __shared__ uint32_t s_lq[2 * DIRECT_LQCAP];
     __shared__ uint32_t s_scr[SG_WORDS];
-    __shared__ uint32_t s_wsum[NT / 64];
+    __shared__ uint32_t s_sid[SEG_ROWS];
+    __shared__ uint32_t s_bid[256];
     __shared__ uint32_t s_first;
     const int tid = threadIdx.x;
+    s_bid[tid] = T.byte_id[tid];                                   // (NT == 256; the first barrier below orders it)
     const uint32_t nq = min(b.qcount[2], b.qcaplong), nbig = min(b.qcount[4], b.qcaplong), total = nq + nbig;
     uint2* const qbig = b.qlong + (b.qcaplong - 1u);
     auto slot = [&](uint32_t i) -> uint2* { return i < nq ? b.qlong + i : qbig - (i - nq); };
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(NT) void k_bpe_segments(DeviceTables T, Batch b) {
             s_lq[2 * tid + 1] = item.y;
         }
         __syncthreads();
-        const uint32_t nl2 = bpe_tail_segments<2>(T, b, s_lq, cnt, s_slab, s_scr, s_wsum, nullptr, 0, 0,
+        const uint32_t nl2 = bpe_tail_segments<2>(T, b, s_lq, cnt, s_slab, s_scr, s_sid, s_bid, nullptr, 0, 0,
                                                [&](uint32_t q, uint32_t id) { emit_token(b, q, id); });
         // what is left -- chunks not finished, segments set aside -- goes on the survivor list (q64: a
         // dense list that k_bpe_long walks one item per wavefront; the long queue itself is done with)

@@ -72,6 +72,8 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
     __shared__ uint32_t s_ids[DIRECT ? Wv : 1];          // id of the token that starts at this window index
     __shared__ uint32_t s_wpre[DIRECT ? G::NBW + 2 : 1]; // exclusive token counts of the window's bitmap words
     __shared__ uint32_t s_lq[DIRECT ? 2 * DIRECT_LQCAP : 1];   // (global position, length): the tail's working list
+    static_assert(sizeof(PretokTailLds) >= (size_t)SEG_ROWS * (SUB_W + 1) * 4, "the tail's slab must hold SEG_ROWS table rows and their sid[] words");
+    uint32_t* const s_sid = s_u.t.slab[0] + SEG_ROWS * SUB_W;   // the tail's rows: byte | chunk slot << 8 | longest token that starts there << 24
     constexpr bool TILE_LIST = DIRECT && SPL_TILE_MISS_LIST;
     __shared__ uint32_t s_tmiss[TILE_LIST ? G::C16 : 1]; // tile-owned: EVERY miss of the tile, p | n << 16 (outside the union:
                                                          // the tail's slab overlays the scanner's arrays)
@@ -801,7 +803,14 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
 #ifndef SPL_SKIP_TAIL
 #define SPL_SKIP_TAIL 0          /* timing experiment only (tokens missing): the tile-owned tail does nothing */
 #endif
-        if (!SPL_SKIP_TAIL && (n_tm | s_dq[0] | s_dq[1] | s_dq[11])) {         // workgroup-uniform
+#ifndef SPL_TAIL_UNLIKELY
+#define SPL_TAIL_UNLIKELY 1
+#endif
+        if (__builtin_expect(!SPL_SKIP_TAIL && (n_tm | s_dq[0] | s_dq[1] | s_dq[11]) != 0u, SPL_TAIL_UNLIKELY ? 0 : 1)) {         // workgroup-uniform
+            // the single-byte ids in LDS for the tail (the ASCII kind table's 1 KB: dead since the classifier; the tail's first barrier orders it)
+            static_assert(sizeof(s_aent) >= 256 * sizeof(uint32_t), "the byte-id table takes the kind table's place");
+            uint32_t* const s_bid = reinterpret_cast<uint32_t*>(s_aent);
+            { int t_b = tid; asm volatile("" : "+v"(t_b)); s_bid[t_b] = T.byte_id[t_b]; }
             uint32_t mcur = 0;
             for (;;) {
 #ifndef SPL_TAIL_LISTFILL_ALWAYS
@@ -825,7 +834,7 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
                 const uint32_t nl0 = (!TILE_LIST && (s_dq[11] || s_dq[0] > (uint32_t)DIRECT_LQCAP)) ? (uint32_t)DIRECT_LQCAP : s_dq[0];
                 // (the same value in every lane, read from LDS behind a barrier: as a scalar, so that the branch below is one)
                 const uint32_t nl = (uint32_t)__builtin_amdgcn_readfirstlane((int)bpe_tail_segments<2>(
-                    T, b, s_lq, nl0, s_u.t.slab[0], reinterpret_cast<uint32_t*>(s_cpos), s_wsum, s_txt, w0, w0 + iT, emit_g));
+                    T, b, s_lq, nl0, s_u.t.slab[0], reinterpret_cast<uint32_t*>(s_cpos), s_sid, s_bid, s_txt, w0, w0 + iT, emit_g));
                 // (nl: the list's length, finished entries -- length 0 -- included; 0 if no chunk is left at all)
                 if (!SPL_TAIL_SKIP_EMPTY || nl) {
                 for (uint32_t it = wv; it < nl; it += NT / 64) {         // one wavefront per chunk
@@ -903,7 +912,7 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
                             const uint32_t n = e - pc;
                             // (a stretch of DROPPED bytes that outgrows the window -- a gap of a pattern that does not tile the
                             //  text, or a special literal's span -- is deferred like a chunk, but there is nothing to encode:
-                            //  tools/dev/gpu_custom_stress.py found its bytes tokenised, 46 of 2 883 batches)
+                            //  tools/gpu_custom_stress.py found its bytes tokenised, 46 of 2 883 batches)
                             const bool dropped = b.ext_gaps && ((b.ext_gaps[pc >> 5] >> (pc & 31u)) & 1u) != 0u;
                             uint32_t fill = s_dq[0];
                             if (!dropped) {
@@ -1001,10 +1010,12 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
                     const int64_t Bv = B - (int64_t)removed;           // length of the text as the window sees it
                     const int nst = (int)((Bv - base) < (int64_t)(DIRECT_WIN + 16) ? (Bv - base) : (int64_t)(DIRECT_WIN + 16));
                     const int nrec = nst < DIRECT_WIN ? nst + 1 : DIRECT_WIN;
-                    for (int i = tid; i < DIRECT_WIN + 32; i += NT)
+                    int tid_c = tid;                          // (as tid_s above: what these loops derive from the thread index -- 64-bit addresses --
+                    asm volatile("" : "+v"(tid_c));          //  is made here, not kept in registers, or in scratch, from in front of the tail)
+                    for (int i = tid_c; i < DIRECT_WIN + 32; i += NT)
                         wtxt[i] = i < nst ? e_text[base + i + (i >= split ? (int64_t)removed : 0)] : (uint8_t)0;
                     __syncthreads();
-                    for (int i = tid; i < nrec; i += NT) {
+                    for (int i = tid_c; i < nrec; i += NT) {
                         const int64_t g = base + i + (i >= split ? (int64_t)removed : 0);
                         uint32_t r;
                         if (g >= B) r = C_EOT | CB_TSTART | CB_SYNC;

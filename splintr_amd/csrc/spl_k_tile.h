@@ -93,27 +93,52 @@ static_assert((NT / 64) * DIRECT_TAB_NMAX * SUB_W >= 3 * DIRECT_BLOCK_NMAX, "the
 // 3-byte segments: two memory round trips and a few two-step loops per tile, where the node-list
 // loops pay a round trip per merge.
 #ifndef SPL_SEG_ROWS
-#define SPL_SEG_ROWS NT
+#define SPL_SEG_ROWS 448         /* rows (bytes) of one pass: up to two per thread since round 5 (one per thread up to round 4).  448, not 512:
+                                    448 rows of seven cells and the 448 words of sid[] fill the tail's slab exactly -- with 512 the kernel
+                                    needs 2 KB of LDS more, and a batch that fills the GPU several times over loses 1.5 % (C2, 8 MB) */
 #endif
 #ifndef SPL_TAIL_SKIP_EMPTY
 #define SPL_TAIL_SKIP_EMPTY 1    /* 1: no chunk left behind the segment passes (nearly always): none of the caller's three node-list loops, nor their barriers */
 #endif
-constexpr int SEG_ROWS = SPL_SEG_ROWS;     // rows of a pass: one per thread ((A/B) 128: twice the passes -- what a pass costs)
-constexpr int SG_OFF = 0;        // [33] row of each packed chunk's first byte (+ total)
-constexpr int SG_ITEM = 33;      // [32] its index on the long list
-constexpr int SG_HARD = 65;      // [8 + 2 zero words] bit r: nothing spans the boundary after row r
-constexpr int SG_LONG = 75;      // [16] segments of 17..64 bytes: first row | length << 16
-constexpr int SG_CTL = 91;       // [9] packed chunks, long segments, chunks to leave (bit = packing slot), chunks tried
-                                 //     (bit = list index), cut, chunks appended, mid segments
-constexpr int SG_ID = 100;       // [SEG_ROWS] id of each row's byte
-constexpr int SG_MID = SG_ID + SEG_ROWS;     // [32] segments of 9..16 bytes
-constexpr int SG_XSEG = SG_MID + 32;          // [4] segments of 65 .. 64 XNPL bytes
-constexpr int SG_SBITS = SG_XSEG + 4;         // [8] bit r: row r is the first row of a packed chunk
-constexpr int SG_WORDS = SG_SBITS + 8;
+// Round 5: a pass works per CHARACTER where round 4 worked per byte.  Two in three bytes of CJK text are continuation bytes, where
+// (almost) no token starts -- yet every byte row ran the full tabulation: a prefix entry, a filter byte, six probes and the p8
+// bucket, ~200 branch-free instructions, and a pass of 256 rows held 85 characters (profiles/r04_tail_cost.txt: the tail was 35 %
+// of C3's kernel time, 40 % of C5's).  Now a pass holds up to SEG_ROWS = 448 byte rows and fills them in two steps:
+//   1. every row reads its prefix entry (one 8-byte load).  A continuation byte whose two-byte prefix allows nothing beyond the
+//      two-byte token (98 % of them, measured on the CJK generator for cl100k / o200k / deepseek_v3) is LIGHT: cell 0 is that
+//      token's id, the other cells are empty, done.  Every other row -- lead bytes, ASCII, a chunk's first byte, the rare
+//      continuation byte that starts something longer -- is HEAVY and goes on a dense list;
+//   2. the heavy rows, one per lane off that list, get the full tabulation (row_head + row_fill + p8): a wavefront's 64 lanes
+//      are 64 rows that need it.  512 bytes of Chinese text: 171 + a few heavy rows -- three wavefronts, one round of probes --
+//      where round 4 ran two passes of four wavefronts each.
+// The rows stay one per BYTE (node i of a chunk lives at byte offset i: the merge loops are the ones of round 4); the segments
+// of up to 8 bytes -- nearly all of CJK text -- are likewise put on a dense list first and merged one per lane.
+#ifndef SPL_TAIL_CUT
+#define SPL_TAIL_CUT 0           /* timing experiments only (tokens missing): 1 no segment merges, 2 no heavy-row tabulation either, 3 no per-row step either */
+#endif
+constexpr int SEG_ROWS = SPL_SEG_ROWS;
+constexpr int SEG_RPT = (SEG_ROWS + NT - 1) / NT;     // rows per thread in the row-indexed steps: thread t has rows t, t + NT, ...
+constexpr int SEG_PAD = SEG_RPT * NT;                 // (bitmaps over the rows are sized for whole rounds of threads)
+static_assert(SEG_ROWS % 32 == 0 && SEG_RPT >= 1 && SEG_RPT <= 2, "one or two rows per thread");
+constexpr int SG_OFF = 0;                         // [33] row of each packed chunk's first byte (+ total)
+constexpr int SG_ITEM = 33;                       // [32] its index on the long list
+constexpr int SG_HARD = 65;                       // [SEG_PAD / 32 + 2 zero words] bit r: nothing spans the boundary after row r
+constexpr int SG_LONG = SG_HARD + SEG_PAD / 32 + 2;   // [32] segments of 17..64 bytes: first row | length << 16
+constexpr int SG_CTL = SG_LONG + 32;              // [13] packed chunks, long segments, chunks to leave (bit = packing slot), chunks tried
+                                                  //      (bit = list index), cut, chunks appended, mid segments, x segments, any left, heavy rows, short segments
+constexpr int SG_WS = SG_CTL + 13;                // [8] running-maximum totals per wavefront and half
+constexpr int SG_MID = SG_WS + 8;                 // [64] segments of 9..16 bytes
+constexpr int SG_XSEG = SG_MID + 64;              // [8] segments of 65 .. 64 XNPL bytes
+constexpr int SG_SBITS = SG_XSEG + 8;             // [SEG_PAD / 32] bit r: row r is the first row of a packed chunk
+constexpr int SG_LIST = SG_SBITS + SEG_PAD / 32; // [SEG_PAD / 2] u16 lists, one after the other: heavy rows; then segments of up to 8 bytes (row | len - 1 << 9)
+constexpr int SG_SPRE = SG_LIST + SEG_PAD / 2;     // [SEG_PAD / 32] chunk starts in the bitmap words before this one
+constexpr int SG_WORDS = SG_SPRE + SEG_PAD / 32;
+// sid[SEG_ROWS] (the caller's): each row's byte | its chunk's packing slot << 8 | min(longest token that starts there, 255) << 24 (255: to the
+// chunk's end); bid_tab[256]: DeviceTables::byte_id in LDS (the id of a row's byte is needed where a lone byte stays a token)
 template <int XNPL, class EmitG>
 __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, const Batch& b, uint32_t* s_lq, uint32_t nl,
-                                                      uint32_t* slab, uint32_t* scr, uint32_t* s_wsum4, const uint8_t* win_txt,
-                                                      int64_t win_lo, int64_t win_hi, EmitG emit_g) {
+                                                      uint32_t* slab, uint32_t* scr, uint32_t* sid, const uint32_t* bid_tab,
+                                                      const uint8_t* win_txt, int64_t win_lo, int64_t win_hi, EmitG emit_g) {
     const int tid = tidx(), lane = tid & 63, wv = tid >> 6;
     uint32_t* const off = scr + SG_OFF;
     uint32_t* const item = scr + SG_ITEM;
@@ -122,42 +147,54 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
     uint32_t* const mseg = scr + SG_MID;
     uint32_t* const xseg = scr + SG_XSEG;
     uint32_t* const ctl = scr + SG_CTL;
-    uint32_t* const sid = scr + SG_ID;
+    uint32_t* const wsum = scr + SG_WS;
+    uint16_t* const list = reinterpret_cast<uint16_t*>(scr + SG_LIST);
     auto hbits = [&](int pos) {                              // 32 boundary bits from row `pos` on
         const int w = pos >> 5, sh = pos & 31;
         return (hard[w] >> sh) | (sh ? hard[w + 1] << (32 - sh) : 0u);
     };
     uint32_t* const sbits = scr + SG_SBITS;
-    auto chunk_of = [&](int row) {                           // packing slot of the chunk that owns a row:
-#if !SPL_TILE_MISS_LIST
-        // a handful of packed chunks (long chunks of a tile): a linear search beats the popcounts below
-        // (X1 121 -> 116 us, C3 498 -> 486 us); the bitmap is for the many-chunk packing of SPL_TILE_MISS_LIST
-        { uint32_t kk = 0; while (off[kk + 1] <= (uint32_t)row) kk++; return kk; }
-#endif
-        uint32_t k = 0;                                      // chunk starts at or below it, minus one
+    uint32_t* const spre = scr + SG_SPRE;
+    auto chunk_of = [&](int row) {                           // packing slot of the chunk that owns a row: chunk starts at or below it, minus one
+        // (two LDS reads and a popcount; up to round 4 a linear search of off[] -- a chain of dependent LDS reads that was, with two rows
+        //  per thread, a tenth of a pass's instructions)
         const int rw = row >> 5;
-#pragma unroll
-        for (int w = 0; w < SEG_ROWS / 32; w++) {
-            const uint32_t x = sbits[w];
-            k += w < rw ? __popc(x) : w == rw ? __popc(x & (0xFFFFFFFFu >> (31 - (row & 31)))) : 0u;
-        }
-        return k - 1u;
+        return spre[rw] + (uint32_t)__popc(sbits[rw] & (0xFFFFFFFFu >> (31 - (row & 31)))) - 1u;
     };
-    auto first_byte_of = [&](int row) {                      // global position of a row's byte
-        const uint32_t k = chunk_of(row);
+    auto first_byte_of = [&](int row) {                      // global position of a row's byte (its chunk's packing slot: sid, since step 1)
+        const uint32_t k = (sid[row] >> 8) & 31u;
         return s_lq[2 * item[k]] + ((uint32_t)row - off[k]);
     };
-    if (tid == 0) { ctl[3] = 0; ctl[5] = 0; hard[8] = 0; hard[9] = 0; }
+    // the eight text bytes at a row (w1 only on request): from the tile's window where it is staged, else from memory
+    auto row_text = [&](uint64_t g, bool want1, uint32_t& w0, uint32_t& w1) {
+        const uint64_t B = b.n_bytes;
+        w0 = 0; w1 = 0;
+        if ((int64_t)g >= win_lo && (int64_t)g + 8 <= win_hi) {            // staged with the tile's window: no trip to HBM
+            const LdsAcc wt{nullptr, win_txt};
+            const int q = (int)((int64_t)g - win_lo);
+            w0 = wt.load32(q);
+            if (want1) w1 = wt.load32(q + 4);
+        } else if (g + 8 <= B) { __builtin_memcpy(&w0, b.text + g, 4); if (want1) __builtin_memcpy(&w1, b.text + g + 4, 4); }
+        else for (int q = 0; q < 8; q++) if (g + q < B) (q < 4 ? w0 : w1) |= (uint32_t)b.text[g + q] << (8 * (q & 3));
+    };
+    // (the list's length lives in ctl[12] from here on: as a value it was kept -- in scratch -- across the whole pass for its three uses)
+    {
+        uint32_t* c0 = scr + SG_CTL;                         // (an address of its own: the one LDS base register that served this store and the
+        asm volatile("" : "+v"(c0));                         //  reads at the function's end was kept -- spilled -- across everything in between)
+        if (tid == 0) { c0[3] = 0; c0[5] = 0; c0[12] = nl; hard[SEG_PAD / 32] = 0; hard[SEG_PAD / 32 + 1] = 0; }
+    }
+#ifndef SPL_TT_MASK
+#define SPL_TT_MASK 31u
+#endif
 #ifdef SPL_STAMP_TAIL      /* profiling: wall clock of a pass's steps as thread 0 sees them, summed over all workgroups and passes of
-                              a launch of at most ~4000 tiles (tools/dev/gpu_tail_steps.py; the atomics inflate every step) */
+                              a launch (tools/dev/gpu_tail_steps.py; the atomics inflate every step) */
     unsigned long long tt_prev = 0;
-#define TT(k) do { if (b.dbg && tid == 0) { const unsigned long long tt_now = wall_clock64(); \
+#define TT(k) do { if (b.dbg && tid == 0 && (blockIdx.x & SPL_TT_MASK) == 0u) { const unsigned long long tt_now = wall_clock64(); \
                    if ((k) >= 0) atomicAdd(&b.dbg[16 + 4 * (SPL_DEBUG_BLOCKS - 32) + (k)], tt_now - tt_prev); tt_prev = tt_now; } } while (0)
-#define TT_COUNT() do { if (b.dbg && tid == 0) { atomicAdd(&b.dbg[16 + 4 * (SPL_DEBUG_BLOCKS - 32) + 7], 1ull); \
-                        atomicAdd(&b.dbg[16 + 4 * (SPL_DEBUG_BLOCKS - 32) + 6], (unsigned long long)total); } } while (0)
+#define TT_COUNT(k, v) do { if (b.dbg && tid == 0 && (blockIdx.x & SPL_TT_MASK) == 0u) atomicAdd(&b.dbg[16 + 4 * (SPL_DEBUG_BLOCKS - 32) + (k)], (unsigned long long)(v)); } while (0)
 #else
 #define TT(k) do { } while (0)
-#define TT_COUNT() do { } while (0)
+#define TT_COUNT(k, v) do { } while (0)
 #endif
     for (;;) {
         TT(-1);
@@ -165,8 +202,8 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
         if (wv == 0) {
             // pack: the untried chunks in list order while they fit (lane = list index); a chunk beyond
             // SEG_ROWS goes alone -- its first SEG_ROWS bytes -- once it is the first one left
-            const uint32_t tried = ctl[3];
-            const uint32_t n = (lane < 32 && (uint32_t)lane < nl) ? s_lq[2 * lane + 1] : 0u;
+            const uint32_t tried = ctl[3], nlv = ctl[12];
+            const uint32_t n = (lane < 32 && (uint32_t)lane < nlv) ? s_lq[2 * lane + 1] : 0u;
             const bool elig = n >= 2u && !((tried >> (lane & 31)) & 1u);
             const unsigned long long em = __ballot(elig);
             bool take = false;
@@ -183,20 +220,30 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
             }
             const unsigned long long tm = __ballot(take);
             const uint32_t k = mbcnt64(tm), nk = (uint32_t)__popcll(tm);
-            if (lane < SEG_ROWS / 32) sbits[lane] = 0u;
+            if (lane < SEG_PAD / 32) sbits[lane] = 0u;
             wave_lds_sync();
             if (take) { off[k] = offv; item[k] = (uint32_t)lane; atomicOr(&sbits[offv >> 5], 1u << (offv & 31)); }
+            wave_lds_sync();
+            {
+                const uint32_t sc = lane < SEG_PAD / 32 ? (uint32_t)__popc(sbits[lane]) : 0u;
+                const uint32_t sx = wave_scan_incl(sc);
+                if (lane < SEG_PAD / 32) spre[lane] = sx - sc;
+            }
             const uint32_t endv = offv + (n < (uint32_t)SEG_ROWS ? n : (uint32_t)SEG_ROWS);
             const uint32_t total = tm ? (uint32_t)__builtin_amdgcn_readlane((int)endv, 63 - __builtin_clzll(tm)) : 0u;
             // (for the caller: is ANY chunk of two bytes or more on the list -- packed now, left by an earlier pass, or a long
             //  segment set aside behind its end?  Nearly always not once the last pass is done, and the caller then skips
             //  its three node-list loops and their barriers.)
-            const uint32_t nl_now = nl + ctl[5] < (uint32_t)DIRECT_LQCAP ? nl + ctl[5] : (uint32_t)DIRECT_LQCAP;
+            const uint32_t nl_now = nlv + ctl[5] < (uint32_t)DIRECT_LQCAP ? nlv + ctl[5] : (uint32_t)DIRECT_LQCAP;
             const unsigned long long any_m = __ballot(lane < 32 && (uint32_t)lane < nl_now && s_lq[2 * lane + 1] >= 2u);
+            const unsigned long long left_m = __ballot(lane < 32 && (uint32_t)lane < nl_now && s_lq[2 * lane + 1] >= 2u && !take);
             if (lane == 0) {
                 off[nk] = total;
                 ctl[0] = nk; ctl[1] = 0; ctl[2] = 0; ctl[3] = tried | (uint32_t)tm; ctl[4] = cut; ctl[6] = 0; ctl[7] = 0;
-                ctl[8] = any_m != 0ull;
+                ctl[8] = any_m != 0ull; ctl[9] = 0; ctl[10] = 0;
+                // this pass takes everything that is left (nothing untried stays behind, nothing an earlier pass gave up on): if it
+                // finishes all of it -- the usual case -- the closing empty pass (a pack round and three barriers) is not needed
+                ctl[11] = (left_m == 0ull && !cut) ? 0x80000000u | ctl[5] : 0u;
             }
         }
         __syncthreads();
@@ -204,86 +251,211 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
         if (nk == 0) break;
         TT(0);                                               // pack (and the wait for the previous pass's stragglers)
         const uint32_t total = off[nk];
-        // ---- table rows, longest token per row, boundaries ------------------------------------------
-        const bool own = (uint32_t)tid < total;
+        TT_COUNT(12, 1); TT_COUNT(13, total);
         const bool cut = ctl[4] != 0;                        // the (one) chunk continues beyond the rows
-        int maxlen = 0, cap = 0;                             // cap: bytes left in the row's chunk
-        uint32_t w0 = 0, w1 = 0, bid = SPL_DEAD, lm = 0;
-        uint32_t my_gpos = 0;                                // global position of this row's byte (kept: the row's segment starts there)
-        if (own) {
-            const uint32_t k = chunk_of(tid);
-            const uint32_t ci = (uint32_t)tid - off[k], cn = s_lq[2 * item[k] + 1];
-            const uint64_t g = (uint64_t)s_lq[2 * item[k]] + ci, B = b.n_bytes;
-            my_gpos = (uint32_t)g;
-            cap = (int)(cn - ci);
-            maxlen = cn - ci < (uint32_t)SUB_LMAX ? (int)(cn - ci) : SUB_LMAX;
-            if ((int64_t)g >= win_lo && (int64_t)g + 8 <= win_hi) {        // staged with the tile's window: no trip to HBM
-                const LdsAcc wt{nullptr, win_txt};
-                const int q = (int)((int64_t)g - win_lo);
-                w0 = wt.load32(q); w1 = wt.load32(q + 4);
-            } else if (g + 8 <= B) { __builtin_memcpy(&w0, b.text + g, 4); __builtin_memcpy(&w1, b.text + g + 4, 4); }
-            else for (int q = 0; q < 8; q++) if (g + q < B) (q < 4 ? w0 : w1) |= (uint32_t)b.text[g + q] << (8 * (q & 3));
-            bid = T.byte_id[w0 & 0xFFu];
-        }
-        RowHead rh = row_head(T, own, w0, maxlen);           // which token lengths exist at all behind these bytes
-#if defined(SPL_TAIL_CUT)
-        if (SPL_TAIL_CUT >= 2) { rh.lm = 0; maxlen = maxlen < 2 ? maxlen : 2; }
-#endif
-        lm = rh.lm;
-        uint32_t* const row = slab + tid * SUB_W;
-        int ml = 1;
+        // ---- step 1, per row: the prefix entry; light rows are finished here, heavy rows go on the list -------------
+        // sid[r] = the row's byte | its chunk's packing slot << 8 | (longest token that starts there, 255: to the chunk's end) << 24
         {
-            // all six lengths and the p8 bucket in ONE round trip (row_fill: one entry per probe); up to round 3 two batches
-            // of buckets -- with the lengths 5 / 6 swapped between them for rows that start a three-byte character
-            P8Bucket e8{0u, 0u};
-            const bool want8 = maxlen >= 2 && cap > SUB_LMAX && (lm & 0x80u);
-            if (want8) e8 = T.p8_tab[hash_p8(w0, w1) & T.p8_mask];
-            uint32_t r[7];
-            row_fill(T, rh, w0, w1, maxlen, r);
-            if (maxlen >= 2) {
+            uint32_t rk[SEG_RPT], rw0[SEG_RPT], rcap[SEG_RPT], rci[SEG_RPT];
+            PfxEnt rpe[SEG_RPT];
 #pragma unroll
-                for (int k = 0; k < SUB_W; k++) {
-                    row[k] = r[k];
-                    ml = (r[k] != SPL_NO_RANK && maxlen >= k + 2) ? k + 2 : ml;
+            for (int h = 0; h < SEG_RPT; h++) {                  // (the loads of all of a thread's rows in flight together)
+                const int r = tid + h * NT;
+                rk[h] = 0; rw0[h] = 0; rcap[h] = 0; rci[h] = 0; rpe[h] = PfxEnt{0u, SPL_NO_RANK};
+                if ((uint32_t)r < total && SPL_TAIL_CUT < 3) {
+                    const uint32_t k = chunk_of(r);
+                    const uint32_t ci = (uint32_t)r - off[k], cn = s_lq[2 * item[k] + 1];
+                    const uint64_t g = (uint64_t)s_lq[2 * item[k]] + ci;
+                    uint32_t w0, w1;
+                    row_text(g, false, w0, w1);
+                    rk[h] = k; rw0[h] = w0; rcap[h] = cn - ci; rci[h] = ci;
+                    rpe[h] = T.pfx[w0 & 0xFFFFu];
                 }
             }
-            sid[tid] = bid;
-            if (want8) {
-                const int l8 = (int)p8_match(e8.a, e8.b, p8_tag(w0, w1));
-                if (l8) ml = (l8 == 255 || l8 > cap) ? cap : l8;
+#pragma unroll
+            for (int h = 0; h < SEG_RPT; h++) {
+                const int r = tid + h * NT;
+                const bool own = (uint32_t)r < total;
+                bool heavy = false;
+                if (own && SPL_TAIL_CUT >= 3) { sid[r] = 1u << 24; uint32_t* const row = slab + r * SUB_W; for (int c = 0; c < SUB_W; c++) row[c] = SPL_NO_RANK; }
+                if (own && SPL_TAIL_CUT < 3) {
+                    const uint32_t w0 = rw0[h], cap = rcap[h];
+                    const PfxEnt pe = rpe[h];
+                    // lengths 3 .. min(cap, 8) that exist behind these two bytes, and "longer" if the chunk has room for it
+                    const uint32_t maxlen = cap < (uint32_t)SUB_LMAX ? cap : (uint32_t)SUB_LMAX;
+                    const uint32_t allow = maxlen >= 2u ? ((((1u << (maxlen - 1u)) - 1u) & 0x7Eu) | (cap > (uint32_t)SUB_LMAX ? 0x80u : 0u)) : 0u;
+                    heavy = rci[h] == 0u || (w0 & 0xC0u) != 0x80u || cap < 2u || (pe.lm & allow) != 0u;
+                    uint32_t* const row = slab + r * SUB_W;
+                    const uint32_t sw = (w0 & 0xFFu) | (rk[h] << 8);
+                    if (!heavy) {
+                        row[0] = pe.id2;
+#pragma unroll
+                        for (int c = 1; c < SUB_W; c++) row[c] = SPL_NO_RANK;
+                        sid[r] = sw | ((pe.id2 != SPL_NO_RANK ? 2u : 1u) << 24);
+                    } else {                                     // the head, for the lane that tabulates this row in step 2
+                        row[0] = pe.lm; row[1] = pe.id2;
+                        sid[r] = sw;
+                    }
+                }
+                const unsigned long long hm = __ballot(heavy);
+                uint32_t hb = 0;
+                if (lane == 0 && hm) hb = atomicAdd(&ctl[9], (uint32_t)__popcll(hm));
+                hb = (uint32_t)__builtin_amdgcn_readfirstlane((int)hb);
+                if (heavy) list[hb + mbcnt64(hm)] = (uint16_t)r;
             }
         }
-        TT(1);                                               // rows filled (two dependent round trips: row head, entries)
+        __syncthreads();
+        TT(1);                                               // step 1
+        TT_COUNT(14, ctl[9]);
+        // ---- step 2, per heavy row off the list: the full tabulation (ONE call site of the probe code) -------------------
         {
-            uint32_t cover = wave_scan_max(own ? (uint32_t)(tid + ml - 1) : 0u);
-            if (lane == 63) s_wsum4[wv] = cover;
-            __syncthreads();
-            for (int k = 0; k < wv; k++) cover = s_wsum4[k] > cover ? s_wsum4[k] : cover;
-            const unsigned long long hb = __ballot(own && cover == (uint32_t)tid);
-            if (lane == 0) { hard[2 * wv] = (uint32_t)hb; hard[2 * wv + 1] = (uint32_t)(hb >> 32); }
+            const uint32_t nheavy = SPL_TAIL_CUT >= 2 ? 0u : ctl[9];
+            if (SPL_TAIL_CUT >= 2) for (uint32_t i = (uint32_t)tid; i < ctl[9]; i += NT) { const int r = (int)list[i]; sid[r] = 1u << 24; uint32_t* const row = slab + r * SUB_W; for (int c = 0; c < SUB_W; c++) row[c] = SPL_NO_RANK; }
+#pragma nounroll
+            for (uint32_t i0 = 0; i0 < nheavy; i0 += NT) {
+                if (i0 + (uint32_t)(tid & ~63) >= nheavy) break;             // (wave-uniform: this wavefront has no row of the round)
+                const uint32_t i = i0 + (uint32_t)tid;
+                const bool own = i < nheavy;
+                const int r = own ? (int)list[i] : 0;
+                int maxlen = 0, cap = 0;
+                uint32_t w0 = 0, w1 = 0;
+                RowHead rh{0u, SPL_NO_RANK, 0u, 0u};                 // (as row_head() makes it, from the words step 1 left in the row's cells)
+                uint32_t sw0 = 0;
+                if (own) {
+                    sw0 = sid[r];
+                    const uint32_t k = (sw0 >> 8) & 31u;
+                    const uint32_t ci = (uint32_t)r - off[k], cn = s_lq[2 * item[k] + 1];
+                    const uint64_t g = (uint64_t)s_lq[2 * item[k]] + ci;
+                    cap = (int)(cn - ci);
+                    maxlen = cap < SUB_LMAX ? cap : SUB_LMAX;
+                    row_text(g, true, w0, w1);
+                    const uint32_t* const st = slab + r * SUB_W;
+                    // (the filter entry is fetched HERE, for heavy rows only: fetched in step 1 for every row that is heavy by its byte alone --
+                    //  one dependent round trip less -- the pass was 0.8 us SLOWER: it is the count of scattered loads that costs, not their latency)
+                    const uint32_t plm = st[0], f = maxlen >= 4 ? (uint32_t)T.filt4[hash_f4(w0) >> T.filt4_shift] : 0u;
+                    const uint32_t f4 = SPL_ROW_FILTER ? f & 0x3Fu : (maxlen >= 4 ? 0x3Fu : 0u);
+                    rh.lm = plm & 0xFFu & (0x03u | (f4 << 2));
+                    rh.id2 = st[1];
+                    rh.tsalt = plm >> 16;
+                    rh.fsalt = f >> SPL_F4_MASK_BITS;
+                }
+                int ml = 1;
+                P8Bucket e8{0u, 0u};
+                const bool want8 = maxlen >= 2 && cap > SUB_LMAX && (rh.lm & 0x80u);
+                if (want8) e8 = T.p8_tab[hash_p8(w0, w1) & T.p8_mask];
+                uint32_t rr[7];
+                row_fill(T, rh, w0, w1, maxlen, rr);
+                if (own) {
+                    uint32_t* const row = slab + r * SUB_W;
+#pragma unroll
+                    for (int c = 0; c < SUB_W; c++) {
+                        row[c] = rr[c];                              // (maxlen < 2: all empty)
+                        ml = (rr[c] != SPL_NO_RANK && maxlen >= c + 2) ? c + 2 : ml;
+                    }
+                    if (want8) {
+                        const int l8 = (int)p8_match(e8.a, e8.b, p8_tag(w0, w1));
+                        if (l8) ml = (l8 == 255 || l8 > cap) ? cap : l8;
+                    }
+                    sid[r] = (sw0 & 0x1FFFu) | ((uint32_t)(ml >= cap ? (cap < 255 ? cap : 255) : ml) << 24);   // (ml < 255 unless it is the chunk's end)
+                }
+            }
         }
         __syncthreads();
-        TT(2);                                               // boundaries
+        TT(2);                                               // step 2
+        // ---- boundaries: a running maximum of "last row covered by a token that starts at or before this row" ----------------
+        {
+            uint32_t cov[SEG_RPT];
+            bool ownr[SEG_RPT];
+#pragma unroll
+            for (int h = 0; h < SEG_RPT; h++) {
+                const int r = tid + h * NT;
+                ownr[h] = (uint32_t)r < total;
+                uint32_t reach = 0;
+                if (ownr[h]) {
+                    const uint32_t sw = sid[r], mlb = sw >> 24;
+                    if (mlb == 255u) {                               // to the end of the row's chunk
+                        const uint32_t k = (sw >> 8) & 31u;
+                        const uint32_t cn = s_lq[2 * item[k] + 1];
+                        const uint32_t endr = off[k] + (cn < (uint32_t)SEG_ROWS ? cn : (uint32_t)SEG_ROWS);
+                        reach = (endr < total ? endr : total) - 1u;
+                        if (cut) reach = (uint32_t)SEG_ROWS;          // (the one cut chunk: beyond the rows)
+                    } else reach = (uint32_t)r + mlb - 1u;
+                }
+                cov[h] = wave_scan_max(reach);
+                if (lane == 63) wsum[h * 4 + wv] = cov[h];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int h = 0; h < SEG_RPT; h++) {
+                uint32_t c = cov[h];
+                for (int k = 0; k < wv; k++) c = wsum[h * 4 + k] > c ? wsum[h * 4 + k] : c;
+                if (h == 1) for (int k = 0; k < NT / 64; k++) c = wsum[k] > c ? wsum[k] : c;
+                const unsigned long long hb = __ballot(ownr[h] && c == (uint32_t)(tid + h * NT));
+                if (lane == 0) { hard[h * (NT / 32) + 2 * wv] = (uint32_t)hb; hard[h * (NT / 32) + 2 * wv + 1] = (uint32_t)(hb >> 32); }
+            }
+        }
+        __syncthreads();
+        TT(3);                                               // boundaries
         // a cut chunk: only what lies before the last boundary among the rows is complete; the rest
         // goes back on the list as a chunk of its own (nothing spans that boundary)
         uint32_t rows = total;
         if (cut) {
             int last = -1;
-            for (int w = SEG_ROWS / 32 - 1; w >= 0 && last < 0; w--) if (hard[w]) last = 32 * w + 31 - __clz((int)hard[w]);
+            for (int w = SEG_PAD / 32 - 1; w >= 0 && last < 0; w--) if (hard[w]) last = 32 * w + 31 - __clz((int)hard[w]);
             rows = (uint32_t)(last + 1);
             if (last < 0 && tid == 0) ctl[2] = 1u;           // no boundary at all: left to the node-list loops
         }
-        // ---- every row that starts a segment: up to 8 bytes are merged by the row's own lane (all spans
-        //      are in the table), longer ones go to a group of 16 lanes, a wavefront, or back on the list
-#ifndef SPL_TAIL_CUT
-#define SPL_TAIL_CUT 0           /* timing experiments only (tokens missing): 1 no segment merges, 2 no table probes either */
-#endif
-        if (SPL_TAIL_CUT < 1 && (uint32_t)tid < rows && (tid == 0 || ((hard[(tid - 1) >> 5] >> ((tid - 1) & 31)) & 1u))) {
-            const uint32_t h0 = hbits(tid);                  // the first boundary at or after the start ends the segment
-            if (h0 & 0xFFu) {
-                const int len = __ffs((int)h0);
-                const uint32_t gpos = my_gpos;                         // (= first_byte_of(tid), without the search for the row's chunk)
-                const uint32_t* const cells = slab + tid * SUB_W;      // node x of the segment: cells + x * SUB_W
+        // ---- every row that starts a segment: up to 8 bytes go on the short list (one lane each below), longer ones to a
+        //      group of 16 lanes, a wavefront, or back on the list
+#pragma unroll
+        for (int h = 0; h < SEG_RPT; h++) {
+            const int r = tid + h * NT;
+            bool shortseg = false;
+            uint32_t slen = 0;
+            if ((uint32_t)r < rows && (r == 0 || ((hard[(r - 1) >> 5] >> ((r - 1) & 31)) & 1u))) {
+                const uint32_t h0 = hbits(r);                    // the first boundary at or after the start ends the segment
+                if (h0 & 0xFFu) { shortseg = true; slen = (uint32_t)__ffs((int)h0); }
+                else if (h0 & 0xFFFFu) {
+                    mseg[atomicAdd(&ctl[6], 1u)] = (uint32_t)r | (uint32_t)__ffs((int)h0) << 16;
+                } else {
+                    const uint32_t h1 = hbits(r + 32);
+                    const uint32_t l2 = h0 ? (uint32_t)__ffs((int)h0) : h1 ? 32u + (uint32_t)__ffs((int)h1) : 65u;
+                    if (l2 <= 64u) lseg[atomicAdd(&ctl[1], 1u)] = (uint32_t)r | l2 << 16;
+                    else {
+                        int q = r + 64;
+                        uint32_t hq;
+                        while ((hq = hbits(q)) == 0) q += 32;    // (the last row of a chunk is a boundary)
+                        const uint32_t l3 = (uint32_t)(q - r) + (uint32_t)__ffs((int)hq);
+                        const uint32_t qi = ctl[12] + (l3 <= 64u * XNPL ? 0u : atomicAdd(&ctl[5], 1u));
+                        if (l3 <= 64u * XNPL) xseg[atomicAdd(&ctl[7], 1u)] = (uint32_t)r | l3 << 16;   // a wavefront, several nodes per lane
+                        else if (qi < (uint32_t)DIRECT_LQCAP) {  // longer still: a chunk of its own for the loops below
+                            s_lq[2 * qi] = first_byte_of(r);
+                            s_lq[2 * qi + 1] = l3;
+                            atomicOr(&ctl[3], 1u << qi);         // (not to be packed again)
+                        } else {                                 // no room: the whole chunk stays on the list
+                            atomicOr(&ctl[2], 1u << ((sid[r] >> 8) & 31u));
+                        }
+                    }
+                }
+            }
+            const unsigned long long sm = __ballot(shortseg);
+            uint32_t sb = 0;
+            if (lane == 0 && sm) sb = atomicAdd(&ctl[10], (uint32_t)__popcll(sm));
+            sb = (uint32_t)__builtin_amdgcn_readfirstlane((int)sb);
+            if (shortseg) list[sb + mbcnt64(sm)] = (uint16_t)((uint32_t)r | (slen - 1u) << 9);
+        }
+        __syncthreads();
+        TT(4);                                               // classification of the segments
+        TT_COUNT(15, ctl[10]);
+        // ---- segments of up to 8 bytes, one lane each off the dense list: all their spans are in the table ----------------
+        {
+            const uint32_t nshort = SPL_TAIL_CUT >= 1 ? 0u : ctl[10];
+#pragma nounroll
+            for (uint32_t i = (uint32_t)tid; i < nshort; i += NT) {
+                const uint32_t ent = list[i];
+                const int r = (int)(ent & 511u), len = (int)(ent >> 9) + 1;
+                const uint32_t gpos = first_byte_of(r);
+                const uint32_t* const cells = slab + r * SUB_W;      // node x of the segment: cells + x * SUB_W
                 uint32_t alive = (1u << len) - 1u;
                 for (;;) {                                   // bpe.rs:118-190 on at most 8 nodes in a bit mask
                     uint32_t best = SPL_NO_RANK, kill = 0, m = alive;
@@ -293,8 +465,8 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
                         const int y = __ffs((int)m) - 1;
                         const uint32_t m2 = m & (m - 1u);
                         const int e2 = m2 ? __ffs((int)m2) - 1 : len;
-                        const uint32_t r = cells[x * SUB_W + (e2 - x - 2)];
-                        if (r < best) { best = r; kill = 1u << y; }
+                        const uint32_t rk = cells[x * SUB_W + (e2 - x - 2)];
+                        if (rk < best) { best = rk; kill = 1u << y; }
                         x = y;
                         m = m2;
                     }
@@ -305,66 +477,50 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
                     const int x = __ffs((int)m) - 1;
                     m &= m - 1u;
                     const int e2 = m ? __ffs((int)m) - 1 : len;
-                    emit_g(gpos + (uint32_t)x, e2 - x == 1 ? sid[tid + x] : cells[x * SUB_W + (e2 - x - 2)]);
-                }
-            } else if (h0 & 0xFFFFu) {
-                mseg[atomicAdd(&ctl[6], 1u)] = (uint32_t)tid | (uint32_t)__ffs((int)h0) << 16;
-            } else {
-                const uint32_t h1 = hbits(tid + 32);
-                const uint32_t l2 = h0 ? (uint32_t)__ffs((int)h0) : h1 ? 32u + (uint32_t)__ffs((int)h1) : 65u;
-                if (l2 <= 64u) lseg[atomicAdd(&ctl[1], 1u)] = (uint32_t)tid | l2 << 16;
-                else {
-                    int q = tid + 64;
-                    uint32_t hq;
-                    while ((hq = hbits(q)) == 0) q += 32;    // (the last row of a chunk is a boundary)
-                    const uint32_t l3 = (uint32_t)(q - tid) + (uint32_t)__ffs((int)hq);
-                    const uint32_t qi = nl + (l3 <= 64u * XNPL ? 0u : atomicAdd(&ctl[5], 1u));
-                    if (l3 <= 64u * XNPL) xseg[atomicAdd(&ctl[7], 1u)] = (uint32_t)tid | l3 << 16;   // a wavefront, several nodes per lane
-                    else if (qi < (uint32_t)DIRECT_LQCAP) {  // longer still: a chunk of its own for the loops below
-                        s_lq[2 * qi] = my_gpos;
-                        s_lq[2 * qi + 1] = l3;
-                        atomicOr(&ctl[3], 1u << qi);         // (not to be packed again)
-                    } else {                                 // no room: the whole chunk stays on the list
-                        atomicOr(&ctl[2], 1u << chunk_of(tid));
-                    }
+                    emit_g(gpos + (uint32_t)x, e2 - x == 1 ? bid_tab[sid[r + x] & 0xFFu] : cells[x * SUB_W + (e2 - x - 2)]);
                 }
             }
         }
-        __syncthreads();
-        TT(3);                                               // segments of up to 8 bytes, classification of the rest
+        TT(5);                                               // segments of up to 8 bytes (thread 0's wavefront)
         // ---- segments of 9..16 bytes: a group of 16 lanes each ------------------------------------------
         {
             const int gi = tid >> 4, gl = tid & 15;
-            const uint32_t nmid = ctl[6];
+            const uint32_t nmid = SPL_TAIL_CUT >= 1 ? 0u : ctl[6];
             for (uint32_t q0 = 0; q0 < nmid; q0 += NT / 16) {
                 const uint32_t q = q0 + (uint32_t)gi;
                 const int s0 = q < nmid ? (int)(mseg[q] & 0xFFFFu) : 0, len = q < nmid ? (int)(mseg[q] >> 16) : 0;
                 const uint32_t gpos = len ? first_byte_of(s0) : 0u;
                 const bool gown = gl < len;
-                group16_merge(T, slab + (gown ? s0 + gl : 0) * SUB_W, gown ? sid[s0 + gl] : SPL_DEAD, len, FAR_UNBOUNDED,
+                // (far_max: the longest token that can start at the lane's byte -- the row's own bound, from its cells and the p8 table --
+                //  so that a span beyond it ranks "none" without a trip to the pair table; up to round 4 every span of more than 8
+                //  bytes went there, a dependent round trip per merge round: profiles/r05_tail_cost.txt)
+                const uint32_t sw = gown ? sid[s0 + gl] : 0u;
+                group16_merge(T, slab + (gown ? s0 + gl : 0) * SUB_W, gown ? bid_tab[sw & 0xFFu] : SPL_DEAD, len,
+                              (sw >> 24) == 255u ? FAR_UNBOUNDED : (int)(sw >> 24),
                               [&](int i, uint32_t id) { emit_g(gpos + (uint32_t)i, id); });
             }
         }
-        TT(4);                                               // 9..16 (thread 0's wavefront)
+        TT(6);                                               // 9..16 (thread 0's wavefront)
+        TT_COUNT(16, ctl[6]); TT_COUNT(17, ctl[1]);
         // ---- segments of 17..64 bytes: one wavefront each ------------------------------------------
-        for (uint32_t q = (uint32_t)wv; q < ctl[1]; q += NT / 64) {
+        for (uint32_t q = (uint32_t)wv; q < (SPL_TAIL_CUT >= 1 ? 0u : ctl[1]); q += NT / 64) {
             const int s0 = (int)(lseg[q] & 0xFFFFu), len = (int)(lseg[q] >> 16);
             const uint32_t gpos = first_byte_of(s0);
             const bool lown = lane < len;
             const uint32_t* const lrow = slab + (lown ? s0 + lane : 0) * SUB_W;
+            const uint32_t sw = lown ? sid[s0 + lane] : 0u;
             wave64_merge(T, lrow, len >= 64 ? ~0ull : ((1ull << len) - 1ull), len, lane + 1 < len ? lrow[0] : SPL_NO_RANK,
-                         lown ? sid[s0 + lane] : SPL_DEAD, FAR_UNBOUNDED,
+                         lown ? bid_tab[sw & 0xFFu] : SPL_DEAD, (sw >> 24) == 255u ? FAR_UNBOUNDED : (int)(sw >> 24),
                          [&](int i, uint32_t id) { emit_g(gpos + (uint32_t)i, id); });
         }
-        for (uint32_t q = (uint32_t)wv; q < ctl[7]; q += NT / 64) {          // 65 .. 64 XNPL bytes
+        for (uint32_t q = (uint32_t)wv; q < (SPL_TAIL_CUT >= 1 ? 0u : ctl[7]); q += NT / 64) {          // 65 .. 64 XNPL bytes
             const int s0 = (int)(xseg[q] & 0xFFFFu), len = (int)(xseg[q] >> 16);
             const uint32_t gpos = first_byte_of(s0);
-            wave_tab_merge<XNPL>(T, len, slab + s0 * SUB_W, [&](int i) { return sid[s0 + i]; },
+            wave_tab_merge<XNPL>(T, len, slab + s0 * SUB_W, [&](int i) { return bid_tab[sid[s0 + i] & 0xFFu]; },
                                  [&](int i, uint32_t id) { emit_g(gpos + (uint32_t)i, id); });
         }
         __syncthreads();
-        TT(5);                                               // 17..64, 65.. and the wait for the other wavefronts
-        TT_COUNT();
+        TT(7);                                               // 17..64, 65.. and the wait for the other wavefronts
         if ((uint32_t)tid < nk && !((ctl[2] >> tid) & 1u)) {
             if (!cut) s_lq[2 * item[tid] + 1] = 0;          // done: off the list
             else {                                           // the rest of a cut chunk: to be packed again
@@ -375,12 +531,16 @@ __device__ __forceinline__ uint32_t bpe_tail_segments(const DeviceTables& T, con
                 ctl[3] &= ~(1u << item[tid]);
             }
         }
+        // (ctl[2], ctl[5], ctl[11]: final since the barrier behind the classification of the segments -- the same in every thread)
+        if (SPL_TAIL_SKIP_EMPTY && (ctl[11] >> 31) && ctl[2] == 0u && ctl[5] == (ctl[11] & 0x7FFFFFFFu)) { __syncthreads(); return 0u; }
     }
     __syncthreads();
 #undef TT
 #undef TT_COUNT
-    const uint32_t nl2 = nl + ctl[5];                       // the list grew by the segments set aside
-    if (SPL_TAIL_SKIP_EMPTY && !ctl[8]) return 0u;          // (as of the last, empty pass: nothing of two bytes or more is left)
+    const uint32_t* c1 = scr + SG_CTL;
+    asm volatile("" : "+v"(c1));
+    const uint32_t nl2 = c1[12] + c1[5];                    // the list grew by the segments set aside
+    if (SPL_TAIL_SKIP_EMPTY && !c1[8]) return 0u;           // (as of the last, empty pass: nothing of two bytes or more is left)
     return nl2 < (uint32_t)DIRECT_LQCAP ? nl2 : (uint32_t)DIRECT_LQCAP;
 }
 

@@ -5,7 +5,7 @@ end around tile and window edges, special-token literals, everything joined into
 edge_batch:   runs of ONE class that outgrow a tile's halo and end in multi-byte characters of the same
 class at 300 consecutive alignments against the window edges, optionally with special tokens and empty
 texts right behind the edge -- the family that found both window-edge bugs of round 2.
-Used by tests/test_gpu_stress.py (fixed seeds, in the driver-run suite) and tools/dev/gpu_stress.py /
+Used by tests/test_gpu_stress.py (fixed seeds, in the driver-run suite) and tools/gpu_stress.py /
 gpu_edge_sweep.py (open-ended runs)."""
 import json
 import os

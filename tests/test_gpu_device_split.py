@@ -89,6 +89,49 @@ def test_device_bitmaps_equal_the_host_splitter_s(key):
         assert np.array_equal(gp, dgp), f"gap bits differ first at byte {_first_diff(gp, dgp)}"
 
 
+@pytest.mark.parametrize("key", sorted(PATTERNS))
+def test_device_bitmaps_equal_pcre2_find_iter(key):
+    """spl_split_device against the ORACLE directly -- match offsets from PCRE2's find_iter (oracle/pyoracle.py, UTF | UCP) turned into
+    the two bitmaps by the rule of include/splintr_hip.h (a start bit where a match or a stretch of uncovered bytes begins, a gap bit
+    on every uncovered byte) -- with no splitter of the product in between (VERDICT r04 next #4)."""
+    from oracle import pyoracle as O
+    from splintr_amd import Tokenizer
+    if not O.pcre2_available():
+        pytest.skip("libpcre2-8 not present")
+    t = Tokenizer.from_bytes(_blob("cl100k_base"), PATTERNS[key])
+    rx = O.Pcre2Pattern(PATTERNS[key])
+    texts = fuzz_corpus(811, 1500, 40) + latin_corpus(13, 300, 90) + cased_corpus(15, 300, 70)
+    texts += ["", " ", "\n", "a", "'", "x's'S'\u017f'K'\u212a", "http://a.b/c?d=e www.x.y z", "\u4f60\u597d\u4f60\u597d \u4f60 \u597d", "a\nb\r\nc",
+              "12345678901" * 9, "a  ", "  \n", "it'S 'LL '\u017f 'Ve", "$12 \u20ac3 \u00a3 -- \u2014 \u2015", "foo_bar1 baz", "end  \n", "", "x"]
+    for batch in (texts, texts[::-1], ["".join(texts[:300])]):
+        parts = [x.encode("utf-8") for x in batch]
+        n = sum(len(x) for x in parts)
+        words = n // 32 + 2
+        st, gp = np.zeros(words, dtype=np.uint32), np.zeros(words, dtype=np.uint32)
+
+        def setbit(bm, q):
+            bm[q >> 5] |= np.uint32(1 << (q & 31))
+        base = 0
+        for doc in parts:
+            at = 0
+            for s, e in rx.find_iter(doc):
+                if s > at:                                   # uncovered bytes: ONE start bit, a gap bit each
+                    setbit(st, base + at)
+                    for q in range(at, s):
+                        setbit(gp, base + q)
+                setbit(st, base + s)
+                at = e
+            if at < len(doc):
+                setbit(st, base + at)
+                for q in range(at, len(doc)):
+                    setbit(gp, base + q)
+            base += len(doc)
+        _, _, dst, dgp, status = _both(t, batch)
+        assert status == 0, f"the device matcher gave up (status {status})"
+        assert np.array_equal(st, dst), f"start bits differ from PCRE2's first at byte {_first_diff(st, dst)}"
+        assert np.array_equal(gp, dgp), f"gap bits differ from PCRE2's first at byte {_first_diff(gp, dgp)}"
+
+
 def test_invalid_utf8_and_document_boundaries_inside_characters():
     """raw bytes: stray continuation bytes, truncated sequences at document ends, documents of one byte"""
     from splintr_amd import Tokenizer

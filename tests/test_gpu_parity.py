@@ -269,7 +269,7 @@ def test_chunk_that_straddles_the_window_end(coracle, name, geom):
     """A chain that outgrows its window and ends in a multi-byte character on the window's edge: a run of numbers
     (three to a chunk) closed by U+2167, at every alignment.  The last chunk then reaches up to two bytes beyond
     the window -- its last token may START there --, or ends exactly on the edge, where the next chunk is a sync
-    point of the neighbouring tile.  (Found by tools/dev/gpu_stress.py, seed 22739: a token id read from behind
+    point of the neighbouring tile.  (Found by tools/gpu_stress.py, seed 22739: a token id read from behind
     the tile's id array, a chunk worked twice.)"""
     pad = lambda n: ("lorem ipsum " * 400)[:n]
     _force_tiles(name, geom)

@@ -12,7 +12,12 @@ TB = 800
 PASS = int(os.environ.get("SPL_WALLS_PASS", "0"))
 L = _ffi.lib()
 tok = Tokenizer.from_pretrained(os.environ.get("SPL_WALLS_VOCAB", "cl100k_base"))
-texts = getattr(corpus, gen)(ndocs)
+if gen == "purecjk":
+    import random
+    _r = random.Random(7)
+    texts = [corpus.cjk(_r, 4000) for _ in range(ndocs)]
+else:
+    texts = getattr(corpus, gen)(ndocs)
 batch = DeviceBatch(texts, torch.device("cuda", 0))
 reserve(tok, batch.n_bytes, batch.n_docs)
 st = (ctypes.c_uint64 * 16)()

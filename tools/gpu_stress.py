@@ -1,14 +1,18 @@
-"""Dev aid: open-ended randomized parity stress (tests/stressgen.py's random_batch; the driver-run suite holds a
-fixed block of its seeds in tests/test_gpu_stress.py).   python tools/dev/gpu_stress.py [seconds] [first seed]"""
+"""Open-ended randomized parity stress (tests/stressgen.py's random_batch; the driver-run suite holds a
+fixed block of its seeds in tests/test_gpu_stress.py).   python tools/gpu_stress.py --seconds 120 --seed 1000   (the lines in profiles/*_stress.txt are this command's last line)"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_parity as tg
 from stressgen import random_batch, MODES_ALL
 from test_gpu_stress import _compiled
 from oracle.coracle import COracle
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=120.0, help="wall-clock budget")
+ap.add_argument("--seed", type=int, default=1000, help="first seed")
+args = ap.parse_args()
+budget, seed0 = args.seconds, args.seed
 orcs = {}
 def coracle(name):
     if name not in orcs: orcs[name] = COracle(name)
