@@ -109,7 +109,8 @@ uint32_t spl_n_devices(const spl_tokenizer* t);
  * "subdoc_split" (0/1: balance the GPUs by cutting large documents at context-free boundaries),
  * "direct_write" (0/1, default 1: one-chunk batches have the last kernel write the ids straight into
  * the pinned result instead of copying them back), "device_split" (0/1, default 1: a custom split pattern's
- * split runs on the GPU, see spl_split_device; 0 keeps it on the host cores). */
+ * split runs on the GPU, see spl_split_device; 0 keeps it on the host cores), "small_path" (0/1, default 1: batches of at most 4 KB take
+ * the latency path, see spl_small_path_calls). */
 int spl_set_option(spl_tokenizer* t, const char* name, int64_t value);
 
 /* One entry of the special_tokens map (src/core/tokenizer.rs:304, 429-434).  Call before the first
@@ -140,6 +141,13 @@ int spl_reserve(spl_tokenizer* t, uint64_t max_bytes, uint64_t max_docs);
  * buffers are recycled; a result stays valid after spl_destroy). */
 int spl_encode_batch(spl_tokenizer* t, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs,
                      uint32_t flags, spl_result** out);
+/* The latency path (Tokenizer::encode of ONE text, src/core/tokenizer.rs:729-808 -- "~50 MB/s", :266-268): a batch of at most 4096 bytes and
+ * 256 documents on a handle with a built-in pattern does not go through the chunk pipeline.  The CPU copies text and offsets into one small
+ * pinned buffer, the tile kernel reads them there (a few cache lines over PCIe), k_tile_out writes ids and offsets into the pinned result
+ * and, behind a system-scope fence, a completion word the calling thread spins on: two launches, no copy engine, no stream
+ * synchronisation (31 us for a 1 KB text, 23 us for 13 bytes, against 44 / 34 us through the pipeline; the tile kernel's chain of phases
+ * alone is 17 us).  spl_set_option("small_path", 0) turns it off; spl_small_path_calls counts the calls that took it. */
+uint64_t spl_small_path_calls(const spl_tokenizer* t);
 const uint32_t* spl_result_tokens(const spl_result* r);   /* ids[T] */
 const uint64_t* spl_result_offsets(const spl_result* r);  /* out_off[n_docs+1] */
 uint64_t spl_result_n_tokens(const spl_result* r);

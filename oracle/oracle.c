@@ -58,7 +58,7 @@ static int uclass_load(uclass_t *u, const char *path) {
     uint32_t ver;
     char uver[16];
     if (fread(magic, 1, 4, f) != 4 || memcmp(magic, "SPLU", 4)) { fclose(f); return -2; }
-    if (fread(&ver, 4, 1, f) != 1 || (ver != 1 && ver != 2)) { fclose(f); return -2; }   /* (version 2 appends general categories: not used here) */
+    if (fread(&ver, 4, 1, f) != 1 || (ver < 1 || ver > 3)) { fclose(f); return -2; }   /* (versions 2 / 3 append general categories / scripts: not used here) */
     if (fread(&u->shift, 4, 1, f) != 1 || fread(&u->nblocks, 4, 1, f) != 1 ||
         fread(uver, 1, 16, f) != 16) { fclose(f); return -2; }
     size_t n1 = 0x110000u >> u->shift, n2 = (size_t)u->nblocks << u->shift;

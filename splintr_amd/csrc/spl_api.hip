@@ -186,6 +186,13 @@ struct Ctx {
     uint32_t tgroups = 0, tpar = 0;
     uint64_t* off_host = nullptr;             // set by the caller of launch_all: where k_tile_out also stores the offsets (one-chunk host batches)
     bool off_host_written = false;            // launch_all: the tile-owned mode did so
+    // latency path (encode_small): text and offsets read where they lie in pinned host memory, completion by a word k_tile_out stores there
+    uint32_t* done_arm = nullptr;             // set by the caller of launch_all: device pointer of the completion word (this call only)
+    uint32_t done_seq = 0;
+    bool done_armed = false;                  // launch_all: k_tile_out will store it
+    uint8_t* h_small = nullptr; uint8_t* dh_small = nullptr;       // pinned: [text 4096 + 64 | offsets 8 * 257 | completion word], and its device pointer
+    uint32_t small_calls = 0;
+    const void* dp_host[2] = {nullptr, nullptr}; void* dp_dev[2] = {nullptr, nullptr};   // device pointers of the last two pinned result buffers
     bool bitmap_dirty = true;
     // host pipeline (spl_encode_batch / spl_decode_batch)
     hipStream_t s_cmp = nullptr, s_h2d = nullptr, s_d2h = nullptr;
@@ -256,6 +263,7 @@ struct Ctx {
         hipFree((void*)d_dec_sp_ids); hipFree((void*)d_dec_sp_off);
         hipFree(d_ids); hipFree(d_oo);
         hipFree((void*)d_rx_image); hipFree((void*)d_gc1); hipFree((void*)d_gc2); hipFree(d_rx_ws); hipFree(d_rx_status); hipFree(d_rx_bits); if (h_rx_status) (void)hipHostFree(h_rx_status);
+        if (h_small) (void)hipHostFree(h_small);
         hipFree(d_dec_ids); hipFree(d_dec_blk); hipFree(d_dec_idoff); hipFree(d_dec_out); hipFree(d_dec_first); hipFree(d_dec_docoff);
         if (ev_ready) for (auto& e : ev) (void)hipEventDestroy(e);
         for (int i = 0; i < NSLOT; i++) { if (ev_h2d[i]) (void)hipEventDestroy(ev_h2d[i]); if (ev_cmp[i]) (void)hipEventDestroy(ev_cmp[i]); }
@@ -286,6 +294,8 @@ struct spl_tokenizer {
     uint32_t est_div = 2;                     // first guess of the token count: n_bytes / est_div
     int subdoc = 1;                           // cut documents at context-free boundaries to balance the GPUs
     int direct_write = 1;                     // one-chunk batches: the last kernel writes the ids straight into the pinned result
+    int small_path = 1;                       // batches of up to 4 KB take the latency path (encode_small)
+    uint64_t small_calls = 0;                 // ... and how many did (spl_small_path_calls)
 };
 
 // One rank of a node-wide communicator (one process per GPU; RCCL over xGMI).
@@ -534,7 +544,7 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
     b.qcap64 = t->qcap64; b.qcaplong = t->qcaplong; b.qcapdefer = t->qcapdefer;
     b.dbg = (t->dbg_on || t->prof) ? t->d_dbg : nullptr;
     b.stop_phase = (uint32_t)t->stop_phase;
-    { const char* e = getenv("SPL_DEBUG_WG"); b.dbg_wg = e ? (uint32_t)strtoul(e, nullptr, 10) : 0xFFFFFFFFu; }
+    { static const uint32_t dbg_wg = [] { const char* e = getenv("SPL_DEBUG_WG"); return e ? (uint32_t)strtoul(e, nullptr, 10) : 0xFFFFFFFFu; }(); b.dbg_wg = dbg_wg; }
     if (t->prof) {
         const unsigned long long init[2] = {~0ull, 0ull};
         HIP_TRY(hipMemcpyAsync(t->d_dbg + 14, init, 16, hipMemcpyHostToDevice, s));
@@ -604,8 +614,13 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
         b.tdesc = t->d_tdesc; b.tile_ids = t->d_tile_ids; b.tctl = t->d_tctl;
         b.tgroups = t->tgroups; b.tpar = t->tpar; b.tslot = (uint32_t)TileGeom<SPL_TILE_SMALL>::Wv + 1u;
         if (so && ntiles) { b.slab = so->d_slab; b.slab_cap = (uint32_t)so->cap_words; b.slab_max_docs = (uint32_t)so->max_docs; }
+        // (The latency path as ONE launch -- the last workgroup of the tile kernel turning every tile's record into the CSR by itself, no
+        //  k_tile_out -- was built and measured in round 5: 33.6 us per 1 KB call against 31.2 with the two launches, 23.9 against 22.8 for 13
+        //  bytes.  Two back-to-back launches overlap the second one's dispatch with the first kernel; the fused epilogue's device-scope fences,
+        //  L1-bypassing loads and serial walk over the tiles cost more than that launch.  Dropped.)
         if (ntiles) t->tpar ^= 1u;              // k_tile_out zeroes the other parity's sums for the next call
         if (ntiles && t->off_host) { b.off_out2 = t->off_host; t->off_host_written = true; }
+        if (ntiles && t->done_arm) { b.done = t->done_arm; b.done_seq = t->done_seq; t->done_armed = true; }
         if (!special) b.tstart = nullptr;
         b.qcount = nullptr;
         t->last_qcount = nullptr;
@@ -1152,6 +1167,76 @@ int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t
     return SPL_OK;
 }
 
+// ---- the latency path: a batch of a few KB (Tokenizer.encode(text), src/python/bindings.rs:254-256 -> tokenizer.rs:729-808) ----------
+// A 1 KB text through the pipeline below cost 47 us, of which the tile kernel's chain of phases is 17: two H2D copies (text, offsets), two
+// launches, a stream synchronisation and ~10 us of host-side set-up around them.  Here: the text and its offsets are copied by the CPU
+// into ONE small pinned buffer that the tile kernel reads where it lies (over PCIe: a handful of cache lines), k_tile_out writes ids and
+// offsets straight into the pinned result and -- its last workgroup, behind a system-scope fence -- a completion word the host spins on.
+// No copy engine, no event, no hipStreamSynchronize (every 256th call synchronises the stream so that the runtime retires its signals).
+constexpr uint64_t SMALL_MAX_BYTES = 4096, SMALL_MAX_DOCS = 256;
+constexpr size_t SMALL_TEXT = SMALL_MAX_BYTES + 64, SMALL_OFF = (SMALL_MAX_DOCS + 1) * 8;
+void* dev_ptr_cached(Ctx* c, void* host) {
+    for (int i = 0; i < 2; i++) if (c->dp_host[i] == host) return c->dp_dev[i];
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, host, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    c->dp_host[1] = c->dp_host[0]; c->dp_dev[1] = c->dp_dev[0];
+    c->dp_host[0] = host; c->dp_dev[0] = d;
+    return d;
+}
+int encode_small(spl_tokenizer* tk, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags, spl_result* r) {
+    Ctx* c = tk->ctx[0].get();
+    const uint64_t n_bytes = doc_off[n_docs];
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_streams(*c);
+    if (rc) return rc;
+    if (!c->h_small) {
+        HIP_TRY(hipHostMalloc((void**)&c->h_small, SMALL_TEXT + SMALL_OFF + 64, hipHostMallocPortable));
+        void* dp = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&dp, c->h_small, 0));
+        c->dh_small = (uint8_t*)dp;
+        memset(c->h_small, 0, SMALL_TEXT + SMALL_OFF + 64);
+    }
+    volatile uint32_t* const done = (volatile uint32_t*)(c->h_small + SMALL_TEXT + SMALL_OFF);
+    memcpy(c->h_small, utf8, n_bytes);
+    memcpy(c->h_small + SMALL_TEXT, doc_off, (n_docs + 1) * 8);
+    if ((rc = reserve(c, std::max<uint64_t>(n_bytes, SMALL_MAX_BYTES), std::max<uint64_t>(n_docs, SMALL_MAX_DOCS)))) return rc;
+    if (n_docs + 1 > c->oo_cap) {
+        HIP_TRY(hipDeviceSynchronize());
+        hipFree(c->d_oo); c->d_oo = nullptr;
+        c->oo_cap = SMALL_MAX_DOCS + 1 + 1024;
+        HIP_TRY(hipMalloc((void**)&c->d_oo, c->oo_cap * 8));
+    }
+    r->pool = tk->pool;
+    r->n_docs = n_docs;
+    r->off = (uint64_t*)tk->pool->get((n_docs + 1) * 8, r->off_cap);
+    r->ids = (uint32_t*)tk->pool->get((n_bytes + 16) * 4, r->ids_cap);      // (tokens <= bytes: the kernel writes into it directly)
+    if (!r->off || !r->ids) return fail(SPL_EDEVICE, "pinned result allocation failed");
+    uint32_t* const d_ids = (uint32_t*)dev_ptr_cached(c, r->ids);
+    uint64_t* const d_off = (uint64_t*)dev_ptr_cached(c, r->off);
+    if (!d_ids || !d_off) return fail(SPL_EDEVICE, "hipHostGetDevicePointer failed");
+    c->off_host = d_off; c->off_host_written = false;
+    c->done_seq = c->done_seq + 1u ? c->done_seq + 1u : 1u;                  // (never 0: the word's resting value)
+    c->done_arm = (uint32_t*)(c->dh_small + SMALL_TEXT + SMALL_OFF); c->done_armed = false;
+    rc = launch_all(tk, c, c->dh_small, n_bytes, (const uint64_t*)(c->dh_small + SMALL_TEXT), n_docs, flags, d_ids, n_bytes + 16, c->d_oo, c->s_cmp);
+    const bool armed = c->done_armed, offs = c->off_host_written;
+    c->off_host = nullptr; c->done_arm = nullptr;
+    if (rc) return rc;
+    if (!offs) HIP_TRY(hipMemcpyAsync(r->off, c->d_oo, (n_docs + 1) * 8, hipMemcpyDeviceToHost, c->s_cmp));
+    bool seen = false;
+    if (armed && offs) {
+        // (a call normally completes in 25-40 us; a GPU that is busy with other work may take longer: after ~2 ms the stream is synchronised instead)
+        const uint32_t want = c->done_seq;
+        for (uint32_t spin = 0; spin < 400000u; spin++) {
+            if (*done == want) { seen = true; break; }
+            __builtin_ia32_pause();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!seen || (++c->small_calls & 255u) == 0u) HIP_TRY(hipStreamSynchronize(c->s_cmp));
+    r->n_tokens = r->off[n_docs];
+    return SPL_OK;
+}
+
 int encode_host(spl_tokenizer* tk, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags, spl_result* r,
                 bool host_split = true) {
     HT_T(ht0);
@@ -1527,6 +1612,7 @@ int spl_set_option(spl_tokenizer* t, const char* name, int64_t value) {
     else if (k == "subdoc_split") t->subdoc = value != 0;
     else if (k == "direct_write") t->direct_write = value != 0;
     else if (k == "device_split") t->rx_device = value != 0;
+    else if (k == "small_path") t->small_path = value != 0;
     else return fail(SPL_EINVAL, "spl_set_option: unknown option or bad value: " + k);
     return SPL_OK;
 }
@@ -1613,6 +1699,13 @@ int spl_encode_batch(spl_tokenizer* t, const uint8_t* utf8, const uint64_t* doc_
     if (doc_off[n_docs] && !utf8) return fail(SPL_EINVAL, "spl_encode_batch: null text");
     try {
         std::unique_ptr<spl_result> r(new spl_result());
+        if (t->small_path && !t->regex && doc_off[n_docs] > 0 && doc_off[n_docs] <= SMALL_MAX_BYTES && n_docs <= SMALL_MAX_DOCS) {
+            int rcs = encode_small(t, utf8, doc_off, n_docs, flags, r.get());
+            if (rcs) return rcs;
+            t->small_calls++;
+            *out = r.release();
+            return SPL_OK;
+        }
         const bool dev_split = rx_applies(t, flags);
         if (dev_split)                                      // (the status words of the contexts the batch may use: cleared, in stream order)
             for (auto& c : t->ctx) {
@@ -1970,6 +2063,7 @@ int spl_split_device(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, 
 }
 
 uint64_t spl_device_split_fallbacks(const spl_tokenizer* t) { return t ? t->rx_fallbacks : 0; }
+uint64_t spl_small_path_calls(const spl_tokenizer* t) { return t ? t->small_calls : 0; }
 
 int spl_encode_chunks_device(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
                              uint64_t n_docs, const uint32_t* d_start_bits, const uint32_t* d_gap_bits, uint32_t* d_ids,

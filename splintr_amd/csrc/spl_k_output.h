@@ -19,10 +19,13 @@ struct TileOutArgs {
     uint32_t* tctl; const TileDesc* tdesc; const uint32_t* tile_ids; uint32_t* ids_out; uint64_t ids_cap; uint64_t* off_out; uint64_t* off_out2;
     uint32_t* slab; uint32_t* tbits; const uint32_t* stage; const uint32_t* skip;
     uint32_t tpar, tgroups, tslot, slab_cap, slab_max_docs, n_docs;
+    // latency path (small host batches): the LAST workgroup to finish stores done_seq to *done (pinned host memory, system scope) behind
+    // everybody's result stores -- the host spins on that word instead of synchronising the stream (tctl[8]: workgroups finished)
+    uint32_t* done; uint32_t done_seq;
 };
 inline TileOutArgs tile_out_args(const Batch& b) {
     return TileOutArgs{b.tctl, b.tdesc, b.tile_ids, b.ids_out, b.ids_cap, b.off_out, b.off_out2, b.slab, b.tbits, b.stage, b.skip,
-                       b.tpar, b.tgroups, b.tslot, b.slab_cap, b.slab_max_docs, b.n_docs};
+                       b.tpar, b.tgroups, b.tslot, b.slab_cap, b.slab_max_docs, b.n_docs, b.done, b.done_seq};
 }
 __global__ __launch_bounds__(TOUT_NT) void k_tile_out(TileOutArgs b) {
     __shared__ unsigned long long s_part[TOUT_NT / 64];
@@ -95,6 +98,15 @@ __global__ __launch_bounds__(TOUT_NT) void k_tile_out(TileOutArgs b) {
     if (t == 0) {
         uint32_t* other = b.tctl + 16 + (b.tpar ^ 1u) * b.tgroups;
         for (uint32_t k = tid; k < b.tgroups; k += TOUT_NT) other[k] = 0u;
+    }
+    if (b.done) {                                            // (uniform: a kernel argument)
+        __threadfence_system();                              // this workgroup's result stores, visible system-wide ...
+        __syncthreads();
+        if (tid == 0 && atomicAdd(&b.tctl[8], 1u) == gridDim.x - 1u) {        // ... before it counts as finished; the last one:
+            b.tctl[8] = 0u;                                  // (re-armed for the next call on this context)
+            __threadfence_system();
+            __hip_atomic_store(b.done, b.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 

@@ -123,6 +123,7 @@ struct Batch {
     // bit p of ext_starts: a chunk -- or a stretch of dropped bytes -- starts at byte p; bit p of ext_gaps: byte p is
     // dropped (no match covers it).  Tile-owned mode only; the scanner phases are skipped.
     const uint32_t* ext_starts; const uint32_t* ext_gaps;
+    uint32_t* done; uint32_t done_seq;       // tile-owned mode, optional: k_tile_out's completion word in pinned host memory (spl_k_output.h)
 };
 
 // LDS hand-over between the lanes of ONE wavefront (no workgroup barrier)

@@ -122,8 +122,35 @@ struct Parser {
                 {"Cc", 1u << GC_Cc}, {"Cf", 1u << GC_Cf}, {"Cs", 1u << GC_Cs}, {"Co", 1u << GC_Co}, {"Cn", 1u << GC_Cn},
                 {"C", (1u << GC_Cc) | (1u << GC_Cf) | (1u << GC_Cs) | (1u << GC_Co) | (1u << GC_Cn)}};
             for (const auto& e : GCS) if (name == e.n) g = e.g;
-            if (!g) return fail("\\p{" + name + "}: general categories (L, Lu .. Lo, L&, M, Mn .. Me, N, Nd .. No, P, Pc .. Po, S, Sm .. So, Z, Zs .. Zp, C, Cc .. Cn) "
-                                "are the properties implemented; scripts and binary properties are not", at);
+            if (!g) {
+                // a SCRIPT (\p{Han}, \p{Hiragana}, \p{Latin}, \p{Script=Cyrillic}, \p{sc=Greek} ...): the ranges the class table carries for it
+                // (version 3: probed from the engine the table stands for), added to the set -- complemented for \P{..} / \p{^..}
+                std::string sn = name;
+                for (const char* pre : {"Script=", "script=", "sc=", "Is"})
+                    if (sn.compare(0, strlen(pre), pre) == 0 && sn.size() > strlen(pre)) { sn = sn.substr(strlen(pre)); break; }
+                auto norm = [](const std::string& x) {
+                    std::string r;
+                    for (char ch : x) if (ch != '_' && ch != ' ' && ch != '-') r += (char)std::tolower((unsigned char)ch);
+                    return r;
+                };
+                const HostTables::Script* found = nullptr;
+                for (const auto& sc : prog.ht->scripts) if (norm(sc.name) == norm(sn)) found = &sc;
+                if (found) {
+                    if (negate_item != inner_neg) {
+                        uint32_t next = 0;
+                        for (const auto& rg : found->ranges) {                  // (ascending, disjoint)
+                            if (rg.first > next) cs.ranges.emplace_back(next, rg.first - 1u);
+                            next = rg.second + 1u;
+                        }
+                        if (next <= 0x10FFFFu) cs.ranges.emplace_back(next, 0x10FFFFu);
+                    } else for (const auto& rg : found->ranges) cs.ranges.push_back(rg);
+                    return true;
+                }
+                return fail("\\p{" + name + "}: general categories (L, Lu .. Lo, L&, M, Mn .. Me, N, Nd .. No, P, Pc .. Po, S, Sm .. So, Z, Zs .. Zp, C, Cc .. Cn) and "
+                                    + (prog.ht->scripts.empty() ? std::string("-- with a version-3 class table -- ") : std::string()) +
+                                    "scripts (Han, Hiragana, Katakana, Hangul, Latin, Cyrillic ...) are the properties implemented; binary properties and "
+                                    "script extensions are not", at);
+            }
             if (prog.ht->gc_stage1.empty())
                 return fail("\\p{" + name + "} needs the general-category table (a version-2 class table: splintr_amd/data/unicode_classes.bin)", at);
         }

@@ -340,7 +340,7 @@ __device__ __forceinline__ uint32_t rx_vm(RxCtx& c, uint32_t* stk, const RxArgs&
                         uint32_t e_new;
                         // (what is charged against RX_STEPS is the work done: one bit scan inside the tabulated window, k characters re-counted
                         //  beyond it.  Charging k either way made `\s*[\r\n]+` give up on 200 blanks without a newline -- 200 + 199 + ... steps
-                        //  for 200 bit scans; found by the oracle pin of tests/test_gpu_custom_pattern.py, round 5)
+                        //  for 200 bit scans; found by the PCRE2 pin of tests/test_gpu_custom_pattern.py, round 5)
                         if (ei <= (uint32_t)RX_TAB) { e_new = k ? c.wb + c.last_set_below(cs, ei) : pos; steps += 1u; }     // the start of the run's last character
                         else { e_new = pos; for (uint32_t j = 0; j < k; j++) e_new += c.char_len(e_new); steps += k; }
                         if (k > c.inst(pc).y) { stk[(2 * sp) * RXT] = pc | (k << 16); stk[(2 * sp + 1) * RXT] = (pos - p) | ((e_new - p) << 16); sp++; }

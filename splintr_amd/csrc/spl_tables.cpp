@@ -90,7 +90,7 @@ uint32_t host_cp_category(const HostTables& t, uint32_t cp) {
 int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size_t ucls_len, int pattern,
                  bool force_byte_level, HostTables& out, std::string& err) {
     // ---- class table -------------------------------------------------------------------
-    if (ucls_len < 32 || memcmp(ucls, "SPLU", 4) != 0 || (rd32(ucls + 4) != 1 && rd32(ucls + 4) != 2)) { err = "bad unicode class table"; return 1; }
+    if (ucls_len < 32 || memcmp(ucls, "SPLU", 4) != 0 || rd32(ucls + 4) < 1 || rd32(ucls + 4) > 3) { err = "bad unicode class table"; return 1; }
     const uint32_t ucls_version = rd32(ucls + 4);
     out.ucls_shift = rd32(ucls + 8);
     const uint32_t nblocks = rd32(ucls + 12);
@@ -118,6 +118,26 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
         out.gc_stage2.assign(ucls + at + n1 * 2, ucls + at + n1 * 2 + g2);
         for (uint16_t b : out.gc_stage1)
             if (b >= gnb) { err = "unicode class table: category block index out of range"; return 1; }
+        // version 3: behind the categories, the SCRIPT property as ranges per script name (\p{Han}, \p{Hiragana}, \p{Latin} ... in a
+        // custom split pattern: spl_regex.cpp)
+        out.scripts.clear();
+        if (ucls_version >= 3) {
+            at += n1 * 2 + g2;
+            if (ucls_len < at + 4) { err = "truncated unicode class table (scripts)"; return 1; }
+            const uint32_t ns = rd32(ucls + at);
+            at += 4;
+            for (uint32_t k = 0; k < ns; k++) {
+                if (ucls_len < at + 36) { err = "truncated unicode class table (scripts)"; return 1; }
+                HostTables::Script sc;
+                sc.name.assign((const char*)ucls + at, strnlen((const char*)ucls + at, 32));
+                const uint32_t nr = rd32(ucls + at + 32);
+                at += 36;
+                if (ucls_len < at + (size_t)nr * 8) { err = "truncated unicode class table (scripts)"; return 1; }
+                for (uint32_t q = 0; q < nr; q++) sc.ranges.emplace_back(rd32(ucls + at + 8 * q), rd32(ucls + at + 8 * q + 4));
+                at += (size_t)nr * 8;
+                out.scripts.push_back(std::move(sc));
+            }
+        }
     }
     out.cjk_fast = true;
     for (uint32_t cp = 0x4E00; cp < 0xA000 && out.cjk_fast; cp++) out.cjk_fast = host_cp_class(out, cp) == C_LO;

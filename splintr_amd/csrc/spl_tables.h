@@ -7,6 +7,7 @@
 // short-key / long-key / pair tables the kernels probe (spl_common.h).
 #pragma once
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "spl_common.h"
@@ -19,6 +20,9 @@ struct HostTables {
     std::vector<uint8_t> ucls_stage2;
     std::vector<uint16_t> gc_stage1;      // general categories (class table version 2; empty otherwise): host splitter only
     std::vector<uint8_t> gc_stage2;
+    // the SCRIPT property (class table version 3; empty otherwise): inclusive code-point ranges per script name, host splitter only
+    struct Script { std::string name; std::vector<std::pair<uint32_t, uint32_t>> ranges; };
+    std::vector<Script> scripts;
     uint32_t ucls_shift = 7;
     bool cjk_fast = false;
     // vocabulary

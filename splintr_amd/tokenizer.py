@@ -246,8 +246,9 @@ class Tokenizer:
         return _ffi.shim().encode(self._h, text, flags)
 
     def encode(self, text: str) -> List[int]:
-        """src/python/bindings.rs:254-256."""
-        return self._encode_one(text, 0)
+        """src/python/bindings.rs:254-256.  Texts of up to 4 KB take the library's latency path (csrc/spl_api.hip encode_small: no copy
+        engine, no stream synchronisation -- the tile kernel reads the text from pinned host memory, the host spins on a completion word)."""
+        return _ffi.shim().encode(self._h, text, 0)
 
     def encode_rayon(self, text: str) -> List[int]:
         """src/python/bindings.rs:273-275: same ids as encode (the GPU path is always

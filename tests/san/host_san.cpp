@@ -31,7 +31,8 @@ int main(int argc, char** argv) {
     memcpy(&nd, corpus.data(), 8);
     const uint64_t* off = reinterpret_cast<const uint64_t*>(corpus.data() + 8);
     const uint8_t* text = corpus.data() + 8 + 8 * (nd + 1);
-    const char* pats[] = {"'s|'t|'re|'ve|'m|'ll|'d| ?\\p{L}+| ?\\p{N}+| ?[^\\s\\p{L}\\p{N}]+|\\s+(?!\\S)|\\s+", "\\p{L}+|[0-9]{1,3}"};
+    const char* pats[] = {"'s|'t|'re|'ve|'m|'ll|'d| ?\\p{L}+| ?\\p{N}+| ?[^\\s\\p{L}\\p{N}]+|\\s+(?!\\S)|\\s+", "\\p{L}+|[0-9]{1,3}",
+                          "\\p{Han}+|[\\p{Hiragana}\\p{Katakana}]+|\\P{Latin}|\\p{Latin}+"};
     for (const char* pat : pats) {
         spl::RegexPtr re = spl::regex_compile(pat, ht, err);
         if (!re) { fprintf(stderr, "regex_compile: %s\n", err.c_str()); return 4; }
@@ -57,7 +58,7 @@ int main(int argc, char** argv) {
         printf("pattern ok: %llu start bits over %llu bytes\n", (unsigned long long)chunks, (unsigned long long)off[nd]);
     }
     // refused patterns must fail cleanly
-    for (const char* pat : {"\\p{Han}+", "(a", "a*", "[z-a]", "\\p{Foo}", "(?<=x)y", "(?i:\\p{Lu})", "\\b+"}) {
+    for (const char* pat : {"\\p{Alphabetic}+", "(a", "a*", "[z-a]", "\\p{Foo}", "(?<=x)y", "(?i:\\p{Lu})", "\\b+"}) {
         spl::RegexPtr re = spl::regex_compile(pat, ht, err);
         if (re) { fprintf(stderr, "pattern %s should have been refused\n", pat); return 7; }
     }

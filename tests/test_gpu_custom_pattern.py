@@ -13,8 +13,8 @@ import pytest
 
 from conftest import ROOT
 from fuzzgen import cased_corpus, fuzz_corpus, latin_corpus
-from test_host_regex import (DEEPSEEK_LIKE, GPT2_PATTERN, MIXED, QWEN2, SPARSE, TIKTOKEN_CL100K, TIKTOKEN_O200K, VARIANT_A, VARIANT_B,
-                             WORDS_DIGITS)
+from test_host_regex import (DEEPSEEK_LIKE, GPT2_PATTERN, MIXED, QWEN2, SCRIPTS, SCRIPTS_NEG, SPARSE, TIKTOKEN_CL100K, TIKTOKEN_O200K, VARIANT_A,
+                             VARIANT_B, WORDS_DIGITS)
 
 pytestmark = pytest.mark.gpu
 DATA = os.path.join(ROOT, "splintr_amd", "data")
@@ -64,6 +64,9 @@ def _texts(seed):
     ("qwen2", "cl100k_base", QWEN2, False),
     ("deepseek_like", "deepseek_v3", DEEPSEEK_LIKE, True),
     ("words_digits", "llama3", WORDS_DIGITS, False),
+    # round 5: script properties -- \p{Han} \p{Hiragana} \p{Katakana} \p{Hangul} \p{Latin}, and their complements
+    ("scripts", "o200k_base", SCRIPTS, False),
+    ("scripts_neg", "cl100k_base", SCRIPTS_NEG, False),
 ])
 def test_custom_patterns_bit_exact(key, vocab, pattern, bl):
     from splintr_amd import _ffi
@@ -220,8 +223,8 @@ def test_split_on_the_host_encode_on_the_device_entry_points():
 
 def test_unsupported_patterns_raise_the_reference_s_error_type():
     from splintr_amd import Tokenizer
-    with pytest.raises(ValueError, match=r"Regex error.*Han"):
-        Tokenizer.from_bytes(_blob("cl100k_base"), r"\p{Han}+|\s+")
+    with pytest.raises(ValueError, match=r"Regex error.*Alphabetic"):
+        Tokenizer.from_bytes(_blob("cl100k_base"), r"\p{Alphabetic}+|\s+")
     with pytest.raises(ValueError, match="empty string"):
         Tokenizer.from_bytes(_blob("cl100k_base"), r"a*")
     with pytest.raises(IOError, match="look-behind"):

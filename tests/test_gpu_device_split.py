@@ -8,14 +8,14 @@ import numpy as np
 import pytest
 
 from fuzzgen import cased_corpus, fuzz_corpus, latin_corpus
-from test_host_regex import (DEEPSEEK_LIKE, GPT2_PATTERN, MIXED, QWEN2, SPARSE, TIKTOKEN_CL100K, TIKTOKEN_O200K, VARIANT_A, VARIANT_B,
-                             WORDS_DIGITS)
+from test_host_regex import (DEEPSEEK_LIKE, GPT2_PATTERN, MIXED, QWEN2, SCRIPTS, SCRIPTS_NEG, SPARSE, TIKTOKEN_CL100K, TIKTOKEN_O200K, VARIANT_A,
+                             VARIANT_B, WORDS_DIGITS)
 
 pytestmark = pytest.mark.gpu
 DATA = os.path.join(os.path.dirname(__file__), "..", "splintr_amd", "data")
 PATTERNS = {"gpt2": GPT2_PATTERN, "variant_a": VARIANT_A, "variant_b": VARIANT_B, "sparse": SPARSE, "mixed": MIXED,
             "tiktoken_cl100k": TIKTOKEN_CL100K, "tiktoken_o200k": TIKTOKEN_O200K, "qwen2": QWEN2, "deepseek_like": DEEPSEEK_LIKE,
-            "words_digits": WORDS_DIGITS}
+            "words_digits": WORDS_DIGITS, "scripts": SCRIPTS, "scripts_neg": SCRIPTS_NEG}
 
 
 def _blob(name):

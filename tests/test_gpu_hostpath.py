@@ -186,3 +186,40 @@ def test_round_trip_property_on_arbitrary_unicode():
             assert t.encode(texts[0]) == enc[0]
 
     prop()
+
+
+def test_latency_path_equals_the_pipeline_and_the_oracle(coracle):
+    """Batches of at most 4 KB / 256 documents take encode_small (csrc/spl_api.hip: text read from pinned host memory, completion by a
+    word the host spins on): the same ids as the chunk pipeline and as the oracle, at every size up to and across the limit, for
+    several documents, empty ones, special tokens, multi-byte text cut by the limit; and the counter says which calls took it.
+    Reference: Tokenizer::encode, src/core/tokenizer.rs:729-808."""
+    import random
+    from splintr_amd import Tokenizer, corpus, _ffi
+    from test_gpu_parity import oracle_csr
+    L = _ffi.lib()
+    rng = random.Random(31)
+    base = "".join(corpus.c2(8, seed=5)) + "".join(corpus.c3(2, seed=6))
+    for name in ("cl100k_base", "o200k_base", "deepseek_v3"):
+        t = Tokenizer.from_pretrained(name)
+        orc = coracle(name)
+        cases = [[base[:n]] for n in (1, 2, 13, 100, 799, 800, 801, 1600, 2500, 4000)]
+        cases += [[base[k:k + 4096].encode("utf-8")[:4096].decode("utf-8", "ignore")] for k in (0, 3000, 9000)]      # at the limit
+        cases += [[base[:5000]], [base[10000:10000 + 4200]]]                                                  # beyond it: the pipeline
+        cases += [["", "a", "", base[:300], "", "\n", base[300:900]], [base[i * 10:i * 10 + 9] for i in range(256)], ["x"] * 256, ["x"] * 257]
+        cases += [["<|endoftext|>" + base[:200] + "<|endoftext|>", "a<|endoftext|>"]]
+        for texts in cases:
+            for special in (False, True):
+                n_bytes = sum(len(x.encode("utf-8")) for x in texts)
+                want_ids, want_off = oracle_csr(orc, texts, special)
+                got = {}
+                for on in (1, 0):
+                    assert L.spl_set_option(t.handle, b"small_path", on) == 0
+                    before = L.spl_small_path_calls(t.handle)
+                    ids, off = t.encode_batch_csr(texts, with_special=special)
+                    took = L.spl_small_path_calls(t.handle) - before
+                    assert took == (1 if on and 0 < n_bytes <= 4096 and len(texts) <= 256 else 0), (n_bytes, len(texts), on, took)
+                    assert np.array_equal(off, want_off) and np.array_equal(ids, want_ids), (name, n_bytes, len(texts), special, on)
+        L.spl_set_option(t.handle, b"small_path", 1)
+        for _ in range(300):                                     # many calls in a row (the completion word, the 256-call synchronisation)
+            x = base[rng.randrange(0, 20000):][:rng.randrange(1, 1200)]
+            assert t.encode(x) == orc.encode_batch([x])[0]

@@ -31,13 +31,19 @@ QWEN2 = r"(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}| ?[^\s\p{L
 DEEPSEEK_LIKE = (r"\p{N}{1,3}|[\x{4e00}-\x{9fa5}\x{3040}-\x{309f}\x{30a0}-\x{30ff}]+|[!-/:-@\[-`{-~][A-Za-z]+|[^\r\n\p{L}\p{P}\p{S}]?[\p{L}\p{M}]+|"
                  r" ?[\p{P}\p{S}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+")
 WORDS_DIGITS = r"\b\w+\b|\d++|(?>\s+)(?=\S)|\p{Zs}+|\p{Sc}\d*|\p{Pd}+|\A\W|\W\z|[^\w\s]"
+# round 5: SCRIPT properties, as CJK-aware tokenizers use them (Kimi / GLM style: Han runs apart from the other letters, kana and
+# hangul runs of their own), and their complements (\P{..}, \p{^..}, a script inside a negated class)
+SCRIPTS = (r"\p{Han}+|[\p{Hiragana}\p{Katakana}\x{30fc}]+|\p{Hangul}+|[^\r\n\p{L}\p{N}]?[\p{Latin}\p{M}]+(?i:'s|'t|'re|'ve|'m|'ll|'d)?|[^\r\n\p{L}\p{N}]?\p{L}+|"
+           r"\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+")
+SCRIPTS_NEG = r"[^\P{Cyrillic}\x{0451}]+|\p{^Latin}{1,5}|\p{Latin}+[\P{Greek}&]?"
 
 
 def _patterns():
     from splintr_amd import CL100K_BASE_PATTERN, O200K_BASE_PATTERN, MISTRAL_V3_PATTERN
     return {"cl100k": CL100K_BASE_PATTERN, "o200k": O200K_BASE_PATTERN, "mistral_v3": MISTRAL_V3_PATTERN, "gpt2": GPT2_PATTERN,
             "variant_a": VARIANT_A, "variant_b": VARIANT_B, "sparse": SPARSE, "mixed": MIXED, "tiktoken_cl100k": TIKTOKEN_CL100K,
-            "tiktoken_o200k": TIKTOKEN_O200K, "qwen2": QWEN2, "deepseek_like": DEEPSEEK_LIKE, "words_digits": WORDS_DIGITS}
+            "tiktoken_o200k": TIKTOKEN_O200K, "qwen2": QWEN2, "deepseek_like": DEEPSEEK_LIKE, "words_digits": WORDS_DIGITS,
+            "scripts": SCRIPTS, "scripts_neg": SCRIPTS_NEG}
 
 
 @pytest.fixture(scope="module")
@@ -47,7 +53,7 @@ def sim():
 
 
 @pytest.mark.parametrize("key", ["cl100k", "o200k", "mistral_v3", "gpt2", "variant_a", "variant_b", "sparse", "mixed", "tiktoken_cl100k",
-                                 "tiktoken_o200k", "qwen2", "deepseek_like", "words_digits"])
+                                 "tiktoken_o200k", "qwen2", "deepseek_like", "words_digits", "scripts", "scripts_neg"])
 def test_host_splitter_equals_pcre2(sim, key):
     from hostsim import HostRegex
     from oracle import pyoracle as O
@@ -59,7 +65,8 @@ def test_host_splitter_equals_pcre2(sim, key):
     texts = fuzz_corpus(4242, 2500, 40) + latin_corpus(7, 400, 80) + cased_corpus(9, 400, 60)
     texts += ["", " ", "\n", "a", "'", "'s", "x's'S'ſ'K'K", "http://a.b/c?d=e www.x.y z", "你好你好 你 好", "a\nb\r\nc", "{[()]}", "12345678901",
               "a  ", "a \n", "  \n", "x  \n\n", "it'S 'LL 'ſ 'Ve", "$12 €3 £ -- — ―", "٣٤٥ ⅷ ² 12", "foo_bar1 baz", "ひらがな カタカナ 漢字 한글", "a b c",
-              "«quoted» “x” ‘y’", "±×÷ ^ ` ~", "́x ⃝", "end\n", "end  \n"]
+              "«quoted» “x” ‘y’", "±×÷ ^ ` ~", "́x ⃝", "end\n", "end  \n",
+              "漢字かなカナー한글 mixed латиница ελληνικά it's 漢's", "ёЁжук ё", "々〆〇 㐀 𠀀 ｶﾅ ㍿"]
     bad = 0
     for t in texts:
         b = t.encode("utf-8")
@@ -86,7 +93,7 @@ def test_split_bits_mark_chunks_and_gaps(sim):
 
 
 @pytest.mark.parametrize("pattern, what", [
-    (r"(?<=a)b", "look-behind"), (r"(a)\1", r"\1"), (r"\p{Han}+", "Han"), (r"\p{Greek}", "Greek"), (r"[[:alpha:]]", "POSIX"), (r"\Gx", r"\G"),
+    (r"(?<=a)b", "look-behind"), (r"(a)\1", r"\1"), (r"\p{Alphabetic}+", "Alphabetic"), (r"\p{Emoji}", "Emoji"), (r"\p{scx=Han}", "scx=Han"), (r"[[:alpha:]]", "POSIX"), (r"\Gx", r"\G"),
     (r"a\Kb", r"\K"), (r"[\W]", r"\W inside"), (r"(?i:\p{Lu}+)", "under (?i)"), (r"(?i:[à-ÿ])", "non-ASCII"),
     (r"(a", "without )"), (r"a)", "unbalanced"), (r"[a", "without ]"), (r"a{5,2}", "n < m"), (r"(?i:é)", "non-ASCII literal"),
     (r"a*", "empty string"), (r"(a|b*)c?", "empty string"), (r"(a*)*", "empty string"), (r"x{2000}", "beyond 1000"), (r"^", "empty string"),

@@ -69,4 +69,4 @@ def test_product_host_code_under_sanitizers(corpus_file, kind, flags):
         with open(stamp, "w") as f:
             f.write(want + "\n")
     out = _run(exe, corpus_file, {"ASAN_OPTIONS": "detect_leaks=1"})
-    assert out.count("pattern ok") == 2 and "unsalted groups 0" in out
+    assert out.count("pattern ok") == 3 and "unsalted groups 0" in out

@@ -15,6 +15,9 @@ Output: ``splintr_amd/data/unicode_classes.bin``
     (version 2) u32 gc_n_blocks | u16 gc_stage1[0x110000 >> block_shift] | u8 gc_stage2[gc_n_blocks << block_shift]
                 the GENERAL CATEGORY of every code point (GC_NAMES), for the host splitter's \p{P} \p{S} \p{Z}
                 \p{Nd} ... \d (csrc/spl_regex.cpp); the GPU scanner only needs the classes above
+    (version 3) u32 n_scripts | n_scripts x { char[32] name | u32 n_ranges | n_ranges x { u32 first | u32 last } }
+                the SCRIPT property as the engine classes it (\p{Han}, \p{Hiragana}, \p{Latin} ... -- every script name the engine
+                accepts of SCRIPT_NAMES), as inclusive code-point ranges: custom split patterns of CJK-aware tokenizers
 Class codes: see CLASS_NAMES (shared with splintr_amd/csrc/spl_scan.h).
 
 ``--engine regex``: the same tables probed from the Python ``regex`` module instead (its Unicode version is newer than
@@ -34,6 +37,18 @@ CLASS_NAMES = ["P", "AP", "SP", "WS", "NL", "N", "Lu", "Ll", "Lt", "Lm", "Lo", "
 # general categories, code = index (csrc/spl_regex.cpp GC_*); Cn = everything no other category claims
 GC_NAMES = ["Cn", "Lu", "Ll", "Lt", "Lm", "Lo", "Mn", "Mc", "Me", "Nd", "Nl", "No", "Pc", "Pd", "Ps", "Pe", "Pi", "Pf", "Po",
             "Sm", "Sc", "Sk", "So", "Zs", "Zl", "Zp", "Cc", "Cf", "Cs", "Co"]
+# Unicode script names (UAX #24 through Unicode 15.1); an engine that does not know one is skipped for that name
+SCRIPT_NAMES = """Adlam Ahom Anatolian_Hieroglyphs Arabic Armenian Avestan Balinese Bamum Bassa_Vah Batak Bengali Bhaiksuki Bopomofo Brahmi Braille
+Buginese Buhid Canadian_Aboriginal Carian Caucasian_Albanian Chakma Cham Cherokee Chorasmian Common Coptic Cuneiform Cypriot Cypro_Minoan Cyrillic
+Deseret Devanagari Dives_Akuru Dogra Duployan Egyptian_Hieroglyphs Elbasan Elymaic Ethiopic Georgian Glagolitic Gothic Grantha Greek Gujarati
+Gunjala_Gondi Gurmukhi Han Hangul Hanifi_Rohingya Hanunoo Hatran Hebrew Hiragana Imperial_Aramaic Inherited Inscriptional_Pahlavi
+Inscriptional_Parthian Javanese Kaithi Kannada Katakana Kawi Kayah_Li Kharoshthi Khitan_Small_Script Khmer Khojki Khudawadi Lao Latin Lepcha Limbu
+Linear_A Linear_B Lisu Lycian Lydian Mahajani Makasar Malayalam Mandaic Manichaean Marchen Masaram_Gondi Medefaidrin Meetei_Mayek Mende_Kikakui
+Meroitic_Cursive Meroitic_Hieroglyphs Miao Modi Mongolian Mro Multani Myanmar Nabataean Nag_Mundari Nandinagari New_Tai_Lue Newa Nko Nushu
+Nyiakeng_Puachue_Hmong Ogham Ol_Chiki Old_Hungarian Old_Italic Old_North_Arabian Old_Permic Old_Persian Old_Sogdian Old_South_Arabian Old_Turkic
+Old_Uyghur Oriya Osage Osmanya Pahawh_Hmong Palmyrene Pau_Cin_Hau Phags_Pa Phoenician Psalter_Pahlavi Rejang Runic Samaritan Saurashtra Sharada
+Shavian Siddham SignWriting Sinhala Sogdian Sora_Sompeng Soyombo Sundanese Syloti_Nagri Syriac Tagalog Tagbanwa Tai_Le Tai_Tham Tai_Viet Takri
+Tamil Tangsa Tangut Telugu Thaana Thai Tibetan Tifinagh Tirhuta Toto Ugaritic Vai Vithkuqi Wancho Warang_Citi Yezidi Yi Zanabazar_Square""".split()
 C = {n: i for i, n in enumerate(CLASS_NAMES)}
 BLOCK_SHIFT = 7
 
@@ -159,7 +174,28 @@ def main():
             folds.append((cp, ord(ch)))
         print(f"(?i:{ch}) ->", [f"U+{c:04X}" for c in sorted(m)])
 
-    out = bytearray(struct.pack("<4sIII16s", b"SPLU", 2, BLOCK_SHIFT, nblocks, uver.encode()[:16]))
+    # scripts: the runs of \p{Name}+ over all code points in order ARE its ranges
+    scripts = []
+    for name in SCRIPT_NAMES:
+        try:
+            m = members(r"\p{%s}+" % name, data, offs)
+        except Exception:
+            continue
+        if not m:
+            continue
+        rs, cps = [], sorted(m)
+        a = b = cps[0]
+        for cp in cps[1:]:
+            if cp == b + 1 or (b == 0xD7FF and cp == 0xE000):
+                b = cp
+            else:
+                rs.append((a, b)); a = b = cp
+        rs.append((a, b))
+        scripts.append((name, rs))
+    print(f"scripts: {len(scripts)} of {len(SCRIPT_NAMES)} names known to the engine, {sum(len(r) for _, r in scripts)} ranges; "
+          f"Han {sum(b - a + 1 for a, b in dict(scripts).get('Han', []))} code points")
+
+    out = bytearray(struct.pack("<4sIII16s", b"SPLU", 3, BLOCK_SHIFT, nblocks, uver.encode()[:16]))
     out += struct.pack(f"<{len(stage1)}H", *stage1)
     out += stage2
     out += struct.pack("<I", len(folds))
@@ -168,6 +204,11 @@ def main():
     out += struct.pack("<I", gnb)
     out += struct.pack(f"<{len(g1)}H", *g1)
     out += g2
+    out += struct.pack("<I", len(scripts))
+    for name, rs in scripts:
+        out += struct.pack("<32sI", name.encode(), len(rs))
+        for a, b in rs:
+            out += struct.pack("<II", a, b)
     path = os.path.join(OUT, "unicode_classes.bin" if ENGINE == "pcre2" else "unicode_classes_regex.bin")
     with open(path, "wb") as f:
         f.write(out)
