@@ -213,7 +213,32 @@ def main():
         mx = torch.tensor([max(n_tokens), max(b.n_docs for b in batches)], dtype=torch.int64, device=dev)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         comm = Comm.from_torch_group(dev)       # the library's own RCCL communicator (spl_comm_*): torch only carries its 128-byte id
-        gv = GatherV(tok, dev, max_docs=int(mx[1].item()), max_tokens=int(int(mx[0].item()) * 1.02) + 64, comm=comm)
+        # Untimed start-up calibration (VERDICT r04 #2b): bucket depth x collective form -- ncclAllGather of the bucket's slabs against
+        # grouped send / recv of the same slabs -- on this very workload; the fastest (max over ranks) runs the timed region, all four
+        # figures go into `dist.calibration`.  (xGMI is point to point: which form RCCL drives better depends on the message size.)
+        cal = {}
+        gv_max_docs, gv_max_tokens = int(mx[1].item()), int(int(mx[0].item()) * 1.02) + 64
+        cal_steps = 64 if not rehearsal else 16
+        for depth_c in ((8, 32) if not rehearsal else (4, 8)):
+            for form in ("allgather", "p2p"):
+                g_ = GatherV(tok, dev, max_docs=gv_max_docs, max_tokens=gv_max_tokens, comm=comm, depth=depth_c, collective=form)
+                for j in range(depth_c):
+                    g_.encode_and_submit(batches[j % N_ROT])
+                g_.finish()
+                dist.barrier()
+                torch.cuda.synchronize()
+                c0 = time.perf_counter()
+                for j in range(cal_steps):
+                    g_.encode_and_submit(batches[j % N_ROT])
+                g_.finish()
+                torch.cuda.synchronize()
+                ct = torch.tensor([time.perf_counter() - c0], dtype=torch.float64, device=dev)
+                dist.all_reduce(ct, op=dist.ReduceOp.MAX)
+                cal[(depth_c, form)] = float(ct.item()) / cal_steps * 1e3
+                del g_
+                torch.cuda.empty_cache()
+        (best_depth, best_form), _ = min(cal.items(), key=lambda kv: kv[1])
+        gv = GatherV(tok, dev, max_docs=gv_max_docs, max_tokens=gv_max_tokens, comm=comm, depth=best_depth, collective=best_form)
         got = []
         gv.on_bucket = lambda res: got.extend((i.clone(), o.clone()) for i, o in res)
         for _ in range(N_ROT):
@@ -311,7 +336,11 @@ def main():
                                   "encode_only_ms": [round(float(x), 5) for x in allm[:, 1]],
                                   "exchange_stream_ms_per_step": [round(float(x), 5) for x in allm[:, 2]]},
                      "exposed_exchange_ms": round(float(allm[:, 0].max() - allm[:, 1].max()), 5),
-                     "bucket_depth": gv.depth, "buckets_timed": ex_buckets,
+                     "bucket_depth": gv.depth, "collective": gv.collective, "buckets_timed": ex_buckets,
+                     "calibration": {"ms_per_step": {f"depth{d_}_{f_}": round(v_, 5) for (d_, f_), v_ in sorted(cal.items())},
+                                     "chosen": f"depth{gv.depth}_{gv.collective}", "steps_each": cal_steps,
+                                     "note": "untimed, before the timed region: the same steps with every bucket depth x collective form (ncclAllGather of the "
+                                             "slabs / grouped ncclSend+ncclRecv of the same slabs); max over ranks; the fastest runs the timed region"},
                      "slab_bytes_sent_per_batch": sent // gv.depth, "bytes_received_per_batch": recvd // gv.depth,
                      "ids_bytes_per_batch_4T": round(4 * tok_b), "slab_over_4T": round(sent / gv.depth / (4 * tok_b), 4),
                      "note": "per batch and rank: one slab of cap_words u32 (T, N, local offsets, ids; sized 1.02 x the largest shard) out, "
@@ -583,7 +612,7 @@ def main():
                                    f"(splintr_amd.corpus.{args.corpus}, seeds {seed0_} + 100 rank + k{'' if args.corpus == 'c2' else '; NOT the BASELINE corpus: the lexically wide variant'}); KERNEL-ONLY: corpus HBM-resident, CSR left in HBM "
                                    f"(the host->host and Python-surface rates of the same batch are in `throughputs`)"
                                    + (f"; the same mix over a >= 20 000-word lexicon (c2_wide, in rotation, same timing): {c2_wide_rot['value']} MB/s" if c2_wide_rot else "")
-                                   + ("; + RCCL all-gatherv of the ragged ids (slab written by the encoder's last kernel, ONE all-gather per bucket of 8 batches on its own stream, overlapped with the following encodes; every rank gets every batch's global CSR, handed to the consumer per bucket)" if use_dist else ""),
+                                   + (f"; + RCCL all-gatherv of the ragged ids (slab written by the encoder's last kernel, ONE exchange per bucket of {gv.depth} batches on its own stream -- {'ncclAllGather' if gv.collective == 'allgather' else 'grouped ncclSend / ncclRecv'}, chosen by the start-up calibration in `dist` --, overlapped with the following encodes; every rank gets every batch's global CSR, handed to the consumer per bucket)" if use_dist else ""),
                        "vocab": "cl100k_base", "docs_per_batch": args.docs, "bytes_per_batch": round(bytes_rot / N_ROT),
                        "tokens_per_batch": round(sum(n_tokens) / N_ROT), "distinct_batches": N_ROT,
                        "parallelism": f"doc-shard x{world}"},
@@ -606,20 +635,37 @@ def main():
         print(json.dumps(out), flush=True)
 
 
+C5_PIECES = 16          # distributed runs: every C5 document is cut into this many pieces at context-free boundaries (128 KiB each)
+C5_WAVES = 8            # ... and the 1600 pieces are exchanged in this many waves (25 pieces per rank and wave at 8 GPUs)
+
+
+def _dist_run(world):
+    return world > 1 or os.environ.get("SPL_BENCH_FORCE_DIST") == "1"
+
+
+def _c4_slice(args_):
+    k, rank, world = args_
+    part = _c4_part(k)
+    return part[len(part) * rank // world:len(part) * (rank + 1) // world]
+
+
 def gen_c4_texts(rank, world):
-    """This rank's share of BASELINE config 4: parts k of the 8 x 125 000 prompts with 8 k / world == rank."""
+    """BASELINE config 4 (1 000 000 prompts = 8 parts of 125 000, seeds 1004 + part; document order = part order).  One GPU: the whole
+    batch.  Distributed: the batch is exchanged in 8 WAVES (wave k = part k, splintr_amd.distributed.plan_waves' layout with equal
+    document counts): this rank's contiguous slice [125 000 r / W, 125 000 (r + 1) / W) of EVERY part, as a list of 8 lists."""
     from multiprocessing import Pool
-    parts = [k for k in range(C4_PARTS) if k * world // C4_PARTS == rank]
-    if not parts:
-        return []
-    with Pool(min(len(parts), max(1, (os.cpu_count() or 1) // max(world, 1)))) as pool:
-        return [t for part in pool.map(_c4_part, parts) for t in part]
+    procs = max(1, min(C4_PARTS, (os.cpu_count() or 1) // max(world, 1)))
+    if not _dist_run(world):
+        with Pool(procs) as pool:
+            return [t for part in pool.map(_c4_part, range(C4_PARTS)) for t in part]
+    with Pool(procs) as pool:
+        return pool.map(_c4_slice, [(k, rank, world) for k in range(C4_PARTS)])
 
 
 def _c5_cut(doc_bytes, frac_num, frac_den):
-    """Byte offset of the shard boundary inside a document: the first position at or behind the proportional
-    target that follows a newline and holds an ASCII letter or digit -- a context-free match boundary of every
-    supported split pattern (splintr_amd.distributed.plan_shards, spl_api.hip encode_host use the same rule)."""
+    """Byte offset of a cut inside a document: the first position at or behind the proportional target that follows a newline
+    and holds an ASCII letter or digit -- a context-free match boundary of every built-in split pattern
+    (splintr_amd.distributed.plan_shards, spl_api.hip encode_host use the same rule)."""
     i = len(doc_bytes) * frac_num // frac_den
     while True:
         j = doc_bytes.find(b"\n", max(i - 1, 0))
@@ -631,93 +677,159 @@ def _c5_cut(doc_bytes, frac_num, frac_den):
         i = j + 2
 
 
+def _c5_doc_pieces(d):
+    """document d of config 5 as C5_PIECES pieces whose ids concatenate to the document's (cuts at context-free boundaries)"""
+    raw = _c5_doc(d).encode("utf-8")
+    cuts = [0] + [_c5_cut(raw, j, C5_PIECES) for j in range(1, C5_PIECES)] + [len(raw)]
+    cuts = sorted(set(cuts))
+    out = [raw[a:b].decode("utf-8") for a, b in zip(cuts, cuts[1:]) if b > a]      # (cuts sit in front of ASCII bytes)
+    while len(out) < C5_PIECES:
+        out.append("")                                  # (a document without enough boundaries: empty pieces keep the counts aligned)
+    return out
+
+
+def c5_wave_slices(n_docs, world, n_waves, pieces=C5_PIECES):
+    """[(first piece, one past the last)] per wave and rank over the n_docs * pieces pieces in document order: waves of equal piece
+    counts, every wave cut into `world` slices of equal piece counts (the pieces are of about equal size)."""
+    npc = n_docs * pieces
+    out = []
+    for k in range(n_waves):
+        lo, hi = npc * k // n_waves, npc * (k + 1) // n_waves
+        out.append([(lo + (hi - lo) * r // world, lo + (hi - lo) * (r + 1) // world) for r in range(world)])
+    return out
+
+
 def gen_c5_pieces(rank, world):
-    """This rank's share of BASELINE config 5 (deepseek_v3, 100 documents of 2 MiB, seeds 1005 + d): the byte range
-    [100 r / W, 100 (r + 1) / W) in units of documents; where a boundary falls inside a document (W = 8: 12.5
-    documents per rank) the document is cut at a context-free boundary, so the ids of the two pieces concatenate
-    to the ids of the document (the intra-document parallelism encode_rayon stands for,
-    src/core/tokenizer.rs:815-837).  Both neighbours generate the shared document and find the same cut."""
+    """BASELINE config 5 (deepseek_v3, 100 documents of 2 MiB, seeds 1005 + d).  One GPU: the 100 documents as they are.  Distributed:
+    every document is cut into 16 pieces at context-free boundaries (a newline in front of an ASCII letter or digit: the ids of the
+    pieces concatenate to the ids of the document -- the intra-document parallelism encode_rayon stands for,
+    src/core/tokenizer.rs:815-837), the 1600 pieces in document order are the batch, exchanged in 8 waves; this rank's slice of every
+    wave, as a list of lists.  Every rank generates only the documents it holds pieces of."""
     from multiprocessing import Pool
-    lo_n, hi_n = C5_DOCS * rank, C5_DOCS * (rank + 1)           # numerators over `world`
-    d_lo, d_hi = lo_n // world, (hi_n + world - 1) // world     # documents this rank touches
-    with Pool(min(d_hi - d_lo, max(1, (os.cpu_count() or 1) // max(world, 1)))) as pool:
-        docs = pool.map(_c5_doc, range(d_lo, d_hi))
-    pieces = []
-    for d, text in zip(range(d_lo, d_hi), docs):
-        raw = text.encode("utf-8")
-        a = _c5_cut(raw, lo_n - d * world, world) if (d == d_lo and lo_n % world) else 0
-        e = _c5_cut(raw, hi_n - d * world, world) if (d == d_hi - 1 and hi_n % world) else len(raw)
-        if e > a:
-            pieces.append(raw[a:e].decode("utf-8"))             # (cuts sit in front of ASCII bytes)
-    return pieces
+    procs = max(1, (os.cpu_count() or 1) // max(world, 1))
+    if not _dist_run(world):
+        with Pool(min(C5_DOCS, procs)) as pool:
+            return pool.map(_c5_doc, range(C5_DOCS))
+    n_waves = min(C5_WAVES, C5_DOCS)
+    slices = c5_wave_slices(C5_DOCS, world, n_waves)
+    need = sorted({p // C5_PIECES for k in range(n_waves) for p in range(*slices[k][rank])})
+    with Pool(max(1, min(len(need), procs))) as pool:
+        docs = dict(zip(need, pool.map(_c5_doc_pieces, need)))
+    return [[docs[p // C5_PIECES][p % C5_PIECES] for p in range(*slices[k][rank])] for k in range(n_waves)]
 
 
 def run_c4(args, rank, world, local_rank, dev, use_dist, texts):
     """BASELINE config 4 as stated: llama3, 1 000 000 short chat prompts (8 x 125 000, seeds 1004..1011),
-    ONE global batch doc-sharded over the ranks (strong scaling: rank r of W encodes parts
-    [8 r / W, 8 (r + 1) / W)), HBM-resident; with W > 1 the ragged ids are all-gathered over RCCL
-    inside the timed step.  Returns the sub-object for the JSON line (rank 0), None elsewhere."""
+    ONE global batch doc-sharded over the ranks (strong scaling), HBM-resident; with W > 1 the ragged ids are all-gathered over RCCL
+    inside the timed step, wave by wave behind the encodes.  Returns the sub-object for the JSON line (rank 0), None elsewhere."""
     return run_strong("llama3", texts, args.c4_steps, rank, world, local_rank, dev, use_dist, 20000,
                       "llama3, {docs} short chat prompts ({bytes} B, {tokens} tokens) as ONE batch doc-sharded over {world} GPU(s), HBM-resident",
                       "bit-exact vs oracle on the first and last 20 000 prompts of every rank's shard")
 
 
 def run_c5(args, rank, world, local_rank, dev, use_dist, pieces):
-    """BASELINE config 5 as stated: deepseek_v3, 100 documents of 2 MiB as ONE batch byte-sharded over the ranks,
-    documents cut at context-free boundaries (gen_c5_pieces), HBM-resident; with W > 1 the ragged ids are
-    all-gathered over RCCL inside the timed step."""
+    """BASELINE config 5 as stated: deepseek_v3, 100 documents of 2 MiB as ONE batch sharded over the ranks, HBM-resident; distributed:
+    documents cut into pieces at context-free boundaries (gen_c5_pieces), the ragged ids all-gathered over RCCL inside the timed
+    step, wave by wave behind the encodes."""
     return run_strong("deepseek_v3", pieces, args.c5_steps, rank, world, local_rank, dev, use_dist, 1,
-                      "deepseek_v3, 100 x 2 MiB documents as {docs} piece(s) ({bytes} B, {tokens} tokens): ONE batch byte-sharded over {world} GPU(s), "
-                      "cut inside a document at a newline + ASCII letter/digit where a shard boundary falls there, HBM-resident",
+                      "deepseek_v3, 100 x 2 MiB documents as {docs} piece(s) ({bytes} B, {tokens} tokens): ONE batch sharded over {world} GPU(s), "
+                      "cut inside a document at a newline + ASCII letter/digit (distributed runs: 16 pieces per document), HBM-resident",
                       "bit-exact vs oracle on the first and last piece of every rank's shard")
 
 
 def run_strong(vocab, texts, steps, rank, world, local_rank, dev, use_dist, nchk, workload, parity):
+    """One GPU: `texts` is the batch, ONE encode per step.  Distributed: `texts` is this rank's slice of every wave (a list of
+    lists); a step encodes them in order while an exchange stream all-gathers wave k behind encode k + 1
+    (splintr_amd.device.WaveGather): every rank ends the step with the CSR of the whole batch in document order."""
     from splintr_amd import Tokenizer
-    from splintr_amd.device import Comm, DeviceBatch, encode_device, reserve, result_csr
+    from splintr_amd.device import Comm, DeviceBatch, WaveGather, encode_device, reserve, result_csr
     from oracle.coracle import COracle
     tok = Tokenizer.from_pretrained(vocab, device=local_rank)
-    batch = DeviceBatch(texts, dev)
-    reserve(tok, batch.n_bytes, batch.n_docs)
-    encode_device(tok, batch)
-    torch.cuda.synchronize()
-    ids, off = result_csr(batch)
-    # parity on a bounded sample (the oracle needs seconds per 100 MB): the first and last `nchk` documents
+    waves = texts if use_dist else [texts]
+    subs = [DeviceBatch(w, dev) for w in waves]
+    reserve(tok, max(b.n_bytes for b in subs), max(b.n_docs for b in subs))
     orc = COracle(vocab)
-    nchk = min(nchk, len(texts))
-    for sl in ((slice(0, nchk), slice(len(texts) - nchk, len(texts))) if nchk else ()):
-        t_np, t_off = _packed(texts[sl])
-        o_ids, o_off = orc.encode_packed(t_np, t_off, threads=os.cpu_count() or 1)
-        a, b_ = int(off[sl.start]), int(off[sl.stop])
-        if not (np.array_equal(ids[a:b_], o_ids) and np.array_equal(off[sl.start:sl.stop + 1] - off[sl.start], o_off)):
-            raise SystemExit(f"rank {rank}: {vocab} strong-scaling result differs from the oracle")
-    n_tok = int(off[-1])
-    comm = all_ids = all_off = None
+    csr = []
+    for bi, (b, w) in enumerate(zip(subs, waves)):
+        encode_device(tok, b)
+        torch.cuda.synchronize()
+        ids, off = result_csr(b)
+        csr.append((ids, off))
+        if bi not in (0, len(subs) - 1):
+            continue
+        # parity on a bounded sample (the oracle needs seconds per 100 MB): the first and last `nchk` documents of the first and last wave
+        nc = min(nchk, len(w))
+        for sl in ((slice(0, nc), slice(len(w) - nc, len(w))) if nc else ()):
+            t_np, t_off = _packed(w[sl])
+            o_ids, o_off = orc.encode_packed(t_np, t_off, threads=os.cpu_count() or 1)
+            a, b_ = int(off[sl.start]), int(off[sl.stop])
+            if not (np.array_equal(ids[a:b_], o_ids) and np.array_equal(off[sl.start:sl.stop + 1] - off[sl.start], o_off)):
+                raise SystemExit(f"rank {rank}: {vocab} strong-scaling result differs from the oracle")
+    n_tok = sum(int(off[-1]) for _, off in csr)
+    my_bytes, my_docs = sum(b.n_bytes for b in subs), sum(b.n_docs for b in subs)
+    wg = comm = None
+    cal = {}
     if use_dist:
-        # the exact ragged all-gather behind the C ABI (spl_allgatherv_csr): {T, N} of every rank first, then
-        # exactly T_r ids and N_r offsets per rank by grouped ncclSend / ncclRecv, straight into the global CSR
-        comm = Comm.from_torch_group(dev)
-        tot = torch.tensor([n_tok, batch.n_docs], dtype=torch.int64, device=dev)
+        # slab capacity from the largest (rank, wave) slice, result capacity from the totals (one-time, untimed)
+        mx = torch.tensor([max(int(off[-1]) for _, off in csr), max(b.n_docs for b in subs)], dtype=torch.int64, device=dev)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        tot = torch.tensor([n_tok, my_docs], dtype=torch.int64, device=dev)
         dist.all_reduce(tot)
-        all_ids = torch.empty(int(tot[0].item()) + 64, dtype=torch.int32, device=dev)
-        all_off = torch.empty(int(tot[1].item()) + 1, dtype=torch.int64, device=dev)
+        comm = Comm.from_torch_group(dev)
+        K = len(subs)
+
+        def make(form):
+            return WaveGather(tok, dev, comm, K, max_docs=int(mx[1].item()), max_tokens=int(int(mx[0].item()) * 1.02) + 64,
+                              total_tokens_cap=int(tot[0].item()) + 64, total_docs_cap=int(tot[1].item()), collective=form)
+
+        def step_with(g_):
+            g_.begin()
+            for b in subs:
+                g_.encode_and_submit(b)
+            return g_.finish()
+        # calibration of the collective form (untimed): ncclAllGather of the wave's slabs against grouped send / recv
+        for form in ("allgather", "p2p"):
+            g_ = make(form)
+            step_with(g_)
+            torch.cuda.synchronize()
+            dist.barrier()
+            c0 = time.perf_counter()
+            for _ in range(2):
+                step_with(g_)
+            torch.cuda.synchronize()
+            ct = torch.tensor([time.perf_counter() - c0], dtype=torch.float64, device=dev)
+            dist.all_reduce(ct, op=dist.ReduceOp.MAX)
+            cal[form] = float(ct.item()) / 2 * 1e3
+            del g_
+            torch.cuda.empty_cache()
+        wg = make(min(cal, key=cal.get))
 
     def step():
-        encode_device(tok, batch)
-        if comm is not None:
-            return comm.allgatherv_csr(batch.ids, batch.out_off, batch.n_docs, all_ids, all_off)
+        if wg is None:
+            encode_device(tok, subs[0])
+        else:
+            wg.begin()
+            for b in subs:
+                wg.encode_and_submit(b)
+            wg.finish()
     for _ in range(2):
-        got = step()
+        step()
     if use_dist:
-        # every rank holds the whole result: totals, and this rank's ids and offsets at their place
-        assert got == (int(tot[0].item()), int(tot[1].item())), got
-        pre = torch.tensor([n_tok, batch.n_docs], dtype=torch.int64, device=dev)
-        allc = [torch.zeros_like(pre) for _ in range(world)]
-        dist.all_gather(allc, pre)
-        allc = torch.stack(allc).cpu().numpy()
-        t0_, d0_ = int(allc[:rank, 0].sum()), int(allc[:rank, 1].sum())
-        assert np.array_equal(all_ids[t0_:t0_ + n_tok].cpu().numpy().view(np.uint32), ids)
-        assert np.array_equal((all_off[d0_:d0_ + batch.n_docs + 1] - t0_).cpu().numpy().astype(np.uint64), off)
+        # every rank holds the whole result: totals, and this rank's slice of every wave at its place
+        torch.cuda.synchronize()
+        assert not wg.overflowed()
+        run = wg.run.cpu().numpy()
+        assert (int(run[0]), int(run[1])) == (int(tot[0].item()), int(tot[1].item())), (run, tot)
+        mine = torch.tensor([[int(off[-1]), b.n_docs] for (_, off), b in zip(csr, subs)], dtype=torch.int64, device=dev)
+        allc = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allc, mine)
+        allc = torch.stack(allc).cpu().numpy()                       # [rank, wave, {T, N}]
+        g_ids, g_off = wg.all_ids.cpu().numpy().view(np.uint32), wg.all_off.cpu().numpy()
+        for k, ((ids, off), b) in enumerate(zip(csr, subs)):
+            t0_ = int(allc[:, :k, 0].sum() + allc[:rank, k, 0].sum())
+            d0_ = int(allc[:, :k, 1].sum() + allc[:rank, k, 1].sum())
+            assert np.array_equal(g_ids[t0_:t0_ + int(off[-1])], ids), (rank, k)
+            assert np.array_equal((g_off[d0_:d0_ + b.n_docs + 1] - t0_).astype(np.uint64), off), (rank, k)
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -727,47 +839,52 @@ def run_strong(vocab, texts, steps, rank, world, local_rank, dev, use_dist, nchk
     if use_dist:
         dist.barrier()
     el = time.perf_counter() - t0
-    tot_b, tot_d, tot_t = batch.n_bytes, batch.n_docs, n_tok
+    tot_b, tot_d, tot_t = my_bytes, my_docs, n_tok
     dist_info = None
     if use_dist:
         local_ms = el / steps * 1e3
-        # untimed repeats: the encode alone, and the exchange alone (events around spl_allgatherv_csr on its stream)
+        # untimed repeats: the encodes alone, and what the exchange stream spent in collective + unpack (events around them)
         e0 = time.perf_counter()
         for _ in range(steps):
-            encode_device(tok, batch)
+            for b in subs:
+                encode_device(tok, b)
         torch.cuda.synchronize()
         enc_ms = (time.perf_counter() - e0) / steps * 1e3
         dist.barrier()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-        for a, b_ in ev:
-            a.record()
-            comm.allgatherv_csr(batch.ids, batch.out_off, batch.n_docs, all_ids, all_off)
-            b_.record()
-        torch.cuda.synchronize()
-        ex_ms = sum(a.elapsed_time(b_) for a, b_ in ev) / steps
-        mine = torch.tensor([local_ms, enc_ms, ex_ms], dtype=torch.float64, device=dev)
+        wg.enable_timing()
+        for _ in range(steps):
+            step()
+        ex_total, _n = wg.exchange_ms()
+        wg.enable_timing(False)
+        mine = torch.tensor([local_ms, enc_ms, ex_total / steps], dtype=torch.float64, device=dev)
         allm = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allm, mine)
         allm = torch.stack(allm).cpu().numpy()
         v = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(v, op=dist.ReduceOp.MAX)
         el = float(v.item())
-        s = torch.tensor([batch.n_bytes, batch.n_docs, n_tok], dtype=torch.int64, device=dev)
-        dist.all_reduce(s)
-        tot_b, tot_d, tot_t = (int(x) for x in s.tolist())
-        dist_info = {"rccl_ranks": comm.ranks(), "torch_world": world,
+        s_ = torch.tensor([my_bytes, my_docs, n_tok], dtype=torch.int64, device=dev)
+        dist.all_reduce(s_)
+        tot_b, tot_d, tot_t = (int(x) for x in s_.tolist())
+        step_ms, exposed = float(allm[:, 0].max()), float(allm[:, 0].max() - allm[:, 1].max())
+        dist_info = {"rccl_ranks": comm.ranks(), "torch_world": world, "waves": len(subs), "collective": wg.collective,
                      "per_rank": {"step_ms": [round(float(x), 4) for x in allm[:, 0]],
                                   "encode_only_ms": [round(float(x), 4) for x in allm[:, 1]],
-                                  "exchange_ms": [round(float(x), 4) for x in allm[:, 2]]},
-                     "exposed_exchange_ms": round(float(allm[:, 0].max() - allm[:, 1].max()), 4),
-                     "bytes_received_per_rank": 4 * tot_t + 8 * tot_d + 32 * world,
-                     "note": "spl_allgatherv_csr: 32 B of counts per rank, then exactly 4 T_r + 8 N_r bytes from every rank (nothing padded)"}
-    del batch, tok, comm, all_ids, all_off
+                                  "exchange_stream_ms": [round(float(x), 4) for x in allm[:, 2]]},
+                     "exposed_exchange_ms": round(exposed, 4), "exposed_over_step": round(exposed / step_ms, 4) if step_ms else None,
+                     "calibration_ms_per_step": {k_: round(v_, 4) for k_, v_ in cal.items()},
+                     "slab_bytes_sent_per_wave": wg.cap_words * 4, "bytes_received_per_rank": wg.cap_words * 4 * world * len(subs),
+                     "ids_bytes_4T": 4 * tot_t,
+                     "note": "WaveGather: the batch is exchanged in `waves` waves; rank r encodes its slice of wave k into a slab (written by the encoder's "
+                             "last kernel), ONE exchange of the wave's slabs + an unpack behind what the earlier waves left run on an exchange stream while "
+                             "wave k + 1 encodes; no host synchronisation inside a step.  exposed = slowest step - slowest encodes-only"}
+    del subs, tok, comm, wg
     torch.cuda.empty_cache()
     if rank != 0:
         return None
     return {"workload": workload.format(docs=tot_d, bytes=tot_b, tokens=tot_t, world=world)
-                        + ("; RCCL all-gatherv of the ragged result inside the step (spl_allgatherv_csr: counts, then exactly T_r ids and N_r offsets per rank by grouped send/recv)" if use_dist else ""),
+                        + (f"; RCCL all-gatherv of the ragged result inside the step, pipelined: {dist_info['waves']} waves, wave k on the links while wave k + 1 encodes "
+                           f"(splintr_amd.device.WaveGather over spl_allgather_slabs{'_p2p' if dist_info['collective'] == 'p2p' else ''} + spl_gatherv_unpack_at)" if use_dist else ""),
             "value": round(tot_b * steps / el / 1e6, 1), "unit": "MB/s", "ms_per_step": round(el / steps * 1e3, 3),
             "steps": steps, "scaling": "strong", "parity": parity, "dist": dist_info}
 

@@ -236,6 +236,16 @@ int spl_gatherv_unpack_group(spl_tokenizer* t, const uint32_t* d_slabs, uint32_t
                              uint64_t cap_words, uint64_t max_docs, uint32_t* d_all_ids, uint64_t all_ids_cap,
                              uint64_t* d_all_off, uint64_t off_stride, uint32_t* d_status, void* hip_stream);
 
+/* ONE batch exchanged in WAVES (strong scaling, pipelined: the ids of wave k travel while wave k + 1 encodes).  The batch's documents, in
+ * their order, are cut into waves and every wave into one contiguous slice per rank; rank r encodes its slice of wave k into a slab
+ * (spl_encode_batch_device_packed), one all-gather of equal slabs moves the wave (spl_allgather_slabs / _p2p), and this call unpacks the
+ * `world` slabs BEHIND what the waves before it left: d_run[0] tokens and d_run[1] documents (device memory, zeroed by the caller before wave
+ * 0, advanced here -- in stream order, so no host synchronisation sits between the waves).  After the last wave d_all_ids / d_all_off hold
+ * the CSR of the whole batch in document order and d_run its totals.  d_status[0] = 1 if a slab or a result buffer was too small. */
+int spl_gatherv_unpack_at(spl_tokenizer* t, const uint32_t* d_slabs, uint32_t world, uint64_t cap_words, uint64_t max_docs,
+                          uint32_t* d_all_ids, uint64_t all_ids_cap, uint64_t* d_all_off, uint64_t all_off_cap, uint64_t* d_run,
+                          uint32_t* d_status, void* hip_stream);
+
 /* The collective itself behind the C ABI (north_star: "an RCCL all-gatherv over xGMI to reassemble the ragged
  * token-id output"; the reference has nothing distributed -- src/core/tokenizer.rs:932-934 is a Rayon par_iter on
  * one host -- so these are this build's own entry points).  One process per GPU.  RCCL is bound at run time
@@ -264,6 +274,9 @@ void spl_comm_destroy(spl_comm* c);
 int spl_comm_rank(const spl_comm* c);
 int spl_comm_world(const spl_comm* c);
 int spl_allgather_slabs(spl_comm* c, const uint32_t* d_send, uint32_t* d_recv, uint64_t words_per_rank, void* hip_stream);
+/* the same exchange as grouped ncclSend / ncclRecv -- one message per peer and direction, each over its own xGMI link, no ring: the other
+ * candidate of bench.py's start-up calibration (which of the two wins depends on the message size and on RCCL's algorithm choice) */
+int spl_allgather_slabs_p2p(spl_comm* c, const uint32_t* d_send, uint32_t* d_recv, uint64_t words_per_rank, void* hip_stream);
 int spl_allgatherv_csr(spl_comm* c, const uint32_t* d_ids, const uint64_t* d_out_off, uint64_t n_docs, uint32_t* d_all_ids,
                        uint64_t all_ids_cap, uint64_t* d_all_off, uint64_t all_off_cap, uint64_t* n_tokens_total,
                        uint64_t* n_docs_total, void* hip_stream);

@@ -27,7 +27,7 @@ SYMBOLS = [
     "spl_set_devices", "spl_n_devices", "spl_set_option", "spl_host_alloc", "spl_host_free",
     "spl_token_bytes", "spl_is_byte_level",
     "spl_comm_unique_id", "spl_comm_create", "spl_comm_destroy", "spl_comm_rank", "spl_comm_world",
-    "spl_allgather_slabs", "spl_allgatherv_csr", "spl_split_host", "spl_encode_chunks_device",
+    "spl_allgather_slabs", "spl_allgather_slabs_p2p", "spl_gatherv_unpack_at", "spl_allgatherv_csr", "spl_split_host", "spl_encode_chunks_device",
     "spl_split_device", "spl_device_split_fallbacks", "spl_small_path_calls",
 ]
 SPL_PATTERN_CUSTOM = 3
@@ -130,6 +130,9 @@ def lib() -> ctypes.CDLL:
     L.spl_comm_rank.argtypes = [vp]
     L.spl_comm_world.argtypes = [vp]
     L.spl_allgather_slabs.argtypes = [vp, vp, vp, ctypes.c_uint64, vp]
+    L.spl_allgather_slabs_p2p.argtypes = [vp, vp, vp, ctypes.c_uint64, vp]
+    L.spl_gatherv_unpack_at.argtypes = [vp, vp, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64, vp, ctypes.c_uint64, vp, ctypes.c_uint64,
+                                        vp, vp, vp]
     L.spl_allgatherv_csr.argtypes = [vp, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, ctypes.c_uint64,
                                      u64p, u64p, vp]
     _lib = L

@@ -1908,6 +1908,19 @@ int spl_gatherv_unpack_group(spl_tokenizer* t, const uint32_t* d_slabs, uint32_t
     return SPL_OK;
 }
 
+int spl_gatherv_unpack_at(spl_tokenizer* t, const uint32_t* d_slabs, uint32_t world, uint64_t cap_words, uint64_t max_docs,
+                          uint32_t* d_all_ids, uint64_t all_ids_cap, uint64_t* d_all_off, uint64_t all_off_cap, uint64_t* d_run,
+                          uint32_t* d_status, void* hip_stream) {
+    if (!t || !d_slabs || !d_all_ids || !d_all_off || !d_run || !d_status || world == 0 || cap_words < max_docs + 4 || cap_words > 0xFFFFFFFFull)
+        return fail(SPL_EINVAL, "spl_gatherv_unpack_at: bad argument");
+    HIP_TRY(hipSetDevice(t->ctx[0]->device));
+    hipLaunchKernelGGL(k_gatherv_unpack_at, dim3(128, world), dim3(256), 0, (hipStream_t)hip_stream, d_slabs, world, (uint32_t)cap_words,
+                       (uint32_t)max_docs, d_all_ids, all_ids_cap, d_all_off, all_off_cap, (const uint64_t*)d_run, d_status);
+    hipLaunchKernelGGL(k_gatherv_advance, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, d_slabs, world, (uint32_t)cap_words, d_run);
+    HIP_TRY(hipGetLastError());
+    return SPL_OK;
+}
+
 int spl_debug_blocks(spl_tokenizer* t, unsigned long long* out, int max_blocks) {
     if (!t || !out) return fail(SPL_EINVAL, "null argument");
     Ctx* c = t->ctx[0].get();
@@ -2021,6 +2034,20 @@ int spl_allgather_slabs(spl_comm* c, const uint32_t* d_send, uint32_t* d_recv, u
     return guarded("spl_allgather_slabs", [&] {
         HIP_TRY(hipSetDevice(c->device));
         NCCL_TRY(rccl().AllGather(d_send, d_recv, words_per_rank, ncclUint32, c->comm, (hipStream_t)hip_stream));
+        return SPL_OK;
+    });
+}
+int spl_allgather_slabs_p2p(spl_comm* c, const uint32_t* d_send, uint32_t* d_recv, uint64_t words_per_rank, void* hip_stream) {
+    if (!c || !d_send || !d_recv) return fail(SPL_EINVAL, "spl_allgather_slabs_p2p: null argument");
+    return guarded("spl_allgather_slabs_p2p", [&] {
+        Rccl& R = rccl();
+        HIP_TRY(hipSetDevice(c->device));
+        NCCL_TRY(R.GroupStart());
+        for (int p = 0; p < c->world; p++) {
+            NCCL_TRY(R.Send(d_send, words_per_rank, ncclUint32, p, c->comm, (hipStream_t)hip_stream));
+            NCCL_TRY(R.Recv(d_recv + (size_t)p * words_per_rank, words_per_rank, ncclUint32, p, c->comm, (hipStream_t)hip_stream));
+        }
+        NCCL_TRY(R.GroupEnd());
         return SPL_OK;
     });
 }

@@ -161,6 +161,35 @@ __global__ void k_gatherv_unpack(const uint32_t* slabs_all, uint32_t world, uint
         if (tbase + k < all_ids_cap) all_ids[tbase + k] = slab[ids_at + k];
 }
 
+// The same for ONE batch that is exchanged in WAVES (strong scaling, pipelined: wave k is on the links while wave k + 1 encodes): the
+// documents of the batch, in their order, are cut into waves, every wave into one contiguous slice per rank; wave k's slabs land BEHIND
+// what the waves before it left -- run[0] tokens, run[1] documents, in device memory, advanced by k_gatherv_advance behind the unpack
+// (stream order) -- so that all waves together are ONE CSR in document order and no host synchronisation sits between them.
+__global__ void k_gatherv_unpack_at(const uint32_t* slabs, uint32_t world, uint32_t cap_words, uint32_t max_docs, uint32_t* all_ids,
+                                    uint64_t all_ids_cap, uint64_t* all_off, uint64_t all_off_cap, const uint64_t* run, uint32_t* status) {
+    const uint32_t r = blockIdx.y;
+    const uint32_t ids_at = 3 + max_docs, ids_cap = cap_words - ids_at;
+    uint64_t tbase = run[0], dbase = run[1];
+    for (uint32_t q = 0; q < r; q++) { tbase += slabs[(size_t)q * cap_words]; dbase += slabs[(size_t)q * cap_words + 1]; }
+    const uint32_t* slab = slabs + (size_t)r * cap_words;
+    const uint32_t T = slab[0], N = slab[1];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    if (i == 0 && (T > ids_cap || tbase + T > all_ids_cap || dbase + N + 1 > all_off_cap)) status[0] = 1;
+    for (uint32_t d = i; d < N; d += stride)
+        if (dbase + d < all_off_cap) all_off[dbase + d] = tbase + slab[2 + d];
+    if (r == world - 1 && i == 0 && dbase + N < all_off_cap) all_off[dbase + N] = tbase + T;      // the closing entry (the next wave's first)
+    const uint32_t ncopy = T < ids_cap ? T : ids_cap;
+    for (uint32_t k = i; k < ncopy; k += stride)
+        if (tbase + k < all_ids_cap) all_ids[tbase + k] = slab[ids_at + k];
+}
+__global__ void k_gatherv_advance(const uint32_t* slabs, uint32_t world, uint32_t cap_words, uint64_t* run) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        uint64_t t = 0, n = 0;
+        for (uint32_t q = 0; q < world; q++) { t += slabs[(size_t)q * cap_words]; n += slabs[(size_t)q * cap_words + 1]; }
+        run[0] += t; run[1] += n;
+    }
+}
+
 // Exact ragged all-gather (spl_allgatherv_csr): every rank's {T, N} travel first, then exactly T ids and N
 // offsets per rank land at their place of the global CSR by grouped send / recv.  These two kernels are the
 // device side: the counts as the collective's input, and the received LOCAL offsets rebased by the tokens of the

@@ -138,9 +138,12 @@ class GatherV:
     """
 
     def __init__(self, tok: Tokenizer, device: torch.device, max_docs: int, max_tokens: int, group=None, depth: int = 8,
-                 comm: "Comm" = None):
+                 comm: "Comm" = None, collective: str = "allgather"):
         import torch.distributed as dist
         self.tok, self.dev, self.group, self.dist, self.comm = tok, device, group, dist, comm
+        if collective not in ("allgather", "p2p") or (collective == "p2p" and comm is None):
+            raise ValueError("GatherV: collective is 'allgather' or -- with the library's communicator -- 'p2p'")
+        self.collective = collective             # ncclAllGather of the bucket's slabs, or grouped send / recv of the same slabs
         self.world = comm.world if comm is not None else dist.get_world_size(group)
         self.depth = int(depth)
         self.max_docs = int(max_docs)
@@ -238,10 +241,10 @@ class GatherV:
     def _allgather(self, s) -> None:
         """world x depth slabs, on the exchange stream (current here)."""
         if self.comm is not None:             # the collective behind the C ABI (librccl bound by the library)
-            rc = _ffi.lib().spl_allgather_slabs(self.comm.handle, self.send[s].data_ptr(), self.recv[s].data_ptr(),
-                                                self.depth * self.cap_words, self.exch.cuda_stream)
+            fn = _ffi.lib().spl_allgather_slabs_p2p if self.collective == "p2p" else _ffi.lib().spl_allgather_slabs
+            rc = fn(self.comm.handle, self.send[s].data_ptr(), self.recv[s].data_ptr(), self.depth * self.cap_words, self.exch.cuda_stream)
             if rc != 0:
-                raise RuntimeError(f"spl_allgather_slabs failed ({rc}): {_ffi.last_error()}")
+                raise RuntimeError(f"spl_allgather_slabs{'_p2p' if self.collective == 'p2p' else ''} failed ({rc}): {_ffi.last_error()}")
             return
         work = self.dist.all_gather_into_tensor(self.recv[s], self.send[s], group=self.group, async_op=True)
         work.wait()                           # the exchange stream (not the encode stream) waits for the collective
@@ -300,6 +303,95 @@ class GatherV:
             return self._views(0, 0)
         s, n = self.last
         return self._views(s, max(n - 1, 0))
+
+    def overflowed(self) -> bool:
+        return bool(self.status.item())
+
+
+class WaveGather:
+    """ONE batch, doc-sharded over the ranks (strong scaling), exchanged in WAVES so that the ids of wave k travel while wave k + 1 encodes.
+
+    The batch's documents, in their order, are cut into `n_waves` waves and every wave into one contiguous slice per rank
+    (splintr_amd.distributed.plan_waves); rank r encodes its slice of wave k straight into a slab (the encoder's last kernel writes it),
+    an exchange stream of its own all-gathers the wave's `world` slabs and unpacks them BEHIND what the earlier waves left
+    (spl_gatherv_unpack_at: running totals in device memory, advanced in stream order) -- no host synchronisation anywhere, the
+    only exposed exchange is the last wave's.  After `finish()` every rank holds the CSR of the whole batch in document order.
+    Order it replaces: Rayon's order-preserving collect, src/core/tokenizer.rs:932-942."""
+
+    def __init__(self, tok: Tokenizer, device: torch.device, comm: "Comm", n_waves: int, max_docs: int, max_tokens: int,
+                 total_tokens_cap: int, total_docs_cap: int, collective: str = "allgather"):
+        self.tok, self.dev, self.comm, self.world = tok, device, comm, comm.world
+        self.n_waves, self.max_docs, self.max_tokens = int(n_waves), int(max_docs), int(max_tokens)
+        self.cap_words = self.max_tokens + self.max_docs + 4
+        if self.cap_words >= 1 << 32:
+            raise ValueError("WaveGather: a slab must stay below 2**32 words")
+        self.collective = collective
+        kw = dict(device=device)
+        self.send = [torch.zeros(self.cap_words, dtype=torch.int32, **kw) for _ in range(self.n_waves)]
+        self.recv = [torch.zeros(self.world * self.cap_words, dtype=torch.int32, **kw) for _ in range(self.n_waves)]
+        self.all_ids = torch.zeros(int(total_tokens_cap), dtype=torch.int32, **kw)
+        self.all_off = torch.zeros(int(total_docs_cap) + 1, dtype=torch.int64, **kw)
+        self.run = torch.zeros(2, dtype=torch.int64, **kw)            # tokens, documents landed so far
+        self.status = torch.zeros(1, dtype=torch.int32, **kw)
+        self.exch = torch.cuda.Stream(device=device)
+        self.encoded = [torch.cuda.Event() for _ in range(self.n_waves)]
+        self.k = 0
+        self._timing = None
+
+    def enable_timing(self, on: bool = True) -> None:
+        self._timing = [] if on else None
+
+    def exchange_ms(self):
+        if not self._timing:
+            return 0.0, 0
+        torch.cuda.synchronize(self.dev)
+        total, n = sum(a.elapsed_time(b) for a, b in self._timing), len(self._timing)
+        self._timing = []
+        return float(total), n
+
+    def begin(self) -> None:
+        """Start a new batch: the running totals back to zero (on the exchange stream, behind the previous batch's last unpack;
+        the main stream waits for it only through finish())."""
+        self.k = 0
+        with torch.cuda.stream(self.exch):
+            self.run.zero_()
+
+    def encode_and_submit(self, batch: "DeviceBatch", with_special: bool = False) -> None:
+        """This rank's slice of the next wave: encode (slab written by the encoder's last kernel) on the current stream, exchange and
+        unpack on the exchange stream."""
+        L = _ffi.lib()
+        k = self.k
+        main = torch.cuda.current_stream(self.dev)
+        rc = L.spl_encode_batch_device_packed(self.tok.handle, batch.text.data_ptr(), batch.n_bytes, batch.doc_off.data_ptr(), batch.n_docs,
+                                              _ffi.SPL_WITH_SPECIAL if with_special else 0, batch.ids.data_ptr(), batch.ids.numel(),
+                                              batch.out_off.data_ptr(), self.send[k].data_ptr(), self.cap_words, self.max_docs, main.cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"spl_encode_batch_device_packed failed ({rc}): {_ffi.last_error()}")
+        self.encoded[k].record(main)
+        with torch.cuda.stream(self.exch):
+            self.exch.wait_event(self.encoded[k])
+            if self._timing is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record(self.exch)
+            fn = L.spl_allgather_slabs_p2p if self.collective == "p2p" else L.spl_allgather_slabs
+            rc = fn(self.comm.handle, self.send[k].data_ptr(), self.recv[k].data_ptr(), self.cap_words, self.exch.cuda_stream)
+            if rc != 0:
+                raise RuntimeError(f"spl_allgather_slabs failed ({rc}): {_ffi.last_error()}")
+            rc = L.spl_gatherv_unpack_at(self.tok.handle, self.recv[k].data_ptr(), self.world, self.cap_words, self.max_docs,
+                                         self.all_ids.data_ptr(), self.all_ids.numel(), self.all_off.data_ptr(), self.all_off.numel(),
+                                         self.run.data_ptr(), self.status.data_ptr(), self.exch.cuda_stream)
+            if rc != 0:
+                raise RuntimeError(f"spl_gatherv_unpack_at failed ({rc}): {_ffi.last_error()}")
+            if self._timing is not None:
+                ev[1].record(self.exch)
+                self._timing.append(ev)
+        self.k += 1
+
+    def finish(self):
+        """The main stream waits for the last wave's unpack.  Returns (all_ids, all_off, run): int32 ids, int64 offsets of the whole batch in
+        document order, run = [total tokens, total documents] (device tensors; no host synchronisation here)."""
+        torch.cuda.current_stream(self.dev).wait_stream(self.exch)
+        return self.all_ids, self.all_off, self.run
 
     def overflowed(self) -> bool:
         return bool(self.status.item())

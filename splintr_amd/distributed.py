@@ -35,6 +35,42 @@ def shard_bounds(doc_bytes: Sequence[int], world: int) -> List[int]:
     return bounds
 
 
+def plan_waves(doc_bytes: Sequence[int], world: int, n_waves: int) -> List[List[Tuple[int, int]]]:
+    """ONE batch for the pipelined strong-scaling exchange (splintr_amd.device.WaveGather): the documents, in their order, are cut into
+    `n_waves` contiguous waves of about equal bytes and every wave into `world` contiguous slices of about equal bytes.  Returns
+    waves[k][r] = (first document, one past the last) of rank r's slice of wave k.  The result of the batch is the concatenation over k
+    of (the concatenation over r of slice (k, r)) -- document order -- so wave k can be exchanged, and land at its final place, while
+    wave k + 1 is still being encoded: its place depends only on the waves before it."""
+    wb = shard_bounds(doc_bytes, n_waves)
+    waves = []
+    for k in range(n_waves):
+        lo, hi = wb[k], wb[k + 1]
+        rb = shard_bounds(doc_bytes[lo:hi], world)
+        waves.append([(lo + rb[r], lo + rb[r + 1]) for r in range(world)])
+    return waves
+
+
+def encode_batch_waves(encode_csr, texts: Sequence[str], device: torch.device, n_waves: int = 4, group=None):
+    """encode_batch over the process group in waves (whole documents; the host-tensor form of WaveGather, on whatever backend the
+    group uses -- gloo on CPU tensors in the tests): rank r encodes its slice of every wave with `encode_csr`, wave k's ragged
+    result is all-gathered and lands behind the waves before it; the offsets rebase per wave.  Returns (ids, off) numpy arrays
+    for ALL documents, in their order, on every rank."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lens = [len(t.encode("utf-8")) for t in texts]
+    waves = plan_waves(lens, world, n_waves)
+    ids_parts, off_parts, t_done = [], [np.zeros(1, dtype=np.int64)], 0
+    for k in range(n_waves):
+        lo, hi = waves[k][rank]
+        ids, off = encode_csr(list(texts[lo:hi]))
+        t_ids = torch.from_numpy(ids.astype(np.int32, copy=False).copy()).to(device)
+        dc = torch.from_numpy(np.diff(off.astype(np.int64))).to(device)
+        w_ids, w_off = all_gather_csr(t_ids, int(off[-1]), dc, group)
+        ids_parts.append(w_ids.cpu().numpy().view(np.uint32))
+        off_parts.append(w_off.cpu().numpy().astype(np.int64)[1:] + t_done)          # the wave's offsets, rebased by what came before
+        t_done += int(w_off[-1])
+    return np.concatenate(ids_parts) if ids_parts else np.zeros(0, np.uint32), np.concatenate(off_parts).astype(np.uint64)
+
+
 def all_gather_csr(ids: torch.Tensor, n_tokens, doc_counts: torch.Tensor,
                    group=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Ragged all-gather.  ids[:n_tokens] = this rank's token ids (int32), doc_counts = tokens per
@@ -144,12 +180,22 @@ def encode_batch_sharded(encode_csr, texts: Sequence[str], device: torch.device,
     `context_free_cuts`: whether "behind a newline, in front of an ASCII letter or digit" is a match boundary of the
     encoder's split pattern whatever surrounds it.  True for the three built-in patterns, unknown for a custom one
     (src/core/tokenizer.rs:410-456 compiles any pattern), so False there: documents then stay whole.  None (default)
-    asks the encoder: a bound method of a `Tokenizer` (or any object with `has_custom_pattern`) answers for itself;
-    an opaque callable is taken to use a built-in pattern."""
+    asks the encoder: a bound method of a `Tokenizer` (or any object with `has_custom_pattern`), also behind functools.partial or a
+    decorator that sets __wrapped__, answers for itself; for an opaque callable the documents stay whole (pass True to allow cuts)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if context_free_cuts is None:
-        owner = getattr(encode_csr, "__self__", None)
-        context_free_cuts = not bool(getattr(owner, "has_custom_pattern", False))
+        # (ADVICE r04: a functools.partial or a decorated function has no __self__ of its own -- unwrap; an encoder whose owner cannot be
+        #  found is NOT assumed to use a built-in pattern: its documents stay whole, which is always correct)
+        fn = encode_csr
+        for _ in range(8):
+            if hasattr(fn, "func") and callable(getattr(fn, "func")):
+                fn = fn.func
+            elif hasattr(fn, "__wrapped__"):
+                fn = fn.__wrapped__
+            else:
+                break
+        owner = getattr(fn, "__self__", None)
+        context_free_cuts = owner is not None and hasattr(owner, "has_custom_pattern") and not bool(owner.has_custom_pattern)
     if not context_free_cuts or any("\n" in lit for lit in special_literals):
         split_docs = False
     docs = [t.encode("utf-8") for t in texts]

@@ -37,46 +37,46 @@ def test_more_gpus_than_the_box_has_is_a_clear_error():
 
 
 def test_c5_pieces_tile_the_documents():
-    """gen_c5_pieces: the ranks' pieces of BASELINE config 5 concatenate to the 100 documents, and every cut
-    inside a document sits behind a newline, in front of an ASCII letter or digit (a context-free match
-    boundary of every split pattern)."""
+    """bench.py's BASELINE config 5 in a distributed run: every document is cut into pieces whose concatenation is the document, every
+    cut sits behind a newline in front of an ASCII letter or digit (a context-free match boundary of every built-in split pattern),
+    and the ranks' slices of the waves, read wave by wave and rank by rank, are the pieces in document order."""
     sys.path.insert(0, ROOT)
     import bench
+    from splintr_amd import corpus
     saved = (bench.C5_DOCS, bench._c5_doc)
+    docs = {k: corpus.c5(1, seed=1005 + k, doc_bytes=1 << 15)[0] for k in range(5)}
     try:
-        from splintr_amd import corpus
         bench.C5_DOCS = 5
-        docs = {k: corpus.c5(1, seed=1005 + k, doc_bytes=1 << 15)[0] for k in range(5)}
-        for world in (1, 2, 4, 8):
-            pieces = []
+        bench._c5_doc = lambda k: docs[k]
+        allp = []
+        for k in range(5):
+            ps = bench._c5_doc_pieces(k)
+            assert len(ps) == bench.C5_PIECES and "".join(ps) == docs[k]
+            for a, b in zip(ps, ps[1:]):
+                if b:
+                    assert a.endswith("\n") and b[0].isascii() and b[0].isalnum(), (k, a[-5:], b[:5])
+            allp += ps
 
-            class _P:                       # (no fork in the test: map in-process)
-                def __init__(self, *a): pass
-                def __enter__(self): return self
-                def __exit__(self, *a): return False
-                def map(self, f, it): return [docs[k] for k in it]
-            import multiprocessing
-            real = multiprocessing.Pool
-            multiprocessing.Pool = _P
-            try:
-                for r in range(world):
-                    pieces.append(bench.gen_c5_pieces(r, world))
-            finally:
-                multiprocessing.Pool = real
-            flat = "".join(p for ps in pieces for p in ps)
-            assert flat == "".join(docs[k] for k in range(5)), world
-            # cuts inside documents: the piece starts with an ASCII alnum and the previous piece ends with \n
-            total, starts = 0, set()
-            for k in range(5):
-                starts.add(total)
-                total += len(docs[k])
-            pos = 0
-            prev = None
-            for ps in pieces:
-                for p in ps:
-                    if pos not in starts:
-                        assert prev is not None and prev.endswith("\n") and p[0].isascii() and p[0].isalnum(), (world, pos)
-                    pos += len(p)
-                    prev = p
+        class _P:                       # (no fork in the test: map in-process)
+            def __init__(self, *a): pass
+            def __enter__(self): return self
+            def __exit__(self, *a): return False
+            def map(self, f, it): return [f(x) for x in it]
+        import multiprocessing
+        real = multiprocessing.Pool
+        multiprocessing.Pool = _P
+        os.environ["SPL_BENCH_FORCE_DIST"] = "1"
+        try:
+            for world in (1, 2, 3, 8):
+                waves = [bench.gen_c5_pieces(r, world) for r in range(world)]          # [rank][wave] -> pieces
+                n_waves = len(waves[0])
+                flat = [p for k in range(n_waves) for r in range(world) for p in waves[r][k]]
+                assert flat == allp, world
+        finally:
+            multiprocessing.Pool = real
+            os.environ.pop("SPL_BENCH_FORCE_DIST", None)
+        sl = bench.c5_wave_slices(100, 8, bench.C5_WAVES)
+        assert [x for k in range(bench.C5_WAVES) for r in range(8) for x in range(*sl[k][r])] == list(range(100 * bench.C5_PIECES))
+        assert max(b - a for k in range(bench.C5_WAVES) for a, b in sl[k]) == min(b - a for k in range(bench.C5_WAVES) for a, b in sl[k]) == 25
     finally:
         bench.C5_DOCS, bench._c5_doc = saved

@@ -146,21 +146,31 @@ def test_bench_distributed_branch_rehearsal_world_1():
     from conftest import ROOT
     env = dict(os.environ, SPL_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--docs", "200", "--steps", "24", "--warmup", "8",
-           "--c4-steps", "1", "--c5-steps", "1", "--c4-part-docs", "1500", "--c5-docs", "3", "--c5-doc-bytes", "200000",
-           "--no-cpu-baseline", "--no-throughputs"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--docs", "200", "--steps", "24", "--warmup", "8", "--regions", "3",
+           "--c4-steps", "3", "--c5-steps", "3", "--c4-part-docs", "12000", "--c5-docs", "8", "--c5-doc-bytes", "1000000",
+           "--no-cpu-baseline", "--no-throughputs", "--no-c2-wide"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, (p.returncode, p.stdout[-1500:], p.stderr[-3000:])
     line = json.loads(p.stdout.strip().splitlines()[-1])
     assert line["rehearsal"] is True and line["n_gpus"] == 1 and line["value"] > 0
     assert "bit-exact" in line["parity"] and "RCCL all-gatherv" in line["config"]["workload"]
+    assert line["timing"]["regions"] == 3 and len(line["timing"]["region_values"]) == 3
     d = line["dist"]
     assert d["rccl_ranks"] == 1 and d["torch_world"] == 1
     for key in ("step_ms", "encode_only_ms", "exchange_stream_ms_per_step"):
         assert len(d["per_rank"][key]) == 1 and d["per_rank"][key][0] > 0, (key, d)
-    assert d["slab_bytes_sent_per_batch"] >= d["ids_bytes_per_batch_4T"] > 0 and d["buckets_timed"] == 3
+    assert d["slab_bytes_sent_per_batch"] >= d["ids_bytes_per_batch_4T"] > 0 and d["buckets_timed"] == 24 // d["bucket_depth"]
+    # the start-up calibration: every depth x collective form was timed, the fastest one ran the timed region
+    cal = d["calibration"]
+    assert len(cal["ms_per_step"]) == 4 and all(v > 0 for v in cal["ms_per_step"].values())
+    assert cal["chosen"] == min(cal["ms_per_step"], key=cal["ms_per_step"].get) == f"depth{d['bucket_depth']}_{d['collective']}"
     for key in ("c4_strong", "c5_strong"):
         c = line[key]
         assert c["scaling"] == "strong" and c["value"] > 0 and "bit-exact" in c["parity"], c
-        assert c["dist"]["rccl_ranks"] == 1 and c["dist"]["per_rank"]["exchange_ms"][0] > 0, c
-        assert c["dist"]["bytes_received_per_rank"] > 0
+        cd = c["dist"]
+        assert cd["rccl_ranks"] == 1 and cd["per_rank"]["exchange_stream_ms"][0] > 0 and cd["waves"] == 8, c
+        assert set(cd["calibration_ms_per_step"]) == {"allgather", "p2p"} and cd["collective"] in ("allgather", "p2p")
+        assert cd["bytes_received_per_rank"] >= cd["ids_bytes_4T"] > 0
+        # pipelined: what the exchange adds to a step is (at most) the last wave's exchange, not all of it (<= 5 % of the
+        # step at full size; the rehearsal's waves are 2-3 MB, a step is under a millisecond and the exchange with itself shares the GPU with the encodes: 40 %; full size at world 1: profiles/r05_wave_exchange.txt)
+        assert cd["exposed_exchange_ms"] <= 0.40 * max(cd["per_rank"]["step_ms"]), cd
