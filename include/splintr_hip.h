@@ -43,14 +43,16 @@ extern "C" {
 #define SPL_PATTERN_O200K 1
 /* MISTRAL_V3_PATTERN (src/core/tokenizer.rs:64; mistral_v3 / Tekken, src/python/bindings.rs:152-158) */
 #define SPL_PATTERN_MISTRAL_V3 2
-/* These three are the patterns the GPU scanner implements.  ANY OTHER pattern (Tokenizer::new compiles whatever it
- * is given, src/core/tokenizer.rs:410-456): SPL_PATTERN_CUSTOM with the pattern text in spl_opts -- there is no
- * regex engine on the GPU, so its split runs on the host cores (a backtracking matcher over the same code-point class
- * table, csrc/spl_regex.h: literals, classes, \s \d \w, every general category as \p{..}, groups, (?i:), (?>), alternation,
- * greedy / lazy / possessive quantifiers, look-ahead, ^ $ \A \Z \z \b \B -- upstream tiktoken's cl100k_base / o200k_base
- * strings, Qwen2's and GPT-2's are accepted as they are) and the chunk boundaries feed the same probe / merge kernels.
- * What the matcher cannot express (scripts, look-behind, back-references, \p{Lu} under (?i), a pattern that can match
- * the empty string) is refused by spl_create with the construct named. */
+/* These three are the patterns the GPU scanner implements as closed forms.  ANY OTHER pattern (Tokenizer::new compiles whatever it
+ * is given, src/core/tokenizer.rs:410-456): SPL_PATTERN_CUSTOM with the pattern text in spl_opts.  It is compiled by csrc/spl_regex.h
+ * (a backtracking matcher over the same code-point class table: literals, classes, \s \d \w, every general category and -- with a
+ * version-3 class table -- every SCRIPT as \p{..} (\p{Han}, \p{Hiragana}, \p{Latin} ...), groups, (?i:), (?>), alternation, greedy /
+ * lazy / possessive quantifiers, look-ahead, ^ $ \A \Z \z \b \B -- upstream tiktoken's cl100k_base / o200k_base strings, Qwen2's and
+ * GPT-2's are accepted as they are) and its split runs ON THE GPU (csrc/spl_rx_split.h: the same matcher program at every text position,
+ * the walk from each document's start by pointer doubling) in front of the same probe / merge kernels; documents that hold something the
+ * device matcher gives up on -- a match longer than ~1 KB -- are split on the host cores instead, one by one (spl_device_split_fallbacks).
+ * What the matcher cannot express (binary properties, script extensions, look-behind, back-references, \p{Lu} under (?i), a pattern that
+ * can match the empty string) is refused by spl_create with the construct named. */
 #define SPL_PATTERN_CUSTOM 3
 
 /* spl_opts.flags */
@@ -110,7 +112,8 @@ uint32_t spl_n_devices(const spl_tokenizer* t);
  * "direct_write" (0/1, default 1: one-chunk batches have the last kernel write the ids straight into
  * the pinned result instead of copying them back), "device_split" (0/1, default 1: a custom split pattern's
  * split runs on the GPU, see spl_split_device; 0 keeps it on the host cores), "small_path" (0/1, default 1: batches of at most 4 KB take
- * the latency path, see spl_small_path_calls). */
+ * the latency path, see spl_small_path_calls), "direct_read" (0/1, default 1: a batch of ONE pipeline chunk whose text comes from
+ * spl_host_alloc is not copied to the device -- the tile kernel reads it, and the offsets, where they lie; 93 -> 83 us per 1 MB call). */
 int spl_set_option(spl_tokenizer* t, const char* name, int64_t value);
 
 /* One entry of the special_tokens map (src/core/tokenizer.rs:304, 429-434).  Call before the first
@@ -167,19 +170,27 @@ void spl_host_free(void* p);
  *   d_out_off[n_docs+1]   output offsets; d_out_off[n_docs] is the total token count
  * Tokens beyond ids_capacity are dropped (compare d_out_off[n_docs] with the capacity).
  * Size limits of ONE device call (SPL_EINVAL beyond them; spl_encode_batch on host buffers has none, it feeds
- * chunks of at most 8 MiB): n_bytes <= 2047 MiB without SPL_WITH_SPECIAL, n_bytes <= 256 MB with it (the
- * special-token scan of larger calls belongs to the multi-pass pipeline, which only -DSPL_MULTIPASS=1 builds
- * carry).  Split a larger corpus at document boundaries. */
+ * chunks of at most 8 MiB): n_bytes < 2^31 - 65536 (2047 MiB) without SPL_WITH_SPECIAL, n_bytes <= 256 MB with it and for handles with
+ * SPL_PATTERN_CUSTOM (the special-token scan and the device splitter exist for the two-launch mode only).  Split a larger corpus at
+ * document boundaries.
+ * What is asynchronous: a handle with one of the three built-in patterns enqueues its kernels on `hip_stream` and returns -- no host
+ * synchronisation, with or without SPL_WITH_SPECIAL.  A handle with SPL_PATTERN_CUSTOM synchronises `hip_stream` ONCE before it returns
+ * (to read which documents, if any, the device splitter gave up on; see below).  All calls on one handle -- this one, spl_split_device,
+ * spl_encode_chunks_device, spl_encode_batch -- share the handle's workspace: they must be stream-ordered (issued on the same stream, or
+ * with the earlier one complete); different handles are independent. */
 int spl_encode_batch_device(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
                             uint64_t n_docs, uint32_t flags, uint32_t* d_ids, uint64_t ids_capacity,
                             uint64_t* d_out_off, void* hip_stream);
 
-/* Handles with SPL_PATTERN_CUSTOM: spl_encode_batch / spl_decode_batch work as for every other handle (the split of
- * each pipeline chunk runs on the device splitter, csrc/spl_rx_split.h, behind the GPU's special-token scan with
- * SPL_WITH_SPECIAL -- or, for what the device matcher gives up on, on the host cores while the previous chunk is on the GPU).  spl_encode_batch_device
- * and spl_encode_batch_device_packed run the device splitter in front of the tile kernel (SPL_WITH_SPECIAL included) and
- * synchronise `hip_stream` ONCE before they return, to read the splitter's status word; when it gave up the text goes to
- * the host once, is split there, and the encode runs again on those boundaries.  The halves are available separately:
+/* Handles with SPL_PATTERN_CUSTOM: spl_encode_batch / spl_decode_batch work as for every other handle (the split of each pipeline chunk
+ * runs on the device splitter, csrc/spl_rx_split.h, behind the GPU's special-token scan with SPL_WITH_SPECIAL).  What the device matcher
+ * gives up on is handled per DOCUMENT: the 256-byte blocks of such positions come back in a small pinned list, the documents they lie in
+ * are split on the host cores by the calling (producer) thread -- while the previous chunk's tile kernel runs -- and their stretch of the
+ * two bitmaps is patched before the tile kernel reads it; every other document keeps the device split.  Only a list that overflows (more
+ * than 1024 such blocks in one chunk: a pattern that gives up everywhere) sends the whole batch through the host splitter.
+ * spl_encode_batch_device / _packed run splitter and tile kernel in one go and synchronise `hip_stream` ONCE before they return; if
+ * documents need the host, THEIR text (nothing else) is copied back, split, patched, and the tile kernel runs again on the patched bitmaps.
+ * The halves are available separately:
  *   spl_split_host          the matches of the handle's pattern over a packed HOST corpus as two bitmaps of
  *                           n_bytes / 32 + 2 words each (zeroed here): bit p of start_bits -- a chunk, or a stretch of
  *                           bytes no match covers, starts at byte p; bit p of gap_bits -- byte p is dropped
@@ -195,9 +206,10 @@ int spl_split_host(spl_tokenizer* t, const uint8_t* utf8, const uint64_t* doc_of
  *                           afterwards if the text held something the device matcher gives up on (a match or look-ahead
  *                           reaching more than ~1 KB beyond its start, a runaway attempt): the bitmaps are then incomplete
  *                           and the split belongs to spl_split_host.  SPL_EINVAL if the pattern's program does not fit the
- *                           device matcher.  spl_encode_batch uses it for every batch without SPL_WITH_SPECIAL and falls back
- *                           by itself (spl_set_option "device_split" 0 keeps the split on the host cores;
- *                           spl_device_split_fallbacks counts the batches that fell back).  Up to 256 MB per call. */
+ *                           device matcher.  spl_encode_batch uses it for every batch and falls back by itself, document by document
+ *                           (spl_set_option "device_split" 0 keeps the split on the host cores; spl_device_split_fallbacks counts the
+ *                           DOCUMENTS the host split instead -- all of a batch's if the whole batch went there).  Up to 256 MB per call.
+ *                           Shares the handle's splitter workspace with the encode calls: stream-ordered with them (see above). */
 int spl_split_device(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off, uint64_t n_docs,
                      uint32_t* d_start_bits, uint32_t* d_gap_bits, uint32_t* d_status, void* hip_stream);
 uint64_t spl_device_split_fallbacks(const spl_tokenizer* t);
@@ -317,9 +329,9 @@ int spl_last_queue_counts(spl_tokenizer* t, uint32_t counts_out[4]);
 
 /* Development aid: when enabled (bit 0 of `enable`; -DSPL_DEBUG_STAMPS builds), one k_pretok workgroup
  * stamps the shader clock at its phase boundaries; the call returns the stamps of the previous batch
- * (synchronises).  Bits 1-3 force an execution mode for the tests (0 the size decides, 1 small tiles,
- * 2 large tiles, 3 small tiles + multi-pass pipeline, 4 queue mode); bits 4-6 cut the kernel off after a
- * phase (profiling builds only). */
+ * (synchronises).  Bits 1-3 force an execution mode for the tests (0 the size decides, 1 the small-tile geometry,
+ * 4 queue mode, 5 tile-owned mode with the second geometry; 2 and 3 were the multi-pass pipeline, removed in round 4: SPL_EINVAL);
+ * bits 4-6 cut the kernel off after a phase (profiling builds only). */
 int spl_debug_phases(spl_tokenizer* t, int enable, unsigned long long stamps_out[16]);
 
 /* Development aid: per-workgroup records of the last stamped k_pretok launch, 4 wall-clock ticks

@@ -216,6 +216,10 @@ struct Ctx {
     uint32_t* dh_rx_status = nullptr;                               // (its device pointer)
     uint32_t* h_rx_status = nullptr;                                // pinned copy: written behind every chunk's split, read when the batch is done
     uint32_t* d_rx_bits = nullptr; uint64_t rx_bits_cap = 0;       // the two bitmaps of a device-text call (spl_encode_batch_device)
+    uint32_t* d_rx_patch = nullptr; uint64_t rx_patch_cap = 0;     // per-document fallback: the patch of one split (grow-only)
+    uint32_t* d_rx_bad = nullptr;                                   // [0] count, [1 .. RX_BAD_CAP] blocks the matcher gave up on (device list of one split)
+    uint32_t* h_rx_bad = nullptr; uint32_t* dh_rx_bad = nullptr;    // ... where k_rx_mark leaves it for the host (pinned), and its device pointer
+    hipEvent_t ev_split = nullptr;                                  // host pipeline: a chunk's split is through (the producer waits for it: per-document fallback)
     hipEvent_t ev_h2d[NSLOT] = {nullptr, nullptr, nullptr}, ev_cmp[NSLOT] = {nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ev_chunk;
     // decode scratch (grow-only)
@@ -264,6 +268,7 @@ struct Ctx {
         hipFree(d_ids); hipFree(d_oo);
         hipFree((void*)d_rx_image); hipFree((void*)d_gc1); hipFree((void*)d_gc2); hipFree(d_rx_ws); hipFree(d_rx_status); hipFree(d_rx_bits); if (h_rx_status) (void)hipHostFree(h_rx_status);
         if (h_small) (void)hipHostFree(h_small);
+        hipFree(d_rx_patch); hipFree(d_rx_bad); if (h_rx_bad) (void)hipHostFree(h_rx_bad); if (ev_split) (void)hipEventDestroy(ev_split);
         hipFree(d_dec_ids); hipFree(d_dec_blk); hipFree(d_dec_idoff); hipFree(d_dec_out); hipFree(d_dec_first); hipFree(d_dec_docoff);
         if (ev_ready) for (auto& e : ev) (void)hipEventDestroy(e);
         for (int i = 0; i < NSLOT; i++) { if (ev_h2d[i]) (void)hipEventDestroy(ev_h2d[i]); if (ev_cmp[i]) (void)hipEventDestroy(ev_cmp[i]); }
@@ -285,7 +290,7 @@ struct spl_tokenizer {
     RegexPtr regex;                           // SPL_PATTERN_CUSTOM: the host splitter's program (null: one of the GPU scanner's patterns)
     std::vector<uint32_t> rx_image;           // ... and its image for the device splitter (empty: the program does not fit, the split stays on the host)
     int rx_device = 1;                        // spl_set_option("device_split"): 0 keeps a custom pattern's split on the host cores
-    uint64_t rx_fallbacks = 0;                // batches the device splitter gave up on (spl_get_option("device_split_fallbacks"))
+    uint64_t rx_fallbacks = 0;                // DOCUMENTS the device splitter gave up on and the host split instead (spl_device_split_fallbacks)
     std::vector<std::unique_ptr<Ctx>> ctx;
     std::shared_ptr<PinnedPool> pool = std::make_shared<PinnedPool>();
     // host pipeline tuning (spl_set_option)
@@ -295,6 +300,7 @@ struct spl_tokenizer {
     int subdoc = 1;                           // cut documents at context-free boundaries to balance the GPUs
     int direct_write = 1;                     // one-chunk batches: the last kernel writes the ids straight into the pinned result
     int small_path = 1;                       // batches of up to 4 KB take the latency path (encode_small)
+    int direct_read = 1;                      // one-chunk batches from pinned memory: the tile kernel reads text and offsets where they lie (no H2D copy)
     uint64_t small_calls = 0;                 // ... and how many did (spl_small_path_calls)
 };
 
@@ -508,17 +514,19 @@ struct ExtIn {
 };
 int rx_launch(spl_tokenizer* tk, Ctx* c, const uint8_t* d_text, uint64_t n_bytes, const uint64_t* d_doc_off, uint64_t n_docs,
               uint32_t* d_starts, uint32_t* d_gaps, uint32_t* d_status, hipStream_t s, const Batch* sp = nullptr, uint32_t sp_words = 0,
-              uint32_t* d_status_host = nullptr);
+              uint32_t* d_status_host = nullptr, bool bad_sets_status = false);
 
 int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off, uint64_t n_docs,
                uint32_t flags, uint32_t* d_ids, uint64_t ids_cap, uint64_t* d_out_off, hipStream_t s,
-               const SlabOut* so = nullptr, const ExtIn* ext = nullptr) {
+               const SlabOut* so = nullptr, const ExtIn* ext = nullptr, int phase = 0) {
+    // phase (tile-owned mode with the device splitter, per-document fallback): 0 = everything; 1 = only what comes in FRONT of the tile kernel
+    // (bitmap fills, special-token scan, the device splitter); 2 = only the tile kernel and k_tile_out, on bitmaps the caller may have patched
     if (((uintptr_t)d_utf8 & 15) != 0) return fail(SPL_EINVAL, "text buffer must be 16-byte aligned");
     if (ext && n_bytes > SPL_DIRECT_MAX_BYTES) return fail(SPL_EINVAL, "external chunk boundaries: at most 256 MB per device call");
     // (external boundaries from the HOST splitter: the special tokens -- if any -- were found there; the GPU's literal scan stays off)
     const bool special = (!ext || ext->d_status) && (flags & SPL_WITH_SPECIAL) && !tk->specials.empty();
     if (special) { int rc0 = upload_specials(tk, t); if (rc0) return rc0; }
-    if (n_bytes > 0x7FFF0000ull) return fail(SPL_EINVAL, "n_bytes per device call must be < 2^31 - 65536");
+    if (n_bytes > 0x7FFF0000ull) return fail(SPL_EINVAL, "n_bytes per device call must be < 2^31 - 65536 (split the corpus at document boundaries; spl_encode_batch does that by itself)");
     if (n_docs > 0xFFFFFFF0ull) return fail(SPL_EINVAL, "n_docs per device call must be < 2^32 - 16");
     int rc = reserve(t, n_bytes, n_docs);
     if (rc) return rc;
@@ -599,7 +607,8 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
         MARK(KI_N);
     } else if (direct) {
         const bool ext_sp = ext && ext->n_sp > 0;
-        if (special) {
+        if (phase == 2) {
+        } else if (special) {
             // the three bitmaps are cleared per call; documents and literals are marked by the
             // multi-pass kernels, the tile kernel reads the bitmaps on top of its document search
             HIP_TRY(hipMemsetAsync(t->d_zero, 0, (nbm * uw + QCOUNT_WORDS) * 4, s));
@@ -618,9 +627,9 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
         //  k_tile_out -- was built and measured in round 5: 33.6 us per 1 KB call against 31.2 with the two launches, 23.9 against 22.8 for 13
         //  bytes.  Two back-to-back launches overlap the second one's dispatch with the first kernel; the fused epilogue's device-scope fences,
         //  L1-bypassing loads and serial walk over the tiles cost more than that launch.  Dropped.)
-        if (ntiles) t->tpar ^= 1u;              // k_tile_out zeroes the other parity's sums for the next call
-        if (ntiles && t->off_host) { b.off_out2 = t->off_host; t->off_host_written = true; }
-        if (ntiles && t->done_arm) { b.done = t->done_arm; b.done_seq = t->done_seq; t->done_armed = true; }
+        if (ntiles && phase != 1) t->tpar ^= 1u;              // k_tile_out zeroes the other parity's sums for the next call
+        if (ntiles && t->off_host && phase != 1) { b.off_out2 = t->off_host; t->off_host_written = true; }
+        if (ntiles && t->done_arm && phase != 1) { b.done = t->done_arm; b.done_seq = t->done_seq; t->done_armed = true; }
         if (!special) b.tstart = nullptr;
         b.qcount = nullptr;
         t->last_qcount = nullptr;
@@ -628,23 +637,28 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
             b.ext_starts = ext->d_starts; b.ext_gaps = ext->d_gaps;
             if (ext_sp) {
                 b.skip = const_cast<uint32_t*>(ext->d_gaps);     // (read-only here: the spans the literals' tokens lie in)
-                hipLaunchKernelGGL(k_ext_specials, dim3((ext->n_sp + 255) / 256), dim3(256), 0, s, b, ext->d_sp_pos, ext->d_sp_id, ext->n_sp);
+                if (phase != 2) hipLaunchKernelGGL(k_ext_specials, dim3((ext->n_sp + 255) / 256), dim3(256), 0, s, b, ext->d_sp_pos, ext->d_sp_id, ext->n_sp);
             }
         }
         MARK(KI_MARK);
-        if (special && n_docs) hipLaunchKernelGGL(k_mark_docs, dim3((uint32_t)((n_docs + 255) / 256)), dim3(256), 0, s, b);
+        if (special && n_docs && phase != 2) hipLaunchKernelGGL(k_mark_docs, dim3((uint32_t)((n_docs + 255) / 256)), dim3(256), 0, s, b);
         MARK(KI_SPECIAL);
-        if (special && n_bytes) {
+        if (special && n_bytes && phase != 2) {
             if (!general) hipLaunchKernelGGL(k_special_scan, dim3((uint32_t)((n_bytes + 255) / 256)), dim3(256), 0, s, b);
             else {
                 hipLaunchKernelGGL(k_special_ends, dim3((uint32_t)((n_bytes + 255) / 256)), dim3(256), 0, s, b);
                 hipLaunchKernelGGL(k_special_select, dim3((uint32_t)((n_docs + 255) / 256)), dim3(256), 0, s, b);
             }
         }
-        if (ext && ext->d_status) {            // the device splitter, behind the literal scan whose bitmaps it reads
+        if (ext && ext->d_status && phase != 2) {            // the device splitter, behind the literal scan whose bitmaps it reads
             int rcx = rx_launch(tk, t, d_utf8, n_bytes, d_doc_off, n_docs, const_cast<uint32_t*>(ext->d_starts), const_cast<uint32_t*>(ext->d_gaps),
                                 ext->d_status, s, special ? &b : nullptr, (uint32_t)uw, ext->d_status_host);
             if (rcx) return rcx;
+        }
+        if (phase == 1) {
+            const hipError_t le1 = hipGetLastError();
+            if (le1 != hipSuccess) return fail(SPL_EDEVICE, std::string("kernel launch: ") + hipGetErrorString(le1));
+            return SPL_OK;
         }
         MARK(KI_PRETOK);
         if (ntiles && direct_b) hipLaunchKernelGGL((k_pretok<SPL_TILE_DIRECT_B>), dim3(ntiles), dim3(NT), 0, s, PRETOK_EARLY(t->dt, b), t->dt, b);
@@ -655,8 +669,9 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
         MARK(KI_N);
     } else {
         (void)fused_scan_used;
-        return fail(SPL_EINVAL, "a device call with SPL_WITH_SPECIAL beyond 256 MB (or a forced multi-pass geometry) is not supported: the multi-pass "
-                                "pipeline was removed in round 4; split the call at document boundaries -- spl_encode_batch does that by itself");
+        return fail(SPL_EINVAL, (flags & SPL_WITH_SPECIAL) && !tk->specials.empty()
+                                    ? "a device call with SPL_WITH_SPECIAL takes at most 256 MB: split the call at document boundaries -- spl_encode_batch does that by itself"
+                                    : "this device call fits neither the tile-owned mode (256 MB) nor queue mode (2047 MiB, no forced geometry): split it at document boundaries");
     }
 #undef MARK
     {
@@ -720,6 +735,18 @@ int rx_ensure(spl_tokenizer* tk, Ctx* c) {
         HIP_TRY(hipHostGetDevicePointer(&dp, c->h_rx_status, 0));
         c->dh_rx_status = (uint32_t*)dp;
     }
+    if (!c->d_rx_bad) {
+        HIP_TRY(hipMalloc((void**)&c->d_rx_bad, (1 + RX_BAD_CAP) * 4));
+        HIP_TRY(hipMemset(c->d_rx_bad, 0, (1 + RX_BAD_CAP) * 4));
+    }
+    if (!c->h_rx_bad) {
+        HIP_TRY(hipHostMalloc((void**)&c->h_rx_bad, (1 + 2 * RX_BAD_CAP) * 4, hipHostMallocPortable));
+        c->h_rx_bad[0] = 0;
+        void* dp = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&dp, c->h_rx_bad, 0));
+        c->dh_rx_bad = (uint32_t*)dp;
+    }
+    if (!c->ev_split) HIP_TRY(hipEventCreateWithFlags(&c->ev_split, hipEventDisableTiming));
     return dev_upload(tk->rx_image, &c->d_rx_image);
 }
 // This batch's status word: the next one of the context's rotation -- cleared by the previous batch's k_rx_mark, or here if that batch launched none
@@ -730,7 +757,8 @@ int rx_next_status(Ctx* c, hipStream_t s) {
     return SPL_OK;
 }
 int rx_launch(spl_tokenizer* tk, Ctx* c, const uint8_t* d_text, uint64_t n_bytes, const uint64_t* d_doc_off, uint64_t n_docs,
-              uint32_t* d_starts, uint32_t* d_gaps, uint32_t* d_status, hipStream_t s, const Batch* sp, uint32_t sp_words, uint32_t* d_status_host) {
+              uint32_t* d_starts, uint32_t* d_gaps, uint32_t* d_status, hipStream_t s, const Batch* sp, uint32_t sp_words, uint32_t* d_status_host,
+              bool bad_sets_status) {
     if (n_bytes > SPL_DIRECT_MAX_BYTES) return fail(SPL_EINVAL, "device split: at most 256 MB per call");
     if (((uintptr_t)d_text & 15) != 0) return fail(SPL_EINVAL, "text buffer must be 16-byte aligned");
     int rc = rx_ensure(tk, c);
@@ -743,12 +771,12 @@ int rx_launch(spl_tokenizer* tk, Ctx* c, const uint8_t* d_text, uint64_t n_bytes
     }
     const uint64_t nblk = (n_bytes + RXB - 1) / RXB;
     // workspace, laid out by its CAPACITY in blocks (the per-block entries must stay where they are from call to call -- they are
-    // told apart by generation, not cleared): blk | bskip | dstart | nx | gx
+    // told apart by generation, not cleared): blk | bskip | bad_hi | bad_lo | dstart | nx | gx
     if (nblk > c->rx_cap_blk) {
         HIP_TRY(hipDeviceSynchronize());
         hipFree(c->d_rx_ws); c->d_rx_ws = nullptr; c->rx_ws_cap = 0; c->rx_cap_blk = 0;
         const uint64_t cb = nblk + nblk / 4 + 16;
-        const uint64_t cap = 8 * cb + 4 * (8 * cb + 2) + 4 * cb * RXB + 256;
+        const uint64_t cap = 16 * cb + 4 * (8 * cb + 2) + 4 * cb * RXB + 256;
         HIP_TRY(hipMalloc((void**)&c->d_rx_ws, cap));
         c->rx_ws_cap = cap; c->rx_cap_blk = cb;
         c->rx_gen = 0xFFFFu;                           // (fresh memory: cleared below)
@@ -764,7 +792,9 @@ int rx_launch(spl_tokenizer* tk, Ctx* c, const uint8_t* d_text, uint64_t n_bytes
     a.text = d_text; a.doc_off = d_doc_off; a.n_bytes = (uint32_t)n_bytes; a.n_docs = (uint32_t)n_docs;
     a.ucls1 = c->dt.ucls_stage1; a.ucls2 = c->dt.ucls_stage2; a.shift = c->dt.ucls_shift;
     a.gc1 = c->d_gc1; a.gc2 = c->d_gc2;
-    a.blk = (uint32_t*)c->d_rx_ws; a.bskip = a.blk + c->rx_cap_blk; a.dstart = a.bskip + c->rx_cap_blk;
+    a.blk = (uint32_t*)c->d_rx_ws; a.bskip = a.blk + c->rx_cap_blk; a.bad_hi = a.bskip + c->rx_cap_blk; a.bad_lo = a.bad_hi + c->rx_cap_blk;
+    a.dstart = a.bad_lo + c->rx_cap_blk;
+    a.bad_list = c->d_rx_bad; a.bad_host = c->dh_rx_bad; a.bad_sets_status = bad_sets_status ? 1u : 0u;
     a.nx = (uint16_t*)(a.dstart + 8 * c->rx_cap_blk + 2); a.gx = a.nx + c->rx_cap_blk * RXB;
     a.gen = c->rx_gen; a.bm_words = (uint32_t)words;
     a.starts = d_starts; a.gaps = d_gaps; a.status = d_status; a.status_host = d_status_host;
@@ -898,6 +928,67 @@ int host_split_docs(const spl_tokenizer* tk, const uint8_t* text, const uint64_t
     return SPL_OK;
 }
 
+// ---- per-document fallback of the device splitter ------------------------------------------------------------------
+// The blocks k_rx_mark left in the context's pinned list (h_rx_bad: [0] count, then per block two words: the 256-byte block, first << 8 | last position in it
+// that the matcher gave up on -- a match longer than ~1 KB, a runaway attempt): the documents those stretches touch are split HERE, on the calling thread,
+// and their stretch of the two device bitmaps is patched (k_rx_patch, on `s`, behind the device split whose completion the caller has
+// waited for); every other document keeps what the device splitter made.  `rel[0 .. nd]`: the documents' offsets relative to the
+// bitmaps' origin; text_of(d): the first byte of document d on the host.  Up to round 4 ONE such position sent the whole batch through
+// the host splitter ("a 5x cliff triggered by a single base64 blob").  Reference semantics: tokenizer.rs:729-808.
+template <class TextOf>
+int rx_patch_docs(spl_tokenizer* tk, Ctx* c, const uint64_t* rel, uint64_t nd, bool special, uint32_t* d_starts, uint32_t* d_gaps,
+                  hipStream_t s, TextOf text_of, uint64_t* n_patched) {
+    const uint32_t nb = std::min<uint32_t>(c->h_rx_bad[0], RX_BAD_CAP);
+    std::vector<uint64_t> docs;
+    for (uint32_t i = 0; i < nb; i++) {
+        // the (non-empty) documents that overlap [first, last] -- the positions of the listed block at which the matcher gave up
+        const uint32_t blk = c->h_rx_bad[1 + 2 * i], e = c->h_rx_bad[2 + 2 * i];
+        const uint64_t lo = (uint64_t)blk * RXB + ((e >> 8) & 255u), hi = (uint64_t)blk * RXB + (e & 255u) + 1;
+        uint64_t d = (uint64_t)(std::upper_bound(rel + 1, rel + nd + 1, lo) - (rel + 1));      // first d with rel[d + 1] > lo
+        for (; d < nd && rel[d] < hi; d++)
+            if (rel[d + 1] > rel[d]) docs.push_back(d);
+    }
+    std::sort(docs.begin(), docs.end());
+    docs.erase(std::unique(docs.begin(), docs.end()), docs.end());
+    *n_patched = docs.size();
+    if (docs.empty()) return SPL_OK;
+    std::vector<uint32_t> patch, at;
+    std::vector<SpHit> hits;
+    for (uint64_t d : docs) {
+        const uint64_t lo = rel[d], hi = rel[d + 1];
+        const uint64_t w0 = lo >> 5, n = ((hi - 1) >> 5) - w0 + 1;
+        TRACE("device split gave up inside document %llu [%llu, %llu): split on the host, %llu bitmap words patched", (unsigned long long)d,
+              (unsigned long long)lo, (unsigned long long)hi, (unsigned long long)n);
+        at.push_back((uint32_t)patch.size());
+        const size_t h = patch.size();
+        patch.resize(h + 4 + 2 * n + 2, 0u);                     // (+ 2: the bit of position hi may fall into the word behind)
+        patch[h] = (uint32_t)w0; patch[h + 1] = (uint32_t)n;
+        patch[h + 2] = 0xFFFFFFFFu << (lo & 31);
+        patch[h + 3] = (hi & 31) ? (1u << (hi & 31)) - 1u : 0xFFFFFFFFu;
+        std::vector<uint32_t> st(n + 1, 0u), gp(n + 1, 0u);
+        const uint64_t lo_b = lo - w0 * 32;                      // the document's first bit in these words
+        const uint8_t* base = text_of(d) - lo_b;                 // (indexed by bit position: base + lo_b is the document's first byte)
+        if (!host_split_doc(tk, base, lo_b, lo_b + (hi - lo), special, st.data(), gp.data(), &hits))
+            return fail(SPL_EINVAL, "the split pattern ran out of its matching budget on this text (catastrophic backtracking)");
+        memcpy(&patch[h + 4], st.data(), n * 4);
+        memcpy(&patch[h + 4 + n], gp.data(), n * 4);
+    }
+    const size_t need = patch.size() + at.size();
+    if (need > c->rx_patch_cap) {
+        HIP_TRY(hipStreamSynchronize(s));
+        hipFree(c->d_rx_patch); c->d_rx_patch = nullptr; c->rx_patch_cap = 0;
+        HIP_TRY(hipMalloc((void**)&c->d_rx_patch, (need + need / 2 + 1024) * 4));
+        c->rx_patch_cap = need + need / 2 + 1024;
+    }
+    // (pageable -> device, blocking: the stream's earlier work -- the device split -- is through, the patch kernel follows on it)
+    HIP_TRY(hipMemcpy(c->d_rx_patch, patch.data(), patch.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_rx_patch + patch.size(), at.data(), at.size() * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_rx_patch, dim3((uint32_t)docs.size()), dim3(256), 0, s, d_starts, d_gaps, (const uint32_t*)c->d_rx_patch,
+                       (const uint32_t*)(c->d_rx_patch + patch.size()));
+    HIP_TRY(hipGetLastError());
+    return SPL_OK;
+}
+
 // A custom-pattern handle with its text in HBM (spl_encode_batch_device / _packed): the device splitter and the tile kernel in one go,
 // then ONE stream synchronisation to read the splitter's status word; when the matcher gave up (rare: a match longer than ~1 KB) the text
 // goes to the host once, is split there (special-token literals included) and the encode runs again on those boundaries.
@@ -920,13 +1011,43 @@ int encode_device_custom(spl_tokenizer* t, Ctx* c, const uint8_t* d_utf8, uint64
         rc = rx_next_status(c, s);
         if (rc) return rc;
         ext.d_status = c->d_rx_status + c->rx_slot;
-        rc = launch_all(t, c, d_utf8, n_bytes, d_doc_off, n_docs, flags, d_ids, ids_cap, d_out_off, s, so, &ext);
+        // optimistic: splitter and tile kernel go out together, ONE synchronisation to read what the splitter gave up on -- except with special
+        // tokens (the literal scan's bitmap would keep the first tile pass's bits): there the splitter goes first, the tile kernel behind the check
+        const bool two_phase = (flags & SPL_WITH_SPECIAL) && !t->specials.empty();
+        rc = launch_all(t, c, d_utf8, n_bytes, d_doc_off, n_docs, flags, d_ids, ids_cap, d_out_off, s, so, &ext, two_phase ? 1 : 0);
         if (rc) return rc;
         uint32_t gave_up = 1;
         HIP_TRY(hipMemcpyAsync(&gave_up, c->d_rx_status + c->rx_slot, 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        if (!gave_up) return SPL_OK;
-        t->rx_fallbacks++;
+        if (!gave_up && c->h_rx_bad[0] == 0) {
+            if (two_phase) { rc = launch_all(t, c, d_utf8, n_bytes, d_doc_off, n_docs, flags, d_ids, ids_cap, d_out_off, s, so, &ext, 2); if (rc) return rc; HIP_TRY(hipStreamSynchronize(s)); }
+            return SPL_OK;
+        }
+        if (!gave_up) {
+            // a few documents hold something the device matcher gives up on: THEIR text comes to the host, is split there, their stretch of
+            // the bitmaps is patched and the tile kernel runs again on the patched bitmaps (the device split itself is not repeated)
+            std::vector<uint64_t> off(n_docs + 1);
+            HIP_TRY(hipMemcpy(off.data(), d_doc_off, (n_docs + 1) * 8, hipMemcpyDeviceToHost));
+            std::vector<std::vector<uint8_t>> keep;
+            hipError_t cerr = hipSuccess;
+            auto text_of = [&](uint64_t d) -> const uint8_t* {
+                keep.emplace_back((size_t)(off[d + 1] - off[d]) + 16);
+                const hipError_t e = hipMemcpy(keep.back().data(), d_utf8 + off[d], (size_t)(off[d + 1] - off[d]), hipMemcpyDeviceToHost);
+                if (e != hipSuccess) cerr = e;
+                return keep.back().data();
+            };
+            uint64_t n_patched = 0;
+            const bool special = (flags & SPL_WITH_SPECIAL) && !t->specials.empty();
+            rc = rx_patch_docs(t, c, off.data(), n_docs, special, c->d_rx_bits, c->d_rx_bits + bw, s, text_of, &n_patched);
+            if (rc) return rc;
+            if (cerr != hipSuccess) return fail(SPL_EDEVICE, std::string("hipMemcpy: ") + hipGetErrorString(cerr));
+            t->rx_fallbacks += n_patched;
+            rc = launch_all(t, c, d_utf8, n_bytes, d_doc_off, n_docs, flags, d_ids, ids_cap, d_out_off, s, so, &ext, 2);
+            if (rc) return rc;
+            HIP_TRY(hipStreamSynchronize(s));
+            return SPL_OK;
+        }
+        t->rx_fallbacks += n_docs;              // the whole batch (the list of blocks overflowed, or walks that never fall into step)
         ext.d_status = nullptr;
     }
     const bool special = (flags & SPL_WITH_SPECIAL) && !t->specials.empty();
@@ -984,6 +1105,7 @@ struct Lane {
     std::atomic<int> rc{0};
     std::string err;
     bool host_split = true;      // custom pattern: the split of this lane's chunks runs on the host cores (false: k_rx_match / k_rx_mark)
+    uint64_t patched = 0;        // documents of this lane that the device splitter gave up on and the host split instead
 };
 
 bool is_pinned_host(const void* p) {
@@ -1091,7 +1213,7 @@ int lane_prepare(spl_tokenizer* tk, Lane& ln, const uint64_t* doc_off, uint64_t 
 
 // producer: every chunk of one lane, in order (runs in the caller's thread for a single chunk)
 int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t* doc_off, uint32_t flags, bool src_pinned,
-                bool solo = false, uint32_t* ids_direct = nullptr) {
+                bool solo = false, uint32_t* ids_direct = nullptr, bool mapped = false) {
     Ctx* c = ln.c;
     HIP_TRY(hipSetDevice(c->device));
     uint64_t* const h_tot = (uint64_t*)c->h_tot.p;
@@ -1109,8 +1231,18 @@ int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t
         if (k >= NSLOT) HIP_TRY(hipStreamWaitEvent(c->s_h2d, c->ev_cmp[sl], 0));   // the slot's device text has been consumed
         // (a batch of ONE chunk has nothing to overlap: its copies go on the compute stream, no event in between)
         hipStream_t hs = solo ? c->s_cmp : c->s_h2d;
+        // ("direct_read": the one chunk of a batch whose text is pinned is not copied at all -- the tile kernel reads text and offsets over PCIe)
+        const uint8_t* text_arg = c->d_text[sl];
+        const uint64_t* off_arg = c->d_off[sl];
+        if (mapped && solo && nb) {
+            void *tp = nullptr, *op = nullptr;
+            HIP_TRY(hipHostGetDevicePointer(&tp, (void*)src, 0));
+            HIP_TRY(hipHostGetDevicePointer(&op, rel, 0));
+            text_arg = (const uint8_t*)tp; off_arg = (const uint64_t*)op;
+        } else {
         if (nb) HIP_TRY(hipMemcpyAsync(c->d_text[sl], src, nb, hipMemcpyHostToDevice, hs));
         HIP_TRY(hipMemcpyAsync(c->d_off[sl], rel, (nd + 1) * 8, hipMemcpyHostToDevice, hs));
+        }
         if (!solo) {
             HIP_TRY(hipEventRecord(c->ev_h2d[sl], c->s_h2d));
             HIP_TRY(hipStreamWaitEvent(c->s_cmp, c->ev_h2d[sl], 0));
@@ -1155,7 +1287,34 @@ int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t
                 HIP_TRY(hipStreamWaitEvent(c->s_cmp, c->ev_h2d[sl], 0));
             }
         }
-        int rc = launch_all(tk, c, c->d_text[sl], nb, c->d_off[sl], nd, flags, ids_direct ? ids_direct : c->d_ids + (ch.lo - ln.lo),
+        int rc;
+        const bool sp_flag = (flags & SPL_WITH_SPECIAL) && !tk->specials.empty();
+        if (tk->regex && !ln.host_split && (!solo || sp_flag)) {
+            // (a one-chunk batch runs optimistically instead -- splitter and tile kernel out together, one more tile pass if a document needs
+            //  it: encode_host --, except with special tokens: the first tile pass would leave token bits in the bitmap the literal scan has
+            //  written, which only a fill per call clears)
+            // device split of a pipeline chunk, per-document fallback: the splitter first; the producer waits for it (the GPU has the
+            // previous chunk's tile kernel to run meanwhile), has the documents of the listed blocks split on the host -- normally none --
+            // and their bits patched, then the tile kernel follows
+            rc = launch_all(tk, c, text_arg, nb, off_arg, nd, flags, ids_direct ? ids_direct : c->d_ids + (ch.lo - ln.lo), nb + 16, oo, c->s_cmp,
+                            nullptr, &ext, 1);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(c->ev_split, c->s_cmp));
+            HIP_TRY(hipEventSynchronize(c->ev_split));
+            if (c->h_rx_status[0] == 0 && c->h_rx_bad[0] != 0) {
+                const uint64_t bw = nb / 32 + 4;
+                const uint8_t* const ctext = utf8 + ch.lo;
+                uint64_t n_patched = 0;
+                rc = rx_patch_docs(tk, c, rel, nd, (flags & SPL_WITH_SPECIAL) && !tk->specials.empty(), c->d_ext[sl], c->d_ext[sl] + bw, c->s_cmp,
+                                   [&](uint64_t d) { return ctext + rel[d]; }, &n_patched);
+                if (rc) return rc;
+                ln.patched += n_patched;
+                c->h_rx_bad[0] = 0;                          // (dealt with: the one-chunk caller looks at it again)
+            }
+            rc = launch_all(tk, c, text_arg, nb, off_arg, nd, flags, ids_direct ? ids_direct : c->d_ids + (ch.lo - ln.lo), nb + 16, oo, c->s_cmp,
+                            nullptr, &ext, 2);
+        } else
+            rc = launch_all(tk, c, text_arg, nb, off_arg, nd, flags, ids_direct ? ids_direct : c->d_ids + (ch.lo - ln.lo),
                             nb + 16, oo, c->s_cmp, nullptr, tk->regex ? &ext : nullptr);
         if (rc) return rc;
         if (solo) break;                                   // (the batch is ONE chunk: the caller finishes on the compute stream itself)
@@ -1324,13 +1483,37 @@ int encode_host(spl_tokenizer* tk, const uint8_t* utf8, const uint64_t* doc_off,
             void* optr = nullptr;
             HIP_TRY(hipHostGetDevicePointer(&optr, r->off, 0));
             c->off_host = (uint64_t*)optr; c->off_host_written = false;
-            int rc = lane_submit(tk, ln, utf8, doc_off, flags, src_pinned, true, (uint32_t*)dptr);
+            const bool mapped = tk->direct_read && src_pinned && ((uintptr_t)(utf8 + ch.lo) & 15) == 0 && !tk->regex;
+            // (completion by k_tile_out's word in pinned memory instead of the stream synchronisation -- what the latency path does for a handful of
+            //  tiles -- was measured here too: 150 us against 93 for the 1 MB batch; 1250 workgroups each pay a system-scope fence.  Not adopted.)
+            int rc = lane_submit(tk, ln, utf8, doc_off, flags, src_pinned, true, (uint32_t*)dptr, mapped);
             c->off_host = nullptr;
             if (rc) return rc;
             if (!c->off_host_written) HIP_TRY(hipMemcpyAsync(r->off, c->d_oo + ch.oo_at, (nd + 1) * 8, hipMemcpyDeviceToHost, c->s_cmp));
             HT_T(ht2);
             HT_ACC(1, ht1, ht2);
             HIP_TRY(hipStreamSynchronize(c->s_cmp));
+            if (tk->regex && !ln.host_split && c->h_rx_status[0] == 0 && c->h_rx_bad[0] != 0) {
+                // the device splitter gave up on a few documents (optimistic run: splitter and tile kernel went out together): split those
+                // on the host, patch their bits, and run the tile kernel once more on the patched bitmaps -- its results overwrite the first run's
+                const uint64_t nb = ch.hi - ch.lo, bw = nb / 32 + 4;
+                const uint64_t* const rel = (const uint64_t*)c->h_off[0].p;
+                const uint8_t* const ctext = utf8 + ch.lo;
+                uint64_t n_patched = 0;
+                rc = rx_patch_docs(tk, c, rel, nd, (flags & SPL_WITH_SPECIAL) && !tk->specials.empty(), c->d_ext[0], c->d_ext[0] + bw, c->s_cmp,
+                                   [&](uint64_t d) { return ctext + rel[d]; }, &n_patched);
+                if (rc) return rc;
+                ExtIn ext;
+                ext.d_starts = c->d_ext[0]; ext.d_gaps = c->d_ext[0] + bw;
+                ext.d_status = c->d_rx_status + c->rx_slot; ext.d_status_host = c->dh_rx_status;
+                c->off_host = (uint64_t*)optr; c->off_host_written = false;
+                rc = launch_all(tk, c, c->d_text[0], nb, c->d_off[0], nd, flags, (uint32_t*)dptr, nb + 16, c->d_oo + ch.oo_at, c->s_cmp, nullptr, &ext, 2);
+                c->off_host = nullptr;
+                if (rc) return rc;
+                HIP_TRY(hipStreamSynchronize(c->s_cmp));
+                ln.patched = n_patched;
+            }
+            if (ln.patched) { tk->rx_fallbacks += ln.patched; ln.patched = 0; }     // (a one-chunk batch WITH special tokens: patched inside lane_submit)
             HT_T(ht3);
             HT_ACC(2, ht2, ht3);
 #ifdef SPL_HOST_TIMING
@@ -1349,6 +1532,9 @@ int encode_host(spl_tokenizer* tk, const uint8_t* utf8, const uint64_t* doc_off,
         HIP_TRY(hipMemcpyAsync(r->off, c->d_oo + ch.oo_at, (nd + 1) * 8, hipMemcpyDeviceToHost, c->s_cmp));
         if (spec) HIP_TRY(hipMemcpyAsync(r->ids, c->d_ids, spec * 4, hipMemcpyDeviceToHost, c->s_cmp));
         HIP_TRY(hipStreamSynchronize(c->s_cmp));
+        // ("direct_write" 0: this path has no second tile pass to give -- documents the device matcher gave up on send the batch through the
+        //  host splitter as a whole, as a status word would)
+        if (tk->regex && !ln.host_split && c->h_rx_bad[0] != 0) c->h_rx_status[0] |= RXS_REACH;
         const uint64_t T = r->off[nd];
         if (T > spec) {                                                // the guess was too small: a bigger buffer, the rest
             size_t ncap = 0;
@@ -1436,6 +1622,7 @@ int encode_host(spl_tokenizer* tk, const uint8_t* utf8, const uint64_t* doc_off,
         for (auto& ln : lanes) { if (hipSetDevice(ln.c->device) == hipSuccess) (void)hipDeviceSynchronize(); }
         return fail(rc_all, err_all);
     }
+    for (auto& ln : lanes) tk->rx_fallbacks += ln.patched;
     r->off[n_docs] = base;
     r->n_tokens = base;
     return SPL_OK;
@@ -1613,6 +1800,7 @@ int spl_set_option(spl_tokenizer* t, const char* name, int64_t value) {
     else if (k == "direct_write") t->direct_write = value != 0;
     else if (k == "device_split") t->rx_device = value != 0;
     else if (k == "small_path") t->small_path = value != 0;
+    else if (k == "direct_read") t->direct_read = value != 0;
     else return fail(SPL_EINVAL, "spl_set_option: unknown option or bad value: " + k);
     return SPL_OK;
 }
@@ -1716,6 +1904,7 @@ int spl_encode_batch(spl_tokenizer* t, const uint8_t* utf8, const uint64_t* doc_
                 if (!rcx) rcx = rx_next_status(c.get(), c->s_cmp);   // (this batch's status word: cleared by the previous batch's k_rx_mark)
                 if (rcx) return rcx;
                 c->h_rx_status[0] = 0;
+                c->h_rx_bad[0] = 0;
             }
         int rc = encode_host(t, utf8, doc_off, n_docs, flags, r.get(), !dev_split);
         if (rc) return rc;
@@ -1725,7 +1914,7 @@ int spl_encode_batch(spl_tokenizer* t, const uint8_t* utf8, const uint64_t* doc_
             //  encode_host has waited for: nothing to copy or wait for here)
             uint32_t gave_up = 0;
             for (auto& c : t->ctx) gave_up |= c->h_rx_status[0];
-            t->rx_fallbacks += gave_up ? 1 : 0;
+            t->rx_fallbacks += gave_up ? n_docs : 0;
             if (gave_up) {
                 r.reset(new spl_result());
                 rc = encode_host(t, utf8, doc_off, n_docs, flags, r.get(), true);
@@ -2085,7 +2274,8 @@ int spl_split_device(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, 
     if (t->rx_image.empty()) return fail(SPL_EINVAL, "spl_split_device: this pattern's program does not fit the device matcher (use spl_split_host)");
     return guarded("spl_split_device", [&] {
         HIP_TRY(hipSetDevice(t->ctx[0]->device));
-        return rx_launch(t, t->ctx[0].get(), d_utf8, n_bytes, d_doc_off, n_docs, d_start_bits, d_gap_bits, d_status, (hipStream_t)hip_stream);
+        return rx_launch(t, t->ctx[0].get(), d_utf8, n_bytes, d_doc_off, n_docs, d_start_bits, d_gap_bits, d_status, (hipStream_t)hip_stream, nullptr, 0, nullptr,
+                         true);      // (the public half has no per-document fallback behind it: anything given up on shows in *d_status)
     });
 }
 

@@ -22,10 +22,13 @@
 //                behind a marked node is on the walk), and ORs the result into the two bitmaps k_pretok takes in place of its
 //                own scanner: chunk starts and dropped bytes, bit for bit what regex_split_bits leaves.
 //
-// What the matcher gives up on is REPORTED, never approximated (status word != 0, the caller splits that batch on the host):
-// a match or a look-ahead that reaches RX_REACH bytes beyond its start (every position of a run scans to the run's end --
-// the work is quadratic in the run length, so it is bounded), RX_STEPS matcher steps in one attempt, RX_DEPTH entries on the
-// backtracking stack, RX_MAX_OPEN blocks in a row whose walks never fall into step.
+// What the matcher gives up on is REPORTED, never approximated: a match or a look-ahead that reaches RX_REACH bytes beyond its start
+// (every position of a run scans to the run's end -- the work is quadratic in the run length, so it is bounded), RX_STEPS matcher
+// steps in one attempt, RX_DEPTH entries on the backtracking stack.  Since round 5 per DOCUMENT: the 256-byte block of such a position goes
+// on a list, with the first and last such position in it (k_rx_mark leaves it in pinned host memory), the caller splits the documents those stretches touch on the host cores and
+// patches their stretch of the two bitmaps (k_rx_patch) -- a walk that went wrong inside a document still lands on the next document's
+// start, because no hop crosses the end of its document.  Only a list that overflows (RX_BAD_CAP blocks: a pattern that gives up
+// everywhere) or RX_MAX_OPEN blocks in a row whose walks never fall into step set the status word: the whole batch then goes to the host.
 // With SPL_WITH_SPECIAL the literals come from the GPU's own scan (k_special_scan / the general matcher, spl_k_special.h: text-start and
 // token bitmaps); a literal is a position whose hop is its length, dropped, with the text ending in front of it and beginning anew behind it.
 #pragma once
@@ -48,6 +51,7 @@ constexpr int RX_DEPTH = 10;                     // entries of a lane's backtrac
 constexpr uint32_t RX_STEPS = 8192;
 constexpr int RX_MAX_OPEN = 1024;                // blocks in a row that do not close (k_rx_mark carries the walk through them one by one)
 constexpr uint32_t RX_FAIL = 0xFFFFFFFFu, RX_ABORT = 0xFFFFFFFEu, RX_NOK = 0xFFFFFFFFu;
+constexpr uint32_t RX_BAD_CAP = 1024;            // blocks with a position the matcher gave up on, per call: beyond that the whole batch goes to the host
 enum : uint32_t { RXS_REACH = 1, RXS_STEPS = 2, RXS_DEPTH = 4 };
 enum : uint32_t { RXO_CHAR = 0, RXO_CHAR_FOLD, RXO_CLASS, RXO_ANY, RXO_SPLIT, RXO_JMP, RXO_MATCH, RXO_LOOK, RXO_NLOOK, RXO_REP1, RXO_ATOMIC, RXO_ASSERT };
 enum : uint32_t { RXA_BOL = 0, RXA_EOL, RXA_EOT, RXA_WORDB, RXA_NWORDB };
@@ -67,6 +71,11 @@ struct RxArgs {
     uint32_t* status;                                                  // out: RXS_* bits, OR-ed
     uint32_t* status_host;                                             // null, or the status word's copy in pinned host memory: k_rx_mark leaves the word there (no copy back)
     uint32_t* status_next;                                             // null, or a word k_rx_mark clears for the NEXT batch (the contexts rotate through a few status words: no fill per batch)
+    // per-document fallback: bad_hi[k] / bad_lo[k] = gen << 8 | (last / 255 - first) offset of a position of block k that was given up on
+    // (first setter of a call appends k to bad_list, device memory: [0] count, [1 ..] blocks); k_rx_mark copies the list to bad_host
+    // (pinned: [0] count, then per block two words: the block, first << 8 | last) and re-arms the count
+    uint32_t* bad_hi; uint32_t* bad_lo; uint32_t* bad_list; uint32_t* bad_host;
+    uint32_t bad_sets_status;                                          // spl_split_device: a listed block also sets the status word (the caller has nothing else)
     // SPL_WITH_SPECIAL: the bitmaps k_mark_docs / k_special_scan have left (null: none) -- text starts (documents AND behind every literal),
     // tokens so far (= where a literal starts); sp_words words each.  A literal is a stretch of dropped bytes with a start bit at either end
     // (encode_with_special runs the pattern over the stretches between the literals, tokenizer.rs:842-874): here a position whose hop is
@@ -221,10 +230,10 @@ __device__ __forceinline__ uint32_t rx_vm(RxCtx& c, uint32_t* stk, const RxArgs&
     for (;;) {
         uint32_t fin = NOTYET, r = RX_FAIL;
         bool ended = false;
-#define RX_PUSH(A, B) do { if (sp == RX_DEPTH) { atomicOr(a.status, RXS_DEPTH); fin = RX_ABORT; break; } stk[(2 * sp) * RXT] = (A); stk[(2 * sp + 1) * RXT] = (B); sp++; } while (0)
+#define RX_PUSH(A, B) do { if (sp == RX_DEPTH) { fin = RX_ABORT; break; } stk[(2 * sp) * RXT] = (A); stk[(2 * sp + 1) * RXT] = (B); sp++; } while (0)
         if (run) do {                                       // ONE instruction (break: done with it; run == false: this way has failed)
-            if (++steps > RX_STEPS) { atomicOr(a.status, RXS_STEPS); fin = RX_ABORT; break; }
-            if (trunc && pos + 8 > lim) { atomicOr(a.status, RXS_REACH); fin = RX_ABORT; break; }
+            if (++steps > RX_STEPS) { fin = RX_ABORT; break; }                 // (the caller marks the position's block: rx_bad)
+            if (trunc && pos + 8 > lim) { fin = RX_ABORT; break; }
             const uint4 in = c.inst(pc);
             const uint32_t op = in.x, x = in.y, y = in.z, f = in.w;
             if (op == RXO_MATCH) { ended = true; r = pos; run = false; break; }
@@ -301,7 +310,7 @@ __device__ __forceinline__ uint32_t rx_vm(RxCtx& c, uint32_t* stk, const RxArgs&
                     }
                     k++;
                 }
-                if (far) { atomicOr(a.status, RXS_REACH); fin = RX_ABORT; break; }
+                if (far) { fin = RX_ABORT; break; }
                 steps += k;
                 if (k < x) { run = false; break; }
                 if (k > x && f != 1u) {                      // (k - 1 characters next time: stored as (k - 1) + 1; the run's start and end)
@@ -486,6 +495,18 @@ __device__ __forceinline__ uint32_t rx_simple_alt(const RxCtx& c, const uint32_t
 // alternative 0, then those it did not match try alternative 1, ... (leftmost-first: the first alternative that matches is the match).
 // A simple alternative is evaluated at full width; another one runs the matcher program from its first instruction for the lanes
 // that can start it (its first-character filter) -- on GPT-2's pattern that is `\s+(?!\S)` at blanks that no earlier alternative took.
+// the matcher gave up at position p: its 256-byte block goes on the list once per call, with the first and the last such position of the
+// block (bad_lo / bad_hi: the call's generation above an 8-bit offset, kept up by atomicMax -- entries of earlier calls are smaller, so
+// nothing is ever cleared); the host splits the documents that overlap [first, last] of a listed block itself.  A list that overflows
+// turns into the whole-batch status.
+__device__ __forceinline__ void rx_bad(const RxArgs& a, uint32_t p) {
+    const uint32_t blk = p >> 8, o = p & 255u;
+    atomicMax(&a.bad_lo[blk], (a.gen << 8) | (255u - o));
+    if ((atomicMax(&a.bad_hi[blk], (a.gen << 8) | o) >> 8) == a.gen) return;          // (already listed in this call)
+    const uint32_t i = atomicAdd(&a.bad_list[0], 1u);
+    if (i < RX_BAD_CAP) a.bad_list[1 + i] = blk;
+    else atomicOr(a.status, RXS_STEPS);
+}
 __device__ __forceinline__ void rx_attempts(RxCtx& c, uint32_t* stk, const RxBlock& bk, const RxArgs& a, uint32_t pl) {
     constexpr int DSW = (RX_BACK + RXB + RX_REACH) / 32 + 2;
     const uint32_t* const cs = c.bm + RX_MAX_RUNSETS * RX_BMW;
@@ -507,8 +528,9 @@ __device__ __forceinline__ void rx_attempts(RxCtx& c, uint32_t* stk, const RxBlo
     const uint32_t p = bk.start + pl;
     if (p >= bk.B) bk.s_j[pl] = (uint16_t)(RXJ_EXIT | 0u);
     const uint32_t wi = pl + RX_BACK;
-    // (something has been given up on already -- the batch will be split on the host --: no more attempts.  This bounds what a
-    //  pattern that backtracks without end can cost: the attempts in flight run into RX_STEPS, everything behind them is skipped)
+    // (the WHOLE batch has been given up on already -- more than RX_BAD_CAP blocks hold a position the matcher gave up on --: no more
+    //  attempts.  This bounds what a pattern that backtracks without end can cost: RX_BAD_CAP blocks' worth of attempts run into RX_STEPS,
+    //  everything behind them is skipped)
     const bool given_up = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
     // (a byte inside a character: the walk never stands there, its hop is "one on")
     const bool lit = p < bk.B && bk.s_ls && ((bk.s_ls[wi >> 5] >> (wi & 31)) & 1u) != 0u;       // a special-token literal starts here
@@ -546,7 +568,7 @@ __device__ __forceinline__ void rx_attempts(RxCtx& c, uint32_t* stk, const RxBlo
         uint32_t r = RX_FAIL, why = 0;
         if (alt.y & 1u) r = rx_simple_alt(c, c.img + (alt.w >> 16), alt.w & 0xFFFFu, alt.y >> 8, p, at.n, can, why);
         else if (can) r = rx_vm(c, stk, a, at, alt.z, steps);
-        if (can && r == RX_ABORT) { if (why) atomicOr(a.status, why); act = false; }
+        if (can && r == RX_ABORT) { rx_bad(a, p); act = false; }
         else if (can && r != RX_FAIL && r > p) e = r;
         else if (can && r != RX_FAIL) act = false;         // (an empty match: find_iter skips the character, as behind no match)
     }
@@ -556,7 +578,7 @@ __device__ __forceinline__ void rx_attempts(RxCtx& c, uint32_t* stk, const RxBlo
             nxv = (next_start(wi, bk.B) - p) | 0x8000u;
         } else if (e != RX_FAIL) {
             uint32_t d = e - p;
-            if (d > (uint32_t)RX_REACH - 8u) { atomicOr(a.status, RXS_REACH); d = RX_REACH - 8; }
+            if (d > (uint32_t)RX_REACH - 8u) { rx_bad(a, p); d = RX_REACH - 8; }
             nxv = d;
             // a hop over whole blocks: they may not be touched by the walk at all
             for (uint32_t k = (p >> 8) + 1; (k + 1) * (uint32_t)RXB <= p + d; k++) a.bskip[k] = a.gen;
@@ -768,6 +790,20 @@ __global__ __launch_bounds__(RXB) void k_rx_mark(RxArgs a) {
     const uint32_t B = a.n_bytes;
     const uint32_t b = blockIdx.x, start = b * (uint32_t)RXB;
     const uint32_t p = start + (uint32_t)tid;
+    if (b == 0 && a.bad_host) {
+        // the blocks the matcher gave up on, for the host (k_rx_match is done: the list is final); the count re-armed for the next call
+        const uint32_t nb = a.bad_list[0] < RX_BAD_CAP ? a.bad_list[0] : RX_BAD_CAP;
+        for (uint32_t i = (uint32_t)tid; i < nb; i += RXB) {
+            const uint32_t k = a.bad_list[1 + i];
+            a.bad_host[1 + 2 * i] = k;
+            a.bad_host[2 + 2 * i] = ((255u - (a.bad_lo[k] & 255u)) << 8) | (a.bad_hi[k] & 255u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            if (a.bad_sets_status && a.bad_list[0]) atomicOr(a.status, RXS_REACH);
+            a.bad_host[0] = a.bad_list[0]; a.bad_list[0] = 0u;
+        }
+    } else if (b == 0 && tid == 0) a.bad_list[0] = 0u;
     if (b == 0 && tid == 1) {
         if (a.status_next) *a.status_next = 0u;
         // (k_rx_match is done: what it gave up on is final; what THIS kernel gives up on goes to the host word directly, below)
@@ -853,6 +889,27 @@ __global__ __launch_bounds__(RXB) void k_rx_mark(RxArgs a) {
         put(a.starts, w0 + 1, (uint32_t)(sm >> 32));
     }
     if (tid < RXB / 32) put(a.gaps, wb0 + (uint32_t)tid, s_gb[tid]);
+}
+
+// The stretches of the two bitmaps that belong to documents split on the host (per-document fallback): patch = per document four words
+// {first bitmap word, words, mask of the first word, mask of the last word} followed by `words` start words and `words` gap words; one
+// workgroup per document.  Bits outside the document's own byte range (the masks) keep what the device splitter left.
+__global__ __launch_bounds__(256) void k_rx_patch(uint32_t* starts, uint32_t* gaps, const uint32_t* patch, const uint32_t* at) {
+    const uint32_t* h = patch + at[blockIdx.x];
+    const uint32_t w0 = h[0], n = h[1], m_first = h[2], m_last = h[3];
+    const uint32_t* ps = h + 4;
+    const uint32_t* pg = ps + n;
+    for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
+        uint32_t m = 0xFFFFFFFFu;
+        if (k == 0) m &= m_first;
+        if (k == n - 1u) m &= m_last;
+        if (m == 0xFFFFFFFFu) { starts[w0 + k] = ps[k]; gaps[w0 + k] = pg[k]; }
+        else {
+            // an edge word: the neighbouring document may be patched by another workgroup at the same time (disjoint masks: atomics, in any order)
+            atomicAnd(&starts[w0 + k], ~m); atomicOr(&starts[w0 + k], ps[k] & m);
+            atomicAnd(&gaps[w0 + k], ~m); atomicOr(&gaps[w0 + k], pg[k] & m);
+        }
+    }
 }
 
 }  // namespace spl

@@ -206,6 +206,74 @@ def test_encode_batch_uses_the_device_splitter_and_falls_back_by_itself():
     assert L.spl_device_split_fallbacks(t.handle) == 1
 
 
+def test_one_long_match_costs_one_document_not_the_batch():
+    """VERDICT r04 #3a: a C3-sized batch (40 MB, five pipeline chunks) in which ONE document holds a 64 KB run of '=' and another an 8 KB
+    base64 line.  The device splitter gives up at the positions of the run (a match longer than its reach); only the documents those
+    positions lie in are split on the host cores, their bits patched, every other document keeps the device split: the fallback counter
+    counts DOCUMENTS (<= 2), the ids equal the host splitter's, and the call takes about what the batch without the two takes.  Also
+    through the one-chunk path (optimistic run + one more tile pass) and the device-text entry point."""
+    import base64
+    import time
+    import torch
+    from splintr_amd import Tokenizer, corpus, _ffi
+    from splintr_amd.device import DeviceBatch
+    L = _ffi.lib()
+    t = Tokenizer.from_bytes(_blob("o200k_base"), GPT2_PATTERN)
+    h = Tokenizer.from_bytes(_blob("o200k_base"), GPT2_PATTERN)
+    assert L.spl_set_option(h.handle, b"device_split", 0) == 0
+    docs = corpus.c3(10000)
+    b64 = base64.b64encode(bytes(range(256)) * 24).decode()
+    assert len(b64) == 8192
+    bad = list(docs)
+    bad[1234] = bad[1234][:700] + "\n" + "=" * 65536 + "\n" + bad[1234][700:]
+    bad[7777] = bad[7777][:1500] + " " + b64 + " " + bad[7777][1500:]
+    want = h.encode_batch_csr(bad)
+
+    def timed(tok, texts, n=5):
+        tok.encode_batch_csr(texts)
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            r = tok.encode_batch_csr(texts)
+            ts.append(time.perf_counter() - t0)
+        return r, sorted(ts)[n // 2]
+    _, t_clean = timed(t, docs)
+    assert L.spl_device_split_fallbacks(t.handle) == 0
+    before = L.spl_device_split_fallbacks(t.handle)
+    got, t_bad = timed(t, bad)
+    per_call = (L.spl_device_split_fallbacks(t.handle) - before) / 6
+    assert np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0])
+    assert 1 <= per_call <= 2, per_call                      # documents, not batches; the base64 line is no long MATCH under this pattern
+    print(f"40 MB batch: {t_clean * 1e3:.2f} ms without, {t_bad * 1e3:.2f} ms with the two documents ({t_bad / t_clean:.3f} x)")
+    assert t_bad <= 1.25 * t_clean, (t_clean, t_bad)
+    # one chunk (the optimistic path): a 1 MB batch with the run in it
+    small = docs[:250]
+    small[100] = small[100][:300] + "=" * 3000 + small[100][300:]
+    before = L.spl_device_split_fallbacks(t.handle)
+    a, b = t.encode_batch_csr(small), h.encode_batch_csr(small)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0]) and L.spl_device_split_fallbacks(t.handle) - before == 1
+    # the device-text entry point: the documents' text comes to the host, nothing else
+    dev = torch.device("cuda", 0)
+    db = DeviceBatch(small, dev)
+    db.ids.fill_(-1)
+    before = L.spl_device_split_fallbacks(t.handle)
+    rc = L.spl_encode_batch_device(t.handle, db.text.data_ptr(), db.n_bytes, db.doc_off.data_ptr(), db.n_docs, 0, db.ids.data_ptr(), db.ids.numel(),
+                                   db.out_off.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, _ffi.last_error()
+    torch.cuda.synchronize()
+    off = db.out_off.cpu().numpy().astype(np.uint64)
+    assert np.array_equal(off, b[1]) and np.array_equal(db.ids[:int(off[-1])].cpu().numpy().view(np.uint32), b[0])
+    assert L.spl_device_split_fallbacks(t.handle) - before == 1
+    # ... and with special tokens in the documents around (the literals come from the GPU's scan, the host splits around them)
+    sp = {"<|endoftext|>": 200100}
+    ts_, hs_ = Tokenizer.from_bytes(_blob("o200k_base"), GPT2_PATTERN, sp), Tokenizer.from_bytes(_blob("o200k_base"), GPT2_PATTERN, sp)
+    assert L.spl_set_option(hs_.handle, b"device_split", 0) == 0
+    mixed = [x + "<|endoftext|>" for x in small]
+    mixed[100] = mixed[100][:200] + "<|endoftext|>" + mixed[100][200:]
+    a, b = ts_.encode_batch_csr(mixed, with_special=True), hs_.encode_batch_csr(mixed, with_special=True)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0]) and L.spl_device_split_fallbacks(ts_.handle) == 1
+
+
 def test_a_pattern_that_backtracks_without_end_is_given_up_quickly_and_reported_by_the_host():
     """(?:a|aa)+b over a long run of a's: every attempt runs into the device matcher's step limit; the first one to do so stops the rest, and
     the host splitter (its own budget: 64 n + 10^6 steps per attempt) raises the error the reference's engines would turn into a timeout"""
