@@ -113,7 +113,9 @@ uint32_t spl_n_devices(const spl_tokenizer* t);
  * the pinned result instead of copying them back), "device_split" (0/1, default 1: a custom split pattern's
  * split runs on the GPU, see spl_split_device; 0 keeps it on the host cores), "small_path" (0/1, default 1: batches of at most 4 KB take
  * the latency path, see spl_small_path_calls), "direct_read" (0/1, default 1: a batch of ONE pipeline chunk whose text comes from
- * spl_host_alloc is not copied to the device -- the tile kernel reads it, and the offsets, where they lie; 93 -> 83 us per 1 MB call). */
+ * spl_host_alloc is not copied to the device -- the tile kernel reads it, and the offsets, where they lie; 93 -> 83 us per 1 MB call),
+ * "sdma_d2h" (0/1, default 1: the ids of a pipeline chunk leave through hsa_amd_memory_async_copy -- an SDMA engine -- instead of
+ * hipMemcpyAsync, which runs as a shader copy beside the next chunk's tile kernel; hipMemcpyAsync where the HSA runtime cannot be bound). */
 int spl_set_option(spl_tokenizer* t, const char* name, int64_t value);
 
 /* One entry of the special_tokens map (src/core/tokenizer.rs:304, 429-434).  Call before the first

@@ -17,6 +17,10 @@
 #include <unordered_map>
 #include <vector>
 
+#include <dlfcn.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+
 #include "../../include/splintr_hip.h"
 #include "spl_kernels.hip"
 #include "spl_tables.h"
@@ -139,6 +143,67 @@ struct LooseBuffers {
 };
 LooseBuffers& loose() { static LooseBuffers* l = new LooseBuffers(); return *l; }   // (never destroyed: results may outlive every handle)
 
+// The DMA engines driven directly (VERDICT r04 #5a): hipMemcpyAsync device -> pinned host runs as a SHADER copy on this stack
+// (__amd_rocclr_copyBuffer: 7 % of the GPU time of the C3 pipeline, and it slows the next chunk's tile kernel while it runs);
+// hsa_amd_memory_async_copy hands the same copy to an SDMA engine.  libhsa-runtime64 is the runtime HIP itself sits on (already in
+// the process); its entry points are bound with dlsym so that the library gains no link dependency.  Option "sdma_d2h".
+struct HsaDma {
+    bool ok = false;
+    std::string err;
+    hsa_agent_t cpu{};
+    std::vector<hsa_agent_t> gpus;
+    decltype(&hsa_init) Init = nullptr;
+    decltype(&hsa_iterate_agents) IterateAgents = nullptr;
+    decltype(&hsa_agent_get_info) AgentGetInfo = nullptr;
+    decltype(&hsa_signal_create) SignalCreate = nullptr;
+    decltype(&hsa_signal_destroy) SignalDestroy = nullptr;
+    decltype(&hsa_signal_store_relaxed) SignalStore = nullptr;
+    decltype(&hsa_signal_wait_scacquire) SignalWait = nullptr;
+    decltype(&hsa_amd_memory_async_copy) AsyncCopy = nullptr;
+    static hsa_status_t on_agent(hsa_agent_t a, void* self) {
+        HsaDma* h = (HsaDma*)self;
+        hsa_device_type_t ty;
+        if (h->AgentGetInfo(a, HSA_AGENT_INFO_DEVICE, &ty) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+        if (ty == HSA_DEVICE_TYPE_GPU) h->gpus.push_back(a);
+        else if (ty == HSA_DEVICE_TYPE_CPU && h->cpu.handle == 0) h->cpu = a;
+        return HSA_STATUS_SUCCESS;
+    }
+    void load() {
+        void* lib = dlopen("libhsa-runtime64.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) { const char* e = dlerror(); err = std::string("libhsa-runtime64 not found: ") + (e ? e : ""); return; }
+        auto sym = [&](const char* n) { void* p = dlsym(lib, n); if (!p && err.empty()) err = std::string("libhsa-runtime64 lacks ") + n; return p; };
+        Init = (decltype(Init))sym("hsa_init");
+        IterateAgents = (decltype(IterateAgents))sym("hsa_iterate_agents");
+        AgentGetInfo = (decltype(AgentGetInfo))sym("hsa_agent_get_info");
+        SignalCreate = (decltype(SignalCreate))sym("hsa_signal_create");
+        SignalDestroy = (decltype(SignalDestroy))sym("hsa_signal_destroy");
+        SignalStore = (decltype(SignalStore))sym("hsa_signal_store_relaxed");
+        SignalWait = (decltype(SignalWait))sym("hsa_signal_wait_scacquire");
+        AsyncCopy = (decltype(AsyncCopy))sym("hsa_amd_memory_async_copy");
+        if (!err.empty()) return;
+        if (Init() != HSA_STATUS_SUCCESS) { err = "hsa_init failed"; return; }          // (reference counted: HIP has initialised it already)
+        if (IterateAgents(&HsaDma::on_agent, this) != HSA_STATUS_SUCCESS || gpus.empty() || cpu.handle == 0) { err = "no HSA agents"; return; }
+        ok = true;
+    }
+};
+HsaDma& hsa_dma() { static HsaDma* h = [] { auto* p = new HsaDma(); p->load(); return p; }(); return *h; }
+// the HSA agent of a HIP device: matched by PCI bus / device / function (HIP_VISIBLE_DEVICES may reorder or hide devices); false if none
+bool hsa_agent_of(int hip_device, hsa_agent_t* out) {
+    HsaDma& H = hsa_dma();
+    if (!H.ok) return false;
+    int bus = -1, dev = -1, dom = 0;
+    if (hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, hip_device) != hipSuccess ||
+        hipDeviceGetAttribute(&dev, hipDeviceAttributePciDeviceId, hip_device) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, hip_device) != hipSuccess) { (void)hipGetLastError(); dom = 0; }
+    for (hsa_agent_t a : H.gpus) {
+        uint32_t bdf = 0, adom = 0;
+        if (H.AgentGetInfo(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf) != HSA_STATUS_SUCCESS) continue;
+        (void)H.AgentGetInfo(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &adom);
+        if ((int)((bdf >> 8) & 0xFFu) == bus && (int)((bdf >> 3) & 0x1Fu) == dev && (int)adom == dom) { *out = a; return true; }
+    }
+    return false;
+}
+
 constexpr int NSLOT = 3;                      // staging slots of the host pipeline per GPU
 
 // SPL_TRACE=1: progress of the host pipeline on stderr (development aid)
@@ -193,6 +258,8 @@ struct Ctx {
     uint8_t* h_small = nullptr; uint8_t* dh_small = nullptr;       // pinned: [text 4096 + 64 | offsets 8 * 257 | completion word], and its device pointer
     uint32_t small_calls = 0;
     const void* dp_host[2] = {nullptr, nullptr}; void* dp_dev[2] = {nullptr, nullptr};   // device pointers of the last two pinned result buffers
+    const uint8_t* solo_text = nullptr; const uint64_t* solo_off = nullptr;
+    hsa_agent_t hsa_agent{}; int hsa_state = 0;    // this device's HSA agent for the SDMA copies (0 not looked for yet, 1 found, 2 none: hipMemcpyAsync)
     bool bitmap_dirty = true;
     // host pipeline (spl_encode_batch / spl_decode_batch)
     hipStream_t s_cmp = nullptr, s_h2d = nullptr, s_d2h = nullptr;
@@ -300,6 +367,7 @@ struct spl_tokenizer {
     int subdoc = 1;                           // cut documents at context-free boundaries to balance the GPUs
     int direct_write = 1;                     // one-chunk batches: the last kernel writes the ids straight into the pinned result
     int small_path = 1;                       // batches of up to 4 KB take the latency path (encode_small)
+    int sdma_d2h = 1;                         // pipeline chunks: their ids leave through hsa_amd_memory_async_copy (an SDMA engine) instead of hipMemcpyAsync
     int direct_read = 1;                      // one-chunk batches from pinned memory: the tile kernel reads text and offsets where they lie (no H2D copy)
     uint64_t small_calls = 0;                 // ... and how many did (spl_small_path_calls)
 };
@@ -1248,6 +1316,7 @@ int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t
             HIP_TRY(hipStreamWaitEvent(c->s_cmp, c->ev_h2d[sl], 0));
         }
         uint64_t* oo = c->d_oo + ch.oo_at;
+        c->solo_text = text_arg; c->solo_off = off_arg;          // (a one-chunk batch: where its tile kernel read text and offsets -- the per-document redo reads them again)
         ExtIn ext;
         if (tk->regex) {
             // custom pattern: the chunk's boundaries from the host splitter (this lane's producer thread plus helpers,
@@ -1483,7 +1552,7 @@ int encode_host(spl_tokenizer* tk, const uint8_t* utf8, const uint64_t* doc_off,
             void* optr = nullptr;
             HIP_TRY(hipHostGetDevicePointer(&optr, r->off, 0));
             c->off_host = (uint64_t*)optr; c->off_host_written = false;
-            const bool mapped = tk->direct_read && src_pinned && ((uintptr_t)(utf8 + ch.lo) & 15) == 0 && !tk->regex;
+            const bool mapped = tk->direct_read && src_pinned && ((uintptr_t)(utf8 + ch.lo) & 15) == 0 && (!tk->regex || !ln.host_split);
             // (completion by k_tile_out's word in pinned memory instead of the stream synchronisation -- what the latency path does for a handful of
             //  tiles -- was measured here too: 150 us against 93 for the 1 MB batch; 1250 workgroups each pay a system-scope fence.  Not adopted.)
             int rc = lane_submit(tk, ln, utf8, doc_off, flags, src_pinned, true, (uint32_t*)dptr, mapped);
@@ -1507,7 +1576,7 @@ int encode_host(spl_tokenizer* tk, const uint8_t* utf8, const uint64_t* doc_off,
                 ext.d_starts = c->d_ext[0]; ext.d_gaps = c->d_ext[0] + bw;
                 ext.d_status = c->d_rx_status + c->rx_slot; ext.d_status_host = c->dh_rx_status;
                 c->off_host = (uint64_t*)optr; c->off_host_written = false;
-                rc = launch_all(tk, c, c->d_text[0], nb, c->d_off[0], nd, flags, (uint32_t*)dptr, nb + 16, c->d_oo + ch.oo_at, c->s_cmp, nullptr, &ext, 2);
+                rc = launch_all(tk, c, c->solo_text, nb, c->solo_off, nd, flags, (uint32_t*)dptr, nb + 16, c->d_oo + ch.oo_at, c->s_cmp, nullptr, &ext, 2);
                 c->off_host = nullptr;
                 if (rc) return rc;
                 HIP_TRY(hipStreamSynchronize(c->s_cmp));
@@ -1573,6 +1642,8 @@ int encode_host(spl_tokenizer* tk, const uint8_t* utf8, const uint64_t* doc_off,
     int rc_all = SPL_OK;
     std::string err_all;
     uint64_t base = 0;
+    std::vector<hsa_signal_t> dma_sigs;
+    struct SigGuard { std::vector<hsa_signal_t>& v; ~SigGuard() { for (hsa_signal_t sg : v) { hsa_dma().SignalWait(sg, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED); hsa_dma().SignalDestroy(sg); } } } sig_guard{dma_sigs};
     auto consume = [&]() -> int {
         for (size_t l = 0; l < nl; l++) {
             Lane& ln = lanes[l];
@@ -1600,6 +1671,18 @@ int encode_host(spl_tokenizer* tk, const uint8_t* utf8, const uint64_t* doc_off,
                     tk->pool->put(r->ids, r->ids_cap);
                     r->ids = nids; r->ids_cap = ncap;
                 }
+                if (T && tk->sdma_d2h && c->hsa_state == 0) c->hsa_state = hsa_agent_of(c->device, &c->hsa_agent) ? 1 : 2;
+                if (T && tk->sdma_d2h && c->hsa_state == 1) {
+                    // (the chunk's kernels are through -- the event above --, so the copy has no dependency; its signal is waited for at the end)
+                    HsaDma& H = hsa_dma();
+                    hsa_signal_t sg;
+                    if (H.SignalCreate(1, 0, nullptr, &sg) != HSA_STATUS_SUCCESS) return fail(SPL_EDEVICE, "hsa_signal_create failed");
+                    if (H.AsyncCopy(r->ids + base, H.cpu, c->d_ids + (ch.lo - ln.lo), c->hsa_agent, T * 4, 0, nullptr, sg) != HSA_STATUS_SUCCESS) {
+                        H.SignalDestroy(sg);
+                        return fail(SPL_EDEVICE, "hsa_amd_memory_async_copy failed");
+                    }
+                    dma_sigs.push_back(sg);
+                } else
                 if (T) HIP_TRY(hipMemcpyAsync(r->ids + base, c->d_ids + (ch.lo - ln.lo), T * 4, hipMemcpyDeviceToHost, c->s_d2h));
                 const uint64_t skip = ch.cont ? 1 : 0;
                 if (nd > skip) {
@@ -1611,6 +1694,7 @@ int encode_host(spl_tokenizer* tk, const uint8_t* utf8, const uint64_t* doc_off,
             }
         }
         for (auto& ln : lanes) { HIP_TRY(hipSetDevice(ln.c->device)); HIP_TRY(hipStreamSynchronize(ln.c->s_d2h)); }
+        for (hsa_signal_t sg : dma_sigs) hsa_dma().SignalWait(sg, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED);
         return SPL_OK;
     };
     rc_all = consume();
@@ -1801,6 +1885,7 @@ int spl_set_option(spl_tokenizer* t, const char* name, int64_t value) {
     else if (k == "device_split") t->rx_device = value != 0;
     else if (k == "small_path") t->small_path = value != 0;
     else if (k == "direct_read") t->direct_read = value != 0;
+    else if (k == "sdma_d2h") t->sdma_d2h = value != 0;        // (where the HSA runtime or the device's agent cannot be found: hipMemcpyAsync, silently)
     else return fail(SPL_EINVAL, "spl_set_option: unknown option or bad value: " + k);
     return SPL_OK;
 }

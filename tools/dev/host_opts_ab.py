@@ -12,7 +12,7 @@ for vocab, gen, n in (("cl100k_base", "c2", 1000), ("cl100k_base", "c2", 3000), 
     blob = b"".join(bs); nb = len(blob)
     p = L.spl_host_alloc(nb + 64); ctypes.memmove(p, blob, nb)
     toks = {}
-    for name, opts in (("default", {}), ("direct_read", {"direct_read": 1}), ("spin_done", {"spin_done": 1}), ("both", {"direct_read": 1, "spin_done": 1})):
+    for name, opts in (("default", {}), ("no_direct_read", {"direct_read": 0})):
         t = Tokenizer.from_pretrained(vocab)
         for k, v in opts.items(): assert L.spl_set_option(t.handle, k.encode(), v) == 0
         toks[name] = t
