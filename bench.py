@@ -218,27 +218,33 @@ def main():
         # figures go into `dist.calibration`.  (xGMI is point to point: which form RCCL drives better depends on the message size.)
         cal = {}
         gv_max_docs, gv_max_tokens = int(mx[1].item()), int(int(mx[0].item()) * 1.02) + 64
-        cal_steps = 64 if not rehearsal else 16
-        for depth_c in ((8, 32) if not rehearsal else (4, 8)):
-            for form in ("allgather", "p2p"):
-                g_ = GatherV(tok, dev, max_docs=gv_max_docs, max_tokens=gv_max_tokens, comm=comm, depth=depth_c, collective=form)
+        # calibration regions have the timed region's shape -- K steps, then the last bucket's exchange exposed -- because the best depth
+        # depends on K: at the driver's K = 20 a bucket of 32 never fills and its one exchange is all exposed
+        cal_regions = max(3, -(-64 // max(1, args.steps))) if not rehearsal else 2
+        cal_steps = cal_regions * args.steps
+        for depth_c in ((4, 8, 32) if not rehearsal else (4, 8)):
+            for form in ("allgather", "p2p", "allgather+pack24"):
+                g_ = GatherV(tok, dev, max_docs=gv_max_docs, max_tokens=gv_max_tokens, comm=comm, depth=depth_c, collective=form.split("+")[0],
+                             pack24=form.endswith("pack24"))
                 for j in range(depth_c):
                     g_.encode_and_submit(batches[j % N_ROT])
                 g_.finish()
                 dist.barrier()
                 torch.cuda.synchronize()
                 c0 = time.perf_counter()
-                for j in range(cal_steps):
-                    g_.encode_and_submit(batches[j % N_ROT])
-                g_.finish()
-                torch.cuda.synchronize()
+                for r_ in range(cal_regions):
+                    for j in range(args.steps):
+                        g_.encode_and_submit(batches[j % N_ROT])
+                    g_.finish()
+                    torch.cuda.synchronize()
                 ct = torch.tensor([time.perf_counter() - c0], dtype=torch.float64, device=dev)
                 dist.all_reduce(ct, op=dist.ReduceOp.MAX)
                 cal[(depth_c, form)] = float(ct.item()) / cal_steps * 1e3
                 del g_
                 torch.cuda.empty_cache()
         (best_depth, best_form), _ = min(cal.items(), key=lambda kv: kv[1])
-        gv = GatherV(tok, dev, max_docs=gv_max_docs, max_tokens=gv_max_tokens, comm=comm, depth=best_depth, collective=best_form)
+        gv = GatherV(tok, dev, max_docs=gv_max_docs, max_tokens=gv_max_tokens, comm=comm, depth=best_depth, collective=best_form.split("+")[0],
+                     pack24=best_form.endswith("pack24"))
         got = []
         gv.on_bucket = lambda res: got.extend((i.clone(), o.clone()) for i, o in res)
         for _ in range(N_ROT):
@@ -336,11 +342,12 @@ def main():
                                   "encode_only_ms": [round(float(x), 5) for x in allm[:, 1]],
                                   "exchange_stream_ms_per_step": [round(float(x), 5) for x in allm[:, 2]]},
                      "exposed_exchange_ms": round(float(allm[:, 0].max() - allm[:, 1].max()), 5),
-                     "bucket_depth": gv.depth, "collective": gv.collective, "buckets_timed": ex_buckets,
+                     "bucket_depth": gv.depth, "collective": gv.collective, "pack24": gv.pack24, "buckets_timed": ex_buckets,
                      "calibration": {"ms_per_step": {f"depth{d_}_{f_}": round(v_, 5) for (d_, f_), v_ in sorted(cal.items())},
-                                     "chosen": f"depth{gv.depth}_{gv.collective}", "steps_each": cal_steps,
-                                     "note": "untimed, before the timed region: the same steps with every bucket depth x collective form (ncclAllGather of the "
-                                             "slabs / grouped ncclSend+ncclRecv of the same slabs); max over ranks; the fastest runs the timed region"},
+                                     "chosen": f"depth{gv.depth}_{gv.collective}{'+pack24' if gv.pack24 else ''}", "steps_each": cal_steps, "regions_each": cal_regions,
+                                     "note": "untimed, before the timed region: regions of the same K steps (+ the last bucket's exchange) with every bucket depth x collective form (ncclAllGather of the "
+                                             "slabs / grouped ncclSend+ncclRecv of the same slabs / ncclAllGather of slabs whose ids are packed three bytes each); "
+                                             "max over ranks; the fastest runs the timed region"},
                      "slab_bytes_sent_per_batch": sent // gv.depth, "bytes_received_per_batch": recvd // gv.depth,
                      "ids_bytes_per_batch_4T": round(4 * tok_b), "slab_over_4T": round(sent / gv.depth / (4 * tok_b), 4),
                      "note": "per batch and rank: one slab of cap_words u32 (T, N, local offsets, ids; sized 1.02 x the largest shard) out, "
@@ -428,7 +435,7 @@ def main():
         b_alg = (bytes_rot + 4 * sum(n_tokens) + 16 * sum(b.n_docs + 1 for b in batches)) / N_ROT
         achieved = b_alg / (kernels[dom] * 1e-6) / 1e9
         traffic, tsrc = None, None
-        for cand in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "hbm_traffic.json"):
+        for cand in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "hbm_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", cand)
             if os.path.exists(tpath):
                 try:
@@ -445,7 +452,7 @@ def main():
                     "all_kernels_us": kernels}
         # the roofline that binds this kernel: VALU issue.  Counters come from rocprofv3 --pmc (not
         # available inside a plain run): the committed pass over this very command.
-        vname = next((n for n in ("r04_pmc_sq.json", "r03_pmc_sq.json", "r02_pmc_sq.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
+        vname = next((n for n in ("r05_pmc_sq.json", "r04_pmc_sq.json", "r03_pmc_sq.json", "r02_pmc_sq.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
         vpath = os.path.join(ROOT, "profiles", vname) if vname else ""
         if vname:
             try:
@@ -780,7 +787,8 @@ def run_strong(vocab, texts, steps, rank, world, local_rank, dev, use_dist, nchk
 
         def make(form):
             return WaveGather(tok, dev, comm, K, max_docs=int(mx[1].item()), max_tokens=int(int(mx[0].item()) * 1.02) + 64,
-                              total_tokens_cap=int(tot[0].item()) + 64, total_docs_cap=int(tot[1].item()), collective=form)
+                              total_tokens_cap=int(tot[0].item()) + 64, total_docs_cap=int(tot[1].item()), collective=form.split("+")[0],
+                              pack24=form.endswith("pack24"))
 
         def step_with(g_):
             g_.begin()
@@ -788,18 +796,19 @@ def run_strong(vocab, texts, steps, rank, world, local_rank, dev, use_dist, nchk
                 g_.encode_and_submit(b)
             return g_.finish()
         # calibration of the collective form (untimed): ncclAllGather of the wave's slabs against grouped send / recv
-        for form in ("allgather", "p2p"):
+        for form in ("allgather", "p2p", "allgather+pack24"):
             g_ = make(form)
-            step_with(g_)
+            for _ in range(2):
+                step_with(g_)
             torch.cuda.synchronize()
             dist.barrier()
             c0 = time.perf_counter()
-            for _ in range(2):
+            for _ in range(steps):                                   # as the timed region: `steps` steps back to back
                 step_with(g_)
             torch.cuda.synchronize()
             ct = torch.tensor([time.perf_counter() - c0], dtype=torch.float64, device=dev)
             dist.all_reduce(ct, op=dist.ReduceOp.MAX)
-            cal[form] = float(ct.item()) / 2 * 1e3
+            cal[form] = float(ct.item()) / steps * 1e3
             del g_
             torch.cuda.empty_cache()
         wg = make(min(cal, key=cal.get))
@@ -830,15 +839,22 @@ def run_strong(vocab, texts, steps, rank, world, local_rank, dev, use_dist, nchk
             d0_ = int(allc[:, :k, 1].sum() + allc[:rank, k, 1].sum())
             assert np.array_equal(g_ids[t0_:t0_ + int(off[-1])], ids), (rank, k)
             assert np.array_equal((g_off[d0_:d0_ + b.n_docs + 1] - t0_).astype(np.uint64), off), (rank, k)
+        for _ in range(2):                                           # the check above left the GPU idle for a while: warm up again
+            step()
+        torch.cuda.synchronize()
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    t_issue = time.perf_counter() - t0
     torch.cuda.synchronize()
+    t_sync = time.perf_counter() - t0
     if use_dist:
         dist.barrier()
     el = time.perf_counter() - t0
+    if os.environ.get("SPL_BENCH_DEBUG"):
+        print(f"[debug] {vocab}: issue {t_issue * 1e3:.3f} ms, synchronised {t_sync * 1e3:.3f} ms, after the barrier {el * 1e3:.3f} ms", file=sys.stderr)
     tot_b, tot_d, tot_t = my_bytes, my_docs, n_tok
     dist_info = None
     if use_dist:
@@ -867,7 +883,7 @@ def run_strong(vocab, texts, steps, rank, world, local_rank, dev, use_dist, nchk
         dist.all_reduce(s_)
         tot_b, tot_d, tot_t = (int(x) for x in s_.tolist())
         step_ms, exposed = float(allm[:, 0].max()), float(allm[:, 0].max() - allm[:, 1].max())
-        dist_info = {"rccl_ranks": comm.ranks(), "torch_world": world, "waves": len(subs), "collective": wg.collective,
+        dist_info = {"rccl_ranks": comm.ranks(), "torch_world": world, "waves": len(subs), "collective": wg.collective, "pack24": wg.pack24,
                      "per_rank": {"step_ms": [round(float(x), 4) for x in allm[:, 0]],
                                   "encode_only_ms": [round(float(x), 4) for x in allm[:, 1]],
                                   "exchange_stream_ms": [round(float(x), 4) for x in allm[:, 2]]},

@@ -93,7 +93,13 @@ int spl_device_count(void);
  * Restrictions (refused with SPL_EINVAL): ids must be < 2^21; the vocabulary must contain all 256
  * single bytes (ByteLevel: all 256 alphabet characters, each ranking below every longer token) --
  * the merge kernels identify a node with a token id, which byte_pair_encode's "unknown byte" branches
- * (src/core/bpe.rs:73-75, 182-191) would break; two different keys must not share an id. */
+ * (src/core/bpe.rs:73-75, 182-191) would break; two different keys must not share an id.
+ * Keys of up to 8 bytes live in single-slot tables built by hash-and-displace: keys that share a
+ * two-byte prefix (1..4-byte keys, 16-bit salt) or a four-byte-prefix filter slot (5..8-byte keys,
+ * 10-bit salt) share a salt, and a vocabulary for which no salt separates one such group even after
+ * three doublings of the table is refused (SPL_EINVAL, "could not give every key of the ... table a
+ * slot of its own").  No pretrained vocabulary comes near that; the reference's hash map has no
+ * such limit. */
 spl_tokenizer* spl_create(const void* vocab, size_t vocab_len, const void* uclass_tab, size_t uclass_len,
                           const spl_opts* opts);
 
@@ -114,8 +120,9 @@ uint32_t spl_n_devices(const spl_tokenizer* t);
  * split runs on the GPU, see spl_split_device; 0 keeps it on the host cores), "small_path" (0/1, default 1: batches of at most 4 KB take
  * the latency path, see spl_small_path_calls), "direct_read" (0/1, default 1: a batch of ONE pipeline chunk whose text comes from
  * spl_host_alloc is not copied to the device -- the tile kernel reads it, and the offsets, where they lie; 93 -> 83 us per 1 MB call),
- * "sdma_d2h" (0/1, default 1: the ids of a pipeline chunk leave through hsa_amd_memory_async_copy -- an SDMA engine -- instead of
- * hipMemcpyAsync, which runs as a shader copy beside the next chunk's tile kernel; hipMemcpyAsync where the HSA runtime cannot be bound). */
+ * "sdma_d2h" (0/1, default 0: the ids of a pipeline chunk leave through hsa_amd_memory_async_copy -- an SDMA engine -- instead of
+ * hipMemcpyAsync, which runs as a shader copy beside the next chunk's tile kernel; measured at +0.5 .. 3 % on the 40 MB batch, so not the
+ * default; hipMemcpyAsync where the HSA runtime cannot be bound). */
 int spl_set_option(spl_tokenizer* t, const char* name, int64_t value);
 
 /* One entry of the special_tokens map (src/core/tokenizer.rs:304, 429-434).  Call before the first

@@ -367,7 +367,8 @@ struct spl_tokenizer {
     int subdoc = 1;                           // cut documents at context-free boundaries to balance the GPUs
     int direct_write = 1;                     // one-chunk batches: the last kernel writes the ids straight into the pinned result
     int small_path = 1;                       // batches of up to 4 KB take the latency path (encode_small)
-    int sdma_d2h = 1;                         // pipeline chunks: their ids leave through hsa_amd_memory_async_copy (an SDMA engine) instead of hipMemcpyAsync
+    int slab_pack24 = 0;                      // the ids of the all-gather slabs travel three bytes each (spl_set_option "slab_pack24": every rank alike)
+    int sdma_d2h = 0;                         // (measured, +0.5..3 %: not the default) pipeline chunks: their ids leave through hsa_amd_memory_async_copy (an SDMA engine) instead of hipMemcpyAsync
     int direct_read = 1;                      // one-chunk batches from pinned memory: the tile kernel reads text and offsets where they lie (no H2D copy)
     uint64_t small_calls = 0;                 // ... and how many did (spl_small_path_calls)
 };
@@ -690,7 +691,7 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
         }
         b.tdesc = t->d_tdesc; b.tile_ids = t->d_tile_ids; b.tctl = t->d_tctl;
         b.tgroups = t->tgroups; b.tpar = t->tpar; b.tslot = (uint32_t)TileGeom<SPL_TILE_SMALL>::Wv + 1u;
-        if (so && ntiles) { b.slab = so->d_slab; b.slab_cap = (uint32_t)so->cap_words; b.slab_max_docs = (uint32_t)so->max_docs; }
+        if (so && ntiles) { b.slab = so->d_slab; b.slab_cap = (uint32_t)so->cap_words; b.slab_max_docs = (uint32_t)so->max_docs; b.slab_p24 = tk->slab_pack24 ? 1u : 0u; }
         // (The latency path as ONE launch -- the last workgroup of the tile kernel turning every tile's record into the CSR by itself, no
         //  k_tile_out -- was built and measured in round 5: 33.6 us per 1 KB call against 31.2 with the two launches, 23.9 against 22.8 for 13
         //  bytes.  Two back-to-back launches overlap the second one's dispatch with the first kernel; the fused epilogue's device-scope fences,
@@ -750,7 +751,7 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
     }
     if (so && !(direct && ntiles))          // the slab copy of the result, where k_tile_out did not write it
         hipLaunchKernelGGL(k_gatherv_pack, dim3(256), dim3(256), 0, s, d_ids, d_out_off, (uint32_t)n_docs, so->d_slab,
-                           (uint32_t)so->cap_words, (uint32_t)so->max_docs);
+                           (uint32_t)so->cap_words, (uint32_t)so->max_docs, tk->slab_pack24 ? 1u : 0u);
     if (pf) {
         HIP_TRY(hipEventSynchronize(t->ev[KI_N]));
         for (int i = 0; i < KI_N; i++) {
@@ -1885,7 +1886,8 @@ int spl_set_option(spl_tokenizer* t, const char* name, int64_t value) {
     else if (k == "device_split") t->rx_device = value != 0;
     else if (k == "small_path") t->small_path = value != 0;
     else if (k == "direct_read") t->direct_read = value != 0;
-    else if (k == "sdma_d2h") t->sdma_d2h = value != 0;        // (where the HSA runtime or the device's agent cannot be found: hipMemcpyAsync, silently)
+    else if (k == "sdma_d2h") t->sdma_d2h = value != 0;
+    else if (k == "slab_pack24") t->slab_pack24 = value != 0;        // (where the HSA runtime or the device's agent cannot be found: hipMemcpyAsync, silently)
     else return fail(SPL_EINVAL, "spl_set_option: unknown option or bad value: " + k);
     return SPL_OK;
 }
@@ -2151,7 +2153,7 @@ int spl_gatherv_pack(spl_tokenizer* t, const uint32_t* d_ids, const uint64_t* d_
         return fail(SPL_EINVAL, "spl_gatherv_pack: slab too small for the document table");
     HIP_TRY(hipSetDevice(t->ctx[0]->device));
     hipLaunchKernelGGL(k_gatherv_pack, dim3(256), dim3(256), 0, (hipStream_t)hip_stream, d_ids, d_out_off, (uint32_t)n_docs,
-                       d_slab, (uint32_t)cap_words, (uint32_t)max_docs);
+                       d_slab, (uint32_t)cap_words, (uint32_t)max_docs, t->slab_pack24 ? 1u : 0u);
     HIP_TRY(hipGetLastError());
     return SPL_OK;
 }
@@ -2163,7 +2165,7 @@ int spl_gatherv_unpack(spl_tokenizer* t, const uint32_t* d_slabs, uint32_t world
     HIP_TRY(hipSetDevice(t->ctx[0]->device));
     hipLaunchKernelGGL(k_gatherv_unpack, dim3(128, world), dim3(256), 0, (hipStream_t)hip_stream, d_slabs, world,
                        (uint32_t)cap_words, (uint32_t)max_docs, d_all_ids, all_ids_cap, d_all_off, d_status,
-                       (uint64_t)cap_words, (uint64_t)0);
+                       (uint64_t)cap_words, (uint64_t)0, t->slab_pack24 ? 1u : 0u);
     HIP_TRY(hipGetLastError());
     return SPL_OK;
 }
@@ -2177,7 +2179,7 @@ int spl_gatherv_unpack_group(spl_tokenizer* t, const uint32_t* d_slabs, uint32_t
     HIP_TRY(hipSetDevice(t->ctx[0]->device));
     hipLaunchKernelGGL(k_gatherv_unpack, dim3(128, world, n_batches), dim3(256), 0, (hipStream_t)hip_stream, d_slabs, world,
                        (uint32_t)cap_words, (uint32_t)max_docs, d_all_ids, all_ids_cap, d_all_off, d_status,
-                       (uint64_t)depth * cap_words, off_stride);
+                       (uint64_t)depth * cap_words, off_stride, t->slab_pack24 ? 1u : 0u);
     HIP_TRY(hipGetLastError());
     return SPL_OK;
 }
@@ -2189,7 +2191,7 @@ int spl_gatherv_unpack_at(spl_tokenizer* t, const uint32_t* d_slabs, uint32_t wo
         return fail(SPL_EINVAL, "spl_gatherv_unpack_at: bad argument");
     HIP_TRY(hipSetDevice(t->ctx[0]->device));
     hipLaunchKernelGGL(k_gatherv_unpack_at, dim3(128, world), dim3(256), 0, (hipStream_t)hip_stream, d_slabs, world, (uint32_t)cap_words,
-                       (uint32_t)max_docs, d_all_ids, all_ids_cap, d_all_off, all_off_cap, (const uint64_t*)d_run, d_status);
+                       (uint32_t)max_docs, d_all_ids, all_ids_cap, d_all_off, all_off_cap, (const uint64_t*)d_run, d_status, t->slab_pack24 ? 1u : 0u);
     hipLaunchKernelGGL(k_gatherv_advance, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, d_slabs, world, (uint32_t)cap_words, d_run);
     HIP_TRY(hipGetLastError());
     return SPL_OK;

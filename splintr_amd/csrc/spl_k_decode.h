@@ -128,26 +128,26 @@ __global__ void k_add_base(uint64_t* p, uint64_t n, uint64_t base) {
 // CSR.  No host synchronisation: the token counts travel inside the slabs.
 //   slab (u32 words): [0] T  [1] N  [2 .. 2+max_docs] local out_off (N+1 used)  [2+max_docs+1 ..] ids
 __global__ void k_gatherv_pack(const uint32_t* ids, const uint64_t* out_off, uint32_t n_docs, uint32_t* slab,
-                               uint32_t cap_words, uint32_t max_docs) {
+                               uint32_t cap_words, uint32_t max_docs, uint32_t p24) {
     const uint32_t T = (uint32_t)out_off[n_docs];
-    const uint32_t ids_at = 3 + max_docs, ids_cap = cap_words - ids_at;
+    const uint32_t ids_at = 3 + max_docs, ids_cap = slab_id_cap(cap_words - ids_at, p24 != 0u);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
     if (i == 0) { slab[0] = T; slab[1] = n_docs; }
     for (uint32_t d = i; d <= n_docs; d += stride) slab[2 + d] = (uint32_t)out_off[d];
     const uint32_t ncopy = T < ids_cap ? T : ids_cap;        // T > ids_cap is reported by the unpacker
-    for (uint32_t k = i; k < ncopy; k += stride) slab[ids_at + k] = ids[k];
+    for (uint32_t k = i; k < ncopy; k += stride) slab_put_id(slab + ids_at, k, ids[k], p24 != 0u);
 }
 // grid.y = source rank, grid.z = batch of the group (a rank sends `depth` slabs back to back per
 // collective: rank_stride = depth * cap_words; batch j's slabs start at j * cap_words and its outputs
 // at j * all_ids_cap / j * off_stride).  status[0] is set to 1 if any slab overflowed its id capacity.
 __global__ void k_gatherv_unpack(const uint32_t* slabs_all, uint32_t world, uint32_t cap_words, uint32_t max_docs,
                                  uint32_t* all_ids_all, uint64_t all_ids_cap, uint64_t* all_off_all, uint32_t* status,
-                                 uint64_t rank_stride, uint64_t off_stride) {
+                                 uint64_t rank_stride, uint64_t off_stride, uint32_t p24) {
     const uint32_t r = blockIdx.y, j = blockIdx.z;
     const uint32_t* slabs = slabs_all + (size_t)j * cap_words;
     uint32_t* all_ids = all_ids_all + (size_t)j * all_ids_cap;
     uint64_t* all_off = all_off_all + (size_t)j * off_stride;
-    const uint32_t ids_at = 3 + max_docs, ids_cap = cap_words - ids_at;
+    const uint32_t ids_at = 3 + max_docs, ids_cap = slab_id_cap(cap_words - ids_at, p24 != 0u);
     uint64_t tbase = 0, dbase = 0;
     for (uint32_t q = 0; q < r; q++) { tbase += slabs[(size_t)q * rank_stride]; dbase += slabs[(size_t)q * rank_stride + 1]; }
     const uint32_t* slab = slabs + (size_t)r * rank_stride;
@@ -158,7 +158,7 @@ __global__ void k_gatherv_unpack(const uint32_t* slabs_all, uint32_t world, uint
     if (r == world - 1 && i == 0) all_off[dbase + N] = tbase + T;
     const uint32_t ncopy = T < ids_cap ? T : ids_cap;
     for (uint32_t k = i; k < ncopy; k += stride)
-        if (tbase + k < all_ids_cap) all_ids[tbase + k] = slab[ids_at + k];
+        if (tbase + k < all_ids_cap) all_ids[tbase + k] = slab_get_id(slab + ids_at, k, p24 != 0u);
 }
 
 // The same for ONE batch that is exchanged in WAVES (strong scaling, pipelined: wave k is on the links while wave k + 1 encodes): the
@@ -166,9 +166,9 @@ __global__ void k_gatherv_unpack(const uint32_t* slabs_all, uint32_t world, uint
 // what the waves before it left -- run[0] tokens, run[1] documents, in device memory, advanced by k_gatherv_advance behind the unpack
 // (stream order) -- so that all waves together are ONE CSR in document order and no host synchronisation sits between them.
 __global__ void k_gatherv_unpack_at(const uint32_t* slabs, uint32_t world, uint32_t cap_words, uint32_t max_docs, uint32_t* all_ids,
-                                    uint64_t all_ids_cap, uint64_t* all_off, uint64_t all_off_cap, const uint64_t* run, uint32_t* status) {
+                                    uint64_t all_ids_cap, uint64_t* all_off, uint64_t all_off_cap, const uint64_t* run, uint32_t* status, uint32_t p24) {
     const uint32_t r = blockIdx.y;
-    const uint32_t ids_at = 3 + max_docs, ids_cap = cap_words - ids_at;
+    const uint32_t ids_at = 3 + max_docs, ids_cap = slab_id_cap(cap_words - ids_at, p24 != 0u);
     uint64_t tbase = run[0], dbase = run[1];
     for (uint32_t q = 0; q < r; q++) { tbase += slabs[(size_t)q * cap_words]; dbase += slabs[(size_t)q * cap_words + 1]; }
     const uint32_t* slab = slabs + (size_t)r * cap_words;
@@ -180,7 +180,7 @@ __global__ void k_gatherv_unpack_at(const uint32_t* slabs, uint32_t world, uint3
     if (r == world - 1 && i == 0 && dbase + N < all_off_cap) all_off[dbase + N] = tbase + T;      // the closing entry (the next wave's first)
     const uint32_t ncopy = T < ids_cap ? T : ids_cap;
     for (uint32_t k = i; k < ncopy; k += stride)
-        if (tbase + k < all_ids_cap) all_ids[tbase + k] = slab[ids_at + k];
+        if (tbase + k < all_ids_cap) all_ids[tbase + k] = slab_get_id(slab + ids_at, k, p24 != 0u);
 }
 __global__ void k_gatherv_advance(const uint32_t* slabs, uint32_t world, uint32_t cap_words, uint64_t* run) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {

@@ -18,14 +18,14 @@ constexpr int TOUT_NT = SPL_TILE_OUT_NT;               // threads of a k_tile_ou
 struct TileOutArgs {
     uint32_t* tctl; const TileDesc* tdesc; const uint32_t* tile_ids; uint32_t* ids_out; uint64_t ids_cap; uint64_t* off_out; uint64_t* off_out2;
     uint32_t* slab; uint32_t* tbits; const uint32_t* stage; const uint32_t* skip;
-    uint32_t tpar, tgroups, tslot, slab_cap, slab_max_docs, n_docs;
+    uint32_t tpar, tgroups, tslot, slab_cap, slab_max_docs, n_docs, slab_p24;
     // latency path (small host batches): the LAST workgroup to finish stores done_seq to *done (pinned host memory, system scope) behind
     // everybody's result stores -- the host spins on that word instead of synchronising the stream (tctl[8]: workgroups finished)
     uint32_t* done; uint32_t done_seq;
 };
 inline TileOutArgs tile_out_args(const Batch& b) {
     return TileOutArgs{b.tctl, b.tdesc, b.tile_ids, b.ids_out, b.ids_cap, b.off_out, b.off_out2, b.slab, b.tbits, b.stage, b.skip,
-                       b.tpar, b.tgroups, b.tslot, b.slab_cap, b.slab_max_docs, b.n_docs, b.done, b.done_seq};
+                       b.tpar, b.tgroups, b.tslot, b.slab_cap, b.slab_max_docs, b.n_docs, b.slab_p24, b.done, b.done_seq};
 }
 __global__ __launch_bounds__(TOUT_NT) void k_tile_out(TileOutArgs b) {
     __shared__ unsigned long long s_part[TOUT_NT / 64];
@@ -51,12 +51,12 @@ __global__ __launch_bounds__(TOUT_NT) void k_tile_out(TileOutArgs b) {
     __syncthreads();
     unsigned long long base = 0;
     for (int k = 0; k < TOUT_NT / 64; k++) base += s_part[k];
-    const uint32_t s_ids_at = 3 + b.slab_max_docs, s_ids_cap = b.slab ? b.slab_cap - s_ids_at : 0u;
+    const uint32_t s_ids_at = 3 + b.slab_max_docs, s_ids_cap = b.slab ? slab_id_cap(b.slab_cap - s_ids_at, b.slab_p24 != 0u) : 0u;
     for (uint32_t k = tid; k < td.c_win; k += TOUT_NT) {
         const unsigned long long r = base + k;
         const uint32_t id = k < (uint32_t)TOUT_NT ? first_id : b.tile_ids[td.slot + k];
         if (r < b.ids_cap) b.ids_out[r] = id;
-        if (r < s_ids_cap) b.slab[s_ids_at + r] = id;
+        if (r < s_ids_cap) slab_put_id(b.slab + s_ids_at, (uint32_t)r, id, b.slab_p24 != 0u);
     }
     for (uint32_t k = tid; k < td.d_cnt; k += TOUT_NT) {
         const unsigned long long v = b.off_out[td.d_first + k] + base;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(TOUT_NT) void k_tile_out(TileOutArgs b) {
                 const int bit = __ffs(word) - 1;
                 word &= word - 1;
                 if (r < b.ids_cap) b.ids_out[r] = b.stage[w * 32 + bit];
-                if (r < s_ids_cap) b.slab[s_ids_at + r] = b.stage[w * 32 + bit];
+                if (r < s_ids_cap) slab_put_id(b.slab + s_ids_at, (uint32_t)r, b.stage[w * 32 + bit], b.slab_p24 != 0u);
                 r++;
             }
             running += all;

@@ -117,6 +117,7 @@ struct Batch {
     // optional second copy of the result, laid out as a ragged all-gather slab (k_gatherv_pack's
     // format): k_tile_out writes it in the same pass, the separate pack launch goes away
     uint32_t* slab; uint32_t slab_cap, slab_max_docs;
+    uint32_t slab_p24;         // the slab's ids are packed three bytes each (ids < 2^21: a quarter less on the links)
     uint32_t tpar;             // parity of this call
     uint64_t* off_out2;        // tile-owned mode, optional: k_tile_out stores the final offsets here as well (pinned host memory)
     // EXTERNAL chunk boundaries (split patterns the scanner does not implement: the host splitter, spl_regex.h):
@@ -137,6 +138,20 @@ __device__ __forceinline__ void wave_lds_sync() {
 // alive across the 46 000-instruction kernel: with this, k_pretok<800,192> has NO spilled VGPR (round 3: 20, 84 B of scratch
 // per lane) -- found while building the persistent-workgroup experiment (profiles/r04_persistent_workgroups.txt), whose loop
 // made LLVM hoist all of it.
+// Slab ids (the ragged all-gather's wire format, spl_k_decode.h): u32 each, or -- "slab_pack24" -- three bytes each, little endian.
+__device__ __forceinline__ void slab_put_id(uint32_t* area, uint32_t r, uint32_t id, bool p24) {
+    if (!p24) { area[r] = id; return; }
+    uint8_t* p = reinterpret_cast<uint8_t*>(area) + 3u * (size_t)r;
+    p[0] = (uint8_t)id; p[1] = (uint8_t)(id >> 8); p[2] = (uint8_t)(id >> 16);
+}
+__device__ __forceinline__ uint32_t slab_get_id(const uint32_t* area, uint32_t k, bool p24) {
+    if (!p24) return area[k];
+    const size_t bo = 3u * (size_t)k;
+    const uint32_t lo = area[bo >> 2], hi = area[(bo >> 2) + 1];            // (the area is padded by a word)
+    return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(bo & 3)) & 0xFFFFFFu;
+}
+__device__ __forceinline__ uint32_t slab_id_cap(uint32_t area_words, bool p24) { return p24 ? (uint32_t)(((size_t)(area_words - 1u) * 4u) / 3u) : area_words; }
+
 __device__ __forceinline__ uint32_t tidx() {
     uint32_t x = threadIdx.x;
     asm volatile("" : "+v"(x));

@@ -6,7 +6,7 @@ PyTorch is plumbing here (device memory, streams, torch.distributed); the work i
 from __future__ import annotations
 
 import ctypes
-from typing import Sequence, Tuple
+from typing import Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -116,6 +116,34 @@ class Comm:
             pass
 
 
+def _slab_words(max_tokens: int, max_docs: int, pack24: bool) -> int:
+    """words of one slab: header, offsets, then the ids -- u32 each, or three bytes each (+ one word of slack for the unpacker's reads)"""
+    return ((3 * max_tokens + 3) // 4 + 1 if pack24 else max_tokens) + max_docs + 4
+
+
+_EXCH_STREAMS = {}
+
+
+def exchange_stream(device: torch.device) -> "torch.cuda.Stream":
+    """THE exchange stream of a device: one per process and GPU, shared by every GatherV / WaveGather on it, at high priority.
+    HIP maps streams onto a handful of hardware queues round-robin in creation order: the n-th stream a process creates may land
+    on the queue the encoder's stream uses, and then the exchange runs BEHIND the encodes instead of beside them (measured: the
+    fourth WaveGather of a process lost the whole overlap, 5.47 -> 6.05 ms per step).  A stream of another priority has a queue
+    of its own, and the exchange is what should be scheduled first when both have work."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    st = _EXCH_STREAMS.get(key)
+    if st is None:
+        st = _EXCH_STREAMS[key] = torch.cuda.Stream(device=device, priority=-1)
+    return st
+
+
+def _set_pack24(tok: Optional[Tokenizer], on: bool) -> None:
+    if tok is None:                              # the bucket logic driven without an encoder (CPU tests): slabs come from the caller
+        return
+    if _ffi.lib().spl_set_option(tok.handle, b"slab_pack24", 1 if on else 0) != 0:
+        raise RuntimeError(_ffi.last_error())
+
+
 class GatherV:
     """Pipelined, bucketed ragged all-gather of per-rank CSR results.
 
@@ -138,9 +166,11 @@ class GatherV:
     """
 
     def __init__(self, tok: Tokenizer, device: torch.device, max_docs: int, max_tokens: int, group=None, depth: int = 8,
-                 comm: "Comm" = None, collective: str = "allgather"):
+                 comm: "Comm" = None, collective: str = "allgather", pack24: bool = False):
         import torch.distributed as dist
         self.tok, self.dev, self.group, self.dist, self.comm = tok, device, group, dist, comm
+        self.pack24 = bool(pack24)                # slab ids travel three bytes each (ids < 2**21): a quarter less on the links; EVERY rank alike
+        _set_pack24(tok, self.pack24)
         if collective not in ("allgather", "p2p") or (collective == "p2p" and comm is None):
             raise ValueError("GatherV: collective is 'allgather' or -- with the library's communicator -- 'p2p'")
         self.collective = collective             # ncclAllGather of the bucket's slabs, or grouped send / recv of the same slabs
@@ -148,7 +178,7 @@ class GatherV:
         self.depth = int(depth)
         self.max_docs = int(max_docs)
         self.max_tokens = int(max_tokens)
-        self.cap_words = self.max_tokens + self.max_docs + 4
+        self.cap_words = _slab_words(self.max_tokens, self.max_docs, self.pack24)
         if self.cap_words >= 1 << 32:
             raise ValueError("GatherV: a slab must stay below 2**32 words")
         self.off_stride = self.world * self.max_docs + 1
@@ -171,7 +201,7 @@ class GatherV:
 
     # (overridable: the CPU test drives the bucket / event logic with a stub encoder on gloo)
     def _new_stream(self):
-        return torch.cuda.Stream(device=self.dev)
+        return exchange_stream(self.dev)
 
     def _new_event(self):
         return torch.cuda.Event()
@@ -319,10 +349,12 @@ class WaveGather:
     Order it replaces: Rayon's order-preserving collect, src/core/tokenizer.rs:932-942."""
 
     def __init__(self, tok: Tokenizer, device: torch.device, comm: "Comm", n_waves: int, max_docs: int, max_tokens: int,
-                 total_tokens_cap: int, total_docs_cap: int, collective: str = "allgather"):
+                 total_tokens_cap: int, total_docs_cap: int, collective: str = "allgather", pack24: bool = False):
         self.tok, self.dev, self.comm, self.world = tok, device, comm, comm.world
         self.n_waves, self.max_docs, self.max_tokens = int(n_waves), int(max_docs), int(max_tokens)
-        self.cap_words = self.max_tokens + self.max_docs + 4
+        self.pack24 = bool(pack24)
+        _set_pack24(tok, self.pack24)
+        self.cap_words = _slab_words(self.max_tokens, self.max_docs, self.pack24)
         if self.cap_words >= 1 << 32:
             raise ValueError("WaveGather: a slab must stay below 2**32 words")
         self.collective = collective
@@ -333,7 +365,7 @@ class WaveGather:
         self.all_off = torch.zeros(int(total_docs_cap) + 1, dtype=torch.int64, **kw)
         self.run = torch.zeros(2, dtype=torch.int64, **kw)            # tokens, documents landed so far
         self.status = torch.zeros(1, dtype=torch.int32, **kw)
-        self.exch = torch.cuda.Stream(device=device)
+        self.exch = exchange_stream(device)
         self.encoded = [torch.cuda.Event() for _ in range(self.n_waves)]
         self.k = 0
         self._timing = None

@@ -107,13 +107,19 @@ class Tokenizer:
     Differences from the reference, all refused loudly rather than approximated:
     * `pattern`: CL100K_BASE_PATTERN, O200K_BASE_PATTERN (= LLAMA3_PATTERN) and MISTRAL_V3_PATTERN are split on the
       GPU by closed-form scanners; any other pattern is compiled by the library's own regex matcher and run at every text position
-      on the GPU (csrc/spl_rx_split.h; on the host cores for the rare batch the device matcher gives up
-      on -- a match longer than ~1 KB) (literals, classes, \s \d \w,
-      every general category as \p{..}, groups, (?i:), (?>), alternation, greedy / lazy / possessive quantifiers,
-      look-ahead, ^ $ \A \Z \z \b \B: upstream tiktoken's cl100k_base / o200k_base strings, Qwen2's and GPT-2's are accepted as
-      they are) and merged on the GPU; a pattern with anything else in it (scripts, look-behind, back-references, \p{Lu}
-      under (?i)) or one that can match the empty string raises the reference's "Regex error" ValueError naming the construct;
+      on the GPU (csrc/spl_rx_split.h; on the host cores for the rare DOCUMENT the device matcher gives up
+      on -- a match longer than ~1 KB -- while the rest of its batch keeps the device split) (literals, classes, \s \d \w,
+      every general category and every script as \p{..} / \P{..}, groups, (?i:), (?>), alternation, greedy / lazy / possessive
+      quantifiers, look-ahead, ^ $ \A \Z \z \b \B: upstream tiktoken's cl100k_base / o200k_base strings, Qwen2's, GPT-2's and
+      \p{Han}-style patterns are accepted as they are) and merged on the GPU; a pattern with anything else in it (binary
+      properties, script extensions, look-behind, back-references, \p{Lu} under (?i)) or one that can match the empty string
+      raises the reference's "Regex error" ValueError naming the construct;
     * the vocabulary must contain all 256 single bytes and ids below 2**21;
+    * every key of up to 8 bytes gets a table slot of its own by hash-and-displace (csrc/spl_tables.cpp): a vocabulary in
+      which so many such keys share one two-byte prefix (keys of 1..4 bytes: 16-bit salt) or one four-byte-prefix filter slot
+      (keys of 5..8 bytes: 10-bit salt) that no salt separates them even after the table was doubled three times is refused
+      ("could not give every key ... a slot of its own").  None of the pretrained or tested vocabularies comes near it
+      (largest group: 256 keys); the reference's FxHashMap has no such limit;
     * special-token literals are at most 255 bytes (any set: literals that contain or chain into one
       another are matched as the reference's Aho-Corasick matcher does).
     Extensions: `device=` / `devices=` select the GPU(s), `byte_level=True` is the reference's

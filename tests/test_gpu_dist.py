@@ -65,6 +65,47 @@ def test_gatherv_pipeline_one_rank_rccl(coracle):
         for (g_ids, g_off), k in zip(got, (3, 1)):
             w_ids, w_off = want[k]
             assert np.array_equal(g_ids[:int(w_off[-1])].cpu().numpy().view(np.uint32), w_ids)
+        # the same with the slab's ids packed three bytes each ("slab_pack24": a quarter less on the links), fused and separate pack
+        gp = GatherV(tok, dev, max_docs=max(b.n_docs for b in batches), max_tokens=max_tok + 64, depth=2, pack24=True)
+        assert gp.cap_words < gv.cap_words - max_tok // 5
+        got.clear()
+        gp.on_bucket = lambda res: got.extend((i.clone(), o.clone()) for i, o in res)
+        for k in order:
+            gp.encode_and_submit(batches[k])
+        for k in (3, 1):
+            encode_device(tok, batches[k])
+            gp.submit(batches[k])
+        gp.finish()
+        torch.cuda.synchronize()
+        assert not gp.overflowed() and len(got) == len(order) + 2
+        for (g_ids, g_off), k in zip(got, order + [3, 1]):
+            w_ids, w_off = want[k]
+            assert np.array_equal(g_off[:batches[k].n_docs + 1].cpu().numpy().astype(np.uint64), w_off)
+            assert np.array_equal(g_ids[:int(w_off[-1])].cpu().numpy().view(np.uint32), w_ids)
+        # ... and the waves of ONE batch landing behind each other (WaveGather over the library's communicator, both slab formats)
+        from splintr_amd.device import Comm, WaveGather
+        comm = Comm(Comm.unique_id(), 0, 1, 0)
+        for p24 in (False, True):
+            wg = WaveGather(tok, dev, comm, 5, max_docs=max(b.n_docs for b in batches), max_tokens=max_tok + 64,
+                            total_tokens_cap=sum(int(w[1][-1]) for w in want) + 64, total_docs_cap=sum(b.n_docs for b in batches), pack24=p24)
+            for _ in range(2):                                     # (twice: the running totals start over)
+                wg.begin()
+                for b in batches:
+                    wg.encode_and_submit(b)
+                a_ids, a_off, run = wg.finish()
+            torch.cuda.synchronize()
+            assert not wg.overflowed()
+            w_all = np.concatenate([w[0] for w in want])
+            assert run.cpu().tolist() == [len(w_all), sum(b.n_docs for b in batches)]
+            assert np.array_equal(a_ids[:len(w_all)].cpu().numpy().view(np.uint32), w_all)
+            o_all, tdone = [np.zeros(1, dtype=np.uint64)], 0
+            for w in want:
+                o_all.append(w[1][1:] + np.uint64(tdone))
+                tdone += int(w[1][-1])
+            assert np.array_equal(a_off.cpu().numpy().astype(np.uint64), np.concatenate(o_all))
+        comm.close()
+        _ffi_reset = __import__("splintr_amd")._ffi.lib().spl_set_option(tok.handle, b"slab_pack24", 0)
+        assert _ffi_reset == 0
         # a slab that is too small is reported, not silently truncated
         small = GatherV(tok, dev, max_docs=max(b.n_docs for b in batches), max_tokens=100, depth=1)
         small.encode_and_submit(batches[0])
@@ -159,18 +200,19 @@ def test_bench_distributed_branch_rehearsal_world_1():
     assert d["rccl_ranks"] == 1 and d["torch_world"] == 1
     for key in ("step_ms", "encode_only_ms", "exchange_stream_ms_per_step"):
         assert len(d["per_rank"][key]) == 1 and d["per_rank"][key][0] > 0, (key, d)
-    assert d["slab_bytes_sent_per_batch"] >= d["ids_bytes_per_batch_4T"] > 0 and d["buckets_timed"] == 24 // d["bucket_depth"]
+    # a slab holds the batch's ids: four bytes each, three with the packed format
+    assert d["slab_bytes_sent_per_batch"] >= d["ids_bytes_per_batch_4T"] * (3 if d["pack24"] else 4) // 4 > 0 and d["buckets_timed"] == 24 // d["bucket_depth"]
     # the start-up calibration: every depth x collective form was timed, the fastest one ran the timed region
     cal = d["calibration"]
-    assert len(cal["ms_per_step"]) == 4 and all(v > 0 for v in cal["ms_per_step"].values())
-    assert cal["chosen"] == min(cal["ms_per_step"], key=cal["ms_per_step"].get) == f"depth{d['bucket_depth']}_{d['collective']}"
+    assert len(cal["ms_per_step"]) == 6 and all(v > 0 for v in cal["ms_per_step"].values())
+    assert cal["chosen"] == min(cal["ms_per_step"], key=cal["ms_per_step"].get) and cal["chosen"].startswith(f"depth{d['bucket_depth']}_{d['collective']}")
     for key in ("c4_strong", "c5_strong"):
         c = line[key]
         assert c["scaling"] == "strong" and c["value"] > 0 and "bit-exact" in c["parity"], c
         cd = c["dist"]
         assert cd["rccl_ranks"] == 1 and cd["per_rank"]["exchange_stream_ms"][0] > 0 and cd["waves"] == 8, c
-        assert set(cd["calibration_ms_per_step"]) == {"allgather", "p2p"} and cd["collective"] in ("allgather", "p2p")
-        assert cd["bytes_received_per_rank"] >= cd["ids_bytes_4T"] > 0
+        assert set(cd["calibration_ms_per_step"]) == {"allgather", "p2p", "allgather+pack24"} and cd["collective"] in ("allgather", "p2p")
+        assert cd["bytes_received_per_rank"] >= cd["ids_bytes_4T"] * (3 if cd["pack24"] else 4) // 4 > 0
         # pipelined: what the exchange adds to a step is (at most) the last wave's exchange, not all of it (<= 5 % of the
         # step at full size; the rehearsal's waves are 2-3 MB, a step is under a millisecond and the exchange with itself shares the GPU with the encodes: 40 %; full size at world 1: profiles/r05_wave_exchange.txt)
         # (only when the timed steps ran at the speed the calibration saw a moment earlier: run behind the other tests of this file, whose RCCL

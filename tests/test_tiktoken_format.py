@@ -116,7 +116,7 @@ def test_constructors_on_tiktoken_text(tmp_path, name):
         Tokenizer.from_bytes(b"not base64!! 0\n", pattern)
     with pytest.raises(ValueError):
         Tokenizer.from_bytes(blob, r"\p{Alphabetic}+|\s+")              # a construct the matcher refuses (binary properties; scripts are accepted since round 5)
-    th = Tokenizer.from_bytes(blob, r"\p{Han}+|\p{Latin}+|\s+|.")
+    th = (Tokenizer.from_bytes_byte_level if byte_level else Tokenizer.from_bytes)(blob, r"\p{Han}+|\p{Latin}+|\s+|.")
     assert th.has_custom_pattern and th.decode(th.encode("漢字 and Latin")) == "漢字 and Latin"
     with pytest.raises(IOError):
         Tokenizer(str(path), r"(?<=a)b|\s+")
