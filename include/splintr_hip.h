@@ -111,7 +111,7 @@ spl_tokenizer* spl_create(const void* vocab, size_t vocab_len, const void* uclas
 int spl_set_devices(spl_tokenizer* t, const int32_t* devices, uint32_t n);
 uint32_t spl_n_devices(const spl_tokenizer* t);
 
-/* Host pipeline tuning: "chunk_bytes" (upper bound of one pipeline chunk, default 8 MiB),
+/* Host pipeline tuning: "chunk_bytes" (upper bound of one pipeline chunk, default 5 MiB),
  * "single_chunk_max_bytes" (batches up to this size run as one chunk, default 4 MiB),
  * "result_estimate_div" (first guess of the token count = bytes / div; default 0.375 tokens per byte),
  * "subdoc_split" (0/1: balance the GPUs by cutting large documents at context-free boundaries),
@@ -122,7 +122,12 @@ uint32_t spl_n_devices(const spl_tokenizer* t);
  * spl_host_alloc is not copied to the device -- the tile kernel reads it, and the offsets, where they lie; 93 -> 83 us per 1 MB call),
  * "sdma_d2h" (0/1, default 0: the ids of a pipeline chunk leave through hsa_amd_memory_async_copy -- an SDMA engine -- instead of
  * hipMemcpyAsync, which runs as a shader copy beside the next chunk's tile kernel; measured at +0.5 .. 3 % on the 40 MB batch, so not the
- * default; hipMemcpyAsync where the HSA runtime cannot be bound). */
+ * default; hipMemcpyAsync where the HSA runtime cannot be bound), "twin_streams" (0/1, default 1: the kernels of consecutive pipeline chunks
+ * run on two compute streams with a workspace each, so that a chunk's tile kernel starts while the stragglers of the previous one finish:
+ * 24.1 -> 28.8 GB/s host -> host on the 40 MB batch together with the smaller chunks; built-in patterns only), "copy_threads" (1..64,
+ * default 4: threads that copy a chunk of PAGEABLE text into pinned staging -- one core copies ~19 GB/s, less than the pipeline takes:
+ * 18.7 -> 27.6 GB/s from pageable memory), "chunk_ramp" (0/1, default 0: a lane's first and last chunk a quarter of the others;
+ * measured no better or worse on every BASELINE configuration). */
 int spl_set_option(spl_tokenizer* t, const char* name, int64_t value);
 
 /* One entry of the special_tokens map (src/core/tokenizer.rs:304, 429-434).  Call before the first
@@ -179,7 +184,7 @@ void spl_host_free(void* p);
  *   d_out_off[n_docs+1]   output offsets; d_out_off[n_docs] is the total token count
  * Tokens beyond ids_capacity are dropped (compare d_out_off[n_docs] with the capacity).
  * Size limits of ONE device call (SPL_EINVAL beyond them; spl_encode_batch on host buffers has none, it feeds
- * chunks of at most 8 MiB): n_bytes < 2^31 - 65536 (2047 MiB) without SPL_WITH_SPECIAL, n_bytes <= 256 MB with it and for handles with
+ * chunks of at most 5 MiB): n_bytes < 2^31 - 65536 (2047 MiB) without SPL_WITH_SPECIAL, n_bytes <= 256 MB with it and for handles with
  * SPL_PATTERN_CUSTOM (the special-token scan and the device splitter exist for the two-launch mode only).  Split a larger corpus at
  * document boundaries.
  * What is asynchronous: a handle with one of the three built-in patterns enqueues its kernels on `hip_stream` and returns -- no host

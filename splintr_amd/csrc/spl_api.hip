@@ -217,7 +217,8 @@ static double g_ht[8]; static int g_htn;
 #define HT_T(v) do { } while (0)
 #define HT_ACC(i, a, b_) do { } while (0)
 #endif
-#define TRACE(...) do { if (trace_on()) { fprintf(stderr, "[spl] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
+inline double trace_us() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)(ts.tv_sec % 1000) * 1e6 + (double)ts.tv_nsec * 1e-3; }
+#define TRACE(...) do { if (trace_on()) { fprintf(stderr, "[spl %12.1f] ", trace_us()); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 
 // Everything that lives on ONE GPU: lookup tables, workspace, and the host pipeline's streams and
 // staging.  A handle has one context per device of spl_set_devices (one by default).
@@ -268,7 +269,12 @@ struct Ctx {
     uint64_t slot_cap_bytes = 0, slot_cap_docs = 0;
     uint32_t* d_ids = nullptr; uint64_t ids_cap = 0;         // the lane's ids, chunk c at its byte offset
     uint64_t* d_oo = nullptr; uint64_t oo_cap = 0;           // chunk-local output offsets, chunk after chunk
-    Pinned h_text[NSLOT], h_off[NSLOT], h_tot;
+    // pipeline: the kernels of consecutive chunks alternate between this context and a TWIN on the same GPU -- a workspace and a compute
+    // stream of its own, the tables shared -- so that chunk k + 1's tile kernel starts while the stragglers of chunk k's finish
+    std::unique_ptr<Ctx> twin;
+    bool owns_tables = true;
+    Pinned h_text[NSLOT], h_off[NSLOT], h_oo;          // h_oo: the pipeline chunks' local output offsets (k_tile_out writes them there: no copy, no count to fetch)
+    uint64_t* dh_oo = nullptr;                          // its device-side address
     // custom split patterns: the chunk's boundary bitmaps (starts | gaps, back to back) and the special tokens the
     // host splitter found (positions | ids), per staging slot
     Pinned h_ext[NSLOT], h_extsp[NSLOT];
@@ -323,8 +329,10 @@ struct Ctx {
     ~Ctx() {
         if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return; }
         (void)hipDeviceSynchronize();
+        twin.reset();
         free_workspace();
         free_slots();
+        if (!owns_tables) dt = DeviceTables{};
         hipFree((void*)dt.ucls_stage1); hipFree((void*)dt.ucls_stage2); hipFree((void*)dt.short_tab);
         hipFree((void*)dt.tiny_tab); hipFree((void*)dt.t8_tab);
         hipFree((void*)dt.long_tab); hipFree((void*)dt.key_blob); hipFree((void*)dt.pair_tab);
@@ -361,7 +369,7 @@ struct spl_tokenizer {
     std::vector<std::unique_ptr<Ctx>> ctx;
     std::shared_ptr<PinnedPool> pool = std::make_shared<PinnedPool>();
     // host pipeline tuning (spl_set_option)
-    uint64_t chunk_bytes = 8ull << 20;        // upper bound of one pipeline chunk (5 .. 16 MiB measure alike; 8 is best from pageable input)
+    uint64_t chunk_bytes = 5ull << 20;        // upper bound of one pipeline chunk (with the kernels of consecutive chunks on two streams 4 .. 6 MiB are best: C3 28.8 GB/s, 26.8 at 8 MiB)
     uint64_t single_max = 4ull << 20;         // batches up to this size run as ONE chunk
     uint32_t est_div = 2;                     // first guess of the token count: n_bytes / est_div
     int subdoc = 1;                           // cut documents at context-free boundaries to balance the GPUs
@@ -369,6 +377,9 @@ struct spl_tokenizer {
     int small_path = 1;                       // batches of up to 4 KB take the latency path (encode_small)
     int slab_pack24 = 0;                      // the ids of the all-gather slabs travel three bytes each (spl_set_option "slab_pack24": every rank alike)
     int sdma_d2h = 0;                         // (measured, +0.5..3 %: not the default) pipeline chunks: their ids leave through hsa_amd_memory_async_copy (an SDMA engine) instead of hipMemcpyAsync
+    int copy_threads = 4;                     // pipeline, pageable input: threads that copy a chunk into pinned staging
+    int twin_streams = 1;                     // pipeline: consecutive chunks' kernels on two streams / workspaces (Ctx::twin)
+    int chunk_ramp = 0;                       // pipeline: a lane's first and last chunk are a quarter of the others (a shorter first H2D and last D2H)
     int direct_read = 1;                      // one-chunk batches from pinned memory: the tile kernel reads text and offsets where they lie (no H2D copy)
     uint64_t small_calls = 0;                 // ... and how many did (spl_small_path_calls)
 };
@@ -1211,6 +1222,8 @@ int lane_prepare(spl_tokenizer* tk, Lane& ln, const uint64_t* doc_off, uint64_t 
     auto start_of = [&](uint64_t d) { return std::max(doc_off[d], ln.lo); };
     auto end_of = [&](uint64_t d) { return std::min(doc_off[d + 1], ln.hi); };
     uint64_t max_bytes = 0, max_docs = 0, oo_words = 0;
+    const uint64_t small = std::max<uint64_t>(chunk_target / 4, 512ull << 10);
+    const bool ramp = tk->chunk_ramp && ln.hi - ln.lo >= 2 * chunk_target && chunk_target >= (2ull << 20);
     uint64_t d = dlo;
     do {
         Chunk ch{};
@@ -1218,10 +1231,17 @@ int lane_prepare(spl_tokenizer* tk, Lane& ln, const uint64_t* doc_off, uint64_t 
         ch.lo = d < dhi ? start_of(d) : ln.lo;
         ch.cont = (d == dlo) && cont;
         uint64_t e = d;
-        // (chunk sizes that ramp up at the start and down at the end -- a shorter first H2D and last D2H --
-        //  measured no better: C3 15.1 vs 15.8 GB/s, C4 17.2 vs 16.6, C5 14.9 vs 15.9; a chunk costs ~80 us of
-        //  host-side API work, so fewer, equal chunks win)
-        while (e < dhi && (e == d || end_of(e) - ch.lo <= chunk_target)) e++;
+        // (the lane's first and last chunk are a quarter of the others: what nothing overlaps is the first chunk's H2D and the
+        //  last one's D2H -- 153 + 164 us of a 1.7 ms call on C3 with five equal chunks, profiles/r05_host_timeline.txt.  Round 2
+        //  had measured such a ramp as no better, when a chunk cost ~80 us of host-side API work and the kernels were half as fast.)
+        uint64_t lim = chunk_target;
+        if (ramp && d < dhi) {
+            const uint64_t rem = ln.hi - ch.lo;
+            if (d == dlo) lim = small;
+            else if (rem <= small + small / 2) lim = rem;
+            else if (rem <= chunk_target + small) lim = rem - small;
+        }
+        while (e < dhi && (e == d || end_of(e) - ch.lo <= lim)) e++;
         ch.dhi = e;
         ch.hi = e > d ? end_of(e - 1) : ch.lo;
         if (e == dhi) ch.hi = ln.hi;
@@ -1261,7 +1281,12 @@ int lane_prepare(spl_tokenizer* tk, Lane& ln, const uint64_t* doc_off, uint64_t 
         if (!src_pinned && !c->h_text[i].ensure(tk->pool, max_bytes + 64)) return fail(SPL_EDEVICE, "pinned staging allocation failed");
         if (!c->h_off[i].ensure(tk->pool, (max_docs + 1) * 8)) return fail(SPL_EDEVICE, "pinned staging allocation failed");
     }
-    if (!c->h_tot.ensure(tk->pool, ln.chunks.size() * 8)) return fail(SPL_EDEVICE, "pinned staging allocation failed");
+    {
+        if (!c->h_oo.ensure(tk->pool, oo_words * 8)) return fail(SPL_EDEVICE, "pinned staging allocation failed");
+        void* dp = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&dp, c->h_oo.p, 0));
+        c->dh_oo = (uint64_t*)dp;
+    }
     if (tk->regex) {                                         // boundary bitmaps of a chunk: starts | gaps
         const uint64_t words = 2 * (max_bytes / 32 + 4);
         if (words > c->ext_cap_words) {
@@ -1277,6 +1302,16 @@ int lane_prepare(spl_tokenizer* tk, Lane& ln, const uint64_t* doc_off, uint64_t 
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         c->ev_chunk.push_back(e);
     }
+    if (tk->twin_streams && !tk->regex && ln.chunks.size() >= 3) {
+        if (!c->twin) {
+            c->twin.reset(new Ctx());
+            c->twin->device = c->device;
+            c->twin->dt = c->dt;
+            c->twin->owns_tables = false;
+            if ((rc = ensure_streams(*c->twin))) return rc;
+        }
+        if ((rc = reserve(c->twin.get(), max_bytes, max_docs))) return rc;
+    }
     return reserve(c, max_bytes, max_docs);
 }
 
@@ -1285,10 +1320,10 @@ int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t
                 bool solo = false, uint32_t* ids_direct = nullptr, bool mapped = false) {
     Ctx* c = ln.c;
     HIP_TRY(hipSetDevice(c->device));
-    uint64_t* const h_tot = (uint64_t*)c->h_tot.p;
     for (size_t k = 0; k < ln.chunks.size(); k++) {
         const Chunk& ch = ln.chunks[k];
         const int sl = (int)(k % NSLOT);
+        Ctx* const w = (!solo && c->twin && (k & 1)) ? c->twin.get() : c;     // whose workspace and compute stream run this chunk's kernels
         const uint64_t nb = ch.hi - ch.lo, nd = ch.dhi - ch.dlo;
         TRACE("submit dev %d chunk %zu/%zu bytes %llu docs %llu", c->device, k, ln.chunks.size(), (unsigned long long)nb, (unsigned long long)nd);
         if (k >= NSLOT) HIP_TRY(hipEventSynchronize(c->ev_h2d[sl]));     // the slot's pinned staging has been read
@@ -1296,7 +1331,21 @@ int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t
         for (uint64_t i = 0; i < nd; i++) rel[i] = std::min(std::max(doc_off[ch.dlo + i], ch.lo), ch.hi) - ch.lo;
         rel[nd] = nb;
         const uint8_t* src = utf8 + ch.lo;
-        if (!src_pinned && nb) { memcpy(c->h_text[sl].p, src, nb); src = (const uint8_t*)c->h_text[sl].p; }
+        if (!src_pinned && nb) {
+            // pageable text into pinned staging: one core copies ~20 GB/s, less than the pipeline behind it takes -- a few of the pool's threads
+            uint8_t* const dst = (uint8_t*)c->h_text[sl].p;
+            const unsigned nt = tk->copy_threads > 1 && nb >= (2ull << 20) ? (unsigned)std::min<uint64_t>(std::min<unsigned>((unsigned)tk->copy_threads, std::max(1u, std::thread::hardware_concurrency())), nb >> 19) : 1u;
+            if (nt <= 1) memcpy(dst, src, nb);
+            else {
+                const uint64_t part = ((nb + nt - 1) / nt + 4095) & ~4095ull;
+                const std::function<void(unsigned)> cp = [&](unsigned q) {
+                    const uint64_t a = std::min<uint64_t>(nb, q * part), e = std::min<uint64_t>(nb, a + part);
+                    if (e > a) memcpy(dst + a, src + a, e - a);
+                };
+                work_pool().run(nt, cp);
+            }
+            src = dst;
+        }
         if (k >= NSLOT) HIP_TRY(hipStreamWaitEvent(c->s_h2d, c->ev_cmp[sl], 0));   // the slot's device text has been consumed
         // (a batch of ONE chunk has nothing to overlap: its copies go on the compute stream, no event in between)
         hipStream_t hs = solo ? c->s_cmp : c->s_h2d;
@@ -1314,9 +1363,10 @@ int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t
         }
         if (!solo) {
             HIP_TRY(hipEventRecord(c->ev_h2d[sl], c->s_h2d));
-            HIP_TRY(hipStreamWaitEvent(c->s_cmp, c->ev_h2d[sl], 0));
+            HIP_TRY(hipStreamWaitEvent(w->s_cmp, c->ev_h2d[sl], 0));
         }
         uint64_t* oo = c->d_oo + ch.oo_at;
+        if (!solo) { w->off_host = c->dh_oo + ch.oo_at; w->off_host_written = false; }
         c->solo_text = text_arg; c->solo_off = off_arg;          // (a one-chunk batch: where its tile kernel read text and offsets -- the per-document redo reads them again)
         ExtIn ext;
         if (tk->regex) {
@@ -1384,13 +1434,17 @@ int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t
             rc = launch_all(tk, c, text_arg, nb, off_arg, nd, flags, ids_direct ? ids_direct : c->d_ids + (ch.lo - ln.lo), nb + 16, oo, c->s_cmp,
                             nullptr, &ext, 2);
         } else
-            rc = launch_all(tk, c, text_arg, nb, off_arg, nd, flags, ids_direct ? ids_direct : c->d_ids + (ch.lo - ln.lo),
-                            nb + 16, oo, c->s_cmp, nullptr, tk->regex ? &ext : nullptr);
+            rc = launch_all(tk, w, text_arg, nb, off_arg, nd, flags, ids_direct ? ids_direct : c->d_ids + (ch.lo - ln.lo),
+                            nb + 16, oo, w->s_cmp, nullptr, tk->regex ? &ext : nullptr);
         if (rc) return rc;
         if (solo) break;                                   // (the batch is ONE chunk: the caller finishes on the compute stream itself)
-        HIP_TRY(hipEventRecord(c->ev_cmp[sl], c->s_cmp));
-        HIP_TRY(hipMemcpyAsync(&h_tot[k], oo + nd, 8, hipMemcpyDeviceToHost, c->s_cmp));
-        HIP_TRY(hipEventRecord(c->ev_chunk[k], c->s_cmp));
+        HIP_TRY(hipEventRecord(c->ev_cmp[sl], w->s_cmp));
+        // (the chunk's local offsets -- the last one is its token count -- are in pinned memory when the event fires: k_tile_out has written
+        //  them there beside the device copy; up to round 4 an 8-byte copy fetched the count, a kernel rebased the offsets on the device and
+        //  a second copy brought them back: three small operations and their launch gaps per chunk on the streams the kernels wait behind)
+        if (!w->off_host_written) HIP_TRY(hipMemcpyAsync((uint64_t*)c->h_oo.p + ch.oo_at, oo, (nd + 1) * 8, hipMemcpyDeviceToHost, w->s_cmp));
+        w->off_host = nullptr;
+        HIP_TRY(hipEventRecord(c->ev_chunk[k], w->s_cmp));
         ln.submitted.store((uint32_t)k + 1, std::memory_order_release);
     }
     return SPL_OK;
@@ -1650,15 +1704,16 @@ int encode_host(spl_tokenizer* tk, const uint8_t* utf8, const uint64_t* doc_off,
             Lane& ln = lanes[l];
             Ctx* c = ln.c;
             HIP_TRY(hipSetDevice(c->device));
-            const uint64_t* h_tot = (const uint64_t*)c->h_tot.p;
+            const uint64_t* const h_oo = (const uint64_t*)c->h_oo.p;
             for (size_t k = 0; k < ln.chunks.size(); k++) {
                 while (ln.submitted.load(std::memory_order_acquire) <= k) {
                     if (ln.rc.load(std::memory_order_acquire)) return fail(ln.rc.load(), ln.err);
                     std::this_thread::yield();
                 }
                 HIP_TRY(hipEventSynchronize(c->ev_chunk[k]));
+                TRACE("chunk %zu event", k);
                 const Chunk& ch = ln.chunks[k];
-                const uint64_t T = h_tot[k], nd = ch.dhi - ch.dlo;
+                const uint64_t nd = ch.dhi - ch.dlo, T = h_oo[ch.oo_at + nd];
                 TRACE("place lane %zu chunk %zu tokens %llu base %llu", l, k, (unsigned long long)T, (unsigned long long)base);
                 if ((base + T + 16) * 4 > r->ids_cap) {
                     // the first guess was too small: move to a buffer that holds whatever may still come
@@ -1686,19 +1741,22 @@ int encode_host(spl_tokenizer* tk, const uint8_t* utf8, const uint64_t* doc_off,
                 } else
                 if (T) HIP_TRY(hipMemcpyAsync(r->ids + base, c->d_ids + (ch.lo - ln.lo), T * 4, hipMemcpyDeviceToHost, c->s_d2h));
                 const uint64_t skip = ch.cont ? 1 : 0;
-                if (nd > skip) {
-                    uint64_t* oo = c->d_oo + ch.oo_at + skip;
-                    if (base) hipLaunchKernelGGL(k_add_base, dim3((uint32_t)((nd - skip + 255) / 256)), dim3(256), 0, c->s_d2h, oo, nd - skip, base);
-                    HIP_TRY(hipMemcpyAsync(r->off + ch.dlo + skip, oo, (nd - skip) * 8, hipMemcpyDeviceToHost, c->s_d2h));
+                {                                                      // the chunk's offsets, rebased: a few thousand additions on this thread
+                    const uint64_t* const oo = h_oo + ch.oo_at;
+                    uint64_t* const dst = r->off + ch.dlo;
+                    for (uint64_t i = skip; i < nd; i++) dst[i] = oo[i] + base;
                 }
                 base += T;
             }
         }
+        TRACE("all placed, waiting for the copies");
         for (auto& ln : lanes) { HIP_TRY(hipSetDevice(ln.c->device)); HIP_TRY(hipStreamSynchronize(ln.c->s_d2h)); }
         for (hsa_signal_t sg : dma_sigs) hsa_dma().SignalWait(sg, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED);
         return SPL_OK;
     };
+    TRACE("encode_host: producers started");
     rc_all = consume();
+    TRACE("encode_host: consumed");
     if (rc_all) err_all = g_err;
     for (auto& th : producers) th.join();
     for (auto& ln : lanes)
@@ -1886,6 +1944,9 @@ int spl_set_option(spl_tokenizer* t, const char* name, int64_t value) {
     else if (k == "device_split") t->rx_device = value != 0;
     else if (k == "small_path") t->small_path = value != 0;
     else if (k == "direct_read") t->direct_read = value != 0;
+    else if (k == "chunk_ramp") t->chunk_ramp = value != 0;
+    else if (k == "twin_streams") t->twin_streams = value != 0;
+    else if (k == "copy_threads" && value >= 1 && value <= 64) t->copy_threads = (int)value;
     else if (k == "sdma_d2h") t->sdma_d2h = value != 0;
     else if (k == "slab_pack24") t->slab_pack24 = value != 0;        // (where the HSA runtime or the device's agent cannot be found: hipMemcpyAsync, silently)
     else return fail(SPL_EINVAL, "spl_set_option: unknown option or bad value: " + k);
@@ -1921,7 +1982,7 @@ static int spl_add_special_impl(spl_tokenizer* t, const uint8_t* literal, size_t
         if (general) t->special_general = true;
         t->specials.push_back(Special{lit, id});
     }
-    for (auto& c : t->ctx) { c->sp_uploaded = false; c->dec_uploaded = false; }
+    for (auto& c : t->ctx) { c->sp_uploaded = false; c->dec_uploaded = false; if (c->twin) c->twin->sp_uploaded = false; }
     t->max_special_id = 0;
     for (const auto& sp : t->specials) t->max_special_id = std::max(t->max_special_id, sp.id);
     if (lit.find('\n') != std::string::npos) t->special_newline = true;
@@ -1968,6 +2029,7 @@ static int spl_encode_batch_device_packed_impl(spl_tokenizer* t, const uint8_t* 
 int spl_encode_batch(spl_tokenizer* t, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,
                      spl_result** out) {
     if (!t || !doc_off || !out) return fail(SPL_EINVAL, "spl_encode_batch: null argument");
+    TRACE("spl_encode_batch: enter");
     if (doc_off[0] != 0) return fail(SPL_EINVAL, "spl_encode_batch: doc_off[0] must be 0");
     for (uint64_t d = 0; d < n_docs; d++)
         if (doc_off[d + 1] < doc_off[d]) return fail(SPL_EINVAL, "spl_encode_batch: doc_off must be non-decreasing");
@@ -1994,6 +2056,7 @@ int spl_encode_batch(spl_tokenizer* t, const uint8_t* utf8, const uint64_t* doc_
                 c->h_rx_bad[0] = 0;
             }
         int rc = encode_host(t, utf8, doc_off, n_docs, flags, r.get(), !dev_split);
+        TRACE("spl_encode_batch: encode_host returned %d", rc);
         if (rc) return rc;
         if (dev_split) {
             // what the device splitter gave up on (a match longer than RX_REACH, a runaway attempt): the batch again, split on the host

@@ -1,4 +1,4 @@
-// spl_k_decode.h -- part of spl_kernels.hip (included there, in this order; one translation unit): decode (k_decode_len / _scan / _copy / _docs), k_ext_specials, k_add_base, the gather-v slabs and the CSR counts / rebase of the collective.
+// spl_k_decode.h -- part of spl_kernels.hip (included there, in this order; one translation unit): decode (k_decode_len / _scan / _copy / _docs), k_ext_specials, the gather-v slabs and the CSR counts / rebase of the collective.
 #pragma once
 
 namespace spl {
@@ -113,12 +113,6 @@ __global__ void k_ext_specials(Batch b, const uint32_t* pos, const uint32_t* id,
     const uint32_t p = pos[i];
     b.stage[p] = id[i];
     atomicOr(&b.tbits[p >> 5], 1u << (p & 31));
-}
-
-// Host pipeline (spl_encode_batch): chunk-local output offsets -> offsets in the whole result.
-__global__ void k_add_base(uint64_t* p, uint64_t n, uint64_t base) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] += base;
 }
 
 // ------------------------------------------------------------------------------------------

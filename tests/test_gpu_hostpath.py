@@ -113,6 +113,26 @@ def test_pinned_and_pageable_input_and_result_lifetime(coracle):
     ctypes.memmove(p, blob, len(blob))
     ids, oo = t._encode_packed(p, off.ctypes.data, len(bs), 0)        # pinned input: DMA straight from it
     assert np.array_equal(ids, want_ids) and np.array_equal(oo, want_off)
+    # a batch of several chunks from pageable memory: the chunks are copied into pinned staging by several threads, the kernels of
+    # consecutive chunks run on two streams (the context and its twin); the same batch from pinned memory; both against the oracle
+    big = corpus.c3(3200, seed=5)                                      # ~13 MB: three chunks of <= 5 MiB
+    bb = [x.encode() for x in big]
+    boff = np.zeros(len(bb) + 1, dtype=np.uint64)
+    np.cumsum([len(b) for b in bb], out=boff[1:])
+    bblob = b"".join(bb)
+    t3 = Tokenizer.from_pretrained("o200k_base")
+    big_ids, big_off = oracle_csr(coracle("o200k_base"), big)
+    for opts in ({}, {"copy_threads": 1}, {"twin_streams": 0}, {"chunk_ramp": 1}):
+        for k, v in opts.items():
+            assert L.spl_set_option(t3.handle, k.encode(), v) == 0
+        ids, oo = t3.encode_packed(bblob, boff)
+        assert np.array_equal(ids, big_ids) and np.array_equal(oo, big_off), opts
+    pb = L.spl_host_alloc(len(bblob) + 64)
+    ctypes.memmove(pb, bblob, len(bblob))
+    ids, oo = t3._encode_packed(pb, boff.ctypes.data, len(bb), 0)
+    assert np.array_equal(ids, big_ids) and np.array_equal(oo, big_off)
+    L.spl_host_free(pb)
+    del t3
     # two results alive at once, one of them outliving the handle
     r1, r2 = ctypes.c_void_p(), ctypes.c_void_p()
     assert L.spl_encode_batch(t.handle, p, off.ctypes.data, len(bs), 0, ctypes.byref(r1)) == 0
