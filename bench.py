@@ -36,6 +36,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+# HIP multiplexes a process's streams onto FOUR hardware queues by default; the distributed legs keep an encode stream or two, an exchange
+# stream and RCCL's own busy at once.  Eight queues, unless the caller chose: fewer streams share one.  (What matters more -- which busy
+# streams share a PIPE of the command processor -- cannot be set from here: the strong legs' calibration tries three pairs of encode streams,
+# profiles/r05_wave_exchange.txt.)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -161,6 +166,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # the distributed legs encode on a stream of their own, never on the NULL stream: a launch there synchronises with the other
+        # streams' work (one encode stream: 1.80 ms per WaveGather step on the null stream, 1.06 on any other)
+        torch.cuda.set_stream(torch.cuda.Stream(dev))
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -761,6 +769,12 @@ def run_strong(vocab, texts, steps, rank, world, local_rank, dev, use_dist, nchk
     waves = texts if use_dist else [texts]
     subs = [DeviceBatch(w, dev) for w in waves]
     reserve(tok, max(b.n_bytes for b in subs), max(b.n_docs for b in subs))
+    tok2 = None
+    if use_dist:
+        # a second handle: WaveGather encodes consecutive waves on two streams in alternation (a rank's slice of a wave is 3.4 MB at 8 ranks:
+        # launches of that size one after the other run at 30 GB/s, in alternation at 39 -- tools/dev/wave_overlap.py)
+        tok2 = Tokenizer.from_pretrained(vocab, device=local_rank)
+        reserve(tok2, max(b.n_bytes for b in subs), max(b.n_docs for b in subs))
     orc = COracle(vocab)
     csr = []
     for bi, (b, w) in enumerate(zip(subs, waves)):
@@ -794,7 +808,7 @@ def run_strong(vocab, texts, steps, rank, world, local_rank, dev, use_dist, nchk
         def make(form):
             return WaveGather(tok, dev, comm, K, max_docs=int(mx[1].item()), max_tokens=int(int(mx[0].item()) * 1.02) + 64,
                               total_tokens_cap=int(tot[0].item()) + 64, total_docs_cap=int(tot[1].item()), collective=form.split("+")[0],
-                              pack24=form.endswith("pack24"))
+                              pack24="pack24" in form, tok2=tok2 if "+2s" in form else None, enc_pair=int(form.split("@")[1]) if "@" in form else 0)
 
         def step_with(g_):
             g_.begin()
@@ -802,7 +816,10 @@ def run_strong(vocab, texts, steps, rank, world, local_rank, dev, use_dist, nchk
                 g_.encode_and_submit(b)
             return g_.finish()
         # calibration of the collective form (untimed): ncclAllGather of the wave's slabs against grouped send / recv
-        for form in ("allgather", "p2p", "allgather+pack24"):
+        # ... and one or two encode streams ("+2s": consecutive waves on two handles in alternation -- fewer idle CUs between the launches of
+        # small waves, but the exchange then has no idle CUs to hide in)
+        # (two streams that land on one pipe of the command processor take turns: which do is not knowable, so three pairs are tried)
+        for form in ("allgather", "p2p", "allgather+pack24") + tuple(f"{f_}+2s@{p_}" for p_ in range(3) for f_ in ("allgather", "allgather+pack24")):
             g_ = make(form)
             for _ in range(2):
                 step_with(g_)
@@ -866,10 +883,16 @@ def run_strong(vocab, texts, steps, rank, world, local_rank, dev, use_dist, nchk
     if use_dist:
         local_ms = el / steps * 1e3
         # untimed repeats: the encodes alone, and what the exchange stream spent in collective + unpack (events around them)
+        from splintr_amd.device import encode_streams
+        es_ = encode_streams(dev, wg.enc_pair)
         e0 = time.perf_counter()
         for _ in range(steps):
-            for b in subs:
-                encode_device(tok, b)
+            for k_, b in enumerate(subs):                          # as WaveGather encodes them: on one stream, or two handles and streams in alternation
+                if wg.enc is None:
+                    encode_device(tok, b)
+                else:
+                    with torch.cuda.stream(es_[k_ & 1]):
+                        encode_device((tok, tok2)[k_ & 1], b)
         torch.cuda.synchronize()
         enc_ms = (time.perf_counter() - e0) / steps * 1e3
         dist.barrier()
@@ -897,10 +920,11 @@ def run_strong(vocab, texts, steps, rank, world, local_rank, dev, use_dist, nchk
                      "calibration_ms_per_step": {k_: round(v_, 4) for k_, v_ in cal.items()},
                      "slab_bytes_sent_per_wave": wg.cap_words * 4, "bytes_received_per_rank": wg.cap_words * 4 * world * len(subs),
                      "ids_bytes_4T": 4 * tot_t,
+                     "encode_streams": 1 if wg.enc is None else 2,
                      "note": "WaveGather: the batch is exchanged in `waves` waves; rank r encodes its slice of wave k into a slab (written by the encoder's "
-                             "last kernel), ONE exchange of the wave's slabs + an unpack behind what the earlier waves left run on an exchange stream while "
+                             "last kernel; with encode_streams 2 consecutive waves on two handles and streams in alternation), ONE exchange of the wave's slabs + an unpack behind what the earlier waves left run on an exchange stream while "
                              "wave k + 1 encodes; no host synchronisation inside a step.  exposed = slowest step - slowest encodes-only"}
-    del subs, tok, comm, wg
+    del subs, tok, tok2, comm, wg
     torch.cuda.empty_cache()
     if rank != 0:
         return None

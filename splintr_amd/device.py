@@ -137,6 +137,22 @@ def exchange_stream(device: torch.device) -> "torch.cuda.Stream":
     return st
 
 
+_ENC_STREAMS = {}
+
+
+def encode_streams(device: torch.device, pair: int = 0):
+    """Two streams per process and GPU on which WaveGather encodes consecutive waves in alternation -- pair `pair` of three pairs created
+    once.  HIP multiplexes a process's streams onto a few hardware queues, and hardware queues onto four pipes of the command processor:
+    two busy streams that end up on one pipe take turns instead of running side by side (kernel trace: every small kernel of such a stream
+    takes 40 - 55 us instead of 4 - 13, the tile kernels 215 us instead of 130).  Which streams share is decided by what else the process has
+    created; nothing in the HIP API tells.  So a caller that can afford a calibration tries the pairs and keeps the fastest (bench.py)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    st = _ENC_STREAMS.get(key)
+    if st is None:
+        st = _ENC_STREAMS[key] = tuple(torch.cuda.Stream(device=device) for _ in range(6))
+    return st[2 * (pair % 3)], st[2 * (pair % 3) + 1]
+
+
 def _set_pack24(tok: Optional[Tokenizer], on: bool) -> None:
     if tok is None:                              # the bucket logic driven without an encoder (CPU tests): slabs come from the caller
         return
@@ -349,11 +365,21 @@ class WaveGather:
     Order it replaces: Rayon's order-preserving collect, src/core/tokenizer.rs:932-942."""
 
     def __init__(self, tok: Tokenizer, device: torch.device, comm: "Comm", n_waves: int, max_docs: int, max_tokens: int,
-                 total_tokens_cap: int, total_docs_cap: int, collective: str = "allgather", pack24: bool = False):
+                 total_tokens_cap: int, total_docs_cap: int, collective: str = "allgather", pack24: bool = False,
+                 tok2: Optional[Tokenizer] = None, enc_pair: int = 0):
         self.tok, self.dev, self.comm, self.world = tok, device, comm, comm.world
         self.n_waves, self.max_docs, self.max_tokens = int(n_waves), int(max_docs), int(max_tokens)
         self.pack24 = bool(pack24)
         _set_pack24(tok, self.pack24)
+        # A second handle of the same vocabulary (a workspace of its own): consecutive waves are then encoded on two streams in alternation,
+        # wave k + 1's tile kernel starting while the stragglers of wave k's finish.  A rank's slice of a wave is small at high rank counts
+        # (3.4 MB at 8 ranks x 8 waves), and launches of that size one after the other leave the GPU to every launch's ramp and tail: eight
+        # of them took 0.90 ms on one stream, 0.69 ms on two -- one launch of the 27 MB: 0.63 (profiles/r05_wave_exchange.txt).
+        self.toks = (tok,) if tok2 is None else (tok, tok2)
+        if tok2 is not None:
+            _set_pack24(tok2, self.pack24)
+        self.enc = encode_streams(device, enc_pair) if tok2 is not None else None
+        self.enc_pair = int(enc_pair)
         self.cap_words = _slab_words(self.max_tokens, self.max_docs, self.pack24)
         if self.cap_words >= 1 << 32:
             raise ValueError("WaveGather: a slab must stay below 2**32 words")
@@ -387,14 +413,18 @@ class WaveGather:
         self.k = 0
         with torch.cuda.stream(self.exch):
             self.run.zero_()
+        if self.enc is not None:                 # what the caller has queued so far (the batches' text) comes first
+            main = torch.cuda.current_stream(self.dev)
+            for st in self.enc:
+                st.wait_stream(main)
 
     def encode_and_submit(self, batch: "DeviceBatch", with_special: bool = False) -> None:
         """This rank's slice of the next wave: encode (slab written by the encoder's last kernel) on the current stream, exchange and
         unpack on the exchange stream."""
         L = _ffi.lib()
         k = self.k
-        main = torch.cuda.current_stream(self.dev)
-        rc = L.spl_encode_batch_device_packed(self.tok.handle, batch.text.data_ptr(), batch.n_bytes, batch.doc_off.data_ptr(), batch.n_docs,
+        main = torch.cuda.current_stream(self.dev) if self.enc is None else self.enc[k & 1]
+        rc = L.spl_encode_batch_device_packed(self.toks[k % len(self.toks)].handle, batch.text.data_ptr(), batch.n_bytes, batch.doc_off.data_ptr(), batch.n_docs,
                                               _ffi.SPL_WITH_SPECIAL if with_special else 0, batch.ids.data_ptr(), batch.ids.numel(),
                                               batch.out_off.data_ptr(), self.send[k].data_ptr(), self.cap_words, self.max_docs, main.cuda_stream)
         if rc != 0:

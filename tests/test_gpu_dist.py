@@ -85,9 +85,12 @@ def test_gatherv_pipeline_one_rank_rccl(coracle):
         # ... and the waves of ONE batch landing behind each other (WaveGather over the library's communicator, both slab formats)
         from splintr_amd.device import Comm, WaveGather
         comm = Comm(Comm.unique_id(), 0, 1, 0)
-        for p24 in (False, True):
+        tok_b = Tokenizer.from_pretrained("cl100k_base")          # a second handle: consecutive waves on two streams in alternation
+        reserve(tok_b, max(b.n_bytes for b in batches), max(b.n_docs for b in batches))
+        for p24, t2 in ((False, None), (True, None), (False, tok_b), (True, tok_b)):
             wg = WaveGather(tok, dev, comm, 5, max_docs=max(b.n_docs for b in batches), max_tokens=max_tok + 64,
-                            total_tokens_cap=sum(int(w[1][-1]) for w in want) + 64, total_docs_cap=sum(b.n_docs for b in batches), pack24=p24)
+                            total_tokens_cap=sum(int(w[1][-1]) for w in want) + 64, total_docs_cap=sum(b.n_docs for b in batches), pack24=p24,
+                            tok2=t2)
             for _ in range(2):                                     # (twice: the running totals start over)
                 wg.begin()
                 for b in batches:
@@ -211,7 +214,8 @@ def test_bench_distributed_branch_rehearsal_world_1():
         assert c["scaling"] == "strong" and c["value"] > 0 and "bit-exact" in c["parity"], c
         cd = c["dist"]
         assert cd["rccl_ranks"] == 1 and cd["per_rank"]["exchange_stream_ms"][0] > 0 and cd["waves"] == 8, c
-        assert set(cd["calibration_ms_per_step"]) == {"allgather", "p2p", "allgather+pack24"} and cd["collective"] in ("allgather", "p2p")
+        assert set(cd["calibration_ms_per_step"]) == {"allgather", "p2p", "allgather+pack24"} | {f"{f}+2s@{p}" for p in range(3) for f in ("allgather", "allgather+pack24")}
+        assert cd["collective"] in ("allgather", "p2p") and cd["encode_streams"] in (1, 2)
         assert cd["bytes_received_per_rank"] >= cd["ids_bytes_4T"] * (3 if cd["pack24"] else 4) // 4 > 0
         # pipelined: what the exchange adds to a step is (at most) the last wave's exchange, not all of it (<= 5 % of the
         # step at full size; the rehearsal's waves are 2-3 MB, a step is under a millisecond and the exchange with itself shares the GPU with the encodes: 40 %; full size at world 1: profiles/r05_wave_exchange.txt)
