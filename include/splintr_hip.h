@@ -126,7 +126,11 @@ uint32_t spl_n_devices(const spl_tokenizer* t);
  * run on two compute streams with a workspace each, so that a chunk's tile kernel starts while the stragglers of the previous one finish:
  * 24.1 -> 28.8 GB/s host -> host on the 40 MB batch together with the smaller chunks; built-in patterns only), "copy_threads" (1..64,
  * default 4: threads that copy a chunk of PAGEABLE text into pinned staging -- one core copies ~19 GB/s, less than the pipeline takes:
- * 18.7 -> 27.6 GB/s from pageable memory), "chunk_ramp" (0/1, default 0: a lane's first and last chunk a quarter of the others;
+ * 18.7 -> 27.6 GB/s from pageable memory), "pick_streams" (0/1, default 1: the pipeline's copy streams and second compute stream are chosen by
+ * MEASUREMENT at the pipeline's first use on a context -- a 120 us spin kernel on one stream, four empty kernels on the candidate -- so that
+ * they really run side by side: HIP maps streams to hardware queues, and queues to the four pipes of the command processor, by what else
+ * the process has created, and two busy queues on one pipe take turns; without it the same call measured 29 or 20-22 GB/s depending on
+ * the process's other streams; costs 5-80 ms once), "chunk_ramp" (0/1, default 0: a lane's first and last chunk a quarter of the others;
  * measured no better or worse on every BASELINE configuration). */
 int spl_set_option(spl_tokenizer* t, const char* name, int64_t value);
 

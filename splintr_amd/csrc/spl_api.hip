@@ -217,6 +217,7 @@ static double g_ht[8]; static int g_htn;
 #define HT_T(v) do { } while (0)
 #define HT_ACC(i, a, b_) do { } while (0)
 #endif
+inline double mono_us() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec * 1e6 + (double)ts.tv_nsec * 1e-3; }
 inline double trace_us() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)(ts.tv_sec % 1000) * 1e6 + (double)ts.tv_nsec * 1e-3; }
 #define TRACE(...) do { if (trace_on()) { fprintf(stderr, "[spl %12.1f] ", trace_us()); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 
@@ -273,6 +274,7 @@ struct Ctx {
     // stream of its own, the tables shared -- so that chunk k + 1's tile kernel starts while the stragglers of chunk k's finish
     std::unique_ptr<Ctx> twin;
     bool owns_tables = true;
+    bool streams_picked = false;              // the pipeline's copy streams have been chosen by measurement (pick_stream_beside)
     Pinned h_text[NSLOT], h_off[NSLOT], h_oo;          // h_oo: the pipeline chunks' local output offsets (k_tile_out writes them there: no copy, no count to fetch)
     uint64_t* dh_oo = nullptr;                          // its device-side address
     // custom split patterns: the chunk's boundary bitmaps (starts | gaps, back to back) and the special tokens the
@@ -378,6 +380,7 @@ struct spl_tokenizer {
     int slab_pack24 = 0;                      // the ids of the all-gather slabs travel three bytes each (spl_set_option "slab_pack24": every rank alike)
     int sdma_d2h = 0;                         // (measured, +0.5..3 %: not the default) pipeline chunks: their ids leave through hsa_amd_memory_async_copy (an SDMA engine) instead of hipMemcpyAsync
     int copy_threads = 4;                     // pipeline, pageable input: threads that copy a chunk into pinned staging
+    int pick_streams = 1;                     // pipeline: its streams chosen by measurement so that they run side by side (pick_stream_beside)
     int twin_streams = 1;                     // pipeline: consecutive chunks' kernels on two streams / workspaces (Ctx::twin)
     int chunk_ramp = 0;                       // pipeline: a lane's first and last chunk are a quarter of the others (a shorter first H2D and last D2H)
     int direct_read = 1;                      // one-chunk batches from pinned memory: the tile kernel reads text and offsets where they lie (no H2D copy)
@@ -441,6 +444,56 @@ int upload_tables(Ctx& c, const HostTables& ht) {
     c.dt.max_key_len = ht.max_key_len;
     c.dt.pattern = (uint32_t)ht.pattern;
     c.dt.all_bytes = ht.all_bytes ? 1u : 0u;
+    return SPL_OK;
+}
+
+// ---- streams that really run side by side -----------------------------------------------------------------------------------------------
+// HIP gives a stream a hardware queue of its own only up to GPU_MAX_HW_QUEUES per priority (4 by default; streams beyond share one and run
+// one behind the other), and the n-th hardware queue a process creates sits on pipe n mod 4 of the command processor: two busy queues on one
+// pipe take turns -- every kernel of either waits tens of microseconds (kernel traces: profiles/r05_wave_exchange.txt, r05_host_pipeline.txt).
+// Which queue a stream gets depends on what else the process has created; the API neither tells nor sets it.  It can be MEASURED: a kernel
+// that spins for 150 us on one stream, a few empty kernels on the other -- 14 us until they are through when the two run side by side, 22 - 55
+// on one pipe, 165 in one queue (tools/dev/queue_probe.hip).  The pipeline's streams are picked that way, once per context.
+__global__ void k_probe_spin(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) { }
+}
+__global__ void k_probe_nop() { }
+double probe_us(hipStream_t spin, hipStream_t other) {       // `spin` busy, four empty kernels on `other`: us until they are through (min of 3; spin null: alone)
+    double best = 1e30;
+    for (int rep = 0; rep < 3; rep++) {
+        if (spin) (void)hipStreamSynchronize(spin);
+        (void)hipStreamSynchronize(other);
+        if (spin) hipLaunchKernelGGL(k_probe_spin, dim3(8), dim3(64), 0, spin, 12000ull);       // wall_clock64: 100 MHz
+        const double t0 = mono_us();
+        for (int k = 0; k < 4; k++) hipLaunchKernelGGL(k_probe_nop, dim3(1), dim3(64), 0, other);
+        (void)hipStreamSynchronize(other);
+        best = std::min(best, mono_us() - t0);
+        if (spin) (void)hipStreamSynchronize(spin);
+    }
+    return best;
+}
+// A new stream that runs beside every stream of `busy` (each of which may be the one that is busy): up to 12 candidates over the three
+// priorities (a priority has queues of its own); the first without a conflict, else the least bad.  *conflict_us: what was left.
+int pick_stream_beside(const std::vector<hipStream_t>& busy, hipStream_t* out, double* conflict_us) {
+    int lo = 0, hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    hipStream_t best_s = nullptr;
+    double best_v = 1e30;
+    for (int k = 0; k < 12; k++) {
+        hipStream_t s = nullptr;
+        HIP_TRY(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, k % 3 == 0 ? 0 : (k % 3 == 1 ? hi : lo)));
+        hipLaunchKernelGGL(k_probe_nop, dim3(1), dim3(64), 0, s);            // (its queue is created with its first use)
+        (void)hipStreamSynchronize(s);
+        const double alone = probe_us(nullptr, s);
+        double worst = 0;
+        for (hipStream_t b : busy) worst = std::max(worst, std::max(probe_us(b, s), probe_us(s, b)) - alone);
+        if (worst < best_v) { if (best_s) (void)hipStreamDestroy(best_s); best_s = s; best_v = worst; }
+        else (void)hipStreamDestroy(s);
+        if (best_v < 5.0) break;
+    }
+    *out = best_s;
+    if (conflict_us) *conflict_us = best_v;
     return SPL_OK;
 }
 
@@ -1302,13 +1355,32 @@ int lane_prepare(spl_tokenizer* tk, Lane& ln, const uint64_t* doc_off, uint64_t 
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         c->ev_chunk.push_back(e);
     }
+    if (ln.chunks.size() >= 2 && !c->streams_picked && tk->pick_streams) {
+        // the pipeline's first use on this context: copy streams that run beside the compute stream (and each other) instead of whatever
+        // the runtime handed out -- a D2H of ids that shares the compute stream's pipe slows both
+        HIP_TRY(hipDeviceSynchronize());
+        hipStream_t d2h = nullptr, h2d = nullptr;
+        double cf = 0;
+        if ((rc = pick_stream_beside({c->s_cmp}, &d2h, &cf))) return rc;
+        TRACE("picked the D2H stream (conflict %.1f us)", cf);
+        if ((rc = pick_stream_beside({c->s_cmp, d2h}, &h2d, &cf))) return rc;
+        TRACE("picked the H2D stream (conflict %.1f us)", cf);
+        (void)hipStreamDestroy(c->s_d2h); (void)hipStreamDestroy(c->s_h2d);
+        c->s_d2h = d2h; c->s_h2d = h2d;
+        c->streams_picked = true;
+    }
     if (tk->twin_streams && !tk->regex && ln.chunks.size() >= 3) {
         if (!c->twin) {
             c->twin.reset(new Ctx());
             c->twin->device = c->device;
             c->twin->dt = c->dt;
             c->twin->owns_tables = false;
-            if ((rc = ensure_streams(*c->twin))) return rc;
+            if (tk->pick_streams) {
+                HIP_TRY(hipDeviceSynchronize());
+                double cf = 0;
+                if ((rc = pick_stream_beside({c->s_cmp, c->s_d2h, c->s_h2d}, &c->twin->s_cmp, &cf))) return rc;
+                TRACE("picked the twin's compute stream (conflict %.1f us)", cf);
+            } else if ((rc = ensure_streams(*c->twin))) return rc;
         }
         if ((rc = reserve(c->twin.get(), max_bytes, max_docs))) return rc;
     }
@@ -1946,6 +2018,7 @@ int spl_set_option(spl_tokenizer* t, const char* name, int64_t value) {
     else if (k == "direct_read") t->direct_read = value != 0;
     else if (k == "chunk_ramp") t->chunk_ramp = value != 0;
     else if (k == "twin_streams") t->twin_streams = value != 0;
+    else if (k == "pick_streams") t->pick_streams = value != 0;
     else if (k == "copy_threads" && value >= 1 && value <= 64) t->copy_threads = (int)value;
     else if (k == "sdma_d2h") t->sdma_d2h = value != 0;
     else if (k == "slab_pack24") t->slab_pack24 = value != 0;        // (where the HSA runtime or the device's agent cannot be found: hipMemcpyAsync, silently)

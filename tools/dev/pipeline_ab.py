@@ -20,6 +20,13 @@ bs = [t.encode() for t in texts]
 off = np.zeros(len(bs) + 1, dtype=np.uint64); np.cumsum([len(b) for b in bs], out=off[1:])
 blob = b"".join(bs); nb = len(blob)
 p = L.spl_host_alloc(nb + 64); ctypes.memmove(p, blob, nb)
+_perturb = int(os.environ.get("PERTURB", "0"))     # that many live torch streams first: shifts which hardware queues the library's streams get
+if _perturb:
+    import torch
+    _keep = [torch.cuda.Stream() for _ in range(_perturb)]
+    for s_ in _keep:
+        with torch.cuda.stream(s_): torch.zeros(16, device="cuda").add_(1)
+    torch.cuda.synchronize()
 toks = []
 for name, o in sets:
     t = Tokenizer.from_pretrained(vocab)
