@@ -296,6 +296,15 @@ int spl_gatherv_unpack_at(spl_tokenizer* t, const uint32_t* d_slabs, uint32_t wo
  *                        from the gathered capacities, so every rank returns it alike and none is left waiting
  *                        in the exchange.  Rank order == document order when rank r holds the r-th contiguous
  *                        shard. */
+/* A new HIP stream on `device` that really runs BESIDE the given ones (an exchange stream beside the encoder's, a second encode stream
+ * beside the first): HIP maps streams to hardware queues and queues to the four pipes of the command processor by what else the process has
+ * created -- two busy streams on one queue run one behind the other, on one pipe they take turns -- and no API tells which.  This call
+ * measures it: up to twelve candidates over the three priorities, a 120 us spin kernel on a given stream and four empty kernels on the
+ * candidate (and the other way round); the first candidate without a conflict, else the least bad one.  *conflict_us (may be NULL): what is
+ * left, 0 when the streams run side by side.  Costs a few ms (synchronises the given streams).  The stream belongs to the caller
+ * (hipStreamDestroy). */
+int spl_pick_stream(int device, void* const* busy_hip_streams, uint32_t n_busy, void** hip_stream_out, double* conflict_us);
+
 #define SPL_COMM_ID_BYTES 128
 typedef struct spl_comm spl_comm;
 int spl_comm_unique_id(uint8_t id_out[SPL_COMM_ID_BYTES]);

@@ -28,7 +28,7 @@ SYMBOLS = [
     "spl_token_bytes", "spl_is_byte_level",
     "spl_comm_unique_id", "spl_comm_create", "spl_comm_destroy", "spl_comm_rank", "spl_comm_world",
     "spl_allgather_slabs", "spl_allgather_slabs_p2p", "spl_gatherv_unpack_at", "spl_allgatherv_csr", "spl_split_host", "spl_encode_chunks_device",
-    "spl_split_device", "spl_device_split_fallbacks", "spl_small_path_calls",
+    "spl_split_device", "spl_device_split_fallbacks", "spl_small_path_calls", "spl_pick_stream",
 ]
 SPL_PATTERN_CUSTOM = 3
 SPL_OPT_BYTE_LEVEL = 1
@@ -121,6 +121,8 @@ def lib() -> ctypes.CDLL:
     L.spl_device_split_fallbacks.argtypes = [vp]
     L.spl_small_path_calls.restype = ctypes.c_uint64
     L.spl_small_path_calls.argtypes = [vp]
+    L.spl_pick_stream.restype = ctypes.c_int
+    L.spl_pick_stream.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_double)]
     L.spl_encode_chunks_device.argtypes = [vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp, vp, ctypes.c_uint64, vp, vp]
     L.spl_comm_unique_id.argtypes = [ctypes.c_char_p]
     L.spl_comm_create.restype = vp

@@ -2505,6 +2505,18 @@ int spl_split_device(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, 
 uint64_t spl_device_split_fallbacks(const spl_tokenizer* t) { return t ? t->rx_fallbacks : 0; }
 uint64_t spl_small_path_calls(const spl_tokenizer* t) { return t ? t->small_calls : 0; }
 
+int spl_pick_stream(int device, void* const* busy_hip_streams, uint32_t n_busy, void** hip_stream_out, double* conflict_us) {
+    if (!hip_stream_out || (n_busy && !busy_hip_streams)) return fail(SPL_EINVAL, "spl_pick_stream: null argument");
+    HIP_TRY(hipSetDevice(device));
+    std::vector<hipStream_t> busy;
+    for (uint32_t i = 0; i < n_busy; i++) busy.push_back((hipStream_t)busy_hip_streams[i]);
+    hipStream_t s = nullptr;
+    int rc = pick_stream_beside(busy, &s, conflict_us);
+    if (rc) return rc;
+    *hip_stream_out = (void*)s;
+    return SPL_OK;
+}
+
 int spl_encode_chunks_device(spl_tokenizer* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
                              uint64_t n_docs, const uint32_t* d_start_bits, const uint32_t* d_gap_bits, uint32_t* d_ids,
                              uint64_t ids_capacity, uint64_t* d_out_off, void* hip_stream) {

@@ -125,15 +125,28 @@ _EXCH_STREAMS = {}
 
 
 def exchange_stream(device: torch.device) -> "torch.cuda.Stream":
-    """THE exchange stream of a device: one per process and GPU, shared by every GatherV / WaveGather on it, at high priority.
-    HIP maps streams onto a handful of hardware queues round-robin in creation order: the n-th stream a process creates may land
-    on the queue the encoder's stream uses, and then the exchange runs BEHIND the encodes instead of beside them (measured: the
-    fourth WaveGather of a process lost the whole overlap, 5.47 -> 6.05 ms per step).  A stream of another priority has a queue
-    of its own, and the exchange is what should be scheduled first when both have work."""
+    """THE exchange stream of a device: one per process and GPU, shared by every GatherV / WaveGather on it.
+    HIP maps streams onto a handful of hardware queues by what else the process has created: the n-th stream may land on the queue
+    (or the command-processor pipe) the encoder's stream uses, and then the exchange runs BEHIND the encodes instead of beside them
+    (measured: the fourth WaveGather of a process lost the whole overlap, 5.47 -> 6.05 ms per step).  The stream is therefore picked
+    by measurement beside the stream that is current when it is first asked for (spl_pick_stream)."""
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     st = _EXCH_STREAMS.get(key)
     if st is None:
-        st = _EXCH_STREAMS[key] = torch.cuda.Stream(device=device, priority=-1)
+        st = _EXCH_STREAMS[key] = pick_stream(device, [torch.cuda.current_stream(device)])
+    return st
+
+
+def pick_stream(device: torch.device, beside) -> "torch.cuda.Stream":
+    """A new stream that really runs beside the streams in `beside` (spl_pick_stream: measured, not assumed)."""
+    import ctypes
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    arr = (ctypes.c_void_p * max(1, len(beside)))(*[ctypes.c_void_p(int(s.cuda_stream)) for s in beside])
+    out, left = ctypes.c_void_p(), ctypes.c_double()
+    if _ffi.lib().spl_pick_stream(idx, arr, len(beside), ctypes.byref(out), ctypes.byref(left)) != 0:
+        raise RuntimeError(_ffi.last_error())
+    st = torch.cuda.ExternalStream(out.value, device=device)
+    st.conflict_us = left.value
     return st
 
 
@@ -145,12 +158,16 @@ def encode_streams(device: torch.device, pair: int = 0):
     once.  HIP multiplexes a process's streams onto a few hardware queues, and hardware queues onto four pipes of the command processor:
     two busy streams that end up on one pipe take turns instead of running side by side (kernel trace: every small kernel of such a stream
     takes 40 - 55 us instead of 4 - 13, the tile kernels 215 us instead of 130).  Which streams share is decided by what else the process has
-    created; nothing in the HIP API tells.  So a caller that can afford a calibration tries the pairs and keeps the fastest (bench.py)."""
+    created; nothing in the HIP API tells.  The streams are therefore PICKED by measurement (spl_pick_stream) beside the exchange stream and
+    each other; a caller that can afford a calibration still tries the pairs and keeps the fastest (bench.py)."""
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
-    st = _ENC_STREAMS.get(key)
-    if st is None:
-        st = _ENC_STREAMS[key] = tuple(torch.cuda.Stream(device=device) for _ in range(6))
-    return st[2 * (pair % 3)], st[2 * (pair % 3) + 1]
+    st = _ENC_STREAMS.setdefault(key, {})
+    p = pair % 3
+    if p not in st:
+        ex = exchange_stream(device)
+        a = pick_stream(device, [ex])
+        st[p] = (a, pick_stream(device, [ex, a]))
+    return st[p]
 
 
 def _set_pack24(tok: Optional[Tokenizer], on: bool) -> None:
