@@ -400,7 +400,10 @@ def main():
     pipelined = None
     if rank == 0 and world == 1 and not use_dist and args.inflight > 1 and not args.no_throughputs:
         toks = [tok] + [Tokenizer.from_pretrained("cl100k_base", device=local_rank) for _ in range(args.inflight - 1)]
-        strs = [torch.cuda.Stream(dev) for _ in range(args.inflight)]
+        from splintr_amd.device import pick_stream
+        strs = [torch.cuda.current_stream(dev)]
+        while len(strs) < args.inflight:          # streams that really run side by side (spl_pick_stream: measured)
+            strs.append(pick_stream(dev, strs))
         for t_ in toks[1:]:
             reserve(t_, max(b.n_bytes for b in batches), max(b.n_docs for b in batches))
 
