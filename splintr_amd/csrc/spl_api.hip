@@ -301,6 +301,14 @@ struct Ctx {
     uint32_t* d_dec_ids = nullptr; uint64_t* d_dec_blk = nullptr; uint64_t* d_dec_idoff = nullptr; uint8_t* d_dec_out = nullptr;
     uint64_t* d_dec_first = nullptr; uint64_t* d_dec_docoff = nullptr;
     uint64_t dec_cap_ids = 0, dec_cap_out = 0, dec_cap_docs = 0;
+    // decode pipeline (large batches): two slots of the same scratch, a second compute stream, events per slot
+    struct DecSlot {
+        uint32_t* ids = nullptr; uint64_t* blk = nullptr; uint64_t* idoff = nullptr; uint64_t* first = nullptr; uint64_t* docoff = nullptr;
+        uint8_t* out = nullptr; uint64_t cap_ids = 0, cap_docs = 0, cap_out = 0;
+        hipEvent_t ev_in = nullptr, ev_len = nullptr, ev_cp = nullptr, ev_out = nullptr;
+    } dslot[2];
+    hipStream_t s_dec2 = nullptr;
+    Pinned h_dtot;
     // profiling
     bool prof = false;
     hipEvent_t ev[KI_N + 1]{};
@@ -347,6 +355,11 @@ struct Ctx {
         if (h_small) (void)hipHostFree(h_small);
         hipFree(d_rx_patch); hipFree(d_rx_bad); if (h_rx_bad) (void)hipHostFree(h_rx_bad); if (ev_split) (void)hipEventDestroy(ev_split);
         hipFree(d_dec_ids); hipFree(d_dec_blk); hipFree(d_dec_idoff); hipFree(d_dec_out); hipFree(d_dec_first); hipFree(d_dec_docoff);
+        for (auto& ds : dslot) {
+            hipFree(ds.ids); hipFree(ds.blk); hipFree(ds.idoff); hipFree(ds.first); hipFree(ds.docoff); hipFree(ds.out);
+            for (hipEvent_t e : {ds.ev_in, ds.ev_len, ds.ev_cp, ds.ev_out}) if (e) (void)hipEventDestroy(e);
+        }
+        if (s_dec2) (void)hipStreamDestroy(s_dec2);
         if (ev_ready) for (auto& e : ev) (void)hipEventDestroy(e);
         for (int i = 0; i < NSLOT; i++) { if (ev_h2d[i]) (void)hipEventDestroy(ev_h2d[i]); if (ev_cmp[i]) (void)hipEventDestroy(ev_cmp[i]); }
         for (auto e : ev_chunk) (void)hipEventDestroy(e);
@@ -379,6 +392,7 @@ struct spl_tokenizer {
     int small_path = 1;                       // batches of up to 4 KB take the latency path (encode_small)
     int slab_pack24 = 0;                      // the ids of the all-gather slabs travel three bytes each (spl_set_option "slab_pack24": every rank alike)
     int sdma_d2h = 0;                         // (measured, +0.5..3 %: not the default) pipeline chunks: their ids leave through hsa_amd_memory_async_copy (an SDMA engine) instead of hipMemcpyAsync
+    uint64_t dec_chunk_ids = 2ull << 20;      // decode pipeline: ids per chunk (batches of fewer than three such chunks are decoded in one piece; C3: 28.3 GB/s at 1 M, 30.5 at 2 M, 29.6 at 3 M)
     int copy_threads = 4;                     // pipeline, pageable input: threads that copy a chunk into pinned staging
     int pick_streams = 1;                     // pipeline: its streams chosen by measurement so that they run side by side (pick_stream_beside)
     int twin_streams = 1;                     // pipeline: consecutive chunks' kernels on two streams / workspaces (Ctx::twin)
@@ -2020,6 +2034,7 @@ int spl_set_option(spl_tokenizer* t, const char* name, int64_t value) {
     else if (k == "twin_streams") t->twin_streams = value != 0;
     else if (k == "pick_streams") t->pick_streams = value != 0;
     else if (k == "copy_threads" && value >= 1 && value <= 64) t->copy_threads = (int)value;
+    else if (k == "decode_chunk_ids" && value >= 1024) t->dec_chunk_ids = (uint64_t)value;
     else if (k == "sdma_d2h") t->sdma_d2h = value != 0;
     else if (k == "slab_pack24") t->slab_pack24 = value != 0;        // (where the HSA runtime or the device's agent cannot be found: hipMemcpyAsync, silently)
     else return fail(SPL_EINVAL, "spl_set_option: unknown option or bad value: " + k);
@@ -2168,6 +2183,137 @@ void* spl_host_alloc(size_t bytes) {
 }
 void spl_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
+// ---- decode of a LARGE batch as a pipeline -------------------------------------------------------------------------------------
+// In one piece (below) a 12.5 M-token batch is 0.9 ms of H2D, 0.3 ms of kernels and 0.75 ms of D2H one after the other.  Here the batch goes
+// in chunks of whole documents through two slots of scratch: the ids of chunk k + 1 travel in and are measured (k_decode_len / k_decode_scan on
+// the compute stream) while chunk k's bytes are gathered (k_decode_copy / k_decode_docs on a second compute stream, picked to run beside the
+// first) and travel out.  The host learns a chunk's byte count from pinned memory, knows where its bytes go in the ONE result, and launches
+// its second half; document offsets leave the device already rebased.
+struct DecOut {
+    std::shared_ptr<PinnedPool> pool; uint8_t* b = nullptr; uint64_t* o = nullptr; size_t bcap = 0, ocap = 0;
+    ~DecOut() { if (b) pool->put(b, bcap); if (o) pool->put(o, ocap); }
+};
+static int decode_pipelined(spl_tokenizer* t, Ctx* c, const uint32_t* ids, const uint64_t* ids_off, uint64_t n_docs, DecOut& o) {
+    struct DC { uint64_t d0, d1; };
+    std::vector<DC> ch;
+    uint64_t max_ids = 0, max_docs = 0;
+    for (uint64_t d = 0; d < n_docs;) {
+        uint64_t e = d + 1;
+        while (e < n_docs && ids_off[e + 1] - ids_off[d] <= t->dec_chunk_ids) e++;
+        ch.push_back(DC{d, e});
+        max_ids = std::max(max_ids, ids_off[e] - ids_off[d]);
+        max_docs = std::max(max_docs, e - d);
+        d = e;
+    }
+    const uint64_t n = ids_off[n_docs] - ids_off[0];
+    int rc;
+    if (!c->s_dec2) {
+        HIP_TRY(hipDeviceSynchronize());
+        double cf = 0;
+        if (t->pick_streams) { if ((rc = pick_stream_beside({c->s_cmp, c->s_d2h, c->s_h2d}, &c->s_dec2, &cf))) return rc; }
+        else HIP_TRY(hipStreamCreateWithFlags(&c->s_dec2, hipStreamNonBlocking));
+    }
+    for (auto& ds : c->dslot) {
+        if (!ds.ev_in) for (hipEvent_t* e : {&ds.ev_in, &ds.ev_len, &ds.ev_cp, &ds.ev_out}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        if (max_ids > ds.cap_ids) {
+            HIP_TRY(hipDeviceSynchronize());
+            hipFree(ds.ids); hipFree(ds.blk); hipFree(ds.idoff);
+            ds.ids = nullptr; ds.blk = nullptr; ds.idoff = nullptr;
+            ds.cap_ids = max_ids + max_ids / 4 + 4096;
+            HIP_TRY(hipMalloc((void**)&ds.ids, ds.cap_ids * 4));
+            HIP_TRY(hipMalloc((void**)&ds.blk, (ds.cap_ids / DEC_BLK + 4) * 8));
+            HIP_TRY(hipMalloc((void**)&ds.idoff, (ds.cap_ids + 1) * 8));
+        }
+        if (max_docs + 1 > ds.cap_docs) {
+            HIP_TRY(hipDeviceSynchronize());
+            hipFree(ds.first); hipFree(ds.docoff);
+            ds.first = nullptr; ds.docoff = nullptr;
+            ds.cap_docs = max_docs + 1 + max_docs / 4 + 1024;
+            HIP_TRY(hipMalloc((void**)&ds.first, ds.cap_docs * 8));
+            HIP_TRY(hipMalloc((void**)&ds.docoff, ds.cap_docs * 8));
+        }
+    }
+    if (!c->h_dtot.ensure(t->pool, ch.size() * 8)) return fail(SPL_EDEVICE, "spl_decode_batch: pinned allocation failed");
+    uint64_t* const h_tot = (uint64_t*)c->h_dtot.p;
+    // the result: a first guess of its size (5 bytes per token), moved to a larger buffer if a chunk does not fit
+    o.b = (uint8_t*)t->pool->get(n * 5 + 4096, o.bcap);
+    if (!o.b) return fail(SPL_EDEVICE, "spl_decode_batch: pinned allocation failed");
+    auto args_of = [&](size_t k) {
+        const DC& q = ch[k];
+        Ctx::DecSlot& ds = c->dslot[k & 1];
+        DecodeArgs a{};
+        a.ids = ds.ids; a.n_ids = ids_off[q.d1] - ids_off[q.d0]; a.tok_off = c->d_tok_off; a.tok_bytes = c->d_tok_bytes; a.max_id = c->dec_max_id;
+        a.sp_ids = c->d_dec_sp_ids; a.sp_off = c->d_dec_sp_off; a.n_sp = c->dec_n_sp;
+        a.blk = ds.blk; a.id_off = ds.idoff; a.doc_first = ds.first; a.n_docs = q.d1 - q.d0; a.doc_off = ds.docoff; a.out = ds.out;
+        return a;
+    };
+    auto submit_len = [&](size_t k) -> int {                  // ids in, lengths, the chunk's byte count to pinned memory
+        const DC& q = ch[k];
+        Ctx::DecSlot& ds = c->dslot[k & 1];
+        if (k >= 2) { HIP_TRY(hipStreamWaitEvent(c->s_h2d, ds.ev_cp, 0)); HIP_TRY(hipStreamWaitEvent(c->s_cmp, ds.ev_cp, 0)); }   // the slot's previous chunk has been gathered
+        const DecodeArgs a = args_of(k);
+        if (a.n_ids) HIP_TRY(hipMemcpyAsync(ds.ids, ids + ids_off[q.d0], a.n_ids * 4, hipMemcpyHostToDevice, c->s_h2d));
+        HIP_TRY(hipMemcpyAsync(ds.first, ids_off + q.d0, (a.n_docs + 1) * 8, hipMemcpyHostToDevice, c->s_h2d));
+        HIP_TRY(hipEventRecord(ds.ev_in, c->s_h2d));
+        HIP_TRY(hipStreamWaitEvent(c->s_cmp, ds.ev_in, 0));
+        const uint64_t n_blk = (a.n_ids + DEC_BLK - 1) / DEC_BLK;
+        if (n_blk) hipLaunchKernelGGL(k_decode_len, dim3((uint32_t)n_blk), dim3(NT), 0, c->s_cmp, a);
+        hipLaunchKernelGGL(k_decode_scan, dim3(1), dim3(1024), 0, c->s_cmp, ds.blk, n_blk);
+        HIP_TRY(hipMemcpyAsync(&h_tot[k], ds.blk + n_blk, 8, hipMemcpyDeviceToHost, c->s_cmp));
+        HIP_TRY(hipEventRecord(ds.ev_len, c->s_cmp));
+        return SPL_OK;
+    };
+    uint64_t base = 0;
+    auto finish = [&](size_t k) -> int {                      // bytes gathered, rebased offsets, both on their way into the result
+        const DC& q = ch[k];
+        Ctx::DecSlot& ds = c->dslot[k & 1];
+        HIP_TRY(hipEventSynchronize(ds.ev_len));
+        const uint64_t total = h_tot[k];
+        if (total + 16 > ds.cap_out) {                        // (grow-only; the slot's previous bytes have left: its event first)
+            if (k >= 2) HIP_TRY(hipEventSynchronize(ds.ev_out));
+            HIP_TRY(hipDeviceSynchronize());
+            hipFree(ds.out); ds.out = nullptr;
+            ds.cap_out = total + total / 4 + 4096;
+            HIP_TRY(hipMalloc((void**)&ds.out, ds.cap_out));
+        }
+        if (base + total > o.bcap) {                          // the guess was too small: what is still to come is at most 128 bytes per token
+            HIP_TRY(hipStreamSynchronize(c->s_d2h));
+            const uint64_t rest_ids = ids_off[n_docs] - ids_off[q.d1];
+            size_t ncap = 0;
+            uint8_t* nb = (uint8_t*)t->pool->get(base + total + rest_ids * 8 + 4096, ncap);
+            if (!nb) return fail(SPL_EDEVICE, "spl_decode_batch: pinned allocation failed");
+            memcpy(nb, o.b, base);
+            t->pool->put(o.b, o.bcap);
+            o.b = nb; o.bcap = ncap;
+        }
+        DecodeArgs a = args_of(k);
+        a.out_base = base;
+        if (k >= 2) HIP_TRY(hipStreamWaitEvent(c->s_dec2, ds.ev_out, 0));     // the slot's previous bytes and offsets have left
+        HIP_TRY(hipStreamWaitEvent(c->s_dec2, ds.ev_len, 0));
+        const uint64_t n_blk = (a.n_ids + DEC_BLK - 1) / DEC_BLK;
+        if (n_blk) hipLaunchKernelGGL(k_decode_copy, dim3((uint32_t)n_blk), dim3(NT), 0, c->s_dec2, a);
+        else HIP_TRY(hipMemsetAsync(ds.idoff, 0, 8, c->s_dec2));              // (a chunk of empty documents: id_off[0] = 0)
+        hipLaunchKernelGGL(k_decode_docs, dim3((uint32_t)((a.n_docs + 1 + 255) / 256)), dim3(256), 0, c->s_dec2, a);
+        HIP_TRY(hipEventRecord(ds.ev_cp, c->s_dec2));
+        HIP_TRY(hipStreamWaitEvent(c->s_d2h, ds.ev_cp, 0));
+        if (total) HIP_TRY(hipMemcpyAsync(o.b + base, ds.out, total, hipMemcpyDeviceToHost, c->s_d2h));
+        const bool last = k + 1 == ch.size();
+        HIP_TRY(hipMemcpyAsync(o.o + q.d0, ds.docoff, (a.n_docs + (last ? 1 : 0)) * 8, hipMemcpyDeviceToHost, c->s_d2h));
+        HIP_TRY(hipEventRecord(ds.ev_out, c->s_d2h));
+        base += total;
+        return SPL_OK;
+    };
+    if ((rc = submit_len(0))) return rc;
+    for (size_t k = 1; k < ch.size(); k++) {
+        if ((rc = submit_len(k))) return rc;
+        if ((rc = finish(k - 1))) return rc;
+    }
+    if ((rc = finish(ch.size() - 1))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->s_d2h));
+    HIP_TRY(hipGetLastError());
+    return SPL_OK;
+}
+
 static int spl_decode_batch_impl(spl_tokenizer* t, const uint32_t* ids, const uint64_t* ids_off, uint64_t n_docs, uint8_t** out_bytes,
                      uint64_t** out_off) {
     if (!t || !ids_off || !out_bytes || !out_off) return fail(SPL_EINVAL, "spl_decode_batch: null argument");
@@ -2183,15 +2329,14 @@ static int spl_decode_batch_impl(spl_tokenizer* t, const uint32_t* ids, const ui
     const uint64_t n_blk = (n + DEC_BLK - 1) / DEC_BLK;
     // outputs in pinned memory from the handle's pool (the D2H copies run at PCIe speed into it; pageable
     // memory would be staged by the runtime page by page); returned to the pool on every error path
-    struct Out {
-        std::shared_ptr<PinnedPool> pool; uint8_t* b = nullptr; uint64_t* o = nullptr; size_t bcap = 0, ocap = 0;
-        ~Out() { if (b) pool->put(b, bcap); if (o) pool->put(o, ocap); }
-    } o;
+    DecOut o;
     o.pool = t->pool;
     o.o = (uint64_t*)t->pool->get((n_docs + 1) * 8, o.ocap);
     if (!o.o) return fail(SPL_EDEVICE, "spl_decode_batch: pinned allocation failed");
     uint64_t total = 0;
-    if (n) {
+    if (n >= 3 * t->dec_chunk_ids && n_docs >= 3) {
+        if ((rc = decode_pipelined(t, c, ids, ids_off, n_docs, o))) return rc;
+    } else if (n) {
         // scratch grows, never shrinks: a steady stream of calls allocates nothing
         if (n > c->dec_cap_ids || !c->d_dec_ids) {
             HIP_TRY(hipDeviceSynchronize());

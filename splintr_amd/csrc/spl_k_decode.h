@@ -23,6 +23,7 @@ struct DecodeArgs {
     uint64_t* id_off;       // [n_ids + 1] byte offset of every id (+ total)
     uint8_t* out;
     const uint64_t* doc_first; uint64_t n_docs; uint64_t* doc_off;   // doc d = ids [doc_first[d] - doc_first[0], ...)
+    uint64_t out_base;      // added to every document offset (a chunk of the host pipeline: where its bytes start in the whole result)
 };
 __device__ __forceinline__ uint32_t dec_span(const DecodeArgs& a, uint32_t id, uint32_t& off) {
     if (id <= a.max_id) { off = a.tok_off[id]; return a.tok_off[id + 1] - off; }
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(NT) void k_decode_copy(DecodeArgs a) {
 __global__ void k_decode_docs(DecodeArgs a) {
     const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d > a.n_docs) return;
-    a.doc_off[d] = a.id_off[a.doc_first[d] - a.doc_first[0]];
+    a.doc_off[d] = a.id_off[a.doc_first[d] - a.doc_first[0]] + a.out_base;
 }
 
 // External chunk boundaries with special tokens: the host splitter found the literals too; their ids go where

@@ -91,6 +91,37 @@ def test_decode_a_large_batch_twice_without_regrowing():
     assert sum(len(e) for e in enc) > 100000
 
 
+def test_decode_pipeline_equals_one_piece_and_the_oracle():
+    """Large batches are decoded in chunks of whole documents through two slots (ids of chunk k + 1 in and measured while chunk k's bytes
+    are gathered and leave).  A small chunk size forces that path on a modest batch: empty documents (whole chunks of them), a document
+    larger than a chunk, ids of neither map, special ids; the result must equal the one-piece path's and the oracle's, and the result
+    buffer's growth path (bytes per token far above the first guess) must hold."""
+    from splintr_amd import Tokenizer, corpus, _ffi
+    L = _ffi.lib()
+    t, o = pair("o200k_base")
+    rng = random.Random(99)
+    texts = corpus.c3(300, seed=21)
+    enc = t.encode_batch(texts)
+    streams = []
+    for e in enc:
+        streams.append(e)
+        if rng.random() < 0.3:
+            streams.extend([[]] * rng.randint(1, 40))                        # runs of empty documents: chunks without an id
+    streams.append([x for e in enc[:60] for x in e])                         # one document of ~70 000 ids: larger than a chunk
+    streams.append([t.vocab_size + 5, 2 ** 31 - 1] + enc[0] + sorted(o.special_tokens.values())[:3])
+    want = [o.decode_bytes(s) for s in streams]
+    tp = Tokenizer.from_pretrained("o200k_base")
+    assert L.spl_set_option(tp.handle, b"decode_chunk_ids", 4096) == 0       # ~90 chunks
+    got = tp._decode_batch_bytes(streams)
+    assert got == want
+    assert got == t._decode_batch_bytes(streams)                              # the one-piece path (chunks of 2^20 ids: below three chunks)
+    assert tp._decode_batch_bytes(streams[:7]) == want[:7]                   # a small call on the same handle afterwards
+    # far more bytes per token than the first guess of the result's size: ids of long tokens only
+    longest = sorted(range(min(t.vocab_size, 200000)), key=lambda i: -len(o.decode_bytes([i])))[:50]
+    big = [[rng.choice(longest) for _ in range(3000)] for _ in range(12)]
+    assert tp._decode_batch_bytes(big) == [o.decode_bytes(s) for s in big]
+
+
 def test_deepseek_ids_that_are_not_byte_level_text():
     t, o = pair("deepseek_v3")
     # ids 0..2 hold text with characters outside the ByteLevel alphabet: decode_bytes gives the key itself

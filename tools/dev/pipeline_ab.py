@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 from splintr_amd import Tokenizer, corpus, _ffi
 L = _ffi.lib()
-CONFIGS = {"c3": ("o200k_base", "c3", 10000), "c4": ("llama3", "c4", 250000), "c5": ("deepseek_v3", "c5", 25), "c2x8": ("cl100k_base", "c2", 8000)}
+CONFIGS = {"c3": ("o200k_base", "c3", 10000), "c4": ("llama3", "c4", 250000), "c5": ("deepseek_v3", "c5", 25), "c2x8": ("cl100k_base", "c2", 8000), "c2": ("cl100k_base", "c2", 1000)}
 cfg = sys.argv[1]
 vocab, gen, n = CONFIGS[cfg]
 if len(sys.argv) > 2 and sys.argv[2] != "-": n = int(sys.argv[2])
