@@ -232,7 +232,7 @@ def main():
         cal_regions = max(3, -(-64 // max(1, args.steps))) if not rehearsal else 2
         cal_steps = cal_regions * args.steps
         # (depths that leave a SMALL last bucket for this K -- its exchange is the one nothing hides -- beside the round ones)
-        depths = sorted({4, 8, 32} | {d_ for d_ in (6, 9, 12) if 0 < args.steps % d_ <= d_ // 2}) if not rehearsal else (4, 8)
+        depths = sorted({2, 3, 4, 8, 32} | {d_ for d_ in (6, 9, 12) if 0 < args.steps % d_ <= d_ // 2}) if not rehearsal else (4, 8)
         for depth_c in depths:
             for form in ("allgather", "p2p", "allgather+pack24"):
                 g_ = GatherV(tok, dev, max_docs=gv_max_docs, max_tokens=gv_max_tokens, comm=comm, depth=depth_c, collective=form.split("+")[0],

@@ -119,6 +119,29 @@ def test_gatherv_pipeline_one_rank_rccl(coracle):
         dist.destroy_process_group()
 
 
+def test_pick_stream_returns_a_stream_that_runs_beside_the_given_ones():
+    """spl_pick_stream (include/splintr_hip.h): a stream measured to run beside the given ones -- usable as a torch stream, work on it and
+    on the given stream completes, and what conflict is left is small (on a GPU nobody else uses: none)."""
+    import torch
+    from splintr_amd.device import pick_stream
+    dev = torch.device("cuda", 0)
+    a = torch.cuda.Stream(dev)
+    b = pick_stream(dev, [a])
+    c = pick_stream(dev, [a, b])
+    assert len({a.cuda_stream, b.cuda_stream, c.cuda_stream}) == 3
+    assert b.conflict_us < 8.0 and c.conflict_us < 8.0, (b.conflict_us, c.conflict_us)
+    x = torch.zeros(1 << 20, device=dev)
+    torch.cuda.synchronize()
+    for s in (a, b, c):
+        with torch.cuda.stream(s):
+            x.add_(1)                            # (racy on purpose? no: the three adds are ordered by the events below)
+            ev = torch.cuda.Event(); ev.record(s)
+        for o in (a, b, c):
+            o.wait_event(ev)
+    torch.cuda.synchronize()
+    assert float(x[0].item()) == 3.0 and float(x.sum().item()) == 3.0 * (1 << 20)
+
+
 def test_collective_behind_the_c_abi_one_rank(coracle):
     """spl_comm_* / spl_allgather_slabs / spl_allgatherv_csr (include/splintr_hip.h) on a one-rank communicator the
     LIBRARY creates (librccl bound by dlopen, no torch.distributed anywhere): the bucketed GatherV pipeline through
