@@ -246,6 +246,12 @@ def test_one_long_match_costs_one_document_not_the_batch():
     assert 1 <= per_call <= 2, per_call                      # documents, not batches; the base64 line is no long MATCH under this pattern
     print(f"40 MB batch: {t_clean * 1e3:.2f} ms without, {t_bad * 1e3:.2f} ms with the two documents ({t_bad / t_clean:.3f} x)")
     assert t_bad <= 1.25 * t_clean, (t_clean, t_bad)
+    # (how much of that is the fallback, how much the 64 KB chunk itself -- a single-class run is merged a rank per round, milliseconds
+    #  whoever split it: the same two batches through the built-in pattern's scanner, which has no fallback)
+    tb = Tokenizer.from_pretrained("o200k_base")
+    _, tb_clean = timed(tb, docs)
+    _, tb_bad = timed(tb, bad)
+    print(f"built-in o200k_base pattern, same batches: {tb_clean * 1e3:.2f} ms without, {tb_bad * 1e3:.2f} ms with ({tb_bad / tb_clean:.3f} x)")
     # one chunk (the optimistic path): a 1 MB batch with the run in it
     small = docs[:250]
     small[100] = small[100][:300] + "=" * 3000 + small[100][300:]
