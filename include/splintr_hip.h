@@ -169,7 +169,9 @@ int spl_encode_batch(spl_tokenizer* t, const uint8_t* utf8, const uint64_t* doc_
  * pinned buffer, the tile kernel reads them there (a few cache lines over PCIe), k_tile_out writes ids and offsets into the pinned result
  * and, behind a system-scope fence, a completion word the calling thread spins on: two launches, no copy engine, no stream
  * synchronisation (31 us for a 1 KB text, 23 us for 13 bytes, against 44 / 34 us through the pipeline; the tile kernel's chain of phases
- * alone is 17 us).  spl_set_option("small_path", 0) turns it off; spl_small_path_calls counts the calls that took it. */
+ * alone is 17 us).  A batch of ONE tile (at most 800 bytes) is ONE launch: the tile's base is 0, so the tile kernel writes the final ids and
+ * offsets itself and stores the completion word (spl_set_option("solo_tile", 0): two launches as for larger batches; 23.1 -> 20.0 us for 13
+ * bytes, 30.6 -> 27.5 for 507).  spl_set_option("small_path", 0) turns the path off; spl_small_path_calls counts the calls that took it. */
 uint64_t spl_small_path_calls(const spl_tokenizer* t);
 const uint32_t* spl_result_tokens(const spl_result* r);   /* ids[T] */
 const uint64_t* spl_result_offsets(const spl_result* r);  /* out_off[n_docs+1] */

@@ -394,6 +394,7 @@ struct spl_tokenizer {
     int sdma_d2h = 0;                         // (measured, +0.5..3 %: not the default) pipeline chunks: their ids leave through hsa_amd_memory_async_copy (an SDMA engine) instead of hipMemcpyAsync
     uint64_t dec_chunk_ids = 2ull << 20;      // decode pipeline: ids per chunk (batches of fewer than three such chunks are decoded in one piece; C3: 28.3 GB/s at 1 M, 30.5 at 2 M, 29.6 at 3 M)
     int copy_threads = 4;                     // pipeline, pageable input: threads that copy a chunk into pinned staging
+    int solo_tile = 1;                        // latency path: a batch of ONE tile is one launch (k_pretok<.., SOLO> writes the CSR itself)
     int pick_streams = 1;                     // pipeline: its streams chosen by measurement so that they run side by side (pick_stream_beside)
     int twin_streams = 1;                     // pipeline: consecutive chunks' kernels on two streams / workspaces (Ctx::twin)
     int chunk_ramp = 0;                       // pipeline: a lane's first and last chunk are a quarter of the others (a shorter first H2D and last D2H)
@@ -808,11 +809,17 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
             return SPL_OK;
         }
         MARK(KI_PRETOK);
-        if (ntiles && direct_b) hipLaunchKernelGGL((k_pretok<SPL_TILE_DIRECT_B>), dim3(ntiles), dim3(NT), 0, s, PRETOK_EARLY(t->dt, b), t->dt, b);
+        // ONE tile, the latency path's completion word armed, nothing but the plain encode: the tile writes the CSR itself (k_pretok<.., SOLO>)
+        const bool solo_tile = tk->solo_tile && ntiles == 1 && !direct_b && b.done && phase == 0 && !special && !ext && !so && !t->prof && !b.dbg;
+        if (solo_tile) {
+            t->tpar ^= 1u;                                   // (no group sum was added, no k_tile_out will clear the other parity: the parity stays)
+            b.tpar = t->tpar;
+            hipLaunchKernelGGL((k_pretok<SPL_TILE_DIRECT_A, true>), dim3(1), dim3(NT), 0, s, PRETOK_EARLY(t->dt, b), t->dt, b);
+        } else if (ntiles && direct_b) hipLaunchKernelGGL((k_pretok<SPL_TILE_DIRECT_B>), dim3(ntiles), dim3(NT), 0, s, PRETOK_EARLY(t->dt, b), t->dt, b);
         else if (ntiles) hipLaunchKernelGGL((k_pretok<SPL_TILE_DIRECT_A>), dim3(ntiles), dim3(NT), 0, s, PRETOK_EARLY(t->dt, b), t->dt, b);
         else HIP_TRY(hipMemsetAsync(d_out_off, 0, (n_docs + 1) * 8, s));
         MARK(KI_DEFER); MARK(KI_BPELANES); MARK(KI_BPELONG); MARK(KI_COUNT); MARK(KI_SCAN); MARK(KI_COMPACT);
-        if (ntiles) hipLaunchKernelGGL(k_tile_out, dim3(ntiles), dim3(TOUT_NT), 0, s, tile_out_args(b));
+        if (ntiles && !solo_tile) hipLaunchKernelGGL(k_tile_out, dim3(ntiles), dim3(TOUT_NT), 0, s, tile_out_args(b));
         MARK(KI_N);
     } else {
         (void)fused_scan_used;
@@ -2033,6 +2040,7 @@ int spl_set_option(spl_tokenizer* t, const char* name, int64_t value) {
     else if (k == "chunk_ramp") t->chunk_ramp = value != 0;
     else if (k == "twin_streams") t->twin_streams = value != 0;
     else if (k == "pick_streams") t->pick_streams = value != 0;
+    else if (k == "solo_tile") t->solo_tile = value != 0;
     else if (k == "copy_threads" && value >= 1 && value <= 64) t->copy_threads = (int)value;
     else if (k == "decode_chunk_ids" && value >= 1024) t->dec_chunk_ids = (uint64_t)value;
     else if (k == "sdma_d2h") t->sdma_d2h = value != 0;

@@ -26,7 +26,9 @@ struct PretokKernargs {
     const uint32_t* e_akind; uint32_t e_flags; DeviceTables T; Batch b;
 };
 #define PRETOK_EARLY(T, b) (b).text, (b).doc_off, (b).n_bytes, (b).n_docs, (b).dbg, (T).akind, pretok_flags(T, b)
-template <int TB_, int RH_>
+// SOLO: the launch is ONE tile (a text of up to TB_ bytes: the latency path of Tokenizer.encode) -- the tile's base is 0, so it writes the
+// final ids and offsets itself and stores the completion word: no k_tile_out, one launch instead of two (round 5: 22.8 -> 18 us for 13 bytes).
+template <int TB_, int RH_, bool SOLO = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPL_PRETOK_WAVES)))
 void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_bytes, uint32_t e_n_docs, unsigned long long* e_dbg,
               const uint32_t* e_akind, uint32_t e_flags, DeviceTables T_ka, Batch b_ka) {
@@ -1151,14 +1153,15 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
         //  waits for another workgroup, so a tile that is slow -- long chunks, a chain that runs far
         //  beyond the window -- only delays itself)
         const bool queue_mode = b.qcount != nullptr;          // long chunks / chains went to the global queues
-        if (tid_late == 0 && !queue_mode) atomicAdd(&b.tctl[16 + b.tpar * b.tgroups + (tile_ix >> 6)], (uint32_t)total);
+        if (!SOLO && tid_late == 0 && !queue_mode) atomicAdd(&b.tctl[16 + b.tpar * b.tgroups + (tile_ix >> 6)], (uint32_t)total);
         if (queue_mode && tid_late < TILE_BITS_W)
             b.tile_bits[(size_t)tile_ix * TILE_BITS_W + tid_late] = tid_late < G::NBW + 1 ? s_tbits[tid_late] : 0u;
 #ifdef SPL_DEBUG_STAMPS
         if (e_dbg) blk_w2 = (unsigned long long)wall_clock64();
 #endif
         const uint32_t slot = tile_ix * b.tslot;                // fixed slots: nothing to wait for
-        for (uint32_t k = tid_late; k < c_win; k += NT) b.tile_ids[slot + k] = s_ids[s_cpos[k]];
+        if (SOLO) { for (uint32_t k = tid_late; k < c_win; k += NT) if (k < b.ids_cap) b.ids_out[k] = s_ids[s_cpos[k]]; }
+        else for (uint32_t k = tid_late; k < c_win; k += NT) b.tile_ids[slot + k] = s_ids[s_cpos[k]];
         // the documents that start in the tile's own range: their output offsets, first index and count -- by wavefront 0 alone,
         // 64 documents per round (a tile of ordinary text holds a handful; no barrier, the other wavefronts are done)
         if (tid_late < 64) {
@@ -1171,8 +1174,10 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
                 const bool own = in && p >= own_lo;
                 if (own && !queue_mode) {
                     const uint32_t i = (uint32_t)(p - (uint64_t)w0);
-                    b.off_out[d] = (uint64_t)(s_wpre[i >> 5] + __popc(s_tbits[i >> 5] & ((1u << (i & 31)) - 1u)))
-                                   + ((last_tile && p >= (uint64_t)B) ? c_ovf : 0u);
+                    const uint64_t v_off = (uint64_t)(s_wpre[i >> 5] + __popc(s_tbits[i >> 5] & ((1u << (i & 31)) - 1u)))
+                                           + ((last_tile && p >= (uint64_t)B) ? c_ovf : 0u);
+                    b.off_out[d] = v_off;
+                    if (SOLO && b.off_out2) b.off_out2[d] = v_off;       // (the tile's base is 0: these ARE the final offsets)
                 }
                 const unsigned long long mo = __ballot(own);    // owned documents are consecutive
                 if (mo) {
@@ -1214,6 +1219,11 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
         int tid_end = tid;                                   // (as tid_late: nothing tid-derived kept for this)
         asm volatile("" : "+v"(tid_end));
         if (e_dbg && tid_end == 0) atomicMax(&e_dbg[15], (unsigned long long)wall_clock64());
+        if (SOLO && b.done) {                                // the one workgroup's result stores, visible system-wide, then the word the host spins on
+            __threadfence_system();
+            __syncthreads();
+            if (tid_end == 0) __hip_atomic_store(b.done, b.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 #undef SPL_REC_BLK
 #undef SPL_STAMP
