@@ -682,6 +682,9 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
             if (lane == 0) it = atomicAdd(&s_nq[3], SPL_MEDIUM_PAIRS ? 2u : 1u);
             it = __builtin_amdgcn_readfirstlane(it);
             if (it >= m64) break;
+#ifdef SPL_SKIP_MEDIUM          /* timing experiment only (tokens missing): what the 17..64-byte misses cost */
+            continue;
+#endif
 #ifdef SPL_DEBUG_STAMPS
             ws_nmed++;
 #endif
@@ -733,6 +736,9 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
             it = __shfl(it, lane & ~15);
             const bool slot = it < nslots;
             if (!__any(slot)) break;
+#ifdef SPL_SKIP_SHORT           /* timing experiment only (tokens missing): what the misses of up to 16 bytes cost */
+            continue;
+#endif
 #ifdef SPL_DEBUG_STAMPS
             ws_nshort++;
 #endif
