@@ -111,29 +111,29 @@ spl_tokenizer* spl_create(const void* vocab, size_t vocab_len, const void* uclas
 int spl_set_devices(spl_tokenizer* t, const int32_t* devices, uint32_t n);
 uint32_t spl_n_devices(const spl_tokenizer* t);
 
-/* Host pipeline tuning: "chunk_bytes" (upper bound of one pipeline chunk, default 5 MiB),
- * "single_chunk_max_bytes" (batches up to this size run as one chunk, default 4 MiB),
- * "result_estimate_div" (first guess of the token count = bytes / div; default 0.375 tokens per byte),
- * "subdoc_split" (0/1: balance the GPUs by cutting large documents at context-free boundaries),
- * "direct_write" (0/1, default 1: one-chunk batches have the last kernel write the ids straight into
- * the pinned result instead of copying them back), "device_split" (0/1, default 1: a custom split pattern's
- * split runs on the GPU, see spl_split_device; 0 keeps it on the host cores), "small_path" (0/1, default 1: batches of at most 4 KB take
- * the latency path, see spl_small_path_calls), "direct_read" (0/1, default 1: a batch of ONE pipeline chunk whose text comes from
- * spl_host_alloc is not copied to the device -- the tile kernel reads it, and the offsets, where they lie; 93 -> 83 us per 1 MB call),
- * "sdma_d2h" (0/1, default 0: the ids of a pipeline chunk leave through hsa_amd_memory_async_copy -- an SDMA engine -- instead of
- * hipMemcpyAsync, which runs as a shader copy beside the next chunk's tile kernel; measured at +0.5 .. 3 % on the 40 MB batch, so not the
- * default; hipMemcpyAsync where the HSA runtime cannot be bound), "twin_streams" (0/1, default 1: the kernels of consecutive pipeline chunks
- * run on two compute streams with a workspace each, so that a chunk's tile kernel starts while the stragglers of the previous one finish:
- * 24.1 -> 28.8 GB/s host -> host on the 40 MB batch together with the smaller chunks; built-in patterns only), "copy_threads" (1..64,
- * default 4: threads that copy a chunk of PAGEABLE text into pinned staging -- one core copies ~19 GB/s, less than the pipeline takes:
- * 18.7 -> 27.6 GB/s from pageable memory), "pick_streams" (0/1, default 1: the pipeline's copy streams and second compute stream are chosen by
- * MEASUREMENT at the pipeline's first use on a context -- a 120 us spin kernel on one stream, four empty kernels on the candidate -- so that
- * they really run side by side: HIP maps streams to hardware queues, and queues to the four pipes of the command processor, by what else
- * the process has created, and two busy queues on one pipe take turns; without it the same call measured 29 or 20-22 GB/s depending on
- * the process's other streams; costs 5-80 ms once), "chunk_ramp" (0/1, default 0: a lane's first and last chunk a quarter of the others;
- * measured no better or worse on every BASELINE configuration), "decode_chunk_ids" (>= 1024, default 2^21: spl_decode_batch sends batches of
- * at least three such chunks through a two-slot pipeline -- ids of chunk k + 1 in and measured while chunk k's bytes are gathered and leave:
- * 21.8 -> 30.5 GB/s of decoded bytes on the 12.5 M-token batch). */
+/* Tuning switches (name, value; measurements behind each default: DESIGN.md section 5 and profiles/).
+ *   "chunk_bytes"            upper bound of one pipeline chunk of spl_encode_batch (default 5 MiB)
+ *   "single_chunk_max_bytes" batches up to this size run as ONE chunk (default 4 MiB)
+ *   "result_estimate_div"    first guess of the token count = bytes / div (default 2; a result that outgrows it moves to a larger buffer)
+ *   "subdoc_split"           0/1 (1): balance the GPUs by cutting large documents at context-free boundaries
+ *   "direct_write"           0/1 (1): one-chunk batches -- the last kernel writes the ids straight into the pinned result
+ *   "direct_read"            0/1 (1): one-chunk batches whose text comes from spl_host_alloc are read where they lie (no H2D copy)
+ *   "device_split"           0/1 (1): a custom split pattern's split runs on the GPU (spl_split_device); 0 keeps it on the host cores
+ *   "small_path"             0/1 (1): batches of at most 4 KB and 256 documents take the latency path (spl_small_path_calls)
+ *   "fuse"                   0/1 (1): batches of up to "fuse_max_tiles" tiles (default and maximum 1536: about 1.2 MB) are ONE launch --
+ *                            every tile learns the number of tokens in front of it from the other tiles' published counts and writes its
+ *                            part of the CSR itself; 0: the tile kernel and k_tile_out, as for larger batches
+ *   "twin_streams"           0/1 (1): the kernels of consecutive pipeline chunks run on two compute streams with a workspace each
+ *   "pick_streams"           0/1 (1): the pipeline's copy streams and second compute stream are chosen by measurement at first use
+ *                            (spl_pick_stream) so that they run side by side; costs 5-80 ms once per context
+ *   "copy_threads"           1..64 (4): threads that copy a chunk of pageable text into pinned staging
+ *   "chunk_ramp"             0/1 (0): a lane's first and last chunk a quarter of the others
+ *   "sdma_d2h"               0/1 (0): the ids of a pipeline chunk leave through hsa_amd_memory_async_copy (an SDMA engine) instead of
+ *                            hipMemcpyAsync; hipMemcpyAsync where the HSA runtime cannot be bound
+ *   "decode_chunk_ids"       >= 1024 (2^21): spl_decode_batch pipelines batches of at least three such chunks through two slots
+ *   "slab_pack24"            0/1 (0): the ids of the all-gather slabs travel three bytes each; every rank alike; refused (SPL_EINVAL) when an
+ *                            id of the tokenizer -- vocabulary or special token -- does not fit 24 bits
+ * Unknown names and values out of range: SPL_EINVAL. */
 int spl_set_option(spl_tokenizer* t, const char* name, int64_t value);
 
 /* One entry of the special_tokens map (src/core/tokenizer.rs:304, 429-434).  Call before the first
@@ -166,12 +166,10 @@ int spl_encode_batch(spl_tokenizer* t, const uint8_t* utf8, const uint64_t* doc_
                      uint32_t flags, spl_result** out);
 /* The latency path (Tokenizer::encode of ONE text, src/core/tokenizer.rs:729-808 -- "~50 MB/s", :266-268): a batch of at most 4096 bytes and
  * 256 documents on a handle with a built-in pattern does not go through the chunk pipeline.  The CPU copies text and offsets into one small
- * pinned buffer, the tile kernel reads them there (a few cache lines over PCIe), k_tile_out writes ids and offsets into the pinned result
- * and, behind a system-scope fence, a completion word the calling thread spins on: two launches, no copy engine, no stream
- * synchronisation (31 us for a 1 KB text, 23 us for 13 bytes, against 44 / 34 us through the pipeline; the tile kernel's chain of phases
- * alone is 17 us).  A batch of ONE tile (at most 800 bytes) is ONE launch: the tile's base is 0, so the tile kernel writes the final ids and
- * offsets itself and stores the completion word (spl_set_option("solo_tile", 0): two launches as for larger batches; 23.1 -> 20.0 us for 13
- * bytes, 30.6 -> 27.5 for 507).  spl_set_option("small_path", 0) turns the path off; spl_small_path_calls counts the calls that took it. */
+ * pinned buffer, the tile kernel reads them there (a few cache lines over PCIe) and writes ids and offsets into the pinned result; the last
+ * tile to finish stores, behind a system-scope fence, a completion word the calling thread spins on: ONE launch ("fuse"), no copy engine,
+ * no stream synchronisation.  spl_set_option("small_path", 0) turns the path off; spl_small_path_calls counts the calls that took it.
+ * (Latencies per text size: DESIGN.md section 7.) */
 uint64_t spl_small_path_calls(const spl_tokenizer* t);
 const uint32_t* spl_result_tokens(const spl_result* r);   /* ids[T] */
 const uint64_t* spl_result_offsets(const spl_result* r);  /* out_off[n_docs+1] */

@@ -55,6 +55,8 @@ def lib():
                                        ctypes.POINTER(ctypes.POINTER(ctypes.c_uint32)), ctypes.c_void_p]
         L.orc_pool_pin.argtypes = [ctypes.c_int]
         L.orc_pool_pin.restype = None
+        L.orc_pool_set_cpus.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+        L.orc_pool_set_cpus.restype = None
         L.orc_class_of.restype = ctypes.c_int
         L.orc_class_of.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
         _lib = L
@@ -64,6 +66,52 @@ def lib():
 def pool_pin(on: bool = True) -> None:
     """Pin the batch pool's threads (and the calling thread) to one CPU each: bench.py's cpu_baseline legs."""
     lib().orc_pool_pin(1 if on else 0)
+
+
+def pool_set_cpus(cpus: Sequence[int]) -> None:
+    """The CPUs the pinned pool uses, in order (empty: whatever the process may run on).  Call before pool_pin(True)."""
+    arr = (ctypes.c_int * max(1, len(cpus)))(*cpus)
+    lib().orc_pool_set_cpus(len(cpus), arr)
+
+
+def idle_cpus(sample_s: float = 0.25, busy_max: float = 0.05) -> List[int]:
+    """CPUs of this process's affinity mask that are idle right now (/proc/stat over `sample_s` seconds) and on which none of
+    this process's other threads last ran -- the GPU runtime's helper threads among them (/proc/self/task/*/stat, field 39)."""
+    import os, time
+
+    def snap():
+        out = {}
+        with open("/proc/stat") as f:
+            for line in f:
+                if line.startswith("cpu") and line[3].isdigit():
+                    p = line.split()
+                    v = [int(x) for x in p[1:9]]
+                    out[int(p[0][3:])] = (sum(v), v[3] + v[4])          # total, idle + iowait
+        return out
+    allowed = sorted(os.sched_getaffinity(0))
+    try:
+        a = snap(); time.sleep(sample_s); b = snap()
+    except OSError:
+        return allowed
+    mine = set()
+    me = os.getpid()
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            if int(tid) == me:
+                continue
+            with open(f"/proc/self/task/{tid}/stat") as f:
+                fields = f.read().rsplit(")", 1)[1].split()
+            mine.add(int(fields[36]))                                # (field 39 of the line: the CPU the thread last ran on)
+    except (OSError, ValueError, IndexError):
+        pass
+    good = []
+    for c in allowed:
+        if c not in a or c not in b or c in mine:
+            continue
+        dt, di = b[c][0] - a[c][0], b[c][1] - a[c][1]
+        if dt <= 0 or 1.0 - di / dt <= busy_max:
+            good.append(c)
+    return good if len(good) >= 8 else allowed
 
 
 class COracle:

@@ -603,8 +603,16 @@ static void *pool_main(void *arg) {
  * Unpinned, the 1 ms calls of a 1000-document batch scattered 50x between repetitions (threads woken on busy or
  * sleeping cores); pinned they stay within a few per cent.  Off by default: tests do not care. */
 static int g_pin = 0;
+/* An explicit CPU list for the pinned pool (bench.py: the CPUs this process may run on MINUS the ones that are busy -- a worker pinned
+ * onto a CPU that something else occupies is not scheduled for a time slice, and a 1 ms call becomes a 10 ms one). */
+static int g_cpus[1024], g_ncpus = 0;
+void orc_pool_set_cpus(int n, const int *cpus) {
+    g_ncpus = 0;
+    for (int i = 0; i < n && i < 1024; i++) g_cpus[g_ncpus++] = cpus[i];
+}
 static void pin_self(int k) {
     cpu_set_t all, one;
+    if (g_ncpus > 0) { CPU_ZERO(&one); CPU_SET(g_cpus[k % g_ncpus], &one); pthread_setaffinity_np(pthread_self(), sizeof one, &one); return; }
     if (sched_getaffinity(0, sizeof all, &all) != 0) return;
     int n = CPU_COUNT(&all), want = n ? k % n : 0, seen = 0;
     for (int c = 0; c < CPU_SETSIZE; c++) {

@@ -251,6 +251,10 @@ struct Ctx {
     uint32_t* d_tile_ids = nullptr;
     uint32_t* d_tctl = nullptr;
     uint32_t tgroups = 0, tpar = 0;
+    // fused mode (spl_k_fuse.h): per parity the tiles' published token counts (FUSE_REPL copies of u16[FUSE_STRIDE], then the 32-bit side
+    // array u32[FUSE_STRIDE]); a fused launch uses parity fpar and zeroes what the previous fused launch (fprev tiles) left in the other one
+    uint8_t* d_fctl = nullptr;
+    uint32_t fpar = 0, fprev = 0;
     uint64_t* off_host = nullptr;             // set by the caller of launch_all: where k_tile_out also stores the offsets (one-chunk host batches)
     bool off_host_written = false;            // launch_all: the tile-owned mode did so
     // latency path (encode_small): text and offsets read where they lie in pinned host memory, completion by a word k_tile_out stores there
@@ -323,8 +327,8 @@ struct Ctx {
     void free_workspace() {
         hipFree(d_zero); hipFree(d_stage); hipFree(d_rank);
         hipFree(d_q64); hipFree(d_qlong); hipFree(d_qdefer); hipFree(d_blk); hipFree(d_dbg);
-        hipFree(d_tdesc); hipFree(d_tile_ids); hipFree(d_tctl); hipFree(d_tile_bits); hipFree(d_tcnt);
-        d_tdesc = nullptr; d_tile_ids = nullptr; d_tctl = nullptr; d_tile_bits = nullptr; d_tcnt = nullptr;
+        hipFree(d_tdesc); hipFree(d_tile_ids); hipFree(d_tctl); hipFree(d_tile_bits); hipFree(d_tcnt); hipFree(d_fctl);
+        d_fctl = nullptr; d_tdesc = nullptr; d_tile_ids = nullptr; d_tctl = nullptr; d_tile_bits = nullptr; d_tcnt = nullptr;
         d_zero = nullptr; d_stage = nullptr; d_rank = nullptr;
         d_q64 = nullptr; d_qlong = nullptr; d_qdefer = nullptr; d_blk = nullptr; d_dbg = nullptr;
         cap_bytes = cap_docs = 0;
@@ -394,7 +398,8 @@ struct spl_tokenizer {
     int sdma_d2h = 0;                         // (measured, +0.5..3 %: not the default) pipeline chunks: their ids leave through hsa_amd_memory_async_copy (an SDMA engine) instead of hipMemcpyAsync
     uint64_t dec_chunk_ids = 2ull << 20;      // decode pipeline: ids per chunk (batches of fewer than three such chunks are decoded in one piece; C3: 28.3 GB/s at 1 M, 30.5 at 2 M, 29.6 at 3 M)
     int copy_threads = 4;                     // pipeline, pageable input: threads that copy a chunk into pinned staging
-    int solo_tile = 1;                        // latency path: a batch of ONE tile is one launch (k_pretok<.., SOLO> writes the CSR itself)
+    int fuse = 1;                             // tile-owned mode as ONE launch (spl_k_fuse.h) for batches of up to fuse_max_tiles tiles; 0: k_pretok + k_tile_out
+    uint32_t fuse_max_tiles = FUSE_MAX_TILES; // (every tile of such a launch is resident at once -- 256 CUs x 6 workgroups: a tile that waits for its base holds nobody up)
     int pick_streams = 1;                     // pipeline: its streams chosen by measurement so that they run side by side (pick_stream_beside)
     int twin_streams = 1;                     // pipeline: consecutive chunks' kernels on two streams / workspaces (Ctx::twin)
     int chunk_ramp = 0;                       // pipeline: a lane's first and last chunk are a quarter of the others (a shorter first H2D and last D2H)
@@ -557,6 +562,9 @@ int reserve(Ctx* t, uint64_t max_bytes, uint64_t max_docs) {
         HIP_TRY(hipMalloc((void**)&t->d_tctl, (16 + 2 * (size_t)t->tgroups) * 4));
         HIP_TRY(hipMemset(t->d_tctl, 0, (16 + 2 * (size_t)t->tgroups) * 4));
         t->tpar = 0;
+        HIP_TRY(hipMalloc((void**)&t->d_fctl, 2 * FUSE_PARITY_BYTES));
+        HIP_TRY(hipMemset(t->d_fctl, 0, 2 * FUSE_PARITY_BYTES));
+        t->fpar = 0; t->fprev = 0;
     }
     t->bitmap_dirty = true;
     t->cap_bytes = nb;
@@ -732,6 +740,7 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
     //  single-workgroup tails and agent-scope fences sit on the critical path.)
     // Single pass: small batches without special tokens are finished by ONE kernel.
     bool fused_scan_used = false;
+    bool fused_launch = false;               // tile-owned mode as ONE launch: no k_tile_out
     if (queue_mode) {
         t->bitmap_dirty = true;
         HIP_TRY(hipMemsetAsync(t->d_zero, 0, (2 * uw + QCOUNT_WORDS) * 4, s));
@@ -775,7 +784,18 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
         //  k_tile_out -- was built and measured in round 5: 33.6 us per 1 KB call against 31.2 with the two launches, 23.9 against 22.8 for 13
         //  bytes.  Two back-to-back launches overlap the second one's dispatch with the first kernel; the fused epilogue's device-scope fences,
         //  L1-bypassing loads and serial walk over the tiles cost more than that launch.  Dropped.)
-        if (ntiles && phase != 1) t->tpar ^= 1u;              // k_tile_out zeroes the other parity's sums for the next call
+        // ONE launch (spl_k_fuse.h): every tile resident at once, each learns its base from the others' published counts and writes its
+        // part of the CSR itself
+        const bool fuse = tk->fuse && ntiles && ntiles <= tk->fuse_max_tiles && phase != 1;
+        if (fuse) {
+            uint8_t* const mine = t->d_fctl + (size_t)t->fpar * FUSE_PARITY_BYTES, * const other = t->d_fctl + (size_t)(t->fpar ^ 1u) * FUSE_PARITY_BYTES;
+            b.ftc = (uint16_t*)mine; b.ftb = (uint32_t*)(mine + (size_t)FUSE_REPL * FUSE_STRIDE * 2);
+            b.fzc = (uint16_t*)other; b.fzb = (uint32_t*)(other + (size_t)FUSE_REPL * FUSE_STRIDE * 2); b.fz_n = t->fprev;
+            t->fpar ^= 1u;
+            t->fprev = ntiles;
+            fused_launch = true;
+        }
+        if (ntiles && phase != 1 && !fuse) t->tpar ^= 1u;     // k_tile_out zeroes the other parity's sums for the next call
         if (ntiles && t->off_host && phase != 1) { b.off_out2 = t->off_host; t->off_host_written = true; }
         if (ntiles && t->done_arm && phase != 1) { b.done = t->done_arm; b.done_seq = t->done_seq; t->done_armed = true; }
         if (!special) b.tstart = nullptr;
@@ -809,17 +829,11 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
             return SPL_OK;
         }
         MARK(KI_PRETOK);
-        // ONE tile, the latency path's completion word armed, nothing but the plain encode: the tile writes the CSR itself (k_pretok<.., SOLO>)
-        const bool solo_tile = tk->solo_tile && ntiles == 1 && !direct_b && b.done && phase == 0 && !special && !ext && !so && !t->prof && !b.dbg;
-        if (solo_tile) {
-            t->tpar ^= 1u;                                   // (no group sum was added, no k_tile_out will clear the other parity: the parity stays)
-            b.tpar = t->tpar;
-            hipLaunchKernelGGL((k_pretok<SPL_TILE_DIRECT_A, true>), dim3(1), dim3(NT), 0, s, PRETOK_EARLY(t->dt, b), t->dt, b);
-        } else if (ntiles && direct_b) hipLaunchKernelGGL((k_pretok<SPL_TILE_DIRECT_B>), dim3(ntiles), dim3(NT), 0, s, PRETOK_EARLY(t->dt, b), t->dt, b);
+        if (ntiles && direct_b) hipLaunchKernelGGL((k_pretok<SPL_TILE_DIRECT_B>), dim3(ntiles), dim3(NT), 0, s, PRETOK_EARLY(t->dt, b), t->dt, b);
         else if (ntiles) hipLaunchKernelGGL((k_pretok<SPL_TILE_DIRECT_A>), dim3(ntiles), dim3(NT), 0, s, PRETOK_EARLY(t->dt, b), t->dt, b);
         else HIP_TRY(hipMemsetAsync(d_out_off, 0, (n_docs + 1) * 8, s));
         MARK(KI_DEFER); MARK(KI_BPELANES); MARK(KI_BPELONG); MARK(KI_COUNT); MARK(KI_SCAN); MARK(KI_COMPACT);
-        if (ntiles && !solo_tile) hipLaunchKernelGGL(k_tile_out, dim3(ntiles), dim3(TOUT_NT), 0, s, tile_out_args(b));
+        if (ntiles && !fuse) hipLaunchKernelGGL(k_tile_out, dim3(ntiles), dim3(TOUT_NT), 0, s, tile_out_args(b));
         MARK(KI_N);
     } else {
         (void)fused_scan_used;
@@ -841,7 +855,7 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
         HIP_TRY(hipEventSynchronize(t->ev[KI_N]));
         for (int i = 0; i < KI_N; i++) {
             // slots whose kernels were not launched in this mode would only show the event overhead
-            const bool launched = queue_mode ? (i != KI_SPECIAL && i != KI_SCAN) : direct ? (i == KI_PRETOK || i == KI_COMPACT || (special && (i == KI_MARK || i == KI_SPECIAL)))
+            const bool launched = queue_mode ? (i != KI_SPECIAL && i != KI_SCAN) : direct ? (i == KI_PRETOK || (i == KI_COMPACT && !fused_launch) || (special && (i == KI_MARK || i == KI_SPECIAL)))
                                          : !((i == KI_SPECIAL && !special) ||
                                              (i == KI_COUNT && fused_scan_used));
             if (!launched) continue;
@@ -1566,7 +1580,7 @@ int encode_small(spl_tokenizer* tk, const uint8_t* utf8, const uint64_t* doc_off
     int rc = ensure_streams(*c);
     if (rc) return rc;
     if (!c->h_small) {
-        HIP_TRY(hipHostMalloc((void**)&c->h_small, SMALL_TEXT + SMALL_OFF + 64, hipHostMallocPortable));
+        HIP_TRY(hipHostMalloc((void**)&c->h_small, SMALL_TEXT + SMALL_OFF + 64, hipHostMallocPortable | hipHostMallocCoherent | hipHostMallocMapped));   // (coherent: the completion word must become visible while the kernel runs)
         void* dp = nullptr;
         HIP_TRY(hipHostGetDevicePointer(&dp, c->h_small, 0));
         c->dh_small = (uint8_t*)dp;
@@ -1604,7 +1618,11 @@ int encode_small(spl_tokenizer* tk, const uint8_t* utf8, const uint64_t* doc_off
         const uint32_t want = c->done_seq;
         for (uint32_t spin = 0; spin < 400000u; spin++) {
             if (*done == want) { seen = true; break; }
+#if defined(__x86_64__) || defined(__i386__)
             __builtin_ia32_pause();
+#else
+            std::this_thread::yield();
+#endif
         }
         std::atomic_thread_fence(std::memory_order_acquire);
     }
@@ -1811,6 +1829,9 @@ int encode_host(spl_tokenizer* tk, const uint8_t* utf8, const uint64_t* doc_off,
                 if ((base + T + 16) * 4 > r->ids_cap) {
                     // the first guess was too small: move to a buffer that holds whatever may still come
                     for (size_t q = 0; q <= l; q++) { HIP_TRY(hipSetDevice(lanes[q].c->device)); HIP_TRY(hipStreamSynchronize(lanes[q].c->s_d2h)); }
+                    // (sdma_d2h: the copies queued so far write into the OLD buffer -- they must have landed before it is copied and handed back)
+                    for (hsa_signal_t sg : dma_sigs) { hsa_dma().SignalWait(sg, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED); hsa_dma().SignalDestroy(sg); }
+                    dma_sigs.clear();
                     HIP_TRY(hipSetDevice(c->device));
                     const uint64_t rest = n_bytes - ch.lo;              // tokens <= bytes
                     size_t ncap = 0;
@@ -2040,11 +2061,16 @@ int spl_set_option(spl_tokenizer* t, const char* name, int64_t value) {
     else if (k == "chunk_ramp") t->chunk_ramp = value != 0;
     else if (k == "twin_streams") t->twin_streams = value != 0;
     else if (k == "pick_streams") t->pick_streams = value != 0;
-    else if (k == "solo_tile") t->solo_tile = value != 0;
+    else if (k == "fuse") t->fuse = value != 0;
+    else if (k == "fuse_max_tiles" && value >= 0 && value <= (int64_t)FUSE_MAX_TILES) t->fuse_max_tiles = (uint32_t)value;
     else if (k == "copy_threads" && value >= 1 && value <= 64) t->copy_threads = (int)value;
     else if (k == "decode_chunk_ids" && value >= 1024) t->dec_chunk_ids = (uint64_t)value;
-    else if (k == "sdma_d2h") t->sdma_d2h = value != 0;
-    else if (k == "slab_pack24") t->slab_pack24 = value != 0;        // (where the HSA runtime or the device's agent cannot be found: hipMemcpyAsync, silently)
+    else if (k == "sdma_d2h") t->sdma_d2h = value != 0;        // (where the HSA runtime or the device's agent cannot be found: hipMemcpyAsync, silently)
+    else if (k == "slab_pack24") {
+        if (value && std::max(t->ht.max_id, t->max_special_id) >= (1u << 24))
+            return fail(SPL_EINVAL, "slab_pack24: an id of this tokenizer does not fit three bytes (vocabulary or special-token ids >= 2^24)");
+        t->slab_pack24 = value != 0;
+    }
     else return fail(SPL_EINVAL, "spl_set_option: unknown option or bad value: " + k);
     return SPL_OK;
 }
@@ -2053,6 +2079,8 @@ static int spl_add_special_impl(spl_tokenizer* t, const uint8_t* literal, size_t
     if (!t || !literal || len == 0) return fail(SPL_EINVAL, "spl_add_special: bad argument");
     if (len > 255) return fail(SPL_EINVAL, "spl_add_special: literal longer than 255 bytes");
     if (id > 0x7FFFFFFFu) return fail(SPL_EINVAL, "spl_add_special: id out of range");
+    if (t->slab_pack24 && id >= (1u << 24))
+        return fail(SPL_EINVAL, "spl_add_special: the all-gather slabs of this handle carry three bytes per id (slab_pack24): ids must be < 2^24");
     const std::string lit((const char*)literal, len);
     bool replaced = false;
     for (auto& sp : t->specials)

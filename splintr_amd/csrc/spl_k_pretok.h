@@ -15,10 +15,10 @@ __device__ __forceinline__ uint32_t xcd_tile() {
     return x * q + (x < r ? x : r) + j;
 }
 // e_flags of k_pretok: which optional inputs exist, and the split pattern
-constexpr uint32_t PRETOK_E_TSTART = 1u, PRETOK_E_SKIP = 2u, PRETOK_E_GAPS = 4u, PRETOK_E_EXT = 8u;
+constexpr uint32_t PRETOK_E_TSTART = 1u, PRETOK_E_SKIP = 2u, PRETOK_E_GAPS = 4u, PRETOK_E_EXT = 8u, PRETOK_E_FUSE = 64u;
 inline uint32_t pretok_flags(const DeviceTables& T, const Batch& b) {
     return (b.tstart ? PRETOK_E_TSTART : 0u) | (b.skip ? PRETOK_E_SKIP : 0u) | (b.ext_gaps ? PRETOK_E_GAPS : 0u) |
-           (b.ext_starts ? PRETOK_E_EXT : 0u) | (T.pattern << 4);
+           (b.ext_starts ? PRETOK_E_EXT : 0u) | (T.pattern << 4) | (b.ftc ? PRETOK_E_FUSE : 0u);
 }
 // the kernel-argument segment of k_pretok as the ABI lays it out (every argument at its natural alignment, in order)
 struct PretokKernargs {
@@ -26,9 +26,7 @@ struct PretokKernargs {
     const uint32_t* e_akind; uint32_t e_flags; DeviceTables T; Batch b;
 };
 #define PRETOK_EARLY(T, b) (b).text, (b).doc_off, (b).n_bytes, (b).n_docs, (b).dbg, (T).akind, pretok_flags(T, b)
-// SOLO: the launch is ONE tile (a text of up to TB_ bytes: the latency path of Tokenizer.encode) -- the tile's base is 0, so it writes the
-// final ids and offsets itself and stores the completion word: no k_tile_out, one launch instead of two (round 5: 22.8 -> 18 us for 13 bytes).
-template <int TB_, int RH_, bool SOLO = false>
+template <int TB_, int RH_>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(SPL_PRETOK_WAVES)))
 void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_bytes, uint32_t e_n_docs, unsigned long long* e_dbg,
               const uint32_t* e_akind, uint32_t e_flags, DeviceTables T_ka, Batch b_ka) {
@@ -92,7 +90,14 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
 #if defined(SPL_DEBUG_STAMPS) && defined(SPL_STAMP_ALL)
     // every workgroup's wall clock at the phase boundaries (tools/dev/gpu_phase_walls.py): eight words per workgroup
     // in the per-workgroup record area -- start, stamps 1 2 3 4 6 7, end
-#define SPL_STAMP(i) do { if (e_dbg && threadIdx.x == 0 && SPL_REC_BLK < SPL_DEBUG_BLOCKS / 2 && (i) >= 1 && (i) <= 7 && (i) != 5) \
+#ifdef SPL_STAMP_FUSE     /* the fused mode's epilogue in place of the first two boundaries: [1] count published, [2] base known, [3] ids stored, [4] offsets stored (tools/dev/fuse_walls.py) */
+#define SPL_STAMP_LO 7
+#define SPL_FSTAMP(i) do { if (e_dbg && SPL_REC_BLK < SPL_DEBUG_BLOCKS / 2) e_dbg[16 + 8 * SPL_REC_BLK + (i)] = (unsigned long long)wall_clock64(); } while (0)
+#define SPL_FSTAMP_T(t, i) do { if ((int)threadIdx.x == (t)) SPL_FSTAMP(i); } while (0)
+#else
+#define SPL_STAMP_LO 1
+#endif
+#define SPL_STAMP(i) do { if (e_dbg && threadIdx.x == 0 && SPL_REC_BLK < SPL_DEBUG_BLOCKS / 2 && (i) >= SPL_STAMP_LO && (i) <= 7 && (i) != 5) \
                               e_dbg[16 + 8 * SPL_REC_BLK + ((i) < 5 ? (i) : (i) - 1)] = (unsigned long long)wall_clock64(); } while (0)
 #elif defined(SPL_DEBUG_STAMPS)
 #define SPL_STAMP(i) do { if (e_dbg && blockIdx.x == SPL_DBG_WG && threadIdx.x == 0) e_dbg[i] = clock64(); \
@@ -100,12 +105,20 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
 #else
 #define SPL_STAMP(i) do { } while (0)
 #endif
+#ifndef SPL_FSTAMP
+#define SPL_FSTAMP(i) do { } while (0)
+#define SPL_FSTAMP_T(t, i) do { } while (0)
+#endif
 
     const int tid = (int)threadIdx.x;                    // (wavefront indices rotated by the workgroup index, so that the phases of the low wavefronts
                                                          //  load different SIMDs in different workgroups: measured in round 2, no gain)
 #define SPL_REC_BLK blockIdx.x
     if (DIRECT) __builtin_amdgcn_s_setprio(SPL_WORK_PRIO);
-    const uint32_t tile_ix = xcd_tile();
+    // (fused mode: tile = workgroup index -- a tile waits for the tiles in front of it, which must have been dispatched before it)
+#ifndef SPL_FUSE_XCD
+#define SPL_FUSE_XCD 0           /* 1 (A/B only: not safe beside other launches): the XCD map in the fused mode too */
+#endif
+    const uint32_t tile_ix = (!SPL_FUSE_XCD && (e_flags & PRETOK_E_FUSE)) ? blockIdx.x : xcd_tile();
     const int64_t t0 = (int64_t)tile_ix * TB_;
     const int64_t w0 = t0 - LH;                       // global position of window index 0
     const int64_t B = e_n_bytes;
@@ -1111,9 +1124,30 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
         // the first NT documents of the window are fetched now: their load overlaps the count below
         const bool last_tile = tile_ix == gridDim.x - 1;
         const uint64_t own_lo = (uint64_t)t0, own_hi = (uint64_t)(t0 + TB_);
-        const uint64_t d_first = (uint64_t)dw + (uint32_t)tid_late;
+        // (the documents are wavefront 2's: wavefront 0 counts and publishes, wavefront 1 reads the other tiles' counts in the fused mode -- a
+        //  wavefront's memory operations complete in order, so whoever has just stored must not be the one that waits for a load)
+        const bool docs_wave = (tid_late >> 6) == 2;
+        const int dl = tid_late & 63;
+        const uint64_t d_first = (uint64_t)dw + (uint32_t)dl;
         uint64_t p_first = ~0ull;
-        if (tid_late < 64 && d_first <= e_n_docs) p_first = e_doc_off[d_first];      // entry n_docs is the end of the corpus
+        if (docs_wave && d_first <= e_n_docs) p_first = e_doc_off[d_first];      // entry n_docs is the end of the corpus
+        // what the result stores need of the argument segment: scalar loads of lines no earlier phase touched.  Wavefronts 2 and 3 -- idle
+        // here -- wait for them now (0.3-0.7 us), so that they are in the scalar cache when the others ask
+        uint32_t* o_ids = b.ids_out; uint64_t o_cap = b.ids_cap; uint64_t* o_off = b.off_out; uint64_t* o_off2 = b.off_out2;
+        uint32_t* o_slab = b.slab; uint32_t* o_done = b.done;
+        if ((tid_late >> 6) >= 2) asm volatile("" : "+s"(o_ids), "+s"(o_cap), "+s"(o_off), "+s"(o_off2), "+s"(o_slab), "+s"(o_done));
+        // fused mode (spl_k_fuse.h): ONE launch -- the tile learns its base from the counts of the tiles in front of it and writes its part
+        // of the CSR itself.  Wavefront 1 reads those counts NOW, beside wavefront 0's count of this tile's own tokens.
+        const bool fuse = (e_flags & PRETOK_E_FUSE) != 0u;                    // (uniform)
+#ifndef SPL_FUSE_EARLY
+#define SPL_FUSE_EARLY 0         /* 1 (A/B): wavefront 1 reads the counts BESIDE this tile's own count instead of behind it: 28.85 against 27.93 us per step on the bench batch -- polls that cannot succeed yet only add to the traffic past the L2 */
+#endif
+        if (SPL_FUSE_EARLY && fuse && (tid_late >> 6) == 1) {
+            SPL_FSTAMP_T(64, 4);
+            const unsigned long long bb = fuse_base(b, tile_ix);
+            if (tid_late == 64) { s_red[0] = bb; SPL_FSTAMP(2); }
+            __builtin_amdgcn_s_setprio(SPL_WORK_PRIO);
+        }
         // ---- token count of the tile: window bitmap + overflow range --------------------------------
         // (the bitmap is 34 words: ONE wavefront counts, ranks and lists them -- no sums across wavefronts, one barrier)
         static_assert(G::NBW + 2 <= 64, "the window's bitmap words must fit one wavefront");
@@ -1125,6 +1159,13 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
                 const uint32_t x = wave_scan_incl(cnt);
                 uint32_t basew = x - cnt;
                 if (tid_late == 63) s_total = x;
+                // fused mode: nothing of this tile lies beyond its window (nearly always): x IS its token count -- published now, for the
+                // tiles behind this one, before the positions are listed
+                if (e_flags & PRETOK_E_FUSE) {
+                    if (s_dq[4] == 0u && tile_ix + 1u < gridDim.x) fuse_publish(b, tile_ix, (uint32_t)__builtin_amdgcn_readlane((int)x, 63));   // (the last tile: nobody reads its count)
+                    fuse_rearm(b.fzc, tile_ix);
+                    if (tid_late == 0) SPL_FSTAMP(1);
+                }
                 if (tid_late < G::NBW + 2) s_wpre[tid_late] = basew;
                 while (word) {                                  // token positions in order
                     const int bit = __ffs(word) - 1;
@@ -1132,8 +1173,9 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
                     s_cpos[basew++] = (uint16_t)(tid_late * 32 + bit);
                 }
             }
-            __syncthreads();
+            lds_barrier();                                      // (the count, the positions -- and in the fused mode the base)
             c_win = s_total;
+            if (tid_late == 64) SPL_FSTAMP(5);
         }
         const uint32_t ovf_hi = s_dq[4];                     // exclusive; 0 if nothing went beyond the window
         const uint32_t wlo = ovf_lo >> 5, whi = ovf_hi > ovf_lo ? (ovf_hi + 31) >> 5 : wlo;
@@ -1159,31 +1201,63 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
         //  waits for another workgroup, so a tile that is slow -- long chunks, a chain that runs far
         //  beyond the window -- only delays itself)
         const bool queue_mode = b.qcount != nullptr;          // long chunks / chains went to the global queues
-        if (!SOLO && tid_late == 0 && !queue_mode) atomicAdd(&b.tctl[16 + b.tpar * b.tgroups + (tile_ix >> 6)], (uint32_t)total);
+        if (fuse) { if (tid_late < 64 && ovf_hi != 0u && tile_ix + 1u < gridDim.x) fuse_publish(b, tile_ix, (uint32_t)total); }
+        else if (tid_late == 0 && !queue_mode) atomicAdd(&b.tctl[16 + b.tpar * b.tgroups + (tile_ix >> 6)], (uint32_t)total);
+        // the first 64 documents of the window (one per lane of wavefront 0) are ranked NOW: their offsets were fetched before the count,
+        // and a wait for that load placed behind the id stores below would wait for the stores as well (one counter, in order: 1-5 us
+        // under load -- profiles/r06_one_launch.txt)
+        bool in0 = false, own0 = false;
+        uint64_t v0 = 0;
+        if (docs_wave) {
+            in0 = d_first <= e_n_docs && (p_first < own_hi || last_tile);
+            own0 = in0 && p_first >= own_lo;
+            if (own0 && !queue_mode) {
+                const uint32_t i = (uint32_t)(p_first - (uint64_t)w0);
+                v0 = (uint64_t)(s_wpre[i >> 5] + __popc(s_tbits[i >> 5] & ((1u << (i & 31)) - 1u))) + ((last_tile && p_first >= (uint64_t)B) ? c_ovf : 0u);
+            }
+        }
+        if (!SPL_FUSE_EARLY && fuse) {
+            if ((tid_late >> 6) == 1) { const unsigned long long bb = fuse_base(b, tile_ix); if (tid_late == 64) s_red[0] = bb; __builtin_amdgcn_s_setprio(SPL_WORK_PRIO); }
+            lds_barrier();
+        }
+        const unsigned long long fbase = fuse ? s_red[0] : 0ull;
+        if (!fuse) o_slab = nullptr;
         if (queue_mode && tid_late < TILE_BITS_W)
             b.tile_bits[(size_t)tile_ix * TILE_BITS_W + tid_late] = tid_late < G::NBW + 1 ? s_tbits[tid_late] : 0u;
 #ifdef SPL_DEBUG_STAMPS
         if (e_dbg) blk_w2 = (unsigned long long)wall_clock64();
 #endif
         const uint32_t slot = tile_ix * b.tslot;                // fixed slots: nothing to wait for
-        if (SOLO) { for (uint32_t k = tid_late; k < c_win; k += NT) if (k < b.ids_cap) b.ids_out[k] = s_ids[s_cpos[k]]; }
+        const uint32_t s_ids_at = 3 + b.slab_max_docs, s_ids_cap = (fuse && o_slab) ? slab_id_cap(b.slab_cap - s_ids_at, b.slab_p24 != 0u) : 0u;
+        auto put_final = [&](unsigned long long r, uint32_t id) {
+            if (r < o_cap) o_ids[r] = id;
+            if (r < s_ids_cap) slab_put_id(o_slab + s_ids_at, (uint32_t)r, id, b.slab_p24 != 0u);
+        };
+        if (fuse) { for (uint32_t k = tid_late; k < c_win; k += NT) put_final(fbase + k, s_ids[s_cpos[k]]); }
         else for (uint32_t k = tid_late; k < c_win; k += NT) b.tile_ids[slot + k] = s_ids[s_cpos[k]];
-        // the documents that start in the tile's own range: their output offsets, first index and count -- by wavefront 0 alone,
+        // the documents that start in the tile's own range: their output offsets, first index and count -- by ONE wavefront,
         // 64 documents per round (a tile of ordinary text holds a handful; no barrier, the other wavefronts are done)
-        if (tid_late < 64) {
+        if (docs_wave) {
             uint32_t d_lo = 0xFFFFFFFFu, d_n = 0;
             for (uint32_t db = dw;; db += 64u) {
-                const uint64_t d = (uint64_t)db + tid_late;
-                uint64_t p = p_first;
-                if (db != dw) { p = ~0ull; if (d <= e_n_docs) p = e_doc_off[d]; }
-                const bool in = d <= e_n_docs && (p < own_hi || last_tile);
-                const bool own = in && p >= own_lo;
+                const uint64_t d = (uint64_t)db + dl;
+                bool in = in0, own = own0;
+                uint64_t v_off = v0;
+                if (db != dw) {                                   // (more than 64 documents start in the window: rare)
+                    uint64_t p = ~0ull;
+                    if (d <= e_n_docs) p = e_doc_off[d];
+                    in = d <= e_n_docs && (p < own_hi || last_tile);
+                    own = in && p >= own_lo;
+                    if (own && !queue_mode) {
+                        const uint32_t i = (uint32_t)(p - (uint64_t)w0);
+                        v_off = (uint64_t)(s_wpre[i >> 5] + __popc(s_tbits[i >> 5] & ((1u << (i & 31)) - 1u))) + ((last_tile && p >= (uint64_t)B) ? c_ovf : 0u);
+                    }
+                }
                 if (own && !queue_mode) {
-                    const uint32_t i = (uint32_t)(p - (uint64_t)w0);
-                    const uint64_t v_off = (uint64_t)(s_wpre[i >> 5] + __popc(s_tbits[i >> 5] & ((1u << (i & 31)) - 1u)))
-                                           + ((last_tile && p >= (uint64_t)B) ? c_ovf : 0u);
-                    b.off_out[d] = v_off;
-                    if (SOLO && b.off_out2) b.off_out2[d] = v_off;       // (the tile's base is 0: these ARE the final offsets)
+                    const uint64_t v_fin = v_off + fbase;            // (fused: the tile's base is known: these ARE the final offsets)
+                    o_off[d] = v_fin;
+                    if (fuse && o_off2) o_off2[d] = v_fin;
+                    if (fuse && o_slab && d <= b.slab_max_docs) o_slab[2 + d] = (uint32_t)v_fin;
                 }
                 const unsigned long long mo = __ballot(own);    // owned documents are consecutive
                 if (mo) {
@@ -1192,12 +1266,49 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
                 }
                 if (!((__ballot(in) >> 63) & 1ull)) break;      // more documents beyond these 64?
             }
-            if (tid_late == 0) {
+            if (fuse && whi > wlo) {                             // rare: the tokens that start beyond the window, behind the window's (as k_tile_out)
+                unsigned long long running = fbase + c_win;
+                for (uint32_t wb = wlo; wb < whi; wb += 64u) {
+                    const uint32_t w = wb + (uint32_t)dl;
+                    uint32_t word = w < whi ? ld_agent(b.tbits + w) : 0u;
+                    if (w == whi - 1u && (ovf_hi & 31u)) word &= (1u << (ovf_hi & 31u)) - 1u;
+                    const uint32_t cnt = __popc(word);
+                    const uint32_t x = wave_scan_incl(cnt);
+                    unsigned long long r = running + (x - cnt);
+                    if (word && !b.skip) st_agent(b.tbits + w, 0u);          // clean after use: the bitmap is all-zero between calls
+                    while (word) {
+                        const int bit = __ffs(word) - 1;
+                        word &= word - 1;
+                        put_final(r, ld_agent(b.stage + (size_t)w * 32u + (uint32_t)bit));
+                        r++;
+                    }
+                    running += (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+                }
+            }
+            if (fuse) {
+                if (o_slab && last_tile && dl == 0) { o_slab[0] = (uint32_t)(fbase + total); o_slab[1] = e_n_docs; }   // header: T, N
+            } else if (dl == 0) {
                 TileDesc td;
                 td.slot = slot; td.c_win = c_win; td.c_ovf = c_ovf; td.ovf_hi = whi > wlo ? ovf_hi : 0u;
                 td.d_first = d_lo == 0xFFFFFFFFu ? 0u : d_lo; td.d_cnt = d_n; td.ovf_lo = ovf_lo;
                 td.c_own = s_wpre[DIRECT ? (LH + TB_) >> 5 : 0];             // tile range ends on a word boundary
                 b.tdesc[tile_ix] = td;
+            }
+        }
+        if (fuse) {
+            if (tile_ix == 0 && b.fz_n > gridDim.x) {            // the previous fused launch had more tiles than this one: their entries of the other parity
+                for (uint32_t k = gridDim.x + (uint32_t)tid_late; k < b.fz_n; k += NT) {
+                    for (uint32_t r = 0; r < FUSE_REPL; r++) st_agent(b.fzc + r * FUSE_STRIDE + k, (uint16_t)0u);
+                    st_agent(b.fzb + k, 0u);
+                }
+            }
+            if (o_done) {                                        // latency path: the last tile to get here stores the word the host spins on
+                __threadfence_system();
+                __syncthreads();
+                if (tid_late == 0 && (gridDim.x == 1u || atomicAdd(&b.tctl[8], 1u) == gridDim.x - 1u)) {
+                    if (gridDim.x != 1u) { b.tctl[8] = 0u; __threadfence_system(); }
+                    __hip_atomic_store(o_done, b.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
         }
     }
@@ -1225,14 +1336,11 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
         int tid_end = tid;                                   // (as tid_late: nothing tid-derived kept for this)
         asm volatile("" : "+v"(tid_end));
         if (e_dbg && tid_end == 0) atomicMax(&e_dbg[15], (unsigned long long)wall_clock64());
-        if (SOLO && b.done) {                                // the one workgroup's result stores, visible system-wide, then the word the host spins on
-            __threadfence_system();
-            __syncthreads();
-            if (tid_end == 0) __hip_atomic_store(b.done, b.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
     }
 #undef SPL_REC_BLK
 #undef SPL_STAMP
+#undef SPL_FSTAMP
+#undef SPL_FSTAMP_T
 }
 
 }  // namespace spl

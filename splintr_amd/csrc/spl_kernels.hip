@@ -8,6 +8,7 @@
 //                      (src/core/bpe.rs:67-197) as merge loops with one node per lane and tabulated pair ranks;
 //                      queue mode's k_deferred_wave
 //   spl_k_tile.h       tile geometry, LDS layout, the tail that finishes a tile's long chunks (bpe_tail_segments)
+//   spl_k_fuse.h       the fused mode (ONE launch): tiles publish their token counts and place their part of the CSR themselves
 //   spl_k_pretok.h     k_pretok<tile, halo>: one workgroup per tile -- stage the window in LDS, classify code points into
 //                      class bit masks (spl_scan_words.h), all match starts by bit-vector arithmetic (spl_scan_starts.h),
 //                      whole-chunk vocabulary probe (spl_lookup.h), merge loops for the tile's misses, the tile's record
@@ -125,7 +126,15 @@ struct Batch {
     // dropped (no match covers it).  Tile-owned mode only; the scanner phases are skipped.
     const uint32_t* ext_starts; const uint32_t* ext_gaps;
     uint32_t* done; uint32_t done_seq;       // tile-owned mode, optional: k_tile_out's completion word in pinned host memory (spl_k_output.h)
+    // fused mode (ONE launch, spl_k_fuse.h; ftc == nullptr: the two-launch form).  This call's parity: ftc[tile] = the tile's token
+    // count + 1 (0: not known yet; 0xFFFF: ftb[tile] holds it, 32 bits).  fzc / fzb: the other parity's arrays, of which tile 0 zeroes
+    // the first fz_n entries (what the previous fused launch used).
+    uint16_t* ftc; uint32_t* ftb; uint16_t* fzc; uint32_t* fzb; uint32_t fz_n;
 };
+
+// Workgroup barrier for hand-overs through LDS ONLY: __syncthreads() also waits for the wavefront's outstanding global stores (its release
+// fence), which in the fused mode are the count just published -- a microsecond, write-through past the L2 (profiles/r06_one_launch.txt).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // LDS hand-over between the lanes of ONE wavefront (no workgroup barrier)
 __device__ __forceinline__ void wave_lds_sync() {
@@ -163,6 +172,7 @@ __device__ __forceinline__ uint32_t tidx() {
 #include "spl_k_special.h"
 #include "spl_k_merge.h"
 #include "spl_k_tile.h"
+#include "spl_k_fuse.h"
 #include "spl_k_pretok.h"
 #include "spl_k_output.h"
 #include "spl_k_decode.h"

@@ -232,15 +232,15 @@ def test_latency_path_equals_the_pipeline_and_the_oracle(coracle):
                 n_bytes = sum(len(x.encode("utf-8")) for x in texts)
                 want_ids, want_off = oracle_csr(orc, texts, special)
                 got = {}
-                for on, solo in ((1, 1), (1, 0), (0, 1)):          # (solo_tile: a batch of ONE tile is one launch, the tile writes the CSR itself)
-                    assert L.spl_set_option(t.handle, b"small_path", on) == 0 and L.spl_set_option(t.handle, b"solo_tile", solo) == 0
+                for on, fuse in ((1, 1), (1, 0), (0, 1)):          # (fuse: ONE launch, the tiles place their part of the CSR themselves; 0: k_pretok + k_tile_out)
+                    assert L.spl_set_option(t.handle, b"small_path", on) == 0 and L.spl_set_option(t.handle, b"fuse", fuse) == 0
                     before = L.spl_small_path_calls(t.handle)
                     ids, off = t.encode_batch_csr(texts, with_special=special)
                     took = L.spl_small_path_calls(t.handle) - before
                     assert took == (1 if on and 0 < n_bytes <= 4096 and len(texts) <= 256 else 0), (n_bytes, len(texts), on, took)
                     assert np.array_equal(off, want_off) and np.array_equal(ids, want_ids), (name, n_bytes, len(texts), special, on)
         L.spl_set_option(t.handle, b"small_path", 1)
-        L.spl_set_option(t.handle, b"solo_tile", 1)
+        L.spl_set_option(t.handle, b"fuse", 1)
         for _ in range(300):                                     # many calls in a row (the completion word, the 256-call synchronisation)
             x = base[rng.randrange(0, 20000):][:rng.randrange(1, 1200)]
             assert t.encode(x) == orc.encode_batch([x])[0]
