@@ -255,6 +255,7 @@ struct Ctx {
     // array u32[FUSE_STRIDE]); a fused launch uses parity fpar and zeroes what the previous fused launch (fprev tiles) left in the other one
     uint8_t* d_fctl = nullptr;
     uint32_t fpar = 0, fprev = 0;
+    bool fuse_off = false;                    // set by the caller of launch_all for this call: the two-launch form (text read in place over PCIe, below)
     uint64_t* off_host = nullptr;             // set by the caller of launch_all: where k_tile_out also stores the offsets (one-chunk host batches)
     bool off_host_written = false;            // launch_all: the tile-owned mode did so
     // latency path (encode_small): text and offsets read where they lie in pinned host memory, completion by a word k_tile_out stores there
@@ -786,7 +787,7 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
         //  L1-bypassing loads and serial walk over the tiles cost more than that launch.  Dropped.)
         // ONE launch (spl_k_fuse.h): every tile resident at once, each learns its base from the others' published counts and writes its
         // part of the CSR itself
-        const bool fuse = tk->fuse && ntiles && ntiles <= tk->fuse_max_tiles && phase != 1;
+        const bool fuse = tk->fuse && !t->fuse_off && ntiles && ntiles <= tk->fuse_max_tiles && phase != 1;
         if (fuse) {
             uint8_t* const mine = t->d_fctl + (size_t)t->fpar * FUSE_PARITY_BYTES, * const other = t->d_fctl + (size_t)(t->fpar ^ 1u) * FUSE_PARITY_BYTES;
             b.ftc = (uint16_t*)mine; b.ftb = (uint32_t*)(mine + (size_t)FUSE_REPL * FUSE_STRIDE * 2);
@@ -865,6 +866,15 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
                 // the dominant kernel is timed on the device's wall clock instead (see k_pretok)
                 unsigned long long span[2];
                 HIP_TRY(hipMemcpy(span, t->d_dbg + 14, 16, hipMemcpyDeviceToHost));
+#ifndef SPL_DEBUG_STAMPS
+                {   // the end: the latest of the workgroups' own words (spl_k_pretok.h)
+                    static thread_local std::vector<unsigned long long> ends;
+                    ends.resize(std::min<size_t>(ntiles, 4 * (size_t)SPL_DEBUG_BLOCKS));
+                    HIP_TRY(hipMemcpy(ends.data(), t->d_dbg + 16, ends.size() * 8, hipMemcpyDeviceToHost));
+                    span[1] = 0;
+                    for (unsigned long long e : ends) span[1] = std::max(span[1], e);
+                }
+#endif
                 int khz = 0;
                 HIP_TRY(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, t->device));
                 if (khz > 0 && span[1] > span[0]) ms = (float)((double)(span[1] - span[0]) / (double)khz);
@@ -1464,6 +1474,9 @@ int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t
             HIP_TRY(hipHostGetDevicePointer(&tp, (void*)src, 0));
             HIP_TRY(hipHostGetDevicePointer(&op, rel, 0));
             text_arg = (const uint8_t*)tp; off_arg = (const uint64_t*)op;
+            // (text that arrives over PCIe while the kernel runs: the tiles of the fused mode would wait for the last of it, polling -- 94 against 86 us
+            //  per 1 MB call; with the text copied first it is 92 fused against 95.  profiles/r06_surface_bisect.txt)
+            c->fuse_off = true;
         } else {
         if (nb) HIP_TRY(hipMemcpyAsync(c->d_text[sl], src, nb, hipMemcpyHostToDevice, hs));
         HIP_TRY(hipMemcpyAsync(c->d_off[sl], rel, (nd + 1) * 8, hipMemcpyHostToDevice, hs));
@@ -1543,6 +1556,7 @@ int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t
         } else
             rc = launch_all(tk, w, text_arg, nb, off_arg, nd, flags, ids_direct ? ids_direct : c->d_ids + (ch.lo - ln.lo),
                             nb + 16, oo, w->s_cmp, nullptr, tk->regex ? &ext : nullptr);
+        c->fuse_off = false;
         if (rc) return rc;
         if (solo) break;                                   // (the batch is ONE chunk: the caller finishes on the compute stream itself)
         HIP_TRY(hipEventRecord(c->ev_cmp[sl], w->s_cmp));
@@ -1718,7 +1732,9 @@ int encode_host(spl_tokenizer* tk, const uint8_t* utf8, const uint64_t* doc_off,
             void* optr = nullptr;
             HIP_TRY(hipHostGetDevicePointer(&optr, r->off, 0));
             c->off_host = (uint64_t*)optr; c->off_host_written = false;
-            const bool mapped = tk->direct_read && src_pinned && ((uintptr_t)(utf8 + ch.lo) & 15) == 0 && (!tk->regex || !ln.host_split);
+            // (not with a custom pattern: the device splitter's kernels read the text as well -- in place it would cross PCIe two or three times:
+            //  216 against 182 us per 1 MB call, profiles/r06_surface_bisect.txt; round 5 had it on: the 5.50 -> 4.99 GB/s of VERDICT r05)
+            const bool mapped = tk->direct_read && src_pinned && ((uintptr_t)(utf8 + ch.lo) & 15) == 0 && !tk->regex;
             // (completion by k_tile_out's word in pinned memory instead of the stream synchronisation -- what the latency path does for a handful of
             //  tiles -- was measured here too: 150 us against 93 for the 1 MB batch; 1250 workgroups each pay a system-scope fence.  Not adopted.)
             int rc = lane_submit(tk, ln, utf8, doc_off, flags, src_pinned, true, (uint32_t*)dptr, mapped);

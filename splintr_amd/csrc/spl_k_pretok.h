@@ -1335,7 +1335,13 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
     {
         int tid_end = tid;                                   // (as tid_late: nothing tid-derived kept for this)
         asm volatile("" : "+v"(tid_end));
+#ifdef SPL_DEBUG_STAMPS
         if (e_dbg && tid_end == 0) atomicMax(&e_dbg[15], (unsigned long long)wall_clock64());
+#else
+        // (profiling: every workgroup's end in a word of its own, the host takes the maximum -- as ONE word updated by atomicMax the
+        //  1248 workgroups of the fused mode, which all end at the same moment, queued up behind each other for 7 us)
+        if (e_dbg && tid_end == 0) e_dbg[16 + (blockIdx.x & (4u * SPL_DEBUG_BLOCKS - 1u))] = (unsigned long long)wall_clock64();
+#endif
     }
 #undef SPL_REC_BLK
 #undef SPL_STAMP

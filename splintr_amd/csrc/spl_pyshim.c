@@ -404,4 +404,24 @@ static PyMethodDef methods[] = {
 
 static struct PyModuleDef mod = {PyModuleDef_HEAD_INIT, "_spl_py", "CPython front end of libsplintr_hip", -1, methods};
 
-PyMODINIT_FUNC PyInit__spl_py(void) { return PyModule_Create(&mod); }
+/* The lists of one large call are tens of megabytes of small heap blocks (C3: 10 000 lists, 12.5 M pointers, 100 MB), allocated and freed per
+ * call.  With glibc's defaults the heap top goes back to the kernel on every free beyond 128 KB and is faulted in again by the next call: the
+ * SAME list building measured 21.8 ms in one process state and 14.5 ms in another (whether some earlier free of a large block had happened to
+ * raise the dynamic thresholds) -- BENCH_r04 1 600 MB/s against BENCH_r05 1 001 MB/s on the C3 batch with an unchanged shim
+ * (profiles/r06_surface_bisect.txt).  The thresholds are therefore set once, at import: freed heap stays with the process (up to 1 GiB at the
+ * top) and blocks of up to 32 MiB come from the heap.  SPLINTR_KEEP_MALLOC_DEFAULTS=1 leaves the allocator alone. */
+#if defined(__GLIBC__)
+#include <malloc.h>
+#include <stdlib.h>
+static void tune_malloc(void) {
+    const char* e = getenv("SPLINTR_KEEP_MALLOC_DEFAULTS");
+    if (e && e[0] == '1') return;
+    mallopt(M_MMAP_THRESHOLD, 32 << 20);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    mallopt(M_TOP_PAD, 16 << 20);
+}
+#else
+static void tune_malloc(void) {}
+#endif
+
+PyMODINIT_FUNC PyInit__spl_py(void) { tune_malloc(); return PyModule_Create(&mod); }

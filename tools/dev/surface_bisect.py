@@ -67,3 +67,22 @@ if what in ("custom", "both"):
         L.spl_host_free(p)
         print(f"[custom {name:16s}] c_abi_host {nb/t_c/1e6:7.0f} MB/s ({t_c*1e6:6.1f} us) | python_surface {nb/t_py/1e6:7.0f} MB/s", flush=True)
         del tok
+
+if what in ("c2", "both"):
+    texts = corpus.c2(1000)
+    bs = [t.encode() for t in texts]; nb = sum(map(len, bs))
+    off = np.zeros(len(bs) + 1, dtype=np.uint64); np.cumsum([len(b) for b in bs], out=off[1:])
+    blob = b"".join(bs)
+    tok = Tokenizer.from_pretrained("cl100k_base")
+    p = L.spl_host_alloc(nb + 64); ctypes.memmove(p, blob, nb)
+    def c_call():
+        r = ctypes.c_void_p()
+        assert L.spl_encode_batch(tok.handle, p, off.ctypes.data, len(bs), 0, ctypes.byref(r)) == 0, _ffi.last_error()
+        L.spl_result_free(r)
+    for name, o in [("default", {}), ("fuse=0", dict(fuse=0)), ("direct_read=0", dict(direct_read=0)), ("fuse=0 direct_read=0", dict(fuse=0, direct_read=0)), ("default", {}), ("fuse=0", dict(fuse=0))]:
+        for k, v in dict(fuse=1, direct_read=1).items(): opt(tok, k, v)
+        for k, v in o.items(): opt(tok, k, v)
+        t_c = med(c_call, n=201)
+        t_py = med(lambda: tok.encode_batch(texts), n=21)
+        print(f"[c2 {name:22s}] c_abi_host {nb/t_c/1e6:7.0f} MB/s ({t_c*1e6:6.1f} us) | python_surface {nb/t_py/1e6:7.0f} MB/s", flush=True)
+    L.spl_host_free(p)
