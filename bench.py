@@ -281,6 +281,16 @@ def main():
     # over ranks -- is run R = --regions times back to back and `value` is the MEDIAN region (one 20-step
     # region of a 30 us step is 0.6 ms of wall clock, and the first one behind an idle GPU came out 5 % low two rounds
     # running).  Every region is reported (`regions`), with p10 / p90 beside the median.
+    # (behind the verification passes -- seconds of CPU work, the GPU idle -- the first ~150 steps of a run came out 7 % slower than the
+    #  rest, run after run: 37.3 - 38.3 GB/s for the first eight 20-step regions, 40.1 - 40.6 for the others (profiles/r06_bench_regions.txt):
+    #  the GPU's clocks come up under load.  The same steps are therefore run untimed for ~30 ms first; the contract's W warm-up steps follow.)
+    ramp0 = time.perf_counter()
+    while time.perf_counter() - ramp0 < 0.03:
+        for _ in range(16):
+            step()
+        if gv is not None:
+            gv.finish()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     reg_t, reg_b = [], []
@@ -319,7 +329,8 @@ def main():
                     "value_p10_p90": [round(pq(0.1), 2), round(pq(0.9), 2)],
                     "region_values": [round(b_ / t_ / 1e6, 1) for t_, b_ in zip(reg_t, reg_b)],
                     "note": "`value` / `ms_per_step` are the MEDIAN of `regions` timed regions of `steps` steps each (every region bracketed by "
-                            "barrier + synchronize, MAX over ranks); region_values in run order"}
+                            "barrier + synchronize, MAX over ranks); region_values in run order; ~30 ms of the same steps run untimed before the W warm-up steps "
+                            "(the GPU's clocks come up under load: without them the first eight regions of a run are 7 % slower than the rest)"}
 
     # ---- distributed runs: what a rank's step is made of (untimed repeats of the same steps) -------------
     # encode_only_ms: the same steps without the exchange; exchange_stream_ms: what the exchange stream spent in the
@@ -353,6 +364,7 @@ def main():
                                   "encode_only_ms": [round(float(x), 5) for x in allm[:, 1]],
                                   "exchange_stream_ms_per_step": [round(float(x), 5) for x in allm[:, 2]]},
                      "exposed_exchange_ms": round(float(allm[:, 0].max() - allm[:, 1].max()), 5),
+                     "stream_picks": _stream_picks(), "least_bad_pick": any(p_["least_bad"] for p_ in _stream_picks()),
                      "bucket_depth": gv.depth, "collective": gv.collective, "pack24": gv.pack24, "buckets_timed": ex_buckets,
                      "calibration": {"ms_per_step": {f"depth{d_}_{f_}": round(v_, 5) for (d_, f_), v_ in sorted(cal.items())},
                                      "chosen": f"depth{gv.depth}_{gv.collective}{'+pack24' if gv.pack24 else ''}", "steps_each": cal_steps, "regions_each": cal_regions,
@@ -363,6 +375,32 @@ def main():
                      "ids_bytes_per_batch_4T": round(4 * tok_b), "slab_over_4T": round(sent / gv.depth / (4 * tok_b), 4),
                      "note": "per batch and rank: one slab of cap_words u32 (T, N, local offsets, ids; sized 1.02 x the largest shard) out, "
                              "world slabs in; ONE all-gather per bucket of `bucket_depth` batches on its own stream"}
+
+    # ---- the chunk memo: the same rotation with it OFF (what a batch costs cold), and what it holds ------------------------------
+    memo_info = None
+    if rank == 0 and world == 1 and not use_dist:
+        ms_ = (ctypes.c_uint64 * 4)()
+        L.spl_memo_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+        L.spl_memo_stats(tok.handle, ms_)
+        L.spl_set_option(tok.handle, b"memo", 0)
+        for j in range(args.warmup):
+            encode_device(tok, batches[j % N_ROT])
+        off_rates = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            o0 = time.perf_counter()
+            for j in range(args.steps):
+                encode_device(tok, batches[j % N_ROT])
+            torch.cuda.synchronize()
+            off_rates.append(sum(batches[j % N_ROT].n_bytes for j in range(args.steps)) / (time.perf_counter() - o0) / 1e6)
+        L.spl_set_option(tok.handle, b"memo", 1)
+        off_rates.sort()
+        memo_info = {"fills": int(ms_[0]), "chunks_put_in": int(ms_[1]), "chunks_beyond_an_entry": int(ms_[2]), "entries": int(ms_[3]),
+                     "value_memo_off": round(off_rates[len(off_rates) // 2], 2), "unit": "MB/s",
+                     "note": "`value` is measured with the chunk memo WARM: the rotation's 8 batches were each encoded by the verification pass and the warm-up steps before "
+                             "the timed regions, so every chunk the vocabulary does not hold as one token is in the memo (the reference's LRU of encoded chunks, "
+                             "src/core/tokenizer.rs:707-722, is warm in its own benchmark in the same way).  value_memo_off: the same rotation with "
+                             "spl_set_option(memo, 0), median of 5 regions -- what a batch of text never seen before costs, minus the one-off fills"}
 
     # ---- the lexically wide variant of the same mix, in rotation, timed the same way (single GPU) ---------
     # C2's 925 distinct words flatter the vocabulary probe (every whole-chunk probe hits); c2_wide draws the same mix from a
@@ -455,7 +493,7 @@ def main():
         b_alg = (bytes_rot + 4 * sum(n_tokens) + 16 * sum(b.n_docs + 1 for b in batches)) / N_ROT
         achieved = b_alg / (kernels[dom] * 1e-6) / 1e9
         traffic, tsrc = None, None
-        for cand in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "hbm_traffic.json"):
+        for cand in ("r06_hbm_traffic.json", "r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "hbm_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", cand)
             if os.path.exists(tpath):
                 try:
@@ -472,7 +510,7 @@ def main():
                     "all_kernels_us": kernels}
         # the roofline that binds this kernel: VALU issue.  Counters come from rocprofv3 --pmc (not
         # available inside a plain run): the committed pass over this very command.
-        vname = next((n for n in ("r05_pmc_sq.json", "r04_pmc_sq.json", "r03_pmc_sq.json", "r02_pmc_sq.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
+        vname = next((n for n in ("r06_pmc_sq.json", "r05_pmc_sq.json", "r04_pmc_sq.json", "r03_pmc_sq.json", "r02_pmc_sq.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
         vpath = os.path.join(ROOT, "profiles", vname) if vname else ""
         if vname:
             try:
@@ -710,7 +748,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"cl100k_base, {args.docs} x ~1 KB mixed English/code per batch and GPU, {N_ROT} distinct batches in rotation "
                                    f"(splintr_amd.corpus.{args.corpus}, seeds {seed0_} + 100 rank + k{'' if args.corpus == 'c2' else '; NOT the BASELINE corpus: the lexically wide variant'}); KERNEL-ONLY: corpus HBM-resident, CSR left in HBM "
-                                   f"(the host->host and Python-surface rates of the same batch are in `throughputs`)"
+                                   f"(the host->host and Python-surface rates of the same batch are in `throughputs`); chunk memo warm (`memo.value_memo_off`: the same rotation without it)"
                                    + (f"; the same mix over a >= 20 000-word lexicon (c2_wide, in rotation, same timing): {c2_wide_rot['value']} MB/s" if c2_wide_rot else "")
                                    + (f"; + RCCL all-gatherv of the ragged ids (slab written by the encoder's last kernel, ONE exchange per bucket of {gv.depth} batches on its own stream -- {'ncclAllGather' if gv.collective == 'allgather' else 'grouped ncclSend / ncclRecv'}, chosen by the start-up calibration in `dist` --, overlapped with the following encodes; every rank gets every batch's global CSR, handed to the consumer per bucket)" if use_dist else ""),
                        "vocab": "cl100k_base", "docs_per_batch": args.docs, "bytes_per_batch": round(bytes_rot / N_ROT),
@@ -719,7 +757,7 @@ def main():
             "parity": "bit-exact vs oracle (untimed verification pass over every batch of the rotation)",
             "roofline": roofline, "roofline_valu": roofline_valu, "throughputs": throughputs, "c4_strong": c4, "c5_strong": c5,
             "cpu_baseline": cpu, "pipelined": pipelined, "dist": dist_info, "timing": region_stats, "c2_wide_rotation": c2_wide_rot,
-            "vs_prev": vs_prev, "vs_prev_source": prev_name, "regressions": regressions,
+            "memo": memo_info, "vs_prev": vs_prev, "vs_prev_source": prev_name, "regressions": regressions,
         }
         if rehearsal:
             out["rehearsal"] = True
@@ -737,30 +775,65 @@ def main():
 
 
 C5_PIECES = 16          # distributed runs: every C5 document is cut into this many pieces at context-free boundaries (128 KiB each)
-C5_WAVES = 8            # ... and the 1600 pieces are exchanged in this many waves (25 pieces per rank and wave at 8 GPUs)
+# Distributed strong-scaling legs: the batch is exchanged in N_WAVES TAPERED waves (splintr_amd.distributed.wave_fractions: wave k gets
+# taper ** k of the batch -- 33 / 23 / 16 / 11 / 8 / 5.5 / 3.8 % for 7 waves at 0.7).  Up to round 5 it was 8 equal waves: a rank's slice of
+# every wave 3.4 MB at 8 GPUs (launches of that size run at 30 GB/s one after the other, 27 MB in one launch at 42) and the last wave, whose
+# exchange nothing hides, an eighth of the batch.  Now the early launches are large and the one exposed exchange is 3.8 % of the result.
+N_WAVES = int(os.environ.get("SPL_BENCH_WAVES", "7"))
+WAVE_TAPER = float(os.environ.get("SPL_BENCH_WAVE_TAPER", "0.7"))
+
+
+def wave_count_bounds(n_items, n_waves=None, taper=None):
+    """n_items equal-sized items (prompts, pieces) in their order as tapered waves: n_waves + 1 item indices"""
+    from splintr_amd.distributed import wave_fractions
+    fr = wave_fractions(N_WAVES if n_waves is None else n_waves, WAVE_TAPER if taper is None else taper)
+    b, acc = [0], 0.0
+    for f in fr[:-1]:
+        acc += f
+        b.append(min(max(int(round(n_items * acc)), b[-1]), n_items))
+    b.append(n_items)
+    return b
+
+
+def _stream_picks():
+    """every stream this process picked by measurement (spl_pick_stream) and what the kept candidate still lost to its neighbours: a leg whose
+    `least_bad_pick` is true ran with an exchange or encode stream that shares a hardware queue or pipe -- its figure is suspect (a bad pick
+    costs up to 2 x, profiles/r05_wave_exchange.txt section 3)"""
+    from splintr_amd.device import stream_picks
+    return stream_picks()
 
 
 def _dist_run(world):
     return world > 1 or os.environ.get("SPL_BENCH_FORCE_DIST") == "1"
 
 
+def c4_wave_slices(rank, world):
+    """[(first prompt, one past the last)] of this rank's slice of every wave, over the C4_PARTS * C4_PART_DOCS prompts in their order"""
+    b = wave_count_bounds(C4_PARTS * C4_PART_DOCS)
+    return [(b[k] + (b[k + 1] - b[k]) * rank // world, b[k] + (b[k + 1] - b[k]) * (rank + 1) // world) for k in range(len(b) - 1)]
+
+
 def _c4_slice(args_):
+    """what this rank holds of part k: for every wave, the prompts of its slice that lie in the part"""
     k, rank, world = args_
     part = _c4_part(k)
-    return part[len(part) * rank // world:len(part) * (rank + 1) // world]
+    lo_p = k * C4_PART_DOCS
+    return [part[max(a, lo_p) - lo_p:max(min(b_, lo_p + C4_PART_DOCS), lo_p) - lo_p] if b_ > lo_p and a < lo_p + C4_PART_DOCS else []
+            for a, b_ in c4_wave_slices(rank, world)]
 
 
 def gen_c4_texts(rank, world):
     """BASELINE config 4 (1 000 000 prompts = 8 parts of 125 000, seeds 1004 + part; document order = part order).  One GPU: the whole
-    batch.  Distributed: the batch is exchanged in 8 WAVES (wave k = part k, splintr_amd.distributed.plan_waves' layout with equal
-    document counts): this rank's contiguous slice [125 000 r / W, 125 000 (r + 1) / W) of EVERY part, as a list of 8 lists."""
+    batch.  Distributed: the batch is exchanged in N_WAVES tapered WAVES over the prompts in their order (splintr_amd.distributed.plan_waves'
+    layout by prompt counts: the prompts are of one size distribution): this rank's contiguous slice of EVERY wave, as a list of lists."""
     from multiprocessing import Pool
     procs = max(1, min(C4_PARTS, (os.cpu_count() or 1) // max(world, 1)))
     if not _dist_run(world):
         with Pool(procs) as pool:
             return [t for part in pool.map(_c4_part, range(C4_PARTS)) for t in part]
     with Pool(procs) as pool:
-        return pool.map(_c4_slice, [(k, rank, world) for k in range(C4_PARTS)])
+        per_part = pool.map(_c4_slice, [(k, rank, world) for k in range(C4_PARTS)])       # [part][wave] -> prompts
+    return [[t for k in range(C4_PARTS) for t in per_part[k][w]] for w in range(len(per_part[0]))]
 
 
 def _c5_cut(doc_bytes, frac_num, frac_den):
@@ -789,13 +862,13 @@ def _c5_doc_pieces(d):
     return out
 
 
-def c5_wave_slices(n_docs, world, n_waves, pieces=C5_PIECES):
-    """[(first piece, one past the last)] per wave and rank over the n_docs * pieces pieces in document order: waves of equal piece
-    counts, every wave cut into `world` slices of equal piece counts (the pieces are of about equal size)."""
-    npc = n_docs * pieces
+def c5_wave_slices(n_docs, world, n_waves, pieces=C5_PIECES, taper=None):
+    """[(first piece, one past the last)] per wave and rank over the n_docs * pieces pieces in document order: TAPERED waves by piece
+    counts (wave_count_bounds), every wave cut into `world` slices of equal piece counts (the pieces are of about equal size)."""
+    b = wave_count_bounds(n_docs * pieces, n_waves, taper)
     out = []
     for k in range(n_waves):
-        lo, hi = npc * k // n_waves, npc * (k + 1) // n_waves
+        lo, hi = b[k], b[k + 1]
         out.append([(lo + (hi - lo) * r // world, lo + (hi - lo) * (r + 1) // world) for r in range(world)])
     return out
 
@@ -804,14 +877,14 @@ def gen_c5_pieces(rank, world):
     """BASELINE config 5 (deepseek_v3, 100 documents of 2 MiB, seeds 1005 + d).  One GPU: the 100 documents as they are.  Distributed:
     every document is cut into 16 pieces at context-free boundaries (a newline in front of an ASCII letter or digit: the ids of the
     pieces concatenate to the ids of the document -- the intra-document parallelism encode_rayon stands for,
-    src/core/tokenizer.rs:815-837), the 1600 pieces in document order are the batch, exchanged in 8 waves; this rank's slice of every
+    src/core/tokenizer.rs:815-837), the 1600 pieces in document order are the batch, exchanged in N_WAVES tapered waves; this rank's slice of every
     wave, as a list of lists.  Every rank generates only the documents it holds pieces of."""
     from multiprocessing import Pool
     procs = max(1, (os.cpu_count() or 1) // max(world, 1))
     if not _dist_run(world):
         with Pool(min(C5_DOCS, procs)) as pool:
             return pool.map(_c5_doc, range(C5_DOCS))
-    n_waves = min(C5_WAVES, C5_DOCS)
+    n_waves = min(N_WAVES, C5_DOCS)
     slices = c5_wave_slices(C5_DOCS, world, n_waves)
     need = sorted({p // C5_PIECES for k in range(n_waves) for p in range(*slices[k][rank])})
     with Pool(max(1, min(len(need), procs))) as pool:
@@ -960,6 +1033,20 @@ def run_strong(vocab, texts, steps, rank, world, local_rank, dev, use_dist, nchk
         print(f"[debug] {vocab}: issue {t_issue * 1e3:.3f} ms, synchronised {t_sync * 1e3:.3f} ms, after the barrier {el * 1e3:.3f} ms", file=sys.stderr)
     tot_b, tot_d, tot_t = my_bytes, my_docs, n_tok
     dist_info = None
+    memo_off_ms = None
+    if not use_dist:
+        # the same steps with the chunk memo OFF: every step of this leg re-encodes the SAME batch, so the memo is warm from the verification
+        # pass on (as the reference's LRU is in its own benchmark, which times repeated calls on one batch); this is what a batch costs cold
+        from splintr_amd import _ffi as _f2
+        _f2.lib().spl_set_option(tok.handle, b"memo", 0)
+        step()
+        torch.cuda.synchronize()
+        m0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        memo_off_ms = (time.perf_counter() - m0) / steps * 1e3
+        _f2.lib().spl_set_option(tok.handle, b"memo", 1)
     if use_dist:
         local_ms = el / steps * 1e3
         # untimed repeats: the encodes alone, and what the exchange stream spent in collective + unpack (events around them)
@@ -1001,6 +1088,7 @@ def run_strong(vocab, texts, steps, rank, world, local_rank, dev, use_dist, nchk
                      "slab_bytes_sent_per_wave": wg.cap_words * 4, "bytes_received_per_rank": wg.cap_words * 4 * world * len(subs),
                      "ids_bytes_4T": 4 * tot_t,
                      "encode_streams": 1 if wg.enc is None else 2,
+                     "stream_picks": _stream_picks(), "least_bad_pick": any(p_["least_bad"] for p_ in _stream_picks()),
                      "note": "WaveGather: the batch is exchanged in `waves` waves; rank r encodes its slice of wave k into a slab (written by the encoder's "
                              "last kernel; with encode_streams 2 consecutive waves on two handles and streams in alternation), ONE exchange of the wave's slabs + an unpack behind what the earlier waves left run on an exchange stream while "
                              "wave k + 1 encodes; no host synchronisation inside a step.  exposed = slowest step - slowest encodes-only"}
@@ -1012,7 +1100,10 @@ def run_strong(vocab, texts, steps, rank, world, local_rank, dev, use_dist, nchk
                         + (f"; RCCL all-gatherv of the ragged result inside the step, pipelined: {dist_info['waves']} waves, wave k on the links while wave k + 1 encodes "
                            f"(splintr_amd.device.WaveGather over spl_allgather_slabs{'_p2p' if dist_info['collective'] == 'p2p' else ''} + spl_gatherv_unpack_at)" if use_dist else ""),
             "value": round(tot_b * steps / el / 1e6, 1), "unit": "MB/s", "ms_per_step": round(el / steps * 1e3, 3),
-            "steps": steps, "scaling": "strong", "parity": parity, "dist": dist_info}
+            "steps": steps, "scaling": "strong", "parity": parity, "dist": dist_info,
+            "memo": None if memo_off_ms is None else {"value_memo_off": round(tot_b / (memo_off_ms * 1e-3) / 1e6, 1), "ms_per_step_memo_off": round(memo_off_ms, 3),
+                                                       "note": "`value` is with the chunk memo WARM (every step re-encodes the same batch); value_memo_off: the same steps with "
+                                                               "spl_set_option(memo, 0) -- what the batch costs cold"}}
 
 
 if __name__ == "__main__":

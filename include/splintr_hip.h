@@ -120,6 +120,8 @@ uint32_t spl_n_devices(const spl_tokenizer* t);
  *   "direct_read"            0/1 (1): one-chunk batches whose text comes from spl_host_alloc are read where they lie (no H2D copy)
  *   "device_split"           0/1 (1): a custom split pattern's split runs on the GPU (spl_split_device); 0 keeps it on the host cores
  *   "small_path"             0/1 (1): batches of at most 4 KB and 256 documents take the latency path (spl_small_path_calls)
+ *   "memo"                   0/1 (1): the chunk memo (spl_memo_stats); "memo_bits" 4..22 (16): log2 of its 64-byte entries; "memo_log_cap"
+ *                            1..65536 (512): missed chunks the tiles log per region (of 64) between two fills
  *   "fuse"                   0/1 (1): batches of up to "fuse_max_tiles" tiles (default and maximum 1536: about 1.2 MB) are ONE launch --
  *                            every tile learns the number of tokens in front of it from the other tiles' published counts and writes its
  *                            part of the CSR itself; 0: the tile kernel and k_tile_out, as for larger batches
@@ -350,6 +352,12 @@ int spl_profile_enable(spl_tokenizer* t, int on);
 int spl_profile_reset(spl_tokenizer* t);
 int spl_profile_read(spl_tokenizer* t, double ms_out[SPL_MAX_KERNELS], uint64_t launches_out[SPL_MAX_KERNELS]);
 const char* spl_kernel_name(int index);   /* NULL past the last kernel */
+
+/* The chunk memo of the handle's first context -- the GPU path's counterpart of the reference's LRU of encoded chunks
+ * (src/core/tokenizer.rs:707-722; result-transparent there and here: keys are compared in full): out[0] fills run (k_memo_fill, between two
+ * launches), out[1] chunks put in, out[2] chunks found to be beyond an entry (more than fourteen tokens: remembered as such), out[3] entries of
+ * the table (0: off).  spl_set_option("memo", 0) turns it off; "memo_bits" (4..22, default 16) sizes it.  Synchronises the device. */
+int spl_memo_stats(spl_tokenizer* t, uint64_t out[4]);
 
 /* Counters of the last encode call on this handle (device -> host copy, synchronises):
  * [2] items of the global long-chunk queue (> 64 B, plus every miss of a deferred segment),

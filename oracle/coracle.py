@@ -75,8 +75,9 @@ def pool_set_cpus(cpus: Sequence[int]) -> None:
 
 
 def idle_cpus(sample_s: float = 0.25, busy_max: float = 0.05) -> List[int]:
-    """CPUs of this process's affinity mask that are idle right now (/proc/stat over `sample_s` seconds) and on which none of
-    this process's other threads last ran -- the GPU runtime's helper threads among them (/proc/self/task/*/stat, field 39)."""
+    """CPUs of this process's affinity mask that are idle right now (/proc/stat over `sample_s` seconds), minus the ones on which a thread
+    of this process that was RUNNING during the sample last ran -- a GPU runtime's spinning helper thread, say (/proc/self/task/*/stat:
+    utime + stime before and after, field 39 = the CPU).  Threads that merely exist -- a BLAS pool of 256 sleepers -- exclude nothing."""
     import os, time
 
     def snap():
@@ -88,22 +89,28 @@ def idle_cpus(sample_s: float = 0.25, busy_max: float = 0.05) -> List[int]:
                     v = [int(x) for x in p[1:9]]
                     out[int(p[0][3:])] = (sum(v), v[3] + v[4])          # total, idle + iowait
         return out
+
+    def threads():
+        out = {}
+        me = os.getpid()
+        try:
+            for tid in os.listdir("/proc/self/task"):
+                if int(tid) == me:
+                    continue
+                with open(f"/proc/self/task/{tid}/stat") as f:
+                    fields = f.read().rsplit(")", 1)[1].split()
+                out[int(tid)] = (int(fields[11]) + int(fields[12]), int(fields[36]))     # utime + stime, last CPU
+        except (OSError, ValueError, IndexError):
+            pass
+        return out
     allowed = sorted(os.sched_getaffinity(0))
     try:
-        a = snap(); time.sleep(sample_s); b = snap()
+        a, ta = snap(), threads()
+        time.sleep(sample_s)
+        b, tb = snap(), threads()
     except OSError:
         return allowed
-    mine = set()
-    me = os.getpid()
-    try:
-        for tid in os.listdir("/proc/self/task"):
-            if int(tid) == me:
-                continue
-            with open(f"/proc/self/task/{tid}/stat") as f:
-                fields = f.read().rsplit(")", 1)[1].split()
-            mine.add(int(fields[36]))                                # (field 39 of the line: the CPU the thread last ran on)
-    except (OSError, ValueError, IndexError):
-        pass
+    mine = {cpu for tid, (ticks, cpu) in tb.items() if tid in ta and ticks > ta[tid][0]}
     good = []
     for c in allowed:
         if c not in a or c not in b or c in mine:

@@ -28,7 +28,7 @@ SYMBOLS = [
     "spl_token_bytes", "spl_is_byte_level",
     "spl_comm_unique_id", "spl_comm_create", "spl_comm_destroy", "spl_comm_rank", "spl_comm_world",
     "spl_allgather_slabs", "spl_allgather_slabs_p2p", "spl_gatherv_unpack_at", "spl_allgatherv_csr", "spl_split_host", "spl_encode_chunks_device",
-    "spl_split_device", "spl_device_split_fallbacks", "spl_small_path_calls", "spl_pick_stream",
+    "spl_split_device", "spl_device_split_fallbacks", "spl_small_path_calls", "spl_pick_stream", "spl_memo_stats",
 ]
 SPL_PATTERN_CUSTOM = 3
 SPL_OPT_BYTE_LEVEL = 1

@@ -255,6 +255,12 @@ struct Ctx {
     // array u32[FUSE_STRIDE]); a fused launch uses parity fpar and zeroes what the previous fused launch (fprev tiles) left in the other one
     uint8_t* d_fctl = nullptr;
     uint32_t fpar = 0, fprev = 0;
+    // chunk memo (spl_k_memo.h): the table, the tiles' log of what it did not hold, one claim word per slot for k_memo_fill, the pinned flag
+    MemoEnt* d_memo = nullptr; MemoExt* d_memo_ext = nullptr; uint32_t* d_mlog = nullptr; uint32_t* d_mlog_cnt = nullptr; uint32_t* d_mclaim = nullptr;
+    unsigned long long* d_mstats = nullptr;
+    uint32_t* h_mflag = nullptr; uint32_t* dh_mflag = nullptr;
+    uint32_t memo_round = 0, memo_cap = 0, memo_mask = 0;
+    uint64_t memo_fills = 0, memo_since = 0;
     bool fuse_off = false;                    // set by the caller of launch_all for this call: the two-launch form (text read in place over PCIe, below)
     uint64_t* off_host = nullptr;             // set by the caller of launch_all: where k_tile_out also stores the offsets (one-chunk host batches)
     bool off_host_written = false;            // launch_all: the tile-owned mode did so
@@ -334,6 +340,14 @@ struct Ctx {
         d_q64 = nullptr; d_qlong = nullptr; d_qdefer = nullptr; d_blk = nullptr; d_dbg = nullptr;
         cap_bytes = cap_docs = 0;
     }
+    void memo_drop() {                        // (a new geometry: the next launch builds an empty memo)
+        if (!d_memo) return;
+        if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return; }
+        (void)hipDeviceSynchronize();
+        hipFree(d_memo); hipFree(d_memo_ext); hipFree(d_mlog); hipFree(d_mlog_cnt); hipFree(d_mclaim); hipFree(d_mstats);
+        d_memo = nullptr; d_memo_ext = nullptr; d_mlog = nullptr; d_mlog_cnt = nullptr; d_mclaim = nullptr; d_mstats = nullptr;
+        dt.memo = nullptr; dt.memo_mask = 0;
+    }
     void free_slots() {
         for (int i = 0; i < NSLOT; i++) {
             hipFree(d_text[i]); hipFree(d_off[i]); hipFree(d_ext[i]); hipFree(d_extsp[i]);
@@ -358,6 +372,7 @@ struct Ctx {
         hipFree(d_ids); hipFree(d_oo);
         hipFree((void*)d_rx_image); hipFree((void*)d_gc1); hipFree((void*)d_gc2); hipFree(d_rx_ws); hipFree(d_rx_status); hipFree(d_rx_bits); if (h_rx_status) (void)hipHostFree(h_rx_status);
         if (h_small) (void)hipHostFree(h_small);
+        hipFree(d_memo); hipFree(d_memo_ext); hipFree(d_mlog); hipFree(d_mlog_cnt); hipFree(d_mclaim); hipFree(d_mstats); if (h_mflag) (void)hipHostFree(h_mflag);
         hipFree(d_rx_patch); hipFree(d_rx_bad); if (h_rx_bad) (void)hipHostFree(h_rx_bad); if (ev_split) (void)hipEventDestroy(ev_split);
         hipFree(d_dec_ids); hipFree(d_dec_blk); hipFree(d_dec_idoff); hipFree(d_dec_out); hipFree(d_dec_first); hipFree(d_dec_docoff);
         for (auto& ds : dslot) {
@@ -399,6 +414,8 @@ struct spl_tokenizer {
     int sdma_d2h = 0;                         // (measured, +0.5..3 %: not the default) pipeline chunks: their ids leave through hsa_amd_memory_async_copy (an SDMA engine) instead of hipMemcpyAsync
     uint64_t dec_chunk_ids = 2ull << 20;      // decode pipeline: ids per chunk (batches of fewer than three such chunks are decoded in one piece; C3: 28.3 GB/s at 1 M, 30.5 at 2 M, 29.6 at 3 M)
     int copy_threads = 4;                     // pipeline, pageable input: threads that copy a chunk into pinned staging
+    int memo = 1;                             // the chunk memo (spl_k_memo.h); "memo_bits": log2 of its entries (64 bytes each), "memo_log_cap": logged misses per region and fill
+    uint32_t memo_bits = 20, memo_log_cap = 1024;
     int fuse = 1;                             // tile-owned mode as ONE launch (spl_k_fuse.h) for batches of up to fuse_max_tiles tiles; 0: k_pretok + k_tile_out
     uint32_t fuse_max_tiles = FUSE_MAX_TILES; // (every tile of such a launch is resident at once -- 256 CUs x 6 workgroups: a tile that waits for its base holds nobody up)
     int pick_streams = 1;                     // pipeline: its streams chosen by measurement so that they run side by side (pick_stream_beside)
@@ -673,6 +690,54 @@ int rx_launch(spl_tokenizer* tk, Ctx* c, const uint8_t* d_text, uint64_t n_bytes
               uint32_t* d_starts, uint32_t* d_gaps, uint32_t* d_status, hipStream_t s, const Batch* sp = nullptr, uint32_t sp_words = 0,
               uint32_t* d_status_host = nullptr, bool bad_sets_status = false);
 
+// The chunk memo of a context (spl_k_memo.h): built empty at the first launch; the tiles log what it did not hold and raise the pinned
+// flag; a launch that finds the flag raised first runs k_memo_fill on its stream -- encode the logged chunks, put them in -- and then
+// its own kernels: the memo is only ever written between two launches of the stream that reads it.
+int memo_ensure(spl_tokenizer* tk, Ctx* t) {
+    if (t->d_memo) return SPL_OK;
+    const size_t slots = (size_t)1 << tk->memo_bits;
+    HIP_TRY(hipMalloc((void**)&t->d_memo, slots * sizeof(MemoEnt)));
+    HIP_TRY(hipMemset(t->d_memo, 0, slots * sizeof(MemoEnt)));
+    HIP_TRY(hipMalloc((void**)&t->d_memo_ext, slots * sizeof(MemoExt)));      // (only hits of seven to fourteen tokens ever touch it)
+    HIP_TRY(hipMalloc((void**)&t->d_mclaim, slots * 4));
+    HIP_TRY(hipMemset(t->d_mclaim, 0, slots * 4));
+    t->memo_cap = tk->memo_log_cap;
+    HIP_TRY(hipMalloc((void**)&t->d_mlog, (size_t)SPL_MEMO_LOG_REGIONS * t->memo_cap * SPL_MEMO_LOG_WORDS * 4));
+    HIP_TRY(hipMalloc((void**)&t->d_mlog_cnt, SPL_MEMO_LOG_REGIONS * 4));
+    HIP_TRY(hipMemset(t->d_mlog_cnt, 0, SPL_MEMO_LOG_REGIONS * 4));
+    HIP_TRY(hipMalloc((void**)&t->d_mstats, 16));
+    HIP_TRY(hipMemset(t->d_mstats, 0, 16));
+    if (!t->h_mflag) {
+        HIP_TRY(hipHostMalloc((void**)&t->h_mflag, 64, hipHostMallocPortable));
+        t->h_mflag[0] = 0;
+        void* dp = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&dp, t->h_mflag, 0));
+        t->dh_mflag = (uint32_t*)dp;
+    }
+    t->memo_mask = (uint32_t)(slots - 1);
+    t->dt.memo = t->d_memo; t->dt.memo_mask = t->memo_mask; t->dt.memo_ext = t->d_memo_ext;
+    t->memo_round = 0; t->memo_fills = 0; t->memo_since = 0;
+    return SPL_OK;
+}
+int memo_before_launch(spl_tokenizer* tk, Ctx* t, hipStream_t s) {
+    if (!tk->memo) { t->dt.memo = nullptr; return SPL_OK; }
+    int rc = memo_ensure(tk, t);
+    if (rc) return rc;
+    t->dt.memo = t->d_memo; t->dt.memo_mask = t->memo_mask; t->dt.memo_ext = t->d_memo_ext;
+    t->memo_since++;
+    // (the flag was raised by an EARLIER launch's tiles, when one of the log's regions became half full)
+    if (*(volatile uint32_t*)t->h_mflag) {
+        *(volatile uint32_t*)t->h_mflag = 0;
+        t->memo_round++;
+        hipLaunchKernelGGL(k_memo_fill, dim3((t->memo_cap + MEMO_FILL_NT - 1) / MEMO_FILL_NT, SPL_MEMO_LOG_REGIONS), dim3(MEMO_FILL_NT), 0, s, t->dt, t->d_memo, t->d_memo_ext, (const uint32_t*)t->d_mlog,
+                           t->d_mlog_cnt, t->memo_cap, t->d_mclaim, t->memo_round, t->d_mstats);
+        HIP_TRY(hipMemsetAsync(t->d_mlog_cnt, 0, SPL_MEMO_LOG_REGIONS * 4, s));
+        t->memo_fills++;
+        t->memo_since = 0;
+    }
+    return SPL_OK;
+}
+
 int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off, uint64_t n_docs,
                uint32_t flags, uint32_t* d_ids, uint64_t ids_cap, uint64_t* d_out_off, hipStream_t s,
                const SlabOut* so = nullptr, const ExtIn* ext = nullptr, int phase = 0) {
@@ -716,6 +781,11 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
     }
     b.blk_base = t->d_blk;
     b.ids_out = d_ids; b.ids_cap = ids_cap; b.off_out = d_out_off;
+    if (phase != 1) {                                        // (the chunk memo: a fill, if the earlier launches left something to put in)
+        int rcm = memo_before_launch(tk, t, s);
+        if (rcm) return rcm;
+        if (t->dt.memo) { b.mlog = t->d_mlog; b.mlog_cnt = t->d_mlog_cnt; b.mlog_cap = t->memo_cap; b.mflag = t->dh_mflag; }
+    }
 
     const bool pf = t->prof;
 #define MARK(i) do { if (pf) HIP_TRY(hipEventRecord(t->ev[i], s)); } while (0)
@@ -2078,6 +2148,9 @@ int spl_set_option(spl_tokenizer* t, const char* name, int64_t value) {
     else if (k == "twin_streams") t->twin_streams = value != 0;
     else if (k == "pick_streams") t->pick_streams = value != 0;
     else if (k == "fuse") t->fuse = value != 0;
+    else if (k == "memo") t->memo = value != 0;
+    else if (k == "memo_bits" && value >= 4 && value <= 22) { t->memo_bits = (uint32_t)value; for (auto& c : t->ctx) { c->memo_drop(); if (c->twin) c->twin->memo_drop(); } }
+    else if (k == "memo_log_cap" && value >= 1 && value <= 65536) { t->memo_log_cap = (uint32_t)value; for (auto& c : t->ctx) { c->memo_drop(); if (c->twin) c->twin->memo_drop(); } }
     else if (k == "fuse_max_tiles" && value >= 0 && value <= (int64_t)FUSE_MAX_TILES) t->fuse_max_tiles = (uint32_t)value;
     else if (k == "copy_threads" && value >= 1 && value <= 64) t->copy_threads = (int)value;
     else if (k == "decode_chunk_ids" && value >= 1024) t->dec_chunk_ids = (uint64_t)value;
@@ -2565,6 +2638,20 @@ int spl_debug_merge_timing(unsigned long long out[8], int reset) {
     return 0;
 }
 #endif
+
+int spl_memo_stats(spl_tokenizer* t, uint64_t out[4]) {
+    if (!t || !out) return fail(SPL_EINVAL, "null argument");
+    Ctx* c = t->ctx[0].get();
+    out[0] = c->memo_fills; out[1] = out[2] = 0; out[3] = c->d_memo ? (uint64_t)c->memo_mask + 1 : 0;
+    if (c->d_mstats) {
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipDeviceSynchronize());
+        unsigned long long st[2] = {0, 0};
+        HIP_TRY(hipMemcpy(st, c->d_mstats, 16, hipMemcpyDeviceToHost));
+        out[1] = st[0]; out[2] = st[1];
+    }
+    return SPL_OK;
+}
 
 int spl_last_queue_counts(spl_tokenizer* t, uint32_t counts_out[4]) {
     if (!t || !t->ctx[0]->d_zero) return fail(SPL_EINVAL, "no batch has run");

@@ -112,6 +112,29 @@ struct P8Bucket { uint32_t a, b; };
 //   id2: the id of the token that IS those two bytes, or SPL_NO_RANK -- a two-byte key needs no bucket probe at all.
 struct alignas(8) PfxEnt { uint32_t lm, id2; };
 
+// Chunk memo (round 6): what the reference's LRU of encoded chunks is to its CPU path (src/core/tokenizer.rs:707-722), as a direct-mapped
+// table in HBM -- chunks of up to 32 bytes that the vocabulary does not hold as ONE token, with the tokens their merge produced.  Probed
+// (read-only) right behind the whole-chunk probe; filled BETWEEN launches by k_memo_fill from the misses the tiles logged, so that kernel
+// boundaries on one stream give the coherence an in-kernel insert lacked (round 3).  Keys are compared in full: result-transparent.
+struct alignas(64) MemoEnt {
+    uint32_t key[8];     // the chunk's bytes, little endian, zero padded
+    uint32_t meta0;      // bits 0-5 length in bytes (2..32), bits 8-11 tokens (0: known, but not memoizable -- more than fourteen), bit 31 valid
+    uint32_t meta1;      // token t (t = 0..4) ends at byte (meta1 >> 6 t) & 63 of the chunk; the last token ends with the chunk
+    uint32_t ids[6];
+};
+static_assert(sizeof(MemoEnt) == 64, "one cache line");
+// A chunk of seven to fourteen tokens -- a long identifier, a hex string: few, but they are the tile kernel's longest merges, and the tile that
+// holds one ends last -- has the rest of its tokens in the slot's entry of a second array, which only such a hit touches.
+struct alignas(64) MemoExt {
+    uint32_t ids[8];     // tokens 6..13
+    uint32_t ends[2];    // token t (t = 5..12) ends at byte (ends[(t - 5) / 5] >> 6 ((t - 5) % 5)) & 63
+    uint32_t pad[6];
+};
+static_assert(sizeof(MemoExt) == 64, "one cache line");
+constexpr int SPL_MEMO_MAX_LEN = 32, SPL_MEMO_TOK1 = 6, SPL_MEMO_MAX_TOK = 14;
+constexpr uint32_t SPL_MEMO_LOG_WORDS = 12;              // one logged miss: length, eight key words, padding (48 bytes)
+constexpr uint32_t SPL_MEMO_LOG_REGIONS = 64;            // a tile appends to region tile % 64: one returning atomic per tile and region counter
+
 struct DeviceTables {
     // code-point classes
     const uint16_t* ucls_stage1;
@@ -159,6 +182,8 @@ struct DeviceTables {
     const PfxEnt* pfx;
     // (round 4: 16-bit entries -- the six length bits below, the t8 table's salt for keys with these four bytes above)
     const uint16_t* filt4;    uint32_t filt4_shift;
+    const MemoEnt* memo;      uint32_t memo_mask;        // chunk memo (nullptr: off); slots - 1
+    const MemoExt* memo_ext;
 };
 SPL_HD uint32_t hash_f4(uint32_t w0) { return w0 * 0x9E3779B1u; }      // (index = the upper bits: >> filt4_shift)
 
@@ -195,6 +220,13 @@ SPL_HD uint32_t hash_short(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len, 
 SPL_HD uint32_t hash_long_step(uint32_t h, uint32_t w) { h = (h ^ w) * 0x9E3779B1u; return (h << 13) | (h >> 19); }
 SPL_HD uint32_t hash_long_fin(uint32_t h, uint32_t len) { return mix32(h ^ len); }
 SPL_HD uint32_t hash_long_tag(uint32_t h) { return mix32(h * 0x85EBCA77u + 0x3C6EF372u); }
+SPL_HD uint32_t hash_memo(const uint32_t k[8], uint32_t n) {
+    uint32_t h = n * 0x27D4EB2Fu + 0x165667B1u;
+    for (int i = 0; i < 8; i++) { h = (h ^ k[i]) * 0x9E3779B1u; h = (h << 13) | (h >> 19); }
+    return mix32(h);
+}
+// (a chunk has TWO candidate slots: the second one is tried where the first is taken by another chunk)
+SPL_HD uint32_t memo_slot2(uint32_t h, uint32_t mask) { const uint32_t g = ((h >> 17) | (h << 15)) * 0x85EBCA77u; return ((g ^ (g >> 15)) & mask) ^ 1u; }
 SPL_HD uint32_t hash_pair(uint32_t l, uint32_t r) { return mix32(l * 0x9E3779B1u + r * 0x85EBCA77u + 0x27D4EB2Fu); }
 SPL_HD uint64_t pair_key(uint32_t l, uint32_t r) { return (uint64_t)l | ((uint64_t)r << SPL_ID_BITS); }
 constexpr uint64_t SPL_PAIR_KEY_MASK = (1ull << (2 * SPL_ID_BITS)) - 1;

@@ -590,7 +590,14 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
                 else b.stage[w0 + p] = id;
                 atomicOr(&s_tbits[p >> 5], 1u << (p & 31));
             } else if (n > 1) {
-                const uint32_t item = (uint32_t)p | ((uint32_t)n << 16);
+                // the chunk memo (spl_k_memo.h): a chunk it holds is finished here -- its tokens go in place -- and never reaches the merge loops
+                const int held = (T.memo && n <= SPL_MEMO_MAX_LEN && p + n <= Wv)
+                                     ? memo_probe(T, tx, p, n, [&](int q, uint32_t tid_) { s_ids[q] = tid_; atomicOr(&s_tbits[q >> 5], 1u << (q & 31)); }) : 0;
+#ifdef SPL_MEMO_STATS      /* profiling: chunks the vocabulary misses by what the memo said -- e_dbg[4..7]: not probed, not held, held, known as too long */
+                if (e_dbg) atomicAdd(&e_dbg[4 + ((T.memo && n <= SPL_MEMO_MAX_LEN && p + n <= Wv) ? 1 + held : 0)], 1ull);
+#endif
+                if (held == 1) continue;
+                const uint32_t item = (uint32_t)p | ((uint32_t)n << 16) | (held == 2 ? MISS_KNOWN : 0u);
                 if (TILE_LIST) {
                     // tile-owned: every miss goes on ONE list and through the segment pass of the tail
                     // (bpe_tail_segments: all of them tabulated together, merged side by side); queue
@@ -642,7 +649,7 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
 #pragma unroll
             for (int q = 0; q < (G::C16 + NT - 1) / NT; q++) {
                 const uint32_t k = tid + q * NT;
-                if (k < m16) { my_item[q] = s_miss[k]; my_r[q] = atomicAdd(&s_scnt[16 - (my_item[q] >> 16)], 1u); }
+                if (k < m16) { my_item[q] = s_miss[k]; my_r[q] = atomicAdd(&s_scnt[16 - MISS_N(my_item[q])], 1u); }
             }
             __syncthreads();
             if (tid < 64) {                                // exclusive prefix sums of the 17 counts: one wavefront scan
@@ -655,7 +662,7 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
             for (int q = 0; q < (G::C16 + NT - 1) / NT; q++) {
                 const uint32_t k = tid + q * NT;
                 if (k < m16) {
-                    const uint32_t n = my_item[q] >> 16;
+                    const uint32_t n = MISS_N(my_item[q]);
                     s_cpos[s_scnt[16 - n] + my_r[q]] = (uint16_t)((my_item[q] & 0x3FFu) | ((n - 1) << 10));
                 }
             }
@@ -704,7 +711,7 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
             if (DIRECT && SPL_MEDIUM_PRIO != SPL_MERGE_PRIO) __builtin_amdgcn_s_setprio(SPL_MEDIUM_PRIO);
             const uint32_t itemA = s_miss[G::C16 + it];
             const uint32_t itemB = (SPL_MEDIUM_PAIRS && it + 1u < m64) ? s_miss[G::C16 + it + 1u] : 0u;
-            const int pA = (int)(itemA & 0xFFFFu), nA = (int)(itemA >> 16), pB = (int)(itemB & 0xFFFFu), nB = (int)(itemB >> 16);
+            const int pA = (int)(itemA & 0xFFFFu), nA = (int)MISS_N(itemA), pB = (int)(itemB & 0xFFFFu), nB = (int)MISS_N(itemB);
             bool pair = SPL_MEDIUM_PAIRS && nA <= 32 && nB <= 32;
             if (pair) {
                 const int half = lane >> 5, hl = lane & 31;
@@ -769,7 +776,7 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
 #else
             long long* const wtp = nullptr;
 #endif
-            bpe_group16_tab(T, LdsAcc{s_rec, s_txt}, p, has ? (int)(item >> 16) : 0, s_sub[tid >> 4],
+            bpe_group16_tab(T, LdsAcc{s_rec, s_txt}, p, has ? (int)MISS_N(item) : 0, s_sub[tid >> 4],
                             [&](int i, uint32_t id) {
                                 put(p + i, id);
                             }, wtp, paired ? 8 : 16);
@@ -797,6 +804,10 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
     SPL_STAMP(10);
     __syncthreads();
     SPL_STAMP(7);
+    // chunk memo: what this tile had to merge goes into the handle's log (wavefront 3: in the fused mode it has nothing to do until the tile's
+    // base is known; the lists are intact here -- the tail below overlays them)
+    if (!TILE_LIST && b.mlog && (tid >> 6) == NT / 64 - 1 && (s_nq[0] | s_nq[1]) != 0u)
+        memo_log(b, LdsAcc{s_rec, s_txt}, s_miss, s_nq[0], (uint32_t)G::C16, s_nq[1], tile_ix);
 #ifdef SPL_DEBUG_STAMPS
     if (e_dbg) blk_w1 = blk_w2 = (unsigned long long)wall_clock64();
 #endif
@@ -844,7 +855,7 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
                     if ((uint32_t)tid < m) {
                         const uint32_t item = s_tmiss[mcur + tid];
                         s_lq[2 * (have + tid)] = (uint32_t)(w0 + (item & 0xFFFFu));
-                        s_lq[2 * (have + tid) + 1] = item >> 16;
+                        s_lq[2 * (have + tid) + 1] = MISS_N(item);
                     }
                     __syncthreads();
                     if (tid == 0) s_dq[0] = have + m;

@@ -9,6 +9,7 @@
 //                      queue mode's k_deferred_wave
 //   spl_k_tile.h       tile geometry, LDS layout, the tail that finishes a tile's long chunks (bpe_tail_segments)
 //   spl_k_fuse.h       the fused mode (ONE launch): tiles publish their token counts and place their part of the CSR themselves
+//   spl_k_memo.h       the chunk memo: its probe, the log of what it did not hold, k_memo_fill (between two launches)
 //   spl_k_pretok.h     k_pretok<tile, halo>: one workgroup per tile -- stage the window in LDS, classify code points into
 //                      class bit masks (spl_scan_words.h), all match starts by bit-vector arithmetic (spl_scan_starts.h),
 //                      whole-chunk vocabulary probe (spl_lookup.h), merge loops for the tile's misses, the tile's record
@@ -130,6 +131,9 @@ struct Batch {
     // count + 1 (0: not known yet; 0xFFFF: ftb[tile] holds it, 32 bits).  fzc / fzb: the other parity's arrays, of which tile 0 zeroes
     // the first fz_n entries (what the previous fused launch used).
     uint16_t* ftc; uint32_t* ftb; uint16_t* fzc; uint32_t* fzb; uint32_t fz_n;
+    // chunk memo (spl_k_memo.h; mlog == nullptr: the tiles log nothing): SPL_MEMO_LOG_REGIONS regions of mlog_cap entries of SPL_MEMO_LOG_WORDS
+    // words each, their fill counters, and the word in pinned host memory that tells the host there is something to put in
+    uint32_t* mlog; uint32_t* mlog_cnt; uint32_t mlog_cap; uint32_t* mflag;
 };
 
 // Workgroup barrier for hand-overs through LDS ONLY: __syncthreads() also waits for the wavefront's outstanding global stores (its release
@@ -173,6 +177,7 @@ __device__ __forceinline__ uint32_t tidx() {
 #include "spl_k_merge.h"
 #include "spl_k_tile.h"
 #include "spl_k_fuse.h"
+#include "spl_k_memo.h"
 #include "spl_k_pretok.h"
 #include "spl_k_output.h"
 #include "spl_k_decode.h"

@@ -147,7 +147,19 @@ def pick_stream(device: torch.device, beside) -> "torch.cuda.Stream":
         raise RuntimeError(_ffi.last_error())
     st = torch.cuda.ExternalStream(out.value, device=device)
     st.conflict_us = left.value
+    _PICKS.append({"beside": len(beside), "conflict_us": round(float(left.value), 1), "least_bad": bool(left.value >= PICK_CONFLICT_US)})
     return st
+
+
+# Every stream this process picked by measurement, in order: what the candidate that was kept still lost to its neighbours (microseconds
+# for four empty kernels beside a spinning stream, minus the same alone).  spl_pick_stream keeps the first candidate without a conflict and
+# otherwise the LEAST BAD one -- silently, up to round 5; a scaling run records the picks and flags a leg that ran on a least-bad one.
+PICK_CONFLICT_US = 15.0
+_PICKS = []
+
+
+def stream_picks():
+    return list(_PICKS)
 
 
 _ENC_STREAMS = {}

@@ -35,13 +35,48 @@ def shard_bounds(doc_bytes: Sequence[int], world: int) -> List[int]:
     return bounds
 
 
-def plan_waves(doc_bytes: Sequence[int], world: int, n_waves: int) -> List[List[Tuple[int, int]]]:
+def wave_fractions(n_waves: int, taper: float = 1.0) -> List[float]:
+    """Shares of a batch for `n_waves` waves: wave k gets taper ** k (normalised).  taper = 1: equal waves.  taper < 1: TAPERED -- the early
+    waves are large (a rank's slice of them is a launch big enough to run at the tile kernel's full rate, and their exchange hides behind
+    the encodes that follow), the last wave -- whose exchange nothing hides -- is small: 7 waves at taper 0.7 are 33 / 23 / 16 / 11 / 8 /
+    5.5 / 3.8 % of the batch, where 8 equal waves expose 12.5 %."""
+    if n_waves < 1 or not (0.0 < taper <= 1.0):
+        raise ValueError("wave_fractions: n_waves >= 1, 0 < taper <= 1")
+    w = [taper ** k for k in range(n_waves)]
+    t = sum(w)
+    return [x / t for x in w]
+
+
+def fraction_bounds(doc_bytes: Sequence[int], fractions: Sequence[float]) -> List[int]:
+    """Cut N documents into len(fractions) contiguous ranges whose bytes are about the given shares.  Returns len + 1 document indices."""
+    n = len(doc_bytes)
+    csum = np.concatenate([[0], np.cumsum(np.asarray(doc_bytes, dtype=np.int64))])
+    total = int(csum[-1])
+    tot_f = float(sum(fractions))
+    bounds, acc = [0], 0.0
+    for f in list(fractions)[:-1]:
+        acc += f / tot_f
+        target = total * acc
+        i = int(np.searchsorted(csum, target, side="left"))
+        if i > 0 and abs(csum[i - 1] - target) <= abs(csum[min(i, n)] - target):
+            i -= 1
+        bounds.append(min(max(i, bounds[-1]), n))
+    bounds.append(n)
+    return bounds
+
+
+def plan_waves(doc_bytes: Sequence[int], world: int, n_waves: int, taper: float = 1.0,
+               fractions: Sequence[float] = None) -> List[List[Tuple[int, int]]]:
     """ONE batch for the pipelined strong-scaling exchange (splintr_amd.device.WaveGather): the documents, in their order, are cut into
-    `n_waves` contiguous waves of about equal bytes and every wave into `world` contiguous slices of about equal bytes.  Returns
-    waves[k][r] = (first document, one past the last) of rank r's slice of wave k.  The result of the batch is the concatenation over k
-    of (the concatenation over r of slice (k, r)) -- document order -- so wave k can be exchanged, and land at its final place, while
-    wave k + 1 is still being encoded: its place depends only on the waves before it."""
-    wb = shard_bounds(doc_bytes, n_waves)
+    `n_waves` contiguous waves -- of about equal bytes, or TAPERED (`taper` < 1, wave_fractions; or explicit `fractions`) -- and every
+    wave into `world` contiguous slices of about equal bytes.  Returns waves[k][r] = (first document, one past the last) of rank r's
+    slice of wave k.  The result of the batch is the concatenation over k of (the concatenation over r of slice (k, r)) -- document
+    order (what Rayon's order-preserving collect gives the reference, src/core/tokenizer.rs:932-942) -- so wave k can be exchanged, and
+    land at its final place, while wave k + 1 is still being encoded: its place depends only on the waves before it."""
+    fr = list(fractions) if fractions is not None else wave_fractions(n_waves, taper)
+    if len(fr) != n_waves:
+        raise ValueError("plan_waves: one fraction per wave")
+    wb = fraction_bounds(doc_bytes, fr)
     waves = []
     for k in range(n_waves):
         lo, hi = wb[k], wb[k + 1]
@@ -50,14 +85,14 @@ def plan_waves(doc_bytes: Sequence[int], world: int, n_waves: int) -> List[List[
     return waves
 
 
-def encode_batch_waves(encode_csr, texts: Sequence[str], device: torch.device, n_waves: int = 4, group=None):
+def encode_batch_waves(encode_csr, texts: Sequence[str], device: torch.device, n_waves: int = 4, group=None, taper: float = 1.0):
     """encode_batch over the process group in waves (whole documents; the host-tensor form of WaveGather, on whatever backend the
     group uses -- gloo on CPU tensors in the tests): rank r encodes its slice of every wave with `encode_csr`, wave k's ragged
     result is all-gathered and lands behind the waves before it; the offsets rebase per wave.  Returns (ids, off) numpy arrays
     for ALL documents, in their order, on every rank."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     lens = [len(t.encode("utf-8")) for t in texts]
-    waves = plan_waves(lens, world, n_waves)
+    waves = plan_waves(lens, world, n_waves, taper)
     ids_parts, off_parts, t_done = [], [np.zeros(1, dtype=np.int64)], 0
     for k in range(n_waves):
         lo, hi = waves[k][rank]

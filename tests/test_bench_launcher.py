@@ -75,8 +75,18 @@ def test_c5_pieces_tile_the_documents():
         finally:
             multiprocessing.Pool = real
             os.environ.pop("SPL_BENCH_FORCE_DIST", None)
-        sl = bench.c5_wave_slices(100, 8, bench.C5_WAVES)
-        assert [x for k in range(bench.C5_WAVES) for r in range(8) for x in range(*sl[k][r])] == list(range(100 * bench.C5_PIECES))
-        assert max(b - a for k in range(bench.C5_WAVES) for a, b in sl[k]) == min(b - a for k in range(bench.C5_WAVES) for a, b in sl[k]) == 25
+        sl = bench.c5_wave_slices(100, 8, bench.N_WAVES)
+        assert [x for k in range(bench.N_WAVES) for r in range(8) for x in range(*sl[k][r])] == list(range(100 * bench.C5_PIECES))
+        # tapered: the waves shrink, the last one is a few per cent of the batch; within a wave the ranks' slices differ by at most one piece
+        sizes = [sum(b - a for a, b in sl[k]) for k in range(bench.N_WAVES)]
+        assert sizes == sorted(sizes, reverse=True) and sizes[-1] <= 0.06 * sum(sizes) and sizes[0] >= 0.25 * sum(sizes), sizes
+        assert all(max(b - a for a, b in sl[k]) - min(b - a for a, b in sl[k]) <= 1 for k in range(bench.N_WAVES))
+        eq = bench.c5_wave_slices(100, 8, 8, taper=1.0)
+        assert max(b - a for k in range(8) for a, b in eq[k]) == min(b - a for k in range(8) for a, b in eq[k]) == 25
+        # config 4's prompts: every rank's slices of every wave tile the million prompts in order
+        cs = [bench.c4_wave_slices(r, 8) for r in range(8)]
+        assert [x for k in range(bench.N_WAVES) for r in range(8) for x in (cs[r][k][0], cs[r][k][1])][0] == 0
+        ends = [cs[r][k] for k in range(bench.N_WAVES) for r in range(8)]
+        assert all(a[1] == b[0] for a, b in zip(ends, ends[1:])) and ends[-1][1] == bench.C4_PARTS * bench.C4_PART_DOCS
     finally:
         bench.C5_DOCS, bench._c5_doc = saved

@@ -20,6 +20,10 @@ else:
     texts = getattr(corpus, gen)(ndocs)
 batch = DeviceBatch(texts, torch.device("cuda", 0))
 reserve(tok, batch.n_bytes, batch.n_docs)
+for k_, v_ in (("memo", "SPL_WALLS_MEMO"), ("fuse", "SPL_WALLS_FUSE")):
+    if os.environ.get(v_) is not None: L.spl_set_option(tok.handle, k_.encode(), int(os.environ[v_]))
+for _ in range(6): encode_device(tok, batch)          # (the chunk memo fills)
+torch.cuda.synchronize()
 st = (ctypes.c_uint64 * 16)()
 L.spl_debug_phases(tok.handle, 1, st)
 nt = min((batch.n_bytes + TB - 1) // TB, 2048)
