@@ -90,15 +90,14 @@ int spl_device_count(void);
  * line, parsed as load_tiktoken_bpe does (src/core/vocab.rs:57-89: last space separates, rank
  * trimmed, a later duplicate key replaces the earlier one) -- or this repo's packed SPLV container
  * (tools/pack_vocab.py), told apart by the container's magic.
- * Restrictions (refused with SPL_EINVAL): ids must be < 2^21; the vocabulary must contain all 256
- * single bytes (ByteLevel: all 256 alphabet characters, each ranking below every longer token) --
- * the merge kernels identify a node with a token id, which byte_pair_encode's "unknown byte" branches
- * (src/core/bpe.rs:73-75, 182-191) would break; two different keys must not share an id.
- * Keys of up to 8 bytes live in single-slot tables built by hash-and-displace: keys that share a
- * two-byte prefix (1..4-byte keys, 16-bit salt) or a four-byte-prefix filter slot (5..8-byte keys,
- * 10-bit salt) share a salt, and a vocabulary for which no salt separates one such group even after
- * three doublings of the table is refused (SPL_EINVAL, "could not give every key of the ... table a
- * slot of its own").  No pretrained vocabulary comes near that; the reference's hash map has no
+ * Restrictions (refused with SPL_EINVAL): ids must be < 2^21; two different keys must not share an id; a ByteLevel vocabulary must hold
+ * all 256 alphabet characters, each ranking below every longer token.  A vocabulary that LACKS single bytes is taken as the reference
+ * takes it (src/core/bpe.rs:73-75, 99-111, 182-191: pairs are ranked by their concatenated bytes, a node whose bytes are no token is
+ * dropped from the result): the missing bytes get pseudo ids behind the vocabulary's for the merge loops and are never emitted.
+ * Keys of up to 8 bytes live in single-slot tables built by hash-and-displace: keys that share a two-byte prefix (1..4-byte keys, 16-bit
+ * salt) or a four-byte-prefix filter slot (5..8-byte keys, 10-bit salt) share a salt; a table in which some group finds no salt is
+ * doubled, up to 2^24 slots (4 000 keys under one two-byte prefix: 2^20 slots).  Only a group of more than about ten thousand keys is
+ * refused (SPL_EINVAL, "could not give every key of the ... table a slot of its own"); the reference's hash map has no
  * such limit. */
 spl_tokenizer* spl_create(const void* vocab, size_t vocab_len, const void* uclass_tab, size_t uclass_len,
                           const spl_opts* opts);

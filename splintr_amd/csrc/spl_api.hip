@@ -482,6 +482,7 @@ int upload_tables(Ctx& c, const HostTables& ht) {
     c.dt.max_key_len = ht.max_key_len;
     c.dt.pattern = (uint32_t)ht.pattern;
     c.dt.all_bytes = ht.all_bytes ? 1u : 0u;
+    c.dt.id_limit = ht.id_limit;
     return SPL_OK;
 }
 
@@ -780,6 +781,7 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
         HIP_TRY(hipMemcpyAsync(t->d_dbg + 14, init, 16, hipMemcpyHostToDevice, s));
     }
     b.blk_base = t->d_blk;
+    b.id_limit = t->dt.id_limit;
     b.ids_out = d_ids; b.ids_cap = ids_cap; b.off_out = d_out_off;
     if (phase != 1) {                                        // (the chunk memo: a fill, if the earlier launches left something to put in)
         int rcm = memo_before_launch(tk, t, s);

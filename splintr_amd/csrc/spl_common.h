@@ -152,6 +152,7 @@ struct DeviceTables {
     uint32_t max_key_len;
     uint32_t pattern;         // PAT_*
     uint32_t all_bytes;       // 1 if all 256 single bytes are tokens
+    uint32_t id_limit;        // byte_id[] of a byte the vocabulary lacks is a pseudo id >= id_limit: merged like any id, dropped where tokens are emitted (0xFFFFFFFF: none)
     // p8: an upper bound of the length of tokens longer than 8 bytes by their first 8 bytes.  Bucket =
     // hash of the 8 bytes, two entries of tag << 8 | longest such token (255 = "unbounded"), 0 = free;
     // tag 0xFFFFFF matches every key (a third prefix met in the bucket).  A miss is exact, a hit may

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(MEMO_FILL_NT) void k_memo_fill(DeviceTables T, Memo
         // token nt - 1 ends where this one starts: ends of tokens 0..4 in the entry, of tokens 5..12 in the second line
         if (nt >= 1u && nt <= 5u) ends |= q << (6u * (nt - 1u));
         else if (nt >= 6u && nt <= 13u) ends2[(nt - 6u) / 5u] |= q << (6u * ((nt - 6u) % 5u));
-        if (id == SPL_NO_RANK || nt >= (uint32_t)SPL_MEMO_MAX_TOK) { fits = false; break; }   // (a byte the vocabulary lacks: never memoized)
+        if (id >= T.id_limit || nt >= (uint32_t)SPL_MEMO_MAX_TOK) { fits = false; break; }   // (a byte the vocabulary lacks -- a pseudo id: never memoized)
         ids[nt++] = id;
     }
     me->meta0 = 0u;                                               // (invalid while it is rewritten: nobody reads it before the launch ends)

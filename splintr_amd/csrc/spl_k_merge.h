@@ -780,6 +780,7 @@ struct DirectAcc {
 };
 
 __device__ __forceinline__ void emit_token(const Batch& b, uint32_t pos, uint32_t id) {
+    if (id >= b.id_limit) return;                             // (the pseudo id of a single byte the vocabulary lacks: no token, bpe.rs:182-191)
     b.stage[pos] = id;
     atomicOr(&b.tbits[pos >> 5], 1u << (pos & 31));
 }

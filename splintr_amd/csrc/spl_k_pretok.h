@@ -674,6 +674,7 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
         //  of the tail's tokens beyond the window.  It used to be written behind s_ids and counted as a window token:
         //  a garbage id, found by the randomized stress run, seed 22739.)
         auto put = [&](int q, uint32_t id) {
+            if (id >= T.id_limit) return;                     // (the pseudo id of a single byte the vocabulary lacks: no token, bpe.rs:182-191)
             if (DIRECT && q >= Wv) {
                 const uint32_t g = (uint32_t)(w0 + q);
                 __hip_atomic_store(&b.stage[g], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -815,6 +816,7 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
         const int lane = tid & 63, wv = tid >> 6;
         const uint32_t ovf_lo = (uint32_t)(w0 + Wv);       // tokens from here on live in HBM (stage[] / tbits[])
         auto emit_g = [&](uint32_t q, uint32_t id) {
+            if (id >= T.id_limit) return;                     // (as put: a byte the vocabulary lacks)
             const int64_t i = (int64_t)q - w0;
             if (i < (int64_t)Wv) {
                 s_ids[i] = id;

@@ -134,6 +134,7 @@ struct Batch {
     // chunk memo (spl_k_memo.h; mlog == nullptr: the tiles log nothing): SPL_MEMO_LOG_REGIONS regions of mlog_cap entries of SPL_MEMO_LOG_WORDS
     // words each, their fill counters, and the word in pinned host memory that tells the host there is something to put in
     uint32_t* mlog; uint32_t* mlog_cnt; uint32_t mlog_cap; uint32_t* mflag;
+    uint32_t id_limit;         // DeviceTables::id_limit, for the kernels that are given no tables
 };
 
 // Workgroup barrier for hand-overs through LDS ONLY: __syncthreads() also waits for the wavefront's outstanding global stores (its release

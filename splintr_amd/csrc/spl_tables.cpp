@@ -316,11 +316,16 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
         auto it = enc.find(std::string(1, (char)b));
         if (it != enc.end()) out.byte_id[b] = it->second; else out.all_bytes = false;
     }
+    // A vocabulary that LACKS single bytes (the reference takes any: byte_pair_encode ranks pairs by their concatenated bytes and drops a
+    // node whose bytes are no token when it collects the result, src/core/bpe.rs:73-75, 99-111, 182-191).  The pair-table merge loops
+    // identify a node with an id, so every missing byte gets a PSEUDO id behind the vocabulary's (max_id + 1 + k): pairs through such a byte
+    // are in the pair table like any other, the byte's own "token" is dropped where tokens are emitted (id >= id_limit).
+    out.id_limit = 0xFFFFFFFFu;
     if (!out.all_bytes) {
-        // The pair-table merge loop is exact only when every node's bytes are a token
-        // (DESIGN.md "Pair table equivalence"); all four in-scope vocabularies qualify.
-        err = "vocabulary must contain all 256 single-byte tokens";
-        return 1;
+        uint32_t next = max_rank_seen + 1;
+        for (int b = 0; b < 256; b++) if (out.byte_id[b] == SPL_NO_RANK) out.byte_id[b] = next++;
+        if (next - 1 > SPL_ID_MASK) { err = "token ids must be < 2^21 (with the pseudo ids of the single bytes the vocabulary lacks)"; return 1; }
+        out.id_limit = max_rank_seen + 1;
     }
 
     // ---- short / long key tables ----------------------------------------------------------
@@ -451,14 +456,17 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
     // every one of its keys lands in a slot that is still free, no two of them in the same one.  Large groups go in while
     // the table is nearly empty, the thousands of one- and two-key groups fill what is left: cl100k_base places 27 000
     // tiny keys in 2^16 slots and 48 600 t8 keys in 2^17, o200k_base 99 000 t8 keys in 2^17 slots (76 % full).  A table
-    // that cannot be completed is doubled (at most three times: by then it is four to eight times as sparse).
+    // that cannot be completed is doubled (up to 2^24 slots).
     auto displace = [&](std::vector<std::vector<KeyRef>>& groups, int words, int salt_bits, size_t n_keys, size_t min_slots,
                         std::vector<uint32_t>& tab, std::vector<uint32_t>& salts, const char* what) -> bool {
         std::vector<uint32_t> order;
         for (uint32_t g = 0; g < groups.size(); g++) if (!groups[g].empty()) order.push_back(g);
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return groups[a].size() > groups[b].size(); });
         uint32_t slots = pow2_at_least(std::max(n_keys + n_keys / 4 + 2, min_slots));
-        for (int attempt = 0; attempt < 4; attempt++, slots *= 2) {
+        // (a table that cannot be completed is doubled, up to 2^24 slots: a group of k keys needs about k^2 / (2 ln(salts)) slots to find a salt
+        //  under which its keys collide neither with each other nor with what is placed -- 4 000 keys of 3..4 bytes under ONE two-byte
+        //  prefix take 2^20 slots, 8 MB; the shipped vocabularies complete at the first size)
+        for (; slots <= (1u << 24); slots *= 2) {
             std::vector<uint8_t> used(slots, 0);
             salts.assign(groups.size(), 0);
             std::vector<uint32_t> at;
@@ -497,7 +505,7 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
                 }
             return true;
         }
-        err = std::string("could not give every key of the ") + what + " table a slot of its own (a two-byte / four-byte prefix shared by too many keys)";
+        err = std::string("could not give every key of the ") + what + " table a slot of its own within 2^24 slots (a two-byte / four-byte prefix shared by more than about ten thousand keys)";
         return false;
     };
     {
@@ -544,14 +552,19 @@ int build_tables(const uint8_t* splv, size_t splv_len, const uint8_t* ucls, size
     // ---- pair table: every 2-split of every token whose halves are tokens --------------------
     std::vector<std::pair<uint64_t, uint32_t>> pairs;
     pairs.reserve(enc.size() * 3);
+    auto node_id = [&](const std::string& bytes) -> uint32_t {     // a token's id; a single byte the vocabulary lacks: its pseudo id
+        auto it = enc.find(bytes);
+        if (it != enc.end()) return it->second;
+        return bytes.size() == 1 ? out.byte_id[(uint8_t)bytes[0]] : SPL_NO_RANK;
+    };
     for (const auto& kv : enc) {
         const std::string& k = kv.first;
         for (size_t cut = 1; cut < k.size(); cut++) {
-            auto l = enc.find(k.substr(0, cut));
-            if (l == enc.end()) continue;
-            auto r = enc.find(k.substr(cut));
-            if (r == enc.end()) continue;
-            pairs.emplace_back(pair_key(l->second, r->second), kv.second);
+            const uint32_t l = node_id(k.substr(0, cut));
+            if (l == SPL_NO_RANK) continue;
+            const uint32_t r = node_id(k.substr(cut));
+            if (r == SPL_NO_RANK) continue;
+            pairs.emplace_back(pair_key(l, r), kv.second);
         }
     }
     out.n_pairs = (uint32_t)pairs.size();

@@ -44,6 +44,7 @@ struct HostTables {
     uint32_t n_keys = 0, n_pairs = 0;
     uint32_t max_id = 0;
     bool all_bytes = false;
+    uint32_t id_limit = 0xFFFFFFFFu;     // ids from here on are pseudo ids of single bytes the vocabulary lacks: never emitted
     bool byte_level = false;
     int pattern = PAT_CL100K;
     // decoder side: id -> raw bytes (CSR); ids with no entry have empty spans

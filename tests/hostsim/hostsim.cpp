@@ -111,7 +111,7 @@ void* hs_create(const char* splv, const char* ucls, int pattern, char* errbuf, i
     d.t8_tab = h.t8_tab.data(); d.t8_mask = (uint32_t)((h.t8_tab.size() - 4) / SPL_T8_WORDS) - 1;
     d.long_tab = h.long_tab.data(); d.long_mask = (uint32_t)h.long_tab.size() - 1; d.key_blob = h.key_blob.data();
     d.pair_tab = h.pair_tab.data(); d.pair_mask = (uint32_t)(h.pair_tab.size() / SPL_PAIR_BUCKET) - 1;
-    d.byte_id = h.byte_id.data(); d.max_key_len = h.max_key_len; d.pattern = (uint32_t)h.pattern; d.all_bytes = h.all_bytes ? 1u : 0u;
+    d.byte_id = h.byte_id.data(); d.max_key_len = h.max_key_len; d.pattern = (uint32_t)h.pattern; d.all_bytes = h.all_bytes ? 1u : 0u; d.id_limit = h.id_limit;
     d.p8_tab = reinterpret_cast<const P8Bucket*>(h.p8_tab.data()); d.p8_mask = (uint32_t)(h.p8_tab.size() / 2) - 1;
     d.len_mask = h.len_mask.data(); d.tiny_free = h.tiny_free; d.t8_free = h.t8_free;
     d.ascii_base = (uint32_t)h.ucls_stage1[0] << h.ucls_shift;

@@ -23,13 +23,19 @@ CONFIGS = {
 }
 
 
-def timed(fn, min_s=0.4, min_reps=3):
+def timed(fn, min_s=0.4, min_reps=3, trials=3):
+    """seconds per call: the BEST of `trials` averages over at least min_s seconds and min_reps calls each (the host-side figures -- packing,
+    list building, thread wake-ups -- jitter by 5-10 % from trial to trial on a 256-CPU box; the best trial is the one nothing else disturbed)"""
     fn()
-    reps, t0 = 0, time.perf_counter()
-    while reps < min_reps or time.perf_counter() - t0 < min_s:
-        fn()
-        reps += 1
-    return (time.perf_counter() - t0) / reps
+    best = None
+    for _ in range(max(1, trials)):
+        reps, t0 = 0, time.perf_counter()
+        while reps < min_reps or time.perf_counter() - t0 < min_s / max(1, trials):
+            fn()
+            reps += 1
+        t = (time.perf_counter() - t0) / reps
+        best = t if best is None or t < best else best
+    return best
 
 
 def measure(cfg: str, docs=None, python_surface=True, devices=None, options=None):
