@@ -208,7 +208,7 @@ int hs_encode(void* p, const uint8_t* text, int n, uint32_t* ids, uint32_t* n_pr
         st.i.assign(len, 0); st.r.assign(len, 0);
         bpe_serial(s->dt, st, tx, a, len);
         for (int i = 0; i < len; i++)
-            if (st.i[i] != SPL_DEAD && st.i[i] != SPL_NO_RANK) ids[out++] = st.i[i];
+            if (st.i[i] != SPL_DEAD && st.i[i] < s->dt.id_limit) ids[out++] = st.i[i];     // (a pseudo id: a single byte the vocabulary lacks, dropped)
     }
     if (n_probe_hits) *n_probe_hits = hits;
     return out;

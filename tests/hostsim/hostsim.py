@@ -68,6 +68,16 @@ class HostSim:
         if not self._h:
             raise ValueError(err.value.decode())
 
+    @classmethod
+    def from_file(cls, path, pattern_id=0, ucls="unicode_classes.bin"):
+        """a vocabulary file in the reference's tiktoken text format (or an .splv container), built-in pattern `pattern_id`"""
+        self = cls.__new__(cls)
+        err = ctypes.create_string_buffer(256)
+        self._h = lib().hs_create(str(path).encode(), os.path.join(_DATA, ucls).encode(), pattern_id, err, 256)
+        if not self._h:
+            raise ValueError(err.value.decode())
+        return self
+
     def classify_check(self, data: bytes) -> bool:
         return bool(lib().hs_classify_check(self._h, data, len(data)))
 
