@@ -776,11 +776,15 @@ def main():
 
 C5_PIECES = 16          # distributed runs: every C5 document is cut into this many pieces at context-free boundaries (128 KiB each)
 # Distributed strong-scaling legs: the batch is exchanged in N_WAVES TAPERED waves (splintr_amd.distributed.wave_fractions: wave k gets
-# taper ** k of the batch -- 33 / 23 / 16 / 11 / 8 / 5.5 / 3.8 % for 7 waves at 0.7).  Up to round 5 it was 8 equal waves: a rank's slice of
-# every wave 3.4 MB at 8 GPUs (launches of that size run at 30 GB/s one after the other, 27 MB in one launch at 42) and the last wave, whose
-# exchange nothing hides, an eighth of the batch.  Now the early launches are large and the one exposed exchange is 3.8 % of the result.
-N_WAVES = int(os.environ.get("SPL_BENCH_WAVES", "7"))
-WAVE_TAPER = float(os.environ.get("SPL_BENCH_WAVE_TAPER", "0.7"))
+# taper ** k of the batch).  What the taper should be depends on X / E -- the time the links need for the whole result over the time the
+# rank needs to encode its share: a wave's exchange hides behind the NEXT wave's encode only if that one is not shorter, so the waves may
+# shrink by at most X / E from one to the next, and the last wave -- whose exchange nothing hides -- is then as small as it can be
+# (DESIGN.md section 6 has the arithmetic; tools/dev/wave_taper.py the encode side measured at a rank's slice sizes).  With round 6's
+# encoder (a rank's eighth of config 4 in 0.59 - 0.63 ms) and 300 GB/s of all-gather bandwidth X / E is 0.85 - 0.9 with ids packed three
+# bytes each: 8 waves at 0.85 are 20.6 / 17.5 / 14.9 / 12.7 / 10.8 / 9.1 / 7.8 / 6.6 % -- the exposed exchange half of what 8 equal waves
+# expose, and no wave's exchange waits for the one before it.  Faster links want a smaller taper: SPL_BENCH_WAVE_TAPER / SPL_BENCH_WAVES.
+N_WAVES = int(os.environ.get("SPL_BENCH_WAVES", "8"))
+WAVE_TAPER = float(os.environ.get("SPL_BENCH_WAVE_TAPER", "0.85"))
 
 
 def wave_count_bounds(n_items, n_waves=None, taper=None):

@@ -121,6 +121,7 @@ uint32_t spl_n_devices(const spl_tokenizer* t);
  *   "small_path"             0/1 (1): batches of at most 4 KB and 256 documents take the latency path (spl_small_path_calls)
  *   "memo"                   0/1 (1): the chunk memo (spl_memo_stats); "memo_bits" 4..22 (16): log2 of its 64-byte entries; "memo_log_cap"
  *                            1..65536 (512): missed chunks the tiles log per region (of 64) between two fills
+ *   "memo_clear"             (any value) empties the memo of every context: Tokenizer::clear_cache (src/core/tokenizer.rs:995-1000)
  *   "fuse"                   0/1 (1): batches of up to "fuse_max_tiles" tiles (default and maximum 1536: about 1.2 MB) are ONE launch --
  *                            every tile learns the number of tokens in front of it from the other tiles' published counts and writes its
  *                            part of the CSR itself; 0: the tile kernel and k_tile_out, as for larger batches

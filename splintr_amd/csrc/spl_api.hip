@@ -715,6 +715,7 @@ int memo_ensure(spl_tokenizer* tk, Ctx* t) {
         HIP_TRY(hipHostGetDevicePointer(&dp, t->h_mflag, 0));
         t->dh_mflag = (uint32_t*)dp;
     }
+    t->h_mflag[0] = 0;
     t->memo_mask = (uint32_t)(slots - 1);
     t->dt.memo = t->d_memo; t->dt.memo_mask = t->memo_mask; t->dt.memo_ext = t->d_memo_ext;
     t->memo_round = 0; t->memo_fills = 0; t->memo_since = 0;
@@ -2151,6 +2152,7 @@ int spl_set_option(spl_tokenizer* t, const char* name, int64_t value) {
     else if (k == "pick_streams") t->pick_streams = value != 0;
     else if (k == "fuse") t->fuse = value != 0;
     else if (k == "memo") t->memo = value != 0;
+    else if (k == "memo_clear") { for (auto& c : t->ctx) { c->memo_drop(); if (c->twin) c->twin->memo_drop(); } }      // Tokenizer::clear_cache (tokenizer.rs:995-1000)
     else if (k == "memo_bits" && value >= 4 && value <= 22) { t->memo_bits = (uint32_t)value; for (auto& c : t->ctx) { c->memo_drop(); if (c->twin) c->twin->memo_drop(); } }
     else if (k == "memo_log_cap" && value >= 1 && value <= 65536) { t->memo_log_cap = (uint32_t)value; for (auto& c : t->ctx) { c->memo_drop(); if (c->twin) c->twin->memo_drop(); } }
     else if (k == "fuse_max_tiles" && value >= 0 && value <= (int64_t)FUSE_MAX_TILES) t->fuse_max_tiles = (uint32_t)value;

@@ -355,12 +355,21 @@ class Tokenizer:
 
     @property
     def cache_len(self) -> int:
-        """The reference's LRU (src/core/tokenizer.rs:310) is a CPU optimisation that does not
-        change results; the GPU path keeps no cache."""
-        return 0
+        """Tokenizer::cache_len (src/core/tokenizer.rs:1002-1005; bindings.rs:438-440).  The reference's LRU of encoded chunks is, on the GPU
+        path, the chunk memo (csrc/spl_k_memo.h): result-transparent there and here.  The memo is filled BETWEEN launches, once the tiles have
+        logged enough chunks it did not hold -- so unlike the reference's cache it may still be empty after one short text."""
+        import ctypes
+        out = (ctypes.c_uint64 * 4)()
+        L = _ffi.lib()
+        L.spl_memo_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+        if L.spl_memo_stats(self.handle, out) != 0:
+            raise RuntimeError(_ffi.last_error())
+        return int(out[1] + out[2])
 
     def clear_cache(self) -> None:
-        return None
+        """Tokenizer::clear_cache (src/core/tokenizer.rs:995-1000): the memo starts empty again."""
+        if _ffi.lib().spl_set_option(self.handle, b"memo_clear", 1) != 0:
+            raise RuntimeError(_ffi.last_error())
 
     @property
     def has_custom_pattern(self) -> bool:

@@ -79,7 +79,7 @@ def test_c5_pieces_tile_the_documents():
         assert [x for k in range(bench.N_WAVES) for r in range(8) for x in range(*sl[k][r])] == list(range(100 * bench.C5_PIECES))
         # tapered: the waves shrink, the last one is a few per cent of the batch; within a wave the ranks' slices differ by at most one piece
         sizes = [sum(b - a for a, b in sl[k]) for k in range(bench.N_WAVES)]
-        assert sizes == sorted(sizes, reverse=True) and sizes[-1] <= 0.06 * sum(sizes) and sizes[0] >= 0.25 * sum(sizes), sizes
+        assert sizes == sorted(sizes, reverse=True) and sizes[-1] <= 0.08 * sum(sizes) and sizes[0] >= 0.18 * sum(sizes), sizes
         assert all(max(b - a for a, b in sl[k]) - min(b - a for a, b in sl[k]) <= 1 for k in range(bench.N_WAVES))
         eq = bench.c5_wave_slices(100, 8, 8, taper=1.0)
         assert max(b - a for k in range(8) for a, b in eq[k]) == min(b - a for k in range(8) for a, b in eq[k]) == 25

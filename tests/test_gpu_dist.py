@@ -236,7 +236,7 @@ def test_bench_distributed_branch_rehearsal_world_1():
         c = line[key]
         assert c["scaling"] == "strong" and c["value"] > 0 and "bit-exact" in c["parity"], c
         cd = c["dist"]
-        assert cd["rccl_ranks"] == 1 and cd["per_rank"]["exchange_stream_ms"][0] > 0 and cd["waves"] == 7, c
+        assert cd["rccl_ranks"] == 1 and cd["per_rank"]["exchange_stream_ms"][0] > 0 and cd["waves"] == 8, c
         assert isinstance(cd["stream_picks"], list) and len(cd["stream_picks"]) >= 1 and cd["least_bad_pick"] in (True, False)
         assert set(cd["calibration_ms_per_step"]) == {"allgather", "p2p", "allgather+pack24"} | {f"{f}+2s@{p}" for p in range(3) for f in ("allgather", "allgather+pack24")}
         assert cd["collective"] in ("allgather", "p2p") and cd["encode_streams"] in (1, 2)

@@ -130,3 +130,17 @@ def test_the_latency_path_and_device_batches_share_the_memo(coracle):
         assert np.array_equal(ids, want[0]) and np.array_equal(off, want[1])
     for x in texts[:200]:                                              # single texts (the latency path) through the memo the batches filled
         assert t.encode(x) == orc.encode_batch([x])[0]
+
+
+def test_cache_len_and_clear_cache_are_the_memo_s(coracle):
+    """Tokenizer::cache_len / clear_cache (/root/reference/src/core/tokenizer.rs:995-1005; its tests :1111-1129)."""
+    from splintr_amd import Tokenizer, corpus
+    t = Tokenizer.from_pretrained("cl100k_base")
+    assert t.cache_len == 0
+    texts = corpus.c2_wide(400, seed=51)
+    _passes(t, coracle("cl100k_base"), texts, 4)
+    assert t.cache_len > 0
+    t.clear_cache()
+    assert t.cache_len == 0
+    _passes(t, coracle("cl100k_base"), texts, 4)
+    assert t.cache_len > 0

@@ -33,6 +33,11 @@ def _create(blob: bytes, pattern: int = 0, flags: int = 0):
     return bool(h), err
 
 
+def _parsed(ok, err):
+    """The file was taken: the handle exists (a GPU box), or the one thing that failed is the device this box lacks."""
+    return ok or "hipSetDevice" in err or "ROCm-capable" in err
+
+
 def test_parser_errors_are_the_reference_s():
     ok, err = _create(b"SGVsbG8= 0\nnospace\n")
     assert not ok and "Missing space separator" in err                 # vocab.rs:69-72
@@ -43,17 +48,17 @@ def test_parser_errors_are_the_reference_s():
     ok, err = _create(b"SGVsbG8= twelve\n")
     assert not ok and "Invalid rank" in err                            # vocab.rs:80-83
     ok, err = _create(b"SGVsbG8= 12\xc2\xa0\n")                        # str::trim takes Unicode White_Space (NBSP) off the rank:
-    assert not ok and "256 single-byte" in err                         # the line parses (and the vocabulary is then too small)
+    assert _parsed(ok, err)                                            # the line parses
     ok, err = _create("SGVsbG8= \u3000\u200312\u2028\n".encode())
-    assert not ok and "256 single-byte" in err
+    assert _parsed(ok, err)
     ok, err = _create(b"SGVsbG8= 1\xc2\xa02\n")                        # ... but not out of its middle
     assert not ok and "Invalid rank" in err
     ok, err = _create(b"SGVsbG8= 99999999999\n")
     assert not ok and "Invalid rank" in err                            # does not fit u32
     ok, err = _create(b"")
     assert not ok and "empty vocabulary" in err
-    ok, err = _create(b"SGVsbG8= 0\n")                                 # parses, but is no usable vocabulary here
-    assert not ok and "256 single-byte" in err
+    ok, err = _create(b"SGVsbG8= 0\n")                                 # one key and no single byte: a vocabulary (bpe.rs:203-215 has three bytes)
+    assert _parsed(ok, err)
     ok, err = _create(b"YQ== 5\nYg== 5\n")                              # two keys, one id: refused (see the header)
     assert not ok and "share the id 5" in err
     ok, err = _create(b"YQ== 3000000\n")
