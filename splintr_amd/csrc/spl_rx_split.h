@@ -86,7 +86,8 @@ struct RxArgs {
 struct RxCh { uint32_t cp, len, cls; };
 
 // One lane's view of the text and of the program.
-struct RxCtx {
+template <int LT> struct RxCtxT {
+    static constexpr int LDS_TEXT = LT, TAB = LT - 4, BMW = (TAB + 63) / 64 * 2;     // staged bytes; tabulated positions; words of one window bitmap
     const uint32_t* img;              // LDS
     const uint8_t* s_txt;             // LDS: text[wbase, wbase + RX_LDS_TEXT)
     uint32_t wb;                      // wbase modulo 2^32 (-4 for block 0): q - wb is q's window index
@@ -96,7 +97,7 @@ struct RxCtx {
                                       // character), slot RX_MAX_RUNSETS: the bytes that START a character
     __device__ __forceinline__ uint32_t rd(uint32_t q) const {
         const uint32_t i = q - wb;
-        return i < (uint32_t)RX_LDS_TEXT ? (uint32_t)s_txt[i] : (uint32_t)a->text[q];
+        return i < (uint32_t)LDS_TEXT ? (uint32_t)s_txt[i] : (uint32_t)a->text[q];
     }
     // first 0 bit of bitmap m at or behind window index i0, below lim (lim if none)
     __device__ __forceinline__ uint32_t first_zero(const uint32_t* m, uint32_t i0, uint32_t lim) const {
@@ -194,6 +195,7 @@ struct RxCtx {
         return c.cp == '_' || ((SPL_BIT(c.cls) & (M_L | SPL_BIT(C_N))) != 0 && c.cp != 0xFFFFFFFFu);
     }
 };
+using RxCtx = RxCtxT<RX_LDS_TEXT>;
 
 // Every position of one block through the matcher (spl_regex.cpp Matcher::run with its recursion for look-aheads and atomic
 // groups unrolled onto the one stack: a CALL entry below the sub-run's floor).  ONE flat loop: a lane that has no attempt pulls
@@ -217,9 +219,10 @@ __device__ __forceinline__ uint32_t rx_hop(uint32_t q, uint32_t nxv);
 // One run of the matcher program from pc0, anchored at p (a whole pattern, or ONE alternative of its top-level alternation: what is
 // on the stack when the run ends with nothing left to try are only its own entries).  Returns the end, RX_FAIL or RX_ABORT.
 struct RxAt { uint32_t p, n, back; bool p_is_start; };
-__device__ __forceinline__ uint32_t rx_vm(RxCtx& c, uint32_t* stk, const RxArgs& a, const RxAt& at, uint32_t pc0, uint32_t& steps) {
+template <class C>
+__device__ __forceinline__ uint32_t rx_vm(C& c, uint32_t* stk, const RxArgs& a, const RxAt& at, uint32_t pc0, uint32_t& steps) {
     constexpr uint32_t NOTYET = 0xFFFFFFFDu;
-    const uint32_t* const cs = c.bm + RX_MAX_RUNSETS * RX_BMW;
+    const uint32_t* const cs = c.bm + RX_MAX_RUNSETS * C::BMW;
     const uint32_t p = at.p, n = at.n, back = at.back;
     const bool p_is_start = at.p_is_start;
     const bool trunc = n > p + (uint32_t)RX_REACH;
@@ -287,11 +290,11 @@ __device__ __forceinline__ uint32_t rx_vm(RxCtx& c, uint32_t* stk, const RxArgs&
                 if (aop == RXO_CLASS && y > 8u && pos < n) {
                     // a long run of a tabulated class: a bit scan over the window (every byte of a member character is a 1 bit)
                     const uint32_t slot = c.set(ax)[9], i0 = pos - c.wb;
-                    if (slot != 0xFFFFFFFFu && i0 < (uint32_t)RX_TAB) {
+                    if (slot != 0xFFFFFFFFu && i0 < (uint32_t)C::TAB) {
                         const uint32_t ni = n - c.wb;
-                        const uint32_t tl = ni < (uint32_t)RX_TAB ? ni : (uint32_t)RX_TAB;
-                        uint32_t e = c.first_zero(c.bm + slot * RX_BMW, i0, tl);
-                        const bool open_end = e == (uint32_t)RX_TAB && e < ni;          // the table ends here, perhaps inside a character:
+                        const uint32_t tl = ni < (uint32_t)C::TAB ? ni : (uint32_t)C::TAB;
+                        uint32_t e = c.first_zero(c.bm + slot * C::BMW, i0, tl);
+                        const bool open_end = e == (uint32_t)C::TAB && e < ni;          // the table ends here, perhaps inside a character:
                         if (open_end && e > i0) e = c.last_set_below(cs, e);             // the loop below goes on from that character's start
                         const uint32_t kk = c.count_set(cs, i0, e);
                         if (kk <= y) { k = kk; q = pos + (e - i0); more = open_end; }
@@ -350,7 +353,7 @@ __device__ __forceinline__ uint32_t rx_vm(RxCtx& c, uint32_t* stk, const RxArgs&
                         // (what is charged against RX_STEPS is the work done: one bit scan inside the tabulated window, k characters re-counted
                         //  beyond it.  Charging k either way made `\s*[\r\n]+` give up on 200 blanks without a newline -- 200 + 199 + ... steps
                         //  for 200 bit scans; found by the PCRE2 pin of tests/test_gpu_custom_pattern.py, round 5)
-                        if (ei <= (uint32_t)RX_TAB) { e_new = k ? c.wb + c.last_set_below(cs, ei) : pos; steps += 1u; }     // the start of the run's last character
+                        if (ei <= (uint32_t)C::TAB) { e_new = k ? c.wb + c.last_set_below(cs, ei) : pos; steps += 1u; }     // the start of the run's last character
                         else { e_new = pos; for (uint32_t j = 0; j < k; j++) e_new += c.char_len(e_new); steps += k; }
                         if (k > c.inst(pc).y) { stk[(2 * sp) * RXT] = pc | (k << 16); stk[(2 * sp + 1) * RXT] = (pos - p) | ((e_new - p) << 16); sp++; }
                         pos = e_new;
@@ -386,9 +389,10 @@ __device__ __forceinline__ uint32_t rx_vm(RxCtx& c, uint32_t* stk, const RxArgs&
 // One SIMPLE alternative (regex_device_image: a straight line of one-character / run items in which giving characters back can never
 // help -- possessive, or the item's characters cannot be taken by what follows) at p: greedy, item by item, no stack.  Every lane of
 // the wavefront walks the same items: this is the code that runs at full width.
-__device__ __forceinline__ uint32_t rx_simple_alt(const RxCtx& c, const uint32_t* items, uint32_t n_items, uint32_t tail, uint32_t p, uint32_t n, bool on,
+template <bool UNI, class C>
+__device__ __forceinline__ uint32_t rx_simple_alt(const C& c, const uint32_t* items, uint32_t n_items, uint32_t tail, uint32_t p, uint32_t n, bool on,
                                                   uint32_t& why) {
-    const uint32_t* const cs = c.bm + RX_MAX_RUNSETS * RX_BMW;
+    const uint32_t* const cs = c.bm + RX_MAX_RUNSETS * C::BMW;
     const bool trunc = n > p + (uint32_t)RX_REACH;
     const uint32_t lim = p + (uint32_t)RX_REACH;
     uint32_t pos = p, rs = p, rk = 0;                       // rs, rk: where the last item began and how many characters it took
@@ -396,8 +400,9 @@ __device__ __forceinline__ uint32_t rx_simple_alt(const RxCtx& c, const uint32_t
     for (uint32_t it = 0; it < n_items; it++) {
         const uint4 item = *reinterpret_cast<const uint4*>(items + 4 * it);       // op, x, min, max
         // (the same for every lane: in scalar registers the tests on them are scalar branches, not exec-mask detours)
-        const uint32_t op = __builtin_amdgcn_readfirstlane(item.x), x = __builtin_amdgcn_readfirstlane(item.y);
-        const uint32_t mn = __builtin_amdgcn_readfirstlane(item.z), mx = __builtin_amdgcn_readfirstlane(item.w);
+        // (UNI: the items are the same for every lane of the wavefront -- k_rx_match's lock step; the walk kernel's lanes each have their own)
+        const uint32_t op = UNI ? __builtin_amdgcn_readfirstlane(item.x) : item.x, x = UNI ? __builtin_amdgcn_readfirstlane(item.y) : item.y;
+        const uint32_t mn = UNI ? __builtin_amdgcn_readfirstlane(item.z) : item.z, mx = UNI ? __builtin_amdgcn_readfirstlane(item.w) : item.w;
         if (op == RXO_CHAR && mx == 1u && x < 0x80u) {          // an ASCII literal, once or not at all: no branch per lane
             const bool hit = ok && pos < n && c.rd(pos) == x;
             ok = ok && (hit || mn == 0u);
@@ -424,12 +429,12 @@ __device__ __forceinline__ uint32_t rx_simple_alt(const RxCtx& c, const uint32_t
         bool more = true;
         if (op == RXO_CLASS && mx > 8u && pos < n) {
             const uint32_t slot = c.set(x)[9], i0 = pos - c.wb;
-            if (slot != 0xFFFFFFFFu && i0 < (uint32_t)RX_TAB) {
+            if (slot != 0xFFFFFFFFu && i0 < (uint32_t)C::TAB) {
                 const uint32_t ni = n - c.wb;
-                const uint32_t tl = ni < (uint32_t)RX_TAB ? ni : (uint32_t)RX_TAB;
+                const uint32_t tl = ni < (uint32_t)C::TAB ? ni : (uint32_t)C::TAB;
                 // the 64 bits from i0 on, without a loop: nearly every run ends inside them (the words behind a bitmap's end that this may
                 // read belong to the next bitmap / the padding, and lie beyond tl)
-                const uint32_t* const m = c.bm + slot * RX_BMW + (i0 >> 5);
+                const uint32_t* const m = c.bm + slot * C::BMW + (i0 >> 5);
                 const uint32_t* const s3 = cs + (i0 >> 5);
                 const uint32_t sh = i0 & 31u;
                 const uint32_t mlo = __builtin_amdgcn_alignbit(m[1], m[0], sh), mhi = __builtin_amdgcn_alignbit(m[2], m[1], sh);
@@ -440,8 +445,8 @@ __device__ __forceinline__ uint32_t rx_simple_alt(const RxCtx& c, const uint32_t
                                                   : (uint32_t)__popc(clo & ((1u << er) - 1u));
                     if (kk <= mx) { k = kk; q = pos + er; more = false; }
                 } else {
-                    uint32_t e = c.first_zero(c.bm + slot * RX_BMW, i0, tl);
-                    const bool open_end = e == (uint32_t)RX_TAB && e < ni;
+                    uint32_t e = c.first_zero(c.bm + slot * C::BMW, i0, tl);
+                    const bool open_end = e == (uint32_t)C::TAB && e < ni;
                     if (open_end && e > i0) e = c.last_set_below(cs, e);
                     const uint32_t kk = c.count_set(cs, i0, e);
                     if (kk <= mx) { k = kk; q = pos + (e - i0); more = open_end; }
@@ -486,7 +491,7 @@ __device__ __forceinline__ uint32_t rx_simple_alt(const RxCtx& c, const uint32_t
         if (t <= cut) return RX_FAIL;
         // one character less: the start of the run's last character
         const uint32_t ei = pos - c.wb;
-        if (ei <= (uint32_t)RX_TAB) pos = c.wb + c.last_set_below(cs, ei);
+        if (ei <= (uint32_t)C::TAB) pos = c.wb + c.last_set_below(cs, ei);
         else { pos = rs; for (uint32_t j = 0; j + 1 < t; j++) pos += c.char_len(pos); }
     }
 }
@@ -566,7 +571,7 @@ __device__ __forceinline__ void rx_attempts(RxCtx& c, uint32_t* stk, const RxBlo
         alt.x = __builtin_amdgcn_readfirstlane(alt.x); alt.y = __builtin_amdgcn_readfirstlane(alt.y);     // (the same for every lane)
         alt.z = __builtin_amdgcn_readfirstlane(alt.z); alt.w = __builtin_amdgcn_readfirstlane(alt.w);
         uint32_t r = RX_FAIL, why = 0;
-        if (alt.y & 1u) r = rx_simple_alt(c, c.img + (alt.w >> 16), alt.w & 0xFFFFu, alt.y >> 8, p, at.n, can, why);
+        if (alt.y & 1u) r = rx_simple_alt<true>(c, c.img + (alt.w >> 16), alt.w & 0xFFFFu, alt.y >> 8, p, at.n, can, why);
         else if (can) r = rx_vm(c, stk, a, at, alt.z, steps);
         if (can && r == RX_ABORT) { rx_bad(a, p); act = false; }
         else if (can && r != RX_FAIL && r > p) e = r;
