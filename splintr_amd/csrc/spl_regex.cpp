@@ -944,6 +944,66 @@ bool regex_device_image(const RegexProg& prog, std::vector<uint32_t>& w) {
         w.push_back(alts.size() > 32 ? 0xFFFFFFFFu : mask);
     }
     while (w.size() % 4) w.push_back(0u);
+    // ---- the two-byte dispatch: for an attempt that begins with two ASCII bytes, the alternatives that can start with THAT pair -- a blank
+    // in front of a digit starts ` ?\p{N}+`, not the letter run, the punctuation run and the two blank runs its first byte alone lets in.
+    // A simple alternative is walked over the two bytes exactly as the device walks it (greedy, item by item); whatever two bytes do not
+    // decide -- an alternative that runs the matcher program, a tail that walks back into its run, items beyond the second byte -- counts
+    // as "can".  Bytes that behave alike share a class (rows / columns of the 128 x 128 table that are equal): cls0[128], cls1[128] as bytes,
+    // the number of column classes, then the table.  w[12] = 0: none (more than 32 alternatives, or too many classes).
+    if (alts.size() <= 32) {
+        auto first_ok = [&](const Alt& al, uint32_t b) {
+            if (al.f == 0xFFFFFFFFu) return true;
+            const FirstSet& fs = prog.firsts[al.f];
+            return ((fs.ascii[b >> 6] >> (b & 63)) & 1ull) != 0;
+        };
+        auto can2 = [&](const Alt& al, uint32_t b0, uint32_t b1) {
+            if (!first_ok(al, b0)) return false;
+            if (!al.simple) return true;
+            const uint32_t ch[2] = {b0, b1};
+            int ci = 0;
+            for (size_t j = 0; j < al.items.size(); j++) {
+                const Item& it = al.items[j];
+                if (j + 1 == al.items.size() && al.tail != TAIL_NONE) return true;
+                uint32_t k = 0;
+                while (k < it.mx && ci < 2 && takes(it, Ch{ch[ci], 1, host_cp_class(ht, ch[ci])})) { k++; ci++; }
+                if (ci == 2) return true;
+                if (k < it.mn) return false;
+            }
+            return true;
+        };
+        std::vector<uint32_t> full(128 * 128, 0u);
+        for (uint32_t b0 = 0; b0 < 128; b0++)
+            for (uint32_t b1 = 0; b1 < 128; b1++) {
+                uint32_t mask = 0;
+                for (size_t i = 0; i < alts.size(); i++) if (can2(alts[i], b0, b1)) mask |= 1u << i;
+                full[b0 * 128 + b1] = mask;
+            }
+        std::vector<uint32_t> cls0(128), cls1(128), rep0, rep1;
+        for (uint32_t b = 0; b < 128; b++) {
+            size_t k = 0;
+            for (; k < rep0.size(); k++) if (std::equal(full.begin() + b * 128, full.begin() + b * 128 + 128, full.begin() + rep0[k] * 128)) break;
+            if (k == rep0.size()) rep0.push_back(b);
+            cls0[b] = (uint32_t)k;
+        }
+        for (uint32_t b = 0; b < 128; b++) {
+            size_t k = 0;
+            for (; k < rep1.size(); k++) {
+                bool eq = true;
+                for (uint32_t r = 0; r < 128 && eq; r++) eq = full[r * 128 + b] == full[r * 128 + rep1[k]];
+                if (eq) break;
+            }
+            if (k == rep1.size()) rep1.push_back(b);
+            cls1[b] = (uint32_t)k;
+        }
+        if (rep0.size() * rep1.size() <= 512) {
+            w[12] = (uint32_t)w.size();
+            for (uint32_t q = 0; q < 32; q++) w.push_back(cls0[4 * q] | cls0[4 * q + 1] << 8 | cls0[4 * q + 2] << 16 | cls0[4 * q + 3] << 24);
+            for (uint32_t q = 0; q < 32; q++) w.push_back(cls1[4 * q] | cls1[4 * q + 1] << 8 | cls1[4 * q + 2] << 16 | cls1[4 * q + 3] << 24);
+            w.push_back((uint32_t)rep1.size());
+            for (uint32_t r : rep0) for (uint32_t c : rep1) w.push_back(full[r * 128 + c]);
+            while (w.size() % 4) w.push_back(0u);
+        }
+    }
     w[11] = (uint32_t)w.size();
     w.push_back((uint32_t)alts.size()); w.push_back(0u); w.push_back(0u); w.push_back(0u);
     const size_t ent = w.size();

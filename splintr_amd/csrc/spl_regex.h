@@ -45,17 +45,17 @@ bool regex_split_bits(const RegexProg& prog, const uint8_t* text, size_t n, uint
 // The program as a flat image of 32-bit words for the DEVICE splitter (spl_rx_split.h: the same matcher, one text position per
 // lane).  Layout: RX_HDR_WORDS header words -- [0] instructions, [1] word offset of the class sets, [2] sets, [3] offset of the
 // first-character filters, [4] filters, [5] offset of the ranges, [6] ranges, [7] 1 if a set tests general categories, [8] offset
-// of the first-byte dispatch, [9] class sets with a run bitmap, [10] offset of their list, [11] offset of the alternatives --; from word RX_HDR_WORDS the
+// of the first-byte dispatch, [9] class sets with a run bitmap, [10] offset of their list, [11] offset of the alternatives, [12] offset of the two-byte dispatch (0: none) --; from word RX_HDR_WORDS the
 // instructions, RX_INST_WORDS words each (op, x, y, f); class sets of RX_SET_WORDS words (class-code bits, general-category bits,
 // negated, four words of ASCII membership, first range, ranges, run-bitmap slot or ~0); filters of RX_FIRST_WORDS words (four
 // words of ASCII membership, "anything beyond ASCII"); ranges as (first, last) pairs; the first-byte table: for each ASCII byte and (entry
-// 128) for any other, a bit per alternative of the top-level alternation whose first-character filter lets the byte in; the list of the (at most RX_MAX_RUNSETS) class sets
+// 128) for any other, a bit per alternative of the top-level alternation whose first-character filter lets the byte in; the two-byte dispatch (byte classes of the first and the second byte, 128 bytes each; the number of second-byte classes; for each pair of classes the alternatives an attempt that begins with such bytes can start); the list of the (at most RX_MAX_RUNSETS) class sets
 // that a run instruction repeats: the device matcher tabulates their membership over its text window once per block and takes a
 // run as a bit scan; the alternatives of the top-level alternation (count, three words of padding, then four words each: first-
 // character filter or ~0, 1 if SIMPLE | its tail kind << 8, first instruction, items | word offset of the items << 16; a simple alternative's items are
 // four words each: one-character op, its operand, fewest, most repeats -- see regex_device_image).  Returns false if the program is larger than the device matcher keeps in LDS (RX_IMAGE_MAX_WORDS): such a
 // pattern is split on the host.
-constexpr uint32_t RX_HDR_WORDS = 12, RX_INST_WORDS = 4, RX_SET_WORDS = 10, RX_FIRST_WORDS = 5, RX_IMAGE_MAX_WORDS = 3072, RX_MAX_RUNSETS = 12;
+constexpr uint32_t RX_HDR_WORDS = 16, RX_INST_WORDS = 4, RX_SET_WORDS = 10, RX_FIRST_WORDS = 5, RX_IMAGE_MAX_WORDS = 3072, RX_MAX_RUNSETS = 12;
 bool regex_device_image(const RegexProg& prog, std::vector<uint32_t>& words);
 
 // The same as a list of (start, end) pairs (tests).

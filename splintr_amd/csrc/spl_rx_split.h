@@ -557,7 +557,21 @@ __device__ __forceinline__ void rx_attempts(RxCtx& c, uint32_t* stk, const RxBlo
     const uint32_t* const alts = c.img + __builtin_amdgcn_readfirstlane(c.img[11]);
     const uint32_t* const fsets = c.img + __builtin_amdgcn_readfirstlane(c.img[3]);
     const uint32_t n_alts = __builtin_amdgcn_readfirstlane(alts[0]);
-    const uint32_t viable = act ? c.img[c.img[8] + (b0 < 0x80 ? b0 : 128u)] : 0u;
+    uint32_t viable = act ? c.img[c.img[8] + (b0 < 0x80 ? b0 : 128u)] : 0u;
+#ifndef SPL_RX_PAIRS
+#define SPL_RX_PAIRS 1            /* 0: dispatch on the first byte alone (A/B) */
+#endif
+    {   // two ASCII bytes: the alternatives that can start with that PAIR (regex_device_image: byte classes, a table over pairs of them)
+        const uint32_t po = __builtin_amdgcn_readfirstlane(c.img[12]);
+        if (SPL_RX_PAIRS && po != 0u && act && b0 < 0x80 && p + 1 < at.n) {
+            const uint32_t b1 = c.rd(p + 1);
+            if (b1 < 0x80) {
+                const uint32_t* const pt = c.img + po;
+                const uint32_t c0 = (pt[b0 >> 2] >> ((b0 & 3u) * 8u)) & 0xFFu, c1 = (pt[32 + (b1 >> 2)] >> ((b1 & 3u) * 8u)) & 0xFFu;
+                viable = pt[65 + c0 * pt[64] + c1];
+            }
+        }
+    }
     uint32_t e = RX_FAIL, steps = 0;
     for (uint32_t ai = 0; ai < n_alts; ai++) {             // (uniform)
         // (which alternatives the attempt's first byte can start: one word from the image's first-byte table instead of a filter per alternative)

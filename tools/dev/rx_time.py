@@ -17,7 +17,8 @@ def pack(texts):
 cases = [("c2", corpus.c2(1000)), ("c3x400", corpus.c3(400)), ("c2x8000", corpus.c2(8000))]
 if once or os.environ.get("RX_TIME_QUICK") == "1": cases = cases[:1]
 WALKS = (1,)
-PATS = [x for x in (("gpt2", GPT2_PATTERN), ("tk_cl100k", TIKTOKEN_CL100K), ("tk_o200k", TIKTOKEN_O200K)) if os.environ.get("RX_TIME_PAT", x[0]) == x[0]]
+ALL = (("gpt2", GPT2_PATTERN), ("tk_cl100k", TIKTOKEN_CL100K), ("tk_o200k", TIKTOKEN_O200K), ("p3", r" ?\p{L}+| ?[^\s\p{L}]+|\s+"), ("p2", r"\S+|\s+"))
+PATS = [x for x in ALL if x[0] in os.environ.get("RX_TIME_PAT", "gpt2,tk_cl100k,tk_o200k").split(",")]
 for pname, pat in PATS:
     t = Tokenizer.from_bytes(blob_v, pat)
     for cname, texts in cases:

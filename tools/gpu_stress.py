@@ -11,6 +11,8 @@ import argparse
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=120.0, help="wall-clock budget")
 ap.add_argument("--seed", type=int, default=1000, help="first seed")
+ap.add_argument("--device", action="store_true", help="every batch ALSO device-resident through spl_encode_batch_device (batches of up to 1536 tiles: the one-launch form), "
+                "encoded twice -- the chunk memo the handle has built over the earlier batches, then with this batch's chunks in it")
 args = ap.parse_args()
 budget, seed0 = args.seconds, args.seed
 orcs = {}
@@ -24,6 +26,15 @@ while time.time() - t0 < budget:
     tg._force_tiles(name, geom)
     try:
         tg.assert_batch_equal(name, texts, coracle, special=special)
+        if args.device and texts:
+            import numpy as np, torch
+            from splintr_amd.device import DeviceBatch, encode_device, result_csr
+            o_ids, o_off = tg.oracle_csr(coracle(name), texts, special)
+            b = DeviceBatch(texts, torch.device("cuda", 0))
+            for rep in range(2):
+                encode_device(tg.tok(name), b, with_special=special); torch.cuda.synchronize()
+                ids, off = result_csr(b)
+                assert np.array_equal(off, o_off) and np.array_equal(ids, o_ids), f"device-resident pass {rep}"
     except AssertionError as e:
         bad += 1; print("MISMATCH seed", seed, name, "geom", geom, "special", special, str(e)[:300], flush=True)
     finally:
