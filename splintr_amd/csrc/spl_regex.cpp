@@ -1017,7 +1017,16 @@ bool regex_device_image(const RegexProg& prog, std::vector<uint32_t>& w) {
             const Item& run = al.items.back();
             w.push_back(al.tail_item.op); w.push_back(al.tail_item.x); w.push_back(0u); w.push_back(run.gives_back ? run.mn : 0xFFFFFFFFu);
         }
-        w[ent + 4 * i] = al.f; w[ent + 4 * i + 1] = al.simple ? (1u | (al.tail << 8)) : 0u; w[ent + 4 * i + 2] = al.start;
+        // (bits 16..23 of the flags: how many alternatives from this one on have its SHAPE -- simple, as many items, single characters and runs
+        //  at the same places, the same kind of tail: the device evaluates them in ONE sweep, every lane with the items of its own alternative)
+        uint32_t glen = 1;
+        auto same_shape = [](const Alt& x, const Alt& y) {
+            if (!x.simple || !y.simple || x.items.size() != y.items.size() || x.tail != y.tail) return false;
+            for (size_t j = 0; j < x.items.size(); j++) if ((x.items[j].mx == 1u) != (y.items[j].mx == 1u)) return false;
+            return true;
+        };
+        if (alts.size() <= 32) while (i + glen < alts.size() && glen < 16 && same_shape(al, alts[i + glen])) glen++;
+        w[ent + 4 * i] = al.f; w[ent + 4 * i + 1] = al.simple ? (1u | (al.tail << 8) | (glen << 16)) : 0u; w[ent + 4 * i + 2] = al.start;
         w[ent + 4 * i + 3] = (al.simple ? (uint32_t)al.items.size() : 0u) | (off << 16);
     }
     return w.size() <= RX_IMAGE_MAX_WORDS;

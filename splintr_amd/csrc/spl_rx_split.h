@@ -573,19 +573,45 @@ __device__ __forceinline__ void rx_attempts(RxCtx& c, uint32_t* stk, const RxBlo
         }
     }
     uint32_t e = RX_FAIL, steps = 0;
-    for (uint32_t ai = 0; ai < n_alts; ai++) {             // (uniform)
+#ifndef SPL_RX_GROUPS
+#define SPL_RX_GROUPS 1           /* 0: every alternative in a sweep of its own (A/B) */
+#endif
+    for (uint32_t ai = 0; ai < n_alts;) {                  // (uniform)
         // (which alternatives the attempt's first byte can start: one word from the image's first-byte table instead of a filter per alternative)
-        bool can = act && e == RX_FAIL && ((viable >> (ai & 31u)) & 1u) != 0u;
-        if (n_alts > 32u && can && alts[4 + 4 * ai] != 0xFFFFFFFFu) {
-            const uint32_t* fs = fsets + RX_FIRST_WORDS * alts[4 + 4 * ai];
-            can = b0 < 0x80 ? ((fs[b0 >> 5] >> (b0 & 31)) & 1u) != 0 : fs[4] != 0u;
-        }
-        if (!__any(can)) continue;
         uint4 alt = *reinterpret_cast<const uint4*>(alts + 4 + 4 * ai);           // filter, flags, first instruction, items (count | offset << 16)
         alt.x = __builtin_amdgcn_readfirstlane(alt.x); alt.y = __builtin_amdgcn_readfirstlane(alt.y);     // (the same for every lane)
         alt.z = __builtin_amdgcn_readfirstlane(alt.z); alt.w = __builtin_amdgcn_readfirstlane(alt.w);
+        const uint32_t glen = SPL_RX_GROUPS && (alt.y & 1u) ? (alt.y >> 16) & 0xFFu : 1u;
+        if (glen > 1u) {
+            // alternatives ai .. ai + glen - 1 have ONE shape (regex_device_image): a sweep for all of them, every lane with the items of the
+            // first of them that its bytes can start -- ` ?\p{L}+`, ` ?\p{N}+`, ` ?[^\s\p{L}\p{N}]+` are one sweep, not three; a lane whose
+            // alternative fails takes its next one of the group in the next sweep (leftmost-first is kept: the group is consecutive)
+            uint32_t vg = act && e == RX_FAIL ? (viable >> ai) & ((1u << glen) - 1u) : 0u;
+            while (__any(vg != 0u)) {
+                const bool on = vg != 0u;
+                const uint32_t k = ai + (on ? (uint32_t)__ffs((int)vg) - 1u : 0u);
+                const uint32_t aw = alts[4 + 4 * k + 3];
+                uint32_t why = 0;
+                const uint32_t r = rx_simple_alt<false>(c, c.img + (aw >> 16), alt.w & 0xFFFFu, (alt.y >> 8) & 0xFFu, p, at.n, on, why);
+                if (on) {
+                    if (r == RX_ABORT) { rx_bad(a, p); act = false; vg = 0; }
+                    else if (r != RX_FAIL && r > p) { e = r; vg = 0; }
+                    else if (r != RX_FAIL) { act = false; vg = 0; }       // (an empty match: find_iter skips the character, as behind no match)
+                    else vg &= vg - 1u;
+                }
+            }
+            ai += glen;
+            continue;
+        }
+        bool can = act && e == RX_FAIL && ((viable >> (ai & 31u)) & 1u) != 0u;
+        if (n_alts > 32u && can && alt.x != 0xFFFFFFFFu) {
+            const uint32_t* fs = fsets + RX_FIRST_WORDS * alt.x;
+            can = b0 < 0x80 ? ((fs[b0 >> 5] >> (b0 & 31)) & 1u) != 0 : fs[4] != 0u;
+        }
+        ai++;
+        if (!__any(can)) continue;
         uint32_t r = RX_FAIL, why = 0;
-        if (alt.y & 1u) r = rx_simple_alt<true>(c, c.img + (alt.w >> 16), alt.w & 0xFFFFu, alt.y >> 8, p, at.n, can, why);
+        if (alt.y & 1u) r = rx_simple_alt<true>(c, c.img + (alt.w >> 16), alt.w & 0xFFFFu, (alt.y >> 8) & 0xFFu, p, at.n, can, why);
         else if (can) r = rx_vm(c, stk, a, at, alt.z, steps);
         if (can && r == RX_ABORT) { rx_bad(a, p); act = false; }
         else if (can && r != RX_FAIL && r > p) e = r;
