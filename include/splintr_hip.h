@@ -119,8 +119,9 @@ uint32_t spl_n_devices(const spl_tokenizer* t);
  *   "direct_read"            0/1 (1): one-chunk batches whose text comes from spl_host_alloc are read where they lie (no H2D copy)
  *   "device_split"           0/1 (1): a custom split pattern's split runs on the GPU (spl_split_device); 0 keeps it on the host cores
  *   "small_path"             0/1 (1): batches of at most 4 KB and 256 documents take the latency path (spl_small_path_calls)
- *   "memo"                   0/1 (1): the chunk memo (spl_memo_stats); "memo_bits" 4..22 (16): log2 of its 64-byte entries; "memo_log_cap"
- *                            1..65536 (512): missed chunks the tiles log per region (of 64) between two fills
+ *   "memo"                   0/1 (1): the chunk memo (spl_memo_stats); "memo_bits" 4..22 (20): log2 of its entries for chunks of up to 32 bytes
+ *                            (128 bytes each); "memo_long_bits" 0..20 (16; 0: none): ... for chunks of 33..64 bytes (164 bytes each);
+ *                            "memo_log_cap" 1..65536 (1024): missed chunks the tiles log per region (of 64) between two fills
  *   "memo_clear"             (any value) empties the memo of every context: Tokenizer::clear_cache (src/core/tokenizer.rs:995-1000)
  *   "fuse"                   0/1 (1): batches of up to "fuse_max_tiles" tiles (default and maximum 1536: about 1.2 MB) are ONE launch --
  *                            every tile learns the number of tokens in front of it from the other tiles' published counts and writes its

@@ -257,6 +257,8 @@ struct Ctx {
     uint32_t fpar = 0, fprev = 0;
     // chunk memo (spl_k_memo.h): the table, the tiles' log of what it did not hold, one claim word per slot for k_memo_fill, the pinned flag
     MemoEnt* d_memo = nullptr; MemoExt* d_memo_ext = nullptr; uint32_t* d_mlog = nullptr; uint32_t* d_mlog_cnt = nullptr; uint32_t* d_mclaim = nullptr;
+    uint8_t* d_memo2 = nullptr;               // the second table (chunks of 33..64 bytes), ONE allocation: entries | second lines | key bytes 32..63 | claim words | log
+    uint32_t memo2_mask = 0, memo2_cap = 0;
     unsigned long long* d_mstats = nullptr;
     uint32_t* h_mflag = nullptr; uint32_t* dh_mflag = nullptr;
     uint32_t memo_round = 0, memo_cap = 0, memo_mask = 0;
@@ -344,9 +346,9 @@ struct Ctx {
         if (!d_memo) return;
         if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return; }
         (void)hipDeviceSynchronize();
-        hipFree(d_memo); hipFree(d_memo_ext); hipFree(d_mlog); hipFree(d_mlog_cnt); hipFree(d_mclaim); hipFree(d_mstats);
-        d_memo = nullptr; d_memo_ext = nullptr; d_mlog = nullptr; d_mlog_cnt = nullptr; d_mclaim = nullptr; d_mstats = nullptr;
-        dt.memo = nullptr; dt.memo_mask = 0;
+        hipFree(d_memo); hipFree(d_memo_ext); hipFree(d_mlog); hipFree(d_mlog_cnt); hipFree(d_mclaim); hipFree(d_mstats); hipFree(d_memo2);
+        d_memo = nullptr; d_memo_ext = nullptr; d_mlog = nullptr; d_mlog_cnt = nullptr; d_mclaim = nullptr; d_mstats = nullptr; d_memo2 = nullptr;
+        dt.memo = nullptr; dt.memo_mask = 0; dt.memo2 = nullptr; dt.memo2_mask = 0;
     }
     void free_slots() {
         for (int i = 0; i < NSLOT; i++) {
@@ -372,7 +374,7 @@ struct Ctx {
         hipFree(d_ids); hipFree(d_oo);
         hipFree((void*)d_rx_image); hipFree((void*)d_gc1); hipFree((void*)d_gc2); hipFree(d_rx_ws); hipFree(d_rx_status); hipFree(d_rx_bits); if (h_rx_status) (void)hipHostFree(h_rx_status);
         if (h_small) (void)hipHostFree(h_small);
-        hipFree(d_memo); hipFree(d_memo_ext); hipFree(d_mlog); hipFree(d_mlog_cnt); hipFree(d_mclaim); hipFree(d_mstats); if (h_mflag) (void)hipHostFree(h_mflag);
+        hipFree(d_memo); hipFree(d_memo_ext); hipFree(d_mlog); hipFree(d_mlog_cnt); hipFree(d_mclaim); hipFree(d_mstats); hipFree(d_memo2); if (h_mflag) (void)hipHostFree(h_mflag);
         hipFree(d_rx_patch); hipFree(d_rx_bad); if (h_rx_bad) (void)hipHostFree(h_rx_bad); if (ev_split) (void)hipEventDestroy(ev_split);
         hipFree(d_dec_ids); hipFree(d_dec_blk); hipFree(d_dec_idoff); hipFree(d_dec_out); hipFree(d_dec_first); hipFree(d_dec_docoff);
         for (auto& ds : dslot) {
@@ -415,7 +417,7 @@ struct spl_tokenizer {
     uint64_t dec_chunk_ids = 2ull << 20;      // decode pipeline: ids per chunk (batches of fewer than three such chunks are decoded in one piece; C3: 28.3 GB/s at 1 M, 30.5 at 2 M, 29.6 at 3 M)
     int copy_threads = 4;                     // pipeline, pageable input: threads that copy a chunk into pinned staging
     int memo = 1;                             // the chunk memo (spl_k_memo.h); "memo_bits": log2 of its entries (64 bytes each), "memo_log_cap": logged misses per region and fill
-    uint32_t memo_bits = 20, memo_log_cap = 1024;
+    uint32_t memo_bits = 20, memo_log_cap = 1024, memo_long_bits = 16;          // "memo_long_bits": log2 of the entries for chunks of 33..64 bytes (160 bytes each; 0: none)
     int fuse = 1;                             // tile-owned mode as ONE launch (spl_k_fuse.h) for batches of up to fuse_max_tiles tiles; 0: k_pretok + k_tile_out
     uint32_t fuse_max_tiles = FUSE_MAX_TILES; // (every tile of such a launch is resident at once -- 256 CUs x 6 workgroups: a tile that waits for its base holds nobody up)
     int pick_streams = 1;                     // pipeline: its streams chosen by measurement so that they run side by side (pick_stream_beside)
@@ -694,6 +696,19 @@ int rx_launch(spl_tokenizer* tk, Ctx* c, const uint8_t* d_text, uint64_t n_bytes
 // The chunk memo of a context (spl_k_memo.h): built empty at the first launch; the tiles log what it did not hold and raise the pinned
 // flag; a launch that finds the flag raised first runs k_memo_fill on its stream -- encode the logged chunks, put them in -- and then
 // its own kernels: the memo is only ever written between two launches of the stream that reads it.
+// (the parts of the second table's one allocation)
+struct Memo2Parts { MemoEnt* ent; MemoExt* ext; MemoHi* hi; uint32_t* claim; uint32_t* log; };
+Memo2Parts memo2_parts(Ctx* t) {
+    const size_t s2 = (size_t)t->memo2_mask + 1;
+    Memo2Parts m;
+    m.ent = (MemoEnt*)t->d_memo2; m.ext = (MemoExt*)(m.ent + s2); m.hi = (MemoHi*)(m.ext + s2); m.claim = (uint32_t*)(m.hi + s2); m.log = m.claim + s2;
+    return m;
+}
+void memo_tables(Ctx* t) {
+    t->dt.memo = t->d_memo; t->dt.memo_mask = t->memo_mask; t->dt.memo_ext = t->d_memo_ext;
+    t->dt.memo2 = nullptr; t->dt.memo2_mask = 0; t->dt.memo2_ext = nullptr; t->dt.memo2_hi = nullptr;
+    if (t->d_memo2) { const Memo2Parts m = memo2_parts(t); t->dt.memo2 = m.ent; t->dt.memo2_mask = t->memo2_mask; t->dt.memo2_ext = m.ext; t->dt.memo2_hi = m.hi; }
+}
 int memo_ensure(spl_tokenizer* tk, Ctx* t) {
     if (t->d_memo) return SPL_OK;
     const size_t slots = (size_t)1 << tk->memo_bits;
@@ -704,8 +719,17 @@ int memo_ensure(spl_tokenizer* tk, Ctx* t) {
     HIP_TRY(hipMemset(t->d_mclaim, 0, slots * 4));
     t->memo_cap = tk->memo_log_cap;
     HIP_TRY(hipMalloc((void**)&t->d_mlog, (size_t)SPL_MEMO_LOG_REGIONS * t->memo_cap * SPL_MEMO_LOG_WORDS * 4));
-    HIP_TRY(hipMalloc((void**)&t->d_mlog_cnt, SPL_MEMO_LOG_REGIONS * 4));
-    HIP_TRY(hipMemset(t->d_mlog_cnt, 0, SPL_MEMO_LOG_REGIONS * 4));
+    HIP_TRY(hipMalloc((void**)&t->d_mlog_cnt, 2 * SPL_MEMO_LOG_REGIONS * 4));              // (the second half: the log of chunks of 33..64 bytes)
+    HIP_TRY(hipMemset(t->d_mlog_cnt, 0, 2 * SPL_MEMO_LOG_REGIONS * 4));
+    t->memo2_mask = 0; t->memo2_cap = 0;
+    if (tk->memo_long_bits) {
+        const size_t s2 = (size_t)1 << tk->memo_long_bits;
+        t->memo2_cap = std::max<uint32_t>(tk->memo_log_cap / 8, 16);
+        const size_t bytes = s2 * (sizeof(MemoEnt) + sizeof(MemoExt) + sizeof(MemoHi) + 4) + (size_t)SPL_MEMO_LOG_REGIONS * t->memo2_cap * SPL_MEMO_LOG_WORDS2 * 4;
+        HIP_TRY(hipMalloc((void**)&t->d_memo2, bytes));
+        HIP_TRY(hipMemset(t->d_memo2, 0, s2 * (sizeof(MemoEnt) + sizeof(MemoExt) + sizeof(MemoHi) + 4)));
+        t->memo2_mask = (uint32_t)(s2 - 1);
+    }
     HIP_TRY(hipMalloc((void**)&t->d_mstats, 16));
     HIP_TRY(hipMemset(t->d_mstats, 0, 16));
     if (!t->h_mflag) {
@@ -717,23 +741,28 @@ int memo_ensure(spl_tokenizer* tk, Ctx* t) {
     }
     t->h_mflag[0] = 0;
     t->memo_mask = (uint32_t)(slots - 1);
-    t->dt.memo = t->d_memo; t->dt.memo_mask = t->memo_mask; t->dt.memo_ext = t->d_memo_ext;
+    memo_tables(t);
     t->memo_round = 0; t->memo_fills = 0; t->memo_since = 0;
     return SPL_OK;
 }
 int memo_before_launch(spl_tokenizer* tk, Ctx* t, hipStream_t s) {
-    if (!tk->memo) { t->dt.memo = nullptr; return SPL_OK; }
+    if (!tk->memo) { t->dt.memo = nullptr; t->dt.memo2 = nullptr; return SPL_OK; }
     int rc = memo_ensure(tk, t);
     if (rc) return rc;
-    t->dt.memo = t->d_memo; t->dt.memo_mask = t->memo_mask; t->dt.memo_ext = t->d_memo_ext;
+    memo_tables(t);
     t->memo_since++;
     // (the flag was raised by an EARLIER launch's tiles, when one of the log's regions became half full)
     if (*(volatile uint32_t*)t->h_mflag) {
         *(volatile uint32_t*)t->h_mflag = 0;
         t->memo_round++;
-        hipLaunchKernelGGL(k_memo_fill, dim3((t->memo_cap + MEMO_FILL_NT - 1) / MEMO_FILL_NT, SPL_MEMO_LOG_REGIONS), dim3(MEMO_FILL_NT), 0, s, t->dt, t->d_memo, t->d_memo_ext, (const uint32_t*)t->d_mlog,
-                           t->d_mlog_cnt, t->memo_cap, t->d_mclaim, t->memo_round, t->d_mstats);
-        HIP_TRY(hipMemsetAsync(t->d_mlog_cnt, 0, SPL_MEMO_LOG_REGIONS * 4, s));
+        hipLaunchKernelGGL(k_memo_fill<false>, dim3((t->memo_cap + MEMO_FILL_NT - 1) / MEMO_FILL_NT, SPL_MEMO_LOG_REGIONS), dim3(MEMO_FILL_NT), 0, s, t->dt, t->d_memo, t->d_memo_ext,
+                           (MemoHi*)nullptr, (const uint32_t*)t->d_mlog, (const uint32_t*)t->d_mlog_cnt, t->memo_cap, t->d_mclaim, t->memo_round, t->d_mstats);
+        if (t->d_memo2) {
+            const Memo2Parts m = memo2_parts(t);
+            hipLaunchKernelGGL(k_memo_fill<true>, dim3((t->memo2_cap + MEMO_FILL_NT2 - 1) / MEMO_FILL_NT2, SPL_MEMO_LOG_REGIONS), dim3(MEMO_FILL_NT2), 0, s, t->dt, m.ent, m.ext, m.hi,
+                               (const uint32_t*)m.log, (const uint32_t*)(t->d_mlog_cnt + SPL_MEMO_LOG_REGIONS), t->memo2_cap, m.claim, t->memo_round, t->d_mstats);
+        }
+        HIP_TRY(hipMemsetAsync(t->d_mlog_cnt, 0, 2 * SPL_MEMO_LOG_REGIONS * 4, s));
         t->memo_fills++;
         t->memo_since = 0;
     }
@@ -788,6 +817,7 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
         int rcm = memo_before_launch(tk, t, s);
         if (rcm) return rcm;
         if (t->dt.memo) { b.mlog = t->d_mlog; b.mlog_cnt = t->d_mlog_cnt; b.mlog_cap = t->memo_cap; b.mflag = t->dh_mflag; }
+        if (t->dt.memo && t->d_memo2) { b.mlog2 = memo2_parts(t).log; b.mlog2_cap = t->memo2_cap; }
     }
 
     const bool pf = t->prof;
@@ -2154,6 +2184,7 @@ int spl_set_option(spl_tokenizer* t, const char* name, int64_t value) {
     else if (k == "memo") t->memo = value != 0;
     else if (k == "memo_clear") { for (auto& c : t->ctx) { c->memo_drop(); if (c->twin) c->twin->memo_drop(); } }      // Tokenizer::clear_cache (tokenizer.rs:995-1000)
     else if (k == "memo_bits" && value >= 4 && value <= 22) { t->memo_bits = (uint32_t)value; for (auto& c : t->ctx) { c->memo_drop(); if (c->twin) c->twin->memo_drop(); } }
+    else if (k == "memo_long_bits" && value >= 0 && value <= 20) { t->memo_long_bits = (uint32_t)value; for (auto& c : t->ctx) { c->memo_drop(); if (c->twin) c->twin->memo_drop(); } }
     else if (k == "memo_log_cap" && value >= 1 && value <= 65536) { t->memo_log_cap = (uint32_t)value; for (auto& c : t->ctx) { c->memo_drop(); if (c->twin) c->twin->memo_drop(); } }
     else if (k == "fuse_max_tiles" && value >= 0 && value <= (int64_t)FUSE_MAX_TILES) t->fuse_max_tiles = (uint32_t)value;
     else if (k == "copy_threads" && value >= 1 && value <= 64) t->copy_threads = (int)value;
@@ -2646,7 +2677,7 @@ int spl_debug_merge_timing(unsigned long long out[8], int reset) {
 int spl_memo_stats(spl_tokenizer* t, uint64_t out[4]) {
     if (!t || !out) return fail(SPL_EINVAL, "null argument");
     Ctx* c = t->ctx[0].get();
-    out[0] = c->memo_fills; out[1] = out[2] = 0; out[3] = c->d_memo ? (uint64_t)c->memo_mask + 1 : 0;
+    out[0] = c->memo_fills; out[1] = out[2] = 0; out[3] = c->d_memo ? (uint64_t)c->memo_mask + 1 + (c->d_memo2 ? (uint64_t)c->memo2_mask + 1 : 0) : 0;
     if (c->d_mstats) {
         HIP_TRY(hipSetDevice(c->device));
         HIP_TRY(hipDeviceSynchronize());

@@ -131,8 +131,12 @@ struct alignas(64) MemoExt {
     uint32_t pad[6];
 };
 static_assert(sizeof(MemoExt) == 64, "one cache line");
-constexpr int SPL_MEMO_MAX_LEN = 32, SPL_MEMO_TOK1 = 6, SPL_MEMO_MAX_TOK = 14;
+// Chunks of 33..64 bytes -- long identifiers, URLs: few, but a wavefront merges each of them alone and the tile that holds one ends its launch
+// last (profiles/r06_memo.txt, block 8) -- live in a second, smaller table of the same entries; bytes 32..63 of their keys in a parallel array.
+struct alignas(32) MemoHi { uint32_t k[8]; };
+constexpr int SPL_MEMO_MAX_LEN = 32, SPL_MEMO_MAX_LEN2 = 64, SPL_MEMO_TOK1 = 6, SPL_MEMO_MAX_TOK = 14;
 constexpr uint32_t SPL_MEMO_LOG_WORDS = 12;              // one logged miss: length, eight key words, padding (48 bytes)
+constexpr uint32_t SPL_MEMO_LOG_WORDS2 = 20;             // ... of 33..64 bytes: length, sixteen key words, padding (80 bytes)
 constexpr uint32_t SPL_MEMO_LOG_REGIONS = 64;            // a tile appends to region tile % 64: one returning atomic per tile and region counter
 
 struct DeviceTables {
@@ -185,6 +189,8 @@ struct DeviceTables {
     const uint16_t* filt4;    uint32_t filt4_shift;
     const MemoEnt* memo;      uint32_t memo_mask;        // chunk memo (nullptr: off); slots - 1
     const MemoExt* memo_ext;
+    const MemoEnt* memo2;     uint32_t memo2_mask;       // ... for chunks of 33..64 bytes (meta0's length field: bytes - 32)
+    const MemoExt* memo2_ext; const MemoHi* memo2_hi;
 };
 SPL_HD uint32_t hash_f4(uint32_t w0) { return w0 * 0x9E3779B1u; }      // (index = the upper bits: >> filt4_shift)
 
@@ -221,11 +227,12 @@ SPL_HD uint32_t hash_short(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len, 
 SPL_HD uint32_t hash_long_step(uint32_t h, uint32_t w) { h = (h ^ w) * 0x9E3779B1u; return (h << 13) | (h >> 19); }
 SPL_HD uint32_t hash_long_fin(uint32_t h, uint32_t len) { return mix32(h ^ len); }
 SPL_HD uint32_t hash_long_tag(uint32_t h) { return mix32(h * 0x85EBCA77u + 0x3C6EF372u); }
-SPL_HD uint32_t hash_memo(const uint32_t k[8], uint32_t n) {
+template <int KW> SPL_HD uint32_t hash_memo_w(const uint32_t (&k)[KW], uint32_t n) {
     uint32_t h = n * 0x27D4EB2Fu + 0x165667B1u;
-    for (int i = 0; i < 8; i++) { h = (h ^ k[i]) * 0x9E3779B1u; h = (h << 13) | (h >> 19); }
+    for (int i = 0; i < KW; i++) { h = (h ^ k[i]) * 0x9E3779B1u; h = (h << 13) | (h >> 19); }
     return mix32(h);
 }
+SPL_HD uint32_t hash_memo(const uint32_t (&k)[8], uint32_t n) { return hash_memo_w<8>(k, n); }
 // (a chunk has TWO candidate slots: the second one is tried where the first is taken by another chunk)
 SPL_HD uint32_t memo_slot2(uint32_t h, uint32_t mask) { const uint32_t g = ((h >> 17) | (h << 15)) * 0x85EBCA77u; return ((g ^ (g >> 15)) & mask) ^ 1u; }
 SPL_HD uint32_t hash_pair(uint32_t l, uint32_t r) { return mix32(l * 0x9E3779B1u + r * 0x85EBCA77u + 0x27D4EB2Fu); }

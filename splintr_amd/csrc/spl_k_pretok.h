@@ -591,10 +591,13 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
                 atomicOr(&s_tbits[p >> 5], 1u << (p & 31));
             } else if (n > 1) {
                 // the chunk memo (spl_k_memo.h): a chunk it holds is finished here -- its tokens go in place -- and never reaches the merge loops
-                const int held = (T.memo && n <= SPL_MEMO_MAX_LEN && p + n <= Wv)
-                                     ? memo_probe(T, tx, p, n, [&](int q, uint32_t tid_) { s_ids[q] = tid_; atomicOr(&s_tbits[q >> 5], 1u << (q & 31)); }) : 0;
+                auto memo_put = [&](int q, uint32_t tid_) { s_ids[q] = tid_; atomicOr(&s_tbits[q >> 5], 1u << (q & 31)); };
+                const bool m_short = T.memo && n <= SPL_MEMO_MAX_LEN && p + n <= Wv;
+                const bool m_long = T.memo2 && n > SPL_MEMO_MAX_LEN && n <= SPL_MEMO_MAX_LEN2 && p + n <= Wv;       // (few: long identifiers, URLs)
+                int held = m_short ? memo_probe<false>(T, tx, p, n, memo_put) : 0;
+                if (m_long) held = memo_probe<true>(T, tx, p, n, memo_put);
 #ifdef SPL_MEMO_STATS      /* profiling: chunks the vocabulary misses by what the memo said -- e_dbg[4..7]: not probed, not held, held, known as too long */
-                if (e_dbg) atomicAdd(&e_dbg[4 + ((T.memo && n <= SPL_MEMO_MAX_LEN && p + n <= Wv) ? 1 + held : 0)], 1ull);
+                if (e_dbg) atomicAdd(&e_dbg[4 + ((m_short || m_long) ? 1 + held : 0)], 1ull);
 #endif
                 if (held == 1) continue;
                 const uint32_t item = (uint32_t)p | ((uint32_t)n << 16) | (held == 2 ? MISS_KNOWN : 0u);

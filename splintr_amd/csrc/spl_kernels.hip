@@ -134,6 +134,7 @@ struct Batch {
     // chunk memo (spl_k_memo.h; mlog == nullptr: the tiles log nothing): SPL_MEMO_LOG_REGIONS regions of mlog_cap entries of SPL_MEMO_LOG_WORDS
     // words each, their fill counters, and the word in pinned host memory that tells the host there is something to put in
     uint32_t* mlog; uint32_t* mlog_cnt; uint32_t mlog_cap; uint32_t* mflag;
+    uint32_t* mlog2; uint32_t mlog2_cap;      // ... of chunks of 33..64 bytes (SPL_MEMO_LOG_WORDS2 words an entry; counters: mlog_cnt + SPL_MEMO_LOG_REGIONS; nullptr: not logged)
     uint32_t id_limit;         // DeviceTables::id_limit, for the kernels that are given no tables
 };
 

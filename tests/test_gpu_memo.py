@@ -62,21 +62,22 @@ def test_a_table_of_sixteen_entries_keeps_losing_its_chunks_and_stays_exact(cora
     from splintr_amd import Tokenizer, corpus
     t = Tokenizer.from_pretrained("cl100k_base")
     _opt(t, "memo_bits", 4)
+    _opt(t, "memo_long_bits", 4)
     _opt(t, "memo_log_cap", 8)
     texts = corpus.c2_wide(400, seed=11)
     _passes(t, coracle("cl100k_base"), texts, 8)
-    assert _stats(t)[3] == 16 and _stats(t)[0] >= 2
+    assert _stats(t)[3] == 16 + 16 and _stats(t)[0] >= 2
 
 
 def test_chunks_of_every_token_count(coracle):
-    """Chunks the vocabulary lacks with 2 .. 20 tokens: up to six live in an entry, seven to fourteen in the slot's second line, more
-    are remembered as beyond it (and merged every time)."""
+    """Chunks the vocabulary lacks with 2 .. 20+ tokens and 2 .. 64 bytes: up to six tokens live in an entry, seven to fourteen in the slot's
+    second line, more are remembered as beyond it (and merged every time); chunks of 33 .. 64 bytes live in the second table."""
     from splintr_amd import Tokenizer
     rng = random.Random(3)
     orc = coracle("cl100k_base")
     words = []
-    for n in range(2, 33):
-        for _ in range(40):
+    for n in range(2, 65):
+        for _ in range(24):
             w = "".join(rng.choice("qxzjkvwQXZJKVW") for _ in range(n))
             words.append(w)
             words.append(" " + w[: max(1, n - 1)])
@@ -98,6 +99,27 @@ def test_special_tokens_and_a_custom_pattern_through_the_warm_memo(coracle):
     for sp in (False, True, False, True, True):
         _passes(t, coracle("cl100k_base"), texts, 1, special=sp)
     assert _stats(t)[1] > 0
+
+
+def test_long_identifiers_with_and_without_the_second_table(coracle):
+    """Chunks of 33 .. 64 bytes (snake_case / camelCase identifiers, URLs): held by the second table; with it off ("memo_long_bits" 0) and
+    with sixteen entries of it, the same ids."""
+    from splintr_amd import Tokenizer
+    rng = random.Random(9)
+    parts = ["user", "account", "manager", "factory", "Handler", "Config", "Service", "request", "response", "buffer", "Stream", "http", "www", "index", "Value"]
+    idents = ["_".join(rng.sample(parts, rng.randrange(4, 9))) for _ in range(150)] + ["".join(rng.sample(parts, rng.randrange(5, 10))) for _ in range(150)]
+    idents += ["https://" + ".".join(rng.sample(parts, 3)) + "/" + "/".join(rng.sample(parts, 3)) for _ in range(60)]
+    assert any(33 <= len(x) <= 64 for x in idents)
+    texts = [" ".join(rng.choice(idents) for _ in range(rng.randrange(3, 40))) + "\n" for _ in range(400)]
+    orc = coracle("cl100k_base")
+    for bits in (None, 0, 4):
+        t = Tokenizer.from_pretrained("cl100k_base")
+        if bits is not None:
+            _opt(t, "memo_long_bits", bits)
+        _passes(t, orc, texts, 6)
+        _passes(t, orc, list(reversed(texts)), 2)
+        if bits != 0:
+            assert _stats(t)[1] > 0
 
 
 def test_memo_off_and_on_in_one_handle(coracle):
