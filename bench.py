@@ -702,7 +702,7 @@ def main():
 
     # ---- tripwire: every rate of this line against the last committed line of an earlier round (profiles/rNN_bench.json) ------
     # (two surfaces had become 9 % and 37 % slower without anybody noticing.)  vs_prev = this / previous for rates, previous /
-    # this for latencies; anything at or below 0.95 is listed in `regressions`.
+    # this for latencies; anything at or below 0.95 (0.75 for the figures that are the host cores') is listed in `regressions`.
     vs_prev = regressions = prev_name = None
     if rank == 0 and world == 1 and not use_dist:
         import glob
@@ -718,13 +718,18 @@ def main():
         if prev:
             vs_prev, regressions = {}, []
 
+            # (figures that are the HOST cores' -- the host splitter, list building in CPython -- move by 20 % from one GPU box to the next:
+            #  1 106 / 1 533 / 1 597 / 1 283 MB/s for split_host in four runs of one build; their threshold is 0.75)
+            host_bound = ("split_host", "c_abi_host_host_split", "python_surface")
+
             def cmp_(name, now, before, lower_is_better=False):
                 if not isinstance(now, (int, float)) or not isinstance(before, (int, float)) or not now or not before:
                     return
                 r = (before / now) if lower_is_better else (now / before)
                 vs_prev[name] = round(r, 3)
-                if r <= 0.95:
-                    regressions.append({"what": name, "now": now, "previous": before, "ratio": round(r, 3)})
+                limit = 0.75 if name.rsplit(".", 1)[-1] in host_bound else 0.95
+                if r <= limit:
+                    regressions.append({"what": name, "now": now, "previous": before, "ratio": round(r, 3), "limit": limit})
             cmp_("value", value, prev.get("value"))
             cmp_("c2_wide_rotation", (c2_wide_rot or {}).get("value"), (prev.get("c2_wide_rotation") or {}).get("value"))
             cmp_("pipelined", (pipelined or {}).get("value"), (prev.get("pipelined") or {}).get("value"))
