@@ -182,7 +182,10 @@ def encode_streams(device: torch.device, pair: int = 0):
     return st[p]
 
 
-def _set_pack24(tok: Optional[Tokenizer], on: bool) -> None:
+def _set_pack24(tok: Optional[Tokenizer], on: bool, owner=None) -> None:
+    """The slab format is the HANDLE's (spl_set_option "slab_pack24"), read by the encoder at every launch: a gatherer (re)asserts ITS format
+    in front of each of its encodes and packs (one C call that stores an int), so that gatherers of both formats can live on one Tokenizer
+    (one thread) without one silently changing the wire format of the other."""
     if tok is None:                              # the bucket logic driven without an encoder (CPU tests): slabs come from the caller
         return
     if _ffi.lib().spl_set_option(tok.handle, b"slab_pack24", 1 if on else 0) != 0:
@@ -215,7 +218,7 @@ class GatherV:
         import torch.distributed as dist
         self.tok, self.dev, self.group, self.dist, self.comm = tok, device, group, dist, comm
         self.pack24 = bool(pack24)                # slab ids travel three bytes each (ids < 2**21): a quarter less on the links; EVERY rank alike
-        _set_pack24(tok, self.pack24)
+        _set_pack24(tok, self.pack24, self)
         if collective not in ("allgather", "p2p") or (collective == "p2p" and comm is None):
             raise ValueError("GatherV: collective is 'allgather' or -- with the library's communicator -- 'p2p'")
         self.collective = collective             # ncclAllGather of the bucket's slabs, or grouped send / recv of the same slabs
@@ -292,12 +295,14 @@ class GatherV:
             self._exchange()
 
     def _pack(self, batch, slab, stream_ptr) -> None:
+        _set_pack24(self.tok, self.pack24)
         rc = _ffi.lib().spl_gatherv_pack(self.tok.handle, batch.ids.data_ptr(), batch.out_off.data_ptr(), batch.n_docs,
                                          slab.data_ptr(), self.cap_words, self.max_docs, stream_ptr)
         if rc != 0:
             raise RuntimeError(_ffi.last_error())
 
     def _encode_packed(self, batch, slab, with_special, stream_ptr) -> None:
+        _set_pack24(self.tok, self.pack24)
         rc = _ffi.lib().spl_encode_batch_device_packed(
             self.tok.handle, batch.text.data_ptr(), batch.n_bytes, batch.doc_off.data_ptr(), batch.n_docs,
             _ffi.SPL_WITH_SPECIAL if with_special else 0, batch.ids.data_ptr(), batch.ids.numel(),
@@ -399,14 +404,14 @@ class WaveGather:
         self.tok, self.dev, self.comm, self.world = tok, device, comm, comm.world
         self.n_waves, self.max_docs, self.max_tokens = int(n_waves), int(max_docs), int(max_tokens)
         self.pack24 = bool(pack24)
-        _set_pack24(tok, self.pack24)
+        _set_pack24(tok, self.pack24, self)
         # A second handle of the same vocabulary (a workspace of its own): consecutive waves are then encoded on two streams in alternation,
         # wave k + 1's tile kernel starting while the stragglers of wave k's finish.  A rank's slice of a wave is small at high rank counts
         # (3.4 MB at 8 ranks x 8 waves), and launches of that size one after the other leave the GPU to every launch's ramp and tail: eight
         # of them took 0.90 ms on one stream, 0.69 ms on two -- one launch of the 27 MB: 0.63 (profiles/r05_wave_exchange.txt).
         self.toks = (tok,) if tok2 is None else (tok, tok2)
         if tok2 is not None:
-            _set_pack24(tok2, self.pack24)
+            _set_pack24(tok2, self.pack24, self)
         self.enc = encode_streams(device, enc_pair) if tok2 is not None else None
         self.enc_pair = int(enc_pair)
         self.cap_words = _slab_words(self.max_tokens, self.max_docs, self.pack24)
@@ -453,6 +458,7 @@ class WaveGather:
         L = _ffi.lib()
         k = self.k
         main = torch.cuda.current_stream(self.dev) if self.enc is None else self.enc[k & 1]
+        _set_pack24(self.toks[k % len(self.toks)], self.pack24)
         rc = L.spl_encode_batch_device_packed(self.toks[k % len(self.toks)].handle, batch.text.data_ptr(), batch.n_bytes, batch.doc_off.data_ptr(), batch.n_docs,
                                               _ffi.SPL_WITH_SPECIAL if with_special else 0, batch.ids.data_ptr(), batch.ids.numel(),
                                               batch.out_off.data_ptr(), self.send[k].data_ptr(), self.cap_words, self.max_docs, main.cuda_stream)
