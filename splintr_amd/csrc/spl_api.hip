@@ -325,6 +325,8 @@ struct Ctx {
     // profiling
     bool prof = false;
     hipEvent_t ev[KI_N + 1]{};
+    // a large device batch as ranges of its tiles (launch_all): a second stream beside the caller's, one event per range (grow-only), the hand-overs
+    hipStream_t s_rng = nullptr, s_rng_for = nullptr; std::vector<hipEvent_t> ev_rng; hipEvent_t ev_rng_in = nullptr, ev_rng_out = nullptr;
     bool ev_ready = false;
     double prof_ms[SPL_MAX_KERNELS]{};
     uint64_t prof_n[SPL_MAX_KERNELS]{};
@@ -386,6 +388,10 @@ struct Ctx {
         for (int i = 0; i < NSLOT; i++) { if (ev_h2d[i]) (void)hipEventDestroy(ev_h2d[i]); if (ev_cmp[i]) (void)hipEventDestroy(ev_cmp[i]); }
         for (auto e : ev_chunk) (void)hipEventDestroy(e);
         if (s_cmp) (void)hipStreamDestroy(s_cmp);
+        if (s_rng) (void)hipStreamDestroy(s_rng);
+        for (hipEvent_t e : ev_rng) (void)hipEventDestroy(e);
+        if (ev_rng_in) (void)hipEventDestroy(ev_rng_in);
+        if (ev_rng_out) (void)hipEventDestroy(ev_rng_out);
         if (s_h2d) (void)hipStreamDestroy(s_h2d);
         if (s_d2h) (void)hipStreamDestroy(s_d2h);
     }
@@ -418,6 +424,8 @@ struct spl_tokenizer {
     int copy_threads = 4;                     // pipeline, pageable input: threads that copy a chunk into pinned staging
     int memo = 1;                             // the chunk memo (spl_k_memo.h); "memo_bits": log2 of its entries (64 bytes each), "memo_log_cap": logged misses per region and fill
     uint32_t memo_bits = 20, memo_log_cap = 1024, memo_long_bits = 16;          // "memo_long_bits": log2 of the entries for chunks of 33..64 bytes (160 bytes each; 0: none)
+    uint32_t range_tiles = 0;                 // "range_tiles" (measured, +2 % on the 215 MB configurations, -2 % on C3 in the bench line: not the default): batches of more than 1.25 x this many tiles go out as ranges of this many (k_pretok + k_tile_out per range; 0: one launch pair)
+    int range_streams = 2;                    // "range_streams": ... on the caller's stream alone (1) or alternating with a second one (2)
     int fuse = 1;                             // tile-owned mode as ONE launch (spl_k_fuse.h) for batches of up to fuse_max_tiles tiles; 0: k_pretok + k_tile_out
     uint32_t fuse_max_tiles = FUSE_MAX_TILES; // (every tile of such a launch is resident at once -- 256 CUs x 6 workgroups: a tile that waits for its base holds nobody up)
     int pick_streams = 1;                     // pipeline: its streams chosen by measurement so that they run side by side (pick_stream_beside)
@@ -933,11 +941,49 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
             return SPL_OK;
         }
         MARK(KI_PRETOK);
-        if (ntiles && direct_b) hipLaunchKernelGGL((k_pretok<SPL_TILE_DIRECT_B>), dim3(ntiles), dim3(NT), 0, s, PRETOK_EARLY(t->dt, b), t->dt, b);
+        // A LARGE batch goes out as ranges of its tiles -- k_pretok and k_tile_out of range k, then of range k + 1, ...: what k_pretok leaves for
+        // k_tile_out (the tiles' ids and records) is still in the caches when k_tile_out reads it (one launch pair over 215 MB: 42 GB/s; its
+        // 27 MB ranges: 50), and on two streams the slow last tiles of one range run beside the next range's first.  A tile's base is the sum
+        // of the counts of the tiles in front of it: k_tile_out of range k needs k_pretok of the ranges 0 .. k, nothing else.
+        const bool ranged = ntiles && !fuse && tk->range_tiles && ntiles > tk->range_tiles + tk->range_tiles / 4 && !so && !pf && !b.done && !b.off_out2 &&
+                            phase == 0 && direct_b;
+        if (ranged) {
+            // (ranges of equal size, a multiple of 64 tiles: the tiles' counts are summed per group of 64)
+            const uint32_t nr = (ntiles + tk->range_tiles - 1) / tk->range_tiles, R = (((ntiles + nr - 1) / nr) + 63u) & ~63u;
+            const bool two = tk->range_streams == 2;
+            if (two && t->s_rng && t->s_rng_for != s && tk->pick_streams) { (void)hipStreamSynchronize(t->s_rng); (void)hipStreamDestroy(t->s_rng); t->s_rng = nullptr; }
+            if (two && !t->s_rng) {
+                // (a stream MEASURED to run beside the caller's: which hardware queue a stream gets is the runtime's choice -- pick_stream_beside)
+                if (tk->pick_streams) { double cf = 0; int rcp = pick_stream_beside({s}, &t->s_rng, &cf); if (rcp) return rcp; }
+                else HIP_TRY(hipStreamCreateWithFlags(&t->s_rng, hipStreamNonBlocking));
+                t->s_rng_for = s;
+                if (!t->ev_rng_in) {
+                HIP_TRY(hipEventCreateWithFlags(&t->ev_rng_in, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&t->ev_rng_out, hipEventDisableTiming));
+                }
+            }
+            while (two && t->ev_rng.size() < nr) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); t->ev_rng.push_back(e); }
+            if (two) { HIP_TRY(hipEventRecord(t->ev_rng_in, s)); HIP_TRY(hipStreamWaitEvent(t->s_rng, t->ev_rng_in, 0)); }     // (what the caller's stream holds comes first)
+            for (uint32_t k = 0; k < nr; k++) {
+                hipStream_t st = (two && (k & 1u)) ? t->s_rng : s;
+                if (k * R >= ntiles) break;
+                const uint32_t n = std::min(R, ntiles - k * R);
+                b.tile0 = k * R;
+                hipLaunchKernelGGL((k_pretok<SPL_TILE_DIRECT_B>), dim3(n), dim3(NT), 0, st, PRETOK_EARLY(t->dt, b), t->dt, b);
+                if (two) {
+                    HIP_TRY(hipEventRecord(t->ev_rng[k], st));
+                    if (k) HIP_TRY(hipStreamWaitEvent(st, t->ev_rng[k - 1], 0));        // (k_pretok of range k - 1, on the other stream; the ranges before it: in order)
+                }
+                hipLaunchKernelGGL(k_tile_out, dim3(n), dim3(TOUT_NT), 0, st, tile_out_args(b));
+            }
+            b.tile0 = 0;
+            if (two) { HIP_TRY(hipEventRecord(t->ev_rng_out, t->s_rng)); HIP_TRY(hipStreamWaitEvent(s, t->ev_rng_out, 0)); }
+        }
+        else if (ntiles && direct_b) hipLaunchKernelGGL((k_pretok<SPL_TILE_DIRECT_B>), dim3(ntiles), dim3(NT), 0, s, PRETOK_EARLY(t->dt, b), t->dt, b);
         else if (ntiles) hipLaunchKernelGGL((k_pretok<SPL_TILE_DIRECT_A>), dim3(ntiles), dim3(NT), 0, s, PRETOK_EARLY(t->dt, b), t->dt, b);
         else HIP_TRY(hipMemsetAsync(d_out_off, 0, (n_docs + 1) * 8, s));
         MARK(KI_DEFER); MARK(KI_BPELANES); MARK(KI_BPELONG); MARK(KI_COUNT); MARK(KI_SCAN); MARK(KI_COMPACT);
-        if (ntiles && !fuse) hipLaunchKernelGGL(k_tile_out, dim3(ntiles), dim3(TOUT_NT), 0, s, tile_out_args(b));
+        if (ntiles && !fuse && !ranged) hipLaunchKernelGGL(k_tile_out, dim3(ntiles), dim3(TOUT_NT), 0, s, tile_out_args(b));
         MARK(KI_N);
     } else {
         (void)fused_scan_used;
@@ -2181,6 +2227,8 @@ int spl_set_option(spl_tokenizer* t, const char* name, int64_t value) {
     else if (k == "twin_streams") t->twin_streams = value != 0;
     else if (k == "pick_streams") t->pick_streams = value != 0;
     else if (k == "fuse") t->fuse = value != 0;
+    else if (k == "range_tiles" && value >= 0 && value < (1 << 24)) t->range_tiles = (uint32_t)value;
+    else if (k == "range_streams" && (value == 1 || value == 2)) t->range_streams = (int)value;
     else if (k == "memo") t->memo = value != 0;
     else if (k == "memo_clear") { for (auto& c : t->ctx) { c->memo_drop(); if (c->twin) c->twin->memo_drop(); } }      // Tokenizer::clear_cache (tokenizer.rs:995-1000)
     else if (k == "memo_bits" && value >= 4 && value <= 22) { t->memo_bits = (uint32_t)value; for (auto& c : t->ctx) { c->memo_drop(); if (c->twin) c->twin->memo_drop(); } }

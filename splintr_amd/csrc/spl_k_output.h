@@ -22,15 +22,16 @@ struct TileOutArgs {
     // latency path (small host batches): the LAST workgroup to finish stores done_seq to *done (pinned host memory, system scope) behind
     // everybody's result stores -- the host spins on that word instead of synchronising the stream (tctl[8]: workgroups finished)
     uint32_t* done; uint32_t done_seq;
+    uint32_t tile0;           // the launch's first tile (launch_all's ranges of a large batch; 0 otherwise)
 };
 inline TileOutArgs tile_out_args(const Batch& b) {
     return TileOutArgs{b.tctl, b.tdesc, b.tile_ids, b.ids_out, b.ids_cap, b.off_out, b.off_out2, b.slab, b.tbits, b.stage, b.skip,
-                       b.tpar, b.tgroups, b.tslot, b.slab_cap, b.slab_max_docs, b.n_docs, b.slab_p24, b.done, b.done_seq};
+                       b.tpar, b.tgroups, b.tslot, b.slab_cap, b.slab_max_docs, b.n_docs, b.slab_p24, b.done, b.done_seq, b.tile0};
 }
 __global__ __launch_bounds__(TOUT_NT) void k_tile_out(TileOutArgs b) {
     __shared__ unsigned long long s_part[TOUT_NT / 64];
     __shared__ uint32_t s_wsum[TOUT_NT / 64];
-    const uint32_t t = xcd_tile();
+    const uint32_t t = xcd_tile() + b.tile0;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t* gs = b.tctl + 16 + b.tpar * b.tgroups;
     const uint32_t g = t >> 6;

@@ -18,7 +18,7 @@ __device__ __forceinline__ uint32_t xcd_tile() {
 constexpr uint32_t PRETOK_E_TSTART = 1u, PRETOK_E_SKIP = 2u, PRETOK_E_GAPS = 4u, PRETOK_E_EXT = 8u, PRETOK_E_FUSE = 64u;
 inline uint32_t pretok_flags(const DeviceTables& T, const Batch& b) {
     return (b.tstart ? PRETOK_E_TSTART : 0u) | (b.skip ? PRETOK_E_SKIP : 0u) | (b.ext_gaps ? PRETOK_E_GAPS : 0u) |
-           (b.ext_starts ? PRETOK_E_EXT : 0u) | (T.pattern << 4) | (b.ftc ? PRETOK_E_FUSE : 0u);
+           (b.ext_starts ? PRETOK_E_EXT : 0u) | (T.pattern << 4) | (b.ftc ? PRETOK_E_FUSE : 0u) | (b.tile0 << 8);        // (bits 8..31: the launch's first tile)
 }
 // the kernel-argument segment of k_pretok as the ABI lays it out (every argument at its natural alignment, in order)
 struct PretokKernargs {
@@ -118,7 +118,7 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
 #ifndef SPL_FUSE_XCD
 #define SPL_FUSE_XCD 0           /* 1 (A/B only: not safe beside other launches): the XCD map in the fused mode too */
 #endif
-    const uint32_t tile_ix = (!SPL_FUSE_XCD && (e_flags & PRETOK_E_FUSE)) ? blockIdx.x : xcd_tile();
+    const uint32_t tile_ix = ((!SPL_FUSE_XCD && (e_flags & PRETOK_E_FUSE)) ? blockIdx.x : xcd_tile()) + (e_flags >> 8);       // (+ the launch's first tile: launch_all's ranges)
     const int64_t t0 = (int64_t)tile_ix * TB_;
     const int64_t w0 = t0 - LH;                       // global position of window index 0
     const int64_t B = e_n_bytes;
@@ -1138,7 +1138,7 @@ void k_pretok(const uint8_t* e_text, const uint64_t* e_doc_off, uint32_t e_n_byt
             __syncthreads();
         }
         // the first NT documents of the window are fetched now: their load overlaps the count below
-        const bool last_tile = tile_ix == gridDim.x - 1;
+        const bool last_tile = t0 + TB_ >= B;               // (the tile that holds the corpus' end -- whatever range of the tiles this launch works)
         const uint64_t own_lo = (uint64_t)t0, own_hi = (uint64_t)(t0 + TB_);
         // (the documents are wavefront 2's: wavefront 0 counts and publishes, wavefront 1 reads the other tiles' counts in the fused mode -- a
         //  wavefront's memory operations complete in order, so whoever has just stored must not be the one that waits for a load)

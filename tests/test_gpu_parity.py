@@ -461,6 +461,33 @@ def test_full_size_c5_deepseek(coracle, mode):
         _force_tiles("deepseek_v3", 0)
 
 
+@pytest.mark.parametrize("name,gen,ndocs,range_tiles,streams", [("cl100k_base", "c2", 12000, 2048, 2), ("cl100k_base", "c2", 12000, 2048, 1),
+                                                                ("o200k_base", "c3", 10000, 32768, 2), ("deepseek_v3", "c5", 12, 8192, 2)])
+def test_a_large_device_batch_as_ranges_of_its_tiles(coracle, name, gen, ndocs, range_tiles, streams):
+    """launch_all sends a device-resident batch of many tiles out as ranges (k_pretok + k_tile_out per range, alternating between the caller's
+    stream and a second one): the CSR must be the oracle's, and the one launch pair's, whatever the number of ranges."""
+    import torch
+    from splintr_amd import Tokenizer, corpus, _ffi
+    from splintr_amd.device import DeviceBatch, encode_device, reserve, result_csr
+    L = _ffi.lib()
+    texts = getattr(corpus, gen)(ndocs)
+    dev = torch.device("cuda", 0)
+    b = DeviceBatch(texts, dev)
+    o_ids, o_off = oracle_csr(coracle(name), texts)
+    got = []
+    for rt in (range_tiles, 0):
+        t = Tokenizer.from_pretrained(name)
+        reserve(t, b.n_bytes + (1 << 20), b.n_docs + 16)
+        assert L.spl_set_option(t.handle, b"range_tiles", rt) == 0 and L.spl_set_option(t.handle, b"range_streams", streams) == 0
+        for _ in range(3):                                  # (cold, while the memo fills, warm; every call joins the second stream again)
+            encode_device(t, b)
+        torch.cuda.synchronize()
+        ids, off = result_csr(b)
+        assert np.array_equal(off, o_off) and np.array_equal(ids, o_ids), f"range_tiles={rt}"
+        got.append((ids.copy(), off.copy()))
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+
+
 def test_gatherv_pack_unpack_two_simulated_ranks(coracle):
     """The slab pack / unpack kernels of the ragged all-gather, without a process group: two
     different shards are packed as if by two ranks, their slabs are laid side by side exactly as
