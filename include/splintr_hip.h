@@ -123,6 +123,8 @@ uint32_t spl_n_devices(const spl_tokenizer* t);
  *                            (128 bytes each); "memo_long_bits" 0..20 (16; 0: none): ... for chunks of 33..64 bytes (164 bytes each);
  *                            "memo_log_cap" 1..65536 (1024): missed chunks the tiles log per region (of 64) between two fills
  *   "memo_clear"             (any value) empties the memo of every context: Tokenizer::clear_cache (src/core/tokenizer.rs:995-1000)
+ *   "group_scan_min"         0..2^24 (256; 0: never): a batch of more than this many groups of 64 tiles gets the groups' prefix sums from one small launch
+ *                            (k_group_scan) between k_pretok and k_tile_out instead of every tile adding up the sums of the groups in front of it
  *   "range_tiles"            0..2^24 (0: one launch pair): a device-resident batch of more than 1.25 x this many tiles goes out as ranges of its tiles --
  *                            k_pretok and k_tile_out per range -- alternating between the caller's stream and a second one ("range_streams" 1/2 (2))
  *   "fuse"                   0/1 (1): batches of up to "fuse_max_tiles" tiles (default and maximum 1536: about 1.2 MB) are ONE launch --

@@ -425,6 +425,7 @@ struct spl_tokenizer {
     int memo = 1;                             // the chunk memo (spl_k_memo.h); "memo_bits": log2 of its entries (64 bytes each), "memo_log_cap": logged misses per region and fill
     uint32_t memo_bits = 20, memo_log_cap = 1024, memo_long_bits = 16;          // "memo_long_bits": log2 of the entries for chunks of 33..64 bytes (160 bytes each; 0: none)
     uint32_t range_tiles = 0;                 // "range_tiles" (measured, +2 % on the 215 MB configurations, -2 % on C3 in the bench line: not the default): batches of more than 1.25 x this many tiles go out as ranges of this many (k_pretok + k_tile_out per range; 0: one launch pair)
+    uint32_t group_scan_min = 256;            // "group_scan_min": batches of more than this many groups of 64 tiles get the groups' prefix sums from k_group_scan (0: never)
     int range_streams = 2;                    // "range_streams": ... on the caller's stream alone (1) or alternating with a second one (2)
     int fuse = 1;                             // tile-owned mode as ONE launch (spl_k_fuse.h) for batches of up to fuse_max_tiles tiles; 0: k_pretok + k_tile_out
     uint32_t fuse_max_tiles = FUSE_MAX_TILES; // (every tile of such a launch is resident at once -- 256 CUs x 6 workgroups: a tile that waits for its base holds nobody up)
@@ -588,8 +589,8 @@ int reserve(Ctx* t, uint64_t max_bytes, uint64_t max_docs) {
         HIP_TRY(hipMalloc((void**)&t->d_tile_ids, tiles * (size_t)(TileGeom<SPL_TILE_SMALL>::Wv + 1) * 4));
         HIP_TRY(hipMalloc((void**)&t->d_tile_bits, tiles * (size_t)TILE_BITS_W * 4));
         HIP_TRY(hipMalloc((void**)&t->d_tcnt, tiles * 4));
-        HIP_TRY(hipMalloc((void**)&t->d_tctl, (16 + 2 * (size_t)t->tgroups) * 4));
-        HIP_TRY(hipMemset(t->d_tctl, 0, (16 + 2 * (size_t)t->tgroups) * 4));
+        HIP_TRY(hipMalloc((void**)&t->d_tctl, (16 + 2 * (size_t)t->tgroups + 2 + 2 * (size_t)t->tgroups) * 4));      // (control words, two parities of group sums, their prefix sums as u64)
+        HIP_TRY(hipMemset(t->d_tctl, 0, (16 + 2 * (size_t)t->tgroups + 2 + 2 * (size_t)t->tgroups) * 4));
         t->tpar = 0;
         HIP_TRY(hipMalloc((void**)&t->d_fctl, 2 * FUSE_PARITY_BYTES));
         HIP_TRY(hipMemset(t->d_fctl, 0, 2 * FUSE_PARITY_BYTES));
@@ -983,7 +984,15 @@ int launch_all(spl_tokenizer* tk, Ctx* t, const uint8_t* d_utf8, uint64_t n_byte
         else if (ntiles) hipLaunchKernelGGL((k_pretok<SPL_TILE_DIRECT_A>), dim3(ntiles), dim3(NT), 0, s, PRETOK_EARLY(t->dt, b), t->dt, b);
         else HIP_TRY(hipMemsetAsync(d_out_off, 0, (n_docs + 1) * 8, s));
         MARK(KI_DEFER); MARK(KI_BPELANES); MARK(KI_BPELONG); MARK(KI_COUNT); MARK(KI_SCAN); MARK(KI_COMPACT);
-        if (ntiles && !fuse && !ranged) hipLaunchKernelGGL(k_tile_out, dim3(ntiles), dim3(TOUT_NT), 0, s, tile_out_args(b));
+        if (ntiles && !fuse && !ranged) {
+            const uint32_t ng = (ntiles + 63u) / 64u;
+            if (ng > tk->group_scan_min && tk->group_scan_min) {
+                unsigned long long* const gpre = reinterpret_cast<unsigned long long*>(t->d_tctl + ((16 + 2 * (size_t)t->tgroups + 1) & ~(size_t)1));
+                hipLaunchKernelGGL(k_group_scan, dim3(1), dim3(256), 0, s, (const uint32_t*)(t->d_tctl + 16 + b.tpar * t->tgroups), ng, gpre);
+                b.gpre = gpre;
+            }
+            hipLaunchKernelGGL(k_tile_out, dim3(ntiles), dim3(TOUT_NT), 0, s, tile_out_args(b));
+        }
         MARK(KI_N);
     } else {
         (void)fused_scan_used;
@@ -2227,6 +2236,7 @@ int spl_set_option(spl_tokenizer* t, const char* name, int64_t value) {
     else if (k == "twin_streams") t->twin_streams = value != 0;
     else if (k == "pick_streams") t->pick_streams = value != 0;
     else if (k == "fuse") t->fuse = value != 0;
+    else if (k == "group_scan_min" && value >= 0 && value < (1 << 24)) t->group_scan_min = (uint32_t)value;
     else if (k == "range_tiles" && value >= 0 && value < (1 << 24)) t->range_tiles = (uint32_t)value;
     else if (k == "range_streams" && (value == 1 || value == 2)) t->range_streams = (int)value;
     else if (k == "memo") t->memo = value != 0;

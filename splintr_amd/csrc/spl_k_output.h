@@ -23,11 +23,31 @@ struct TileOutArgs {
     // everybody's result stores -- the host spins on that word instead of synchronising the stream (tctl[8]: workgroups finished)
     uint32_t* done; uint32_t done_seq;
     uint32_t tile0;           // the launch's first tile (launch_all's ranges of a large batch; 0 otherwise)
+    const unsigned long long* gpre;     // null, or the exclusive prefix sums of the groups' counts (k_group_scan: batches of many tiles)
 };
 inline TileOutArgs tile_out_args(const Batch& b) {
     return TileOutArgs{b.tctl, b.tdesc, b.tile_ids, b.ids_out, b.ids_cap, b.off_out, b.off_out2, b.slab, b.tbits, b.stage, b.skip,
-                       b.tpar, b.tgroups, b.tslot, b.slab_cap, b.slab_max_docs, b.n_docs, b.slab_p24, b.done, b.done_seq, b.tile0};
+                       b.tpar, b.tgroups, b.tslot, b.slab_cap, b.slab_max_docs, b.n_docs, b.slab_p24, b.done, b.done_seq, b.tile0, b.gpre};
 }
+// Exclusive prefix sums of the groups' token counts, between k_pretok and k_tile_out of a batch of many tiles: every workgroup of k_tile_out
+// adds up the counts of all groups in front of its tile's -- 4 200 of them at 215 MB, 243 000 workgroups: 1.9 GB of reads for what one
+// workgroup does once (k_tile_out: 550 -> us of the 5.4 ms step).
+__global__ __launch_bounds__(256) void k_group_scan(const uint32_t* gs, uint32_t n, unsigned long long* gpre) {
+    __shared__ unsigned long long s_w[4];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t per = (n + 255u) / 256u, lo = (uint32_t)tid * per, hi = lo + per < n ? lo + per : n;
+    unsigned long long sum = 0;
+    for (uint32_t k = lo; k < hi; k++) sum += gs[k];
+    unsigned long long incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+    if (lane == 63) s_w[wv] = incl;
+    __syncthreads();
+    unsigned long long run = incl - sum;
+    for (int w = 0; w < wv; w++) run += s_w[w];
+    for (uint32_t k = lo; k < hi; k++) { gpre[k] = run; run += gs[k]; }
+}
+
 __global__ __launch_bounds__(TOUT_NT) void k_tile_out(TileOutArgs b) {
     __shared__ unsigned long long s_part[TOUT_NT / 64];
     __shared__ uint32_t s_wsum[TOUT_NT / 64];
@@ -40,7 +60,9 @@ __global__ __launch_bounds__(TOUT_NT) void k_tile_out(TileOutArgs b) {
     const uint32_t slot0 = t * b.tslot;
     const uint32_t first_id = b.tile_ids[slot0 + tid];
     unsigned long long mine = 0;
-    for (uint32_t k = tid; k < g; k += TOUT_NT) mine += gs[k];
+    // (a batch of many tiles: the sums of the groups in front are ONE load -- k_group_scan has added them up; else every workgroup adds them itself)
+    if (b.gpre) { if (tid == 0) mine = b.gpre[g]; }
+    else for (uint32_t k = tid; k < g; k += TOUT_NT) mine += gs[k];
     {
         const uint32_t u = (g << 6) + (uint32_t)tid;
         if (tid < 64 && u < t) { const TileDesc q = b.tdesc[u]; mine += (unsigned long long)q.c_win + q.c_ovf; }

@@ -131,6 +131,7 @@ struct Batch {
     // count + 1 (0: not known yet; 0xFFFF: ftb[tile] holds it, 32 bits).  fzc / fzb: the other parity's arrays, of which tile 0 zeroes
     // the first fz_n entries (what the previous fused launch used).
     uint16_t* ftc; uint32_t* ftb; uint16_t* fzc; uint32_t* fzb; uint32_t fz_n;
+    const unsigned long long* gpre;     // tile-owned mode, batches of many tiles: the groups' exclusive prefix sums (k_group_scan, spl_k_output.h); null: k_tile_out adds the sums up itself
     uint32_t tile0;          // the first tile of this launch: a large batch goes out as several launches over ranges of its tiles (launch_all; 0 otherwise)
     // chunk memo (spl_k_memo.h; mlog == nullptr: the tiles log nothing): SPL_MEMO_LOG_REGIONS regions of mlog_cap entries of SPL_MEMO_LOG_WORDS
     // words each, their fill counters, and the word in pinned host memory that tells the host there is something to put in

@@ -475,17 +475,19 @@ def test_a_large_device_batch_as_ranges_of_its_tiles(coracle, name, gen, ndocs, 
     b = DeviceBatch(texts, dev)
     o_ids, o_off = oracle_csr(coracle(name), texts)
     got = []
-    for rt in (range_tiles, 0):
+    # (group_scan_min: the groups' prefix sums by k_group_scan -- 1: whatever the number of groups -- or added up by every tile of k_tile_out: 0)
+    for rt, gsm in ((range_tiles, 1), (0, 1), (0, 0)):
         t = Tokenizer.from_pretrained(name)
         reserve(t, b.n_bytes + (1 << 20), b.n_docs + 16)
         assert L.spl_set_option(t.handle, b"range_tiles", rt) == 0 and L.spl_set_option(t.handle, b"range_streams", streams) == 0
+        assert L.spl_set_option(t.handle, b"group_scan_min", gsm) == 0
         for _ in range(3):                                  # (cold, while the memo fills, warm; every call joins the second stream again)
             encode_device(t, b)
         torch.cuda.synchronize()
         ids, off = result_csr(b)
-        assert np.array_equal(off, o_off) and np.array_equal(ids, o_ids), f"range_tiles={rt}"
+        assert np.array_equal(off, o_off) and np.array_equal(ids, o_ids), f"range_tiles={rt} group_scan_min={gsm}"
         got.append((ids.copy(), off.copy()))
-    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+    assert all(np.array_equal(got[0][0], g[0]) and np.array_equal(got[0][1], g[1]) for g in got[1:])
 
 
 def test_gatherv_pack_unpack_two_simulated_ranks(coracle):

@@ -17,11 +17,11 @@ with torch.cuda.stream(torch.cuda.Stream(dev)):
         b = DeviceBatch(texts, dev)
         orc = COracle(vocab)
         ref = None
-        for label, rt, rs, memo in (("one pair", 0, 1, 1), ("ranges, 1 stream", 32768, 1, 1), ("ranges, 2 streams", 32768, 2, 1), ("ranges of 16384, 2 streams", 16384, 2, 1), ("ranges of 65536, 2 streams", 65536, 2, 1),
-                                    ("one pair, memo off", 0, 1, 0), ("ranges, 2 streams, memo off", 32768, 2, 0)):
+        for label, rt, rs, memo, gsm in (("one pair, sums added by every tile", 0, 1, 1, 0), ("one pair", 0, 1, 1, 256), ("one pair, sums added by every tile", 0, 1, 1, 0), ("one pair", 0, 1, 1, 256),
+                                         ("ranges, 2 streams", 32768, 2, 1, 256), ("one pair, memo off", 0, 1, 0, 256)):
             tok = Tokenizer.from_pretrained(vocab)
             reserve(tok, b.n_bytes + (1 << 20), b.n_docs + 16)
-            opt(tok, "range_tiles", rt); opt(tok, "range_streams", rs); opt(tok, "memo", memo)
+            opt(tok, "range_tiles", rt); opt(tok, "range_streams", rs); opt(tok, "memo", memo); opt(tok, "group_scan_min", gsm)
             for _ in range(4): encode_device(tok, b)
             torch.cuda.synchronize()
             off = b.out_off.clone(); T = int(off[-1].item()); ids = b.ids[:T].clone()
@@ -38,5 +38,5 @@ with torch.cuda.stream(torch.cuda.Stream(dev)):
                 for _ in range(5): encode_device(tok, b)
                 torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / 5)
             ts.sort()
-            print(f"{name} {b.n_bytes/1e6:.0f} MB {label:28s}: {ts[1]*1e3:7.3f} ms {b.n_bytes/ts[1]/1e9:6.2f} GB/s  CSR == one pair's: {same}  first {k} docs == oracle: {ok_o}", flush=True)
+            print(f"{name} {b.n_bytes/1e6:.0f} MB {label:36s}: {ts[1]*1e3:7.3f} ms {b.n_bytes/ts[1]/1e9:6.2f} GB/s  CSR == one pair's: {same}  first {k} docs == oracle: {ok_o}", flush=True)
             del tok
