@@ -1008,6 +1008,22 @@ def run_strong(vocab, texts, steps, rank, world, local_rank, dev, use_dist, nchk
             wg.finish()
     for _ in range(2):
         step()
+    if wg is None:
+        # "memo warm" means what it says: a cold pass over 200 MB logs more missed chunks than one fill takes (65 536 a fill, duplicates among
+        # them), so the fills of the first passes run on until every chunk is in -- steps until two in a row have run without a fill (12 at most)
+        import ctypes as _ct
+        from splintr_amd import _ffi as _f1
+        _L1 = _f1.lib()
+        _L1.spl_memo_stats.argtypes = [_ct.c_void_p, _ct.POINTER(_ct.c_uint64)]
+        _ms, _prev, _quiet = (_ct.c_uint64 * 4)(), -1, 0
+        for _ in range(12):
+            step()
+            torch.cuda.synchronize()
+            _L1.spl_memo_stats(tok.handle, _ms)
+            _quiet = _quiet + 1 if int(_ms[0]) == _prev else 0
+            _prev = int(_ms[0])
+            if _quiet >= 2:
+                break
     if use_dist:
         # every rank holds the whole result: totals, and this rank's slice of every wave at its place
         torch.cuda.synchronize()
