@@ -1008,7 +1008,7 @@ def run_strong(vocab, texts, steps, rank, world, local_rank, dev, use_dist, nchk
             wg.finish()
     for _ in range(2):
         step()
-    if wg is None:
+    if True:
         # "memo warm" means what it says: a cold pass over 200 MB logs more missed chunks than one fill takes (65 536 a fill, duplicates among
         # them), so the fills of the first passes run on until every chunk is in -- steps until two in a row have run without a fill (12 at most)
         import ctypes as _ct
@@ -1019,10 +1019,19 @@ def run_strong(vocab, texts, steps, rank, world, local_rank, dev, use_dist, nchk
         for _ in range(12):
             step()
             torch.cuda.synchronize()
-            _L1.spl_memo_stats(tok.handle, _ms)
-            _quiet = _quiet + 1 if int(_ms[0]) == _prev else 0
-            _prev = int(_ms[0])
-            if _quiet >= 2:
+            _fills = 0
+            for _t in (tok, tok2):                      # (the distributed form: two handles, consecutive waves in alternation -- a memo each)
+                if _t is not None:
+                    _L1.spl_memo_stats(_t.handle, _ms)
+                    _fills += int(_ms[0])
+            _quiet = _quiet + 1 if _fills == _prev else 0
+            _prev = _fills
+            _done = 1 if _quiet >= 2 else 0
+            if use_dist:                                # (every rank runs the same number of steps: a step holds a collective)
+                _dv = torch.tensor([_done], dtype=torch.int32, device=dev)
+                dist.all_reduce(_dv, op=dist.ReduceOp.MIN)
+                _done = int(_dv.item())
+            if _done:
                 break
     if use_dist:
         # every rank holds the whole result: totals, and this rank's slice of every wave at its place
