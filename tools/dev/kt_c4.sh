@@ -1,3 +1,5 @@
+# On the GPU box: rocprofv3 kernel trace of the LARGE configurations (config 4 at 215 MB and 21 MB, config 5 at 210 MB; eight device-resident calls each):
+# k_pretok / k_group_scan / k_tile_out / k_memo_fill by launch -> gpurun_out/kt_c4.txt (per-kernel statistics), gpurun_out/kt_c4_timeline.txt (the last launches in order)
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 d=$R/gpurun_out/kt_c4; rm -rf $d; mkdir -p $d
