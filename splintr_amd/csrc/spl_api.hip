@@ -726,14 +726,16 @@ int memo_ensure(spl_tokenizer* tk, Ctx* t) {
     HIP_TRY(hipMalloc((void**)&t->d_memo_ext, slots * sizeof(MemoExt)));      // (only hits of seven to fourteen tokens ever touch it)
     HIP_TRY(hipMalloc((void**)&t->d_mclaim, slots * 4));
     HIP_TRY(hipMemset(t->d_mclaim, 0, slots * 4));
-    t->memo_cap = tk->memo_log_cap;
+    // (the log of a context that takes LARGE batches is larger: a cold pass over 200 MB misses the vocabulary three million times, and at 65 536
+    //  logged chunks a fill -- duplicates among them -- the memo needed a dozen passes to hold them all; one entry per 192 bytes of capacity, 16 384 a region at most)
+    t->memo_cap = (uint32_t)std::min<uint64_t>(16384, std::max<uint64_t>(tk->memo_log_cap, t->cap_bytes / ((uint64_t)SPL_MEMO_LOG_REGIONS * 192)));
     HIP_TRY(hipMalloc((void**)&t->d_mlog, (size_t)SPL_MEMO_LOG_REGIONS * t->memo_cap * SPL_MEMO_LOG_WORDS * 4));
     HIP_TRY(hipMalloc((void**)&t->d_mlog_cnt, 2 * SPL_MEMO_LOG_REGIONS * 4));              // (the second half: the log of chunks of 33..64 bytes)
     HIP_TRY(hipMemset(t->d_mlog_cnt, 0, 2 * SPL_MEMO_LOG_REGIONS * 4));
     t->memo2_mask = 0; t->memo2_cap = 0;
     if (tk->memo_long_bits) {
         const size_t s2 = (size_t)1 << tk->memo_long_bits;
-        t->memo2_cap = std::max<uint32_t>(tk->memo_log_cap / 8, 16);
+        t->memo2_cap = std::max<uint32_t>(t->memo_cap / 8, 16);
         const size_t bytes = s2 * (sizeof(MemoEnt) + sizeof(MemoExt) + sizeof(MemoHi) + 4) + (size_t)SPL_MEMO_LOG_REGIONS * t->memo2_cap * SPL_MEMO_LOG_WORDS2 * 4;
         HIP_TRY(hipMalloc((void**)&t->d_memo2, bytes));
         HIP_TRY(hipMemset(t->d_memo2, 0, s2 * (sizeof(MemoEnt) + sizeof(MemoExt) + sizeof(MemoHi) + 4)));

@@ -98,9 +98,11 @@ __device__ __forceinline__ void memo_log_part(const Batch& b, const TX& tx, cons
     if (lane == 0u) base = atomicAdd(&b.mlog_cnt[(LONG ? SPL_MEMO_LOG_REGIONS : 0) + region], n_el);
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
     if (base >= cap) return;                                      // the region is full: the fill has not run yet
-    // the region becomes half full: the host enqueues a fill with one of its next launches (a word in pinned host memory).  Not before: a few
+    // the region becomes half full (512 entries at most): the host enqueues a fill with one of its next launches (a word in pinned host memory).  Not before: a few
     // chunks per launch that lose their slot to another again and again would otherwise cost a fill every few launches
-    if (lane == 0u && base < cap / 2u && base + n_el >= cap / 2u) *b.mflag = 1u;
+    // (a large log -- a context that takes large batches -- asks at 512 entries all the same: what a first fill left over trickles in slowly)
+    const uint32_t ask = cap / 2u < 512u ? cap / 2u : 512u;
+    if (lane == 0u && base < ask && base + n_el >= ask) *b.mflag = 1u;
     uint32_t* const out = (LONG ? b.mlog2 : b.mlog) + ((size_t)region * cap) * LW;
     auto put = [&](uint32_t slot, uint32_t item) {
         if (base + slot >= cap) return;
