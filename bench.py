@@ -702,7 +702,7 @@ def main():
 
     # ---- tripwire: every rate of this line against the last committed line of an earlier round (profiles/rNN_bench.json) ------
     # (two surfaces had become 9 % and 37 % slower without anybody noticing.)  vs_prev = this / previous for rates, previous /
-    # this for latencies; anything at or below 0.95 (0.75 for the figures that are the host cores') is listed in `regressions`.
+    # this for latencies; anything at or below 0.95 (0.90 for host <-> device figures, 0.75 for the figures that are the host cores') is listed in `regressions`.
     vs_prev = regressions = prev_name = None
     if rank == 0 and world == 1 and not use_dist:
         import glob
@@ -727,7 +727,10 @@ def main():
                     return
                 r = (before / now) if lower_is_better else (now / before)
                 vs_prev[name] = round(r, 3)
-                limit = 0.75 if name.rsplit(".", 1)[-1] in host_bound else 0.95
+                # (what crosses PCIe or is a single call's latency moves by +-4 % from box to box -- 27.9 .. 30.2 us for the 1 KB call, 11.7 .. 12.4 GB/s
+                #  host to host for one build: 0.90)
+                leaf = name.rsplit(".", 1)[-1]
+                limit = 0.75 if leaf in host_bound else 0.90 if leaf in ("encode_one_call_us", "c_abi_host", "c_abi_host_pageable", "decode_host") else 0.95
                 if r <= limit:
                     regressions.append({"what": name, "now": now, "previous": before, "ratio": round(r, 3), "limit": limit})
             cmp_("value", value, prev.get("value"))
