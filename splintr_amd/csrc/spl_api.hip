@@ -1574,7 +1574,8 @@ int lane_prepare(spl_tokenizer* tk, Lane& ln, const uint64_t* doc_off, uint64_t 
         c->s_d2h = d2h; c->s_h2d = h2d;
         c->streams_picked = true;
     }
-    if (tk->twin_streams && !tk->regex && ln.chunks.size() >= 3) {
+    // (not while per-kernel profiling is on: spl_profile_read reports this context's kernels -- with the twin it would cover every other chunk)
+    if (tk->twin_streams && !tk->regex && ln.chunks.size() >= 3 && !c->prof) {
         if (!c->twin) {
             c->twin.reset(new Ctx());
             c->twin->device = c->device;
@@ -1600,7 +1601,7 @@ int lane_submit(spl_tokenizer* tk, Lane& ln, const uint8_t* utf8, const uint64_t
     for (size_t k = 0; k < ln.chunks.size(); k++) {
         const Chunk& ch = ln.chunks[k];
         const int sl = (int)(k % NSLOT);
-        Ctx* const w = (!solo && c->twin && (k & 1)) ? c->twin.get() : c;     // whose workspace and compute stream run this chunk's kernels
+        Ctx* const w = (!solo && c->twin && !c->prof && (k & 1)) ? c->twin.get() : c;     // whose workspace and compute stream run this chunk's kernels
         const uint64_t nb = ch.hi - ch.lo, nd = ch.dhi - ch.dlo;
         TRACE("submit dev %d chunk %zu/%zu bytes %llu docs %llu", c->device, k, ln.chunks.size(), (unsigned long long)nb, (unsigned long long)nd);
         if (k >= NSLOT) HIP_TRY(hipEventSynchronize(c->ev_h2d[sl]));     // the slot's pinned staging has been read
